@@ -1,0 +1,190 @@
+"""Generates tests/golden/*.npz.  Run ONLY in the build container:
+
+    python tests/golden/make_golden.py
+
+It imports the UNMODIFIED reference sources from /root/reference (through the
+test-only dgl stand-in oracle/dgl_shim.py, because dgl 0.7.2 is not
+installable here), runs them on CPU on the reference's own shipped split
+(datasets/sample) plus a hand-made edge-case batch, cross-checks the build's
+oracle restatement (oracle/models_ref.py, oracle/collate_ref.py) against them
+and commits inputs + expected outputs as fixtures.  Nothing from the reference
+is copied: fixtures hold data (click sequences, labels, seeded weights,
+expected tensors) only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch as th
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from oracle import dgl_shim  # noqa: E402
+
+dgl_shim.install()
+sys.path.insert(0, REF)
+from src.models import LESSR as RLESSR, MSGIFSR as RMSGIFSR, NISER as RNISER, SRGNN as RSRGNN  # noqa: E402
+from src.utils.data import collate as rcollate  # noqa: E402
+from src.utils.data.dataset import AugmentedDataset as RAugmentedDataset  # noqa: E402
+from src.utils import train as rtrain  # noqa: E402
+
+from oracle import collate_ref as oc  # noqa: E402
+from oracle import models_ref as om  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+D = 32
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def read_sessions(path):
+    with open(path) as f:
+        return [list(map(int, line.strip().split(','))) for line in f if line.strip()]
+
+
+def first_samples(n):
+    sess = read_sessions(os.path.join(REF, 'datasets/sample/train.txt'))
+    ds = RAugmentedDataset(np.array(sess, dtype=object))
+    return [(list(ds[i][0]), int(ds[i][1])) for i in range(n)]
+
+
+EDGE_CASES = [           # len-1, repeated item, shorter-than-order, long with repeats, all-same
+    ([7], 3), ([5, 5], 9), ([4, 9], 1), ([3, 1, 3, 6, 2, 5, 1, 2, 4, 1, 2], 8),
+    ([250, 250, 250, 250, 3, 1, 2, 4, 1], 2), ([11, 12, 13], 14), ([2, 2, 2], 2),
+    ([9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 9, 8, 7, 6, 5, 4, 3, 2, 1], 0),
+]
+
+
+def cmp_graph(rg, og, name):
+    if 'rel' in og:
+        for k in range(1, og['order'] + 1):
+            t = 's%d' % k
+            assert np.array_equal(rg.nodes[t].data['iid'].numpy(), og['iid'][k]), (name, 'iid', k)
+            assert np.array_equal(rg.batch_num_nodes(t).numpy(), og['num_nodes'][k]), (name, 'nn', k)
+            last = th.nonzero(rg.nodes[t].data['last'] == 1).reshape(-1).numpy()
+            assert np.array_equal(last, og['last'][k]), (name, 'last', k)
+        for (s, e, d), r in og['rel'].items():
+            rs, rd = rg._edges[('s%d' % s, e, 's%d' % d)]
+            assert np.array_equal(rs.numpy(), r['src']) and np.array_equal(rd.numpy(), r['dst']), (name, s, e, d)
+    else:
+        rs, rd = rg._edges[rg.canonical_etypes[0]]
+        assert np.array_equal(rs.numpy(), og['src']) and np.array_equal(rd.numpy(), og['dst']), name
+        assert np.array_equal(rg.batch_num_nodes().numpy(), og['num_nodes']), name
+        if og['iid'] is not None:
+            assert np.array_equal(rg.ndata['iid'].numpy(), og['iid']), name
+            assert np.array_equal(th.nonzero(rg.ndata['last'] == 1).reshape(-1).numpy(), og['last']), name
+        if og['w'] is not None:
+            assert np.array_equal(rg.edata['w'].numpy(), og['w']), name
+
+
+def run_case(name, rmodel, omodel, rcol, ocol, samples, steps=3, full=True):
+    omodel.load_state_dict(rmodel.state_dict(), strict=True)
+    init = {k: v.detach().clone().numpy() for k, v in rmodel.state_dict().items()}
+    rin, rlab = rcol(samples)
+    oin, olab = ocol(samples)
+    for a, b in zip(rin, oin):
+        cmp_graph(a, b, name)
+    oin_t = [om.to_torch(x) for x in oin]
+    olab_t = th.from_numpy(olab)
+    out = dict(seqs=np.array([','.join(map(str, s)) for s, _ in samples]), labels=olab)
+    for k, v in init.items():
+        out['init/' + k] = v
+    ropt = th.optim.Adam(rtrain.fix_weight_decay(rmodel), lr=1e-3, weight_decay=1e-4)
+    oopt = th.optim.Adam(rtrain.fix_weight_decay(omodel), lr=1e-3, weight_decay=1e-4)
+    rmodel.train()
+    omodel.train()
+    losses = []
+    for step in range(steps):
+        ropt.zero_grad()
+        oopt.zero_grad()
+        rs = rmodel(*rin)
+        os_ = omodel(*oin_t)
+        assert th.allclose(rs, os_, **TOL), (name, step, (rs - os_).abs().max())
+        rl = th.nn.functional.nll_loss(rs, rlab)
+        ol = th.nn.functional.nll_loss(os_, olab_t)
+        rl.backward()
+        ol.backward()
+        rg = dict(rmodel.named_parameters())
+        for k, p in omodel.named_parameters():
+            if p.grad is None:
+                assert rg[k].grad is None, (name, k)
+                continue
+            assert th.allclose(rg[k].grad, p.grad, rtol=1e-4, atol=1e-7), (name, step, k, (rg[k].grad - p.grad).abs().max())
+        if step == 0:
+            out['logprobs'] = rs.detach().numpy() if full else rs.detach().numpy()[:4]
+            for k, p in rmodel.named_parameters():
+                if p.grad is not None and (full or p.numel() < 20000):
+                    out['grad/' + k] = p.grad.detach().clone().numpy()
+                elif p.grad is None:
+                    out['nograd/' + k] = np.zeros(0, np.float32)
+        losses.append(rl.item())
+        ropt.step()
+        oopt.step()
+    out['losses'] = np.array(losses, dtype=np.float64)
+    for k, v in rmodel.state_dict().items():
+        if full or v.numel() < 20000:
+            out['final/' + k] = v.detach().clone().numpy()
+    rmodel.eval()
+    with th.no_grad():
+        ev = rmodel(*rin)
+        topk = ev.topk(20)[1]
+        out['eval_top20'] = topk.numpy()
+        out['eval_logprobs_head'] = ev[:4].numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('%-28s ok  losses=%s' % (name, np.round(losses, 5)))
+
+
+def allow_zero(m):
+    for mod in m.modules():
+        if hasattr(mod, 'set_allow_zero_in_degree'):
+            mod.set_allow_zero_in_degree(True)      # documented deviation
+    return m
+
+
+def main():
+    samples = first_samples(32)
+    edge = EDGE_CASES
+    sets = {'s32': samples, 'edge': edge}
+    for sname, smp in sets.items():
+        full = sname == 's32'
+        V = 3429 if full else 300          # edge-case ids are < 300: keeps those fixtures tiny
+        th.manual_seed(123)
+        run_case('srgnn_%s' % sname, RSRGNN(V, D, 1), om.SRGNN(V, D, 1),
+                 rcollate.collate_fn_factory(rcollate.seq_to_session_graph),
+                 oc.collate_fn_factory(oc.seq_to_session_graph), smp, full=full)
+        th.manual_seed(123)
+        run_case('niser_%s' % sname, RNISER(V, D, 1), om.NISER(V, D, 1),
+                 rcollate.collate_fn_factory(rcollate.seq_to_session_graph),
+                 oc.collate_fn_factory(oc.seq_to_session_graph), smp, full=full)
+        for L in (1, 3):
+            th.manual_seed(123)
+            fr = (rcollate.seq_to_eop_multigraph, rcollate.seq_to_shortcut_graph) if L > 1 else (rcollate.seq_to_eop_multigraph,)
+            fo = (oc.seq_to_eop_multigraph, oc.seq_to_shortcut_graph) if L > 1 else (oc.seq_to_eop_multigraph,)
+            run_case('lessr_L%d_%s' % (L, sname), RLESSR(V, D, L), om.LESSR(V, D, L),
+                     rcollate.collate_fn_factory(*fr), oc.collate_fn_factory(*fo), smp, full=full and L == 1)
+        for K in (1, 2, 3):
+            for fusion in ((False, True) if K == 3 else (False,)):
+                th.manual_seed(123)
+                rm = allow_zero(RMSGIFSR(V, 'sample', D, 1, order=K, extra=False, fusion=fusion))
+                omod = om.MSGIFSR(V, 'sample', D, 1, order=K, extra=False, fusion=fusion)
+                run_case('msgifsr_K%d%s_%s' % (K, '_fus' if fusion else '', sname), rm, omod,
+                         rcollate.collate_fn_factory_ccs((rcollate.seq_to_ccs_graph,), K),
+                         oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K), smp,
+                         full=full and K == 3 and not fusion)
+    # reference evaluate() on a fixed batch list pins the (mrr, hit) tuple order (train.py:36-55)
+    th.manual_seed(123)
+    V = 3429
+    rm = RSRGNN(V, D, 1)
+    test = read_sessions(os.path.join(REF, 'datasets/sample/test.txt'))
+    ds = RAugmentedDataset(np.array(test, dtype=object))
+    rcol = rcollate.collate_fn_factory(rcollate.seq_to_session_graph)
+    batches = [rcol([(list(ds[i][0]), int(ds[i][1])) for i in range(b * 32, b * 32 + 32)]) for b in range(10)]
+    mrr, hit = rtrain.evaluate(rm, batches, th.device('cpu'))
+    np.savez_compressed(os.path.join(OUT, 'srgnn_evaluate.npz'), mrr=mrr, hit=hit,
+                        **{'init/' + k: v.numpy() for k, v in rm.state_dict().items()})
+    print('evaluate: mrr=%.6f hit=%.6f' % (mrr, hit))
+
+
+if __name__ == '__main__':
+    main()
