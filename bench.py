@@ -1,0 +1,258 @@
+"""bench.py - training throughput (sessions/sec) of the HIP hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--model MSGIFSR|SRGNN|NISER|LESSR]
+
+A "step" = one pass of the hot path over one batch: embedding gather -> session encoder ->
+fused full-catalog scoring + softmax-CE forward/backward -> fused Adam (dense over the item
+table).  Inputs (the collated flat batches) are resident in HBM before the timed region.
+Synthetic data of the Yoochoose-1/64 shape (no datasets in the image): V = 37 484 items,
+batch 512, session length <= 20, ids Zipf(1.0), 20 % immediate revisits, seed 123;
+random-init weights of the named architecture.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  "roofline":     dominant kernel (fused scoring/CE backward dE pass) timed live with HIP events
+  "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the reference math) timed on the
+                  host cores of the same box on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V_YOOCHOOSE = 37484
+
+
+def synth_sessions(n_sessions, V, mean_len, max_len, rng):
+    """clipped-geometric lengths (min 2), Zipf(1.0) item ids, 20 % immediate-revisit probability."""
+    p = 1.0 / (mean_len - 1.0)
+    lens = np.clip(rng.geometric(p, size=n_sessions) + 1, 2, max_len)
+    w = 1.0 / np.arange(1, V + 1)
+    cdf = np.cumsum(w / w.sum())
+    out = []
+    for L in lens:
+        ids = np.searchsorted(cdf, rng.random(L)).clip(0, V - 1)
+        rev = rng.random(L) < 0.2
+        for i in range(1, L):
+            if rev[i]:
+                ids[i] = ids[i - 1]
+        out.append(ids.tolist())
+    return out
+
+
+def make_batches(model_name, order, n_batches, B, V, max_len, seed):
+    ds = importlib.import_module('sessionrec-pytorch_amd.dataset')
+    col = importlib.import_module('sessionrec-pytorch_amd.collate')
+    rng = np.random.default_rng(seed)
+    sessions = synth_sessions(int(n_batches * B / 4.5) + 64, V, 6.2, max_len, rng)
+    arr = np.empty(len(sessions), dtype=object)
+    arr[:] = sessions
+    data = ds.AugmentedDataset(arr)
+    assert len(data) >= n_batches * B, (len(data), n_batches * B)
+    if model_name in ('SRGNN', 'NISER'):
+        fn = col.collate_fn_factory(col.seq_to_session_graph)
+    elif model_name == 'LESSR':
+        fn = col.collate_fn_factory(col.seq_to_eop_multigraph)
+    else:
+        fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), order)
+    samples = [[data[b * B + i] for i in range(B)] for b in range(n_batches)]
+    return [fn(s) for s in samples], samples
+
+
+def build_model(sp, name, V, d, order):
+    if name == 'SRGNN':
+        return sp.SRGNN(V, d, 1, feat_drop=0.0)
+    if name == 'NISER':
+        return sp.NISER(V, d, 1, feat_drop=0.0)
+    if name == 'LESSR':
+        return sp.LESSR(V, d, 1, feat_drop=0.0)
+    return sp.MSGIFSR(V, 'synthetic', d, 1, dropout=0.0, order=order, extra=False, fusion=False)
+
+
+def time_dominant_kernel(model, B, V, d, dev, iters=20):
+    """HIP-event timing of the fused scoring/CE backward dE kernel alone (4*B*V*d flop per launch)."""
+    ops = importlib.import_module('sessionrec-pytorch_amd.ops')
+    L = importlib.import_module('sessionrec-pytorch_amd._lib')
+    lib, ptr, stream = L.lib, L.ptr, L.stream
+    table = model._table().detach()
+    sr = torch.randn(B, d, device=dev) * 0.1
+    labels = torch.randint(0, V, (B,), device=dev, dtype=torch.int32)
+    ws = ops.CEWorkspace(B, V, d, dev)
+    lse = torch.empty(B, device=dev)
+    lossvec = torch.empty(B, device=dev)
+    loss = torch.empty((), device=dev)
+    dE = torch.empty_like(table)
+    dsr = torch.empty(B, d, device=dev)
+    lib.srec_score_ce_fwd(ptr(sr), d, ptr(table), d, None, ptr(labels), B, V, d, None, ptr(ws.stats), ptr(ws.lab_logit),
+                          ptr(lse), ptr(lossvec), ptr(loss), stream())
+
+    def run(parts):
+        lib.srec_score_ce_bwd(ptr(sr), d, ptr(table), d, None, ptr(labels), ptr(lse), None, B, V, d, None, ptr(dE), d,
+                              ptr(ws.dsr_part), ptr(dsr), parts, stream())
+    out = {}
+    for name, parts in (('dE', 1), ('dsr', 2)):
+        for _ in range(3):
+            run(parts)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run(parts)
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / iters * 1e-3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.srec_score_ce_fwd(ptr(sr), d, ptr(table), d, None, ptr(labels), B, V, d, None, ptr(ws.stats),
+                              ptr(ws.lab_logit), ptr(lse), ptr(lossvec), ptr(loss), stream())
+    e1.record()
+    torch.cuda.synchronize()
+    out['fwd'] = e0.elapsed_time(e1) / iters * 1e-3
+    return out
+
+
+def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=20.0):
+    """the CPU oracle (restatement of the reference math: materialised logits, log(softmax), nll_loss,
+    autograd backward, torch Adam with L2) on this box's host cores, bounded sample."""
+    from oracle import collate_ref as oc
+    from oracle import models_ref as om
+    train = importlib.import_module('sessionrec-pytorch_amd.train')
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    if model_name == 'SRGNN':
+        m, fn = om.SRGNN(V, d, 1), oc.collate_fn_factory(oc.seq_to_session_graph)
+    elif model_name == 'NISER':
+        m, fn = om.NISER(V, d, 1), oc.collate_fn_factory(oc.seq_to_session_graph)
+    elif model_name == 'LESSR':
+        m, fn = om.LESSR(V, d, 1), oc.collate_fn_factory(oc.seq_to_eop_multigraph)
+    else:
+        m = om.MSGIFSR(V, 'synthetic', d, 1, order=order, extra=False, fusion=False)
+        fn = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), order)
+    m.load_state_dict(state_dict)
+    opt = torch.optim.Adam(train.fix_weight_decay(m), lr=1e-3, weight_decay=1e-4)
+    batches = [fn(s) for s in samples[:4]]
+    batches = [([om.to_torch(x) for x in inp], torch.from_numpy(lab)) for inp, lab in batches]
+    m.train()
+
+    def step(b):
+        inp, lab = b
+        opt.zero_grad()
+        loss = torch.nn.functional.nll_loss(m(*inp), lab)
+        loss.backward()
+        opt.step()
+    step(batches[0])                       # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        step(batches[n % len(batches)])
+        n += 1
+        if time.time() - t0 > budget_s or n >= 40:
+            break
+    dt = time.time() - t0
+    B = len(samples[0])
+    return dict(value=n * B / dt, unit='sessions/s', cores=cores, kind='port',
+                sample='%d training steps (batch %d) of the CPU oracle (%s, V=%d, d=%d), collate excluded, %d torch threads'
+                       % (n, B, model_name, V, d, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--model', default=os.environ.get('SREC_BENCH_MODEL', 'SRGNN'))
+    ap.add_argument('--order', type=int, default=3)
+    ap.add_argument('--dim', type=int, default=256)
+    ap.add_argument('--items', type=int, default=V_YOOCHOOSE)
+    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    sp = importlib.import_module('sessionrec-pytorch_amd')
+    train = importlib.import_module('sessionrec-pytorch_amd.train')
+    optim = importlib.import_module('sessionrec-pytorch_amd.optim')
+    B, V, d = args.batch, args.items, args.dim
+    n_batches = args.steps + args.warmup
+    batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank)
+    torch.manual_seed(123)
+    model = build_model(sp, args.model, V, d, args.order)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model)
+    dev_batches = [([x.to(dev) for x in inp], lab.to(dev)) for inp, lab in batches]
+    model.train()
+
+    def step(b):
+        inp, lab = b
+        opt.zero_grad()
+        loss = model.fused_loss(*inp, lab)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(dev_batches[i])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(dev_batches[args.warmup + i])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        kt = time_dominant_kernel(model, B, V, d, dev)
+        flops_dE = 4.0 * B * V * d
+        peak = 157.3                                      # TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
+        roof = dict(bound='mfma', kernel='flash_ce_kernel<MODE_DE> (fused scoring/CE backward, dE pass)',
+                    achieved=flops_dE / kt['dE'] / 1e12, peak=peak, unit='TFLOP/s',
+                    frac=flops_dE / kt['dE'] / 1e12 / peak, traffic=None,
+                    kernel_ms=dict(fwd=kt['fwd'] * 1e3, bwd_dE=kt['dE'] * 1e3, bwd_dsr=kt['dsr'] * 1e3))
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.model, samples, V, d, args.order, state)
+        out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=world * B * args.steps / dt,
+                   unit='sessions/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='f32', data='synthetic',
+                   config=dict(workload='%s training step, synthetic Yoochoose-1/64 shape (V=%d items, d=%d, batch %d per GPU, '
+                                        'session length<=20%s)' % (args.model, V, d, B,
+                                                                   ', order %d' % args.order if args.model == 'MSGIFSR' else ''),
+                               global_batch=B * world, parallelism='replicas x%d' % world if world > 1 else 'single GPU',
+                               final_loss=final_loss),
+                   roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

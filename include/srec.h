@@ -1,0 +1,103 @@
+/* libsrec_hip.so - C ABI of the MI355X (gfx950) session-recommendation training hot path.
+ *
+ * The reference (SpaceLearner/SessionRec-pytorch) has no FFI: its hot path is Python calling
+ * DGL / PyTorch CUDA ops.  Each entry point below names the reference call site(s) whose
+ * arithmetic it replaces; the host-side mirror (sessionrec-pytorch_amd/) binds them with ctypes
+ * (see INTEGRATION.md for the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (outputs pre-allocated), fp32 /
+ *     int32 unless noted; the library allocates nothing and never synchronises;
+ *   - `stream` is a hipStream_t (pass the framework's current stream; NULL = default stream);
+ *   - row-major matrices with an explicit leading dimension `ld_*` (floats); d, ld multiples of 4,
+ *     base pointers 16-byte aligned (float4 / 1 KiB-per-wave coalesced rows);
+ *   - `dyn*` (nullable) points at an int32 in device memory holding the LIVE extent of a
+ *     capacity-padded dimension, so one captured hipGraph serves batches of any size:
+ *     effective n = min(n_cap, *dyn); rows in [n, n_cap) are written as zeros by producers;
+ *   - return 0 on success, a hipError_t value or SREC_BAD_ARG (1001) otherwise.
+ */
+#ifndef SREC_H
+#define SREC_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SREC_BAD_ARG 1001
+
+/* ---- dense linear algebra on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ----------------
+ * C[m,n] = alpha * sum_k A(m,k) B(n,k) + beta*C[m,n] + bias[n];  A(m,k)=A[m*a_rs+k*a_cs], same for B.
+ * dyn_mode: 0 none, 1 clamps M, 2 clamps K.
+ * Replaces nn.Linear fwd/bwd: srgnn.py:66-68,124  lessr.py:16-17,59-62,94-100,164  msgifsr.py:114-116,202
+ * gatconv.py:157,282-283; GRU input/hidden projections srgnn.py:15, msgifsr.py:25. */
+int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_cs, float* C, int ldc,
+                  const float* bias, int M, int N, int K, const int* dyn, int dyn_mode, float alpha, float beta,
+                  void* stream);
+
+/* ---- fused full-catalog scoring + softmax-CE (score_ce.hip) -----------------------------------------
+ * z[b,v] = cs[v] * <sr_b, E_v> (cs NULL -> 1).  Replaces sr @ E^T, log(softmax), nll_loss:
+ * srgnn.py:145-147  niser.py:149-156  lessr.py:182-183  msgifsr.py:276-309,321  train.py:99 (+ backward). */
+int srec_ce_plan(int B, int V, int d, int* n_item_tiles, int* n_ranges);
+/* ws_stats: 2*n_item_tiles*B floats.  Outputs lab_logit[B], lse[B], lossvec[B], loss[1]. */
+int srec_score_ce_fwd(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const int* labels,
+                      int B, int V, int d, const int* dynB, float* ws_stats, float* lab_logit, float* lse,
+                      float* lossvec, float* loss, void* stream);
+/* ws_dsr: n_ranges*B*d floats.  gscale (nullable): upstream d loss.  Outputs dE[V,d] (every row), dsr[B,d].
+ * parts: bit0 = dE kernel, bit1 = d sr kernels (3 = both). */
+int srec_score_ce_bwd(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const int* labels,
+                      const float* lse, const float* gscale, int B, int V, int d, const int* dynB, float* dE,
+                      int ld_de, float* ws_dsr, float* dsr, int parts, void* stream);
+/* log-probabilities (B,V): the (B,num_items) tensor every reference model's forward() returns. */
+int srec_score_logp(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const float* lse, int B,
+                    int V, int d, const int* dynB, float* logp, long ld_logp, void* stream);
+
+/* ---- embedding rows (rowops.hip) --------------------------------------------------------------------
+ * gather: nn.Embedding lookup srgnn.py:133 niser.py:133 lessr.py:168 msgifsr.py:247.
+ * scatter_add_sorted: its backward as a deterministic segmented sum (items[u] distinct, pos grouped by ptr). */
+int srec_gather_rows(const float* src, int ld_src, const int* idx, float* out, int ld_out, int n_cap,
+                     const int* dyn, int d, void* stream);
+int srec_scatter_add_sorted(const float* g, int ld_g, const int* items, const int* ptr, const int* pos, float* dst,
+                            int ld_dst, int u_cap, const int* dyn, int d, int accumulate, void* stream);
+/* Embedding(max_norm) in-place renorm, idx distinct or NULL (= all rows): lessr.py:126 msgifsr.py:162 */
+int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, const int* dyn, int d, float max_norm,
+                     void* stream);
+/* out[v] = scale / norm(E_v); eps_mode 0: max(norm,eps) (F.normalize), 1: norm+eps (niser.py:151) */
+int srec_row_invnorm(const float* W, int ld, int n, int d, int eps_mode, float eps, float scale, float* out,
+                     void* stream);
+/* row L2 normalisation of node / session features: niser.py:135,142,148  msgifsr.py:253,263,273 */
+int srec_normalize_fwd(const float* X, int ld_x, float* Y, int ld_y, float* inv, int n_cap, const int* dyn, int d,
+                       int eps_mode, float eps, void* stream);
+int srec_normalize_bwd(const float* Y, int ld_y, const float* dY, int ld_dy, const float* inv, float* dX, int ld_dx,
+                       int n_cap, const int* dyn, int d, void* stream);
+/* chain rule of the catalog-row normalisation on the dense dE: G_v -= e_v <e_v, G_v> */
+int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g, int n, int d,
+                         void* stream);
+int srec_col_sum(const float* X, int ld, int n_cap, const int* dyn, int ncol, float* out, int accumulate,
+                 void* stream);
+
+/* ---- per-session kernels (segops.hip): one wavefront per session ------------------------------------
+ * attention readout core: srgnn.py:79-86 niser.py:77-84 lessr.py:106-113 msgifsr.py:139-146 */
+int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const float* X, int ld_x,
+                      const int* seg, int B, const int* dynB, int h, int D, float* alpha, float* out, int ld_out,
+                      void* stream);
+int srec_seg_attn_bwd(const float* dout, int ld_do, const float* X, int ld_x, const float* alpha, const float* U,
+                      int ld_u, const float* Vq, int ld_v, const float* we, const int* seg, int B, const int* dynB,
+                      int h, int D, float* dX, int ld_dx, float* dU, int ld_du, float* dVq, int ld_dv,
+                      float* dwe_part, int ld_dw, void* stream);
+/* out_i = h_i + mean_{session(i)} f  (msgifsr.py:86-89) */
+int srec_seg_mean_add_fwd(const float* H, int ld_h, const float* F, int ld_f, const int* seg, int B, const int* dynB,
+                          int D, float* out, int ld_out, void* stream);
+int srec_seg_mean_add_bwd(const float* dout, int ld_do, const int* seg, int B, const int* dynB, int D, float* dF,
+                          int ld_df, void* stream);
+
+/* ---- optimizer (adam.hip): torch.optim.Adam + coupled L2, train.py:70-75,101 ------------------------
+ * hyper (device) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2} */
+int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
+                   void* stream);
+int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
+                   int use_wd, float max_norm, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,233 @@
+"""Session -> flat batched graph builders: the host-side mirror of the reference's
+collate surface (src/utils/data/collate.py), emitting FlatBatch objects instead of
+DGL graphs.
+
+  seq_to_eop_multigraph   collate.py:29-44   every consecutive transition, click order
+  seq_to_shortcut_graph   collate.py:46-59   distinct (i<=j) position pairs, self loops included
+  seq_to_session_graph    collate.py:61-85   distinct transitions + multiplicity, self loop for 1 click
+  seq_to_ccs_graph        collate.py:87-217  1..K-gram heterograph
+  collate_fn_factory / collate_fn_factory_ccs   collate.py:219-256
+
+Same call surface: `collate_fn_factory(*fns)(samples) -> (inputs, labels)` with
+`samples = [(seq, label), ...]`; every element of `inputs` supports `.to(device)`.
+The per-sequence builders return small local graphs (python tuples); batching
+offsets node ids exactly like dgl.batch and additionally emits what the HIP
+kernels want: int32 everywhere, in-/out-edge CSR per relation (edge-id ordered, so
+EOPA's time order is preserved), the item -> positions CSR for the deterministic
+embedding backward, and the per-session concatenation permutation of the
+multi-order readout.  When the native builder (csrc/collate.cpp) is present it is
+used instead of the python loops; both produce identical buffers.
+"""
+import numpy as np
+import torch
+
+from .batch import FlatBatch
+
+
+# ------------------------------------------------------------------------------------ per-sequence
+def _rank(seq):
+    seq = np.asarray(seq, dtype=np.int64)
+    items, nid = np.unique(seq, return_inverse=True)
+    return items, nid.tolist()
+
+
+def _first_occurrence(pairs):
+    d = {}
+    for p in pairs:
+        d[p] = d.get(p, 0) + 1
+    return d
+
+
+def seq_to_eop_multigraph(seq):
+    items, nid = _rank(seq)
+    return ('eop', items, nid[-1], nid[:-1], nid[1:], None)
+
+
+def seq_to_shortcut_graph(seq):
+    items, nid = _rank(seq)
+    L = len(nid)
+    d = _first_occurrence((nid[i], nid[j]) for i in range(L) for j in range(i, L))
+    src, dst = zip(*d.keys())
+    return ('shortcut', items, None, list(src), list(dst), None)
+
+
+def seq_to_session_graph(seq):
+    items, nid = _rank(seq)
+    d = _first_occurrence(zip(nid[:-1], nid[1:]))
+    if d:
+        src, dst = zip(*d.keys())
+        w = list(d.values())
+    else:
+        src, dst, w = (0,), (0,), [1]
+    return ('session', items, nid[-1], list(src), list(dst), w)
+
+
+def seq_to_ccs_graph(seq, order=1, coaDict=None):
+    K = order
+    seq = [int(x) for x in seq]
+    L = len(seq)
+    eff = min(K, L)
+    items, nid = _rank(seq)
+    n = {1: len(items)}
+    iid = {1: items}
+    last = {1: nid[-1]}
+    gid = {1: nid}                       # per order: gram id at each start position
+    for k in range(2, K + 1):
+        ids, table, grams = [], {}, []
+        for j in range(L - k + 1):
+            key = tuple(seq[j:j + k])
+            g = table.get(key)
+            if g is None:
+                g = table[key] = len(table)
+                grams.append(key)
+            ids.append(g)
+        gid[k] = ids
+        if k <= eff:
+            n[k] = len(grams)
+            iid[k] = np.asarray(grams, dtype=np.int64).reshape(-1, k)
+            last[k] = ids[-1]
+        else:                            # session shorter than k: one dummy node (collate.py:203-208)
+            n[k] = 1
+            iid[k] = np.full((1, k), items[0], dtype=np.int64)
+            last[k] = 0
+    rel = {}
+    for k in range(1, K + 1):
+        if k <= eff:
+            g = gid[k]
+            rel[(k, 'intra%d' % k, k)] = list(_first_occurrence(zip(g[:-1], g[1:])).keys())
+        else:
+            rel[(k, 'intra%d' % k, k)] = []
+    for k in range(2, K + 1):
+        if k <= eff:
+            g = gid[k]
+            rel[(1, 'inter', k)] = list(_first_occurrence((nid[i], g[i + 1]) for i in range(L - k)).keys())
+            rel[(k, 'inter', 1)] = list(_first_occurrence((g[i], nid[i + k]) for i in range(L - k)).keys())
+        else:
+            rel[(1, 'inter', k)] = []
+            rel[(k, 'inter', 1)] = []
+    return ('ccs', K, n, iid, last, rel)
+
+
+# ------------------------------------------------------------------------------------ batching
+def _csr(key, n):
+    """stable grouping of edge ids by `key` (node id): ptr[n+1], idx[E]."""
+    key = np.asarray(key, dtype=np.int64)
+    idx = np.argsort(key, kind='stable').astype(np.int32)
+    ptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(key, minlength=n), out=ptr[1:])
+    return ptr, idx
+
+
+def _uniq_csr(gidx):
+    """distinct items and, per item, the positions where it is looked up."""
+    gidx = np.asarray(gidx, dtype=np.int64)
+    pos = np.argsort(gidx, kind='stable').astype(np.int32)
+    items, cnt = np.unique(gidx, return_counts=True)
+    ptr = np.zeros(len(items) + 1, dtype=np.int32)
+    np.cumsum(cnt, out=ptr[1:])
+    return items.astype(np.int32), ptr, pos
+
+
+def _cat(lst, dtype=np.int64):
+    lst = [np.asarray(a, dtype=dtype).reshape(-1) for a in lst]
+    return np.concatenate(lst) if lst else np.zeros(0, dtype)
+
+
+def batch_homogeneous(graphs, caps=None):
+    kind = graphs[0][0]
+    B = len(graphs)
+    nn = np.array([len(g[1]) for g in graphs], dtype=np.int64)
+    seg = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(nn, out=seg[1:])
+    N = int(seg[-1])
+    ne = np.array([len(g[3]) for g in graphs], dtype=np.int64)
+    eseg = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(ne, out=eseg[1:])
+    src = _cat([np.asarray(g[3], dtype=np.int64) + seg[i] for i, g in enumerate(graphs)])
+    dst = _cat([np.asarray(g[4], dtype=np.int64) + seg[i] for i, g in enumerate(graphs)])
+    E = len(src)
+    in_ptr, in_idx = _csr(dst, N)
+    out_ptr, out_idx = _csr(src, N)
+    fields = dict(seg=seg, eseg=eseg, esrc=src, edst=dst, in_ptr=in_ptr, in_idx=in_idx, out_ptr=out_ptr,
+                  out_idx=out_idx)
+    counts = dict(B=B, N=N, E=E)
+    if kind != 'shortcut':
+        iid = _cat([g[1] for g in graphs])
+        fields['iid'] = iid
+        fields['last'] = np.array([g[2] + seg[i] for i, g in enumerate(graphs)], dtype=np.int64)
+        ui, up, upos = _uniq_csr(iid)
+        fields.update(uniq_items=ui, uniq_ptr=up, uniq_pos=upos)
+        counts['U'] = len(ui)
+    if kind == 'session':
+        fields['ew'] = _cat([g[5] for g in graphs])
+    meta = dict(kind=kind, B=B, max_nodes=int(nn.max()) if B else 0)
+    return FlatBatch.build(fields, counts, meta, caps)
+
+
+def batch_ccs(graphs, caps=None):
+    K = graphs[0][1]
+    B = len(graphs)
+    fields, counts = {}, dict(B=B)
+    segs = {}
+    for k in range(1, K + 1):
+        nn = np.array([g[2][k] for g in graphs], dtype=np.int64)
+        seg = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(nn, out=seg[1:])
+        segs[k] = seg
+        fields['seg%d' % k] = seg
+        iid = np.concatenate([np.asarray(g[3][k], dtype=np.int64).reshape(-1, k) for g in graphs], axis=0)
+        fields['iid%d' % k] = iid if k > 1 else iid.reshape(-1)
+        fields['last%d' % k] = np.array([g[4][k] + seg[i] for i, g in enumerate(graphs)], dtype=np.int64)
+        counts['N%d' % k] = int(seg[-1])
+    # one fused embedding lookup for all orders: rows = [iid1 | iid2.flat | iid3.flat ...]
+    gidx = _cat([fields['iid%d' % k] for k in range(1, K + 1)])
+    ui, up, upos = _uniq_csr(gidx)
+    fields.update(gidx=gidx, uniq_items=ui, uniq_ptr=up, uniq_pos=upos)
+    counts['G'] = len(gidx)
+    counts['U'] = len(ui)
+    rel_names = []
+    for key in sorted(graphs[0][5].keys()):
+        s, et, d = key
+        name = 'r_%d_%s_%d' % (s, et, d)
+        rel_names.append((key, name))
+        src = _cat([np.asarray([e[0] for e in g[5][key]], dtype=np.int64) + segs[s][i] for i, g in enumerate(graphs)])
+        dst = _cat([np.asarray([e[1] for e in g[5][key]], dtype=np.int64) + segs[d][i] for i, g in enumerate(graphs)])
+        in_ptr, in_idx = _csr(dst, int(segs[d][-1]))
+        out_ptr, out_idx = _csr(src, int(segs[s][-1]))
+        fields.update({name + '_src': src, name + '_dst': dst, name + '_in_ptr': in_ptr, name + '_in_idx': in_idx,
+                       name + '_out_ptr': out_ptr, name + '_out_idx': out_idx})
+        counts['E_' + name] = len(src)
+    # readout: per session, nodes of all orders concatenated [s1 | s2 | ...] (msgifsr.py:135)
+    offs = np.concatenate([[0], np.cumsum([segs[k][-1] for k in range(1, K + 1)])])
+    perm = []
+    cat_seg = np.zeros(B + 1, dtype=np.int64)
+    for i in range(B):
+        for k in range(1, K + 1):
+            perm.append(np.arange(segs[k][i], segs[k][i + 1]) + offs[k - 1])
+        cat_seg[i + 1] = cat_seg[i] + sum(int(segs[k][i + 1] - segs[k][i]) for k in range(1, K + 1))
+    perm = _cat(perm)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    fields.update(cat_perm=perm, cat_inv=inv, cat_seg=cat_seg)
+    for k in range(1, K + 1):
+        fields['lastcat%d' % k] = fields['last%d' % k] + offs[k - 1]
+    counts['NT'] = len(perm)
+    max_nodes = int((cat_seg[1:] - cat_seg[:-1]).max()) if B else 0
+    meta = dict(kind='ccs', order=K, B=B, rels=rel_names, max_nodes=max_nodes)
+    return FlatBatch.build(fields, counts, meta, caps)
+
+
+def collate_fn_factory(*seq_to_graph_fns):
+    def collate_fn(samples):
+        seqs, labels = zip(*samples)
+        inputs = [batch_homogeneous([fn(s) for s in seqs]) for fn in seq_to_graph_fns]
+        return inputs, torch.as_tensor(np.asarray(labels, dtype=np.int64))
+    return collate_fn
+
+
+def collate_fn_factory_ccs(seq_to_graph_fns, order):
+    def collate_fn(samples):
+        seqs, labels = zip(*samples)
+        inputs = [batch_ccs([fn(s, order) for s in seqs]) for fn in seq_to_graph_fns]
+        return inputs, torch.as_tensor(np.asarray(labels, dtype=np.int64))
+    return collate_fn

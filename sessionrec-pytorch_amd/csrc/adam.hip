@@ -1,0 +1,124 @@
+// Fused Adam with coupled L2 weight decay (torch.optim.Adam semantics used by the
+// reference: train.py:70-75,101; fix_weight_decay groups train.py:12-23).
+//
+//   g = g + wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g
+//   p = p - (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+//
+// Hyper-parameters live in a small device array so a captured hipGraph can be
+// replayed while lr (StepLR) and the bias corrections change between steps:
+//   hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2}
+//
+// srec_adam_flat : any parameter, viewed as a flat fp32 array (one streaming pass over p,g,m,v).
+// srec_adam_rows : the item-embedding table, one wavefront per row, with the row-wise
+//                  epilogues fused into the same pass over HBM: Embedding(max_norm) renorm
+//                  (lessr.py:126, msgifsr.py:162) and the next step's cosine scale
+//                  cs_v = scale/||E_v|| (niser.py:151, msgifsr.py:279) - so the reference's
+//                  per-step full-table normalise passes cost no extra traffic.
+#include "common.h"
+
+namespace {
+
+struct Hyper { float lr, b1, b2, eps, wd, bc1, bc2; };
+
+__device__ __forceinline__ Hyper load_hyper(const float* __restrict__ h) {
+    Hyper r{h[0], h[1], h[2], h[3], h[4], h[5], h[6]};
+    return r;
+}
+
+__device__ __forceinline__ float adam1(float& p, float g, float& m, float& v, const Hyper& h, float wd,
+                                       float step, float rs2) {
+    g += wd * p;
+    m = h.b1 * m + (1.f - h.b1) * g;
+    v = h.b2 * v + (1.f - h.b2) * g * g;
+    p -= step * m / (sqrtf(v) * rs2 + h.eps);
+    return p;
+}
+
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, size_t n, const float* __restrict__ hyper, int use_wd) {
+    const Hyper h = load_hyper(hyper);
+    const float wd = use_wd ? h.wd : 0.f, step = h.lr / h.bc1, rs2 = 1.f / sqrtf(h.bc2);
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 pp = *reinterpret_cast<float4*>(p + i);
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            float4 mm = *reinterpret_cast<float4*>(m + i);
+            float4 vv = *reinterpret_cast<float4*>(v + i);
+            adam1(pp.x, gg.x, mm.x, vv.x, h, wd, step, rs2);
+            adam1(pp.y, gg.y, mm.y, vv.y, h, wd, step, rs2);
+            adam1(pp.z, gg.z, mm.z, vv.z, h, wd, step, rs2);
+            adam1(pp.w, gg.w, mm.w, vv.w, h, wd, step, rs2);
+            *reinterpret_cast<float4*>(p + i) = pp;
+            *reinterpret_cast<float4*>(m + i) = mm;
+            *reinterpret_cast<float4*>(v + i) = vv;
+        } else {
+            for (size_t j = i; j < n; ++j) adam1(p[j], g[j], m[j], v[j], h, wd, step, rs2);
+        }
+    }
+}
+
+__global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict__ G, float* __restrict__ M,
+                                 float* __restrict__ Vv, int n, int d, int ld, const float* __restrict__ hyper,
+                                 int use_wd, float max_norm, float* __restrict__ cs_out, float cs_scale, int eps_mode,
+                                 float cs_eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const Hyper h = load_hyper(hyper);
+    const float wd = use_wd ? h.wd : 0.f, step = h.lr / h.bc1, rs2 = 1.f / sqrtf(h.bc2);
+    const size_t off = (size_t)i * ld;
+    float ss = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 pp = *reinterpret_cast<float4*>(W + off + c);
+        const float4 gg = *reinterpret_cast<const float4*>(G + off + c);
+        float4 mm = *reinterpret_cast<float4*>(M + off + c);
+        float4 vv = *reinterpret_cast<float4*>(Vv + off + c);
+        adam1(pp.x, gg.x, mm.x, vv.x, h, wd, step, rs2);
+        adam1(pp.y, gg.y, mm.y, vv.y, h, wd, step, rs2);
+        adam1(pp.z, gg.z, mm.z, vv.z, h, wd, step, rs2);
+        adam1(pp.w, gg.w, mm.w, vv.w, h, wd, step, rs2);
+        ss += pp.x * pp.x + pp.y * pp.y + pp.z * pp.z + pp.w * pp.w;
+        *reinterpret_cast<float4*>(W + off + c) = pp;
+        *reinterpret_cast<float4*>(M + off + c) = mm;
+        *reinterpret_cast<float4*>(Vv + off + c) = vv;
+    }
+    if (max_norm <= 0.f && cs_out == nullptr) return;
+    float nrm = sqrtf(wave_sum(ss));
+    if (max_norm > 0.f && nrm > max_norm) {
+        const float sc = max_norm / (nrm + 1e-7f);
+        for (int c = lane * 4; c < d; c += 256) {       // same lane re-reads what it wrote
+            float4 pp = *reinterpret_cast<float4*>(W + off + c);
+            pp.x *= sc; pp.y *= sc; pp.z *= sc; pp.w *= sc;
+            *reinterpret_cast<float4*>(W + off + c) = pp;
+        }
+        nrm *= sc;
+    }
+    if (cs_out != nullptr && lane == 0)
+        cs_out[i] = cs_scale * (eps_mode == 0 ? 1.f / fmaxf(nrm, cs_eps) : 1.f / (nrm + cs_eps));
+}
+
+}  // namespace
+
+extern "C" int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
+                              void* stream) {
+    if (n <= 0) return 0;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SREC_BAD_ARG;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (size_t)n, hyper, use_wd);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
+                              int use_wd, float max_norm, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
+                              void* stream) {
+    if (n <= 0) return 0;
+    if (d <= 0 || (d & 3) || (ld & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld,
+                       hyper, use_wd, max_norm, cs_out, cs_scale, eps_mode, cs_eps);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,34 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  Wavefront = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SREC_LAUNCH_CHECK()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+#define SREC_BAD_ARG 1001
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+static __device__ __forceinline__ int dyn_count(const int* dyn, int n_static) {
+    if (dyn == nullptr) return n_static;
+    int v = *dyn;
+    return v < n_static ? v : n_static;
+}
+static __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,212 @@
+// srec_gemm_f32: exact-fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   C[m,n] = alpha * sum_k A(m,k) * B(n,k) + beta * C[m,n] + bias[n]
+//
+// A(m,k) lives at A[m*a_rs + k*a_cs], B(n,k) at B[n*b_rs + k*b_cs]; for each
+// operand exactly one of the two strides is 1.  That covers the three products a
+// linear layer needs without any transposed copies:
+//   Y  = X W^T  (nn.Linear forward)   A=X (k contiguous)  B=W  (k contiguous)
+//   dX = dY W                          A=dY (k contiguous) B=W  (n contiguous)
+//   dW = dY^T X                        A=dY (m contiguous) B=X  (n contiguous)
+// Replaces the cuBLAS calls behind nn.Linear in the reference models
+// (srgnn.py:66-68,124; lessr.py:16-17,59-62; msgifsr.py:114-116,202; gatconv.py:157).
+//
+// Tiling: 256 threads = 4 waves (2x2); block tile BMxBNx16, LDS tiles stored
+// k-major ([k][m]) so each MFMA operand read is a conflict-free ds_read_b32 of 32
+// consecutive floats per half-wave; global->register prefetch of the next k-tile
+// overlaps the MFMAs of the current one (double-buffered LDS, one barrier/tile).
+// A "dynamic extent" (node count living in device memory, so a captured hipGraph
+// can be replayed for batches of different size) may clamp M or K.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(
+    const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
+    float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
+    const int* __restrict__ dyn, int dyn_mode, float alpha, float beta) {
+    constexpr int SA = BM + 4, SB = BN + 4;
+    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave
+    constexpr int LA = BM * BK / 4 / 256, LB = BN * BK / 4 / 256;   // float4 loads per thread
+    __shared__ __attribute__((aligned(16))) float As[2][BK][SA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][SB];
+
+    const int Mfull = M;
+    if (dyn_mode == 1) M = dyn_count(dyn, M);
+    if (dyn_mode == 2) K = dyn_count(dyn, K);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    if (m0 >= M) {                                    // tile fully in the padded (dynamic) region
+        if (beta == 0.f) {
+            for (int i = tid; i < BM * BN; i += 256) {
+                int r = m0 + i / BN, c = n0 + i % BN;
+                if (r < Mfull && c < N) C[(size_t)r * ldc + c] = 0.f;
+            }
+        }
+        return;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[LA], rb[LB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < LA; ++p) {
+            int idx = tid + p * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A_KC) {
+                int m = m0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
+                if (m < M && k < K) {
+                    v = *reinterpret_cast<const float4*>(A + (size_t)m * a_rs + k);
+                    if (k + 3 >= K) { if (k + 1 >= K) v.y = 0.f; if (k + 2 >= K) v.z = 0.f; v.w = 0.f; }
+                }
+            } else {
+                int k = k0 + idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
+                if (m < M && k < K) v = *reinterpret_cast<const float4*>(A + (size_t)k * a_cs + m);
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < LB; ++p) {
+            int idx = tid + p * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (B_KC) {
+                int n = n0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
+                if (n < N && k < K) {
+                    v = *reinterpret_cast<const float4*>(B + (size_t)n * b_rs + k);
+                    if (k + 3 >= K) { if (k + 1 >= K) v.y = 0.f; if (k + 2 >= K) v.z = 0.f; v.w = 0.f; }
+                }
+            } else {
+                int k = k0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+                if (n < N && k < K) v = *reinterpret_cast<const float4*>(B + (size_t)k * b_cs + n);
+            }
+            rb[p] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < LA; ++p) {
+            int idx = tid + p * 256;
+            if (A_KC) {
+                int m = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
+                As[buf][k + 0][m] = ra[p].x; As[buf][k + 1][m] = ra[p].y;
+                As[buf][k + 2][m] = ra[p].z; As[buf][k + 3][m] = ra[p].w;
+            } else {
+                int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[buf][k][m]) = ra[p];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < LB; ++p) {
+            int idx = tid + p * 256;
+            if (B_KC) {
+                int n = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
+                Bs[buf][k + 0][n] = rb[p].x; Bs[buf][k + 1][n] = rb[p].y;
+                Bs[buf][k + 2][n] = rb[p].z; Bs[buf][k + 3][n] = rb[p].w;
+            } else {
+                int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[buf][k][n]) = rb[p];
+            }
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    if (nk > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk * 2 + half][wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk * 2 + half][wn * (BN / 2) + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+            const float bv = (bias != nullptr && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < Mfull && col < N) {
+                    float* p = C + (size_t)row * ldc + col;
+                    if (row < M) {
+                        float v = alpha * acc[i][j][r] + bv;
+                        if (beta != 0.f) v += beta * *p;
+                        *p = v;
+                    } else if (beta == 0.f) {
+                        *p = 0.f;
+                    }
+                }
+            }
+        }
+}
+
+template <int BM, int BN>
+int launch(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_cs, float* C, int ldc,
+           const float* bias, int M, int N, int K, const int* dyn, int dyn_mode, float alpha, float beta,
+           hipStream_t st) {
+    dim3 grid(cdiv(N, BN), cdiv(M, BM));
+    const bool akc = (a_cs == 1), bkc = (b_cs == 1);
+#define SREC_GEMM_GO(AK, BK_)                                                                             \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_>), grid, dim3(256), 0, st, A, a_rs, a_cs, B, b_rs, \
+                       b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta)
+    if (akc && bkc) SREC_GEMM_GO(true, true);
+    else if (akc && !bkc) SREC_GEMM_GO(true, false);
+    else if (!akc && bkc) SREC_GEMM_GO(false, true);
+    else SREC_GEMM_GO(false, false);
+#undef SREC_GEMM_GO
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_cs, float* C,
+                             int ldc, const float* bias, int M, int N, int K, const int* dyn, int dyn_mode,
+                             float alpha, float beta, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if ((a_rs != 1 && a_cs != 1) || (b_rs != 1 && b_cs != 1)) return SREC_BAD_ARG;
+    // float4 paths: the non-unit stride and the contiguous extent must be multiples of 4 floats
+    const int a_ld = (a_cs == 1) ? a_rs : a_cs, b_ld = (b_cs == 1) ? b_rs : b_cs;
+    if ((a_ld & 3) || (b_ld & 3)) return SREC_BAD_ARG;
+    if ((a_cs == 1 && (K & 3)) || (a_cs != 1 && (M & 3))) return SREC_BAD_ARG;
+    if ((b_cs == 1 && (K & 3)) || (b_cs != 1 && (N & 3))) return SREC_BAD_ARG;
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return SREC_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // small problems: 64x64 tiles keep more CUs busy; large: 128x128 for operand reuse
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    if (tiles128 >= 192)
+        return launch<128, 128>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, st);
+    return launch<64, 64>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, st);
+}

@@ -1,0 +1,264 @@
+// Row-structured HBM-bound kernels: one 64-lane wavefront per embedding / node row,
+// 16 B per lane (float4), so a d=256 fp32 row is exactly one coalesced 1 KiB wave access.
+//
+//   srec_gather_rows         nn.Embedding lookup                (srgnn.py:133, niser.py:133, lessr.py:168, msgifsr.py:247)
+//   srec_scatter_add_sorted  its backward: deterministic segmented sum over the positions of each
+//                            distinct item (collate emits the item -> positions CSR), no atomics
+//   srec_renorm_rows         Embedding(max_norm=1) in-place renorm (lessr.py:126, msgifsr.py:162)
+//   srec_row_invnorm         1/||E_v|| (x scale) for the cosine-scored models (niser.py:151, msgifsr.py:279)
+//   srec_normalize_fwd/bwd   F.normalize / x.div(norm) on node features (niser.py:135,142,148; msgifsr.py:253,263,273)
+//   srec_rownorm_project     chain rule of the catalog-row normalisation applied to the dense dE
+//   srec_col_sum             column sums (bias gradients, fc_e gradients)
+#include "common.h"
+
+namespace {
+
+constexpr int WPB = 4;   // waves (rows) per 256-thread block
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, const int* __restrict__ idx,
+                                   float* __restrict__ out, int ld_out, int n_cap, const int* __restrict__ dyn,
+                                   int d) {
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_cap) return;
+    const int n = dyn_count(dyn, n_cap);
+    const bool live = row < n;
+    const int s = live ? idx[row] : 0;
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = *reinterpret_cast<const float4*>(src + (size_t)s * ld_src + c);
+        *reinterpret_cast<float4*>(out + (size_t)row * ld_out + c) = v;
+    }
+}
+
+// dst[items[u], :] (+)= sum_{p in pos[ptr[u]:ptr[u+1]]} g[p, :]
+__global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g, const int* __restrict__ items,
+                                          const int* __restrict__ ptr, const int* __restrict__ pos,
+                                          float* __restrict__ dst, int ld_dst, int u_cap,
+                                          const int* __restrict__ dyn, int d, int accumulate) {
+    const int u = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= dyn_count(dyn, u_cap)) return;
+    const int beg = ptr[u], end = ptr[u + 1], item = items[u];
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = beg; e < end; ++e) {
+            const float4 v = *reinterpret_cast<const float4*>(g + (size_t)pos[e] * ld_g + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float4* o = reinterpret_cast<float4*>(dst + (size_t)item * ld_dst + c);
+        if (accumulate) {
+            const float4 t = *o;
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *o = s;
+    }
+}
+
+__device__ __forceinline__ float row_sumsq(const float* __restrict__ p, int d, int lane) {
+    float s = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    return wave_sum(s);
+}
+
+// rows = idx[0:n] (distinct!) or all rows when idx == NULL
+__global__ void renorm_rows_kernel(float* __restrict__ W, int ld, const int* __restrict__ idx, int n_cap,
+                                   const int* __restrict__ dyn, int d, float max_norm) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= dyn_count(dyn, n_cap)) return;
+    float* p = W + (size_t)(idx != nullptr ? idx[i] : i) * ld;
+    const float nrm = sqrtf(row_sumsq(p, d, lane));
+    if (nrm > max_norm) {
+        const float sc = max_norm / (nrm + 1e-7f);
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 v = *reinterpret_cast<float4*>(p + c);
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            *reinterpret_cast<float4*>(p + c) = v;
+        }
+    }
+}
+
+// eps_mode 0: 1/max(||x||, eps) (F.normalize)   1: 1/(||x|| + eps) (niser.py)
+__device__ __forceinline__ float inv_norm(float sumsq, int eps_mode, float eps) {
+    const float n = sqrtf(sumsq);
+    return eps_mode == 0 ? 1.f / fmaxf(n, eps) : 1.f / (n + eps);
+}
+
+__global__ void row_invnorm_kernel(const float* __restrict__ W, int ld, int n, int d, int eps_mode, float eps,
+                                   float scale, float* __restrict__ out) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float s = row_sumsq(W + (size_t)i * ld, d, lane);
+    if (lane == 0) out[i] = scale * inv_norm(s, eps_mode, eps);
+}
+
+__global__ void normalize_fwd_kernel(const float* __restrict__ X, int ld_x, float* __restrict__ Y, int ld_y,
+                                     float* __restrict__ inv, int n_cap, const int* __restrict__ dyn, int d,
+                                     int eps_mode, float eps) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_cap) return;
+    const bool live = i < dyn_count(dyn, n_cap);
+    float iv = 0.f;
+    if (live) iv = inv_norm(row_sumsq(X + (size_t)i * ld_x, d, lane), eps_mode, eps);
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            v = *reinterpret_cast<const float4*>(X + (size_t)i * ld_x + c);
+            v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
+        }
+        *reinterpret_cast<float4*>(Y + (size_t)i * ld_y + c) = v;
+    }
+    if (lane == 0) inv[i] = iv;
+}
+
+// dX = inv * (dY - Y (Y . dY))
+__global__ void normalize_bwd_kernel(const float* __restrict__ Y, int ld_y, const float* __restrict__ dY, int ld_dy,
+                                     const float* __restrict__ inv, float* __restrict__ dX, int ld_dx, int n_cap,
+                                     const int* __restrict__ dyn, int d) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_cap) return;
+    const bool live = i < dyn_count(dyn, n_cap);
+    float dot = 0.f;
+    if (live) {
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)i * ld_y + c);
+            const float4 g = *reinterpret_cast<const float4*>(dY + (size_t)i * ld_dy + c);
+            dot += y.x * g.x + y.y * g.y + y.z * g.z + y.w * g.w;
+        }
+        dot = wave_sum(dot);
+    }
+    const float iv = live ? inv[i] : 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)i * ld_y + c);
+            const float4 g = *reinterpret_cast<const float4*>(dY + (size_t)i * ld_dy + c);
+            o.x = iv * (g.x - y.x * dot); o.y = iv * (g.y - y.y * dot);
+            o.z = iv * (g.z - y.z * dot); o.w = iv * (g.w - y.w * dot);
+        }
+        *reinterpret_cast<float4*>(dX + (size_t)i * ld_dx + c) = o;
+    }
+}
+
+// G_v <- G_v - e_v (e_v . G_v),  e_v = W_v * inv_v   (inv = cs / scale)
+__global__ void rownorm_project_kernel(const float* __restrict__ W, int ld_w, const float* __restrict__ cs,
+                                       float inv_scale, float* __restrict__ G, int ld_g, int n, int d) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float iv = cs[i] * inv_scale;
+    float dot = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (size_t)i * ld_w + c);
+        const float4 g = *reinterpret_cast<const float4*>(G + (size_t)i * ld_g + c);
+        dot += w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w;
+    }
+    dot = wave_sum(dot) * iv * iv;
+    for (int c = lane * 4; c < d; c += 256) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (size_t)i * ld_w + c);
+        float4 g = *reinterpret_cast<float4*>(G + (size_t)i * ld_g + c);
+        g.x -= w.x * dot; g.y -= w.y * dot; g.z -= w.z * dot; g.w -= w.w * dot;
+        *reinterpret_cast<float4*>(G + (size_t)i * ld_g + c) = g;
+    }
+}
+
+// out[c] (+)= sum_{r<n} X[r,c]; block = 64 columns x 4 row groups
+__global__ void col_sum_kernel(const float* __restrict__ X, int ld, int n_cap, const int* __restrict__ dyn, int ncol,
+                               float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int n = dyn_count(dyn, n_cap);
+    float s = 0.f;
+    if (c < ncol)
+        for (int r = rg; r < n; r += 4) s += X[(size_t)r * ld + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < ncol) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+inline bool bad_row_args(int d, int ld) { return d <= 0 || (d & 3) || (ld & 3); }
+
+}  // namespace
+
+extern "C" int srec_gather_rows(const float* src, int ld_src, const int* idx, float* out, int ld_out, int n_cap,
+                                const int* dyn, int d, void* stream) {
+    if (n_cap <= 0) return 0;
+    if (bad_row_args(d, ld_src) || (ld_out & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx,
+                       out, ld_out, n_cap, dyn, d);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_scatter_add_sorted(const float* g, int ld_g, const int* items, const int* ptr, const int* pos,
+                                       float* dst, int ld_dst, int u_cap, const int* dyn, int d, int accumulate,
+                                       void* stream) {
+    if (u_cap <= 0) return 0;
+    if (bad_row_args(d, ld_g) || (ld_dst & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(scatter_add_sorted_kernel, dim3(cdiv(u_cap, WPB)), dim3(256), 0, (hipStream_t)stream, g, ld_g,
+                       items, ptr, pos, dst, ld_dst, u_cap, dyn, d, accumulate);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, const int* dyn, int d, float max_norm,
+                                void* stream) {
+    if (n_cap <= 0) return 0;
+    if (bad_row_args(d, ld)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(renorm_rows_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, W, ld, idx, n_cap,
+                       dyn, d, max_norm);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_row_invnorm(const float* W, int ld, int n, int d, int eps_mode, float eps, float scale, float* out,
+                                void* stream) {
+    if (n <= 0) return 0;
+    if (bad_row_args(d, ld)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(row_invnorm_kernel, dim3(cdiv(n, WPB)), dim3(256), 0, (hipStream_t)stream, W, ld, n, d, eps_mode,
+                       eps, scale, out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_normalize_fwd(const float* X, int ld_x, float* Y, int ld_y, float* inv, int n_cap, const int* dyn,
+                                  int d, int eps_mode, float eps, void* stream) {
+    if (n_cap <= 0) return 0;
+    if (bad_row_args(d, ld_x) || (ld_y & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(normalize_fwd_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, X, ld_x, Y, ld_y,
+                       inv, n_cap, dyn, d, eps_mode, eps);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_normalize_bwd(const float* Y, int ld_y, const float* dY, int ld_dy, const float* inv, float* dX,
+                                  int ld_dx, int n_cap, const int* dyn, int d, void* stream) {
+    if (n_cap <= 0) return 0;
+    if (bad_row_args(d, ld_y) || (ld_dy & 3) || (ld_dx & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, Y, ld_y, dY,
+                       ld_dy, inv, dX, ld_dx, n_cap, dyn, d);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g,
+                                    int n, int d, void* stream) {
+    if (n <= 0) return 0;
+    if (bad_row_args(d, ld_w) || (ld_g & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(rownorm_project_kernel, dim3(cdiv(n, WPB)), dim3(256), 0, (hipStream_t)stream, W, ld_w, cs,
+                       inv_scale, G, ld_g, n, d);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_col_sum(const float* X, int ld, int n_cap, const int* dyn, int ncol, float* out, int accumulate,
+                            void* stream) {
+    if (ncol <= 0) return 0;
+    hipLaunchKernelGGL(col_sum_kernel, dim3(cdiv(ncol, 64)), dim3(256), 0, (hipStream_t)stream, X, ld, n_cap, dyn, ncol,
+                       out, accumulate);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,196 @@
+// Per-session (segment) kernels: one 64-lane wavefront owns one session's nodes.
+// Session graphs are tiny (<= 256 nodes), so attention scores live in LDS and all
+// softmax / weighted-sum reductions are wavefront reductions - no atomics, no DGL
+// segment kernels, deterministic.
+//
+//   srec_seg_attn_fwd/bwd     AttnReadout core after the fc_u / fc_v GEMMs:
+//       e_i = fc_e(sigmoid(u_i + v_b)); alpha = softmax_session(e); out_b = sum_i alpha_i x_i
+//       (srgnn.py:79-86, niser.py:77-84, lessr.py:106-113, msgifsr.py:139-146)
+//   srec_seg_mean_add_fwd/bwd out_i = h_i + mean_{j in session(i)} f_j   (msgifsr.py:86-89)
+#include "common.h"
+
+namespace {
+
+constexpr int WPB = 4;
+constexpr int MAXN = 256;   // max nodes of one session (host checks)
+
+__global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const float* __restrict__ Vq, int ld_v,
+                                    const float* __restrict__ we, const float* __restrict__ X, int ld_x,
+                                    const int* __restrict__ seg, int B, const int* __restrict__ dynB, int h, int D,
+                                    float* __restrict__ alpha, float* __restrict__ out, int ld_out) {
+    __shared__ float es[WPB][MAXN];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * WPB + w;
+    if (b >= B) return;
+    const bool live = b < dyn_count(dynB, B);
+    const int base = live ? seg[b] : 0;
+    const int n = live ? min(seg[b + 1] - base, MAXN) : 0;
+    float* e = es[w];
+    for (int i = 0; i < n; ++i) {
+        float acc = 0.f;
+        for (int k = lane; k < h; k += 64)
+            acc += we[k] * sigmoidf_(U[(size_t)(base + i) * ld_u + k] + Vq[(size_t)b * ld_v + k]);
+        acc = wave_sum(acc);
+        if (lane == 0) e[i] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, e[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(e[i] - m);
+    s = wave_sum(s);
+    const float inv = n > 0 ? 1.f / s : 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const float a = expf(e[i] - m) * inv;
+        e[i] = a;
+        alpha[base + i] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < n; ++i) {
+            const float a = e[i];
+            const float4 x = *reinterpret_cast<const float4*>(X + (size_t)(base + i) * ld_x + c);
+            o.x += a * x.x; o.y += a * x.y; o.z += a * x.z; o.w += a * x.w;
+        }
+        *reinterpret_cast<float4*>(out + (size_t)b * ld_out + c) = o;
+    }
+}
+
+__global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, const float* __restrict__ X, int ld_x,
+                                    const float* __restrict__ alpha, const float* __restrict__ U, int ld_u,
+                                    const float* __restrict__ Vq, int ld_v, const float* __restrict__ we,
+                                    const int* __restrict__ seg, int B, const int* __restrict__ dynB, int h, int D,
+                                    float* __restrict__ dX, int ld_dx, float* __restrict__ dU, int ld_du,
+                                    float* __restrict__ dVq, int ld_dv, float* __restrict__ dwe_part, int ld_dw) {
+    __shared__ float de_s[WPB][MAXN];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * WPB + w;
+    if (b >= B) return;
+    const bool live = b < dyn_count(dynB, B);
+    const int base = live ? seg[b] : 0;
+    const int n = live ? min(seg[b + 1] - base, MAXN) : 0;
+    float* de = de_s[w];
+    // dalpha_i = <dout_b, x_i>;  dX_i = alpha_i dout_b
+    for (int i = 0; i < n; ++i) {
+        const float a = alpha[base + i];
+        float acc = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)b * ld_do + c);
+            const float4 x = *reinterpret_cast<const float4*>(X + (size_t)(base + i) * ld_x + c);
+            acc += g.x * x.x + g.y * x.y + g.z * x.z + g.w * x.w;
+            *reinterpret_cast<float4*>(dX + (size_t)(base + i) * ld_dx + c) =
+                make_float4(a * g.x, a * g.y, a * g.z, a * g.w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) de[i] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += alpha[base + i] * de[i];
+    s = wave_sum(s);
+    for (int i = lane; i < n; i += 64) de[i] = alpha[base + i] * (de[i] - s);     // d e_i
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < h; k += 64) {
+        const float vq = live ? Vq[(size_t)b * ld_v + k] : 0.f;
+        const float wk = we[k];
+        float dv = 0.f, dw = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float sg = sigmoidf_(U[(size_t)(base + i) * ld_u + k] + vq);
+            const float dei = de[i];
+            dw += dei * sg;
+            const float dp = dei * wk * sg * (1.f - sg);
+            dU[(size_t)(base + i) * ld_du + k] = dp;
+            dv += dp;
+        }
+        dVq[(size_t)b * ld_dv + k] = dv;
+        dwe_part[(size_t)b * ld_dw + k] = dw;
+    }
+}
+
+__global__ void seg_mean_add_fwd_kernel(const float* __restrict__ H, int ld_h, const float* __restrict__ F, int ld_f,
+                                        const int* __restrict__ seg, int B, const int* __restrict__ dynB, int D,
+                                        float* __restrict__ out, int ld_out) {
+    const int b = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= dyn_count(dynB, B)) return;
+    const int base = seg[b], n = seg[b + 1] - base;
+    const float inv = 1.f / (float)(n > 0 ? n : 1);
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < n; ++i) {
+            const float4 f = *reinterpret_cast<const float4*>(F + (size_t)(base + i) * ld_f + c);
+            m.x += f.x; m.y += f.y; m.z += f.z; m.w += f.w;
+        }
+        m.x *= inv; m.y *= inv; m.z *= inv; m.w *= inv;
+        for (int i = 0; i < n; ++i) {
+            const float4 hv = *reinterpret_cast<const float4*>(H + (size_t)(base + i) * ld_h + c);
+            *reinterpret_cast<float4*>(out + (size_t)(base + i) * ld_out + c) =
+                make_float4(hv.x + m.x, hv.y + m.y, hv.z + m.z, hv.w + m.w);
+        }
+    }
+}
+
+// dF_j = (1/n) sum_{i in session(j)} dout_i     (dH = dout is a pass-through)
+__global__ void seg_mean_add_bwd_kernel(const float* __restrict__ dout, int ld_do, const int* __restrict__ seg, int B,
+                                        const int* __restrict__ dynB, int D, float* __restrict__ dF, int ld_df) {
+    const int b = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= dyn_count(dynB, B)) return;
+    const int base = seg[b], n = seg[b + 1] - base;
+    const float inv = 1.f / (float)(n > 0 ? n : 1);
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < n; ++i) {
+            const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)(base + i) * ld_do + c);
+            m.x += g.x; m.y += g.y; m.z += g.z; m.w += g.w;
+        }
+        m.x *= inv; m.y *= inv; m.z *= inv; m.w *= inv;
+        for (int i = 0; i < n; ++i) *reinterpret_cast<float4*>(dF + (size_t)(base + i) * ld_df + c) = m;
+    }
+}
+
+}  // namespace
+
+extern "C" int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const float* X,
+                                 int ld_x, const int* seg, int B, const int* dynB, int h, int D, float* alpha,
+                                 float* out, int ld_out, void* stream) {
+    if (B <= 0) return 0;
+    if ((D & 3) || (ld_x & 3) || (ld_out & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(seg_attn_fwd_kernel, dim3(cdiv(B, WPB)), dim3(256), 0, (hipStream_t)stream, U, ld_u, Vq, ld_v, we,
+                       X, ld_x, seg, B, dynB, h, D, alpha, out, ld_out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_seg_attn_bwd(const float* dout, int ld_do, const float* X, int ld_x, const float* alpha,
+                                 const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const int* seg,
+                                 int B, const int* dynB, int h, int D, float* dX, int ld_dx, float* dU, int ld_du,
+                                 float* dVq, int ld_dv, float* dwe_part, int ld_dw, void* stream) {
+    if (B <= 0) return 0;
+    if ((D & 3) || (ld_x & 3) || (ld_do & 3) || (ld_dx & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(seg_attn_bwd_kernel, dim3(cdiv(B, WPB)), dim3(256), 0, (hipStream_t)stream, dout, ld_do, X, ld_x,
+                       alpha, U, ld_u, Vq, ld_v, we, seg, B, dynB, h, D, dX, ld_dx, dU, ld_du, dVq, ld_dv, dwe_part,
+                       ld_dw);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_seg_mean_add_fwd(const float* H, int ld_h, const float* F, int ld_f, const int* seg, int B,
+                                     const int* dynB, int D, float* out, int ld_out, void* stream) {
+    if (B <= 0) return 0;
+    if ((D & 3) || (ld_h & 3) || (ld_f & 3) || (ld_out & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(seg_mean_add_fwd_kernel, dim3(cdiv(B, WPB)), dim3(256), 0, (hipStream_t)stream, H, ld_h, F, ld_f,
+                       seg, B, dynB, D, out, ld_out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_seg_mean_add_bwd(const float* dout, int ld_do, const int* seg, int B, const int* dynB, int D,
+                                     float* dF, int ld_df, void* stream) {
+    if (B <= 0) return 0;
+    if ((D & 3) || (ld_do & 3) || (ld_df & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(seg_mean_add_bwd_kernel, dim3(cdiv(B, WPB)), dim3(256), 0, (hipStream_t)stream, dout, ld_do, seg,
+                       B, dynB, D, dF, ld_df);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

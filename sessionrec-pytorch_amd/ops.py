@@ -1,0 +1,389 @@
+"""torch.autograd.Function wrappers over the C ABI (include/srec.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and the
+autograd tape; every forward AND backward below is a hand-written gfx950 kernel
+launched through libsrec_hip.so.  CPU tensors raise (no fallback).
+
+`dyn` arguments are optional 1-element int32 device tensors holding the live
+extent of a capacity-padded dimension (see batch.FlatBatch.dyn).
+"""
+import torch
+
+from ._lib import lib, ptr, stream
+
+
+def _rows(t):
+    """2-D fp32 tensor with unit inner stride (row-strided views allowed) -> tensor usable as (ptr, ld)."""
+    assert t.dim() == 2 and t.dtype == torch.float32, (t.shape, t.dtype)
+    if t.stride(1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & 15) or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm_nt(x, w, out, bias=None, dyn=None, dyn_mode=0, beta=0.0):
+    """out[M,N] = x[M,K] @ w[N,K]^T (+bias) (+beta*out)"""
+    M, K = x.shape
+    N = w.shape[0]
+    lib.srec_gemm_f32(ptr(x), _ld(x), 1, ptr(w), _ld(w), 1, ptr(out), _ld(out), ptr(bias), M, N, K, ptr(dyn), dyn_mode,
+                      1.0, beta, stream())
+
+
+def gemm_nn(g, w, out, dyn=None, dyn_mode=0, beta=0.0):
+    """out[M,K] = g[M,N] @ w[N,K]"""
+    M, N = g.shape
+    K = w.shape[1]
+    lib.srec_gemm_f32(ptr(g), _ld(g), 1, ptr(w), 1, _ld(w), ptr(out), _ld(out), None, M, K, N, ptr(dyn), dyn_mode, 1.0,
+                      beta, stream())
+
+
+def gemm_tn(g, x, out, dyn=None, beta=0.0):
+    """out[N,K] = g[M,N]^T @ x[M,K]   (reduction over the M rows; dyn clamps M)"""
+    M, N = g.shape
+    K = x.shape[1]
+    lib.srec_gemm_f32(ptr(g), 1, _ld(g), ptr(x), 1, _ld(x), ptr(out), _ld(out), None, N, K, M, ptr(dyn),
+                      2 if dyn is not None else 0, 1.0, beta, stream())
+
+
+class LinearCat(torch.autograd.Function):
+    """y = sum_i x_i @ W[:, off_i:off_i+k_i]^T + b   == nn.Linear(cat(x_i, dim=1)) without the concat."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, dyn, *xs):
+        xs = [_rows(x) for x in xs]
+        M = xs[0].shape[0]
+        N = weight.shape[0]
+        w = _rows(weight)
+        y = torch.empty(M, N, device=w.device, dtype=torch.float32)
+        off = 0
+        for i, x in enumerate(xs):
+            k = x.shape[1]
+            gemm_nt(x, w[:, off:off + k], y, bias if i == 0 else None, dyn, 1 if dyn is not None else 0,
+                    0.0 if i == 0 else 1.0)
+            off += k
+        assert off == w.shape[1], (off, w.shape)
+        ctx.save_for_backward(w, *xs)
+        ctx.dyn = dyn
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        w, *xs = ctx.saved_tensors
+        dyn = ctx.dyn
+        gy = _rows(gy)
+        need_x = ctx.needs_input_grad[3:]
+        gw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        gb = None
+        gxs = []
+        off = 0
+        for i, x in enumerate(xs):
+            k = x.shape[1]
+            if need_x[i]:
+                gx = torch.empty_like(x, memory_format=torch.contiguous_format)
+                gemm_nn(gy, w[:, off:off + k], gx, dyn, 1 if dyn is not None else 0)
+                gxs.append(gx)
+            else:
+                gxs.append(None)
+            if gw is not None:
+                gemm_tn(gy, x, gw[:, off:off + k], dyn)
+            off += k
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32)
+            lib.srec_col_sum(ptr(gy), _ld(gy), gy.shape[0], ptr(dyn), w.shape[0], ptr(gb), 0, stream())
+        return (gw, gb, None) + tuple(gxs)
+
+
+def linear(x, weight, bias=None, dyn=None):
+    return LinearCat.apply(weight, bias, dyn, x)
+
+
+def linear_cat(xs, weight, bias=None, dyn=None):
+    return LinearCat.apply(weight, bias, dyn, *xs)
+
+
+class TableGrad:
+    """Dense gradient buffer of the item table, shared by the scoring backward (writes every row)
+    and the embedding-lookup backward (adds its rows in place): no dense+dense autograd sum."""
+
+    def __init__(self, weight):
+        self.buf = torch.zeros_like(weight)
+        self.fresh = False       # True once the scoring backward has overwritten it this step
+
+
+class EmbeddingLookup(torch.autograd.Function):
+    """rows = table[idx].  Backward = deterministic segmented row sums (no atomics): added in place
+    into TableGrad when the fused loss owns the table gradient, else returned as a dense grad."""
+
+    @staticmethod
+    def forward(ctx, table, idx, uniq, tgrad, dyn_n, dyn_u):
+        n = idx.numel()
+        d = table.shape[1]
+        out = torch.empty(n, d, device=table.device, dtype=torch.float32)
+        lib.srec_gather_rows(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, ptr(dyn_n), d, stream())
+        ctx.uniq, ctx.tgrad, ctx.dyn_u, ctx.shape = uniq, tgrad, dyn_u, tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        items, uptr, upos = ctx.uniq
+        tg = ctx.tgrad
+        g = _rows(g)
+        V, d = ctx.shape
+        if tg is not None:
+            dst, acc, ret = tg.buf, 1, None
+        else:
+            dst = torch.zeros(V, d, device=g.device, dtype=torch.float32)
+            acc, ret = 0, dst
+        lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(items), ptr(uptr), ptr(upos), ptr(dst), dst.stride(0),
+                                    items.numel(), ptr(ctx.dyn_u), d, acc, stream())
+        return ret, None, None, None, None, None
+
+
+def embedding_lookup(table, idx, uniq, tgrad=None, dyn_n=None, dyn_u=None):
+    return EmbeddingLookup.apply(table, idx, uniq, tgrad, dyn_n, dyn_u)
+
+
+class RowGather(torch.autograd.Function):
+    """out = x[idx] for DISTINCT idx (last-node pick, permutations); backward scatters rows back."""
+
+    @staticmethod
+    def forward(ctx, x, idx, dyn):
+        x = _rows(x)
+        n, d = idx.numel(), x.shape[1]
+        out = torch.empty(n, d, device=x.device, dtype=torch.float32)
+        lib.srec_gather_rows(ptr(x), _ld(x), ptr(idx), ptr(out), d, n, ptr(dyn), d, stream())
+        ctx.save_for_backward(idx)
+        ctx.nrows, ctx.dyn = x.shape[0], dyn
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _rows(g)
+        n, d = g.shape
+        gx = torch.zeros(ctx.nrows, d, device=g.device, dtype=torch.float32)
+        ar = _arange(n + 1, g.device)
+        lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(idx), ptr(ar), ptr(ar), ptr(gx), d, n, ptr(ctx.dyn), d, 0,
+                                    stream())
+        return gx, None, None
+
+
+_ARANGE = {}
+
+
+def _arange(n, device):
+    key = (str(device),)
+    t = _ARANGE.get(key)
+    if t is None or t.numel() < n:
+        t = torch.arange(max(n, 4096), device=device, dtype=torch.int32)
+        _ARANGE[key] = t
+    return t
+
+
+def row_gather(x, idx, dyn=None):
+    return RowGather.apply(x, idx, dyn)
+
+
+class Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps_mode, dyn):
+        x = _rows(x)
+        n, d = x.shape
+        y = torch.empty(n, d, device=x.device, dtype=torch.float32)
+        inv = torch.empty(n, device=x.device, dtype=torch.float32)
+        lib.srec_normalize_fwd(ptr(x), _ld(x), ptr(y), d, ptr(inv), n, ptr(dyn), d, eps_mode, 1e-12, stream())
+        ctx.save_for_backward(y, inv)
+        ctx.dyn = dyn
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, inv = ctx.saved_tensors
+        gy = _rows(gy)
+        n, d = y.shape
+        gx = torch.empty_like(y)
+        lib.srec_normalize_bwd(ptr(y), d, ptr(gy), _ld(gy), ptr(inv), ptr(gx), d, n, ptr(ctx.dyn), d, stream())
+        return gx, None, None
+
+
+def normalize(x, eps_mode=0, dyn=None):
+    return Normalize.apply(x, eps_mode, dyn)
+
+
+class SegAttn(torch.autograd.Function):
+    """alpha = softmax_session(fc_e(sigmoid(U + Vq[b])));  out_b = sum_i alpha_i x_i"""
+
+    @staticmethod
+    def forward(ctx, U, Vq, we, X, seg, dynB):
+        U, Vq, X = _rows(U), _rows(Vq), _rows(X)
+        we = we.reshape(-1).contiguous()
+        B, h = Vq.shape
+        N, D = X.shape
+        alpha = torch.zeros(N, device=X.device, dtype=torch.float32)
+        out = torch.empty(B, D, device=X.device, dtype=torch.float32)
+        lib.srec_seg_attn_fwd(ptr(U), _ld(U), ptr(Vq), _ld(Vq), ptr(we), ptr(X), _ld(X), ptr(seg), B, ptr(dynB), h, D,
+                              ptr(alpha), ptr(out), D, stream())
+        ctx.save_for_backward(U, Vq, we, X, alpha, seg)
+        ctx.dynB = dynB
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        U, Vq, we, X, alpha, seg = ctx.saved_tensors
+        gout = _rows(gout)
+        B, h = Vq.shape
+        N, D = X.shape
+        dX = torch.zeros(N, D, device=X.device, dtype=torch.float32)
+        dU = torch.zeros(N, h, device=X.device, dtype=torch.float32)
+        dVq = torch.empty(B, h, device=X.device, dtype=torch.float32)
+        dwp = torch.empty(B, h, device=X.device, dtype=torch.float32)
+        lib.srec_seg_attn_bwd(ptr(gout), _ld(gout), ptr(X), _ld(X), ptr(alpha), ptr(U), _ld(U), ptr(Vq), _ld(Vq),
+                              ptr(we), ptr(seg), B, ptr(ctx.dynB), h, D, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp),
+                              h, stream())
+        dwe = torch.empty(h, device=X.device, dtype=torch.float32)
+        lib.srec_col_sum(ptr(dwp), h, B, ptr(ctx.dynB), h, ptr(dwe), 0, stream())
+        return dU, dVq, dwe.view(1, h), dX, None, None
+
+
+def seg_attn(U, Vq, we, X, seg, dynB=None):
+    return SegAttn.apply(U, Vq, we, X, seg, dynB)
+
+
+class SegMeanAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, F, seg, B, dynB):
+        H, F = _rows(H), _rows(F)
+        N, D = F.shape
+        out = torch.zeros(N, D, device=F.device, dtype=torch.float32)
+        lib.srec_seg_mean_add_fwd(ptr(H), _ld(H), ptr(F), _ld(F), ptr(seg), B, ptr(dynB), D, ptr(out), D, stream())
+        ctx.save_for_backward(seg)
+        ctx.B, ctx.dynB = B, dynB
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (seg,) = ctx.saved_tensors
+        g = _rows(g)
+        N, D = g.shape
+        dF = torch.zeros(N, D, device=g.device, dtype=torch.float32)
+        lib.srec_seg_mean_add_bwd(ptr(g), _ld(g), ptr(seg), ctx.B, ptr(ctx.dynB), D, ptr(dF), D, stream())
+        return g, dF, None, None, None
+
+
+def seg_mean_add(H, F, seg, B, dynB=None):
+    return SegMeanAdd.apply(H, F, seg, B, dynB)
+
+
+# ------------------------------------------------------------------------------------------ scoring
+class CEWorkspace:
+    """Reusable scratch of the fused scoring/CE kernels for one (B, V, d)."""
+
+    def __init__(self, B, V, d, device):
+        import ctypes
+        nt, nr = ctypes.c_int(), ctypes.c_int()
+        lib.srec_ce_plan(B, V, d, ctypes.addressof(nt), ctypes.addressof(nr))
+        self.B, self.V, self.d = B, V, d
+        self.stats = torch.empty(2 * nt.value * B, device=device, dtype=torch.float32)
+        self.dsr_part = torch.empty(nr.value * B * d, device=device, dtype=torch.float32)
+        self.lab_logit = torch.zeros(B, device=device, dtype=torch.float32)
+
+
+class ScoreCE(torch.autograd.Function):
+    """loss = mean_b CE(cs * sr_b E^T, label_b), logits never materialised.  Writes the dense
+    table gradient into `tgrad.buf` (all rows) instead of returning it."""
+
+    @staticmethod
+    def forward(ctx, sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale):
+        sr = _rows(sr)
+        B, d = sr.shape
+        V = table.shape[0]
+        lse = torch.empty(B, device=sr.device, dtype=torch.float32)
+        lossvec = torch.empty(B, device=sr.device, dtype=torch.float32)
+        loss = torch.empty((), device=sr.device, dtype=torch.float32)
+        lib.srec_score_ce_fwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), B, V, d, ptr(dynB),
+                              ptr(ws.stats), ptr(ws.lab_logit), ptr(lse), ptr(lossvec), ptr(loss), stream())
+        ctx.save_for_backward(sr, table, cs, labels, lse)
+        ctx.ws, ctx.tgrad, ctx.dynB, ctx.cs_inv_scale = ws, tgrad, dynB, cs_inv_scale
+        ctx.mark_non_differentiable(lse)
+        return loss, lse
+
+    @staticmethod
+    def backward(ctx, gloss, _glse):
+        sr, table, cs, labels, lse = ctx.saved_tensors
+        B, d = sr.shape
+        V = table.shape[0]
+        tg, ws = ctx.tgrad, ctx.ws
+        gl = gloss.reshape(1).to(torch.float32).contiguous()
+        dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
+        lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), ptr(gl),
+                              B, V, d, ptr(ctx.dynB), ptr(tg.buf), tg.buf.stride(0), ptr(ws.dsr_part), ptr(dsr),
+                              3, stream())
+        if cs is not None:      # rows were L2-normalised before scoring: project out the radial part
+            lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(tg.buf),
+                                     tg.buf.stride(0), V, d, stream())
+        tg.fresh = True
+        return dsr, None, None, None, None, None, None, None
+
+
+def score_ce(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0):
+    return ScoreCE.apply(sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale)
+
+
+class ScoreLogProb(torch.autograd.Function):
+    """(B,V) log-probabilities - the tensor the reference models' forward() returns (compat /
+    evaluation path).  Backward materialises d z (B,V) and runs two MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, sr, table, cs, ws, cs_inv_scale):
+        sr = _rows(sr)
+        B, d = sr.shape
+        V = table.shape[0]
+        dev = sr.device
+        lse = torch.empty(B, device=dev, dtype=torch.float32)
+        lossvec = torch.empty(B, device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        zeros = torch.zeros(B, device=dev, dtype=torch.int32)
+        lib.srec_score_ce_fwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(zeros), B, V, d, None,
+                              ptr(ws.stats), ptr(ws.lab_logit), ptr(lse), ptr(lossvec), ptr(loss), stream())
+        ldp = (V + 3) & ~3
+        logp = torch.empty(B, ldp, device=dev, dtype=torch.float32)[:, :V]
+        lib.srec_score_logp(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(lse), B, V, d, None, ptr(logp),
+                            ldp, stream())
+        ctx.save_for_backward(sr, table, cs, logp)
+        ctx.cs_inv_scale = cs_inv_scale
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        sr, table, cs, logp = ctx.saved_tensors
+        dz = g - torch.exp(logp) * g.sum(dim=1, keepdim=True)
+        if cs is not None:
+            dz = dz * cs.unsqueeze(0)
+        V, d = table.shape
+        ldp = (V + 3) & ~3
+        dzp = torch.zeros(dz.shape[0], ldp, device=dz.device, dtype=torch.float32)
+        dzp[:, :V] = dz
+        tablep = table if ldp == V else _pad_rows(table, ldp)
+        dsr = torch.empty_like(sr)
+        gemm_nn(dzp, tablep, dsr)
+        dEp = torch.empty(ldp, d, device=dz.device, dtype=torch.float32)
+        gemm_tn(dzp, sr, dEp)
+        dE = dEp[:V]
+        if cs is not None:
+            lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(dE), dE.stride(0), V,
+                                     d, stream())
+        return dsr, dE, None, None, None
+
+
+def _pad_rows(t, n):
+    out = torch.zeros(n, t.shape[1], device=t.device, dtype=t.dtype)
+    out[:t.shape[0]] = t
+    return out
+
+
+def score_logp(sr, table, cs, ws, cs_inv_scale=1.0):
+    return ScoreLogProb.apply(sr, table, cs, ws, cs_inv_scale)

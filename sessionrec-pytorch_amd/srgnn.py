@@ -1,0 +1,184 @@
+"""SRGNN and NISER on the HIP path - host-side mirror of
+/root/reference/src/models/srgnn.py:93-148 and niser.py:91-157.
+
+Same constructor signatures, parameter names and shapes (state_dicts interchange
+with the reference / the oracle), same `forward(mg, sg=None) -> (B, num_items)`
+log-probabilities.  The nn.Embedding / nn.Linear / nn.GRUCell children are
+parameter containers only: all arithmetic goes through sessionrec-pytorch_amd.ops
+(hand-written gfx950 kernels).  `fused_loss(mg, labels)` is the training entry the
+TrainRunner uses: logits are never materialised and the dense table gradient is
+written once, in place, by the scoring backward.
+
+Reference quirk kept: the SRGNNLayer outputs are not consumed by the
+readout (srgnn.py:135-142), so by default the layers are not even executed;
+`use_gnn_output=True` runs them and feeds their output on (a documented extension).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _ScoringMixin:
+    """Shared scoring head: fused CE for training, materialised log-probs for the forward() API."""
+
+    def _table(self):
+        return self.embedding.weight
+
+    def _cosine(self):
+        return None            # (scale, eps_mode) for cosine-scored models
+
+    def _state(self, B):
+        dev = self._table().device
+        st = self.__dict__.setdefault('_srec_state', {})
+        if st.get('dev') != dev:
+            st.clear()
+            st['dev'] = dev
+            st['tgrad'] = ops.TableGrad(self._table())
+            st['ws'] = {}
+            st['cs'] = None
+            st['cs_fresh'] = False
+        if B not in st['ws']:
+            V, d = self._table().shape
+            st['ws'][B] = ops.CEWorkspace(B, V, d, dev)
+        return st
+
+    @property
+    def table_grad(self):
+        return self._state(1)['tgrad']
+
+    def _col_scale(self, st):
+        cos = self._cosine()
+        if cos is None:
+            return None, 1.0
+        scale, eps_mode = cos
+        W = self._table()
+        if st['cs'] is None:
+            st['cs'] = torch.empty(W.shape[0], device=W.device, dtype=torch.float32)
+        if not st['cs_fresh']:
+            from ._lib import lib, ptr, stream
+            lib.srec_row_invnorm(ptr(W), W.stride(0), W.shape[0], W.shape[1], eps_mode, 1e-12, float(scale),
+                                 ptr(st['cs']), stream())
+        st['cs_fresh'] = False          # the optimizer sets it again after refreshing cs in its row pass
+        return st['cs'], 1.0 / float(scale)
+
+    def fused_loss(self, *inputs_and_labels, dynB=None):
+        *inputs, labels = inputs_and_labels
+        B = labels.numel()
+        st = self._state(B)
+        cs, inv_scale = self._col_scale(st)
+        sr = self.session_repr(*inputs, tgrad=st['tgrad'])
+        loss, _ = ops.score_ce(sr, self._table(), cs, labels.to(torch.int32), st['ws'][B], st['tgrad'], dynB, inv_scale)
+        return loss
+
+    def _log_probs(self, sr):
+        B = sr.shape[0]
+        st = self._state(B)
+        cs, inv_scale = self._col_scale(st)
+        return ops.score_logp(sr, self._table(), cs, st['ws'][B], inv_scale)
+
+
+class AttnReadout(nn.Module):
+    """srgnn.py:53-91 / niser.py:51-89 (batch_norm=None there).  fc_u/fc_v run as MFMA GEMMs over all
+    nodes of the batch; sigmoid / fc_e / per-session softmax / weighted sum is one wave per session."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, batch_norm=None, feat_drop=0.0, activation=None):
+        super().__init__()
+        assert not batch_norm and output_dim == input_dim and activation is None
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.fc_u = nn.Linear(input_dim, hidden_dim, bias=False)
+        self.fc_v = nn.Linear(input_dim, hidden_dim, bias=True)
+        self.fc_e = nn.Linear(hidden_dim, 1, bias=False)
+
+    def forward(self, mg, feat):
+        feat = self.feat_drop(feat)
+        U = ops.linear(feat, self.fc_u.weight)
+        Vq = ops.linear(ops.row_gather(feat, mg.last), self.fc_v.weight, self.fc_v.bias)
+        return ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg)
+
+
+class SRGNNLayer(nn.Module):
+    """Parameter container for srgnn.py:11-51 (kernel: ops.srgnn_layer, see gnn.py)."""
+
+    def __init__(self, input_dim, output_dim, feat_drop=0.0):
+        super().__init__()
+        self.dropout = nn.Dropout(feat_drop)
+        self.gru = nn.GRUCell(2 * input_dim, output_dim)
+        self.W1 = nn.Linear(input_dim, output_dim, bias=False)
+        self.W2 = nn.Linear(input_dim, output_dim, bias=False)
+
+    def forward(self, mg, feat):
+        from . import gnn
+        return gnn.srgnn_layer(self, mg, feat)
+
+
+class SRGNN(_ScoringMixin, nn.Module):
+    def __init__(self, num_items, embedding_dim, num_layers, feat_drop=0.0, use_gnn_output=False):
+        super().__init__()
+        self.embedding = nn.Embedding(num_items, embedding_dim)
+        self.register_buffer('indices', torch.arange(num_items, dtype=torch.long))
+        self.embedding_dim = embedding_dim
+        self.num_layers = num_layers
+        self.use_gnn_output = use_gnn_output
+        self.layers = nn.ModuleList([SRGNNLayer(embedding_dim, embedding_dim, feat_drop) for _ in range(num_layers)])
+        self.readout = AttnReadout(embedding_dim, embedding_dim, embedding_dim, feat_drop=feat_drop)
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.fc_sr = nn.Linear(2 * embedding_dim, embedding_dim, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.embedding_dim)
+        for w in self.parameters():
+            w.data.uniform_(-stdv, stdv)
+
+    def _pre(self, feat):
+        return feat
+
+    def _post(self, sr):
+        return sr
+
+    def session_repr(self, mg, sg=None, tgrad=None):
+        feat = ops.embedding_lookup(self.embedding.weight, mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos), tgrad)
+        feat = self._pre(self.feat_drop(feat))
+        if self.use_gnn_output:
+            for layer in self.layers:
+                feat = layer(mg, feat)
+        sr_g = self.readout(mg, feat)
+        sr_l = ops.row_gather(feat, mg.last)
+        return self._post(ops.linear_cat([sr_l, sr_g], self.fc_sr.weight))
+
+    def forward(self, mg, sg=None):
+        return self._log_probs(self.session_repr(mg))
+
+
+class NISER(SRGNN):
+    """niser.py:91-157: L2-normalised item / session vectors, logits scaled by `scale`."""
+
+    def __init__(self, num_items, embedding_dim, num_layers, feat_drop=0.0, norm=True, scale=12,
+                 use_gnn_output=False):
+        self.norm, self.scale = norm, scale
+        super().__init__(num_items, embedding_dim, num_layers, feat_drop, use_gnn_output)
+
+    def _cosine(self):
+        if self.norm:
+            return (self.scale if self.scale else 1.0, 1)
+        return None
+
+    def _col_scale(self, st):
+        if self.norm or not self.scale:
+            return super()._col_scale(st)
+        W = self._table()                 # un-normalised but scaled logits
+        if st['cs'] is None or st['cs'].numel() != W.shape[0]:
+            st['cs'] = torch.full((W.shape[0],), float(self.scale), device=W.device)
+        return st['cs'], 0.0
+
+    def _pre(self, feat):
+        # niser.py:135 and :142 normalise twice; the second one divides a unit vector by its norm
+        # (identity up to 1 ulp, and its Jacobian is the same projection): applied once here.
+        return ops.normalize(feat, 1) if self.norm else feat
+
+    def _post(self, sr):
+        return ops.normalize(sr, 1) if self.norm else sr

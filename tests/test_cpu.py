@@ -1,0 +1,246 @@
+"""CPU suite (`-m "not gpu"`): oracle vs the golden vectors generated from the reference, host
+logic (collate / dataset / train-loop plumbing) and the C-ABI surface (library loads and exports
+every symbol include/srec.h declares; no compute calls without a GPU)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, ROOT, close, load_golden, pkg
+
+from oracle import collate_ref as oc
+from oracle import models_ref as om
+
+ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz') and f != 'srgnn_evaluate.npz')
+
+
+def _oracle(name, V):
+    d = 32
+    if name.startswith('srgnn'):
+        return om.SRGNN(V, d, 1), oc.collate_fn_factory(oc.seq_to_session_graph)
+    if name.startswith('niser'):
+        return om.NISER(V, d, 1), oc.collate_fn_factory(oc.seq_to_session_graph)
+    if name.startswith('lessr'):
+        L = int(name.split('_')[1][1:])
+        fns = (oc.seq_to_eop_multigraph, oc.seq_to_shortcut_graph) if L > 1 else (oc.seq_to_eop_multigraph,)
+        return om.LESSR(V, d, L), oc.collate_fn_factory(*fns)
+    K = int(name.split('_')[1][1:])
+    return (om.MSGIFSR(V, 'sample', d, 1, order=K, extra=False, fusion='_fus' in name),
+            oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K))
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_oracle_reproduces_reference_fixture(name):
+    """The oracle, re-run from the fixture's inputs and seeded weights, reproduces what the
+    reference itself produced (log-probs, loss trace over 3 Adam steps, gradients)."""
+    train = pkg('train')
+    z, samples, init = load_golden(name)
+    V = [v for k, v in init.items() if k.startswith('embedding')][0].shape[0]
+    model, fn = _oracle(name, V)
+    model.load_state_dict(init, strict=True)
+    inputs, labels = fn(samples)
+    inputs = [om.to_torch(x) for x in inputs]
+    labels = torch.from_numpy(labels)
+    opt = torch.optim.Adam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4)
+    model.train()
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        lp = model(*inputs)
+        loss = torch.nn.functional.nll_loss(lp, labels)
+        loss.backward()
+        if step == 0:
+            ref = torch.from_numpy(z['logprobs'])
+            close(lp[:ref.shape[0]], ref, rtol=2e-5, atol=2e-6, what='logprobs')
+            params = dict(model.named_parameters())
+            for k in z.files:
+                if k.startswith('grad/'):
+                    close(params[k[5:]].grad, z[k], rtol=1e-4, atol=1e-7, what=k)
+                if k.startswith('nograd/'):
+                    assert params[k[7:]].grad is None
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, z['losses'], rtol=1e-6, atol=1e-6), (losses, z['losses'])
+
+
+def test_evaluate_tuple_order_and_values():
+    """train.evaluate returns (MRR@20, HR@20) like the reference's evaluate (train.py:36-55)."""
+    train = pkg('train')
+    z = np.load(os.path.join(GOLDEN, 'srgnn_evaluate.npz'))
+    init = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('init/')}
+    model = om.SRGNN(3429, 32, 1)
+    model.load_state_dict(init)
+    ds = pkg('dataset')
+    test = ds.read_sessions(os.path.join(ROOT, 'tests', 'golden', 'sample_test.txt'))
+    data = ds.AugmentedDataset(test)
+    fn = oc.collate_fn_factory(oc.seq_to_session_graph)
+
+    class Wrap:
+        def __init__(self, x):
+            self.x = x
+
+        def to(self, device):
+            return self.x
+    batches = []
+    for b in range(10):
+        inp, lab = fn([data[i] for i in range(b * 32, b * 32 + 32)])
+        batches.append(([Wrap(om.to_torch(x)) for x in inp], torch.from_numpy(lab)))
+    mrr, hit = train.evaluate(model, batches, torch.device('cpu'))
+    assert abs(mrr - float(z['mrr'])) < 1e-7 and abs(hit - float(z['hit'])) < 1e-9, (mrr, hit, z['mrr'], z['hit'])
+
+
+# ---------------------------------------------------------------------------------------- host logic
+def _rand_samples(rng, n, V=60, max_len=12):
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(1, max_len))
+        seq = rng.integers(0, V, size=L).tolist()
+        if rng.random() < 0.3 and L > 1:
+            seq[1] = seq[0]
+        out.append((seq, int(rng.integers(0, V))))
+    return out
+
+
+EDGE = [([7], 3), ([5, 5], 9), ([4, 9], 1), ([3, 1, 3, 6, 2, 5, 1, 2, 4, 1, 2], 8), ([2, 2, 2], 2),
+        ([250, 250, 250, 250, 3, 1, 2, 4, 1], 2), ([11, 12, 13], 14)]
+
+
+@pytest.mark.parametrize('kind', ['session', 'eop', 'shortcut'])
+def test_collate_homogeneous_matches_oracle(kind):
+    c = pkg('collate')
+    rng = np.random.default_rng(7)
+    samples = EDGE + _rand_samples(rng, 40)
+    pf = dict(session=c.seq_to_session_graph, eop=c.seq_to_eop_multigraph, shortcut=c.seq_to_shortcut_graph)[kind]
+    of = dict(session=oc.seq_to_session_graph, eop=oc.seq_to_eop_multigraph, shortcut=oc.seq_to_shortcut_graph)[kind]
+    (fb,), labels = c.collate_fn_factory(pf)(samples)
+    (ob,), olab = oc.collate_fn_factory(of)(samples)
+    assert np.array_equal(labels.numpy(), olab)
+    assert np.array_equal(fb.esrc.numpy(), ob['src']) and np.array_equal(fb.edst.numpy(), ob['dst'])
+    assert np.array_equal(np.diff(fb.seg.numpy()), ob['num_nodes'])
+    assert np.array_equal(np.diff(fb.eseg.numpy()), ob['num_edges'])
+    if kind != 'shortcut':
+        assert np.array_equal(fb.iid.numpy(), ob['iid']) and np.array_equal(fb.last.numpy(), ob['last'])
+        # item -> positions CSR really inverts the lookup
+        it, pt, ps = fb.uniq_items.numpy(), fb.uniq_ptr.numpy(), fb.uniq_pos.numpy()
+        assert np.all(np.diff(it) > 0)
+        for u in range(len(it)):
+            assert np.all(fb.iid.numpy()[ps[pt[u]:pt[u + 1]]] == it[u])
+        assert pt[-1] == len(fb.iid)
+    if kind == 'session':
+        assert np.array_equal(fb.ew.numpy(), ob['w'])
+    # in-edge CSR: grouped by destination, edge ids ascending inside a group (EOPA's time order)
+    ip, ii = fb.in_ptr.numpy(), fb.in_idx.numpy()
+    for v in range(len(ip) - 1):
+        e = ii[ip[v]:ip[v + 1]]
+        assert np.all(ob['dst'][e] == v) and np.all(np.diff(e) > 0)
+    op, oi = fb.out_ptr.numpy(), fb.out_idx.numpy()
+    for v in range(len(op) - 1):
+        e = oi[op[v]:op[v + 1]]
+        assert np.all(ob['src'][e] == v) and np.all(np.diff(e) > 0)
+
+
+@pytest.mark.parametrize('K', [1, 2, 3, 4])
+def test_collate_ccs_matches_oracle(K):
+    c = pkg('collate')
+    rng = np.random.default_rng(11)
+    samples = EDGE + _rand_samples(rng, 40)
+    (fb,), labels = c.collate_fn_factory_ccs((c.seq_to_ccs_graph,), K)(samples)
+    (ob,), olab = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K)(samples)
+    B = len(samples)
+    for k in range(1, K + 1):
+        assert np.array_equal(np.diff(fb.field('seg%d' % k).numpy()), ob['num_nodes'][k])
+        assert np.array_equal(fb.field('iid%d' % k).numpy().reshape(ob['iid'][k].shape), ob['iid'][k])
+        assert np.array_equal(fb.field('last%d' % k).numpy(), ob['last'][k])
+    for key, name in fb.meta['rels']:
+        r = ob['rel'][key]
+        assert np.array_equal(fb.field(name + '_src').numpy(), r['src']), key
+        assert np.array_equal(fb.field(name + '_dst').numpy(), r['dst']), key
+    # per-session concatenation permutation of the multi-order readout
+    perm, inv, cseg = fb.cat_perm.numpy(), fb.cat_inv.numpy(), fb.cat_seg.numpy()
+    assert np.array_equal(perm[inv], np.arange(len(perm)))
+    offs = np.concatenate([[0], np.cumsum([fb.count('N%d' % k) for k in range(1, K + 1)])])
+    for i in range(B):
+        want = np.concatenate([np.arange(int(fb.field("seg%d" % k)[i]), int(fb.field("seg%d" % k)[i + 1])) + offs[k - 1]
+                               for k in range(1, K + 1)])
+        assert np.array_equal(perm[cseg[i]:cseg[i + 1]], want)
+
+
+def test_reference_collate_smoke_answer():
+    """collate.py:258-266 (tuple argument fixed): batch_num_nodes('s2') == [9, 6]."""
+    c = pkg('collate')
+    seq = [3, 1, 3, 6, 2, 5, 1, 2, 4, 1, 2]
+    seq0 = [250, 250, 250, 250, 3, 1, 2, 4, 1]
+    (fb,), _ = c.collate_fn_factory_ccs((c.seq_to_ccs_graph,), 2)([[seq, 1], [seq0, 2]])
+    assert fb.batch_num_nodes(2).tolist() == [9, 6]
+
+
+def test_dataset_index_and_files(tmp_path):
+    ds = pkg('dataset')
+    sess = [[1, 2, 3], [4, 5], [6], [7, 8, 9, 10]]
+    idx = ds.create_index(sess)
+    assert idx.tolist() == [[0, 1], [0, 2], [1, 1], [3, 1], [3, 2], [3, 3]]
+    (tmp_path / 'train.txt').write_text('0,1,2\n3,4\n')
+    (tmp_path / 'test.txt').write_text('5,6,5\n')
+    (tmp_path / 'num_items.txt').write_text('7\n')
+    tr, te, n = ds.read_dataset(tmp_path)
+    assert n == 7 and list(tr[0]) == [0, 1, 2] and list(te[0]) == [5, 6, 5]
+    a = ds.AugmentedDataset(tr)
+    assert len(a) == 3 and a[1] == ([0, 1], 2)
+
+
+def test_fix_weight_decay_groups():
+    train = pkg('train')
+    m = om.LESSR(50, 8, 2)
+    decay, no_decay = train.fix_weight_decay(m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    nd = {names[id(p)] for p in no_decay['params']}
+    assert all(('bias' in n) or ('batch_norm' in n) or ('activation' in n) for n in nd)
+    assert 'indices' not in {names[id(p)] for p in decay['params']}     # frozen Parameter excluded
+    assert no_decay['weight_decay'] == 0
+
+
+def test_train_runner_cpu_plumbing():
+    """Config C1 plumbing: the runner drives a CPU model end to end (oracle SRGNN, batch 32) with the
+    reference's log strings, scheduler and (mrr, hit) contract."""
+    train = pkg('train')
+    rng = np.random.default_rng(0)
+    V = 80
+    samples = _rand_samples(rng, 96, V=V, max_len=8)
+    fn = oc.collate_fn_factory(oc.seq_to_session_graph)
+
+    class G:
+        def __init__(self, x):
+            self.x = om.to_torch(x)
+
+        def to(self, device):
+            return self.x
+    loader = []
+    for b in range(3):
+        inp, lab = fn(samples[b * 32:(b + 1) * 32])
+        loader.append(([G(x) for x in inp], torch.from_numpy(lab)))
+    torch.manual_seed(0)
+    model = om.SRGNN(V, 16, 1)
+    runner = train.TrainRunner('x', model, loader, loader, torch.device('cpu'), lr=1e-2, weight_decay=1e-4, patience=2)
+    mrr, hit = runner.train(2, log_interval=2)
+    assert 0 <= mrr <= hit <= 1
+    assert len(runner.loss_trace) == 6 and runner.loss_trace[-1] < runner.loss_trace[0]
+
+
+# ---------------------------------------------------------------------------------------- C ABI
+def test_c_abi_exports_every_declared_symbol():
+    L = pkg('_lib')
+    protos = L.parse_header()
+    assert len(protos) >= 15
+    dll = L.lib.load()
+    for name in protos:
+        assert hasattr(dll, name), name
+
+
+def test_product_ops_refuse_cpu_tensors():
+    ops = pkg('ops')
+    x = torch.randn(4, 8)
+    w = torch.randn(8, 8)
+    with pytest.raises(RuntimeError):
+        ops.linear(x, w)

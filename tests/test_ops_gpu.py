@@ -1,0 +1,237 @@
+"""GPU parity of every C-ABI kernel against a plain PyTorch fp32 restatement of the same op.
+Tolerances (fp32 HIP vs fp32 torch): forward 1e-4 abs/rel, gradients 1e-4 rel."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    return importlib.import_module('sessionrec-pytorch_amd.ops')
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, what=''):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    ref = b.abs().max().item() if b.numel() else 0.0
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), '%s: max abs err %.3e (ref max %.3e)' % (what, err, ref)
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 4, 4), (37, 64, 32), (130, 96, 100), (512, 256, 512), (1391, 2048, 256), (3000, 32, 96)])
+def test_gemm_nt_nn_tn(dev, M, N, K):
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = torch.randn(N, K, generator=g).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    gy = torch.randn(M, N, generator=g).to(dev)
+    y = torch.empty(M, N, device=dev)
+    ops.gemm_nt(x, w, y, b)
+    close(y, x @ w.t() + b, what='nt')
+    ops.gemm_nt(x, w, y, None, beta=1.0)
+    close(y, 2 * (x @ w.t()) + b, what='nt beta', atol=5e-5)
+    gx = torch.empty(M, K, device=dev)
+    ops.gemm_nn(gy, w, gx)
+    close(gx, gy @ w, what='nn', atol=5e-5)
+    gw = torch.empty(N, K, device=dev)
+    ops.gemm_tn(gy, x, gw)
+    close(gw, gy.t() @ x, what='tn', atol=2e-4)
+
+
+def test_gemm_dynamic_extent(dev):
+    ops = _ops()
+    M, N, K, live = 300, 64, 32, 170
+    x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    dyn = torch.tensor([live], dtype=torch.int32, device=dev)
+    y = torch.full((M, N), 7.0, device=dev)
+    ops.gemm_nt(x, w, y, None, dyn, 1)
+    close(y[:live], x[:live] @ w.t(), what='dyn rows')
+    assert (y[live:] == 0).all()
+    gy = torch.randn(M, N, device=dev)
+    gw = torch.empty(N, K, device=dev)
+    ops.gemm_tn(gy, x, gw, dyn)
+    close(gw, gy[:live].t() @ x[:live], what='dyn K', atol=1e-4)
+
+
+def test_linear_cat_autograd(dev):
+    ops = _ops()
+    torch.manual_seed(0)
+    a = torch.randn(50, 32, device=dev, requires_grad=True)
+    b = torch.randn(50, 64, device=dev, requires_grad=True)
+    w = torch.randn(48, 96, device=dev, requires_grad=True)
+    bias = torch.randn(48, device=dev, requires_grad=True)
+    y = ops.linear_cat([a, b], w, bias)
+    ref = torch.nn.functional.linear(torch.cat([a, b], 1), w, bias)
+    close(y, ref, what='fwd')
+    gy = torch.randn_like(ref)
+    g1 = torch.autograd.grad(y, [a, b, w, bias], gy)
+    g2 = torch.autograd.grad(ref, [a, b, w, bias], gy)
+    for u, v, n in zip(g1, g2, 'a b w bias'.split()):
+        close(u, v, what='grad ' + n, atol=1e-4)
+
+
+def _ce_ref(sr, E, cs, labels):
+    z = sr @ E.t()
+    if cs is not None:
+        z = z * cs.unsqueeze(0)
+    logp = torch.log_softmax(z, dim=1)
+    return torch.nn.functional.nll_loss(logp, labels), logp
+
+
+@pytest.mark.parametrize('B,V,d,cosine', [(32, 3429, 32, False), (32, 3429, 32, True), (100, 1000, 96, False),
+                                          (512, 5000, 256, True), (7, 70, 64, False), (64, 64, 100, True)])
+def test_score_ce_fwd_bwd(dev, B, V, d, cosine):
+    ops = _ops()
+    torch.manual_seed(B + V)
+    sr = (torch.randn(B, d, device=dev) * 0.3).requires_grad_()
+    E = (torch.randn(V, d, device=dev) * 0.3).requires_grad_()
+    labels = torch.randint(0, V, (B,), device=dev)
+    labels[0], labels[-1] = 0, V - 1
+    cs = None
+    if cosine:
+        cs = (12.0 / E.detach().norm(dim=1)).contiguous()
+    ws = ops.CEWorkspace(B, V, d, dev)
+    tg = ops.TableGrad(E.detach())
+    loss, lse = ops.score_ce(sr, E.detach(), cs, labels.int(), ws, tg, None, 1.0 / 12.0)
+    sr2, E2 = sr.detach().clone().requires_grad_(), E.detach().clone().requires_grad_()
+    if cosine:
+        z = 12.0 * (sr2 @ torch.nn.functional.normalize(E2, dim=1).t())
+        ref = torch.nn.functional.cross_entropy(z, labels)
+    else:
+        ref, _ = _ce_ref(sr2, E2, None, labels)
+    close(loss, ref, what='loss', rtol=1e-5, atol=1e-5)
+    loss.backward()
+    ref.backward()
+    close(sr.grad, sr2.grad, what='dsr', rtol=1e-4, atol=1e-6)
+    close(tg.buf, E2.grad, what='dE', rtol=1e-4, atol=1e-6)
+    # materialised log-probabilities (forward() contract)
+    logp = ops.score_logp(sr.detach(), E.detach(), cs, ws, 1.0 / 12.0)
+    _, lref = _ce_ref(sr.detach(), E.detach(), cs, labels)
+    close(logp, lref, what='logp', rtol=1e-4, atol=1e-4)
+
+
+def test_score_logp_autograd(dev):
+    ops = _ops()
+    torch.manual_seed(3)
+    B, V, d = 20, 333, 32
+    sr = (torch.randn(B, d, device=dev) * 0.3).requires_grad_()
+    E = (torch.randn(V, d, device=dev) * 0.3).requires_grad_()
+    labels = torch.randint(0, V, (B,), device=dev)
+    ws = ops.CEWorkspace(B, V, d, dev)
+    logp = ops.score_logp(sr, E, None, ws)
+    loss = torch.nn.functional.nll_loss(logp, labels)
+    loss.backward()
+    sr2, E2 = sr.detach().clone().requires_grad_(), E.detach().clone().requires_grad_()
+    ref, _ = _ce_ref(sr2, E2, None, labels)
+    ref.backward()
+    close(sr.grad, sr2.grad, what='dsr')
+    close(E.grad, E2.grad, what='dE')
+
+
+def test_score_ce_dynamic_batch(dev):
+    ops = _ops()
+    torch.manual_seed(5)
+    B, live, V, d = 128, 77, 900, 64
+    sr = torch.randn(B, d, device=dev) * 0.3
+    E = torch.randn(V, d, device=dev) * 0.3
+    labels = torch.randint(0, V, (B,), device=dev)
+    dyn = torch.tensor([live], dtype=torch.int32, device=dev)
+    ws = ops.CEWorkspace(B, V, d, dev)
+    tg = ops.TableGrad(E)
+    srg = sr.clone().requires_grad_()
+    loss, _ = ops.score_ce(srg, E, None, labels.int(), ws, tg, dyn)
+    loss.backward()
+    sr2, E2 = sr[:live].clone().requires_grad_(), E.clone().requires_grad_()
+    ref, _ = _ce_ref(sr2, E2, None, labels[:live])
+    ref.backward()
+    close(loss, ref, what='loss')
+    close(srg.grad[:live], sr2.grad, what='dsr')
+    assert (srg.grad[live:] == 0).all()
+    close(tg.buf, E2.grad, what='dE')
+
+
+def test_gather_scatter_normalize(dev):
+    ops = _ops()
+    torch.manual_seed(1)
+    V, d, n = 500, 64, 300
+    W = torch.randn(V, d, device=dev, requires_grad=True)
+    idx = torch.randint(0, 50, (n,), device=dev)
+    items, inv = torch.unique(idx, return_inverse=True)
+    pos = torch.argsort(idx, stable=True).int()
+    cnt = torch.bincount(inv)
+    ptr_ = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), cnt.cumsum(0)]).int()
+    out = ops.embedding_lookup(W, idx.int(), (items.int(), ptr_, pos), None)
+    close(out, W[idx], what='gather')
+    g = torch.randn(n, d, device=dev)
+    (gw,) = torch.autograd.grad(out, W, g)
+    ref = torch.zeros(V, d, device=dev).index_add_(0, idx, g)
+    close(gw, ref, what='scatter', atol=1e-5)
+    x = torch.randn(n, d, device=dev, requires_grad=True)
+    for mode in (0, 1):
+        y = ops.normalize(x, mode)
+        r = torch.nn.functional.normalize(x, dim=1)
+        close(y, r, what='normalize')
+        gy = torch.randn_like(r)
+        close(torch.autograd.grad(y, x, gy)[0], torch.autograd.grad(r, x, gy)[0], what='normalize bwd', atol=1e-5)
+    sel = torch.randperm(n, device=dev)[:40].int()
+    y = ops.row_gather(x, sel)
+    close(y, x[sel.long()], what='row_gather')
+    gy = torch.randn(40, d, device=dev)
+    close(torch.autograd.grad(y, x, gy)[0], torch.zeros_like(x).index_add_(0, sel.long(), gy), what='row_gather bwd')
+
+
+def test_seg_attn(dev):
+    ops = _ops()
+    torch.manual_seed(2)
+    lens = torch.tensor([1, 5, 3, 20, 2, 7, 1, 64, 9], device=dev)
+    B, N, h, D = len(lens), int(lens.sum()), 48, 96
+    seg = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), lens.cumsum(0)]).int()
+    sid = torch.repeat_interleave(torch.arange(B, device=dev), lens)
+    U = torch.randn(N, h, device=dev, requires_grad=True)
+    Vq = torch.randn(B, h, device=dev, requires_grad=True)
+    we = torch.randn(1, h, device=dev, requires_grad=True)
+    X = torch.randn(N, D, device=dev, requires_grad=True)
+    out = ops.seg_attn(U, Vq, we, X, seg)
+    e = (torch.sigmoid(U + Vq[sid]) * we).sum(1)
+    mx = torch.full((B,), -1e30, device=dev).index_reduce_(0, sid, e.detach(), 'amax')
+    ex = torch.exp(e - mx[sid])
+    alpha = ex / torch.zeros(B, device=dev).index_add_(0, sid, ex)[sid]
+    ref = torch.zeros(B, D, device=dev).index_add_(0, sid, X * alpha.unsqueeze(1))
+    close(out, ref, what='fwd')
+    g = torch.randn_like(ref)
+    g1 = torch.autograd.grad(out, [U, Vq, we, X], g)
+    g2 = torch.autograd.grad(ref, [U, Vq, we, X], g)
+    for a, b, n in zip(g1, g2, ['dU', 'dVq', 'dwe', 'dX']):
+        close(a, b, what=n, atol=2e-5)
+    H = torch.randn(N, D, device=dev, requires_grad=True)
+    o = ops.seg_mean_add(H, X, seg, B)
+    mean = torch.zeros(B, D, device=dev).index_add_(0, sid, X) / lens.unsqueeze(1)
+    r = H + mean[sid]
+    close(o, r, what='seg_mean_add')
+    g = torch.randn_like(r)
+    for a, b, n in zip(torch.autograd.grad(o, [H, X], g), torch.autograd.grad(r, [H, X], g), ['dH', 'dF']):
+        close(a, b, what=n, atol=1e-5)
+
+
+def test_fused_adam_matches_torch(dev):
+    optim = importlib.import_module('sessionrec-pytorch_amd.optim')
+    torch.manual_seed(4)
+    shapes = [(301, 64), (64,), (5, 3), (1, 48)]
+    p1 = [torch.randn(s, device=dev).requires_grad_() for s in shapes]
+    p2 = [p.detach().clone().requires_grad_() for p in p1]
+    groups = lambda ps: [{'params': ps[:2]}, {'params': ps[2:], 'weight_decay': 0}]
+    o1 = optim.FusedAdam(groups(p1), lr=1e-2, weight_decay=1e-2)
+    o2 = torch.optim.Adam(groups(p2), lr=1e-2, weight_decay=1e-2)
+    for step in range(4):
+        for a, b in zip(p1, p2):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        if step == 2:
+            p1[1].grad, p2[1].grad = None, None
+        o1.step()
+        o2.step()
+    for a, b in zip(p1, p2):
+        close(a, b, what='adam', rtol=1e-5, atol=1e-6)
