@@ -14,36 +14,60 @@ COLLATE_LIB = os.path.join(HERE, 'libsrec_collate.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 
-def _newer(srcs, target):
-    if not os.path.exists(target):
+def _digest(paths, extra=''):
+    """content hash (mtimes do not survive the gpurun snapshot, and a stale .so segfaults)."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, digest):
+    stamp = target + '.stamp'
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in srcs)
+    return open(stamp).read().strip() != digest
+
+
+def _mark(target, digest):
+    with open(target + '.stamp', 'w') as f:
+        f.write(digest)
 
 
 def build(force=False, verbose=True):
     hip_srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
-    deps = hip_srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
-    if force or _newer(deps, LIB):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    dig = _digest(hip_srcs + hdrs, ' '.join(flags))
+    if force or _stale(LIB, dig):
         objs = []
         for s in hip_srcs:
             o = s[:-4] + '.o'
-            if force or _newer([s] + [d for d in deps if d.endswith('.h')], o):
-                cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+            odig = _digest([s] + hdrs, ' '.join(flags))
+            if force or _stale(o, odig):
+                cmd = [HIPCC] + flags + ['-c', s, '-o', o]
                 if verbose:
                     print(' '.join(cmd), flush=True)
                 subprocess.check_call(cmd)
+                _mark(o, odig)
             objs.append(o)
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        _mark(LIB, dig)
     cpp = os.path.join(CSRC, 'collate.cpp')
-    if os.path.exists(cpp) and (force or _newer([cpp], COLLATE_LIB)):
-        cmd = ['g++', '-O3', '-std=c++17', '-fPIC', '-shared', cpp, '-o', COLLATE_LIB]
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    if os.path.exists(cpp):
+        cdig = _digest([cpp], 'g++ -O3')
+        if force or _stale(COLLATE_LIB, cdig):
+            cmd = ['g++', '-O3', '-std=c++17', '-fPIC', '-shared', cpp, '-o', COLLATE_LIB]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            _mark(COLLATE_LIB, cdig)
     return LIB
 
 
