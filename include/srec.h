@@ -89,6 +89,46 @@ int srec_seg_mean_add_fwd(const float* H, int ld_h, const float* F, int ld_f, co
 int srec_seg_mean_add_bwd(const float* dout, int ld_do, const int* seg, int B, const int* dynB, int D, float* dF,
                           int ld_df, void* stream);
 
+/* ---- MSGIFSR message passing (gat.hip): multi-head GAT over one relation, layout [N,H,D] ------------
+ * gatconv.py:267-311 via msgifsr.py:58-64,74-89.  el/er [N,H]; A, DP [E,H] indexed by edge id;
+ * in_ptr/in_idx = in-edge CSR of the destinations, out_ptr/out_idx = out-edge CSR of the sources. */
+int srec_head_dot(const float* X, int ld, const float* a, int n_cap, const int* dyn, int H, int D, float* out,
+                  void* stream);
+int srec_gat_agg_fwd(const float* Fs, int ld_s, const float* el, const float* er, const int* in_ptr,
+                     const int* in_idx, const int* esrc, int nd_cap, const int* dyn_nd, int H, int D, float slope,
+                     float* A, float* rst, int ld_r, void* stream);
+int srec_gat_bwd_dst(const float* dR, int ld_r, const float* Fs, int ld_s, const float* el, const float* er,
+                     const float* A, const int* in_ptr, const int* in_idx, const int* esrc, int nd_cap,
+                     const int* dyn_nd, int H, int D, float slope, float* DP, float* der, void* stream);
+int srec_gat_bwd_src(const float* dR, int ld_r, const float* A, const float* DP, const float* attn_l,
+                     const int* out_ptr, const int* out_idx, const int* edst, int ns_cap, const int* dyn_ns, int H,
+                     int D, float* dFs, int ld_s, float* del, void* stream);
+int srec_head_outer(const float* wgt, const float* a, int n_cap, const int* dyn, int H, int D, float* out, int ld,
+                    void* stream);
+int srec_head_wcolsum(const float* wgt, const float* X, int ld, int n_cap, const int* dyn, int H, int D, float* out,
+                      int accumulate, void* stream);
+/* h_v = max_head(sum_i R_i + bias + nres*x): msgifsr.py:78-85 (+ identity residual / bias of gatconv.py:306-311).
+ * rsts is a HOST array of n_rst (<= 8) device pointers. */
+int srec_head_combine_fwd(const float* const* rsts, int n_rst, int ld_r, const float* x, int ld_x, const float* bias,
+                          float nres, int n_cap, const int* dyn, int H, int D, float* out, int ld_o,
+                          unsigned char* arg, void* stream);
+int srec_head_combine_bwd(const float* dout, int ld_o, const unsigned char* arg, int n_cap, const int* dyn, int H,
+                          int D, float* dR, int ld_r, void* stream);
+
+/* ---- GRU gate math (gru.hip): msgifsr.py:25,42 (k-gram GRU), srgnn.py:15,45 (GRUCell) -----------------
+ * GI/GH = input/hidden projections [n,3d] (r,z,n); GH NULL => h_prev = 0 and gh = bhh. */
+int srec_gru_pointwise_fwd(const float* GI, int ld_gi, const float* GH, int ld_gh, const float* bhh, const float* Hp,
+                           int ld_hp, int n_cap, const int* dyn, int d, float* Hn, int ld_hn, float* gates,
+                           void* stream);
+int srec_gru_pointwise_bwd(const float* dHn, int ld_dh, const float* gates, const float* GH, int ld_gh,
+                           const float* bhh, const float* Hp, int ld_hp, int n_cap, const int* dyn, int d, float* dGI,
+                           int ld_dgi, float* dGH, int ld_dgh, float* dHp, int ld_dhp, void* stream);
+/* out = 0.5*mean_t X[n,t,:] + 0.5*Hl  (msgifsr.py:37,45), X contiguous [n,k,d] */
+int srec_gram_combine_fwd(const float* X, const float* Hl, int ld_h, int n_cap, const int* dyn, int k, int d,
+                          float* out, int ld_o, void* stream);
+int srec_gram_combine_bwd(const float* dout, int ld_o, int n_cap, const int* dyn, int k, int d, float* dX, float* dHl,
+                          int ld_h, void* stream);
+
 /* ---- optimizer (adam.hip): torch.optim.Adam + coupled L2, train.py:70-75,101 ------------------------
  * hyper (device) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2} */
 int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,

@@ -1,0 +1,265 @@
+"""MSGIFSR on the HIP path - host-side mirror of /root/reference/src/models/msgifsr.py:157-323
+(SemanticExpander :14-45, MSHGNN :47-91, AttnReadout :94-155) and gnn_models/gatconv.py:136-319.
+
+Same constructor signature and parameter names / shapes as the reference (state_dicts
+interchange), `forward(mg) -> (B, num_items)` log-probabilities, plus `fused_loss`.
+All arithmetic runs in hand-written gfx950 kernels (sessionrec-pytorch_amd.ops); the nn.*
+children only hold parameters.
+
+Documented deviations:
+  * GATConv is run with zero-in-degree destinations zero-filled (the shipped module would raise);
+  * one fc projection per (GAT module, node type) is shared by every relation that uses it as
+    source or destination - identical to the reference whenever feat_drop == 0; with dropout the
+    reference draws an independent mask per (relation, role), here one mask per (conv, type);
+  * `extra` (repeat/explore mix) and the 'max'/'concat' reducers are not on the HIP path yet.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .srgnn import _ScoringMixin
+
+
+class GATConv(nn.Module):
+    """Parameter container for gatconv.py:136-197 (in_feats int, residual=True -> Identity, bias)."""
+
+    def __init__(self, in_feats, out_feats, num_heads, feat_drop=0., attn_drop=0., negative_slope=0.2):
+        super().__init__()
+        assert in_feats == out_feats
+        self._num_heads, self._out_feats = num_heads, out_feats
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.bias = nn.Parameter(torch.empty(num_heads * out_feats))
+        self.negative_slope = negative_slope
+        self.feat_drop, self.attn_drop = feat_drop, attn_drop
+
+
+class HeteroConv(nn.Module):
+    """dglnn.HeteroGraphConv container: modules keyed by edge-type name."""
+
+    def __init__(self, mods):
+        super().__init__()
+        self.mods = nn.ModuleDict(mods)
+
+
+class SemanticExpander(nn.Module):
+    def __init__(self, input_dim, reducer, order):
+        super().__init__()
+        self.input_dim, self.order, self.reducer = input_dim, order, reducer
+        self.GRUs = nn.ModuleList([nn.GRU(input_dim, input_dim, 1, True, True) for _ in range(order)])
+        if reducer == 'concat':
+            self.Ws = nn.ModuleList([nn.Linear(input_dim * (i + 1), input_dim) for i in range(1, order)])
+
+    def forward(self, x, k, dyn=None):
+        """x: [N_k * k, d] gathered gram rows (contiguous) -> [N_k, d]"""
+        if self.reducer != 'mean':
+            raise NotImplementedError("reducer '%s' is not on the HIP path yet (only 'mean')" % self.reducer)
+        gru = self.GRUs[k - 2]
+        d = self.input_dim
+        n = x.shape[0] // k
+        GI = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0).view(n, k, 3 * d)
+        h = None
+        for t in range(k):
+            gi = GI[:, t, :]
+            if t == 0:
+                h = ops.gru_step(gi, None, gru.bias_hh_l0, None, dyn)
+            else:
+                gh = ops.linear(h, gru.weight_hh_l0, gru.bias_hh_l0, dyn)
+                h = ops.gru_step(gi, gh, None, h, dyn)
+        return ops.gram_combine(x.view(n, k, d), h, k, dyn)
+
+
+class MSHGNN(nn.Module):
+    def __init__(self, input_dim, output_dim, dropout=0.0, activation=None, order=1, reducer='mean'):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        self.output_dim, self.activation, self.order = output_dim, activation, order
+        mk = lambda: GATConv(input_dim, output_dim, 8, dropout, dropout)
+        m1 = {'intra%d' % (i + 1): mk() for i in range(order)}
+        m1['inter'] = mk()
+        self.conv1 = HeteroConv(m1)
+        m2 = {'intra%d' % (i + 1): mk() for i in range(order)}
+        m2['inter'] = mk()
+        self.conv2 = HeteroConv(m2)
+        self.lint = nn.Linear(output_dim, 1, bias=False)
+        self.linq = nn.Linear(output_dim, output_dim)
+        self.link = nn.Linear(output_dim, output_dim, bias=False)
+
+    def _graph(self, mg, name, reverse):
+        f = mg.field
+        if not reverse:
+            return (f(name + '_in_ptr'), f(name + '_in_idx'), f(name + '_out_ptr'), f(name + '_out_idx'),
+                    f(name + '_src'), f(name + '_dst'))
+        return (f(name + '_out_ptr'), f(name + '_out_idx'), f(name + '_in_ptr'), f(name + '_in_idx'),
+                f(name + '_dst'), f(name + '_src'))
+
+    def forward(self, mg, feat):
+        """feat: {k: [N_k, d]} -> {k: [N_k, d]}"""
+        H = 8
+        K = self.order
+        outs = {k: [] for k in range(1, K + 1)}
+        biases = {k: [] for k in range(1, K + 1)}
+        for conv, reverse in ((self.conv1, False), (self.conv2, True)):
+            proj = {}                                   # (module name, type) -> fc(dropout(feat))
+            dropped = {}
+
+            def fc(et, k):
+                key = (et, k)
+                if key not in proj:
+                    if k not in dropped:
+                        dropped[k] = F.dropout(feat[k], conv.mods[et].feat_drop, self.training)
+                    proj[key] = ops.linear(dropped[k], conv.mods[et].fc.weight)
+                return proj[key]
+            for (s, et, d_), name in mg.meta['rels']:
+                if mg.count('E_' + name) == 0:
+                    continue                            # HeteroGraphConv skips relations without edges
+                src_t, dst_t = (d_, s) if reverse else (s, d_)
+                mod = conv.mods[et]
+                rst = ops.gat_relation(fc(et, src_t), fc(et, dst_t), mod.attn_l, mod.attn_r,
+                                       self._graph(mg, name, reverse), H, None, None, mod.negative_slope)
+                if mod.attn_drop > 0 and self.training:
+                    raise NotImplementedError('attention dropout inside the fused GAT kernel')
+                outs[dst_t].append(rst)
+                biases[dst_t].append(mod.bias)
+        h = {}
+        for k in range(1, K + 1):
+            nres = len(outs[k])
+            if nres:
+                bias = biases[k][0] if nres == 1 else torch.stack(biases[k], 0).sum(0)
+            else:
+                bias = torch.zeros(H * self.output_dim, device=feat[k].device)
+            x = ops.head_combine(feat[k], bias, float(nres), H, outs[k])
+            h[k] = ops.seg_mean_add(x, feat[k], mg.field('seg%d' % k), mg.B)
+        return h
+
+
+class AttnReadout(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, feat_drop=0.0, activation=None, order=1,
+                 device=torch.device('cpu')):
+        super().__init__()
+        assert output_dim == input_dim and activation is None
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.order = order
+        self.fc_u = nn.ModuleList([nn.Linear(input_dim, hidden_dim, bias=True) for _ in range(order)])
+        self.fc_v = nn.ModuleList([nn.Linear(input_dim, hidden_dim, bias=False) for _ in range(order)])
+        self.fc_e = nn.ModuleList([nn.Linear(hidden_dim, 1, bias=False) for _ in range(order)])
+        self.fc_p = nn.ModuleList()
+
+    def forward(self, mg, allf, feat_vs, orders):
+        """allf: [NT, d] per-session concatenation of all orders' nodes; feat_vs[i]: [B, d]."""
+        out = {}
+        for i in orders:
+            U = ops.linear(allf, self.fc_u[i].weight, self.fc_u[i].bias)
+            Vq = ops.linear(feat_vs[i], self.fc_v[i].weight)
+            out[i] = ops.seg_attn(U, Vq, self.fc_e[i].weight, allf, mg.cat_seg)
+        return out
+
+
+class MSGIFSR(_ScoringMixin, nn.Module):
+    def __init__(self, num_items, datasets, embedding_dim, num_layers, dropout=0.0, reducer='mean', order=3,
+                 norm=True, extra=True, fusion=True, device=torch.device('cpu')):
+        super().__init__()
+        self.embeddings = nn.Embedding(num_items, embedding_dim, max_norm=1)
+        self.num_items = num_items
+        self.register_buffer('indices', torch.arange(num_items, dtype=torch.long))
+        self.embedding_dim, self.num_layers, self.reducer, self.order = embedding_dim, num_layers, reducer, order
+        self.alpha = nn.Parameter(torch.Tensor(order))
+        self.beta = nn.Parameter(torch.Tensor(1))
+        self.norm = norm
+        self.expander = SemanticExpander(embedding_dim, reducer, order)
+        self.device = device
+        self.layers = nn.ModuleList([
+            MSHGNN(embedding_dim, embedding_dim, dropout=dropout, order=order, activation=nn.PReLU(embedding_dim))
+            for _ in range(num_layers)])
+        self.readout = AttnReadout(embedding_dim, embedding_dim, embedding_dim, feat_drop=dropout, order=order)
+        self.feat_drop = nn.Dropout(dropout)
+        self.fc_sr = nn.ModuleList([nn.Linear(2 * embedding_dim, embedding_dim, bias=False) for _ in range(order)])
+        self.sc_sr = nn.ModuleList([
+            nn.Sequential(nn.Linear(embedding_dim, embedding_dim, bias=True), nn.ReLU(),
+                          nn.Linear(embedding_dim, 2, bias=False), nn.Softmax(dim=-1)) for _ in range(order)])
+        self.reset_parameters()
+        self.alpha.data = torch.zeros(order)
+        self.alpha.data[0] = torch.tensor(1.0)
+        self.beta.data = torch.tensor(1.0)
+        self.fusion, self.extra = fusion, extra
+        self._max_norm = 1.0
+
+    def reset_parameters(self):
+        stdv = 1 / math.sqrt(self.embedding_dim)
+        for w in self.parameters():
+            w.data.uniform_(-stdv, stdv)
+
+    # ---- scoring head hooks
+    def _table(self):
+        return self.embeddings.weight
+
+    def _cosine(self):
+        return (12.0, 0) if self.norm else None
+
+    def _col_scale(self, st):
+        if self.norm:
+            return super()._col_scale(st)
+        W = self._table()
+        if st['cs'] is None:
+            st['cs'] = torch.full((W.shape[0],), 12.0, device=W.device)
+        return st['cs'], 0.0
+
+    def zero_grad_params(self):
+        """Parameters the reference reaches only through `score[:, 0]` (order > 1, no fusion): autograd
+        gives them ZERO (not None) gradients there, so Adam still applies weight decay to them."""
+        if self.order > 1 and not self.fusion:
+            ps = []
+            for i in range(1, self.order):
+                ps += list(self.readout.fc_u[i].parameters()) + list(self.readout.fc_v[i].parameters())
+                ps += list(self.readout.fc_e[i].parameters()) + list(self.fc_sr[i].parameters())
+            return ps
+        return []
+
+    def _renorm(self, mg):
+        """Embedding(max_norm=1): rows are renormalised in place (no grad) before they are read."""
+        from ._lib import lib, ptr, stream
+        W = self._table()
+        with torch.no_grad():
+            lib.srec_renorm_rows(ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], 1.0, stream())
+
+    def session_repr(self, mg, tgrad=None):
+        K = self.order
+        if self.extra:
+            raise NotImplementedError('MSGIFSR(extra=True) is not on the HIP path yet; pass extra=False '
+                                      '(the reference scripts default to it: main_msgifsr.py:100-104)')
+        if self.fusion and K > 1:
+            raise NotImplementedError('MSGIFSR(fusion=True) is not on the HIP path yet; pass fusion=False')
+        self._renorm(mg)
+        W = self._table()
+        d = self.embedding_dim
+        rows = ops.embedding_lookup(W, mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos), tgrad)
+        rows = self.feat_drop(rows)
+        feats, off = {}, 0
+        for k in range(1, K + 1):
+            nk = mg.count('N%d' % k)
+            x = rows[off:off + nk * k]
+            off += nk * k
+            f = x if k == 1 else self.expander(x, k)
+            feats[k] = ops.normalize(f, 0) if self.norm else f
+        h = feats
+        for layer in self.layers:
+            h = layer(mg, h)
+        if self.norm:
+            h = {k: ops.normalize(v, 0) for k, v in h.items()}
+        stacked = h[1] if K == 1 else torch.cat([h[k] for k in range(1, K + 1)], 0)
+        allf = stacked if K == 1 else ops.row_gather(stacked, mg.cat_perm)
+        live = range(K) if (K == 1 or self.fusion) else (0,)
+        feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1))) for i in live}
+        sr_g = self.readout(mg, allf, feat_vs, live)
+        srs = []
+        for i in live:
+            s = ops.linear_cat([feat_vs[i], sr_g[i]], self.fc_sr[i].weight)
+            srs.append(ops.normalize(s, 0) if self.norm else s)
+        return srs[0]
+
+    def forward(self, mg):
+        return self._log_probs(self.session_repr(mg))

@@ -387,3 +387,176 @@ def _pad_rows(t, n):
 
 def score_logp(sr, table, cs, ws, cs_inv_scale=1.0):
     return ScoreLogProb.apply(sr, table, cs, ws, cs_inv_scale)
+
+
+# ------------------------------------------------------------------------------------------ GRU
+class GRUPointwise(torch.autograd.Function):
+    """One GRU time step given the two projections (GI, GH); GH=None <=> h_prev = 0 (gh = b_hh)."""
+
+    @staticmethod
+    def forward(ctx, GI, GH, bhh, Hp, dyn):
+        GI = _rows(GI)
+        n, d3 = GI.shape
+        d = d3 // 3
+        dev = GI.device
+        Hn = torch.empty(n, d, device=dev, dtype=torch.float32)
+        gates = torch.empty(n, d3, device=dev, dtype=torch.float32)
+        if GH is not None:
+            GH, Hp = _rows(GH), _rows(Hp)
+            lib.srec_gru_pointwise_fwd(ptr(GI), _ld(GI), ptr(GH), _ld(GH), None, ptr(Hp), _ld(Hp), n, ptr(dyn), d,
+                                       ptr(Hn), d, ptr(gates), stream())
+        else:
+            bhh = bhh.contiguous()
+            lib.srec_gru_pointwise_fwd(ptr(GI), _ld(GI), None, 0, ptr(bhh), None, 0, n, ptr(dyn), d, ptr(Hn), d,
+                                       ptr(gates), stream())
+        ctx.save_for_backward(gates, GH, bhh, Hp)
+        ctx.dyn = dyn
+        return Hn
+
+    @staticmethod
+    def backward(ctx, dHn):
+        gates, GH, bhh, Hp = ctx.saved_tensors
+        dHn = _rows(dHn)
+        n, d3 = gates.shape
+        d = d3 // 3
+        dev = gates.device
+        dGI = torch.empty(n, d3, device=dev, dtype=torch.float32)
+        dGH = torch.empty(n, d3, device=dev, dtype=torch.float32)
+        if GH is not None:
+            dHp = torch.empty(n, d, device=dev, dtype=torch.float32)
+            lib.srec_gru_pointwise_bwd(ptr(dHn), _ld(dHn), ptr(gates), ptr(GH), _ld(GH), None, ptr(Hp), _ld(Hp), n,
+                                       ptr(ctx.dyn), d, ptr(dGI), d3, ptr(dGH), d3, ptr(dHp), d, stream())
+            return dGI, dGH, None, dHp, None
+        lib.srec_gru_pointwise_bwd(ptr(dHn), _ld(dHn), ptr(gates), None, 0, ptr(bhh), None, 0, n, ptr(ctx.dyn), d,
+                                   ptr(dGI), d3, ptr(dGH), d3, None, 0, stream())
+        db = torch.empty(d3, device=dev, dtype=torch.float32)
+        lib.srec_col_sum(ptr(dGH), d3, n, ptr(ctx.dyn), d3, ptr(db), 0, stream())
+        return dGI, None, db, None, None
+
+
+def gru_step(GI, GH, bhh, Hp, dyn=None):
+    return GRUPointwise.apply(GI, GH, bhh, Hp, dyn)
+
+
+class GramCombine(torch.autograd.Function):
+    """0.5 * mean_t x[n,t,:] + 0.5 * h_last[n,:]"""
+
+    @staticmethod
+    def forward(ctx, X, Hl, k, dyn):
+        X = X.contiguous()
+        Hl = _rows(Hl)
+        n, d = Hl.shape
+        out = torch.empty(n, d, device=Hl.device, dtype=torch.float32)
+        lib.srec_gram_combine_fwd(ptr(X), ptr(Hl), _ld(Hl), n, ptr(dyn), k, d, ptr(out), d, stream())
+        ctx.k, ctx.dyn, ctx.xshape = k, dyn, tuple(X.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _rows(g)
+        n, d = g.shape
+        dX = torch.empty(ctx.xshape, device=g.device, dtype=torch.float32)
+        dH = torch.empty(n, d, device=g.device, dtype=torch.float32)
+        lib.srec_gram_combine_bwd(ptr(g), _ld(g), n, ptr(ctx.dyn), ctx.k, d, ptr(dX), ptr(dH), d, stream())
+        return dX, dH, None, None
+
+
+def gram_combine(X, Hl, k, dyn=None):
+    return GramCombine.apply(X, Hl, k, dyn)
+
+
+# ------------------------------------------------------------------------------------------ GAT
+class GATRelation(torch.autograd.Function):
+    """rst[v,h,:] = sum_{u->v} softmax_v(LeakyReLU(el_u + er_v)) * feat_src[u,h,:] for one relation.
+    graph = (in_ptr, in_idx, out_ptr, out_idx, esrc, edst); feats are [N, H*D]."""
+
+    @staticmethod
+    def forward(ctx, Fs, Fd, attn_l, attn_r, graph, H, dyn_ns, dyn_nd, slope):
+        Fs, Fd = _rows(Fs), _rows(Fd)
+        in_ptr, in_idx, out_ptr, out_idx, esrc, edst = graph
+        Ns, HD = Fs.shape
+        Nd = Fd.shape[0]
+        D = HD // H
+        E = esrc.numel()
+        dev = Fs.device
+        al, ar = attn_l.reshape(-1).contiguous(), attn_r.reshape(-1).contiguous()
+        el = torch.empty(Ns, H, device=dev, dtype=torch.float32)
+        er = torch.empty(Nd, H, device=dev, dtype=torch.float32)
+        lib.srec_head_dot(ptr(Fs), _ld(Fs), ptr(al), Ns, ptr(dyn_ns), H, D, ptr(el), stream())
+        lib.srec_head_dot(ptr(Fd), _ld(Fd), ptr(ar), Nd, ptr(dyn_nd), H, D, ptr(er), stream())
+        A = torch.zeros(max(E, 1), H, device=dev, dtype=torch.float32)
+        rst = torch.empty(Nd, HD, device=dev, dtype=torch.float32)
+        lib.srec_gat_agg_fwd(ptr(Fs), _ld(Fs), ptr(el), ptr(er), ptr(in_ptr), ptr(in_idx), ptr(esrc), Nd, ptr(dyn_nd),
+                             H, D, slope, ptr(A), ptr(rst), HD, stream())
+        ctx.save_for_backward(Fs, Fd, al, ar, el, er, A)
+        ctx.graph, ctx.H, ctx.dyn, ctx.slope = graph, H, (dyn_ns, dyn_nd), slope
+        ctx.shapes = (attn_l.shape, attn_r.shape)
+        return rst
+
+    @staticmethod
+    def backward(ctx, dR):
+        Fs, Fd, al, ar, el, er, A = ctx.saved_tensors
+        in_ptr, in_idx, out_ptr, out_idx, esrc, edst = ctx.graph
+        dyn_ns, dyn_nd = ctx.dyn
+        H = ctx.H
+        dR = _rows(dR)
+        Ns, HD = Fs.shape
+        Nd = Fd.shape[0]
+        D = HD // H
+        dev = Fs.device
+        DP = torch.zeros_like(A)
+        der = torch.empty(Nd, H, device=dev, dtype=torch.float32)
+        lib.srec_gat_bwd_dst(ptr(dR), _ld(dR), ptr(Fs), _ld(Fs), ptr(el), ptr(er), ptr(A), ptr(in_ptr), ptr(in_idx),
+                             ptr(esrc), Nd, ptr(dyn_nd), H, D, ctx.slope, ptr(DP), ptr(der), stream())
+        dFs = torch.empty(Ns, HD, device=dev, dtype=torch.float32)
+        del_ = torch.empty(Ns, H, device=dev, dtype=torch.float32)
+        lib.srec_gat_bwd_src(ptr(dR), _ld(dR), ptr(A), ptr(DP), ptr(al), ptr(out_ptr), ptr(out_idx), ptr(edst), Ns,
+                             ptr(dyn_ns), H, D, ptr(dFs), HD, ptr(del_), stream())
+        dFd = torch.empty(Nd, HD, device=dev, dtype=torch.float32)
+        lib.srec_head_outer(ptr(der), ptr(ar), Nd, ptr(dyn_nd), H, D, ptr(dFd), HD, stream())
+        dal = torch.empty(HD, device=dev, dtype=torch.float32)
+        dar = torch.empty(HD, device=dev, dtype=torch.float32)
+        lib.srec_head_wcolsum(ptr(del_), ptr(Fs), _ld(Fs), Ns, ptr(dyn_ns), H, D, ptr(dal), 0, stream())
+        lib.srec_head_wcolsum(ptr(der), ptr(Fd), _ld(Fd), Nd, ptr(dyn_nd), H, D, ptr(dar), 0, stream())
+        return dFs, dFd, dal.view(ctx.shapes[0]), dar.view(ctx.shapes[1]), None, None, None, None, None
+
+
+def gat_relation(Fs, Fd, attn_l, attn_r, graph, H, dyn_ns=None, dyn_nd=None, slope=0.2):
+    return GATRelation.apply(Fs, Fd, attn_l, attn_r, graph, H, dyn_ns, dyn_nd, slope)
+
+
+class HeadCombine(torch.autograd.Function):
+    """out[v,:] = max_head( sum_i R_i[v,h,:] + bias[h,:] + nres * x[v,:] )"""
+
+    @staticmethod
+    def forward(ctx, x, bias, nres, H, dyn, *rsts):
+        import ctypes
+        x = _rows(x)
+        N, D = x.shape
+        dev = x.device
+        rsts = [_rows(r) for r in rsts]
+        bias = bias.reshape(-1).contiguous()
+        out = torch.empty(N, D, device=dev, dtype=torch.float32)
+        arg = torch.empty(N, D, device=dev, dtype=torch.uint8)
+        arr = (ctypes.c_void_p * max(len(rsts), 1))(*[r.data_ptr() for r in rsts])
+        lib.srec_head_combine_fwd(ctypes.addressof(arr), len(rsts), H * D, ptr(x), _ld(x), ptr(bias), float(nres), N,
+                                  ptr(dyn), H, D, ptr(out), D, ptr(arg), stream())
+        ctx.save_for_backward(arg)
+        ctx.meta = (H, D, N, nres, dyn, len(rsts))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        H, D, N, nres, dyn, nr = ctx.meta
+        g = _rows(g)
+        dR = torch.empty(N, H * D, device=g.device, dtype=torch.float32)
+        lib.srec_head_combine_bwd(ptr(g), _ld(g), ptr(arg), N, ptr(dyn), H, D, ptr(dR), H * D, stream())
+        dbias = torch.empty(H * D, device=g.device, dtype=torch.float32)
+        lib.srec_col_sum(ptr(dR), H * D, N, ptr(dyn), H * D, ptr(dbias), 0, stream())
+        dx = g * nres if nres != 0 else None
+        return (dx, dbias, None, None, None) + tuple(dR for _ in range(nr))
+
+
+def head_combine(x, bias, nres, H, rsts, dyn=None):
+    return HeadCombine.apply(x, bias, nres, H, dyn, *rsts)

@@ -44,6 +44,9 @@ class FusedAdam(torch.optim.Optimizer):
             st = model.__dict__.get('_srec_state')
             if st is not None and st.get('tgrad') is not None and st['tgrad'].fresh:
                 tgrad = st['tgrad']
+        zero_ids = {}
+        if model is not None and hasattr(model, 'zero_grad_params'):
+            zero_ids = {id(p): p for p in model.zero_grad_params()}
         for group in self.param_groups:
             hyper_cache = {}
             use_wd = 1 if group['weight_decay'] != 0 else 0
@@ -52,6 +55,8 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad
                 if is_table and tgrad is not None:
                     g = tgrad.buf if g is None else g.add_(tgrad.buf)
+                if g is None and id(p) in zero_ids:
+                    g = torch.zeros_like(p)          # zero (not None) gradient in the reference: decay only
                 if g is None:
                     continue
                 state = self.state[p]

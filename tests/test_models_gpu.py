@@ -53,7 +53,16 @@ def adam_close(a, b, lr=1e-3, steps=3, what=''):
     assert err.max().item() <= 0.02 * lr * steps, '%s: max err %.3e' % (what, err.max().item())
 
 
-CASES = ['srgnn_s32', 'srgnn_edge', 'niser_s32', 'niser_edge']
+CASES = ['srgnn_s32', 'srgnn_edge', 'niser_s32', 'niser_edge',
+         'msgifsr_K1_s32', 'msgifsr_K1_edge', 'msgifsr_K2_s32', 'msgifsr_K2_edge', 'msgifsr_K3_s32', 'msgifsr_K3_edge']
+
+
+def grad_close(p, ref, what):
+    """a parameter the product never touches (dead branch) has grad None; the reference may hold exact zeros"""
+    if p.grad is None:
+        assert float(abs(ref).max()) == 0.0, what + ': grad is None but the reference gradient is non-zero'
+        return
+    close(p.grad, ref, rtol=1e-4, atol=1e-7, what=what)
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -79,7 +88,7 @@ def test_model_matches_reference_fixture(dev, name):
     params = dict(model.named_parameters())
     for k in z.files:
         if k.startswith('grad/'):
-            close(params[k[5:]].grad, z[k], rtol=1e-4, atol=1e-7, what='compat ' + k)
+            grad_close(params[k[5:]], z[k], 'compat ' + k)
         if k.startswith('nograd/'):
             assert params[k[7:]].grad is None, k
     # 3) fused training path: 3 steps of fused loss + FusedAdam vs the reference's Adam trajectory
@@ -92,12 +101,12 @@ def test_model_matches_reference_fixture(dev, name):
         loss.backward()
         if step == 0:
             tg = model.table_grad.buf
-            gk = [k for k in z.files if k.startswith('grad/embedding')][0]
-            if z[gk].shape == tuple(tg.shape):
-                close(tg, z[gk], rtol=1e-4, atol=1e-7, what='fused table grad')
+            gks = [k for k in z.files if k.startswith('grad/embedding')]      # big tensors only in "full" fixtures
+            if gks and z[gks[0]].shape == tuple(tg.shape):
+                close(tg, z[gks[0]], rtol=1e-4, atol=1e-7, what='fused table grad')
             for k in z.files:
                 if k.startswith('grad/') and not k.startswith('grad/embedding'):
-                    close(params[k[5:]].grad, z[k], rtol=1e-4, atol=1e-7, what='fused ' + k)
+                    grad_close(params[k[5:]], z[k], 'fused ' + k)
         opt.step()
         losses.append(loss.item())
     close(torch.tensor(losses), torch.from_numpy(z['losses']).float(), rtol=1e-5, atol=1e-5, what='loss trace')

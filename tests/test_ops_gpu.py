@@ -237,3 +237,79 @@ def test_fused_adam_matches_torch(dev):
         o2.step()
     for a, b in zip(p1, p2):
         close(a, b, what='adam', rtol=1e-5, atol=1e-6)
+
+
+def test_gru_step_and_gram_combine(dev):
+    ops = _ops()
+    torch.manual_seed(6)
+    n, d, k = 37, 32, 3
+    gru = torch.nn.GRU(d, d, 1, True, True).to(dev)
+    x = torch.randn(n * k, d, device=dev, requires_grad=True)
+    GI = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0).view(n, k, 3 * d)
+    h = None
+    for t in range(k):
+        if t == 0:
+            h = ops.gru_step(GI[:, t, :], None, gru.bias_hh_l0, None)
+        else:
+            h = ops.gru_step(GI[:, t, :], ops.linear(h, gru.weight_hh_l0, gru.bias_hh_l0), None, h)
+    out = ops.gram_combine(x.view(n, k, d), h, k)
+    x2 = x.detach().clone().requires_grad_()
+    ref = 0.5 * x2.view(n, k, d).mean(1) + 0.5 * gru(x2.view(n, k, d))[1].squeeze(0)
+    close(out, ref, what='expander fwd')
+    g = torch.randn_like(ref)
+    ps = list(gru.parameters())
+    g1 = torch.autograd.grad(out, [x] + ps, g)
+    g2 = torch.autograd.grad(ref, [x2] + ps, g)
+    for a, b, nm in zip(g1, g2, ['dx', 'w_ih', 'w_hh', 'b_ih', 'b_hh']):
+        close(a, b, what='expander ' + nm, atol=2e-5)
+
+
+def _csr(key, n):
+    idx = torch.argsort(key, stable=True).int()
+    ptr_ = torch.zeros(n + 1, dtype=torch.long, device=key.device)
+    ptr_[1:] = torch.bincount(key, minlength=n).cumsum(0)
+    return ptr_.int(), idx
+
+
+def test_gat_relation_and_head_combine(dev):
+    ops = _ops()
+    torch.manual_seed(8)
+    Ns, Nd, H, D, E = 23, 17, 8, 32, 60
+    src = torch.randint(0, Ns, (E,), device=dev)
+    dst = torch.randint(0, Nd - 3, (E,), device=dev)          # last 3 destinations have no in-edges
+    in_ptr, in_idx = _csr(dst, Nd)
+    out_ptr, out_idx = _csr(src, Ns)
+    graph = (in_ptr, in_idx, out_ptr, out_idx, src.int(), dst.int())
+    Fs = torch.randn(Ns, H * D, device=dev, requires_grad=True)
+    Fd = torch.randn(Nd, H * D, device=dev, requires_grad=True)
+    al = torch.randn(1, H, D, device=dev, requires_grad=True)
+    ar = torch.randn(1, H, D, device=dev, requires_grad=True)
+    rst = ops.gat_relation(Fs, Fd, al, ar, graph, H)
+
+    def ref_fn(Fs, Fd, al, ar):
+        fs, fd = Fs.view(Ns, H, D), Fd.view(Nd, H, D)
+        el, er = (fs * al).sum(-1), (fd * ar).sum(-1)
+        e = torch.nn.functional.leaky_relu(el[src] + er[dst], 0.2)
+        mx = torch.full((Nd, H), -1e30, device=dev).index_reduce_(0, dst, e.detach(), 'amax')
+        ex = torch.exp(e - mx[dst])
+        a = ex / torch.zeros(Nd, H, device=dev).index_add_(0, dst, ex)[dst]
+        return torch.zeros(Nd, H, D, device=dev).index_add_(0, dst, fs[src] * a.unsqueeze(-1)).view(Nd, H * D)
+    ref = ref_fn(Fs, Fd, al, ar)
+    close(rst, ref, what='gat fwd')
+    g = torch.randn_like(ref)
+    g1 = torch.autograd.grad(rst, [Fs, Fd, al, ar], g)
+    g2 = torch.autograd.grad(ref, [Fs, Fd, al, ar], g)
+    for a, b, nm in zip(g1, g2, ['dFs', 'dFd', 'dal', 'dar']):
+        close(a, b, what='gat ' + nm, atol=5e-5)
+    # head combine
+    x = torch.randn(Nd, D, device=dev, requires_grad=True)
+    bias = torch.randn(H * D, device=dev, requires_grad=True)
+    R1 = torch.randn(Nd, H * D, device=dev, requires_grad=True)
+    R2 = torch.randn(Nd, H * D, device=dev, requires_grad=True)
+    out = ops.head_combine(x, bias, 2.0, H, [R1, R2])
+    r = ((R1 + R2 + bias).view(Nd, H, D) + 2.0 * x.unsqueeze(1)).max(1)[0]
+    close(out, r, what='head combine')
+    g = torch.randn_like(r)
+    for a, b, nm in zip(torch.autograd.grad(out, [x, bias, R1, R2], g), torch.autograd.grad(r, [x, bias, R1, R2], g),
+                        ['dx', 'dbias', 'dR1', 'dR2']):
+        close(a, b, what='combine ' + nm, atol=1e-5)
