@@ -183,7 +183,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--model', default=os.environ.get('SREC_BENCH_MODEL', 'SRGNN'))
+    ap.add_argument('--model', default=os.environ.get('SREC_BENCH_MODEL', 'MSGIFSR'))
     ap.add_argument('--order', type=int, default=3)
     ap.add_argument('--dim', type=int, default=256)
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)

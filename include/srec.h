@@ -26,12 +26,12 @@ extern "C" {
 
 /* ---- dense linear algebra on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ----------------
  * C[m,n] = alpha * sum_k A(m,k) B(n,k) + beta*C[m,n] + bias[n];  A(m,k)=A[m*a_rs+k*a_cs], same for B.
- * dyn_mode: 0 none, 1 clamps M, 2 clamps K.
+ * dyn_mode: 0 none, 1 clamps M, 2 clamps K.  ws (nullable): ws_floats of scratch for split-K slabs.
  * Replaces nn.Linear fwd/bwd: srgnn.py:66-68,124  lessr.py:16-17,59-62,94-100,164  msgifsr.py:114-116,202
  * gatconv.py:157,282-283; GRU input/hidden projections srgnn.py:15, msgifsr.py:25. */
 int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_cs, float* C, int ldc,
                   const float* bias, int M, int N, int K, const int* dyn, int dyn_mode, float alpha, float beta,
-                  void* stream);
+                  float* ws, long ws_floats, void* stream);
 
 /* ---- fused full-catalog scoring + softmax-CE (score_ce.hip) -----------------------------------------
  * z[b,v] = cs[v] * <sr_b, E_v> (cs NULL -> 1).  Replaces sr @ E^T, log(softmax), nll_loss:
@@ -71,8 +71,10 @@ int srec_normalize_bwd(const float* Y, int ld_y, const float* dY, int ld_dy, con
 /* chain rule of the catalog-row normalisation on the dense dE: G_v -= e_v <e_v, G_v> */
 int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g, int n, int d,
                          void* stream);
-int srec_col_sum(const float* X, int ld, int n_cap, const int* dyn, int ncol, float* out, int accumulate,
-                 void* stream);
+/* out[c] (+)= sum_r w[r, c/D] * X[r,c] (wgt NULL -> plain column sums: bias / fc_e / attention-vector
+ * gradients).  Two deterministic stages; ws = 32*ncol floats of scratch. */
+int srec_col_sum(const float* X, int ld, const float* wgt, int H, int D, int n_cap, const int* dyn, int ncol,
+                 float* out, int accumulate, float* ws, void* stream);
 
 /* ---- per-session kernels (segops.hip): one wavefront per session ------------------------------------
  * attention readout core: srgnn.py:79-86 niser.py:77-84 lessr.py:106-113 msgifsr.py:139-146 */
@@ -105,8 +107,6 @@ int srec_gat_bwd_src(const float* dR, int ld_r, const float* A, const float* DP,
                      int D, float* dFs, int ld_s, float* del, void* stream);
 int srec_head_outer(const float* wgt, const float* a, int n_cap, const int* dyn, int H, int D, float* out, int ld,
                     void* stream);
-int srec_head_wcolsum(const float* wgt, const float* X, int ld, int n_cap, const int* dyn, int H, int D, float* out,
-                      int accumulate, void* stream);
 /* h_v = max_head(sum_i R_i + bias + nres*x): msgifsr.py:78-85 (+ identity residual / bias of gatconv.py:306-311).
  * rsts is a HOST array of n_rst (<= 8) device pointers. */
 int srec_head_combine_fwd(const float* const* rsts, int n_rst, int ld_r, const float* x, int ld_x, const float* bias,

@@ -128,6 +128,25 @@ def _uniq_csr(gidx):
     return items.astype(np.int32), ptr, pos
 
 
+CHUNK = 16
+
+
+def _chunk_csr(ptr):
+    """split every item's position list into pieces of <= CHUNK positions (popular items appear hundreds
+    of times per batch; one wavefront per piece keeps the segmented sum balanced)."""
+    cnt = np.diff(ptr)
+    nch = (cnt + CHUNK - 1) // CHUNK
+    cptr = np.zeros(len(cnt) + 1, dtype=np.int32)          # item -> chunk range
+    np.cumsum(nch, out=cptr[1:])
+    C = int(cptr[-1])
+    owner = np.repeat(np.arange(len(cnt)), nch)
+    k = np.arange(C) - cptr[:-1][owner]
+    beg = ptr[:-1][owner] + k * CHUNK
+    end = np.minimum(beg + CHUNK, ptr[1:][owner])
+    chunk_ptr = np.concatenate([beg, end[-1:]]).astype(np.int32) if C else np.zeros(1, np.int32)
+    return cptr, chunk_ptr
+
+
 def _cat(lst, dtype=np.int64):
     lst = [np.asarray(a, dtype=dtype).reshape(-1) for a in lst]
     return np.concatenate(lst) if lst else np.zeros(0, dtype)
@@ -156,8 +175,10 @@ def batch_homogeneous(graphs, caps=None):
         fields['iid'] = iid
         fields['last'] = np.array([g[2] + seg[i] for i, g in enumerate(graphs)], dtype=np.int64)
         ui, up, upos = _uniq_csr(iid)
-        fields.update(uniq_items=ui, uniq_ptr=up, uniq_pos=upos)
+        cptr, chptr = _chunk_csr(up)
+        fields.update(uniq_items=ui, uniq_ptr=up, uniq_pos=upos, uniq_cptr=cptr, chunk_ptr=chptr)
         counts['U'] = len(ui)
+        counts['C'] = len(chptr) - 1
     if kind == 'session':
         fields['ew'] = _cat([g[5] for g in graphs])
     meta = dict(kind=kind, B=B, max_nodes=int(nn.max()) if B else 0)
@@ -182,9 +203,11 @@ def batch_ccs(graphs, caps=None):
     # one fused embedding lookup for all orders: rows = [iid1 | iid2.flat | iid3.flat ...]
     gidx = _cat([fields['iid%d' % k] for k in range(1, K + 1)])
     ui, up, upos = _uniq_csr(gidx)
-    fields.update(gidx=gidx, uniq_items=ui, uniq_ptr=up, uniq_pos=upos)
+    cptr, chptr = _chunk_csr(up)
+    fields.update(gidx=gidx, uniq_items=ui, uniq_ptr=up, uniq_pos=upos, uniq_cptr=cptr, chunk_ptr=chptr)
     counts['G'] = len(gidx)
     counts['U'] = len(ui)
+    counts['C'] = len(chptr) - 1
     rel_names = []
     for key in sorted(graphs[0][5].keys()):
         s, et, d = key

@@ -184,25 +184,6 @@ __global__ void head_outer_kernel(const float* __restrict__ wgt, const float* __
     }
 }
 
-// out[h*D + c] (+)= sum_{n<N} w[n,h] * X[n,h,c]     block = 64 columns x 4 row groups
-__global__ void head_wcolsum_kernel(const float* __restrict__ wgt, const float* __restrict__ X, int ld, int n_cap,
-                                    const int* __restrict__ dyn, int H, int D, float* __restrict__ out,
-                                    int accumulate) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    const int n = dyn_count(dyn, n_cap);
-    const int h = col / D;
-    float s = 0.f;
-    if (col < H * D)
-        for (int r = rg; r < n; r += 4) s += wgt[(size_t)r * H + h] * X[(size_t)r * ld + col];
-    red[rg][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rg == 0 && col < H * D) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        out[col] = accumulate ? out[col] + t : t;
-    }
-}
-
 struct RstList {
     const float* p[8];
     int n;
@@ -313,15 +294,6 @@ extern "C" int srec_head_outer(const float* wgt, const float* a, int n_cap, cons
     if (bad(H, D, ld)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(head_outer_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, wgt, a, n_cap, dyn, H,
                        D, out, ld);
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int srec_head_wcolsum(const float* wgt, const float* X, int ld, int n_cap, const int* dyn, int H, int D,
-                                 float* out, int accumulate, void* stream) {
-    if (bad(H, D, ld)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(head_wcolsum_kernel, dim3(cdiv(H * D, 64)), dim3(256), 0, (hipStream_t)stream, wgt, X, ld, n_cap,
-                       dyn, H, D, out, accumulate);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,8 @@
 // overlaps the MFMAs of the current one (double-buffered LDS, one barrier/tile).
 // A "dynamic extent" (node count living in device memory, so a captured hipGraph
 // can be replayed for batches of different size) may clamp M or K.
+// Skinny products (weight gradients: K = #nodes) are split along K into scratch slabs + a
+// deterministic reduce so that >= 2 workgroups per CU are in flight.
 #include "common.h"
 
 namespace {
@@ -27,7 +29,7 @@ template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
     float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
-    const int* __restrict__ dyn, int dyn_mode, float alpha, float beta) {
+    const int* __restrict__ dyn, int dyn_mode, float alpha, float beta, float* __restrict__ part) {
     constexpr int SA = BM + 4, SB = BN + 4;
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave
     constexpr int LA = BM * BK / 4 / 256, LB = BN * BK / 4 / 256;   // float4 loads per thread
@@ -40,6 +42,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // split-K: blockIdx.z owns the k-range [kbeg, kend); raw partial sums go to part[z][Mfull][N]
+    const int nsplit = gridDim.z;
+    int kbeg = 0, kend = K;
+    if (nsplit > 1) {
+        const int kper = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+        kbeg = blockIdx.z * kper;
+        kend = min(K, kbeg + kper);
+        C = part + (size_t)blockIdx.z * Mfull * N;
+        ldc = N; bias = nullptr; alpha = 1.f; beta = 0.f;
+    }
 
     if (m0 >= M) {                                    // tile fully in the padded (dynamic) region
         if (beta == 0.f) {
@@ -121,16 +134,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         }
     };
 
-    const int nk = (K + BK - 1) / BK;
+    K = kend;                                          // loads are bounded by this split's k-range
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
     if (nk > 0) {
-        gload(0);
+        gload(kbeg);
         lstore(0);
     }
     __syncthreads();
     const int half = lane >> 5, l31 = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], b[TN];
@@ -172,20 +186,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         }
 }
 
+// C = alpha * sum_z part[z] + bias + beta * C   (rows >= live M are zeroed when beta == 0)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ C, int ldc,
+                                     const float* __restrict__ bias, int M, int N, const int* __restrict__ dyn,
+                                     int dyn_mode, float alpha, float beta) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (size_t)M * N) return;
+    const int row = (int)(i / N), col = (int)(i % N);
+    const int Ml = dyn_mode == 1 ? dyn_count(dyn, M) : M;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nsplit; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * M * N + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* c = C + (size_t)row * ldc + col;
+    if (row >= Ml) {
+        if (beta == 0.f) { c[0] = 0.f; c[1] = 0.f; c[2] = 0.f; c[3] = 0.f; }
+        return;
+    }
+    float o[4] = {alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (bias != nullptr) o[j] += bias[col + j];
+        if (beta != 0.f) o[j] += beta * c[j];
+        c[j] = o[j];
+    }
+}
+
 template <int BM, int BN>
 int launch(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_cs, float* C, int ldc,
            const float* bias, int M, int N, int K, const int* dyn, int dyn_mode, float alpha, float beta,
-           hipStream_t st) {
-    dim3 grid(cdiv(N, BN), cdiv(M, BM));
+           float* ws, int nsplit, hipStream_t st) {
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), nsplit);
     const bool akc = (a_cs == 1), bkc = (b_cs == 1);
 #define SREC_GEMM_GO(AK, BK_)                                                                             \
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_>), grid, dim3(256), 0, st, A, a_rs, a_cs, B, b_rs, \
-                       b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta)
+                       b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, ws)
     if (akc && bkc) SREC_GEMM_GO(true, true);
     else if (akc && !bkc) SREC_GEMM_GO(true, false);
     else if (!akc && bkc) SREC_GEMM_GO(false, true);
     else SREC_GEMM_GO(false, false);
 #undef SREC_GEMM_GO
+    if (nsplit > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N / 4 + 255) / 256)), dim3(256), 0, st, ws,
+                           nsplit, C, ldc, bias, M, N, dyn, dyn_mode, alpha, beta);
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -194,7 +238,7 @@ int launch(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_c
 
 extern "C" int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_cs, float* C,
                              int ldc, const float* bias, int M, int N, int K, const int* dyn, int dyn_mode,
-                             float alpha, float beta, void* stream) {
+                             float alpha, float beta, float* ws, long ws_floats, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if ((a_rs != 1 && a_cs != 1) || (b_rs != 1 && b_cs != 1)) return SREC_BAD_ARG;
     // float4 paths: the non-unit stride and the contiguous extent must be multiples of 4 floats
@@ -207,6 +251,19 @@ extern "C" int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B,
     // small problems: 64x64 tiles keep more CUs busy; large: 128x128 for operand reuse
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
     if (tiles128 >= 192)
-        return launch<128, 128>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, st);
-    return launch<64, 64>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, st);
+        return launch<128, 128>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta,
+                                nullptr, 1, st);
+    // skinny problems (few output tiles, long K - every weight-gradient GEMM): split K across
+    // workgroups so all 256 CUs work; partial slabs in ws, reduced deterministically.
+    const long tiles64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    int nsplit = 1;
+    if (ws != nullptr && tiles64 < 256 && K >= 256 && (N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0) {
+        nsplit = (int)(512 / tiles64);
+        if (nsplit > K / 64) nsplit = K / 64;
+        if (nsplit > 32) nsplit = 32;
+        while (nsplit > 1 && (long)nsplit * M * N > ws_floats) --nsplit;
+        if (nsplit < 1) nsplit = 1;
+    }
+    return launch<64, 64>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, ws, nsplit,
+                          st);
 }

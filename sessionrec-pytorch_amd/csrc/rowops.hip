@@ -162,21 +162,38 @@ __global__ void rownorm_project_kernel(const float* __restrict__ W, int ld_w, co
     }
 }
 
-// out[c] (+)= sum_{r<n} X[r,c]; block = 64 columns x 4 row groups
-__global__ void col_sum_kernel(const float* __restrict__ X, int ld, int n_cap, const int* __restrict__ dyn, int ncol,
-                               float* __restrict__ out, int accumulate) {
+// Column sums, two deterministic stages: grid (column blocks x NCHUNK row chunks) writes partial sums,
+// a second tiny kernel adds the NCHUNK partials.  (w != NULL: per-(row, head) weights, head = col / D.)
+constexpr int NCHUNK = 32;
+
+__global__ void col_sum_part_kernel(const float* __restrict__ X, int ld, const float* __restrict__ wgt, int H, int D,
+                                    int n_cap, const int* __restrict__ dyn, int ncol, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     const int n = dyn_count(dyn, n_cap);
+    const int per = (n + NCHUNK - 1) / NCHUNK;
+    const int r0 = blockIdx.y * per, r1 = min(n, r0 + per);
     float s = 0.f;
-    if (c < ncol)
-        for (int r = rg; r < n; r += 4) s += X[(size_t)r * ld + c];
+    if (c < ncol) {
+        if (wgt != nullptr) {
+            const int h = c / D;
+            for (int r = r0 + rg; r < r1; r += 4) s += wgt[(size_t)r * H + h] * X[(size_t)r * ld + c];
+        } else {
+            for (int r = r0 + rg; r < r1; r += 4) s += X[(size_t)r * ld + c];
+        }
+    }
     red[rg][threadIdx.x & 63] = s;
     __syncthreads();
-    if (rg == 0 && c < ncol) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        out[c] = accumulate ? out[c] + t : t;
-    }
+    if (rg == 0 && c < ncol)
+        part[(size_t)blockIdx.y * ncol + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void col_sum_final_kernel(const float* __restrict__ part, int ncol, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    float s = 0.f;
+    for (int k = 0; k < NCHUNK; ++k) s += part[(size_t)k * ncol + c];
+    out[c] = accumulate ? out[c] + s : s;
 }
 
 inline bool bad_row_args(int d, int ld) { return d <= 0 || (d & 3) || (ld & 3); }
@@ -254,11 +271,15 @@ extern "C" int srec_rownorm_project(const float* W, int ld_w, const float* cs, f
     return 0;
 }
 
-extern "C" int srec_col_sum(const float* X, int ld, int n_cap, const int* dyn, int ncol, float* out, int accumulate,
-                            void* stream) {
+// ws: NCHUNK(32) * ncol floats of scratch.  wgt (nullable) [n, H] weights per (row, head), head = col / D.
+extern "C" int srec_col_sum(const float* X, int ld, const float* wgt, int H, int D, int n_cap, const int* dyn, int ncol,
+                            float* out, int accumulate, float* ws, void* stream) {
     if (ncol <= 0) return 0;
-    hipLaunchKernelGGL(col_sum_kernel, dim3(cdiv(ncol, 64)), dim3(256), 0, (hipStream_t)stream, X, ld, n_cap, dyn, ncol,
-                       out, accumulate);
+    if (ws == nullptr) return SREC_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(col_sum_part_kernel, dim3(cdiv(ncol, 64), NCHUNK), dim3(256), 0, st, X, ld, wgt, H, D, n_cap, dyn,
+                       ncol, ws);
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ws, ncol, out, accumulate);
     SREC_LAUNCH_CHECK();
     return 0;
 }

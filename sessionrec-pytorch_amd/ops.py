@@ -20,6 +20,33 @@ def _rows(t):
     return t
 
 
+_WS = {}
+
+
+def _ws(n, device):
+    """grow-only fp32 scratch per device (column-sum partials, split-K slabs)"""
+    t = _WS.get(str(device))
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1 << 22), device=device, dtype=torch.float32)
+        _WS[str(device)] = t
+    return t
+
+
+_GEMM_WS = {}
+
+
+def _gemm_ws(device):
+    t = _GEMM_WS.get(str(device))
+    if t is None:
+        t = _GEMM_WS[str(device)] = torch.empty(1 << 24, device=device, dtype=torch.float32)   # 64 MiB of split-K slabs
+    return t.data_ptr(), t.numel()
+
+
+def col_sum(X, n, ncol, out, dyn=None, wgt=None, H=1, D=1, accumulate=0):
+    ws = _ws(32 * ncol, X.device)
+    lib.srec_col_sum(ptr(X), _ld(X), ptr(wgt), H, D, n, ptr(dyn), ncol, ptr(out), accumulate, ptr(ws), stream())
+
+
 def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
@@ -29,7 +56,7 @@ def gemm_nt(x, w, out, bias=None, dyn=None, dyn_mode=0, beta=0.0):
     M, K = x.shape
     N = w.shape[0]
     lib.srec_gemm_f32(ptr(x), _ld(x), 1, ptr(w), _ld(w), 1, ptr(out), _ld(out), ptr(bias), M, N, K, ptr(dyn), dyn_mode,
-                      1.0, beta, stream())
+                      1.0, beta, *_gemm_ws(x.device), stream())
 
 
 def gemm_nn(g, w, out, dyn=None, dyn_mode=0, beta=0.0):
@@ -37,7 +64,7 @@ def gemm_nn(g, w, out, dyn=None, dyn_mode=0, beta=0.0):
     M, N = g.shape
     K = w.shape[1]
     lib.srec_gemm_f32(ptr(g), _ld(g), 1, ptr(w), 1, _ld(w), ptr(out), _ld(out), None, M, K, N, ptr(dyn), dyn_mode, 1.0,
-                      beta, stream())
+                      beta, *_gemm_ws(g.device), stream())
 
 
 def gemm_tn(g, x, out, dyn=None, beta=0.0):
@@ -45,7 +72,7 @@ def gemm_tn(g, x, out, dyn=None, beta=0.0):
     M, N = g.shape
     K = x.shape[1]
     lib.srec_gemm_f32(ptr(g), 1, _ld(g), ptr(x), 1, _ld(x), ptr(out), _ld(out), None, N, K, M, ptr(dyn),
-                      2 if dyn is not None else 0, 1.0, beta, stream())
+                      2 if dyn is not None else 0, 1.0, beta, *_gemm_ws(g.device), stream())
 
 
 class LinearCat(torch.autograd.Function):
@@ -93,7 +120,7 @@ class LinearCat(torch.autograd.Function):
             off += k
         if ctx.has_bias and ctx.needs_input_grad[1]:
             gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32)
-            lib.srec_col_sum(ptr(gy), _ld(gy), gy.shape[0], ptr(dyn), w.shape[0], ptr(gb), 0, stream())
+            col_sum(gy, gy.shape[0], w.shape[0], gb, dyn)
         return (gw, gb, None) + tuple(gxs)
 
 
@@ -129,7 +156,7 @@ class EmbeddingLookup(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        items, uptr, upos = ctx.uniq
+        items, uptr, upos = ctx.uniq[:3]
         tg = ctx.tgrad
         g = _rows(g)
         V, d = ctx.shape
@@ -138,8 +165,19 @@ class EmbeddingLookup(torch.autograd.Function):
         else:
             dst = torch.zeros(V, d, device=g.device, dtype=torch.float32)
             acc, ret = 0, dst
-        lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(items), ptr(uptr), ptr(upos), ptr(dst), dst.stride(0),
-                                    items.numel(), ptr(ctx.dyn_u), d, acc, stream())
+        if len(ctx.uniq) == 5:
+            # two balanced levels: <=16 positions per wavefront, then the pieces of each item
+            cptr, chunk_ptr = ctx.uniq[3], ctx.uniq[4]
+            C = chunk_ptr.numel() - 1
+            part = torch.empty(max(C, 1), d, device=g.device, dtype=torch.float32)
+            ar = _arange(C + 1, g.device)
+            lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, d,
+                                        0, stream())
+            lib.srec_scatter_add_sorted(ptr(part), d, ptr(items), ptr(cptr), ptr(ar), ptr(dst), dst.stride(0),
+                                        items.numel(), ptr(ctx.dyn_u), d, acc, stream())
+        else:
+            lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(items), ptr(uptr), ptr(upos), ptr(dst), dst.stride(0),
+                                        items.numel(), ptr(ctx.dyn_u), d, acc, stream())
         return ret, None, None, None, None, None
 
 
@@ -245,7 +283,7 @@ class SegAttn(torch.autograd.Function):
                               ptr(we), ptr(seg), B, ptr(ctx.dynB), h, D, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp),
                               h, stream())
         dwe = torch.empty(h, device=X.device, dtype=torch.float32)
-        lib.srec_col_sum(ptr(dwp), h, B, ptr(ctx.dynB), h, ptr(dwe), 0, stream())
+        col_sum(dwp, B, h, dwe, ctx.dynB)
         return dU, dVq, dwe.view(1, h), dX, None, None
 
 
@@ -430,7 +468,7 @@ class GRUPointwise(torch.autograd.Function):
         lib.srec_gru_pointwise_bwd(ptr(dHn), _ld(dHn), ptr(gates), None, 0, ptr(bhh), None, 0, n, ptr(ctx.dyn), d,
                                    ptr(dGI), d3, ptr(dGH), d3, None, 0, stream())
         db = torch.empty(d3, device=dev, dtype=torch.float32)
-        lib.srec_col_sum(ptr(dGH), d3, n, ptr(ctx.dyn), d3, ptr(db), 0, stream())
+        col_sum(dGH, n, d3, db, ctx.dyn)
         return dGI, None, db, None, None
 
 
@@ -516,8 +554,8 @@ class GATRelation(torch.autograd.Function):
         lib.srec_head_outer(ptr(der), ptr(ar), Nd, ptr(dyn_nd), H, D, ptr(dFd), HD, stream())
         dal = torch.empty(HD, device=dev, dtype=torch.float32)
         dar = torch.empty(HD, device=dev, dtype=torch.float32)
-        lib.srec_head_wcolsum(ptr(del_), ptr(Fs), _ld(Fs), Ns, ptr(dyn_ns), H, D, ptr(dal), 0, stream())
-        lib.srec_head_wcolsum(ptr(der), ptr(Fd), _ld(Fd), Nd, ptr(dyn_nd), H, D, ptr(dar), 0, stream())
+        col_sum(Fs, Ns, HD, dal, dyn_ns, del_, H, D)
+        col_sum(Fd, Nd, HD, dar, dyn_nd, der, H, D)
         return dFs, dFd, dal.view(ctx.shapes[0]), dar.view(ctx.shapes[1]), None, None, None, None, None
 
 
@@ -553,7 +591,7 @@ class HeadCombine(torch.autograd.Function):
         dR = torch.empty(N, H * D, device=g.device, dtype=torch.float32)
         lib.srec_head_combine_bwd(ptr(g), _ld(g), ptr(arg), N, ptr(dyn), H, D, ptr(dR), H * D, stream())
         dbias = torch.empty(H * D, device=g.device, dtype=torch.float32)
-        lib.srec_col_sum(ptr(dR), H * D, N, ptr(dyn), H * D, ptr(dbias), 0, stream())
+        col_sum(dR, N, H * D, dbias, dyn)
         dx = g * nres if nres != 0 else None
         return (dx, dbias, None, None, None) + tuple(dR for _ in range(nr))
 

@@ -141,7 +141,7 @@ class SRGNN(_ScoringMixin, nn.Module):
         return sr
 
     def session_repr(self, mg, sg=None, tgrad=None):
-        feat = ops.embedding_lookup(self.embedding.weight, mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos), tgrad)
+        feat = ops.embedding_lookup(self.embedding.weight, mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
         feat = self._pre(self.feat_drop(feat))
         if self.use_gnn_output:
             for layer in self.layers:
