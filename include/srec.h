@@ -129,8 +129,50 @@ int srec_gram_combine_fwd(const float* X, const float* Hl, int ld_h, int n_cap, 
 int srec_gram_combine_bwd(const float* dout, int ld_o, int n_cap, const int* dyn, int k, int d, float* dX, float* dHl,
                           int ld_h, void* stream);
 
+/* SRGNN weighted-mean neighbour aggregation (srgnn.py:21-29,36-41): coef[e] = w_e / sum of w into the same
+ * endpoint; out[v] = sum_{e in list(v)} coef[e] X[other[e]].  (ptr, idx) = in-edge CSR with other = esrc for
+ * the graph, out-edge CSR with other = edst for the reversed graph; the backward is the same kernel on the
+ * opposite CSR. */
+int srec_edge_coef(const int* ptr, const int* idx, const int* ew, int n_cap, const int* dyn, float* coef,
+                   void* stream);
+int srec_edge_agg(const float* X, int ld_x, const int* ptr, const int* idx, const int* other, const float* coef,
+                  int n_cap, const int* dyn, int D, float* out, int ld_o, void* stream);
+
+/* ---- LESSR (bn.hip, gruseq.hip, sgat.hip) -------------------------------------------------------------
+ * BatchNorm1d lessr.py:12,32,56,66,90,105,162,179 (ws = 32*D floats); PReLU lessr.py:140,149,159 */
+int srec_bn_stats(const float* X, int ld, int n_cap, const int* dyn, int D, float* mean, float* var, float* rmean,
+                  float* rvar, float momentum, float* ws, void* stream);
+int srec_bn_apply_fwd(const float* X, int ld_x, const float* mean, const float* var, float eps, const float* gamma,
+                      const float* beta, int n_cap, const int* dyn, int D, float* Y, int ld_y, void* stream);
+int srec_bn_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const float* mean, const float* var, float eps,
+                const float* gamma, int training, int n_cap, const int* dyn, int D, float* dX, int ld_dx,
+                float* dgamma, float* dbeta, float* ws, void* stream);
+int srec_prelu_fwd(const float* X, int ld_x, const float* a, int n_cap, const int* dyn, int D, float* Y, int ld_y,
+                   void* stream);
+int srec_prelu_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const float* a, int n_cap, const int* dyn,
+                   int D, float* dX, int ld_dx, float* T, int ld_t, void* stream);
+/* EOPA: per node GRU over in-neighbours in edge-id order (lessr.py:20-27,35).  GI [Nsrc,3D] = ft W_ih^T + b_ih;
+ * WhhT [D,3D] k-major copy, Whh [3D,D] as stored; gates [E,3D], Hprev/ghn [E,D], dGIe/dGHe [E,3D] by edge id. */
+int srec_gru_seq_fwd(const float* GI, int ld_gi, const float* WhhT, const float* bhh, const int* in_ptr,
+                     const int* in_idx, const int* esrc, int n_cap, const int* dyn, int D, float* neigh, int ld_n,
+                     float* gates, float* Hprev, float* ghn, void* stream);
+int srec_gru_seq_bwd(const float* dneigh, int ld_dn, const float* Whh, const float* gates, const float* Hprev,
+                     const float* ghn, const int* in_ptr, const int* in_idx, int n_cap, const int* dyn, int D,
+                     float* dGIe, float* dGHe, void* stream);
+/* SGAT: e = fc_e(sigmoid(q_u + k_v)), softmax over in-edges, sum a v_u (lessr.py:68-74).  A [E], dQe [E,Hh]. */
+int srec_sgat_fwd(const float* Q, int ld_q, const float* K, int ld_k, const float* we, const float* Vf, int ld_v,
+                  const int* in_ptr, const int* in_idx, const int* esrc, int n_cap, const int* dyn, int Hh, int Do,
+                  float* A, float* out, int ld_o, void* stream);
+int srec_sgat_bwd_dst(const float* dout, int ld_o, const float* Q, int ld_q, const float* K, int ld_k,
+                      const float* we, const float* Vf, int ld_v, const float* A, const int* in_ptr,
+                      const int* in_idx, const int* esrc, int n_cap, const int* dyn, int Hh, int Do, float* dQe,
+                      float* dK, int ld_dk, float* dwe_part, int ld_dw, void* stream);
+int srec_sgat_bwd_src(const float* dout, int ld_o, const float* A, const float* dQe, const int* out_ptr,
+                      const int* out_idx, const int* edst, int n_cap, const int* dyn, int Hh, int Do, float* dQ,
+                      int ld_dq, float* dVf, int ld_dv, void* stream);
+
 /* ---- optimizer (adam.hip): torch.optim.Adam + coupled L2, train.py:70-75,101 ------------------------
- * hyper (device) = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2} */
+ * hyper (device, 8 floats) = {lr/(1-b1^t), beta1, beta2, eps, weight_decay, 1-beta1, 1-beta2, sqrt(1-b2^t)} */
 int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                    void* stream);
 int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,

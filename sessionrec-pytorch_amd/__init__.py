@@ -9,3 +9,4 @@ module at the repo root.
 from .batch import FlatBatch  # noqa: F401
 from .srgnn import NISER, SRGNN  # noqa: F401
 from .msgifsr import MSGIFSR  # noqa: F401
+from .lessr import LESSR  # noqa: F401

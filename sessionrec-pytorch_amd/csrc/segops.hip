@@ -149,7 +149,58 @@ __global__ void seg_mean_add_bwd_kernel(const float* __restrict__ dout, int ld_d
     }
 }
 
+// SRGNN weighted-mean aggregation (srgnn.py:21-29,36-41): coef[e] = w_e / sum_{e' into dst(e)} w_e'
+__global__ void edge_coef_kernel(const int* __restrict__ ptr, const int* __restrict__ idx, const int* __restrict__ ew,
+                                 int n_cap, const int* __restrict__ dyn, float* __restrict__ coef) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= dyn_count(dyn, n_cap)) return;
+    const int beg = ptr[v], end = ptr[v + 1];
+    float s = 0.f;
+    for (int j = beg; j < end; ++j) s += (float)ew[idx[j]];
+    for (int j = beg; j < end; ++j) coef[idx[j]] = (float)ew[idx[j]] / s;
+}
+
+// out[v,:] = sum_{e in list(v)} coef[e] * X[other[e],:]   (zero rows for empty lists: DGL zero fill)
+__global__ void edge_agg_kernel(const float* __restrict__ X, int ld_x, const int* __restrict__ ptr,
+                                const int* __restrict__ idx, const int* __restrict__ other,
+                                const float* __restrict__ coef, int n_cap, const int* __restrict__ dyn, int D,
+                                float* __restrict__ out, int ld_o) {
+    const int v = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n_cap) return;
+    const bool live = v < dyn_count(dyn, n_cap);
+    const int beg = live ? ptr[v] : 0, end = live ? ptr[v + 1] : 0;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = beg; j < end; ++j) {
+            const int e = idx[j];
+            const float a = coef[e];
+            const float4 x = *reinterpret_cast<const float4*>(X + (size_t)other[e] * ld_x + c);
+            o.x += a * x.x; o.y += a * x.y; o.z += a * x.z; o.w += a * x.w;
+        }
+        *reinterpret_cast<float4*>(out + (size_t)v * ld_o + c) = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int srec_edge_coef(const int* ptr, const int* idx, const int* ew, int n_cap, const int* dyn, float* coef,
+                              void* stream) {
+    if (n_cap <= 0) return 0;
+    hipLaunchKernelGGL(edge_coef_kernel, dim3(cdiv(n_cap, 256)), dim3(256), 0, (hipStream_t)stream, ptr, idx, ew, n_cap,
+                       dyn, coef);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_edge_agg(const float* X, int ld_x, const int* ptr, const int* idx, const int* other,
+                             const float* coef, int n_cap, const int* dyn, int D, float* out, int ld_o, void* stream) {
+    if (n_cap <= 0) return 0;
+    if ((D & 3) || (ld_x & 3) || (ld_o & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(edge_agg_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, X, ld_x, ptr, idx, other,
+                       coef, n_cap, dyn, D, out, ld_o);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const float* X,
                                  int ld_x, const int* seg, int B, const int* dynB, int h, int D, float* alpha,

@@ -598,3 +598,211 @@ class HeadCombine(torch.autograd.Function):
 
 def head_combine(x, bias, nres, H, rsts, dyn=None):
     return HeadCombine.apply(x, bias, nres, H, dyn, *rsts)
+
+
+# ------------------------------------------------------------------------------------------ LESSR
+class BatchNorm(torch.autograd.Function):
+    """nn.BatchNorm1d over the live rows (training: batch statistics + running-stat update)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, dyn):
+        x = _rows(x)
+        n, D = x.shape
+        dev = x.device
+        ws = _ws(32 * D, dev)
+        if training:
+            mean = torch.empty(D, device=dev, dtype=torch.float32)
+            var = torch.empty(D, device=dev, dtype=torch.float32)
+            lib.srec_bn_stats(ptr(x), _ld(x), n, ptr(dyn), D, ptr(mean), ptr(var), ptr(rmean), ptr(rvar),
+                              float(momentum), ptr(ws), stream())
+        else:
+            mean, var = rmean, rvar
+        y = torch.empty(n, D, device=dev, dtype=torch.float32)
+        lib.srec_bn_apply_fwd(ptr(x), _ld(x), ptr(mean), ptr(var), float(eps), ptr(gamma), ptr(beta), n, ptr(dyn), D,
+                              ptr(y), D, stream())
+        ctx.save_for_backward(x, mean, var, gamma)
+        ctx.meta = (training, eps, dyn)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, var, gamma = ctx.saved_tensors
+        training, eps, dyn = ctx.meta
+        gy = _rows(gy)
+        n, D = x.shape
+        dev = x.device
+        dx = torch.empty(n, D, device=dev, dtype=torch.float32)
+        dg = torch.empty(D, device=dev, dtype=torch.float32)
+        db = torch.empty(D, device=dev, dtype=torch.float32)
+        lib.srec_bn_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(mean), ptr(var), float(eps), ptr(gamma),
+                        1 if training else 0, n, ptr(dyn), D, ptr(dx), D, ptr(dg), ptr(db), ptr(_ws(32 * D, dev)),
+                        stream())
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def batch_norm(x, bn, dyn=None):
+    """bn: an nn.BatchNorm1d used as parameter / running-stat container"""
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, dyn)
+
+
+class PReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, dyn):
+        x = _rows(x)
+        n, D = x.shape
+        y = torch.empty(n, D, device=x.device, dtype=torch.float32)
+        lib.srec_prelu_fwd(ptr(x), _ld(x), ptr(a), n, ptr(dyn), D, ptr(y), D, stream())
+        ctx.save_for_backward(x, a)
+        ctx.dyn = dyn
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, a = ctx.saved_tensors
+        gy = _rows(gy)
+        n, D = x.shape
+        dx = torch.empty(n, D, device=x.device, dtype=torch.float32)
+        T = torch.empty(n, D, device=x.device, dtype=torch.float32)
+        lib.srec_prelu_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(a), n, ptr(ctx.dyn), D, ptr(dx), D, ptr(T), D, stream())
+        da = torch.empty(D, device=x.device, dtype=torch.float32)
+        col_sum(T, n, D, da, ctx.dyn)
+        return dx, da, None
+
+
+def prelu(x, a, dyn=None):
+    return PReLU.apply(x, a, dyn)
+
+
+class GRUSeq(torch.autograd.Function):
+    """EOPA: last hidden state of a GRU run over each node's in-neighbours in edge-id order.
+    GI = ft W_ih^T + b_ih (per source node); graph = (in_ptr, in_idx, out_ptr, out_idx, esrc, edst)."""
+
+    @staticmethod
+    def forward(ctx, GI, Whh, bhh, graph, dyn):
+        GI = _rows(GI)
+        in_ptr, in_idx, out_ptr, out_idx, esrc, edst = graph
+        N, D3 = GI.shape
+        D = D3 // 3
+        E = esrc.numel()
+        dev = GI.device
+        Whh = Whh.contiguous()
+        WhhT = Whh.t().contiguous()
+        neigh = torch.empty(N, D, device=dev, dtype=torch.float32)
+        gates = torch.zeros(max(E, 1), D3, device=dev, dtype=torch.float32)
+        Hprev = torch.zeros(max(E, 1), D, device=dev, dtype=torch.float32)
+        ghn = torch.zeros(max(E, 1), D, device=dev, dtype=torch.float32)
+        lib.srec_gru_seq_fwd(ptr(GI), _ld(GI), ptr(WhhT), ptr(bhh), ptr(in_ptr), ptr(in_idx), ptr(esrc), N, ptr(dyn), D,
+                             ptr(neigh), D, ptr(gates), ptr(Hprev), ptr(ghn), stream())
+        ctx.save_for_backward(Whh, gates, Hprev, ghn)
+        ctx.graph, ctx.dyn, ctx.shape = graph, dyn, (N, D, E)
+        return neigh
+
+    @staticmethod
+    def backward(ctx, dneigh):
+        Whh, gates, Hprev, ghn = ctx.saved_tensors
+        in_ptr, in_idx, out_ptr, out_idx, esrc, edst = ctx.graph
+        N, D, E = ctx.shape
+        dev = Whh.device
+        dneigh = _rows(dneigh)
+        dGIe = torch.zeros(max(E, 1), 3 * D, device=dev, dtype=torch.float32)
+        dGHe = torch.zeros(max(E, 1), 3 * D, device=dev, dtype=torch.float32)
+        lib.srec_gru_seq_bwd(ptr(dneigh), _ld(dneigh), ptr(Whh), ptr(gates), ptr(Hprev), ptr(ghn), ptr(in_ptr),
+                             ptr(in_idx), N, ptr(ctx.dyn), D, ptr(dGIe), ptr(dGHe), stream())
+        # per-source sum of the edge records (out-edge CSR), then weight gradients as GEMMs over the E records
+        dGI = torch.zeros(N, 3 * D, device=dev, dtype=torch.float32)
+        ar = _arange(N + 1, dev)
+        lib.srec_scatter_add_sorted(ptr(dGIe), 3 * D, ptr(ar), ptr(out_ptr), ptr(out_idx), ptr(dGI), 3 * D, N,
+                                    ptr(ctx.dyn), 3 * D, 0, stream())
+        dWhh = torch.zeros(3 * D, D, device=dev, dtype=torch.float32)
+        dbhh = torch.zeros(3 * D, device=dev, dtype=torch.float32)
+        if E > 0:
+            gemm_tn(dGHe[:E], Hprev[:E], dWhh)
+            col_sum(dGHe, E, 3 * D, dbhh)
+        return dGI, dWhh, dbhh, None, None
+
+
+def gru_seq(GI, Whh, bhh, graph, dyn=None):
+    return GRUSeq.apply(GI, Whh, bhh, graph, dyn)
+
+
+class SGATAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Q, K, we, Vf, graph, dyn):
+        Q, K, Vf = _rows(Q), _rows(K), _rows(Vf)
+        in_ptr, in_idx, out_ptr, out_idx, esrc, edst = graph
+        N, Hh = Q.shape
+        Do = Vf.shape[1]
+        E = esrc.numel()
+        dev = Q.device
+        we = we.reshape(-1).contiguous()
+        A = torch.zeros(max(E, 1), device=dev, dtype=torch.float32)
+        out = torch.empty(N, Do, device=dev, dtype=torch.float32)
+        lib.srec_sgat_fwd(ptr(Q), _ld(Q), ptr(K), _ld(K), ptr(we), ptr(Vf), _ld(Vf), ptr(in_ptr), ptr(in_idx), ptr(esrc),
+                          N, ptr(dyn), Hh, Do, ptr(A), ptr(out), Do, stream())
+        ctx.save_for_backward(Q, K, we, Vf, A)
+        ctx.graph, ctx.dyn = graph, dyn
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Q, K, we, Vf, A = ctx.saved_tensors
+        in_ptr, in_idx, out_ptr, out_idx, esrc, edst = ctx.graph
+        g = _rows(g)
+        N, Hh = Q.shape
+        Do = Vf.shape[1]
+        E = esrc.numel()
+        dev = Q.device
+        dQe = torch.zeros(max(E, 1), Hh, device=dev, dtype=torch.float32)
+        dK = torch.empty(N, Hh, device=dev, dtype=torch.float32)
+        dwp = torch.empty(N, Hh, device=dev, dtype=torch.float32)
+        lib.srec_sgat_bwd_dst(ptr(g), _ld(g), ptr(Q), _ld(Q), ptr(K), _ld(K), ptr(we), ptr(Vf), _ld(Vf), ptr(A),
+                              ptr(in_ptr), ptr(in_idx), ptr(esrc), N, ptr(ctx.dyn), Hh, Do, ptr(dQe), ptr(dK), Hh,
+                              ptr(dwp), Hh, stream())
+        dQ = torch.empty(N, Hh, device=dev, dtype=torch.float32)
+        dV = torch.empty(N, Do, device=dev, dtype=torch.float32)
+        lib.srec_sgat_bwd_src(ptr(g), _ld(g), ptr(A), ptr(dQe), ptr(out_ptr), ptr(out_idx), ptr(edst), N, ptr(ctx.dyn),
+                              Hh, Do, ptr(dQ), Hh, ptr(dV), Do, stream())
+        dwe = torch.empty(Hh, device=dev, dtype=torch.float32)
+        col_sum(dwp, N, Hh, dwe, ctx.dyn)
+        return dQ, dK, dwe.view(1, Hh), dV, None, None
+
+
+def sgat_attn(Q, K, we, Vf, graph, dyn=None):
+    return SGATAttn.apply(Q, K, we, Vf, graph, dyn)
+
+
+class EdgeAgg(torch.autograd.Function):
+    """out[v] = sum_{e into v} coef[e] x[src(e)] (coef constant); backward = the same kernel on the out-edge CSR."""
+
+    @staticmethod
+    def forward(ctx, x, coef, fwd_csr, bwd_csr, dyn):
+        x = _rows(x)
+        N, D = x.shape
+        out = torch.empty(N, D, device=x.device, dtype=torch.float32)
+        p, i, o = fwd_csr
+        lib.srec_edge_agg(ptr(x), _ld(x), ptr(p), ptr(i), ptr(o), ptr(coef), N, ptr(dyn), D, ptr(out), D, stream())
+        ctx.save_for_backward(coef)
+        ctx.bwd_csr, ctx.dyn = bwd_csr, dyn
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (coef,) = ctx.saved_tensors
+        g = _rows(g)
+        N, D = g.shape
+        dx = torch.empty(N, D, device=g.device, dtype=torch.float32)
+        p, i, o = ctx.bwd_csr
+        lib.srec_edge_agg(ptr(g), _ld(g), ptr(p), ptr(i), ptr(o), ptr(coef), N, ptr(ctx.dyn), D, ptr(dx), D, stream())
+        return dx, None, None, None, None
+
+
+def edge_coef(ptr_, idx, ew, n, dyn=None):
+    coef = torch.zeros(max(ew.numel(), 1), device=ew.device, dtype=torch.float32)
+    lib.srec_edge_coef(ptr(ptr_), ptr(idx), ptr(ew), n, ptr(dyn), ptr(coef), stream())
+    return coef
+
+
+def edge_agg(x, coef, fwd_csr, bwd_csr, dyn=None):
+    return EdgeAgg.apply(x, coef, fwd_csr, bwd_csr, dyn)

@@ -22,7 +22,8 @@ class FusedAdam(torch.optim.Optimizer):
     def _hyper_dev(self, group, step, device):
         b1, b2 = group['betas']
         key = (id(group), step)
-        vals = [group['lr'], b1, b2, group['eps'], group['weight_decay'], 1.0 - b1 ** step, 1.0 - b2 ** step, 0.0]
+        vals = [group['lr'] / (1.0 - b1 ** step), b1, b2, group['eps'], group['weight_decay'], 1.0 - b1, 1.0 - b2,
+                (1.0 - b2 ** step) ** 0.5]
         slot = self._hyper.get(id(group))
         if slot is None:
             slot = self._hyper[id(group)] = {}
@@ -71,7 +72,7 @@ class FusedAdam(torch.optim.Optimizer):
                 hyper = hyper_cache[s]
                 g = g.contiguous()
                 if is_table and p.dim() == 2 and (p.shape[1] & 3) == 0:
-                    max_norm = getattr(model, '_max_norm', 0.0) or 0.0
+                    max_norm = 0.0     # Embedding(max_norm) renorm stays in forward (reference state after step())
                     cos = model._cosine() if hasattr(model, '_cosine') else None
                     st = model.__dict__.get('_srec_state')
                     cs_out, cs_scale, eps_mode = None, 1.0, 0

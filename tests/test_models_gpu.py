@@ -40,6 +40,57 @@ def _collate(name, samples):
     return c.collate_fn_factory_ccs((c.seq_to_ccs_graph,), K)(samples)
 
 
+def _oracle_fp64_final(name, init, samples, V):
+    """the same 3 Adam steps by the CPU oracle in float64: the yardstick for fp32 round-off"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import collate_ref as oc, models_ref as om
+    train = pkg('train')
+    d = 32
+    if name.startswith('srgnn'):
+        m, fn = om.SRGNN(V, d, 1), oc.collate_fn_factory(oc.seq_to_session_graph)
+    elif name.startswith('niser'):
+        m, fn = om.NISER(V, d, 1), oc.collate_fn_factory(oc.seq_to_session_graph)
+    elif name.startswith('lessr'):
+        L = int(name.split('_')[1][1:])
+        fns = (oc.seq_to_eop_multigraph, oc.seq_to_shortcut_graph) if L > 1 else (oc.seq_to_eop_multigraph,)
+        m, fn = om.LESSR(V, d, L), oc.collate_fn_factory(*fns)
+    else:
+        K = int(name.split('_')[1][1:])
+        m = om.MSGIFSR(V, 'sample', d, 1, order=K, extra=False, fusion='_fus' in name)
+        fn = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K)
+    m.load_state_dict(init)
+    m = m.double()
+    torch.set_default_dtype(torch.float64)
+    try:
+        inputs, labels = fn(samples)
+        inputs = [om.to_torch(x) for x in inputs]
+        labels = torch.from_numpy(labels)
+        opt = torch.optim.Adam(train.fix_weight_decay(m), lr=1e-3, weight_decay=1e-4)
+        m.train()
+        for _ in range(3):
+            opt.zero_grad()
+            torch.nn.functional.nll_loss(m(*inputs), labels).backward()
+            opt.step()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return {k: v.detach() for k, v in m.state_dict().items()}
+
+
+def roundoff_close(mine, ref32, truth64, what):
+    """`mine` (fp32 HIP) must be as close to the float64 trajectory as the reference's own fp32 run is:
+    Adam divides by sqrt(v), so fp32 summation-order noise in near-zero gradient components becomes a
+    visible fraction of a step in BOTH fp32 implementations."""
+    mine = torch.as_tensor(mine).detach().double().cpu()
+    ref32 = torch.as_tensor(ref32).detach().double().cpu()
+    t = truth64.double().cpu()
+    e_mine, e_ref = (mine - t).abs(), (ref32 - t).abs()
+    assert e_mine.mean().item() <= 3.0 * e_ref.mean().item() + 1e-9, \
+        '%s: mean |err| vs fp64 %.3e (reference fp32 run: %.3e)' % (what, e_mine.mean().item(), e_ref.mean().item())
+    assert e_mine.max().item() <= max(6.0 * e_ref.max().item(), 4e-6), \
+        '%s: max |err| vs fp64 %.3e (reference fp32 run: %.3e)' % (what, e_mine.max().item(), e_ref.max().item())
+
+
 def adam_close(a, b, lr=1e-3, steps=3, what=''):
     """Parameters after `steps` Adam updates.  Adam divides by sqrt(v): where a gradient component is
     ~0 after cancellation its relative fp32 error (summation order) is amplified to a fraction of a
@@ -54,6 +105,7 @@ def adam_close(a, b, lr=1e-3, steps=3, what=''):
 
 
 CASES = ['srgnn_s32', 'srgnn_edge', 'niser_s32', 'niser_edge',
+         'lessr_L1_s32', 'lessr_L1_edge', 'lessr_L3_s32', 'lessr_L3_edge',
          'msgifsr_K1_s32', 'msgifsr_K1_edge', 'msgifsr_K2_s32', 'msgifsr_K2_edge', 'msgifsr_K3_s32', 'msgifsr_K3_edge']
 
 
@@ -71,7 +123,9 @@ def test_model_matches_reference_fixture(dev, name):
     optim = pkg('optim')
     z, samples, init = load_golden(name)
     V = init[[k for k in init if k.startswith('embedding')][0]].shape[0]
-    model = _build(name, init, V, dev)
+    import copy
+    fused_model = _build(name, init, V, dev)
+    model = copy.deepcopy(fused_model)          # compat-path copy (its train-mode forward moves BN running stats)
     inputs, labels = _collate(name, samples)
     inputs = [x.to(dev) for x in inputs]
     labels = labels.to(dev)
@@ -92,6 +146,9 @@ def test_model_matches_reference_fixture(dev, name):
         if k.startswith('nograd/'):
             assert params[k[7:]].grad is None, k
     # 3) fused training path: 3 steps of fused loss + FusedAdam vs the reference's Adam trajectory
+    model = fused_model
+    model.train()
+    params = dict(model.named_parameters())
     model.zero_grad(set_to_none=True)
     opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model)
     losses = []
@@ -111,9 +168,10 @@ def test_model_matches_reference_fixture(dev, name):
         losses.append(loss.item())
     close(torch.tensor(losses), torch.from_numpy(z['losses']).float(), rtol=1e-5, atol=1e-5, what='loss trace')
     sd = model.state_dict()
+    truth = _oracle_fp64_final(name, init, samples, V)
     for k in z.files:
         if k.startswith('final/') and k[6:] in sd and sd[k[6:]].dtype == torch.float32:
-            adam_close(sd[k[6:]], z[k], what=k)
+            roundoff_close(sd[k[6:]], z[k], truth[k[6:]], k)
     # 4) evaluation ranking
     model.eval()
     with torch.no_grad():

@@ -313,3 +313,78 @@ def test_gat_relation_and_head_combine(dev):
     for a, b, nm in zip(torch.autograd.grad(out, [x, bias, R1, R2], g), torch.autograd.grad(r, [x, bias, R1, R2], g),
                         ['dx', 'dbias', 'dR1', 'dR2']):
         close(a, b, what='combine ' + nm, atol=1e-5)
+
+
+def test_srgnn_layer_matches_oracle(dev):
+    """K3 (srgnn.py:11-51): weighted-mean in/out aggregation + GRUCell vs the oracle layer."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import collate_ref as oc, models_ref as om
+    sp = importlib.import_module('sessionrec-pytorch_amd')
+    col = importlib.import_module('sessionrec-pytorch_amd.collate')
+    gnn = importlib.import_module('sessionrec-pytorch_amd.gnn')
+    srg = importlib.import_module('sessionrec-pytorch_amd.srgnn')
+    rng = np.random.default_rng(3)
+    samples = [(rng.integers(0, 30, size=int(rng.integers(1, 12))).tolist(), 1) for _ in range(20)]
+    torch.manual_seed(0)
+    d = 32
+    ref = om.SRGNNLayer(d, d)
+    mine = srg.SRGNNLayer(d, d)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev)
+    (fb,), _ = col.collate_fn_factory(col.seq_to_session_graph)(samples)
+    (ob,), _ = oc.collate_fn_factory(oc.seq_to_session_graph)(samples)
+    ob = om.to_torch(ob)
+    N = fb.count('N')
+    x = torch.randn(N, d)
+    xr = x.clone().requires_grad_()
+    xg = x.to(dev).requires_grad_()
+    out_r = ref(ob, xr)
+    out_g = gnn.srgnn_layer(mine, fb.to(dev), xg)
+    close(out_g, out_r, what='srgnn layer fwd')
+    g = torch.randn(N, d)
+    out_r.backward(g)
+    out_g.backward(g.to(dev))
+    close(xg.grad, xr.grad, what='srgnn layer dx', atol=2e-5)
+    for (n1, p1), (n2, p2) in zip(mine.named_parameters(), ref.named_parameters()):
+        close(p1.grad, p2.grad, what='srgnn layer ' + n1, atol=5e-5)
+
+
+def test_batch_norm_prelu(dev):
+    ops = _ops()
+    torch.manual_seed(9)
+    n, D = 200, 96
+    x = torch.randn(n, D, device=dev) * 2 + 1
+    for training in (True, False):
+        bn1 = torch.nn.BatchNorm1d(D).to(dev)
+        bn2 = torch.nn.BatchNorm1d(D).to(dev)
+        with torch.no_grad():
+            for b in (bn1, bn2):
+                b.weight.copy_(torch.linspace(0.5, 1.5, D))
+                b.bias.copy_(torch.linspace(-1, 1, D))
+                b.running_mean.copy_(torch.linspace(-0.2, 0.2, D))
+                b.running_var.copy_(torch.linspace(0.5, 2.0, D))
+        bn1.train(training)
+        bn2.train(training)
+        x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+        y1, y2 = ops.batch_norm(x1, bn1), bn2(x2)
+        close(y1, y2, what='bn fwd %s' % training, atol=2e-5)
+        g = torch.randn_like(y2)
+        y1.backward(g)
+        y2.backward(g)
+        close(x1.grad, x2.grad, what='bn dx', atol=2e-5)
+        close(bn1.weight.grad, bn2.weight.grad, what='bn dgamma', atol=1e-4)
+        close(bn1.bias.grad, bn2.bias.grad, what='bn dbeta', atol=1e-4)
+        close(bn1.running_mean, bn2.running_mean, what='running mean')
+        close(bn1.running_var, bn2.running_var, what='running var')
+    a = torch.rand(D, device=dev, requires_grad=True)
+    x1 = x.clone().requires_grad_()
+    y = ops.prelu(x1, a)
+    a2, x2 = a.detach().clone().requires_grad_(), x.clone().requires_grad_()
+    r = torch.nn.functional.prelu(x2, a2)
+    close(y, r, what='prelu')
+    g = torch.randn_like(r)
+    y.backward(g)
+    r.backward(g)
+    close(x1.grad, x2.grad, what='prelu dx')
+    close(a.grad, a2.grad, what='prelu da', atol=1e-4)
