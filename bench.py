@@ -212,7 +212,12 @@ def main():
     model = build_model(sp, args.model, V, d, args.order)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
+    shard = None
+    if world > 1:                                  # item table row-sharded over the node's GPUs (RCCL / xGMI)
+        D = importlib.import_module('sessionrec-pytorch_amd.dist')
+        shard = D.VocabParallel(model)
     opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model)
+    replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
     dev_batches = [([x.to(dev) for x in inp], lab.to(dev)) for inp, lab in batches]
     model.train()
 
@@ -221,6 +226,8 @@ def main():
         opt.zero_grad()
         loss = model.fused_loss(*inp, lab)
         loss.backward()
+        if shard is not None:
+            shard.sync_replicated_grads(replicated)
         opt.step()
         return loss
 
@@ -245,8 +252,9 @@ def main():
     final_loss = loss.item()
 
     if rank == 0:
-        kt = time_dominant_kernel(model, B, V, d, dev)
-        flops_dE = 4.0 * B * V * d
+        V = model._table().shape[0] if shard is None else shard.n_live
+        kt = time_dominant_kernel(model, B * world, V, d, dev)
+        flops_dE = 4.0 * B * world * V * d
         peak = 157.3                                      # TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
         roof = dict(bound='mfma', kernel='flash_ce_kernel<MODE_DE> (fused scoring/CE backward, dE pass)',
                     achieved=flops_dE / kt['dE'] / 1e12, peak=peak, unit='TFLOP/s',
@@ -262,7 +270,8 @@ def main():
                    config=dict(workload='%s training step, synthetic Yoochoose-1/64 shape (V=%d items, d=%d, batch %d per GPU, '
                                         'session length<=20%s)' % (args.model, V, d, B,
                                                                    ', order %d' % args.order if args.model == 'MSGIFSR' else ''),
-                               global_batch=B * world, parallelism='replicas x%d' % world if world > 1 else 'single GPU',
+                               global_batch=B * world, parallelism=('item table row-sharded x%d (vocab-parallel scoring, RCCL all-gather/reduce-scatter), '
+                                            'encoder replicated' % world) if world > 1 else 'single GPU',
                                final_loss=final_loss),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out))

@@ -21,8 +21,8 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, co
     const int row = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n_cap) return;
     const int n = dyn_count(dyn, n_cap);
-    const bool live = row < n;
-    const int s = live ? idx[row] : 0;
+    const int s = row < n ? idx[row] : -1;            // negative index (row owned by another shard) -> zero row
+    const bool live = s >= 0;
     for (int c = lane * 4; c < d; c += 256) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) v = *reinterpret_cast<const float4*>(src + (size_t)s * ld_src + c);
@@ -38,6 +38,7 @@ __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g,
     const int u = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (u >= dyn_count(dyn, u_cap)) return;
     const int beg = ptr[u], end = ptr[u + 1], item = items[u];
+    if (item < 0) return;                             // row owned by another shard
     for (int c = lane * 4; c < d; c += 256) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e = beg; e < end; ++e) {

@@ -1,0 +1,279 @@
+"""Row-sharded (vocab-parallel) item table over the GPUs of one node - RCCL over xGMI.
+
+Reference: none (the reference is single-device); the partitioning is the one
+BASELINE.json's north star names: the item-embedding table and its use as output projection are
+sharded row-wise, the small session encoder is replicated, and each rank feeds its OWN batch of B
+sessions (weak scaling: global batch = world * B, one optimiser step on the mean loss of all of them).
+
+Per step and rank r (rows [lo, hi) of the table, Adam state for those rows only):
+  lookup   all-gather the (padded) item-id lists -> every rank gathers the rows it owns for every
+           request (others zero) -> reduce-scatter(sum): each rank receives the rows of its own nodes.
+           backward: local segmented sum to one row per distinct item -> all-gather (ids, rows) ->
+           each rank adds the rows it owns into its dense shard gradient, rank by rank (deterministic).
+  scoring  all-gather sr (world*B, d) and labels -> fused flash-CE forward on the local shard for ALL
+           sessions -> all-gather the per-shard log-sum-exp, all-reduce the label logit -> global lse
+           and loss.  backward: fused kernels with the GLOBAL lse: dE for the shard is complete
+           locally; d sr partials are reduce-scattered to the owners of the sessions.
+  encoder  replicated parameters: gradients all-reduced (sum of per-rank contributions to the global
+           mean loss) in ONE flat bucket, then the same fused Adam everywhere.
+All exchanges are small (<= a few MB): latency-bound on xGMI, so they are few and flat (one
+collective per exchange, no ring of tiny messages).  The local compute goes through `local`, an
+object with the HIP kernels (HipLocal); tests drive the same algebra on CPU/gloo with a plain-torch
+stand-in to prove the collectives reassemble the single-device result.
+"""
+import torch
+import torch.distributed as dist
+
+
+# ------------------------------------------------------------------------------- collectives
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def _rank(group=None):
+    return dist.get_rank(group) if dist.is_initialized() else 0
+
+
+def all_gather_cat(t, group=None):
+    """[n, ...] per rank -> [world*n, ...] (same n everywhere)"""
+    w = _world(group)
+    if w == 1:
+        return t
+    t = t.contiguous()
+    out = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    if dist.get_backend(group) == 'nccl':
+        dist.all_gather_into_tensor(out, t, group=group)
+    else:
+        dist.all_gather(list(out.chunk(w, 0)), t, group=group)
+    return out
+
+
+def reduce_scatter_sum(t, group=None):
+    """[world*n, ...] per rank -> [n, ...]: rank r receives the sum over ranks of block r"""
+    w = _world(group)
+    if w == 1:
+        return t
+    t = t.contiguous()
+    n = t.shape[0] // w
+    if dist.get_backend(group) == 'nccl':
+        out = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
+        return out
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)       # gloo has no reduce-scatter
+    r = _rank(group)
+    return t[r * n:(r + 1) * n].clone()
+
+
+def all_reduce_sum(t, group=None):
+    if _world(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def shard_bounds(V, world, rank):
+    per = (V + world - 1) // world
+    per = (per + 63) // 64 * 64                 # whole 64-row scoring tiles per shard
+    lo = min(V, rank * per)
+    return lo, min(V, lo + per), per
+
+
+# ------------------------------------------------------------------------------- local compute (HIP)
+class HipLocal:
+    """The per-rank compute of the sharded path, on the HIP kernels."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def gather_masked(self, table, idx):
+        from ._lib import lib, ptr, stream
+        n, d = idx.numel(), table.shape[1]
+        out = torch.empty(n, d, device=table.device, dtype=torch.float32)
+        lib.srec_gather_rows(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, None, d, stream())
+        return out
+
+    def segment_rows(self, g, uniq):
+        """one summed row per distinct item of the local batch: [U, d]"""
+        from ._lib import lib, ptr, stream
+        items, uptr, upos = uniq[:3]
+        U, d = items.numel(), g.shape[1]
+        g = g.contiguous()
+        out = torch.zeros(U, d, device=g.device, dtype=torch.float32)
+        ar = self.ops._arange(U + 1, g.device)
+        lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(uptr), ptr(upos), ptr(out), d, U, None, d, 0, stream())
+        return out
+
+    def add_rows(self, rows, items_local, dst):
+        """dst[items_local[u]] += rows[u] for items_local[u] >= 0 (distinct within the call)"""
+        from ._lib import lib, ptr, stream
+        U, d = rows.shape
+        ar = self.ops._arange(U + 1, rows.device)
+        lib.srec_scatter_add_sorted(ptr(rows), d, ptr(items_local), ptr(ar), ptr(ar), ptr(dst), dst.stride(0), U, None,
+                                    d, 1, stream())
+
+    def ce_fwd(self, sr, table, cs, labels_local, ws):
+        from ._lib import lib, ptr, stream
+        B, d = sr.shape
+        dev = sr.device
+        lse = torch.empty(B, device=dev, dtype=torch.float32)
+        lossvec = torch.empty(B, device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        ws.lab_logit.zero_()
+        lib.srec_score_ce_fwd(ptr(sr), sr.stride(0), ptr(table), table.stride(0), ptr(cs), ptr(labels_local), B,
+                              table.shape[0], d, None, ptr(ws.stats), ptr(ws.lab_logit), ptr(lse), ptr(lossvec), ptr(loss),
+                              stream())
+        return lse, ws.lab_logit.clone()
+
+    def ce_bwd(self, sr, table, cs, labels_local, lse, gscale, dE, ws, cs_inv_scale):
+        from ._lib import lib, ptr, stream
+        B, d = sr.shape
+        dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
+        lib.srec_score_ce_bwd(ptr(sr), sr.stride(0), ptr(table), table.stride(0), ptr(cs), ptr(labels_local), ptr(lse),
+                              ptr(gscale), B, table.shape[0], d, None, ptr(dE), dE.stride(0), ptr(ws.dsr_part), ptr(dsr),
+                              3, stream())
+        if cs is not None:
+            lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), cs_inv_scale, ptr(dE), dE.stride(0),
+                                     table.shape[0], d, stream())
+        return dsr
+
+    def workspace(self, B, V, d, device):
+        return self.ops.CEWorkspace(B, V, d, device)
+
+
+# ------------------------------------------------------------------------------- autograd functions
+class ShardedLookup(torch.autograd.Function):
+    """rows = E[idx] with E row-sharded; idx padded with -1 to a capacity that is equal on all ranks."""
+
+    @staticmethod
+    def forward(ctx, shard, idx_pad, uniq_pad, dE, lo, local, group):
+        n_loc = shard.shape[0]
+        idx_all = all_gather_cat(idx_pad, group)
+        rel = idx_all - lo
+        rel = torch.where((idx_all >= 0) & (rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1))
+        rows_all = local.gather_masked(shard, rel.to(torch.int32))
+        out = reduce_scatter_sum(rows_all, group)
+        ctx.uniq_pad, ctx.dE, ctx.lo, ctx.local, ctx.group, ctx.n_loc = uniq_pad, dE, lo, local, group, n_loc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        items_pad, uptr, upos = ctx.uniq_pad                 # items padded with -1 to a common capacity
+        rows = ctx.local.segment_rows(g, (items_pad, uptr, upos))
+        rows_all = all_gather_cat(rows, ctx.group)
+        items_all = all_gather_cat(items_pad, ctx.group)
+        w = _world(ctx.group)
+        U = items_pad.numel()
+        for r in range(w):                                   # rank by rank: distinct items within each call
+            it = items_all[r * U:(r + 1) * U]
+            rel = it - ctx.lo
+            rel = torch.where((it >= 0) & (rel >= 0) & (rel < ctx.n_loc), rel, torch.full_like(rel, -1))
+            ctx.local.add_rows(rows_all[r * U:(r + 1) * U], rel.to(torch.int32), ctx.dE)
+        return None, None, None, None, None, None, None
+
+
+class ShardedScoreCE(torch.autograd.Function):
+    """mean CE over the GLOBAL batch (world*B sessions) against the row-sharded catalog."""
+
+    @staticmethod
+    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group):
+        n_loc = shard.shape[0]
+        sr_all = all_gather_cat(sr.contiguous(), group)
+        lab_all = all_gather_cat(labels.to(torch.int64), group)
+        rel = lab_all - lo
+        lab_loc = torch.where((rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1)).to(torch.int32)
+        lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
+        lse_all = all_gather_cat(lse_r.unsqueeze(0), group)            # [world, world*B]
+        lse = torch.logsumexp(lse_all, dim=0).contiguous()
+        lab_logit = all_reduce_sum(lab_logit, group)
+        loss = (lse - lab_logit).mean()
+        ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
+        ctx.misc = (dE, ws, cs_inv_scale, local, group)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        sr_all, shard, cs, lab_loc, lse = ctx.saved_tensors
+        dE, ws, cs_inv_scale, local, group = ctx.misc
+        gs = gloss.reshape(1).to(torch.float32).contiguous()
+        dsr_part = local.ce_bwd(sr_all, shard, cs, lab_loc, lse, gs, dE, ws, cs_inv_scale)
+        dsr = reduce_scatter_sum(dsr_part, group)
+        return dsr, None, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------- model wiring
+class VocabParallel:
+    """Attach to a model (`model.shard = VocabParallel(model)`): the model's table parameter becomes this
+    rank's row shard and the lookup / fused loss route through the collectives above."""
+
+    def __init__(self, model, group=None, local=None, idx_cap=None):
+        self.group = group
+        self.world, self.rank = _world(group), _rank(group)
+        self.local = local if local is not None else HipLocal()
+        table = model._table()
+        self.V, self.d = table.shape
+        self.lo, self.hi, self.per = shard_bounds(self.V, self.world, self.rank)
+        with torch.no_grad():
+            shard = torch.zeros(self.per, self.d, device=table.device, dtype=table.dtype)
+            shard[:self.hi - self.lo] = table[self.lo:self.hi]
+            table.data = shard                      # parameter now holds only this rank's rows
+        self.n_live = self.hi - self.lo
+        model.__dict__.pop('_srec_state', None)     # rebuild the scoring state for the sharded table
+        self.tgrad = model._state(1)['tgrad']
+        self.dE = self.tgrad.buf
+        self.idx_cap = idx_cap
+        self._ws = {}
+        model.shard = self
+
+    def _pad(self, t, cap, fill=-1):
+        out = torch.full((cap,), fill, device=t.device, dtype=t.dtype)
+        out[:t.numel()] = t
+        return out
+
+    def capacity(self, n):
+        """a common padded length: max over ranks, rounded up (one tiny all-reduce per batch)"""
+        if self.idx_cap is not None:
+            assert n <= self.idx_cap
+            return self.idx_cap
+        t = torch.tensor([n], dtype=torch.int64, device=self.dE.device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return (int(t.item()) + 255) // 256 * 256
+
+    def lookup(self, table, idx, uniq):
+        items, uptr, upos = uniq[:3]
+        n, U = idx.numel(), items.numel()
+        cap = self.capacity(max(n, U))
+        idx_pad = self._pad(idx.to(torch.int64), cap)
+        items_pad = self._pad(items.to(torch.int64), cap)
+        uptr_pad = torch.full((cap + 1,), int(n), device=idx.device, dtype=torch.int32)
+        uptr_pad[:U + 1] = uptr
+        rows = ShardedLookup.apply(table, idx_pad, (items_pad, uptr_pad, upos), self.dE, self.lo, self.local, self.group)
+        return rows[:n]
+
+    def loss(self, sr, table, cs, labels, cs_inv_scale):
+        B = sr.shape[0] * self.world
+        key = B
+        if key not in self._ws:
+            self._ws[key] = self.local.workspace(B, table.shape[0], self.d, sr.device)
+        live = table[:self.n_live] if self.n_live < table.shape[0] else table
+        dE = self.dE[:self.n_live] if self.n_live < table.shape[0] else self.dE
+        csl = None if cs is None else cs[:self.n_live]
+        out = ShardedScoreCE.apply(sr, live, csl, labels, dE, self.lo, self._ws[key], cs_inv_scale, self.local, self.group)
+        self.tgrad.fresh = True                      # the backward of `out` overwrites every live row of dE
+        return out
+
+    def sync_replicated_grads(self, params):
+        """sum the replicated-parameter gradients over ranks in one flat bucket"""
+        if self.world == 1:
+            return
+        gs = [p.grad for p in params if p.grad is not None]
+        if not gs:
+            return
+        flat = torch.cat([g.reshape(-1) for g in gs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for g in gs:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n

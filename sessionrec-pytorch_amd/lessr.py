@@ -115,8 +115,7 @@ class LESSR(_ScoringMixin, nn.Module):
         W = self.embedding.weight
         with torch.no_grad():                    # Embedding(max_norm=1): in-place renorm before the lookup
             lib.srec_renorm_rows(ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], 1.0, stream())
-        feat = ops.embedding_lookup(W, mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr),
-                                    tgrad)
+        feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
         for i, layer in enumerate(self.layers):
             out = layer(mg, feat) if i % 2 == 0 else layer(sg, feat)
             feat = torch.cat([out, feat], dim=1)

@@ -236,7 +236,7 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         self._renorm(mg)
         W = self._table()
         d = self.embedding_dim
-        rows = ops.embedding_lookup(W, mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
+        rows = self._lookup(mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
         rows = self.feat_drop(rows)
         feats, off = {}, 0
         for k in range(1, K + 1):

@@ -65,12 +65,22 @@ class _ScoringMixin:
         st['cs_fresh'] = False          # the optimizer sets it again after refreshing cs in its row pass
         return st['cs'], 1.0 / float(scale)
 
+    shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
+
+    def _lookup(self, idx, uniq, tgrad):
+        """item rows for the batch: local gather, or the collective lookup when the table is sharded"""
+        if self.shard is not None:
+            return self.shard.lookup(self._table(), idx, uniq)
+        return ops.embedding_lookup(self._table(), idx, uniq, tgrad)
+
     def fused_loss(self, *inputs_and_labels, dynB=None):
         *inputs, labels = inputs_and_labels
         B = labels.numel()
         st = self._state(B)
         cs, inv_scale = self._col_scale(st)
         sr = self.session_repr(*inputs, tgrad=st['tgrad'])
+        if self.shard is not None:
+            return self.shard.loss(sr, self._table(), cs, labels, inv_scale)
         loss, _ = ops.score_ce(sr, self._table(), cs, labels.to(torch.int32), st['ws'][B], st['tgrad'], dynB, inv_scale)
         return loss
 
@@ -141,7 +151,7 @@ class SRGNN(_ScoringMixin, nn.Module):
         return sr
 
     def session_repr(self, mg, sg=None, tgrad=None):
-        feat = ops.embedding_lookup(self.embedding.weight, mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
+        feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
         feat = self._pre(self.feat_drop(feat))
         if self.use_gnn_output:
             for layer in self.layers:

@@ -1,0 +1,111 @@
+"""Shared driver of the four launcher scripts.  Flag names, defaults and printed strings follow the
+reference CLIs (main_lessr.py:7-53, main_niser.py:7-53, main_msgifsr.py:35-112); main_srgnn.py is the
+script start.sh:6 expects but the reference never shipped.  GPU selection is ROCm
+aware (HIP_VISIBLE_DEVICES / first device) instead of shelling out to nvidia-smi (quirk 4)."""
+import argparse
+import os
+import random
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve()
+sys.path.insert(0, str(HERE.parents[2]))
+sys.path.insert(0, str(HERE.parents[1]))
+
+DEFAULTS = {
+    'LESSR': dict(embedding_dim=32, num_layers=3, feat_drop=0.2, batch_size=512, patience=2, num_workers=0),
+    'NISER': dict(embedding_dim=64, num_layers=2, feat_drop=0.5, batch_size=128, patience=2, num_workers=4),
+    'SRGNN': dict(embedding_dim=64, num_layers=2, feat_drop=0.5, batch_size=128, patience=2, num_workers=4),
+    'MSGIFSR': dict(embedding_dim=256, num_layers=1, feat_drop=0.1, batch_size=512, patience=3, num_workers=4),
+}
+
+
+def parse(model):
+    d = DEFAULTS[model]
+    p = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('--dataset-dir', default='../datasets/sample', help='the dataset directory')
+    p.add_argument('--embedding-dim', type=int, default=d['embedding_dim'], help='the embedding size')
+    p.add_argument('--num-layers', type=int, default=d['num_layers'], help='the number of layers')
+    p.add_argument('--feat-drop', type=float, default=d['feat_drop'], help='the dropout ratio for features')
+    p.add_argument('--lr', type=float, default=1e-3, help='the learning rate')
+    p.add_argument('--batch-size', type=int, default=d['batch_size'], help='the batch size for training')
+    p.add_argument('--epochs', type=int, default=30, help='the number of training epochs')
+    p.add_argument('--weight-decay', type=float, default=1e-4, help='the parameter for L2 regularization')
+    p.add_argument('--patience', type=int, default=d['patience'],
+                   help='the number of epochs that the performance does not improves after which the training stops')
+    p.add_argument('--num-workers', type=int, default=d['num_workers'],
+                   help='the number of processes to load the input graphs')
+    p.add_argument('--valid-split', type=float, default=None, help='the fraction for the validation set')
+    p.add_argument('--log-interval', type=int, default=100, help='print the loss after this number of iterations')
+    if model == 'MSGIFSR':
+        p.add_argument('--order', type=int, default=3, help='order of msg')
+        p.add_argument('--reducer', type=str, default='mean', help='method for reducer')
+        p.add_argument('--norm', type=bool, default=True, help='whether use l2 norm')
+        p.add_argument('--extra', action='store_true', help='whether use REnorm.')
+        p.add_argument('--fusion', action='store_true', help='whether use IFR.')
+    args = p.parse_args()
+    print(args)
+    return args
+
+
+def seed_all(seed=123):
+    import numpy as np
+    import torch
+    random.seed(seed)
+    os.environ['PYTHONHASHSEED'] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+
+def run(model_name):
+    args = parse(model_name)
+    seed_all(123)
+    import torch as th
+    from torch.utils.data import DataLoader, SequentialSampler
+    from src.models import LESSR, MSGIFSR, NISER, SRGNN
+    from src.utils.data.collate import (collate_fn_factory, collate_fn_factory_ccs, seq_to_ccs_graph,
+                                        seq_to_eop_multigraph, seq_to_session_graph, seq_to_shortcut_graph)
+    from src.utils.data.dataset import AugmentedDataset, read_dataset
+    from src.utils.train import TrainRunner
+
+    device = th.device('cuda' if th.cuda.is_available() else 'cpu')
+    print('reading dataset')
+    train_sessions, test_sessions, num_items = read_dataset(Path(args.dataset_dir))
+    if args.valid_split is not None:
+        num_valid = int(len(train_sessions) * args.valid_split)
+        test_sessions = train_sessions[-num_valid:]
+        train_sessions = train_sessions[:-num_valid]
+    train_set, test_set = AugmentedDataset(train_sessions), AugmentedDataset(test_sessions)
+    print(len(train_set))
+    print(len(test_set))
+    if model_name == 'LESSR':
+        fns = (seq_to_eop_multigraph, seq_to_shortcut_graph) if args.num_layers > 1 else (seq_to_eop_multigraph,)
+        collate_fn = collate_fn_factory(*fns)
+        model = LESSR(num_items, args.embedding_dim, args.num_layers, feat_drop=args.feat_drop)
+    elif model_name == 'MSGIFSR':
+        collate_fn = collate_fn_factory_ccs((seq_to_ccs_graph,), order=args.order)
+        model = MSGIFSR(num_items, args.dataset_dir, args.embedding_dim, args.num_layers, dropout=args.feat_drop,
+                        reducer=args.reducer, order=args.order, norm=args.norm, extra=args.extra, fusion=args.fusion,
+                        device=device)
+    else:
+        collate_fn = collate_fn_factory(seq_to_session_graph)
+        cls = NISER if model_name == 'NISER' else SRGNN
+        model = cls(num_items, args.embedding_dim, args.num_layers, feat_drop=args.feat_drop)
+    # reference loaders: LESSR / MSGIFSR train in time order (SequentialSampler), NISER shuffles; test shuffles
+    if model_name in ('LESSR', 'MSGIFSR'):
+        train_loader = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.num_workers,
+                                  collate_fn=collate_fn, sampler=SequentialSampler(train_set))
+    else:
+        train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
+                                  collate_fn=collate_fn)
+    test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
+                             collate_fn=collate_fn)
+    model = model.to(device)
+    print(model)
+    runner = TrainRunner(args.dataset_dir, model, train_loader, test_loader, device=device, lr=args.lr,
+                         weight_decay=args.weight_decay, patience=args.patience)
+    print('start training')
+    mrr, hit = runner.train(args.epochs, args.log_interval)
+    print('MRR@20\tHR@20')
+    print(f'{mrr * 100:.3f}%\t{hit * 100:.3f}%')

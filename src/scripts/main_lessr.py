@@ -1,0 +1,8 @@
+"""python -u scripts/main_lessr.py --dataset-dir ../datasets/<name>   (launched by start.sh)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from common import run  # noqa: E402
+
+run('LESSR')

@@ -1,0 +1,187 @@
+"""world_size-2 gloo test of the row-sharded (vocab-parallel) path on CPU: the collectives of
+sessionrec-pytorch_amd/dist.py must reassemble exactly what a single device computes on the
+concatenated global batch.  The per-rank compute is a plain-torch stand-in for the HIP kernels
+(the kernels themselves are covered by the -m gpu tests)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import pkg
+
+
+class TorchLocal:
+    """plain-torch restatement of dist.HipLocal's interface (test-only)"""
+
+    def gather_masked(self, table, idx):
+        idx = idx.long()
+        out = table[idx.clamp(min=0)]
+        return out * (idx >= 0).unsqueeze(1)
+
+    def segment_rows(self, g, uniq):
+        items, uptr, upos = uniq
+        U = items.numel()
+        out = torch.zeros(U, g.shape[1])
+        for u in range(U):
+            for e in range(int(uptr[u]), int(uptr[u + 1])):
+                out[u] += g[int(upos[e])]
+        return out
+
+    def add_rows(self, rows, items_local, dst):
+        m = items_local >= 0
+        dst.index_add_(0, items_local[m].long(), rows[m])
+
+    def _z(self, sr, table, cs):
+        z = sr @ table.t()
+        return z if cs is None else z * cs.unsqueeze(0)
+
+    def ce_fwd(self, sr, table, cs, labels_local, ws):
+        z = self._z(sr, table, cs)
+        lse = torch.logsumexp(z, dim=1)
+        lab = torch.zeros(sr.shape[0])
+        m = labels_local >= 0
+        lab[m] = z[m, labels_local[m].long()]
+        return lse, lab
+
+    def ce_bwd(self, sr, table, cs, labels_local, lse, gscale, dE, ws, cs_inv_scale):
+        z = self._z(sr, table, cs)
+        p = torch.exp(z - lse.unsqueeze(1))
+        m = labels_local >= 0
+        p[m, labels_local[m].long()] -= 1.0
+        p = p * (gscale / sr.shape[0])
+        if cs is not None:
+            p = p * cs.unsqueeze(0)
+        g = p.t() @ sr
+        if cs is not None:                      # chain rule of the row normalisation (srec_rownorm_project)
+            e = table * (cs * cs_inv_scale).unsqueeze(1)
+            g = g - e * (e * g).sum(1, keepdim=True)
+        dE.copy_(g)
+        return p @ table
+
+    def workspace(self, B, V, d, device):
+        return None
+
+
+class FakeModel:
+    def __init__(self, table):
+        self.w = torch.nn.Parameter(table.clone())
+        self.shard = None
+
+    def _table(self):
+        return self.w
+
+    def _state(self, B):
+        ops = pkg('ops')
+        st = self.__dict__.setdefault('_srec_state', {})
+        if 'tgrad' not in st:
+            st['tgrad'] = ops.TableGrad(self.w)
+        return st
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(world, V=150, d=16, B=6):
+    g = torch.Generator().manual_seed(5)
+    table = torch.randn(V, d, generator=g) * 0.3
+    per_rank = []
+    for r in range(world):
+        n = 9 + r * 2
+        idx = torch.randint(0, V, (n,), generator=g)
+        idx[0] = V - 1                                   # a row of the last shard, from every rank
+        sr_w = torch.randn(d, d, generator=g) * 0.3
+        labels = torch.randint(0, V, (B,), generator=g)
+        pick = torch.randint(0, n, (B,), generator=g)
+        gout = torch.randn(n, d, generator=g)
+        per_rank.append(dict(idx=idx, sr_w=sr_w, labels=labels, pick=pick, gout=gout))
+    return table, per_rank
+
+
+def _uniq(idx):
+    items, inv = torch.unique(idx, return_inverse=True)
+    pos = torch.argsort(idx, stable=True).int()
+    ptr_ = torch.zeros(items.numel() + 1, dtype=torch.int32)
+    ptr_[1:] = torch.bincount(inv).cumsum(0).int()
+    return items.int(), ptr_, pos
+
+
+def _reference(table, per_rank, cosine):
+    """single device, global batch = concatenation of the ranks' batches"""
+    W = table.clone().requires_grad_()
+    srs, labs, extra = [], [], 0.0
+    for b in per_rank:
+        rows = W[b['idx']]
+        srs.append(rows[b['pick']] @ b['sr_w'])
+        labs.append(b['labels'])
+        extra = extra + (rows * b['gout']).sum()
+    sr = torch.cat(srs)
+    lab = torch.cat(labs)
+    Wn = torch.nn.functional.normalize(W, dim=1) * 12.0 if cosine else W
+    loss = torch.nn.functional.cross_entropy(sr @ Wn.t(), lab)
+    (loss + 1e-3 * extra).backward()
+    return loss.item(), W.grad
+
+
+def _worker(rank, world, port, cosine, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        D = pkg('dist')
+        table, per_rank = _make(world)
+        b = per_rank[rank]
+        model = FakeModel(table)
+        vp = D.VocabParallel(model, local=TorchLocal())
+        shard = model._table()
+        cs = None
+        if cosine:
+            cs = 12.0 / shard.detach().norm(dim=1).clamp(min=1e-12)
+        rows = vp.lookup(shard, b['idx'].int(), _uniq(b['idx']))
+        sr = rows[b['pick']] @ b['sr_w']
+        loss = vp.loss(sr, shard, cs, b['labels'], 1.0 / 12.0)
+        (loss + 1e-3 * (rows * b['gout']).sum()).backward()
+        dE = vp.dE[:vp.n_live].clone()
+        q.put((rank, loss.item(), vp.lo, vp.hi, dE.numpy().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('cosine', [False, True])
+def test_vocab_parallel_two_ranks_match_single_device(cosine):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cosine, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table, per_rank = _make(world)
+    ref_loss, ref_grad = _reference(table, per_rank, cosine)
+    for rank, loss, lo, hi, dE in res:
+        dE = torch.tensor(dE)
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+        assert torch.allclose(dE, ref_grad[lo:hi], rtol=1e-4, atol=1e-6), (rank, (dE - ref_grad[lo:hi]).abs().max())
+
+
+def test_shard_bounds_cover_the_catalog():
+    D = pkg('dist')
+    for V in (1, 63, 64, 65, 3429, 37484, 10_000_000):
+        for world in (1, 2, 4, 8):
+            seen = 0
+            for r in range(world):
+                lo, hi, per = D.shard_bounds(V, world, r)
+                assert lo == min(V, r * per) and hi - lo <= per and per % 64 == 0
+                seen += hi - lo
+            assert seen == V
