@@ -252,9 +252,9 @@ def main():
     final_loss = loss.item()
 
     if rank == 0:
-        V = model._table().shape[0] if shard is None else shard.n_live
-        kt = time_dominant_kernel(model, B * world, V, d, dev)
-        flops_dE = 4.0 * B * world * V * d
+        Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
+        kt = time_dominant_kernel(model, B * world, Vk, d, dev)
+        flops_dE = 4.0 * B * world * Vk * d
         peak = 157.3                                      # TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
         roof = dict(bound='mfma', kernel='flash_ce_kernel<MODE_DE> (fused scoring/CE backward, dE pass)',
                     achieved=flops_dE / kt['dE'] / 1e12, peak=peak, unit='TFLOP/s',
