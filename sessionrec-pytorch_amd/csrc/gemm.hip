@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     __shared__ __attribute__((aligned(16))) float As[2][BK][SA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][SB];
 
-    const int Mfull = M;
+    const int Mfull = M, Kfull = K;
     if (dyn_mode == 1) M = dyn_count(dyn, M);
     if (dyn_mode == 2) K = dyn_count(dyn, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,63 +73,74 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[LA], rb[LB];
+    int va[LA], vb[LB];          // number of valid leading elements (0..4) of each prefetched float4
+    // Loads are UNCONDITIONAL from clamped (always valid) addresses; the masking happens when the registers
+    // are written to LDS, AFTER the MFMAs of the current tile.  (Predicated loads make hipcc wait vmcnt(0)
+    // inside every exec-mask branch: 4 dependent L2/HBM round trips per k-tile instead of one in flight
+    // under the matrix cores.)
+    const int Mc = M > 0 ? M - 1 : 0, Nc = N - 1;
+    auto nvalid = [](int first, int limit, bool ok) { return ok ? max(0, min(4, limit - first)) : 0; };
     auto gload = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < LA; ++p) {
             int idx = tid + p * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (A_KC) {
-                int m = m0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
-                if (m < M && k < K) {
-                    v = *reinterpret_cast<const float4*>(A + (size_t)m * a_rs + k);
-                    if (k + 3 >= K) { if (k + 1 >= K) v.y = 0.f; if (k + 2 >= K) v.z = 0.f; v.w = 0.f; }
-                }
+                const int m = m0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
+                const int kc = min(k, Kfull - 4);
+                ra[p] = *reinterpret_cast<const float4*>(A + (size_t)min(m, Mc) * a_rs + kc);
+                va[p] = nvalid(k, K, m < M && kc == k);
             } else {
-                int k = k0 + idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
-                if (m < M && k < K) v = *reinterpret_cast<const float4*>(A + (size_t)k * a_cs + m);
+                const int k = k0 + idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
+                const int mc = min(m, Mfull - 4);
+                ra[p] = *reinterpret_cast<const float4*>(A + (size_t)min(k, Kfull - 1) * a_cs + mc);
+                va[p] = nvalid(m, M, k < K && mc == m);
             }
-            ra[p] = v;
         }
 #pragma unroll
         for (int p = 0; p < LB; ++p) {
             int idx = tid + p * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (B_KC) {
-                int n = n0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
-                if (n < N && k < K) {
-                    v = *reinterpret_cast<const float4*>(B + (size_t)n * b_rs + k);
-                    if (k + 3 >= K) { if (k + 1 >= K) v.y = 0.f; if (k + 2 >= K) v.z = 0.f; v.w = 0.f; }
-                }
+                const int n = n0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
+                const int kc = min(k, Kfull - 4);
+                rb[p] = *reinterpret_cast<const float4*>(B + (size_t)min(n, Nc) * b_rs + kc);
+                vb[p] = nvalid(k, K, n < N && kc == k);
             } else {
-                int k = k0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
-                if (n < N && k < K) v = *reinterpret_cast<const float4*>(B + (size_t)k * b_cs + n);
+                const int k = k0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+                const int nc = min(n, N - 4);
+                rb[p] = *reinterpret_cast<const float4*>(B + (size_t)min(k, Kfull - 1) * b_cs + nc);
+                vb[p] = nvalid(n, N, k < K && nc == n);
             }
-            rb[p] = v;
         }
+    };
+    auto masked = [](float4 v, int nv) {
+        v.x = nv > 0 ? v.x : 0.f; v.y = nv > 1 ? v.y : 0.f; v.z = nv > 2 ? v.z : 0.f; v.w = nv > 3 ? v.w : 0.f;
+        return v;
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < LA; ++p) {
             int idx = tid + p * 256;
+            const float4 v = masked(ra[p], va[p]);
             if (A_KC) {
                 int m = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
-                As[buf][k + 0][m] = ra[p].x; As[buf][k + 1][m] = ra[p].y;
-                As[buf][k + 2][m] = ra[p].z; As[buf][k + 3][m] = ra[p].w;
+                As[buf][k + 0][m] = v.x; As[buf][k + 1][m] = v.y;
+                As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
             } else {
                 int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
-                *reinterpret_cast<float4*>(&As[buf][k][m]) = ra[p];
+                *reinterpret_cast<float4*>(&As[buf][k][m]) = v;
             }
         }
 #pragma unroll
         for (int p = 0; p < LB; ++p) {
             int idx = tid + p * 256;
+            const float4 v = masked(rb[p], vb[p]);
             if (B_KC) {
                 int n = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
-                Bs[buf][k + 0][n] = rb[p].x; Bs[buf][k + 1][n] = rb[p].y;
-                Bs[buf][k + 2][n] = rb[p].z; Bs[buf][k + 3][n] = rb[p].w;
+                Bs[buf][k + 0][n] = v.x; Bs[buf][k + 1][n] = v.y;
+                Bs[buf][k + 2][n] = v.z; Bs[buf][k + 3][n] = v.w;
             } else {
                 int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
-                *reinterpret_cast<float4*>(&Bs[buf][k][n]) = rb[p];
+                *reinterpret_cast<float4*>(&Bs[buf][k][n]) = v;
             }
         }
     };

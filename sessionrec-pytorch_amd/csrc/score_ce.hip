@@ -51,35 +51,57 @@ struct Tile {
     static constexpr int NV = 2 * NT;   // float4 per thread per 64-row tile
 };
 
+// Tile staging.  Thread t owns the float4 column c = 4*(t % Q) of rows (t / Q) + p*(256/Q): all address
+// arithmetic is loop-invariant (one base pointer + compile-time strides), loads are unconditional from a
+// clamped row and zeroed afterwards, so a full tile costs 2*NT global_load_dwordx4 + 8*NT ds_write_b32 and
+// almost no VALU (with one wave per SIMD every VALU cycle is a cycle the matrix pipe idles).
 template <int NT>
 __device__ __forceinline__ void gload_tile(float4 (&regs)[2 * NT], const float* __restrict__ src, int ld,
                                            int row0, int nrows, int d, int tid) {
-    constexpr int Q = NT * 8;   // float4 per row
+    constexpr int Q = NT * 8, RS = 256 / Q;            // float4 per row, row stride between a thread's loads
+    const int last = nrows - 1;
+    if constexpr (256 % Q == 0) {
+        const int r = tid / Q, c = (tid % Q) * 4;
+        const int cc = c < d ? c : 0;
 #pragma unroll
-    for (int p = 0; p < 2 * NT; ++p) {
-        const int idx = tid + p * 256;
-        const int row = idx / Q, c = (idx % Q) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + row < nrows && c < d) v = *reinterpret_cast<const float4*>(src + (size_t)(row0 + row) * ld + c);
-        regs[p] = v;
+        for (int p = 0; p < 2 * NT; ++p) {
+            const int row = row0 + r + p * RS;
+            regs[p] = *reinterpret_cast<const float4*>(src + (size_t)min(row, last) * ld + cc);
+        }
+    } else {                                           // NT = 3, 6: rows do not divide the 256 threads evenly
+#pragma unroll
+        for (int p = 0; p < 2 * NT; ++p) {
+            const int idx = tid + p * 256;
+            const int row = row0 + idx / Q, c = (idx % Q) * 4;
+            regs[p] = *reinterpret_cast<const float4*>(src + (size_t)min(row, last) * ld + (c < d ? c : 0));
+        }
     }
 }
 
 template <int NT>
-__device__ __forceinline__ void lstore_tile(float* __restrict__ tile, const float4 (&regs)[2 * NT], int tid) {
-    constexpr int Q = NT * 8, LD = NT * 32 + 1;
-    const int rot = (tid >> 3) & 3;   // rotate the component order per 8-lane group: conflict-free ds_write_b32
+__device__ __forceinline__ void lstore_tile(float* __restrict__ tile, const float4 (&regs)[2 * NT], int row0,
+                                            int nrows, int d, int tid) {
+    constexpr int Q = NT * 8, RS = 256 / Q, LD = NT * 32 + 1;
+    if constexpr (256 % Q == 0) {
+        const int r = tid / Q, c = (tid % Q) * 4;
+        const bool cok = c < d;
+        float* dst = tile + r * LD + c;
 #pragma unroll
-    for (int p = 0; p < 2 * NT; ++p) {
-        const int idx = tid + p * 256;
-        const int row = idx / Q, c = (idx % Q) * 4;
-        float* dst = tile + row * LD + c;
-        const float4 v = regs[p];
+        for (int p = 0; p < 2 * NT; ++p) {
+            const bool ok = cok && (row0 + r + p * RS < nrows);
+            const float4 v = regs[p];
+            float* q = dst + p * RS * LD;
+            q[0] = ok ? v.x : 0.f; q[1] = ok ? v.y : 0.f; q[2] = ok ? v.z : 0.f; q[3] = ok ? v.w : 0.f;
+        }
+    } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int jp = (j + rot) & 3;
-            const float val = jp == 0 ? v.x : (jp == 1 ? v.y : (jp == 2 ? v.z : v.w));
-            dst[jp] = val;
+        for (int p = 0; p < 2 * NT; ++p) {
+            const int idx = tid + p * 256;
+            const int row = idx / Q, c = (idx % Q) * 4;
+            const bool ok = c < d && (row0 + row < nrows);
+            const float4 v = regs[p];
+            float* q = tile + row * LD + c;
+            q[0] = ok ? v.x : 0.f; q[1] = ok ? v.y : 0.f; q[2] = ok ? v.z : 0.f; q[3] = ok ? v.w : 0.f;
         }
     }
 }
@@ -107,16 +129,17 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
         Xsrc = a.E; ldx = a.ld_e; nx = a.V; x0 = blockIdx.x * 64;
         Ysrc = a.sr; ldy = a.ld_sr; ny = Bd; ybeg = 0; yend = Bd;
     } else {
-        Xsrc = a.sr; ldx = a.ld_sr; nx = Bd; x0 = blockIdx.x * 64;
+        Xsrc = a.sr; ldx = a.ld_sr; nx = Bd; x0 = blockIdx.y * 64;
         Ysrc = a.E; ldy = a.ld_e; ny = a.V;
-        ybeg = blockIdx.y * a.chunks_per_range * 64;
+        ybeg = blockIdx.x * a.chunks_per_range * 64;
         yend = min(a.V, ybeg + a.chunks_per_range * 64);
     }
     const bool x_empty = (x0 >= nx);
+    const int tile_id = ITEMS_X ? blockIdx.x : 0;
 
     float4 regs[2 * NT];
-    gload_tile<NT>(regs, Xsrc, ldx, x0, nx, d, tid);
-    lstore_tile<NT>(Xs, regs, tid);
+    gload_tile<NT>(regs, Xsrc, ldx, x0, nx > 0 ? nx : 1, d, tid);
+    lstore_tile<NT>(Xs, regs, x0, nx, d, tid);
 
     float gs = 1.f;
     if (HAS_ACC) {
@@ -147,27 +170,63 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
     if (ybeg < yend && !x_empty) gload_tile<NT>(regs, Ysrc, ldy, ybeg, yend, d, tid);
 
     for (int y0 = ybeg; y0 < yend && !x_empty; y0 += 64) {
-        lstore_tile<NT>(Ys, regs, tid);
+        lstore_tile<NT>(Ys, regs, y0, yend, d, tid);
         __syncthreads();                                                   // (A) Xs / Ys visible
         if (y0 + 64 < yend) gload_tile<NT>(regs, Ysrc, ldy, y0 + 64, yend, d, tid);
 
-        // ---- S = X Y^T for this wave's 32x32 sub-tile
+        // per-column quantities of this chunk: issued before the MFMAs so their L2 latency hides under them
+        const int yj = y0 + sj * 32 + l31;           // global Y row of this lane's column
+        const bool yvalid = yj < yend;
+        float yq = 1.f; int ylab = -1;
+        if (MODE == MODE_FWD) {
+            ylab = yvalid ? a.labels[yj] : -1;
+        } else if (MODE == MODE_DE) {
+            yq = yvalid ? a.lse[yj] : 0.f;
+            ylab = yvalid ? a.labels[yj] : -1;
+        } else {
+            yq = (a.cs != nullptr && yvalid) ? a.cs[yj] : 1.f;
+        }
+
+        // ---- S = X Y^T for this wave's 32x32 sub-tile.  One wave per SIMD => nothing else hides the LDS
+        // latency: operands are read one 8-step block AHEAD of the MFMAs that consume them (two register
+        // sets), so the matrix pipe issues back to back.
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         {
             const float* xa = Xs + (si * 32 + l31) * LD + half;
             const float* yb = Ys + (sj * 32 + l31) * LD + half;
-#pragma unroll 8
-            for (int k2 = 0; k2 < DP / 2; ++k2)
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * k2], yb[2 * k2], s, 0, 0, 0);
+            constexpr int UB = 8, NBLK = DP / 2 / UB;
+            float a0[UB], b0[UB], a1[UB], b1[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { a0[u] = xa[2 * u]; b0[u] = yb[2 * u]; }
+            for (int blk = 0; blk < NBLK; blk += 2) {
+                {
+                    const float* xn = xa + 2 * UB * (blk + 1);
+                    const float* yn = yb + 2 * UB * (blk + 1);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { a1[u] = xn[2 * u]; b1[u] = yn[2 * u]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (blk + 2 < NBLK) {
+                    const float* xn = xa + 2 * UB * (blk + 2);
+                    const float* yn = yb + 2 * UB * (blk + 2);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { a0[u] = xn[2 * u]; b0[u] = yn[2 * u]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
-        const int yj = y0 + sj * 32 + l31;           // global Y row of this lane's column
-        const bool yvalid = yj < yend;
         if (MODE == MODE_FWD) {
             // per-session (column) stats over this wave's 32 items
-            const int lab = yvalid ? a.labels[yj] : -1;
+            const int lab = ylab;
             float m = -INFINITY;
             float z[16];
 #pragma unroll
@@ -196,13 +255,13 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
                     const float mm = fmaxf(m0, m1);
                     const float mms = (mm == -INFINITY) ? 0.f : mm;
                     const float ll = l0 * expf(m0 - mms) + l1 * expf(m1 - mms);
-                    a.part_m[(size_t)blockIdx.x * a.B + y] = mm;
-                    a.part_l[(size_t)blockIdx.x * a.B + y] = ll;
+                    a.part_m[(size_t)tile_id * a.B + y] = mm;
+                    a.part_l[(size_t)tile_id * a.B + y] = ll;
                 }
             }
             __syncthreads();                                               // (C)
         } else if (MODE == MODE_LOGP) {
-            const float csy = (a.cs != nullptr && yvalid) ? a.cs[yj] : 1.f;
+            const float csy = yq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int sess = x0 + si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -211,14 +270,6 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
             __syncthreads();                                               // (C)
         } else {
             // ---- P tile
-            float yq; int ylab;
-            if (ITEMS_X) {                    // Y = sessions
-                yq = yvalid ? a.lse[yj] : 0.f;
-                ylab = yvalid ? a.labels[yj] : -1;
-            } else {                          // Y = items
-                yq = (a.cs != nullptr && yvalid) ? a.cs[yj] : 1.f;
-                ylab = 0;
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int xl = si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -227,29 +278,43 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
                 if (xi < nx && yvalid) {
                     if (ITEMS_X) {
                         const float zz = xq[r] * s[r];
-                        p = (expf(zz - yq) - (ylab == xi ? 1.f : 0.f)) * gs * xq[r];
+                        p = (__expf(zz - yq) - (ylab == xi ? 1.f : 0.f)) * gs * xq[r];
                     } else {
                         const float zz = yq * s[r];
-                        p = (expf(zz - xq[r]) - (xlab[r] == yj ? 1.f : 0.f)) * gs * yq;
+                        p = (__expf(zz - xq[r]) - (xlab[r] == yj ? 1.f : 0.f)) * gs * yq;
                     }
                 }
                 Ps[xl * PLD + sj * 32 + l31] = p;
             }
             __syncthreads();                                               // (B) P visible
-            // ---- ACC += P Y : this wave owns row block si, col blocks sj, sj+2, ...
+            // ---- ACC += P Y : this wave owns row block si, col blocks sj, sj+2, ...  (operands of step
+            // k2+1 are read while the MFMAs of step k2 run)
             {
                 const float* pa = Ps + (si * 32 + l31) * PLD + half;
                 const float* yb = Ys + half * LD + sj * 32 + l31;
-#pragma unroll 4
-                for (int k2 = 0; k2 < 32; ++k2) {
-                    const float av = pa[2 * k2];
+                float av0, av1, bv0[NCB], bv1[NCB];
+                av0 = pa[0];
 #pragma unroll
-                    for (int c = 0; c < NCB; ++c) {
-                        if (sj + 2 * c < NT) {
-                            const float bv = yb[(2 * k2) * LD + c * 64];
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c], 0, 0, 0);
-                        }
+                for (int c = 0; c < NCB; ++c) bv0[c] = (sj + 2 * c < NT) ? yb[c * 64] : 0.f;
+                for (int k2 = 0; k2 < 32; k2 += 2) {
+                    av1 = pa[2 * (k2 + 1)];
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) bv1[c] = (sj + 2 * c < NT) ? yb[(2 * (k2 + 1)) * LD + c * 64] : 0.f;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c)
+                        if (sj + 2 * c < NT) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[c], acc[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k2 + 2 < 32) {
+                        av0 = pa[2 * (k2 + 2)];
+#pragma unroll
+                        for (int c = 0; c < NCB; ++c) bv0[c] = (sj + 2 * c < NT) ? yb[(2 * (k2 + 2)) * LD + c * 64] : 0.f;
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c)
+                        if (sj + 2 * c < NT) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[c], acc[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();                                               // (C) before Ys/Ps reuse
@@ -269,7 +334,7 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
                 if (MODE == MODE_DE) {
                     if (xi < a.V) a.dE[(size_t)xi * a.ld_de + col] = acc[c][r];
                 } else {
-                    if (xi < a.B) a.part_dsr[((size_t)blockIdx.y * a.B + xi) * d + col] = (xi < nx) ? acc[c][r] : 0.f;
+                    if (xi < a.B) a.part_dsr[((size_t)blockIdx.x * a.B + xi) * d + col] = (xi < nx) ? acc[c][r] : 0.f;
                 }
             }
         }
@@ -416,7 +481,7 @@ extern "C" int srec_score_ce_bwd(const float* sr, int ld_sr, const float* E, int
     if (!(parts & 2)) return 0;
     const int R = pick_ranges(B, V);
     a.chunks_per_range = cdiv(cdiv(V, 64), R);
-    rc = launch_mode<MODE_DSR>(a, dim3(cdiv(B, 64), R), st);
+    rc = launch_mode<MODE_DSR>(a, dim3(R, cdiv(B, 64)), st);
     if (rc) return rc;
     const size_t n = (size_t)B * d;
     hipLaunchKernelGGL(dsr_reduce_kernel, dim3((unsigned)cdiv((int)(n / 4), 256)), dim3(256), 0, st, ws_dsr, R, n, dsr);
@@ -435,5 +500,5 @@ extern "C" int srec_score_logp(const float* sr, int ld_sr, const float* E, int l
     a.B = B; a.V = V; a.d = d; a.logp = logp; a.ld_logp = ld_logp;
     const int R = pick_ranges(B, V);
     a.chunks_per_range = cdiv(cdiv(V, 64), R);
-    return launch_mode<MODE_LOGP>(a, dim3(cdiv(B, 64), R), st);
+    return launch_mode<MODE_LOGP>(a, dim3(R, cdiv(B, 64)), st);
 }
