@@ -47,7 +47,7 @@ def synth_sessions(n_sessions, V, mean_len, max_len, rng):
     return out
 
 
-def make_batches(model_name, order, n_batches, B, V, max_len, seed):
+def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False):
     ds = importlib.import_module('sessionrec-pytorch_amd.dataset')
     col = importlib.import_module('sessionrec-pytorch_amd.collate')
     rng = np.random.default_rng(seed)
@@ -56,13 +56,18 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed):
     arr[:] = sessions
     data = ds.AugmentedDataset(arr)
     assert len(data) >= n_batches * B, (len(data), n_batches * B)
-    if model_name in ('SRGNN', 'NISER'):
-        fn = col.collate_fn_factory(col.seq_to_session_graph)
-    elif model_name == 'LESSR':
-        fn = col.collate_fn_factory(col.seq_to_eop_multigraph)
-    else:
-        fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), order)
     samples = [[data[b * B + i] for i in range(B)] for b in range(n_batches)]
+    caps = None
+    if padded:                          # capacities from the data (max over the batches + 10 %), as a loader would
+        mx = max(sum(len(set(s)) for s, _ in smp) for smp in samples)
+        n = (int(mx * 1.1) + 255) // 256 * 256
+        caps = dict(B=B, N=n, E=n, U=n)
+    if model_name in ('SRGNN', 'NISER'):
+        fn = col.collate_fn_factory(col.seq_to_session_graph, caps=caps)
+    elif model_name == 'LESSR':
+        fn = col.collate_fn_factory(col.seq_to_eop_multigraph, caps=caps)
+    else:
+        fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), order, caps=caps)
     return [fn(s) for s in samples], samples
 
 
@@ -189,6 +194,7 @@ def main():
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     ap.add_argument('--kernel-only', action='store_true', help='only launch the scoring/CE kernels (PMC collection target)')
     args = ap.parse_args()
 
@@ -213,7 +219,8 @@ def main():
         print(json.dumps(time_dominant_kernel(model, B, V, d, dev, iters=5)))
         return
     n_batches = args.steps + args.warmup
-    batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank)
+    use_graph = (not args.no_graph) and args.model in ('SRGNN', 'NISER', 'MSGIFSR') and world == 1
+    batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank, padded=use_graph)
     torch.manual_seed(123)
     model = build_model(sp, args.model, V, d, args.order)
     state = {k: v.clone() for k, v in model.state_dict().items()}
@@ -237,6 +244,12 @@ def main():
         opt.step()
         return loss
 
+    if use_graph:
+        G = importlib.import_module('sessionrec-pytorch_amd.graph')
+        gstep = G.GraphedTrainStep(model, opt, dev_batches[0][0], dev_batches[0][1])
+
+        def step(b):                                   # noqa: F811  (replay of the captured step)
+            return gstep(b[0], b[1])
     for i in range(args.warmup):
         step(dev_batches[i])
     torch.cuda.synchronize()
@@ -272,7 +285,7 @@ def main():
         out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=world * B * args.steps / dt,
                    unit='sessions/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='f32', data='synthetic',
+                   dtype='f32', data='synthetic', launch='hipGraph replay' if use_graph else 'eager',
                    config=dict(workload='%s training step, synthetic Yoochoose-1/64 shape (V=%d items, d=%d, batch %d per GPU, '
                                         'session length<=20%s)' % (args.model, V, d, B,
                                                                    ', order %d' % args.order if args.model == 'MSGIFSR' else ''),

@@ -48,13 +48,20 @@ class FlatBatch:
         buf = np.zeros(off, dtype=np.int32)
         slots = {}
         for i, (name, val) in enumerate(counts.items()):
-            assert i < HEADER
+            assert i < HEADER, 'too many header counts'
             slots[name] = i
             buf[i] = val
         for name, arr in fields.items():
-            o = layout[name][0]
+            o, cap, _ = layout[name]
             a = np.asarray(arr).reshape(-1)
+            assert a.size <= cap, (name, a.size, cap)
             buf[o:o + a.size] = a
+            if a.size < cap:
+                # capacity padding: offset arrays repeat their last value (empty segments), index arrays -1
+                if name.endswith('ptr') or name.startswith(('seg', 'eseg', 'cat_seg')):
+                    buf[o + a.size:o + cap] = a[-1] if a.size else 0
+                elif name.startswith(('iid', 'gidx', 'uniq_items', 'cat_perm', 'last')):
+                    buf[o + a.size:o + cap] = -1
         m = dict(meta)
         m['counts'] = {k: int(v) for k, v in counts.items()}
         m['slots'] = slots
@@ -112,6 +119,10 @@ class FlatBatch:
         """1-element int32 device view holding the live count `name` (for `dyn*` kernel arguments)."""
         s = self.meta['slots'][name]
         return self.buf[s:s + 1]
+
+    def dynp(self, name):
+        """`dyn(name)` for capacity-padded batches, None for exact layouts (kernels then use the static extent)."""
+        return self.dyn(name) if self.meta.get('padded') else None
 
     @property
     def B(self):

@@ -181,28 +181,52 @@ def batch_homogeneous(graphs, caps=None):
         counts['C'] = len(chptr) - 1
     if kind == 'session':
         fields['ew'] = _cat([g[5] for g in graphs])
-    meta = dict(kind=kind, B=B, max_nodes=int(nn.max()) if B else 0)
-    return FlatBatch.build(fields, counts, meta, caps)
+    Bc = caps['B'] if caps else B
+    meta = dict(kind=kind, B=Bc, max_nodes=int(nn.max()) if B else 0, padded=caps is not None)
+    fcaps = None
+    if caps:
+        Nc, Ec, Uc = caps['N'], caps['E'], caps['U']
+        assert N <= Nc and E <= Ec, ('capacity exceeded', N, Nc, E, Ec)
+        fcaps = dict(seg=Bc + 1, eseg=Bc + 1, esrc=Ec, edst=Ec, in_ptr=Nc + 1, in_idx=Ec, out_ptr=Nc + 1, out_idx=Ec,
+                     iid=Nc, last=Bc, uniq_items=Uc, uniq_ptr=Uc + 1, uniq_pos=Nc, uniq_cptr=Uc + 1,
+                     chunk_ptr=Uc + Nc // CHUNK + 2, ew=Ec)
+        fcaps = {k: v for k, v in fcaps.items() if k in fields}
+    return FlatBatch.build(fields, counts, meta, fcaps)
 
 
 def batch_ccs(graphs, caps=None):
+    """caps (optional): {'B': sessions, 'N': nodes per order, 'E': edges per relation, 'U': distinct items}
+    -> capacity-padded layout whose offsets do not depend on the batch (hipGraph replay)."""
     K = graphs[0][1]
     B = len(graphs)
+    Bc = caps['B'] if caps else B
     fields, counts = {}, dict(B=B)
-    segs = {}
+    segs, ncap = {}, {}
     for k in range(1, K + 1):
         nn = np.array([g[2][k] for g in graphs], dtype=np.int64)
         seg = np.zeros(B + 1, dtype=np.int64)
         np.cumsum(nn, out=seg[1:])
         segs[k] = seg
+        ncap[k] = caps['N'] if caps else int(seg[-1])
+        assert seg[-1] <= ncap[k], ('node capacity exceeded', k, int(seg[-1]), ncap[k])
         fields['seg%d' % k] = seg
         iid = np.concatenate([np.asarray(g[3][k], dtype=np.int64).reshape(-1, k) for g in graphs], axis=0)
         fields['iid%d' % k] = iid if k > 1 else iid.reshape(-1)
         fields['last%d' % k] = np.array([g[4][k] + seg[i] for i, g in enumerate(graphs)], dtype=np.int64)
         counts['N%d' % k] = int(seg[-1])
-    # one fused embedding lookup for all orders: rows = [iid1 | iid2.flat | iid3.flat ...]
-    gidx = _cat([fields['iid%d' % k] for k in range(1, K + 1)])
-    ui, up, upos = _uniq_csr(gidx)
+        counts['GK%d' % k] = int(seg[-1]) * k
+    # one fused embedding lookup for all orders: rows = [iid1 | iid2.flat | iid3.flat ...], every order's block
+    # padded to its capacity (idx -1 -> zero row) so the block offsets are static
+    blocks = []
+    for k in range(1, K + 1):
+        blk = np.full(ncap[k] * k, -1, dtype=np.int64)
+        flat = np.asarray(fields['iid%d' % k]).reshape(-1)
+        blk[:flat.size] = flat
+        blocks.append(blk)
+    gidx = np.concatenate(blocks)
+    livepos = np.nonzero(gidx >= 0)[0]
+    ui, up, upos = _uniq_csr(gidx[livepos])
+    upos = livepos[upos].astype(np.int32)
     cptr, chptr = _chunk_csr(up)
     fields.update(gidx=gidx, uniq_items=ui, uniq_ptr=up, uniq_pos=upos, uniq_cptr=cptr, chunk_ptr=chptr)
     counts['G'] = len(gidx)
@@ -220,8 +244,9 @@ def batch_ccs(graphs, caps=None):
         fields.update({name + '_src': src, name + '_dst': dst, name + '_in_ptr': in_ptr, name + '_in_idx': in_idx,
                        name + '_out_ptr': out_ptr, name + '_out_idx': out_idx})
         counts['E_' + name] = len(src)
-    # readout: per session, nodes of all orders concatenated [s1 | s2 | ...] (msgifsr.py:135)
-    offs = np.concatenate([[0], np.cumsum([segs[k][-1] for k in range(1, K + 1)])])
+    # readout: per session, nodes of all orders concatenated [s1 | s2 | ...] (msgifsr.py:135); rows of the
+    # stacked [h1 ; h2 ; ...] tensor whose blocks start at the (capacity) offsets below
+    offs = np.concatenate([[0], np.cumsum([ncap[k] for k in range(1, K + 1)])])
     perm = []
     cat_seg = np.zeros(B + 1, dtype=np.int64)
     for i in range(B):
@@ -229,28 +254,54 @@ def batch_ccs(graphs, caps=None):
             perm.append(np.arange(segs[k][i], segs[k][i + 1]) + offs[k - 1])
         cat_seg[i + 1] = cat_seg[i] + sum(int(segs[k][i + 1] - segs[k][i]) for k in range(1, K + 1))
     perm = _cat(perm)
-    inv = np.empty_like(perm)
+    inv = np.full(int(offs[-1]), -1, dtype=np.int64)
     inv[perm] = np.arange(len(perm))
     fields.update(cat_perm=perm, cat_inv=inv, cat_seg=cat_seg)
     for k in range(1, K + 1):
         fields['lastcat%d' % k] = fields['last%d' % k] + offs[k - 1]
     counts['NT'] = len(perm)
     max_nodes = int((cat_seg[1:] - cat_seg[:-1]).max()) if B else 0
-    meta = dict(kind='ccs', order=K, B=B, rels=rel_names, max_nodes=max_nodes)
-    return FlatBatch.build(fields, counts, meta, caps)
+    meta = dict(kind='ccs', order=K, B=Bc, rels=rel_names, max_nodes=max_nodes, ncap=ncap, padded=caps is not None)
+    fcaps = None
+    if caps:
+        N, E, U = caps['N'], caps['E'], caps['U']
+        fcaps = dict(uniq_items=U, uniq_ptr=U + 1, uniq_pos=len(gidx), uniq_cptr=U + 1,
+                     chunk_ptr=U + len(gidx) // CHUNK + 2, cat_perm=N * K, cat_seg=Bc + 1)
+        for k in range(1, K + 1):
+            fcaps.update({'seg%d' % k: Bc + 1, 'iid%d' % k: N * k, 'last%d' % k: Bc, 'lastcat%d' % k: Bc})
+        for _, name in rel_names:
+            fcaps.update({name + '_src': E, name + '_dst': E, name + '_in_idx': E, name + '_out_idx': E,
+                          name + '_in_ptr': N + 1, name + '_out_ptr': N + 1})
+    return FlatBatch.build(fields, counts, meta, fcaps)
 
 
-def collate_fn_factory(*seq_to_graph_fns):
+def _labels(labels, caps):
+    lab = np.asarray(labels, dtype=np.int64)
+    if caps and len(lab) < caps['B']:
+        lab = np.concatenate([lab, np.zeros(caps['B'] - len(lab), dtype=np.int64)])
+    return torch.as_tensor(lab)
+
+
+def collate_fn_factory(*seq_to_graph_fns, caps=None):
+    """caps=None: exact layouts.  caps={'B','N','E','U'}: capacity-padded layouts with batch-independent
+    offsets (every batch then fits the same device buffer and the same captured hipGraph)."""
     def collate_fn(samples):
         seqs, labels = zip(*samples)
-        inputs = [batch_homogeneous([fn(s) for s in seqs]) for fn in seq_to_graph_fns]
-        return inputs, torch.as_tensor(np.asarray(labels, dtype=np.int64))
+        inputs = [batch_homogeneous([fn(s) for s in seqs], caps) for fn in seq_to_graph_fns]
+        return inputs, _labels(labels, caps)
     return collate_fn
 
 
-def collate_fn_factory_ccs(seq_to_graph_fns, order):
+def collate_fn_factory_ccs(seq_to_graph_fns, order, caps=None):
     def collate_fn(samples):
         seqs, labels = zip(*samples)
-        inputs = [batch_ccs([fn(s, order) for s in seqs]) for fn in seq_to_graph_fns]
-        return inputs, torch.as_tensor(np.asarray(labels, dtype=np.int64))
+        inputs = [batch_ccs([fn(s, order) for s in seqs], caps) for fn in seq_to_graph_fns]
+        return inputs, _labels(labels, caps)
     return collate_fn
+
+
+def default_caps(batch_size, max_len=20, headroom=1.0):
+    """worst-case capacities for sessions of <= max_len clicks"""
+    n = int(batch_size * max_len * headroom)
+    n = (n + 255) // 256 * 256
+    return dict(B=batch_size, N=n, E=n, U=n)

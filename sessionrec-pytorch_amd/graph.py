@@ -1,0 +1,90 @@
+"""Whole-step hipGraph: the ~500 kernel launches of one training step (gather -> encoder -> fused
+scoring/CE forward+backward -> fused Adam) are captured ONCE on capacity-padded, statically placed
+tensors and replayed per batch.  Per step the host then does: one H2D copy of the FlatBatch buffer
+into the static device buffer, a host-only refresh of the Adam scalars, one hipGraphLaunch.
+
+This is what makes the launch-bound step GPU-bound: every kernel reads its live extents from the
+batch header in device memory (`dyn*` arguments of include/srec.h), so the same launch sequence is
+valid for every batch that fits the capacities.  (MI355X guide: capture launch-bound inner loops in
+hipGraphs; no tracing compiler involved - the graph is the recorded launch sequence of our own C ABI.)
+"""
+import torch
+
+from .batch import FlatBatch
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, inputs, labels, after_backward=None, warmup=2):
+        """inputs: list of capacity-padded FlatBatch on the GPU (their layout fixes the graph), labels (B,)"""
+        assert all(x.meta.get('padded') for x in inputs), 'graph capture needs capacity-padded batches (collate caps=...)'
+        self.model, self.opt, self.after_backward = model, optimizer, after_backward
+        self.static_inputs = [FlatBatch(x.buf.clone(), x.layout, dict(x.meta)) for x in inputs]
+        self.static_labels = labels.clone()
+        self._sig = [self._signature(x) for x in inputs]
+        # ---- eager warm-up on a side stream (lazy allocations, LDS opt-in attributes, Adam state), then undo
+        #      its effect on parameters / optimizer state so capture does not change the training trajectory
+        snap_p = [p.detach().clone() for p in model.parameters()]
+        snap_b = [b.detach().clone() for b in model.buffers()]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), snap_p):
+                p.copy_(q)
+            for b, q in zip(model.buffers(), snap_b):
+                b.copy_(q)
+            for st in optimizer.state.values():
+                st['step'] = 0
+                st['exp_avg'].zero_()
+                st['exp_avg_sq'].zero_()
+        ms = model.__dict__.get('_srec_state')
+        if ms is not None:
+            ms['cs_fresh'] = False
+        # ---- capture
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        self._pending_advance = None
+        with torch.cuda.graph(self.graph):
+            self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
+            self.loss.backward()
+            if self.after_backward is not None:
+                self.after_backward()
+            work = optimizer._work()
+            optimizer._frozen = work
+            # step counters are bumped on the host before every replay (advance()); during capture they
+            # only need to be consistent, so bump once here and take it back after the capture
+            optimizer.advance(work)
+            optimizer.launch(work)
+        for _, _, items in work:
+            for _, _, st in items:
+                st['step'] -= 1
+        self.work = work
+
+    @staticmethod
+    def _signature(x):
+        rels = tuple(x.count('E_' + n) > 0 for _, n in x.meta.get('rels', ()))
+        return (tuple(sorted(x.layout.items())), rels, x.meta.get('kind'), x.meta.get('order'))
+
+    def _eager(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
+        loss.backward()
+        if self.after_backward is not None:
+            self.after_backward()
+        self.opt.step()
+        return loss
+
+    def __call__(self, inputs, labels):
+        for st, x, sig in zip(self.static_inputs, inputs, self._sig):
+            if self._signature(x) != sig:
+                raise RuntimeError('batch layout / relation pattern differs from the captured one')
+            st.buf.copy_(x.buf, non_blocking=True)
+            st.meta['counts'] = x.meta['counts']
+        self.static_labels.copy_(labels, non_blocking=True)
+        self.opt.advance(self.work)
+        self.graph.replay()
+        return self.loss

@@ -54,14 +54,14 @@ class SemanticExpander(nn.Module):
         if reducer == 'concat':
             self.Ws = nn.ModuleList([nn.Linear(input_dim * (i + 1), input_dim) for i in range(1, order)])
 
-    def forward(self, x, k, dyn=None):
+    def forward(self, x, k, dyn=None, dyn_rows=None):
         """x: [N_k * k, d] gathered gram rows (contiguous) -> [N_k, d]"""
         if self.reducer != 'mean':
             raise NotImplementedError("reducer '%s' is not on the HIP path yet (only 'mean')" % self.reducer)
         gru = self.GRUs[k - 2]
         d = self.input_dim
         n = x.shape[0] // k
-        GI = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0).view(n, k, 3 * d)
+        GI = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0, dyn_rows).view(n, k, 3 * d)
         h = None
         for t in range(k):
             gi = GI[:, t, :]
@@ -103,6 +103,7 @@ class MSHGNN(nn.Module):
         K = self.order
         outs = {k: [] for k in range(1, K + 1)}
         biases = {k: [] for k in range(1, K + 1)}
+        dN = {k: mg.dynp('N%d' % k) for k in range(1, K + 1)}
         for conv, reverse in ((self.conv1, False), (self.conv2, True)):
             proj = {}                                   # (module name, type) -> fc(dropout(feat))
             dropped = {}
@@ -112,7 +113,7 @@ class MSHGNN(nn.Module):
                 if key not in proj:
                     if k not in dropped:
                         dropped[k] = F.dropout(feat[k], conv.mods[et].feat_drop, self.training)
-                    proj[key] = ops.linear(dropped[k], conv.mods[et].fc.weight)
+                    proj[key] = ops.linear(dropped[k], conv.mods[et].fc.weight, None, dN[k])
                 return proj[key]
             for (s, et, d_), name in mg.meta['rels']:
                 if mg.count('E_' + name) == 0:
@@ -120,7 +121,7 @@ class MSHGNN(nn.Module):
                 src_t, dst_t = (d_, s) if reverse else (s, d_)
                 mod = conv.mods[et]
                 rst = ops.gat_relation(fc(et, src_t), fc(et, dst_t), mod.attn_l, mod.attn_r,
-                                       self._graph(mg, name, reverse), H, None, None, mod.negative_slope)
+                                       self._graph(mg, name, reverse), H, dN[src_t], dN[dst_t], mod.negative_slope)
                 if mod.attn_drop > 0 and self.training:
                     raise NotImplementedError('attention dropout inside the fused GAT kernel')
                 outs[dst_t].append(rst)
@@ -132,8 +133,8 @@ class MSHGNN(nn.Module):
                 bias = biases[k][0] if nres == 1 else torch.stack(biases[k], 0).sum(0)
             else:
                 bias = torch.zeros(H * self.output_dim, device=feat[k].device)
-            x = ops.head_combine(feat[k], bias, float(nres), H, outs[k])
-            h[k] = ops.seg_mean_add(x, feat[k], mg.field('seg%d' % k), mg.B)
+            x = ops.head_combine(feat[k], bias, float(nres), H, outs[k], dN[k])
+            h[k] = ops.seg_mean_add(x, feat[k], mg.field('seg%d' % k), mg.B, mg.dynp('B'))
         return h
 
 
@@ -152,10 +153,11 @@ class AttnReadout(nn.Module):
     def forward(self, mg, allf, feat_vs, orders):
         """allf: [NT, d] per-session concatenation of all orders' nodes; feat_vs[i]: [B, d]."""
         out = {}
+        dT, dB = mg.dynp('NT'), mg.dynp('B')
         for i in orders:
-            U = ops.linear(allf, self.fc_u[i].weight, self.fc_u[i].bias)
-            Vq = ops.linear(feat_vs[i], self.fc_v[i].weight)
-            out[i] = ops.seg_attn(U, Vq, self.fc_e[i].weight, allf, mg.cat_seg)
+            U = ops.linear(allf, self.fc_u[i].weight, self.fc_u[i].bias, dT)
+            Vq = ops.linear(feat_vs[i], self.fc_v[i].weight, None, dB)
+            out[i] = ops.seg_attn(U, Vq, self.fc_e[i].weight, allf, mg.cat_seg, dB)
         return out
 
 
@@ -236,29 +238,32 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         self._renorm(mg)
         W = self._table()
         d = self.embedding_dim
-        rows = self._lookup(mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
+        rows = self._lookup(mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
+                            None, mg.dynp('U'))            # padded slots of gidx are -1 -> zero rows
         rows = self.feat_drop(rows)
         feats, off = {}, 0
+        dB = mg.dynp('B')
         for k in range(1, K + 1):
-            nk = mg.count('N%d' % k)
+            nk = mg.meta['ncap'][k]                        # block size of order k (capacity in padded layouts)
             x = rows[off:off + nk * k]
             off += nk * k
-            f = x if k == 1 else self.expander(x, k)
-            feats[k] = ops.normalize(f, 0) if self.norm else f
+            dk = mg.dynp('N%d' % k)
+            f = x if k == 1 else self.expander(x, k, dk, mg.dynp('GK%d' % k))
+            feats[k] = ops.normalize(f, 0, dk) if self.norm else f
         h = feats
         for layer in self.layers:
             h = layer(mg, h)
         if self.norm:
-            h = {k: ops.normalize(v, 0) for k, v in h.items()}
+            h = {k: ops.normalize(v, 0, mg.dynp('N%d' % k)) for k, v in h.items()}
         stacked = h[1] if K == 1 else torch.cat([h[k] for k in range(1, K + 1)], 0)
-        allf = stacked if K == 1 else ops.row_gather(stacked, mg.cat_perm)
+        allf = stacked if K == 1 else ops.row_gather(stacked, mg.cat_perm, mg.dynp('NT'))
         live = range(K) if (K == 1 or self.fusion) else (0,)
-        feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1))) for i in live}
+        feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1)), dB) for i in live}
         sr_g = self.readout(mg, allf, feat_vs, live)
         srs = []
         for i in live:
-            s = ops.linear_cat([feat_vs[i], sr_g[i]], self.fc_sr[i].weight)
-            srs.append(ops.normalize(s, 0) if self.norm else s)
+            s = ops.linear_cat([feat_vs[i], sr_g[i]], self.fc_sr[i].weight, None, dB)
+            srs.append(ops.normalize(s, 0, dB) if self.norm else s)
         return srs[0]
 
     def forward(self, mg):

@@ -172,7 +172,7 @@ class EmbeddingLookup(torch.autograd.Function):
             part = torch.empty(max(C, 1), d, device=g.device, dtype=torch.float32)
             ar = _arange(C + 1, g.device)
             lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, d,
-                                        0, stream())
+                                        0, stream())          # padded chunks are empty segments -> zero rows
             lib.srec_scatter_add_sorted(ptr(part), d, ptr(items), ptr(cptr), ptr(ar), ptr(dst), dst.stride(0),
                                         items.numel(), ptr(ctx.dyn_u), d, acc, stream())
         else:

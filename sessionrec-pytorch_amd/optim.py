@@ -4,8 +4,12 @@ with no gradient skipped) executed by the HIP kernels of csrc/adam.hip.
 Mirrors the optimizer the reference's TrainRunner builds (train.py:70-75): param groups from
 fix_weight_decay, lr driven by torch's StepLR (it subclasses torch.optim.Optimizer so the
 scheduler works unchanged).  The item table takes the row-structured kernel, fed from the
-TableGrad buffer the fused scoring backward filled, with the Embedding(max_norm) renorm and the
-cosine column scale of the NEXT step fused into the same pass over HBM.
+TableGrad buffer the fused scoring backward filled, with the cosine column scale of the NEXT
+step fused into the same pass over HBM.
+
+Graph-friendly: the per-step scalars (lr / bias corrections, computed in double like torch) live in
+a pinned host array that is copied to a static device array at the start of the launch sequence, so
+a captured hipGraph of `launch()` is replayed after a host-only `advance()`.
 """
 import torch
 
@@ -17,47 +21,53 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.model = model
-        self._hyper = {}
+        self._hyper = {}            # (group index, slot) -> (pinned host [8], device [8])
+        self._frozen = None         # parameter lists frozen by a captured graph
 
-    def _hyper_dev(self, group, step, device):
-        b1, b2 = group['betas']
-        key = (id(group), step)
-        vals = [group['lr'] / (1.0 - b1 ** step), b1, b2, group['eps'], group['weight_decay'], 1.0 - b1, 1.0 - b2,
-                (1.0 - b2 ** step) ** 0.5]
-        slot = self._hyper.get(id(group))
-        if slot is None:
-            slot = self._hyper[id(group)] = {}
-        ent = slot.get('buf')
-        if ent is None:
-            host = torch.empty(8, dtype=torch.float32).pin_memory() if device.type == 'cuda' else torch.empty(8)
-            slot['host'] = host
-        # one tiny device tensor per distinct step value inside this call (dead params keep older steps)
-        t = torch.tensor(vals, dtype=torch.float32, device=device)
-        return t
-
-    @torch.no_grad()
-    def step(self, closure=None):
+    # ------------------------------------------------------------------ helpers
+    def _table_info(self):
         model = self.model
-        table = None
-        tgrad = None
+        table, tgrad, st = None, None, None
         if model is not None and hasattr(model, '_table'):
             table = model._table()
             st = model.__dict__.get('_srec_state')
             if st is not None and st.get('tgrad') is not None and st['tgrad'].fresh:
                 tgrad = st['tgrad']
+        return table, tgrad, st
+
+    def _grad_of(self, p, table, tgrad, zero_ids):
+        g = p.grad
+        if table is not None and p is table and tgrad is not None:
+            g = tgrad.buf if g is None else g.add_(tgrad.buf)
+        if g is None and id(p) in zero_ids:
+            g = torch.zeros_like(p)          # zero (not None) gradient in the reference: weight decay only
+        return g
+
+    def _buffers(self, gi, slot, device):
+        key = (gi, slot)
+        if key not in self._hyper:
+            host = torch.zeros(8, dtype=torch.float32)
+            if device.type == 'cuda':
+                host = host.pin_memory()
+            self._hyper[key] = (host, torch.zeros(8, dtype=torch.float32, device=device))
+        return self._hyper[key]
+
+    def _vals(self, group, step):
+        b1, b2 = group['betas']
+        return [group['lr'] / (1.0 - b1 ** step), b1, b2, group['eps'], group['weight_decay'], 1.0 - b1, 1.0 - b2,
+                (1.0 - b2 ** step) ** 0.5]
+
+    def _work(self):
+        """[(group idx, group, [(p, g, state)])] for every parameter that has a gradient now"""
+        table, tgrad, _ = self._table_info()
         zero_ids = {}
-        if model is not None and hasattr(model, 'zero_grad_params'):
-            zero_ids = {id(p): p for p in model.zero_grad_params()}
-        for group in self.param_groups:
-            hyper_cache = {}
-            use_wd = 1 if group['weight_decay'] != 0 else 0
+        if self.model is not None and hasattr(self.model, 'zero_grad_params'):
+            zero_ids = {id(p): p for p in self.model.zero_grad_params()}
+        work = []
+        for gi, group in enumerate(self.param_groups):
+            items = []
             for p in group['params']:
-                is_table = table is not None and p is table
-                g = p.grad
-                if is_table and tgrad is not None:
-                    g = tgrad.buf if g is None else g.add_(tgrad.buf)
-                if g is None and id(p) in zero_ids:
-                    g = torch.zeros_like(p)          # zero (not None) gradient in the reference: decay only
+                g = self._grad_of(p, table, tgrad, zero_ids)
                 if g is None:
                     continue
                 state = self.state[p]
@@ -65,22 +75,51 @@ class FusedAdam(torch.optim.Optimizer):
                     state['step'] = 0
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                items.append((p, g, state))
+            work.append((gi, group, items))
+        return work
+
+    # ------------------------------------------------------------------ the two halves of step()
+    def advance(self, work=None):
+        """host only: bump the step counters and refresh the pinned hyper-parameter arrays"""
+        if work is None:
+            work = self._frozen
+        for gi, group, items in work:
+            steps = set()
+            for p, g, state in items:
                 state['step'] += 1
-                s = state['step']
-                if s not in hyper_cache:
-                    hyper_cache[s] = self._hyper_dev(group, s, p.device)
-                hyper = hyper_cache[s]
+                steps.add(state['step'])
+            for slot, s in enumerate(sorted(steps)):
+                host, _ = self._buffers(gi, slot, items[0][0].device)
+                host.copy_(torch.tensor(self._vals(group, s), dtype=torch.float32))
+        return work
+
+    def launch(self, work):
+        """device work only (capturable): hyper H2D copies + the Adam kernels"""
+        table, tgrad, st = self._table_info()
+        model = self.model
+        for gi, group, items in work:
+            if not items:
+                continue
+            use_wd = 1 if group['weight_decay'] != 0 else 0
+            order = sorted({state['step'] for _, _, state in items})
+            slot_of = {s: i for i, s in enumerate(order)}
+            for s, slot in slot_of.items():
+                host, dev = self._buffers(gi, slot, items[0][0].device)
+                dev.copy_(host, non_blocking=True)
+            for p, g, state in items:
+                hyper = self._buffers(gi, slot_of[state['step']], p.device)[1]
                 g = g.contiguous()
+                is_table = table is not None and p is table
                 if is_table and p.dim() == 2 and (p.shape[1] & 3) == 0:
-                    max_norm = 0.0     # Embedding(max_norm) renorm stays in forward (reference state after step())
                     cos = model._cosine() if hasattr(model, '_cosine') else None
-                    st = model.__dict__.get('_srec_state')
                     cs_out, cs_scale, eps_mode = None, 1.0, 0
                     if cos is not None and st is not None and st.get('cs') is not None:
                         cs_out, cs_scale, eps_mode = st['cs'], float(cos[0]), int(cos[1])
+                    # Embedding(max_norm) renorm stays in forward (reference state after step()): max_norm = 0
                     lib.srec_adam_rows(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
-                                       p.shape[1], p.stride(0), ptr(hyper), use_wd, float(max_norm), ptr(cs_out),
-                                       cs_scale, eps_mode, 1e-12, stream())
+                                       p.shape[1], p.stride(0), ptr(hyper), use_wd, 0.0, ptr(cs_out), cs_scale,
+                                       eps_mode, 1e-12, stream())
                     if cs_out is not None:
                         st['cs_fresh'] = True
                 else:
@@ -88,4 +127,10 @@ class FusedAdam(torch.optim.Optimizer):
                                        ptr(hyper), use_wd, stream())
         if tgrad is not None:
             tgrad.fresh = False
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        work = self._work()
+        self.advance(work)
+        self.launch(work)
         return None

@@ -67,15 +67,17 @@ class _ScoringMixin:
 
     shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
 
-    def _lookup(self, idx, uniq, tgrad):
+    def _lookup(self, idx, uniq, tgrad, dyn_n=None, dyn_u=None):
         """item rows for the batch: local gather, or the collective lookup when the table is sharded"""
         if self.shard is not None:
             return self.shard.lookup(self._table(), idx, uniq)
-        return ops.embedding_lookup(self._table(), idx, uniq, tgrad)
+        return ops.embedding_lookup(self._table(), idx, uniq, tgrad, dyn_n, dyn_u)
 
     def fused_loss(self, *inputs_and_labels, dynB=None):
         *inputs, labels = inputs_and_labels
         B = labels.numel()
+        if dynB is None and hasattr(inputs[0], 'dynp'):
+            dynB = inputs[0].dynp('B')
         st = self._state(B)
         cs, inv_scale = self._col_scale(st)
         sr = self.session_repr(*inputs, tgrad=st['tgrad'])
@@ -104,10 +106,11 @@ class AttnReadout(nn.Module):
         self.fc_e = nn.Linear(hidden_dim, 1, bias=False)
 
     def forward(self, mg, feat):
+        dN, dB = mg.dynp('N'), mg.dynp('B')
         feat = self.feat_drop(feat)
-        U = ops.linear(feat, self.fc_u.weight)
-        Vq = ops.linear(ops.row_gather(feat, mg.last), self.fc_v.weight, self.fc_v.bias)
-        return ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg)
+        U = ops.linear(feat, self.fc_u.weight, None, dN)
+        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB)
+        return ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg, dB)
 
 
 class SRGNNLayer(nn.Module):
@@ -144,21 +147,23 @@ class SRGNN(_ScoringMixin, nn.Module):
         for w in self.parameters():
             w.data.uniform_(-stdv, stdv)
 
-    def _pre(self, feat):
+    def _pre(self, feat, dyn=None):
         return feat
 
-    def _post(self, sr):
+    def _post(self, sr, dyn=None):
         return sr
 
     def session_repr(self, mg, sg=None, tgrad=None):
-        feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
-        feat = self._pre(self.feat_drop(feat))
+        dN, dB = mg.dynp('N'), mg.dynp('B')
+        feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
+                            dN, mg.dynp('U'))
+        feat = self._pre(self.feat_drop(feat), dN)
         if self.use_gnn_output:
             for layer in self.layers:
                 feat = layer(mg, feat)
         sr_g = self.readout(mg, feat)
-        sr_l = ops.row_gather(feat, mg.last)
-        return self._post(ops.linear_cat([sr_l, sr_g], self.fc_sr.weight))
+        sr_l = ops.row_gather(feat, mg.last, dB)
+        return self._post(ops.linear_cat([sr_l, sr_g], self.fc_sr.weight, None, dB), dB)
 
     def forward(self, mg, sg=None):
         return self._log_probs(self.session_repr(mg))
@@ -185,10 +190,10 @@ class NISER(SRGNN):
             st['cs'] = torch.full((W.shape[0],), float(self.scale), device=W.device)
         return st['cs'], 0.0
 
-    def _pre(self, feat):
+    def _pre(self, feat, dyn=None):
         # niser.py:135 and :142 normalise twice; the second one divides a unit vector by its norm
         # (identity up to 1 ulp, and its Jacobian is the same projection): applied once here.
-        return ops.normalize(feat, 1) if self.norm else feat
+        return ops.normalize(feat, 1, dyn) if self.norm else feat
 
-    def _post(self, sr):
-        return ops.normalize(sr, 1) if self.norm else sr
+    def _post(self, sr, dyn=None):
+        return ops.normalize(sr, 1, dyn) if self.norm else sr

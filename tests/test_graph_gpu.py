@@ -1,0 +1,96 @@
+"""Capacity-padded batches and whole-step hipGraph replay (GPU): same numbers as the exact eager path."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from util import close, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _samples(rng, n, V, max_len=12):
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(1, max_len))
+        seq = rng.integers(0, V, size=L).tolist()
+        if L > 1 and rng.random() < 0.3:
+            seq[1] = seq[0]
+        out.append((seq, int(rng.integers(0, V))))
+    return out
+
+
+def _setup(kind, dev, V=400, d=32):
+    sp, c = pkg(), pkg('collate')
+    torch.manual_seed(1)
+    if kind == 'msgifsr':
+        model = sp.MSGIFSR(V, 'x', d, 1, order=3, extra=False, fusion=False).to(dev)
+        mk = lambda caps: c.collate_fn_factory_ccs((c.seq_to_ccs_graph,), 3, caps=caps)
+    elif kind == 'niser':
+        model = sp.NISER(V, d, 1).to(dev)
+        mk = lambda caps: c.collate_fn_factory(c.seq_to_session_graph, caps=caps)
+    else:
+        model = sp.SRGNN(V, d, 1).to(dev)
+        mk = lambda caps: c.collate_fn_factory(c.seq_to_session_graph, caps=caps)
+    return model, mk
+
+
+@pytest.mark.parametrize('kind', ['srgnn', 'niser', 'msgifsr'])
+def test_padded_layout_equals_exact(dev, kind):
+    c = pkg('collate')
+    rng = np.random.default_rng(2)
+    V = 400
+    model, mk = _setup(kind, dev, V)
+    m2 = copy.deepcopy(model)
+    samples = _samples(rng, 24, V)
+    caps = c.default_caps(32, 12)
+    (xe,), le = mk(None)(samples)
+    (xp,), lp = mk(caps)(samples)
+    assert lp.numel() == 32 and xp.meta['padded']
+    l1 = model.fused_loss(xe.to(dev), le.to(dev))
+    l1.backward()
+    l2 = m2.fused_loss(xp.to(dev), lp.to(dev))
+    l2.backward()
+    close(l2, l1, rtol=1e-6, atol=1e-6, what='loss')
+    close(m2.table_grad.buf, model.table_grad.buf, rtol=1e-4, atol=1e-7, what='table grad')
+    p1, p2 = dict(model.named_parameters()), dict(m2.named_parameters())
+    for k, p in p1.items():
+        if p.grad is not None:
+            close(p2[k].grad, p.grad, rtol=1e-4, atol=1e-7, what=k)
+
+
+@pytest.mark.parametrize('kind', ['niser', 'msgifsr'])
+def test_graph_replay_matches_eager_training(dev, kind):
+    c, train, optim, G = pkg('collate'), pkg('train'), pkg('optim'), pkg('graph')
+    rng = np.random.default_rng(3)
+    V = 400
+    model, mk = _setup(kind, dev, V)
+    ref = copy.deepcopy(model)
+    caps = c.default_caps(32, 12)
+    batches = [_samples(rng, n, V) for n in (32, 32, 20, 32, 27)]     # full and partial batches
+    # eager, exact layouts
+    opt_r = optim.FusedAdam(train.fix_weight_decay(ref), lr=1e-2, weight_decay=1e-4, model=ref)
+    ref.train()
+    ref_losses = []
+    for s in batches:
+        (x,), lab = mk(None)(s)
+        opt_r.zero_grad()
+        loss = ref.fused_loss(x.to(dev), lab.to(dev))
+        loss.backward()
+        opt_r.step()
+        ref_losses.append(loss.item())
+    # graph replay, padded layouts
+    opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-2, weight_decay=1e-4, model=model)
+    model.train()
+    padded = [mk(caps)(s) for s in batches]
+    (x0,), l0 = padded[0]
+    step = G.GraphedTrainStep(model, opt, [x0.to(dev)], l0.to(dev))
+    losses = []
+    for (x,), lab in padded:
+        losses.append(step([x.to(dev)], lab.to(dev)).item())
+    assert np.allclose(losses, ref_losses, rtol=2e-5, atol=2e-5), (losses, ref_losses)
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        err = (p.detach() - q.detach()).abs()
+        frac = (err <= 2e-5 + 1e-4 * q.detach().abs()).float().mean().item()
+        assert frac >= 0.995 and err.max().item() <= 0.02 * 1e-2 * len(batches), (k, frac, err.max().item())
