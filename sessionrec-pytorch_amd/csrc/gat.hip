@@ -8,7 +8,7 @@
 //   h_v = max_head( sum_rel (rst_rel + bias_rel) + n_rel * x_v )      (srec_head_combine_*)
 // Zero-in-degree destinations get rst = 0 (DGL zero fill).
 //
-// One 64-lane wavefront owns one destination node: its in-edge list (<= MAXDEG, sessions are
+// One 64-lane wavefront owns one (destination node, head) pair: its in-edge list (<= MAXDEG, sessions are
 // tiny) is staged in LDS, the per-head softmax is a wavefront reduction and the aggregation
 // streams 1 KiB feature rows with 16 B per lane.  The backward is two gather-style passes
 // (per destination, then per source over the out-edge CSR): deterministic, no atomics.
@@ -24,20 +24,19 @@ constexpr int MAXH = 8;
 // out[n,h] = sum_d X[n,h,d] * a[h,d]
 __global__ void head_dot_kernel(const float* __restrict__ X, int ld, const float* __restrict__ a, int n_cap,
                                 const int* __restrict__ dyn, int H, int D, float* __restrict__ out) {
-    const int n = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = gid / H, h = gid % H;               // one wavefront per (node, head)
     if (n >= n_cap) return;
     const bool live = n < dyn_count(dyn, n_cap);
-    for (int h = 0; h < H; ++h) {
-        float s = 0.f;
-        if (live)
-            for (int c = lane * 4; c < D; c += 256) {
-                const float4 x = *reinterpret_cast<const float4*>(X + (size_t)n * ld + h * D + c);
-                const float4 w = *reinterpret_cast<const float4*>(a + h * D + c);
-                s += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
-            }
-        s = wave_sum(s);
-        if (lane == 0) out[(size_t)n * H + h] = s;
-    }
+    float s = 0.f;
+    if (live)
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(X + (size_t)n * ld + h * D + c);
+            const float4 w = *reinterpret_cast<const float4*>(a + h * D + c);
+            s += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+        }
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)n * H + h] = s;
 }
 
 // per destination node: edge softmax (saved to A[e,h]) + aggregation
@@ -49,14 +48,15 @@ __global__ void gat_agg_fwd_kernel(const float* __restrict__ Fs, int ld_s, const
     __shared__ float sc[WPB][MAXDEG];
     __shared__ int su[WPB][MAXDEG];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int v = blockIdx.x * WPB + w;
+    const int gid = blockIdx.x * WPB + w;
+    const int v = gid / H, h = gid % H;               // one wavefront per (destination, head)
     if (v >= nd_cap) return;
     const bool live = v < dyn_count(dyn_nd, nd_cap);
     const int beg = live ? in_ptr[v] : 0;
     const int deg = live ? min(in_ptr[v + 1] - beg, MAXDEG) : 0;
     for (int j = lane; j < deg; j += 64) su[w][j] = esrc[in_idx[beg + j]];
     __builtin_amdgcn_wave_barrier();
-    for (int h = 0; h < H; ++h) {
+    {
         const float erv = live ? er[(size_t)v * H + h] : 0.f;
         float m = -INFINITY;
         for (int j = lane; j < deg; j += 64) {
@@ -85,7 +85,6 @@ __global__ void gat_agg_fwd_kernel(const float* __restrict__ Fs, int ld_s, const
             }
             *reinterpret_cast<float4*>(rst + (size_t)v * ld_r + h * D + c) = o;
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -99,14 +98,15 @@ __global__ void gat_bwd_dst_kernel(const float* __restrict__ dR, int ld_r, const
     __shared__ float da[WPB][MAXDEG];
     __shared__ int su[WPB][MAXDEG];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int v = blockIdx.x * WPB + w;
+    const int gid = blockIdx.x * WPB + w;
+    const int v = gid / H, h = gid % H;
     if (v >= nd_cap) return;
     const bool live = v < dyn_count(dyn_nd, nd_cap);
     const int beg = live ? in_ptr[v] : 0;
     const int deg = live ? min(in_ptr[v + 1] - beg, MAXDEG) : 0;
     for (int j = lane; j < deg; j += 64) su[w][j] = esrc[in_idx[beg + j]];
     __builtin_amdgcn_wave_barrier();
-    for (int h = 0; h < H; ++h) {
+    {
         for (int j = 0; j < deg; ++j) {
             float s = 0.f;
             for (int c = lane * 4; c < D; c += 256) {
@@ -133,7 +133,6 @@ __global__ void gat_bwd_dst_kernel(const float* __restrict__ dR, int ld_r, const
         }
         dsum = wave_sum(dsum);
         if (lane == 0) der[(size_t)v * H + h] = dsum;
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -144,12 +143,13 @@ __global__ void gat_bwd_src_kernel(const float* __restrict__ dR, int ld_r, const
                                    const int* __restrict__ edst, int ns_cap, const int* __restrict__ dyn_ns, int H,
                                    int D, float* __restrict__ dFs, int ld_s, float* __restrict__ del) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int u = blockIdx.x * WPB + w;
+    const int gid = blockIdx.x * WPB + w;
+    const int u = gid / H, h = gid % H;
     if (u >= ns_cap) return;
     const bool live = u < dyn_count(dyn_ns, ns_cap);
     const int beg = live ? out_ptr[u] : 0;
     const int deg = live ? out_ptr[u + 1] - beg : 0;
-    for (int h = 0; h < H; ++h) {
+    {
         float dl = 0.f;
         for (int j = lane; j < deg; j += 64) dl += DP[(size_t)out_idx[beg + j] * H + h];
         dl = wave_sum(dl);
@@ -171,10 +171,11 @@ __global__ void gat_bwd_src_kernel(const float* __restrict__ dR, int ld_r, const
 // out[n,h,:] = w[n,h] * a[h,:]
 __global__ void head_outer_kernel(const float* __restrict__ wgt, const float* __restrict__ a, int n_cap,
                                   const int* __restrict__ dyn, int H, int D, float* __restrict__ out, int ld) {
-    const int n = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = gid / H, h = gid % H;
     if (n >= n_cap) return;
     const bool live = n < dyn_count(dyn, n_cap);
-    for (int h = 0; h < H; ++h) {
+    {
         const float wv = live ? wgt[(size_t)n * H + h] : 0.f;
         for (int c = lane * 4; c < D; c += 256) {
             const float4 av = *reinterpret_cast<const float4*>(a + h * D + c);
@@ -249,7 +250,7 @@ extern "C" int srec_head_dot(const float* X, int ld, const float* a, int n_cap, 
                              float* out, void* stream) {
     if (n_cap <= 0) return 0;
     if (bad(H, D, ld)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(head_dot_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, X, ld, a, n_cap, dyn,
+    hipLaunchKernelGGL(head_dot_kernel, dim3(cdiv(n_cap * H, WPB)), dim3(256), 0, (hipStream_t)stream, X, ld, a, n_cap, dyn,
                        H, D, out);
     SREC_LAUNCH_CHECK();
     return 0;
@@ -260,7 +261,7 @@ extern "C" int srec_gat_agg_fwd(const float* Fs, int ld_s, const float* el, cons
                                 float slope, float* A, float* rst, int ld_r, void* stream) {
     if (nd_cap <= 0) return 0;
     if (bad(H, D, ld_s) || (ld_r & 3)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(gat_agg_fwd_kernel, dim3(cdiv(nd_cap, WPB)), dim3(256), 0, (hipStream_t)stream, Fs, ld_s, el, er,
+    hipLaunchKernelGGL(gat_agg_fwd_kernel, dim3(cdiv(nd_cap * H, WPB)), dim3(256), 0, (hipStream_t)stream, Fs, ld_s, el, er,
                        in_ptr, in_idx, esrc, nd_cap, dyn_nd, H, D, slope, A, rst, ld_r);
     SREC_LAUNCH_CHECK();
     return 0;
@@ -271,7 +272,7 @@ extern "C" int srec_gat_bwd_dst(const float* dR, int ld_r, const float* Fs, int 
                                 const int* dyn_nd, int H, int D, float slope, float* DP, float* der, void* stream) {
     if (nd_cap <= 0) return 0;
     if (bad(H, D, ld_s) || (ld_r & 3)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(gat_bwd_dst_kernel, dim3(cdiv(nd_cap, WPB)), dim3(256), 0, (hipStream_t)stream, dR, ld_r, Fs, ld_s,
+    hipLaunchKernelGGL(gat_bwd_dst_kernel, dim3(cdiv(nd_cap * H, WPB)), dim3(256), 0, (hipStream_t)stream, dR, ld_r, Fs, ld_s,
                        el, er, A, in_ptr, in_idx, esrc, nd_cap, dyn_nd, H, D, slope, DP, der);
     SREC_LAUNCH_CHECK();
     return 0;
@@ -282,7 +283,7 @@ extern "C" int srec_gat_bwd_src(const float* dR, int ld_r, const float* A, const
                                 int H, int D, float* dFs, int ld_s, float* del, void* stream) {
     if (ns_cap <= 0) return 0;
     if (bad(H, D, ld_s) || (ld_r & 3)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(gat_bwd_src_kernel, dim3(cdiv(ns_cap, WPB)), dim3(256), 0, (hipStream_t)stream, dR, ld_r, A, DP,
+    hipLaunchKernelGGL(gat_bwd_src_kernel, dim3(cdiv(ns_cap * H, WPB)), dim3(256), 0, (hipStream_t)stream, dR, ld_r, A, DP,
                        attn_l, out_ptr, out_idx, edst, ns_cap, dyn_ns, H, D, dFs, ld_s, del);
     SREC_LAUNCH_CHECK();
     return 0;
@@ -292,7 +293,7 @@ extern "C" int srec_head_outer(const float* wgt, const float* a, int n_cap, cons
                                int ld, void* stream) {
     if (n_cap <= 0) return 0;
     if (bad(H, D, ld)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(head_outer_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, wgt, a, n_cap, dyn, H,
+    hipLaunchKernelGGL(head_outer_kernel, dim3(cdiv(n_cap * H, WPB)), dim3(256), 0, (hipStream_t)stream, wgt, a, n_cap, dyn, H,
                        D, out, ld);
     SREC_LAUNCH_CHECK();
     return 0;
