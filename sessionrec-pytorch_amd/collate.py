@@ -275,6 +275,105 @@ def batch_ccs(graphs, caps=None):
     return FlatBatch.build(fields, counts, meta, fcaps)
 
 
+# ------------------------------------------------------------------------------------ native builder
+_NATIVE = None
+
+
+def _native():
+    """libsrec_collate.so (csrc/collate.cpp) or None; SREC_PY_COLLATE=1 forces the python builders"""
+    global _NATIVE
+    if _NATIVE is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libsrec_collate.so')
+        if os.environ.get('SREC_PY_COLLATE') == '1' or not os.path.exists(path):
+            _NATIVE = False
+        else:
+            dll = ctypes.CDLL(path)
+            dll.srec_collate.restype = ctypes.c_long
+            dll.srec_collate.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p]
+            _NATIVE = dll
+    return _NATIVE or None
+
+
+_HOMOG_FIELDS = ['seg', 'eseg', 'esrc', 'edst', 'in_ptr', 'in_idx', 'out_ptr', 'out_idx']
+_ITEM_FIELDS = ['iid', 'last', 'uniq_items', 'uniq_ptr', 'uniq_pos', 'uniq_cptr', 'chunk_ptr']
+
+
+def _ccs_schema(K):
+    rel_keys = sorted([(k, 'intra%d' % k, k) for k in range(1, K + 1)] + [(1, 'inter', k) for k in range(2, K + 1)] +
+                      [(k, 'inter', 1) for k in range(2, K + 1)])
+    rels = [(key, 'r_%d_%s_%d' % key) for key in rel_keys]
+    names, shapes, counts = [], {}, ['B']
+    for k in range(1, K + 1):
+        names += ['seg%d' % k, 'iid%d' % k, 'last%d' % k]
+        if k > 1:
+            shapes['iid%d' % k] = (k,)
+        counts += ['N%d' % k, 'GK%d' % k]
+    names += ['gidx', 'uniq_items', 'uniq_ptr', 'uniq_pos', 'uniq_cptr', 'chunk_ptr']
+    counts += ['G', 'U', 'C']
+    for _, n in rels:
+        names += [n + sfx for sfx in ('_src', '_dst', '_in_ptr', '_in_idx', '_out_ptr', '_out_idx')]
+        counts.append('E_' + n)
+    names += ['cat_perm', 'cat_inv', 'cat_seg'] + ['lastcat%d' % k for k in range(1, K + 1)]
+    counts.append('NT')
+    return names, shapes, counts, rels
+
+
+def collate_native(kind, seqs, order=1, caps=None):
+    """kind: 'session' | 'eop' | 'shortcut' | 'ccs' -> FlatBatch built by csrc/collate.cpp (or None if unavailable)"""
+    import ctypes
+    dll = _native()
+    if dll is None:
+        return None
+    B = len(seqs)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=B)
+    offs = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    flat = np.fromiter((x for s in seqs for x in s), dtype=np.int64, count=int(offs[-1]))
+    kid = {'session': 0, 'eop': 1, 'shortcut': 2, 'ccs': 3}[kind]
+    if kind == 'ccs':
+        names, shapes, cnames, rels = _ccs_schema(order)
+    else:
+        names = list(_HOMOG_FIELDS) + (list(_ITEM_FIELDS) if kind != 'shortcut' else []) + (['ew'] if kind == 'session' else [])
+        shapes, rels = {}, None
+        cnames = ['B', 'N', 'E'] + (['U', 'C'] if kind != 'shortcut' else [])
+    capv = None if caps is None else np.array([caps['B'], caps['N'], caps['E'], caps['U']], dtype=np.int64)
+    total = int(offs[-1])
+    if caps is None:
+        guess = 64 + 40 * (total + B) * (order if kind == 'ccs' else 1) + (total * 21 if kind == 'shortcut' else 0)
+    else:
+        guess = 64 + (12 * order + 16) * (caps['N'] * max(order, 1) + caps['E'] + caps['U'] + caps['B']) + 4096
+    info = np.zeros(3 * (len(names) + 4), dtype=np.int64)
+    nf = ctypes.c_int(0)
+    for _ in range(2):
+        out = np.empty(guess, dtype=np.int32)
+        n = dll.srec_collate(kid, flat.ctypes.data, offs.ctypes.data, B, order,
+                             None if capv is None else capv.ctypes.data, out.ctypes.data, guess, info.ctypes.data,
+                             len(names) + 4, ctypes.addressof(nf))
+        if n > 0:
+            break
+        if n == 0:
+            raise ValueError('native collate failed: empty session, order > 6, or capacity exceeded')
+        guess = -n + 16
+    assert nf.value == len(names), (nf.value, len(names))
+    buf = out[:n].copy()
+    layout = {nm: (int(info[3 * i]), int(info[3 * i + 1]), shapes.get(nm)) for i, nm in enumerate(names)}
+    counts = {cn: int(buf[i]) for i, cn in enumerate(cnames)}
+    meta = dict(kind=kind, B=caps['B'] if caps else B, padded=caps is not None, counts=counts,
+                slots={cn: i for i, cn in enumerate(cnames)})
+    if kind == 'ccs':
+        cs = buf[layout['cat_seg'][0]:layout['cat_seg'][0] + B + 1]
+        meta.update(order=order, rels=rels, max_nodes=int(np.diff(cs).max()),
+                    ncap={k: (caps['N'] if caps else counts['N%d' % k]) for k in range(1, order + 1)})
+    else:
+        sg = buf[layout['seg'][0]:layout['seg'][0] + B + 1]
+        meta['max_nodes'] = int(np.diff(sg).max())
+    return FlatBatch(torch.from_numpy(buf), layout, meta)
+
+
 def _labels(labels, caps):
     lab = np.asarray(labels, dtype=np.int64)
     if caps and len(lab) < caps['B']:
@@ -285,9 +384,16 @@ def _labels(labels, caps):
 def collate_fn_factory(*seq_to_graph_fns, caps=None):
     """caps=None: exact layouts.  caps={'B','N','E','U'}: capacity-padded layouts with batch-independent
     offsets (every batch then fits the same device buffer and the same captured hipGraph)."""
+    kinds = {seq_to_session_graph: 'session', seq_to_eop_multigraph: 'eop', seq_to_shortcut_graph: 'shortcut'}
+
     def collate_fn(samples):
         seqs, labels = zip(*samples)
-        inputs = [batch_homogeneous([fn(s) for s in seqs], caps) for fn in seq_to_graph_fns]
+        inputs = []
+        for fn in seq_to_graph_fns:
+            fb = collate_native(kinds[fn], seqs, 1, caps) if fn in kinds else None
+            if fb is None:
+                fb = batch_homogeneous([fn(s) for s in seqs], caps)
+            inputs.append(fb)
         return inputs, _labels(labels, caps)
     return collate_fn
 
@@ -295,7 +401,12 @@ def collate_fn_factory(*seq_to_graph_fns, caps=None):
 def collate_fn_factory_ccs(seq_to_graph_fns, order, caps=None):
     def collate_fn(samples):
         seqs, labels = zip(*samples)
-        inputs = [batch_ccs([fn(s, order) for s in seqs], caps) for fn in seq_to_graph_fns]
+        inputs = []
+        for fn in seq_to_graph_fns:
+            fb = collate_native('ccs', seqs, order, caps) if fn is seq_to_ccs_graph else None
+            if fb is None:
+                fb = batch_ccs([fn(s, order) for s in seqs], caps)
+            inputs.append(fb)
         return inputs, _labels(labels, caps)
     return collate_fn
 

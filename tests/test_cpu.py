@@ -244,3 +244,31 @@ def test_product_ops_refuse_cpu_tensors():
     w = torch.randn(8, 8)
     with pytest.raises(RuntimeError):
         ops.linear(x, w)
+
+
+# ---------------------------------------------------------------------------------------- native collate
+@pytest.mark.parametrize('kind,order,padded', [('session', 1, False), ('eop', 1, False), ('shortcut', 1, False),
+                                               ('ccs', 1, False), ('ccs', 2, False), ('ccs', 3, False), ('ccs', 4, False),
+                                               ('session', 1, True), ('ccs', 3, True)])
+def test_native_collate_is_bit_identical_to_python_builder(kind, order, padded):
+    """csrc/collate.cpp must emit exactly the buffer, layout and header of the python builders"""
+    c = pkg('collate')
+    if c._native() is None:
+        pytest.skip('libsrec_collate.so not built')
+    rng = np.random.default_rng(17)
+    samples = EDGE + _rand_samples(rng, 57, V=40, max_len=15)
+    seqs = [s for s, _ in samples]
+    caps = c.default_caps(64, 15) if padded else None
+    if kind == 'ccs':
+        ref = c.batch_ccs([c.seq_to_ccs_graph(s, order) for s in seqs], caps)
+    else:
+        fn = dict(session=c.seq_to_session_graph, eop=c.seq_to_eop_multigraph, shortcut=c.seq_to_shortcut_graph)[kind]
+        ref = c.batch_homogeneous([fn(s) for s in seqs], caps)
+    nat = c.collate_native(kind, seqs, order, caps)
+    assert nat.layout == ref.layout, [(k, nat.layout.get(k), v) for k, v in ref.layout.items() if nat.layout.get(k) != v][:5]
+    assert nat.meta['counts'] == ref.meta['counts'] and nat.meta['slots'] == ref.meta['slots']
+    for key in ('kind', 'B', 'padded', 'max_nodes', 'order', 'rels', 'ncap'):
+        assert nat.meta.get(key) == ref.meta.get(key), (key, nat.meta.get(key), ref.meta.get(key))
+    assert nat.buf.numel() == ref.buf.numel()
+    diff = torch.nonzero(nat.buf != ref.buf).reshape(-1)
+    assert diff.numel() == 0, ('first differing word', int(diff[0]), [k for k, v in ref.layout.items() if v[0] <= int(diff[0]) < v[0] + v[1]])
