@@ -194,6 +194,8 @@ def main():
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'fp32'), choices=['fp32', 'bf16'],
+                    help="MFMA operand type of the forward / backward-data GEMMs ('bf16' = BASELINE config C3)")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     ap.add_argument('--kernel-only', action='store_true', help='only launch the scoring/CE kernels (PMC collection target)')
     args = ap.parse_args()
@@ -210,6 +212,7 @@ def main():
     dev = torch.device('cuda', local)
 
     sp = importlib.import_module('sessionrec-pytorch_amd')
+    importlib.import_module('sessionrec-pytorch_amd.ops').set_precision(args.precision)
     train = importlib.import_module('sessionrec-pytorch_amd.train')
     optim = importlib.import_module('sessionrec-pytorch_amd.optim')
     B, V, d = args.batch, args.items, args.dim
@@ -285,7 +288,7 @@ def main():
         out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=world * B * args.steps / dt,
                    unit='sessions/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='f32', data='synthetic', launch='hipGraph replay' if use_graph else 'eager',
+                   dtype='f32' if args.precision == 'fp32' else 'bf16 (MFMA operands; fp32 accumulate, master weights, scoring)', data='synthetic', launch='hipGraph replay' if use_graph else 'eager',
                    config=dict(workload='%s training step, synthetic Yoochoose-1/64 shape (V=%d items, d=%d, batch %d per GPU, '
                                         'session length<=20%s)' % (args.model, V, d, B,
                                                                    ', order %d' % args.order if args.model == 'MSGIFSR' else ''),

@@ -33,6 +33,12 @@ int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B, int b_rs, 
                   const float* bias, int M, int N, int K, const int* dyn, int dyn_mode, float alpha, float beta,
                   float* ws, long ws_floats, void* stream);
 
+/* bf16-operand variant (v_mfma_f32_32x32x16_bf16, fp32 accumulate): A [M,K], B [N,K] fp32 in HBM, rounded to
+ * bf16 while staged into LDS; K % 32 == 0; dyn (nullable) clamps M.  The reduced-precision path BASELINE
+ * config C3 names; same call sites as srec_gemm_f32 (forward and backward-data products). */
+int srec_gemm_bf16_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, int M,
+                      int N, int K, const int* dyn, float alpha, float beta, float* ws, long ws_floats, void* stream);
+
 /* ---- fused full-catalog scoring + softmax-CE (score_ce.hip) -----------------------------------------
  * z[b,v] = cs[v] * <sr_b, E_v> (cs NULL -> 1).  Replaces sr @ E^T, log(softmax), nll_loss:
  * srgnn.py:145-147  niser.py:149-156  lessr.py:182-183  msgifsr.py:276-309,321  train.py:99 (+ backward). */

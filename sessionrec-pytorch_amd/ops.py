@@ -51,10 +51,42 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+PRECISION = {'matmul': 'fp32'}      # 'fp32': exact fp32 MFMA everywhere; 'bf16': bf16-operand MFMA for the
+                                    # forward / backward-data products and the scoring kernels (config C3)
+_WT_CACHE = {}
+
+
+def set_precision(mode):
+    assert mode in ('fp32', 'bf16')
+    PRECISION['matmul'] = mode
+    _WT_CACHE.clear()
+
+
+def weights_changed():
+    """called by the optimizer after it updated parameters: cached transposed weight copies are stale"""
+    _WT_CACHE.clear()
+
+
+def _transposed(w):
+    key = (w.data_ptr(), tuple(w.shape), w.stride(0))
+    t = _WT_CACHE.get(key)
+    if t is None:
+        t = _WT_CACHE[key] = w.t().contiguous()
+    return t
+
+
+def _bf16_ok(K, *ts):
+    return PRECISION['matmul'] == 'bf16' and K % 32 == 0 and all((_ld(t) & 3) == 0 and (t.data_ptr() & 15) == 0 for t in ts)
+
+
 def gemm_nt(x, w, out, bias=None, dyn=None, dyn_mode=0, beta=0.0):
     """out[M,N] = x[M,K] @ w[N,K]^T (+bias) (+beta*out)"""
     M, K = x.shape
     N = w.shape[0]
+    if dyn_mode in (0, 1) and _bf16_ok(K, x, w):
+        lib.srec_gemm_bf16_nt(ptr(x), _ld(x), ptr(w), _ld(w), ptr(out), _ld(out), ptr(bias), M, N, K,
+                              ptr(dyn) if dyn_mode == 1 else None, 1.0, beta, *_gemm_ws(x.device), stream())
+        return
     lib.srec_gemm_f32(ptr(x), _ld(x), 1, ptr(w), _ld(w), 1, ptr(out), _ld(out), ptr(bias), M, N, K, ptr(dyn), dyn_mode,
                       1.0, beta, *_gemm_ws(x.device), stream())
 
@@ -63,6 +95,11 @@ def gemm_nn(g, w, out, dyn=None, dyn_mode=0, beta=0.0):
     """out[M,K] = g[M,N] @ w[N,K]"""
     M, N = g.shape
     K = w.shape[1]
+    if dyn_mode in (0, 1) and _bf16_ok(N, g) and w.shape[0] * w.shape[1] <= (1 << 22):
+        wt = _transposed(w)                          # [K, N]: the product becomes NT on the bf16 matrix cores
+        lib.srec_gemm_bf16_nt(ptr(g), _ld(g), ptr(wt), _ld(wt), ptr(out), _ld(out), None, M, K, N,
+                              ptr(dyn) if dyn_mode == 1 else None, 1.0, beta, *_gemm_ws(g.device), stream())
+        return
     lib.srec_gemm_f32(ptr(g), _ld(g), 1, ptr(w), 1, _ld(w), ptr(out), _ld(out), None, M, K, N, ptr(dyn), dyn_mode, 1.0,
                       beta, *_gemm_ws(g.device), stream())
 

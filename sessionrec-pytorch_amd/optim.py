@@ -127,6 +127,8 @@ class FusedAdam(torch.optim.Optimizer):
                                        ptr(hyper), use_wd, stream())
         if tgrad is not None:
             tgrad.fresh = False
+        from . import ops
+        ops.weights_changed()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -388,3 +388,30 @@ def test_batch_norm_prelu(dev):
     r.backward(g)
     close(x1.grad, x2.grad, what='prelu dx')
     close(a.grad, a2.grad, what='prelu da', atol=1e-4)
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 4, 32), (200, 96, 64), (3000, 2048, 256), (513, 256, 2048)])
+def test_gemm_bf16_matches_bf16_rounded_reference(dev, M, N, K):
+    """bf16-operand MFMA with fp32 accumulation == fp32 matmul of bf16-rounded operands (tolerance: fp32
+    accumulation order only); vs the unrounded fp32 product the error is the bf16 input rounding (2^-9 rel/elem)."""
+    ops = _ops()
+    torch.manual_seed(M + N)
+    x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    b = torch.randn(N, device=dev)
+    ops.set_precision('bf16')
+    try:
+        y = torch.empty(M, N, device=dev)
+        ops.gemm_nt(x, w, y, b)
+        ref = x.bfloat16().float() @ w.bfloat16().float().t() + b
+        close(y, ref, what='bf16 nt', rtol=1e-4, atol=1e-4)
+        exact = x @ w.t() + b
+        rel = (y - exact).norm() / exact.norm()
+        assert rel < 6e-3, rel
+        g = torch.randn(M, N, device=dev)
+        gx = torch.empty(M, K, device=dev)
+        ops.gemm_nn(g, w, gx)
+        if N % 32 == 0:       # otherwise the exact fp32 kernel is (correctly) used
+            ref = g.bfloat16().float() @ w.bfloat16().float()
+            close(gx, ref, what='bf16 nn', rtol=1e-4, atol=2e-4)
+    finally:
+        ops.set_precision('fp32')
