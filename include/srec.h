@@ -110,7 +110,7 @@ int srec_gat_bwd_dst(const float* dR, int ld_r, const float* Fs, int ld_s, const
                      const int* dyn_nd, int H, int D, float slope, float* DP, float* der, void* stream);
 int srec_gat_bwd_src(const float* dR, int ld_r, const float* A, const float* DP, const float* attn_l,
                      const int* out_ptr, const int* out_idx, const int* edst, int ns_cap, const int* dyn_ns, int H,
-                     int D, float* dFs, int ld_s, float* del, void* stream);
+                     int D, float* dFs, int ld_s, float* del, const float* der, const float* attn_r, void* stream);
 int srec_head_outer(const float* wgt, const float* a, int n_cap, const int* dyn, int H, int D, float* out, int ld,
                     void* stream);
 /* h_v = max_head(sum_i R_i + bias + nres*x): msgifsr.py:78-85 (+ identity residual / bias of gatconv.py:306-311).
@@ -181,6 +181,9 @@ int srec_sgat_bwd_src(const float* dout, int ld_o, const float* A, const float* 
  * hyper (device, 8 floats) = {lr/(1-b1^t), beta1, beta2, eps, weight_decay, 1-beta1, 1-beta2, sqrt(1-b2^t)} */
 int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                    void* stream);
+/* one launch for many small tensors: desc[t] = {p, g, m, v, numel, use_wd} (6 x int64, device), blockmap[b] =
+ * {tensor, first element} (2 x int32, device) per 1024-element block */
+int srec_adam_multi(const long long* desc, const int* blockmap, int total_blocks, const float* hyper, void* stream);
 int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
                    int use_wd, float max_norm, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
                    void* stream);

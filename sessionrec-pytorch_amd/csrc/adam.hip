@@ -99,7 +99,36 @@ __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict_
         cs_out[i] = cs_scale * (eps_mode == 0 ? 1.f / fmaxf(nrm, cs_eps) : 1.f / (nrm + cs_eps));
 }
 
+// Multi-tensor variant: ONE launch updates every (small) parameter tensor of a group.  desc[t] = {p, g, m, v,
+// numel, use_wd} as 6 x int64 (device memory); blockmap[b] = {tensor index, first element} per 1024-element block.
+__global__ void adam_multi_kernel(const long long* __restrict__ desc, const int* __restrict__ blockmap,
+                                  const float* __restrict__ hyper) {
+    const int t = blockmap[2 * blockIdx.x], e0 = blockmap[2 * blockIdx.x + 1];
+    const long long* d = desc + 6 * (size_t)t;
+    float* p = reinterpret_cast<float*>(d[0]);
+    const float* g = reinterpret_cast<const float*>(d[1]);
+    float* m = reinterpret_cast<float*>(d[2]);
+    float* v = reinterpret_cast<float*>(d[3]);
+    const long long n = d[4];
+    const Hyper h = load_hyper(hyper);
+    const float wd = d[5] ? h.wd : 0.f;
+    const long long i0 = (long long)e0 + threadIdx.x * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long i = i0 + j;
+        if (i < n) adam1(p[i], g[i], m[i], v[i], h, wd, h.step, h.bc2s);
+    }
+}
+
 }  // namespace
+
+extern "C" int srec_adam_multi(const long long* desc, const int* blockmap, int total_blocks, const float* hyper,
+                               void* stream) {
+    if (total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, desc, blockmap, hyper);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                               void* stream) {

@@ -141,7 +141,8 @@ __global__ void gat_bwd_src_kernel(const float* __restrict__ dR, int ld_r, const
                                    const float* __restrict__ DP, const float* __restrict__ attn_l,
                                    const int* __restrict__ out_ptr, const int* __restrict__ out_idx,
                                    const int* __restrict__ edst, int ns_cap, const int* __restrict__ dyn_ns, int H,
-                                   int D, float* __restrict__ dFs, int ld_s, float* __restrict__ del) {
+                                   int D, float* __restrict__ dFs, int ld_s, float* __restrict__ del,
+                                   const float* __restrict__ der, const float* __restrict__ attn_r) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gid = blockIdx.x * WPB + w;
     const int u = gid / H, h = gid % H;
@@ -154,9 +155,16 @@ __global__ void gat_bwd_src_kernel(const float* __restrict__ dR, int ld_r, const
         for (int j = lane; j < deg; j += 64) dl += DP[(size_t)out_idx[beg + j] * H + h];
         dl = wave_sum(dl);
         if (lane == 0) del[(size_t)u * H + h] = dl;
+        // same-type relation (source features == destination features): the er-side term der[u,h]*a_r[h,:]
+        // is added here instead of materialising a second [N,H,D] gradient
+        const float dr = (der != nullptr && live) ? der[(size_t)u * H + h] : 0.f;
         for (int c = lane * 4; c < D; c += 256) {
             const float4 al = *reinterpret_cast<const float4*>(attn_l + h * D + c);
             float4 o = make_float4(dl * al.x, dl * al.y, dl * al.z, dl * al.w);
+            if (der != nullptr) {
+                const float4 ar = *reinterpret_cast<const float4*>(attn_r + h * D + c);
+                o.x += dr * ar.x; o.y += dr * ar.y; o.z += dr * ar.z; o.w += dr * ar.w;
+            }
             for (int j = 0; j < deg; ++j) {
                 const int e = out_idx[beg + j];
                 const float a = A[(size_t)e * H + h];
@@ -280,11 +288,12 @@ extern "C" int srec_gat_bwd_dst(const float* dR, int ld_r, const float* Fs, int 
 
 extern "C" int srec_gat_bwd_src(const float* dR, int ld_r, const float* A, const float* DP, const float* attn_l,
                                 const int* out_ptr, const int* out_idx, const int* edst, int ns_cap, const int* dyn_ns,
-                                int H, int D, float* dFs, int ld_s, float* del, void* stream) {
+                                int H, int D, float* dFs, int ld_s, float* del, const float* der, const float* attn_r,
+                                void* stream) {
     if (ns_cap <= 0) return 0;
     if (bad(H, D, ld_s) || (ld_r & 3)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(gat_bwd_src_kernel, dim3(cdiv(ns_cap * H, WPB)), dim3(256), 0, (hipStream_t)stream, dR, ld_r, A, DP,
-                       attn_l, out_ptr, out_idx, edst, ns_cap, dyn_ns, H, D, dFs, ld_s, del);
+                       attn_l, out_ptr, out_idx, edst, ns_cap, dyn_ns, H, D, dFs, ld_s, del, der, attn_r);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -564,6 +564,7 @@ class GATRelation(torch.autograd.Function):
         lib.srec_gat_agg_fwd(ptr(Fs), _ld(Fs), ptr(el), ptr(er), ptr(in_ptr), ptr(in_idx), ptr(esrc), Nd, ptr(dyn_nd),
                              H, D, slope, ptr(A), ptr(rst), HD, stream())
         ctx.save_for_backward(Fs, Fd, al, ar, el, er, A)
+        ctx.same = Fs.data_ptr() == Fd.data_ptr() and Fs.shape == Fd.shape
         ctx.graph, ctx.H, ctx.dyn, ctx.slope = graph, H, (dyn_ns, dyn_nd), slope
         ctx.shapes = (attn_l.shape, attn_r.shape)
         return rst
@@ -585,10 +586,14 @@ class GATRelation(torch.autograd.Function):
                              ptr(esrc), Nd, ptr(dyn_nd), H, D, ctx.slope, ptr(DP), ptr(der), stream())
         dFs = torch.empty(Ns, HD, device=dev, dtype=torch.float32)
         del_ = torch.empty(Ns, H, device=dev, dtype=torch.float32)
+        same = ctx.same
         lib.srec_gat_bwd_src(ptr(dR), _ld(dR), ptr(A), ptr(DP), ptr(al), ptr(out_ptr), ptr(out_idx), ptr(edst), Ns,
-                             ptr(dyn_ns), H, D, ptr(dFs), HD, ptr(del_), stream())
-        dFd = torch.empty(Nd, HD, device=dev, dtype=torch.float32)
-        lib.srec_head_outer(ptr(der), ptr(ar), Nd, ptr(dyn_nd), H, D, ptr(dFd), HD, stream())
+                             ptr(dyn_ns), H, D, ptr(dFs), HD, ptr(del_), ptr(der) if same else None,
+                             ptr(ar) if same else None, stream())
+        dFd = None                                    # same tensor as Fs: its er-side term is already in dFs
+        if not same:
+            dFd = torch.empty(Nd, HD, device=dev, dtype=torch.float32)
+            lib.srec_head_outer(ptr(der), ptr(ar), Nd, ptr(dyn_nd), H, D, ptr(dFd), HD, stream())
         dal = torch.empty(HD, device=dev, dtype=torch.float32)
         dar = torch.empty(HD, device=dev, dtype=torch.float32)
         col_sum(Fs, Ns, HD, dal, dyn_ns, del_, H, D)

@@ -107,10 +107,14 @@ class FusedAdam(torch.optim.Optimizer):
             for s, slot in slot_of.items():
                 host, dev = self._buffers(gi, slot, items[0][0].device)
                 dev.copy_(host, non_blocking=True)
+            multi = {}                       # step slot -> rows of the multi-tensor descriptor
             for p, g, state in items:
                 hyper = self._buffers(gi, slot_of[state['step']], p.device)[1]
                 g = g.contiguous()
                 is_table = table is not None and p is table
+                if not is_table and p.is_contiguous() and p.numel() < (1 << 22):
+                    multi.setdefault(slot_of[state['step']], []).append((p, g, state))
+                    continue
                 if is_table and p.dim() == 2 and (p.shape[1] & 3) == 0:
                     cos = model._cosine() if hasattr(model, '_cosine') else None
                     cs_out, cs_scale, eps_mode = None, 1.0, 0
@@ -125,6 +129,27 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     lib.srec_adam_flat(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.numel(),
                                        ptr(hyper), use_wd, stream())
+            for slot, rows in multi.items():      # every small tensor of the group in ONE launch
+                desc, bmap = [], []
+                for t, (p, g, state) in enumerate(rows):
+                    desc += [p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
+                             p.numel(), use_wd]
+                    for e0 in range(0, p.numel(), 1024):
+                        bmap += [t, e0]
+                dev = rows[0][0].device
+                key = ('multi', gi, slot)
+                hd = torch.tensor(desc, dtype=torch.int64)
+                hb = torch.tensor(bmap, dtype=torch.int32)
+                ent = self._hyper.get(key)
+                if ent is None or ent[0].numel() != hd.numel() or ent[2].numel() != hb.numel():
+                    ent = (hd.pin_memory(), torch.empty_like(hd, device=dev), hb.pin_memory(), torch.empty_like(hb, device=dev))
+                    self._hyper[key] = ent
+                ent[0].copy_(hd)
+                ent[2].copy_(hb)
+                ent[1].copy_(ent[0], non_blocking=True)
+                ent[3].copy_(ent[2], non_blocking=True)
+                hyper = self._buffers(gi, slot, dev)[1]
+                lib.srec_adam_multi(ptr(ent[1]), ptr(ent[3]), len(bmap) // 2, ptr(hyper), stream())
         if tgrad is not None:
             tgrad.fresh = False
         from . import ops
