@@ -99,7 +99,7 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20):
                           ptr(lse), ptr(lossvec), ptr(loss), stream())
 
     def run(parts):
-        lib.srec_score_ce_bwd(ptr(sr), d, ptr(table), d, None, ptr(labels), ptr(lse), None, B, V, d, None, ptr(dE), d,
+        lib.srec_score_ce_bwd(ptr(sr), d, ptr(table), d, None, ptr(labels), ptr(lse), None, None, None, B, V, d, None, ptr(dE), d,
                               ptr(ws.dsr_part), ptr(dsr), parts, stream())
     out = {}
     for name, parts in (('dE', 1), ('dsr', 2)):

@@ -48,10 +48,12 @@ int srec_score_ce_fwd(const float* sr, int ld_sr, const float* E, int ld_e, cons
                       int B, int V, int d, const int* dynB, float* ws_stats, float* lab_logit, float* lse,
                       float* lossvec, float* loss, void* stream);
 /* ws_dsr: n_ranges*B*d floats.  gscale (nullable): upstream d loss.  Outputs dE[V,d] (every row), dsr[B,d].
- * parts: bit0 = dE kernel, bit1 = d sr kernels (3 = both). */
+ * parts: bit0 = dE kernel, bit1 = d sr kernels (3 = both), bit2 = accumulate into dE.  ga/gc (nullable): per-session coefficients
+ * dS[b,v] = (ga[b] softmax[b,v] - gc[b] [v==label_b]) cs[v] for losses built from (lse_b, z[b,label_b]), e.g. the
+ * order-fusion mixture of msgifsr.py:311-317. */
 int srec_score_ce_bwd(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const int* labels,
-                      const float* lse, const float* gscale, int B, int V, int d, const int* dynB, float* dE,
-                      int ld_de, float* ws_dsr, float* dsr, int parts, void* stream);
+                      const float* lse, const float* gscale, const float* ga, const float* gc, int B, int V, int d,
+                      const int* dynB, float* dE, int ld_de, float* ws_dsr, float* dsr, int parts, void* stream);
 /* log-probabilities (B,V): the (B,num_items) tensor every reference model's forward() returns. */
 int srec_score_logp(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const float* lse, int B,
                     int V, int d, const int* dynB, float* logp, long ld_logp, void* stream);

@@ -35,10 +35,11 @@ struct CEArgs {
     const int* labels;
     const float* lse;
     const float* gscale;
+    const float* ga; const float* gc;   // optional per-session coefficients of the softmax / one-hot terms
     const int* dynB;
     int B, V, d;
     float* part_m; float* part_l; float* lab_logit;   // FWD
-    float* dE; int ld_de;                              // DE
+    float* dE; int ld_de; int acc_dE;                  // DE (acc_dE: add to the existing contents)
     float* part_dsr;                                   // DSR [R][B][d]
     float* logp; long ld_logp;                         // LOGP
     int chunks_per_range;
@@ -137,18 +138,17 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
     const bool x_empty = (x0 >= nx);
     const int tile_id = ITEMS_X ? blockIdx.x : 0;
 
+    float gs = 1.f;
+    if (HAS_ACC) gs = (a.gscale != nullptr ? *a.gscale : 1.f) / (float)(Bd > 0 ? Bd : 1);
+
     float4 regs[2 * NT];
     gload_tile<NT>(regs, Xsrc, ldx, x0, nx > 0 ? nx : 1, d, tid);
     lstore_tile<NT>(Xs, regs, x0, nx, d, tid);
 
-    float gs = 1.f;
-    if (HAS_ACC) {
-        gs = (a.gscale != nullptr ? *a.gscale : 1.f) / (float)(Bd > 0 ? Bd : 1);
-    }
-
     // per-X-row quantities for this lane's 16 accumulator rows
     float xq[16];      // ITEMS_X: cs[item]   SESS_X: lse[session]
     int xlab[16];      // SESS_X: label[session]
+    float xga[16], xgc[16];   // SESS_X: per-session gradient coefficients
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int xi = x0 + si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
             xq[r] = (MODE != MODE_FWD && xi < nx) ? a.lse[xi] : 0.f;
             xlab[r] = (MODE == MODE_DSR && xi < nx) ? a.labels[xi] : -1;
         }
+        xga[r] = (MODE == MODE_DSR && a.ga != nullptr && xi < nx) ? a.ga[xi] : gs;
+        xgc[r] = (MODE == MODE_DSR && a.gc != nullptr && xi < nx) ? a.gc[xi] : gs;
     }
 
     f32x16 acc[NCB];
@@ -178,11 +180,13 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
         const int yj = y0 + sj * 32 + l31;           // global Y row of this lane's column
         const bool yvalid = yj < yend;
         float yq = 1.f; int ylab = -1;
+        float yga = gs, ygc = gs;
         if (MODE == MODE_FWD) {
             ylab = yvalid ? a.labels[yj] : -1;
         } else if (MODE == MODE_DE) {
             yq = yvalid ? a.lse[yj] : 0.f;
             ylab = yvalid ? a.labels[yj] : -1;
+            if (a.ga != nullptr) { yga = yvalid ? a.ga[yj] : 0.f; ygc = yvalid ? a.gc[yj] : 0.f; }
         } else {
             yq = (a.cs != nullptr && yvalid) ? a.cs[yj] : 1.f;
         }
@@ -278,10 +282,10 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
                 if (xi < nx && yvalid) {
                     if (ITEMS_X) {
                         const float zz = xq[r] * s[r];
-                        p = (__expf(zz - yq) - (ylab == xi ? 1.f : 0.f)) * gs * xq[r];
+                        p = (__expf(zz - yq) * yga - (ylab == xi ? ygc : 0.f)) * xq[r];
                     } else {
                         const float zz = yq * s[r];
-                        p = (__expf(zz - xq[r]) - (xlab[r] == yj ? 1.f : 0.f)) * gs * yq;
+                        p = (__expf(zz - xq[r]) * xga[r] - (xlab[r] == yj ? xgc[r] : 0.f)) * yq;
                     }
                 }
                 Ps[xl * PLD + sj * 32 + l31] = p;
@@ -332,7 +336,10 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int xi = x0 + si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (MODE == MODE_DE) {
-                    if (xi < a.V) a.dE[(size_t)xi * a.ld_de + col] = acc[c][r];
+                    if (xi < a.V) {
+                        float* q = a.dE + (size_t)xi * a.ld_de + col;
+                        *q = a.acc_dE ? *q + acc[c][r] : acc[c][r];
+                    }
                 } else {
                     if (xi < a.B) a.part_dsr[((size_t)blockIdx.x * a.B + xi) * d + col] = (xi < nx) ? acc[c][r] : 0.f;
                 }
@@ -464,17 +471,20 @@ extern "C" int srec_score_ce_fwd(const float* sr, int ld_sr, const float* E, int
 }
 
 // Backward: dE[V,d] (dense, every row written) and dsr[B,d].  ws_dsr holds n_ranges*B*d floats.
-// parts: bit0 = dE kernel, bit1 = d sr kernels (3 = both; single parts exist so bench.py can time one kernel).
+// parts: bit0 = dE kernel, bit1 = d sr kernels (3 = both; single parts exist so bench.py can time one kernel),
+// bit2 = accumulate into dE instead of overwriting it (several scoring heads on one table).
+// ga/gc (nullable, both or none): per-session coefficients, dS[b,v] = (ga[b]*softmax[b,v] - gc[b]*[v==label_b]) * cs[v]
+// (any loss that is a function of (lse_b, z[b,label_b]): mixtures of soft-maxes, weighted CE); default gscale/B.
 extern "C" int srec_score_ce_bwd(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs,
-                                 const int* labels, const float* lse, const float* gscale, int B, int V, int d,
-                                 const int* dynB, float* dE, int ld_de, float* ws_dsr, float* dsr, int parts,
-                                 void* stream) {
+                                 const int* labels, const float* lse, const float* gscale, const float* ga,
+                                 const float* gc, int B, int V, int d, const int* dynB, float* dE, int ld_de,
+                                 float* ws_dsr, float* dsr, int parts, void* stream) {
     if (d <= 0 || d > 256 || (d & 3) || (ld_sr & 3) || (ld_e & 3)) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     CEArgs a{};
     a.sr = sr; a.ld_sr = ld_sr; a.E = E; a.ld_e = ld_e; a.cs = cs; a.labels = labels; a.lse = lse;
-    a.gscale = gscale; a.dynB = dynB; a.B = B; a.V = V; a.d = d;
-    a.dE = dE; a.ld_de = ld_de; a.part_dsr = ws_dsr;
+    a.gscale = gscale; a.ga = ga; a.gc = gc; a.dynB = dynB; a.B = B; a.V = V; a.d = d;
+    a.dE = dE; a.ld_de = ld_de; a.part_dsr = ws_dsr; a.acc_dE = (parts & 4) ? 1 : 0;
     int rc = 0;
     if (parts & 1) rc = launch_mode<MODE_DE>(a, dim3(cdiv(V, 64)), st);
     if (rc) return rc;

@@ -130,7 +130,7 @@ class HipLocal:
         B, d = sr.shape
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         lib.srec_score_ce_bwd(ptr(sr), sr.stride(0), ptr(table), table.stride(0), ptr(cs), ptr(labels_local), ptr(lse),
-                              ptr(gscale), B, table.shape[0], d, None, ptr(dE), dE.stride(0), ptr(ws.dsr_part), ptr(dsr),
+                              ptr(gscale), None, None, B, table.shape[0], d, None, ptr(dE), dE.stride(0), ptr(ws.dsr_part), ptr(dsr),
                               3, stream())
         if cs is not None:
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), cs_inv_scale, ptr(dE), dE.stride(0),

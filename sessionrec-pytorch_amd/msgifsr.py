@@ -11,7 +11,8 @@ Documented deviations:
   * one fc projection per (GAT module, node type) is shared by every relation that uses it as
     source or destination - identical to the reference whenever feat_drop == 0; with dropout the
     reference draws an independent mask per (relation, role), here one mask per (conv, type);
-  * `extra` (repeat/explore mix) and the 'max'/'concat' reducers are not on the HIP path yet.
+  * `extra` (repeat/explore mix) and the 'max'/'concat' reducers are not on the HIP path yet; `fusion`
+    (order mixture, msgifsr.py:311-317) is: K fused scoring passes, the mixture on the (lse, label-logit) pairs.
 """
 import math
 
@@ -233,8 +234,6 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         if self.extra:
             raise NotImplementedError('MSGIFSR(extra=True) is not on the HIP path yet; pass extra=False '
                                       '(the reference scripts default to it: main_msgifsr.py:100-104)')
-        if self.fusion and K > 1:
-            raise NotImplementedError('MSGIFSR(fusion=True) is not on the HIP path yet; pass fusion=False')
         self._renorm(mg)
         W = self._table()
         d = self.embedding_dim
@@ -264,7 +263,38 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         for i in live:
             s = ops.linear_cat([feat_vs[i], sr_g[i]], self.fc_sr[i].weight, None, dB)
             srs.append(ops.normalize(s, 0, dB) if self.norm else s)
+        if self.fusion and K > 1:
+            return srs                                     # one session vector per order (IFR mixture)
         return srs[0]
 
+    def fused_loss(self, *inputs_and_labels, dynB=None):
+        if not (self.fusion and self.order > 1):
+            return super().fused_loss(*inputs_and_labels, dynB=dynB)
+        if self.shard is not None:
+            raise NotImplementedError('order fusion with a row-sharded table')
+        # msgifsr.py:311-321: score = sum_k softmax(alpha)_k softmax(12 logits_k); loss = -mean log score[label]
+        mg, labels = inputs_and_labels
+        B = labels.numel()
+        if dynB is None:
+            dynB = mg.dynp('B')
+        st = self._state(B)
+        cs, inv_scale = self._col_scale(st)
+        srs = self.session_repr(mg, tgrad=st['tgrad'])
+        lab32 = labels.to(torch.int32)
+        st['tgrad'].fresh = False
+        logits = []
+        for sr in srs:
+            lse, lab = ops.score_stats(sr, self._table(), cs, lab32, st['ws'][B], st['tgrad'], dynB, inv_scale)
+            logits.append(lab - lse)                       # log softmax_k[label]
+        logp = torch.logsumexp(torch.stack(logits, 1) + torch.log_softmax(self.alpha, 0).unsqueeze(0), dim=1)
+        if dynB is not None:
+            live = (torch.arange(B, device=logp.device) < dynB).to(logp.dtype)
+            return -(logp * live).sum() / dynB.to(logp.dtype).clamp(min=1).sum()
+        return -logp.mean()
+
     def forward(self, mg):
-        return self._log_probs(self.session_repr(mg))
+        sr = self.session_repr(mg)
+        if self.fusion and self.order > 1:
+            la = torch.log_softmax(self.alpha, 0)
+            return torch.logsumexp(torch.stack([self._log_probs(s) + la[k] for k, s in enumerate(sr)], 0), dim=0)
+        return self._log_probs(sr)

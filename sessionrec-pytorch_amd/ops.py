@@ -395,13 +395,59 @@ class ScoreCE(torch.autograd.Function):
         gl = gloss.reshape(1).to(torch.float32).contiguous()
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), ptr(gl),
-                              B, V, d, ptr(ctx.dynB), ptr(tg.buf), tg.buf.stride(0), ptr(ws.dsr_part), ptr(dsr),
+                              None, None, B, V, d, ptr(ctx.dynB), ptr(tg.buf), tg.buf.stride(0), ptr(ws.dsr_part), ptr(dsr),
                               3, stream())
         if cs is not None:      # rows were L2-normalised before scoring: project out the radial part
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(tg.buf),
                                      tg.buf.stride(0), V, d, stream())
         tg.fresh = True
         return dsr, None, None, None, None, None, None, None
+
+
+class ScoreStats(torch.autograd.Function):
+    """(lse_b, z[b,label_b]) of the full-catalog logits, logits never materialised; differentiable in both
+    outputs, so any loss built from them (mixtures of soft-maxes: msgifsr.py:311-317) trains through the
+    fused kernels.  Several heads may share one table: the first backward of a step overwrites the dense
+    table gradient, later ones accumulate."""
+
+    @staticmethod
+    def forward(ctx, sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale):
+        sr = _rows(sr)
+        B, d = sr.shape
+        V = table.shape[0]
+        dev = sr.device
+        lse = torch.empty(B, device=dev, dtype=torch.float32)
+        lossvec = torch.empty(B, device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        lab = torch.zeros(B, device=dev, dtype=torch.float32)
+        lib.srec_score_ce_fwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), B, V, d, ptr(dynB),
+                              ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
+        ctx.save_for_backward(sr, table, cs, labels, lse)
+        ctx.ws, ctx.tgrad, ctx.dynB, ctx.cs_inv_scale = ws, tgrad, dynB, cs_inv_scale
+        return lse, lab
+
+    @staticmethod
+    def backward(ctx, dlse, dlab):
+        sr, table, cs, labels, lse = ctx.saved_tensors
+        B, d = sr.shape
+        V = table.shape[0]
+        tg, ws = ctx.tgrad, ctx.ws
+        ga = dlse.contiguous().float()
+        gc = (-dlab).contiguous().float()
+        dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
+        parts = 3 | (4 if tg.fresh else 0)
+        lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), None,
+                              ptr(ga), ptr(gc), B, V, d, ptr(ctx.dynB), ptr(tg.buf), tg.buf.stride(0), ptr(ws.dsr_part),
+                              ptr(dsr), parts, stream())
+        if cs is not None:      # projection is linear and idempotent: safe after every accumulation
+            lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(tg.buf),
+                                     tg.buf.stride(0), V, d, stream())
+        tg.fresh = True
+        return dsr, None, None, None, None, None, None, None
+
+
+def score_stats(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0):
+    return ScoreStats.apply(sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale)
 
 
 def score_ce(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0):

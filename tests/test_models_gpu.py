@@ -106,7 +106,8 @@ def adam_close(a, b, lr=1e-3, steps=3, what=''):
 
 CASES = ['srgnn_s32', 'srgnn_edge', 'niser_s32', 'niser_edge',
          'lessr_L1_s32', 'lessr_L1_edge', 'lessr_L3_s32', 'lessr_L3_edge',
-         'msgifsr_K1_s32', 'msgifsr_K1_edge', 'msgifsr_K2_s32', 'msgifsr_K2_edge', 'msgifsr_K3_s32', 'msgifsr_K3_edge']
+         'msgifsr_K1_s32', 'msgifsr_K1_edge', 'msgifsr_K2_s32', 'msgifsr_K2_edge', 'msgifsr_K3_s32', 'msgifsr_K3_edge',
+         'msgifsr_K3_fus_s32', 'msgifsr_K3_fus_edge']
 
 
 def grad_close(p, ref, what):
