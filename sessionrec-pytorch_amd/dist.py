@@ -243,6 +243,7 @@ class VocabParallel:
     def lookup(self, table, idx, uniq):
         items, uptr, upos = uniq[:3]
         n, U = idx.numel(), items.numel()
+        uptr = uptr[:U + 1]
         cap = self.capacity(max(n, U))
         idx_pad = self._pad(idx.to(torch.int64), cap)
         items_pad = self._pad(items.to(torch.int64), cap)

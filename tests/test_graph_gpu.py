@@ -94,3 +94,24 @@ def test_graph_replay_matches_eager_training(dev, kind):
         err = (p.detach() - q.detach()).abs()
         frac = (err <= 2e-5 + 1e-4 * q.detach().abs()).float().mean().item()
         assert frac >= 0.995 and err.max().item() <= 0.02 * 1e-2 * len(batches), (k, frac, err.max().item())
+
+
+def test_sharded_single_rank_with_padded_batch(dev):
+    """the bench's N>1 configuration (row-sharded table + capacity-padded batches + fixed request capacity),
+    exercised with one rank: must equal the plain fused path"""
+    c, D = pkg('collate'), pkg('dist')
+    rng = np.random.default_rng(5)
+    V = 400
+    model, mk = _setup('msgifsr', dev, V)
+    plain = copy.deepcopy(model)
+    samples = _samples(rng, 32, V)
+    caps = c.default_caps(32, 12)
+    (xp,), lp = mk(caps)(samples)
+    (xe,), le = mk(None)(samples)
+    vp = D.VocabParallel(model, idx_cap=xp.cap('gidx'))
+    l1 = plain.fused_loss(xe.to(dev), le.to(dev))
+    l1.backward()
+    l2 = model.fused_loss(xp.to(dev), lp.to(dev))
+    l2.backward()
+    close(l2, l1, rtol=1e-6, atol=1e-6, what='loss')
+    close(vp.dE[:V], plain.table_grad.buf, rtol=1e-4, atol=1e-7, what='table grad')
