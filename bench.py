@@ -286,9 +286,19 @@ def main():
         kt = time_dominant_kernel(model, B * world, Vk, d, dev)
         flops_dE = 4.0 * B * world * Vk * d
         peak = 157.3                                      # TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
+        traffic, tsrc = None, None
+        try:                                  # HBM bytes per launch from the committed PMC passes (same kernel & shape)
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_flash_ce.json')))
+            w = pm['workload']
+            if (w['V'], w['d'], w['B']) == (Vk, d, B * world):
+                traffic = pm['kernels']['MODE_DE']['traffic_bytes']
+                tsrc = 'profiles/r01_pmc_flash_ce.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 2x FETCH correction)'
+        except Exception:
+            pass
         roof = dict(bound='mfma', kernel='flash_ce_kernel<MODE_DE> (fused scoring/CE backward, dE pass)',
                     achieved=flops_dE / kt['dE'] / 1e12, peak=peak, unit='TFLOP/s',
-                    frac=flops_dE / kt['dE'] / 1e12 / peak, traffic=None,
+                    frac=flops_dE / kt['dE'] / 1e12 / peak, traffic=traffic, traffic_unit='bytes/launch', traffic_source=tsrc,
+                    algorithmic_bytes=2.0 * Vk * d * 4, algorithmic_flop=flops_dE,
                     kernel_ms=dict(fwd=kt['fwd'] * 1e3, bwd_dE=kt['dE'] * 1e3, bwd_dsr=kt['dsr'] * 1e3))
         cpu = None
         if not args.no_cpu_baseline:

@@ -298,7 +298,7 @@ class SegAttn(torch.autograd.Function):
         we = we.reshape(-1).contiguous()
         B, h = Vq.shape
         N, D = X.shape
-        alpha = torch.zeros(N, device=X.device, dtype=torch.float32)
+        alpha = torch.empty(N, device=X.device, dtype=torch.float32)      # live nodes written, padded never read
         out = torch.empty(B, D, device=X.device, dtype=torch.float32)
         lib.srec_seg_attn_fwd(ptr(U), _ld(U), ptr(Vq), _ld(Vq), ptr(we), ptr(X), _ld(X), ptr(seg), B, ptr(dynB), h, D,
                               ptr(alpha), ptr(out), D, stream())
@@ -605,7 +605,7 @@ class GATRelation(torch.autograd.Function):
         er = torch.empty(Nd, H, device=dev, dtype=torch.float32)
         lib.srec_head_dot(ptr(Fs), _ld(Fs), ptr(al), Ns, ptr(dyn_ns), H, D, ptr(el), stream())
         lib.srec_head_dot(ptr(Fd), _ld(Fd), ptr(ar), Nd, ptr(dyn_nd), H, D, ptr(er), stream())
-        A = torch.zeros(max(E, 1), H, device=dev, dtype=torch.float32)
+        A = torch.empty(max(E, 1), H, device=dev, dtype=torch.float32)    # every live edge written by the kernel
         rst = torch.empty(Nd, HD, device=dev, dtype=torch.float32)
         lib.srec_gat_agg_fwd(ptr(Fs), _ld(Fs), ptr(el), ptr(er), ptr(in_ptr), ptr(in_idx), ptr(esrc), Nd, ptr(dyn_nd),
                              H, D, slope, ptr(A), ptr(rst), HD, stream())
@@ -626,7 +626,7 @@ class GATRelation(torch.autograd.Function):
         Nd = Fd.shape[0]
         D = HD // H
         dev = Fs.device
-        DP = torch.zeros_like(A)
+        DP = torch.empty_like(A)
         der = torch.empty(Nd, H, device=dev, dtype=torch.float32)
         lib.srec_gat_bwd_dst(ptr(dR), _ld(dR), ptr(Fs), _ld(Fs), ptr(el), ptr(er), ptr(A), ptr(in_ptr), ptr(in_idx),
                              ptr(esrc), Nd, ptr(dyn_nd), H, D, ctx.slope, ptr(DP), ptr(der), stream())
