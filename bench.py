@@ -57,17 +57,24 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False
     data = ds.AugmentedDataset(arr)
     assert len(data) >= n_batches * B, (len(data), n_batches * B)
     samples = [[data[b * B + i] for i in range(B)] for b in range(n_batches)]
+    def factory(caps):
+        if model_name in ('SRGNN', 'NISER'):
+            return col.collate_fn_factory(col.seq_to_session_graph, caps=caps)
+        if model_name == 'LESSR':
+            return col.collate_fn_factory(col.seq_to_eop_multigraph, caps=caps)
+        return col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), order, caps=caps)
     caps = None
-    if padded:                          # capacities from the data (max over the batches + 10 %), as a loader would
-        mx = max(sum(len(set(s)) for s, _ in smp) for smp in samples)
-        n = (int(mx * 1.1) + 255) // 256 * 256
-        caps = dict(B=B, N=n, E=n, U=n)
-    if model_name in ('SRGNN', 'NISER'):
-        fn = col.collate_fn_factory(col.seq_to_session_graph, caps=caps)
-    elif model_name == 'LESSR':
-        fn = col.collate_fn_factory(col.seq_to_eop_multigraph, caps=caps)
-    else:
-        fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), order, caps=caps)
+    if padded:          # capacities = the maxima over the epoch's batches (a loader knows them after one pass)
+        mxN = mxE = mxU = 1
+        for smp in samples:
+            (fb,), _ = factory(None)(smp)
+            cnt = fb.meta['counts']
+            mxN = max([mxN] + [v for k, v in cnt.items() if k.startswith('N') and k != 'NT'])
+            mxE = max([mxE] + [v for k, v in cnt.items() if k.startswith('E')])
+            mxU = max(mxU, cnt.get('U', 1))
+        r256 = lambda v: (v + 255) // 256 * 256
+        caps = dict(B=B, N=r256(mxN), E=r256(mxE), U=r256(mxU))
+    fn = factory(caps)
     return [fn(s) for s in samples], samples
 
 
@@ -222,7 +229,7 @@ def main():
         print(json.dumps(time_dominant_kernel(model, B, V, d, dev, iters=5)))
         return
     n_batches = args.steps + args.warmup
-    padded = args.model in ('SRGNN', 'NISER', 'MSGIFSR')
+    padded = True
     use_graph = (not args.no_graph) and padded and world == 1       # N > 1: eager launches (RCCL inside)
     batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank, padded=padded)
     torch.manual_seed(123)
@@ -314,8 +321,9 @@ def main():
                                             'encoder replicated' % world) if world > 1 else 'single GPU',
                                final_loss=final_loss),
                    roofline=roof, cpu_baseline=cpu)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()                      # the other ranks wait for rank 0's kernel timing / CPU baseline
         dist.destroy_process_group()
 
 

@@ -24,17 +24,18 @@ class EOPA(nn.Module):
         self.activation = activation
 
     def forward(self, mg, feat):
+        dN = mg.dynp('N')
         if self.batch_norm is not None:
-            feat = ops.batch_norm(feat, self.batch_norm)
+            feat = ops.batch_norm(feat, self.batch_norm, dN)
         if mg.count('E') > 0:
             ft = self.feat_drop(feat)
-            GI = ops.linear(ft, self.gru.weight_ih_l0, self.gru.bias_ih_l0)
-            neigh = ops.gru_seq(GI, self.gru.weight_hh_l0, self.gru.bias_hh_l0, _graph(mg))
-            rst = ops.linear_cat([feat, neigh], torch.cat([self.fc_self.weight, self.fc_neigh.weight], 1))
+            GI = ops.linear(ft, self.gru.weight_ih_l0, self.gru.bias_ih_l0, dN)
+            neigh = ops.gru_seq(GI, self.gru.weight_hh_l0, self.gru.bias_hh_l0, _graph(mg), dN, mg.dynp('E'))
+            rst = ops.linear_cat([feat, neigh], torch.cat([self.fc_self.weight, self.fc_neigh.weight], 1), None, dN)
         else:
-            rst = ops.linear(feat, self.fc_self.weight)
+            rst = ops.linear(feat, self.fc_self.weight, None, dN)
         if self.activation is not None:
-            rst = ops.prelu(rst, self.activation.weight)
+            rst = ops.prelu(rst, self.activation.weight, dN)
         return rst
 
 
@@ -50,15 +51,16 @@ class SGAT(nn.Module):
         self.activation = activation
 
     def forward(self, sg, feat):
+        dN = sg.dynp('N')
         if self.batch_norm is not None:
-            feat = ops.batch_norm(feat, self.batch_norm)
+            feat = ops.batch_norm(feat, self.batch_norm, dN)
         feat = self.feat_drop(feat)
-        q = ops.linear(feat, self.fc_q.weight, self.fc_q.bias)
-        k = ops.linear(feat, self.fc_k.weight)
-        v = ops.linear(feat, self.fc_v.weight)
-        rst = ops.sgat_attn(q, k, self.fc_e.weight, v, _graph(sg))
+        q = ops.linear(feat, self.fc_q.weight, self.fc_q.bias, dN)
+        k = ops.linear(feat, self.fc_k.weight, None, dN)
+        v = ops.linear(feat, self.fc_v.weight, None, dN)
+        rst = ops.sgat_attn(q, k, self.fc_e.weight, v, _graph(sg), dN)
         if self.activation is not None:
-            rst = ops.prelu(rst, self.activation.weight)
+            rst = ops.prelu(rst, self.activation.weight, dN)
         return rst
 
 
@@ -74,16 +76,17 @@ class AttnReadout(nn.Module):
         self.activation = activation
 
     def forward(self, mg, feat):
+        dN, dB = mg.dynp('N'), mg.dynp('B')
         if self.batch_norm is not None:
-            feat = ops.batch_norm(feat, self.batch_norm)
+            feat = ops.batch_norm(feat, self.batch_norm, dN)
         feat = self.feat_drop(feat)
-        U = ops.linear(feat, self.fc_u.weight)
-        Vq = ops.linear(ops.row_gather(feat, mg.last), self.fc_v.weight, self.fc_v.bias)
-        rst = ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg)
+        U = ops.linear(feat, self.fc_u.weight, None, dN)
+        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB)
+        rst = ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg, dB)
         if self.fc_out is not None:
-            rst = ops.linear(rst, self.fc_out.weight)
+            rst = ops.linear(rst, self.fc_out.weight, None, dB)
         if self.activation is not None:
-            rst = ops.prelu(rst, self.activation.weight)
+            rst = ops.prelu(rst, self.activation.weight, dB)
         return rst
 
 
@@ -115,16 +118,18 @@ class LESSR(_ScoringMixin, nn.Module):
         W = self.embedding.weight
         with torch.no_grad():                    # Embedding(max_norm=1): in-place renorm before the lookup
             lib.srec_renorm_rows(ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], 1.0, stream())
-        feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad)
+        dN, dB = mg.dynp('N'), mg.dynp('B')
+        feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
+                            dN, mg.dynp('U'))
         for i, layer in enumerate(self.layers):
             out = layer(mg, feat) if i % 2 == 0 else layer(sg, feat)
             feat = torch.cat([out, feat], dim=1)
         sr_g = self.readout(mg, feat)
-        sr_l = ops.row_gather(feat, mg.last)
+        sr_l = ops.row_gather(feat, mg.last, dB)
         sr = torch.cat([sr_l, sr_g], dim=1)
         if self.batch_norm is not None:
-            sr = ops.batch_norm(sr, self.batch_norm)
-        return ops.linear(self.feat_drop(sr), self.fc_sr.weight)
+            sr = ops.batch_norm(sr, self.batch_norm, dB)
+        return ops.linear(self.feat_drop(sr), self.fc_sr.weight, None, dB)
 
     def forward(self, mg, sg=None):
         return self._log_probs(self.session_repr(mg, sg))

@@ -768,7 +768,7 @@ class GRUSeq(torch.autograd.Function):
     GI = ft W_ih^T + b_ih (per source node); graph = (in_ptr, in_idx, out_ptr, out_idx, esrc, edst)."""
 
     @staticmethod
-    def forward(ctx, GI, Whh, bhh, graph, dyn):
+    def forward(ctx, GI, Whh, bhh, graph, dyn, dynE=None):
         GI = _rows(GI)
         in_ptr, in_idx, out_ptr, out_idx, esrc, edst = graph
         N, D3 = GI.shape
@@ -784,7 +784,7 @@ class GRUSeq(torch.autograd.Function):
         lib.srec_gru_seq_fwd(ptr(GI), _ld(GI), ptr(WhhT), ptr(bhh), ptr(in_ptr), ptr(in_idx), ptr(esrc), N, ptr(dyn), D,
                              ptr(neigh), D, ptr(gates), ptr(Hprev), ptr(ghn), stream())
         ctx.save_for_backward(Whh, gates, Hprev, ghn)
-        ctx.graph, ctx.dyn, ctx.shape = graph, dyn, (N, D, E)
+        ctx.graph, ctx.dyn, ctx.dynE, ctx.shape = graph, dyn, dynE, (N, D, E)
         return neigh
 
     @staticmethod
@@ -806,13 +806,13 @@ class GRUSeq(torch.autograd.Function):
         dWhh = torch.zeros(3 * D, D, device=dev, dtype=torch.float32)
         dbhh = torch.zeros(3 * D, device=dev, dtype=torch.float32)
         if E > 0:
-            gemm_tn(dGHe[:E], Hprev[:E], dWhh)
-            col_sum(dGHe, E, 3 * D, dbhh)
-        return dGI, dWhh, dbhh, None, None
+            gemm_tn(dGHe[:E], Hprev[:E], dWhh, ctx.dynE)       # padded edge records are zero rows
+            col_sum(dGHe, E, 3 * D, dbhh, ctx.dynE)
+        return dGI, dWhh, dbhh, None, None, None
 
 
-def gru_seq(GI, Whh, bhh, graph, dyn=None):
-    return GRUSeq.apply(GI, Whh, bhh, graph, dyn)
+def gru_seq(GI, Whh, bhh, graph, dyn=None, dynE=None):
+    return GRUSeq.apply(GI, Whh, bhh, graph, dyn, dynE)
 
 
 class SGATAttn(torch.autograd.Function):

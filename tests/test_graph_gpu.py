@@ -30,13 +30,16 @@ def _setup(kind, dev, V=400, d=32):
     elif kind == 'niser':
         model = sp.NISER(V, d, 1).to(dev)
         mk = lambda caps: c.collate_fn_factory(c.seq_to_session_graph, caps=caps)
+    elif kind == 'lessr':
+        model = sp.LESSR(V, d, 3).to(dev)
+        mk = lambda caps: c.collate_fn_factory(c.seq_to_eop_multigraph, c.seq_to_shortcut_graph, caps=caps)
     else:
         model = sp.SRGNN(V, d, 1).to(dev)
         mk = lambda caps: c.collate_fn_factory(c.seq_to_session_graph, caps=caps)
     return model, mk
 
 
-@pytest.mark.parametrize('kind', ['srgnn', 'niser', 'msgifsr'])
+@pytest.mark.parametrize('kind', ['srgnn', 'niser', 'msgifsr', 'lessr'])
 def test_padded_layout_equals_exact(dev, kind):
     c = pkg('collate')
     rng = np.random.default_rng(2)
@@ -45,12 +48,16 @@ def test_padded_layout_equals_exact(dev, kind):
     m2 = copy.deepcopy(model)
     samples = _samples(rng, 24, V)
     caps = c.default_caps(32, 12)
-    (xe,), le = mk(None)(samples)
-    (xp,), lp = mk(caps)(samples)
-    assert lp.numel() == 32 and xp.meta['padded']
-    l1 = model.fused_loss(xe.to(dev), le.to(dev))
+    if kind == 'lessr':                       # shortcut graphs have up to L(L+1)/2 edges per session
+        caps = dict(caps, E=caps['N'] * 7)
+    xe, le = mk(None)(samples)
+    xp, lp = mk(caps)(samples)
+    assert lp.numel() == 32 and xp[0].meta['padded']
+    model.train()
+    m2.train()
+    l1 = model.fused_loss(*[x.to(dev) for x in xe], le.to(dev))
     l1.backward()
-    l2 = m2.fused_loss(xp.to(dev), lp.to(dev))
+    l2 = m2.fused_loss(*[x.to(dev) for x in xp], lp.to(dev))
     l2.backward()
     close(l2, l1, rtol=1e-6, atol=1e-6, what='loss')
     close(m2.table_grad.buf, model.table_grad.buf, rtol=1e-4, atol=1e-7, what='table grad')
@@ -60,7 +67,7 @@ def test_padded_layout_equals_exact(dev, kind):
             close(p2[k].grad, p.grad, rtol=1e-4, atol=1e-7, what=k)
 
 
-@pytest.mark.parametrize('kind', ['niser', 'msgifsr'])
+@pytest.mark.parametrize('kind', ['niser', 'msgifsr', 'lessr'])
 def test_graph_replay_matches_eager_training(dev, kind):
     c, train, optim, G = pkg('collate'), pkg('train'), pkg('optim'), pkg('graph')
     rng = np.random.default_rng(3)
@@ -68,15 +75,17 @@ def test_graph_replay_matches_eager_training(dev, kind):
     model, mk = _setup(kind, dev, V)
     ref = copy.deepcopy(model)
     caps = c.default_caps(32, 12)
+    if kind == 'lessr':
+        caps = dict(caps, E=caps['N'] * 7)
     batches = [_samples(rng, n, V) for n in (32, 32, 20, 32, 27)]     # full and partial batches
     # eager, exact layouts
     opt_r = optim.FusedAdam(train.fix_weight_decay(ref), lr=1e-2, weight_decay=1e-4, model=ref)
     ref.train()
     ref_losses = []
     for s in batches:
-        (x,), lab = mk(None)(s)
+        xs, lab = mk(None)(s)
         opt_r.zero_grad()
-        loss = ref.fused_loss(x.to(dev), lab.to(dev))
+        loss = ref.fused_loss(*[x.to(dev) for x in xs], lab.to(dev))
         loss.backward()
         opt_r.step()
         ref_losses.append(loss.item())
@@ -84,11 +93,11 @@ def test_graph_replay_matches_eager_training(dev, kind):
     opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-2, weight_decay=1e-4, model=model)
     model.train()
     padded = [mk(caps)(s) for s in batches]
-    (x0,), l0 = padded[0]
-    step = G.GraphedTrainStep(model, opt, [x0.to(dev)], l0.to(dev))
+    x0, l0 = padded[0]
+    step = G.GraphedTrainStep(model, opt, [x.to(dev) for x in x0], l0.to(dev))
     losses = []
-    for (x,), lab in padded:
-        losses.append(step([x.to(dev)], lab.to(dev)).item())
+    for xs, lab in padded:
+        losses.append(step([x.to(dev) for x in xs], lab.to(dev)).item())
     assert np.allclose(losses, ref_losses, rtol=2e-5, atol=2e-5), (losses, ref_losses)
     for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         err = (p.detach() - q.detach()).abs()
