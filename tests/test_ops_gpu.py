@@ -415,3 +415,47 @@ def test_gemm_bf16_matches_bf16_rounded_reference(dev, M, N, K):
             close(gx, ref, what='bf16 nn', rtol=1e-4, atol=2e-4)
     finally:
         ops.set_precision('fp32')
+
+
+def test_score_ce_full_size_properties(dev):
+    """BASELINE full size (C3: V=37 484, d=256, B=512; logits would be 77 MB) through size-independent
+    properties instead of a materialised reference:
+      (1) identical catalog rows  -> loss = log V exactly, d sr = 0, every dE row = (1/V - [v==label]) sr / B summed;
+      (2) gradient linearity in the upstream scale;  (3) sum_v dE_v = -(1/B) sum_b (1 - 1) ... = 0 row-sum identity:
+          sum_v dS[b,v] = 0  =>  sum_v dE_v = sum_b (sum_v dS[b,v]) sr_b = 0;
+      (4) fused loss == -mean(log-prob[label]) from the LOGP pass on a slice of sessions."""
+    ops = _ops()
+    torch.manual_seed(11)
+    B, V, d = 512, 37484, 256
+    sr = torch.randn(B, d, device=dev) * 0.2
+    labels = torch.randint(0, V, (B,), device=dev)
+    ws = ops.CEWorkspace(B, V, d, dev)
+    # (1) identical rows
+    e = torch.randn(d, device=dev) * 0.1
+    E = e.unsqueeze(0).repeat(V, 1).contiguous()
+    tg = ops.TableGrad(E)
+    s1 = sr.clone().requires_grad_()
+    loss, _ = ops.score_ce(s1, E, None, labels.int(), ws, tg)
+    loss.backward()
+    assert abs(loss.item() - float(np.log(V))) < 1e-4, loss.item()
+    assert s1.grad.abs().max().item() < 1e-6
+    # (2)+(3) random catalog
+    E = (torch.randn(V, d, device=dev) * 0.1).contiguous()
+    tg = ops.TableGrad(E)
+    s2 = sr.clone().requires_grad_()
+    loss, _ = ops.score_ce(s2, E, None, labels.int(), ws, tg)
+    (3.0 * loss).backward()
+    g3, dE3 = s2.grad.clone(), tg.buf.clone()
+    s3 = sr.clone().requires_grad_()
+    loss2, _ = ops.score_ce(s3, E, None, labels.int(), ws, tg)
+    loss2.backward()
+    close(g3, 3.0 * s3.grad, what='linearity dsr', rtol=1e-5, atol=1e-9)
+    close(dE3, 3.0 * tg.buf, what='linearity dE', rtol=1e-5, atol=1e-9)
+    colsum = tg.buf.double().sum(0)
+    assert colsum.abs().max().item() < 1e-5, colsum.abs().max().item()
+    # (4) against the materialised log-probabilities of the first 64 sessions
+    logp = ops.score_logp(sr[:64].contiguous(), E, None, ops.CEWorkspace(64, V, d, dev))
+    ref = -logp.gather(1, labels[:64].unsqueeze(1)).mean()
+    l64, _ = ops.score_ce(sr[:64].contiguous(), E, None, labels[:64].int(), ops.CEWorkspace(64, V, d, dev), ops.TableGrad(E))
+    close(l64, ref, what='loss vs logp', rtol=1e-5, atol=1e-5)
+    assert torch.allclose(torch.logsumexp(logp, 1), torch.zeros(64, device=dev), atol=1e-4)
