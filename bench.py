@@ -89,11 +89,12 @@ def build_model(sp, name, V, d, order):
 
 
 def time_dominant_kernel(model, B, V, d, dev, iters=20):
-    """HIP-event timing of the fused scoring/CE backward dE kernel alone (4*B*V*d flop per launch)."""
+    """HIP-event timing (on the launch stream) of the fused scoring/CE kernels alone:
+    forward, backward dE pass (4*B*V*d flop per launch), backward d-sr pass."""
     ops = importlib.import_module('sessionrec-pytorch_amd.ops')
     L = importlib.import_module('sessionrec-pytorch_amd._lib')
     lib, ptr, stream = L.lib, L.ptr, L.stream
-    table = model._table().detach()
+    table = model._table().detach()[:V]
     sr = torch.randn(B, d, device=dev) * 0.1
     labels = torch.randint(0, V, (B,), device=dev, dtype=torch.int32)
     ws = ops.CEWorkspace(B, V, d, dev)
@@ -102,32 +103,41 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20):
     loss = torch.empty((), device=dev)
     dE = torch.empty_like(table)
     dsr = torch.empty(B, d, device=dev)
-    lib.srec_score_ce_fwd(ptr(sr), d, ptr(table), d, None, ptr(labels), B, V, d, None, ptr(ws.stats), ptr(ws.lab_logit),
-                          ptr(lse), ptr(lossvec), ptr(loss), stream())
+    bf16 = ops.use_bf16_scoring(d)
+    tb = ops.TableBF16(table).refresh(table) if bf16 else None
 
-    def run(parts):
-        lib.srec_score_ce_bwd(ptr(sr), d, ptr(table), d, None, ptr(labels), ptr(lse), None, None, None, B, V, d, None, ptr(dE), d,
-                              ptr(ws.dsr_part), ptr(dsr), parts, stream())
+    def fwd():
+        ops._ce_fwd(sr, table, None, labels, ws, None, tb, ws.lab_logit, lse, lossvec, loss)
+
+    def bwd(parts):
+        ops._ce_bwd(sr, table, None, labels, lse, None, None, None, ws, None, tb, dE, dsr, parts)
+    fwd()
     out = {}
-    for name, parts in (('dE', 1), ('dsr', 2)):
+    for name, fn in (('dE', lambda: bwd(1)), ('dsr', lambda: bwd(2)), ('fwd', fwd)):
         for _ in range(3):
-            run(parts)
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            run(parts)
+            fn()
         e1.record()
         torch.cuda.synchronize()
         out[name] = e0.elapsed_time(e1) / iters * 1e-3
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        lib.srec_score_ce_fwd(ptr(sr), d, ptr(table), d, None, ptr(labels), B, V, d, None, ptr(ws.stats),
-                              ptr(ws.lab_logit), ptr(lse), ptr(lossvec), ptr(loss), stream())
-    e1.record()
-    torch.cuda.synchronize()
-    out['fwd'] = e0.elapsed_time(e1) / iters * 1e-3
+    if bf16:
+        def prep():
+            tb.refresh(table)
+        for _ in range(3):
+            prep()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            prep()
+        e1.record()
+        torch.cuda.synchronize()
+        out['table_bf16_prepare'] = e0.elapsed_time(e1) / iters * 1e-3
+    out['bf16'] = bf16
     return out
 
 
@@ -226,7 +236,8 @@ def main():
     if args.kernel_only:
         torch.manual_seed(123)
         model = build_model(sp, 'SRGNN', V, d, 1).to(dev)
-        print(json.dumps(time_dominant_kernel(model, B, V, d, dev, iters=5)))
+        kt = time_dominant_kernel(model, B, V, d, dev, iters=5)
+        print(json.dumps(kt))
         return
     n_batches = args.steps + args.warmup
     padded = True

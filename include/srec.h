@@ -58,6 +58,20 @@ int srec_score_ce_bwd(const float* sr, int ld_sr, const float* E, int ld_e, cons
 int srec_score_logp(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const float* lse, int B,
                     int V, int d, const int* dynB, float* logp, long ld_logp, void* stream);
 
+/* bf16-operand variant of the fused scoring (score_ce_bf16.hip; BASELINE config C3).  srec_bf16_prepare rounds
+ * rows [R,d] fp32 into zero-padded bf16 copies: dst16 [Rp,d] and the transpose dstT16 [d,Rp] (Rp % 64 == 0, rows
+ * >= the live count zero).  The scoring entry points mirror the fp32 ones; d in {32,64,96,128,256}. */
+int srec_bf16_prepare(const float* src, int ld, int R, const int* dynR, int d, void* dst16, void* dstT16, int Rp,
+                      void* stream);
+int srec_ce_plan_bf16(int B, int V, int d, int* n_item_tiles, int* n_ranges);
+int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16, int Vp, const float* cs, const int* labels,
+                           int B, int V, int d, const int* dynB, float* ws_stats, float* lab_logit, float* lse,
+                           float* lossvec, float* loss, void* stream);
+int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int Bp, const void* E16, const void* ET16, int Vp,
+                           const float* cs, const int* labels, const float* lse, const float* gscale, const float* ga,
+                           const float* gc, int B, int V, int d, const int* dynB, float* dE, int ld_de, float* ws_dsr,
+                           float* dsr, int parts, void* stream);
+
 /* ---- embedding rows (rowops.hip) --------------------------------------------------------------------
  * gather: nn.Embedding lookup srgnn.py:133 niser.py:133 lessr.py:168 msgifsr.py:247.
  * scatter_add_sorted: its backward as a deterministic segmented sum (items[u] distinct, pos grouped by ptr). */

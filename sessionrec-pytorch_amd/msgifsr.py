@@ -283,8 +283,9 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         lab32 = labels.to(torch.int32)
         st['tgrad'].fresh = False
         logits = []
+        tb = self._table_bf16(st)
         for sr in srs:
-            lse, lab = ops.score_stats(sr, self._table(), cs, lab32, st['ws'][B], st['tgrad'], dynB, inv_scale)
+            lse, lab = ops.score_stats(sr, self._table(), cs, lab32, st['ws'][B], st['tgrad'], dynB, inv_scale, tb)
             logits.append(lab - lse)                       # log softmax_k[label]
         logp = torch.logsumexp(torch.stack(logits, 1) + torch.log_softmax(self.alpha, 0).unsqueeze(0), dim=1)
         if dynB is not None:

@@ -354,17 +354,77 @@ def seg_mean_add(H, F, seg, B, dynB=None):
 
 
 # ------------------------------------------------------------------------------------------ scoring
+BF16_DIMS = (32, 64, 96, 128, 256)
+
+
 class CEWorkspace:
-    """Reusable scratch of the fused scoring/CE kernels for one (B, V, d)."""
+    """Reusable scratch of the fused scoring/CE kernels for one (B, V, d) (sized for the fp32 and bf16 plans)."""
 
     def __init__(self, B, V, d, device):
         import ctypes
         nt, nr = ctypes.c_int(), ctypes.c_int()
         lib.srec_ce_plan(B, V, d, ctypes.addressof(nt), ctypes.addressof(nr))
+        nrange = nr.value
+        if d in BF16_DIMS:
+            lib.srec_ce_plan_bf16(B, V, d, ctypes.addressof(nt), ctypes.addressof(nr))
+            nrange = max(nrange, nr.value)
         self.B, self.V, self.d = B, V, d
         self.stats = torch.empty(2 * nt.value * B, device=device, dtype=torch.float32)
-        self.dsr_part = torch.empty(nr.value * B * d, device=device, dtype=torch.float32)
+        self.dsr_part = torch.empty(nrange * B * d, device=device, dtype=torch.float32)
         self.lab_logit = torch.zeros(B, device=device, dtype=torch.float32)
+        # bf16 operand copies of the session vectors (row-major + transposed), zero padded to 64 rows
+        self.Bp = (B + 63) // 64 * 64
+        self.sr16 = self.srT16 = None
+        if d in BF16_DIMS:
+            self.sr16 = torch.zeros(self.Bp, d, device=device, dtype=torch.bfloat16)
+            self.srT16 = torch.zeros(d, self.Bp, device=device, dtype=torch.bfloat16)
+
+
+class TableBF16:
+    """bf16 copies of the item table for the bf16 scoring kernels: E16 [Vp, d] and its transpose ET16 [d, Vp],
+    refreshed once per step (one pass over the table) by srec_bf16_prepare."""
+
+    def __init__(self, table):
+        V, d = table.shape
+        self.Vp = (V + 63) // 64 * 64
+        self.E16 = torch.zeros(self.Vp, d, device=table.device, dtype=torch.bfloat16)
+        self.ET16 = torch.zeros(d, self.Vp, device=table.device, dtype=torch.bfloat16)
+
+    def refresh(self, table):
+        V, d = table.shape
+        lib.srec_bf16_prepare(ptr(table), table.stride(0), V, None, d, ptr(self.E16), ptr(self.ET16), self.Vp, stream())
+        return self
+
+
+def use_bf16_scoring(d):
+    return PRECISION['matmul'] == 'bf16' and d in BF16_DIMS
+
+
+def _ce_fwd(sr, table, cs, labels, ws, dynB, tb, lab, lse, lossvec, loss):
+    B, d = sr.shape
+    V = table.shape[0]
+    if tb is not None:
+        lib.srec_bf16_prepare(ptr(sr), _ld(sr), B, ptr(dynB), d, ptr(ws.sr16), ptr(ws.srT16), ws.Bp, stream())
+        lib.srec_score_ce_fwd_bf16(ptr(ws.sr16), ws.Bp, ptr(tb.E16), tb.Vp, ptr(cs), ptr(labels), B, V, d, ptr(dynB),
+                                   ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
+    else:
+        lib.srec_score_ce_fwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), B, V, d, ptr(dynB),
+                              ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
+
+
+def _ce_bwd(sr, table, cs, labels, lse, gl, ga, gc, ws, dynB, tb, dE, dsr, parts):
+    B, d = sr.shape
+    V = table.shape[0]
+    if tb is not None:
+        # sr16 / srT16 still hold this head's session vectors only if no other head ran in between: re-prepare
+        lib.srec_bf16_prepare(ptr(sr), _ld(sr), B, ptr(dynB), d, ptr(ws.sr16), ptr(ws.srT16), ws.Bp, stream())
+        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), ptr(ws.srT16), ws.Bp, ptr(tb.E16), ptr(tb.ET16), tb.Vp, ptr(cs),
+                                   ptr(labels), ptr(lse), ptr(gl), ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE),
+                                   dE.stride(0), ptr(ws.dsr_part), ptr(dsr), parts, stream())
+    else:
+        lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), ptr(gl),
+                              ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE), dE.stride(0), ptr(ws.dsr_part), ptr(dsr),
+                              parts, stream())
 
 
 class ScoreCE(torch.autograd.Function):
@@ -372,17 +432,16 @@ class ScoreCE(torch.autograd.Function):
     table gradient into `tgrad.buf` (all rows) instead of returning it."""
 
     @staticmethod
-    def forward(ctx, sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale):
+    def forward(ctx, sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale, tb=None):
         sr = _rows(sr)
         B, d = sr.shape
         V = table.shape[0]
         lse = torch.empty(B, device=sr.device, dtype=torch.float32)
         lossvec = torch.empty(B, device=sr.device, dtype=torch.float32)
         loss = torch.empty((), device=sr.device, dtype=torch.float32)
-        lib.srec_score_ce_fwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), B, V, d, ptr(dynB),
-                              ptr(ws.stats), ptr(ws.lab_logit), ptr(lse), ptr(lossvec), ptr(loss), stream())
+        _ce_fwd(sr, table, cs, labels, ws, dynB, tb, ws.lab_logit, lse, lossvec, loss)
         ctx.save_for_backward(sr, table, cs, labels, lse)
-        ctx.ws, ctx.tgrad, ctx.dynB, ctx.cs_inv_scale = ws, tgrad, dynB, cs_inv_scale
+        ctx.ws, ctx.tgrad, ctx.dynB, ctx.cs_inv_scale, ctx.tb = ws, tgrad, dynB, cs_inv_scale, tb
         ctx.mark_non_differentiable(lse)
         return loss, lse
 
@@ -394,14 +453,12 @@ class ScoreCE(torch.autograd.Function):
         tg, ws = ctx.tgrad, ctx.ws
         gl = gloss.reshape(1).to(torch.float32).contiguous()
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
-        lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), ptr(gl),
-                              None, None, B, V, d, ptr(ctx.dynB), ptr(tg.buf), tg.buf.stride(0), ptr(ws.dsr_part), ptr(dsr),
-                              3, stream())
+        _ce_bwd(sr, table, cs, labels, lse, gl, None, None, ws, ctx.dynB, ctx.tb, tg.buf, dsr, 3)
         if cs is not None:      # rows were L2-normalised before scoring: project out the radial part
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(tg.buf),
                                      tg.buf.stride(0), V, d, stream())
         tg.fresh = True
-        return dsr, None, None, None, None, None, None, None
+        return dsr, None, None, None, None, None, None, None, None
 
 
 class ScoreStats(torch.autograd.Function):
@@ -411,7 +468,7 @@ class ScoreStats(torch.autograd.Function):
     table gradient, later ones accumulate."""
 
     @staticmethod
-    def forward(ctx, sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale):
+    def forward(ctx, sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale, tb=None):
         sr = _rows(sr)
         B, d = sr.shape
         V = table.shape[0]
@@ -420,10 +477,9 @@ class ScoreStats(torch.autograd.Function):
         lossvec = torch.empty(B, device=dev, dtype=torch.float32)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         lab = torch.zeros(B, device=dev, dtype=torch.float32)
-        lib.srec_score_ce_fwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), B, V, d, ptr(dynB),
-                              ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
+        _ce_fwd(sr, table, cs, labels, ws, dynB, tb, lab, lse, lossvec, loss)
         ctx.save_for_backward(sr, table, cs, labels, lse)
-        ctx.ws, ctx.tgrad, ctx.dynB, ctx.cs_inv_scale = ws, tgrad, dynB, cs_inv_scale
+        ctx.ws, ctx.tgrad, ctx.dynB, ctx.cs_inv_scale, ctx.tb = ws, tgrad, dynB, cs_inv_scale, tb
         return lse, lab
 
     @staticmethod
@@ -436,22 +492,20 @@ class ScoreStats(torch.autograd.Function):
         gc = (-dlab).contiguous().float()
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         parts = 3 | (4 if tg.fresh else 0)
-        lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), None,
-                              ptr(ga), ptr(gc), B, V, d, ptr(ctx.dynB), ptr(tg.buf), tg.buf.stride(0), ptr(ws.dsr_part),
-                              ptr(dsr), parts, stream())
+        _ce_bwd(sr, table, cs, labels, lse, None, ga, gc, ws, ctx.dynB, ctx.tb, tg.buf, dsr, parts)
         if cs is not None:      # projection is linear and idempotent: safe after every accumulation
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(tg.buf),
                                      tg.buf.stride(0), V, d, stream())
         tg.fresh = True
-        return dsr, None, None, None, None, None, None, None
+        return dsr, None, None, None, None, None, None, None, None
 
 
-def score_stats(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0):
-    return ScoreStats.apply(sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale)
+def score_stats(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0, tb=None):
+    return ScoreStats.apply(sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale, tb)
 
 
-def score_ce(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0):
-    return ScoreCE.apply(sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale)
+def score_ce(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0, tb=None):
+    return ScoreCE.apply(sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale, tb)
 
 
 class ScoreLogProb(torch.autograd.Function):

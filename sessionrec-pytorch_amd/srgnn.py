@@ -83,8 +83,18 @@ class _ScoringMixin:
         sr = self.session_repr(*inputs, tgrad=st['tgrad'])
         if self.shard is not None:
             return self.shard.loss(sr, self._table(), cs, labels, inv_scale)
-        loss, _ = ops.score_ce(sr, self._table(), cs, labels.to(torch.int32), st['ws'][B], st['tgrad'], dynB, inv_scale)
+        loss, _ = ops.score_ce(sr, self._table(), cs, labels.to(torch.int32), st['ws'][B], st['tgrad'], dynB, inv_scale,
+                               self._table_bf16(st))
         return loss
+
+    def _table_bf16(self, st):
+        """bf16 operand copies of the table for the bf16 scoring kernels (precision 'bf16'), refreshed per step"""
+        W = self._table()
+        if not ops.use_bf16_scoring(W.shape[1]):
+            return None
+        if st.get('tb16') is None:
+            st['tb16'] = ops.TableBF16(W)
+        return st['tb16'].refresh(W)
 
     def _log_probs(self, sr):
         B = sr.shape[0]

@@ -459,3 +459,32 @@ def test_score_ce_full_size_properties(dev):
     l64, _ = ops.score_ce(sr[:64].contiguous(), E, None, labels[:64].int(), ops.CEWorkspace(64, V, d, dev), ops.TableGrad(E))
     close(l64, ref, what='loss vs logp', rtol=1e-5, atol=1e-5)
     assert torch.allclose(torch.logsumexp(logp, 1), torch.zeros(64, device=dev), atol=1e-4)
+
+
+@pytest.mark.parametrize('B,V,d,cosine', [(512, 5000, 256, True), (100, 1000, 96, False), (37, 700, 64, True), (64, 64, 32, False)])
+def test_score_ce_bf16_within_stated_tolerance(dev, B, V, d, cosine):
+    """bf16-operand scoring kernels vs the fp32 reference.  Stated bf16 tolerances (SURVEY 8(c)): loss 5e-3 rel;
+    gradients: norm-wise relative error <= 2e-2 (bf16 operands + bf16 P, fp32 accumulation)."""
+    ops = _ops()
+    torch.manual_seed(B + V)
+    sr = (torch.randn(B, d, device=dev) * 0.3)
+    E = (torch.randn(V, d, device=dev) * 0.3)
+    labels = torch.randint(0, V, (B,), device=dev)
+    cs = (12.0 / E.norm(dim=1)).contiguous() if cosine else None
+    if cosine:
+        sr = torch.nn.functional.normalize(sr, dim=1)
+    ws = ops.CEWorkspace(B, V, d, dev)
+    tg = ops.TableGrad(E)
+    tb = ops.TableBF16(E).refresh(E)
+    srg = sr.clone().requires_grad_()
+    loss, lse = ops.score_ce(srg, E, cs, labels.int(), ws, tg, None, 1.0 / 12.0, tb)
+    loss.backward()
+    sr2, E2 = sr.clone().requires_grad_(), E.clone().requires_grad_()
+    z = sr2 @ (torch.nn.functional.normalize(E2, dim=1) * 12.0 if cosine else E2).t()
+    ref = torch.nn.functional.cross_entropy(z, labels)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 5e-3 * abs(ref.item()), (loss.item(), ref.item())
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert rel(srg.grad, sr2.grad) < 2e-2, rel(srg.grad, sr2.grad)
+    assert rel(tg.buf, E2.grad) < 2e-2, rel(tg.buf, E2.grad)
+    close(lse, torch.logsumexp(z, 1), what='lse', rtol=0, atol=3e-2)
