@@ -10,7 +10,8 @@ batch 512, session length <= 20, ids Zipf(1.0), 20 % immediate revisits, seed 12
 random-init weights of the named architecture.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  "roofline":     dominant kernel (fused scoring/CE backward dE pass) timed live with HIP events
+  "roofline":     dominant kernel (fused scoring/CE backward launch) timed live with HIP events around a hipGraph of
+                  back-to-back launches on the launch stream
   "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the reference math) timed on the
                   host cores of the same box on a bounded sample of the same workload.
 """
@@ -111,32 +112,37 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20):
 
     def bwd(parts):
         ops._ce_bwd(sr, table, None, labels, lse, None, None, None, ws, None, tb, dE, dsr, parts)
+
+    def bwd_kernel():         # the backward launch alone: session copies already prepared, slabs left unreduced
+        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), ptr(ws.srT16), ws.Bp, ptr(tb.E16), ptr(tb.ET16), tb.Vp, None,
+                                   ptr(labels), ptr(lse), None, None, None, B, V, d, None, ptr(dE), dE.stride(0),
+                                   ptr(ws.dsr_part), ptr(dsr), 3 | 8, stream())
     fwd()
     out = {}
-    for name, fn in (('dE', lambda: bwd(1)), ('dsr', lambda: bwd(2)), ('fwd', fwd)):
+
+    def timed(fn):
+        """`iters` back-to-back launches captured in one hipGraph (no host launch gaps), HIP events around the replay"""
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
-        out[name] = e0.elapsed_time(e1) / iters * 1e-3
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    for name, fn in (('dE', lambda: bwd(1)), ('dsr', lambda: bwd(2)), ('bwd', lambda: bwd(3)), ('fwd', fwd)):
+        out[name] = timed(fn)
     if bf16:
-        def prep():
-            tb.refresh(table)
-        for _ in range(3):
-            prep()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            prep()
-        e1.record()
-        torch.cuda.synchronize()
-        out['table_bf16_prepare'] = e0.elapsed_time(e1) / iters * 1e-3
+        out['table_bf16_prepare'] = timed(lambda: tb.refresh(table))
+        out['bwd_kernel'] = timed(bwd_kernel)
     out['bf16'] = bf16
     return out
 
@@ -302,22 +308,33 @@ def main():
     if rank == 0:
         Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
         kt = time_dominant_kernel(model, B * world, Vk, d, dev)
-        flops_dE = 4.0 * B * world * Vk * d
-        peak = 157.3                                      # TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
+        Bg = B * world
+        kms = {k: v * 1e3 for k, v in kt.items() if k != 'bf16'}
+        if kt['bf16']:
+            # one launch computes dE (all item tiles) and the d-sr slabs: 2*B*V*d algorithmic flop each
+            # (the S = sr E^T recomputation inside both halves is not counted)
+            name, flop, t, peak = ('flash_ce_bf16_kernel<KIND_BWD> (fused scoring/CE backward: dE item tiles + d-sr '
+                                   'item ranges in one launch)', 4.0 * Bg * Vk * d, kt['bwd_kernel'], 2500.0)
+            alg_bytes = Vk * d * 2.0 + Vk * d * 4.0      # read the bf16 table once, write dE fp32 once
+            pmc, pkey = 'r01_pmc_flash_ce_bf16.json', 'KIND_BWD'
+        else:
+            name, flop, t, peak = ('flash_ce_kernel<MODE_DE> (fused scoring/CE backward, dE pass)', 4.0 * Bg * Vk * d,
+                                   kt['dE'], 157.3)
+            alg_bytes = 2.0 * Vk * d * 4
+            pmc, pkey = 'r01_pmc_flash_ce.json', 'MODE_DE'
         traffic, tsrc = None, None
         try:                                  # HBM bytes per launch from the committed PMC passes (same kernel & shape)
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_flash_ce.json')))
+            pm = json.load(open(os.path.join(ROOT, 'profiles', pmc)))
             w = pm['workload']
-            if (w['V'], w['d'], w['B']) == (Vk, d, B * world):
-                traffic = pm['kernels']['MODE_DE']['traffic_bytes']
-                tsrc = 'profiles/r01_pmc_flash_ce.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 2x FETCH correction)'
+            if (w['V'], w['d'], w['B']) == (Vk, d, Bg):
+                traffic = pm['kernels'][pkey]['traffic_bytes']
+                tsrc = ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 2x FETCH '
+                        'correction)' % pmc)
         except Exception:
             pass
-        roof = dict(bound='mfma', kernel='flash_ce_kernel<MODE_DE> (fused scoring/CE backward, dE pass)',
-                    achieved=flops_dE / kt['dE'] / 1e12, peak=peak, unit='TFLOP/s',
-                    frac=flops_dE / kt['dE'] / 1e12 / peak, traffic=traffic, traffic_unit='bytes/launch', traffic_source=tsrc,
-                    algorithmic_bytes=2.0 * Vk * d * 4, algorithmic_flop=flops_dE,
-                    kernel_ms=dict(fwd=kt['fwd'] * 1e3, bwd_dE=kt['dE'] * 1e3, bwd_dsr=kt['dsr'] * 1e3))
+        roof = dict(bound='mfma', kernel=name, achieved=flop / t / 1e12, peak=peak, unit='TFLOP/s',
+                    frac=flop / t / 1e12 / peak, traffic=traffic, traffic_unit='bytes/launch', traffic_source=tsrc,
+                    algorithmic_bytes=alg_bytes, algorithmic_flop=flop, kernel_ms=kms)
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.model, samples, V, d, args.order, state)

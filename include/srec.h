@@ -39,6 +39,12 @@ int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B, int b_rs, 
 int srec_gemm_bf16_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, int M,
                       int N, int K, const int* dyn, float alpha, float beta, float* ws, long ws_floats, void* stream);
 
+/* bf16-operand weight-gradient product: C[N,K] = alpha * A[Mred,N]^T B[Mred,K] + beta*C (dW = dY^T X of every
+ * nn.Linear backward: autograd of F.linear at e.g. msgifsr.py:77-79, gatconv.py:166-175); operands are transposed
+ * to reduction-contiguous bf16 while staged into LDS; dyn (nullable) clamps the reduction rows. N % 4 == K % 4 == 0. */
+int srec_gemm_bf16_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int Mred, int N, int K,
+                      const int* dyn, float alpha, float beta, float* ws, long ws_floats, void* stream);
+
 /* ---- fused full-catalog scoring + softmax-CE (score_ce.hip) -----------------------------------------
  * z[b,v] = cs[v] * <sr_b, E_v> (cs NULL -> 1).  Replaces sr @ E^T, log(softmax), nll_loss:
  * srgnn.py:145-147  niser.py:149-156  lessr.py:182-183  msgifsr.py:276-309,321  train.py:99 (+ backward). */
@@ -58,12 +64,16 @@ int srec_score_ce_bwd(const float* sr, int ld_sr, const float* E, int ld_e, cons
 int srec_score_logp(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const float* lse, int B,
                     int V, int d, const int* dynB, float* logp, long ld_logp, void* stream);
 
-/* bf16-operand variant of the fused scoring (score_ce_bf16.hip; BASELINE config C3).  srec_bf16_prepare rounds
- * rows [R,d] fp32 into zero-padded bf16 copies: dst16 [Rp,d] and the transpose dstT16 [d,Rp] (Rp % 64 == 0, rows
- * >= the live count zero).  The scoring entry points mirror the fp32 ones; d in {32,64,96,128,256}. */
+/* bf16-operand variant of the fused scoring (score_ce_bf16.hip; BASELINE config C3 "bf16"): same call sites as
+ * srec_score_ce_fwd/bwd.  srec_bf16_prepare rounds rows [R,d] fp32 (RNE) into a row-major copy dst16 [Rp, d_pad] and
+ * a transposed copy dstT16 [d_pad, Rp] (zero for rows >= live R / columns >= d; Rp % 128 == 0; d <= 256, d % 4 == 0;
+ * d_pad from srec_ce_plan_bf16); call it once per step for the table and once per head for the session vectors.
+ * ws_stats >= 2 * n_stat_slabs * B floats, ws_dsr >= n_ranges * B * d floats.  Soft-max statistics, exp and all
+ * accumulation stay fp32; dE / dsr are fp32.  The backward runs both parts in one launch (parts bits as above;
+ * bit3 = leave the d-sr partial slabs in ws_dsr unreduced). */
 int srec_bf16_prepare(const float* src, int ld, int R, const int* dynR, int d, void* dst16, void* dstT16, int Rp,
                       void* stream);
-int srec_ce_plan_bf16(int B, int V, int d, int* n_item_tiles, int* n_ranges);
+int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_ranges, int* d_pad);
 int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16, int Vp, const float* cs, const int* labels,
                            int B, int V, int d, const int* dynB, float* ws_stats, float* lab_logit, float* lse,
                            float* lossvec, float* loss, void* stream);

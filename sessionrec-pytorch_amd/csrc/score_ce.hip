@@ -439,7 +439,7 @@ extern "C" int srec_score_ce_bwd(const float* sr, int ld_sr, const float* E, int
     rc = launch_mode<MODE_DSR>(a, dim3(R, cdiv(B, 64)), st);
     if (rc) return rc;
     const size_t n = (size_t)B * d;
-    hipLaunchKernelGGL(dsr_reduce_kernel, dim3((unsigned)cdiv((int)(n / 4), 256)), dim3(256), 0, st, ws_dsr, R, n, dsr);
+    hipLaunchKernelGGL(dsr_reduce_kernel, dim3((unsigned)cdiv((int)(n / 4), 64)), dim3(256), 0, st, ws_dsr, R, n, dsr);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -1,17 +1,27 @@
 // bf16-operand variant of the fused full-catalog scoring + softmax-CE ("flash-CE", see score_ce.hip for the
 // algorithm and the reference call sites it replaces).  BASELINE config C3's reduced-precision path.
 //
-// Differences to the exact-fp32 kernel, all driven by the gfx950 hardware model:
-//   * v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 16x the fp32-MFMA rate, so the kernel is bound by staging and
-//     LDS traffic, not by the matrix pipe;
+// Design (gfx950): with v_mfma_f32_32x32x16_bf16 the matrix pipe is 16x faster than fp32, so the kernel is
+// shaped around LDS traffic and occupancy instead:
 //   * operands are pre-rounded ONCE per step into zero-padded bf16 copies (srec_bf16_prepare): row-major
-//     [rows, d] for the S = X Y^T product and TRANSPOSED [d, rows] for ACC += P Y, whose B operand needs 8
-//     consecutive reduction indices per lane - no transposes inside the hot loop, no bounds masks in the staging;
-//   * the owner tile X lives in REGISTERS as ready-made MFMA fragments (64 VGPRs at d=256), LDS holds only
-//     the streamed chunk twice (Ys, YsT) and P: 78 KB -> TWO workgroups per CU, whose staging / soft-max
-//     phases overlap each other's MFMA phases (the fp32 kernel needs 148 KB and runs one per CU);
-//   * every LDS fragment read is a 16-B ds_read_b128; row strides 528 B / 144 B put the 16 lanes of a b128 group
-//     on 16 distinct 4-bank slots.
+//     [rows, D] feeds S, a TRANSPOSED copy [D, rows] feeds ACC += P Y.  D = d padded to 32/64/128/256.
+//   * every wave OWNS 32 rows (items for dE, sessions for d sr / forward) as ready-made MFMA fragments in
+//     registers and keeps its 32 x D accumulator in registers; a workgroup is 4 independent waves (128 owner
+//     rows) that only share the streamed chunk in LDS.  256 VGPRs -> two workgroups per CU.
+//   * the product is computed TRANSPOSED, S^T = Y X^T (streamed rows x owner rows): the MFMA result layout
+//     (lane = owner row, registers = streamed rows) is exactly the A-operand layout of the second product, so P
+//     never touches LDS - it is exponentiated, rounded to bf16 and fed back from registers.  The k-order this
+//     implies (register r <-> streamed row (r&3) + 8(r>>2) + 4(lane>>5)) is baked into the transposed copy by
+//     swapping bits 2 and 3 of the row index, so the matching B fragments are single ds_read_b128.
+//   * streamed chunks (32 rows, both layouts) go global -> LDS by LDS-DMA (global_load_lds_dwordx4), double
+//     buffered, one barrier per chunk, no staging registers and no ds_write pass.  LDS-DMA fills lane-linear,
+//     so the tiles are unpadded and bank conflicts are removed by an XOR swizzle applied to the SOURCE address
+//     of each 16-B piece and to the fragment reads (piece p of row r sits at p ^ f(r)); with f below the 16
+//     lanes of every ds_read_b128 group hit 16 distinct 16-B slots.
+//   * backward = ONE launch: workgroups [0, nDE) own item tiles (dE), the rest own (session tile, item range)
+//     pairs (d sr partial slabs, reduced by dsr_reduce_kernel); the second kind fills the CUs the 128-row item
+//     tiling leaves idle (293 tiles on 256 CUs at V = 37 484).  Range workgroups are numbered so the session
+//     tiles of one item range share an XCD (blockIdx % 8) and therefore an L2.
 // Soft-max statistics, exp, the one-hot subtraction and all accumulation stay fp32; dE / d sr are written fp32.
 #include "common.h"
 #include "score_common.h"
@@ -19,16 +29,30 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-enum { BMODE_FWD = 0, BMODE_DE = 1, BMODE_DSR = 2 };
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CH = 32;    // streamed rows per chunk
+constexpr int SB = 512;   // streamed rows per side-data block (lse / labels / column scales in LDS)
+constexpr int OWN = 128;  // owner rows per workgroup (4 waves x 32)
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ unsigned short f2bf(float a) {
     unsigned u = __float_as_uint(a);
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) & 0xffff0000u;
+    return ua | ub;
+}
+__device__ __forceinline__ int kperm(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-// dst16[r, c] = bf16(src[r, c]),  dstT16[c, r] = bf16(src[r, c]);  rows >= live R and padding are zero.
+// dst16[r, c] = bf16(src[r, c]) (c < Dp, zero beyond d);  dstT16[c, kperm(r)] = bf16(src[r, c]);
+// rows >= live R are zero.
 __global__ void bf16_prepare_kernel(const float* __restrict__ src, int ld, int R, const int* __restrict__ dynR, int d,
-                                    unsigned short* __restrict__ dst16, unsigned short* __restrict__ dstT16, int Rp) {
+                                    int Dp, unsigned short* __restrict__ dst16, unsigned short* __restrict__ dstT16,
+                                    int Rp) {
     __shared__ unsigned short tile[64][66];
     const int Rl = dyn_count(dynR, R);
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -38,295 +62,441 @@ __global__ void bf16_prepare_kernel(const float* __restrict__ src, int ld, int R
         unsigned short v = 0;
         if (r < Rl && c < d) v = f2bf(src[(size_t)r * ld + c]);
         tile[rr][tc] = v;
-        if (r < Rp && c < d) dst16[(size_t)r * d + c] = v;
+        if (c < Dp) dst16[(size_t)r * Dp + c] = v;
     }
     __syncthreads();
     for (int cc = tr; cc < 64; cc += 4) {
-        const int c = c0 + cc, r = r0 + tc;
-        if (c < d && r < Rp) dstT16[(size_t)c * Rp + r] = tile[tc][cc];
+        const int c = c0 + cc;
+        if (c < Dp) dstT16[(size_t)c * Rp + r0 + tc] = tile[kperm(tc)][cc];   // kperm is an involution
     }
 }
 
 struct BArgs {
-    const unsigned short* X16;    // owner rows   [Xp, d]
-    const unsigned short* Y16;    // streamed rows [Yp, d]
-    const unsigned short* YT16;   // streamed rows transposed [d, Yp]
-    int Yp;
+    const unsigned short* E16;   // items   [Vp, D]
+    const unsigned short* ET16;  // items   [D, Vp]  (k-permuted)
+    const unsigned short* S16;   // sessions [Bp, D]
+    const unsigned short* ST16;  // sessions [D, Bp] (k-permuted)
+    int Vp, Bp;
     const float* cs; const int* labels; const float* lse; const float* gscale; const float* ga; const float* gc;
     const int* dynB;
     int B, V, d;
     float* part_m; float* part_l; float* lab_logit;
     float* dE; int ld_de; int acc_dE;
     float* part_dsr;
-    int chunks_per_range;
+    int n_de_pad;                // item-tile workgroups (padded to a multiple of 8); 0 = none
+    int n_ranges, chunks_per_range, n_sess_tiles;
 };
 
-template <int NT, int MODE>
+enum { KIND_FWD = 0, KIND_BWD = 1, KIND_BWD_G = 2 };   // _G: per-session coefficients ga / gc (order fusion)
+
+template <int NT, int KIND_>
 __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
-    constexpr int D = NT * 32, KS = D / 16, LDY = D + 8, LDT = 72, LDP = 72;
-    constexpr int NCB = (NT + 1) / 2;
-    constexpr bool ITEMS_X = (MODE == BMODE_FWD || MODE == BMODE_DE);
+    constexpr int PFD = (NT == 8 && KIND_ != KIND_FWD) ? 2 : 4;   // fragment prefetch depth (D = 256 backward sits at 256 VGPRs)
+    constexpr int KIND = KIND_ == KIND_FWD ? KIND_FWD : KIND_BWD;
+    constexpr bool has_g = KIND_ == KIND_BWD_G;
+    constexpr int D = NT * 32, KS = D / 16, PR = D / 8;          // PR: 16-B pieces per row-major row
+    constexpr int RBS = PR >= 16 ? 1 : 16 / PR, FM = (PR >= 16 ? 16 : PR) - 1;
+    constexpr int YS = CH * D;                                    // elements of one row-major chunk (= one transposed)
+    constexpr int BUF = KIND == KIND_FWD ? YS : 2 * YS;
+    constexpr int NI = D / 16;                                    // 1-KiB LDS-DMA instructions per layout per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    unsigned short* Ys = smem16;                       // [64][LDY]
-    unsigned short* YsT = Ys + 64 * LDY;               // [D][LDT]
-    unsigned short* Ps = YsT + D * LDT;                // [64][LDP]  (or FWD scratch)
-    float* scratch = reinterpret_cast<float*>(Ps);
-    float* gaL = reinterpret_cast<float*>(Ps + 64 * LDP);   // [64] per-owner-row coefficients (DSR with ga/gc)
-    float* gcL = gaL + 64;
-    int* labL = reinterpret_cast<int*>(gcL + 64);          // [64] labels of the owner sessions (DSR)
+    float* sideF = reinterpret_cast<float*>(smem16 + 2 * BUF);   // [SB] lse (dE) or column scale (d sr, fwd)
+    int* sideI = reinterpret_cast<int*>(sideF + SB);             // [SB] labels (dE)
+    float* sideGa = reinterpret_cast<float*>(sideI + SB);        // [SB] per-session coefficients (dE, order fusion)
+    float* sideGc = sideGa + SB;
+    int* sideHit = reinterpret_cast<int*>(sideGc + SB);          // [SB / CH] chunk may contain a label of this item tile (dE)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int si = wave >> 1, sj = wave & 1;
     const int Bd = dyn_count(a.dynB, a.B);
-    int nx, x0, ybeg, yend, tile_id;
-    if (ITEMS_X) {
-        nx = a.V; x0 = blockIdx.x * 64; ybeg = 0; yend = Bd; tile_id = blockIdx.x;
-    } else {
-        nx = Bd; x0 = blockIdx.y * 64; tile_id = 0;
-        ybeg = blockIdx.x * a.chunks_per_range * 64;
-        yend = min(a.V, ybeg + a.chunks_per_range * 64);
-    }
-    const bool x_empty = x0 >= nx;
 
-    // owner tile as MFMA A-fragments: row si*32 + l31, k = ks*16 + 8*half .. +7   (padded buffer: no masks)
+    bool role_de = false;
+    int x0, ybeg, yend, range = 0;
+    if (KIND == KIND_BWD && (int)blockIdx.x < a.n_de_pad) {
+        role_de = true;
+        x0 = blockIdx.x * OWN;
+        if (x0 >= a.V) return;
+        ybeg = 0; yend = Bd;
+    } else {
+        const int b = blockIdx.x - (KIND == KIND_BWD ? a.n_de_pad : 0);
+        const int xcd = b & 7, j = b >> 3;
+        const int tile = j % a.n_sess_tiles;
+        range = (j / a.n_sess_tiles) * 8 + xcd;
+        if (range >= a.n_ranges) return;
+        x0 = tile * OWN;
+        ybeg = range * a.chunks_per_range * CH;
+        yend = min(a.V, ybeg + a.chunks_per_range * CH);
+    }
+    const unsigned short* X16 = role_de ? a.E16 : a.S16;
+    const unsigned short* Y16 = role_de ? a.S16 : a.E16;
+    const unsigned short* YT16 = role_de ? a.ST16 : a.ET16;
+    const int Yp = role_de ? a.Bp : a.Vp;
+    const int xi = x0 + wave * 32 + l31;                          // this lane's owner row (column of S^T)
+
+    // owner rows as MFMA B-fragments of S^T = Y X^T: row xi, k = ks*16 + 8*half .. +7 (padded copy: no masks)
     bf16x8 xf[KS];
     {
-        const unsigned short* xp = a.X16 + (size_t)(x0 + si * 32 + l31) * D + 8 * half;
+        const unsigned short* xp = X16 + (size_t)xi * D + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + ks * 16);
     }
-    float gs = 1.f;
-    if (MODE != BMODE_FWD) gs = (a.gscale != nullptr ? *a.gscale : 1.f) / (float)(Bd > 0 ? Bd : 1);
-    float xq[16];      // ITEMS_X: cs[item]   else: lse[session]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int xi = x0 + si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ITEMS_X) xq[r] = (a.cs != nullptr && xi < nx) ? a.cs[xi] : 1.f;
-        else xq[r] = xi < nx ? a.lse[xi] : 0.f;
-    }
-    if (MODE == BMODE_DSR && tid < 64) labL[tid] = (x0 + tid < nx) ? a.labels[x0 + tid] : -1;
-    const bool has_g = (MODE == BMODE_DSR) && a.ga != nullptr;     // per-session coefficients (rare: order fusion)
-    if (has_g && tid < 64) {
-        const int xi = x0 + tid;
-        gaL[tid] = xi < nx ? a.ga[xi] : 0.f;
-        gcL[tid] = xi < nx ? a.gc[xi] : 0.f;
-    }
-    f32x16 acc[NCB];
-#pragma unroll
-    for (int c = 0; c < NCB; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-
-    constexpr int YQ = D / 8;                           // 16-B pieces per Ys row
-    for (int y0 = ybeg; y0 < yend && !x_empty; y0 += 64) {
-        // ---- stage the chunk: Ys[64][D] (rows y0..y0+63) and YsT[D][64] (columns y0..y0+63 of the transposed copy)
-#pragma unroll 4
-        for (int p = 0; p < NT; ++p) {
-            const int idx = tid + p * 256;               // 64 * YQ = 256 * NT pieces
-            const int row = idx / YQ, c8 = idx % YQ;
-            const uint4 v = *reinterpret_cast<const uint4*>(a.Y16 + (size_t)(y0 + row) * D + c8 * 8);
-            *reinterpret_cast<uint4*>(Ys + row * LDY + c8 * 8) = v;
+    // per-lane owner constants
+    const float gs = (KIND == KIND_BWD) ? (a.gscale != nullptr ? *a.gscale : 1.f) / (float)(Bd > 0 ? Bd : 1) : 1.f;
+    float csL = 0.f, lseL = INFINITY, gaL = gs, gcL = gs;
+    int labL = -1;
+    if (role_de) {
+        csL = xi < a.V ? (a.cs != nullptr ? a.cs[xi] : 1.f) : 0.f;
+    } else if (xi < Bd) {
+        labL = a.labels[xi];
+        if (KIND == KIND_BWD) {
+            lseL = a.lse[xi];
+            if (has_g) { gaL = a.ga[xi]; gcL = a.gc[xi]; }
         }
-        if (MODE != BMODE_FWD) {
-#pragma unroll 4
-            for (int p = 0; p < NT; ++p) {
-                const int idx = tid + p * 256;           // D * 8 = 256 * NT pieces
-                const int row = idx >> 3, c8 = idx & 7;
-                const uint4 v = *reinterpret_cast<const uint4*>(a.YT16 + (size_t)row * a.Yp + y0 + c8 * 8);
-                *reinterpret_cast<uint4*>(YsT + row * LDT + c8 * 8) = v;
+    }
+
+    const float csL2 = csL * LOG2E;
+    if (!role_de) { lseL *= LOG2E; gaL *= LN2; gcL *= LN2; }      // d sr: the streamed column scales carry log2(e)
+    f32x16 acc[KIND == KIND_BWD ? NT : 1];
+    if (KIND == KIND_BWD) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    }
+    float m_run = -INFINITY, l_run = 0.f;                         // forward: online soft-max of this lane's rows
+
+    // LDS-DMA of one chunk: piece p of row r lands at position p ^ f(r) (row-major) / p ^ ((r>>2)&3) (transposed).
+    // Issued as inline asm (SGPR base + 32-bit lane offset): hipcc would otherwise drain every outstanding DMA at
+    // the next LDS read it cannot prove disjoint (a vmcnt(0) in the middle of the chunk); the only wait needed is
+    // the explicit vmcnt(0) in front of the barrier that publishes the chunk.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem16;
+    auto glds = [&](const unsigned short* sbase, unsigned voff, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    };
+    auto stage = [&](int y0, int bufsel, int lane) {
+        constexpr int RPI = 64 / PR > 0 ? 64 / PR : 1;           // row-major rows per DMA instruction (D <= 256: >= 2)
+        const int row_l = lane / PR, pos = lane % PR;
+#pragma unroll
+        for (int ii = 0; ii < (NI + 3) / 4; ++ii) {
+            const int i = ii * 4 + wave;
+            if (i < NI) {
+                const int g = pos ^ (((i * RPI + row_l) / RBS) & FM);
+                const unsigned voff = (unsigned)(row_l * D + g * 8) * 2u;
+                glds(Y16 + (size_t)(y0 + i * RPI) * D, voff, lds0 + (unsigned)(bufsel * BUF + i * 512) * 2u);
             }
         }
-        const int yj = y0 + sj * 32 + l31;
-        const bool yvalid = yj < yend;
-        float yq = 1.f, yga = gs, ygc = gs;
-        int ylab = -1;
-        if (MODE == BMODE_FWD) {
-            ylab = yvalid ? a.labels[yj] : -1;
-        } else if (MODE == BMODE_DE) {
-            yq = yvalid ? a.lse[yj] : 0.f;
-            ylab = yvalid ? a.labels[yj] : -1;
-            if (a.ga != nullptr) { yga = yvalid ? a.ga[yj] : 0.f; ygc = yvalid ? a.gc[yj] : 0.f; }
-        } else {
-            yq = (a.cs != nullptr && yvalid) ? a.cs[yj] : 1.f;
+        if (KIND == KIND_BWD) {
+            const int g = (lane & 3) ^ ((lane >> 4) & 3);
+            const unsigned voff = ((unsigned)(lane >> 2) * (unsigned)Yp + (unsigned)g * 8u) * 2u;
+#pragma unroll
+            for (int ii = 0; ii < (NI + 3) / 4; ++ii) {
+                const int i = ii * 4 + wave;
+                if (i < NI)
+                    glds(YT16 + (size_t)(i * 16) * Yp + y0, voff, lds0 + (unsigned)(bufsel * BUF + YS + i * 512) * 2u);
+            }
         }
-        __syncthreads();                                                  // (A)
+    };
 
-        // ---- S = X Y^T (32x32 per wave), K = D in steps of 16
+    const int nchunks = yend > ybeg ? (yend - ybeg + CH - 1) / CH : 0;
+    if (nchunks > 0) stage(ybeg, 0, lane);
+    int lane_v = lane;   // re-derived per chunk (see the asm below): keeps ~40 loop-invariant address registers
+                         // from being hoisted out of the chunk loop - the kernel lives at the 256-VGPR limit
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int y0 = ybeg + c * CH;
+        asm volatile("" : "+v"(lane_v));
+        const int l31v = lane_v & 31, halfv = lane_v >> 5;
+        const int fsw = (l31v / RBS) & FM;                        // read-side swizzle of this lane's row-major row
+        const int tsw = (l31v >> 2) & 3;                          // ... of its transposed rows
+        unsigned short* cur = smem16 + (c & 1) * BUF;
+        const int sbase = (c % (SB / CH)) * CH;                   // offset of this chunk inside the side block
+        if (sbase == 0) {
+            if (c > 0) __syncthreads();                           // everyone is done with the previous side block
+            for (int i = tid; i < SB; i += 256) {
+                const int row = y0 + i;
+                const bool ok = row < yend;
+                if (role_de) {
+                    const int lab = ok ? a.labels[row] : -1;
+                    sideF[i] = ok ? a.lse[row] * LOG2E : INFINITY;
+                    sideI[i] = lab;
+                    if (has_g) { sideGa[i] = ok ? a.ga[row] : 0.f; sideGc[i] = ok ? a.gc[row] : 0.f; }
+                    const unsigned long long hit = __builtin_amdgcn_ballot_w64(lab >= x0 && lab < x0 + OWN);
+                    if ((lane & 31) == 0) sideHit[i >> 5] = ((hit >> (lane & 32)) & 0xffffffffull) != 0;
+                } else {
+                    sideF[i] = ok ? (a.cs != nullptr ? a.cs[row] * LOG2E : LOG2E) : 0.f;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of chunk c has landed ...
+        __syncthreads();                                          // ... everyone's has; the other buffer is free again
+        if (c + 1 < nchunks) stage(y0 + CH, (c & 1) ^ 1, lane_v);
+
+        // ---- S^T = Y X^T : 32 streamed rows x 32 owner rows per wave, K = D.  Fragment reads run PF steps ahead of
+        // the MFMAs that consume them (LDS latency ~ 4 MFMA issue slots).
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         {
-            const unsigned short* yb = Ys + (sj * 32 + l31) * LDY + 8 * half;
+            constexpr int PF = KS < PFD ? KS : PFD;
+            const unsigned short* yb = cur + l31v * D;
+            bf16x8 af[PF];
+#pragma unroll
+            for (int j = 0; j < PF; ++j)
+                af[j] = *reinterpret_cast<const bf16x8*>(yb + (((2 * j + halfv) ^ fsw) << 3));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(yb + ks * 16);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks], b, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks % PF], xf[ks], s, 0, 0, 0);
+                if (ks + PF < KS)
+                    af[ks % PF] = *reinterpret_cast<const bf16x8*>(yb + (((2 * (ks + PF) + halfv) ^ fsw) << 3));
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS - PF; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
             }
         }
-        if (MODE == BMODE_FWD) {
-            float m = -INFINITY, z[16];
+        // register r of s <-> streamed row (r&3) + 8*(r>>2) + 4*half, owner row = xi
+        if (KIND == KIND_FWD) {
+            const int nvalid = yend - y0 - 4 * half;              // rows >= this are beyond the range
+            const int labrel = labL - y0 - 4 * half;
+            float z[16], m = m_run;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int item = x0 + si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                z[r] = (item < nx) ? xq[r] * s[r] : -INFINITY;
-                m = fmaxf(m, z[r]);
-                if (yvalid && item == ylab) a.lab_logit[yj] = z[r];
-            }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            const float ms = (m == -INFINITY) ? 0.f : m;
-            float l = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const float4 c4 = *reinterpret_cast<const float4*>(sideF + sbase + 8 * q + 4 * half);
+                const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) l += __expf(z[r] - ms);
-            l += __shfl_xor(l, 32, 64);
-            if (half == 0) {
-                scratch[(si * 2 + 0) * 64 + sj * 32 + l31] = m;
-                scratch[(si * 2 + 1) * 64 + sj * 32 + l31] = l;
-            }
-            __syncthreads();                                              // (B)
-            if (tid < 64) {
-                const int y = y0 + tid;
-                if (y < yend) {
-                    const float m0 = scratch[tid], l0 = scratch[64 + tid], m1 = scratch[128 + tid], l1 = scratch[192 + tid];
-                    const float mm = fmaxf(m0, m1);
-                    const float mms = (mm == -INFINITY) ? 0.f : mm;
-                    a.part_m[(size_t)tile_id * a.B + y] = mm;
-                    a.part_l[(size_t)tile_id * a.B + y] = l0 * __expf(m0 - mms) + l1 * __expf(m1 - mms);
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e, rr = 8 * q + e;
+                    z[r] = rr < nvalid ? cv[e] * s[r] : -INFINITY;          // base-2 logits (cv carries log2 e)
+                    m = fmaxf(m, z[r]);
+                    if (rr == labrel) a.lab_logit[xi] = z[r] * LN2;
                 }
             }
-            __syncthreads();                                              // (C)
+            if (m != -INFINITY) {
+                float l = l_run * __builtin_amdgcn_exp2f(m_run - m);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) l += __builtin_amdgcn_exp2f(z[r] - m);
+                l_run = l; m_run = m;
+            }
         } else {
-            // ---- P (bf16) -> LDS
+            // P = (softmax - onehot) * scales, in base 2: the side arrays / lane constants carry log2(e) so one fma +
+            // v_exp_f32 per element; the one-hot compare runs only in the rare chunk that can contain a label.
+            float p[16];
+            if (role_de) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int xl = si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int xi = x0 + xl;
-                float p = 0.f;
-                if (xi < nx && yvalid) {
-                    if (ITEMS_X) {
-                        const float zz = xq[r] * s[r];
-                        p = (__expf(zz - yq) * yga - (ylab == xi ? ygc : 0.f)) * xq[r];
-                    } else {
-                        const float zz = yq * s[r];
-                        const float ga_ = has_g ? gaL[xl] : gs, gc_ = has_g ? gcL[xl] : gs;
-                        p = (__expf(zz - xq[r]) * ga_ - (labL[xl] == yj ? gc_ : 0.f)) * yq;
+                for (int q = 0; q < 4; ++q) {
+                    const int sb = sbase + 8 * q + 4 * halfv;
+                    const float4 l4 = *reinterpret_cast<const float4*>(sideF + sb);
+                    float4 a4 = make_float4(gs, gs, gs, gs);
+                    if (has_g) a4 = *reinterpret_cast<const float4*>(sideGa + sb);
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * q + e;
+                        p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(csL2, s[r], -lv[e])) * (av[e] * csL);
                     }
                 }
-                Ps[xl * LDP + sj * 32 + l31] = f2bf(p);
+                if (sideHit[sbase >> 5]) {                        // some label of this chunk lies in this item tile
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int sb = sbase + 8 * q + 4 * halfv;
+                        const int4 i4 = *reinterpret_cast<const int4*>(sideI + sb);
+                        float4 c4 = make_float4(gs, gs, gs, gs);
+                        if (has_g) c4 = *reinterpret_cast<const float4*>(sideGc + sb);
+                        const int iv[4] = {i4.x, i4.y, i4.z, i4.w};
+                        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (iv[e] == xi) p[4 * q + e] -= cv[e] * csL;
+                    }
+                }
+            } else {
+                const int labrel = labL - y0 - 4 * halfv;
+                const float gaS = gaL;                            // already divided by log2(e): cv below carries it
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(sideF + sbase + 8 * q + 4 * halfv);
+                    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * q + e;
+                        p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cv[e], s[r], -lseL)) * (gaS * cv[e]);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(labrel >= 0 && labrel < 28 + 4) != 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(sideF + sbase + 8 * q + 4 * halfv);
+                        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (8 * q + e == labrel) p[4 * q + e] -= gcL * cv[e];
+                    }
+                }
             }
-            __syncthreads();                                              // (B)
-            // ---- ACC += P Y : row block si, column blocks sj, sj+2, ...; K = 64 chunk rows in steps of 16
+            // P as two A fragments (k-step t <-> registers 8t .. 8t+7), straight from registers
+            bf16x8 pf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x8 w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = p[8 * t + e];
+                pf[t] = __builtin_convertvector(w, bf16x8);       // v_cvt_pk_bf16_f32 (RNE)
+            }
+            // ---- ACC (32 owner rows x D) += P Y, K = 32 streamed rows in 2 steps; B fragments prefetched PFB ahead
             {
-                const unsigned short* pa = Ps + (si * 32 + l31) * LDP + 8 * half;
-                const unsigned short* yt = YsT + (sj * 32 + l31) * LDT + 8 * half;
+                constexpr int NB = 2 * NT, PFB = NB < PFD ? NB : PFD;
+                const unsigned short* yt = cur + YS + l31v * CH;
+                const int off0 = ((0 + halfv) ^ tsw) << 3, off1 = ((2 + halfv) ^ tsw) << 3;
+                bf16x8 bf[PFB];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(pa + ks * 16);
+                for (int j = 0; j < PFB; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8*>(yt + (j % NT) * 32 * CH + (j / NT ? off1 : off0));
 #pragma unroll
-                    for (int c = 0; c < NCB; ++c) {
-                        if (sj + 2 * c < NT) {
-                            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(yt + c * 64 * LDT + ks * 16);
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[c], 0, 0, 0);
-                        }
-                    }
+                for (int j = 0; j < NB; ++j) {
+                    acc[j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[j / NT], bf[j % PFB], acc[j % NT], 0, 0, 0);
+                    if (j + PFB < NB)
+                        bf[j % PFB] = *reinterpret_cast<const bf16x8*>(yt + ((j + PFB) % NT) * 32 * CH +
+                                                                       ((j + PFB) / NT ? off1 : off0));
+                }
+#pragma unroll
+                for (int j = 0; j < NB - PFB; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
-            __syncthreads();                                              // (C)
         }
     }
 
-    if (MODE != BMODE_FWD) {
-        const int d = a.d;
+    if (KIND == KIND_FWD) {
+        // the two halves of a wave hold disjoint rows of the same session: merge, one partial per (range, session)
+        const float mo = __shfl_xor(m_run, 32, 64), lo = __shfl_xor(l_run, 32, 64);
+        const float mm = fmaxf(m_run, mo);
+        float l = 0.f;
+        if (mm != -INFINITY) l = l_run * __builtin_amdgcn_exp2f(m_run - mm) + lo * __builtin_amdgcn_exp2f(mo - mm);
+        if (half == 0 && xi < a.B) {
+            a.part_m[(size_t)range * a.B + xi] = mm * LN2;        // statistics leave in natural-log units
+            a.part_l[(size_t)range * a.B + xi] = l;
+        }
+        return;
+    }
+    const int d = a.d;
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) {
-            const int cb = sj + 2 * c;
-            if (cb >= NT) continue;
-            const int col = cb * 32 + l31;
-            if (col >= d) continue;
+    for (int cb = 0; cb < NT; ++cb) {
+        const int col = cb * 32 + l31;
+        if (col >= d) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int xi = x0 + si * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (MODE == BMODE_DE) {
-                    if (xi < a.V) {
-                        float* q = a.dE + (size_t)xi * a.ld_de + col;
-                        *q = a.acc_dE ? *q + acc[c][r] : acc[c][r];
-                    }
-                } else {
-                    if (xi < a.B) a.part_dsr[((size_t)blockIdx.x * a.B + xi) * d + col] = (xi < nx) ? acc[c][r] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int xr = x0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (role_de) {
+                if (xr < a.V) {
+                    float* q = a.dE + (size_t)xr * a.ld_de + col;
+                    *q = a.acc_dE ? *q + acc[cb][r] : acc[cb][r];
                 }
+            } else if (xr < a.B) {
+                a.part_dsr[((size_t)range * a.B + xr) * d + col] = acc[cb][r];
             }
         }
     }
 }
 
-template <int NTV, int MODE>
-int launch_b(const BArgs& a, dim3 grid, hipStream_t st) {
+template <int NTV, int KIND>
+int launch_b(const BArgs& a, int nblocks, hipStream_t st) {
+    if (KIND == KIND_BWD && a.ga != nullptr) return launch_b<NTV, KIND == KIND_BWD ? KIND_BWD_G : KIND>(a, nblocks, st);
     constexpr int D = NTV * 32;
-    constexpr size_t lds = (size_t)(64 * (D + 8) + D * 72 + 64 * 72) * sizeof(unsigned short) + 192 * sizeof(float);
+    constexpr size_t lds = (size_t)(KIND == KIND_FWD ? 2 : 4) * CH * D * sizeof(unsigned short) + 4 * SB * sizeof(float) + (SB / CH) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)flash_ce_bf16_kernel<NTV, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)flash_ce_bf16_kernel<NTV, KIND>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((flash_ce_bf16_kernel<NTV, MODE>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((flash_ce_bf16_kernel<NTV, KIND>), dim3(nblocks), dim3(256), lds, st, a);
     SREC_LAUNCH_CHECK();
     return 0;
 }
 
-template <int MODE>
-int launch_bmode(const BArgs& a, dim3 grid, hipStream_t st) {
-    switch (a.d / 32) {
-        case 1: return launch_b<1, MODE>(a, grid, st);
-        case 2: return launch_b<2, MODE>(a, grid, st);
-        case 3: return launch_b<3, MODE>(a, grid, st);
-        case 4: return launch_b<4, MODE>(a, grid, st);
-        case 8: return launch_b<8, MODE>(a, grid, st);
-        default: return SREC_BAD_ARG;
+inline int dpad(int d) { return d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 256; }
+
+template <int KIND>
+int launch_kind(const BArgs& a, int nblocks, hipStream_t st) {
+    switch (dpad(a.d)) {
+        case 32: return launch_b<1, KIND>(a, nblocks, st);
+        case 64: return launch_b<2, KIND>(a, nblocks, st);
+        case 128: return launch_b<4, KIND>(a, nblocks, st);
+        default: return launch_b<8, KIND>(a, nblocks, st);
     }
 }
 
-int pick_ranges_b(int B, int V) {
-    const int sess_tiles = cdiv(B, 64), chunks = cdiv(V, 64);
-    int R = cdiv(1024, sess_tiles);
+// item ranges of the session-owner workgroups: `slots` workgroups wanted in total, at most `rmax` ranges
+void pick_ranges_b(int B, int V, int slots, int rmax, int* n_ranges, int* chunks_per_range) {
+    const int T = cdiv(B, OWN), chunks = cdiv(V, CH);
+    int R = slots / T;
+    if (R > rmax) R = rmax;
     if (R > chunks) R = chunks;
-    return R < 1 ? 1 : R;
+    if (R < 1) R = 1;
+    const int cpr = cdiv(chunks, R);
+    *chunks_per_range = cpr;
+    *n_ranges = cdiv(chunks, cpr);
 }
 
-inline bool bad_d(int d) { return !(d == 32 || d == 64 || d == 96 || d == 128 || d == 256); }
+constexpr int FWD_SLOTS = 512, FWD_RMAX = 1024, BWD_SLOTS = 512, BWD_RMAX = 64;
+
+inline int bwd_slots(int V, int d, bool with_de) {
+    const int slots = BWD_SLOTS;                          // workgroups resident at once (2 per CU)
+    if (!with_de) return slots;
+    const int rem = cdiv(V, OWN) % slots;
+    return rem == 0 ? slots : slots - rem;                // fill the residency the item tiles leave free
+}
+
+inline bool bad_d(int d) { return d <= 0 || d > 256 || (d & 3); }
 
 }  // namespace
 
-// rows [R, d] fp32 -> dst16 [Rp, d] and dstT16 [d, Rp] bf16 (RNE), zero for rows >= live R; Rp % 64 == 0.
+// rows [R, d] fp32 -> dst16 [Rp, Dp] and dstT16 [Dp, Rp] bf16 (RNE), zero for rows >= live R and columns >= d;
+// Dp = d padded to 32/64/128/256 (srec_ce_plan_bf16), Rp % 128 == 0.  The transposed copy is stored in the
+// MFMA k-order (bits 2 and 3 of the row index swapped).
 extern "C" int srec_bf16_prepare(const float* src, int ld, int R, const int* dynR, int d, void* dst16, void* dstT16,
                                  int Rp, void* stream) {
-    if (R <= 0 || (Rp & 63) || Rp < R) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(bf16_prepare_kernel, dim3(Rp / 64, cdiv(d, 64)), dim3(256), 0, (hipStream_t)stream, src, ld, R, dynR,
-                       d, (unsigned short*)dst16, (unsigned short*)dstT16, Rp);
+    if (R <= 0 || (Rp & 127) || Rp < R || bad_d(d)) return SREC_BAD_ARG;
+    const int Dp = dpad(d);
+    hipLaunchKernelGGL(bf16_prepare_kernel, dim3(Rp / 64, cdiv(Dp, 64)), dim3(256), 0, (hipStream_t)stream, src, ld, R,
+                       dynR, d, Dp, (unsigned short*)dst16, (unsigned short*)dstT16, Rp);
     SREC_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int srec_ce_plan_bf16(int B, int V, int d, int* n_item_tiles, int* n_ranges) {
-    if (bad_d(d)) return SREC_BAD_ARG;
-    *n_item_tiles = cdiv(V, 64);
-    *n_ranges = pick_ranges_b(B, V);
+// workspace plan: ws_stats >= 2 * n_stat_slabs * B floats, ws_dsr >= n_ranges * B * d floats, copies [.., d_pad]
+extern "C" int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_ranges, int* d_pad) {
+    if (bad_d(d) || B <= 0 || V <= 0) return SREC_BAD_ARG;
+    int R, cpr, R2;
+    pick_ranges_b(B, V, FWD_SLOTS, FWD_RMAX, &R, &cpr);
+    *n_stat_slabs = R;
+    pick_ranges_b(B, V, bwd_slots(V, d, true), BWD_RMAX, &R, &cpr);
+    pick_ranges_b(B, V, bwd_slots(V, d, false), BWD_RMAX, &R2, &cpr);
+    *n_ranges = R > R2 ? R : R2;
+    *d_pad = dpad(d);
     return 0;
 }
 
-// sr16 [Bp,d], E16 [Vp,d] from srec_bf16_prepare.  Outputs as srec_score_ce_fwd.
+// sr16 [Bp, Dp], E16 [Vp, Dp] from srec_bf16_prepare.  Outputs as srec_score_ce_fwd.
 extern "C" int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16, int Vp, const float* cs,
                                       const int* labels, int B, int V, int d, const int* dynB, float* ws_stats,
                                       float* lab_logit, float* lse, float* lossvec, float* loss, void* stream) {
-    if (bad_d(d) || (Bp & 63) || (Vp & 63)) return SREC_BAD_ARG;
+    if (bad_d(d) || (Bp & 127) || (Vp & 127) || Bp < B || Vp < V) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int nt = cdiv(V, 64);
     BArgs a{};
-    a.X16 = (const unsigned short*)E16; a.Y16 = (const unsigned short*)sr16; a.YT16 = nullptr; a.Yp = Bp;
+    a.S16 = (const unsigned short*)sr16; a.E16 = (const unsigned short*)E16; a.Bp = Bp; a.Vp = Vp;
     a.cs = cs; a.labels = labels; a.dynB = dynB; a.B = B; a.V = V; a.d = d;
+    a.n_sess_tiles = cdiv(B, OWN);
+    pick_ranges_b(B, V, FWD_SLOTS, FWD_RMAX, &a.n_ranges, &a.chunks_per_range);
+    const int nt = a.n_ranges;
     a.part_m = ws_stats; a.part_l = ws_stats + (size_t)nt * B; a.lab_logit = lab_logit;
-    int rc = launch_bmode<BMODE_FWD>(a, dim3(nt), st);
+    int rc = launch_kind<KIND_FWD>(a, 8 * cdiv(nt, 8) * a.n_sess_tiles, st);
     if (rc) return rc;
     hipLaunchKernelGGL(ce_reduce_stats_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, a.part_m, a.part_l, lab_logit, nt, B,
                        dynB, lse, lossvec);
@@ -341,27 +511,31 @@ extern "C" int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int B
                                       const float* gscale, const float* ga, const float* gc, int B, int V, int d,
                                       const int* dynB, float* dE, int ld_de, float* ws_dsr, float* dsr, int parts,
                                       void* stream) {
-    if (bad_d(d) || (Bp & 63) || (Vp & 63)) return SREC_BAD_ARG;
+    if (bad_d(d) || (Bp & 127) || (Vp & 127) || Bp < B || Vp < V) return SREC_BAD_ARG;
+    if (!(parts & 3)) return 0;
     hipStream_t st = (hipStream_t)stream;
     BArgs a{};
+    a.S16 = (const unsigned short*)sr16; a.ST16 = (const unsigned short*)srT16; a.Bp = Bp;
+    a.E16 = (const unsigned short*)E16; a.ET16 = (const unsigned short*)ET16; a.Vp = Vp;
     a.cs = cs; a.labels = labels; a.lse = lse; a.gscale = gscale; a.ga = ga; a.gc = gc; a.dynB = dynB;
     a.B = B; a.V = V; a.d = d; a.dE = dE; a.ld_de = ld_de; a.acc_dE = (parts & 4) ? 1 : 0; a.part_dsr = ws_dsr;
-    int rc = 0;
-    if (parts & 1) {
-        a.X16 = (const unsigned short*)E16; a.Y16 = (const unsigned short*)sr16; a.YT16 = (const unsigned short*)srT16;
-        a.Yp = Bp;
-        rc = launch_bmode<BMODE_DE>(a, dim3(cdiv(V, 64)), st);
-        if (rc) return rc;
+    a.n_sess_tiles = cdiv(B, OWN);
+    const bool with_de = parts & 1, with_dsr = parts & 2;
+    a.n_de_pad = with_de ? 8 * cdiv(cdiv(V, OWN), 8) : 0;
+    int nblocks = a.n_de_pad;
+    if (with_dsr) {
+        pick_ranges_b(B, V, bwd_slots(V, d, with_de), BWD_RMAX, &a.n_ranges, &a.chunks_per_range);
+        nblocks += 8 * cdiv(a.n_ranges, 8) * a.n_sess_tiles;
+    } else {
+        a.n_ranges = 0; a.chunks_per_range = 1;
     }
-    if (!(parts & 2)) return 0;
-    const int R = pick_ranges_b(B, V);
-    a.chunks_per_range = cdiv(cdiv(V, 64), R);
-    a.X16 = (const unsigned short*)sr16; a.Y16 = (const unsigned short*)E16; a.YT16 = (const unsigned short*)ET16;
-    a.Yp = Vp;
-    rc = launch_bmode<BMODE_DSR>(a, dim3(R, cdiv(B, 64)), st);
+    int rc = launch_kind<KIND_BWD>(a, nblocks, st);
     if (rc) return rc;
-    const size_t n = (size_t)B * d;
-    hipLaunchKernelGGL(dsr_reduce_kernel, dim3((unsigned)cdiv((int)(n / 4), 256)), dim3(256), 0, st, ws_dsr, R, n, dsr);
+    if (with_dsr && !(parts & 8)) {
+        const size_t n = (size_t)B * d;
+        hipLaunchKernelGGL(dsr_reduce_kernel, dim3((unsigned)cdiv((int)(n / 4), 64)), dim3(256), 0, st, ws_dsr,
+                           a.n_ranges, n, dsr);
+    }
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -49,16 +49,26 @@ __global__ void ce_mean_kernel(const float* __restrict__ lossvec, int B, const i
     }
 }
 
+// out = sum_r part[r]  (fixed order: deterministic).  64 float4 columns per block, the R slabs split over the 4 waves.
 __global__ void dsr_reduce_kernel(const float* __restrict__ part, int R, size_t n, float* __restrict__ out) {
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < R; ++r) {
-        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)r * n + i);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (i < n) {
+        const int per = (R + 3) / 4, r0 = g * per, r1 = min(R, r0 + per);
+        for (int r = r0; r < r1; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)r * n + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    *reinterpret_cast<float4*>(out + i) = s;
+    red[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { s.x += red[k][lane].x; s.y += red[k][lane].y; s.z += red[k][lane].z; s.w += red[k][lane].w; }
+        *reinterpret_cast<float4*>(out + i) = s;
+    }
 }
-
 
 }  // namespace

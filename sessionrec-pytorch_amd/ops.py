@@ -108,6 +108,11 @@ def gemm_tn(g, x, out, dyn=None, beta=0.0):
     """out[N,K] = g[M,N]^T @ x[M,K]   (reduction over the M rows; dyn clamps M)"""
     M, N = g.shape
     K = x.shape[1]
+    if (PRECISION['matmul'] == 'bf16' and M >= 256 and not ((N | K | _ld(g) | _ld(x) | _ld(out)) & 3)
+            and not ((g.data_ptr() | x.data_ptr() | out.data_ptr()) & 15)):
+        lib.srec_gemm_bf16_tn(ptr(g), _ld(g), ptr(x), _ld(x), ptr(out), _ld(out), M, N, K, ptr(dyn), 1.0, beta,
+                              *_gemm_ws(g.device), stream())
+        return
     lib.srec_gemm_f32(ptr(g), 1, _ld(g), ptr(x), 1, _ld(x), ptr(out), _ld(out), None, N, K, M, ptr(dyn),
                       2 if dyn is not None else 0, 1.0, beta, *_gemm_ws(g.device), stream())
 
@@ -354,7 +359,8 @@ def seg_mean_add(H, F, seg, B, dynB=None):
 
 
 # ------------------------------------------------------------------------------------------ scoring
-BF16_DIMS = (32, 64, 96, 128, 256)
+def _bf16_dim_ok(d):
+    return d <= 256 and d % 4 == 0
 
 
 class CEWorkspace:
@@ -362,22 +368,23 @@ class CEWorkspace:
 
     def __init__(self, B, V, d, device):
         import ctypes
-        nt, nr = ctypes.c_int(), ctypes.c_int()
+        nt, nr, dp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         lib.srec_ce_plan(B, V, d, ctypes.addressof(nt), ctypes.addressof(nr))
-        nrange = nr.value
-        if d in BF16_DIMS:
-            lib.srec_ce_plan_bf16(B, V, d, ctypes.addressof(nt), ctypes.addressof(nr))
-            nrange = max(nrange, nr.value)
+        nrange, nstat = nr.value, nt.value
+        if _bf16_dim_ok(d):
+            lib.srec_ce_plan_bf16(B, V, d, ctypes.addressof(nt), ctypes.addressof(nr), ctypes.addressof(dp))
+            nrange, nstat = max(nrange, nr.value), max(nstat, nt.value)
         self.B, self.V, self.d = B, V, d
-        self.stats = torch.empty(2 * nt.value * B, device=device, dtype=torch.float32)
+        self.stats = torch.empty(2 * nstat * B, device=device, dtype=torch.float32)
         self.dsr_part = torch.empty(nrange * B * d, device=device, dtype=torch.float32)
         self.lab_logit = torch.zeros(B, device=device, dtype=torch.float32)
-        # bf16 operand copies of the session vectors (row-major + transposed), zero padded to 64 rows
-        self.Bp = (B + 63) // 64 * 64
+        # bf16 operand copies of the session vectors (row-major + transposed), zero padded to 128 rows / d_pad columns
+        self.Bp = (B + 127) // 128 * 128
         self.sr16 = self.srT16 = None
-        if d in BF16_DIMS:
-            self.sr16 = torch.zeros(self.Bp, d, device=device, dtype=torch.bfloat16)
-            self.srT16 = torch.zeros(d, self.Bp, device=device, dtype=torch.bfloat16)
+        self.sr_key = None
+        if _bf16_dim_ok(d):
+            self.sr16 = torch.zeros(self.Bp, dp.value, device=device, dtype=torch.bfloat16)
+            self.srT16 = torch.zeros(dp.value, self.Bp, device=device, dtype=torch.bfloat16)
 
 
 class TableBF16:
@@ -385,10 +392,13 @@ class TableBF16:
     refreshed once per step (one pass over the table) by srec_bf16_prepare."""
 
     def __init__(self, table):
+        import ctypes
         V, d = table.shape
-        self.Vp = (V + 63) // 64 * 64
-        self.E16 = torch.zeros(self.Vp, d, device=table.device, dtype=torch.bfloat16)
-        self.ET16 = torch.zeros(d, self.Vp, device=table.device, dtype=torch.bfloat16)
+        nt, nr, dp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib.srec_ce_plan_bf16(1, V, d, ctypes.addressof(nt), ctypes.addressof(nr), ctypes.addressof(dp))
+        self.Vp = (V + 127) // 128 * 128
+        self.E16 = torch.zeros(self.Vp, dp.value, device=table.device, dtype=torch.bfloat16)
+        self.ET16 = torch.zeros(dp.value, self.Vp, device=table.device, dtype=torch.bfloat16)
 
     def refresh(self, table):
         V, d = table.shape
@@ -397,14 +407,25 @@ class TableBF16:
 
 
 def use_bf16_scoring(d):
-    return PRECISION['matmul'] == 'bf16' and d in BF16_DIMS
+    return PRECISION['matmul'] == 'bf16' and _bf16_dim_ok(d)
+
+
+def _prepare_sr(sr, ws, dynB):
+    """bf16 copies of the session vectors; skipped when the workspace still holds exactly this tensor (the backward
+    of the head whose forward ran last)."""
+    key = (sr.data_ptr(), sr._version, tuple(sr.shape))
+    if ws.sr_key != key:
+        B, d = sr.shape
+        lib.srec_bf16_prepare(ptr(sr), _ld(sr), B, ptr(dynB), d, ptr(ws.sr16), ptr(ws.srT16), ws.Bp, stream())
+        ws.sr_key = key
 
 
 def _ce_fwd(sr, table, cs, labels, ws, dynB, tb, lab, lse, lossvec, loss):
     B, d = sr.shape
     V = table.shape[0]
     if tb is not None:
-        lib.srec_bf16_prepare(ptr(sr), _ld(sr), B, ptr(dynB), d, ptr(ws.sr16), ptr(ws.srT16), ws.Bp, stream())
+        ws.sr_key = None
+        _prepare_sr(sr, ws, dynB)
         lib.srec_score_ce_fwd_bf16(ptr(ws.sr16), ws.Bp, ptr(tb.E16), tb.Vp, ptr(cs), ptr(labels), B, V, d, ptr(dynB),
                                    ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
     else:
@@ -416,8 +437,7 @@ def _ce_bwd(sr, table, cs, labels, lse, gl, ga, gc, ws, dynB, tb, dE, dsr, parts
     B, d = sr.shape
     V = table.shape[0]
     if tb is not None:
-        # sr16 / srT16 still hold this head's session vectors only if no other head ran in between: re-prepare
-        lib.srec_bf16_prepare(ptr(sr), _ld(sr), B, ptr(dynB), d, ptr(ws.sr16), ptr(ws.srT16), ws.Bp, stream())
+        _prepare_sr(sr, ws, dynB)
         lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), ptr(ws.srT16), ws.Bp, ptr(tb.E16), ptr(tb.ET16), tb.Vp, ptr(cs),
                                    ptr(labels), ptr(lse), ptr(gl), ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE),
                                    dE.stride(0), ptr(ws.dsr_part), ptr(dsr), parts, stream())

@@ -417,6 +417,34 @@ def test_gemm_bf16_matches_bf16_rounded_reference(dev, M, N, K):
         ops.set_precision('fp32')
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 4, 8), (1000, 96, 64), (3001, 2048, 256), (5000, 256, 768)])
+def test_gemm_bf16_tn_weight_gradient(dev, M, N, K):
+    """dW = dY^T X with bf16 operands / fp32 accumulation == fp32 product of the bf16-rounded operands; a device-side
+    live row count clamps the reduction (padded batches)."""
+    ops = _ops()
+    torch.manual_seed(M + K)
+    g, x = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
+    ops.set_precision('bf16')
+    try:
+        out = torch.empty(N, K, device=dev)
+        ops.gemm_tn(g, x, out)
+        ref = g.bfloat16().float().t() @ x.bfloat16().float()
+        close(out, ref, what='bf16 tn', rtol=1e-4, atol=1e-3)
+        exact = g.t() @ x
+        assert (out - exact).norm() / exact.norm() < 6e-3
+        live = M - 137
+        dyn = torch.tensor([live], device=dev, dtype=torch.int32)
+        out2 = torch.full((N, K), 7.0, device=dev)
+        ops.gemm_tn(g, x, out2, dyn)
+        ref2 = g[:live].bfloat16().float().t() @ x[:live].bfloat16().float()
+        close(out2, ref2, what='bf16 tn dyn', rtol=1e-4, atol=1e-3)
+        out3 = torch.ones(N, K, device=dev)
+        ops.gemm_tn(g, x, out3, None, beta=1.0)
+        close(out3, ref + 1.0, what='bf16 tn beta', rtol=1e-4, atol=1e-3)
+    finally:
+        ops.set_precision('fp32')
+
+
 def test_score_ce_full_size_properties(dev):
     """BASELINE full size (C3: V=37 484, d=256, B=512; logits would be 77 MB) through size-independent
     properties instead of a materialised reference:
