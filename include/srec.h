@@ -18,6 +18,8 @@
  */
 #ifndef SREC_H
 #define SREC_H
+#include "srec_hg.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -213,6 +215,18 @@ int srec_adam_multi(const long long* desc, const int* blockmap, int total_blocks
 int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
                    int use_wd, float max_norm, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
                    void* stream);
+
+/* ---- MSGIFSR MSHGNN layer, all relations of both HeteroGraphConvs in one batched pass (hgat.hip) ------------------
+ * Replaces msgifsr.py:70-89 (conv1(g) + conv2(reverse g), relation sum, head max, + session mean) around the fc GEMMs
+ * of the GAT modules; `desc` points to a host srec_hg_desc (srec_hg.h).
+ *   fwd: the caller has filled P[m] = x[rows of m] fc_m^T; writes out[NT, D] = max_h(sum_rel rst + bias + n_rel x) +
+ *        session mean of x, arg[NT, D] (winning head), and the saved A / eL / eR.
+ *   bwd: g = d out; writes dx = n_rel g + session-mean term (the caller then accumulates dP[m] fc_m into it), dP[m],
+ *        d_attn_l / d_attn_r / d_bias of every module.  ws: srec_hg_ws_floats() floats of scratch. */
+int srec_hg_ws_floats(const void* desc, long* n_floats);
+int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg, void* stream);
+int srec_hg_bwd(const void* desc, const float* g, int ld_g, const unsigned char* arg, float* dx, int ld_dx, float* ws,
+                void* stream);
 
 #ifdef __cplusplus
 }

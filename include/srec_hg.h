@@ -1,0 +1,61 @@
+/* Layer descriptor of the batched MSHGNN (heterogeneous multi-head GAT) pass - see srec_hg_fwd / srec_hg_bwd in
+ * srec.h and csrc/hgat.hip.  Plain C, host memory, read only during the call; every pointer inside is a DEVICE
+ * pointer owned by the caller.  Mirrors msgifsr.py:47-91 (conv1 + conv2 over the reversed graph) with
+ * gatconv.py:136-319 per relation.
+ *
+ *   node types   t < n_types : rows [row0[t], row0[t]+ncap[t]) of the stacked feature matrix x [NT, D]; live prefix
+ *                              *dyn_n[t] (NULL = ncap); seg[t] = [B+1] offsets of each session's nodes of that type
+ *   modules      m < n_mods  : one GATConv (conv, edge-type name): projection P[m] = x[rows of m] fc_m^T  [rows_m, H*D]
+ *                              (computed by the caller's GEMM), attn_l / attn_r [H*D], bias [H*D]; gradients d*
+ *   blocks       b < n_blocks: rows of type blk_type[b] inside module blk_mod[b]'s projection, starting at row
+ *                              blk_row[b] of P[m] / dP[m]; eL/eR/wL/wR are [ncap, H] scratch per block
+ *   instances    i < n_inst  : relation instance (conv, relation) of module inst_mod[i]: source block inst_sblk[i],
+ *                              destination block inst_dblk[i] (its type receives the messages); CSR by destination
+ *                              (in_ptr [Nd+1], in_idx -> edge id, esrc[e] source node) and by source (out_ptr, out_idx,
+ *                              edst[e]), node ids local to the type; A / DP [E, H], der [Nd, H] scratch
+ */
+#ifndef SREC_HG_H
+#define SREC_HG_H
+
+#define SREC_HG_MAXT 4
+#define SREC_HG_MAXM 8
+#define SREC_HG_MAXB 16
+#define SREC_HG_MAXI 16
+
+typedef struct {
+    int H, D, n_types, n_mods, n_blocks, n_inst, B;
+    float slope;
+    const int* dynB;
+    /* node types */
+    int row0[SREC_HG_MAXT], ncap[SREC_HG_MAXT];
+    const int* dyn_n[SREC_HG_MAXT];
+    const int* seg[SREC_HG_MAXT];
+    /* modules */
+    const float* P[SREC_HG_MAXM];
+    float* dP[SREC_HG_MAXM];
+    const float* attn_l[SREC_HG_MAXM];
+    const float* attn_r[SREC_HG_MAXM];
+    const float* bias[SREC_HG_MAXM];
+    float* d_attn_l[SREC_HG_MAXM];
+    float* d_attn_r[SREC_HG_MAXM];
+    float* d_bias[SREC_HG_MAXM];
+    /* projection blocks */
+    int blk_mod[SREC_HG_MAXB], blk_type[SREC_HG_MAXB], blk_row[SREC_HG_MAXB];
+    float* eL[SREC_HG_MAXB];
+    float* eR[SREC_HG_MAXB];
+    float* wL[SREC_HG_MAXB];
+    float* wR[SREC_HG_MAXB];
+    /* relation instances */
+    int inst_mod[SREC_HG_MAXI], inst_sblk[SREC_HG_MAXI], inst_dblk[SREC_HG_MAXI];
+    const int* in_ptr[SREC_HG_MAXI];
+    const int* in_idx[SREC_HG_MAXI];
+    const int* esrc[SREC_HG_MAXI];
+    const int* out_ptr[SREC_HG_MAXI];
+    const int* out_idx[SREC_HG_MAXI];
+    const int* edst[SREC_HG_MAXI];
+    float* A[SREC_HG_MAXI];
+    float* DP[SREC_HG_MAXI];
+    float* der[SREC_HG_MAXI];
+} srec_hg_desc;
+
+#endif

@@ -40,6 +40,8 @@ def _mark(target, digest):
 def build(force=False, verbose=True):
     hip_srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    inc = os.path.join(os.path.dirname(HERE), 'include')
+    hdrs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h')]
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
     dig = _digest(hip_srcs + hdrs, ' '.join(flags))
     if force or _stale(LIB, dig):

@@ -1,0 +1,569 @@
+// MSGIFSR's MSHGNN layer as ONE batched pass over all relations of both HeteroGraphConvs
+// (msgifsr.py:47-91 = conv1(g) + conv2(reverse g), sum over relations, max over heads, + session mean;
+// gatconv.py:267-311 per relation).  The per-relation formulation in gat.hip launches ~18 kernels per relation
+// instance (14 instances at order 3) and materialises a [N, H*D] result per instance; here the whole layer is
+//   forward : srec_hg_fwd  = 2 launches  (attention logits of every projection block; fused edge-softmax +
+//             aggregation over EVERY relation into a destination + bias + residual + head-max + session mean)
+//   backward: srec_hg_bwd  = 5 launches  (d x pre-fill; per-destination score gradients; per-source projection
+//             gradients; two-stage column sums for attn_l / attn_r / bias of every module)
+// around the fc GEMMs of the 8 GAT modules.  Nothing of size [N, H*D] is written except the projection
+// gradients the backward GEMMs consume.  All reductions are gather-style and ordered: deterministic, no atomics.
+//
+// Layout: node features of all types stacked [NT, D]; type t owns rows [row0[t], row0[t] + ncap[t]) with a live
+// prefix dyn_n[t].  Module m's projection P[m] = x[rows of m] W_m^T is [rows_m, H*D]; a projection BLOCK is the
+// row range of one type inside one module's projection (the shared 'inter' module projects every type at once).
+// A relation INSTANCE (conv, relation) reads its source block and writes into its destination type.
+// Grid geometry: one wavefront per (node, head) for the logits / gradient passes; one 8-wave workgroup per
+// destination node for the fused aggregation (wave h = head h, the head-max goes through 8 KB of LDS).
+#include "common.h"
+#include "../../include/srec_hg.h"
+
+namespace {
+
+constexpr int WPB = 4;
+constexpr int MAXDEG = 128;
+constexpr int MAXH = 8;
+constexpr int NCHUNK = 16;
+constexpr int MAXT = SREC_HG_MAXT, MAXM = SREC_HG_MAXM, MAXB = SREC_HG_MAXB, MAXI = SREC_HG_MAXI;
+
+template <int N>
+__device__ __forceinline__ int find_range(const int (&start)[N], int n, int x) {
+    int b = 0;
+#pragma unroll
+    for (int i = 1; i < N; ++i)
+        if (i < n && x >= start[i]) b = i;
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------------ logits
+struct DotsArgs {
+    const float* P[MAXB]; const float* al[MAXB]; const float* ar[MAXB];
+    float* eL[MAXB]; float* eR[MAXB];
+    const int* dyn[MAXB];
+    int ncap[MAXB];
+    int start[MAXB + 1];     // first thread block of each projection block
+    int nb, H, D;
+};
+
+// eL[n,h] = <P[n,h,:], a_l[h,:]>, eR[n,h] = <P[n,h,:], a_r[h,:]> for every projection block
+__global__ void hg_dots_kernel(DotsArgs a) {
+    const int b = find_range(a.start, a.nb, (int)blockIdx.x);
+    const int gid = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int H = a.H, D = a.D;
+    const int n = gid / H, h = gid % H;
+    if (n >= a.ncap[b]) return;
+    const bool live = n < dyn_count(a.dyn[b], a.ncap[b]);
+    float sl = 0.f, sr = 0.f;
+    const int c = lane * 4;
+    if (live && c < D) {
+        const float4 x = *reinterpret_cast<const float4*>(a.P[b] + (size_t)n * H * D + h * D + c);
+        const float4 wl = *reinterpret_cast<const float4*>(a.al[b] + h * D + c);
+        const float4 wr = *reinterpret_cast<const float4*>(a.ar[b] + h * D + c);
+        sl = x.x * wl.x + x.y * wl.y + x.z * wl.z + x.w * wl.w;
+        sr = x.x * wr.x + x.y * wr.y + x.z * wr.z + x.w * wr.w;
+    }
+    sl = wave_sum(sl);
+    sr = wave_sum(sr);
+    if (lane == 0) {
+        a.eL[b][(size_t)n * H + h] = sl;
+        a.eR[b][(size_t)n * H + h] = sr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct AggArgs {
+    // node types
+    const int* seg[MAXT]; const int* dyn_n[MAXT];
+    int row0[MAXT + 1], ncap[MAXT], ninst[MAXT], inst[MAXT][8];
+    int nt, B;
+    const int* dynB;
+    // instances
+    const float* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* bias[MAXI];
+    const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
+    float* A[MAXI];
+    const float* x; int ld_x;
+    float* out; int ld_out;
+    unsigned char* arg;
+    int H, D;
+    float slope;
+};
+
+__global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
+    __shared__ float sc[MAXH][MAXDEG];
+    __shared__ int su[MAXH][MAXDEG];
+    __shared__ float comb[MAXH][256];
+    const int row = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int H = a.H, D = a.D, HD = H * D;
+    const int t = find_range(a.row0, a.nt, row);
+    const int v = row - a.row0[t];
+    const bool live = v < dyn_count(a.dyn_n[t], a.ncap[t]);
+    const int c = lane * 4;
+    if (w < H) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            for (int q = 0; q < a.ninst[t]; ++q) {
+                const int i = a.inst[t][q];
+                const int* ip = a.in_ptr[i];
+                const int beg = ip[v], deg = min(ip[v + 1] - beg, MAXDEG);
+                const int* idx = a.in_idx[i] + beg;
+                for (int j = lane; j < deg; j += 64) su[w][j] = a.esrc[i][idx[j]];
+                __builtin_amdgcn_wave_barrier();
+                const float erv = a.eRd[i][(size_t)v * H + w];
+                float m = -INFINITY;
+                for (int j = lane; j < deg; j += 64) {
+                    float s = a.eLs[i][(size_t)su[w][j] * H + w] + erv;
+                    s = s > 0.f ? s : a.slope * s;
+                    sc[w][j] = s;
+                    m = fmaxf(m, s);
+                }
+                m = wave_max(m);
+                float z = 0.f;
+                for (int j = lane; j < deg; j += 64) z += expf(sc[w][j] - m);
+                z = wave_sum(z);
+                const float iz = deg > 0 ? 1.f / z : 0.f;
+                for (int j = lane; j < deg; j += 64) {
+                    const float p = expf(sc[w][j] - m) * iz;
+                    sc[w][j] = p;
+                    a.A[i][(size_t)idx[j] * H + w] = p;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (c < D) {
+                    const float* ps = a.Ps[i] + w * D + c;
+                    for (int j = 0; j < deg; ++j) {
+                        const float p = sc[w][j];
+                        const float4 f = *reinterpret_cast<const float4*>(ps + (size_t)su[w][j] * HD);
+                        acc.x += p * f.x; acc.y += p * f.y; acc.z += p * f.z; acc.w += p * f.w;
+                    }
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias[i] + w * D + c);
+                    acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (c < D) {
+                const float nres = (float)a.ninst[t];
+                const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)row * a.ld_x + c);
+                acc.x += nres * xv.x; acc.y += nres * xv.y; acc.z += nres * xv.z; acc.w += nres * xv.w;
+            }
+        }
+        if (c < D) *reinterpret_cast<float4*>(&comb[w][c]) = acc;
+    }
+    __syncthreads();
+    if (tid < D) {
+        float best = 0.f;
+        int bi = 0;
+        if (live) {
+            best = -INFINITY;
+            for (int h = 0; h < H; ++h)
+                if (comb[h][tid] > best) { best = comb[h][tid]; bi = h; }
+            // + mean of the session's input features (nodes of this type)
+            const int* seg = a.seg[t];
+            int lo = 0, hi = dyn_count(a.dynB, a.B);       // session b with seg[b] <= v < seg[b+1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (seg[mid] <= v) lo = mid; else hi = mid;
+            }
+            const int s0 = seg[lo], s1 = seg[lo + 1];
+            float mean = 0.f;
+            for (int j = s0; j < s1; ++j) mean += a.x[(size_t)(a.row0[t] + j) * a.ld_x + tid];
+            best += mean / (float)(s1 - s0 > 0 ? s1 - s0 : 1);
+        }
+        a.out[(size_t)row * a.ld_out + tid] = best;
+        a.arg[(size_t)row * D + tid] = (unsigned char)bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+struct PreArgs {
+    const int* seg[MAXT]; const int* dyn_n[MAXT];
+    int row0[MAXT + 1], ncap[MAXT], ninst[MAXT];
+    int nt, B, D;
+    const int* dynB;
+    const float* g; int ld_g;
+    float* dx; int ld_dx;
+};
+
+// dx[row,:] = nres * g[row,:] + (1/n_session) * sum_{rows of the session} g   (residual + session-mean terms)
+__global__ void hg_pre_kernel(PreArgs a) {
+    const int row = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.row0[a.nt]) return;
+    const int t = find_range(a.row0, a.nt, row);
+    const int v = row - a.row0[t];
+    const bool live = v < dyn_count(a.dyn_n[t], a.ncap[t]);
+    const int c = lane * 4;
+    if (c >= a.D) return;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        const int* seg = a.seg[t];
+        int lo = 0, hi = dyn_count(a.dynB, a.B);
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg[mid] <= v) lo = mid; else hi = mid;
+        }
+        const int s0 = seg[lo], s1 = seg[lo + 1];
+        for (int j = s0; j < s1; ++j) {
+            const float4 gv = *reinterpret_cast<const float4*>(a.g + (size_t)(a.row0[t] + j) * a.ld_g + c);
+            o.x += gv.x; o.y += gv.y; o.z += gv.z; o.w += gv.w;
+        }
+        const float inv = 1.f / (float)(s1 - s0 > 0 ? s1 - s0 : 1), nres = (float)a.ninst[t];
+        const float4 gv = *reinterpret_cast<const float4*>(a.g + (size_t)row * a.ld_g + c);
+        o.x = o.x * inv + nres * gv.x; o.y = o.y * inv + nres * gv.y;
+        o.z = o.z * inv + nres * gv.z; o.w = o.w * inv + nres * gv.w;
+    }
+    *reinterpret_cast<float4*>(a.dx + (size_t)row * a.ld_dx + c) = o;
+}
+
+__device__ __forceinline__ float4 masked_grad(const float* g, int ld_g, const unsigned char* arg, int D, int row, int h,
+                                              int c) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)row * ld_g + c);
+    const uchar4 bi = *reinterpret_cast<const uchar4*>(arg + (size_t)row * D + c);
+    return make_float4(bi.x == h ? gv.x : 0.f, bi.y == h ? gv.y : 0.f, bi.z == h ? gv.z : 0.f, bi.w == h ? gv.w : 0.f);
+}
+
+struct DstArgs {
+    const float* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* A[MAXI];
+    const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
+    float* DP[MAXI]; float* der[MAXI];
+    const int* dyn_d[MAXI];
+    int ncap_d[MAXI], row0_d[MAXI];
+    int start[MAXI + 1];
+    int ni, H, D;
+    float slope;
+    const float* g; int ld_g;
+    const unsigned char* arg;
+};
+
+// per (instance, destination, head): d(pre-activation score) of every in-edge -> DP[e,h]; der[v,h] = their sum.
+// The gradient of every relation result into a destination is the same masked tensor g[v,c] * [arg[v,c] == h].
+__global__ void hg_bwd_dst_kernel(DstArgs a) {
+    __shared__ float da[WPB][MAXDEG];
+    __shared__ int su[WPB][MAXDEG];
+    const int i = find_range(a.start, a.ni, (int)blockIdx.x);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gid = ((int)blockIdx.x - a.start[i]) * WPB + w;
+    const int H = a.H, D = a.D, HD = H * D;
+    const int v = gid / H, h = gid % H;
+    if (v >= a.ncap_d[i]) return;
+    const bool live = v < dyn_count(a.dyn_d[i], a.ncap_d[i]);
+    const int beg = live ? a.in_ptr[i][v] : 0;
+    const int deg = live ? min(a.in_ptr[i][v + 1] - beg, MAXDEG) : 0;
+    const int* idx = a.in_idx[i] + beg;
+    for (int j = lane; j < deg; j += 64) su[w][j] = a.esrc[i][idx[j]];
+    __builtin_amdgcn_wave_barrier();
+    const int c = lane * 4;
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && c < D) gm = masked_grad(a.g, a.ld_g, a.arg, D, a.row0_d[i] + v, h, c);
+    for (int j = 0; j < deg; ++j) {
+        float s = 0.f;
+        if (c < D) {
+            const float4 f = *reinterpret_cast<const float4*>(a.Ps[i] + (size_t)su[w][j] * HD + h * D + c);
+            s = gm.x * f.x + gm.y * f.y + gm.z * f.z + gm.w * f.w;
+        }
+        s = wave_sum(s);
+        if (lane == 0) da[w][j] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float tsum = 0.f;
+    for (int j = lane; j < deg; j += 64) tsum += a.A[i][(size_t)idx[j] * H + h] * da[w][j];
+    tsum = wave_sum(tsum);
+    const float erv = live ? a.eRd[i][(size_t)v * H + h] : 0.f;
+    float dsum = 0.f;
+    for (int j = lane; j < deg; j += 64) {
+        const int e = idx[j];
+        const float p = a.A[i][(size_t)e * H + h];
+        const float pre = a.eLs[i][(size_t)su[w][j] * H + h] + erv;
+        const float dp = p * (da[w][j] - tsum) * (pre > 0.f ? 1.f : a.slope);
+        a.DP[i][(size_t)e * H + h] = dp;
+        dsum += dp;
+    }
+    dsum = wave_sum(dsum);
+    if (lane == 0) a.der[i][(size_t)v * H + h] = dsum;
+}
+
+struct SrcArgs {
+    // projection blocks
+    float* dP[MAXB]; float* wL[MAXB]; float* wR[MAXB];
+    const float* al[MAXB]; const float* ar[MAXB];
+    const int* dyn[MAXB];
+    int ncap[MAXB], nsrc[MAXB], ndst[MAXB], src[MAXB][4], dst[MAXB][4];
+    int start[MAXB + 1];
+    // instances
+    const float* A[MAXI]; const float* DP[MAXI]; const float* der[MAXI];
+    const int* out_ptr[MAXI]; const int* out_idx[MAXI]; const int* edst[MAXI];
+    int row0_d[MAXI];
+    int nb, H, D;
+    const float* g; int ld_g;
+    const unsigned char* arg;
+};
+
+// per (projection block, node u, head): dP[u,h,:] = sum over the instances that read the block as SOURCE of
+//   sum_{e in out(u)} A[e,h] * dT[dst_e,h,:] + del[u,h] * a_l[h,:]   (del = sum of DP over out-edges)
+// + sum over the instances that use it as DESTINATION of der[u,h] * a_r[h,:];  wL / wR = the summed del / der.
+__global__ void hg_bwd_src_kernel(SrcArgs a) {
+    const int b = find_range(a.start, a.nb, (int)blockIdx.x);
+    const int lane = threadIdx.x & 63;
+    const int gid = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6);
+    const int H = a.H, D = a.D, HD = H * D;
+    const int u = gid / H, h = gid % H;
+    if (u >= a.ncap[b]) return;
+    const bool live = u < dyn_count(a.dyn[b], a.ncap[b]);
+    const int c = lane * 4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wl = 0.f, wr = 0.f;
+    if (live) {
+        for (int q = 0; q < a.nsrc[b]; ++q) {
+            const int i = a.src[b][q];
+            const int beg = a.out_ptr[i][u], deg = a.out_ptr[i][u + 1] - beg;
+            const int* idx = a.out_idx[i] + beg;
+            float dl = 0.f;
+            for (int j = lane; j < deg; j += 64) dl += a.DP[i][(size_t)idx[j] * H + h];
+            dl = wave_sum(dl);
+            wl += dl;
+            if (c < D) {
+                for (int j = 0; j < deg; ++j) {
+                    const int e = idx[j];
+                    const float p = a.A[i][(size_t)e * H + h];
+                    const float4 gm = masked_grad(a.g, a.ld_g, a.arg, D, a.row0_d[i] + a.edst[i][e], h, c);
+                    o.x += p * gm.x; o.y += p * gm.y; o.z += p * gm.z; o.w += p * gm.w;
+                }
+            }
+        }
+        for (int q = 0; q < a.ndst[b]; ++q) wr += a.der[a.dst[b][q]][(size_t)u * H + h];
+        if (c < D) {
+            const float4 l4 = *reinterpret_cast<const float4*>(a.al[b] + h * D + c);
+            const float4 r4 = *reinterpret_cast<const float4*>(a.ar[b] + h * D + c);
+            o.x += wl * l4.x + wr * r4.x; o.y += wl * l4.y + wr * r4.y;
+            o.z += wl * l4.z + wr * r4.z; o.w += wl * l4.w + wr * r4.w;
+        }
+    }
+    if (c < D) *reinterpret_cast<float4*>(a.dP[b] + (size_t)u * HD + h * D + c) = o;
+    if (lane == 0) {
+        a.wL[b][(size_t)u * H + h] = wl;
+        a.wR[b][(size_t)u * H + h] = wr;
+    }
+}
+
+// column sums: job j < 2*nb : sum_n w[n,h] * P[n,h,c] over a projection block (w = wL for even, wR for odd j)
+//              job 2*nb + t : sum_v g[v,c] * [arg[v,c] == h] over the rows of node type t
+struct ColArgs {
+    const float* P[MAXB]; const float* wL[MAXB]; const float* wR[MAXB];
+    const int* dyn_b[MAXB];
+    int ncap_b[MAXB];
+    const int* dyn_t[MAXT];
+    int row0[MAXT + 1], ncap_t[MAXT];
+    int nb, nt, H, D;
+    const float* g; int ld_g;
+    const unsigned char* arg;
+    float* part;             // [njobs][NCHUNK][H*D]
+};
+
+__global__ void hg_colsum_part_kernel(ColArgs a) {
+    __shared__ float red[4][64];
+    const int H = a.H, D = a.D, HD = H * D;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int job = blockIdx.z, chunk = blockIdx.y;
+    float s = 0.f;
+    if (col < HD) {
+        const int h = col / D, c = col % D;
+        if (job < 2 * a.nb) {
+            const int b = job >> 1;
+            const float* wgt = (job & 1) ? a.wR[b] : a.wL[b];
+            const int n = dyn_count(a.dyn_b[b], a.ncap_b[b]);
+            const int per = (n + NCHUNK - 1) / NCHUNK, r0 = chunk * per, r1 = min(n, r0 + per);
+            for (int r = r0 + rg; r < r1; r += 4) s += wgt[(size_t)r * H + h] * a.P[b][(size_t)r * HD + col];
+        } else {
+            const int t = job - 2 * a.nb;
+            const int n = dyn_count(a.dyn_t[t], a.ncap_t[t]);
+            const int per = (n + NCHUNK - 1) / NCHUNK, r0 = chunk * per, r1 = min(n, r0 + per);
+            for (int r = r0 + rg; r < r1; r += 4) {
+                const size_t row = (size_t)(a.row0[t] + r);
+                if (a.arg[row * D + c] == h) s += a.g[row * a.ld_g + c];
+            }
+        }
+    }
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && col < HD)
+        a.part[((size_t)job * NCHUNK + chunk) * HD + col] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+struct ColFinalArgs {
+    float* out[3 * MAXM];
+    int njob[3 * MAXM], jobs[3 * MAXM][8];
+    int HD;
+    const float* part;
+};
+
+__global__ void hg_colsum_final_kernel(ColFinalArgs a) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
+    if (col >= a.HD || a.out[o] == nullptr) return;
+    float s = 0.f;
+    for (int q = 0; q < a.njob[o]; ++q) {
+        const float* p = a.part + (size_t)a.jobs[o][q] * NCHUNK * a.HD + col;
+        for (int k = 0; k < NCHUNK; ++k) s += p[(size_t)k * a.HD];
+    }
+    a.out[o][col] = s;
+}
+
+bool bad_desc(const srec_hg_desc* d) {
+    return d == nullptr || d->H <= 0 || d->H > MAXH || d->D <= 0 || d->D > 256 || (d->D & 3) || d->n_types <= 0 ||
+           d->n_types > MAXT || d->n_blocks < 0 || d->n_blocks > MAXB || d->n_inst < 0 || d->n_inst > MAXI ||
+           d->n_mods < 0 || d->n_mods > MAXM;
+}
+
+}  // namespace
+
+extern "C" int srec_hg_ws_floats(const void* desc_, long* n_floats) {
+    const srec_hg_desc* d = (const srec_hg_desc*)desc_;
+    if (bad_desc(d) || n_floats == nullptr) return SREC_BAD_ARG;
+    *n_floats = (long)(2 * d->n_blocks + d->n_types) * NCHUNK * d->H * d->D;
+    return 0;
+}
+
+extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg,
+                           void* stream) {
+    const srec_hg_desc* d = (const srec_hg_desc*)desc_;
+    if (bad_desc(d) || (ld_x & 3)) return SREC_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = d->H, D = d->D, HD = H * D;
+    if (d->n_blocks > 0) {
+        DotsArgs a{};
+        a.nb = d->n_blocks; a.H = H; a.D = D;
+        int blocks = 0;
+        for (int b = 0; b < d->n_blocks; ++b) {
+            const int m = d->blk_mod[b], t = d->blk_type[b];
+            a.P[b] = d->P[m] + (size_t)d->blk_row[b] * HD;
+            a.al[b] = d->attn_l[m]; a.ar[b] = d->attn_r[m];
+            a.eL[b] = d->eL[b]; a.eR[b] = d->eR[b];
+            a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t];
+            a.start[b] = blocks;
+            blocks += cdiv(d->ncap[t] * H, WPB);
+        }
+        a.start[d->n_blocks] = blocks;
+        if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), 0, st, a);
+    }
+    AggArgs g{};
+    g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;
+    g.x = x; g.ld_x = ld_x; g.out = out; g.ld_out = ld_out; g.arg = arg;
+    int rows = 0;
+    for (int t = 0; t < d->n_types; ++t) {
+        if (d->row0[t] != rows) return SREC_BAD_ARG;            // types must tile the stacked matrix
+        g.seg[t] = d->seg[t]; g.dyn_n[t] = d->dyn_n[t]; g.row0[t] = d->row0[t]; g.ncap[t] = d->ncap[t];
+        g.ninst[t] = 0;
+        rows += d->ncap[t];
+    }
+    g.row0[d->n_types] = rows;
+    for (int i = 0; i < d->n_inst; ++i) {
+        const int sb = d->inst_sblk[i], db = d->inst_dblk[i], m = d->inst_mod[i], t = d->blk_type[db];
+        if (g.ninst[t] >= 8) return SREC_BAD_ARG;
+        g.inst[t][g.ninst[t]++] = i;
+        g.Ps[i] = d->P[m] + (size_t)d->blk_row[sb] * HD;
+        g.eLs[i] = d->eL[sb]; g.eRd[i] = d->eR[db]; g.bias[i] = d->bias[m];
+        g.in_ptr[i] = d->in_ptr[i]; g.in_idx[i] = d->in_idx[i]; g.esrc[i] = d->esrc[i];
+        g.A[i] = d->A[i];
+    }
+    if (rows > 0) hipLaunchKernelGGL(hg_agg_kernel, dim3(rows), dim3(512), 0, st, g);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const unsigned char* arg, float* dx, int ld_dx,
+                           float* ws, void* stream) {
+    const srec_hg_desc* d = (const srec_hg_desc*)desc_;
+    if (bad_desc(d) || (ld_g & 3) || (ld_dx & 3) || ws == nullptr) return SREC_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = d->H, D = d->D, HD = H * D;
+    int ninst_t[MAXT] = {0, 0, 0, 0};
+    for (int i = 0; i < d->n_inst; ++i) ninst_t[d->blk_type[d->inst_dblk[i]]]++;
+    int rows = 0;
+    {
+        PreArgs a{};
+        a.nt = d->n_types; a.B = d->B; a.D = D; a.dynB = d->dynB; a.g = g; a.ld_g = ld_g; a.dx = dx; a.ld_dx = ld_dx;
+        for (int t = 0; t < d->n_types; ++t) {
+            a.seg[t] = d->seg[t]; a.dyn_n[t] = d->dyn_n[t]; a.row0[t] = d->row0[t]; a.ncap[t] = d->ncap[t];
+            a.ninst[t] = ninst_t[t];
+            rows += d->ncap[t];
+        }
+        a.row0[d->n_types] = rows;
+        if (rows > 0) hipLaunchKernelGGL(hg_pre_kernel, dim3(cdiv(rows, WPB)), dim3(256), 0, st, a);
+    }
+    if (d->n_inst > 0) {
+        DstArgs a{};
+        a.ni = d->n_inst; a.H = H; a.D = D; a.slope = d->slope; a.g = g; a.ld_g = ld_g; a.arg = arg;
+        int blocks = 0;
+        for (int i = 0; i < d->n_inst; ++i) {
+            const int sb = d->inst_sblk[i], db = d->inst_dblk[i], m = d->inst_mod[i], t = d->blk_type[db];
+            a.Ps[i] = d->P[m] + (size_t)d->blk_row[sb] * HD;
+            a.eLs[i] = d->eL[sb]; a.eRd[i] = d->eR[db]; a.A[i] = d->A[i];
+            a.in_ptr[i] = d->in_ptr[i]; a.in_idx[i] = d->in_idx[i]; a.esrc[i] = d->esrc[i];
+            a.DP[i] = d->DP[i]; a.der[i] = d->der[i];
+            a.dyn_d[i] = d->dyn_n[t]; a.ncap_d[i] = d->ncap[t]; a.row0_d[i] = d->row0[t];
+            a.start[i] = blocks;
+            blocks += cdiv(d->ncap[t] * H, WPB);
+        }
+        a.start[d->n_inst] = blocks;
+        if (blocks > 0) hipLaunchKernelGGL(hg_bwd_dst_kernel, dim3(blocks), dim3(256), 0, st, a);
+    }
+    if (d->n_blocks > 0) {
+        SrcArgs a{};
+        a.nb = d->n_blocks; a.H = H; a.D = D; a.g = g; a.ld_g = ld_g; a.arg = arg;
+        int blocks = 0;
+        for (int b = 0; b < d->n_blocks; ++b) {
+            const int m = d->blk_mod[b], t = d->blk_type[b];
+            a.dP[b] = d->dP[m] + (size_t)d->blk_row[b] * HD;
+            a.wL[b] = d->wL[b]; a.wR[b] = d->wR[b]; a.al[b] = d->attn_l[m]; a.ar[b] = d->attn_r[m];
+            a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t];
+            a.nsrc[b] = a.ndst[b] = 0;
+            a.start[b] = blocks;
+            blocks += cdiv(d->ncap[t] * H, WPB);
+        }
+        a.start[d->n_blocks] = blocks;
+        for (int i = 0; i < d->n_inst; ++i) {
+            const int sb = d->inst_sblk[i], db = d->inst_dblk[i];
+            if (a.nsrc[sb] >= 4 || a.ndst[db] >= 4) return SREC_BAD_ARG;
+            a.src[sb][a.nsrc[sb]++] = i;
+            a.dst[db][a.ndst[db]++] = i;
+            a.A[i] = d->A[i]; a.DP[i] = d->DP[i]; a.der[i] = d->der[i];
+            a.out_ptr[i] = d->out_ptr[i]; a.out_idx[i] = d->out_idx[i]; a.edst[i] = d->edst[i];
+            a.row0_d[i] = d->row0[d->blk_type[db]];
+        }
+        if (blocks > 0) hipLaunchKernelGGL(hg_bwd_src_kernel, dim3(blocks), dim3(256), 0, st, a);
+    }
+    {
+        ColArgs a{};
+        a.nb = d->n_blocks; a.nt = d->n_types; a.H = H; a.D = D; a.g = g; a.ld_g = ld_g; a.arg = arg; a.part = ws;
+        for (int b = 0; b < d->n_blocks; ++b) {
+            const int m = d->blk_mod[b], t = d->blk_type[b];
+            a.P[b] = d->P[m] + (size_t)d->blk_row[b] * HD;
+            a.wL[b] = d->wL[b]; a.wR[b] = d->wR[b]; a.dyn_b[b] = d->dyn_n[t]; a.ncap_b[b] = d->ncap[t];
+        }
+        int r = 0;
+        for (int t = 0; t < d->n_types; ++t) {
+            a.dyn_t[t] = d->dyn_n[t]; a.row0[t] = d->row0[t]; a.ncap_t[t] = d->ncap[t];
+            r += d->ncap[t];
+        }
+        a.row0[d->n_types] = r;
+        const int njobs = 2 * d->n_blocks + d->n_types;
+        hipLaunchKernelGGL(hg_colsum_part_kernel, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
+        ColFinalArgs f{};
+        f.HD = HD; f.part = ws;
+        for (int m = 0; m < d->n_mods; ++m) {
+            f.out[3 * m + 0] = d->d_attn_l[m]; f.out[3 * m + 1] = d->d_attn_r[m]; f.out[3 * m + 2] = d->d_bias[m];
+        }
+        for (int b = 0; b < d->n_blocks; ++b) {
+            const int m = d->blk_mod[b];
+            if (f.njob[3 * m] >= 8) return SREC_BAD_ARG;
+            f.jobs[3 * m + 0][f.njob[3 * m + 0]++] = 2 * b;
+            f.jobs[3 * m + 1][f.njob[3 * m + 1]++] = 2 * b + 1;
+        }
+        for (int i = 0; i < d->n_inst; ++i) {
+            const int m = d->inst_mod[i], t = d->blk_type[d->inst_dblk[i]];
+            if (f.njob[3 * m + 2] >= 8) return SREC_BAD_ARG;
+            f.jobs[3 * m + 2][f.njob[3 * m + 2]++] = 2 * d->n_blocks + t;
+        }
+        if (d->n_mods > 0)
+            hipLaunchKernelGGL(hg_colsum_final_kernel, dim3(cdiv(HD, 256), 3 * d->n_mods), dim3(256), 0, st, f);
+    }
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

@@ -98,6 +98,51 @@ class MSHGNN(nn.Module):
         return (f(name + '_out_ptr'), f(name + '_out_idx'), f(name + '_in_ptr'), f(name + '_in_idx'),
                 f(name + '_dst'), f(name + '_src'))
 
+    def plan(self, mg, D):
+        """static topology of this layer for one FlatBatch (ops.HgPlan): types, modules, projection blocks, instances"""
+        K = self.order
+        types, r = [], 0
+        for k in range(1, K + 1):
+            nk = mg.meta['ncap'][k]
+            types.append((r, nk, mg.dynp('N%d' % k), mg.field('seg%d' % k)))
+            r += nk
+        NT = r
+        mods, mod_id, blocks, blk_id, insts, params = [], {}, [], {}, [], []
+        used = {}                                            # (conv index, etype) -> set of node types it touches
+        live = [((s, et, d_), name) for (s, et, d_), name in mg.meta['rels'] if mg.count('E_' + name) > 0]
+        for ci in (0, 1):
+            for (s, et, d_), name in live:
+                used.setdefault((ci, et), set()).update((s, d_))
+        for ci, conv in enumerate((self.conv1, self.conv2)):
+            for (s, et, d_), name in live:
+                key = (ci, et)
+                if key not in mod_id:
+                    ks = sorted(used[key])
+                    if len(ks) == 1:                         # intra_k: only the rows of type k
+                        r0, nr, dyn = types[ks[0] - 1][0], types[ks[0] - 1][1], types[ks[0] - 1][2]
+                    else:                                    # shared 'inter' module: project every row once
+                        r0, nr, dyn = 0, NT, None
+                    mod_id[key] = len(mods)
+                    mods.append((r0, nr, dyn))
+                    mod = conv.mods[et]
+                    if mod.attn_drop > 0 and self.training:
+                        raise NotImplementedError('attention dropout inside the fused GAT kernel')
+                    params += [mod.fc.weight, mod.attn_l, mod.attn_r, mod.bias]
+                m = mod_id[key]
+                src_t, dst_t = (d_, s) if ci == 1 else (s, d_)
+                for k in (src_t, dst_t):
+                    if (m, k) not in blk_id:
+                        blk_id[(m, k)] = len(blocks)
+                        blocks.append((m, k - 1))
+                insts.append((m, blk_id[(m, src_t)], blk_id[(m, dst_t)], self._graph(mg, name, ci == 1)))
+        slope = self.conv1.mods['intra1'].negative_slope
+        return ops.HgPlan(8, D, slope, mg.B, mg.dynp('B'), types, mods, blocks, insts), params
+
+    def forward_stacked(self, mg, x):
+        """x: [NT, d] node features of all orders stacked (order-1 rows first) -> [NT, d]; one batched pass"""
+        plan, params = self.plan(mg, x.shape[1])
+        return ops.hgat_layer(x, plan, params)
+
     def forward(self, mg, feat):
         """feat: {k: [N_k, d]} -> {k: [N_k, d]}"""
         H = 8
@@ -249,12 +294,21 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             dk = mg.dynp('N%d' % k)
             f = x if k == 1 else self.expander(x, k, dk, mg.dynp('GK%d' % k))
             feats[k] = ops.normalize(f, 0, dk) if self.norm else f
-        h = feats
-        for layer in self.layers:
-            h = layer(mg, h)
-        if self.norm:
-            h = {k: ops.normalize(v, 0, mg.dynp('N%d' % k)) for k, v in h.items()}
-        stacked = h[1] if K == 1 else torch.cat([h[k] for k in range(1, K + 1)], 0)
+        fused = not (self.training and any(l.conv1.mods['intra1'].feat_drop > 0 for l in self.layers))
+        if fused and len(self.layers) > 0:
+            # all orders stacked once; every layer is one batched pass over all relations (ops.hgat_layer)
+            stacked = feats[1] if K == 1 else torch.cat([feats[k] for k in range(1, K + 1)], 0)
+            for layer in self.layers:
+                stacked = layer.forward_stacked(mg, stacked)
+            if self.norm:
+                stacked = ops.normalize(stacked, 0, mg.dynp('N1') if K == 1 else None)   # padded rows are exact zeros
+        else:
+            h = feats
+            for layer in self.layers:
+                h = layer(mg, h)
+            if self.norm:
+                h = {k: ops.normalize(v, 0, mg.dynp('N%d' % k)) for k, v in h.items()}
+            stacked = h[1] if K == 1 else torch.cat([h[k] for k in range(1, K + 1)], 0)
         allf = stacked if K == 1 else ops.row_gather(stacked, mg.cat_perm, mg.dynp('NT'))
         live = range(K) if (K == 1 or self.fusion) else (0,)
         feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1)), dB) for i in live}

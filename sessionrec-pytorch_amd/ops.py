@@ -968,3 +968,146 @@ def edge_coef(ptr_, idx, ew, n, dyn=None):
 
 def edge_agg(x, coef, fwd_csr, bwd_csr, dyn=None):
     return EdgeAgg.apply(x, coef, fwd_csr, bwd_csr, dyn)
+
+
+# ------------------------------------------------------------------------------------------ MSHGNN layer (batched)
+import ctypes as _ct
+
+
+class HgDesc(_ct.Structure):
+    """host mirror of srec_hg_desc (include/srec_hg.h)"""
+    _T, _M, _B, _I = 4, 8, 16, 16
+    _fields_ = ([(n, _ct.c_int) for n in ('H', 'D', 'n_types', 'n_mods', 'n_blocks', 'n_inst', 'B')] +
+                [('slope', _ct.c_float), ('dynB', _ct.c_void_p),
+                 ('row0', _ct.c_int * 4), ('ncap', _ct.c_int * 4), ('dyn_n', _ct.c_void_p * 4), ('seg', _ct.c_void_p * 4)] +
+                [(n, _ct.c_void_p * 8) for n in ('P', 'dP', 'attn_l', 'attn_r', 'bias', 'd_attn_l', 'd_attn_r', 'd_bias')] +
+                [(n, _ct.c_int * 16) for n in ('blk_mod', 'blk_type', 'blk_row')] +
+                [(n, _ct.c_void_p * 16) for n in ('eL', 'eR', 'wL', 'wR')] +
+                [(n, _ct.c_int * 16) for n in ('inst_mod', 'inst_sblk', 'inst_dblk')] +
+                [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der')])
+
+
+class HgPlan:
+    """Static topology of one MSHGNN layer call (built by msgifsr.MSHGNN from the FlatBatch).
+    types:   [(row0, ncap, dyn_n, seg)]                          node types, stacked rows
+    modules: [(row_start, n_rows, dyn)]                          rows of x each GAT module projects (dyn or None)
+    blocks:  [(module, type)]                                    projection blocks
+    insts:   [(module, src_block, dst_block, (in_ptr, in_idx, out_ptr, out_idx, esrc, edst))]"""
+
+    def __init__(self, H, D, slope, B, dynB, types, modules, blocks, insts):
+        self.H, self.D, self.slope, self.B, self.dynB = H, D, slope, B, dynB
+        self.types, self.modules, self.blocks, self.insts = types, modules, blocks, insts
+        assert len(types) <= 4 and len(modules) <= 8 and len(blocks) <= 16 and len(insts) <= 16
+
+    def scratch_layout(self):
+        """-> (n_floats, offsets) of the small per-call scratch: eL,eR,wL,wR per block; A,DP,der per instance"""
+        H, off, lay = self.H, 0, {}
+        for b, (m, t) in enumerate(self.blocks):
+            n = self.types[t][1] * H
+            for nm in ('eL', 'eR', 'wL', 'wR'):
+                lay[(nm, b)] = off
+                off += n
+        for i, (m, sb, db, gr) in enumerate(self.insts):
+            E = max(gr[4].numel(), 1) * H
+            nd = self.types[self.blocks[db][1]][1] * H
+            for nm, n in (('A', E), ('DP', E), ('der', nd)):
+                lay[(nm, i)] = off
+                off += n
+        return off, lay
+
+    def fill(self, desc, small, lay, P, dP, params, grads):
+        d = desc
+        d.H, d.D, d.slope, d.B = self.H, self.D, self.slope, self.B
+        d.n_types, d.n_mods, d.n_blocks, d.n_inst = len(self.types), len(self.modules), len(self.blocks), len(self.insts)
+        d.dynB = ptr(self.dynB)
+        for t, (r0, nc, dyn, seg) in enumerate(self.types):
+            d.row0[t], d.ncap[t], d.dyn_n[t], d.seg[t] = r0, nc, ptr(dyn), ptr(seg)
+        base = small.data_ptr()
+        for m in range(len(self.modules)):
+            W, al, ar, bias = params[4 * m:4 * m + 4]
+            d.P[m] = ptr(P[m])
+            d.attn_l[m], d.attn_r[m], d.bias[m] = ptr(al), ptr(ar), ptr(bias)
+            if dP is not None:
+                d.dP[m] = ptr(dP[m])
+                d.d_attn_l[m], d.d_attn_r[m], d.d_bias[m] = (grads[m, j].data_ptr() for j in range(3))
+        for b, (m, t) in enumerate(self.blocks):
+            d.blk_mod[b], d.blk_type[b] = m, t
+            d.blk_row[b] = self.types[t][0] - self.modules[m][0]
+            for nm in ('eL', 'eR', 'wL', 'wR'):
+                getattr(d, nm)[b] = base + 4 * lay[(nm, b)]
+        for i, (m, sb, db, gr) in enumerate(self.insts):
+            d.inst_mod[i], d.inst_sblk[i], d.inst_dblk[i] = m, sb, db
+            for nm, g in zip(('in_ptr', 'in_idx', 'out_ptr', 'out_idx', 'esrc', 'edst'), gr):
+                getattr(d, nm)[i] = ptr(g)
+            for nm in ('A', 'DP', 'der'):
+                getattr(d, nm)[i] = base + 4 * lay[(nm, i)]
+        return d
+
+
+_HG_WS = {}
+
+
+class HGATLayer(torch.autograd.Function):
+    """out = MSHGNN(x): all relation instances of conv1 / conv2 in one batched pass (csrc/hgat.hip) around the fc
+    GEMMs.  params = (fc.weight, attn_l, attn_r, bias) per module, in plan.modules order."""
+
+    @staticmethod
+    def forward(ctx, x, plan, *params):
+        x = _rows(x)
+        NT, D = x.shape
+        H = plan.H
+        HD = H * D
+        dev = x.device
+        P = []
+        for m, (r0, nr, dyn) in enumerate(plan.modules):
+            Pm = torch.empty(nr, HD, device=dev, dtype=torch.float32)
+            gemm_nt(x[r0:r0 + nr], _rows(params[4 * m]), Pm, None, dyn, 1 if dyn is not None else 0)
+            P.append(Pm)
+        nfl, lay = plan.scratch_layout()
+        small = torch.empty(max(nfl, 1), device=dev, dtype=torch.float32)
+        out = torch.empty(NT, D, device=dev, dtype=torch.float32)
+        arg = torch.empty(NT, D, device=dev, dtype=torch.uint8)
+        flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
+        desc = plan.fill(HgDesc(), small, lay, P, None, flat, None)
+        lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
+        ctx.save_for_backward(x, small, arg, *P, *params)
+        ctx.plan, ctx.lay = plan, lay
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, lay = ctx.plan, ctx.lay
+        nm = len(plan.modules)
+        x, small, arg = ctx.saved_tensors[:3]
+        P = ctx.saved_tensors[3:3 + nm]
+        params = ctx.saved_tensors[3 + nm:]
+        g = _rows(g)
+        NT, D = x.shape
+        HD = plan.H * D
+        dev = x.device
+        dP = [torch.empty_like(p) for p in P]
+        grads = torch.empty(nm, 3, HD, device=dev, dtype=torch.float32)
+        dx = torch.empty(NT, D, device=dev, dtype=torch.float32)
+        flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
+        desc = plan.fill(HgDesc(), small, lay, P, dP, flat, grads)
+        n = _ct.c_long()
+        lib.srec_hg_ws_floats(_ct.addressof(desc), _ct.addressof(n))
+        key = (dev.index, n.value)
+        ws = _HG_WS.get(key)
+        if ws is None:
+            ws = _HG_WS[key] = torch.empty(max(n.value, 1), device=dev, dtype=torch.float32)
+        lib.srec_hg_bwd(_ct.addressof(desc), ptr(g), _ld(g), ptr(arg), ptr(dx), D, ptr(ws), stream())
+        outs = []
+        for m, (r0, nr, dyn) in enumerate(plan.modules):
+            W = _rows(params[4 * m])
+            mode = 1 if dyn is not None else 0
+            gemm_nn(dP[m], W, dx[r0:r0 + nr], dyn, mode, beta=1.0)
+            gW = torch.empty_like(W)
+            gemm_tn(dP[m], x[r0:r0 + nr], gW, dyn)
+            outs += [gW, grads[m, 0].view(params[4 * m + 1].shape), grads[m, 1].view(params[4 * m + 2].shape),
+                     grads[m, 2].view(params[4 * m + 3].shape)]
+        return (dx, None) + tuple(outs)
+
+
+def hgat_layer(x, plan, params):
+    return HGATLayer.apply(x, plan, *params)
