@@ -228,6 +228,12 @@ int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_o
 int srec_hg_bwd(const void* desc, const float* g, int ld_g, const unsigned char* arg, float* dx, int ld_dx, float* ws,
                 void* stream);
 
+/* grouped, K-segmented bf16-operand GEMM (gemm_group_bf16.hip): up to 8 problems C_p [M,N] (+)= sum_s opA(A_ps) opB(B_ps)
+ * in one launch.  desc: host srec_gemm_group (srec_hg.h).  mode 0: A [M,K], B [N,K] (nn.Linear forward); 1: A [M,K],
+ * B [K,N] reduction-major, segments summed (backward-data over several modules); 2: A [K,M], B [K,N] both
+ * reduction-major (weight gradient; dyn clamps the reduction).  dyn clamps the output rows in modes 0 / 1. */
+int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

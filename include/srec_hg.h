@@ -58,4 +58,17 @@ typedef struct {
     float* der[SREC_HG_MAXI];
 } srec_hg_desc;
 
+/* problem table of srec_gemm_group_bf16 (srec.h) */
+#define SREC_GG_MAXP 8
+#define SREC_GG_MAXS 4
+typedef struct {
+    int np, lda, ldb, ldc;
+    float beta;
+    int M[SREC_GG_MAXP], N[SREC_GG_MAXP], K[SREC_GG_MAXP], nseg[SREC_GG_MAXP];
+    const float* A[SREC_GG_MAXP][SREC_GG_MAXS];
+    const float* B[SREC_GG_MAXP][SREC_GG_MAXS];
+    float* C[SREC_GG_MAXP];
+    const int* dyn[SREC_GG_MAXP];
+} srec_gemm_group;
+
 #endif

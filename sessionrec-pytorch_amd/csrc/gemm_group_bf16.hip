@@ -1,0 +1,199 @@
+// Grouped, K-segmented bf16-operand GEMM: several independent problems in ONE launch, each
+//   C_p [M_p, N_p] (+)= sum_s  opA(A_{p,s}) * opB(B_{p,s})        (fp32 in HBM, bf16 MFMA operands, fp32 accumulate)
+// Used by the batched MSHGNN layer (ops.HGATLayer), whose 8 GAT modules otherwise cost 24 GEMM launches + 16 split-K
+// reductions + 8 weight transposes per layer:
+//   forward        P_m  = x[rows_m] W_m^T            A k-contiguous, B k-contiguous       (nn.Linear, gatconv.py:166-175)
+//   backward-data  dx_t = sum_{m touching t} dP_m[rows_t] W_m   A k-contiguous, B reduction-major, one segment per module:
+//                  the sum over modules is the K loop, so no split-K slabs, no beta chains, no transposed weight copies
+//   weight grad    dW_m = dP_m^T x[rows_m]           A and B reduction-major (reduction = node rows, clamped by dyn)
+// 64x64x32 tiles, 4 waves (2x2) of one v_mfma_f32_32x32x16_bf16 accumulator each; operands are rounded to bf16 while
+// staged (k-contiguous: float4 along k; reduction-major: (m, m+1) pairs packed and transposed, see gemm_bf16.hip).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BK = 32, LDS_LD = BK + 8, MAXP = 8, MAXS = 4;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) & 0xffff0000u;
+    return ua | ub;
+}
+
+struct GArgs {
+    const float* A[MAXP][MAXS];
+    const float* B[MAXP][MAXS];
+    float* C[MAXP];
+    const int* dyn[MAXP];
+    int M[MAXP], N[MAXP], K[MAXP], nseg[MAXP], start[MAXP + 1];
+    int np, lda, ldb, ldc;
+    float beta;
+};
+
+// AK / BK_: operand is k-contiguous ([rows, K] row-major); otherwise reduction-major ([K, rows] row-major).
+// dyn clamps the output rows M when AK (rows >= live: zeroed if beta == 0, untouched otherwise), the reduction otherwise.
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][64][LDS_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][64][LDS_LD];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i)
+        if (i < g.np && (int)blockIdx.x >= g.start[i]) p = i;
+    const int M = g.M[p], N = g.N[p];
+    const int tn = (N + 63) / 64, tile = blockIdx.x - g.start[p];
+    const int m0 = (tile / tn) * 64, n0 = (tile % tn) * 64;
+    const int live = dyn_count(g.dyn[p], AK ? M : g.K[p]);
+    const int Ml = AK ? live : M, Kr = AK ? g.K[p] : live;          // live output rows, reduction length per segment
+    float* __restrict__ C = g.C[p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    if (m0 >= Ml) {
+        if (g.beta == 0.f)
+            for (int i = tid; i < 64 * 64; i += 256) {
+                const int r = m0 + i / 64, c = n0 + i % 64;
+                if (r < M && c < N) C[(size_t)r * g.ldc + c] = 0.f;
+            }
+        return;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // staging coordinates: k-contiguous -> rows sr, sr+32, float4 at k = sk; reduction-major -> 4 columns c4, rows q2, q2+1
+    const int sr = tid >> 3, sk = (tid & 7) * 4;
+    const int c4 = ((tid & 3) + 4 * (tid >> 6)) * 4, q2 = ((tid >> 2) & 15) * 2;
+    const int nkt = (Kr + BK - 1) / BK, total = nkt * g.nseg[p];
+    float4 ra[2], rb[2];
+    auto gload = [&](int it) {
+        const int s = it / nkt, k0 = (it % nkt) * BK;
+        const float* __restrict__ A = g.A[p][s];
+        const float* __restrict__ B = g.B[p][s];
+        if (AK) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ra[q] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + sr + 32 * q, Ml - 1) * g.lda + min(k0 + sk, Kr - 4));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ra[q] = *reinterpret_cast<const float4*>(A + (size_t)min(k0 + q2 + q, Kr - 1) * g.lda + min(m0 + c4, M - 4));
+        }
+        if (BKC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                rb[q] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + sr + 32 * q, N - 1) * g.ldb + min(k0 + sk, Kr - 4));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                rb[q] = *reinterpret_cast<const float4*>(B + (size_t)min(k0 + q2 + q, Kr - 1) * g.ldb + min(n0 + c4, N - 4));
+        }
+    };
+    auto lstore = [&](int buf, int it) {
+        const int k0 = (it % nkt) * BK;
+        if (AK) {
+            const bool kok = k0 + sk < Kr;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = kok && (m0 + sr + 32 * q < Ml);
+                uint2 v;
+                v.x = ok ? pack_bf16(ra[q].x, ra[q].y) : 0u; v.y = ok ? pack_bf16(ra[q].z, ra[q].w) : 0u;
+                *reinterpret_cast<uint2*>(&As[buf][sr + 32 * q][sk]) = v;
+            }
+        } else {
+            const bool ok0 = k0 + q2 < Kr, ok1 = k0 + q2 + 1 < Kr, cok = m0 + c4 < M;
+            const float a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w}, a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<unsigned*>(&As[buf][c4 + j][q2]) =
+                    pack_bf16((cok && ok0) ? a0[j] : 0.f, (cok && ok1) ? a1[j] : 0.f);
+        }
+        if (BKC) {
+            const bool kok = k0 + sk < Kr;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = kok && (n0 + sr + 32 * q < N);
+                uint2 v;
+                v.x = ok ? pack_bf16(rb[q].x, rb[q].y) : 0u; v.y = ok ? pack_bf16(rb[q].z, rb[q].w) : 0u;
+                *reinterpret_cast<uint2*>(&Bs[buf][sr + 32 * q][sk]) = v;
+            }
+        } else {
+            const bool ok0 = k0 + q2 < Kr, ok1 = k0 + q2 + 1 < Kr, cok = n0 + c4 < N;
+            const float b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<unsigned*>(&Bs[buf][c4 + j][q2]) =
+                    pack_bf16((cok && ok0) ? b0[j] : 0.f, (cok && ok1) ? b1[j] : 0.f);
+        }
+    };
+    if (total > 0) {
+        gload(0);
+        lstore(0, 0);
+    }
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < total) gload(it + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][wm * 32 + l31][ks * 16 + half * 8]);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[buf][wn * 32 + l31][ks * 16 + half * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        if (it + 1 < total) lstore(buf ^ 1, it + 1);
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + l31;
+    if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < M) {
+                float* q = C + (size_t)row * g.ldc + col;
+                if (row < Ml) *q = g.beta != 0.f ? acc[r] + g.beta * *q : acc[r];
+                else if (g.beta == 0.f) *q = 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// desc (host): srec_gemm_group (srec_hg.h).  mode 0: A, B k-contiguous (NT); 1: A k-contiguous, B reduction-major
+// (NN, segments summed); 2: both reduction-major (TN, dyn clamps the reduction).
+extern "C" int srec_gemm_group_bf16(const void* desc_, int mode, void* stream) {
+    struct Desc {
+        int np, lda, ldb, ldc;
+        float beta;
+        int M[MAXP], N[MAXP], K[MAXP], nseg[MAXP];
+        const float* A[MAXP][MAXS];
+        const float* B[MAXP][MAXS];
+        float* C[MAXP];
+        const int* dyn[MAXP];
+    };
+    const Desc* d = (const Desc*)desc_;
+    if (d == nullptr || d->np <= 0 || d->np > MAXP || mode < 0 || mode > 2 || (d->lda & 3) || (d->ldb & 3)) return SREC_BAD_ARG;
+    GArgs g{};
+    g.np = d->np; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.beta = d->beta;
+    int blocks = 0;
+    for (int p = 0; p < d->np; ++p) {
+        if (d->nseg[p] <= 0 || d->nseg[p] > MAXS || d->M[p] <= 0 || d->N[p] <= 0 || d->K[p] < 4) return SREC_BAD_ARG;
+        if (mode != 2 && (d->K[p] & 3)) return SREC_BAD_ARG;                 // k-contiguous float4 reads
+        if ((mode == 2 && (d->M[p] & 3)) || (mode != 0 && (d->N[p] & 3))) return SREC_BAD_ARG;
+        g.M[p] = d->M[p]; g.N[p] = d->N[p]; g.K[p] = d->K[p]; g.nseg[p] = d->nseg[p]; g.C[p] = d->C[p]; g.dyn[p] = d->dyn[p];
+        for (int s = 0; s < d->nseg[p]; ++s) {
+            if (((uintptr_t)d->A[p][s] & 15) || ((uintptr_t)d->B[p][s] & 15)) return SREC_BAD_ARG;
+            g.A[p][s] = d->A[p][s]; g.B[p][s] = d->B[p][s];
+        }
+        g.start[p] = blocks;
+        blocks += cdiv(d->M[p], 64) * cdiv(d->N[p], 64);
+    }
+    g.start[d->np] = blocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true>), dim3(blocks), dim3(256), 0, st, g);
+    else if (mode == 1) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false>), dim3(blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false>), dim3(blocks), dim3(256), 0, st, g);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

@@ -987,6 +987,25 @@ class HgDesc(_ct.Structure):
                 [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der')])
 
 
+class GemmGroup(_ct.Structure):
+    """host mirror of srec_gemm_group (include/srec_hg.h)"""
+    _fields_ = [('np', _ct.c_int), ('lda', _ct.c_int), ('ldb', _ct.c_int), ('ldc', _ct.c_int), ('beta', _ct.c_float),
+                ('M', _ct.c_int * 8), ('N', _ct.c_int * 8), ('K', _ct.c_int * 8), ('nseg', _ct.c_int * 8),
+                ('A', (_ct.c_void_p * 4) * 8), ('B', (_ct.c_void_p * 4) * 8), ('C', _ct.c_void_p * 8),
+                ('dyn', _ct.c_void_p * 8)]
+
+
+def gemm_group(mode, probs, lda, ldb, ldc, beta=0.0):
+    """probs: [(M, N, K, [(A, B), ...] segments, C, dyn)] tensors -> one srec_gemm_group_bf16 launch"""
+    g = GemmGroup()
+    g.np, g.lda, g.ldb, g.ldc, g.beta = len(probs), lda, ldb, ldc, beta
+    for p, (M, N, K, segs, C, dyn) in enumerate(probs):
+        g.M[p], g.N[p], g.K[p], g.nseg[p], g.C[p], g.dyn[p] = M, N, K, len(segs), ptr(C), ptr(dyn)
+        for si, (A, B) in enumerate(segs):
+            g.A[p][si], g.B[p][si] = ptr(A), ptr(B)
+    lib.srec_gemm_group_bf16(_ct.addressof(g), mode, stream())
+
+
 class HgPlan:
     """Static topology of one MSHGNN layer call (built by msgifsr.MSHGNN from the FlatBatch).
     types:   [(row0, ncap, dyn_n, seg)]                          node types, stacked rows
@@ -1058,11 +1077,14 @@ class HGATLayer(torch.autograd.Function):
         H = plan.H
         HD = H * D
         dev = x.device
-        P = []
-        for m, (r0, nr, dyn) in enumerate(plan.modules):
-            Pm = torch.empty(nr, HD, device=dev, dtype=torch.float32)
-            gemm_nt(x[r0:r0 + nr], _rows(params[4 * m]), Pm, None, dyn, 1 if dyn is not None else 0)
-            P.append(Pm)
+        P = [torch.empty(nr, HD, device=dev, dtype=torch.float32) for (r0, nr, dyn) in plan.modules]
+        grouped = PRECISION['matmul'] == 'bf16' and D % 4 == 0 and _ld(x) == D and len(plan.modules) <= 8
+        if grouped:
+            gemm_group(0, [(nr, HD, D, [(x[r0:r0 + nr], params[4 * m])], P[m], dyn)
+                           for m, (r0, nr, dyn) in enumerate(plan.modules)], D, D, HD)
+        else:
+            for m, (r0, nr, dyn) in enumerate(plan.modules):
+                gemm_nt(x[r0:r0 + nr], _rows(params[4 * m]), P[m], None, dyn, 1 if dyn is not None else 0)
         nfl, lay = plan.scratch_layout()
         small = torch.empty(max(nfl, 1), device=dev, dtype=torch.float32)
         out = torch.empty(NT, D, device=dev, dtype=torch.float32)
@@ -1071,7 +1093,7 @@ class HGATLayer(torch.autograd.Function):
         desc = plan.fill(HgDesc(), small, lay, P, None, flat, None)
         lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
         ctx.save_for_backward(x, small, arg, *P, *params)
-        ctx.plan, ctx.lay = plan, lay
+        ctx.plan, ctx.lay, ctx.grouped = plan, lay, grouped
         return out
 
     @staticmethod
@@ -1085,7 +1107,10 @@ class HGATLayer(torch.autograd.Function):
         NT, D = x.shape
         HD = plan.H * D
         dev = x.device
-        dP = [torch.empty_like(p) for p in P]
+        # rows of a module's projection that no relation instance touches (a type without live 'inter' edges) get no
+        # gradient from the kernels: those buffers start from zero
+        cov = [sum(plan.types[bt][1] for bm, bt in plan.blocks if bm == m) for m in range(nm)]
+        dP = [torch.empty_like(p) if cov[m] == p.shape[0] else torch.zeros_like(p) for m, p in enumerate(P)]
         grads = torch.empty(nm, 3, HD, device=dev, dtype=torch.float32)
         dx = torch.empty(NT, D, device=dev, dtype=torch.float32)
         flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
@@ -1098,12 +1123,24 @@ class HGATLayer(torch.autograd.Function):
             ws = _HG_WS[key] = torch.empty(max(n.value, 1), device=dev, dtype=torch.float32)
         lib.srec_hg_bwd(_ct.addressof(desc), ptr(g), _ld(g), ptr(arg), ptr(dx), D, ptr(ws), stream())
         outs = []
+        gWs = [torch.empty_like(params[4 * m]) for m in range(nm)]
+        if ctx.grouped:
+            # d x of one node type = sum over the modules that project it: the module sum is the K loop (segments)
+            probs = []
+            for t, (t0, nc, dyn_t, _) in enumerate(plan.types):
+                segs = [(dP[m][t0 - r0:t0 - r0 + nc], params[4 * m]) for m, (r0, nr, _) in enumerate(plan.modules)
+                        if r0 <= t0 and t0 + nc <= r0 + nr and any(bm == m and bt == t for bm, bt in plan.blocks)]
+                if segs:
+                    probs.append((nc, D, HD, segs, dx[t0:t0 + nc], dyn_t))
+            gemm_group(1, probs, HD, D, D, beta=1.0)
+            gemm_group(2, [(HD, D, nr, [(dP[m], x[r0:r0 + nr])], gWs[m], dyn)
+                           for m, (r0, nr, dyn) in enumerate(plan.modules)], HD, D, D)
         for m, (r0, nr, dyn) in enumerate(plan.modules):
-            W = _rows(params[4 * m])
-            mode = 1 if dyn is not None else 0
-            gemm_nn(dP[m], W, dx[r0:r0 + nr], dyn, mode, beta=1.0)
-            gW = torch.empty_like(W)
-            gemm_tn(dP[m], x[r0:r0 + nr], gW, dyn)
+            gW = gWs[m]
+            if not ctx.grouped:
+                W = _rows(params[4 * m])
+                gemm_nn(dP[m], W, dx[r0:r0 + nr], dyn, 1 if dyn is not None else 0, beta=1.0)
+                gemm_tn(dP[m], x[r0:r0 + nr], gW, dyn)
             outs += [gW, grads[m, 0].view(params[4 * m + 1].shape), grads[m, 1].view(params[4 * m + 2].shape),
                      grads[m, 2].view(params[4 * m + 3].shape)]
         return (dx, None) + tuple(outs)

@@ -516,3 +516,38 @@ def test_score_ce_bf16_within_stated_tolerance(dev, B, V, d, cosine):
     assert rel(srg.grad, sr2.grad) < 2e-2, rel(srg.grad, sr2.grad)
     assert rel(tg.buf, E2.grad) < 2e-2, rel(tg.buf, E2.grad)
     close(lse, torch.logsumexp(z, 1), what='lse', rtol=0, atol=3e-2)
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_gemm_group_bf16(dev, mode):
+    """grouped / K-segmented bf16 GEMM == per-problem fp32 products of the bf16-rounded operands"""
+    ops = _ops()
+    torch.manual_seed(mode)
+    r = lambda *s: torch.randn(*s, device=dev)
+    bf = lambda t: t.bfloat16().float()
+    if mode == 0:
+        xs, ws = [r(300, 64), r(1000, 64)], [r(128, 64), r(128, 64)]
+        Cs = [torch.empty(300, 128, device=dev), torch.full((1000, 128), 5.0, device=dev)]
+        dyn = torch.tensor([777], device=dev, dtype=torch.int32)
+        ops.gemm_group(0, [(300, 128, 64, [(xs[0], ws[0])], Cs[0], None), (1000, 128, 64, [(xs[1], ws[1])], Cs[1], dyn)], 64, 64, 128)
+        close(Cs[0], bf(xs[0]) @ bf(ws[0]).t(), what='group nt 0', rtol=1e-4, atol=1e-3)
+        ref = bf(xs[1]) @ bf(ws[1]).t()
+        ref[777:] = 0
+        close(Cs[1], ref, what='group nt 1 (dyn rows zeroed)', rtol=1e-4, atol=1e-3)
+    elif mode == 1:
+        g1, g2, g3 = r(500, 256), r(500, 256), r(200, 256)
+        w1, w2 = r(256, 64), r(256, 64)
+        C0, C1 = torch.ones(500, 64, device=dev), torch.ones(200, 64, device=dev)
+        dyn = torch.tensor([450], device=dev, dtype=torch.int32)
+        ops.gemm_group(1, [(500, 64, 256, [(g1, w1), (g2, w2)], C0, dyn), (200, 64, 256, [(g3, w2)], C1, None)], 256, 64, 64, beta=1.0)
+        ref0 = 1.0 + bf(g1) @ bf(w1) + bf(g2) @ bf(w2)
+        ref0[450:] = 1.0
+        close(C0, ref0, what='group nn segmented', rtol=1e-4, atol=2e-3)
+        close(C1, 1.0 + bf(g3) @ bf(w2), what='group nn 1', rtol=1e-4, atol=2e-3)
+    else:
+        g1, x1, g2, x2 = r(900, 128), r(900, 64), r(333, 128), r(333, 64)
+        C0, C1 = torch.empty(128, 64, device=dev), torch.empty(128, 64, device=dev)
+        dyn = torch.tensor([801], device=dev, dtype=torch.int32)
+        ops.gemm_group(2, [(128, 64, 900, [(g1, x1)], C0, dyn), (128, 64, 333, [(g2, x2)], C1, None)], 128, 64, 64)
+        close(C0, bf(g1[:801]).t() @ bf(x1[:801]), what='group tn dyn', rtol=1e-4, atol=2e-3)
+        close(C1, bf(g2).t() @ bf(x2), what='group tn', rtol=1e-4, atol=2e-3)
