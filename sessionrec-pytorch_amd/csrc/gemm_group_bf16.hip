@@ -13,7 +13,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BK = 32, LDS_LD = BK + 8, MAXP = 8, MAXS = 4;
+constexpr int MAXP = 8, MAXS = 4;
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
@@ -32,12 +32,17 @@ struct GArgs {
     float beta;
 };
 
-// AK / BK_: operand is k-contiguous ([rows, K] row-major); otherwise reduction-major ([K, rows] row-major).
+// AK / BKC: operand is k-contiguous ([rows, K] row-major); otherwise reduction-major ([K, rows] row-major).
 // dyn clamps the output rows M when AK (rows >= live: zeroed if beta == 0, untouched otherwise), the reduction otherwise.
-template <bool AK, bool BKC>
+// BKT = k-tile: 32 for the short-K forward, 64 for the long reductions (twice the bytes in flight per barrier; the
+// loops are global-latency bound - one 64x64 accumulator per wave leaves little MFMA work to hide a load behind).
+template <bool AK, bool BKC, int BKT>
 __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][64][LDS_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][64][LDS_LD];
+    constexpr int LD = BKT + 8;                 // bf16 elements per LDS row: 16-B fragment reads hit distinct 4-bank slots
+    constexpr int NLK = BKT / 16;               // float4 loads per thread, k-contiguous operand (64 x BKT floats)
+    constexpr int NLR = BKT / 32;               // row-pair items per thread, reduction-major operand
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][64][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][64][LD];
     int p = 0;
 #pragma unroll
     for (int i = 1; i < MAXP; ++i)
@@ -62,69 +67,86 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // staging coordinates: k-contiguous -> rows sr, sr+32, float4 at k = sk; reduction-major -> 4 columns c4, rows q2, q2+1
-    const int sr = tid >> 3, sk = (tid & 7) * 4;
-    const int c4 = ((tid & 3) + 4 * (tid >> 6)) * 4, q2 = ((tid >> 2) & 15) * 2;
-    const int nkt = (Kr + BK - 1) / BK, total = nkt * g.nseg[p];
-    float4 ra[2], rb[2];
+    const int nkt = (Kr + BKT - 1) / BKT, total = nkt * g.nseg[p];
+    constexpr int NA = AK ? NLK : 2 * NLR, NB = BKC ? NLK : 2 * NLR;
+    float4 ra[NA], rb[NB];
+    // k-contiguous item q: row = idx / (BKT/4), k = 4 * (idx % (BKT/4)), idx = tid + 256 q
+    // reduction-major item q: 4 columns c4, reduction rows q2, q2 + 1 (lane -> (column group, row pair) keeps a wave's
+    // 64 packed words on 64 distinct LDS banks: see gemm_bf16.hip)
+    auto kc_row = [&](int q) { return (tid + 256 * q) / (BKT / 4); };
+    auto kc_k = [&](int q) { return ((tid + 256 * q) % (BKT / 4)) * 4; };
+    const int c4 = ((tid & 3) + 4 * (tid >> 6)) * 4;
+    auto rm_q2 = [&](int q) { return (((tid >> 2) & 15) + 16 * q) * 2; };
     auto gload = [&](int it) {
-        const int s = it / nkt, k0 = (it % nkt) * BK;
+        const int s = it / nkt, k0 = (it % nkt) * BKT;
         const float* __restrict__ A = g.A[p][s];
         const float* __restrict__ B = g.B[p][s];
         if (AK) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                ra[q] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + sr + 32 * q, Ml - 1) * g.lda + min(k0 + sk, Kr - 4));
+            for (int q = 0; q < NLK; ++q)
+                ra[q] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + kc_row(q), Ml - 1) * g.lda + min(k0 + kc_k(q), Kr - 4));
         } else {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                ra[q] = *reinterpret_cast<const float4*>(A + (size_t)min(k0 + q2 + q, Kr - 1) * g.lda + min(m0 + c4, M - 4));
+            for (int q = 0; q < NLR; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    ra[2 * q + e] = *reinterpret_cast<const float4*>(A + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.lda + min(m0 + c4, M - 4));
         }
         if (BKC) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                rb[q] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + sr + 32 * q, N - 1) * g.ldb + min(k0 + sk, Kr - 4));
+            for (int q = 0; q < NLK; ++q)
+                rb[q] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + kc_row(q), N - 1) * g.ldb + min(k0 + kc_k(q), Kr - 4));
         } else {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                rb[q] = *reinterpret_cast<const float4*>(B + (size_t)min(k0 + q2 + q, Kr - 1) * g.ldb + min(n0 + c4, N - 4));
+            for (int q = 0; q < NLR; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    rb[2 * q + e] = *reinterpret_cast<const float4*>(B + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.ldb + min(n0 + c4, N - 4));
         }
     };
     auto lstore = [&](int buf, int it) {
-        const int k0 = (it % nkt) * BK;
+        const int k0 = (it % nkt) * BKT;
         if (AK) {
-            const bool kok = k0 + sk < Kr;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const bool ok = kok && (m0 + sr + 32 * q < Ml);
+            for (int q = 0; q < NLK; ++q) {
+                const bool ok = (k0 + kc_k(q) < Kr) && (m0 + kc_row(q) < Ml);
                 uint2 v;
                 v.x = ok ? pack_bf16(ra[q].x, ra[q].y) : 0u; v.y = ok ? pack_bf16(ra[q].z, ra[q].w) : 0u;
-                *reinterpret_cast<uint2*>(&As[buf][sr + 32 * q][sk]) = v;
+                *reinterpret_cast<uint2*>(&As[buf][kc_row(q)][kc_k(q)]) = v;
             }
         } else {
-            const bool ok0 = k0 + q2 < Kr, ok1 = k0 + q2 + 1 < Kr, cok = m0 + c4 < M;
-            const float a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w}, a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
+            const bool cok = m0 + c4 < M;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<unsigned*>(&As[buf][c4 + j][q2]) =
-                    pack_bf16((cok && ok0) ? a0[j] : 0.f, (cok && ok1) ? a1[j] : 0.f);
+            for (int q = 0; q < NLR; ++q) {
+                const int q2 = rm_q2(q);
+                const bool ok0 = cok && (k0 + q2 < Kr), ok1 = cok && (k0 + q2 + 1 < Kr);
+                const float a0[4] = {ra[2 * q].x, ra[2 * q].y, ra[2 * q].z, ra[2 * q].w};
+                const float a1[4] = {ra[2 * q + 1].x, ra[2 * q + 1].y, ra[2 * q + 1].z, ra[2 * q + 1].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<unsigned*>(&As[buf][c4 + j][q2]) = pack_bf16(ok0 ? a0[j] : 0.f, ok1 ? a1[j] : 0.f);
+            }
         }
         if (BKC) {
-            const bool kok = k0 + sk < Kr;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const bool ok = kok && (n0 + sr + 32 * q < N);
+            for (int q = 0; q < NLK; ++q) {
+                const bool ok = (k0 + kc_k(q) < Kr) && (n0 + kc_row(q) < N);
                 uint2 v;
                 v.x = ok ? pack_bf16(rb[q].x, rb[q].y) : 0u; v.y = ok ? pack_bf16(rb[q].z, rb[q].w) : 0u;
-                *reinterpret_cast<uint2*>(&Bs[buf][sr + 32 * q][sk]) = v;
+                *reinterpret_cast<uint2*>(&Bs[buf][kc_row(q)][kc_k(q)]) = v;
             }
         } else {
-            const bool ok0 = k0 + q2 < Kr, ok1 = k0 + q2 + 1 < Kr, cok = n0 + c4 < N;
-            const float b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+            const bool cok = n0 + c4 < N;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<unsigned*>(&Bs[buf][c4 + j][q2]) =
-                    pack_bf16((cok && ok0) ? b0[j] : 0.f, (cok && ok1) ? b1[j] : 0.f);
+            for (int q = 0; q < NLR; ++q) {
+                const int q2 = rm_q2(q);
+                const bool ok0 = cok && (k0 + q2 < Kr), ok1 = cok && (k0 + q2 + 1 < Kr);
+                const float b0[4] = {rb[2 * q].x, rb[2 * q].y, rb[2 * q].z, rb[2 * q].w};
+                const float b1[4] = {rb[2 * q + 1].x, rb[2 * q + 1].y, rb[2 * q + 1].z, rb[2 * q + 1].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<unsigned*>(&Bs[buf][c4 + j][q2]) = pack_bf16(ok0 ? b0[j] : 0.f, ok1 ? b1[j] : 0.f);
+            }
         }
     };
     if (total > 0) {
@@ -136,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
         const int buf = it & 1;
         if (it + 1 < total) gload(it + 1);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < BKT / 16; ++ks) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][wm * 32 + l31][ks * 16 + half * 8]);
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[buf][wn * 32 + l31][ks * 16 + half * 8]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
@@ -191,9 +213,9 @@ extern "C" int srec_gemm_group_bf16(const void* desc_, int mode, void* stream) {
     }
     g.start[d->np] = blocks;
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true>), dim3(blocks), dim3(256), 0, st, g);
-    else if (mode == 1) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false>), dim3(blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false>), dim3(blocks), dim3(256), 0, st, g);
+    if (mode == 0) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true, 32>), dim3(blocks), dim3(256), 0, st, g);
+    else if (mode == 1) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false, 64>), dim3(blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false, 64>), dim3(blocks), dim3(256), 0, st, g);
     SREC_LAUNCH_CHECK();
     return 0;
 }
