@@ -117,7 +117,7 @@ int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const
                       void* stream);
 int srec_seg_attn_bwd(const float* dout, int ld_do, const float* X, int ld_x, const float* alpha, const float* U,
                       int ld_u, const float* Vq, int ld_v, const float* we, const int* seg, int B, const int* dynB,
-                      int h, int D, float* dX, int ld_dx, float* dU, int ld_du, float* dVq, int ld_dv,
+                      int h, int D, int n_cap, float* dX, int ld_dx, float* dU, int ld_du, float* dVq, int ld_dv,
                       float* dwe_part, int ld_dw, void* stream);
 /* out_i = h_i + mean_{session(i)} f  (msgifsr.py:86-89) */
 int srec_seg_mean_add_fwd(const float* H, int ld_h, const float* F, int ld_f, const int* seg, int B, const int* dynB,

@@ -14,66 +14,78 @@ namespace {
 constexpr int WPB = 4;
 constexpr int MAXN = 256;   // max nodes of one session (host checks)
 
+// One 256-thread workgroup per session: the 4 waves split the session's nodes for the per-node dot products
+// (float4 per lane along the hidden dim), the soft-max is one wave, the weighted sums run one column per thread.
 __global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const float* __restrict__ Vq, int ld_v,
                                     const float* __restrict__ we, const float* __restrict__ X, int ld_x,
                                     const int* __restrict__ seg, int B, const int* __restrict__ dynB, int h, int D,
                                     float* __restrict__ alpha, float* __restrict__ out, int ld_out) {
-    __shared__ float es[WPB][MAXN];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * WPB + w;
-    if (b >= B) return;
+    __shared__ float e[MAXN];
+    const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const bool live = b < dyn_count(dynB, B);
     const int base = live ? seg[b] : 0;
     const int n = live ? min(seg[b + 1] - base, MAXN) : 0;
-    float* e = es[w];
-    for (int i = 0; i < n; ++i) {
+    for (int i = w; i < n; i += WPB) {
         float acc = 0.f;
-        for (int k = lane; k < h; k += 64)
-            acc += we[k] * sigmoidf_(U[(size_t)(base + i) * ld_u + k] + Vq[(size_t)b * ld_v + k]);
+        for (int k = lane * 4; k < h; k += 256) {
+            const float4 u = *reinterpret_cast<const float4*>(U + (size_t)(base + i) * ld_u + k);
+            const float4 v = *reinterpret_cast<const float4*>(Vq + (size_t)b * ld_v + k);
+            const float4 wk = *reinterpret_cast<const float4*>(we + k);
+            acc += wk.x * sigmoidf_(u.x + v.x) + wk.y * sigmoidf_(u.y + v.y) + wk.z * sigmoidf_(u.z + v.z) +
+                   wk.w * sigmoidf_(u.w + v.w);
+        }
         acc = wave_sum(acc);
         if (lane == 0) e[i] = acc;
     }
-    __builtin_amdgcn_wave_barrier();
-    float m = -INFINITY;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, e[i]);
-    m = wave_max(m);
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += expf(e[i] - m);
-    s = wave_sum(s);
-    const float inv = n > 0 ? 1.f / s : 0.f;
-    for (int i = lane; i < n; i += 64) {
-        const float a = expf(e[i] - m) * inv;
-        e[i] = a;
-        alpha[base + i] = a;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int c = lane * 4; c < D; c += 256) {
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < n; ++i) {
-            const float a = e[i];
-            const float4 x = *reinterpret_cast<const float4*>(X + (size_t)(base + i) * ld_x + c);
-            o.x += a * x.x; o.y += a * x.y; o.z += a * x.z; o.w += a * x.w;
+    __syncthreads();
+    if (w == 0) {
+        float m = -INFINITY;
+        for (int i = lane; i < n; i += 64) m = fmaxf(m, e[i]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += expf(e[i] - m);
+        s = wave_sum(s);
+        const float inv = n > 0 ? 1.f / s : 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const float a = expf(e[i] - m) * inv;
+            e[i] = a;
+            alpha[base + i] = a;
         }
-        *reinterpret_cast<float4*>(out + (size_t)b * ld_out + c) = o;
+    }
+    __syncthreads();
+    for (int c = tid; c < D; c += 256) {
+        float o = 0.f;
+        for (int i = 0; i < n; ++i) o += e[i] * X[(size_t)(base + i) * ld_x + c];
+        out[(size_t)b * ld_out + c] = o;
     }
 }
 
+// grid = B + 1: workgroup b < live B owns session b; all workgroups share the zeroing of the rows of dX / dU behind
+// the last live node (padded layouts), so the outputs need no host-side zero fill.
 __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, const float* __restrict__ X, int ld_x,
                                     const float* __restrict__ alpha, const float* __restrict__ U, int ld_u,
                                     const float* __restrict__ Vq, int ld_v, const float* __restrict__ we,
                                     const int* __restrict__ seg, int B, const int* __restrict__ dynB, int h, int D,
-                                    float* __restrict__ dX, int ld_dx, float* __restrict__ dU, int ld_du,
+                                    int n_cap, float* __restrict__ dX, int ld_dx, float* __restrict__ dU, int ld_du,
                                     float* __restrict__ dVq, int ld_dv, float* __restrict__ dwe_part, int ld_dw) {
-    __shared__ float de_s[WPB][MAXN];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * WPB + w;
-    if (b >= B) return;
-    const bool live = b < dyn_count(dynB, B);
-    const int base = live ? seg[b] : 0;
-    const int n = live ? min(seg[b + 1] - base, MAXN) : 0;
-    float* de = de_s[w];
+    __shared__ float de[MAXN];
+    __shared__ float al[MAXN];
+    const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int Bd = dyn_count(dynB, B);
+    // rows behind the last live node: every workgroup zeroes its share (row r0 + b, r0 + b + grid, ...)
+    for (int r = seg[Bd] + b; r < n_cap; r += gridDim.x) {
+        for (int c = tid; c < D; c += 256) dX[(size_t)r * ld_dx + c] = 0.f;
+        for (int k = tid; k < h; k += 256) dU[(size_t)r * ld_du + k] = 0.f;
+    }
+    if (b >= Bd) {
+        if (b < B)
+            for (int k = tid; k < h; k += 256) { dVq[(size_t)b * ld_dv + k] = 0.f; dwe_part[(size_t)b * ld_dw + k] = 0.f; }
+        return;
+    }
+    const int base = seg[b];
+    const int n = min(seg[b + 1] - base, MAXN);
     // dalpha_i = <dout_b, x_i>;  dX_i = alpha_i dout_b
-    for (int i = 0; i < n; ++i) {
+    for (int i = w; i < n; i += WPB) {
         const float a = alpha[base + i];
         float acc = 0.f;
         for (int c = lane * 4; c < D; c += 256) {
@@ -84,16 +96,18 @@ __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, c
                 make_float4(a * g.x, a * g.y, a * g.z, a * g.w);
         }
         acc = wave_sum(acc);
-        if (lane == 0) de[i] = acc;
+        if (lane == 0) { de[i] = acc; al[i] = a; }
     }
-    __builtin_amdgcn_wave_barrier();
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += alpha[base + i] * de[i];
-    s = wave_sum(s);
-    for (int i = lane; i < n; i += 64) de[i] = alpha[base + i] * (de[i] - s);     // d e_i
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < h; k += 64) {
-        const float vq = live ? Vq[(size_t)b * ld_v + k] : 0.f;
+    __syncthreads();
+    if (w == 0) {
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s += al[i] * de[i];
+        s = wave_sum(s);
+        for (int i = lane; i < n; i += 64) de[i] = al[i] * (de[i] - s);     // d e_i
+    }
+    __syncthreads();
+    for (int k = tid; k < h; k += 256) {
+        const float vq = Vq[(size_t)b * ld_v + k];
         const float wk = we[k];
         float dv = 0.f, dw = 0.f;
         for (int i = 0; i < n; ++i) {
@@ -207,21 +221,21 @@ extern "C" int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int 
                                  float* out, int ld_out, void* stream) {
     if (B <= 0) return 0;
     if ((D & 3) || (ld_x & 3) || (ld_out & 3)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(seg_attn_fwd_kernel, dim3(cdiv(B, WPB)), dim3(256), 0, (hipStream_t)stream, U, ld_u, Vq, ld_v, we,
-                       X, ld_x, seg, B, dynB, h, D, alpha, out, ld_out);
+    if ((h & 3) || (ld_u & 3) || (ld_v & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(seg_attn_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, U, ld_u, Vq, ld_v, we, X, ld_x, seg,
+                       B, dynB, h, D, alpha, out, ld_out);
     SREC_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int srec_seg_attn_bwd(const float* dout, int ld_do, const float* X, int ld_x, const float* alpha,
                                  const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const int* seg,
-                                 int B, const int* dynB, int h, int D, float* dX, int ld_dx, float* dU, int ld_du,
+                                 int B, const int* dynB, int h, int D, int n_cap, float* dX, int ld_dx, float* dU, int ld_du,
                                  float* dVq, int ld_dv, float* dwe_part, int ld_dw, void* stream) {
     if (B <= 0) return 0;
     if ((D & 3) || (ld_x & 3) || (ld_do & 3) || (ld_dx & 3)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(seg_attn_bwd_kernel, dim3(cdiv(B, WPB)), dim3(256), 0, (hipStream_t)stream, dout, ld_do, X, ld_x,
-                       alpha, U, ld_u, Vq, ld_v, we, seg, B, dynB, h, D, dX, ld_dx, dU, ld_du, dVq, ld_dv, dwe_part,
-                       ld_dw);
+    hipLaunchKernelGGL(seg_attn_bwd_kernel, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, dout, ld_do, X, ld_x, alpha, U,
+                       ld_u, Vq, ld_v, we, seg, B, dynB, h, D, n_cap, dX, ld_dx, dU, ld_du, dVq, ld_dv, dwe_part, ld_dw);
     SREC_LAUNCH_CHECK();
     return 0;
 }

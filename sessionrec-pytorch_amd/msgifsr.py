@@ -62,10 +62,10 @@ class SemanticExpander(nn.Module):
         gru = self.GRUs[k - 2]
         d = self.input_dim
         n = x.shape[0] // k
-        GI = ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0, dyn_rows).view(n, k, 3 * d)
+        GI = ops.unbind_mid(ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0, dyn_rows).view(n, k, 3 * d))
         h = None
         for t in range(k):
-            gi = GI[:, t, :]
+            gi = GI[t]
             if t == 0:
                 h = ops.gru_step(gi, None, gru.bias_hh_l0, None, dyn)
             else:

@@ -95,10 +95,10 @@ def gemm_nn(g, w, out, dyn=None, dyn_mode=0, beta=0.0):
     """out[M,K] = g[M,N] @ w[N,K]"""
     M, N = g.shape
     K = w.shape[1]
-    if dyn_mode in (0, 1) and _bf16_ok(N, g) and w.shape[0] * w.shape[1] <= (1 << 22):
-        wt = _transposed(w)                          # [K, N]: the product becomes NT on the bf16 matrix cores
-        lib.srec_gemm_bf16_nt(ptr(g), _ld(g), ptr(wt), _ld(wt), ptr(out), _ld(out), None, M, K, N,
-                              ptr(dyn) if dyn_mode == 1 else None, 1.0, beta, *_gemm_ws(g.device), stream())
+    if dyn_mode in (0, 1) and _bf16_ok(N, g) and not (K & 3) and not (_ld(w) & 3) and not (w.data_ptr() & 15):
+        # B operand reduction-major: the weight is transposed while it is staged into LDS (no transposed copy, no
+        # split-K slabs: gemm_group_bf16.hip)
+        gemm_group(1, [(M, K, N, [(g, w)], out, dyn if dyn_mode == 1 else None)], _ld(g), _ld(w), _ld(out), beta)
         return
     lib.srec_gemm_f32(ptr(g), _ld(g), 1, ptr(w), 1, _ld(w), ptr(out), _ld(out), None, M, K, N, ptr(dyn), dyn_mode, 1.0,
                       beta, *_gemm_ws(g.device), stream())
@@ -317,12 +317,12 @@ class SegAttn(torch.autograd.Function):
         gout = _rows(gout)
         B, h = Vq.shape
         N, D = X.shape
-        dX = torch.zeros(N, D, device=X.device, dtype=torch.float32)
-        dU = torch.zeros(N, h, device=X.device, dtype=torch.float32)
+        dX = torch.empty(N, D, device=X.device, dtype=torch.float32)      # rows behind the live nodes zeroed in-kernel
+        dU = torch.empty(N, h, device=X.device, dtype=torch.float32)
         dVq = torch.empty(B, h, device=X.device, dtype=torch.float32)
         dwp = torch.empty(B, h, device=X.device, dtype=torch.float32)
         lib.srec_seg_attn_bwd(ptr(gout), _ld(gout), ptr(X), _ld(X), ptr(alpha), ptr(U), _ld(U), ptr(Vq), _ld(Vq),
-                              ptr(we), ptr(seg), B, ptr(ctx.dynB), h, D, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp),
+                              ptr(we), ptr(seg), B, ptr(ctx.dynB), h, D, N, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp),
                               h, stream())
         dwe = torch.empty(h, device=X.device, dtype=torch.float32)
         col_sum(dwp, B, h, dwe, ctx.dynB)
@@ -627,6 +627,26 @@ class GRUPointwise(torch.autograd.Function):
         db = torch.empty(d3, device=dev, dtype=torch.float32)
         col_sum(dGH, n, d3, db, ctx.dyn)
         return dGI, None, db, None, None
+
+
+class UnbindMid(torch.autograd.Function):
+    """x [n, k, m] -> k row-strided views x[:, t, :]; the backward is ONE stack instead of autograd's k zero-fills,
+    k slice copies and k-1 adds (SelectBackward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return tuple(x[:, t, :] for t in range(x.shape[1]))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, k, m = ctx.shape
+        gs = [g if g is not None else torch.zeros(n, m, device=gs[0].device if gs[0] is not None else None) for g in gs]
+        return torch.stack(gs, 1)
+
+
+def unbind_mid(x):
+    return UnbindMid.apply(x)
 
 
 def gru_step(GI, GH, bhh, Hp, dyn=None):

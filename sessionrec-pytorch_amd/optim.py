@@ -40,7 +40,12 @@ class FusedAdam(torch.optim.Optimizer):
         if table is not None and p is table and tgrad is not None:
             g = tgrad.buf if g is None else g.add_(tgrad.buf)
         if g is None and id(p) in zero_ids:
-            g = torch.zeros_like(p)          # zero (not None) gradient in the reference: weight decay only
+            # zero (not None) gradient in the reference: weight decay only.  One static all-zero buffer per parameter
+            # (never written), not a fill per step.
+            cache = self.__dict__.setdefault('_zero_grads', {})
+            g = cache.get(id(p))
+            if g is None or g.shape != p.shape or g.device != p.device:
+                g = cache[id(p)] = torch.zeros_like(p)
         return g
 
     def _buffers(self, gi, slot, device):
