@@ -25,14 +25,15 @@
 typedef struct {
     int H, D, n_types, n_mods, n_blocks, n_inst, B;
     float slope;
+    int p16;                       /* 1: P / dP hold bf16 (2-byte) elements, 0: fp32 */
     const int* dynB;
     /* node types */
     int row0[SREC_HG_MAXT], ncap[SREC_HG_MAXT];
     const int* dyn_n[SREC_HG_MAXT];
     const int* seg[SREC_HG_MAXT];
     /* modules */
-    const float* P[SREC_HG_MAXM];
-    float* dP[SREC_HG_MAXM];
+    const void* P[SREC_HG_MAXM];
+    void* dP[SREC_HG_MAXM];
     const float* attn_l[SREC_HG_MAXM];
     const float* attn_r[SREC_HG_MAXM];
     const float* bias[SREC_HG_MAXM];
@@ -64,10 +65,11 @@ typedef struct {
 typedef struct {
     int np, lda, ldb, ldc;
     float beta;
+    int a16, c16;                  /* A operands / C outputs are bf16 (2-byte) instead of fp32 */
     int M[SREC_GG_MAXP], N[SREC_GG_MAXP], K[SREC_GG_MAXP], nseg[SREC_GG_MAXP];
-    const float* A[SREC_GG_MAXP][SREC_GG_MAXS];
+    const void* A[SREC_GG_MAXP][SREC_GG_MAXS];
     const float* B[SREC_GG_MAXP][SREC_GG_MAXS];
-    float* C[SREC_GG_MAXP];
+    void* C[SREC_GG_MAXP];
     const int* dyn[SREC_GG_MAXP];
 } srec_gemm_group;
 

@@ -23,9 +23,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 
 struct GArgs {
-    const float* A[MAXP][MAXS];
+    const void* A[MAXP][MAXS];
     const float* B[MAXP][MAXS];
-    float* C[MAXP];
+    void* C[MAXP];
     const int* dyn[MAXP];
     int M[MAXP], N[MAXP], K[MAXP], nseg[MAXP], start[MAXP + 1];
     int np, lda, ldb, ldc;
@@ -36,7 +36,8 @@ struct GArgs {
 // dyn clamps the output rows M when AK (rows >= live: zeroed if beta == 0, untouched otherwise), the reduction otherwise.
 // BKT = k-tile: 32 for the short-K forward, 64 for the long reductions (twice the bytes in flight per barrier; the
 // loops are global-latency bound - one 64x64 accumulator per wave leaves little MFMA work to hide a load behind).
-template <bool AK, bool BKC, int BKT>
+// A16: the A operands are already bf16 in HBM (projection gradients written by hgat.hip); C16: C is stored as bf16.
+template <bool AK, bool BKC, int BKT, bool A16, bool C16>
 __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     constexpr int LD = BKT + 8;                 // bf16 elements per LDS row: 16-B fragment reads hit distinct 4-bank slots
     constexpr int NLK = BKT / 16;               // float4 loads per thread, k-contiguous operand (64 x BKT floats)
@@ -52,14 +53,15 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     const int m0 = (tile / tn) * 64, n0 = (tile % tn) * 64;
     const int live = dyn_count(g.dyn[p], AK ? M : g.K[p]);
     const int Ml = AK ? live : M, Kr = AK ? g.K[p] : live;          // live output rows, reduction length per segment
-    float* __restrict__ C = g.C[p];
+    float* __restrict__ C = static_cast<float*>(g.C[p]);
+    unsigned short* __restrict__ C16p = static_cast<unsigned short*>(g.C[p]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
     if (m0 >= Ml) {
         if (g.beta == 0.f)
             for (int i = tid; i < 64 * 64; i += 256) {
                 const int r = m0 + i / 64, c = n0 + i % 64;
-                if (r < M && c < N) C[(size_t)r * g.ldc + c] = 0.f;
+                if (r < M && c < N) { if (C16) C16p[(size_t)r * g.ldc + c] = 0; else C[(size_t)r * g.ldc + c] = 0.f; }
             }
         return;
     }
@@ -70,6 +72,11 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     const int nkt = (Kr + BKT - 1) / BKT, total = nkt * g.nseg[p];
     constexpr int NA = AK ? NLK : 2 * NLR, NB = BKC ? NLK : 2 * NLR;
     float4 ra[NA], rb[NB];
+    uint4 ra16[AK ? (BKT / 32 > 0 ? BKT / 32 : 1) : 1];      // A16, k-contiguous: 8 bf16 per 16-B load
+    uint2 rr16[2 * NLR];                                     // A16, reduction-major: 4 bf16 per 8-B load
+    constexpr int NL16 = BKT / 32;                           // 64 x BKT bf16 = 16-B loads per thread
+    auto k16_row = [&](int q) { return (tid + 256 * q) / (BKT / 8); };
+    auto k16_k = [&](int q) { return ((tid + 256 * q) % (BKT / 8)) * 8; };
     // k-contiguous item q: row = idx / (BKT/4), k = 4 * (idx % (BKT/4)), idx = tid + 256 q
     // reduction-major item q: 4 columns c4, reduction rows q2, q2 + 1 (lane -> (column group, row pair) keeps a wave's
     // 64 packed words on 64 distinct LDS banks: see gemm_bf16.hip)
@@ -79,9 +86,20 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     auto rm_q2 = [&](int q) { return (((tid >> 2) & 15) + 16 * q) * 2; };
     auto gload = [&](int it) {
         const int s = it / nkt, k0 = (it % nkt) * BKT;
-        const float* __restrict__ A = g.A[p][s];
+        const float* __restrict__ A = static_cast<const float*>(g.A[p][s]);
+        const unsigned short* __restrict__ A16p = static_cast<const unsigned short*>(g.A[p][s]);
         const float* __restrict__ B = g.B[p][s];
-        if (AK) {
+        if (A16 && AK) {
+#pragma unroll
+            for (int q = 0; q < NL16; ++q)
+                ra16[q] = *reinterpret_cast<const uint4*>(A16p + (size_t)min(m0 + k16_row(q), Ml - 1) * g.lda + min(k0 + k16_k(q), Kr - 8));
+        } else if (A16) {
+#pragma unroll
+            for (int q = 0; q < NLR; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    rr16[2 * q + e] = *reinterpret_cast<const uint2*>(A16p + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.lda + min(m0 + c4, M - 4));
+        } else if (AK) {
 #pragma unroll
             for (int q = 0; q < NLK; ++q)
                 ra[q] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + kc_row(q), Ml - 1) * g.lda + min(k0 + kc_k(q), Kr - 4));
@@ -106,7 +124,25 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     };
     auto lstore = [&](int buf, int it) {
         const int k0 = (it % nkt) * BKT;
-        if (AK) {
+        if (A16 && AK) {
+#pragma unroll
+            for (int q = 0; q < NL16; ++q) {
+                const bool ok = (k0 + k16_k(q) < Kr) && (m0 + k16_row(q) < Ml);
+                *reinterpret_cast<uint4*>(&As[buf][k16_row(q)][k16_k(q)]) = ok ? ra16[q] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else if (A16) {
+            const bool cok = m0 + c4 < M;
+#pragma unroll
+            for (int q = 0; q < NLR; ++q) {
+                const int q2 = rm_q2(q);
+                const bool ok0 = cok && (k0 + q2 < Kr), ok1 = cok && (k0 + q2 + 1 < Kr);
+                const uint2 r0 = ok0 ? rr16[2 * q] : make_uint2(0u, 0u), r1 = ok1 ? rr16[2 * q + 1] : make_uint2(0u, 0u);
+                *reinterpret_cast<unsigned*>(&As[buf][c4 + 0][q2]) = (r0.x & 0xffffu) | (r1.x << 16);
+                *reinterpret_cast<unsigned*>(&As[buf][c4 + 1][q2]) = (r0.x >> 16) | (r1.x & 0xffff0000u);
+                *reinterpret_cast<unsigned*>(&As[buf][c4 + 2][q2]) = (r0.y & 0xffffu) | (r1.y << 16);
+                *reinterpret_cast<unsigned*>(&As[buf][c4 + 3][q2]) = (r0.y >> 16) | (r1.y & 0xffff0000u);
+            }
+        } else if (AK) {
 #pragma unroll
             for (int q = 0; q < NLK; ++q) {
                 const bool ok = (k0 + kc_k(q) < Kr) && (m0 + kc_row(q) < Ml);
@@ -172,9 +208,15 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (row < M) {
-                float* q = C + (size_t)row * g.ldc + col;
-                if (row < Ml) *q = g.beta != 0.f ? acc[r] + g.beta * *q : acc[r];
-                else if (g.beta == 0.f) *q = 0.f;
+                if (C16) {                                   // bf16 output (beta is ignored: forward projections)
+                    unsigned u = __float_as_uint(row < Ml ? acc[r] : 0.f);
+                    u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+                    C16p[(size_t)row * g.ldc + col] = (unsigned short)u;
+                } else {
+                    float* q = C + (size_t)row * g.ldc + col;
+                    if (row < Ml) *q = g.beta != 0.f ? acc[r] + g.beta * *q : acc[r];
+                    else if (g.beta == 0.f) *q = 0.f;
+                }
             }
         }
     }
@@ -188,20 +230,22 @@ extern "C" int srec_gemm_group_bf16(const void* desc_, int mode, void* stream) {
     struct Desc {
         int np, lda, ldb, ldc;
         float beta;
+        int a16, c16;
         int M[MAXP], N[MAXP], K[MAXP], nseg[MAXP];
-        const float* A[MAXP][MAXS];
+        const void* A[MAXP][MAXS];
         const float* B[MAXP][MAXS];
-        float* C[MAXP];
+        void* C[MAXP];
         const int* dyn[MAXP];
     };
     const Desc* d = (const Desc*)desc_;
     if (d == nullptr || d->np <= 0 || d->np > MAXP || mode < 0 || mode > 2 || (d->lda & 3) || (d->ldb & 3)) return SREC_BAD_ARG;
+    if ((d->a16 && (mode == 0 || (d->lda & 7))) || (d->c16 && mode != 0)) return SREC_BAD_ARG;
     GArgs g{};
     g.np = d->np; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.beta = d->beta;
     int blocks = 0;
     for (int p = 0; p < d->np; ++p) {
         if (d->nseg[p] <= 0 || d->nseg[p] > MAXS || d->M[p] <= 0 || d->N[p] <= 0 || d->K[p] < 4) return SREC_BAD_ARG;
-        if (mode != 2 && (d->K[p] & 3)) return SREC_BAD_ARG;                 // k-contiguous float4 reads
+        if (mode != 2 && (d->K[p] & (d->a16 ? 7 : 3))) return SREC_BAD_ARG;   // k-contiguous 16-B reads
         if ((mode == 2 && (d->M[p] & 3)) || (mode != 0 && (d->N[p] & 3))) return SREC_BAD_ARG;
         g.M[p] = d->M[p]; g.N[p] = d->N[p]; g.K[p] = d->K[p]; g.nseg[p] = d->nseg[p]; g.C[p] = d->C[p]; g.dyn[p] = d->dyn[p];
         for (int s = 0; s < d->nseg[p]; ++s) {
@@ -213,9 +257,13 @@ extern "C" int srec_gemm_group_bf16(const void* desc_, int mode, void* stream) {
     }
     g.start[d->np] = blocks;
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true, 32>), dim3(blocks), dim3(256), 0, st, g);
-    else if (mode == 1) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false, 64>), dim3(blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false, 64>), dim3(blocks), dim3(256), 0, st, g);
+    const dim3 gr(blocks), bl(256);
+    if (mode == 0 && d->c16) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true, 32, false, true>), gr, bl, 0, st, g);
+    else if (mode == 0) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true, 32, false, false>), gr, bl, 0, st, g);
+    else if (mode == 1 && d->a16) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false, 64, true, false>), gr, bl, 0, st, g);
+    else if (mode == 1) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false, 64, false, false>), gr, bl, 0, st, g);
+    else if (d->a16) hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false, 64, true, false>), gr, bl, 0, st, g);
+    else hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false, 64, false, false>), gr, bl, 0, st, g);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -26,6 +26,25 @@ constexpr int MAXH = 8;
 constexpr int NCHUNK = 16;
 constexpr int MAXT = SREC_HG_MAXT, MAXM = SREC_HG_MAXM, MAXB = SREC_HG_MAXB, MAXI = SREC_HG_MAXI;
 
+// projection element type: fp32, or bf16 (unsigned short) when the GEMMs run on bf16 operands anyway - halves the
+// traffic of every pass over the [N, H*D] projections and their gradients
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const unsigned short* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const unsigned short* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(unsigned short* p, float4 v) {
+    const f32x4_t f = {v.x, v.y, v.z, v.w};
+    const bf16x4_t b = __builtin_convertvector(f, bf16x4_t);      // v_cvt_pk_bf16_f32 (RNE)
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, b);
+}
+
 template <int N>
 __device__ __forceinline__ int find_range(const int (&start)[N], int n, int x) {
     int b = 0;
@@ -37,7 +56,7 @@ __device__ __forceinline__ int find_range(const int (&start)[N], int n, int x) {
 
 // ------------------------------------------------------------------------------------------------ logits
 struct DotsArgs {
-    const float* P[MAXB]; const float* al[MAXB]; const float* ar[MAXB];
+    const void* P[MAXB]; const float* al[MAXB]; const float* ar[MAXB];
     float* eL[MAXB]; float* eR[MAXB];
     const int* dyn[MAXB];
     int ncap[MAXB];
@@ -46,6 +65,7 @@ struct DotsArgs {
 };
 
 // eL[n,h] = <P[n,h,:], a_l[h,:]>, eR[n,h] = <P[n,h,:], a_r[h,:]> for every projection block
+template <typename T>
 __global__ void hg_dots_kernel(DotsArgs a) {
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
     const int gid = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -56,7 +76,7 @@ __global__ void hg_dots_kernel(DotsArgs a) {
     float sl = 0.f, sr = 0.f;
     const int c = lane * 4;
     if (live && c < D) {
-        const float4 x = *reinterpret_cast<const float4*>(a.P[b] + (size_t)n * H * D + h * D + c);
+        const float4 x = ld4(static_cast<const T*>(a.P[b]) + (size_t)n * H * D + h * D + c);
         const float4 wl = *reinterpret_cast<const float4*>(a.al[b] + h * D + c);
         const float4 wr = *reinterpret_cast<const float4*>(a.ar[b] + h * D + c);
         sl = x.x * wl.x + x.y * wl.y + x.z * wl.z + x.w * wl.w;
@@ -78,7 +98,7 @@ struct AggArgs {
     int nt, B;
     const int* dynB;
     // instances
-    const float* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* bias[MAXI];
+    const void* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* bias[MAXI];
     const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
     float* A[MAXI];
     const float* x; int ld_x;
@@ -88,6 +108,7 @@ struct AggArgs {
     float slope;
 };
 
+template <typename T>
 __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
     __shared__ float sc[MAXH][MAXDEG];
     __shared__ int su[MAXH][MAXDEG];
@@ -128,10 +149,10 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (c < D) {
-                    const float* ps = a.Ps[i] + w * D + c;
+                    const T* ps = static_cast<const T*>(a.Ps[i]) + w * D + c;
                     for (int j = 0; j < deg; ++j) {
                         const float p = sc[w][j];
-                        const float4 f = *reinterpret_cast<const float4*>(ps + (size_t)su[w][j] * HD);
+                        const float4 f = ld4(ps + (size_t)su[w][j] * HD);
                         acc.x += p * f.x; acc.y += p * f.y; acc.z += p * f.z; acc.w += p * f.w;
                     }
                     const float4 bv = *reinterpret_cast<const float4*>(a.bias[i] + w * D + c);
@@ -220,7 +241,7 @@ __device__ __forceinline__ float4 masked_grad(const float* g, int ld_g, const un
 }
 
 struct DstArgs {
-    const float* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* A[MAXI];
+    const void* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* A[MAXI];
     const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
     float* DP[MAXI]; float* der[MAXI];
     const int* dyn_d[MAXI];
@@ -234,6 +255,7 @@ struct DstArgs {
 
 // per (instance, destination, head): d(pre-activation score) of every in-edge -> DP[e,h]; der[v,h] = their sum.
 // The gradient of every relation result into a destination is the same masked tensor g[v,c] * [arg[v,c] == h].
+template <typename T>
 __global__ void hg_bwd_dst_kernel(DstArgs a) {
     __shared__ float da[WPB][MAXDEG];
     __shared__ int su[WPB][MAXDEG];
@@ -255,7 +277,7 @@ __global__ void hg_bwd_dst_kernel(DstArgs a) {
     for (int j = 0; j < deg; ++j) {
         float s = 0.f;
         if (c < D) {
-            const float4 f = *reinterpret_cast<const float4*>(a.Ps[i] + (size_t)su[w][j] * HD + h * D + c);
+            const float4 f = ld4(static_cast<const T*>(a.Ps[i]) + (size_t)su[w][j] * HD + h * D + c);
             s = gm.x * f.x + gm.y * f.y + gm.z * f.z + gm.w * f.w;
         }
         s = wave_sum(s);
@@ -281,7 +303,7 @@ __global__ void hg_bwd_dst_kernel(DstArgs a) {
 
 struct SrcArgs {
     // projection blocks
-    float* dP[MAXB]; float* wL[MAXB]; float* wR[MAXB];
+    void* dP[MAXB]; float* wL[MAXB]; float* wR[MAXB];
     const float* al[MAXB]; const float* ar[MAXB];
     const int* dyn[MAXB];
     int ncap[MAXB], nsrc[MAXB], ndst[MAXB], src[MAXB][4], dst[MAXB][4];
@@ -298,6 +320,7 @@ struct SrcArgs {
 // per (projection block, node u, head): dP[u,h,:] = sum over the instances that read the block as SOURCE of
 //   sum_{e in out(u)} A[e,h] * dT[dst_e,h,:] + del[u,h] * a_l[h,:]   (del = sum of DP over out-edges)
 // + sum over the instances that use it as DESTINATION of der[u,h] * a_r[h,:];  wL / wR = the summed del / der.
+template <typename T>
 __global__ void hg_bwd_src_kernel(SrcArgs a) {
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
     const int lane = threadIdx.x & 63;
@@ -335,7 +358,7 @@ __global__ void hg_bwd_src_kernel(SrcArgs a) {
             o.z += wl * l4.z + wr * r4.z; o.w += wl * l4.w + wr * r4.w;
         }
     }
-    if (c < D) *reinterpret_cast<float4*>(a.dP[b] + (size_t)u * HD + h * D + c) = o;
+    if (c < D) st4(static_cast<T*>(a.dP[b]) + (size_t)u * HD + h * D + c, o);
     if (lane == 0) {
         a.wL[b][(size_t)u * H + h] = wl;
         a.wR[b][(size_t)u * H + h] = wr;
@@ -345,7 +368,7 @@ __global__ void hg_bwd_src_kernel(SrcArgs a) {
 // column sums: job j < 2*nb : sum_n w[n,h] * P[n,h,c] over a projection block (w = wL for even, wR for odd j)
 //              job 2*nb + t : sum_v g[v,c] * [arg[v,c] == h] over the rows of node type t
 struct ColArgs {
-    const float* P[MAXB]; const float* wL[MAXB]; const float* wR[MAXB];
+    const void* P[MAXB]; const float* wL[MAXB]; const float* wR[MAXB];
     const int* dyn_b[MAXB];
     int ncap_b[MAXB];
     const int* dyn_t[MAXT];
@@ -356,6 +379,7 @@ struct ColArgs {
     float* part;             // [njobs][NCHUNK][H*D]
 };
 
+template <typename T>
 __global__ void hg_colsum_part_kernel(ColArgs a) {
     __shared__ float red[4][64];
     const int H = a.H, D = a.D, HD = H * D;
@@ -369,7 +393,8 @@ __global__ void hg_colsum_part_kernel(ColArgs a) {
             const float* wgt = (job & 1) ? a.wR[b] : a.wL[b];
             const int n = dyn_count(a.dyn_b[b], a.ncap_b[b]);
             const int per = (n + NCHUNK - 1) / NCHUNK, r0 = chunk * per, r1 = min(n, r0 + per);
-            for (int r = r0 + rg; r < r1; r += 4) s += wgt[(size_t)r * H + h] * a.P[b][(size_t)r * HD + col];
+            const T* pb = static_cast<const T*>(a.P[b]);
+            for (int r = r0 + rg; r < r1; r += 4) s += wgt[(size_t)r * H + h] * ld1(pb + (size_t)r * HD + col);
         } else {
             const int t = job - 2 * a.nb;
             const int n = dyn_count(a.dyn_t[t], a.ncap_t[t]);
@@ -426,13 +451,14 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     if (bad_desc(d) || (ld_x & 3)) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int H = d->H, D = d->D, HD = H * D;
+    const size_t esz = d->p16 ? 2 : 4;
     if (d->n_blocks > 0) {
         DotsArgs a{};
         a.nb = d->n_blocks; a.H = H; a.D = D;
         int blocks = 0;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
-            a.P[b] = d->P[m] + (size_t)d->blk_row[b] * HD;
+            a.P[b] = (const char*)d->P[m] + (size_t)d->blk_row[b] * HD * esz;
             a.al[b] = d->attn_l[m]; a.ar[b] = d->attn_r[m];
             a.eL[b] = d->eL[b]; a.eR[b] = d->eR[b];
             a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t];
@@ -440,7 +466,10 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
             blocks += cdiv(d->ncap[t] * H, WPB);
         }
         a.start[d->n_blocks] = blocks;
-        if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), 0, st, a);
+        if (blocks > 0) {
+            if (d->p16) hipLaunchKernelGGL(hg_dots_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(hg_dots_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+        }
     }
     AggArgs g{};
     g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;
@@ -457,12 +486,15 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         const int sb = d->inst_sblk[i], db = d->inst_dblk[i], m = d->inst_mod[i], t = d->blk_type[db];
         if (g.ninst[t] >= 8) return SREC_BAD_ARG;
         g.inst[t][g.ninst[t]++] = i;
-        g.Ps[i] = d->P[m] + (size_t)d->blk_row[sb] * HD;
+        g.Ps[i] = (const char*)d->P[m] + (size_t)d->blk_row[sb] * HD * esz;
         g.eLs[i] = d->eL[sb]; g.eRd[i] = d->eR[db]; g.bias[i] = d->bias[m];
         g.in_ptr[i] = d->in_ptr[i]; g.in_idx[i] = d->in_idx[i]; g.esrc[i] = d->esrc[i];
         g.A[i] = d->A[i];
     }
-    if (rows > 0) hipLaunchKernelGGL(hg_agg_kernel, dim3(rows), dim3(512), 0, st, g);
+    if (rows > 0) {
+        if (d->p16) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL(hg_agg_kernel<float>, dim3(rows), dim3(512), 0, st, g);
+    }
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -473,6 +505,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
     if (bad_desc(d) || (ld_g & 3) || (ld_dx & 3) || ws == nullptr) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int H = d->H, D = d->D, HD = H * D;
+    const size_t esz = d->p16 ? 2 : 4;
     int ninst_t[MAXT] = {0, 0, 0, 0};
     for (int i = 0; i < d->n_inst; ++i) ninst_t[d->blk_type[d->inst_dblk[i]]]++;
     int rows = 0;
@@ -493,7 +526,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
         int blocks = 0;
         for (int i = 0; i < d->n_inst; ++i) {
             const int sb = d->inst_sblk[i], db = d->inst_dblk[i], m = d->inst_mod[i], t = d->blk_type[db];
-            a.Ps[i] = d->P[m] + (size_t)d->blk_row[sb] * HD;
+            a.Ps[i] = (const char*)d->P[m] + (size_t)d->blk_row[sb] * HD * esz;
             a.eLs[i] = d->eL[sb]; a.eRd[i] = d->eR[db]; a.A[i] = d->A[i];
             a.in_ptr[i] = d->in_ptr[i]; a.in_idx[i] = d->in_idx[i]; a.esrc[i] = d->esrc[i];
             a.DP[i] = d->DP[i]; a.der[i] = d->der[i];
@@ -502,7 +535,10 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
             blocks += cdiv(d->ncap[t] * H, WPB);
         }
         a.start[d->n_inst] = blocks;
-        if (blocks > 0) hipLaunchKernelGGL(hg_bwd_dst_kernel, dim3(blocks), dim3(256), 0, st, a);
+        if (blocks > 0) {
+            if (d->p16) hipLaunchKernelGGL(hg_bwd_dst_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(hg_bwd_dst_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+        }
     }
     if (d->n_blocks > 0) {
         SrcArgs a{};
@@ -510,7 +546,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
         int blocks = 0;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
-            a.dP[b] = d->dP[m] + (size_t)d->blk_row[b] * HD;
+            a.dP[b] = (char*)d->dP[m] + (size_t)d->blk_row[b] * HD * esz;
             a.wL[b] = d->wL[b]; a.wR[b] = d->wR[b]; a.al[b] = d->attn_l[m]; a.ar[b] = d->attn_r[m];
             a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t];
             a.nsrc[b] = a.ndst[b] = 0;
@@ -527,14 +563,17 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
             a.out_ptr[i] = d->out_ptr[i]; a.out_idx[i] = d->out_idx[i]; a.edst[i] = d->edst[i];
             a.row0_d[i] = d->row0[d->blk_type[db]];
         }
-        if (blocks > 0) hipLaunchKernelGGL(hg_bwd_src_kernel, dim3(blocks), dim3(256), 0, st, a);
+        if (blocks > 0) {
+            if (d->p16) hipLaunchKernelGGL(hg_bwd_src_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(hg_bwd_src_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+        }
     }
     {
         ColArgs a{};
         a.nb = d->n_blocks; a.nt = d->n_types; a.H = H; a.D = D; a.g = g; a.ld_g = ld_g; a.arg = arg; a.part = ws;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
-            a.P[b] = d->P[m] + (size_t)d->blk_row[b] * HD;
+            a.P[b] = (const char*)d->P[m] + (size_t)d->blk_row[b] * HD * esz;
             a.wL[b] = d->wL[b]; a.wR[b] = d->wR[b]; a.dyn_b[b] = d->dyn_n[t]; a.ncap_b[b] = d->ncap[t];
         }
         int r = 0;
@@ -544,7 +583,8 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
         }
         a.row0[d->n_types] = r;
         const int njobs = 2 * d->n_blocks + d->n_types;
-        hipLaunchKernelGGL(hg_colsum_part_kernel, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
+        if (d->p16) hipLaunchKernelGGL(hg_colsum_part_kernel<unsigned short>, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(hg_colsum_part_kernel<float>, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
         ColFinalArgs f{};
         f.HD = HD; f.part = ws;
         for (int m = 0; m < d->n_mods; ++m) {

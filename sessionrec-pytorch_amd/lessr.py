@@ -80,11 +80,11 @@ class AttnReadout(nn.Module):
         if self.batch_norm is not None:
             feat = ops.batch_norm(feat, self.batch_norm, dN)
         feat = self.feat_drop(feat)
-        U = ops.linear(feat, self.fc_u.weight, None, dN)
-        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB)
+        U = ops.linear(feat, self.fc_u.weight, None, dN, exact=True)
+        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB, exact=True)
         rst = ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg, dB)
         if self.fc_out is not None:
-            rst = ops.linear(rst, self.fc_out.weight, None, dB)
+            rst = ops.linear(rst, self.fc_out.weight, None, dB, exact=True)
         if self.activation is not None:
             rst = ops.prelu(rst, self.activation.weight, dB)
         return rst
@@ -129,7 +129,7 @@ class LESSR(_ScoringMixin, nn.Module):
         sr = torch.cat([sr_l, sr_g], dim=1)
         if self.batch_norm is not None:
             sr = ops.batch_norm(sr, self.batch_norm, dB)
-        return ops.linear(self.feat_drop(sr), self.fc_sr.weight, None, dB)
+        return ops.linear(self.feat_drop(sr), self.fc_sr.weight, None, dB, exact=True)
 
     def forward(self, mg, sg=None):
         return self._log_probs(self.session_repr(mg, sg))

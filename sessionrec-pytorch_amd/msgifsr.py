@@ -201,8 +201,8 @@ class AttnReadout(nn.Module):
         out = {}
         dT, dB = mg.dynp('NT'), mg.dynp('B')
         for i in orders:
-            U = ops.linear(allf, self.fc_u[i].weight, self.fc_u[i].bias, dT)
-            Vq = ops.linear(feat_vs[i], self.fc_v[i].weight, None, dB)
+            U = ops.linear(allf, self.fc_u[i].weight, self.fc_u[i].bias, dT, exact=True)
+            Vq = ops.linear(feat_vs[i], self.fc_v[i].weight, None, dB, exact=True)
             out[i] = ops.seg_attn(U, Vq, self.fc_e[i].weight, allf, mg.cat_seg, dB)
         return out
 
@@ -315,7 +315,7 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         sr_g = self.readout(mg, allf, feat_vs, live)
         srs = []
         for i in live:
-            s = ops.linear_cat([feat_vs[i], sr_g[i]], self.fc_sr[i].weight, None, dB)
+            s = ops.linear_cat([feat_vs[i], sr_g[i]], self.fc_sr[i].weight, None, dB, exact=True)
             srs.append(ops.normalize(s, 0, dB) if self.norm else s)
         if self.fusion and K > 1:
             return srs                                     # one session vector per order (IFR mixture)

@@ -121,7 +121,18 @@ class LinearCat(torch.autograd.Function):
     """y = sum_i x_i @ W[:, off_i:off_i+k_i]^T + b   == nn.Linear(cat(x_i, dim=1)) without the concat."""
 
     @staticmethod
-    def forward(ctx, weight, bias, dyn, *xs):
+    def forward(ctx, weight, bias, dyn, exact, *xs):
+        ctx.exact = exact
+        if exact and PRECISION['matmul'] != 'fp32':         # session-vector head: exact fp32 MFMA even in bf16 mode
+            prev, PRECISION['matmul'] = PRECISION['matmul'], 'fp32'
+            try:
+                return LinearCat._fwd(ctx, weight, bias, dyn, xs)
+            finally:
+                PRECISION['matmul'] = prev
+        return LinearCat._fwd(ctx, weight, bias, dyn, xs)
+
+    @staticmethod
+    def _fwd(ctx, weight, bias, dyn, xs):
         xs = [_rows(x) for x in xs]
         M = xs[0].shape[0]
         N = weight.shape[0]
@@ -141,10 +152,20 @@ class LinearCat(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if ctx.exact and PRECISION['matmul'] != 'fp32':
+            prev, PRECISION['matmul'] = PRECISION['matmul'], 'fp32'
+            try:
+                return LinearCat._bwd(ctx, gy)
+            finally:
+                PRECISION['matmul'] = prev
+        return LinearCat._bwd(ctx, gy)
+
+    @staticmethod
+    def _bwd(ctx, gy):
         w, *xs = ctx.saved_tensors
         dyn = ctx.dyn
         gy = _rows(gy)
-        need_x = ctx.needs_input_grad[3:]
+        need_x = ctx.needs_input_grad[4:]
         gw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
         gb = None
         gxs = []
@@ -163,15 +184,17 @@ class LinearCat(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[1]:
             gb = torch.empty(w.shape[0], device=w.device, dtype=torch.float32)
             col_sum(gy, gy.shape[0], w.shape[0], gb, dyn)
-        return (gw, gb, None) + tuple(gxs)
+        return (gw, gb, None, None) + tuple(gxs)
 
 
-def linear(x, weight, bias=None, dyn=None):
-    return LinearCat.apply(weight, bias, dyn, x)
+def linear(x, weight, bias=None, dyn=None, exact=False):
+    """exact=True: fp32 MFMA regardless of set_precision (the readout / session-vector head, whose output is scaled
+    by 12 before the soft-max in NISER / MSGIFSR)"""
+    return LinearCat.apply(weight, bias, dyn, exact, x)
 
 
-def linear_cat(xs, weight, bias=None, dyn=None):
-    return LinearCat.apply(weight, bias, dyn, *xs)
+def linear_cat(xs, weight, bias=None, dyn=None, exact=False):
+    return LinearCat.apply(weight, bias, dyn, exact, *xs)
 
 
 class TableGrad:
@@ -998,7 +1021,7 @@ class HgDesc(_ct.Structure):
     """host mirror of srec_hg_desc (include/srec_hg.h)"""
     _T, _M, _B, _I = 4, 8, 16, 16
     _fields_ = ([(n, _ct.c_int) for n in ('H', 'D', 'n_types', 'n_mods', 'n_blocks', 'n_inst', 'B')] +
-                [('slope', _ct.c_float), ('dynB', _ct.c_void_p),
+                [('slope', _ct.c_float), ('p16', _ct.c_int), ('dynB', _ct.c_void_p),
                  ('row0', _ct.c_int * 4), ('ncap', _ct.c_int * 4), ('dyn_n', _ct.c_void_p * 4), ('seg', _ct.c_void_p * 4)] +
                 [(n, _ct.c_void_p * 8) for n in ('P', 'dP', 'attn_l', 'attn_r', 'bias', 'd_attn_l', 'd_attn_r', 'd_bias')] +
                 [(n, _ct.c_int * 16) for n in ('blk_mod', 'blk_type', 'blk_row')] +
@@ -1010,15 +1033,16 @@ class HgDesc(_ct.Structure):
 class GemmGroup(_ct.Structure):
     """host mirror of srec_gemm_group (include/srec_hg.h)"""
     _fields_ = [('np', _ct.c_int), ('lda', _ct.c_int), ('ldb', _ct.c_int), ('ldc', _ct.c_int), ('beta', _ct.c_float),
+                ('a16', _ct.c_int), ('c16', _ct.c_int),
                 ('M', _ct.c_int * 8), ('N', _ct.c_int * 8), ('K', _ct.c_int * 8), ('nseg', _ct.c_int * 8),
                 ('A', (_ct.c_void_p * 4) * 8), ('B', (_ct.c_void_p * 4) * 8), ('C', _ct.c_void_p * 8),
                 ('dyn', _ct.c_void_p * 8)]
 
 
-def gemm_group(mode, probs, lda, ldb, ldc, beta=0.0):
+def gemm_group(mode, probs, lda, ldb, ldc, beta=0.0, a16=False, c16=False):
     """probs: [(M, N, K, [(A, B), ...] segments, C, dyn)] tensors -> one srec_gemm_group_bf16 launch"""
     g = GemmGroup()
-    g.np, g.lda, g.ldb, g.ldc, g.beta = len(probs), lda, ldb, ldc, beta
+    g.np, g.lda, g.ldb, g.ldc, g.beta, g.a16, g.c16 = len(probs), lda, ldb, ldc, beta, int(a16), int(c16)
     for p, (M, N, K, segs, C, dyn) in enumerate(probs):
         g.M[p], g.N[p], g.K[p], g.nseg[p], g.C[p], g.dyn[p] = M, N, K, len(segs), ptr(C), ptr(dyn)
         for si, (A, B) in enumerate(segs):
@@ -1057,6 +1081,7 @@ class HgPlan:
     def fill(self, desc, small, lay, P, dP, params, grads):
         d = desc
         d.H, d.D, d.slope, d.B = self.H, self.D, self.slope, self.B
+        d.p16 = int(P[0].dtype == torch.bfloat16) if len(P) else 0
         d.n_types, d.n_mods, d.n_blocks, d.n_inst = len(self.types), len(self.modules), len(self.blocks), len(self.insts)
         d.dynB = ptr(self.dynB)
         for t, (r0, nc, dyn, seg) in enumerate(self.types):
@@ -1097,11 +1122,13 @@ class HGATLayer(torch.autograd.Function):
         H = plan.H
         HD = H * D
         dev = x.device
-        P = [torch.empty(nr, HD, device=dev, dtype=torch.float32) for (r0, nr, dyn) in plan.modules]
-        grouped = PRECISION['matmul'] == 'bf16' and D % 4 == 0 and _ld(x) == D and len(plan.modules) <= 8
+        grouped = PRECISION['matmul'] == 'bf16' and D % 8 == 0 and _ld(x) == D and len(plan.modules) <= 8
+        # bf16 GEMM path: the projections (and their gradients) are STORED as bf16 too - every pass over them is HBM bound
+        P = [torch.empty(nr, HD, device=dev, dtype=torch.bfloat16 if grouped else torch.float32)
+             for (r0, nr, dyn) in plan.modules]
         if grouped:
             gemm_group(0, [(nr, HD, D, [(x[r0:r0 + nr], params[4 * m])], P[m], dyn)
-                           for m, (r0, nr, dyn) in enumerate(plan.modules)], D, D, HD)
+                           for m, (r0, nr, dyn) in enumerate(plan.modules)], D, D, HD, c16=True)
         else:
             for m, (r0, nr, dyn) in enumerate(plan.modules):
                 gemm_nt(x[r0:r0 + nr], _rows(params[4 * m]), P[m], None, dyn, 1 if dyn is not None else 0)
@@ -1152,9 +1179,9 @@ class HGATLayer(torch.autograd.Function):
                         if r0 <= t0 and t0 + nc <= r0 + nr and any(bm == m and bt == t for bm, bt in plan.blocks)]
                 if segs:
                     probs.append((nc, D, HD, segs, dx[t0:t0 + nc], dyn_t))
-            gemm_group(1, probs, HD, D, D, beta=1.0)
+            gemm_group(1, probs, HD, D, D, beta=1.0, a16=True)
             gemm_group(2, [(HD, D, nr, [(dP[m], x[r0:r0 + nr])], gWs[m], dyn)
-                           for m, (r0, nr, dyn) in enumerate(plan.modules)], HD, D, D)
+                           for m, (r0, nr, dyn) in enumerate(plan.modules)], HD, D, D, a16=True)
         for m, (r0, nr, dyn) in enumerate(plan.modules):
             gW = gWs[m]
             if not ctx.grouped:

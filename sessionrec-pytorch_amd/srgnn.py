@@ -118,8 +118,8 @@ class AttnReadout(nn.Module):
     def forward(self, mg, feat):
         dN, dB = mg.dynp('N'), mg.dynp('B')
         feat = self.feat_drop(feat)
-        U = ops.linear(feat, self.fc_u.weight, None, dN)
-        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB)
+        U = ops.linear(feat, self.fc_u.weight, None, dN, exact=True)
+        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB, exact=True)
         return ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg, dB)
 
 
@@ -173,7 +173,7 @@ class SRGNN(_ScoringMixin, nn.Module):
                 feat = layer(mg, feat)
         sr_g = self.readout(mg, feat)
         sr_l = ops.row_gather(feat, mg.last, dB)
-        return self._post(ops.linear_cat([sr_l, sr_g], self.fc_sr.weight, None, dB), dB)
+        return self._post(ops.linear_cat([sr_l, sr_g], self.fc_sr.weight, None, dB, exact=True), dB)
 
     def forward(self, mg, sg=None):
         return self._log_probs(self.session_repr(mg))
