@@ -253,52 +253,78 @@ struct DstArgs {
     const unsigned char* arg;
 };
 
-// per (instance, destination, head): d(pre-activation score) of every in-edge -> DP[e,h]; der[v,h] = their sum.
-// The gradient of every relation result into a destination is the same masked tensor g[v,c] * [arg[v,c] == h].
+// per (instance, destination), ALL heads in one wavefront: d(pre-activation score) of every in-edge -> DP[e,h];
+// der[v,h] = their sum.  The gradient of every relation result into a destination is the same masked tensor
+// g[v,c] * [arg[v,c] == h]: each column c belongs to exactly ONE head, so an edge needs only the D gathered elements
+// P[u, arg[v,c], c] (not H*D) - 8x less gather traffic than a wave per head.  Lane layout of the small per-edge
+// arrays: head = lane & 7, edge slot = lane >> 3.
 template <typename T>
 __global__ void hg_bwd_dst_kernel(DstArgs a) {
-    __shared__ float da[WPB][MAXDEG];
+    __shared__ float da[WPB][MAXDEG][MAXH];
     __shared__ int su[WPB][MAXDEG];
     const int i = find_range(a.start, a.ni, (int)blockIdx.x);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int gid = ((int)blockIdx.x - a.start[i]) * WPB + w;
+    const int v = ((int)blockIdx.x - a.start[i]) * WPB + w;
     const int H = a.H, D = a.D, HD = H * D;
-    const int v = gid / H, h = gid % H;
     if (v >= a.ncap_d[i]) return;
     const bool live = v < dyn_count(a.dyn_d[i], a.ncap_d[i]);
-    const int beg = live ? a.in_ptr[i][v] : 0;
-    const int deg = live ? min(a.in_ptr[i][v + 1] - beg, MAXDEG) : 0;
+    const int hl = lane & 7, jl = lane >> 3;
+    if (!live) {
+        if (lane < H) a.der[i][(size_t)v * H + lane] = 0.f;
+        return;
+    }
+    const int beg = a.in_ptr[i][v];
+    const int deg = min(a.in_ptr[i][v + 1] - beg, MAXDEG);
     const int* idx = a.in_idx[i] + beg;
     for (int j = lane; j < deg; j += 64) su[w][j] = a.esrc[i][idx[j]];
     __builtin_amdgcn_wave_barrier();
     const int c = lane * 4;
-    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live && c < D) gm = masked_grad(a.g, a.ld_g, a.arg, D, a.row0_d[i] + v, h, c);
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 a4 = make_uchar4(0, 0, 0, 0);
+    if (c < D) {
+        const size_t row = (size_t)(a.row0_d[i] + v);
+        g4 = *reinterpret_cast<const float4*>(a.g + row * a.ld_g + c);
+        a4 = *reinterpret_cast<const uchar4*>(a.arg + row * D + c);
+    }
+    const T* P = static_cast<const T*>(a.Ps[i]);
     for (int j = 0; j < deg; ++j) {
-        float s = 0.f;
+        float ph[MAXH];
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) ph[h] = 0.f;
         if (c < D) {
-            const float4 f = ld4(static_cast<const T*>(a.Ps[i]) + (size_t)su[w][j] * HD + h * D + c);
-            s = gm.x * f.x + gm.y * f.y + gm.z * f.z + gm.w * f.w;
+            const T* pr = P + (size_t)su[w][j] * HD + c;
+            const float v0 = g4.x * ld1(pr + a4.x * D), v1 = g4.y * ld1(pr + a4.y * D + 1);
+            const float v2 = g4.z * ld1(pr + a4.z * D + 2), v3 = g4.w * ld1(pr + a4.w * D + 3);
+#pragma unroll
+            for (int h = 0; h < MAXH; ++h)
+                ph[h] = (a4.x == h ? v0 : 0.f) + (a4.y == h ? v1 : 0.f) + (a4.z == h ? v2 : 0.f) + (a4.w == h ? v3 : 0.f);
         }
-        s = wave_sum(s);
-        if (lane == 0) da[w][j] = s;
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h) ph[h] = wave_sum(ph[h]);
+        if (lane < MAXH) {
+            float t = ph[0];
+#pragma unroll
+            for (int h = 1; h < MAXH; ++h) t = lane == h ? ph[h] : t;
+            da[w][j][lane] = t;
+        }
     }
     __builtin_amdgcn_wave_barrier();
+    if (hl >= H) return;
     float tsum = 0.f;
-    for (int j = lane; j < deg; j += 64) tsum += a.A[i][(size_t)idx[j] * H + h] * da[w][j];
-    tsum = wave_sum(tsum);
-    const float erv = live ? a.eRd[i][(size_t)v * H + h] : 0.f;
+    for (int j = jl; j < deg; j += 8) tsum += a.A[i][(size_t)idx[j] * H + hl] * da[w][j][hl];
+    tsum += __shfl_xor(tsum, 8, 64); tsum += __shfl_xor(tsum, 16, 64); tsum += __shfl_xor(tsum, 32, 64);
+    const float erv = a.eRd[i][(size_t)v * H + hl];
     float dsum = 0.f;
-    for (int j = lane; j < deg; j += 64) {
+    for (int j = jl; j < deg; j += 8) {
         const int e = idx[j];
-        const float p = a.A[i][(size_t)e * H + h];
-        const float pre = a.eLs[i][(size_t)su[w][j] * H + h] + erv;
-        const float dp = p * (da[w][j] - tsum) * (pre > 0.f ? 1.f : a.slope);
-        a.DP[i][(size_t)e * H + h] = dp;
+        const float p = a.A[i][(size_t)e * H + hl];
+        const float pre = a.eLs[i][(size_t)su[w][j] * H + hl] + erv;
+        const float dp = p * (da[w][j][hl] - tsum) * (pre > 0.f ? 1.f : a.slope);
+        a.DP[i][(size_t)e * H + hl] = dp;
         dsum += dp;
     }
-    dsum = wave_sum(dsum);
-    if (lane == 0) a.der[i][(size_t)v * H + h] = dsum;
+    dsum += __shfl_xor(dsum, 8, 64); dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
+    if (jl == 0) a.der[i][(size_t)v * H + hl] = dsum;
 }
 
 struct SrcArgs {
@@ -317,51 +343,73 @@ struct SrcArgs {
     const unsigned char* arg;
 };
 
-// per (projection block, node u, head): dP[u,h,:] = sum over the instances that read the block as SOURCE of
-//   sum_{e in out(u)} A[e,h] * dT[dst_e,h,:] + del[u,h] * a_l[h,:]   (del = sum of DP over out-edges)
-// + sum over the instances that use it as DESTINATION of der[u,h] * a_r[h,:];  wL / wR = the summed del / der.
+// per (projection block, node u), ALL heads in one wavefront:
+//   dP[u,h,:] = sum over the instances that read the block as SOURCE of
+//                 sum_{e in out(u)} A[e,h] * dT[dst_e,h,:] + del[u,h] * a_l[h,:]   (del = sum of DP over out-edges)
+//             + sum over the instances that use it as DESTINATION of der[u,h] * a_r[h,:];  wL / wR = summed del / der.
+// dT[dst,h,c] = g[dst,c] * [arg[dst,c] == h]: the row g[dst,:] is read once per edge, not once per head.
 template <typename T>
 __global__ void hg_bwd_src_kernel(SrcArgs a) {
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
     const int lane = threadIdx.x & 63;
-    const int gid = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6);
+    const int u = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6);
     const int H = a.H, D = a.D, HD = H * D;
-    const int u = gid / H, h = gid % H;
     if (u >= a.ncap[b]) return;
     const bool live = u < dyn_count(a.dyn[b], a.ncap[b]);
-    const int c = lane * 4;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    float wl = 0.f, wr = 0.f;
+    const int c = lane * 4, hl = lane & 7, jl = lane >> 3;
+    float4 o[MAXH];
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) o[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wl = 0.f, wr = 0.f;                          // lane holds head hl = lane & 7
     if (live) {
         for (int q = 0; q < a.nsrc[b]; ++q) {
             const int i = a.src[b][q];
             const int beg = a.out_ptr[i][u], deg = a.out_ptr[i][u + 1] - beg;
             const int* idx = a.out_idx[i] + beg;
             float dl = 0.f;
-            for (int j = lane; j < deg; j += 64) dl += a.DP[i][(size_t)idx[j] * H + h];
-            dl = wave_sum(dl);
+            if (hl < H)
+                for (int j = jl; j < deg; j += 8) dl += a.DP[i][(size_t)idx[j] * H + hl];
+            dl += __shfl_xor(dl, 8, 64); dl += __shfl_xor(dl, 16, 64); dl += __shfl_xor(dl, 32, 64);
             wl += dl;
             if (c < D) {
                 for (int j = 0; j < deg; ++j) {
                     const int e = idx[j];
-                    const float p = a.A[i][(size_t)e * H + h];
-                    const float4 gm = masked_grad(a.g, a.ld_g, a.arg, D, a.row0_d[i] + a.edst[i][e], h, c);
-                    o.x += p * gm.x; o.y += p * gm.y; o.z += p * gm.z; o.w += p * gm.w;
+                    const size_t row = (size_t)(a.row0_d[i] + a.edst[i][e]);
+                    const float4 gv = *reinterpret_cast<const float4*>(a.g + row * a.ld_g + c);
+                    const uchar4 bi = *reinterpret_cast<const uchar4*>(a.arg + row * D + c);
+                    const float* ae = a.A[i] + (size_t)e * H;
+#pragma unroll
+                    for (int h = 0; h < MAXH; ++h) {
+                        if (h < H) {
+                            const float p = ae[h];
+                            o[h].x += bi.x == h ? p * gv.x : 0.f; o[h].y += bi.y == h ? p * gv.y : 0.f;
+                            o[h].z += bi.z == h ? p * gv.z : 0.f; o[h].w += bi.w == h ? p * gv.w : 0.f;
+                        }
+                    }
                 }
             }
         }
-        for (int q = 0; q < a.ndst[b]; ++q) wr += a.der[a.dst[b][q]][(size_t)u * H + h];
-        if (c < D) {
-            const float4 l4 = *reinterpret_cast<const float4*>(a.al[b] + h * D + c);
-            const float4 r4 = *reinterpret_cast<const float4*>(a.ar[b] + h * D + c);
-            o.x += wl * l4.x + wr * r4.x; o.y += wl * l4.y + wr * r4.y;
-            o.z += wl * l4.z + wr * r4.z; o.w += wl * l4.w + wr * r4.w;
+        if (hl < H)
+            for (int q = 0; q < a.ndst[b]; ++q) wr += a.der[a.dst[b][q]][(size_t)u * H + hl];
+    }
+    T* dp = static_cast<T*>(a.dP[b]) + (size_t)u * HD + c;
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h) {
+        if (h < H) {
+            const float wlh = __shfl(wl, h, 64), wrh = __shfl(wr, h, 64);
+            if (c < D) {
+                const float4 l4 = *reinterpret_cast<const float4*>(a.al[b] + h * D + c);
+                const float4 r4 = *reinterpret_cast<const float4*>(a.ar[b] + h * D + c);
+                float4 v = o[h];
+                v.x += wlh * l4.x + wrh * r4.x; v.y += wlh * l4.y + wrh * r4.y;
+                v.z += wlh * l4.z + wrh * r4.z; v.w += wlh * l4.w + wrh * r4.w;
+                st4(dp + h * D, v);
+            }
         }
     }
-    if (c < D) st4(static_cast<T*>(a.dP[b]) + (size_t)u * HD + h * D + c, o);
-    if (lane == 0) {
-        a.wL[b][(size_t)u * H + h] = wl;
-        a.wR[b][(size_t)u * H + h] = wr;
+    if (lane < H) {
+        a.wL[b][(size_t)u * H + lane] = wl;
+        a.wR[b][(size_t)u * H + lane] = wr;
     }
 }
 
@@ -532,7 +580,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
             a.DP[i] = d->DP[i]; a.der[i] = d->der[i];
             a.dyn_d[i] = d->dyn_n[t]; a.ncap_d[i] = d->ncap[t]; a.row0_d[i] = d->row0[t];
             a.start[i] = blocks;
-            blocks += cdiv(d->ncap[t] * H, WPB);
+            blocks += cdiv(d->ncap[t], WPB);
         }
         a.start[d->n_inst] = blocks;
         if (blocks > 0) {
@@ -551,7 +599,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
             a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t];
             a.nsrc[b] = a.ndst[b] = 0;
             a.start[b] = blocks;
-            blocks += cdiv(d->ncap[t] * H, WPB);
+            blocks += cdiv(d->ncap[t], WPB);
         }
         a.start[d->n_blocks] = blocks;
         for (int i = 0; i < d->n_inst; ++i) {

@@ -85,7 +85,8 @@ def roundoff_close(mine, ref32, truth64, what):
     ref32 = torch.as_tensor(ref32).detach().double().cpu()
     t = truth64.double().cpu()
     e_mine, e_ref = (mine - t).abs(), (ref32 - t).abs()
-    assert e_mine.mean().item() <= 3.0 * e_ref.mean().item() + 1e-9, \
+    # (+2e-8 absolute: about one ulp of a 0.1-sized parameter - small tensors have noisy means)
+    assert e_mine.mean().item() <= 3.0 * e_ref.mean().item() + 2e-8, \
         '%s: mean |err| vs fp64 %.3e (reference fp32 run: %.3e)' % (what, e_mine.mean().item(), e_ref.mean().item())
     assert e_mine.max().item() <= max(6.0 * e_ref.max().item(), 4e-6), \
         '%s: max |err| vs fp64 %.3e (reference fp32 run: %.3e)' % (what, e_mine.max().item(), e_ref.max().item())
