@@ -225,8 +225,8 @@ int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, i
  *        d_attn_l / d_attn_r / d_bias of every module.  ws: srec_hg_ws_floats() floats of scratch. */
 int srec_hg_ws_floats(const void* desc, long* n_floats);
 int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg, void* stream);
-int srec_hg_bwd(const void* desc, const float* g, int ld_g, const unsigned char* arg, float* dx, int ld_dx, float* ws,
-                void* stream);
+int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
+                int ld_dx, float* ws, void* stream);
 
 /* grouped, K-segmented bf16-operand GEMM (gemm_group_bf16.hip): up to 8 problems C_p [M,N] (+)= sum_s opA(A_ps) opB(B_ps)
  * in one launch.  desc: host srec_gemm_group (srec_hg.h).  mode 0: A [M,K], B [N,K] (nn.Linear forward); 1: A [M,K],

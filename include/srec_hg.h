@@ -34,6 +34,9 @@ typedef struct {
     /* modules */
     const void* P[SREC_HG_MAXM];
     void* dP[SREC_HG_MAXM];
+    const float* W[SREC_HG_MAXM];      /* fc.weight [H*D, D] fp32 */
+    float* V[SREC_HG_MAXM];            /* scratch [2][D][H]: attention vectors folded into W (forward) */
+    float* Z[SREC_HG_MAXM];            /* scratch [2][D][H]: x^T wL / x^T wR (backward) */
     const float* attn_l[SREC_HG_MAXM];
     const float* attn_r[SREC_HG_MAXM];
     const float* bias[SREC_HG_MAXM];

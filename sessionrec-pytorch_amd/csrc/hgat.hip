@@ -55,39 +55,61 @@ __device__ __forceinline__ int find_range(const int (&start)[N], int n, int x) {
 }
 
 // ------------------------------------------------------------------------------------------------ logits
-struct DotsArgs {
-    const void* P[MAXB]; const float* al[MAXB]; const float* ar[MAXB];
-    float* eL[MAXB]; float* eR[MAXB];
-    const int* dyn[MAXB];
-    int ncap[MAXB];
-    int start[MAXB + 1];     // first thread block of each projection block
-    int nb, H, D;
+// el[n,h] = <P[n,h,:], a_l[h,:]> with P = x W^T  ==  x[n,:] . V_l[:,h],  V_l[c,h] = sum_j W[hD+j, c] a_l[hD+j].
+// Folding the attention vectors into the fc weights first (2 MB of W per module, once) turns the logits into a
+// [N, D] x [D, 2H] product over x instead of a pass over the 8x larger projections.  V[m] layout: [2][D][H].
+struct FoldArgs {
+    const float* W[MAXM]; const float* al[MAXM]; const float* ar[MAXM];
+    float* V[MAXM];
+    int H, D;
 };
 
-// eL[n,h] = <P[n,h,:], a_l[h,:]>, eR[n,h] = <P[n,h,:], a_r[h,:]> for every projection block
-template <typename T>
+__global__ void hg_fold_kernel(FoldArgs a) {
+    const int m = blockIdx.x / a.H, h = blockIdx.x % a.H, c = threadIdx.x;
+    const int H = a.H, D = a.D;
+    if (c >= D) return;
+    const float* W = a.W[m] + (size_t)h * D * D + c;
+    const float* al = a.al[m] + h * D;
+    const float* ar = a.ar[m] + h * D;
+    float sl = 0.f, sr = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < D; ++j) {
+        const float w = W[(size_t)j * D];
+        sl += w * al[j];
+        sr += w * ar[j];
+    }
+    a.V[m][(size_t)c * H + h] = sl;
+    a.V[m][(size_t)(D + c) * H + h] = sr;
+}
+
+struct DotsArgs {
+    const float* V[MAXB];
+    float* eL[MAXB]; float* eR[MAXB];
+    const int* dyn[MAXB];
+    int ncap[MAXB], row0[MAXB];
+    int start[MAXB + 1];     // first thread block of each projection block
+    int nb, H, D;
+    const float* x; int ld_x;
+};
+
+// one wavefront per (projection block, node): lane = (output = lane & 15 -> (l/r, head), quarter of the columns = lane >> 4)
 __global__ void hg_dots_kernel(DotsArgs a) {
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
-    const int gid = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int H = a.H, D = a.D;
-    const int n = gid / H, h = gid % H;
     if (n >= a.ncap[b]) return;
     const bool live = n < dyn_count(a.dyn[b], a.ncap[b]);
-    float sl = 0.f, sr = 0.f;
-    const int c = lane * 4;
-    if (live && c < D) {
-        const float4 x = ld4(static_cast<const T*>(a.P[b]) + (size_t)n * H * D + h * D + c);
-        const float4 wl = *reinterpret_cast<const float4*>(a.al[b] + h * D + c);
-        const float4 wr = *reinterpret_cast<const float4*>(a.ar[b] + h * D + c);
-        sl = x.x * wl.x + x.y * wl.y + x.z * wl.z + x.w * wl.w;
-        sr = x.x * wr.x + x.y * wr.y + x.z * wr.z + x.w * wr.w;
+    const int o = lane & 15, part = lane >> 4, lr = o >> 3, h = o & 7;
+    float s = 0.f;
+    if (live && h < H) {
+        const float* xr = a.x + (size_t)(a.row0[b] + n) * a.ld_x;
+        const float* v = a.V[b] + (size_t)lr * D * H + h;
+        const int q = D >> 2;
+        for (int c = part * q; c < (part + 1) * q; ++c) s += xr[c] * v[(size_t)c * H];
     }
-    sl = wave_sum(sl);
-    sr = wave_sum(sr);
-    if (lane == 0) {
-        a.eL[b][(size_t)n * H + h] = sl;
-        a.eR[b][(size_t)n * H + h] = sr;
-    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16 && h < H) (lr ? a.eR[b] : a.eL[b])[(size_t)n * H + h] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -413,69 +435,122 @@ __global__ void hg_bwd_src_kernel(SrcArgs a) {
     }
 }
 
-// column sums: job j < 2*nb : sum_n w[n,h] * P[n,h,c] over a projection block (w = wL for even, wR for odd j)
-//              job 2*nb + t : sum_v g[v,c] * [arg[v,c] == h] over the rows of node type t
+// two-stage ordered reductions over the nodes:
+//   job t < nt      : bias column sums  CS_t[h,c] = sum_v g[v,c] * [arg[v,c] == h]   over the rows of node type t
+//   job nt + m      : Z[m][lr][c][h] = sum over the module's blocks of sum_u x[u,c] * w_lr[u,h]   (w = wL / wR)
+// d attn_l[hD+j] = sum_u wL[u,h] P[u,h,j] = sum_c W[hD+j,c] Z[0][c][h]  (P = x W^T): the weighted column sums over
+// the [N, H*D] projections become a reduction over x (8x smaller) plus a pass over W (hg_dattn_kernel).
 struct ColArgs {
-    const void* P[MAXB]; const float* wL[MAXB]; const float* wR[MAXB];
+    const float* wL[MAXB]; const float* wR[MAXB];
     const int* dyn_b[MAXB];
-    int ncap_b[MAXB];
+    int ncap_b[MAXB], row0_b[MAXB];
+    int mod_nb[MAXM], mod_blk[MAXM][4];
     const int* dyn_t[MAXT];
     int row0[MAXT + 1], ncap_t[MAXT];
-    int nb, nt, H, D;
+    int nt, nm, H, D;
     const float* g; int ld_g;
     const unsigned char* arg;
-    float* part;             // [njobs][NCHUNK][H*D]
+    const float* x; int ld_x;
+    float* part;             // [nt + nm][NCHUNK][2 * H*D]
 };
 
-template <typename T>
 __global__ void hg_colsum_part_kernel(ColArgs a) {
-    __shared__ float red[4][64];
+    __shared__ float red[2][4][64];
     const int H = a.H, D = a.D, HD = H * D;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     const int job = blockIdx.z, chunk = blockIdx.y;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f;
     if (col < HD) {
         const int h = col / D, c = col % D;
-        if (job < 2 * a.nb) {
-            const int b = job >> 1;
-            const float* wgt = (job & 1) ? a.wR[b] : a.wL[b];
-            const int n = dyn_count(a.dyn_b[b], a.ncap_b[b]);
-            const int per = (n + NCHUNK - 1) / NCHUNK, r0 = chunk * per, r1 = min(n, r0 + per);
-            const T* pb = static_cast<const T*>(a.P[b]);
-            for (int r = r0 + rg; r < r1; r += 4) s += wgt[(size_t)r * H + h] * ld1(pb + (size_t)r * HD + col);
-        } else {
-            const int t = job - 2 * a.nb;
+        if (job < a.nt) {
+            const int t = job;
             const int n = dyn_count(a.dyn_t[t], a.ncap_t[t]);
             const int per = (n + NCHUNK - 1) / NCHUNK, r0 = chunk * per, r1 = min(n, r0 + per);
             for (int r = r0 + rg; r < r1; r += 4) {
                 const size_t row = (size_t)(a.row0[t] + r);
-                if (a.arg[row * D + c] == h) s += a.g[row * a.ld_g + c];
+                if (a.arg[row * D + c] == h) s0 += a.g[row * a.ld_g + c];
+            }
+        } else {
+            const int m = job - a.nt;
+            for (int q = 0; q < a.mod_nb[m]; ++q) {
+                const int b = a.mod_blk[m][q];
+                const int n = dyn_count(a.dyn_b[b], a.ncap_b[b]);
+                const int per = (n + NCHUNK - 1) / NCHUNK, r0 = chunk * per, r1 = min(n, r0 + per);
+                for (int r = r0 + rg; r < r1; r += 4) {
+                    const float xv = a.x[(size_t)(a.row0_b[b] + r) * a.ld_x + c];
+                    s0 += xv * a.wL[b][(size_t)r * H + h];
+                    s1 += xv * a.wR[b][(size_t)r * H + h];
+                }
             }
         }
     }
-    red[rg][threadIdx.x & 63] = s;
+    red[0][rg][threadIdx.x & 63] = s0;
+    red[1][rg][threadIdx.x & 63] = s1;
     __syncthreads();
-    if (rg == 0 && col < HD)
-        a.part[((size_t)job * NCHUNK + chunk) * HD + col] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (rg == 0 && col < HD) {
+        const int l = threadIdx.x;
+        float* p = a.part + ((size_t)job * NCHUNK + chunk) * 2 * HD;
+        p[col] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        p[HD + col] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    }
 }
 
+// out o < nm: d_bias[m][h*D + c] = sum over the module's instances of CS_{dst type};  o >= nm: Z[m] ([2][D][H])
 struct ColFinalArgs {
-    float* out[3 * MAXM];
-    int njob[3 * MAXM], jobs[3 * MAXM][8];
-    int HD;
+    float* out[2 * MAXM];
+    int njob[2 * MAXM], jobs[2 * MAXM][8];
+    int nm, H, D;
     const float* part;
 };
 
 __global__ void hg_colsum_final_kernel(ColFinalArgs a) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
-    if (col >= a.HD || a.out[o] == nullptr) return;
-    float s = 0.f;
-    for (int q = 0; q < a.njob[o]; ++q) {
-        const float* p = a.part + (size_t)a.jobs[o][q] * NCHUNK * a.HD + col;
-        for (int k = 0; k < NCHUNK; ++k) s += p[(size_t)k * a.HD];
+    const int HD = a.H * a.D, o = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // < 2*HD
+    if (a.out[o] == nullptr) return;
+    if (o < a.nm) {                                              // bias: first half of the slabs only
+        if (idx >= HD) return;
+        float s = 0.f;
+        for (int q = 0; q < a.njob[o]; ++q) {
+            const float* p = a.part + (size_t)a.jobs[o][q] * NCHUNK * 2 * HD + idx;
+            for (int k = 0; k < NCHUNK; ++k) s += p[(size_t)k * 2 * HD];
+        }
+        a.out[o][idx] = s;
+    } else {
+        if (idx >= 2 * HD) return;
+        const float* p = a.part + (size_t)a.jobs[o][0] * NCHUNK * 2 * HD + idx;
+        float s = 0.f;
+        for (int k = 0; k < NCHUNK; ++k) s += p[(size_t)k * 2 * HD];
+        const int lr = idx / HD, col = idx % HD, h = col / a.D, c = col % a.D;    // slab order (lr, h, c) -> Z [lr][c][h]
+        a.out[o][((size_t)lr * a.D + c) * a.H + h] = s;
     }
-    a.out[o][col] = s;
+}
+
+struct DattnArgs {
+    const float* W[MAXM]; const float* Z[MAXM];
+    float* dal[MAXM]; float* dar[MAXM];
+    int H, D;
+};
+
+// one wavefront per fc row r = h*D + j of a module: d attn_l[r] = <W[r,:], Z[0][:,h]>, d attn_r[r] = <W[r,:], Z[1][:,h]>
+__global__ void hg_dattn_kernel(DattnArgs a) {
+    const int H = a.H, D = a.D, HD = H * D;
+    const int gid = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int m = gid / HD, r = gid % HD, h = r / D;
+    const float* w = a.W[m] + (size_t)r * D;
+    const float* z = a.Z[m];
+    float sl = 0.f, sr = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + c);
+        const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sl += wa[e] * z[(size_t)(c + e) * H + h];
+            sr += wa[e] * z[(size_t)(D + c + e) * H + h];
+        }
+    }
+    sl = wave_sum(sl);
+    sr = wave_sum(sr);
+    if (lane == 0) { a.dal[m][r] = sl; a.dar[m][r] = sr; }
 }
 
 bool bad_desc(const srec_hg_desc* d) {
@@ -489,7 +564,7 @@ bool bad_desc(const srec_hg_desc* d) {
 extern "C" int srec_hg_ws_floats(const void* desc_, long* n_floats) {
     const srec_hg_desc* d = (const srec_hg_desc*)desc_;
     if (bad_desc(d) || n_floats == nullptr) return SREC_BAD_ARG;
-    *n_floats = (long)(2 * d->n_blocks + d->n_types) * NCHUNK * d->H * d->D;
+    *n_floats = (long)(d->n_types + d->n_mods) * NCHUNK * 2 * d->H * d->D;
     return 0;
 }
 
@@ -500,24 +575,26 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     hipStream_t st = (hipStream_t)stream;
     const int H = d->H, D = d->D, HD = H * D;
     const size_t esz = d->p16 ? 2 : 4;
+    if (d->n_mods > 0) {
+        FoldArgs f{};
+        f.H = H; f.D = D;
+        for (int m = 0; m < d->n_mods; ++m) { f.W[m] = d->W[m]; f.al[m] = d->attn_l[m]; f.ar[m] = d->attn_r[m]; f.V[m] = d->V[m]; }
+        hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H), dim3(256), 0, st, f);
+    }
     if (d->n_blocks > 0) {
         DotsArgs a{};
-        a.nb = d->n_blocks; a.H = H; a.D = D;
+        a.nb = d->n_blocks; a.H = H; a.D = D; a.x = x; a.ld_x = ld_x;
         int blocks = 0;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
-            a.P[b] = (const char*)d->P[m] + (size_t)d->blk_row[b] * HD * esz;
-            a.al[b] = d->attn_l[m]; a.ar[b] = d->attn_r[m];
+            a.V[b] = d->V[m];
             a.eL[b] = d->eL[b]; a.eR[b] = d->eR[b];
-            a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t];
+            a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t]; a.row0[b] = d->row0[t];
             a.start[b] = blocks;
-            blocks += cdiv(d->ncap[t] * H, WPB);
+            blocks += cdiv(d->ncap[t], WPB);
         }
         a.start[d->n_blocks] = blocks;
-        if (blocks > 0) {
-            if (d->p16) hipLaunchKernelGGL(hg_dots_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(hg_dots_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
-        }
+        if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), 0, st, a);
     }
     AggArgs g{};
     g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;
@@ -547,10 +624,10 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     return 0;
 }
 
-extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const unsigned char* arg, float* dx, int ld_dx,
-                           float* ws, void* stream) {
+extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg,
+                           float* dx, int ld_dx, float* ws, void* stream) {
     const srec_hg_desc* d = (const srec_hg_desc*)desc_;
-    if (bad_desc(d) || (ld_g & 3) || (ld_dx & 3) || ws == nullptr) return SREC_BAD_ARG;
+    if (bad_desc(d) || (ld_g & 3) || (ld_dx & 3) || (ld_x & 3) || ws == nullptr) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int H = d->H, D = d->D, HD = H * D;
     const size_t esz = d->p16 ? 2 : 4;
@@ -618,11 +695,14 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
     }
     {
         ColArgs a{};
-        a.nb = d->n_blocks; a.nt = d->n_types; a.H = H; a.D = D; a.g = g; a.ld_g = ld_g; a.arg = arg; a.part = ws;
+        a.nt = d->n_types; a.nm = d->n_mods; a.H = H; a.D = D; a.g = g; a.ld_g = ld_g; a.arg = arg; a.part = ws;
+        a.x = x; a.ld_x = ld_x;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
-            a.P[b] = (const char*)d->P[m] + (size_t)d->blk_row[b] * HD * esz;
             a.wL[b] = d->wL[b]; a.wR[b] = d->wR[b]; a.dyn_b[b] = d->dyn_n[t]; a.ncap_b[b] = d->ncap[t];
+            a.row0_b[b] = d->row0[t];
+            if (a.mod_nb[m] >= 4) return SREC_BAD_ARG;
+            a.mod_blk[m][a.mod_nb[m]++] = b;
         }
         int r = 0;
         for (int t = 0; t < d->n_types; ++t) {
@@ -630,27 +710,28 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* g, int ld_g, const un
             r += d->ncap[t];
         }
         a.row0[d->n_types] = r;
-        const int njobs = 2 * d->n_blocks + d->n_types;
-        if (d->p16) hipLaunchKernelGGL(hg_colsum_part_kernel<unsigned short>, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(hg_colsum_part_kernel<float>, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
+        const int njobs = d->n_types + d->n_mods;
+        hipLaunchKernelGGL(hg_colsum_part_kernel, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
         ColFinalArgs f{};
-        f.HD = HD; f.part = ws;
+        f.nm = d->n_mods; f.H = H; f.D = D; f.part = ws;
         for (int m = 0; m < d->n_mods; ++m) {
-            f.out[3 * m + 0] = d->d_attn_l[m]; f.out[3 * m + 1] = d->d_attn_r[m]; f.out[3 * m + 2] = d->d_bias[m];
-        }
-        for (int b = 0; b < d->n_blocks; ++b) {
-            const int m = d->blk_mod[b];
-            if (f.njob[3 * m] >= 8) return SREC_BAD_ARG;
-            f.jobs[3 * m + 0][f.njob[3 * m + 0]++] = 2 * b;
-            f.jobs[3 * m + 1][f.njob[3 * m + 1]++] = 2 * b + 1;
+            f.out[m] = d->d_bias[m];
+            f.out[d->n_mods + m] = d->Z[m];
+            f.njob[d->n_mods + m] = 1;
+            f.jobs[d->n_mods + m][0] = d->n_types + m;
         }
         for (int i = 0; i < d->n_inst; ++i) {
             const int m = d->inst_mod[i], t = d->blk_type[d->inst_dblk[i]];
-            if (f.njob[3 * m + 2] >= 8) return SREC_BAD_ARG;
-            f.jobs[3 * m + 2][f.njob[3 * m + 2]++] = 2 * d->n_blocks + t;
+            if (f.njob[m] >= 8) return SREC_BAD_ARG;
+            f.jobs[m][f.njob[m]++] = t;
         }
-        if (d->n_mods > 0)
-            hipLaunchKernelGGL(hg_colsum_final_kernel, dim3(cdiv(HD, 256), 3 * d->n_mods), dim3(256), 0, st, f);
+        if (d->n_mods > 0) {
+            hipLaunchKernelGGL(hg_colsum_final_kernel, dim3(cdiv(2 * HD, 256), 2 * d->n_mods), dim3(256), 0, st, f);
+            DattnArgs q{};
+            q.H = H; q.D = D;
+            for (int m = 0; m < d->n_mods; ++m) { q.W[m] = d->W[m]; q.Z[m] = d->Z[m]; q.dal[m] = d->d_attn_l[m]; q.dar[m] = d->d_attn_r[m]; }
+            hipLaunchKernelGGL(hg_dattn_kernel, dim3(d->n_mods * HD / WPB), dim3(256), 0, st, q);
+        }
     }
     SREC_LAUNCH_CHECK();
     return 0;

@@ -1023,7 +1023,7 @@ class HgDesc(_ct.Structure):
     _fields_ = ([(n, _ct.c_int) for n in ('H', 'D', 'n_types', 'n_mods', 'n_blocks', 'n_inst', 'B')] +
                 [('slope', _ct.c_float), ('p16', _ct.c_int), ('dynB', _ct.c_void_p),
                  ('row0', _ct.c_int * 4), ('ncap', _ct.c_int * 4), ('dyn_n', _ct.c_void_p * 4), ('seg', _ct.c_void_p * 4)] +
-                [(n, _ct.c_void_p * 8) for n in ('P', 'dP', 'attn_l', 'attn_r', 'bias', 'd_attn_l', 'd_attn_r', 'd_bias')] +
+                [(n, _ct.c_void_p * 8) for n in ('P', 'dP', 'W', 'V', 'Z', 'attn_l', 'attn_r', 'bias', 'd_attn_l', 'd_attn_r', 'd_bias')] +
                 [(n, _ct.c_int * 16) for n in ('blk_mod', 'blk_type', 'blk_row')] +
                 [(n, _ct.c_void_p * 16) for n in ('eL', 'eR', 'wL', 'wR')] +
                 [(n, _ct.c_int * 16) for n in ('inst_mod', 'inst_sblk', 'inst_dblk')] +
@@ -1070,6 +1070,10 @@ class HgPlan:
             for nm in ('eL', 'eR', 'wL', 'wR'):
                 lay[(nm, b)] = off
                 off += n
+        for m in range(len(self.modules)):
+            for nm in ('V', 'Z'):
+                lay[(nm, m)] = off
+                off += 2 * self.D * H
         for i, (m, sb, db, gr) in enumerate(self.insts):
             E = max(gr[4].numel(), 1) * H
             nd = self.types[self.blocks[db][1]][1] * H
@@ -1090,6 +1094,8 @@ class HgPlan:
         for m in range(len(self.modules)):
             W, al, ar, bias = params[4 * m:4 * m + 4]
             d.P[m] = ptr(P[m])
+            d.W[m] = ptr(W)
+            d.V[m], d.Z[m] = base + 4 * lay[('V', m)], base + 4 * lay[('Z', m)]
             d.attn_l[m], d.attn_r[m], d.bias[m] = ptr(al), ptr(ar), ptr(bias)
             if dP is not None:
                 d.dP[m] = ptr(dP[m])
@@ -1168,7 +1174,7 @@ class HGATLayer(torch.autograd.Function):
         ws = _HG_WS.get(key)
         if ws is None:
             ws = _HG_WS[key] = torch.empty(max(n.value, 1), device=dev, dtype=torch.float32)
-        lib.srec_hg_bwd(_ct.addressof(desc), ptr(g), _ld(g), ptr(arg), ptr(dx), D, ptr(ws), stream())
+        lib.srec_hg_bwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(g), _ld(g), ptr(arg), ptr(dx), D, ptr(ws), stream())
         outs = []
         gWs = [torch.empty_like(params[4 * m]) for m in range(nm)]
         if ctx.grouped:
