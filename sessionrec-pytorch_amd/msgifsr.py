@@ -285,12 +285,13 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         rows = self._lookup(mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
                             None, mg.dynp('U'))            # padded slots of gidx are -1 -> zero rows
         rows = self.feat_drop(rows)
-        feats, off = {}, 0
+        feats = {}
         dB = mg.dynp('B')
+        ncap = mg.meta['ncap']                             # block size of order k (capacity in padded layouts)
+        pieces = ops.split_rows(rows, [ncap[k] * k for k in range(1, K + 1)])
         for k in range(1, K + 1):
-            nk = mg.meta['ncap'][k]                        # block size of order k (capacity in padded layouts)
-            x = rows[off:off + nk * k]
-            off += nk * k
+            nk = ncap[k]
+            x = pieces[k - 1]
             dk = mg.dynp('N%d' % k)
             f = x if k == 1 else self.expander(x, k, dk, mg.dynp('GK%d' % k))
             feats[k] = ops.normalize(f, 0, dk) if self.norm else f
@@ -309,9 +310,14 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             if self.norm:
                 h = {k: ops.normalize(v, 0, mg.dynp('N%d' % k)) for k, v in h.items()}
             stacked = h[1] if K == 1 else torch.cat([h[k] for k in range(1, K + 1)], 0)
-        allf = stacked if K == 1 else ops.row_gather(stacked, mg.cat_perm, mg.dynp('NT'))
         live = range(K) if (K == 1 or self.fusion) else (0,)
-        feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1)), dB) for i in live}
+        if K == 1:
+            allf = stacked
+            feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1)), dB) for i in live}
+        else:
+            allf, picked = ops.permute_and_pick(stacked, mg.cat_perm, mg.field('cat_inv'),
+                                                [mg.field('lastcat%d' % (i + 1)) for i in live], mg.dynp('NT'), dB)
+            feat_vs = dict(zip(live, picked))
         sr_g = self.readout(mg, allf, feat_vs, live)
         srs = []
         for i in live:

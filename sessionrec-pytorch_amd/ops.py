@@ -291,6 +291,72 @@ def row_gather(x, idx, dyn=None):
     return RowGather.apply(x, idx, dyn)
 
 
+class PermuteAndPick(torch.autograd.Function):
+    """(x[perm], x[pick_0], x[pick_1], ...) for a PERMUTATION perm of the live rows (inv = its inverse, -1 on padded
+    rows) and small distinct pick lists: MSGIFSR's per-session concatenation and last-node picks (msgifsr.py:131-147).
+    Backward = one inverse-permutation gather (writes every row, padded rows zero) + one in-place scatter per pick list,
+    instead of a zero-fill + scatter per output and autograd's adds."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv, dyn_n, dyn_b, *picks):
+        x = _rows(x)
+        d = x.shape[1]
+        outs = []
+        for idx, dyn in [(perm, dyn_n)] + [(p, dyn_b) for p in picks]:
+            o = torch.empty(idx.numel(), d, device=x.device, dtype=torch.float32)
+            lib.srec_gather_rows(ptr(x), _ld(x), ptr(idx), ptr(o), d, idx.numel(), ptr(dyn), d, stream())
+            outs.append(o)
+        ctx.save_for_backward(inv, *picks)
+        ctx.nrows, ctx.dyn_b = x.shape[0], dyn_b
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_perm, *g_picks):
+        inv, *picks = ctx.saved_tensors
+        g_perm = _rows(g_perm)
+        d = g_perm.shape[1]
+        gx = torch.empty(ctx.nrows, d, device=g_perm.device, dtype=torch.float32)
+        lib.srec_gather_rows(ptr(g_perm), _ld(g_perm), ptr(inv), ptr(gx), d, ctx.nrows, None, d, stream())
+        for idx, g in zip(picks, g_picks):
+            if g is None:
+                continue
+            g = _rows(g)
+            ar = _arange(idx.numel() + 1, g.device)
+            lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(idx), ptr(ar), ptr(ar), ptr(gx), d, idx.numel(),
+                                        ptr(ctx.dyn_b), d, 1, stream())
+        return (gx, None, None, None, None) + (None,) * len(picks)
+
+
+def permute_and_pick(x, perm, inv, picks, dyn_n=None, dyn_b=None):
+    outs = PermuteAndPick.apply(x, perm, inv, dyn_n, dyn_b, *picks)
+    return outs[0], list(outs[1:])
+
+
+class SplitRows(torch.autograd.Function):
+    """row-range views x[o_i : o_i + n_i]; the backward is ONE concatenation instead of a zero-fill, a slice copy and
+    an add per piece (autograd's SliceBackward)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        ctx.sizes, ctx.shape = sizes, x.shape
+        outs, off = [], 0
+        for n in sizes:
+            outs.append(x[off:off + n])
+            off += n
+        assert off == x.shape[0]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g if g is not None else torch.zeros((n,) + tuple(ctx.shape[1:]), device=next(t for t in gs if t is not None).device)
+              for g, n in zip(gs, ctx.sizes)]
+        return torch.cat(gs, 0), None
+
+
+def split_rows(x, sizes):
+    return SplitRows.apply(x, tuple(sizes))
+
+
 class Normalize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps_mode, dyn):
