@@ -59,19 +59,7 @@ class SemanticExpander(nn.Module):
         """x: [N_k * k, d] gathered gram rows (contiguous) -> [N_k, d]"""
         if self.reducer != 'mean':
             raise NotImplementedError("reducer '%s' is not on the HIP path yet (only 'mean')" % self.reducer)
-        gru = self.GRUs[k - 2]
-        d = self.input_dim
-        n = x.shape[0] // k
-        GI = ops.unbind_mid(ops.linear(x, gru.weight_ih_l0, gru.bias_ih_l0, dyn_rows).view(n, k, 3 * d))
-        h = None
-        for t in range(k):
-            gi = GI[t]
-            if t == 0:
-                h = ops.gru_step(gi, None, gru.bias_hh_l0, None, dyn)
-            else:
-                gh = ops.linear(h, gru.weight_hh_l0, gru.bias_hh_l0, dyn)
-                h = ops.gru_step(gi, gh, None, h, dyn)
-        return ops.gram_combine(x.view(n, k, d), h, k, dyn)
+        return ops.gru_expand(x, self.GRUs[k - 2], k, dyn, dyn_rows)
 
 
 class MSHGNN(nn.Module):

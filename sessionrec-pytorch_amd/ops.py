@@ -765,6 +765,80 @@ class GramCombine(torch.autograd.Function):
         return dX, dH, None, None
 
 
+class GRUExpand(torch.autograd.Function):
+    """MSGIFSR SemanticExpander for one order k (msgifsr.py:32-45): out = 0.5 * mean_t x[n,t,:] + 0.5 * GRU(x).h_last,
+    as ONE autograd node on stacked buffers: the time steps share [k, n, *] tensors, so the backward needs one
+    weight-gradient GEMM and one bias column-sum for W_hh / b_hh over all steps, the hidden-state gradient is
+    accumulated by the backward-data GEMM itself (beta = 1) and nothing goes through autograd's select / add kernels."""
+
+    @staticmethod
+    def forward(ctx, x, Wih, bih, Whh, bhh, k, dyn_n, dyn_rows):
+        x = x.contiguous()
+        nk, d = x.shape
+        n, d3 = nk // k, 3 * d
+        dev = x.device
+        Wih, Whh, bhh = _rows(Wih), _rows(Whh), bhh.contiguous()
+        GI = torch.empty(nk, d3, device=dev, dtype=torch.float32)
+        gemm_nt(x, Wih, GI, bih, dyn_rows, 1 if dyn_rows is not None else 0)
+        H = torch.empty(k, n, d, device=dev, dtype=torch.float32)
+        gates = torch.empty(k, n, d3, device=dev, dtype=torch.float32)
+        GH = torch.empty(max(k - 1, 1), n, d3, device=dev, dtype=torch.float32)
+        st = stream()
+        for t in range(k):
+            gi = GI.data_ptr() + 4 * t * d3                                   # GI[:, t, :], row stride k * 3d
+            if t == 0:
+                lib.srec_gru_pointwise_fwd(gi, k * d3, None, 0, ptr(bhh), None, 0, n, ptr(dyn_n), d, ptr(H[0]), d,
+                                           ptr(gates[0]), st)
+            else:
+                gemm_nt(H[t - 1], Whh, GH[t - 1], bhh, dyn_n, 1 if dyn_n is not None else 0)
+                lib.srec_gru_pointwise_fwd(gi, k * d3, ptr(GH[t - 1]), d3, None, ptr(H[t - 1]), d, n, ptr(dyn_n), d,
+                                           ptr(H[t]), d, ptr(gates[t]), st)
+        out = torch.empty(n, d, device=dev, dtype=torch.float32)
+        lib.srec_gram_combine_fwd(ptr(x), ptr(H[k - 1]), d, n, ptr(dyn_n), k, d, ptr(out), d, st)
+        ctx.save_for_backward(x, Wih, Whh, bhh, H, gates, GH)
+        ctx.k, ctx.dyn_n, ctx.dyn_rows = k, dyn_n, dyn_rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wih, Whh, bhh, H, gates, GH = ctx.saved_tensors
+        k, dyn_n, dyn_rows = ctx.k, ctx.dyn_n, ctx.dyn_rows
+        g = _rows(g)
+        n, d = g.shape
+        d3, dev, st = 3 * d, g.device, stream()
+        dX = torch.empty(n * k, d, device=dev, dtype=torch.float32)
+        dh = torch.empty(n, d, device=dev, dtype=torch.float32)
+        lib.srec_gram_combine_bwd(ptr(g), _ld(g), n, ptr(dyn_n), k, d, ptr(dX), ptr(dh), d, st)
+        dGI = torch.empty(n * k, d3, device=dev, dtype=torch.float32)
+        dGH = torch.empty(k, n, d3, device=dev, dtype=torch.float32)          # slot t = d(gh_t); non-live rows zero
+        for t in range(k - 1, -1, -1):
+            dgi = dGI.data_ptr() + 4 * t * d3
+            if t > 0:
+                dhp = torch.empty(n, d, device=dev, dtype=torch.float32)
+                lib.srec_gru_pointwise_bwd(ptr(dh), d, ptr(gates[t]), ptr(GH[t - 1]), d3, None, ptr(H[t - 1]), d, n,
+                                           ptr(dyn_n), d, dgi, k * d3, ptr(dGH[t]), d3, ptr(dhp), d, st)
+                gemm_nn(dGH[t], Whh, dhp, dyn_n, 1 if dyn_n is not None else 0, beta=1.0)      # dh_{t-1} += dgh_t W_hh
+                dh = dhp
+            else:
+                lib.srec_gru_pointwise_bwd(ptr(dh), d, ptr(gates[0]), None, 0, ptr(bhh), None, 0, n, ptr(dyn_n), d,
+                                           dgi, k * d3, ptr(dGH[0]), d3, None, 0, st)
+        gWhh = torch.zeros_like(Whh) if k == 1 else torch.empty_like(Whh)
+        if k > 1:
+            gemm_tn(dGH[1:].reshape((k - 1) * n, d3), H[:k - 1].reshape((k - 1) * n, d), gWhh, None)
+        gbhh = torch.empty(d3, device=dev, dtype=torch.float32)
+        col_sum(dGH.view(k * n, d3), k * n, d3, gbhh, None)
+        gemm_nn(dGI, Wih, dX, dyn_rows, 1 if dyn_rows is not None else 0, beta=1.0)             # + the mean term
+        gWih = torch.empty_like(Wih)
+        gemm_tn(dGI, x, gWih, dyn_rows)
+        gbih = torch.empty(d3, device=dev, dtype=torch.float32)
+        col_sum(dGI, n * k, d3, gbih, dyn_rows)
+        return dX, gWih, gbih, gWhh, gbhh, None, None, None
+
+
+def gru_expand(x, gru, k, dyn_n=None, dyn_rows=None):
+    return GRUExpand.apply(x, gru.weight_ih_l0, gru.bias_ih_l0, gru.weight_hh_l0, gru.bias_hh_l0, k, dyn_n, dyn_rows)
+
+
 def gram_combine(X, Hl, k, dyn=None):
     return GramCombine.apply(X, Hl, k, dyn)
 
