@@ -6,7 +6,7 @@
 //   backward-data  dx_t = sum_{m touching t} dP_m[rows_t] W_m   A k-contiguous, B reduction-major, one segment per module:
 //                  the sum over modules is the K loop, so no split-K slabs, no beta chains, no transposed weight copies
 //   weight grad    dW_m = dP_m^T x[rows_m]           A and B reduction-major (reduction = node rows, clamped by dyn)
-// 64x64x32 tiles, 4 waves (2x2) of one v_mfma_f32_32x32x16_bf16 accumulator each; operands are rounded to bf16 while
+// 64x64 or 128x128 tiles, 4 waves (2x2) of 1 or 2x2 v_mfma_f32_32x32x16_bf16 accumulators each; operands are rounded to bf16 while
 // staged (k-contiguous: float4 along k; reduction-major: (m, m+1) pairs packed and transposed, see gemm_bf16.hip).
 #include "common.h"
 
@@ -34,23 +34,26 @@ struct GArgs {
 
 // AK / BKC: operand is k-contiguous ([rows, K] row-major); otherwise reduction-major ([K, rows] row-major).
 // dyn clamps the output rows M when AK (rows >= live: zeroed if beta == 0, untouched otherwise), the reduction otherwise.
-// BKT = k-tile: 32 for the short-K forward, 64 for the long reductions (twice the bytes in flight per barrier; the
-// loops are global-latency bound - one 64x64 accumulator per wave leaves little MFMA work to hide a load behind).
-// A16: the A operands are already bf16 in HBM (projection gradients written by hgat.hip); C16: C is stored as bf16.
-template <bool AK, bool BKC, int BKT, bool A16, bool C16>
+// TILE = 64 (one 32x32 accumulator per wave) or 128 (2x2 accumulators per wave: one LDS fragment read per MFMA instead
+// of two, 4x the MFMA work behind every global load - these loops are latency bound, not MFMA bound).
+// BKT = k-tile (32 / 64).  A16: the A operands are already bf16 in HBM; C16: C is stored as bf16.
+template <bool AK, bool BKC, int TILE, int BKT, bool A16, bool C16>
 __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     constexpr int LD = BKT + 8;                 // bf16 elements per LDS row: 16-B fragment reads hit distinct 4-bank slots
-    constexpr int NLK = BKT / 16;               // float4 loads per thread, k-contiguous operand (64 x BKT floats)
-    constexpr int NLR = BKT / 32;               // row-pair items per thread, reduction-major operand
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][64][LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][64][LD];
+    constexpr int TM = TILE / 64;               // accumulators per wave and dimension
+    constexpr int NLK = TILE * BKT / 1024;      // float4 loads per thread, k-contiguous fp32 operand
+    constexpr int NL16 = TILE * BKT / 2048;     // 16-B loads per thread, k-contiguous bf16 operand
+    constexpr int NLR = TILE * BKT / 2048;      // (row pair, 4 columns) items per thread, reduction-major operand
+    constexpr int CB = TILE / 16;               // 16-column blocks of a reduction-major tile
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][TILE][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][TILE][LD];
     int p = 0;
 #pragma unroll
     for (int i = 1; i < MAXP; ++i)
         if (i < g.np && (int)blockIdx.x >= g.start[i]) p = i;
     const int M = g.M[p], N = g.N[p];
-    const int tn = (N + 63) / 64, tile = blockIdx.x - g.start[p];
-    const int m0 = (tile / tn) * 64, n0 = (tile % tn) * 64;
+    const int tn = (N + TILE - 1) / TILE, tile = blockIdx.x - g.start[p];
+    const int m0 = (tile / tn) * TILE, n0 = (tile % tn) * TILE;
     const int live = dyn_count(g.dyn[p], AK ? M : g.K[p]);
     const int Ml = AK ? live : M, Kr = AK ? g.K[p] : live;          // live output rows, reduction length per segment
     float* __restrict__ C = static_cast<float*>(g.C[p]);
@@ -59,31 +62,34 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
     if (m0 >= Ml) {
         if (g.beta == 0.f)
-            for (int i = tid; i < 64 * 64; i += 256) {
-                const int r = m0 + i / 64, c = n0 + i % 64;
+            for (int i = tid; i < TILE * TILE; i += 256) {
+                const int r = m0 + i / TILE, c = n0 + i % TILE;
                 if (r < M && c < N) { if (C16) C16p[(size_t)r * g.ldc + c] = 0; else C[(size_t)r * g.ldc + c] = 0.f; }
             }
         return;
     }
-    f32x16 acc;
+    f32x16 acc[TM][TM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (Kr + BKT - 1) / BKT, total = nkt * g.nseg[p];
-    constexpr int NA = AK ? NLK : 2 * NLR, NB = BKC ? NLK : 2 * NLR;
+    constexpr int NA = A16 ? 1 : (AK ? NLK : 2 * NLR), NB = BKC ? NLK : 2 * NLR;
     float4 ra[NA], rb[NB];
-    uint4 ra16[AK ? (BKT / 32 > 0 ? BKT / 32 : 1) : 1];      // A16, k-contiguous: 8 bf16 per 16-B load
-    uint2 rr16[2 * NLR];                                     // A16, reduction-major: 4 bf16 per 8-B load
-    constexpr int NL16 = BKT / 32;                           // 64 x BKT bf16 = 16-B loads per thread
-    auto k16_row = [&](int q) { return (tid + 256 * q) / (BKT / 8); };
-    auto k16_k = [&](int q) { return ((tid + 256 * q) % (BKT / 8)) * 8; };
-    // k-contiguous item q: row = idx / (BKT/4), k = 4 * (idx % (BKT/4)), idx = tid + 256 q
-    // reduction-major item q: 4 columns c4, reduction rows q2, q2 + 1 (lane -> (column group, row pair) keeps a wave's
-    // 64 packed words on 64 distinct LDS banks: see gemm_bf16.hip)
+    uint4 ra16[(A16 && AK) ? NL16 : 1];                      // A16, k-contiguous: 8 bf16 per 16-B load
+    uint2 rr16[(A16 && !AK) ? 2 * NLR : 1];                  // A16, reduction-major: 4 bf16 per 8-B load
+    // k-contiguous fp32 item q: row = idx / (BKT/4), k = 4 * (idx % (BKT/4)), idx = tid + 256 q;  bf16: 8 per item
     auto kc_row = [&](int q) { return (tid + 256 * q) / (BKT / 4); };
     auto kc_k = [&](int q) { return ((tid + 256 * q) % (BKT / 4)) * 4; };
-    const int c4 = ((tid & 3) + 4 * (tid >> 6)) * 4;
-    auto rm_q2 = [&](int q) { return (((tid >> 2) & 15) + 16 * q) * 2; };
+    auto k16_row = [&](int q) { return (tid + 256 * q) / (BKT / 8); };
+    auto k16_k = [&](int q) { return ((tid + 256 * q) % (BKT / 8)) * 8; };
+    // reduction-major item q: unit u = wave + 4 q -> (16-column block u % CB, 16-row-pair block u / CB); inside a wave
+    // lane & 3 = 4-column group, (lane >> 2) & 15 = row pair: a wave's 64 packed words land on 64 distinct LDS banks
+    auto rm_c4 = [&](int q) { return (((wave + 4 * q) % CB) * 4 + (tid & 3)) * 4; };
+    auto rm_q2 = [&](int q) { return (((wave + 4 * q) / CB) * 16 + ((tid >> 2) & 15)) * 2; };
     auto gload = [&](int it) {
         const int s = it / nkt, k0 = (it % nkt) * BKT;
         const float* __restrict__ A = static_cast<const float*>(g.A[p][s]);
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
             for (int q = 0; q < NLR; ++q)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    rr16[2 * q + e] = *reinterpret_cast<const uint2*>(A16p + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.lda + min(m0 + c4, M - 4));
+                    rr16[2 * q + e] = *reinterpret_cast<const uint2*>(A16p + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.lda + min(m0 + rm_c4(q), M - 4));
         } else if (AK) {
 #pragma unroll
             for (int q = 0; q < NLK; ++q)
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
             for (int q = 0; q < NLR; ++q)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    ra[2 * q + e] = *reinterpret_cast<const float4*>(A + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.lda + min(m0 + c4, M - 4));
+                    ra[2 * q + e] = *reinterpret_cast<const float4*>(A + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.lda + min(m0 + rm_c4(q), M - 4));
         }
         if (BKC) {
 #pragma unroll
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
             for (int q = 0; q < NLR; ++q)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    rb[2 * q + e] = *reinterpret_cast<const float4*>(B + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.ldb + min(n0 + c4, N - 4));
+                    rb[2 * q + e] = *reinterpret_cast<const float4*>(B + (size_t)min(k0 + rm_q2(q) + e, Kr - 1) * g.ldb + min(n0 + rm_c4(q), N - 4));
         }
     };
     auto lstore = [&](int buf, int it) {
@@ -131,10 +137,10 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
                 *reinterpret_cast<uint4*>(&As[buf][k16_row(q)][k16_k(q)]) = ok ? ra16[q] : make_uint4(0u, 0u, 0u, 0u);
             }
         } else if (A16) {
-            const bool cok = m0 + c4 < M;
 #pragma unroll
             for (int q = 0; q < NLR; ++q) {
-                const int q2 = rm_q2(q);
+                const int q2 = rm_q2(q), c4 = rm_c4(q);
+                const bool cok = m0 + c4 < M;
                 const bool ok0 = cok && (k0 + q2 < Kr), ok1 = cok && (k0 + q2 + 1 < Kr);
                 const uint2 r0 = ok0 ? rr16[2 * q] : make_uint2(0u, 0u), r1 = ok1 ? rr16[2 * q + 1] : make_uint2(0u, 0u);
                 *reinterpret_cast<unsigned*>(&As[buf][c4 + 0][q2]) = (r0.x & 0xffffu) | (r1.x << 16);
@@ -151,10 +157,10 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
                 *reinterpret_cast<uint2*>(&As[buf][kc_row(q)][kc_k(q)]) = v;
             }
         } else {
-            const bool cok = m0 + c4 < M;
 #pragma unroll
             for (int q = 0; q < NLR; ++q) {
-                const int q2 = rm_q2(q);
+                const int q2 = rm_q2(q), c4 = rm_c4(q);
+                const bool cok = m0 + c4 < M;
                 const bool ok0 = cok && (k0 + q2 < Kr), ok1 = cok && (k0 + q2 + 1 < Kr);
                 const float a0[4] = {ra[2 * q].x, ra[2 * q].y, ra[2 * q].z, ra[2 * q].w};
                 const float a1[4] = {ra[2 * q + 1].x, ra[2 * q + 1].y, ra[2 * q + 1].z, ra[2 * q + 1].w};
@@ -172,10 +178,10 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
                 *reinterpret_cast<uint2*>(&Bs[buf][kc_row(q)][kc_k(q)]) = v;
             }
         } else {
-            const bool cok = n0 + c4 < N;
 #pragma unroll
             for (int q = 0; q < NLR; ++q) {
-                const int q2 = rm_q2(q);
+                const int q2 = rm_q2(q), c4 = rm_c4(q);
+                const bool cok = n0 + c4 < N;
                 const bool ok0 = cok && (k0 + q2 < Kr), ok1 = cok && (k0 + q2 + 1 < Kr);
                 const float b0[4] = {rb[2 * q].x, rb[2 * q].y, rb[2 * q].z, rb[2 * q].w};
                 const float b1[4] = {rb[2 * q + 1].x, rb[2 * q + 1].y, rb[2 * q + 1].z, rb[2 * q + 1].w};
@@ -195,31 +201,44 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
         if (it + 1 < total) gload(it + 1);
 #pragma unroll
         for (int ks = 0; ks < BKT / 16; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][wm * 32 + l31][ks * 16 + half * 8]);
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[buf][wn * 32 + l31][ks * 16 + half * 8]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            bf16x8 a[TM], b[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[buf][wm * (TILE / 2) + i * 32 + l31][ks * 16 + half * 8]);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][wn * (TILE / 2) + j * 32 + l31][ks * 16 + half * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (it + 1 < total) lstore(buf ^ 1, it + 1);
         __syncthreads();
     }
-    const int col = n0 + wn * 32 + l31;
-    if (col < N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < M) {
-                if (C16) {                                   // bf16 output (beta is ignored: forward projections)
-                    unsigned u = __float_as_uint(row < Ml ? acc[r] : 0.f);
-                    u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-                    C16p[(size_t)row * g.ldc + col] = (unsigned short)u;
-                } else {
-                    float* q = C + (size_t)row * g.ldc + col;
-                    if (row < Ml) *q = g.beta != 0.f ? acc[r] + g.beta * *q : acc[r];
-                    else if (g.beta == 0.f) *q = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int col = n0 + wn * (TILE / 2) + j * 32 + l31;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (TILE / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) {
+                    if (C16) {                                   // bf16 output (beta is ignored: forward projections)
+                        unsigned u = __float_as_uint(row < Ml ? acc[i][j][r] : 0.f);
+                        u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+                        C16p[(size_t)row * g.ldc + col] = (unsigned short)u;
+                    } else {
+                        float* q = C + (size_t)row * g.ldc + col;
+                        if (row < Ml) *q = g.beta != 0.f ? acc[i][j][r] + g.beta * *q : acc[i][j][r];
+                        else if (g.beta == 0.f) *q = 0.f;
+                    }
                 }
             }
         }
-    }
 }
 
 }  // namespace
@@ -242,6 +261,11 @@ extern "C" int srec_gemm_group_bf16(const void* desc_, int mode, void* stream) {
     if ((d->a16 && (mode == 0 || (d->lda & 7))) || (d->c16 && mode != 0)) return SREC_BAD_ARG;
     GArgs g{};
     g.np = d->np; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.beta = d->beta;
+    // 128x128 tiles for the forward when they still give every CU a workgroup.  The reductions stay on 64x64: their
+    // outputs are small (a 128-tile grid of the weight gradients is one workgroup per CU and measured slower)
+    long t128 = 0;
+    for (int p = 0; p < d->np; ++p) t128 += (long)cdiv(d->M[p], 128) * cdiv(d->N[p], 128);
+    const int tile = (mode == 0 && t128 >= 256) ? 128 : 64;
     int blocks = 0;
     for (int p = 0; p < d->np; ++p) {
         if (d->nseg[p] <= 0 || d->nseg[p] > MAXS || d->M[p] <= 0 || d->N[p] <= 0 || d->K[p] < 4) return SREC_BAD_ARG;
@@ -253,17 +277,21 @@ extern "C" int srec_gemm_group_bf16(const void* desc_, int mode, void* stream) {
             g.A[p][s] = d->A[p][s]; g.B[p][s] = d->B[p][s];
         }
         g.start[p] = blocks;
-        blocks += cdiv(d->M[p], 64) * cdiv(d->N[p], 64);
+        blocks += cdiv(d->M[p], tile) * cdiv(d->N[p], tile);
     }
     g.start[d->np] = blocks;
     hipStream_t st = (hipStream_t)stream;
     const dim3 gr(blocks), bl(256);
-    if (mode == 0 && d->c16) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true, 32, false, true>), gr, bl, 0, st, g);
-    else if (mode == 0) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, true, 32, false, false>), gr, bl, 0, st, g);
-    else if (mode == 1 && d->a16) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false, 64, true, false>), gr, bl, 0, st, g);
-    else if (mode == 1) hipLaunchKernelGGL((gemm_group_bf16_kernel<true, false, 64, false, false>), gr, bl, 0, st, g);
-    else if (d->a16) hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false, 64, true, false>), gr, bl, 0, st, g);
-    else hipLaunchKernelGGL((gemm_group_bf16_kernel<false, false, 64, false, false>), gr, bl, 0, st, g);
+#define SREC_GG(AK, BKC, T, BKT, A16, C16) hipLaunchKernelGGL((gemm_group_bf16_kernel<AK, BKC, T, BKT, A16, C16>), gr, bl, 0, st, g)
+    if (mode == 0) {
+        if (tile == 128) { if (d->c16) SREC_GG(true, true, 128, 32, false, true); else SREC_GG(true, true, 128, 32, false, false); }
+        else { if (d->c16) SREC_GG(true, true, 64, 32, false, true); else SREC_GG(true, true, 64, 32, false, false); }
+    } else if (mode == 1) {
+        if (d->a16) SREC_GG(true, false, 64, 64, true, false); else SREC_GG(true, false, 64, 64, false, false);
+    } else {
+        if (d->a16) SREC_GG(false, false, 64, 64, true, false); else SREC_GG(false, false, 64, 64, false, false);
+    }
+#undef SREC_GG
     SREC_LAUNCH_CHECK();
     return 0;
 }

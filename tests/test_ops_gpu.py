@@ -551,3 +551,31 @@ def test_gemm_group_bf16(dev, mode):
         ops.gemm_group(2, [(128, 64, 900, [(g1, x1)], C0, dyn), (128, 64, 333, [(g2, x2)], C1, None)], 128, 64, 64)
         close(C0, bf(g1[:801]).t() @ bf(x1[:801]), what='group tn dyn', rtol=1e-4, atol=2e-3)
         close(C1, bf(g2).t() @ bf(x2), what='group tn', rtol=1e-4, atol=2e-3)
+
+
+def test_gemm_group_bf16_large_tiles_and_bf16_storage(dev):
+    """the 128x128-tile forward variant (taken when it still fills the chip) and bf16-stored C / A operands, at the shapes
+    of the MSHGNN layer: forward into a bf16 projection, weight gradient from a bf16 projection gradient"""
+    ops = _ops()
+    torch.manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=dev)
+    bf = lambda t: t.bfloat16().float()
+    xs = [r(1100 + 100 * i, 64) for i in range(8)]
+    ws = [r(2048, 64) for _ in range(8)]
+    Ps = [torch.empty(x.shape[0], 2048, device=dev, dtype=torch.bfloat16) for x in xs]
+    dyn = torch.tensor([1000], device=dev, dtype=torch.int32)
+    ops.gemm_group(0, [(x.shape[0], 2048, 64, [(x, w)], P, dyn if i == 3 else None) for i, (x, w, P) in enumerate(zip(xs, ws, Ps))],
+                   64, 64, 2048, c16=True)
+    for i, (x, w, P) in enumerate(zip(xs, ws, Ps)):
+        ref = (bf(x) @ bf(w).t())
+        if i == 3:
+            ref[1000:] = 0
+        close(P.float(), ref.bfloat16().float(), what='group nt 128 -> bf16 C (%d)' % i, rtol=1e-2, atol=2e-2)
+    gs = [r(x.shape[0], 2048).bfloat16() for x in xs]
+    xw = [r(x.shape[0], 256) for x in xs]
+    Cs = [torch.empty(2048, 256, device=dev) for _ in xs]
+    ops.gemm_group(2, [(2048, 256, x.shape[0], [(g, x2)], C, dyn if i == 5 else None)
+                       for i, (x, g, x2, C) in enumerate(zip(xs, gs, xw, Cs))], 2048, 256, 256, a16=True)
+    for i, (g, x2, C) in enumerate(zip(gs, xw, Cs)):
+        n = 1000 if i == 5 else g.shape[0]
+        close(C, g[:n].float().t() @ bf(x2[:n]), what='group tn 128, bf16 A (%d)' % i, rtol=1e-4, atol=5e-3)
