@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     constexpr int NLK = TILE * BKT / 1024;      // float4 loads per thread, k-contiguous fp32 operand
     constexpr int NL16 = TILE * BKT / 2048;     // 16-B loads per thread, k-contiguous bf16 operand
     constexpr int NLR = TILE * BKT / 2048;      // (row pair, 4 columns) items per thread, reduction-major operand
-    constexpr int CB = TILE / 16;               // 16-column blocks of a reduction-major tile
+    constexpr int CB = TILE / 32;               // 32-column blocks of a reduction-major tile
     __shared__ __attribute__((aligned(16))) unsigned short As[2][TILE][LD];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2][TILE][LD];
     int p = 0;
@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void gemm_group_bf16_kernel(GArgs g) {
     auto kc_k = [&](int q) { return ((tid + 256 * q) % (BKT / 4)) * 4; };
     auto k16_row = [&](int q) { return (tid + 256 * q) / (BKT / 8); };
     auto k16_k = [&](int q) { return ((tid + 256 * q) % (BKT / 8)) * 8; };
-    // reduction-major item q: unit u = wave + 4 q -> (16-column block u % CB, 16-row-pair block u / CB); inside a wave
-    // lane & 3 = 4-column group, (lane >> 2) & 15 = row pair: a wave's 64 packed words land on 64 distinct LDS banks
-    auto rm_c4 = [&](int q) { return (((wave + 4 * q) % CB) * 4 + (tid & 3)) * 4; };
-    auto rm_q2 = [&](int q) { return (((wave + 4 * q) / CB) * 16 + ((tid >> 2) & 15)) * 2; };
+    // reduction-major item q: unit u = wave + 4 q -> (32-column block u % CB, 8-row-pair block u / CB); inside a wave
+    // lane & 7 = 4-column group (8 lanes = 128 contiguous bytes of one fp32 row), lane >> 3 = row pair; the packed
+    // ds_write_b32 are 2-way bank conflicted, the global loads fetch full 128-B lines (64 B for bf16 rows)
+    auto rm_c4 = [&](int q) { return (((wave + 4 * q) % CB) * 8 + (tid & 7)) * 4; };
+    auto rm_q2 = [&](int q) { return (((wave + 4 * q) / CB) * 8 + ((tid >> 3) & 7)) * 2; };
     auto gload = [&](int it) {
         const int s = it / nkt, k0 = (it % nkt) * BKT;
         const float* __restrict__ A = static_cast<const float*>(g.A[p][s]);
