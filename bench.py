@@ -89,7 +89,7 @@ def build_model(sp, name, V, d, order):
     return sp.MSGIFSR(V, 'synthetic', d, 1, dropout=0.0, order=order, extra=False, fusion=False)
 
 
-def time_dominant_kernel(model, B, V, d, dev, iters=20):
+def time_dominant_kernel(model, B, V, d, dev, iters=20, force_fp32=False):
     """HIP-event timing (on the launch stream) of the fused scoring/CE kernels alone:
     forward, backward dE pass (4*B*V*d flop per launch), backward d-sr pass."""
     ops = importlib.import_module('sessionrec-pytorch_amd.ops')
@@ -104,7 +104,7 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20):
     loss = torch.empty((), device=dev)
     dE = torch.empty_like(table)
     dsr = torch.empty(B, d, device=dev)
-    bf16 = ops.use_bf16_scoring(d)
+    bf16 = ops.use_bf16_scoring(d) and not force_fp32      # the row-sharded (N > 1) scoring runs the fp32 kernels
     tb = ops.TableBF16(table).refresh(table) if bf16 else None
 
     def fwd():
@@ -307,7 +307,7 @@ def main():
 
     if rank == 0:
         Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
-        kt = time_dominant_kernel(model, B * world, Vk, d, dev)
+        kt = time_dominant_kernel(model, B * world, Vk, d, dev, force_fp32=shard is not None)
         Bg = B * world
         kms = {k: v * 1e3 for k, v in kt.items() if k != 'bf16'}
         if kt['bf16']:

@@ -11,8 +11,11 @@ Documented deviations:
   * one fc projection per (GAT module, node type) is shared by every relation that uses it as
     source or destination - identical to the reference whenever feat_drop == 0; with dropout the
     reference draws an independent mask per (relation, role), here one mask per (conv, type);
-  * `extra` (repeat/explore mix) and the 'max'/'concat' reducers are not on the HIP path yet; `fusion`
-    (order mixture, msgifsr.py:311-317) is: K fused scoring passes, the mixture on the (lse, label-logit) pairs.
+  * the 'max'/'concat' reducers are not on the HIP path yet; `fusion` (order mixture, msgifsr.py:311-317) is: K
+    fused scoring passes, the mixture on the (lse, label-logit) pairs; `extra` (repeat / explore mixture,
+    msgifsr.py:281-305) never materialises the two masked (B, V) soft-maxes: the in-session log-sum-exp is a
+    [B, <=L] dot product against the session's own (already gathered) item rows and the out-of-session one follows
+    from the fused full-catalog statistics, lse_ex = lse_all + log(1 - exp(lse_in - lse_all)).
 """
 import math
 
@@ -264,9 +267,6 @@ class MSGIFSR(_ScoringMixin, nn.Module):
 
     def session_repr(self, mg, tgrad=None):
         K = self.order
-        if self.extra:
-            raise NotImplementedError('MSGIFSR(extra=True) is not on the HIP path yet; pass extra=False '
-                                      '(the reference scripts default to it: main_msgifsr.py:100-104)')
         self._renorm(mg)
         W = self._table()
         d = self.embedding_dim
@@ -283,6 +283,7 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             dk = mg.dynp('N%d' % k)
             f = x if k == 1 else self.expander(x, k, dk, mg.dynp('GK%d' % k))
             feats[k] = ops.normalize(f, 0, dk) if self.norm else f
+        self._s1_feat = feats[1]                           # the session's own item rows (normalised): `extra` in-session logits
         fused = not (self.training and any(l.conv1.mods['intra1'].feat_drop > 0 for l in self.layers))
         if fused and len(self.layers) > 0:
             # all orders stacked once; every layer is one batched pass over all relations (ops.hgat_layer)
@@ -315,12 +316,51 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             return srs                                     # one session vector per order (IFR mixture)
         return srs[0]
 
+    # ---- `extra`: repeat / explore mixture (msgifsr.py:281-305)
+    def _in_session(self, mg, labels=None):
+        """dense [B, L] view of each session's order-1 nodes: node positions, validity, item ids, label membership"""
+        seg = mg.field('seg1').long()
+        f1 = self._s1_feat
+        B, L = mg.B, int(mg.meta['max_nodes'])
+        pos = seg[:-1, None] + torch.arange(L, device=f1.device)[None, :]
+        valid = pos < seg[1:, None]
+        posc = pos.clamp(max=f1.shape[0] - 1)
+        items = mg.field('iid1').long()[posc]
+        hit = None if labels is None else ((items == labels.long()[:, None]) & valid).any(1)
+        return posc, valid, items, hit
+
+    def _log_phi(self, sr, dynB):
+        """log softmax of sc_sr[0](sr): the (repeat, explore) gate - sc_sr[0] serves every order (msgifsr.py:283)"""
+        sc = self.sc_sr[0]
+        hdn = torch.relu(ops.linear(sr, sc[0].weight, sc[0].bias, dynB, exact=True))
+        two = (hdn.unsqueeze(1) * sc[2].weight.unsqueeze(0)).sum(-1)       # [B, 2]: too narrow for an MFMA tile
+        return torch.log_softmax(two, dim=-1)
+
+    def _extra_label_logprob(self, sr, lse_all, zlab, posc, valid, hit, dynB):
+        zin = 12.0 * (self._s1_feat[posc] * sr[:, None, :]).sum(-1)
+        lse_in = torch.logsumexp(zin.masked_fill(~valid, float('-inf')), dim=1)
+        lse_ex = lse_all + torch.log1p(-torch.exp(lse_in - lse_all).clamp(max=1.0 - 1e-7))
+        lphi = self._log_phi(sr, dynB)
+        return torch.where(hit, lphi[:, 0] + zlab - lse_in, lphi[:, 1] + zlab - lse_ex)
+
+    def _extra_log_probs(self, sr, posc, valid, items):
+        """(B, V) log score of one order with the repeat / explore gate (compat / evaluation path)"""
+        logp = self._log_probs(sr)                          # z - lse_all
+        B, V = logp.shape
+        lin = logp.gather(1, items.clamp(min=0)).masked_fill(~valid, float('-inf'))
+        d_in = torch.logsumexp(lin, dim=1)                  # lse_in - lse_all
+        d_ex = torch.log1p(-torch.exp(d_in).clamp(max=1.0 - 1e-7))
+        mask = torch.zeros(B, V + 1, dtype=torch.bool, device=logp.device)
+        mask.scatter_(1, torch.where(valid, items, torch.full_like(items, V)), True)
+        lphi = self._log_phi(sr, None)
+        return torch.where(mask[:, :V], lphi[:, 0:1] + logp - d_in[:, None], lphi[:, 1:2] + logp - d_ex[:, None])
+
     def fused_loss(self, *inputs_and_labels, dynB=None):
-        if not (self.fusion and self.order > 1):
+        if not (self.extra or (self.fusion and self.order > 1)):
             return super().fused_loss(*inputs_and_labels, dynB=dynB)
         if self.shard is not None:
-            raise NotImplementedError('order fusion with a row-sharded table')
-        # msgifsr.py:311-321: score = sum_k softmax(alpha)_k softmax(12 logits_k); loss = -mean log score[label]
+            raise NotImplementedError('order fusion / extra with a row-sharded table')
+        # msgifsr.py:311-321: score = sum_k softmax(alpha)_k score_k; loss = -mean log score[label]
         mg, labels = inputs_and_labels
         B = labels.numel()
         if dynB is None:
@@ -328,22 +368,37 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         st = self._state(B)
         cs, inv_scale = self._col_scale(st)
         srs = self.session_repr(mg, tgrad=st['tgrad'])
+        if not isinstance(srs, (list, tuple)):
+            srs = [srs]
         lab32 = labels.to(torch.int32)
         st['tgrad'].fresh = False
-        logits = []
         tb = self._table_bf16(st)
+        if self.extra:
+            posc, valid, _, hit = self._in_session(mg, labels)
+        logits = []
         for sr in srs:
             lse, lab = ops.score_stats(sr, self._table(), cs, lab32, st['ws'][B], st['tgrad'], dynB, inv_scale, tb)
-            logits.append(lab - lse)                       # log softmax_k[label]
-        logp = torch.logsumexp(torch.stack(logits, 1) + torch.log_softmax(self.alpha, 0).unsqueeze(0), dim=1)
+            if self.extra:
+                logits.append(self._extra_label_logprob(sr, lse, lab, posc, valid, hit, dynB))
+            else:
+                logits.append(lab - lse)                   # log softmax_k[label]
+        if len(logits) > 1:
+            logp = torch.logsumexp(torch.stack(logits, 1) + torch.log_softmax(self.alpha, 0).unsqueeze(0), dim=1)
+        else:
+            logp = logits[0]
         if dynB is not None:
-            live = (torch.arange(B, device=logp.device) < dynB).to(logp.dtype)
-            return -(logp * live).sum() / dynB.to(logp.dtype).clamp(min=1).sum()
+            live = torch.arange(B, device=logp.device) < dynB
+            return -torch.where(live, logp, torch.zeros_like(logp)).sum() / dynB.to(logp.dtype).clamp(min=1).sum()
         return -logp.mean()
 
     def forward(self, mg):
         sr = self.session_repr(mg)
+        if self.extra:
+            posc, valid, items, _ = self._in_session(mg)
+            per_order = (lambda s: self._extra_log_probs(s, posc, valid, items))
+        else:
+            per_order = self._log_probs
         if self.fusion and self.order > 1:
             la = torch.log_softmax(self.alpha, 0)
-            return torch.logsumexp(torch.stack([self._log_probs(s) + la[k] for k, s in enumerate(sr)], 0), dim=0)
-        return self._log_probs(sr)
+            return torch.logsumexp(torch.stack([per_order(s) + la[k] for k, s in enumerate(sr)], 0), dim=0)
+        return per_order(sr)

@@ -24,12 +24,18 @@ sys.path.insert(0, ROOT)
 from oracle import dgl_shim  # noqa: E402
 
 dgl_shim.install()
+# the repo root also holds a drop-in `src/` package (a regular package, which would shadow the reference's namespace
+# package whatever the path order): import the reference with the repo root off sys.path, then put it back
+_saved = [p for p in sys.path if os.path.abspath(p or '.') in (ROOT, os.getcwd()) and os.path.isdir(os.path.join(p or '.', 'src'))]
+sys.path[:] = [p for p in sys.path if p not in _saved]
 sys.path.insert(0, REF)
 from src.models import LESSR as RLESSR, MSGIFSR as RMSGIFSR, NISER as RNISER, SRGNN as RSRGNN  # noqa: E402
 from src.utils.data import collate as rcollate  # noqa: E402
 from src.utils.data.dataset import AugmentedDataset as RAugmentedDataset  # noqa: E402
 from src.utils import train as rtrain  # noqa: E402
 
+sys.path.insert(1, ROOT)
+assert RSRGNN.__module__.startswith('src.') and sys.modules['src'].__path__._path[0].startswith(REF), 'reference not imported'
 from oracle import collate_ref as oc  # noqa: E402
 from oracle import models_ref as om  # noqa: E402
 
@@ -142,10 +148,26 @@ def allow_zero(m):
     return m
 
 
+def extra_cases(sets):
+    """MSGIFSR(extra=True): repeat / explore mixture (msgifsr.py:281-305), orders 1 and 3, with / without fusion"""
+    for sname, smp in sets.items():
+        V = 3429 if sname == 's32' else 300
+        for K, fusion in ((1, False), (3, False), (3, True)):
+            th.manual_seed(123)
+            rm = allow_zero(RMSGIFSR(V, 'sample', D, 1, order=K, extra=True, fusion=fusion))
+            omod = om.MSGIFSR(V, 'sample', D, 1, order=K, extra=True, fusion=fusion)
+            run_case('msgifsr_K%d_ext%s_%s' % (K, '_fus' if fusion else '', sname), rm, omod,
+                     rcollate.collate_fn_factory_ccs((rcollate.seq_to_ccs_graph,), K),
+                     oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K), smp, full=False)
+
+
 def main():
     samples = first_samples(32)
     edge = EDGE_CASES
     sets = {'s32': samples, 'edge': edge}
+    if '--only-extra' in sys.argv:
+        return extra_cases(sets)
+    extra_cases(sets)
     for sname, smp in sets.items():
         full = sname == 's32'
         V = 3429 if full else 300          # edge-case ids are < 300: keeps those fixtures tiny

@@ -23,7 +23,7 @@ def _build(name, init, V, dev):
         m = sp.LESSR(V, d, L)
     elif name.startswith('msgifsr'):
         K = int(name.split('_')[1][1:])
-        m = sp.MSGIFSR(V, 'sample', d, 1, order=K, extra=False, fusion='_fus' in name)
+        m = sp.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name)
     missing = m.load_state_dict(init, strict=True)
     return m.to(dev)
 
@@ -57,7 +57,7 @@ def _oracle_fp64_final(name, init, samples, V):
         m, fn = om.LESSR(V, d, L), oc.collate_fn_factory(*fns)
     else:
         K = int(name.split('_')[1][1:])
-        m = om.MSGIFSR(V, 'sample', d, 1, order=K, extra=False, fusion='_fus' in name)
+        m = om.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name)
         fn = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K)
     m.load_state_dict(init)
     m = m.double()
@@ -108,7 +108,9 @@ def adam_close(a, b, lr=1e-3, steps=3, what=''):
 CASES = ['srgnn_s32', 'srgnn_edge', 'niser_s32', 'niser_edge',
          'lessr_L1_s32', 'lessr_L1_edge', 'lessr_L3_s32', 'lessr_L3_edge',
          'msgifsr_K1_s32', 'msgifsr_K1_edge', 'msgifsr_K2_s32', 'msgifsr_K2_edge', 'msgifsr_K3_s32', 'msgifsr_K3_edge',
-         'msgifsr_K3_fus_s32', 'msgifsr_K3_fus_edge']
+         'msgifsr_K3_fus_s32', 'msgifsr_K3_fus_edge',
+         'msgifsr_K1_ext_s32', 'msgifsr_K1_ext_edge', 'msgifsr_K3_ext_s32', 'msgifsr_K3_ext_edge',
+         'msgifsr_K3_ext_fus_s32', 'msgifsr_K3_ext_fus_edge']
 
 
 def grad_close(p, ref, what):
