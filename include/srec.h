@@ -234,6 +234,14 @@ int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int 
  * reduction-major (weight gradient; dyn clamps the reduction).  dyn clamps the output rows in modes 0 / 1. */
 int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
 
+/* ---- evaluation: K best items per session without the (B, V) score matrix (topk.hip) -----------------------------
+ * Replaces `logits = model(...); logits.topk(20)` of train.py:36-55 for models whose score is one soft-max
+ * (ranking by z[b,v] = cs[v] * <sr_b, E_v>): out_val [B,K] descending, out_idx [B,K] int32 item ids, ties towards
+ * the lower id.  K <= 32, d % 4 == 0; ws: srec_score_topk_ws() bytes. */
+int srec_score_topk_ws(int B, int V, int K, long* bytes);
+int srec_score_topk(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, int B, int V, int d, int K,
+                    float* out_val, int* out_idx, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@ launched through libsrec_hip.so.  CPU tensors raise (no fallback).
 `dyn` arguments are optional 1-element int32 device tensors holding the live
 extent of a capacity-padded dimension (see batch.FlatBatch.dyn).
 """
+import ctypes as _ct
+
 import torch
 
 from ._lib import lib, ptr, stream
@@ -617,6 +619,27 @@ def score_ce(sr, table, cs, labels, ws, tgrad, dynB=None, cs_inv_scale=1.0, tb=N
     return ScoreCE.apply(sr, table, cs, labels, ws, tgrad, dynB, cs_inv_scale, tb)
 
 
+_TOPK_WS = {}
+
+
+def score_topk(sr, table, cs, k):
+    """(values [B,k], item ids [B,k]) of the k largest z[b,v] = cs[v] <sr_b, E_v> - no (B, V) tensor (evaluation)"""
+    sr = _rows(sr.detach())
+    B, d = sr.shape
+    V = table.shape[0]
+    n = _ct.c_long()
+    lib.srec_score_topk_ws(B, V, k, _ct.addressof(n))
+    key = (sr.device.index, n.value)
+    ws = _TOPK_WS.get(key)
+    if ws is None:
+        ws = _TOPK_WS[key] = torch.empty(n.value, device=sr.device, dtype=torch.uint8)
+    val = torch.empty(B, k, device=sr.device, dtype=torch.float32)
+    idx = torch.empty(B, k, device=sr.device, dtype=torch.int32)
+    lib.srec_score_topk(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), B, V, d, k, ptr(val), ptr(idx), ptr(ws),
+                        stream())
+    return val, idx
+
+
 class ScoreLogProb(torch.autograd.Function):
     """(B,V) log-probabilities - the tensor the reference models' forward() returns (compat /
     evaluation path).  Backward materialises d z (B,V) and runs two MFMA GEMMs."""
@@ -1154,7 +1177,6 @@ def edge_agg(x, coef, fwd_csr, bwd_csr, dyn=None):
 
 
 # ------------------------------------------------------------------------------------------ MSHGNN layer (batched)
-import ctypes as _ct
 
 
 class HgDesc(_ct.Structure):

@@ -96,6 +96,20 @@ class _ScoringMixin:
             st['tb16'] = ops.TableBF16(W)
         return st['tb16'].refresh(W)
 
+    def topk(self, *inputs, k=20):
+        """(scores [B,k], item ids [B,k]) of the k best items per session WITHOUT the (B, V) score matrix
+        (train.evaluate: train.py:36-55).  Models whose score mixes several soft-maxes (MSGIFSR fusion / extra)
+        rank through forward()."""
+        with torch.no_grad():
+            sr = self.session_repr(*inputs)
+            mixed = isinstance(sr, (list, tuple)) or getattr(self, 'extra', False) or self.shard is not None
+            if mixed:
+                v, i = self(*inputs).topk(k)
+                return v, i.to(torch.int32)
+            st = self._state(sr.shape[0])
+            cs, _ = self._col_scale(st)
+            return ops.score_topk(sr, self._table(), cs, k)
+
     def _log_probs(self, sr):
         B = sr.shape[0]
         st = self._state(B)

@@ -35,9 +35,13 @@ def evaluate(model, data_loader, device, cutoff=20):
     with th.no_grad():
         for batch in data_loader:
             inputs, labels = prepare_batch(batch, device)
-            logits = model(*inputs)
-            num_samples += logits.size(0)
-            topk = logits.topk(k=cutoff)[1]
+            if hasattr(model, 'topk') and labels.is_cuda:
+                topk = model.topk(*inputs, k=cutoff)[1].long()    # fused: no (B, V) score matrix
+                num_samples += topk.size(0)
+            else:
+                logits = model(*inputs)
+                num_samples += logits.size(0)
+                topk = logits.topk(k=cutoff)[1]
             hit_ranks = th.where(topk == labels.unsqueeze(-1))[1] + 1
             hit += hit_ranks.numel()
             mrr += hit_ranks.float().reciprocal().sum().item()

@@ -579,3 +579,28 @@ def test_gemm_group_bf16_large_tiles_and_bf16_storage(dev):
     for i, (g, x2, C) in enumerate(zip(gs, xw, Cs)):
         n = 1000 if i == 5 else g.shape[0]
         close(C, g[:n].float().t() @ bf(x2[:n]), what='group tn 128, bf16 A (%d)' % i, rtol=1e-4, atol=5e-3)
+
+
+@pytest.mark.parametrize('B,V,d,K', [(5, 300, 32, 20), (512, 37484, 256, 20), (33, 5000, 96, 7)])
+def test_score_topk_matches_materialised_ranking(dev, B, V, d, K):
+    """fused top-K == torch.topk of the materialised score matrix (values exactly comparable up to fp32 dot-product
+    order; ids equal wherever neighbouring scores are separated by more than that round-off)"""
+    ops = _ops()
+    torch.manual_seed(B + V)
+    sr = torch.randn(B, d, device=dev) * 0.3
+    E = torch.randn(V, d, device=dev) * 0.2
+    cs = torch.rand(V, device=dev) + 0.5
+    val, idx = ops.score_topk(sr, E, cs, K)
+    z = (sr.double() @ E.double().t()) * cs.double()
+    rv, ri = z.topk(K, dim=1)
+    close(val, rv.float(), what='top-k values', rtol=1e-4, atol=1e-4)
+    # ids must agree at every rank whose score is separated from both neighbours (and from the best excluded item) by
+    # more than the fp32 round-off of a d-term dot product
+    nxt = z.masked_fill(torch.zeros_like(z, dtype=torch.bool).scatter_(1, ri, True), -1e30).max(1)[0]
+    ext = torch.cat([torch.full_like(rv[:, :1], 1e30), rv, nxt[:, None]], 1)
+    sep = ((ext[:, :-2] - rv) > 1e-4) & ((rv - ext[:, 2:]) > 1e-4)
+    assert sep.float().mean() > 0.8
+    assert torch.equal(idx.long()[sep], ri[sep])
+    assert (val[:, :-1] >= val[:, 1:]).all()
+    # the ids returned always carry the returned values
+    close(z.gather(1, idx.long()).float(), val, what='values at the returned ids', rtol=1e-4, atol=1e-4)
