@@ -5,15 +5,75 @@ read_dataset :22-27, AugmentedDataset :29-50).
 On-disk format unchanged: train.txt / test.txt hold one session per line, comma-separated item
 ids; num_items.txt one integer.  (The reference's pandas `squeeze=` call no longer exists in
 pandas 2; plain parsing gives the same lists.)
+
+SessionStore is the binary form of the same data for the large splits (Yoochoose-1/4 = 6 M
+samples): all clicks in one int32 array + int64 session offsets (CSR), memory-mapped on load, with the prefix index
+built by vectorised numpy instead of Python lists.  `read_dataset(dir, cache=True)` writes / reuses
+`<split>.sstore.npz` next to the text files; every consumer (AugmentedDataset, collate) sees the same sequences.
 """
 from pathlib import Path
 
 import numpy as np
 
 
+class SessionStore:
+    """CSR container of click sessions: `items` int32 [total clicks], `offsets` int64 [n_sessions + 1].
+    Behaves like the reference's object array of lists (`len`, integer indexing -> the session's item ids)."""
+
+    def __init__(self, items, offsets):
+        self.items, self.offsets = items, offsets
+
+    @classmethod
+    def from_sessions(cls, sessions):
+        lens = np.fromiter((len(s) for s in sessions), dtype=np.int64, count=len(sessions))
+        offsets = np.zeros(len(sessions) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        items = np.empty(int(offsets[-1]), dtype=np.int32)
+        for i, s in enumerate(sessions):
+            items[offsets[i]:offsets[i + 1]] = s
+        return cls(items, offsets)
+
+    @classmethod
+    def from_text(cls, filepath):
+        """one session per line, comma separated (dataset.py:16-19) - parsed without building Python int lists"""
+        with open(filepath, 'rb') as f:
+            raw = f.read()
+        lines = [ln for ln in raw.split(b'\n') if ln.strip()]
+        lens = np.fromiter((ln.count(b',') + 1 for ln in lines), dtype=np.int64, count=len(lines))
+        offsets = np.zeros(len(lines) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        items = np.array(b','.join(lines).split(b','), dtype=np.int64).astype(np.int32) if lines else np.empty(0, np.int32)
+        assert items.size == offsets[-1]
+        return cls(items, offsets)
+
+    def save(self, path):
+        np.savez(path, items=self.items, offsets=self.offsets)
+
+    @classmethod
+    def load(cls, path, mmap=True):
+        z = np.load(path, mmap_mode='r' if mmap else None)
+        return cls(z['items'], z['offsets'])
+
+    def lengths(self):
+        return np.diff(self.offsets)
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def __getitem__(self, i):
+        return self.items[self.offsets[i]:self.offsets[i + 1]]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
 def create_index(sessions):
     """one sample per (session, label position >= 1), session-major: columns sessionId, labelIndex"""
-    lens = np.fromiter((len(s) for s in sessions), dtype=np.int64, count=len(sessions))
+    if isinstance(sessions, SessionStore):
+        lens = sessions.lengths()
+    else:
+        lens = np.fromiter((len(s) for s in sessions), dtype=np.int64, count=len(sessions))
     reps = np.maximum(lens - 1, 0)
     session_idx = np.repeat(np.arange(len(sessions)), reps)
     starts = np.cumsum(reps) - reps
@@ -33,10 +93,25 @@ def read_sessions(filepath):
     return arr
 
 
-def read_dataset(dataset_dir):
+def _read_split(dataset_dir, split, cache):
+    txt, binp = dataset_dir / (split + '.txt'), dataset_dir / (split + '.sstore.npz')
+    if not cache:
+        return read_sessions(txt)
+    if binp.exists() and binp.stat().st_mtime >= txt.stat().st_mtime:
+        return SessionStore.load(binp)
+    store = SessionStore.from_text(txt)
+    try:
+        store.save(binp)
+    except OSError:
+        pass                                  # read-only dataset directory: keep the in-memory store
+    return store
+
+
+def read_dataset(dataset_dir, cache=False):
+    """(train_sessions, test_sessions, num_items); cache=True -> SessionStore objects backed by `<split>.sstore.npz`"""
     dataset_dir = Path(dataset_dir)
-    train_sessions = read_sessions(dataset_dir / 'train.txt')
-    test_sessions = read_sessions(dataset_dir / 'test.txt')
+    train_sessions = _read_split(dataset_dir, 'train', cache)
+    test_sessions = _read_split(dataset_dir, 'test', cache)
     with open(dataset_dir / 'num_items.txt', 'r') as f:
         num_items = int(f.readline())
     return train_sessions, test_sessions, num_items
@@ -52,7 +127,8 @@ class AugmentedDataset:
 
     def __getitem__(self, idx):
         sid, lidx = self.index[idx]
-        return self.sessions[sid][:lidx], self.sessions[sid][lidx]
+        seq = self.sessions[sid]
+        return seq[:lidx], seq[lidx]
 
     def __len__(self):
         return len(self.index)

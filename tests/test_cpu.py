@@ -272,3 +272,28 @@ def test_native_collate_is_bit_identical_to_python_builder(kind, order, padded):
     assert nat.buf.numel() == ref.buf.numel()
     diff = torch.nonzero(nat.buf != ref.buf).reshape(-1)
     assert diff.numel() == 0, ('first differing word', int(diff[0]), [k for k, v in ref.layout.items() if v[0] <= int(diff[0]) < v[0] + v[1]])
+
+
+def test_session_store_equals_text_path(tmp_path):
+    """binary CSR session store: same sessions, same prefix-sample order, same collated batch as
+    the text reader; survives a save / memory-mapped load round trip and is reused by read_dataset(cache=True)."""
+    import shutil
+    ds, col = pkg('dataset'), pkg('collate')
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'datasets', 'sample')
+    for f in ('train.txt', 'test.txt', 'num_items.txt'):
+        shutil.copy(os.path.join(src, f), tmp_path / f)
+    tr, te, n = ds.read_dataset(tmp_path)
+    trs, tes, n2 = ds.read_dataset(tmp_path, cache=True)
+    assert n == n2 and isinstance(trs, ds.SessionStore) and (tmp_path / 'train.sstore.npz').exists()
+    trs2, _, _ = ds.read_dataset(tmp_path, cache=True)          # second call: memory-mapped reload
+    for a, b in ((tr, trs), (te, tes), (tr, trs2)):
+        assert len(a) == len(b)
+        assert all(list(x) == list(y) for x, y in zip(a, b))
+    A, S = ds.AugmentedDataset(tr), ds.AugmentedDataset(trs2)
+    assert np.array_equal(A.index, S.index)
+    ia, ib = [A[i] for i in range(64)], [S[i] for i in range(64)]
+    assert all(list(x[0]) == list(y[0]) and int(x[1]) == int(y[1]) for x, y in zip(ia, ib))
+    fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), 3)
+    (ba,), la = fn([(list(s), int(l)) for s, l in ia])
+    (bb,), lb = fn([(s, l) for s, l in ib])
+    assert torch.equal(ba.buf, bb.buf) and torch.equal(la, lb)
