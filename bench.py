@@ -104,7 +104,7 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20, force_fp32=False):
     loss = torch.empty((), device=dev)
     dE = torch.empty_like(table)
     dsr = torch.empty(B, d, device=dev)
-    bf16 = ops.use_bf16_scoring(d) and not force_fp32      # the row-sharded (N > 1) scoring runs the fp32 kernels
+    bf16 = ops.use_bf16_scoring(d) and not force_fp32
     tb = ops.TableBF16(table).refresh(table) if bf16 else None
 
     def fwd():
@@ -220,6 +220,7 @@ def main():
     ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
                     help="MFMA operand type of the forward / backward-data GEMMs ('bf16' = BASELINE config C3)")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
+    ap.add_argument('--shard', action='store_true', help='debug: row-sharded path + RCCL calls on a 1-rank communicator (set SREC_FORCE_COLLECTIVES=1)')
     ap.add_argument('--kernel-only', action='store_true', help='only launch the scoring/CE kernels (PMC collection target)')
     args = ap.parse_args()
 
@@ -227,9 +228,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or args.shard:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -247,14 +249,14 @@ def main():
         return
     n_batches = args.steps + args.warmup
     padded = True
-    use_graph = (not args.no_graph) and padded and world == 1       # N > 1: eager launches (RCCL inside)
+    use_graph = (not args.no_graph) and padded       # N > 1: the RCCL calls are captured in the step graph too
     batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank, padded=padded)
     torch.manual_seed(123)
     model = build_model(sp, args.model, V, d, args.order)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     shard = None
-    if world > 1:                                  # item table row-sharded over the node's GPUs (RCCL / xGMI)
+    if world > 1 or args.shard:                    # item table row-sharded over the node's GPUs (RCCL / xGMI)
         D = importlib.import_module('sessionrec-pytorch_amd.dist')
         cap = None
         if padded:                                 # equal padded request length on every rank: no size exchange
@@ -275,16 +277,24 @@ def main():
         loss = model.fused_loss(*inp, lab)
         loss.backward()
         if shard is not None:
-            shard.sync_replicated_grads(replicated)
+            shard.sync_replicated_grads(replicated, opt)
         opt.step()
         return loss
 
     if use_graph:
         G = importlib.import_module('sessionrec-pytorch_amd.graph')
-        gstep = G.GraphedTrainStep(model, opt, dev_batches[0][0], dev_batches[0][1])
+        eager_step = step
+        try:
+            gstep = G.GraphedTrainStep(model, opt, dev_batches[0][0], dev_batches[0][1],
+                                       after_backward=(lambda: shard.sync_replicated_grads(replicated, opt)) if shard is not None else None)
 
-        def step(b):                                   # noqa: F811  (replay of the captured step)
-            return gstep(b[0], b[1])
+            def step(b):                               # noqa: F811  (replay of the captured step)
+                return gstep(b[0], b[1])
+        except Exception as e:                         # capture of the collectives refused: eager launches
+            if shard is None:
+                raise
+            print('graph capture with RCCL failed (%s: %s); running eager' % (type(e).__name__, e), file=sys.stderr, flush=True)
+            use_graph, step = False, eager_step
     for i in range(args.warmup):
         step(dev_batches[i])
     torch.cuda.synchronize()
@@ -307,7 +317,7 @@ def main():
 
     if rank == 0:
         Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
-        kt = time_dominant_kernel(model, B * world, Vk, d, dev, force_fp32=shard is not None)
+        kt = time_dominant_kernel(model, B * world, Vk, d, dev)
         Bg = B * world
         kms = {k: v * 1e3 for k, v in kt.items() if k != 'bf16'}
         if kt['bf16']:

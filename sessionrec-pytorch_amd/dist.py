@@ -21,8 +21,14 @@ collective per exchange, no ring of tiny messages).  The local compute goes thro
 object with the HIP kernels (HipLocal); tests drive the same algebra on CPU/gloo with a plain-torch
 stand-in to prove the collectives reassemble the single-device result.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# SREC_FORCE_COLLECTIVES=1: issue the RCCL calls even on a 1-rank communicator (they are then copies) - lets the
+# collective sequence and its hipGraph capture be exercised on a single-GPU box (bench.py --shard)
+FORCE = bool(os.environ.get('SREC_FORCE_COLLECTIVES'))
 
 
 # ------------------------------------------------------------------------------- collectives
@@ -37,7 +43,7 @@ def _rank(group=None):
 def all_gather_cat(t, group=None):
     """[n, ...] per rank -> [world*n, ...] (same n everywhere)"""
     w = _world(group)
-    if w == 1:
+    if w == 1 and not (FORCE and dist.is_initialized()):
         return t
     t = t.contiguous()
     out = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
@@ -51,7 +57,7 @@ def all_gather_cat(t, group=None):
 def reduce_scatter_sum(t, group=None):
     """[world*n, ...] per rank -> [n, ...]: rank r receives the sum over ranks of block r"""
     w = _world(group)
-    if w == 1:
+    if w == 1 and not (FORCE and dist.is_initialized()):
         return t
     t = t.contiguous()
     n = t.shape[0] // w
@@ -66,7 +72,7 @@ def reduce_scatter_sum(t, group=None):
 
 
 def all_reduce_sum(t, group=None):
-    if _world(group) > 1:
+    if _world(group) > 1 or (FORCE and dist.is_initialized()):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -94,14 +100,24 @@ class HipLocal:
         return out
 
     def segment_rows(self, g, uniq):
-        """one summed row per distinct item of the local batch: [U, d]"""
+        """one summed row per distinct item of the local batch: [U, d].  With the (cptr, chunk_ptr) pair of the FlatBatch
+        the sum runs in two balanced levels (<= 16 positions per wavefront, then the pieces of each item): a
+        Zipf-popular item would otherwise serialise ~1000 row reads in one wavefront."""
         from ._lib import lib, ptr, stream
         items, uptr, upos = uniq[:3]
         U, d = items.numel(), g.shape[1]
         g = g.contiguous()
-        out = torch.zeros(U, d, device=g.device, dtype=torch.float32)
-        ar = self.ops._arange(U + 1, g.device)
-        lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(uptr), ptr(upos), ptr(out), d, U, None, d, 0, stream())
+        out = torch.empty(U, d, device=g.device, dtype=torch.float32)
+        if len(uniq) == 5:
+            cptr, chunk_ptr = uniq[3], uniq[4]
+            C = chunk_ptr.numel() - 1
+            part = torch.empty(max(C, 1), d, device=g.device, dtype=torch.float32)
+            ar = self.ops._arange(max(C, U) + 1, g.device)
+            lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, d, 0, stream())
+            lib.srec_scatter_add_sorted(ptr(part), d, ptr(ar), ptr(cptr), ptr(ar), ptr(out), d, U, None, d, 0, stream())
+        else:
+            ar = self.ops._arange(U + 1, g.device)
+            lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(uptr), ptr(upos), ptr(out), d, U, None, d, 0, stream())
         return out
 
     def add_rows(self, rows, items_local, dst):
@@ -112,26 +128,33 @@ class HipLocal:
         lib.srec_scatter_add_sorted(ptr(rows), d, ptr(items_local), ptr(ar), ptr(ar), ptr(dst), dst.stride(0), U, None,
                                     d, 1, stream())
 
+    def _tb(self, table, refresh):
+        """bf16 operand copies of this rank's shard when set_precision('bf16') is on (refreshed once per step)"""
+        ops = self.ops
+        if not ops.use_bf16_scoring(table.shape[1]):
+            return None
+        key = (table.data_ptr(), tuple(table.shape))
+        tb = self.__dict__.setdefault('_tb16', {}).get(key)
+        if tb is None:
+            tb = self._tb16[key] = ops.TableBF16(table)
+            refresh = True
+        return tb.refresh(table) if refresh else tb
+
     def ce_fwd(self, sr, table, cs, labels_local, ws):
-        from ._lib import lib, ptr, stream
         B, d = sr.shape
         dev = sr.device
         lse = torch.empty(B, device=dev, dtype=torch.float32)
         lossvec = torch.empty(B, device=dev, dtype=torch.float32)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         ws.lab_logit.zero_()
-        lib.srec_score_ce_fwd(ptr(sr), sr.stride(0), ptr(table), table.stride(0), ptr(cs), ptr(labels_local), B,
-                              table.shape[0], d, None, ptr(ws.stats), ptr(ws.lab_logit), ptr(lse), ptr(lossvec), ptr(loss),
-                              stream())
+        self.ops._ce_fwd(sr, table, cs, labels_local, ws, None, self._tb(table, True), ws.lab_logit, lse, lossvec, loss)
         return lse, ws.lab_logit.clone()
 
     def ce_bwd(self, sr, table, cs, labels_local, lse, gscale, dE, ws, cs_inv_scale):
         from ._lib import lib, ptr, stream
         B, d = sr.shape
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
-        lib.srec_score_ce_bwd(ptr(sr), sr.stride(0), ptr(table), table.stride(0), ptr(cs), ptr(labels_local), ptr(lse),
-                              ptr(gscale), None, None, B, table.shape[0], d, None, ptr(dE), dE.stride(0), ptr(ws.dsr_part), ptr(dsr),
-                              3, stream())
+        self.ops._ce_bwd(sr, table, cs, labels_local, lse, gscale, None, None, ws, None, self._tb(table, False), dE, dsr, 3)
         if cs is not None:
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), cs_inv_scale, ptr(dE), dE.stride(0),
                                      table.shape[0], d, stream())
@@ -158,8 +181,8 @@ class ShardedLookup(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        items_pad, uptr, upos = ctx.uniq_pad                 # items padded with -1 to a common capacity
-        rows = ctx.local.segment_rows(g, (items_pad, uptr, upos))
+        items_pad = ctx.uniq_pad[0]                           # items padded with -1 to a common capacity
+        rows = ctx.local.segment_rows(g, ctx.uniq_pad)
         rows_all = all_gather_cat(rows, ctx.group)
         items_all = all_gather_cat(items_pad, ctx.group)
         w = _world(ctx.group)
@@ -249,7 +272,14 @@ class VocabParallel:
         items_pad = self._pad(items.to(torch.int64), cap)
         uptr_pad = torch.full((cap + 1,), int(n), device=idx.device, dtype=torch.int32)
         uptr_pad[:U + 1] = uptr
-        rows = ShardedLookup.apply(table, idx_pad, (items_pad, uptr_pad, upos), self.dE, self.lo, self.local, self.group)
+        uq = (items_pad, uptr_pad, upos)
+        if len(uniq) == 5:                                    # chunked CSR of the FlatBatch: balanced two-level sums
+            cptr, chunk_ptr = uniq[3], uniq[4]
+            C = chunk_ptr.numel() - 1
+            cptr_pad = torch.full((cap + 1,), C, device=idx.device, dtype=torch.int32)   # padded items: empty chunk lists
+            cptr_pad[:U + 1] = cptr[:U + 1]
+            uq = uq + (cptr_pad, chunk_ptr)
+        rows = ShardedLookup.apply(table, idx_pad, uq, self.dE, self.lo, self.local, self.group)
         return rows[:n]
 
     def loss(self, sr, table, cs, labels, cs_inv_scale):
@@ -264,17 +294,24 @@ class VocabParallel:
         self.tgrad.fresh = True                      # the backward of `out` overwrites every live row of dE
         return out
 
-    def sync_replicated_grads(self, params):
-        """sum the replicated-parameter gradients over ranks in one flat bucket"""
-        if self.world == 1:
+    def sync_replicated_grads(self, params, optimizer=None):
+        """sum the replicated-parameter gradients over ranks in one flat bucket.  With `optimizer` (FusedAdam) the
+        reduced bucket is handed over as the gradient source (views), so nothing is copied back per parameter."""
+        if self.world == 1 and not (FORCE and dist.is_initialized()):
             return
-        gs = [p.grad for p in params if p.grad is not None]
-        if not gs:
+        ps = [p for p in params if p.grad is not None]
+        if not ps:
             return
-        flat = torch.cat([g.reshape(-1) for g in gs])
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         off = 0
-        for g in gs:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+        views = {}
+        for p in ps:
+            n = p.numel()
+            views[id(p)] = flat[off:off + n].view_as(p)
             off += n
+        if optimizer is not None and hasattr(optimizer, 'grad_override'):
+            optimizer.grad_override = views
+        else:
+            for p in ps:
+                p.grad.copy_(views[id(p)])

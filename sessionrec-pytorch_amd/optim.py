@@ -35,8 +35,12 @@ class FusedAdam(torch.optim.Optimizer):
                 tgrad = st['tgrad']
         return table, tgrad, st
 
+    grad_override = None      # {id(param): tensor}: gradients to use instead of p.grad (the all-reduced flat bucket)
+
     def _grad_of(self, p, table, tgrad, zero_ids):
         g = p.grad
+        if g is not None and self.grad_override and id(p) in self.grad_override:
+            g = self.grad_override[id(p)]
         if table is not None and p is table and tgrad is not None:
             g = tgrad.buf if g is None else g.add_(tgrad.buf)
         if g is None and id(p) in zero_ids:
