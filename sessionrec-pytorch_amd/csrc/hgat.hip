@@ -138,15 +138,10 @@ struct AggArgs {
     float slope;
 };
 
-// Index data of ALL relation instances into the node is resolved up front by the whole workgroup (instance extents
-// -> flattened edge list -> source ids: three dependent round trips in total instead of five per instance), then every
-// wave (= head) does its soft-maxes and the row gathers with all loads independent.
 template <typename T>
 __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
     __shared__ float sc[MAXH][MAXDEG];
-    __shared__ int su[MAXDEG];            // source node of every in-edge, all instances back to back
-    __shared__ int se[MAXDEG];            // ... and its edge id
-    __shared__ int ibeg[9];               // prefix of the per-instance degrees
+    __shared__ int su[MAXH][MAXDEG];
     __shared__ float comb[MAXH][256];
     const int row = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int H = a.H, D = a.D, HD = H * D;
@@ -154,82 +149,49 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
     const int v = row - a.row0[t];
     const bool live = v < dyn_count(a.dyn_n[t], a.ncap[t]);
     const int c = lane * 4;
-    const int ni = live ? a.ninst[t] : 0;
-    if (w == 0) {
-        int deg = 0, beg = 0;
-        if (lane < ni) {
-            const int* ip = a.in_ptr[a.inst[t][lane]];
-            beg = ip[v];
-            deg = ip[v + 1] - beg;
-        }
-        // exclusive prefix over the (<= 8) instances, clamped to MAXDEG edges in total
-        int pre = deg;
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            const int u = __shfl_up(pre, o, 64);
-            if (lane >= o) pre += u;
-        }
-        const int excl = min(pre - deg, MAXDEG);
-        deg = min(deg, MAXDEG - excl);
-        if (lane < ni) ibeg[lane] = excl;
-        if (lane == ni) ibeg[ni] = excl;            // lane ni has deg 0: its exclusive prefix is the total
-        // flattened edge slots: instance q owns slots [excl_q, excl_q + deg_q)
-        for (int q = 0; q < ni; ++q) {
-            const int qb = __shfl(beg, q, 64), qd = __shfl(deg, q, 64), qe = __shfl(excl, q, 64);
-            const int i = a.inst[t][q];
-            for (int j = lane; j < qd; j += 64) {
-                const int e = a.in_idx[i][qb + j];
-                se[qe + j] = e;
-                su[qe + j] = a.esrc[i][e];
-            }
-        }
-    }
-    __syncthreads();
     if (w < H) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) {
-            // scores of every edge of every instance (independent loads), then one soft-max per instance segment
-            for (int q = 0; q < ni; ++q) {
+            for (int q = 0; q < a.ninst[t]; ++q) {
                 const int i = a.inst[t][q];
-                const int e0 = ibeg[q], e1 = ibeg[q + 1];
+                const int* ip = a.in_ptr[i];
+                const int beg = ip[v], deg = min(ip[v + 1] - beg, MAXDEG);
+                const int* idx = a.in_idx[i] + beg;
+                for (int j = lane; j < deg; j += 64) su[w][j] = a.esrc[i][idx[j]];
+                __builtin_amdgcn_wave_barrier();
                 const float erv = a.eRd[i][(size_t)v * H + w];
-                for (int j = e0 + lane; j < e1; j += 64) {
-                    float s = a.eLs[i][(size_t)su[j] * H + w] + erv;
-                    sc[w][j] = s > 0.f ? s : a.slope * s;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (int q = 0; q < ni; ++q) {
-                const int i = a.inst[t][q];
-                const int e0 = ibeg[q], e1 = ibeg[q + 1];
                 float m = -INFINITY;
-                for (int j = e0 + lane; j < e1; j += 64) m = fmaxf(m, sc[w][j]);
+                for (int j = lane; j < deg; j += 64) {
+                    float s = a.eLs[i][(size_t)su[w][j] * H + w] + erv;
+                    s = s > 0.f ? s : a.slope * s;
+                    sc[w][j] = s;
+                    m = fmaxf(m, s);
+                }
                 m = wave_max(m);
                 float z = 0.f;
-                for (int j = e0 + lane; j < e1; j += 64) z += expf(sc[w][j] - m);
+                for (int j = lane; j < deg; j += 64) z += expf(sc[w][j] - m);
                 z = wave_sum(z);
-                const float iz = e1 > e0 ? 1.f / z : 0.f;
-                for (int j = e0 + lane; j < e1; j += 64) {
+                const float iz = deg > 0 ? 1.f / z : 0.f;
+                for (int j = lane; j < deg; j += 64) {
                     const float p = expf(sc[w][j] - m) * iz;
                     sc[w][j] = p;
-                    a.A[i][(size_t)se[j] * H + w] = p;
+                    a.A[i][(size_t)idx[j] * H + w] = p;
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (c < D) {
-                for (int q = 0; q < ni; ++q) {
-                    const int i = a.inst[t][q];
+                __builtin_amdgcn_wave_barrier();
+                if (c < D) {
                     const T* ps = static_cast<const T*>(a.Ps[i]) + w * D + c;
-                    const int e0 = ibeg[q], e1 = ibeg[q + 1];
-                    for (int j = e0; j < e1; ++j) {
+                    for (int j = 0; j < deg; ++j) {
                         const float p = sc[w][j];
-                        const float4 f = ld4(ps + (size_t)su[j] * HD);
+                        const float4 f = ld4(ps + (size_t)su[w][j] * HD);
                         acc.x += p * f.x; acc.y += p * f.y; acc.z += p * f.z; acc.w += p * f.w;
                     }
                     const float4 bv = *reinterpret_cast<const float4*>(a.bias[i] + w * D + c);
                     acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
                 }
-                const float nres = (float)ni;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (c < D) {
+                const float nres = (float)a.ninst[t];
                 const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)row * a.ld_x + c);
                 acc.x += nres * xv.x; acc.y += nres * xv.y; acc.z += nres * xv.z; acc.w += nres * xv.w;
             }
