@@ -43,6 +43,12 @@ typedef struct {
     float* d_attn_l[SREC_HG_MAXM];
     float* d_attn_r[SREC_HG_MAXM];
     float* d_bias[SREC_HG_MAXM];
+    /* dropout (all NULL when off): xin[m] = the feature-dropped input matrix module m projects ([NT, D], same row
+     * layout as x); xres [NT, D] = residual rows already summed over the instances; rm [NT, D] = their per-element
+     * scale (the d x factor of g); Mk[i] [E, H] = attention-dropout mask of instance i, 0 or 1/(1-p) */
+    const float* xin[SREC_HG_MAXM];
+    const float* xres;
+    const float* rm;
     /* projection blocks */
     int blk_mod[SREC_HG_MAXB], blk_type[SREC_HG_MAXB], blk_row[SREC_HG_MAXB];
     float* eL[SREC_HG_MAXB];
@@ -60,6 +66,7 @@ typedef struct {
     float* A[SREC_HG_MAXI];
     float* DP[SREC_HG_MAXI];
     float* der[SREC_HG_MAXI];
+    const float* Mk[SREC_HG_MAXI];
 } srec_hg_desc;
 
 /* problem table of srec_gemm_group_bf16 (srec.h) */

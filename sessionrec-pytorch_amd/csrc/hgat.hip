@@ -89,7 +89,7 @@ struct DotsArgs {
     int ncap[MAXB], row0[MAXB];
     int start[MAXB + 1];     // first thread block of each projection block
     int nb, H, D;
-    const float* x; int ld_x;
+    const float* x[MAXB]; int ld_x;          // the module's (possibly feature-dropped) input rows
 };
 
 // one wavefront per (projection block, node): lane = (output = lane & 15 -> (l/r, head), quarter of the columns = lane >> 4)
@@ -102,7 +102,7 @@ __global__ void hg_dots_kernel(DotsArgs a) {
     const int o = lane & 15, part = lane >> 4, lr = o >> 3, h = o & 7;
     float s = 0.f;
     if (live && h < H) {
-        const float* xr = a.x + (size_t)(a.row0[b] + n) * a.ld_x;
+        const float* xr = a.x[b] + (size_t)(a.row0[b] + n) * a.ld_x;
         const float* v = a.V[b] + (size_t)lr * D * H + h;
         const int q = D >> 2;                          // D % 16 == 0 in practice; D % 4 == 0 guaranteed
         float s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -131,7 +131,9 @@ struct AggArgs {
     const void* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* bias[MAXI];
     const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
     float* A[MAXI];
+    const float* Mk[MAXI];              // attention dropout: 0 or 1/(1-p) per (edge, head); NULL = none
     const float* x; int ld_x;
+    const float* xres;                  // residual rows already summed over the instances (feature dropout); NULL -> n_inst * x
     float* out; int ld_out;
     unsigned char* arg;
     int H, D;
@@ -172,10 +174,11 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
                 for (int j = lane; j < deg; j += 64) z += expf(sc[w][j] - m);
                 z = wave_sum(z);
                 const float iz = deg > 0 ? 1.f / z : 0.f;
+                const float* mk = a.Mk[i];
                 for (int j = lane; j < deg; j += 64) {
                     const float p = expf(sc[w][j] - m) * iz;
-                    sc[w][j] = p;
-                    a.A[i][(size_t)idx[j] * H + w] = p;
+                    a.A[i][(size_t)idx[j] * H + w] = p;                       // soft-max value (the backward needs it)
+                    sc[w][j] = mk != nullptr ? p * mk[(size_t)idx[j] * H + w] : p;   // what the aggregation uses
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (c < D) {
@@ -191,9 +194,14 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
                 __builtin_amdgcn_wave_barrier();
             }
             if (c < D) {
-                const float nres = (float)a.ninst[t];
-                const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)row * a.ld_x + c);
-                acc.x += nres * xv.x; acc.y += nres * xv.y; acc.z += nres * xv.z; acc.w += nres * xv.w;
+                if (a.xres != nullptr) {
+                    const float4 xv = *reinterpret_cast<const float4*>(a.xres + (size_t)row * a.ld_x + c);
+                    acc.x += xv.x; acc.y += xv.y; acc.z += xv.z; acc.w += xv.w;
+                } else {
+                    const float nres = (float)a.ninst[t];
+                    const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)row * a.ld_x + c);
+                    acc.x += nres * xv.x; acc.y += nres * xv.y; acc.z += nres * xv.z; acc.w += nres * xv.w;
+                }
             }
         }
         if (c < D) *reinterpret_cast<float4*>(&comb[w][c]) = acc;
@@ -230,6 +238,7 @@ struct PreArgs {
     int nt, B, D;
     const int* dynB;
     const float* g; int ld_g;
+    const float* rm;                    // [NT, D] per-element residual scale (feature dropout); NULL -> n_inst
     float* dx; int ld_dx;
 };
 
@@ -257,8 +266,10 @@ __global__ void hg_pre_kernel(PreArgs a) {
         }
         const float inv = 1.f / (float)(s1 - s0 > 0 ? s1 - s0 : 1), nres = (float)a.ninst[t];
         const float4 gv = *reinterpret_cast<const float4*>(a.g + (size_t)row * a.ld_g + c);
-        o.x = o.x * inv + nres * gv.x; o.y = o.y * inv + nres * gv.y;
-        o.z = o.z * inv + nres * gv.z; o.w = o.w * inv + nres * gv.w;
+        float4 rs = make_float4(nres, nres, nres, nres);
+        if (a.rm != nullptr) rs = *reinterpret_cast<const float4*>(a.rm + (size_t)row * a.D + c);
+        o.x = o.x * inv + rs.x * gv.x; o.y = o.y * inv + rs.y * gv.y;
+        o.z = o.z * inv + rs.z * gv.z; o.w = o.w * inv + rs.w * gv.w;
     }
     *reinterpret_cast<float4*>(a.dx + (size_t)row * a.ld_dx + c) = o;
 }
@@ -274,6 +285,7 @@ struct DstArgs {
     const void* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* A[MAXI];
     const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
     float* DP[MAXI]; float* der[MAXI];
+    const float* Mk[MAXI];
     const int* dyn_d[MAXI];
     int ncap_d[MAXI], row0_d[MAXI];
     int start[MAXI + 1];
@@ -335,6 +347,7 @@ __global__ void hg_bwd_dst_kernel(DstArgs a) {
             float t = ph[0];
 #pragma unroll
             for (int h = 1; h < MAXH; ++h) t = lane == h ? ph[h] : t;
+            if (a.Mk[i] != nullptr && lane < H) t *= a.Mk[i][(size_t)idx[j] * H + lane];   // d a = d a_dropped * mask
             da[w][j][lane] = t;
         }
     }
@@ -365,7 +378,7 @@ struct SrcArgs {
     int ncap[MAXB], nsrc[MAXB], ndst[MAXB], src[MAXB][4], dst[MAXB][4];
     int start[MAXB + 1];
     // instances
-    const float* A[MAXI]; const float* DP[MAXI]; const float* der[MAXI];
+    const float* A[MAXI]; const float* DP[MAXI]; const float* der[MAXI]; const float* Mk[MAXI];
     const int* out_ptr[MAXI]; const int* out_idx[MAXI]; const int* edst[MAXI];
     int row0_d[MAXI];
     int nb, H, D;
@@ -408,10 +421,11 @@ __global__ void hg_bwd_src_kernel(SrcArgs a) {
                     const float4 gv = *reinterpret_cast<const float4*>(a.g + row * a.ld_g + c);
                     const uchar4 bi = *reinterpret_cast<const uchar4*>(a.arg + row * D + c);
                     const float* ae = a.A[i] + (size_t)e * H;
+                    const float* me = a.Mk[i] != nullptr ? a.Mk[i] + (size_t)e * H : nullptr;
 #pragma unroll
                     for (int h = 0; h < MAXH; ++h) {
                         if (h < H) {
-                            const float p = ae[h];
+                            const float p = me != nullptr ? ae[h] * me[h] : ae[h];
                             o[h].x += bi.x == h ? p * gv.x : 0.f; o[h].y += bi.y == h ? p * gv.y : 0.f;
                             o[h].z += bi.z == h ? p * gv.z : 0.f; o[h].w += bi.w == h ? p * gv.w : 0.f;
                         }
@@ -458,7 +472,7 @@ struct ColArgs {
     int nt, nm, H, D;
     const float* g; int ld_g;
     const unsigned char* arg;
-    const float* x; int ld_x;
+    const float* xb[MAXB]; int ld_x;
     float* part;             // [nt + nm][NCHUNK][2 * H*D]
 };
 
@@ -501,7 +515,7 @@ __global__ void hg_colsum_part_kernel(ColArgs a) {
                     float xv[4], lv[4], rv[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        xv[e] = a.x[(size_t)(a.row0_b[b] + r + 4 * e) * a.ld_x + c];
+                        xv[e] = a.xb[b][(size_t)(a.row0_b[b] + r + 4 * e) * a.ld_x + c];
                         lv[e] = a.wL[b][(size_t)(r + 4 * e) * H + h];
                         rv[e] = a.wR[b][(size_t)(r + 4 * e) * H + h];
                     }
@@ -509,7 +523,7 @@ __global__ void hg_colsum_part_kernel(ColArgs a) {
                     for (int e = 0; e < 4; ++e) { s0 += xv[e] * lv[e]; s1 += xv[e] * rv[e]; }
                 }
                 for (; r < r1; r += 4) {
-                    const float xv = a.x[(size_t)(a.row0_b[b] + r) * a.ld_x + c];
+                    const float xv = a.xb[b][(size_t)(a.row0_b[b] + r) * a.ld_x + c];
                     s0 += xv * a.wL[b][(size_t)r * H + h];
                     s1 += xv * a.wR[b][(size_t)r * H + h];
                 }
@@ -615,11 +629,12 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     }
     if (d->n_blocks > 0) {
         DotsArgs a{};
-        a.nb = d->n_blocks; a.H = H; a.D = D; a.x = x; a.ld_x = ld_x;
+        a.nb = d->n_blocks; a.H = H; a.D = D; a.ld_x = ld_x;
         int blocks = 0;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
             a.V[b] = d->V[m];
+            a.x[b] = d->xin[m] != nullptr ? d->xin[m] : x;
             a.eL[b] = d->eL[b]; a.eR[b] = d->eR[b];
             a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t]; a.row0[b] = d->row0[t];
             a.start[b] = blocks;
@@ -630,7 +645,7 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     }
     AggArgs g{};
     g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;
-    g.x = x; g.ld_x = ld_x; g.out = out; g.ld_out = ld_out; g.arg = arg;
+    g.x = x; g.ld_x = ld_x; g.out = out; g.ld_out = ld_out; g.arg = arg; g.xres = d->xres;
     int rows = 0;
     for (int t = 0; t < d->n_types; ++t) {
         if (d->row0[t] != rows) return SREC_BAD_ARG;            // types must tile the stacked matrix
@@ -646,7 +661,7 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         g.Ps[i] = (const char*)d->P[m] + (size_t)d->blk_row[sb] * HD * esz;
         g.eLs[i] = d->eL[sb]; g.eRd[i] = d->eR[db]; g.bias[i] = d->bias[m];
         g.in_ptr[i] = d->in_ptr[i]; g.in_idx[i] = d->in_idx[i]; g.esrc[i] = d->esrc[i];
-        g.A[i] = d->A[i];
+        g.A[i] = d->A[i]; g.Mk[i] = d->Mk[i];
     }
     if (rows > 0) {
         if (d->p16) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
@@ -668,7 +683,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
     int rows = 0;
     {
         PreArgs a{};
-        a.nt = d->n_types; a.B = d->B; a.D = D; a.dynB = d->dynB; a.g = g; a.ld_g = ld_g; a.dx = dx; a.ld_dx = ld_dx;
+        a.nt = d->n_types; a.B = d->B; a.D = D; a.dynB = d->dynB; a.g = g; a.ld_g = ld_g; a.dx = dx; a.ld_dx = ld_dx; a.rm = d->rm;
         for (int t = 0; t < d->n_types; ++t) {
             a.seg[t] = d->seg[t]; a.dyn_n[t] = d->dyn_n[t]; a.row0[t] = d->row0[t]; a.ncap[t] = d->ncap[t];
             a.ninst[t] = ninst_t[t];
@@ -686,7 +701,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             a.Ps[i] = (const char*)d->P[m] + (size_t)d->blk_row[sb] * HD * esz;
             a.eLs[i] = d->eL[sb]; a.eRd[i] = d->eR[db]; a.A[i] = d->A[i];
             a.in_ptr[i] = d->in_ptr[i]; a.in_idx[i] = d->in_idx[i]; a.esrc[i] = d->esrc[i];
-            a.DP[i] = d->DP[i]; a.der[i] = d->der[i];
+            a.DP[i] = d->DP[i]; a.der[i] = d->der[i]; a.Mk[i] = d->Mk[i];
             a.dyn_d[i] = d->dyn_n[t]; a.ncap_d[i] = d->ncap[t]; a.row0_d[i] = d->row0[t];
             a.start[i] = blocks;
             blocks += cdiv(d->ncap[t], WPB);
@@ -716,7 +731,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             if (a.nsrc[sb] >= 4 || a.ndst[db] >= 4) return SREC_BAD_ARG;
             a.src[sb][a.nsrc[sb]++] = i;
             a.dst[db][a.ndst[db]++] = i;
-            a.A[i] = d->A[i]; a.DP[i] = d->DP[i]; a.der[i] = d->der[i];
+            a.A[i] = d->A[i]; a.DP[i] = d->DP[i]; a.der[i] = d->der[i]; a.Mk[i] = d->Mk[i];
             a.out_ptr[i] = d->out_ptr[i]; a.out_idx[i] = d->out_idx[i]; a.edst[i] = d->edst[i];
             a.row0_d[i] = d->row0[d->blk_type[db]];
         }
@@ -728,9 +743,10 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
     {
         ColArgs a{};
         a.nt = d->n_types; a.nm = d->n_mods; a.H = H; a.D = D; a.g = g; a.ld_g = ld_g; a.arg = arg; a.part = ws;
-        a.x = x; a.ld_x = ld_x;
+        a.ld_x = ld_x;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
+            a.xb[b] = d->xin[m] != nullptr ? d->xin[m] : x;
             a.wL[b] = d->wL[b]; a.wR[b] = d->wR[b]; a.dyn_b[b] = d->dyn_n[t]; a.ncap_b[b] = d->ncap[t];
             a.row0_b[b] = d->row0[t];
             if (a.mod_nb[m] >= 4) return SREC_BAD_ARG;

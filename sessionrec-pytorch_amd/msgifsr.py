@@ -8,9 +8,11 @@ children only hold parameters.
 
 Documented deviations:
   * GATConv is run with zero-in-degree destinations zero-filled (the shipped module would raise);
-  * one fc projection per (GAT module, node type) is shared by every relation that uses it as
-    source or destination - identical to the reference whenever feat_drop == 0; with dropout the
-    reference draws an independent mask per (relation, role), here one mask per (conv, type);
+  * one fc projection per (GAT module, node type) is shared by every relation that uses it as source or destination -
+    identical to the reference whenever feat_drop == 0; with dropout (the scripts' default 0.1) the reference draws an
+    independent feature mask per (relation, role), here one mask per (conv, node type) - projection, attention logits
+    and the identity residual of that conv's modules see the same dropped rows; attention dropout is applied to the
+    edge soft-max inside the batched kernels (mask per (relation instance, edge, head));
   * the 'max'/'concat' reducers are not on the HIP path yet; `fusion` (order mixture, msgifsr.py:311-317) is: K
     fused scoring passes, the mixture on the (lse, label-logit) pairs; `extra` (repeat / explore mixture,
     msgifsr.py:281-305) never materialises the two masked (B, V) soft-maxes: the in-session log-sum-exp is a
@@ -98,7 +100,7 @@ class MSHGNN(nn.Module):
             types.append((r, nk, mg.dynp('N%d' % k), mg.field('seg%d' % k)))
             r += nk
         NT = r
-        mods, mod_id, blocks, blk_id, insts, params = [], {}, [], {}, [], []
+        mods, mod_id, blocks, blk_id, insts, params, mod_conv = [], {}, [], {}, [], [], []
         used = {}                                            # (conv index, etype) -> set of node types it touches
         live = [((s, et, d_), name) for (s, et, d_), name in mg.meta['rels'] if mg.count('E_' + name) > 0]
         for ci in (0, 1):
@@ -115,9 +117,8 @@ class MSHGNN(nn.Module):
                         r0, nr, dyn = 0, NT, None
                     mod_id[key] = len(mods)
                     mods.append((r0, nr, dyn))
+                    mod_conv.append(ci)
                     mod = conv.mods[et]
-                    if mod.attn_drop > 0 and self.training:
-                        raise NotImplementedError('attention dropout inside the fused GAT kernel')
                     params += [mod.fc.weight, mod.attn_l, mod.attn_r, mod.bias]
                 m = mod_id[key]
                 src_t, dst_t = (d_, s) if ci == 1 else (s, d_)
@@ -127,12 +128,14 @@ class MSHGNN(nn.Module):
                         blocks.append((m, k - 1))
                 insts.append((m, blk_id[(m, src_t)], blk_id[(m, dst_t)], self._graph(mg, name, ci == 1)))
         slope = self.conv1.mods['intra1'].negative_slope
-        return ops.HgPlan(8, D, slope, mg.B, mg.dynp('B'), types, mods, blocks, insts), params
+        return ops.HgPlan(8, D, slope, mg.B, mg.dynp('B'), types, mods, blocks, insts, mod_conv), params
 
     def forward_stacked(self, mg, x):
         """x: [NT, d] node features of all orders stacked (order-1 rows first) -> [NT, d]; one batched pass"""
         plan, params = self.plan(mg, x.shape[1])
-        return ops.hgat_layer(x, plan, params)
+        mod = self.conv1.mods['intra1']
+        drop = (mod.feat_drop, mod.attn_drop) if self.training and (mod.feat_drop > 0 or mod.attn_drop > 0) else None
+        return ops.hgat_layer(x, plan, params, drop)
 
     def forward(self, mg, feat):
         """feat: {k: [N_k, d]} -> {k: [N_k, d]}"""
@@ -284,8 +287,7 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             f = x if k == 1 else self.expander(x, k, dk, mg.dynp('GK%d' % k))
             feats[k] = ops.normalize(f, 0, dk) if self.norm else f
         self._s1_feat = feats[1]                           # the session's own item rows (normalised): `extra` in-session logits
-        fused = not (self.training and any(l.conv1.mods['intra1'].feat_drop > 0 for l in self.layers))
-        if fused and len(self.layers) > 0:
+        if len(self.layers) > 0:
             # all orders stacked once; every layer is one batched pass over all relations (ops.hgat_layer)
             stacked = feats[1] if K == 1 else torch.cat([feats[k] for k in range(1, K + 1)], 0)
             for layer in self.layers:

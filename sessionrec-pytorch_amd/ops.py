@@ -1186,10 +1186,11 @@ class HgDesc(_ct.Structure):
                 [('slope', _ct.c_float), ('p16', _ct.c_int), ('dynB', _ct.c_void_p),
                  ('row0', _ct.c_int * 4), ('ncap', _ct.c_int * 4), ('dyn_n', _ct.c_void_p * 4), ('seg', _ct.c_void_p * 4)] +
                 [(n, _ct.c_void_p * 8) for n in ('P', 'dP', 'W', 'V', 'Z', 'attn_l', 'attn_r', 'bias', 'd_attn_l', 'd_attn_r', 'd_bias')] +
+                [('xin', _ct.c_void_p * 8), ('xres', _ct.c_void_p), ('rm', _ct.c_void_p)] +
                 [(n, _ct.c_int * 16) for n in ('blk_mod', 'blk_type', 'blk_row')] +
                 [(n, _ct.c_void_p * 16) for n in ('eL', 'eR', 'wL', 'wR')] +
                 [(n, _ct.c_int * 16) for n in ('inst_mod', 'inst_sblk', 'inst_dblk')] +
-                [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der')])
+                [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der', 'Mk')])
 
 
 class GemmGroup(_ct.Structure):
@@ -1219,7 +1220,8 @@ class HgPlan:
     blocks:  [(module, type)]                                    projection blocks
     insts:   [(module, src_block, dst_block, (in_ptr, in_idx, out_ptr, out_idx, esrc, edst))]"""
 
-    def __init__(self, H, D, slope, B, dynB, types, modules, blocks, insts):
+    def __init__(self, H, D, slope, B, dynB, types, modules, blocks, insts, mod_conv=None):
+        self.mod_conv = mod_conv if mod_conv is not None else [0] * len(modules)      # 0: conv1, 1: conv2 (reversed graph)
         self.H, self.D, self.slope, self.B, self.dynB = H, D, slope, B, dynB
         self.types, self.modules, self.blocks, self.insts = types, modules, blocks, insts
         assert len(types) <= 4 and len(modules) <= 8 and len(blocks) <= 16 and len(insts) <= 16
@@ -1244,8 +1246,15 @@ class HgPlan:
                 off += n
         return off, lay
 
-    def fill(self, desc, small, lay, P, dP, params, grads):
+    def fill(self, desc, small, lay, P, dP, params, grads, drop=None):
         d = desc
+        if drop is not None:
+            xc, xres, rm, mk = drop[:4]
+            for m in range(len(self.modules)):
+                d.xin[m] = ptr(xc[self.mod_conv[m]])
+            d.xres, d.rm = ptr(xres), ptr(rm)
+            for i in range(len(self.insts)):
+                d.Mk[i] = ptr(mk[i]) if mk is not None else None
         d.H, d.D, d.slope, d.B = self.H, self.D, self.slope, self.B
         d.p16 = int(P[0].dtype == torch.bfloat16) if len(P) else 0
         d.n_types, d.n_mods, d.n_blocks, d.n_inst = len(self.types), len(self.modules), len(self.blocks), len(self.insts)
@@ -1281,39 +1290,62 @@ _HG_WS = {}
 
 class HGATLayer(torch.autograd.Function):
     """out = MSHGNN(x): all relation instances of conv1 / conv2 in one batched pass (csrc/hgat.hip) around the fc
-    GEMMs.  params = (fc.weight, attn_l, attn_r, bias) per module, in plan.modules order."""
+    GEMMs.  params = (fc.weight, attn_l, attn_r, bias) per module, in plan.modules order.
+    drop = (p_feat, p_attn) in training: feature dropout with ONE mask per (conv, node type) on the inputs of that
+    conv's GATConv modules (projection, logits and identity residual all see the dropped rows, gatconv.py:268-308;
+    the reference draws one mask per (relation, role) - documented deviation) and attention dropout on the edge
+    soft-max (gatconv.py:300)."""
 
     @staticmethod
-    def forward(ctx, x, plan, *params):
+    def forward(ctx, x, plan, drop, *params):
         x = _rows(x)
         NT, D = x.shape
         H = plan.H
         HD = H * D
         dev = x.device
-        grouped = PRECISION['matmul'] == 'bf16' and D % 8 == 0 and _ld(x) == D and len(plan.modules) <= 8
+        nm = len(plan.modules)
+        dstate = None
+        if drop is not None and (drop[0] > 0 or drop[1] > 0):
+            pf, pa = drop
+            ms = [(torch.rand_like(x) >= pf).to(x.dtype) / (1.0 - pf) if pf > 0 else torch.ones_like(x) for _ in range(2)]
+            xc = [x * ms[0], x * ms[1]]
+            cnt = torch.zeros(2, NT, 1, device=dev)
+            for (m, sb, db, gr) in plan.insts:
+                t0, nc = plan.types[plan.blocks[db][1]][:2]
+                cnt[plan.mod_conv[m], t0:t0 + nc] += 1.0
+            rm = cnt[0] * ms[0] + cnt[1] * ms[1]
+            xres = x * rm
+            mk = None
+            if pa > 0:
+                sizes = [max(gr[4].numel(), 1) * H for (_, _, _, gr) in plan.insts]
+                allm = (torch.rand(sum(sizes), device=dev) >= pa).to(x.dtype) / (1.0 - pa)
+                mk = list(torch.split(allm, sizes))
+            dstate = (xc, xres, rm, mk, ms)
+        xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
+        grouped = PRECISION['matmul'] == 'bf16' and D % 8 == 0 and _ld(x) == D and nm <= 8
         # bf16 GEMM path: the projections (and their gradients) are STORED as bf16 too - every pass over them is HBM bound
         P = [torch.empty(nr, HD, device=dev, dtype=torch.bfloat16 if grouped else torch.float32)
              for (r0, nr, dyn) in plan.modules]
         if grouped:
-            gemm_group(0, [(nr, HD, D, [(x[r0:r0 + nr], params[4 * m])], P[m], dyn)
+            gemm_group(0, [(nr, HD, D, [(xin(m)[r0:r0 + nr], params[4 * m])], P[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], D, D, HD, c16=True)
         else:
             for m, (r0, nr, dyn) in enumerate(plan.modules):
-                gemm_nt(x[r0:r0 + nr], _rows(params[4 * m]), P[m], None, dyn, 1 if dyn is not None else 0)
+                gemm_nt(xin(m)[r0:r0 + nr], _rows(params[4 * m]), P[m], None, dyn, 1 if dyn is not None else 0)
         nfl, lay = plan.scratch_layout()
         small = torch.empty(max(nfl, 1), device=dev, dtype=torch.float32)
         out = torch.empty(NT, D, device=dev, dtype=torch.float32)
         arg = torch.empty(NT, D, device=dev, dtype=torch.uint8)
         flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
-        desc = plan.fill(HgDesc(), small, lay, P, None, flat, None)
+        desc = plan.fill(HgDesc(), small, lay, P, None, flat, None, dstate)
         lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
         ctx.save_for_backward(x, small, arg, *P, *params)
-        ctx.plan, ctx.lay, ctx.grouped = plan, lay, grouped
+        ctx.plan, ctx.lay, ctx.grouped, ctx.dstate = plan, lay, grouped, dstate
         return out
 
     @staticmethod
     def backward(ctx, g):
-        plan, lay = ctx.plan, ctx.lay
+        plan, lay, dstate = ctx.plan, ctx.lay, ctx.dstate
         nm = len(plan.modules)
         x, small, arg = ctx.saved_tensors[:3]
         P = ctx.saved_tensors[3:3 + nm]
@@ -1329,7 +1361,7 @@ class HGATLayer(torch.autograd.Function):
         grads = torch.empty(nm, 3, HD, device=dev, dtype=torch.float32)
         dx = torch.empty(NT, D, device=dev, dtype=torch.float32)
         flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
-        desc = plan.fill(HgDesc(), small, lay, P, dP, flat, grads)
+        desc = plan.fill(HgDesc(), small, lay, P, dP, flat, grads, dstate)
         n = _ct.c_long()
         lib.srec_hg_ws_floats(_ct.addressof(desc), _ct.addressof(n))
         key = (dev.index, n.value)
@@ -1337,29 +1369,42 @@ class HGATLayer(torch.autograd.Function):
         if ws is None:
             ws = _HG_WS[key] = torch.empty(max(n.value, 1), device=dev, dtype=torch.float32)
         lib.srec_hg_bwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(g), _ld(g), ptr(arg), ptr(dx), D, ptr(ws), stream())
-        outs = []
+        xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
         gWs = [torch.empty_like(params[4 * m]) for m in range(nm)]
+        convs = (0, 1) if dstate is not None else (None,)
+        for cv in convs:
+            # d x of one node type = sum over the modules that project it: the module sum is the K loop (segments).
+            # With feature dropout the two convs see differently masked inputs: one masked contribution per conv.
+            tgt = dx if cv is None else torch.zeros(NT, D, device=dev, dtype=torch.float32)
+            mods = [m for m in range(nm) if cv is None or plan.mod_conv[m] == cv]
+            if ctx.grouped:
+                probs = []
+                for t, (t0, nc, dyn_t, _) in enumerate(plan.types):
+                    segs = [(dP[m][t0 - plan.modules[m][0]:t0 - plan.modules[m][0] + nc], params[4 * m]) for m in mods
+                            if plan.modules[m][0] <= t0 and t0 + nc <= plan.modules[m][0] + plan.modules[m][1]
+                            and any(bm == m and bt == t for bm, bt in plan.blocks)]
+                    if segs:
+                        probs.append((nc, D, HD, segs, tgt[t0:t0 + nc], dyn_t))
+                if probs:
+                    gemm_group(1, probs, HD, D, D, beta=1.0, a16=True)
+            else:
+                for m in mods:
+                    r0, nr, dyn = plan.modules[m]
+                    gemm_nn(dP[m], _rows(params[4 * m]), tgt[r0:r0 + nr], dyn, 1 if dyn is not None else 0, beta=1.0)
+            if cv is not None:
+                dx.addcmul_(tgt, dstate[4][cv])
         if ctx.grouped:
-            # d x of one node type = sum over the modules that project it: the module sum is the K loop (segments)
-            probs = []
-            for t, (t0, nc, dyn_t, _) in enumerate(plan.types):
-                segs = [(dP[m][t0 - r0:t0 - r0 + nc], params[4 * m]) for m, (r0, nr, _) in enumerate(plan.modules)
-                        if r0 <= t0 and t0 + nc <= r0 + nr and any(bm == m and bt == t for bm, bt in plan.blocks)]
-                if segs:
-                    probs.append((nc, D, HD, segs, dx[t0:t0 + nc], dyn_t))
-            gemm_group(1, probs, HD, D, D, beta=1.0, a16=True)
-            gemm_group(2, [(HD, D, nr, [(dP[m], x[r0:r0 + nr])], gWs[m], dyn)
+            gemm_group(2, [(HD, D, nr, [(dP[m], xin(m)[r0:r0 + nr])], gWs[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], HD, D, D, a16=True)
+        outs = []
         for m, (r0, nr, dyn) in enumerate(plan.modules):
             gW = gWs[m]
             if not ctx.grouped:
-                W = _rows(params[4 * m])
-                gemm_nn(dP[m], W, dx[r0:r0 + nr], dyn, 1 if dyn is not None else 0, beta=1.0)
-                gemm_tn(dP[m], x[r0:r0 + nr], gW, dyn)
+                gemm_tn(dP[m], xin(m)[r0:r0 + nr], gW, dyn)
             outs += [gW, grads[m, 0].view(params[4 * m + 1].shape), grads[m, 1].view(params[4 * m + 2].shape),
                      grads[m, 2].view(params[4 * m + 3].shape)]
-        return (dx, None) + tuple(outs)
+        return (dx, None, None) + tuple(outs)
 
 
-def hgat_layer(x, plan, params):
-    return HGATLayer.apply(x, plan, *params)
+def hgat_layer(x, plan, params, drop=None):
+    return HGATLayer.apply(x, plan, drop, *params)

@@ -262,3 +262,58 @@ def test_bf16_precision_within_stated_tolerance(dev, name):
         assert rel < 5e-3, 'bf16 loss trace off by %.3e' % rel
     finally:
         ops.set_precision('fp32')
+
+
+def test_mshgnn_layer_dropout_gradients_by_finite_differences(dev):
+    """The batched MSHGNN layer with feature + attention dropout (the reference scripts' default feat-drop 0.1,
+    main_msgifsr.py:42): with the RNG re-seeded before every call the masks are fixed, so autograd gradients of
+    sum(out * R) must match central differences in x, an fc weight, an attention vector and a bias."""
+    ops = pkg('ops')
+    name = 'msgifsr_K3_s32'
+    z, samples, init = load_golden(name)
+    V = init[[k for k in init if k.startswith('embedding')][0]].shape[0]
+    model = _build(name, init, V, dev)
+    (mg,), _ = _collate(name, samples)
+    mg = mg.to(dev)
+    layer = model.layers[0]
+    torch.manual_seed(3)
+    NT = sum(mg.meta['ncap'][k] for k in (1, 2, 3))
+    x0 = (torch.randn(NT, 32, device=dev) * 0.5)
+    R = torch.zeros(NT, 32, device=dev)               # a loss over few rows keeps |f| small: fp32 central differences
+    rows = torch.randperm(NT, device=dev)[:48]         # stay clean at a step small enough not to flip a head arg-max
+    R[rows] = torch.randn(48, 32, device=dev)
+    plan, params = layer.plan(mg, 32)
+    params = [p.detach().clone().requires_grad_() for p in params]
+
+    def f(x, ps):
+        torch.manual_seed(11)
+        return (ops.hgat_layer(x, plan, ps, (0.3, 0.3)) * R).sum()
+
+    x = x0.clone().requires_grad_()
+    f(x, params).backward()
+    # dropout really is active: the output differs from the no-dropout layer
+    with torch.no_grad():
+        assert (ops.hgat_layer(x0, plan, params, None) - ops.hgat_layer(x0, plan, params, (0.3, 0.3))).abs().max() > 1e-3
+    g = torch.Generator().manual_seed(0)
+    eps = 1e-3
+
+    def fd(t, idx):
+        base = t.detach().clone()
+        vals = []
+        for s in (+1, -1):
+            tt = base.clone()
+            tt.view(-1)[idx] += s * eps
+            with torch.no_grad():
+                vals.append(f(tt if t is x else x0, [tt if p is t else p.detach() for p in params]).item())
+        return (vals[0] - vals[1]) / (2 * eps)
+
+    checked = 0
+    for t in (x, params[0], params[1], params[2], params[3], params[12]):
+        n = t.numel()
+        for idx in torch.randint(0, n, (12,), generator=g).tolist():
+            num, ana = fd(t, idx), t.grad.view(-1)[idx].item()
+            if abs(num) < 1e-4 and abs(ana) < 1e-4:
+                continue
+            assert abs(num - ana) <= 3e-2 * max(abs(num), abs(ana)) + 3e-3, (tuple(t.shape), idx, num, ana)
+            checked += 1
+    assert checked >= 10
