@@ -13,7 +13,7 @@ Documented deviations:
     independent feature mask per (relation, role), here one mask per (conv, node type) - projection, attention logits
     and the identity residual of that conv's modules see the same dropped rows; attention dropout is applied to the
     edge soft-max inside the batched kernels (mask per (relation instance, edge, head));
-  * the 'max'/'concat' reducers are not on the HIP path yet; `fusion` (order mixture, msgifsr.py:311-317) is: K
+  * `fusion` (order mixture, msgifsr.py:311-317) is: K
     fused scoring passes, the mixture on the (lse, label-logit) pairs; `extra` (repeat / explore mixture,
     msgifsr.py:281-305) never materialises the two masked (B, V) soft-maxes: the in-session log-sum-exp is a
     [B, <=L] dot product against the session's own (already gathered) item rows and the out-of-session one follows
@@ -62,9 +62,18 @@ class SemanticExpander(nn.Module):
 
     def forward(self, x, k, dyn=None, dyn_rows=None):
         """x: [N_k * k, d] gathered gram rows (contiguous) -> [N_k, d]"""
-        if self.reducer != 'mean':
-            raise NotImplementedError("reducer '%s' is not on the HIP path yet (only 'mean')" % self.reducer)
-        return ops.gru_expand(x, self.GRUs[k - 2], k, dyn, dyn_rows)
+        if self.reducer == 'mean':
+            return ops.gru_expand(x, self.GRUs[k - 2], k, dyn, dyn_rows)          # 0.5 mean_t x + 0.5 h_last, one node
+        var = ops.gru_expand(x, self.GRUs[k - 2], k, dyn, dyn_rows, combine=False)
+        n, d = x.shape[0] // k, x.shape[1]
+        if self.reducer == 'max':
+            invar = x.view(n, k, d).max(dim=1)[0]                                  # padded rows: max of zeros = 0
+        elif self.reducer == 'concat':
+            W = self.Ws[k - 2]
+            invar = ops.linear(x.view(n, k * d), W.weight, W.bias, dyn)
+        else:
+            raise ValueError('unknown reducer %r' % (self.reducer,))
+        return 0.5 * invar + 0.5 * var
 
 
 class MSHGNN(nn.Module):

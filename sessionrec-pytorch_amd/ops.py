@@ -795,7 +795,7 @@ class GRUExpand(torch.autograd.Function):
     accumulated by the backward-data GEMM itself (beta = 1) and nothing goes through autograd's select / add kernels."""
 
     @staticmethod
-    def forward(ctx, x, Wih, bih, Whh, bhh, k, dyn_n, dyn_rows):
+    def forward(ctx, x, Wih, bih, Whh, bhh, k, dyn_n, dyn_rows, combine=True):
         x = x.contiguous()
         nk, d = x.shape
         n, d3 = nk // k, 3 * d
@@ -816,10 +816,12 @@ class GRUExpand(torch.autograd.Function):
                 gemm_nt(H[t - 1], Whh, GH[t - 1], bhh, dyn_n, 1 if dyn_n is not None else 0)
                 lib.srec_gru_pointwise_fwd(gi, k * d3, ptr(GH[t - 1]), d3, None, ptr(H[t - 1]), d, n, ptr(dyn_n), d,
                                            ptr(H[t]), d, ptr(gates[t]), st)
+        ctx.save_for_backward(x, Wih, Whh, bhh, H, gates, GH)
+        ctx.k, ctx.dyn_n, ctx.dyn_rows, ctx.combine = k, dyn_n, dyn_rows, combine
+        if not combine:                                   # 'max' / 'concat' reducers: only the GRU's last hidden state
+            return H[k - 1].clone()
         out = torch.empty(n, d, device=dev, dtype=torch.float32)
         lib.srec_gram_combine_fwd(ptr(x), ptr(H[k - 1]), d, n, ptr(dyn_n), k, d, ptr(out), d, st)
-        ctx.save_for_backward(x, Wih, Whh, bhh, H, gates, GH)
-        ctx.k, ctx.dyn_n, ctx.dyn_rows = k, dyn_n, dyn_rows
         return out
 
     @staticmethod
@@ -829,9 +831,13 @@ class GRUExpand(torch.autograd.Function):
         g = _rows(g)
         n, d = g.shape
         d3, dev, st = 3 * d, g.device, stream()
-        dX = torch.empty(n * k, d, device=dev, dtype=torch.float32)
-        dh = torch.empty(n, d, device=dev, dtype=torch.float32)
-        lib.srec_gram_combine_bwd(ptr(g), _ld(g), n, ptr(dyn_n), k, d, ptr(dX), ptr(dh), d, st)
+        if ctx.combine:
+            dX = torch.empty(n * k, d, device=dev, dtype=torch.float32)
+            dh = torch.empty(n, d, device=dev, dtype=torch.float32)
+            lib.srec_gram_combine_bwd(ptr(g), _ld(g), n, ptr(dyn_n), k, d, ptr(dX), ptr(dh), d, st)
+        else:
+            dX = torch.zeros(n * k, d, device=dev, dtype=torch.float32)
+            dh = g.contiguous()
         dGI = torch.empty(n * k, d3, device=dev, dtype=torch.float32)
         dGH = torch.empty(k, n, d3, device=dev, dtype=torch.float32)          # slot t = d(gh_t); non-live rows zero
         for t in range(k - 1, -1, -1):
@@ -855,11 +861,12 @@ class GRUExpand(torch.autograd.Function):
         gemm_tn(dGI, x, gWih, dyn_rows)
         gbih = torch.empty(d3, device=dev, dtype=torch.float32)
         col_sum(dGI, n * k, d3, gbih, dyn_rows)
-        return dX, gWih, gbih, gWhh, gbhh, None, None, None
+        return dX, gWih, gbih, gWhh, gbhh, None, None, None, None
 
 
-def gru_expand(x, gru, k, dyn_n=None, dyn_rows=None):
-    return GRUExpand.apply(x, gru.weight_ih_l0, gru.bias_ih_l0, gru.weight_hh_l0, gru.bias_hh_l0, k, dyn_n, dyn_rows)
+def gru_expand(x, gru, k, dyn_n=None, dyn_rows=None, combine=True):
+    return GRUExpand.apply(x, gru.weight_ih_l0, gru.bias_ih_l0, gru.weight_hh_l0, gru.bias_hh_l0, k, dyn_n, dyn_rows,
+                           combine)
 
 
 def gram_combine(X, Hl, k, dyn=None):

@@ -161,13 +161,29 @@ def extra_cases(sets):
                      oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K), smp, full=False)
 
 
+def reducer_cases(sets):
+    """SemanticExpander reducers 'max' and 'concat' (msgifsr.py:36-41), order 3"""
+    for sname, smp in sets.items():
+        V = 3429 if sname == 's32' else 300
+        for red in ('max', 'concat'):
+            th.manual_seed(123)
+            rm = allow_zero(RMSGIFSR(V, 'sample', D, 1, reducer=red, order=3, extra=False, fusion=False))
+            omod = om.MSGIFSR(V, 'sample', D, 1, reducer=red, order=3, extra=False, fusion=False)
+            run_case('msgifsr_K3_%s_%s' % (red, sname), rm, omod,
+                     rcollate.collate_fn_factory_ccs((rcollate.seq_to_ccs_graph,), 3),
+                     oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), 3), smp, full=False)
+
+
 def main():
     samples = first_samples(32)
     edge = EDGE_CASES
     sets = {'s32': samples, 'edge': edge}
     if '--only-extra' in sys.argv:
         return extra_cases(sets)
+    if '--only-reducers' in sys.argv:
+        return reducer_cases(sets)
     extra_cases(sets)
+    reducer_cases(sets)
     for sname, smp in sets.items():
         full = sname == 's32'
         V = 3429 if full else 300          # edge-case ids are < 300: keeps those fixtures tiny

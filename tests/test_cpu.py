@@ -27,7 +27,8 @@ def _oracle(name, V):
         fns = (oc.seq_to_eop_multigraph, oc.seq_to_shortcut_graph) if L > 1 else (oc.seq_to_eop_multigraph,)
         return om.LESSR(V, d, L), oc.collate_fn_factory(*fns)
     K = int(name.split('_')[1][1:])
-    return (om.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name),
+    return (om.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name,
+                       reducer='max' if '_max' in name else 'concat' if '_concat' in name else 'mean'),
             oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K))
 
 

@@ -23,7 +23,8 @@ def _build(name, init, V, dev):
         m = sp.LESSR(V, d, L)
     elif name.startswith('msgifsr'):
         K = int(name.split('_')[1][1:])
-        m = sp.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name)
+        m = sp.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name,
+                       reducer='max' if '_max' in name else 'concat' if '_concat' in name else 'mean')
     missing = m.load_state_dict(init, strict=True)
     return m.to(dev)
 
@@ -57,7 +58,8 @@ def _oracle_fp64_final(name, init, samples, V):
         m, fn = om.LESSR(V, d, L), oc.collate_fn_factory(*fns)
     else:
         K = int(name.split('_')[1][1:])
-        m = om.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name)
+        m = om.MSGIFSR(V, 'sample', d, 1, order=K, extra='_ext' in name, fusion='_fus' in name,
+                       reducer='max' if '_max' in name else 'concat' if '_concat' in name else 'mean')
         fn = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K)
     m.load_state_dict(init)
     m = m.double()
@@ -110,7 +112,8 @@ CASES = ['srgnn_s32', 'srgnn_edge', 'niser_s32', 'niser_edge',
          'msgifsr_K1_s32', 'msgifsr_K1_edge', 'msgifsr_K2_s32', 'msgifsr_K2_edge', 'msgifsr_K3_s32', 'msgifsr_K3_edge',
          'msgifsr_K3_fus_s32', 'msgifsr_K3_fus_edge',
          'msgifsr_K1_ext_s32', 'msgifsr_K1_ext_edge', 'msgifsr_K3_ext_s32', 'msgifsr_K3_ext_edge',
-         'msgifsr_K3_ext_fus_s32', 'msgifsr_K3_ext_fus_edge']
+         'msgifsr_K3_ext_fus_s32', 'msgifsr_K3_ext_fus_edge',
+         'msgifsr_K3_max_s32', 'msgifsr_K3_max_edge', 'msgifsr_K3_concat_s32', 'msgifsr_K3_concat_edge']
 
 
 def grad_close(p, ref, what):
