@@ -209,6 +209,10 @@ int srec_sgat_bwd_src(const float* dout, int ld_o, const float* A, const float* 
  * hyper (device, 8 floats) = {lr/(1-b1^t), beta1, beta2, eps, weight_decay, 1-beta1, 1-beta2, sqrt(1-b2^t)} */
 int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                    void* stream);
+/* step scalars on the DEVICE: *counter += 1, then hyper[8] = {lr/(1-b1^t), b1, b2, eps, wd, 1-b1, 1-b2, sqrt(1-b2^t)}
+ * in double from cfg = double[5] {lr, beta1, beta2, eps, weight_decay} (torch.optim.Adam's host arithmetic,
+ * train.py:70-75).  Makes a captured / pipelined optimizer step independent of host timing. */
+int srec_adam_hyper(int* counter, const void* cfg, float* hyper, void* stream);
 /* one launch for many small tensors: desc[t] = {p, g, m, v, numel, use_wd} (6 x int64, device), blockmap[b] =
  * {tensor, first element} (2 x int32, device) per 1024-element block */
 int srec_adam_multi(const long long* desc, const int* blockmap, int total_blocks, const float* hyper, void* stream);

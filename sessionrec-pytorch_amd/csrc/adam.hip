@@ -130,6 +130,31 @@ extern "C" int srec_adam_multi(const long long* desc, const int* blockmap, int t
     return 0;
 }
 
+namespace {
+// one thread: advance the DEVICE step counter and derive the step's scalars in double (like torch on the host).
+// Keeping the counter on the device makes the optimizer step a pure function of device state: a replayed hipGraph
+// (or a host running ahead of the GPU) can no longer pair a step with another step's bias corrections.
+__global__ void adam_hyper_kernel(int* __restrict__ counter, const double* __restrict__ cfg, float* __restrict__ hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = *counter + 1;
+    *counter = t;
+    const double lr = cfg[0], b1 = cfg[1], b2 = cfg[2], eps = cfg[3], wd = cfg[4];
+    hyper[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+    hyper[1] = (float)b1; hyper[2] = (float)b2; hyper[3] = (float)eps; hyper[4] = (float)wd;
+    hyper[5] = (float)(1.0 - b1); hyper[6] = (float)(1.0 - b2);
+    hyper[7] = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+}  // namespace
+
+// counter: device int32 (steps taken so far, incremented here); cfg: device double[5] = {lr, beta1, beta2, eps,
+// weight_decay}; hyper: device float[8] consumed by srec_adam_flat / _rows / _multi of the same step.
+extern "C" int srec_adam_hyper(int* counter, const void* cfg, float* hyper, void* stream) {
+    if (counter == nullptr || cfg == nullptr || hyper == nullptr) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, (const double*)cfg, hyper);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                               void* stream) {
     if (n <= 0) return 0;

@@ -37,8 +37,8 @@ class GraphedTrainStep:
                 p.copy_(q)
             for b, q in zip(model.buffers(), snap_b):
                 b.copy_(q)
+            optimizer.reset_steps()                      # host and device step counters
             for st in optimizer.state.values():
-                st['step'] = 0
                 st['exp_avg'].zero_()
                 st['exp_avg_sq'].zero_()
         ms = model.__dict__.get('_srec_state')
@@ -55,13 +55,15 @@ class GraphedTrainStep:
                 self.after_backward()
             work = optimizer._work()
             optimizer._frozen = work
-            # step counters are bumped on the host before every replay (advance()); during capture they
-            # only need to be consistent, so bump once here and take it back after the capture
+            # the step counters that matter live on the device and are advanced by the captured step itself; the
+            # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
+            # capture and take it back afterwards
             optimizer.advance(work)
             optimizer.launch(work)
         for _, _, items in work:
             for _, _, st in items:
                 st['step'] -= 1
+        optimizer._T -= 1
         self.work = work
 
     @staticmethod

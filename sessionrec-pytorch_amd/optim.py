@@ -21,7 +21,7 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.model = model
-        self._hyper = {}            # (group index, slot) -> (pinned host [8], device [8])
+        self._hyper = {}            # (group index, step offset) -> device step state; ('multi', ...) -> descriptors
         self._frozen = None         # parameter lists frozen by a captured graph
 
     # ------------------------------------------------------------------ helpers
@@ -52,19 +52,37 @@ class FusedAdam(torch.optim.Optimizer):
                 g = cache[id(p)] = torch.zeros_like(p)
         return g
 
-    def _buffers(self, gi, slot, device):
-        key = (gi, slot)
+    def _buffers(self, gi, off, device):
+        """device-resident step state of the parameters of group gi whose step count is (global step - off):
+        (counter int32[1], cfg double[5], hyper float[8]).  The counter lives on the device and is advanced by the
+        captured step itself (srec_adam_hyper), so a replayed graph or a host running ahead cannot mix steps."""
+        key = (gi, off)
         if key not in self._hyper:
-            host = torch.zeros(8, dtype=torch.float32)
-            if device.type == 'cuda':
-                host = host.pin_memory()
-            self._hyper[key] = (host, torch.zeros(8, dtype=torch.float32, device=device))
+            self._hyper[key] = dict(counter=torch.zeros(1, dtype=torch.int32, device=device),
+                                    cfg=torch.zeros(5, dtype=torch.float64, device=device),
+                                    hyper=torch.zeros(8, dtype=torch.float32, device=device), cfg_host=None,
+                                    fresh=True)
         return self._hyper[key]
+
+    def _cfg(self, group):
+        b1, b2 = group['betas']
+        return (float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']))
 
     def _vals(self, group, step):
         b1, b2 = group['betas']
         return [group['lr'] / (1.0 - b1 ** step), b1, b2, group['eps'], group['weight_decay'], 1.0 - b1, 1.0 - b2,
                 (1.0 - b2 ** step) ** 0.5]
+
+    def reset_steps(self):
+        """forget every step taken (host and device counters) - used after a graph-capture warm-up"""
+        self._T = 0
+        for st in self.state.values():
+            if 'step' in st:
+                st['step'] = 0
+        for ent in self._hyper.values():
+            if isinstance(ent, dict):
+                ent['counter'].zero_()
+                ent['fresh'] = False
 
     def _work(self):
         """[(group idx, group, [(p, g, state)])] for every parameter that has a gradient now"""
@@ -90,35 +108,50 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ the two halves of step()
     def advance(self, work=None):
-        """host only: bump the step counters and refresh the pinned hyper-parameter arrays"""
+        """host only: bump the (bookkeeping) step counters; refresh a group's device config when it changed (lr
+        schedule) - a stream-ordered copy from pageable memory, never a pinned buffer the GPU reads later"""
         if work is None:
             work = self._frozen
+        self._T = getattr(self, '_T', 0) + 1
         for gi, group, items in work:
-            steps = set()
+            offs = set()
             for p, g, state in items:
                 state['step'] += 1
-                steps.add(state['step'])
-            for slot, s in enumerate(sorted(steps)):
-                host, _ = self._buffers(gi, slot, items[0][0].device)
-                host.copy_(torch.tensor(self._vals(group, s), dtype=torch.float32))
+                offs.add(self._T - state['step'])
+            cfg = self._cfg(group)
+            for off in offs:
+                ent = self._buffers(gi, off, items[0][0].device)
+                if ent['fresh']:
+                    # a parameter that skipped steps (grad None) moves to a new offset: the device counter of that
+                    # offset starts where the parameter's own count stands (this step brings it to T - off)
+                    ent['counter'].fill_(self._T - off - 1)
+                    ent['fresh'] = False
+                if ent['cfg_host'] != cfg:
+                    ent['cfg'].copy_(torch.tensor(cfg, dtype=torch.float64))
+                    ent['cfg_host'] = cfg
         return work
 
     def launch(self, work):
-        """device work only (capturable): hyper H2D copies + the Adam kernels"""
+        """device work only (capturable): the step-scalar kernel + the Adam kernels"""
         table, tgrad, st = self._table_info()
         model = self.model
+        T = getattr(self, '_T', 0)
         for gi, group, items in work:
             if not items:
                 continue
             use_wd = 1 if group['weight_decay'] != 0 else 0
-            order = sorted({state['step'] for _, _, state in items})
-            slot_of = {s: i for i, s in enumerate(order)}
-            for s, slot in slot_of.items():
-                host, dev = self._buffers(gi, slot, items[0][0].device)
-                dev.copy_(host, non_blocking=True)
+            slot_of = {}
+            for _, _, state in items:
+                slot_of.setdefault(state['step'], T - state['step'])
+            for s_, off in slot_of.items():
+                ent = self._buffers(gi, off, items[0][0].device)
+                if ent['cfg_host'] is None:                     # first use outside advance(): step() on a fresh group
+                    ent['cfg'].copy_(torch.tensor(self._cfg(group), dtype=torch.float64))
+                    ent['cfg_host'] = self._cfg(group)
+                lib.srec_adam_hyper(ptr(ent['counter']), ptr(ent['cfg']), ptr(ent['hyper']), stream())
             multi = {}                       # step slot -> rows of the multi-tensor descriptor
             for p, g, state in items:
-                hyper = self._buffers(gi, slot_of[state['step']], p.device)[1]
+                hyper = self._buffers(gi, slot_of[state['step']], p.device)['hyper']
                 g = g.contiguous()
                 is_table = table is not None and p is table
                 if not is_table and p.is_contiguous() and p.numel() < (1 << 22):
@@ -150,15 +183,26 @@ class FusedAdam(torch.optim.Optimizer):
                 hd = torch.tensor(desc, dtype=torch.int64)
                 hb = torch.tensor(bmap, dtype=torch.int32)
                 ent = self._hyper.get(key)
-                if ent is None or ent[0].numel() != hd.numel() or ent[2].numel() != hb.numel():
-                    ent = (hd.pin_memory(), torch.empty_like(hd, device=dev), hb.pin_memory(), torch.empty_like(hb, device=dev))
+                sig = (tuple(desc), tuple(bmap))
+                if ent is None or ent[2] != sig:
+                    # descriptor changed (tensors re-allocated).  Eager: NEW pinned staging buffers, never overwritten
+                    # in place - the copies are asynchronous and the caching host allocator keeps a block alive until
+                    # the copy that reads it has run.  Under graph capture nothing executes and pinned memory cannot be
+                    # allocated: the buffers of the (synchronised) warm-up are rewritten and become the graph's own.
+                    same = ent is not None and ent[3].numel() == hd.numel() and ent[4].numel() == hb.numel()
+                    if same and torch.cuda.is_current_stream_capturing():
+                        hp, bp, dd, db = ent[3], ent[4], ent[0], ent[1]
+                        hp.copy_(hd)
+                        bp.copy_(hb)
+                    else:
+                        hp, bp = hd.pin_memory(), hb.pin_memory()
+                        dd, db = torch.empty_like(hd, device=dev), torch.empty_like(hb, device=dev)
+                    ent = (dd, db, sig, hp, bp)
+                    dd.copy_(hp, non_blocking=True)
+                    db.copy_(bp, non_blocking=True)
                     self._hyper[key] = ent
-                ent[0].copy_(hd)
-                ent[2].copy_(hb)
-                ent[1].copy_(ent[0], non_blocking=True)
-                ent[3].copy_(ent[2], non_blocking=True)
-                hyper = self._buffers(gi, slot, dev)[1]
-                lib.srec_adam_multi(ptr(ent[1]), ptr(ent[3]), len(bmap) // 2, ptr(hyper), stream())
+                hyper = self._buffers(gi, slot, dev)['hyper']
+                lib.srec_adam_multi(ptr(ent[0]), ptr(ent[1]), len(bmap) // 2, ptr(hyper), stream())
         if tgrad is not None:
             tgrad.fresh = False
         from . import ops

@@ -105,6 +105,35 @@ def test_graph_replay_matches_eager_training(dev, kind):
         assert frac >= 0.995 and err.max().item() <= 0.02 * 1e-2 * len(batches), (k, frac, err.max().item())
 
 
+def test_pipelined_graph_replay_is_independent_of_host_timing(dev):
+    """Regression: the Adam step scalars (bias corrections) used to be staged through a pinned buffer the host rewrote
+    before every replay - a host running ahead of the GPU paired a step with a LATER step's scalars.  The step counter
+    now lives on the device: 60 replays queued without any synchronisation give bit-identical parameters to the same 60
+    steps with a device sync after each."""
+    c, train, optim, G = pkg('collate'), pkg('train'), pkg('optim'), pkg('graph')
+    rng = np.random.default_rng(5)
+    V = 400
+    caps = c.default_caps(32, 12)
+    batches = None
+    finals = []
+    for sync in (True, False):
+        torch.manual_seed(0)
+        model, mk = _setup('niser', dev, V)
+        if batches is None:
+            batches = [[x.to(dev) for x in xs] + [lab.to(dev)] for xs, lab in (mk(caps)(_samples(rng, 32, V)) for _ in range(60))]
+        opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-2, weight_decay=1e-4, model=model)
+        model.train()
+        step = G.GraphedTrainStep(model, opt, batches[0][:-1], batches[0][-1])
+        for b in batches:
+            step(b[:-1], b[-1])
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
 def test_sharded_single_rank_with_padded_batch(dev):
     """the bench's N>1 configuration (row-sharded table + capacity-padded batches + fixed request capacity),
     exercised with one rank: must equal the plain fused path"""
