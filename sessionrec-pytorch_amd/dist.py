@@ -160,6 +160,10 @@ class HipLocal:
                                      table.shape[0], d, stream())
         return dsr
 
+    def topk(self, sr, table, cs, k):
+        from . import ops
+        return ops.score_topk(sr, table, cs, k)
+
     def workspace(self, B, V, d, device):
         return self.ops.CEWorkspace(B, V, d, device)
 
@@ -245,6 +249,7 @@ class VocabParallel:
         self.tgrad = model._state(1)['tgrad']
         self.dE = self.tgrad.buf
         self.idx_cap = idx_cap
+        self.eval_data_parallel = False     # evaluate(): True when every rank feeds its own equal-sized slice of a batch
         self._ws = {}
         model.shard = self
 
@@ -293,6 +298,40 @@ class VocabParallel:
         out = ShardedScoreCE.apply(sr, live, csl, labels, dE, self.lo, self._ws[key], cs_inv_scale, self.local, self.group)
         self.tgrad.fresh = True                      # the backward of `out` overwrites every live row of dE
         return out
+
+    def topk(self, sr, table, cs, k, data_parallel=False):
+        """evaluation over the sharded table (SURVEY 8(e) "Eval"): every rank ranks its own rows with the fused
+        top-k kernel, the (B, k) lists are all-gathered and merged (ties -> lower item id, like one device).
+        data_parallel=False: every rank passes the SAME sessions (replicated evaluation loader) and gets the full
+        answer.  data_parallel=True: each rank passes its own B/world sessions (same count everywhere); the session
+        vectors are all-gathered first and each rank gets the answer for its own sessions."""
+        n_loc = sr.shape[0]
+        sr_all = all_gather_cat(sr.contiguous(), self.group) if data_parallel else sr
+        live = table[:self.n_live]
+        csl = None if cs is None else cs[:self.n_live]
+        kk = min(k, self.n_live)
+        B = sr_all.shape[0]
+        if kk > 0:
+            val, idx = self.local.topk(sr_all, live, csl, kk)
+            idx = idx.to(torch.int64) + self.lo
+        else:
+            val = sr_all.new_empty(B, 0)
+            idx = torch.empty(B, 0, dtype=torch.int64, device=sr.device)
+        if kk < k:                                   # a shard with fewer than k live rows: pad with -inf
+            val = torch.cat([val, val.new_full((B, k - kk), float('-inf'))], 1)
+            idx = torch.cat([idx, idx.new_full((B, k - kk), 2 ** 62)], 1)
+        if self.world > 1 or (FORCE and dist.is_initialized()):
+            w = self.world
+            val = all_gather_cat(val, self.group).view(w, B, k).permute(1, 0, 2).reshape(B, w * k)
+            idx = all_gather_cat(idx, self.group).view(w, B, k).permute(1, 0, 2).reshape(B, w * k)
+        # merge: descending value, ties towards the lower item id (two stable sorts)
+        o = torch.argsort(idx, dim=1, stable=True)
+        val, idx = val.gather(1, o), idx.gather(1, o)
+        o = torch.argsort(val, dim=1, descending=True, stable=True)[:, :k]
+        val, idx = val.gather(1, o), idx.gather(1, o)
+        if data_parallel:
+            val, idx = val[self.rank * n_loc:(self.rank + 1) * n_loc], idx[self.rank * n_loc:(self.rank + 1) * n_loc]
+        return val, idx.to(torch.int32)
 
     def sync_replicated_grads(self, params, optimizer=None):
         """sum the replicated-parameter gradients over ranks in one flat bucket.  With `optimizer` (FusedAdam) the

@@ -7,9 +7,10 @@ scheduler works unchanged).  The item table takes the row-structured kernel, fed
 TableGrad buffer the fused scoring backward filled, with the cosine column scale of the NEXT
 step fused into the same pass over HBM.
 
-Graph-friendly: the per-step scalars (lr / bias corrections, computed in double like torch) live in
-a pinned host array that is copied to a static device array at the start of the launch sequence, so
-a captured hipGraph of `launch()` is replayed after a host-only `advance()`.
+Graph-friendly: the step counter lives on the DEVICE and is advanced by the launch sequence itself
+(srec_adam_hyper: counter += 1, lr / bias corrections in double like torch), so a captured hipGraph
+of `launch()` replays correctly however far the host runs ahead; `advance()` is host bookkeeping
+plus a stream-ordered config copy when the lr schedule changed a group.
 """
 import torch
 
@@ -83,6 +84,18 @@ class FusedAdam(torch.optim.Optimizer):
             if isinstance(ent, dict):
                 ent['counter'].zero_()
                 ent['fresh'] = False
+
+    def load_state_dict(self, state_dict):
+        """torch's loader + the device-side step state: counters are rebuilt from the restored per-parameter step
+        counts the next time advance() meets each (group, offset) slot."""
+        super().load_state_dict(state_dict)
+        steps = [int(st['step']) for st in self.state.values() if 'step' in st]
+        for st in self.state.values():
+            if 'step' in st:
+                st['step'] = int(st['step'])
+        self._T = max(steps) if steps else 0
+        self._hyper = {}
+        self._frozen = None
 
     def _work(self):
         """[(group idx, group, [(p, g, state)])] for every parameter that has a gradient now"""

@@ -102,12 +102,16 @@ class _ScoringMixin:
         rank through forward()."""
         with torch.no_grad():
             sr = self.session_repr(*inputs)
-            mixed = isinstance(sr, (list, tuple)) or getattr(self, 'extra', False) or self.shard is not None
+            mixed = isinstance(sr, (list, tuple)) or getattr(self, 'extra', False)
             if mixed:
+                if self.shard is not None:
+                    raise NotImplementedError('order fusion / extra with a row-sharded table')
                 v, i = self(*inputs).topk(k)
                 return v, i.to(torch.int32)
             st = self._state(sr.shape[0])
             cs, _ = self._col_scale(st)
+            if self.shard is not None:       # local top-k per shard -> all-gather -> merge (SURVEY 8(e))
+                return self.shard.topk(sr, self._table(), cs, k, data_parallel=self.shard.eval_data_parallel)
             return ops.score_topk(sr, self._table(), cs, k)
 
     def _log_probs(self, sr):

@@ -49,7 +49,17 @@ def evaluate(model, data_loader, device, cutoff=20):
 
 
 class TrainRunner:
-    def __init__(self, dataset, model, train_loader, test_loader, device, lr=1e-3, weight_decay=0, patience=3):
+    def __init__(self, dataset, model, train_loader, test_loader, device, lr=1e-3, weight_decay=0, patience=3,
+                 checkpoint=None, resume=True, hooks=()):
+        """Same positional surface as the reference (train.py:57-69).  Additions (the reference has
+        neither): `checkpoint` = path written after every epoch (model, optimizer incl. Adam moments and step counts,
+        scheduler, epoch / batch counters, best metrics) and, with `resume`, read back at the start of train();
+        `hooks` = callables hook(event: dict) invoked after every logged interval and every epoch (the reference's
+        wandb calls sit at the same two places)."""
+        self.checkpoint = checkpoint
+        self.resume = resume
+        self.hooks = list(hooks)
+        self.best = (0, 0, 0)            # max_mrr, max_hit, bad_counter
         self.dataset = dataset
         self.model = model
         params = fix_weight_decay(model) if weight_decay > 0 else model.parameters()
@@ -80,12 +90,47 @@ class TrainRunner:
         self.optimizer.step()
         return loss
 
+    # ------------------------------------------------------------------ checkpoint / hooks (not in the reference)
+    def state_dict(self):
+        return dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(),
+                    scheduler=self.scheduler.state_dict(), epoch=self.epoch, batch=self.batch, best=self.best)
+
+    def load_state_dict(self, sd):
+        self.model.load_state_dict(sd['model'])
+        self.optimizer.load_state_dict(sd['optimizer'])
+        self.scheduler.load_state_dict(sd['scheduler'])
+        self.epoch, self.batch, self.best = sd['epoch'], sd['batch'], tuple(sd['best'])
+        if self.fused:
+            from . import ops
+            ops.weights_changed()          # cached bf16 copies / column scales belong to the old weights
+            self.model.__dict__.pop('_srec_state', None)
+
+    def save_checkpoint(self, path=None):
+        import os
+        path = path or self.checkpoint
+        tmp = path + '.tmp'
+        th.save(self.state_dict(), tmp)
+        os.replace(tmp, path)              # a crash mid-write never leaves a truncated checkpoint behind
+
+    def load_checkpoint(self, path=None):
+        self.load_state_dict(th.load(path or self.checkpoint, map_location=self.device, weights_only=False))
+
+    def _emit(self, **event):
+        for h in self.hooks:
+            h(event)
+
     def train(self, epochs, log_interval=100):
-        max_mrr, max_hit, bad_counter = 0, 0, 0
+        import os
+        done = 0
+        if self.checkpoint and self.resume and os.path.exists(self.checkpoint):
+            self.load_checkpoint()
+            done = self.epoch                # `epochs` is the total of the interrupted run
+            print(f'Resumed from {self.checkpoint}: epoch {self.epoch}, batch {self.batch}')
+        max_mrr, max_hit, bad_counter = self.best
         t = time.time()
         mean_loss = 0
         evaluate(self.model, self.test_loader, self.device)
-        for _ in range(epochs):
+        for _ in range(epochs - done):
             self.model.train()
             for batch in self.train_loader:
                 inputs, labels = prepare_batch(batch, self.device)
@@ -95,19 +140,26 @@ class TrainRunner:
                 mean_loss += loss / log_interval
                 if self.batch > 0 and self.batch % log_interval == 0:
                     print(f'Batch {self.batch}: Loss = {mean_loss:.4f}, Time Elapsed = {time.time() - t:.2f}s')
+                    self._emit(kind='interval', batch=self.batch, loss=mean_loss, seconds=time.time() - t)
                     t = time.time()
                     mean_loss = 0
                 self.batch += 1
             self.scheduler.step()
             mrr, hit = evaluate(self.model, self.test_loader, self.device)
             print(f'Epoch {self.epoch}: MRR = {mrr * 100:.3f}%, Hit = {hit * 100:.3f}%')
+            self._emit(kind='epoch', epoch=self.epoch, mrr=mrr, hit=hit)
+            stop = False
             if mrr < max_mrr and hit < max_hit:
                 bad_counter += 1
-                if bad_counter == self.patience:
-                    break
+                stop = bad_counter == self.patience
             else:
                 bad_counter = 0
+            if stop:
+                break
             max_mrr = max(max_mrr, mrr)
             max_hit = max(max_hit, hit)
             self.epoch += 1
+            self.best = (max_mrr, max_hit, bad_counter)
+            if self.checkpoint:
+                self.save_checkpoint()
         return max_mrr, max_hit

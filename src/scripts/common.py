@@ -37,6 +37,9 @@ def parse(model):
                    help='the number of processes to load the input graphs')
     p.add_argument('--valid-split', type=float, default=None, help='the fraction for the validation set')
     p.add_argument('--log-interval', type=int, default=100, help='print the loss after this number of iterations')
+    p.add_argument('--checkpoint', default=None,
+                   help='(not in the reference) write a resumable checkpoint here after every epoch; resume from it if present')
+    p.add_argument('--metrics-log', default=None, help='(not in the reference) append one JSON line per logged interval / epoch')
     if model == 'MSGIFSR':
         p.add_argument('--order', type=int, default=3, help='order of msg')
         p.add_argument('--reducer', type=str, default='mean', help='method for reducer')
@@ -56,6 +59,15 @@ def seed_all(seed=123):
     np.random.seed(seed)
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
+
+
+def _jsonl(path):
+    import json
+
+    def hook(event):
+        with open(path, 'a') as f:
+            f.write(json.dumps(event) + '\n')
+    return hook
 
 
 def run(model_name):
@@ -104,7 +116,8 @@ def run(model_name):
     model = model.to(device)
     print(model)
     runner = TrainRunner(args.dataset_dir, model, train_loader, test_loader, device=device, lr=args.lr,
-                         weight_decay=args.weight_decay, patience=args.patience)
+                         weight_decay=args.weight_decay, patience=args.patience, checkpoint=args.checkpoint,
+                         hooks=[_jsonl(args.metrics_log)] if args.metrics_log else ())
     print('start training')
     mrr, hit = runner.train(args.epochs, args.log_interval)
     print('MRR@20\tHR@20')

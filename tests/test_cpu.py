@@ -229,6 +229,47 @@ def test_train_runner_cpu_plumbing():
     assert len(runner.loss_trace) == 6 and runner.loss_trace[-1] < runner.loss_trace[0]
 
 
+def test_train_runner_checkpoint_resume_and_hooks(tmp_path):
+    """checkpoint / resume / metric hooks (SURVEY 8(f) rank 4 - absent in the reference): a run interrupted after
+    epoch 2 and resumed from its checkpoint continues exactly like the uninterrupted 4-epoch run."""
+    import copy
+    train = pkg('train')
+    rng = np.random.default_rng(1)
+    V = 80
+    samples = _rand_samples(rng, 96, V=V, max_len=8)
+    fn = oc.collate_fn_factory(oc.seq_to_session_graph)
+
+    class G:
+        def __init__(self, x):
+            self.x = om.to_torch(x)
+
+        def to(self, device):
+            return self.x
+    loader = []
+    for b in range(3):
+        inp, lab = fn(samples[b * 32:(b + 1) * 32])
+        loader.append(([G(x) for x in inp], torch.from_numpy(lab)))
+    torch.manual_seed(0)
+    m0 = om.SRGNN(V, 16, 1)
+    cpu = torch.device('cpu')
+    kw = dict(lr=1e-2, weight_decay=1e-4, patience=9)
+    events = []
+    full = train.TrainRunner('x', copy.deepcopy(m0), loader, loader, cpu, hooks=[events.append], **kw)
+    full.train(4, log_interval=2)
+    assert [e['epoch'] for e in events if e['kind'] == 'epoch'] == [0, 1, 2, 3]
+    assert all(e['loss'] == e['loss'] for e in events if e['kind'] == 'interval') and any(e['kind'] == 'interval' for e in events)
+    ck = str(tmp_path / 'run.pt')
+    first = train.TrainRunner('x', copy.deepcopy(m0), loader, loader, cpu, checkpoint=ck, **kw)
+    first.train(2, log_interval=2)
+    assert os.path.exists(ck) and not os.path.exists(ck + '.tmp')
+    second = train.TrainRunner('x', copy.deepcopy(m0), loader, loader, cpu, checkpoint=ck, **kw)
+    second.train(4, log_interval=2)
+    assert second.epoch == 4 and second.batch == 12
+    assert second.loss_trace == full.loss_trace[6:]                   # same batches, same lr schedule, same moments
+    for (k, a), (_, b) in zip(full.model.state_dict().items(), second.model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 # ---------------------------------------------------------------------------------------- C ABI
 def test_c_abi_exports_every_declared_symbol():
     L = pkg('_lib')

@@ -61,6 +61,11 @@ class TorchLocal:
         dE.copy_(g)
         return p @ table
 
+    def topk(self, sr, table, cs, k):
+        z = self._z(sr, table, cs)
+        o = torch.argsort(z, dim=1, descending=True, stable=True)[:, :k]      # stable: ties -> lower id
+        return z.gather(1, o), o.int()
+
     def workspace(self, B, V, d, device):
         return None
 
@@ -92,6 +97,8 @@ def _free_port():
 def _make(world, V=150, d=16, B=6):
     g = torch.Generator().manual_seed(5)
     table = torch.randn(V, d, generator=g) * 0.3
+    table[130] = table[7]                                 # an exact score tie across the two shards
+    table[9] = table[8]                                   # ... and inside one shard
     per_rank = []
     for r in range(world):
         n = 9 + r * 2
@@ -102,6 +109,10 @@ def _make(world, V=150, d=16, B=6):
         pick = torch.randint(0, n, (B,), generator=g)
         gout = torch.randn(n, d, generator=g)
         per_rank.append(dict(idx=idx, sr_w=sr_w, labels=labels, pick=pick, gout=gout))
+    sr_eval = torch.randn(8, d, generator=g)
+    sr_eval[0] = table[7] * 5                             # session 0 ranks the tied pair first
+    sr_eval[1] = table[8] * 5
+    per_rank[0]['sr_eval'] = sr_eval
     return table, per_rank
 
 
@@ -149,7 +160,14 @@ def _worker(rank, world, port, cosine, q):
         loss = vp.loss(sr, shard, cs, b['labels'], 1.0 / 12.0)
         (loss + 1e-3 * (rows * b['gout']).sum()).backward()
         dE = vp.dE[:vp.n_live].clone()
-        q.put((rank, loss.item(), vp.lo, vp.hi, dE.numpy().tolist()))
+        # evaluation: local top-k per shard -> all-gather -> merge, both feeding conventions
+        with torch.no_grad():
+            sr_same = per_rank[0]['sr_eval']
+            v_rep, i_rep = vp.topk(sr_same, shard, cs, 5)
+            n = sr_same.shape[0] // world
+            v_dp, i_dp = vp.topk(sr_same[rank * n:(rank + 1) * n], shard, cs, 5, data_parallel=True)
+        q.put((rank, loss.item(), vp.lo, vp.hi, dE.numpy().tolist(), v_rep.tolist(), i_rep.tolist(), v_dp.tolist(),
+               i_dp.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -169,7 +187,18 @@ def test_vocab_parallel_two_ranks_match_single_device(cosine):
         assert p.exitcode == 0
     table, per_rank = _make(world)
     ref_loss, ref_grad = _reference(table, per_rank, cosine)
-    for rank, loss, lo, hi, dE in res:
+    sr_eval = per_rank[0]['sr_eval']
+    Wn = torch.nn.functional.normalize(table, dim=1) * 12.0 if cosine else table
+    z = sr_eval @ Wn.t()
+    o = torch.argsort(z, dim=1, descending=True, stable=True)[:, :5]
+    n = sr_eval.shape[0] // world
+    for rank, loss, lo, hi, dE, v_rep, i_rep, v_dp, i_dp in res:
+        if not cosine:                           # exact ties survive only without the per-row scale round-off
+            assert i_rep[0][:2] == [7, 130] and i_rep[1][:2] == [8, 9]
+            assert torch.equal(torch.tensor(i_rep), o.int())
+            assert torch.equal(torch.tensor(i_dp), o[rank * n:(rank + 1) * n].int())
+        assert torch.allclose(torch.tensor(v_rep), z.gather(1, o), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(torch.tensor(v_dp), z.gather(1, o)[rank * n:(rank + 1) * n], rtol=1e-5, atol=1e-5)
         dE = torch.tensor(dE)
         assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
         assert torch.allclose(dE, ref_grad[lo:hi], rtol=1e-4, atol=1e-6), (rank, (dE - ref_grad[lo:hi]).abs().max())

@@ -215,6 +215,13 @@ def test_vocab_parallel_single_rank_equals_plain_path(dev, name):
     for k, p in p1.items():
         if p.grad is not None and 'embedding' not in k:
             close(p2[k].grad, p.grad, rtol=1e-4, atol=1e-7, what=k)
+    # evaluation over the sharded table (local fused top-k -> merge) == the plain fused top-k
+    plain.eval()
+    sharded.eval()
+    v1, i1 = plain.topk(*inputs, k=20)
+    v2, i2 = sharded.topk(*inputs, k=20)
+    assert torch.equal(i1, i2)
+    close(v2, v1, rtol=1e-6, atol=1e-6, what='top-k scores')
 
 
 @pytest.mark.parametrize('name', ['srgnn_s32', 'niser_s32', 'lessr_L3_s32', 'msgifsr_K3_s32', 'msgifsr_K3_edge',

@@ -63,3 +63,41 @@ def test_sample_dataset_training_matches_oracle(dev, model_name):
     assert a.shape == b.shape == (2 * n_train,)
     assert np.allclose(a, b, rtol=2e-4, atol=2e-4), np.abs(a - b).max()
     assert abs(m_gpu[0] - m_ref[0]) <= 0.02 and abs(m_gpu[1] - m_ref[1]) <= 0.02, (m_gpu, m_ref)   # (MRR@20, HR@20)
+
+
+def test_checkpoint_resume_on_the_fused_path(dev, tmp_path):
+    """TrainRunner(checkpoint=...) on the HIP path: FusedAdam's moments AND its device-side step counters come back, so a
+    run resumed after epoch 2 repeats the uninterrupted run's losses bit for bit."""
+    import copy
+    sp, ds, col, train = pkg(), pkg('dataset'), pkg('collate'), pkg('train')
+    tr, te, V = ds.read_dataset(os.path.join(ROOT, 'datasets', 'sample'))
+    train_set = ds.AugmentedDataset(tr)
+    B, n = 32, 6
+    torch.manual_seed(5)
+    m0 = sp.NISER(V, 32, 1).to(dev)
+    cf = col.collate_fn_factory(col.seq_to_session_graph)
+    loader = [cf([train_set[i] for i in range(b * B, (b + 1) * B)]) for b in range(n)]
+    kw = dict(lr=1e-3, weight_decay=1e-4, patience=9)
+    full = train.TrainRunner('sample', copy.deepcopy(m0), loader, loader, dev, **kw)
+    full.train(4, log_interval=100)
+    ck = str(tmp_path / 'run.pt')
+    first = train.TrainRunner('sample', copy.deepcopy(m0), loader, loader, dev, checkpoint=ck, **kw)
+    first.train(2, log_interval=100)
+    second = train.TrainRunner('sample', copy.deepcopy(m0), loader, loader, dev, checkpoint=ck, **kw)
+    assert second.fused
+    second.train(4, log_interval=100)
+    assert second.epoch == 4 and second.loss_trace == full.loss_trace[2 * n:]
+    for (k, a), (_, b) in zip(full.model.state_dict().items(), second.model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize('model_name,dim', [('MSGIFSR', 256), ('NISER', 128), ('LESSR', 32)])
+def test_bf16_training_metrics_within_0p3pt_of_fp32(dev, model_name, dim):
+    """Recall@20 / MRR@20 after training in bf16 mode within +-0.3 pt (absolute) of the same
+    model (same init, same batches) trained in fp32 on the same split (datasets/sample, 3 epochs, batch 512)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bf16_metric_check
+    r = bf16_metric_check.run(model_name, epochs=3, dim=dim)
+    assert r['fp32']['hit'] > 20.0                                  # the model did learn something
+    assert abs(r['d_mrr_pt']) <= 0.3 and abs(r['d_hit_pt']) <= 0.3, r
