@@ -160,6 +160,31 @@ class HipLocal:
                                      table.shape[0], d, stream())
         return dsr
 
+    def stats_bwd(self, sr, table, cs, labels_local, lse, ga, gc, dE, ws, cs_inv_scale, accumulate):
+        """d z[b, v] = ga[b] * softmax(z_b)[v] - gc[b] * [v == label_b] through this rank's rows: dE (+)= dz^T sr,
+        returns the partial d sr = dz E_local"""
+        from ._lib import lib, ptr, stream
+        B, d = sr.shape
+        dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
+        self.ops._ce_bwd(sr, table, cs, labels_local, lse, None, ga, gc, ws, None, self._tb(table, False), dE, dsr,
+                         3 | (4 if accumulate else 0))
+        if cs is not None:
+            lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), cs_inv_scale, ptr(dE), dE.stride(0),
+                                     table.shape[0], d, stream())
+        return dsr
+
+    def logp_cols(self, sr, table, cs, lse):
+        """this rank's columns of the (B, V) log-probabilities: z[b, v] - lse[b] for the local rows v (fp32)"""
+        from ._lib import lib, ptr, stream
+        B, d = sr.shape
+        n = table.shape[0]
+        ld = (n + 3) & ~3
+        out = torch.empty(B, ld, device=sr.device, dtype=torch.float32)
+        sr = sr.contiguous()
+        lib.srec_score_logp(ptr(sr), sr.stride(0), ptr(table), table.stride(0), ptr(cs), ptr(lse), B, n, d, None,
+                            ptr(out), ld, stream())
+        return out[:, :n]
+
     def topk(self, sr, table, cs, k):
         from . import ops
         return ops.score_topk(sr, table, cs, k)
@@ -226,6 +251,40 @@ class ShardedScoreCE(torch.autograd.Function):
         dsr_part = local.ce_bwd(sr_all, shard, cs, lab_loc, lse, gs, dE, ws, cs_inv_scale)
         dsr = reduce_scatter_sum(dsr_part, group)
         return dsr, None, None, None, None, None, None, None, None, None
+
+
+class ShardedScoreStats(torch.autograd.Function):
+    """(lse_b, z[b, label_b]) of this rank's sessions against the row-sharded catalog, differentiable in both outputs:
+    the sharded counterpart of ops.ScoreStats, for losses that mix several soft-maxes (MSGIFSR order fusion / extra,
+    msgifsr.py:281-317).  Several heads share one table: the first backward of a step overwrites dE, later ones
+    accumulate (tgrad.fresh)."""
+
+    @staticmethod
+    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group, tgrad):
+        n_loc, n = shard.shape[0], sr.shape[0]
+        sr_all = all_gather_cat(sr.contiguous(), group)
+        lab_all = all_gather_cat(labels.to(torch.int64), group)
+        rel = lab_all - lo
+        lab_loc = torch.where((rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1)).to(torch.int32)
+        lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
+        lse_all = all_gather_cat(lse_r.unsqueeze(0), group)
+        lse = torch.logsumexp(lse_all, dim=0).contiguous()
+        lab_logit = all_reduce_sum(lab_logit, group)
+        r = _rank(group)
+        ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
+        ctx.misc = (dE, ws, cs_inv_scale, local, group, tgrad)
+        return lse[r * n:(r + 1) * n].clone(), lab_logit[r * n:(r + 1) * n].clone()
+
+    @staticmethod
+    def backward(ctx, dlse, dlab):
+        sr_all, shard, cs, lab_loc, lse = ctx.saved_tensors
+        dE, ws, cs_inv_scale, local, group, tgrad = ctx.misc
+        ga = all_gather_cat(dlse.contiguous().float(), group)
+        gc = all_gather_cat((-dlab).contiguous().float(), group)
+        dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, ga, gc, dE, ws, cs_inv_scale, tgrad.fresh)
+        tgrad.fresh = True
+        dsr = reduce_scatter_sum(dsr_part, group)
+        return (dsr,) + (None,) * 10
 
 
 # ------------------------------------------------------------------------------- model wiring
@@ -298,6 +357,47 @@ class VocabParallel:
         out = ShardedScoreCE.apply(sr, live, csl, labels, dE, self.lo, self._ws[key], cs_inv_scale, self.local, self.group)
         self.tgrad.fresh = True                      # the backward of `out` overwrites every live row of dE
         return out
+
+    def _live(self, table, cs):
+        if self.n_live < table.shape[0]:
+            return table[:self.n_live], self.dE[:self.n_live], (None if cs is None else cs[:self.n_live])
+        return table, self.dE, cs
+
+    def _workspace(self, B, table, device):
+        if B not in self._ws:
+            self._ws[B] = self.local.workspace(B, table.shape[0], self.d, device)
+        return self._ws[B]
+
+    def stats(self, sr, table, cs, labels, cs_inv_scale):
+        """(lse, label logit) of this rank's sessions over the whole catalog (see ShardedScoreStats).  The caller
+        clears `self.tgrad.fresh` once per step before the first head."""
+        live, dE, csl = self._live(table, cs)
+        ws = self._workspace(sr.shape[0] * self.world, table, sr.device)
+        return ShardedScoreStats.apply(sr, live, csl, labels, dE, self.lo, ws, cs_inv_scale, self.local, self.group,
+                                       self.tgrad)
+
+    def log_probs(self, sr, table, cs, data_parallel=False):
+        """(B, V) log-probabilities (the reference models' forward() output; compat / evaluation path, no gradient):
+        local log-sum-exp per shard -> global lse -> each rank's columns -> all-gather of the column blocks."""
+        with torch.no_grad():
+            n_loc = sr.shape[0]
+            sr_all = all_gather_cat(sr.contiguous(), self.group) if data_parallel else sr.contiguous()
+            B = sr_all.shape[0]
+            live, _, csl = self._live(table, cs)
+            ws = self._workspace(B, table, sr.device)
+            none = torch.full((B,), -1, dtype=torch.int32, device=sr.device)
+            lse_r, _ = self.local.ce_fwd(sr_all, live, csl, none, ws)
+            gathered = self.world > 1 or (FORCE and dist.is_initialized())
+            lse = torch.logsumexp(all_gather_cat(lse_r.unsqueeze(0), self.group), dim=0).contiguous() if gathered else lse_r
+            cols = self.local.logp_cols(sr_all, live, csl, lse)                    # [B, n_live]
+            if gathered:
+                pad = cols.new_full((B, self.per), float('-inf'))
+                pad[:, :self.n_live] = cols
+                allc = all_gather_cat(pad.t().contiguous(), self.group)            # [world*per, B]
+                cols = allc[:self.V].t().contiguous()
+            if data_parallel:
+                cols = cols[self.rank * n_loc:(self.rank + 1) * n_loc]
+            return cols
 
     def topk(self, sr, table, cs, k, data_parallel=False):
         """evaluation over the sharded table (SURVEY 8(e) "Eval"): every rank ranks its own rows with the fused

@@ -369,8 +369,6 @@ class MSGIFSR(_ScoringMixin, nn.Module):
     def fused_loss(self, *inputs_and_labels, dynB=None):
         if not (self.extra or (self.fusion and self.order > 1)):
             return super().fused_loss(*inputs_and_labels, dynB=dynB)
-        if self.shard is not None:
-            raise NotImplementedError('order fusion / extra with a row-sharded table')
         # msgifsr.py:311-321: score = sum_k softmax(alpha)_k score_k; loss = -mean log score[label]
         mg, labels = inputs_and_labels
         B = labels.numel()
@@ -383,12 +381,16 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             srs = [srs]
         lab32 = labels.to(torch.int32)
         st['tgrad'].fresh = False
-        tb = self._table_bf16(st)
+        sharded = self.shard is not None
+        tb = None if sharded else self._table_bf16(st)
         if self.extra:
             posc, valid, _, hit = self._in_session(mg, labels)
         logits = []
         for sr in srs:
-            lse, lab = ops.score_stats(sr, self._table(), cs, lab32, st['ws'][B], st['tgrad'], dynB, inv_scale, tb)
+            if sharded:      # global (lse, label logit) of this rank's sessions; heads accumulate into the shard's dE
+                lse, lab = self.shard.stats(sr, self._table(), cs, labels, inv_scale)
+            else:
+                lse, lab = ops.score_stats(sr, self._table(), cs, lab32, st['ws'][B], st['tgrad'], dynB, inv_scale, tb)
             if self.extra:
                 logits.append(self._extra_label_logprob(sr, lse, lab, posc, valid, hit, dynB))
             else:
@@ -397,6 +399,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             logp = torch.logsumexp(torch.stack(logits, 1) + torch.log_softmax(self.alpha, 0).unsqueeze(0), dim=1)
         else:
             logp = logits[0]
+        if sharded:          # this rank's share of the mean over the GLOBAL batch (replicated grads are summed over ranks)
+            return -logp.sum() / (B * self.shard.world)
         if dynB is not None:
             live = torch.arange(B, device=logp.device) < dynB
             return -torch.where(live, logp, torch.zeros_like(logp)).sum() / dynB.to(logp.dtype).clamp(min=1).sum()

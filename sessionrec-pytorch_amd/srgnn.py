@@ -104,9 +104,7 @@ class _ScoringMixin:
             sr = self.session_repr(*inputs)
             mixed = isinstance(sr, (list, tuple)) or getattr(self, 'extra', False)
             if mixed:
-                if self.shard is not None:
-                    raise NotImplementedError('order fusion / extra with a row-sharded table')
-                v, i = self(*inputs).topk(k)
+                v, i = self(*inputs).topk(k)          # sharded table: forward() assembles (B, V) from the column blocks
                 return v, i.to(torch.int32)
             st = self._state(sr.shape[0])
             cs, _ = self._col_scale(st)
@@ -118,6 +116,8 @@ class _ScoringMixin:
         B = sr.shape[0]
         st = self._state(B)
         cs, inv_scale = self._col_scale(st)
+        if self.shard is not None:           # evaluation / compat only (no gradient through the sharded (B, V) matrix)
+            return self.shard.log_probs(sr, self._table(), cs, data_parallel=self.shard.eval_data_parallel)
         return ops.score_logp(sr, self._table(), cs, st['ws'][B], inv_scale)
 
 

@@ -61,6 +61,24 @@ class TorchLocal:
         dE.copy_(g)
         return p @ table
 
+    def stats_bwd(self, sr, table, cs, labels_local, lse, ga, gc, dE, ws, cs_inv_scale, accumulate):
+        z = self._z(sr, table, cs)
+        dz = torch.exp(z - lse.unsqueeze(1)) * ga.unsqueeze(1)
+        m = labels_local >= 0
+        dz[m, labels_local[m].long()] -= gc[m]
+        if cs is not None:
+            dz = dz * cs.unsqueeze(0)
+        g = dz.t() @ sr
+        g = dE + g if accumulate else g
+        if cs is not None:
+            e = table * (cs * cs_inv_scale).unsqueeze(1)
+            g = g - e * (e * g).sum(1, keepdim=True)
+        dE.copy_(g)
+        return dz @ table
+
+    def logp_cols(self, sr, table, cs, lse):
+        return self._z(sr, table, cs) - lse.unsqueeze(1)
+
     def topk(self, sr, table, cs, k):
         z = self._z(sr, table, cs)
         o = torch.argsort(z, dim=1, descending=True, stable=True)[:, :k]      # stable: ties -> lower id
@@ -214,3 +232,79 @@ def test_shard_bounds_cover_the_catalog():
                 assert lo == min(V, r * per) and hi - lo <= per and per % 64 == 0
                 seen += hi - lo
             assert seen == V
+
+
+# ---------------------------------------------------------------------- mixtures of soft-maxes over the sharded table
+def _mix_reference(table, per_rank, cosine, alpha):
+    W = table.clone().requires_grad_()
+    Wn = torch.nn.functional.normalize(W, dim=1) * 12.0 if cosine else W
+    la = torch.log_softmax(alpha, 0)
+    terms, labs = [], torch.cat([b['labels'] for b in per_rank])
+    for h in range(2):
+        sr = torch.cat([W[b['idx']][b['pick']] @ (b['sr_w'] * (1.0 + h)) for b in per_rank])
+        terms.append(torch.log_softmax(sr @ Wn.t(), 1).gather(1, labs[:, None])[:, 0] + la[h])
+    loss = -torch.logsumexp(torch.stack(terms, 1), 1).mean()
+    loss.backward()
+    sr_eval = per_rank[0]['sr_eval']
+    logp = torch.log_softmax(sr_eval @ Wn.detach().t(), 1)
+    return loss.item(), W.grad, logp
+
+
+def _mix_worker(rank, world, port, cosine, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        D = pkg('dist')
+        table, per_rank = _make(world)
+        b = per_rank[rank]
+        model = FakeModel(table)
+        vp = D.VocabParallel(model, local=TorchLocal())
+        shard = model._table()
+        cs = 12.0 / shard.detach().norm(dim=1).clamp(min=1e-12) if cosine else None
+        rows = vp.lookup(shard, b['idx'].int(), _uniq(b['idx']))
+        la = torch.log_softmax(torch.tensor([0.3, -0.2]), 0)
+        vp.tgrad.fresh = False
+        terms = []
+        for h in range(2):
+            sr = rows[b['pick']] @ (b['sr_w'] * (1.0 + h))
+            lse, lab = vp.stats(sr, shard, cs, b['labels'], 1.0 / 12.0)
+            terms.append(lab - lse + la[h])
+        B = b['labels'].numel()
+        loss = -torch.logsumexp(torch.stack(terms, 1), 1).sum() / (B * world)
+        loss.backward()
+        total = loss.detach().clone()
+        dist.all_reduce(total)                                # each rank holds its share of the global mean
+        logp = vp.log_probs(per_rank[0]['sr_eval'], shard, cs)
+        n = 8 // world
+        logp_dp = vp.log_probs(per_rank[0]['sr_eval'][rank * n:(rank + 1) * n], shard, cs, data_parallel=True)
+        q.put((rank, total.item(), vp.lo, vp.hi, vp.dE[:vp.n_live].clone().numpy().tolist(), logp.numpy().tolist(),
+               logp_dp.numpy().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('cosine', [False, True])
+def test_sharded_softmax_mixture_and_logprobs_match_single_device(cosine):
+    """ShardedScoreStats (two heads sharing the table, second backward accumulates) and VocabParallel.log_probs"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mix_worker, args=(r, world, port, cosine, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table, per_rank = _make(world)
+    ref_loss, ref_grad, ref_logp = _mix_reference(table, per_rank, cosine, torch.tensor([0.3, -0.2]))
+    n = 8 // world
+    for rank, loss, lo, hi, dE, logp, logp_dp in res:
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+        dE = torch.tensor(dE)
+        assert torch.allclose(dE, ref_grad[lo:hi], rtol=1e-4, atol=1e-6), (rank, (dE - ref_grad[lo:hi]).abs().max())
+        logp = torch.tensor(logp)
+        assert logp.shape == ref_logp.shape and torch.allclose(logp, ref_logp, rtol=1e-5, atol=1e-5)
+        assert torch.allclose(torch.tensor(logp_dp), ref_logp[rank * n:(rank + 1) * n], rtol=1e-5, atol=1e-5)

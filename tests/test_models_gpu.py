@@ -189,7 +189,8 @@ def test_model_matches_reference_fixture(dev, name):
     assert agree > 0.98, 'top-20 agreement %.3f' % agree
 
 
-@pytest.mark.parametrize('name', ['niser_s32', 'msgifsr_K2_edge'])
+@pytest.mark.parametrize('name', ['niser_s32', 'msgifsr_K2_edge', 'msgifsr_K3_fus_s32', 'msgifsr_K3_ext_fus_edge',
+                                  'msgifsr_K1_ext_s32'])
 def test_vocab_parallel_single_rank_equals_plain_path(dev, name):
     """dist.VocabParallel with one rank (no process group) must give the plain fused path's loss and
     table gradient: exercises HipLocal (masked gather, segmented rows, rank-by-rank add, sharded CE)."""
@@ -222,6 +223,8 @@ def test_vocab_parallel_single_rank_equals_plain_path(dev, name):
     v2, i2 = sharded.topk(*inputs, k=20)
     assert torch.equal(i1, i2)
     close(v2, v1, rtol=1e-6, atol=1e-6, what='top-k scores')
+    with torch.no_grad():                # forward() over the sharded table: (B, V) assembled from the column blocks
+        close(sharded(*inputs), plain(*inputs), rtol=1e-5, atol=1e-5, what='log-probs')
 
 
 @pytest.mark.parametrize('name', ['srgnn_s32', 'niser_s32', 'lessr_L3_s32', 'msgifsr_K3_s32', 'msgifsr_K3_edge',
