@@ -213,9 +213,18 @@ int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const f
  * in double from cfg = double[5] {lr, beta1, beta2, eps, weight_decay} (torch.optim.Adam's host arithmetic,
  * train.py:70-75).  Makes a captured / pipelined optimizer step independent of host timing. */
 int srec_adam_hyper(int* counter, const void* cfg, float* hyper, void* stream);
-/* one launch for many small tensors: desc[t] = {p, g, m, v, numel, use_wd} (6 x int64, device), blockmap[b] =
- * {tensor, first element} (2 x int32, device) per 1024-element block */
-int srec_adam_multi(const long long* desc, const int* blockmap, int total_blocks, const float* hyper, void* stream);
+/* one launch for many small tensors (48 per launch): desc = HOST srec_adam_multi_desc below; the pointers travel by
+ * value in the kernel arguments (nothing staged in device memory; a captured hipGraph bakes them into the node) */
+typedef struct srec_adam_multi_desc {
+    int nt;                    /* number of tensors */
+    const int* use_wd;         /* [nt] apply the group's weight decay (0 for bias / batch_norm / activation, train.py:18) */
+    const long* numel;         /* [nt] */
+    float* const* p;           /* [nt] parameters ... */
+    const float* const* g;     /* ... gradients ... */
+    float* const* m;           /* ... exp_avg ... */
+    float* const* v;           /* ... exp_avg_sq (device pointers, 4-B aligned; float4 path when all four are 16-B aligned) */
+} srec_adam_multi_desc;
+int srec_adam_multi(const void* desc, const float* hyper, void* stream);
 int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
                    int use_wd, float max_norm, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
                    void* stream);

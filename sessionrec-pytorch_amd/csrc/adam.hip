@@ -99,33 +99,89 @@ __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict_
         cs_out[i] = cs_scale * (eps_mode == 0 ? 1.f / fmaxf(nrm, cs_eps) : 1.f / (nrm + cs_eps));
 }
 
-// Multi-tensor variant: ONE launch updates every (small) parameter tensor of a group.  desc[t] = {p, g, m, v,
-// numel, use_wd} as 6 x int64 (device memory); blockmap[b] = {tensor index, first element} per 1024-element block.
-__global__ void adam_multi_kernel(const long long* __restrict__ desc, const int* __restrict__ blockmap,
-                                  const float* __restrict__ hyper) {
-    const int t = blockmap[2 * blockIdx.x], e0 = blockmap[2 * blockIdx.x + 1];
-    const long long* d = desc + 6 * (size_t)t;
-    float* p = reinterpret_cast<float*>(d[0]);
-    const float* g = reinterpret_cast<const float*>(d[1]);
-    float* m = reinterpret_cast<float*>(d[2]);
-    float* v = reinterpret_cast<float*>(d[3]);
-    const long long n = d[4];
-    const Hyper h = load_hyper(hyper);
-    const float wd = d[5] ? h.wd : 0.f;
-    const long long i0 = (long long)e0 + threadIdx.x * 4;
+// Multi-tensor variant: ONE launch updates up to MT (small) parameter tensors of a group.  The descriptor travels BY
+// VALUE in the kernel arguments (no device-side descriptor arrays to stage, nothing to re-upload when autograd hands
+// out new gradient buffers; a captured hipGraph bakes it into the kernel node).  Workgroup b owns a 4096-element chunk
+// of one tensor: blk0[] is the prefix sum of chunks, found by a scalar binary search; float4 accesses when the four
+// pointers are 16-B aligned, scalar otherwise / for the tail.
+constexpr int MT = 48;
+constexpr int MCHUNK = 4096;
+struct MultiArgs {
+    float* p[MT];
+    const float* g[MT];
+    float* m[MT];
+    float* v[MT];
+    int n[MT];
+    int blk0[MT + 1];
+    unsigned long long wd_mask;
+    const float* hyper;
+    int nt;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(MultiArgs a) {
+    int lo = 0, hi = a.nt;                                   // largest t with blk0[t] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int t = lo;
+    float* __restrict__ p = a.p[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const int n = a.n[t];
+    const Hyper h = load_hyper(a.hyper);
+    const float wd = ((a.wd_mask >> t) & 1ull) ? h.wd : 0.f, step = h.step, rs2 = h.bc2s;
+    const int e0 = ((int)blockIdx.x - a.blk0[t]) * MCHUNK;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long i = i0 + j;
-        if (i < n) adam1(p[i], g[i], m[i], v[i], h, wd, h.step, h.bc2s);
+    for (int u = 0; u < MCHUNK / 1024; ++u) {
+        const int i = e0 + u * 1024 + (int)threadIdx.x * 4;
+        if (i >= n) break;
+        if (vec && i + 3 < n) {
+            float4 pp = *reinterpret_cast<float4*>(p + i);
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            float4 mm = *reinterpret_cast<float4*>(m + i);
+            float4 vv = *reinterpret_cast<float4*>(v + i);
+            adam1(pp.x, gg.x, mm.x, vv.x, h, wd, step, rs2);
+            adam1(pp.y, gg.y, mm.y, vv.y, h, wd, step, rs2);
+            adam1(pp.z, gg.z, mm.z, vv.z, h, wd, step, rs2);
+            adam1(pp.w, gg.w, mm.w, vv.w, h, wd, step, rs2);
+            *reinterpret_cast<float4*>(p + i) = pp;
+            *reinterpret_cast<float4*>(m + i) = mm;
+            *reinterpret_cast<float4*>(v + i) = vv;
+        } else {
+            for (int j = i; j < n && j < i + 4; ++j) adam1(p[j], g[j], m[j], v[j], h, wd, step, rs2);
+        }
     }
 }
 
 }  // namespace
 
-extern "C" int srec_adam_multi(const long long* desc, const int* blockmap, int total_blocks, const float* hyper,
-                               void* stream) {
-    if (total_blocks <= 0) return 0;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, desc, blockmap, hyper);
+// desc: HOST srec_adam_multi_desc (srec.h) - nt tensors {p, g, m, v, numel, use_wd}; any nt (launched MT at a time).
+extern "C" int srec_adam_multi(const void* desc_, const float* hyper, void* stream) {
+    struct Desc { int nt; const int* use_wd; const long* numel; float* const* p; const float* const* g; float* const* m; float* const* v; };
+    const Desc* d = (const Desc*)desc_;
+    if (d == nullptr || d->nt < 0 || hyper == nullptr) return SREC_BAD_ARG;
+    for (int t0 = 0; t0 < d->nt; t0 += MT) {
+        MultiArgs a{};
+        a.nt = d->nt - t0 < MT ? d->nt - t0 : MT;
+        a.hyper = hyper;
+        int blocks = 0;
+        for (int t = 0; t < a.nt; ++t) {
+            const int s = t0 + t;
+            if (d->numel[s] <= 0 || d->numel[s] > 0x7fffffffL || d->p[s] == nullptr || d->g[s] == nullptr ||
+                d->m[s] == nullptr || d->v[s] == nullptr || (((uintptr_t)d->p[s] | (uintptr_t)d->g[s] | (uintptr_t)d->m[s] | (uintptr_t)d->v[s]) & 3))
+                return SREC_BAD_ARG;
+            a.p[t] = d->p[s]; a.g[t] = d->g[s]; a.m[t] = d->m[s]; a.v[t] = d->v[s];
+            a.n[t] = (int)d->numel[s];
+            if (d->use_wd[s]) a.wd_mask |= 1ull << t;
+            a.blk0[t] = blocks;
+            blocks += (a.n[t] + MCHUNK - 1) / MCHUNK;
+        }
+        a.blk0[a.nt] = blocks;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
     SREC_LAUNCH_CHECK();
     return 0;
 }

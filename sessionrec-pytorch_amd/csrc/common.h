@@ -6,6 +6,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// fp32 -> bf16, round to nearest even, with the gfx950 conversion instruction (v_cvt_pk_bf16_f32: one VALU op per PAIR
+// instead of ~6 integer ops per element - operand staging in the MFMA kernels is VALU-bound without it)
+typedef __bf16 srec_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float srec_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned srec_pack_bf16(float lo, float hi) {
+    const srec_f32x2 v = {lo, hi};
+    const srec_bf16x2 r = __builtin_convertvector(v, srec_bf16x2);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned short srec_f2bf(float a) { return (unsigned short)(srec_pack_bf16(a, 0.f) & 0xffffu); }
+
 #define SREC_LAUNCH_CHECK()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \

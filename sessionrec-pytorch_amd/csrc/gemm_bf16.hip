@@ -19,12 +19,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 32, LDS_LD = BK + 8;   // elements (bf16)
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
-    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) & 0xffff0000u;
-    return ua | ub;
-}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return srec_pack_bf16(a, b); }
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const float* __restrict__ A, int lda,

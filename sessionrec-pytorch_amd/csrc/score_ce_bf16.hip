@@ -36,16 +36,8 @@ constexpr int SB = 512;   // streamed rows per side-data block (lse / labels / c
 constexpr int OWN = 128;  // owner rows per workgroup (4 waves x 32)
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-__device__ __forceinline__ unsigned short f2bf(float a) {
-    unsigned u = __float_as_uint(a);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
-    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) & 0xffff0000u;
-    return ua | ub;
-}
+__device__ __forceinline__ unsigned short f2bf(float a) { return srec_f2bf(a); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return srec_pack_bf16(a, b); }
 __device__ __forceinline__ int kperm(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // dst16[r, c] = bf16(src[r, c]) (c < Dp, zero beyond d);  dstT16[c, kperm(r)] = bf16(src[r, c]);

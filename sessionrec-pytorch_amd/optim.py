@@ -12,9 +12,18 @@ Graph-friendly: the step counter lives on the DEVICE and is advanced by the laun
 of `launch()` replays correctly however far the host runs ahead; `advance()` is host bookkeeping
 plus a stream-ordered config copy when the lr schedule changed a group.
 """
+import ctypes as _ct
+
 import torch
 
 from ._lib import lib, ptr, stream
+
+
+class _AdamMultiDesc(_ct.Structure):
+    """srec_adam_multi_desc (include/srec.h)"""
+    _fields_ = [('nt', _ct.c_int), ('use_wd', _ct.POINTER(_ct.c_int)), ('numel', _ct.POINTER(_ct.c_long)),
+                ('p', _ct.POINTER(_ct.c_void_p)), ('g', _ct.POINTER(_ct.c_void_p)), ('m', _ct.POINTER(_ct.c_void_p)),
+                ('v', _ct.POINTER(_ct.c_void_p))]
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -22,7 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.model = model
-        self._hyper = {}            # (group index, step offset) -> device step state; ('multi', ...) -> descriptors
+        self._hyper = {}            # (group index, step offset) -> device step state
         self._frozen = None         # parameter lists frozen by a captured graph
 
     # ------------------------------------------------------------------ helpers
@@ -184,38 +193,16 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     lib.srec_adam_flat(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.numel(),
                                        ptr(hyper), use_wd, stream())
-            for slot, rows in multi.items():      # every small tensor of the group in ONE launch
-                desc, bmap = [], []
-                for t, (p, g, state) in enumerate(rows):
-                    desc += [p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
-                             p.numel(), use_wd]
-                    for e0 in range(0, p.numel(), 1024):
-                        bmap += [t, e0]
-                dev = rows[0][0].device
-                key = ('multi', gi, slot)
-                hd = torch.tensor(desc, dtype=torch.int64)
-                hb = torch.tensor(bmap, dtype=torch.int32)
-                ent = self._hyper.get(key)
-                sig = (tuple(desc), tuple(bmap))
-                if ent is None or ent[2] != sig:
-                    # descriptor changed (tensors re-allocated).  Eager: NEW pinned staging buffers, never overwritten
-                    # in place - the copies are asynchronous and the caching host allocator keeps a block alive until
-                    # the copy that reads it has run.  Under graph capture nothing executes and pinned memory cannot be
-                    # allocated: the buffers of the (synchronised) warm-up are rewritten and become the graph's own.
-                    same = ent is not None and ent[3].numel() == hd.numel() and ent[4].numel() == hb.numel()
-                    if same and torch.cuda.is_current_stream_capturing():
-                        hp, bp, dd, db = ent[3], ent[4], ent[0], ent[1]
-                        hp.copy_(hd)
-                        bp.copy_(hb)
-                    else:
-                        hp, bp = hd.pin_memory(), hb.pin_memory()
-                        dd, db = torch.empty_like(hd, device=dev), torch.empty_like(hb, device=dev)
-                    ent = (dd, db, sig, hp, bp)
-                    dd.copy_(hp, non_blocking=True)
-                    db.copy_(bp, non_blocking=True)
-                    self._hyper[key] = ent
-                hyper = self._buffers(gi, slot, dev)['hyper']
-                lib.srec_adam_multi(ptr(ent[0]), ptr(ent[1]), len(bmap) // 2, ptr(hyper), stream())
+            for slot, rows in multi.items():      # every small tensor of the group in ONE launch (by-value descriptor)
+                nt = len(rows)
+                arr = (_ct.c_void_p * nt)
+                desc = _AdamMultiDesc(
+                    nt, (_ct.c_int * nt)(*([use_wd] * nt)), (_ct.c_long * nt)(*[p.numel() for p, _, _ in rows]),
+                    arr(*[p.data_ptr() for p, _, _ in rows]), arr(*[g.data_ptr() for _, g, _ in rows]),
+                    arr(*[st_['exp_avg'].data_ptr() for _, _, st_ in rows]),
+                    arr(*[st_['exp_avg_sq'].data_ptr() for _, _, st_ in rows]))
+                hyper = self._buffers(gi, slot, rows[0][0].device)['hyper']
+                lib.srec_adam_multi(_ct.addressof(desc), ptr(hyper), stream())
         if tgrad is not None:
             tgrad.fresh = False
         from . import ops

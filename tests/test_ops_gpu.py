@@ -239,6 +239,29 @@ def test_fused_adam_matches_torch(dev):
         close(a, b, what='adam', rtol=1e-5, atol=1e-6)
 
 
+def test_fused_adam_multi_tensor_launch_shapes(dev):
+    """srec_adam_multi: more tensors than one launch carries (48), sizes that are not multiples of 4 or of the 4096
+    chunk, and a parameter whose storage is only 4-byte aligned (scalar path)."""
+    optim = importlib.import_module('sessionrec-pytorch_amd.optim')
+    torch.manual_seed(9)
+    sizes = [1, 2, 3, 5, 7, 64, 255, 1023, 4095, 4096, 4097, 9001, 70001] + [13 + 3 * i for i in range(50)]
+    base = torch.randn(1000 + 1, device=dev)
+    p1 = [torch.randn(n, device=dev).requires_grad_() for n in sizes]
+    p1.append(base[1:].detach().requires_grad_())            # data_ptr % 16 == 4
+    assert p1[-1].data_ptr() % 16 == 4
+    p2 = [p.detach().clone().requires_grad_() for p in p1]
+    o1 = optim.FusedAdam(p1, lr=3e-3, weight_decay=1e-2)
+    o2 = torch.optim.Adam(p2, lr=3e-3, weight_decay=1e-2)
+    for step in range(3):
+        for a, b in zip(p1, p2):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+    for n, a, b in zip(sizes + [1000], p1, p2):
+        close(a, b, what='adam multi n=%d' % n, rtol=1e-5, atol=1e-6)
+
+
 def test_gru_step_and_gram_combine(dev):
     ops = _ops()
     torch.manual_seed(6)
