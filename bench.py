@@ -79,14 +79,14 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False
     return [fn(s) for s in samples], samples
 
 
-def build_model(sp, name, V, d, order):
+def build_model(sp, name, V, d, order, dropout=0.0):
     if name == 'SRGNN':
         return sp.SRGNN(V, d, 1, feat_drop=0.0)
     if name == 'NISER':
         return sp.NISER(V, d, 1, feat_drop=0.0)
     if name == 'LESSR':
         return sp.LESSR(V, d, 1, feat_drop=0.0)
-    return sp.MSGIFSR(V, 'synthetic', d, 1, dropout=0.0, order=order, extra=False, fusion=False)
+    return sp.MSGIFSR(V, 'synthetic', d, 1, dropout=dropout, order=order, extra=False, fusion=False)
 
 
 def time_dominant_kernel(model, B, V, d, dev, iters=20, force_fp32=False):
@@ -217,6 +217,7 @@ def main():
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dropout', type=float, default=0.0, help='MSGIFSR feature / attention dropout')
     ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
                     help="MFMA operand type of the forward / backward-data GEMMs ('bf16' = BASELINE config C3)")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
@@ -252,7 +253,7 @@ def main():
     use_graph = (not args.no_graph) and padded       # N > 1: the RCCL calls are captured in the step graph too
     batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank, padded=padded)
     torch.manual_seed(123)
-    model = build_model(sp, args.model, V, d, args.order)
+    model = build_model(sp, args.model, V, d, args.order, args.dropout)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     shard = None

@@ -71,7 +71,8 @@ class FlatBatch:
     def to(self, device, non_blocking=False):
         if torch.device(device) == self.buf.device:
             return self
-        return FlatBatch(self.buf.to(device, non_blocking=non_blocking), self.layout, self.meta)
+        # a pinned buffer (DataLoader(pin_memory=True)) is copied asynchronously: the host goes on to the next batch
+        return FlatBatch(self.buf.to(device, non_blocking=non_blocking or self.buf.is_pinned()), self.layout, self.meta)
 
     def pin_memory(self):
         return FlatBatch(self.buf.pin_memory(), self.layout, self.meta)

@@ -389,12 +389,20 @@ def collate_fn_factory(*seq_to_graph_fns, caps=None):
     def collate_fn(samples):
         seqs, labels = zip(*samples)
         inputs = []
-        for fn in seq_to_graph_fns:
-            fb = collate_native(kinds[fn], seqs, 1, caps) if fn in kinds else None
-            if fb is None:
-                fb = batch_homogeneous([fn(s) for s in seqs], caps)
-            inputs.append(fb)
-        return inputs, _labels(labels, caps)
+        use = caps
+        for attempt in range(2):
+            try:
+                inputs = []
+                for fn in seq_to_graph_fns:
+                    fb = collate_native(kinds[fn], seqs, 1, use) if fn in kinds else None
+                    if fb is None:
+                        fb = batch_homogeneous([fn(s) for s in seqs], use)
+                    inputs.append(fb)
+                return inputs, _labels(labels, use)
+            except (ValueError, AssertionError):
+                if use is None:
+                    raise
+                use = None                       # the batch does not fit the capacities: exact layout (eager step)
     return collate_fn
 
 
@@ -402,13 +410,39 @@ def collate_fn_factory_ccs(seq_to_graph_fns, order, caps=None):
     def collate_fn(samples):
         seqs, labels = zip(*samples)
         inputs = []
-        for fn in seq_to_graph_fns:
-            fb = collate_native('ccs', seqs, order, caps) if fn is seq_to_ccs_graph else None
-            if fb is None:
-                fb = batch_ccs([fn(s, order) for s in seqs], caps)
-            inputs.append(fb)
-        return inputs, _labels(labels, caps)
+        use = caps
+        for attempt in range(2):
+            try:
+                inputs = []
+                for fn in seq_to_graph_fns:
+                    fb = collate_native('ccs', seqs, order, use) if fn is seq_to_ccs_graph else None
+                    if fb is None:
+                        fb = batch_ccs([fn(s, order) for s in seqs], use)
+                    inputs.append(fb)
+                return inputs, _labels(labels, use)
+            except (ValueError, AssertionError):
+                if use is None:
+                    raise
+                use = None                       # the batch does not fit the capacities: exact layout (eager step)
     return collate_fn
+
+
+def estimate_caps(dataset, batch_size, headroom=1.15):
+    """capacities for capacity-padded batches of `dataset` (an AugmentedDataset: index[:, 1] = prefix length): nodes of any
+    order, edges of any relation and distinct items of a batch are all bounded by its total click count, so the cap is
+    the largest click count of a run of batch_size consecutive samples (exact for the sequential loaders, typical for
+    the shuffled ones) plus headroom, never above the worst case.  A batch that still does not fit is collated
+    unpadded (collate_fn_factory*(..., caps) falls back) and simply runs as eager launches."""
+    lens = np.asarray(dataset.index[:, 1], dtype=np.int64)
+    if len(lens) == 0:
+        return default_caps(batch_size)
+    cs = np.concatenate([[0], np.cumsum(lens)])
+    starts = np.arange(0, len(lens), batch_size)
+    sums = cs[np.minimum(starts + batch_size, len(lens))] - cs[starts]
+    n = int(sums.max() * headroom) + 64
+    n = min(n, batch_size * int(lens.max()))
+    n = (n + 255) // 256 * 256
+    return dict(B=batch_size, N=n, E=n, U=n)
 
 
 def default_caps(batch_size, max_len=20, headroom=1.0):

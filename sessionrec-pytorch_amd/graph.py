@@ -23,6 +23,7 @@ class GraphedTrainStep:
         self._sig = [self._signature(x) for x in inputs]
         # ---- eager warm-up on a side stream (lazy allocations, LDS opt-in attributes, Adam state), then undo
         #      its effect on parameters / optimizer state so capture does not change the training trajectory
+        snap_o = optimizer.snapshot()                    # a resumed / already running optimizer keeps its moments
         snap_p = [p.detach().clone() for p in model.parameters()]
         snap_b = [b.detach().clone() for b in model.buffers()]
         s = torch.cuda.Stream()
@@ -37,10 +38,7 @@ class GraphedTrainStep:
                 p.copy_(q)
             for b, q in zip(model.buffers(), snap_b):
                 b.copy_(q)
-            optimizer.reset_steps()                      # host and device step counters
-            for st in optimizer.state.values():
-                st['exp_avg'].zero_()
-                st['exp_avg_sq'].zero_()
+        optimizer.restore(snap_o)                        # moments, host and device step counters
         ms = model.__dict__.get('_srec_state')
         if ms is not None:
             ms['cs_fresh'] = False

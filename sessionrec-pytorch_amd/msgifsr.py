@@ -211,6 +211,11 @@ class AttnReadout(nn.Module):
 
 
 class MSGIFSR(_ScoringMixin, nn.Module):
+    @property
+    def graph_capable(self):
+        """the `extra` epilogue sizes a [B, longest session] view from a per-batch host value: eager only"""
+        return not self.extra
+
     def __init__(self, num_items, datasets, embedding_dim, num_layers, dropout=0.0, reducer='mean', order=3,
                  norm=True, extra=True, fusion=True, device=torch.device('cpu')):
         super().__init__()

@@ -94,6 +94,31 @@ class FusedAdam(torch.optim.Optimizer):
                 ent['counter'].zero_()
                 ent['fresh'] = False
 
+    def snapshot(self):
+        """moments and step counts as they are now (GraphedTrainStep: undo of its eager warm-up steps)"""
+        return dict(T=getattr(self, '_T', 0),
+                    state={p: (st['step'], st['exp_avg'].clone(), st['exp_avg_sq'].clone())
+                           for p, st in self.state.items() if 'exp_avg' in st})
+
+    def restore(self, snap):
+        """back to a snapshot(): parameters that had no state then start from zero moments and step 0"""
+        self._T = snap['T']
+        with torch.no_grad():
+            for p, st in self.state.items():
+                if 'exp_avg' not in st:
+                    continue
+                if p in snap['state']:
+                    st['step'] = snap['state'][p][0]
+                    st['exp_avg'].copy_(snap['state'][p][1])
+                    st['exp_avg_sq'].copy_(snap['state'][p][2])
+                else:
+                    st['step'] = 0
+                    st['exp_avg'].zero_()
+                    st['exp_avg_sq'].zero_()
+            for key, ent in self._hyper.items():
+                ent['counter'].fill_(max(self._T - key[1], 0))       # steps taken by the parameters of this offset slot
+                ent['fresh'] = False
+
     def load_state_dict(self, state_dict):
         """torch's loader + the device-side step state: counters are rebuilt from the restored per-parameter step
         counts the next time advance() meets each (group, offset) slot."""

@@ -66,6 +66,7 @@ class _ScoringMixin:
         return st['cs'], 1.0 / float(scale)
 
     shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
+    graph_capable = False      # True: every kernel of the step reads its live extents from the padded batch (hipGraph replay)
 
     def _lookup(self, idx, uniq, tgrad, dyn_n=None, dyn_u=None):
         """item rows for the batch: local gather, or the collective lookup when the table is sharded"""
@@ -157,6 +158,8 @@ class SRGNNLayer(nn.Module):
 
 
 class SRGNN(_ScoringMixin, nn.Module):
+    graph_capable = True
+
     def __init__(self, num_items, embedding_dim, num_layers, feat_drop=0.0, use_gnn_output=False):
         super().__init__()
         self.embedding = nn.Embedding(num_items, embedding_dim)

@@ -26,7 +26,7 @@ def fix_weight_decay(model):
 
 def prepare_batch(batch, device):
     inputs, labels = batch
-    return [x.to(device) for x in inputs], labels.to(device)
+    return [x.to(device) for x in inputs], labels.to(device, non_blocking=labels.is_pinned())
 
 
 def evaluate(model, data_loader, device, cutoff=20):
@@ -50,12 +50,18 @@ def evaluate(model, data_loader, device, cutoff=20):
 
 class TrainRunner:
     def __init__(self, dataset, model, train_loader, test_loader, device, lr=1e-3, weight_decay=0, patience=3,
-                 checkpoint=None, resume=True, hooks=()):
+                 checkpoint=None, resume=True, hooks=(), graph='auto'):
         """Same positional surface as the reference (train.py:57-69).  Additions (the reference has
         neither): `checkpoint` = path written after every epoch (model, optimizer incl. Adam moments and step counts,
         scheduler, epoch / batch counters, best metrics) and, with `resume`, read back at the start of train();
         `hooks` = callables hook(event: dict) invoked after every logged interval and every epoch (the reference's
-        wandb calls sit at the same two places)."""
+        wandb calls sit at the same two places).  `graph` ('auto' | False): on the GPU, batches that arrive
+        capacity-padded (collate_fn_factory*(..., caps=...)) replay ONE captured hipGraph of the whole step (forward,
+        backward, FusedAdam) instead of ~120 eager launches; a batch with another layout or relation pattern runs
+        eagerly, with the same result."""
+        self.graph = graph
+        self._gstep = None
+        self.graph_steps = self.eager_steps = 0
         self.checkpoint = checkpoint
         self.resume = resume
         self.hooks = list(hooks)
@@ -78,7 +84,33 @@ class TrainRunner:
         self.patience = patience
         self.loss_trace = []
 
+    def _graph_step(self, inputs, labels):
+        """replay of the captured step, or None when this batch has to run eagerly"""
+        if not (self.graph and self.fused and getattr(self.model, 'graph_capable', False)):
+            return None
+        if not all(getattr(x, 'meta', None) is not None and x.meta.get('padded') for x in inputs):
+            return None
+        from .graph import GraphedTrainStep
+        if self._gstep is None:
+            try:
+                self._gstep = GraphedTrainStep(self.model, self.optimizer, inputs, labels)
+            except Exception as e:                     # capture refused: stay eager for the rest of the run
+                print('hipGraph capture failed (%s: %s); eager launches' % (type(e).__name__, e))
+                self.graph = False
+                return None
+        try:
+            return self._gstep(inputs, labels)
+        except RuntimeError as e:
+            if 'differs from the captured one' not in str(e):
+                raise
+            return None
+
     def train_step(self, inputs, labels):
+        loss = self._graph_step(inputs, labels)
+        if loss is not None:
+            self.graph_steps += 1
+            return loss
+        self.eager_steps += 1
         self.optimizer.zero_grad()
         if self.fused:
             loss = self.model.fused_loss(*inputs, labels)
@@ -100,6 +132,7 @@ class TrainRunner:
         self.optimizer.load_state_dict(sd['optimizer'])
         self.scheduler.load_state_dict(sd['scheduler'])
         self.epoch, self.batch, self.best = sd['epoch'], sd['batch'], tuple(sd['best'])
+        self._gstep = None                 # optimizer state tensors were replaced: a captured step would use stale ones
         if self.fused:
             from . import ops
             ops.weights_changed()          # cached bf16 copies / column scales belong to the old weights
@@ -132,18 +165,31 @@ class TrainRunner:
         evaluate(self.model, self.test_loader, self.device)
         for _ in range(epochs - done):
             self.model.train()
+            pending = []                  # device-side loss values not read back yet
+
+            def flush():
+                # The reference reads loss.item() after every step (train.py:99-104), which drains the GPU queue each time.
+                # Same numbers, same NaN check, same running mean - read back in one go where they are needed (the log
+                # line, the end of the epoch), so the host prepares batch i+1 while the GPU runs step i.
+                nonlocal mean_loss
+                if pending:
+                    for v in th.stack(pending).tolist():
+                        assert v == v, 'loss is NaN'
+                        self.loss_trace.append(v)
+                        mean_loss += v / log_interval
+                    pending.clear()
             for batch in self.train_loader:
                 inputs, labels = prepare_batch(batch, self.device)
-                loss = self.train_step(inputs, labels).item()
-                assert loss == loss, 'loss is NaN'
-                self.loss_trace.append(loss)
-                mean_loss += loss / log_interval
+                pending.append(self.train_step(inputs, labels).detach().clone())   # a replayed step returns its static tensor
+                if (self.batch > 0 and self.batch % log_interval == 0) or len(pending) >= 256:
+                    flush()
                 if self.batch > 0 and self.batch % log_interval == 0:
                     print(f'Batch {self.batch}: Loss = {mean_loss:.4f}, Time Elapsed = {time.time() - t:.2f}s')
                     self._emit(kind='interval', batch=self.batch, loss=mean_loss, seconds=time.time() - t)
                     t = time.time()
                     mean_loss = 0
                 self.batch += 1
+            flush()
             self.scheduler.step()
             mrr, hit = evaluate(self.model, self.test_loader, self.device)
             print(f'Epoch {self.epoch}: MRR = {mrr * 100:.3f}%, Hit = {hit * 100:.3f}%')

@@ -37,6 +37,11 @@ def parse(model):
                    help='the number of processes to load the input graphs')
     p.add_argument('--valid-split', type=float, default=None, help='the fraction for the validation set')
     p.add_argument('--log-interval', type=int, default=100, help='print the loss after this number of iterations')
+    p.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'fp32'), choices=['fp32', 'bf16'],
+                   help='(not in the reference) fp32: results match the reference to fp32 round-off; bf16: bf16 MFMA operands '
+                        'with fp32 accumulation and master weights (BASELINE config C3), ~2x faster, metrics within 0.03 pt')
+    p.add_argument('--no-graph', action='store_true',
+                   help='(not in the reference) eager launches instead of replaying one captured hipGraph per training step')
     p.add_argument('--checkpoint', default=None,
                    help='(not in the reference) write a resumable checkpoint here after every epoch; resume from it if present')
     p.add_argument('--metrics-log', default=None, help='(not in the reference) append one JSON line per logged interval / epoch')
@@ -82,6 +87,9 @@ def run(model_name):
     from src.utils.train import TrainRunner
 
     device = th.device('cuda' if th.cuda.is_available() else 'cpu')
+    if device.type == 'cuda':
+        from importlib import import_module
+        import_module('sessionrec-pytorch_amd.ops').set_precision(args.precision)
     print('reading dataset')
     train_sessions, test_sessions, num_items = read_dataset(Path(args.dataset_dir))
     if args.valid_split is not None:
@@ -89,36 +97,45 @@ def run(model_name):
         test_sessions = train_sessions[-num_valid:]
         train_sessions = train_sessions[:-num_valid]
     train_set, test_set = AugmentedDataset(train_sessions), AugmentedDataset(test_sessions)
+    caps = None
+    if device.type == 'cuda' and not args.no_graph and model_name != 'LESSR' and not getattr(args, 'extra', False):
+        from src.utils.data.collate import estimate_caps
+        caps = estimate_caps(train_set, args.batch_size)     # capacity-padded training batches -> whole-step hipGraph replay
     print(len(train_set))
     print(len(test_set))
     if model_name == 'LESSR':
         fns = (seq_to_eop_multigraph, seq_to_shortcut_graph) if args.num_layers > 1 else (seq_to_eop_multigraph,)
-        collate_fn = collate_fn_factory(*fns)
+        collate_fn = train_collate_fn = collate_fn_factory(*fns)
         model = LESSR(num_items, args.embedding_dim, args.num_layers, feat_drop=args.feat_drop)
     elif model_name == 'MSGIFSR':
         collate_fn = collate_fn_factory_ccs((seq_to_ccs_graph,), order=args.order)
+        train_collate_fn = collate_fn_factory_ccs((seq_to_ccs_graph,), order=args.order, caps=caps)
         model = MSGIFSR(num_items, args.dataset_dir, args.embedding_dim, args.num_layers, dropout=args.feat_drop,
                         reducer=args.reducer, order=args.order, norm=args.norm, extra=args.extra, fusion=args.fusion,
                         device=device)
     else:
         collate_fn = collate_fn_factory(seq_to_session_graph)
+        train_collate_fn = collate_fn_factory(seq_to_session_graph, caps=caps)
         cls = NISER if model_name == 'NISER' else SRGNN
         model = cls(num_items, args.embedding_dim, args.num_layers, feat_drop=args.feat_drop)
+    pin = device.type == 'cuda'          # pinned batches: asynchronous H2D copies
     # reference loaders: LESSR / MSGIFSR train in time order (SequentialSampler), NISER shuffles; test shuffles
     if model_name in ('LESSR', 'MSGIFSR'):
         train_loader = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.num_workers,
-                                  collate_fn=collate_fn, sampler=SequentialSampler(train_set))
+                                  collate_fn=train_collate_fn, sampler=SequentialSampler(train_set), pin_memory=pin)
     else:
         train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
-                                  collate_fn=collate_fn)
+                                  collate_fn=train_collate_fn, pin_memory=pin)
     test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
                              collate_fn=collate_fn)
     model = model.to(device)
     print(model)
     runner = TrainRunner(args.dataset_dir, model, train_loader, test_loader, device=device, lr=args.lr,
                          weight_decay=args.weight_decay, patience=args.patience, checkpoint=args.checkpoint,
-                         hooks=[_jsonl(args.metrics_log)] if args.metrics_log else ())
+                         hooks=[_jsonl(args.metrics_log)] if args.metrics_log else (), graph=False if args.no_graph else 'auto')
     print('start training')
     mrr, hit = runner.train(args.epochs, args.log_interval)
+    if runner.graph_steps:
+        print(f'training steps: {runner.graph_steps} hipGraph replays, {runner.eager_steps} eager')
     print('MRR@20\tHR@20')
     print(f'{mrr * 100:.3f}%\t{hit * 100:.3f}%')

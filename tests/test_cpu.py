@@ -270,6 +270,29 @@ def test_train_runner_checkpoint_resume_and_hooks(tmp_path):
         assert torch.equal(a, b), k
 
 
+def test_estimate_caps_and_overflow_fallback():
+    """estimate_caps bounds every sequential batch of the dataset; a batch that does not fit given capacities is collated
+    with the exact layout instead (TrainRunner then runs it eagerly)"""
+    ds, col = pkg('dataset'), pkg('collate')
+    tr, te, V = ds.read_dataset(os.path.join(ROOT, 'datasets', 'sample'))
+    data = ds.AugmentedDataset(tr)
+    B = 64
+    caps = col.estimate_caps(data, B)
+    assert caps['B'] == B and caps['N'] % 256 == 0 and caps['N'] <= B * int(data.index[:, 1].max())
+    for fac in (lambda c: col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), 3, caps=c),
+                lambda c: col.collate_fn_factory(col.seq_to_session_graph, caps=c)):
+        ref_layout = None
+        for b in range(0, len(data) // B, 7):
+            (fb,), lab = fac(caps)([data[i] for i in range(b * B, (b + 1) * B)])
+            assert fb.meta['padded'] and lab.numel() == B
+            ref_layout = ref_layout or fb.layout
+            assert fb.layout == ref_layout                      # batch-independent offsets: one device buffer, one graph
+        (fb,), _ = fac(dict(caps, N=32, E=32, U=32))([data[i] for i in range(B)])
+        assert not fb.meta['padded']
+        (ex,), _ = fac(None)([data[i] for i in range(B)])
+        assert torch.equal(fb.buf, ex.buf)
+
+
 # ---------------------------------------------------------------------------------------- C ABI
 def test_c_abi_exports_every_declared_symbol():
     L = pkg('_lib')

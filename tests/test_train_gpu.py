@@ -101,3 +101,48 @@ def test_bf16_training_metrics_within_0p3pt_of_fp32(dev, model_name, dim):
     r = bf16_metric_check.run(model_name, epochs=3, dim=dim)
     assert r['fp32']['hit'] > 20.0                                  # the model did learn something
     assert abs(r['d_mrr_pt']) <= 0.3 and abs(r['d_hit_pt']) <= 0.3, r
+
+
+@pytest.mark.parametrize('model_name', ['MSGIFSR', 'NISER'])
+def test_train_runner_replays_the_captured_step(dev, model_name, tmp_path):
+    """TrainRunner(graph='auto'): capacity-padded batches replay ONE captured hipGraph of the whole step, batches that do
+    not fit the capacities (collated unpadded) run eagerly in between - and the run equals the all-eager run on the same
+    batches bit for bit,
+    also across a checkpoint resume (the optimizer's moments survive the capture warm-up)."""
+    import copy
+    sp, ds, col, train = pkg(), pkg('dataset'), pkg('collate'), pkg('train')
+    tr, te, V = ds.read_dataset(os.path.join(ROOT, 'datasets', 'sample'))
+    train_set = ds.AugmentedDataset(tr)
+    B, n = 64, 10
+    caps = col.estimate_caps(train_set, B)
+    torch.manual_seed(11)
+    if model_name == 'MSGIFSR':
+        m0 = sp.MSGIFSR(V, 'sample', 32, 1, dropout=0.0, order=2, extra=False, fusion=True).to(dev)
+        mk = lambda c: col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), 2, caps=c)
+    else:
+        m0 = sp.NISER(V, 32, 1).to(dev)
+        mk = lambda c: col.collate_fn_factory(col.seq_to_session_graph, caps=c)
+    samples = lambda b: [train_set[i] for i in range(b * B, (b + 1) * B)]
+    tight = dict(caps, N=64, E=64, U=64)                         # too small for a 64-session batch: falls back to exact
+    padded = [mk(caps)(samples(b)) for b in range(n)]
+    padded[4] = mk(tight)(samples(4))
+    assert padded[0][0][0].meta['padded'] and not padded[4][0][0].meta['padded']
+    exact = [mk(None)(samples(b)) for b in range(n)]
+    kw = dict(lr=1e-3, weight_decay=1e-4, patience=9)
+    # same batches, same layouts, eager launches (exact layouts pick other split-K factors: equal only to round-off)
+    eager = train.TrainRunner('sample', copy.deepcopy(m0), padded, exact[:2], dev, graph=False, **kw)
+    eager.train(2, log_interval=100)
+    assert eager.graph_steps == 0
+    g = train.TrainRunner('sample', copy.deepcopy(m0), padded, exact[:2], dev, **kw)
+    g.train(2, log_interval=100)
+    assert g.graph_steps == 2 * (n - 1) and g.eager_steps == 2
+    assert g.loss_trace == eager.loss_trace
+    for (k, a), (_, b) in zip(eager.model.state_dict().items(), g.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    # resume after epoch 1 into a fresh runner: capture happens with loaded Adam moments
+    ck = str(tmp_path / 'g.pt')
+    first = train.TrainRunner('sample', copy.deepcopy(m0), padded, exact[:2], dev, checkpoint=ck, **kw)
+    first.train(1, log_interval=100)
+    second = train.TrainRunner('sample', copy.deepcopy(m0), padded, exact[:2], dev, checkpoint=ck, **kw)
+    second.train(2, log_interval=100)
+    assert second.graph_steps == n - 1 and second.loss_trace == eager.loss_trace[n:]
