@@ -147,7 +147,7 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20, force_fp32=False):
     return out
 
 
-def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=12.0):
+def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=12.0, dropout=0.0):
     """the CPU oracle (restatement of the reference math: materialised logits, log(softmax), nll_loss,
     autograd backward, torch Adam with L2) on this box's host cores, bounded sample."""
     from oracle import collate_ref as oc
@@ -164,7 +164,7 @@ def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=12.0):
     elif model_name == 'LESSR':
         m, fn = om.LESSR(V, d, 1), oc.collate_fn_factory(oc.seq_to_eop_multigraph)
     else:
-        m = om.MSGIFSR(V, 'synthetic', d, 1, order=order, extra=False, fusion=False)
+        m = om.MSGIFSR(V, 'synthetic', d, 1, dropout=dropout, order=order, extra=False, fusion=False)
         fn = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), order)
     m.load_state_dict(state_dict)
     opt = torch.optim.Adam(train.fix_weight_decay(m), lr=1e-3, weight_decay=1e-4)
@@ -217,7 +217,8 @@ def main():
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--dropout', type=float, default=0.0, help='MSGIFSR feature / attention dropout')
+    ap.add_argument('--dropout', type=float, default=0.1,
+                    help='MSGIFSR feature / attention dropout (0.1 = --feat-drop default of the reference launcher, main_msgifsr.py:42)')
     ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
                     help="MFMA operand type of the forward / backward-data GEMMs ('bf16' = BASELINE config C3)")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
@@ -348,14 +349,14 @@ def main():
                     algorithmic_bytes=alg_bytes, algorithmic_flop=flop, kernel_ms=kms)
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.model, samples, V, d, args.order, state)
+            cpu = cpu_baseline(args.model, samples, V, d, args.order, state, dropout=args.dropout)
         out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=world * B * args.steps / dt,
                    unit='sessions/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
                    dtype='f32' if args.precision == 'fp32' else 'bf16 (MFMA operands; fp32 accumulate, master weights, scoring)', data='synthetic', launch='hipGraph replay' if use_graph else 'eager',
                    config=dict(workload='%s training step, synthetic Yoochoose-1/64 shape (V=%d items, d=%d, batch %d per GPU, '
                                         'session length<=20%s)' % (args.model, V, d, B,
-                                                                   ', order %d' % args.order if args.model == 'MSGIFSR' else ''),
+                                                                   ', order %d, dropout %g' % (args.order, args.dropout) if args.model == 'MSGIFSR' else ''),
                                global_batch=B * world, parallelism=('item table row-sharded x%d (vocab-parallel scoring, RCCL all-gather/reduce-scatter), '
                                             'encoder replicated' % world) if world > 1 else 'single GPU',
                                final_loss=final_loss),

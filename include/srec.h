@@ -238,6 +238,13 @@ int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, i
  *        d_attn_l / d_attn_r / d_bias of every module.  ws: srec_hg_ws_floats() floats of scratch. */
 int srec_hg_ws_floats(const void* desc, long* n_floats);
 int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg, void* stream);
+/* feature-dropout glue of a layer call in one pass each (GATConv feat_drop, gatconv.py:268-283): from uniform draws u
+ * [2, rows, D] (one mask per conv) and cnt [2, rows] (relation instances of the conv into each row): ms = mask / (1-p),
+ * xc = x * ms (the convs' dropped inputs), rm = cnt0 ms0 + cnt1 ms1, xres = x * rm (summed identity residuals);
+ * backward: dx += t0 * ms0 + t1 * ms1 (the convs' masked data gradients). */
+int srec_hg_drop_prep(const float* x, const float* u, const float* cnt, int rows, int D, float p, float* ms, float* xc,
+                      float* rm, float* xres, void* stream);
+int srec_hg_drop_merge(const float* t, const float* ms, long n, float* dx, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
                 int ld_dx, float* ws, void* stream);
 

@@ -784,3 +784,67 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
     SREC_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ feature dropout glue
+namespace {
+// One pass for the feature dropout of a layer call (HGATLayer with drop = (p_feat, p_attn), ops.py): from the uniform draws
+// u [2, n] (one per conv) and the rows x [n] (n = NT * D elements, 4 per thread):
+//   ms[c] = (u[c] >= p) / (1 - p)      mask * scale of conv c (kept for the backward)
+//   xc[c] = x * ms[c]                  the dropped inputs of the conv's GAT modules
+//   rm    = cnt[0] * ms[0] + cnt[1] * ms[1]      per-element residual scale (cnt[c][row] = instances of conv c into the row)
+//   xres  = x * rm
+__global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ cnt,
+                                    long n, int D, long rows, float p, float* __restrict__ ms, float* __restrict__ xc,
+                                    float* __restrict__ rm, float* __restrict__ xres) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float sc = 1.f / (1.f - p);
+    const long row = i / D;
+    const float c0 = cnt[row], c1 = cnt[rows + row];
+    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    const float4 u0 = *reinterpret_cast<const float4*>(u + i), u1 = *reinterpret_cast<const float4*>(u + n + i);
+    float4 m0, m1;
+    m0.x = u0.x >= p ? sc : 0.f; m0.y = u0.y >= p ? sc : 0.f; m0.z = u0.z >= p ? sc : 0.f; m0.w = u0.w >= p ? sc : 0.f;
+    m1.x = u1.x >= p ? sc : 0.f; m1.y = u1.y >= p ? sc : 0.f; m1.z = u1.z >= p ? sc : 0.f; m1.w = u1.w >= p ? sc : 0.f;
+    *reinterpret_cast<float4*>(ms + i) = m0;
+    *reinterpret_cast<float4*>(ms + n + i) = m1;
+    *reinterpret_cast<float4*>(xc + i) = make_float4(xv.x * m0.x, xv.y * m0.y, xv.z * m0.z, xv.w * m0.w);
+    *reinterpret_cast<float4*>(xc + n + i) = make_float4(xv.x * m1.x, xv.y * m1.y, xv.z * m1.z, xv.w * m1.w);
+    const float4 r = make_float4(c0 * m0.x + c1 * m1.x, c0 * m0.y + c1 * m1.y, c0 * m0.z + c1 * m1.z, c0 * m0.w + c1 * m1.w);
+    *reinterpret_cast<float4*>(rm + i) = r;
+    *reinterpret_cast<float4*>(xres + i) = make_float4(xv.x * r.x, xv.y * r.y, xv.z * r.z, xv.w * r.w);
+}
+
+// dx += t[0] * ms[0] + t[1] * ms[1]   (the two convs' masked data gradients)
+__global__ void hg_drop_merge_kernel(const float* __restrict__ t, const float* __restrict__ ms, long n, float* __restrict__ dx) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 a = *reinterpret_cast<const float4*>(t + i), b = *reinterpret_cast<const float4*>(t + n + i);
+    const float4 m0 = *reinterpret_cast<const float4*>(ms + i), m1 = *reinterpret_cast<const float4*>(ms + n + i);
+    float4 d = *reinterpret_cast<float4*>(dx + i);
+    d.x += a.x * m0.x + b.x * m1.x; d.y += a.y * m0.y + b.y * m1.y; d.z += a.z * m0.z + b.z * m1.z; d.w += a.w * m0.w + b.w * m1.w;
+    *reinterpret_cast<float4*>(dx + i) = d;
+}
+}  // namespace
+
+// x [rows, D] contiguous, u [2, rows, D] uniform draws, cnt [2, rows]; outputs ms / xc [2, rows, D], rm / xres [rows, D].
+extern "C" int srec_hg_drop_prep(const float* x, const float* u, const float* cnt, int rows, int D, float p, float* ms,
+                                 float* xc, float* rm, float* xres, void* stream) {
+    if (rows <= 0) return 0;
+    if (D <= 0 || (D & 3) || p < 0.f || p >= 1.f) return SREC_BAD_ARG;
+    const long n = (long)rows * D;
+    hipLaunchKernelGGL(hg_drop_prep_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, u,
+                       cnt, n, D, (long)rows, p, ms, xc, rm, xres);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx [n] += t[0] * ms[0] + t[1] * ms[1], t / ms [2, n]; n % 4 == 0
+extern "C" int srec_hg_drop_merge(const float* t, const float* ms, long n, float* dx, void* stream) {
+    if (n <= 0) return 0;
+    if (n & 3) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(hg_drop_merge_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, ms,
+                       n, dx);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

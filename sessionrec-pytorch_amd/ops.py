@@ -1295,6 +1295,25 @@ class HgPlan:
 _HG_WS = {}
 
 
+_CNT_CACHE = {}
+
+
+def _inst_counts(plan, NT, dev):
+    """[2, NT, 1]: how many relation instances of conv1 / conv2 use each stacked row as a DESTINATION (identity residual
+    count, gatconv.py:306-308) - a function of the plan's static topology"""
+    key = (str(dev), NT, tuple(plan.mod_conv), tuple((m, tuple(plan.types[plan.blocks[db][1]][:2])) for (m, sb, db, gr) in plan.insts))
+    cnt = _CNT_CACHE.get(key)
+    if cnt is None:
+        host = torch.zeros(2, NT, 1)
+        for (m, sb, db, gr) in plan.insts:
+            t0, nc = plan.types[plan.blocks[db][1]][:2]
+            host[plan.mod_conv[m], t0:t0 + nc] += 1.0
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('instance counts must be cached by an eager warm-up step before graph capture')
+        cnt = _CNT_CACHE[key] = host.to(dev)
+    return cnt
+
+
 class HGATLayer(torch.autograd.Function):
     """out = MSHGNN(x): all relation instances of conv1 / conv2 in one batched pass (csrc/hgat.hip) around the fc
     GEMMs.  params = (fc.weight, attn_l, attn_r, bias) per module, in plan.modules order.
@@ -1314,14 +1333,14 @@ class HGATLayer(torch.autograd.Function):
         dstate = None
         if drop is not None and (drop[0] > 0 or drop[1] > 0):
             pf, pa = drop
-            ms = [(torch.rand_like(x) >= pf).to(x.dtype) / (1.0 - pf) if pf > 0 else torch.ones_like(x) for _ in range(2)]
-            xc = [x * ms[0], x * ms[1]]
-            cnt = torch.zeros(2, NT, 1, device=dev)
-            for (m, sb, db, gr) in plan.insts:
-                t0, nc = plan.types[plan.blocks[db][1]][:2]
-                cnt[plan.mod_conv[m], t0:t0 + nc] += 1.0
-            rm = cnt[0] * ms[0] + cnt[1] * ms[1]
-            xres = x * rm
+            # both convs' masks from ONE random draw; the per-row instance counts depend on the plan only (cached)
+            u = torch.rand(2, NT, D, device=dev) if pf > 0 else torch.ones(2, NT, D, device=dev)
+            cnt = _inst_counts(plan, NT, dev)
+            ms, xcs = torch.empty_like(u), torch.empty_like(u)
+            rm, xres = torch.empty(NT, D, device=dev), torch.empty(NT, D, device=dev)
+            xcont = x.contiguous()
+            lib.srec_hg_drop_prep(ptr(xcont), ptr(u), ptr(cnt), NT, D, float(pf), ptr(ms), ptr(xcs), ptr(rm), ptr(xres), stream())
+            xc = [xcs[0], xcs[1]]
             mk = None
             if pa > 0:
                 sizes = [max(gr[4].numel(), 1) * H for (_, _, _, gr) in plan.insts]
@@ -1379,10 +1398,17 @@ class HGATLayer(torch.autograd.Function):
         xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
         gWs = [torch.empty_like(params[4 * m]) for m in range(nm)]
         convs = (0, 1) if dstate is not None else (None,)
+        tgts = None
+        if dstate is not None:
+            # every node type is projected by some module of each conv in the usual plans: the grouped GEMM then writes all
+            # rows (beta = 0 zeroes rows past the live count) and the buffers need no fill
+            full = ctx.grouped and all(any(plan.mod_conv[bm] == cv and bt == t for bm, bt in plan.blocks)
+                                       for cv in (0, 1) for t in range(len(plan.types)))
+            tgts = (torch.empty if full else torch.zeros)(2, NT, D, device=dev, dtype=torch.float32)
         for cv in convs:
             # d x of one node type = sum over the modules that project it: the module sum is the K loop (segments).
             # With feature dropout the two convs see differently masked inputs: one masked contribution per conv.
-            tgt = dx if cv is None else torch.zeros(NT, D, device=dev, dtype=torch.float32)
+            tgt = dx if cv is None else tgts[cv]
             mods = [m for m in range(nm) if cv is None or plan.mod_conv[m] == cv]
             if ctx.grouped:
                 probs = []
@@ -1393,13 +1419,13 @@ class HGATLayer(torch.autograd.Function):
                     if segs:
                         probs.append((nc, D, HD, segs, tgt[t0:t0 + nc], dyn_t))
                 if probs:
-                    gemm_group(1, probs, HD, D, D, beta=1.0, a16=True)
+                    gemm_group(1, probs, HD, D, D, beta=0.0 if (cv is not None and full) else 1.0, a16=True)
             else:
                 for m in mods:
                     r0, nr, dyn = plan.modules[m]
                     gemm_nn(dP[m], _rows(params[4 * m]), tgt[r0:r0 + nr], dyn, 1 if dyn is not None else 0, beta=1.0)
-            if cv is not None:
-                dx.addcmul_(tgt, dstate[4][cv])
+        if dstate is not None:
+            lib.srec_hg_drop_merge(ptr(tgts), ptr(dstate[4]), NT * D, ptr(dx), stream())
         if ctx.grouped:
             gemm_group(2, [(HD, D, nr, [(dP[m], xin(m)[r0:r0 + nr])], gWs[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], HD, D, D, a16=True)
