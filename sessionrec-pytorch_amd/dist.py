@@ -194,13 +194,35 @@ class HipLocal:
 
 
 # ------------------------------------------------------------------------------- autograd functions
+def _merge_stats(lse_r, lab_logit_r, group):
+    """per-shard (log-sum-exp, label logit) of every session -> global: ONE all-gather of the [2, B] pair (the label
+    logit is non-zero on exactly one shard, so its sum over the gathered copies is the all-reduce it replaces)"""
+    if _world(group) == 1 and not (FORCE and dist.is_initialized()):
+        return lse_r, lab_logit_r
+    st = all_gather_cat(torch.stack([lse_r, lab_logit_r]).unsqueeze(0), group)     # [w, 2, B]
+    return torch.logsumexp(st[:, 0], dim=0).contiguous(), st[:, 1].sum(0)
+
+
 class ShardedLookup(torch.autograd.Function):
     """rows = E[idx] with E row-sharded; idx padded with -1 to a capacity that is equal on all ranks."""
 
     @staticmethod
-    def forward(ctx, shard, idx_pad, uniq_pad, dE, lo, local, group):
+    def forward(ctx, shard, idx_pad, uniq_pad, dE, lo, local, group, vp=None):
         n_loc = shard.shape[0]
-        idx_all = all_gather_cat(idx_pad, group)
+        # ONE integer exchange per step: the padded request list, the padded distinct-item list (needed again by the
+        # backward) and, when the caller has announced them (VocabParallel.labels_hint), the labels of the loss - three
+        # all-gathers of a few KB each are three latencies on xGMI, not three bandwidth costs
+        cap = idx_pad.numel()
+        parts = [idx_pad, uniq_pad[0]]
+        lab = vp.labels_hint if vp is not None else None
+        if lab is not None:
+            parts.append(lab.to(torch.int64))
+        w = _world(group)
+        packed = all_gather_cat(torch.cat(parts).unsqueeze(0), group)          # [w, 2 cap (+ B)]
+        idx_all = packed[:, :cap].reshape(-1)
+        ctx.items_all = packed[:, cap:2 * cap].reshape(-1)
+        if lab is not None:
+            vp.lab_all = packed[:, 2 * cap:].reshape(-1)
         rel = idx_all - lo
         rel = torch.where((idx_all >= 0) & (rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1))
         rows_all = local.gather_masked(shard, rel.to(torch.int32))
@@ -213,7 +235,7 @@ class ShardedLookup(torch.autograd.Function):
         items_pad = ctx.uniq_pad[0]                           # items padded with -1 to a common capacity
         rows = ctx.local.segment_rows(g, ctx.uniq_pad)
         rows_all = all_gather_cat(rows, ctx.group)
-        items_all = all_gather_cat(items_pad, ctx.group)
+        items_all = ctx.items_all
         w = _world(ctx.group)
         U = items_pad.numel()
         for r in range(w):                                   # rank by rank: distinct items within each call
@@ -221,23 +243,22 @@ class ShardedLookup(torch.autograd.Function):
             rel = it - ctx.lo
             rel = torch.where((it >= 0) & (rel >= 0) & (rel < ctx.n_loc), rel, torch.full_like(rel, -1))
             ctx.local.add_rows(rows_all[r * U:(r + 1) * U], rel.to(torch.int32), ctx.dE)
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None
 
 
 class ShardedScoreCE(torch.autograd.Function):
     """mean CE over the GLOBAL batch (world*B sessions) against the row-sharded catalog."""
 
     @staticmethod
-    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group):
+    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group, lab_all=None):
         n_loc = shard.shape[0]
         sr_all = all_gather_cat(sr.contiguous(), group)
-        lab_all = all_gather_cat(labels.to(torch.int64), group)
+        if lab_all is None:                                            # not exchanged with the lookup's request lists
+            lab_all = all_gather_cat(labels.to(torch.int64), group)
         rel = lab_all - lo
         lab_loc = torch.where((rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1)).to(torch.int32)
         lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
-        lse_all = all_gather_cat(lse_r.unsqueeze(0), group)            # [world, world*B]
-        lse = torch.logsumexp(lse_all, dim=0).contiguous()
-        lab_logit = all_reduce_sum(lab_logit, group)
+        lse, lab_logit = _merge_stats(lse_r, lab_logit, group)
         loss = (lse - lab_logit).mean()
         ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
         ctx.misc = (dE, ws, cs_inv_scale, local, group)
@@ -250,7 +271,7 @@ class ShardedScoreCE(torch.autograd.Function):
         gs = gloss.reshape(1).to(torch.float32).contiguous()
         dsr_part = local.ce_bwd(sr_all, shard, cs, lab_loc, lse, gs, dE, ws, cs_inv_scale)
         dsr = reduce_scatter_sum(dsr_part, group)
-        return dsr, None, None, None, None, None, None, None, None, None
+        return dsr, None, None, None, None, None, None, None, None, None, None
 
 
 class ShardedScoreStats(torch.autograd.Function):
@@ -267,9 +288,7 @@ class ShardedScoreStats(torch.autograd.Function):
         rel = lab_all - lo
         lab_loc = torch.where((rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1)).to(torch.int32)
         lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
-        lse_all = all_gather_cat(lse_r.unsqueeze(0), group)
-        lse = torch.logsumexp(lse_all, dim=0).contiguous()
-        lab_logit = all_reduce_sum(lab_logit, group)
+        lse, lab_logit = _merge_stats(lse_r, lab_logit, group)
         r = _rank(group)
         ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
         ctx.misc = (dE, ws, cs_inv_scale, local, group, tgrad)
@@ -308,6 +327,8 @@ class VocabParallel:
         self.tgrad = model._state(1)['tgrad']
         self.dE = self.tgrad.buf
         self.idx_cap = idx_cap
+        self.labels_hint = None             # set by the model before the lookup of a training step: labels ride along
+        self.lab_all = None                 # ... and come back gathered for loss()
         self.eval_data_parallel = False     # evaluate(): True when every rank feeds its own equal-sized slice of a batch
         self._ws = {}
         model.shard = self
@@ -343,7 +364,9 @@ class VocabParallel:
             cptr_pad = torch.full((cap + 1,), C, device=idx.device, dtype=torch.int32)   # padded items: empty chunk lists
             cptr_pad[:U + 1] = cptr[:U + 1]
             uq = uq + (cptr_pad, chunk_ptr)
-        rows = ShardedLookup.apply(table, idx_pad, uq, self.dE, self.lo, self.local, self.group)
+        self.lab_all = None
+        rows = ShardedLookup.apply(table, idx_pad, uq, self.dE, self.lo, self.local, self.group, self)
+        self.labels_hint = None
         return rows[:n]
 
     def loss(self, sr, table, cs, labels, cs_inv_scale):
@@ -354,7 +377,11 @@ class VocabParallel:
         live = table[:self.n_live] if self.n_live < table.shape[0] else table
         dE = self.dE[:self.n_live] if self.n_live < table.shape[0] else self.dE
         csl = None if cs is None else cs[:self.n_live]
-        out = ShardedScoreCE.apply(sr, live, csl, labels, dE, self.lo, self._ws[key], cs_inv_scale, self.local, self.group)
+        lab_all, self.lab_all = self.lab_all, None
+        if lab_all is not None and lab_all.numel() != B:
+            lab_all = None
+        out = ShardedScoreCE.apply(sr, live, csl, labels, dE, self.lo, self._ws[key], cs_inv_scale, self.local, self.group,
+                                   lab_all)
         self.tgrad.fresh = True                      # the backward of `out` overwrites every live row of dE
         return out
 

@@ -81,6 +81,8 @@ class _ScoringMixin:
             dynB = inputs[0].dynp('B')
         st = self._state(B)
         cs, inv_scale = self._col_scale(st)
+        if self.shard is not None:
+            self.shard.labels_hint = labels          # gathered together with the lookup's request lists
         sr = self.session_repr(*inputs, tgrad=st['tgrad'])
         if self.shard is not None:
             return self.shard.loss(sr, self._table(), cs, labels, inv_scale)

@@ -173,9 +173,12 @@ def _worker(rank, world, port, cosine, q):
         cs = None
         if cosine:
             cs = 12.0 / shard.detach().norm(dim=1).clamp(min=1e-12)
+        vp.labels_hint = b['labels']                       # labels ride along with the lookup's integer exchange
         rows = vp.lookup(shard, b['idx'].int(), _uniq(b['idx']))
+        assert vp.labels_hint is None and vp.lab_all is not None and vp.lab_all.numel() == world * b['labels'].numel()
         sr = rows[b['pick']] @ b['sr_w']
         loss = vp.loss(sr, shard, cs, b['labels'], 1.0 / 12.0)
+        assert vp.lab_all is None
         (loss + 1e-3 * (rows * b['gout']).sum()).backward()
         dE = vp.dE[:vp.n_live].clone()
         # evaluation: local top-k per shard -> all-gather -> merge, both feeding conventions
