@@ -355,13 +355,15 @@ class VocabParallel:
         cap = self.capacity(max(n, U))
         idx_pad = self._pad(idx.to(torch.int64), cap)
         items_pad = self._pad(items.to(torch.int64), cap)
-        uptr_pad = torch.full((cap + 1,), int(n), device=idx.device, dtype=torch.int32)
+        # entries past the batch's own capacity repeat its LAST offset: empty segments (a constant fill would make entry U
+        # span [uptr[U], fill) - with a capacity-padded batch that is every position: one wavefront summing them serially)
+        uptr_pad = uptr[U:U + 1].expand(cap + 1).clone()
         uptr_pad[:U + 1] = uptr
         uq = (items_pad, uptr_pad, upos)
         if len(uniq) == 5:                                    # chunked CSR of the FlatBatch: balanced two-level sums
             cptr, chunk_ptr = uniq[3], uniq[4]
             C = chunk_ptr.numel() - 1
-            cptr_pad = torch.full((cap + 1,), C, device=idx.device, dtype=torch.int32)   # padded items: empty chunk lists
+            cptr_pad = cptr[U:U + 1].expand(cap + 1).clone()                            # padded items: empty chunk lists
             cptr_pad[:U + 1] = cptr[:U + 1]
             uq = uq + (cptr_pad, chunk_ptr)
         self.lab_all = None

@@ -1,8 +1,8 @@
 #!/bin/bash
-# kernel sequence of the LAST graph replay of the default bench -> gpurun_out/seq.txt
+# kernel sequence of the LAST graph replay of the default bench -> gpurun_out/seq.txt   (extra bench args: "$@")
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trace_seq
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_seq -- python /root/repo/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/trace_seq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_seq -- python /root/repo/bench.py --steps 3 --warmup 2 --no-cpu-baseline "$@" > /tmp/trace_seq.log 2>&1
 f=$(find /tmp/trace_seq -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys
@@ -19,7 +19,7 @@ def short(n):
     return n[:90]
 # choose the 3rd from last adam_rows .. 2nd from last as the window
 cands = [(idx[i], idx[i + 1]) for i in range(len(idx) - 1)]
-best = [c for c in cands if 100 < c[1] - c[0] < 200]
+best = [c for c in cands if 100 < c[1] - c[0] < 400]
 a, b = best[-1]
 t0 = int(rows[a + 1]['Start_Timestamp'])
 out = open('/root/repo/gpurun_out/seq.txt', 'w')
