@@ -263,7 +263,7 @@ def main():
         cap = None
         if padded:                                 # equal padded request length on every rank: no size exchange
             x0 = batches[0][0][0]
-            cap = x0.cap('gidx') if x0.has('gidx') else x0.cap('iid')
+            cap = x0.cap('uniq_items')             # only the distinct items of a batch are exchanged
             t = torch.tensor([cap], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             cap = int(t.item())

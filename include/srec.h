@@ -207,6 +207,15 @@ int srec_sgat_bwd_src(const float* dout, int ld_o, const float* A, const float* 
 
 /* ---- optimizer (adam.hip): torch.optim.Adam + coupled L2, train.py:70-75,101 ------------------------
  * hyper (device, 8 floats) = {lr/(1-b1^t), beta1, beta2, eps, weight_decay, 1-beta1, 1-beta2, sqrt(1-b2^t)} */
+/* row-sharded item table: global ids (int64; -1 = padding) -> local row of the shard [lo, lo + n_loc) or -1 */
+int srec_localize_idx(const long long* idx, long n, long lo, int n_loc, int* out, void* stream);
+
+/* inv[p] = u for the positions p = pos[ptr[u] .. ptr[u+1]) of item u < U (uniq_ptr / uniq_pos of a FlatBatch), -1 elsewhere */
+int srec_inverse_index(const int* ptr, const int* pos, int U, int n, int* inv, void* stream);
+/* row-sharded scoring: st [w, 2, B] = per-shard (log-sum-exp, label logit) gathered from the w ranks -> global lse [B],
+ * label logit [B] and loss = mean(lse - lab) */
+int srec_merge_stats(const float* st, int w, int B, float* lse, float* lab, float* loss, void* stream);
+
 int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                    void* stream);
 /* step scalars on the DEVICE: *counter += 1, then hyper[8] = {lr/(1-b1^t), b1, b2, eps, wd, 1-b1, 1-b2, sqrt(1-b2^t)}

@@ -197,6 +197,55 @@ __global__ void col_sum_final_kernel(const float* __restrict__ part, int ncol, f
     out[c] = accumulate ? out[c] + s : s;
 }
 
+// out[i] = idx[i] - lo when idx[i] is a row of this shard ([lo, lo + n_loc)), else -1 (also for the -1 padding)
+__global__ void localize_idx_kernel(const long long* __restrict__ idx, long n, long long lo, int n_loc, int* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long r = idx[i] - lo;
+    out[i] = (idx[i] >= 0 && r >= 0 && r < n_loc) ? (int)r : -1;
+}
+
+// st [w][2][B]: per-shard (log-sum-exp, label logit) of every session -> global lse[b] = logsumexp_r st[r][0][b],
+// lab[b] = sum_r st[r][1][b] (non-zero on the one shard that owns the label), loss = mean_b (lse - lab).  One workgroup.
+__global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, float* __restrict__ lse,
+                                   float* __restrict__ lab, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float m = -INFINITY, t = 0.f;
+        for (int r = 0; r < w; ++r) {
+            m = fmaxf(m, st[((size_t)r * 2) * B + b]);
+            t += st[((size_t)r * 2 + 1) * B + b];
+        }
+        float l = 0.f;
+        for (int r = 0; r < w; ++r) l += expf(st[((size_t)r * 2) * B + b] - m);
+        const float v = m + logf(l);
+        lse[b] = v;
+        lab[b] = t;
+        acc += v - t;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+// inv[pos[e]] = u for e in [ptr[u], ptr[u+1]); one wavefront per item.  inv is pre-filled with -1 by the first pass.
+__global__ void inverse_index_kernel(const int* __restrict__ ptr, const int* __restrict__ pos, int U, int n,
+                                     int* __restrict__ inv) {
+    const int u = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= U) return;
+    const int beg = ptr[u], end = ptr[u + 1];
+    for (int e = beg + lane; e < end; e += 64) {
+        const int p = pos[e];
+        if (p >= 0 && p < n) inv[p] = u;
+    }
+}
+__global__ void fill_int_kernel(int* __restrict__ p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 inline bool bad_row_args(int d, int ld) { return d <= 0 || (d & 3) || (ld & 3); }
 
 }  // namespace
@@ -281,6 +330,35 @@ extern "C" int srec_col_sum(const float* X, int ld, const float* wgt, int H, int
     hipLaunchKernelGGL(col_sum_part_kernel, dim3(cdiv(ncol, 64), NCHUNK), dim3(256), 0, st, X, ld, wgt, H, D, n_cap, dyn,
                        ncol, ws);
     hipLaunchKernelGGL(col_sum_final_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ws, ncol, out, accumulate);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// Row-sharded table (dist.py): global item ids (int64, -1 = padding) -> row of THIS shard or -1, in one launch
+// (replaces a subtract / three compares / two ands / where / cast chain per exchange).
+extern "C" int srec_localize_idx(const long long* idx, long n, long lo, int n_loc, int* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(localize_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n,
+                       (long long)lo, n_loc, out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// Row-sharded scoring (dist.py): merge the per-shard soft-max statistics gathered from the w ranks.  st [w, 2, B].
+extern "C" int srec_merge_stats(const float* st, int w, int B, float* lse, float* lab, float* loss, void* stream) {
+    if (w <= 0 || B <= 0) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lse, lab, loss);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// inv [n] (int32): inv[p] = u for the positions p = pos[ptr[u] .. ptr[u+1]) of item u (u < U), -1 for unclaimed positions
+// (capacity padding).  The CSR (ptr, pos) is the uniq_ptr / uniq_pos pair of a FlatBatch.
+extern "C" int srec_inverse_index(const int* ptr, const int* pos, int U, int n, int* inv, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, inv, n, -1);
+    if (U > 0) hipLaunchKernelGGL(inverse_index_kernel, dim3(cdiv(U, WPB)), dim3(256), 0, st, ptr, pos, U, n, inv);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -92,6 +92,32 @@ class HipLocal:
         from . import ops
         self.ops = ops
 
+    def localize(self, idx_all, lo, n_loc):
+        """global ids (int64, -1 padding) -> int32 rows of this shard, -1 elsewhere"""
+        from ._lib import lib, ptr, stream
+        idx_all = idx_all.contiguous()
+        out = torch.empty(idx_all.numel(), device=idx_all.device, dtype=torch.int32)
+        lib.srec_localize_idx(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), stream())
+        return out
+
+    def merge_stats(self, st):
+        """st [w, 2, B] gathered per-shard statistics -> (lse [B], label logit [B], mean loss)"""
+        from ._lib import lib, ptr, stream
+        st = st.contiguous()
+        w, _, B = st.shape
+        lse = torch.empty(B, device=st.device, dtype=torch.float32)
+        lab = torch.empty(B, device=st.device, dtype=torch.float32)
+        loss = torch.empty((), device=st.device, dtype=torch.float32)
+        lib.srec_merge_stats(ptr(st), w, B, ptr(lse), ptr(lab), ptr(loss), stream())
+        return lse, lab, loss
+
+    def inverse_index(self, uptr, upos, U, n):
+        """inv[p] = u for every position p of item u (positions listed in upos[uptr[u]:uptr[u+1]]); -1 where no item claims p"""
+        from ._lib import lib, ptr, stream
+        inv = torch.empty(n, device=upos.device, dtype=torch.int32)
+        lib.srec_inverse_index(ptr(uptr), ptr(upos), U, n, ptr(inv), stream())
+        return inv
+
     def gather_masked(self, table, idx):
         from ._lib import lib, ptr, stream
         n, d = idx.numel(), table.shape[1]
@@ -194,56 +220,57 @@ class HipLocal:
 
 
 # ------------------------------------------------------------------------------- autograd functions
-def _merge_stats(lse_r, lab_logit_r, group):
-    """per-shard (log-sum-exp, label logit) of every session -> global: ONE all-gather of the [2, B] pair (the label
-    logit is non-zero on exactly one shard, so its sum over the gathered copies is the all-reduce it replaces)"""
+def _merge_stats(lse_r, lab_logit_r, group, local=None):
+    """per-shard (log-sum-exp, label logit) of every session -> global (lse, label logit, mean loss): ONE all-gather of the
+    [2, B] pair (the label logit is non-zero on exactly one shard, so its sum over the gathered copies is the all-reduce
+    it replaces) and one merge kernel"""
     if _world(group) == 1 and not (FORCE and dist.is_initialized()):
-        return lse_r, lab_logit_r
+        return lse_r, lab_logit_r, (lse_r - lab_logit_r).mean()
     st = all_gather_cat(torch.stack([lse_r, lab_logit_r]).unsqueeze(0), group)     # [w, 2, B]
-    return torch.logsumexp(st[:, 0], dim=0).contiguous(), st[:, 1].sum(0)
+    if local is not None and hasattr(local, 'merge_stats'):
+        return local.merge_stats(st)
+    lse, lab = torch.logsumexp(st[:, 0], dim=0).contiguous(), st[:, 1].sum(0)
+    return lse, lab, (lse - lab).mean()
 
 
 class ShardedLookup(torch.autograd.Function):
-    """rows = E[idx] with E row-sharded; idx padded with -1 to a capacity that is equal on all ranks."""
+    """rows = E[idx] with E row-sharded.  Only the DISTINCT items of a rank's batch travel: their ids are all-gathered
+    (padded with -1 to a capacity that is equal on all ranks), every rank contributes the rows it owns (zeros elsewhere),
+    a reduce-scatter hands each rank the rows of its own items and the positions of the batch are filled from those by a
+    local gather (inv: position -> slot of its item).  The exchange volume is (distinct items) x d per rank and direction,
+    not (positions) x d - ~4x less at the MSGIFSR shapes, where every click is looked up once per n-gram order."""
 
     @staticmethod
-    def forward(ctx, shard, idx_pad, uniq_pad, dE, lo, local, group, vp=None):
+    def forward(ctx, shard, items_pad, inv, uniq, dE, lo, local, group, vp=None):
         n_loc = shard.shape[0]
-        # ONE integer exchange per step: the padded request list, the padded distinct-item list (needed again by the
-        # backward) and, when the caller has announced them (VocabParallel.labels_hint), the labels of the loss - three
-        # all-gathers of a few KB each are three latencies on xGMI, not three bandwidth costs
-        cap = idx_pad.numel()
-        parts = [idx_pad, uniq_pad[0]]
+        # ONE integer exchange per step: the padded distinct-item list (used again by the backward) and, when the caller has
+        # announced them (VocabParallel.labels_hint), the labels of the loss - a few KB each, i.e. latencies on xGMI
+        ucap = items_pad.numel()
+        parts = [items_pad]
         lab = vp.labels_hint if vp is not None else None
         if lab is not None:
             parts.append(lab.to(torch.int64))
-        w = _world(group)
-        packed = all_gather_cat(torch.cat(parts).unsqueeze(0), group)          # [w, 2 cap (+ B)]
-        idx_all = packed[:, :cap].reshape(-1)
-        ctx.items_all = packed[:, cap:2 * cap].reshape(-1)
+        packed = all_gather_cat((torch.cat(parts) if len(parts) > 1 else parts[0]).unsqueeze(0), group)    # [w, ucap (+ B)]
+        ctx.items_all = packed[:, :ucap].reshape(-1)
         if lab is not None:
-            vp.lab_all = packed[:, 2 * cap:].reshape(-1)
-        rel = idx_all - lo
-        rel = torch.where((idx_all >= 0) & (rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1))
-        rows_all = local.gather_masked(shard, rel.to(torch.int32))
-        out = reduce_scatter_sum(rows_all, group)
-        ctx.uniq_pad, ctx.dE, ctx.lo, ctx.local, ctx.group, ctx.n_loc = uniq_pad, dE, lo, local, group, n_loc
+            vp.lab_all = packed[:, ucap:].reshape(-1)
+        rows_all = local.gather_masked(shard, local.localize(ctx.items_all, lo, n_loc))       # [w * ucap, d]
+        mine = reduce_scatter_sum(rows_all, group)                                            # [ucap, d]: my items' rows
+        out = local.gather_masked(mine, inv)                                                  # [n, d]: my positions
+        ctx.uniq, ctx.ucap, ctx.dE, ctx.lo, ctx.local, ctx.group, ctx.n_loc = uniq, ucap, dE, lo, local, group, n_loc
         return out
 
     @staticmethod
     def backward(ctx, g):
-        items_pad = ctx.uniq_pad[0]                           # items padded with -1 to a common capacity
-        rows = ctx.local.segment_rows(g, ctx.uniq_pad)
+        rows = ctx.local.segment_rows(g, ctx.uniq)            # [U, d]: one summed row per distinct item of my batch
+        U, ucap = rows.shape[0], ctx.ucap
+        if U < ucap:
+            rows = torch.cat([rows, rows.new_zeros(ucap - U, rows.shape[1])])
         rows_all = all_gather_cat(rows, ctx.group)
-        items_all = ctx.items_all
-        w = _world(ctx.group)
-        U = items_pad.numel()
-        for r in range(w):                                   # rank by rank: distinct items within each call
-            it = items_all[r * U:(r + 1) * U]
-            rel = it - ctx.lo
-            rel = torch.where((it >= 0) & (rel >= 0) & (rel < ctx.n_loc), rel, torch.full_like(rel, -1))
-            ctx.local.add_rows(rows_all[r * U:(r + 1) * U], rel.to(torch.int32), ctx.dE)
-        return None, None, None, None, None, None, None, None
+        rel = ctx.local.localize(ctx.items_all, ctx.lo, ctx.n_loc)
+        for r in range(_world(ctx.group)):                   # rank by rank: distinct items within each call
+            ctx.local.add_rows(rows_all[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], ctx.dE)
+        return (None,) * 9
 
 
 class ShardedScoreCE(torch.autograd.Function):
@@ -255,11 +282,9 @@ class ShardedScoreCE(torch.autograd.Function):
         sr_all = all_gather_cat(sr.contiguous(), group)
         if lab_all is None:                                            # not exchanged with the lookup's request lists
             lab_all = all_gather_cat(labels.to(torch.int64), group)
-        rel = lab_all - lo
-        lab_loc = torch.where((rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1)).to(torch.int32)
+        lab_loc = local.localize(lab_all, lo, n_loc)
         lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
-        lse, lab_logit = _merge_stats(lse_r, lab_logit, group)
-        loss = (lse - lab_logit).mean()
+        lse, lab_logit, loss = _merge_stats(lse_r, lab_logit, group, local)
         ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
         ctx.misc = (dE, ws, cs_inv_scale, local, group)
         return loss
@@ -285,10 +310,9 @@ class ShardedScoreStats(torch.autograd.Function):
         n_loc, n = shard.shape[0], sr.shape[0]
         sr_all = all_gather_cat(sr.contiguous(), group)
         lab_all = all_gather_cat(labels.to(torch.int64), group)
-        rel = lab_all - lo
-        lab_loc = torch.where((rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1)).to(torch.int32)
+        lab_loc = local.localize(lab_all, lo, n_loc)
         lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
-        lse, lab_logit = _merge_stats(lse_r, lab_logit, group)
+        lse, lab_logit, _ = _merge_stats(lse_r, lab_logit, group, local)
         r = _rank(group)
         ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
         ctx.misc = (dE, ws, cs_inv_scale, local, group, tgrad)
@@ -339,7 +363,8 @@ class VocabParallel:
         return out
 
     def capacity(self, n):
-        """a common padded length: max over ranks, rounded up (one tiny all-reduce per batch)"""
+        """a common padded length for the distinct-item lists: `idx_cap` (capacity-padded batches: no exchange, no host
+        sync, graph-capturable) or the max over ranks, rounded up (one tiny all-reduce per batch)"""
         if self.idx_cap is not None:
             assert n <= self.idx_cap
             return self.idx_cap
@@ -351,25 +376,15 @@ class VocabParallel:
     def lookup(self, table, idx, uniq):
         items, uptr, upos = uniq[:3]
         n, U = idx.numel(), items.numel()
-        uptr = uptr[:U + 1]
-        cap = self.capacity(max(n, U))
-        idx_pad = self._pad(idx.to(torch.int64), cap)
-        items_pad = self._pad(items.to(torch.int64), cap)
-        # entries past the batch's own capacity repeat its LAST offset: empty segments (a constant fill would make entry U
-        # span [uptr[U], fill) - with a capacity-padded batch that is every position: one wavefront summing them serially)
-        uptr_pad = uptr[U:U + 1].expand(cap + 1).clone()
-        uptr_pad[:U + 1] = uptr
-        uq = (items_pad, uptr_pad, upos)
-        if len(uniq) == 5:                                    # chunked CSR of the FlatBatch: balanced two-level sums
-            cptr, chunk_ptr = uniq[3], uniq[4]
-            C = chunk_ptr.numel() - 1
-            cptr_pad = cptr[U:U + 1].expand(cap + 1).clone()                            # padded items: empty chunk lists
-            cptr_pad[:U + 1] = cptr[:U + 1]
-            uq = uq + (cptr_pad, chunk_ptr)
+        ucap = self.capacity(U)
+        items64 = items.to(torch.int64)
+        items_pad = items64 if U == ucap else self._pad(items64, ucap)
+        inv = self.local.inverse_index(uptr, upos, U, n)      # position -> slot of its item in `items`
+        uq = (items, uptr[:U + 1], upos) + tuple(uniq[3:])
         self.lab_all = None
-        rows = ShardedLookup.apply(table, idx_pad, uq, self.dE, self.lo, self.local, self.group, self)
+        rows = ShardedLookup.apply(table, items_pad, inv, uq, self.dE, self.lo, self.local, self.group, self)
         self.labels_hint = None
-        return rows[:n]
+        return rows
 
     def loss(self, sr, table, cs, labels, cs_inv_scale):
         B = sr.shape[0] * self.world

@@ -16,13 +16,24 @@ from util import pkg
 class TorchLocal:
     """plain-torch restatement of dist.HipLocal's interface (test-only)"""
 
+    def localize(self, idx_all, lo, n_loc):
+        rel = idx_all - lo
+        return torch.where((idx_all >= 0) & (rel >= 0) & (rel < n_loc), rel, torch.full_like(rel, -1)).to(torch.int32)
+
+    def inverse_index(self, uptr, upos, U, n):
+        inv = torch.full((n,), -1, dtype=torch.int32)
+        for u in range(U):
+            for e in range(int(uptr[u]), int(uptr[u + 1])):
+                inv[int(upos[e])] = u
+        return inv
+
     def gather_masked(self, table, idx):
         idx = idx.long()
         out = table[idx.clamp(min=0)]
         return out * (idx >= 0).unsqueeze(1)
 
     def segment_rows(self, g, uniq):
-        items, uptr, upos = uniq
+        items, uptr, upos = uniq[:3]
         U = items.numel()
         out = torch.zeros(U, g.shape[1])
         for u in range(U):
