@@ -1,7 +1,8 @@
-"""Whole-step hipGraph: the ~500 kernel launches of one training step (gather -> encoder -> fused
+"""Whole-step hipGraph: the ~130 kernel launches of one training step (gather -> encoder -> fused
 scoring/CE forward+backward -> fused Adam) are captured ONCE on capacity-padded, statically placed
 tensors and replayed per batch.  Per step the host then does: one H2D copy of the FlatBatch buffer
-into the static device buffer, a host-only refresh of the Adam scalars, one hipGraphLaunch.
+into the static device buffer, host bookkeeping of the step counts (the counter the kernels use lives on
+the device and is advanced by the captured step itself), one hipGraphLaunch.
 
 This is what makes the launch-bound step GPU-bound: every kernel reads its live extents from the
 batch header in device memory (`dyn*` arguments of include/srec.h), so the same launch sequence is
