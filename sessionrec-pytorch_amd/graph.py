@@ -20,7 +20,8 @@ class GraphedTrainStep:
         assert all(x.meta.get('padded') for x in inputs), 'graph capture needs capacity-padded batches (collate caps=...)'
         self.model, self.opt, self.after_backward = model, optimizer, after_backward
         self.static_inputs = [FlatBatch(x.buf.clone(), x.layout, dict(x.meta)) for x in inputs]
-        self.static_labels = labels.clone()
+        self.static_labels = labels.to(torch.int32)      # the kernels read int32 labels: the copy per step converts
+        self._one = torch.ones((), device=labels.device, dtype=torch.float32)   # backward root: no fill kernel per replay
         self._sig = [self._signature(x) for x in inputs]
         # ---- eager warm-up on a side stream (lazy allocations, LDS opt-in attributes, Adam state), then undo
         #      its effect on parameters / optimizer state so capture does not change the training trajectory
@@ -49,7 +50,7 @@ class GraphedTrainStep:
         self._pending_advance = None
         with torch.cuda.graph(self.graph):
             self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
-            self.loss.backward()
+            self.loss.backward(self._one)
             if self.after_backward is not None:
                 self.after_backward()
             work = optimizer._work()
