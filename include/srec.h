@@ -106,7 +106,7 @@ int srec_normalize_bwd(const float* Y, int ld_y, const float* dY, int ld_dy, con
 int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g, int n, int d,
                          void* stream);
 /* out[c] (+)= sum_r w[r, c/D] * X[r,c] (wgt NULL -> plain column sums: bias / fc_e / attention-vector
- * gradients).  Two deterministic stages; ws = 32*ncol floats of scratch. */
+ * gradients).  Two deterministic stages; ws = 128*ncol floats of scratch (16-byte aligned). */
 int srec_col_sum(const float* X, int ld, const float* wgt, int H, int D, int n_cap, const int* dyn, int ncol,
                  float* out, int accumulate, float* ws, void* stream);
 

@@ -45,7 +45,7 @@ def _gemm_ws(device):
 
 
 def col_sum(X, n, ncol, out, dyn=None, wgt=None, H=1, D=1, accumulate=0):
-    ws = _ws(32 * ncol, X.device)
+    ws = _ws(128 * ncol, X.device)            # NCHUNK_V partial rows of the vector path (32 for the weighted one)
     lib.srec_col_sum(ptr(X), _ld(X), ptr(wgt), H, D, n, ptr(dyn), ncol, ptr(out), accumulate, ptr(ws), stream())
 
 
