@@ -225,19 +225,28 @@ __global__ __launch_bounds__(256) void col_sum_part_v4_kernel(const float* __res
     }
 }
 
-__global__ void col_sum_final_v_kernel(const float* __restrict__ part, int nchunk, int ncol, float* __restrict__ out,
-                                       int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol) return;
+// 64 columns per workgroup, the chunks split over the 4 waves (fixed order: deterministic), 4 loads in flight
+__global__ __launch_bounds__(256) void col_sum_final_v_kernel(const float* __restrict__ part, int nchunk, int ncol,
+                                                              float* __restrict__ out, int accumulate) {
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= nchunk; k += 4) {
-        s0 += part[(size_t)k * ncol + c]; s1 += part[(size_t)(k + 1) * ncol + c];
-        s2 += part[(size_t)(k + 2) * ncol + c]; s3 += part[(size_t)(k + 3) * ncol + c];
+    if (c < ncol) {
+        int k = g;
+        for (; k + 12 < nchunk; k += 16) {
+            s0 += part[(size_t)k * ncol + c]; s1 += part[(size_t)(k + 4) * ncol + c];
+            s2 += part[(size_t)(k + 8) * ncol + c]; s3 += part[(size_t)(k + 12) * ncol + c];
+        }
+        for (; k < nchunk; k += 4) s0 += part[(size_t)k * ncol + c];
     }
-    for (; k < nchunk; ++k) s0 += part[(size_t)k * ncol + c];
     const float s = (s0 + s1) + (s2 + s3);
-    out[c] = accumulate ? out[c] + s : s;
+    if (g > 0) red[g - 1][lane] = s;
+    __syncthreads();
+    if (g == 0 && c < ncol) {
+        const float t = (s + red[0][lane]) + (red[1][lane] + red[2][lane]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 __global__ void col_sum_final_kernel(const float* __restrict__ part, int ncol, float* __restrict__ out, int accumulate) {
@@ -381,7 +390,7 @@ extern "C" int srec_col_sum(const float* X, int ld, const float* wgt, int H, int
     if (wgt == nullptr && (ncol & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)ws & 15) == 0) {
         hipLaunchKernelGGL(col_sum_part_v4_kernel, dim3(cdiv(ncol, 256), NCHUNK_V), dim3(256), 0, st, X, ld, n_cap, dyn, ncol,
                            ws);
-        hipLaunchKernelGGL(col_sum_final_v_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ws, NCHUNK_V, ncol, out,
+        hipLaunchKernelGGL(col_sum_final_v_kernel, dim3(cdiv(ncol, 64)), dim3(256), 0, st, ws, NCHUNK_V, ncol, out,
                            accumulate);
         SREC_LAUNCH_CHECK();
         return 0;
