@@ -41,7 +41,19 @@ __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g,
     if (item < 0) return;                             // row owned by another shard
     for (int c = lane * 4; c < d; c += 256) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = beg; e < end; ++e) {
+        int e = beg;
+        for (; e + 4 <= end; e += 4) {                // four row loads in flight (a popular item has dozens of pieces)
+            const int p0 = pos[e], p1 = pos[e + 1], p2 = pos[e + 2], p3 = pos[e + 3];
+            const float4 v0 = *reinterpret_cast<const float4*>(g + (size_t)p0 * ld_g + c);
+            const float4 v1 = *reinterpret_cast<const float4*>(g + (size_t)p1 * ld_g + c);
+            const float4 v2 = *reinterpret_cast<const float4*>(g + (size_t)p2 * ld_g + c);
+            const float4 v3 = *reinterpret_cast<const float4*>(g + (size_t)p3 * ld_g + c);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; e < end; ++e) {
             const float4 v = *reinterpret_cast<const float4*>(g + (size_t)pos[e] * ld_g + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
