@@ -166,8 +166,74 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
     const int c = lane * 4;
     if (w < H) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Fast path (the usual case: a handful of in-edges per relation): lane = (instance slot q = lane >> 3, edge j =
+        // lane & 7), so the dependent chains in_ptr -> in_idx -> esrc -> logit of ALL instances run side by side instead of
+        // one instance after the other, the soft-max is a reduction over 8-lane groups, and the (instance, edge) pairs are
+        // then aggregated with four projection-row loads in flight.  A destination with more than 8 in-edges in some
+        // relation takes the general loop below.
+        bool fast = false;
+        if (live && a.ninst[t] <= 8) {
+            const int q = lane >> 3, j = lane & 7;
+            int i = -1, beg = 0, deg = 0;
+            if (q < a.ninst[t]) {
+                i = a.inst[t][q];
+                beg = a.in_ptr[i][v];
+                deg = a.in_ptr[i][v + 1] - beg;
+            }
+            fast = __ballot(deg > 8) == 0ull;
+            if (fast) {
+                const bool valid = i >= 0 && j < deg;
+                int e = 0, src = 0;
+                float sv = -INFINITY;
+                if (valid) {
+                    e = a.in_idx[i][beg + j];
+                    src = a.esrc[i][e];
+                    sv = a.eLs[i][(size_t)src * H + w] + a.eRd[i][(size_t)v * H + w];
+                    sv = sv > 0.f ? sv : a.slope * sv;
+                }
+                float m = sv;
+                m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+                const float ex = valid ? expf(sv - m) : 0.f;
+                float z = ex;
+                z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64); z += __shfl_xor(z, 4, 64);
+                float pm = valid ? ex / z : 0.f;
+                if (valid) {
+                    a.A[i][(size_t)e * H + w] = pm;                        // soft-max value (the backward needs it)
+                    const float* mk = a.Mk[i];
+                    if (mk != nullptr) pm *= mk[(size_t)e * H + w];
+                }
+                unsigned long long mask = __ballot(valid);
+                const bool cok = c < D;                                    // every lane stays in the loop: it feeds the shuffles
+                while (mask != 0ull) {
+                    int L[4]; float pp[4]; const T* rp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        L[u] = mask != 0ull ? __builtin_ctzll(mask) : -1;
+                        if (mask != 0ull) mask &= mask - 1ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int l = L[u] >= 0 ? L[u] : 0;
+                        const int ii = __builtin_amdgcn_readfirstlane(__shfl(i, l, 64));
+                        const int ss = __shfl(src, l, 64);
+                        pp[u] = L[u] >= 0 ? __shfl(pm, l, 64) : 0.f;
+                        rp[u] = static_cast<const T*>(a.Ps[ii >= 0 ? ii : 0]) + (size_t)ss * HD + w * D + c;
+                    }
+                    float4 f[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) f[u] = (L[u] >= 0 && cok) ? ld4(rp[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { acc.x += pp[u] * f[u].x; acc.y += pp[u] * f[u].y; acc.z += pp[u] * f[u].z; acc.w += pp[u] * f[u].w; }
+                }
+                if (c < D)
+                    for (int q2 = 0; q2 < a.ninst[t]; ++q2) {
+                        const float4 bv = *reinterpret_cast<const float4*>(a.bias[a.inst[t][q2]] + w * D + c);
+                        acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+                    }
+            }
+        }
         if (live) {
-            for (int q = 0; q < a.ninst[t]; ++q) {
+            for (int q = 0; q < (fast ? 0 : a.ninst[t]); ++q) {
                 const int i = a.inst[t][q];
                 const int* ip = a.in_ptr[i];
                 const int beg = ip[v], deg = min(ip[v + 1] - beg, MAXDEG);
