@@ -420,14 +420,30 @@ __global__ void hg_bwd_dst_kernel(DstArgs a) {
             for (int h = 0; h < MAXH; ++h)
                 ph[h] = (a4.x == h ? v0 : 0.f) + (a4.y == h ? v1 : 0.f) + (a4.z == h ? v2 : 0.f) + (a4.w == h ? v3 : 0.f);
         }
+        // 8 wave sums in 10 shuffles instead of 48: a reduce-scatter over lane bits 0-2 (each step a lane keeps the half
+        // of its values that matches its bit and adds the partner's copy of that half), then a plain reduction over bits
+        // 3-5.  Lane l ends up with the total of head hb = bit-reversal of (l & 7).
+        {
+            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+            float q4[4];
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h) ph[h] = wave_sum(ph[h]);
-        if (lane < MAXH) {
-            float t = ph[0];
+            for (int k = 0; k < 4; ++k) {
+                const float keep = b0 ? ph[k + 4] : ph[k], send = b0 ? ph[k] : ph[k + 4];
+                q4[k] = keep + __shfl_xor(send, 1, 64);
+            }
+            float q2[2];
 #pragma unroll
-            for (int h = 1; h < MAXH; ++h) t = lane == h ? ph[h] : t;
-            if (a.Mk[i] != nullptr && lane < H) t *= a.Mk[i][(size_t)idx[j] * H + lane];   // d a = d a_dropped * mask
-            da[w][j][lane] = t;
+            for (int k = 0; k < 2; ++k) {
+                const float keep = b1 ? q4[k + 2] : q4[k], send = b1 ? q4[k] : q4[k + 2];
+                q2[k] = keep + __shfl_xor(send, 2, 64);
+            }
+            float t = (b2 ? q2[1] : q2[0]) + __shfl_xor(b2 ? q2[0] : q2[1], 4, 64);
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            const int hb = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
+            if (lane < MAXH) {
+                if (a.Mk[i] != nullptr && hb < H) t *= a.Mk[i][(size_t)idx[j] * H + hb];   // d a = d a_dropped * mask
+                da[w][j][hb] = t;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
