@@ -91,6 +91,8 @@ class AttnReadout(nn.Module):
 
 
 class LESSR(_ScoringMixin, nn.Module):
+    graph_capable = True       # every layer (BatchNorm statistics included) reads the live extents of a padded batch
+
     def __init__(self, num_items, embedding_dim, num_layers, batch_norm=True, feat_drop=0.0):
         super().__init__()
         self.embedding = nn.Embedding(num_items, embedding_dim, max_norm=1)

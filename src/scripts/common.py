@@ -98,14 +98,17 @@ def run(model_name):
         train_sessions = train_sessions[:-num_valid]
     train_set, test_set = AugmentedDataset(train_sessions), AugmentedDataset(test_sessions)
     caps = None
-    if device.type == 'cuda' and not args.no_graph and model_name != 'LESSR' and not getattr(args, 'extra', False):
+    if device.type == 'cuda' and not args.no_graph and not getattr(args, 'extra', False):
         from src.utils.data.collate import estimate_caps
         caps = estimate_caps(train_set, args.batch_size)     # capacity-padded training batches -> whole-step hipGraph replay
+        if model_name == 'LESSR':                            # shortcut graphs: up to L(L+1)/2 edges per session
+            caps = dict(caps, E=caps['N'] * 7)
     print(len(train_set))
     print(len(test_set))
     if model_name == 'LESSR':
         fns = (seq_to_eop_multigraph, seq_to_shortcut_graph) if args.num_layers > 1 else (seq_to_eop_multigraph,)
-        collate_fn = train_collate_fn = collate_fn_factory(*fns)
+        collate_fn = collate_fn_factory(*fns)
+        train_collate_fn = collate_fn_factory(*fns, caps=caps)
         model = LESSR(num_items, args.embedding_dim, args.num_layers, feat_drop=args.feat_drop)
     elif model_name == 'MSGIFSR':
         collate_fn = collate_fn_factory_ccs((seq_to_ccs_graph,), order=args.order)

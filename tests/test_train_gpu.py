@@ -103,7 +103,7 @@ def test_bf16_training_metrics_within_0p3pt_of_fp32(dev, model_name, dim):
     assert abs(r['d_mrr_pt']) <= 0.3 and abs(r['d_hit_pt']) <= 0.3, r
 
 
-@pytest.mark.parametrize('model_name', ['MSGIFSR', 'NISER'])
+@pytest.mark.parametrize('model_name', ['MSGIFSR', 'NISER', 'LESSR'])
 def test_train_runner_replays_the_captured_step(dev, model_name, tmp_path):
     """TrainRunner(graph='auto'): capacity-padded batches replay ONE captured hipGraph of the whole step, batches that do
     not fit the capacities (collated unpadded) run eagerly in between - and the run equals the all-eager run on the same
@@ -119,6 +119,10 @@ def test_train_runner_replays_the_captured_step(dev, model_name, tmp_path):
     if model_name == 'MSGIFSR':
         m0 = sp.MSGIFSR(V, 'sample', 32, 1, dropout=0.0, order=2, extra=False, fusion=True).to(dev)
         mk = lambda c: col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), 2, caps=c)
+    elif model_name == 'LESSR':
+        caps = dict(caps, E=caps['N'] * 7)
+        m0 = sp.LESSR(V, 32, 2).to(dev)
+        mk = lambda c: col.collate_fn_factory(col.seq_to_eop_multigraph, col.seq_to_shortcut_graph, caps=c)
     else:
         m0 = sp.NISER(V, 32, 1).to(dev)
         mk = lambda c: col.collate_fn_factory(col.seq_to_session_graph, caps=c)
