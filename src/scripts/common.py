@@ -90,6 +90,8 @@ def run(model_name):
     if device.type == 'cuda':
         from importlib import import_module
         import_module('sessionrec-pytorch_amd.ops').set_precision(args.precision)
+        if args.precision == 'fp32':
+            print('precision fp32 (reference numerics); --precision bf16 runs the same step about twice as fast')
     print('reading dataset')
     train_sessions, test_sessions, num_items = read_dataset(Path(args.dataset_dir))
     if args.valid_split is not None:

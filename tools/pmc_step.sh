@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over a short default bench (whole training step); one counter group per rocprofv3 run.
 # usage: tools/pmc_step.sh "<kernel-name regex>"  ->  gpurun_out/pmc_step.txt
+# NOTE: the TCC_* / TA_* / FETCH_SIZE groups abort rocprofv3 (signal 6) when the kernels run inside a replayed hipGraph on
+# this ROCm build: collect those on eager launches (bench.py --no-graph, or tools/pmc_flash.sh for the scoring kernels).
 pat=${1:-gemm_group}
 cd /tmp && export TMPDIR=/tmp
 out=/tmp/pmc_step
