@@ -254,6 +254,8 @@ int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_o
 int srec_hg_drop_prep(const float* x, const float* u, const float* cnt, int rows, int D, float p, float* ms, float* xc,
                       float* rm, float* xres, void* stream);
 int srec_hg_drop_merge(const float* t, const float* ms, long n, float* dx, void* stream);
+/* attention-dropout multipliers (gatconv.py:300): out[i] = u[i] >= p ? 1/(1-p) : 0 from uniform draws u */
+int srec_mask_scale(const float* u, long n, float p, float* out, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
                 int ld_dx, float* ws, void* stream);
 

@@ -931,6 +931,24 @@ extern "C" int srec_hg_drop_prep(const float* x, const float* u, const float* cn
     return 0;
 }
 
+namespace {
+__global__ void mask_scale_kernel(const float* __restrict__ u, long n, float p, float sc, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = u[i] >= p ? sc : 0.f;
+}
+}  // namespace
+
+// out[i] = u[i] >= p ? 1 / (1 - p) : 0  - the attention-dropout multipliers of a layer call from uniform draws (one pass
+// instead of compare / cast / scale)
+extern "C" int srec_mask_scale(const float* u, long n, float p, float* out, void* stream) {
+    if (n <= 0) return 0;
+    if (p < 0.f || p >= 1.f) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(mask_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, n, p,
+                       1.f / (1.f - p), out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 // dx [n] += t[0] * ms[0] + t[1] * ms[1], t / ms [2, n]; n % 4 == 0
 extern "C" int srec_hg_drop_merge(const float* t, const float* ms, long n, float* dx, void* stream) {
     if (n <= 0) return 0;

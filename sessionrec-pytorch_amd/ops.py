@@ -1344,7 +1344,9 @@ class HGATLayer(torch.autograd.Function):
             mk = None
             if pa > 0:
                 sizes = [max(gr[4].numel(), 1) * H for (_, _, _, gr) in plan.insts]
-                allm = (torch.rand(sum(sizes), device=dev) >= pa).to(x.dtype) / (1.0 - pa)
+                ua = torch.rand(sum(sizes), device=dev)
+                allm = torch.empty_like(ua)
+                lib.srec_mask_scale(ptr(ua), ua.numel(), float(pa), ptr(allm), stream())
                 mk = list(torch.split(allm, sizes))
             dstate = (xc, xres, rm, mk, ms)
         xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
