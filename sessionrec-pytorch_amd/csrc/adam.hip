@@ -202,6 +202,42 @@ __global__ void adam_hyper_kernel(int* __restrict__ counter, const double* __res
 }
 }  // namespace
 
+namespace {
+constexpr int HYPER_MAX = 16;
+struct HyperArgs { int* counter[HYPER_MAX]; const double* cfg[HYPER_MAX]; float* hyper[HYPER_MAX]; int n; };
+__global__ void adam_hyper_multi_kernel(HyperArgs a) {
+    const int i = threadIdx.x;
+    if (i >= a.n) return;
+    const int t = *a.counter[i] + 1;
+    *a.counter[i] = t;
+    const double* cfg = a.cfg[i];
+    float* hyper = a.hyper[i];
+    const double lr = cfg[0], b1 = cfg[1], b2 = cfg[2], eps = cfg[3], wd = cfg[4];
+    hyper[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+    hyper[1] = (float)b1; hyper[2] = (float)b2; hyper[3] = (float)eps; hyper[4] = (float)wd;
+    hyper[5] = (float)(1.0 - b1); hyper[6] = (float)(1.0 - b2);
+    hyper[7] = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+}  // namespace
+
+// the same for n <= 16 (counter, cfg, hyper) slots in ONE launch (param groups x step offsets of an optimizer step);
+// counter / cfg / hyper are HOST arrays of n device pointers
+extern "C" int srec_adam_hyper_multi(int n, const void* counter, const void* cfg, const void* hyper, void* stream) {
+    if (n <= 0) return 0;
+    if (n > HYPER_MAX || counter == nullptr || cfg == nullptr || hyper == nullptr) return SREC_BAD_ARG;
+    HyperArgs a{};
+    a.n = n;
+    for (int i = 0; i < n; ++i) {
+        a.counter[i] = ((int* const*)counter)[i];
+        a.cfg[i] = ((const double* const*)cfg)[i];
+        a.hyper[i] = ((float* const*)hyper)[i];
+        if (a.counter[i] == nullptr || a.cfg[i] == nullptr || a.hyper[i] == nullptr) return SREC_BAD_ARG;
+    }
+    hipLaunchKernelGGL(adam_hyper_multi_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 // counter: device int32 (steps taken so far, incremented here); cfg: device double[5] = {lr, beta1, beta2, eps,
 // weight_decay}; hyper: device float[8] consumed by srec_adam_flat / _rows / _multi of the same step.
 extern "C" int srec_adam_hyper(int* counter, const void* cfg, float* hyper, void* stream) {

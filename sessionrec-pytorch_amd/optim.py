@@ -183,6 +183,21 @@ class FusedAdam(torch.optim.Optimizer):
         table, tgrad, st = self._table_info()
         model = self.model
         T = getattr(self, '_T', 0)
+        # step scalars of every (group, step offset) slot of this step: one launch
+        ents = []
+        for gi, group, items in work:
+            for off in sorted({T - state['step'] for _, _, state in items}):
+                ent = self._buffers(gi, off, items[0][0].device)
+                if ent['cfg_host'] is None:                     # first use outside advance(): step() on a fresh group
+                    ent['cfg'].copy_(torch.tensor(self._cfg(group), dtype=torch.float64))
+                    ent['cfg_host'] = self._cfg(group)
+                ents.append(ent)
+        for i in range(0, len(ents), 16):
+            chunk = ents[i:i + 16]
+            n = len(chunk)
+            arr = _ct.c_void_p * n
+            cs, cf, hy = (arr(*[e[k].data_ptr() for e in chunk]) for k in ('counter', 'cfg', 'hyper'))
+            lib.srec_adam_hyper_multi(n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), stream())
         for gi, group, items in work:
             if not items:
                 continue
@@ -190,12 +205,6 @@ class FusedAdam(torch.optim.Optimizer):
             slot_of = {}
             for _, _, state in items:
                 slot_of.setdefault(state['step'], T - state['step'])
-            for s_, off in slot_of.items():
-                ent = self._buffers(gi, off, items[0][0].device)
-                if ent['cfg_host'] is None:                     # first use outside advance(): step() on a fresh group
-                    ent['cfg'].copy_(torch.tensor(self._cfg(group), dtype=torch.float64))
-                    ent['cfg_host'] = self._cfg(group)
-                lib.srec_adam_hyper(ptr(ent['counter']), ptr(ent['cfg']), ptr(ent['hyper']), stream())
             multi = {}                       # step slot -> rows of the multi-tensor descriptor
             for p, g, state in items:
                 hyper = self._buffers(gi, slot_of[state['step']], p.device)['hyper']
