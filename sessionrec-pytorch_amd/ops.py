@@ -838,29 +838,32 @@ class GRUExpand(torch.autograd.Function):
         else:
             dX = torch.zeros(n * k, d, device=dev, dtype=torch.float32)
             dh = g.contiguous()
-        dGI = torch.empty(n * k, d3, device=dev, dtype=torch.float32)
-        dGH = torch.empty(k, n, d3, device=dev, dtype=torch.float32)          # slot t = d(gh_t); non-live rows zero
+        # d(gi) and d(gh) side by side in ONE [n k, 2 d3] buffer: both bias gradients are then one column-sum launch.
+        # d(gi) rows are (node, t) = node k + t; d(gh) slot t = rows [t n, (t+1) n).  The gate kernel writes every row of
+        # both (zeros for nodes past the live count).
+        dG = torch.empty(n * k, 2 * d3, device=dev, dtype=torch.float32)
+        dGI = dG[:, :d3]
+        dGH = [dG[t * n:(t + 1) * n, d3:] for t in range(k)]
         for t in range(k - 1, -1, -1):
-            dgi = dGI.data_ptr() + 4 * t * d3
+            dgi = dG.data_ptr() + 4 * t * 2 * d3
             if t > 0:
                 dhp = torch.empty(n, d, device=dev, dtype=torch.float32)
                 lib.srec_gru_pointwise_bwd(ptr(dh), d, ptr(gates[t]), ptr(GH[t - 1]), d3, None, ptr(H[t - 1]), d, n,
-                                           ptr(dyn_n), d, dgi, k * d3, ptr(dGH[t]), d3, ptr(dhp), d, st)
+                                           ptr(dyn_n), d, dgi, k * 2 * d3, ptr(dGH[t]), 2 * d3, ptr(dhp), d, st)
                 gemm_nn(dGH[t], Whh, dhp, dyn_n, 1 if dyn_n is not None else 0, beta=1.0)      # dh_{t-1} += dgh_t W_hh
                 dh = dhp
             else:
                 lib.srec_gru_pointwise_bwd(ptr(dh), d, ptr(gates[0]), None, 0, ptr(bhh), None, 0, n, ptr(dyn_n), d,
-                                           dgi, k * d3, ptr(dGH[0]), d3, None, 0, st)
+                                           dgi, k * 2 * d3, ptr(dGH[0]), 2 * d3, None, 0, st)
         gWhh = torch.zeros_like(Whh) if k == 1 else torch.empty_like(Whh)
         if k > 1:
-            gemm_tn(dGH[1:].reshape((k - 1) * n, d3), H[:k - 1].reshape((k - 1) * n, d), gWhh, None)
-        gbhh = torch.empty(d3, device=dev, dtype=torch.float32)
-        col_sum(dGH.view(k * n, d3), k * n, d3, gbhh, None)
+            gemm_tn(dG[n:, d3:], H[:k - 1].reshape((k - 1) * n, d), gWhh, None)
+        gb = torch.empty(2 * d3, device=dev, dtype=torch.float32)
+        col_sum(dG, n * k, 2 * d3, gb, None)
+        gbih, gbhh = gb[:d3], gb[d3:]
         gemm_nn(dGI, Wih, dX, dyn_rows, 1 if dyn_rows is not None else 0, beta=1.0)             # + the mean term
         gWih = torch.empty_like(Wih)
         gemm_tn(dGI, x, gWih, dyn_rows)
-        gbih = torch.empty(d3, device=dev, dtype=torch.float32)
-        col_sum(dGI, n * k, d3, gbih, dyn_rows)
         return dX, gWih, gbih, gWhh, gbhh, None, None, None, None
 
 
