@@ -124,15 +124,16 @@ def run(model_name):
         cls = NISER if model_name == 'NISER' else SRGNN
         model = cls(num_items, args.embedding_dim, args.num_layers, feat_drop=args.feat_drop)
     pin = device.type == 'cuda'          # pinned batches: asynchronous H2D copies
+    pw = args.num_workers > 0            # keep the loader processes across epochs (a respawn costs seconds per epoch)
     # reference loaders: LESSR / MSGIFSR train in time order (SequentialSampler), NISER shuffles; test shuffles
     if model_name in ('LESSR', 'MSGIFSR'):
         train_loader = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.num_workers,
-                                  collate_fn=train_collate_fn, sampler=SequentialSampler(train_set), pin_memory=pin)
+                                  collate_fn=train_collate_fn, sampler=SequentialSampler(train_set), pin_memory=pin, persistent_workers=pw)
     else:
         train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
-                                  collate_fn=train_collate_fn, pin_memory=pin)
+                                  collate_fn=train_collate_fn, pin_memory=pin, persistent_workers=pw)
     test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
-                             collate_fn=collate_fn)
+                             collate_fn=collate_fn, persistent_workers=pw)
     model = model.to(device)
     print(model)
     runner = TrainRunner(args.dataset_dir, model, train_loader, test_loader, device=device, lr=args.lr,
