@@ -9,6 +9,12 @@ Synthetic data of the Yoochoose-1/64 shape (no datasets in the image): V = 37 48
 batch 512, session length <= 20, ids Zipf(1.0), 20 % immediate revisits, seed 123;
 random-init weights of the named architecture.
 
+`--gpus N` with no WORLD_SIZE in the environment re-executes this script under `python -m torch.distributed.run` with N
+ranks (one per GPU, rendezvous on 127.0.0.1); under the driver's own torchrun launch the ranks are simply used.  The
+item table is then row-sharded over the ranks (dist.VocabParallel, RCCL).  Default = weak scaling (batch 512 PER GPU,
+global batch N * 512); `--global-batch 512` = strong scaling: the SAME 512 consecutive samples per step as one GPU,
+each rank encoding its contiguous slice of them (the reference's 512-sample loss semantics, train.py:94-101).
+
 Prints ONE JSON line (rank 0) with the driver's contract plus
   "roofline":     dominant kernel (fused scoring/CE backward launch) timed live with HIP events around a hipGraph of
                   back-to-back launches on the launch stream
@@ -31,6 +37,17 @@ sys.path.insert(0, ROOT)
 V_YOOCHOOSE = 37484
 
 
+def _latest_profile(stem):
+    """newest committed PMC summary profiles/rNN_<stem>.json (the kernel's HBM traffic per launch)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % stem)))
+    return os.path.basename(c[-1]) if c else 'r01_%s.json' % stem
+
+
+PMC_BF16 = _latest_profile('pmc_flash_ce_bf16')
+PMC_FP32 = _latest_profile('pmc_flash_ce')
+
+
 def synth_sessions(n_sessions, V, mean_len, max_len, rng):
     """clipped-geometric lengths (min 2), Zipf(1.0) item ids, 20 % immediate-revisit probability."""
     p = 1.0 / (mean_len - 1.0)
@@ -48,7 +65,9 @@ def synth_sessions(n_sessions, V, mean_len, max_len, rng):
     return out
 
 
-def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False):
+def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False, part=None):
+    """n_batches batches of B consecutive prefix samples.  part=(r, w): collate only the contiguous slice r of w of every
+    batch (strong scaling: the ranks split ONE global batch); the returned samples stay the whole batches."""
     ds = importlib.import_module('sessionrec-pytorch_amd.dataset')
     col = importlib.import_module('sessionrec-pytorch_amd.collate')
     rng = np.random.default_rng(seed)
@@ -58,6 +77,12 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False
     data = ds.AugmentedDataset(arr)
     assert len(data) >= n_batches * B, (len(data), n_batches * B)
     samples = [[data[b * B + i] for i in range(B)] for b in range(n_batches)]
+    mine = samples
+    if part is not None:
+        r, w = part
+        Bl = B // w
+        mine = [s[r * Bl:(r + 1) * Bl] for s in samples]
+        B = Bl
     def factory(caps):
         if model_name in ('SRGNN', 'NISER'):
             return col.collate_fn_factory(col.seq_to_session_graph, caps=caps)
@@ -67,7 +92,7 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False
     caps = None
     if padded:          # capacities = the maxima over the epoch's batches (a loader knows them after one pass)
         mxN = mxE = mxU = 1
-        for smp in samples:
+        for smp in mine:
             (fb,), _ = factory(None)(smp)
             cnt = fb.meta['counts']
             mxN = max([mxN] + [v for k, v in cnt.items() if k.startswith('N') and k != 'NT'])
@@ -76,7 +101,7 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False
         r256 = lambda v: (v + 255) // 256 * 256
         caps = dict(B=B, N=r256(mxN), E=r256(mxE), U=r256(mxU))
     fn = factory(caps)
-    return [fn(s) for s in samples], samples
+    return [fn(s) for s in mine], samples
 
 
 def build_model(sp, name, V, d, order, dropout=0.0):
@@ -153,10 +178,7 @@ def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=12.0, dr
     from oracle import collate_ref as oc
     from oracle import models_ref as om
     train = importlib.import_module('sessionrec-pytorch_amd.train')
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    avail, phys = physical_cores()
     if model_name == 'SRGNN':
         m, fn = om.SRGNN(V, d, 1), oc.collate_fn_factory(oc.seq_to_session_graph)
     elif model_name == 'NISER':
@@ -201,9 +223,107 @@ def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=12.0, dr
             break
     dt = time.time() - t0
     B = len(samples[0])
-    return dict(value=n * B / dt, unit='sessions/s', cores=cores, kind='port',
+    return dict(value=n * B / dt, unit='sessions/s', cores=cores, host_logical_cpus=avail, host_physical_cores=phys,
+                kind='port',
                 sample='%d training steps (batch %d) of the CPU oracle (%s, V=%d, d=%d), collate excluded, %d torch threads'
                        % (n, B, model_name, V, d, cores))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a torchrun environment: re-execute under torch.distributed.run with N ranks
+    on this node (one process per GPU, rendezvous on 127.0.0.1).  Rank 0's JSON line passes straight through stdout."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL / xGMI peer mappings need it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def physical_cores():
+    """(logical cpus usable by this process, physical cores of the box from /proc/cpuinfo)"""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pid = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                cid = line.split(':')[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return avail, (len(phys) or None)
+
+
+def encoder_flop(model_name, counts, d, order, H=8):
+    """algorithmic flop of the session encoder for one batch, forward + backward (3 x the forward GEMM flop: forward,
+    backward-data, weight gradient), from the batch's live node counts.  MSGIFSR: k-gram GRU projections
+    (msgifsr.py:25,42), the GAT fc of every module of both HeteroGraphConvs (gatconv.py:282-283: intra_k projects the
+    order-k rows, the shared 'inter' module every row), the readout's fc_u / fc_v and fc_sr (msgifsr.py:139-147,272)."""
+    if model_name != 'MSGIFSR':
+        N = counts.get('N', 0)
+        B = counts.get('B', 0)
+        return 3 * (2.0 * N * d * d + 2.0 * B * d * d + 2.0 * B * 2 * d * d)
+    K = order
+    Nk = [counts.get('N%d' % k, 0) for k in range(1, K + 1)]
+    NT, B = sum(Nk), counts.get('B', 0)
+    f = 0.0
+    for k in range(2, K + 1):
+        n = Nk[k - 1]
+        f += 2.0 * n * k * d * 3 * d + 2.0 * n * (k - 1) * d * 3 * d            # GI (all steps) + GH (steps 2..k)
+    for conv in range(2):
+        f += sum(2.0 * n * d * H * d for n in Nk)                               # intra_k modules
+        if K > 1:
+            f += 2.0 * NT * d * H * d                                           # shared 'inter' module
+    f += 2.0 * NT * d * d + 2.0 * B * d * d + 2.0 * B * 2 * d * d               # live readout head: fc_u, fc_v, fc_sr
+    return 3 * f
+
+
+def run_timed(step, dev_batches, warmup, steps, repeats, dist, dev):
+    """W untimed steps, then `repeats` regions of exactly K steps, each bracketed by barrier + synchronize on both sides,
+    max over ranks.  -> (seconds of each region, last loss)"""
+    nb = len(dev_batches)
+    it = 0
+    for _ in range(warmup):
+        step(dev_batches[it % nb])
+        it += 1
+    regions, loss = [], None
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(dev_batches[it % nb])
+            it += 1
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        regions.append(dt)
+    return regions, loss
 
 
 def main():
@@ -211,12 +331,17 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps each; value = the median region')
     ap.add_argument('--model', default=os.environ.get('SREC_BENCH_MODEL', 'MSGIFSR'))
     ap.add_argument('--order', type=int, default=3)
     ap.add_argument('--dim', type=int, default=256)
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)
-    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=512, help='sessions per GPU and step (weak scaling)')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='strong scaling: this many sessions per step over ALL ranks (512 = the reference batch, '
+                         'train.py:94-101); rank r encodes the contiguous slice r of every global batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 side run (the reference arithmetic) of the same step')
     ap.add_argument('--dropout', type=float, default=0.1,
                     help='MSGIFSR feature / attention dropout (0.1 = --feat-drop default of the reference launcher, main_msgifsr.py:42)')
     ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
@@ -224,103 +349,132 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     ap.add_argument('--shard', action='store_true', help='debug: row-sharded path + RCCL calls on a 1-rank communicator (set SREC_FORCE_COLLECTIVES=1)')
     ap.add_argument('--kernel-only', action='store_true', help='only launch the scoring/CE kernels (PMC collection target)')
+    ap.add_argument('--launch-only', action='store_true',
+                    help='initialise the process group over --gpus ranks, print what was seen, exit (launcher self-test; '
+                         'gloo on a box without GPUs)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    has_gpu = torch.cuda.is_available()
     dist = None
-    if world > 1 or args.shard:
+    if world > 1 or args.shard or args.launch_only:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('nccl' if has_gpu else 'gloo', rank=rank, world_size=world)
+    if args.launch_only:
+        dev = torch.device('cuda', local) if has_gpu else torch.device('cpu')
+        if has_gpu:
+            torch.cuda.set_device(local)
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                    # every rank contributes 1: the sum is the number of live ranks
+        if rank == 0:
+            print(json.dumps(dict(launch_only=True, n_gpus=world, gpus_requested=args.gpus, ranks_seen=int(seen.item()),
+                                  world_size=dist.get_world_size(), backend=dist.get_backend())), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if world != args.gpus and rank == 0 and not args.shard:
+        print('note: --gpus %d but WORLD_SIZE=%d: running %d ranks' % (args.gpus, world, world), file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
     sp = importlib.import_module('sessionrec-pytorch_amd')
-    importlib.import_module('sessionrec-pytorch_amd.ops').set_precision(args.precision)
+    ops = importlib.import_module('sessionrec-pytorch_amd.ops')
+    ops.set_precision(args.precision)
     train = importlib.import_module('sessionrec-pytorch_amd.train')
     optim = importlib.import_module('sessionrec-pytorch_amd.optim')
-    B, V, d = args.batch, args.items, args.dim
+    V, d = args.items, args.dim
+    strong = args.global_batch is not None
+    if strong:
+        assert args.global_batch % world == 0, 'global batch must divide over the ranks'
+        Bg, B = args.global_batch, args.global_batch // world
+    else:
+        B, Bg = args.batch, args.batch * world
     if args.kernel_only:
         torch.manual_seed(123)
         model = build_model(sp, 'SRGNN', V, d, 1).to(dev)
         kt = time_dominant_kernel(model, B, V, d, dev, iters=5)
         print(json.dumps(kt))
         return
-    n_batches = args.steps + args.warmup
+    n_batches = min(args.steps + args.warmup, 48)      # distinct resident batches; longer runs cycle through them
     padded = True
     use_graph = (not args.no_graph) and padded       # N > 1: the RCCL calls are captured in the step graph too
-    batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank, padded=padded)
+    if strong:       # every rank collates ITS slice of the same global batches (same seed everywhere)
+        batches, samples = make_batches(args.model, args.order, n_batches, Bg, V, 20, 123, padded=padded,
+                                        part=(rank, world))
+    else:
+        batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank, padded=padded)
     torch.manual_seed(123)
-    model = build_model(sp, args.model, V, d, args.order, args.dropout)
-    state = {k: v.clone() for k, v in model.state_dict().items()}
-    model = model.to(dev)
-    shard = None
-    if world > 1 or args.shard:                    # item table row-sharded over the node's GPUs (RCCL / xGMI)
-        D = importlib.import_module('sessionrec-pytorch_amd.dist')
-        cap = None
-        if padded:                                 # equal padded request length on every rank: no size exchange
-            x0 = batches[0][0][0]
-            cap = x0.cap('uniq_items')             # only the distinct items of a batch are exchanged
-            t = torch.tensor([cap], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            cap = int(t.item())
-        shard = D.VocabParallel(model, idx_cap=cap)
-    opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model)
-    replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
+    state = {k: v.clone() for k, v in build_model(sp, args.model, V, d, args.order, args.dropout).state_dict().items()}
     dev_batches = [([x.to(dev) for x in inp], lab.to(dev)) for inp, lab in batches]
-    model.train()
 
-    def step(b):
-        inp, lab = b
-        opt.zero_grad()
-        loss = model.fused_loss(*inp, lab)
-        loss.backward()
-        if shard is not None:
-            shard.sync_replicated_grads(replicated, opt)
-        opt.step()
-        return loss
+    def setup(precision):
+        """model + optimizer + (graphed) step for one arithmetic mode, from the same initial weights"""
+        ops.set_precision(precision)
+        torch.manual_seed(123)
+        model = build_model(sp, args.model, V, d, args.order, args.dropout)
+        model.load_state_dict(state)
+        model = model.to(dev)
+        shard = None
+        if world > 1 or args.shard:                    # item table row-sharded over the node's GPUs (RCCL / xGMI)
+            D = importlib.import_module('sessionrec-pytorch_amd.dist')
+            cap = batches[0][0][0].cap('uniq_items')   # only the distinct items of a batch are exchanged; equal padded
+            t = torch.tensor([cap], device=dev)        # request length on every rank: no per-step size exchange
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            shard = D.VocabParallel(model, idx_cap=int(t.item()))
+        opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model)
+        replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
+        model.train()
 
-    if use_graph:
-        G = importlib.import_module('sessionrec-pytorch_amd.graph')
-        eager_step = step
-        try:
-            gstep = G.GraphedTrainStep(model, opt, dev_batches[0][0], dev_batches[0][1],
-                                       after_backward=(lambda: shard.sync_replicated_grads(replicated, opt)) if shard is not None else None)
+        def eager(b):
+            inp, lab = b
+            opt.zero_grad()
+            loss = model.fused_loss(*inp, lab)
+            loss.backward()
+            if shard is not None:
+                shard.sync_replicated_grads(replicated, opt)
+            opt.step()
+            return loss
+        step, graphed, gstep = eager, False, None
+        if use_graph:
+            G = importlib.import_module('sessionrec-pytorch_amd.graph')
+            try:
+                gstep = G.GraphedTrainStep(model, opt, dev_batches[0][0], dev_batches[0][1],
+                                           after_backward=(lambda: shard.sync_replicated_grads(replicated, opt)) if shard is not None else None)
+                step, graphed = (lambda b: gstep(b[0], b[1])), True
+            except Exception as e:                         # capture of the collectives refused: eager launches
+                if shard is None:
+                    raise
+                print('graph capture with RCCL failed (%s: %s); running eager' % (type(e).__name__, e), file=sys.stderr, flush=True)
+        return model, shard, step, graphed, gstep
 
-            def step(b):                               # noqa: F811  (replay of the captured step)
-                return gstep(b[0], b[1])
-        except Exception as e:                         # capture of the collectives refused: eager launches
-            if shard is None:
-                raise
-            print('graph capture with RCCL failed (%s: %s); running eager' % (type(e).__name__, e), file=sys.stderr, flush=True)
-            use_graph, step = False, eager_step
-    for i in range(args.warmup):
-        step(dev_batches[i])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(dev_batches[args.warmup + i])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    model, shard, step, graphed, gstep = setup(args.precision)
+    regions, loss = run_timed(step, dev_batches, args.warmup, args.steps, max(args.repeats, 1), dist, dev)
     final_loss = loss.item()
+    dt = sorted(regions)[len(regions) // 2]              # median region
+    ms = [r / args.steps * 1e3 for r in regions]
+    nodes = gstep.node_counts() if graphed and hasattr(gstep, 'node_counts') else None
+
+    fp32 = None
+    if not args.no_fp32 and args.precision != 'fp32':
+        # the reference's own arithmetic (fp32 operands everywhere) on the same batches, same launch mode, same run
+        del step, gstep
+        m32, s32, step32, g32, _ = setup('fp32')
+        r32, _ = run_timed(step32, dev_batches, args.warmup, args.steps, 1, dist, dev)
+        fp32 = dict(ms_per_step=r32[0] / args.steps * 1e3, value=Bg * args.steps / r32[0], unit='sessions/s',
+                    launch='hipGraph replay' if g32 else 'eager')
+        del m32, s32, step32
+        ops.set_precision(args.precision)
 
     if rank == 0:
         Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
-        kt = time_dominant_kernel(model, B * world, Vk, d, dev)
-        Bg = B * world
+        kt = time_dominant_kernel(model, Bg, Vk, d, dev)
         kms = {k: v * 1e3 for k, v in kt.items() if k != 'bf16'}
         if kt['bf16']:
             # one launch computes dE (all item tiles) and the d-sr slabs: 2*B*V*d algorithmic flop each
@@ -328,12 +482,12 @@ def main():
             name, flop, t, peak = ('flash_ce_bf16_kernel<KIND_BWD> (fused scoring/CE backward: dE item tiles + d-sr '
                                    'item ranges in one launch)', 4.0 * Bg * Vk * d, kt['bwd_kernel'], 2500.0)
             alg_bytes = Vk * d * 2.0 + Vk * d * 4.0      # read the bf16 table once, write dE fp32 once
-            pmc, pkey = 'r01_pmc_flash_ce_bf16.json', 'KIND_BWD'
+            pmc, pkey = PMC_BF16, 'KIND_BWD'
         else:
             name, flop, t, peak = ('flash_ce_kernel<MODE_DE> (fused scoring/CE backward, dE pass)', 4.0 * Bg * Vk * d,
                                    kt['dE'], 157.3)
             alg_bytes = 2.0 * Vk * d * 4
-            pmc, pkey = 'r01_pmc_flash_ce.json', 'MODE_DE'
+            pmc, pkey = PMC_FP32, 'MODE_DE'
         traffic, tsrc = None, None
         try:                                  # HBM bytes per launch from the committed PMC passes (same kernel & shape)
             pm = json.load(open(os.path.join(ROOT, 'profiles', pmc)))
@@ -344,23 +498,44 @@ def main():
                         'correction)' % pmc)
         except Exception:
             pass
+        # ---- the whole step against both roofs: 40 V d table bytes + ~6 N d 4 node bytes; 6 B V d
+        #      scoring flop (+ the encoder's GEMM flop, reported separately)
+        cnt = [b[0][0].meta['counts'] for b in batches]
+        mean_counts = {k: float(np.mean([c.get(k, 0) for c in cnt])) for k in cnt[0]}
+        n_rows = mean_counts.get('NT', mean_counts.get('N', 0.0))
+        t_step = dt / args.steps
+        step_bytes = 40.0 * Vk * d + 6.0 * n_rows * d * 4
+        score_flop = 6.0 * Bg * Vk * d
+        enc_flop = encoder_flop(args.model, mean_counts, d, args.order)
+        mfma_peak = 2500.0 if args.precision == 'bf16' else 157.3
+        step_roof = dict(launches=nodes, kernel_time_ms=t_step * 1e3,
+                         kernel_time_note='hipGraph replay: kernels run back to back, step wall time = GPU busy time; per-kernel '
+                                          'split in profiles/ (rocprofv3 --kernel-trace --stats of this command)',
+                         algorithmic_bytes=step_bytes, algorithmic_flop=score_flop, encoder_flop=enc_flop,
+                         hbm_floor_ms=step_bytes / 8e12 * 1e3, mfma_floor_ms=(score_flop + enc_flop) / (mfma_peak * 1e12) * 1e3,
+                         frac_hbm=step_bytes / t_step / 8e12, frac_mfma=(score_flop + enc_flop) / t_step / (mfma_peak * 1e12),
+                         frac_mfma_scoring_only=score_flop / t_step / (mfma_peak * 1e12))
         roof = dict(bound='mfma', kernel=name, achieved=flop / t / 1e12, peak=peak, unit='TFLOP/s',
                     frac=flop / t / 1e12 / peak, traffic=traffic, traffic_unit='bytes/launch', traffic_source=tsrc,
-                    algorithmic_bytes=alg_bytes, algorithmic_flop=flop, kernel_ms=kms)
+                    algorithmic_bytes=alg_bytes, algorithmic_flop=flop, kernel_ms=kms, step=step_roof)
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.model, samples, V, d, args.order, state, dropout=args.dropout)
-        out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=world * B * args.steps / dt,
-                   unit='sessions/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='f32' if args.precision == 'fp32' else 'bf16 (MFMA operands; fp32 accumulate, master weights, scoring)', data='synthetic', launch='hipGraph replay' if use_graph else 'eager',
+            full = samples if not strong else samples      # the CPU oracle runs whole 512-session batches
+            cpu = cpu_baseline(args.model, full, V, d, args.order, state, dropout=args.dropout)
+        scaling = 'strong' if strong else 'weak'
+        out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=Bg * args.steps / dt,
+                   unit='sessions/s', n_gpus=world, ranks_seen=(dist.get_world_size() if dist is not None else 1),
+                   steps=args.steps, warmup=args.warmup,
+                   ms_per_step=dt / args.steps * 1e3, repeats_ms_per_step=ms, spread_ms=max(ms) - min(ms),
+                   higher_is_better=True, scaling=scaling, vs_baseline=None,
+                   dtype='f32' if args.precision == 'fp32' else 'bf16 (MFMA operands; fp32 accumulate, master weights, scoring)', data='synthetic', launch='hipGraph replay' if graphed else 'eager',
                    config=dict(workload='%s training step, synthetic Yoochoose-1/64 shape (V=%d items, d=%d, batch %d per GPU, '
                                         'session length<=20%s)' % (args.model, V, d, B,
                                                                    ', order %d, dropout %g' % (args.order, args.dropout) if args.model == 'MSGIFSR' else ''),
-                               global_batch=B * world, parallelism=('item table row-sharded x%d (vocab-parallel scoring, RCCL all-gather/reduce-scatter), '
-                                            'encoder replicated' % world) if world > 1 else 'single GPU',
+                               global_batch=Bg, parallelism=('item table row-sharded x%d (vocab-parallel scoring, RCCL all-gather/reduce-scatter), '
+                                            'encoder replicated, %s' % (world, 'each rank encodes its slice of one 512-session batch' if strong else 'each rank feeds its own batch')) if world > 1 else 'single GPU',
                                final_loss=final_loss),
-                   roofline=roof, cpu_baseline=cpu)
+                   roofline=roof, fp32=fp32, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()                      # the other ranks wait for rank 0's kernel timing / CPU baseline

@@ -213,8 +213,11 @@ int srec_localize_idx(const long long* idx, long n, long lo, int n_loc, int* out
 /* inv[p] = u for the positions p = pos[ptr[u] .. ptr[u+1]) of item u < U (uniq_ptr / uniq_pos of a FlatBatch), -1 elsewhere */
 int srec_inverse_index(const int* ptr, const int* pos, int U, int n, int* inv, void* stream);
 /* row-sharded scoring: st [w, 2, B] = per-shard (log-sum-exp, label logit) gathered from the w ranks -> global lse [B],
- * label logit [B] and loss = mean(lse - lab) */
-int srec_merge_stats(const float* st, int w, int B, float* lse, float* lab, float* loss, void* stream);
+ * label logit [B] and loss = mean over the LIVE sessions of (lse - lab).  lab_all (nullable, int64 [B]): the gathered
+ * global labels, < 0 marking the capacity padding of a rank's batch (left out of the mean); gw (nullable, [B]):
+ * d loss / d (lse_b - lab_b) = 1 / n_live on live sessions, 0 on padding - the ga / gc of srec_score_ce_bwd*. */
+int srec_merge_stats(const float* st, int w, int B, const long long* lab_all, float* lse, float* lab, float* loss,
+                     float* gw, void* stream);
 
 int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                    void* stream);
@@ -236,9 +239,13 @@ typedef struct srec_adam_multi_desc {
     float* const* v;           /* ... exp_avg_sq (device pointers, 4-B aligned; float4 path when all four are 16-B aligned) */
 } srec_adam_multi_desc;
 int srec_adam_multi(const void* desc, const float* hyper, void* stream);
+/* item table, one wavefront per row.  max_norm > 0: Embedding(max_norm) renorm of the updated row (lessr.py:126,
+ * msgifsr.py:162) - written back when renorm_write != 0, otherwise W keeps the plain Adam result (the reference
+ * renormalises at the start of the NEXT forward) and only cs_out (nullable; = cs_scale / norm of the row as that forward
+ * will see it: niser.py:151, msgifsr.py:279) reflects it. */
 int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
-                   int use_wd, float max_norm, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
-                   void* stream);
+                   int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
+                   float cs_eps, void* stream);
 
 /* ---- MSGIFSR MSHGNN layer, all relations of both HeteroGraphConvs in one batched pass (hgat.hip) ------------------
  * Replaces msgifsr.py:70-89 (conv1(g) + conv2(reverse g), relation sum, head max, + session mean) around the fc GEMMs

@@ -21,6 +21,11 @@ import torch
 HEADER = 32
 
 
+class CapacityExceeded(ValueError):
+    """a batch does not fit the capacities of its padded layout (the collate factories then emit the exact layout and
+    the step runs as eager launches).  An exception, not an assert: `python -O` must not write past a capacity."""
+
+
 def _align4(n):
     return (n + 3) & ~3
 
@@ -54,7 +59,8 @@ class FlatBatch:
         for name, arr in fields.items():
             o, cap, _ = layout[name]
             a = np.asarray(arr).reshape(-1)
-            assert a.size <= cap, (name, a.size, cap)
+            if a.size > cap:
+                raise CapacityExceeded('field %s: %d elements, capacity %d' % (name, a.size, cap))
             buf[o:o + a.size] = a
             if a.size < cap:
                 # capacity padding: offset arrays repeat their last value (empty segments), index arrays -1

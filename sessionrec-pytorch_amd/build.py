@@ -45,17 +45,25 @@ def build(force=False, verbose=True):
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
     dig = _digest(hip_srcs + hdrs, ' '.join(flags))
     if force or _stale(LIB, dig):
-        objs = []
+        objs, todo = [], []
         for s in hip_srcs:
             o = s[:-4] + '.o'
             odig = _digest([s] + hdrs, ' '.join(flags))
             if force or _stale(o, odig):
-                cmd = [HIPCC] + flags + ['-c', s, '-o', o]
-                if verbose:
-                    print(' '.join(cmd), flush=True)
-                subprocess.check_call(cmd)
-                _mark(o, odig)
+                todo.append((s, o, odig))
             objs.append(o)
+
+        def compile_one(job):
+            s, o, odig = job
+            cmd = [HIPCC] + flags + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            _mark(o, odig)
+        if todo:                       # translation units are independent: compile them side by side
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+                list(ex.map(compile_one, todo))
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)

@@ -21,7 +21,7 @@ used instead of the python loops; both produce identical buffers.
 import numpy as np
 import torch
 
-from .batch import FlatBatch
+from .batch import CapacityExceeded, FlatBatch
 
 
 # ------------------------------------------------------------------------------------ per-sequence
@@ -186,7 +186,8 @@ def batch_homogeneous(graphs, caps=None):
     fcaps = None
     if caps:
         Nc, Ec, Uc = caps['N'], caps['E'], caps['U']
-        assert N <= Nc and E <= Ec, ('capacity exceeded', N, Nc, E, Ec)
+        if N > Nc or E > Ec:
+            raise CapacityExceeded('nodes %d / %d, edges %d / %d' % (N, Nc, E, Ec))
         fcaps = dict(seg=Bc + 1, eseg=Bc + 1, esrc=Ec, edst=Ec, in_ptr=Nc + 1, in_idx=Ec, out_ptr=Nc + 1, out_idx=Ec,
                      iid=Nc, last=Bc, uniq_items=Uc, uniq_ptr=Uc + 1, uniq_pos=Nc, uniq_cptr=Uc + 1,
                      chunk_ptr=Uc + Nc // CHUNK + 2, ew=Ec)
@@ -208,7 +209,8 @@ def batch_ccs(graphs, caps=None):
         np.cumsum(nn, out=seg[1:])
         segs[k] = seg
         ncap[k] = caps['N'] if caps else int(seg[-1])
-        assert seg[-1] <= ncap[k], ('node capacity exceeded', k, int(seg[-1]), ncap[k])
+        if seg[-1] > ncap[k]:
+            raise CapacityExceeded('order-%d nodes %d / %d' % (k, int(seg[-1]), ncap[k]))
         fields['seg%d' % k] = seg
         iid = np.concatenate([np.asarray(g[3][k], dtype=np.int64).reshape(-1, k) for g in graphs], axis=0)
         fields['iid%d' % k] = iid if k > 1 else iid.reshape(-1)
@@ -356,7 +358,9 @@ def collate_native(kind, seqs, order=1, caps=None):
         if n > 0:
             break
         if n == 0:
-            raise ValueError('native collate failed: empty session, order > 6, or capacity exceeded')
+            if caps is not None:
+                raise CapacityExceeded('native collate: the batch does not fit the capacities %r' % (caps,))
+            raise ValueError('native collate failed: empty session or order > 6')
         guess = -n + 16
     assert nf.value == len(names), (nf.value, len(names))
     buf = out[:n].copy()
@@ -377,7 +381,9 @@ def collate_native(kind, seqs, order=1, caps=None):
 def _labels(labels, caps):
     lab = np.asarray(labels, dtype=np.int64)
     if caps and len(lab) < caps['B']:
-        lab = np.concatenate([lab, np.zeros(caps['B'] - len(lab), dtype=np.int64)])
+        # capacity padding carries label -1: no kernel reads past the live count on one device, and the row-sharded loss
+        # (dist.ShardedScoreCE) recognises the padding of a rank's partial batch by it
+        lab = np.concatenate([lab, np.full(caps['B'] - len(lab), -1, dtype=np.int64)])
     return torch.as_tensor(lab)
 
 
@@ -399,11 +405,15 @@ def collate_fn_factory(*seq_to_graph_fns, caps=None):
                         fb = batch_homogeneous([fn(s) for s in seqs], use)
                     inputs.append(fb)
                 return inputs, _labels(labels, use)
-            except (ValueError, AssertionError):
+            except CapacityExceeded:
                 if use is None:
                     raise
+                FALLBACKS['exact'] += 1
                 use = None                       # the batch does not fit the capacities: exact layout (eager step)
     return collate_fn
+
+
+FALLBACKS = {'exact': 0}       # batches (of this process) that overflowed their capacities and were collated unpadded
 
 
 def collate_fn_factory_ccs(seq_to_graph_fns, order, caps=None):
@@ -420,14 +430,15 @@ def collate_fn_factory_ccs(seq_to_graph_fns, order, caps=None):
                         fb = batch_ccs([fn(s, order) for s in seqs], use)
                     inputs.append(fb)
                 return inputs, _labels(labels, use)
-            except (ValueError, AssertionError):
+            except CapacityExceeded:
                 if use is None:
                     raise
+                FALLBACKS['exact'] += 1
                 use = None                       # the batch does not fit the capacities: exact layout (eager step)
     return collate_fn
 
 
-def estimate_caps(dataset, batch_size, headroom=1.15):
+def estimate_caps(dataset, batch_size, headroom=1.15, shuffled=False, slices=None):
     """capacities for capacity-padded batches of `dataset` (an AugmentedDataset: index[:, 1] = prefix length): nodes of any
     order, edges of any relation and distinct items of a batch are all bounded by its total click count, so the cap is
     the largest click count of a run of batch_size consecutive samples (exact for the sequential loaders, typical for
@@ -436,9 +447,28 @@ def estimate_caps(dataset, batch_size, headroom=1.15):
     lens = np.asarray(dataset.index[:, 1], dtype=np.int64)
     if len(lens) == 0:
         return default_caps(batch_size)
-    cs = np.concatenate([[0], np.cumsum(lens)])
-    starts = np.arange(0, len(lens), batch_size)
-    sums = cs[np.minimum(starts + batch_size, len(lens))] - cs[starts]
+    if slices is not None:
+        # multi-rank training on sequential batches (dataset.RankSliceBatchSampler): the EXACT maximum click count of any
+        # rank's slice of any batch of the epoch - slices = (global batch size, world); batch_size = per-rank capacity
+        gb, w = slices
+        cs = np.concatenate([[0], np.cumsum(lens)])
+        best = 0
+        for s0 in range(0, len(lens), gb):
+            n = min(gb, len(lens) - s0)
+            edges = s0 + np.arange(w + 1) * n // w
+            best = max(best, int(np.diff(cs[edges]).max()))
+            if n < w:                                   # filler samples of ranks with an empty share
+                best = max(best, int(lens[s0:s0 + n].max()))
+        sums = np.array([best])
+    elif shuffled and len(lens) > batch_size:
+        # shuffled loaders (NISER / SRGNN): batches are random draws, not runs - take the largest click count over a few
+        # hundred random batches (a run of consecutive samples of ONE long session would over- or under-estimate)
+        rng = np.random.default_rng(0)
+        sums = np.array([lens[rng.choice(len(lens), batch_size, replace=False)].sum() for _ in range(256)])
+    else:
+        cs = np.concatenate([[0], np.cumsum(lens)])
+        starts = np.arange(0, len(lens), batch_size)
+        sums = cs[np.minimum(starts + batch_size, len(lens))] - cs[starts]
     n = int(sums.max() * headroom) + 64
     n = min(n, batch_size * int(lens.max()))
     n = (n + 255) // 256 * 256

@@ -62,8 +62,8 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 
 __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict__ G, float* __restrict__ M,
                                  float* __restrict__ Vv, int n, int d, int ld, const float* __restrict__ hyper,
-                                 int use_wd, float max_norm, float* __restrict__ cs_out, float cs_scale, int eps_mode,
-                                 float cs_eps) {
+                                 int use_wd, float max_norm, int renorm_write, float* __restrict__ cs_out, float cs_scale,
+                                 int eps_mode, float cs_eps) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const Hyper h = load_hyper(hyper);
@@ -88,7 +88,9 @@ __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict_
     float nrm = sqrtf(wave_sum(ss));
     if (max_norm > 0.f && nrm > max_norm) {
         const float sc = max_norm / (nrm + 1e-7f);
-        for (int c = lane * 4; c < d; c += 256) {       // same lane re-reads what it wrote
+        // renorm_write == 0: W keeps the plain Adam result (the reference renormalises in the NEXT forward,
+        // msgifsr.py:162,247) and only cs is that of the row as the next forward will see it
+        for (int c = lane * 4; renorm_write && c < d; c += 256) {       // same lane re-reads what it wrote
             float4 pp = *reinterpret_cast<float4*>(W + off + c);
             pp.x *= sc; pp.y *= sc; pp.z *= sc; pp.w *= sc;
             *reinterpret_cast<float4*>(W + off + c) = pp;
@@ -261,12 +263,12 @@ extern "C" int srec_adam_flat(float* p, const float* g, float* m, float* v, long
 }
 
 extern "C" int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
-                              int use_wd, float max_norm, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
-                              void* stream) {
+                              int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
+                              float cs_eps, void* stream) {
     if (n <= 0) return 0;
     if (d <= 0 || (d & 3) || (ld & 3)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(adam_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld,
-                       hyper, use_wd, max_norm, cs_out, cs_scale, eps_mode, cs_eps);
+                       hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps);
     SREC_LAUNCH_CHECK();
     return 0;
 }

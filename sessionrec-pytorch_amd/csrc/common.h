@@ -25,6 +25,21 @@ __device__ __forceinline__ unsigned short srec_f2bf(float a) { return (unsigned 
 
 #define SREC_BAD_ARG 1001
 
+// > 64 KiB of dynamic LDS needs hipFuncSetAttribute once PER DEVICE (function attributes are per device; one process
+// may drive several GPUs): `done` is a per-kernel bit mask indexed by the current device ordinal.
+#include <atomic>
+static inline int srec_lds_optin(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

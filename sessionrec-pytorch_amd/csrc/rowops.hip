@@ -278,12 +278,26 @@ __global__ void localize_idx_kernel(const long long* __restrict__ idx, long n, l
 }
 
 // st [w][2][B]: per-shard (log-sum-exp, label logit) of every session -> global lse[b] = logsumexp_r st[r][0][b],
-// lab[b] = sum_r st[r][1][b] (non-zero on the one shard that owns the label), loss = mean_b (lse - lab).  One workgroup.
-__global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, float* __restrict__ lse,
-                                   float* __restrict__ lab, float* __restrict__ loss) {
+// lab[b] = sum_r st[r][1][b] (non-zero on the one shard that owns the label), loss = mean over the LIVE sessions of
+// (lse - lab).  lab_all (nullable) = the gathered global labels: a session with label < 0 is capacity padding of its
+// rank's batch (dead): it is left out of the mean and gets weight 0 in gw (nullable) = d loss / d (lse_b - lab_b), i.e.
+// 1 / n_live for the live sessions - the per-session coefficients the backward kernels take as ga / gc.  One workgroup.
+__global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, const long long* __restrict__ lab_all,
+                                   float* __restrict__ lse, float* __restrict__ lab, float* __restrict__ loss,
+                                   float* __restrict__ gw) {
     __shared__ float red[4];
+    __shared__ int cnt[4];
+    int c = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) c += (lab_all == nullptr || lab_all[b] >= 0) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    const int n_live = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const float inv = 1.f / (float)(n_live > 0 ? n_live : 1);
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const bool live = lab_all == nullptr || lab_all[b] >= 0;
         float m = -INFINITY, t = 0.f;
         for (int r = 0; r < w; ++r) {
             m = fmaxf(m, st[((size_t)r * 2) * B + b]);
@@ -294,12 +308,13 @@ __global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, f
         const float v = m + logf(l);
         lse[b] = v;
         lab[b] = t;
-        acc += v - t;
+        if (live) acc += v - t;
+        if (gw != nullptr) gw[b] = live ? inv : 0.f;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) * inv;
 }
 
 // inv[pos[e]] = u for e in [ptr[u], ptr[u+1]); one wavefront per item.  inv is pre-filled with -1 by the first pass.
@@ -425,9 +440,11 @@ extern "C" int srec_localize_idx(const long long* idx, long n, long lo, int n_lo
 }
 
 // Row-sharded scoring (dist.py): merge the per-shard soft-max statistics gathered from the w ranks.  st [w, 2, B].
-extern "C" int srec_merge_stats(const float* st, int w, int B, float* lse, float* lab, float* loss, void* stream) {
+extern "C" int srec_merge_stats(const float* st, int w, int B, const long long* lab_all, float* lse, float* lab,
+                                float* loss, float* gw, void* stream) {
     if (w <= 0 || B <= 0) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(merge_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lse, lab, loss);
+    hipLaunchKernelGGL(merge_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lab_all, lse, lab, loss,
+                       gw);
     SREC_LAUNCH_CHECK();
     return 0;
 }

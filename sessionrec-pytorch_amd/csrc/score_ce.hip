@@ -352,13 +352,8 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
 template <int NTV, int MODE>
 int launch_nt(const CEArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * 64 * (NTV * 32 + 1) + 64 * 65) * sizeof(float);
-    static bool attr_set = false;                      // > 64 KiB dynamic LDS needs the opt-in once
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)flash_ce_kernel<NTV, MODE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> optin{0};   // > 64 KiB dynamic LDS needs the opt-in once per device
+    if (int rc = srec_lds_optin((const void*)flash_ce_kernel<NTV, MODE>, (int)lds, optin)) return rc;
     hipLaunchKernelGGL((flash_ce_kernel<NTV, MODE>), grid, dim3(256), lds, st, a);
     SREC_LAUNCH_CHECK();
     return 0;

@@ -400,13 +400,8 @@ int launch_b(const BArgs& a, int nblocks, hipStream_t st) {
     if (KIND == KIND_BWD && a.ga != nullptr) return launch_b<NTV, KIND == KIND_BWD ? KIND_BWD_G : KIND>(a, nblocks, st);
     constexpr int D = NTV * 32;
     constexpr size_t lds = (size_t)(KIND == KIND_FWD ? 2 : 4) * CH * D * sizeof(unsigned short) + 4 * SB * sizeof(float) + (SB / CH) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)flash_ce_bf16_kernel<NTV, KIND>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> optin{0};   // per (kernel instantiation, device)
+    if (int rc = srec_lds_optin((const void*)flash_ce_bf16_kernel<NTV, KIND>, (int)lds, optin)) return rc;
     hipLaunchKernelGGL((flash_ce_bf16_kernel<NTV, KIND>), dim3(nblocks), dim3(256), lds, st, a);
     SREC_LAUNCH_CHECK();
     return 0;

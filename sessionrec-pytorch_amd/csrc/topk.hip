@@ -178,12 +178,8 @@ extern "C" int srec_score_topk(const float* sr, int ld_sr, const float* E, int l
     float* pv = (float*)ws;
     int* pi = (int*)(pv + (size_t)R * B * K);
     const size_t lds = (size_t)SB * d * 4 + (size_t)SB * MAXK * 8 + (size_t)SB * MAXC * 8 + SB * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)topk_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> optin{0};
+    if (int rc = srec_lds_optin((const void*)topk_part_kernel, 160 * 1024, optin)) return rc;
     hipLaunchKernelGGL(topk_part_kernel, dim3(Ract, cdiv(B, SB)), dim3(256), lds, st, sr, ld_sr, E, ld_e, cs, B, V, d, K, ipr,
                        pv, pi);
     hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, pv, pi, Ract, B, K, out_val, out_idx);

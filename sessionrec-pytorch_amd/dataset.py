@@ -126,9 +126,49 @@ class AugmentedDataset:
         self.index = index
 
     def __getitem__(self, idx):
+        if idx < 0:
+            # filler sample of a multi-rank batch slice (RankSliceBatchSampler): the prefix of sample -idx-1 with label -1,
+            # which the sharded loss leaves out of the mean (dist.ShardedScoreCE) - the reference never sees it
+            sid, lidx = self.index[-idx - 1]
+            return self.sessions[sid][:lidx], -1
         sid, lidx = self.index[idx]
         seq = self.sessions[sid]
         return seq[:lidx], seq[lidx]
 
     def __len__(self):
         return len(self.index)
+
+
+class RankSliceBatchSampler:
+    """Multi-rank training on the reference's batches (strong scaling): batches are formed from `sampler` exactly as the
+    single-device DataLoader forms them (`batch_size` consecutive draws, last partial batch kept: main_lessr.py:84-93,
+    main_msgifsr.py:148-157, main_niser.py:83-92) and rank r of w yields positions [r n / w, (r+1) n / w) of each
+    n-sample batch - the loss is then the mean over the SAME samples as on one device.  A rank whose share of a tiny
+    last batch is empty gets one filler index (negative: AugmentedDataset returns it with label -1 = left out of the
+    loss) so that every rank takes part in every step's collectives.  `sampler` must produce the same order on every
+    rank (SequentialSampler, or a RandomSampler with an identically seeded generator)."""
+
+    def __init__(self, sampler, batch_size, rank, world):
+        self.sampler, self.batch_size, self.rank, self.world = sampler, batch_size, rank, world
+
+    def __len__(self):
+        return (len(self.sampler) + self.batch_size - 1) // self.batch_size
+
+    def slice_of(self, batch):
+        n, r, w = len(batch), self.rank, self.world
+        mine = batch[r * n // w:(r + 1) * n // w]
+        return mine if mine else [-batch[r % n] - 1]
+
+    def __iter__(self):
+        batch = []
+        for i in self.sampler:
+            batch.append(int(i))
+            if len(batch) == self.batch_size:
+                yield self.slice_of(batch)
+                batch = []
+        if batch:
+            yield self.slice_of(batch)
+
+    def per_rank_capacity(self):
+        """sessions a rank can receive in one step"""
+        return (self.batch_size + self.world - 1) // self.world

@@ -100,16 +100,18 @@ class HipLocal:
         lib.srec_localize_idx(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), stream())
         return out
 
-    def merge_stats(self, st):
-        """st [w, 2, B] gathered per-shard statistics -> (lse [B], label logit [B], mean loss)"""
+    def merge_stats(self, st, lab_all=None):
+        """st [w, 2, B] gathered per-shard statistics (+ the gathered global labels, < 0 = capacity padding) ->
+        (lse [B], label logit [B], mean loss over the live sessions, gw [B] = d loss / d (lse_b - lab_b))"""
         from ._lib import lib, ptr, stream
         st = st.contiguous()
         w, _, B = st.shape
         lse = torch.empty(B, device=st.device, dtype=torch.float32)
         lab = torch.empty(B, device=st.device, dtype=torch.float32)
+        gw = torch.empty(B, device=st.device, dtype=torch.float32)
         loss = torch.empty((), device=st.device, dtype=torch.float32)
-        lib.srec_merge_stats(ptr(st), w, B, ptr(lse), ptr(lab), ptr(loss), stream())
-        return lse, lab, loss
+        lib.srec_merge_stats(ptr(st), w, B, ptr(lab_all), ptr(lse), ptr(lab), ptr(loss), ptr(gw), stream())
+        return lse, lab, loss, gw
 
     def inverse_index(self, uptr, upos, U, n):
         """inv[p] = u for every position p of item u (positions listed in upos[uptr[u]:uptr[u+1]]); -1 where no item claims p"""
@@ -220,17 +222,25 @@ class HipLocal:
 
 
 # ------------------------------------------------------------------------------- autograd functions
-def _merge_stats(lse_r, lab_logit_r, group, local=None):
-    """per-shard (log-sum-exp, label logit) of every session -> global (lse, label logit, mean loss): ONE all-gather of the
-    [2, B] pair (the label logit is non-zero on exactly one shard, so its sum over the gathered copies is the all-reduce
-    it replaces) and one merge kernel"""
+def _merge_stats(lse_r, lab_logit_r, group, local=None, lab_all=None):
+    """per-shard (log-sum-exp, label logit) of every session -> global (lse, label logit, mean loss, gw): ONE all-gather of
+    the [2, B] pair (the label logit is non-zero on exactly one shard, so its sum over the gathered copies is the
+    all-reduce it replaces) and one merge kernel.  lab_all (optional): the gathered global labels; sessions with a
+    label < 0 are the capacity padding of a rank's (partial) batch and are left out of the mean.  gw [B] =
+    d loss / d (lse_b - lab_b): 1 / n_live on live sessions, 0 on padding."""
+    def torch_merge(lse, lab):
+        if lab_all is None:
+            live = torch.ones_like(lse)
+        else:
+            live = (lab_all >= 0).to(lse.dtype)
+        gw = live / live.sum().clamp(min=1.0)
+        return lse, lab, ((lse - lab) * gw).sum(), gw
     if _world(group) == 1 and not (FORCE and dist.is_initialized()):
-        return lse_r, lab_logit_r, (lse_r - lab_logit_r).mean()
+        return torch_merge(lse_r, lab_logit_r)
     st = all_gather_cat(torch.stack([lse_r, lab_logit_r]).unsqueeze(0), group)     # [w, 2, B]
     if local is not None and hasattr(local, 'merge_stats'):
-        return local.merge_stats(st)
-    lse, lab = torch.logsumexp(st[:, 0], dim=0).contiguous(), st[:, 1].sum(0)
-    return lse, lab, (lse - lab).mean()
+        return local.merge_stats(st, lab_all)
+    return torch_merge(torch.logsumexp(st[:, 0], dim=0).contiguous(), st[:, 1].sum(0))
 
 
 class ShardedLookup(torch.autograd.Function):
@@ -284,17 +294,19 @@ class ShardedScoreCE(torch.autograd.Function):
             lab_all = all_gather_cat(labels.to(torch.int64), group)
         lab_loc = local.localize(lab_all, lo, n_loc)
         lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
-        lse, lab_logit, loss = _merge_stats(lse_r, lab_logit, group, local)
-        ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
+        lse, lab_logit, loss, gw = _merge_stats(lse_r, lab_logit, group, local, lab_all)
+        ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse, gw)
         ctx.misc = (dE, ws, cs_inv_scale, local, group)
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
-        sr_all, shard, cs, lab_loc, lse = ctx.saved_tensors
+        sr_all, shard, cs, lab_loc, lse, gw = ctx.saved_tensors
         dE, ws, cs_inv_scale, local, group = ctx.misc
-        gs = gloss.reshape(1).to(torch.float32).contiguous()
-        dsr_part = local.ce_bwd(sr_all, shard, cs, lab_loc, lse, gs, dE, ws, cs_inv_scale)
+        # d z[b, v] = g_b (softmax_b[v] - [v == label_b]) with g_b = gloss / n_live on live sessions, 0 on the capacity
+        # padding of a rank's partial batch (the mean runs over the live sessions of the GLOBAL batch)
+        g = (gw * gloss.reshape(()).to(torch.float32)).contiguous()
+        dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False)
         dsr = reduce_scatter_sum(dsr_part, group)
         return dsr, None, None, None, None, None, None, None, None, None, None
 
@@ -312,7 +324,7 @@ class ShardedScoreStats(torch.autograd.Function):
         lab_all = all_gather_cat(labels.to(torch.int64), group)
         lab_loc = local.localize(lab_all, lo, n_loc)
         lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
-        lse, lab_logit, _ = _merge_stats(lse_r, lab_logit, group, local)
+        lse, lab_logit, _, _ = _merge_stats(lse_r, lab_logit, group, local)
         r = _rank(group)
         ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse)
         ctx.misc = (dE, ws, cs_inv_scale, local, group, tgrad)
@@ -478,14 +490,45 @@ class VocabParallel:
         return val, idx.to(torch.int32)
 
     def sync_replicated_grads(self, params, optimizer=None):
-        """sum the replicated-parameter gradients over ranks in one flat bucket.  With `optimizer` (FusedAdam) the
-        reduced bucket is handed over as the gradient source (views), so nothing is copied back per parameter."""
+        """sum the replicated-parameter gradients over ranks in ONE flat bucket whose layout is the same on every rank.
+        `params` is the model's replicated parameter list (same order everywhere).  Which of them carry a gradient can
+        differ between ranks (MSHGNN only instantiates the GAT modules of relations with live edges in THIS rank's
+        batch), so the set is agreed on once - the union over ranks at the first call, a host-side all-reduce of a
+        presence mask, outside any graph capture - and from then on the bucket always holds exactly those parameters,
+        a rank without a gradient for one contributing zeros.  With `optimizer` (FusedAdam) the reduced bucket is handed
+        over as the gradient source (views), so nothing is copied back per parameter."""
         if self.world == 1 and not (FORCE and dist.is_initialized()):
             return
-        ps = [p for p in params if p.grad is not None]
+        params = list(params)
+        key = tuple(id(p) for p in params)
+        if getattr(self, '_bucket_key', None) != key:
+            if params and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the gradient bucket layout must be agreed on by an eager step before graph capture')
+            dev = params[0].device if params else self.dE.device
+            present = torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], device=dev)
+            if self.world > 1:
+                dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
+            self._bucket_live = [p for p, f in zip(params, present.tolist()) if f > 0]
+            self._bucket_ids = {id(p) for p in self._bucket_live}
+            self._bucket_key = key
+            self._bucket_zero = {}
+        ps = self._bucket_live
+        late = [p for p in params if p.grad is not None and id(p) not in self._bucket_ids]
+        if late:
+            raise RuntimeError('%d replicated parameters received a gradient on this rank that no rank had when the bucket '
+                               'layout was agreed on (a relation without edges in the first batches?)' % len(late))
         if not ps:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        pieces = []
+        for p in ps:
+            if p.grad is not None:
+                pieces.append(p.grad.reshape(-1))
+            else:                                      # this rank's batch gave it no gradient: zeros (static buffer)
+                z = self._bucket_zero.get(id(p))
+                if z is None:
+                    z = self._bucket_zero[id(p)] = torch.zeros(p.numel(), device=p.device, dtype=p.dtype)
+                pieces.append(z)
+        flat = torch.cat(pieces)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         off = 0
         views = {}
@@ -497,4 +540,7 @@ class VocabParallel:
             optimizer.grad_override = views
         else:
             for p in ps:
-                p.grad.copy_(views[id(p)])
+                if p.grad is None:
+                    p.grad = views[id(p)].clone()
+                else:
+                    p.grad.copy_(views[id(p)])

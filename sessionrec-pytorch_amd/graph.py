@@ -28,13 +28,83 @@ class GraphedTrainStep:
         snap_o = optimizer.snapshot()                    # a resumed / already running optimizer keeps its moments
         snap_p = [p.detach().clone() for p in model.parameters()]
         snap_b = [b.detach().clone() for b in model.buffers()]
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                self._eager()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
+        T0 = getattr(optimizer, '_T', 0)
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+        finally:
+            # whatever happened in the warm-up (including an exception half way): parameters, buffers (BatchNorm running
+            # statistics) and optimizer state go back to where they were, so an eager fallback continues the SAME trajectory
+            self._restore(model, optimizer, snap_p, snap_b, snap_o)
+        # ---- capture
+        optimizer.zero_grad(set_to_none=True)
+        import os
+        try:                                             # the hipGraph_t stays queryable (node_counts); SREC_KEEP_GRAPH=0 opts out
+            self.graph = torch.cuda.CUDAGraph(keep_graph=os.environ.get('SREC_KEEP_GRAPH', '1') != '0')
+        except TypeError:
+            self.graph = torch.cuda.CUDAGraph()
+        self._pending_advance = None
+        work = None
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
+                self.loss.backward(self._one)
+                if self.after_backward is not None:
+                    self.after_backward()
+                work = optimizer._work()
+                optimizer._frozen = work
+                # the step counters that matter live on the device and are advanced by the captured step itself; the
+                # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
+                # capture and take it back afterwards
+                optimizer.advance(work)
+                optimizer.launch(work)
+        except BaseException:
+            # capture refused: nothing ran on the device, but host bookkeeping may be half advanced - undo it all
+            optimizer._frozen = None
+            self._restore(model, optimizer, snap_p, snap_b, snap_o)
+            optimizer.zero_grad(set_to_none=True)
+            raise
+        for _, _, items in work:
+            for _, _, st in items:
+                st['step'] -= 1
+        optimizer._T -= 1
+        assert optimizer._T == T0, (optimizer._T, T0)
+        self.work = work
+        if hasattr(self.graph, 'instantiate'):
+            try:
+                self.graph.instantiate()
+            except Exception:
+                pass
+
+    def node_counts(self):
+        """{'kernel': n, 'memcpy': n, 'memset': n, 'other': n} of the captured step (hipGraphGetNodes on the raw hipGraph_t)
+        or None when the handle is not available: the launch count of one training step, measured, not estimated"""
+        import ctypes
+        try:
+            raw = self.graph.raw_cuda_graph()
+            hip = ctypes.CDLL('libamdhip64.so')
+            n = ctypes.c_size_t(0)
+            if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+                return None
+            nodes = (ctypes.c_void_p * n.value)()
+            if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+                return None
+            out = dict(kernel=0, memcpy=0, memset=0, other=0)
+            for nd in nodes:
+                t = ctypes.c_int(-1)
+                hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(t))
+                out[{0: 'kernel', 1: 'memcpy', 2: 'memset'}.get(t.value, 'other')] += 1
+            return out
+        except Exception:
+            return None
+
+    @staticmethod
+    def _restore(model, optimizer, snap_p, snap_b, snap_o):
         with torch.no_grad():
             for p, q in zip(model.parameters(), snap_p):
                 p.copy_(q)
@@ -44,27 +114,8 @@ class GraphedTrainStep:
         ms = model.__dict__.get('_srec_state')
         if ms is not None:
             ms['cs_fresh'] = False
-        # ---- capture
-        optimizer.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
-        self._pending_advance = None
-        with torch.cuda.graph(self.graph):
-            self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
-            self.loss.backward(self._one)
-            if self.after_backward is not None:
-                self.after_backward()
-            work = optimizer._work()
-            optimizer._frozen = work
-            # the step counters that matter live on the device and are advanced by the captured step itself; the
-            # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
-            # capture and take it back afterwards
-            optimizer.advance(work)
-            optimizer.launch(work)
-        for _, _, items in work:
-            for _, _, st in items:
-                st['step'] -= 1
-        optimizer._T -= 1
-        self.work = work
+            if ms.get('tgrad') is not None:
+                ms['tgrad'].fresh = False
 
     @staticmethod
     def _signature(x):

@@ -275,16 +275,23 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             return ps
         return []
 
-    def _renorm(self, mg):
+    def _renorm(self, mg=None):
         """Embedding(max_norm=1): rows are renormalised in place (no grad) before they are read."""
         from ._lib import lib, ptr, stream
         W = self._table()
         with torch.no_grad():
             lib.srec_renorm_rows(ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], 1.0, stream())
 
+    def _prepare_table(self):
+        # training entry: the renorm runs here, ahead of the cosine column scale (the scale must be that of the rows
+        # the scoring kernels read: msgifsr.py:162 renormalises inside the lookup, :276-279 normalises the result)
+        self._renorm()
+        self._table_ready = True
+
     def session_repr(self, mg, tgrad=None):
         K = self.order
-        self._renorm(mg)
+        if not self.__dict__.pop('_table_ready', False):
+            self._renorm(mg)
         W = self._table()
         d = self.embedding_dim
         rows = self._lookup(mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
@@ -380,6 +387,7 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         if dynB is None:
             dynB = mg.dynp('B')
         st = self._state(B)
+        self._prepare_table()
         cs, inv_scale = self._col_scale(st)
         srs = self.session_repr(mg, tgrad=st['tgrad'])
         if not isinstance(srs, (list, tuple)):
@@ -405,7 +413,11 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         else:
             logp = logits[0]
         if sharded:          # this rank's share of the mean over the GLOBAL batch (replicated grads are summed over ranks)
-            return -logp.sum() / (B * self.shard.world)
+            live = labels >= 0                                  # label -1: capacity padding of a rank's partial batch
+            n_live = live.sum().to(logp.dtype)
+            from .dist import all_reduce_sum
+            n_live = all_reduce_sum(n_live.detach().clone(), self.shard.group)
+            return -torch.where(live, logp, torch.zeros_like(logp)).sum() / n_live.clamp(min=1)
         if dynB is not None:
             live = torch.arange(B, device=logp.device) < dynB
             return -torch.where(live, logp, torch.zeros_like(logp)).sum() / dynB.to(logp.dtype).clamp(min=1).sum()

@@ -49,8 +49,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _grad_of(self, p, table, tgrad, zero_ids):
         g = p.grad
-        if g is not None and self.grad_override and id(p) in self.grad_override:
-            g = self.grad_override[id(p)]
+        if self.grad_override and id(p) in self.grad_override:
+            g = self.grad_override[id(p)]      # all-reduced bucket view: present even when THIS rank's batch gave no gradient
         if table is not None and p is table and tgrad is not None:
             g = tgrad.buf if g is None else g.add_(tgrad.buf)
         if g is None and id(p) in zero_ids:
@@ -218,9 +218,11 @@ class FusedAdam(torch.optim.Optimizer):
                     cs_out, cs_scale, eps_mode = None, 1.0, 0
                     if cos is not None and st is not None and st.get('cs') is not None:
                         cs_out, cs_scale, eps_mode = st['cs'], float(cos[0]), int(cos[1])
-                    # Embedding(max_norm) renorm stays in forward (reference state after step()): max_norm = 0
+                    # Embedding(max_norm) renorm stays in forward (reference state after step()): renorm_write = 0; the
+                    # column scale of the next step is nevertheless that of the rows as the next forward will see them
+                    mn = float(getattr(model, '_max_norm', 0.0) or 0.0) if cs_out is not None else 0.0
                     lib.srec_adam_rows(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
-                                       p.shape[1], p.stride(0), ptr(hyper), use_wd, 0.0, ptr(cs_out), cs_scale,
+                                       p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, 0, ptr(cs_out), cs_scale,
                                        eps_mode, 1e-12, stream())
                     if cs_out is not None:
                         st['cs_fresh'] = True

@@ -65,6 +65,11 @@ class _ScoringMixin:
         st['cs_fresh'] = False          # the optimizer sets it again after refreshing cs in its row pass
         return st['cs'], 1.0 / float(scale)
 
+    def _prepare_table(self):
+        """in-place, no-grad mutation of the table the reference's forward performs before reading it
+        (Embedding(max_norm): lessr.py:126, msgifsr.py:162); called once per step ahead of everything that reads rows"""
+        self._table_ready = False
+
     shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
     graph_capable = False      # True: every kernel of the step reads its live extents from the padded batch (hipGraph replay)
 
@@ -80,6 +85,7 @@ class _ScoringMixin:
         if dynB is None and hasattr(inputs[0], 'dynp'):
             dynB = inputs[0].dynp('B')
         st = self._state(B)
+        self._prepare_table()                        # Embedding(max_norm) renorm BEFORE the cosine column scale is taken
         cs, inv_scale = self._col_scale(st)
         if self.shard is not None:
             self.shard.labels_hint = labels          # gathered together with the lookup's request lists

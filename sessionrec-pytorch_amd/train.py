@@ -50,7 +50,7 @@ def evaluate(model, data_loader, device, cutoff=20):
 
 class TrainRunner:
     def __init__(self, dataset, model, train_loader, test_loader, device, lr=1e-3, weight_decay=0, patience=3,
-                 checkpoint=None, resume=True, hooks=(), graph='auto'):
+                 checkpoint=None, resume=True, hooks=(), graph='auto', shard=None):
         """Same positional surface as the reference (train.py:57-69).  Additions (the reference has
         neither): `checkpoint` = path written after every epoch (model, optimizer incl. Adam moments and step counts,
         scheduler, epoch / batch counters, best metrics) and, with `resume`, read back at the start of train();
@@ -58,7 +58,13 @@ class TrainRunner:
         wandb calls sit at the same two places).  `graph` ('auto' | False): on the GPU, batches that arrive
         capacity-padded (collate_fn_factory*(..., caps=...)) replay ONE captured hipGraph of the whole step (forward,
         backward, FusedAdam) instead of ~120 eager launches; a batch with another layout or relation pattern runs
-        eagerly, with the same result."""
+        eagerly, with the same result.  `shard` (dist.VocabParallel, multi-GPU): the item table is row-sharded over the
+        ranks and every rank feeds its slice of each batch (dataset.RankSliceBatchSampler); the replicated encoder
+        gradients are all-reduced after backward, evaluation merges per-shard top-k lists, only rank 0 prints."""
+        self.shard = shard
+        self.rank = shard.rank if shard is not None else 0
+        self.replicated = ([p for p in model.parameters() if p is not model._table() and p.requires_grad]
+                           if shard is not None else None)
         self.graph = graph
         self._gstep = None
         self.graph_steps = self.eager_steps = 0
@@ -93,8 +99,10 @@ class TrainRunner:
         from .graph import GraphedTrainStep
         if self._gstep is None:
             try:
-                self._gstep = GraphedTrainStep(self.model, self.optimizer, inputs, labels)
-            except Exception as e:                     # capture refused: stay eager for the rest of the run
+                self._gstep = GraphedTrainStep(self.model, self.optimizer, inputs, labels, after_backward=self._sync_grads
+                                               if self.shard is not None else None)
+            except Exception as e:                     # capture refused: stay eager for the rest of the run (the
+                # constructor has put parameters, buffers and optimizer state back: same trajectory)
                 print('hipGraph capture failed (%s: %s); eager launches' % (type(e).__name__, e))
                 self.graph = False
                 return None
@@ -104,6 +112,13 @@ class TrainRunner:
             if 'differs from the captured one' not in str(e):
                 raise
             return None
+
+    def _sync_grads(self):
+        self.shard.sync_replicated_grads(self.replicated, self.optimizer)
+
+    def _print(self, *a):
+        if self.rank == 0:
+            print(*a)
 
     def train_step(self, inputs, labels):
         loss = self._graph_step(inputs, labels)
@@ -119,34 +134,55 @@ class TrainRunner:
             assert not th.isnan(scores).any()
             loss = nn.functional.nll_loss(scores, labels)
         loss.backward()
+        if self.shard is not None:
+            self._sync_grads()
         self.optimizer.step()
         return loss
 
     # ------------------------------------------------------------------ checkpoint / hooks (not in the reference)
     def state_dict(self):
+        """plain tensors, numbers, strings, lists and dicts only: loadable with torch.load(weights_only=True).  RNG states
+        ride along so that a resumed dropout / shuffled run continues the uninterrupted trajectory."""
+        rng = dict(torch=th.get_rng_state())
+        if th.cuda.is_available() and th.device(self.device).type == 'cuda':
+            rng['cuda'] = th.cuda.get_rng_state(self.device)
         return dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(),
-                    scheduler=self.scheduler.state_dict(), epoch=self.epoch, batch=self.batch, best=self.best)
+                    scheduler=self.scheduler.state_dict(), epoch=self.epoch, batch=self.batch, best=list(self.best),
+                    rng=rng)
 
     def load_state_dict(self, sd):
         self.model.load_state_dict(sd['model'])
         self.optimizer.load_state_dict(sd['optimizer'])
         self.scheduler.load_state_dict(sd['scheduler'])
         self.epoch, self.batch, self.best = sd['epoch'], sd['batch'], tuple(sd['best'])
+        rng = sd.get('rng') or {}
+        if 'torch' in rng:
+            th.set_rng_state(rng['torch'].cpu())
+        if 'cuda' in rng and th.cuda.is_available() and th.device(self.device).type == 'cuda':
+            th.cuda.set_rng_state(rng['cuda'].cpu(), self.device)
         self._gstep = None                 # optimizer state tensors were replaced: a captured step would use stale ones
         if self.fused:
             from . import ops
             ops.weights_changed()          # cached bf16 copies / column scales belong to the old weights
             self.model.__dict__.pop('_srec_state', None)
 
+    def _ckpt_path(self, path=None):
+        """with a row-sharded table every rank owns different rows (and Adam moments): one file per rank"""
+        path = path or self.checkpoint
+        if self.shard is not None and self.shard.world > 1:
+            path = '%s.rank%dof%d' % (path, self.shard.rank, self.shard.world)
+        return path
+
     def save_checkpoint(self, path=None):
         import os
-        path = path or self.checkpoint
+        path = self._ckpt_path(path)
         tmp = path + '.tmp'
         th.save(self.state_dict(), tmp)
         os.replace(tmp, path)              # a crash mid-write never leaves a truncated checkpoint behind
 
     def load_checkpoint(self, path=None):
-        self.load_state_dict(th.load(path or self.checkpoint, map_location=self.device, weights_only=False))
+        # weights_only=True: a checkpoint is data (tensors / numbers / containers), never pickled code
+        self.load_state_dict(th.load(self._ckpt_path(path), map_location=self.device, weights_only=True))
 
     def _emit(self, **event):
         for h in self.hooks:
@@ -155,10 +191,10 @@ class TrainRunner:
     def train(self, epochs, log_interval=100):
         import os
         done = 0
-        if self.checkpoint and self.resume and os.path.exists(self.checkpoint):
+        if self.checkpoint and self.resume and os.path.exists(self._ckpt_path()):
             self.load_checkpoint()
             done = self.epoch                # `epochs` is the total of the interrupted run
-            print(f'Resumed from {self.checkpoint}: epoch {self.epoch}, batch {self.batch}')
+            self._print(f'Resumed from {self._ckpt_path()}: epoch {self.epoch}, batch {self.batch}')
         max_mrr, max_hit, bad_counter = self.best
         t = time.time()
         mean_loss = 0
@@ -184,7 +220,7 @@ class TrainRunner:
                 if (self.batch > 0 and self.batch % log_interval == 0) or len(pending) >= 256:
                     flush()
                 if self.batch > 0 and self.batch % log_interval == 0:
-                    print(f'Batch {self.batch}: Loss = {mean_loss:.4f}, Time Elapsed = {time.time() - t:.2f}s')
+                    self._print(f'Batch {self.batch}: Loss = {mean_loss:.4f}, Time Elapsed = {time.time() - t:.2f}s')
                     self._emit(kind='interval', batch=self.batch, loss=mean_loss, seconds=time.time() - t)
                     t = time.time()
                     mean_loss = 0
@@ -192,7 +228,7 @@ class TrainRunner:
             flush()
             self.scheduler.step()
             mrr, hit = evaluate(self.model, self.test_loader, self.device)
-            print(f'Epoch {self.epoch}: MRR = {mrr * 100:.3f}%, Hit = {hit * 100:.3f}%')
+            self._print(f'Epoch {self.epoch}: MRR = {mrr * 100:.3f}%, Hit = {hit * 100:.3f}%')
             self._emit(kind='epoch', epoch=self.epoch, mrr=mrr, hit=hit)
             stop = False
             if mrr < max_mrr and hit < max_hit:

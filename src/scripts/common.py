@@ -45,6 +45,9 @@ def parse(model):
     p.add_argument('--checkpoint', default=None,
                    help='(not in the reference) write a resumable checkpoint here after every epoch; resume from it if present')
     p.add_argument('--metrics-log', default=None, help='(not in the reference) append one JSON line per logged interval / epoch')
+    p.add_argument('--gpus', type=int, default=int(os.environ.get('SREC_GPUS', '1')),
+                   help='(not in the reference) train on this many GPUs of the node: item table row-sharded over them (RCCL), '
+                        'encoder replicated, every rank encoding its slice of each --batch-size batch (same loss as one GPU)')
     if model == 'MSGIFSR':
         p.add_argument('--order', type=int, default=3, help='order of msg')
         p.add_argument('--reducer', type=str, default='mean', help='method for reducer')
@@ -52,7 +55,8 @@ def parse(model):
         p.add_argument('--extra', action='store_true', help='whether use REnorm.')
         p.add_argument('--fusion', action='store_true', help='whether use IFR.')
     args = p.parse_args()
-    print(args)
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(args)
     return args
 
 
@@ -75,8 +79,26 @@ def _jsonl(path):
     return hook
 
 
+def _launch_ranks(n):
+    """`--gpus N` outside a torchrun environment: re-execute this launcher under torch.distributed.run, one rank per GPU"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    env.pop('HIP_VISIBLE_DEVICES', None)          # start.sh pins one device for the single-GPU case
+    cmd = [sys.executable, '-u', '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def run(model_name):
     args = parse(model_name)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        _launch_ranks(args.gpus)
     seed_all(123)
     import torch as th
     from torch.utils.data import DataLoader, SequentialSampler
@@ -86,7 +108,18 @@ def run(model_name):
     from src.utils.data.dataset import AugmentedDataset, read_dataset
     from src.utils.train import TrainRunner
 
-    device = th.device('cuda' if th.cuda.is_available() else 'cpu')
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    sharded = world > 1 or bool(os.environ.get('SREC_FORCE_COLLECTIVES'))
+    if sharded:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29544')
+        dist.init_process_group('nccl' if th.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+        if th.cuda.is_available():
+            th.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        if rank != 0:
+            sys.stdout = open(os.devnull, 'w')            # one log, rank 0's
+    device = th.device('cuda', th.cuda.current_device()) if th.cuda.is_available() else th.device('cpu')
     if device.type == 'cuda':
         from importlib import import_module
         import_module('sessionrec-pytorch_amd.ops').set_precision(args.precision)
@@ -100,9 +133,20 @@ def run(model_name):
         train_sessions = train_sessions[:-num_valid]
     train_set, test_set = AugmentedDataset(train_sessions), AugmentedDataset(test_sessions)
     caps = None
-    if device.type == 'cuda' and not args.no_graph and not getattr(args, 'extra', False):
+    shuffled = model_name in ('NISER', 'SRGNN')
+    per_rank = (args.batch_size + world - 1) // world        # sessions one rank encodes per step
+    if sharded:
+        # every rank must present the SAME padded layout sizes to the collectives in every step: capacities are mandatory
+        # and must never overflow - exact maxima of the epoch for the sequential loaders, worst case for the shuffled ones
+        from src.utils.data.collate import default_caps, estimate_caps
+        max_len = int(train_set.index[:, 1].max()) if len(train_set) else 1
+        caps = (default_caps(per_rank, max_len) if shuffled else
+                estimate_caps(train_set, per_rank, headroom=1.0, slices=(args.batch_size, world)))
+        if model_name == 'LESSR':
+            caps = dict(caps, E=caps['N'] * max(7, max_len))
+    elif device.type == 'cuda' and not args.no_graph and not getattr(args, 'extra', False):
         from src.utils.data.collate import estimate_caps
-        caps = estimate_caps(train_set, args.batch_size)     # capacity-padded training batches -> whole-step hipGraph replay
+        caps = estimate_caps(train_set, args.batch_size, shuffled=shuffled)     # capacity-padded training batches -> whole-step hipGraph replay
         if model_name == 'LESSR':                            # shortcut graphs: up to L(L+1)/2 edges per session
             caps = dict(caps, E=caps['N'] * 7)
     print(len(train_set))
@@ -126,22 +170,48 @@ def run(model_name):
     pin = device.type == 'cuda'          # pinned batches: asynchronous H2D copies
     pw = args.num_workers > 0            # keep the loader processes across epochs (a respawn costs seconds per epoch)
     # reference loaders: LESSR / MSGIFSR train in time order (SequentialSampler), NISER shuffles; test shuffles
-    if model_name in ('LESSR', 'MSGIFSR'):
+    if sharded:
+        # the reference's batches (order and membership), each rank collating its contiguous slice of every batch
+        from importlib import import_module
+        from torch.utils.data import RandomSampler
+        RankSlice = import_module('sessionrec-pytorch_amd.dataset').RankSliceBatchSampler
+        base = (RandomSampler(train_set, generator=th.Generator().manual_seed(123)) if shuffled
+                else SequentialSampler(train_set))
+        train_loader = DataLoader(train_set, batch_sampler=RankSlice(base, args.batch_size, rank, world),
+                                  num_workers=args.num_workers, collate_fn=train_collate_fn, pin_memory=pin,
+                                  persistent_workers=pw)
+        # evaluation: every rank scores the same sessions against its rows (order does not enter the metrics)
+        test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
+                                 collate_fn=collate_fn, persistent_workers=pw)
+    elif model_name in ('LESSR', 'MSGIFSR'):
         train_loader = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.num_workers,
                                   collate_fn=train_collate_fn, sampler=SequentialSampler(train_set), pin_memory=pin, persistent_workers=pw)
+        test_loader = None
     else:
         train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
                                   collate_fn=train_collate_fn, pin_memory=pin, persistent_workers=pw)
-    test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
-                             collate_fn=collate_fn, persistent_workers=pw)
+        test_loader = None
+    if test_loader is None:
+        test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
+                                 collate_fn=collate_fn, persistent_workers=pw)
     model = model.to(device)
     print(model)
+    shard = None
+    if sharded:
+        from importlib import import_module
+        shard = import_module('sessionrec-pytorch_amd.dist').VocabParallel(model, idx_cap=caps['U'])
+        print(f'item table row-sharded over {world} ranks ({shard.per} rows each), {per_rank} sessions per rank and step')
     runner = TrainRunner(args.dataset_dir, model, train_loader, test_loader, device=device, lr=args.lr,
                          weight_decay=args.weight_decay, patience=args.patience, checkpoint=args.checkpoint,
-                         hooks=[_jsonl(args.metrics_log)] if args.metrics_log else (), graph=False if args.no_graph else 'auto')
+                         hooks=[_jsonl(args.metrics_log)] if args.metrics_log and rank == 0 else (),
+                         graph=False if args.no_graph else 'auto', shard=shard)
     print('start training')
     mrr, hit = runner.train(args.epochs, args.log_interval)
     if runner.graph_steps:
         print(f'training steps: {runner.graph_steps} hipGraph replays, {runner.eager_steps} eager')
     print('MRR@20\tHR@20')
     print(f'{mrr * 100:.3f}%\t{hit * 100:.3f}%')
+    if sharded:
+        sys.stdout.flush()
+        dist.barrier()
+        dist.destroy_process_group()

@@ -303,6 +303,37 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(dll, name), name
 
 
+def test_collate_abi_header_matches_the_library():
+    """include/srec_collate.h declares the native collate entry point: the symbol is exported and behaves as documented
+    (returns the int32 count; 0 for an empty session; -(required) when the output buffer is too small)"""
+    import ctypes
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'srec_collate.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = re.findall(r'\b(?:long|int)\s+(srec_\w+)\s*\(', hdr)
+    assert names == ['srec_collate'], names
+    c = pkg('collate')
+    dll = c._native()
+    if dll is None:
+        pytest.skip('libsrec_collate.so not built')
+    for n in names:
+        assert hasattr(dll, n), n
+    seqs = np.array([3, 5, 3, 7, 7], dtype=np.int64)
+    offs = np.array([0, 3, 5], dtype=np.int64)
+    info = np.zeros(3 * 40, dtype=np.int64)
+    nf = ctypes.c_int(0)
+    out = np.empty(4096, dtype=np.int32)
+    n = dll.srec_collate(0, seqs.ctypes.data, offs.ctypes.data, 2, 1, None, out.ctypes.data, out.size, info.ctypes.data, 40,
+                         ctypes.addressof(nf))
+    assert n > 32 and nf.value > 0 and out[0] == 2                      # header slot 0 = B
+    small = dll.srec_collate(0, seqs.ctypes.data, offs.ctypes.data, 2, 1, None, out.ctypes.data, 8, info.ctypes.data, 40,
+                             ctypes.addressof(nf))
+    assert small == -n
+    bad = np.array([0, 3, 3], dtype=np.int64)                           # second session empty
+    assert dll.srec_collate(0, seqs.ctypes.data, bad.ctypes.data, 2, 1, None, out.ctypes.data, out.size, info.ctypes.data,
+                            40, ctypes.addressof(nf)) == 0
+
+
 def test_product_ops_refuse_cpu_tensors():
     ops = pkg('ops')
     x = torch.randn(4, 8)

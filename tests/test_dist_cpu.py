@@ -322,3 +322,176 @@ def test_sharded_softmax_mixture_and_logprobs_match_single_device(cosine):
         logp = torch.tensor(logp)
         assert logp.shape == ref_logp.shape and torch.allclose(logp, ref_logp, rtol=1e-5, atol=1e-5)
         assert torch.allclose(torch.tensor(logp_dp), ref_logp[rank * n:(rank + 1) * n], rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------- partial batches, gradient bucket, launcher
+def _partial_worker(rank, world, port, q):
+    """rank 1's batch has dead (capacity-padding) sessions: label -1, left out of the global mean"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        D = pkg('dist')
+        table, per_rank = _make(world)
+        b = per_rank[rank]
+        labels = b['labels'].clone()
+        if rank == 1:
+            labels[-2:] = -1
+        model = FakeModel(table)
+        vp = D.VocabParallel(model, local=TorchLocal())
+        shard = model._table()
+        vp.labels_hint = labels
+        rows = vp.lookup(shard, b['idx'].int(), _uniq(b['idx']))
+        sr = rows[b['pick']] @ b['sr_w']
+        loss = vp.loss(sr, shard, None, labels, 1.0)
+        loss.backward()
+        q.put((rank, loss.item(), vp.lo, vp.hi, vp.dE[:vp.n_live].clone().numpy().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_loss_ignores_capacity_padding_of_a_partial_batch():
+    """the tail batch of an epoch: ranks hold different live counts inside equal padded layouts; the loss is the mean over
+    the live sessions of the GLOBAL batch and padded sessions contribute no gradient (train.py:94-101 on one device)"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partial_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table, per_rank = _make(world)
+    W = table.clone().requires_grad_()
+    srs, labs = [], []
+    for r, b in enumerate(per_rank):
+        keep = slice(None) if r == 0 else slice(0, b['labels'].numel() - 2)
+        srs.append((W[b['idx']][b['pick']] @ b['sr_w'])[keep])
+        labs.append(b['labels'][keep])
+    ref = torch.nn.functional.cross_entropy(torch.cat(srs) @ W.t(), torch.cat(labs))
+    ref.backward()
+    for rank, loss, lo, hi, dE in res:
+        assert abs(loss - ref.item()) < 1e-5 * max(1.0, abs(ref.item())), (loss, ref.item())
+        dE = torch.tensor(dE)
+        assert torch.allclose(dE, W.grad[lo:hi], rtol=1e-4, atol=1e-6), (rank, (dE - W.grad[lo:hi]).abs().max())
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        D = pkg('dist')
+        table, _ = _make(world)
+        vp = D.VocabParallel(FakeModel(table), local=TorchLocal())
+        ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(4)),
+              torch.nn.Parameter(torch.zeros(5))]
+        # p0: gradient on both ranks; p1: only on rank 0; p2: only on rank 1; p3: on neither (never enters the bucket)
+        ps[0].grad = torch.full((3,), 1.0 + rank)
+        if rank == 0:
+            ps[1].grad = torch.full((2, 2), 10.0)
+        else:
+            ps[2].grad = torch.full((4,), 100.0)
+
+        class Opt:
+            grad_override = None
+        opt = Opt()
+        vp.sync_replicated_grads(ps, opt)
+        got = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps) if id(p) in opt.grad_override}
+        # second step: the pattern flips (rank 0 now lacks p0) - same bucket, still consistent
+        ps[0].grad = None if rank == 0 else torch.full((3,), 7.0)
+        vp.sync_replicated_grads(ps, opt)
+        got2 = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps) if id(p) in opt.grad_override}
+        # a parameter outside the agreed bucket that suddenly has a gradient must fail loudly, not be dropped
+        ps[3].grad = torch.ones(5)
+        try:
+            vp.sync_replicated_grads(ps, opt)
+            late = False
+        except RuntimeError:
+            late = True
+        q.put((rank, {k: v.tolist() for k, v in got.items()}, {k: v.tolist() for k, v in got2.items()}, late))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicated_gradient_bucket_is_rank_independent():
+    """ranks hold gradients for different parameter subsets (MSHGNN instantiates only the GAT modules of relations with
+    live edges in ITS batch): the flat bucket must have one layout everywhere, missing gradients contributing zeros"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, got2, late in res:
+        assert sorted(got) == [0, 1, 2], got
+        assert got[0] == [3.0] * 3 and got[1] == [[10.0, 10.0]] * 2 and got[2] == [100.0] * 4
+        assert got2[0] == [7.0] * 3 and got2[1] == ([[10.0, 10.0]] * 2 if True else None)
+        assert late
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must spawn two ranks itself (the flag used to
+    be parsed and ignored).  --launch-only stops after the process group is up (gloo on a box without GPUs)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-only'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 2 and rec['ranks_seen'] == 2 and rec['world_size'] == 2, rec
+
+
+def test_rank_slice_sampler_partitions_the_reference_batches():
+    ds = pkg('dataset')
+    from torch.utils.data import SequentialSampler
+    n, bs = 23, 8
+    for w in (1, 2, 3, 8):
+        per_rank = [list(ds.RankSliceBatchSampler(SequentialSampler(range(n)), bs, r, w)) for r in range(w)]
+        nb = (n + bs - 1) // bs
+        assert all(len(x) == nb for x in per_rank)
+        for b in range(nb):
+            ref = list(range(b * bs, min(n, (b + 1) * bs)))
+            live = [i for r in range(w) for i in per_rank[r][b] if i >= 0]
+            assert live == ref, (w, b, live, ref)               # contiguous slices in rank order = the reference batch
+            for r in range(w):
+                assert len(per_rank[r][b]) >= 1                  # every rank takes part in every step
+                assert len(per_rank[r][b]) <= (bs + w - 1) // w
+                assert all((-i - 1) in ref for i in per_rank[r][b] if i < 0)
+    # a filler index returns the same prefix with label -1
+    import numpy as np
+    sessions = np.empty(2, dtype=object)
+    sessions[:] = [[1, 2, 3], [4, 5]]
+    data = ds.AugmentedDataset(sessions)
+    seq, lab = data[-2 - 1]
+    seq0, _ = data[2]
+    assert lab == -1 and list(seq) == list(seq0)
+
+
+def test_estimate_caps_for_rank_slices_bounds_every_slice():
+    ds, col = pkg('dataset'), pkg('collate')
+    import numpy as np
+    rng = np.random.default_rng(3)
+    sessions = np.empty(40, dtype=object)
+    sessions[:] = [rng.integers(0, 50, size=int(rng.integers(2, 15))).tolist() for _ in range(40)]
+    data = ds.AugmentedDataset(sessions)
+    gb, w = 16, 4
+    caps = col.estimate_caps(data, (gb + w - 1) // w, headroom=1.0, slices=(gb, w))
+    lens = data.index[:, 1]
+    from torch.utils.data import SequentialSampler
+    for r in range(w):
+        for sl in ds.RankSliceBatchSampler(SequentialSampler(data), gb, r, w):
+            clicks = sum(int(lens[i if i >= 0 else -i - 1]) for i in sl)
+            assert clicks <= caps['N'] and len(sl) <= caps['B']
