@@ -329,16 +329,22 @@ class GATConv(nn.Module):
         self.bias = nn.Parameter(th.empty(num_heads * out_feats))
         assert in_feats == out_feats                      # Identity residual only
 
-    def forward(self, src, dst, h_src_in, h_dst_in):
+    def forward(self, src, dst, h_src_in, h_dst_in, masks=None):
+        """masks (tests only): (feature multipliers of the source rows, of the destination rows, attention multipliers
+        [E, H]) applied INSTEAD of the module's own random dropout draws - lets a test replay the product's masks"""
         H, D = self._num_heads, self._out_feats
-        h_src = self.feat_drop(h_src_in)
-        h_dst = self.feat_drop(h_dst_in)
+        if masks is not None:
+            h_src, h_dst = h_src_in * masks[0], h_dst_in * masks[1]
+        else:
+            h_src = self.feat_drop(h_src_in)
+            h_dst = self.feat_drop(h_dst_in)
         feat_src = self.fc(h_src).view(-1, H, D)
         feat_dst = self.fc(h_dst).view(-1, H, D)
         el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
         er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
         e = self.leaky_relu(el[src] + er[dst])
-        a = self.attn_drop(edge_softmax(dst, e, h_dst.shape[0]))
+        a = edge_softmax(dst, e, h_dst.shape[0])
+        a = a * masks[2].view(-1, H, 1) if masks is not None else self.attn_drop(a)
         rst = th.zeros(h_dst.shape[0], H, D, dtype=feat_src.dtype).index_add_(0, dst, feat_src[src] * a)
         rst = rst + h_dst.view(h_dst.shape[0], -1, D)     # Identity residual broadcast over heads
         rst = rst + self.bias.view(1, -1, D)
@@ -353,7 +359,8 @@ class HeteroConv(nn.Module):
         super().__init__()
         self.mods = nn.ModuleDict(mods)
 
-    def forward(self, rels, feat, reverse=False):
+    def forward(self, rels, feat, reverse=False, masks=None):
+        """masks (tests only): {'feat': {node type: [N, D]}, 'attn': {relation key: [E, H]}} replayed dropout masks"""
         outs = {}
         for key in sorted(rels.keys(), key=lambda t: (('s%d' % t[0]), t[1], ('s%d' % t[2]))) if not reverse else \
                 sorted(rels.keys(), key=lambda t: (('s%d' % t[2]), t[1], ('s%d' % t[0]))):
@@ -362,10 +369,12 @@ class HeteroConv(nn.Module):
             if len(r['src']) == 0:
                 continue
             if reverse:
-                out = self.mods[et](r['dst'], r['src'], feat[d], feat[s])
+                mk = None if masks is None else (masks['feat'][d], masks['feat'][s], masks['attn'][key])
+                out = self.mods[et](r['dst'], r['src'], feat[d], feat[s], mk)
                 outs.setdefault(s, []).append(out)
             else:
-                out = self.mods[et](r['src'], r['dst'], feat[s], feat[d])
+                mk = None if masks is None else (masks['feat'][s], masks['feat'][d], masks['attn'][key])
+                out = self.mods[et](r['src'], r['dst'], feat[s], feat[d], mk)
                 outs.setdefault(d, []).append(out)
         return {k: th.stack(v, 0).sum(0) for k, v in outs.items()}
 
@@ -411,9 +420,9 @@ class MSHGNN(nn.Module):
         self.linq = nn.Linear(output_dim, output_dim)
         self.link = nn.Linear(output_dim, output_dim, bias=False)
 
-    def forward(self, g, feat):
-        h1 = self.conv1(g['rel'], feat)
-        h2 = self.conv2(g['rel'], feat, reverse=True)
+    def forward(self, g, feat, masks=None):
+        h1 = self.conv1(g['rel'], feat, masks=None if masks is None else masks['conv1'])
+        h2 = self.conv2(g['rel'], feat, reverse=True, masks=None if masks is None else masks['conv2'])
         h = {}
         for k in range(1, self.order + 1):
             hl = h1.get(k, th.zeros(1, self.output_dim))
@@ -492,11 +501,15 @@ class MSGIFSR(nn.Module):
         for w in self.parameters():
             w.data.uniform_(-stdv, stdv)
 
-    def session_repr(self, mg):
+    def session_repr(self, mg, masks=None):
+        """masks (tests only): {'rows': {k: multipliers shaped like embeddings(iid_k)}, 'layers': [MSHGNN masks]}: dropout
+        multipliers replayed from the product instead of this module's own random draws"""
         K = self.order
         feats = {}
         for k in range(1, K + 1):
-            feat = self.expander(self.feat_drop(self.embeddings(mg['iid'][k])))
+            rows = self.embeddings(mg['iid'][k])
+            rows = rows * masks['rows'][k] if masks is not None else self.feat_drop(rows)
+            feat = self.expander(rows)
             if th.isnan(feat).any():
                 feat = feat.masked_fill(feat != feat, 0)
             if self.norm:
@@ -505,8 +518,8 @@ class MSGIFSR(nn.Module):
                 feat = feat.unsqueeze(0)
             feats[k] = feat
         h = feats
-        for layer in self.layers:
-            h = layer(mg, h)
+        for li, layer in enumerate(self.layers):
+            h = layer(mg, h, None if masks is None else masks['layers'][li])
         last = []
         for k in range(1, K + 1):
             if self.norm:
@@ -520,8 +533,8 @@ class MSGIFSR(nn.Module):
             sr = F.normalize(sr, dim=-1)
         return sr                                          # (B, K, d)
 
-    def forward(self, mg):
-        sr = self.session_repr(mg)
+    def forward(self, mg, masks=None):
+        sr = self.session_repr(mg, masks)
         target = self.embeddings(self.indices)
         if self.norm:
             target = F.normalize(target, dim=-1)

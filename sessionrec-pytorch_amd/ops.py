@@ -1317,6 +1317,9 @@ def _inst_counts(plan, NT, dev):
     return cnt
 
 
+DROP_TAP = None      # tests: set to a list to receive {'ms': [2, NT, D], 'mk': [per instance (E*H,)]} of every dropout layer call
+
+
 class HGATLayer(torch.autograd.Function):
     """out = MSHGNN(x): all relation instances of conv1 / conv2 in one batched pass (csrc/hgat.hip) around the fc
     GEMMs.  params = (fc.weight, attn_l, attn_r, bias) per module, in plan.modules order.
@@ -1352,6 +1355,8 @@ class HGATLayer(torch.autograd.Function):
                 lib.srec_mask_scale(ptr(ua), ua.numel(), float(pa), ptr(allm), stream())
                 mk = list(torch.split(allm, sizes))
             dstate = (xc, xres, rm, mk, ms)
+            if DROP_TAP is not None:
+                DROP_TAP.append(dict(ms=ms.clone(), mk=[m.clone() for m in mk] if mk is not None else None))
         xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
         grouped = PRECISION['matmul'] == 'bf16' and D % 8 == 0 and _ld(x) == D and nm <= 8
         # bf16 GEMM path: the projections (and their gradients) are STORED as bf16 too - every pass over them is HBM bound
