@@ -174,16 +174,60 @@ def reducer_cases(sets):
                      oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), 3), smp, full=False)
 
 
+def srgnn_layer_cases(sets):
+    """SRGNNLayer.forward called DIRECTLY on the reference class (srgnn.py:11-51, niser.py:11-49 is the same code): the
+    model-level fixtures never see its output (it is dead in SRGNN.forward, srgnn.py:135-142), so the layer gets its own
+    fixture - input features, output, gradients wrt the features and every parameter for a fixed upstream gradient."""
+    from src.models.srgnn import SRGNNLayer as RLayer
+    from src.models.niser import SRGNNLayer as RLayerN
+    for sname, smp in sets.items():
+        rin, _ = rcollate.collate_fn_factory(rcollate.seq_to_session_graph)(smp)
+        oin, _ = oc.collate_fn_factory(oc.seq_to_session_graph)(smp)
+        cmp_graph(rin[0], oin[0], 'srgnn_layer_' + sname)
+        og = om.to_torch(oin[0])
+        th.manual_seed(123)
+        rl, rn, ol = RLayer(D, D), RLayerN(D, D), om.SRGNNLayer(D, D)
+        rn.load_state_dict(rl.state_dict())
+        ol.load_state_dict(rl.state_dict(), strict=True)
+        N = int(rin[0].num_nodes())
+        gen = th.Generator().manual_seed(7)
+        feat = th.randn(N, D, generator=gen) * 0.5
+        gout = th.randn(N, D, generator=gen)
+        res = []
+        for layer, g in ((rl, rin[0]), (rn, rin[0]), (ol, og)):
+            x = feat.clone().requires_grad_()
+            out = layer(g, x)
+            out.backward(gout)
+            res.append((out.detach(), x.grad.detach(), {k: p.grad.detach().clone() for k, p in layer.named_parameters()}))
+            layer.zero_grad()
+        (ro, rdx, rgp), (no, ndx, ngp), (oo, odx, ogp) = res
+        assert th.equal(ro, no) and th.equal(rdx, ndx), 'srgnn.py and niser.py layers differ'
+        assert th.allclose(ro, oo, **TOL) and th.allclose(rdx, odx, rtol=1e-4, atol=1e-7), (sname, (ro - oo).abs().max())
+        for k in rgp:
+            assert th.allclose(rgp[k], ogp[k], rtol=1e-4, atol=1e-6), (sname, k, (rgp[k] - ogp[k]).abs().max())
+        out = dict(seqs=np.array([','.join(map(str, s_)) for s_, _ in smp]), labels=np.array([l for _, l in smp]),
+                   feat=feat.numpy(), gout=gout.numpy(), out=ro.numpy(), dfeat=rdx.numpy())
+        for k, v in rl.state_dict().items():
+            out['init/' + k] = v.numpy()
+        for k, v in rgp.items():
+            out['grad/' + k] = v.numpy()
+        np.savez_compressed(os.path.join(OUT, 'srgnn_layer_%s.npz' % sname), **out)
+        print('%-28s ok  |out|=%.5f' % ('srgnn_layer_' + sname, float(ro.abs().mean())))
+
+
 def main():
     samples = first_samples(32)
     edge = EDGE_CASES
     sets = {'s32': samples, 'edge': edge}
+    if '--only-srgnn-layer' in sys.argv:
+        return srgnn_layer_cases(sets)
     if '--only-extra' in sys.argv:
         return extra_cases(sets)
     if '--only-reducers' in sys.argv:
         return reducer_cases(sets)
     extra_cases(sets)
     reducer_cases(sets)
+    srgnn_layer_cases(sets)
     for sname, smp in sets.items():
         full = sname == 's32'
         V = 3429 if full else 300          # edge-case ids are < 300: keeps those fixtures tiny

@@ -13,7 +13,8 @@ from util import GOLDEN, ROOT, close, load_golden, pkg
 from oracle import collate_ref as oc
 from oracle import models_ref as om
 
-ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz') and f != 'srgnn_evaluate.npz')
+ALL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz') and f != 'srgnn_evaluate.npz'
+                   and not f.startswith('srgnn_layer_'))       # whole-model fixtures (the layer fixtures have their own test)
 
 
 def _oracle(name, V):
@@ -393,3 +394,22 @@ def test_session_store_equals_text_path(tmp_path):
     (ba,), la = fn([(list(s), int(l)) for s, l in ia])
     (bb,), lb = fn([(s, l) for s, l in ib])
     assert torch.equal(ba.buf, bb.buf) and torch.equal(la, lb)
+
+
+# ---------------------------------------------------------------------------------------- SRGNNLayer, reference-pinned
+@pytest.mark.parametrize('name', ['srgnn_layer_s32', 'srgnn_layer_edge'])
+def test_oracle_srgnn_layer_reproduces_the_reference_layer(name):
+    """fixture = the reference's SRGNNLayer.forward called directly (srgnn.py:11-51; make_golden.py
+    srgnn_layer_cases): the model-level fixtures cannot see this layer (its output is dead in SRGNN.forward)."""
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    samples = [([int(x) for x in s.split(',')], int(l)) for s, l in zip(z['seqs'].tolist(), z['labels'].tolist())]
+    layer = om.SRGNNLayer(32, 32)
+    layer.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('init/')})
+    (g,), _ = oc.collate_fn_factory(oc.seq_to_session_graph)(samples)
+    x = torch.from_numpy(z['feat']).requires_grad_()
+    out = layer(om.to_torch(g), x)
+    out.backward(torch.from_numpy(z['gout']))
+    close(out, z['out'], what='layer out')
+    close(x.grad, z['dfeat'], what='layer d feat', atol=1e-6)
+    for k, p in layer.named_parameters():
+        close(p.grad, z['grad/' + k], what='layer grad ' + k, atol=2e-6)

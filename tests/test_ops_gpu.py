@@ -373,6 +373,29 @@ def test_srgnn_layer_matches_oracle(dev):
         close(p1.grad, p2.grad, what='srgnn layer ' + n1, atol=5e-5)
 
 
+@pytest.mark.parametrize('name', ['srgnn_layer_s32', 'srgnn_layer_edge'])
+def test_srgnn_layer_matches_the_reference_layer_fixture(dev, name):
+    """row a3: gnn.srgnn_layer against the fixture produced by calling the REFERENCE's SRGNNLayer.forward directly
+    (srgnn.py:31-51 / niser.py:29-49; tests/golden/make_golden.py srgnn_layer_cases) - not only against the oracle."""
+    import os
+    col = importlib.import_module('sessionrec-pytorch_amd.collate')
+    gnn = importlib.import_module('sessionrec-pytorch_amd.gnn')
+    srg = importlib.import_module('sessionrec-pytorch_amd.srgnn')
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'), allow_pickle=False)
+    samples = [([int(x) for x in s.split(',')], int(l)) for s, l in zip(z['seqs'].tolist(), z['labels'].tolist())]
+    layer = srg.SRGNNLayer(32, 32)
+    layer.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('init/')})
+    layer = layer.to(dev)
+    (fb,), _ = col.collate_fn_factory(col.seq_to_session_graph)(samples)
+    x = torch.from_numpy(z['feat']).to(dev).requires_grad_()
+    out = gnn.srgnn_layer(layer, fb.to(dev), x)
+    out.backward(torch.from_numpy(z['gout']).to(dev))
+    close(out, torch.from_numpy(z['out']), what='layer out')
+    close(x.grad, torch.from_numpy(z['dfeat']), what='layer d feat', atol=2e-5)
+    for k, p in layer.named_parameters():
+        close(p.grad, torch.from_numpy(z['grad/' + k]), what='layer grad ' + k, atol=5e-5)
+
+
 def test_batch_norm_prelu(dev):
     ops = _ops()
     torch.manual_seed(9)
