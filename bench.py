@@ -349,10 +349,16 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     ap.add_argument('--shard', action='store_true', help='debug: row-sharded path + RCCL calls on a 1-rank communicator (set SREC_FORCE_COLLECTIVES=1)')
     ap.add_argument('--kernel-only', action='store_true', help='only launch the scoring/CE kernels (PMC collection target)')
+    ap.add_argument('--step-only', action='store_true',
+                    help='profiling target: only the timed training steps (no dominant-kernel timing loop, no CPU baseline, no '
+                         'fp32 side run), so every kernel row of a rocprofv3 --stats summary belongs to the step')
     ap.add_argument('--launch-only', action='store_true',
                     help='initialise the process group over --gpus ranks, print what was seen, exit (launcher self-test; '
                          'gloo on a box without GPUs)')
     args = ap.parse_args()
+    if args.step_only:
+        args.no_cpu_baseline = args.no_fp32 = True
+        args.repeats = 1
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -472,7 +478,10 @@ def main():
         del m32, s32, step32
         ops.set_precision(args.precision)
 
-    if rank == 0:
+    if rank == 0 and args.step_only:
+        print(json.dumps(dict(step_only=True, ms_per_step=dt / args.steps * 1e3, value=Bg * args.steps / dt, launches=nodes,
+                              final_loss=final_loss)), flush=True)
+    elif rank == 0:
         Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
         kt = time_dominant_kernel(model, Bg, Vk, d, dev)
         kms = {k: v * 1e3 for k, v in kt.items() if k != 'bf16'}

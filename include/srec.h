@@ -274,6 +274,23 @@ int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int 
  * reduction-major (weight gradient; dyn clamps the reduction).  dyn clamps the output rows in modes 0 / 1. */
 int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
 
+/* bf16-in-HBM grouped GEMMs (gemm16.hip): the GAT fc projections and their backward (gatconv.py:166-175,282-283) with every
+ * operand already stored as bf16 - LDS-DMA staging, no conversion pass.  desc: host srec_gemm16_group (srec_hg.h, up to 16
+ * problems per launch).
+ *   srec_gemm16_nt: C_p [M, N] (+)= sum_s A_ps [M, K] B_ps [N, K]^T; K % 32 == 0, lda / ldb % 8 == 0; c16 = bf16 output;
+ *                   dyn clamps the output rows (rows past it: zeros when beta == 0 or c16).
+ *   srec_gemm16_tn: C_p [M, N] = beta C_p + sum_s sum_{m < min(K, *dyn)} A_ps [m, M] B_ps [m, N]  (weight gradients: the
+ *                   reduction runs over rows; both operands row-major as stored, M / N % 8 == 0), fp32 output.
+ *   srec_rows_bf16: dst16 [n, d] = bf16(src [n, d]), zero rows past *dyn.
+ *   srec_weights_bf16: n <= 8 matrices W_i [R_i, C_i] fp32 -> bf16 copy and transposed bf16 copy [C_i, R_i] in one launch;
+ *                   W / W16 / WT16 are HOST arrays of n device pointers (WT16 entries may be NULL), R / Cc HOST int arrays. */
+int srec_gemm16_nt(const void* desc, void* stream);
+int srec_gemm16_tn(const void* desc, void* stream);
+int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, int d, void* dst16, void* stream);
+/* out [C, n] = sum_r part [C, R, n] in fixed order (the row-split weight-gradient products of one module), n % 4 == 0 */
+int srec_sum_slabs(const float* part, int C, int R, long n, float* out, void* stream);
+int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, void* stream);
+
 /* ---- evaluation: K best items per session without the (B, V) score matrix (topk.hip) -----------------------------
  * Replaces `logits = model(...); logits.topk(20)` of train.py:36-55 for models whose score is one soft-max
  * (ranking by z[b,v] = cs[v] * <sr_b, E_v>): out_val [B,K] descending, out_idx [B,K] int32 item ids, ties towards

@@ -83,4 +83,19 @@ typedef struct {
     const int* dyn[SREC_GG_MAXP];
 } srec_gemm_group;
 
+
+/* problem table of srec_gemm16_nt / srec_gemm16_tn (srec.h): up to 16 problems, every operand bf16 in device memory */
+#define SREC_G16_MAXP 16
+#define SREC_G16_MAXS 4
+typedef struct {
+    int np, lda, ldb, ldc;
+    float beta;
+    int c16;                       /* C outputs are bf16 (nt only) */
+    int M[SREC_G16_MAXP], N[SREC_G16_MAXP], K[SREC_G16_MAXP], nseg[SREC_G16_MAXP];
+    const void* A[SREC_G16_MAXP][SREC_G16_MAXS];
+    const void* B[SREC_G16_MAXP][SREC_G16_MAXS];
+    void* C[SREC_G16_MAXP];
+    const int* dyn[SREC_G16_MAXP];
+} srec_gemm16_group;
+
 #endif

@@ -1,0 +1,539 @@
+// bf16-in-HBM grouped GEMMs for the GAT projections of the MSHGNN layer (gatconv.py:166-175,282-283 and their
+// backward) - the FLOP-heavy part of the MSGIFSR encoder (~48 GFLOP per step at the C3 shapes).
+//
+// gemm_group_bf16.hip rounds fp32 operands to bf16 WHILE staging them through registers (global -> VGPR -> cvt ->
+// ds_write), one barrier per 32-deep k-step: it measured 3-5x above its traffic floor.  Here every operand already
+// lives in HBM as bf16 (activations are written as bf16 by their producers; the small fc weights get a bf16 copy and a
+// transposed bf16 copy once per step, srec_weights_bf16), so staging is pure LDS-DMA:
+//   * global_load_lds_dwordx4 (1 KiB per wave instruction) into a lane-linear LDS image, no staging registers, no
+//     ds_write pass; bank conflicts of the ds_read_b128 fragment reads are removed by XOR-swizzling the SOURCE piece of
+//     every 16-B slot (piece p of tile row r sits in slot p ^ ((r >> 1) & 7): with 128-B rows the 16 lanes of each
+//     ds_read_b128 lane group then hit 16 distinct 16-B slots);
+//   * 64-deep k-steps (4 MFMA k-steps per barrier), double buffered, ONE barrier per k-step: wait own DMA, barrier,
+//     issue the next stage, compute;
+//   * 4 waves (2 x 2) of v_mfma_f32_32x32x16_bf16, 128 x 128 (or 64 x 128) output tiles, fp32 accumulation.
+// Two kernels:
+//   nt16  C[M, N] (+)= sum_s A_s[M, K] B_s[N, K]^T      both operands k-contiguous.  Forward projections (B = W,
+//         bf16 output: the accumulator is kept TRANSPOSED - lane = output row, registers = 4 consecutive columns - so
+//         the 63 MB of projections leave as 8-byte packed stores) and backward-data (B = W^T copy, fp32 output, the
+//         sum over the modules that project a node type is the segment loop: no split-K, no beta chains).
+//   tn16  C[N1, N2] = sum over rows m of A[m, N1] B[m, N2]   (weight gradient dW = dP^T x; the reduction runs over the
+//         node rows, clamped by the live count).  Both operands are read ROW-major as they are - the 63 MB dP is never
+//         transposed in memory; the MFMA fragments (8 consecutive reduction rows of one column) are gathered from the
+//         row-major LDS tile by eight 16-bit LDS reads (d16 / d16_hi pairs fill the four fragment registers without
+//         a packing pass): consecutive lanes read consecutive 2-byte columns, conflict free.
+#include "common.h"
+#include "../../include/srec_hg.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short2_t __attribute__((ext_vector_type(2)));
+constexpr int G16_MAXP = 16, G16_MAXS = 4;
+
+struct G16Args {
+    const unsigned short* A[G16_MAXP][G16_MAXS];
+    const unsigned short* B[G16_MAXP][G16_MAXS];
+    void* C[G16_MAXP];
+    const int* dyn[G16_MAXP];
+    int M[G16_MAXP], N[G16_MAXP], K[G16_MAXP], nseg[G16_MAXP], start[G16_MAXP + 1];
+    int np, lda, ldb, ldc;
+    float beta;
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// one 1-KiB LDS-DMA: lane l copies 16 B from sbase + voff[l] to LDS address lds_dst + 16 l (wave-uniform destination
+// in M0).  Inline asm: hipcc would otherwise drain every outstanding DMA (vmcnt(0)) at the next LDS read it cannot prove
+// disjoint; the only wait needed is the explicit one in front of the barrier that publishes the stage.
+__device__ __forceinline__ void glds16(const unsigned short* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    const unsigned dst_s = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);   // wave-uniform by construction: pin it to an SGPR
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst_s) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// wait until at most `ahead` later stages (IPS LDS-DMA instructions each, per wave) are still in flight
+template <int IPS>
+__device__ __forceinline__ void wait_stage(int ahead) {
+    if (ahead >= 2) wait_vm<2 * IPS>();
+    else if (ahead == 1) wait_vm<IPS>();
+    else wait_vm<0>();
+}
+
+constexpr int NS = 4, PD = 3;        // LDS ring: 4 stages, 3 stages of LDS-DMA in flight ahead of the MFMAs
+
+// -------------------------------------------------------------------------------------------------- nt16
+// C16: the accumulator is D^T (rows of D <-> B rows = output columns, lane <-> A row = output row): the bf16 output
+// then leaves as 4 consecutive columns (8 B) per lane and register quad.
+// k-steps of 32 (64-B tile rows, 4 pieces; one DMA instruction = 16 rows): the reductions here are short (K = D = 256
+// for the forward) or streamed from HBM (K = H D for backward-data), so the kernel is bound by load latency, not by
+// barriers - a 4-stage ring keeps 3 stages in flight per workgroup, and 16 KB stages leave room for 2-3 workgroups
+// per CU.  Piece p of tile row r sits in slot p ^ ((r >> 2) & 3): the 16 lanes of every ds_read_b128 group hit 16
+// distinct 16-B slots.
+template <int TM, int TN, bool C16>
+__global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
+    constexpr int BK = 32;
+    constexpr int IM = TM / 64, IN = TN / 64;            // 32x32 accumulators per wave and dimension (2 x 2 waves)
+    constexpr int STG = (TM + TN) * BK;                  // bf16 elements per stage
+    constexpr int NIA = TM / 16, NI = (TM + TN) / 16;    // DMA instructions per stage: A, total
+    constexpr int IPS = NI / 4;                          // ... per wave
+    static_assert(NI % 4 == 0, "every wave must issue the same number of DMA instructions per stage");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+    const int bid = (int)blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < G16_MAXP; ++i)
+        if (i < g.np && bid >= g.start[i]) p = i;
+    const int M = g.M[p], N = g.N[p], K = g.K[p];
+    const int tn = (N + TN - 1) / TN, tile = bid - g.start[p];
+    const int m0 = (tile / tn) * TM, n0 = (tile % tn) * TN;
+    const int Ml = dyn_count(g.dyn[p], M);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    float* __restrict__ C = static_cast<float*>(g.C[p]);
+    unsigned short* __restrict__ C16p = static_cast<unsigned short*>(g.C[p]);
+    if (m0 >= Ml) {                                      // tile of capacity padding: zero rows when overwriting
+        if (C16 || g.beta == 0.f)
+            for (int i = tid; i < TM * TN / 4; i += 256) {
+                const int r = m0 + (i * 4) / TN, c = n0 + (i * 4) % TN;
+                if (r < M && c + 3 < N) {
+                    if (C16) *reinterpret_cast<uint2*>(C16p + (size_t)r * g.ldc + c) = make_uint2(0u, 0u);
+                    else *reinterpret_cast<float4*>(C + (size_t)r * g.ldc + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (r < M) {
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < N) { if (C16) C16p[(size_t)r * g.ldc + c + e] = 0; else C[(size_t)r * g.ldc + c + e] = 0.f; }
+                }
+            }
+        return;
+    }
+
+    f32x16 acc[IM][IN];
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < IN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK, total = nk * g.nseg[p];
+    const unsigned lds0 = lds_addr(smem);
+    // DMA instruction i covers tile rows 16 i .. 16 i + 15 of the concatenated (A rows, then B rows) stage; lane -> (row
+    // l >> 2, slot l & 3).  Rows past an operand are clamped to its last row (their products land in rows / columns the
+    // epilogue does not store).
+    const int rl = lane >> 2, sl = lane & 3;
+    auto stage = [&](int it) {
+        const int s = it / nk, k0 = (it - s * nk) * BK;
+        const unsigned short* Ab = g.A[p][s] + (size_t)m0 * g.lda + k0;
+        const unsigned short* Bb = g.B[p][s] + (size_t)n0 * g.ldb + k0;
+        const unsigned dst = lds0 + (unsigned)((it % NS) * STG) * 2u;
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+            const int i = ii * 4 + wave;                 // wave-uniform
+            const int r = 16 * (i < NIA ? i : i - NIA) + rl;
+            const unsigned pc = (unsigned)((sl ^ ((r >> 2) & 3)) * 8);
+            if (i < NIA) glds16(Ab, ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.lda + pc) * 2u, dst + (unsigned)i * 1024u);
+            else glds16(Bb, ((unsigned)min(r, N - 1 - n0) * (unsigned)g.ldb + pc) * 2u, dst + (unsigned)i * 1024u);
+        }
+    };
+
+    for (int s = 0; s < PD && s < total; ++s) stage(s);
+    for (int it = 0; it < total; ++it) {
+        wait_stage<IPS>(min(total - it - 1, PD - 1));          // this wave's pieces of stage `it` have landed ...
+        __syncthreads();                                       // ... everyone's have; stage it - 1's buffer is free again
+        if (it + PD < total) stage(it + PD);
+        const unsigned short* As = smem + (it % NS) * STG;
+        const unsigned short* Bs = As + TM * BK;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[IM], b[IN];
+#pragma unroll
+            for (int i = 0; i < IM; ++i) {
+                const int r = wm * (TM / 2) + i * 32 + l31;
+                a[i] = *reinterpret_cast<const bf16x8*>(As + r * BK + (((2 * ks + half) ^ ((r >> 2) & 3)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < IN; ++j) {
+                const int r = wn * (TN / 2) + j * 32 + l31;
+                b[j] = *reinterpret_cast<const bf16x8*>(Bs + r * BK + (((2 * ks + half) ^ ((r >> 2) & 3)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int j = 0; j < IN; ++j)
+                    acc[i][j] = C16 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (C16) {
+        // acc[i][j] = D^T: lane <-> output row, register r <-> output column (r & 3) + 8 (r >> 2) + 4 half.  The 4 KB row
+        // stride of P makes per-lane stores 16-B fragments of 32 different rows per instruction (the forward measured
+        // bound by write transactions, not bytes): every wave transposes its tile through its own LDS patch (rows padded
+        // to 144 B: conflict-free 8-B writes) and stores 16 B per lane = 8 full 128-B row segments per instruction.
+        constexpr int WR = TM / 2, WC = TN / 2, LDP = WC + 8;         // wave tile, padded LDS row (bf16 elements)
+        __syncthreads();                                               // every wave is done with the ring buffers
+        unsigned short* patch = smem + wave * (WR * LDP);
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+#pragma unroll
+            for (int j = 0; j < IN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 v;
+                    v.x = srec_pack_bf16(acc[i][j][4 * q], acc[i][j][4 * q + 1]);
+                    v.y = srec_pack_bf16(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    *reinterpret_cast<uint2*>(patch + (i * 32 + l31) * LDP + j * 32 + 8 * q + 4 * half) = v;
+                }
+        constexpr int PPR = WC / 8;                                    // 16-B pieces per row
+#pragma unroll
+        for (int t = 0; t < WR * PPR / 64; ++t) {
+            const int idx = t * 64 + lane, rr = idx / PPR, pc = idx % PPR;
+            const int row = m0 + wm * WR + rr, col = n0 + wn * WC + pc * 8;
+            if (row >= M) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(patch + rr * LDP + pc * 8);
+            if (row >= Ml) v = make_uint4(0u, 0u, 0u, 0u);
+            if (col + 7 < N) {
+                *reinterpret_cast<uint4*>(C16p + (size_t)row * g.ldc + col) = v;
+            } else {
+                const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+                for (int k = 0; k < 8; ++k)
+                    if (col + k < N) C16p[(size_t)row * g.ldc + col + k] = e[k];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < IN; ++j) {
+            const int col = n0 + wn * (TN / 2) + j * 32 + l31;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M) {
+                    float* q = C + (size_t)row * g.ldc + col;
+                    if (row < Ml) *q = g.beta != 0.f ? acc[i][j][r] + g.beta * *q : acc[i][j][r];
+                    else if (g.beta == 0.f) *q = 0.f;
+                }
+            }
+        }
+}
+
+// -------------------------------------------------------------------------------------------------- tn16
+// C[N1, N2] = sum_{m < live} A[m, N1] B[m, N2]; tile 128 x 128, reduction staged 32 rows at a time through the same
+// 4-stage ring.  Both operand tiles sit in LDS ROW-major ([32 reduction rows][128 columns], 256-B rows, filled by
+// LDS-DMA); an MFMA operand fragment (8 consecutive reduction rows of ONE column per lane) is two ds_read_b64_tr_b16:
+// within a 16-lane group lane i supplies the address of (row i >> 2, 4 contiguous columns 4 (i & 3) ..) and receives
+// (rows 0..3, column i) - measured lane map, tools/probes/tr_probe.hip.  The four rows of a group are 256 B apart, i.e.
+// on the same banks: piece p of row r is stored in slot p ^ (4 (r & 3)), which moves them to the four 64-B quarters.
+__device__ __forceinline__ uint2 lds_tr16(unsigned addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
+    constexpr int T = 128, BR = 32;                      // output tile, reduction rows per stage
+    constexpr int STG = 2 * BR * T;                      // bf16 elements per stage (A tile + B tile)
+    constexpr int IPS = (2 * BR / 4) / 4;                // DMA instructions (4 rows each) per stage and wave
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int bid = (int)blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < G16_MAXP; ++i)
+        if (i < g.np && bid >= g.start[i]) p = i;
+    const int N1 = g.M[p], N2 = g.N[p];
+    const int tn = (N2 + T - 1) / T, tile = bid - g.start[p];
+    const int i0 = (tile / tn) * T, j0 = (tile % tn) * T;
+    const int Kr = dyn_count(g.dyn[p], g.K[p]);          // live reduction rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    float* __restrict__ C = static_cast<float*>(g.C[p]);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nst = (Kr + BR - 1) / BR;
+    const int total = nst * g.nseg[p];
+    const unsigned lds0 = lds_addr(smem);
+    // DMA instruction i (0..15): operand i >> 3, reduction rows 4 (i & 7) .. + 3; lane -> (row l >> 4, slot l & 15)
+    const int rl = lane >> 4, sl = lane & 15;
+    auto stage = [&](int it) {
+        const int s = it / nst, r0 = (it - s * nst) * BR;
+        const unsigned dst = lds0 + (unsigned)((it % NS) * STG) * 2u;
+        const int pc = sl ^ (4 * rl);                    // global piece of this lane's slot (row & 3 == rl)
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+            const int i = ii * 4 + wave;
+            const int gr = min(r0 + 4 * (i & 7) + rl, Kr - 1);
+            if (i < 8) glds16(g.A[p][s], ((unsigned)gr * (unsigned)g.lda + (unsigned)min(i0 + pc * 8, N1 - 8)) * 2u, dst + (unsigned)i * 1024u);
+            else glds16(g.B[p][s], ((unsigned)gr * (unsigned)g.ldb + (unsigned)min(j0 + pc * 8, N2 - 8)) * 2u, dst + (unsigned)i * 1024u);
+        }
+    };
+    // per-lane LDS byte offsets of the transposing reads: fragment f (32 columns) of an operand tile, reduction rows
+    // kb + 4 e + (i >> 2) with kb = 16 ks + 8 half, columns cbase + 16 ((lane >> 4) & 1) + 4 (i & 3), i = lane & 15
+    const int ti = lane & 15, tr = ti >> 2;
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (ti & 3);
+    auto tr_off = [&](int col, int row) {                // byte offset of (row, col..col+3) inside an operand tile
+        return (unsigned)(row * 256 + ((((col >> 3) ^ (4 * (row & 3))) << 4) | ((col & 7) << 1)));
+    };
+
+    for (int s = 0; s < PD && s < total; ++s) stage(s);
+    for (int it = 0; it < total; ++it) {
+        wait_stage<IPS>(min(total - it - 1, PD - 1));
+        __syncthreads();
+        if (it + PD < total) stage(it + PD);
+        const int r0 = (it % nst) * BR;
+        const unsigned abase = lds0 + (unsigned)((it % NS) * STG) * 2u, bbase = abase + (unsigned)(BR * T) * 2u;
+        const bool tail = r0 + BR > Kr;                  // the last stage of a segment may hold clamped (repeated) rows
+#pragma unroll
+        for (int ks = 0; ks < BR / 16; ++ks) {
+            const int kb = ks * 16 + 8 * half;
+            uint2 ra[2][2], rb[2][2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    ra[f][e] = lds_tr16(abase + tr_off(wm * 64 + f * 32 + tcol, kb + 4 * e + tr));
+                    rb[f][e] = lds_tr16(bbase + tr_off(wn * 64 + f * 32 + tcol, kb + 4 * e + tr));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tail) {                                  // rows at or past the live count contribute nothing: zero the A side
+                const int nvalid = Kr - r0 - kb;         // this lane's element q of read e is row kb + 4 e + q
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int b0 = 4 * e;
+                        if (b0 + 0 >= nvalid) ra[f][e].x &= 0xffff0000u;
+                        if (b0 + 1 >= nvalid) ra[f][e].x &= 0x0000ffffu;
+                        if (b0 + 2 >= nvalid) ra[f][e].y &= 0xffff0000u;
+                        if (b0 + 3 >= nvalid) ra[f][e].y &= 0x0000ffffu;
+                    }
+            }
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = __builtin_bit_cast(bf16x8, make_uint4(ra[f][0].x, ra[f][0].y, ra[f][1].x, ra[f][1].y));
+                b[f] = __builtin_bit_cast(bf16x8, make_uint4(rb[f][0].x, rb[f][0].y, rb[f][1].x, rb[f][1].y));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j0 + wn * 64 + j * 32 + l31;
+            if (col >= N2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < N1) {
+                    float* q = C + (size_t)row * g.ldc + col;
+                    *q = g.beta != 0.f ? acc[i][j][r] + g.beta * *q : acc[i][j][r];
+                }
+            }
+        }
+}
+
+// -------------------------------------------------------------------------------------------------- operand copies
+// fp32 rows -> bf16 rows (zero past the live count): the activations a GEMM reads that no producer wrote as bf16
+__global__ void rows_bf16_kernel(const float* __restrict__ src, int ld, int n, const int* __restrict__ dyn, int d,
+                                 unsigned short* __restrict__ dst) {
+    const int nl = dyn_count(dyn, n);
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (long)n * d) return;
+    const int r = (int)(i / d), c = (int)(i % d);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nl) v = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+    uint2 o;
+    o.x = srec_pack_bf16(v.x, v.y); o.y = srec_pack_bf16(v.z, v.w);
+    *reinterpret_cast<uint2*>(dst + i) = o;
+}
+
+// fc weights of up to 8 modules: W [R, Cc] fp32 -> W16 [R, Cc] and WT16 [Cc, R] bf16 (64 x 64 tiles through LDS)
+struct WArgs {
+    const float* W[8];
+    unsigned short* W16[8];
+    unsigned short* WT16[8];
+    int R[8], Cc[8], start[9];
+    int n;
+};
+__global__ void weights_bf16_kernel(WArgs a) {
+    __shared__ unsigned short tile[64][66];
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.start[i]) t = i;
+    const int R = a.R[t], Cc = a.Cc[t];
+    const int tc = (Cc + 63) / 64, b = blockIdx.x - a.start[t];
+    const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const float* __restrict__ W = a.W[t];
+    for (int rr = y; rr < 64; rr += 4) {
+        const int r = r0 + rr, c = c0 + x;
+        unsigned short v = 0;
+        if (r < R && c < Cc) {
+            v = srec_f2bf(W[(size_t)r * Cc + c]);
+            a.W16[t][(size_t)r * Cc + c] = v;
+        }
+        tile[rr][x] = v;
+    }
+    __syncthreads();
+    if (a.WT16[t] != nullptr)
+        for (int cc = y; cc < 64; cc += 4) {
+            const int c = c0 + cc, r = r0 + x;
+            if (c < Cc && r < R) a.WT16[t][(size_t)c * R + r] = tile[x][cc];
+        }
+}
+
+// out[c][i] = sum_r part[c][r][i] (fixed order: deterministic), i < n (n % 4 == 0); grid.y = c
+__global__ void sum_slabs_kernel(const float* __restrict__ part, int R, long n, float* __restrict__ out) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float* pc = part + (size_t)blockIdx.y * R * n;
+    float4 s = *reinterpret_cast<const float4*>(pc + i);
+    for (int r = 1; r < R; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(pc + (size_t)r * n + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * n + i) = s;
+}
+
+int fill(G16Args& g, const void* desc_, int tm, int tn, bool tnmode, int& blocks) {
+    const srec_gemm16_group* d = (const srec_gemm16_group*)desc_;
+    if (d == nullptr || d->np <= 0 || d->np > G16_MAXP || (d->lda & 7) || (d->ldb & 7)) return SREC_BAD_ARG;
+    g.np = d->np; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.beta = d->beta;
+    blocks = 0;
+    for (int p = 0; p < d->np; ++p) {
+        if (d->nseg[p] <= 0 || d->nseg[p] > G16_MAXS || d->M[p] <= 0 || d->N[p] <= 0 || d->K[p] <= 0) return SREC_BAD_ARG;
+        if (!tnmode && (d->K[p] & 31)) return SREC_BAD_ARG;                 // 32-deep k-steps
+        if (tnmode && ((d->M[p] & 7) || (d->N[p] & 7) || d->M[p] < 8 || d->N[p] < 8)) return SREC_BAD_ARG;
+        g.M[p] = d->M[p]; g.N[p] = d->N[p]; g.K[p] = d->K[p]; g.nseg[p] = d->nseg[p]; g.C[p] = d->C[p]; g.dyn[p] = d->dyn[p];
+        for (int s = 0; s < d->nseg[p]; ++s) {
+            if (((uintptr_t)d->A[p][s] & 15) || ((uintptr_t)d->B[p][s] & 15)) return SREC_BAD_ARG;
+            g.A[p][s] = (const unsigned short*)d->A[p][s]; g.B[p][s] = (const unsigned short*)d->B[p][s];
+        }
+        g.start[p] = blocks;
+        blocks += cdiv(d->M[p], tm) * cdiv(d->N[p], tn);
+    }
+    g.start[d->np] = blocks;
+    return 0;
+}
+
+template <typename K>
+int optin(K kernel, int bytes, std::atomic<unsigned long long>& done) {
+    return bytes > 64 * 1024 ? srec_lds_optin((const void*)kernel, bytes, done) : 0;
+}
+
+}  // namespace
+
+// desc: host srec_gemm_group (srec_hg.h) with bf16 A and B.  C_p [M, N] (+)= sum_s A_ps [M, K] B_ps [N, K]^T; K % 32 == 0,
+// lda / ldb % 8 == 0, 16-B aligned bases; c16: bf16 output (beta ignored); dyn clamps the output rows.
+extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
+    const srec_gemm16_group* h = (const srec_gemm16_group*)desc_;
+    if (h == nullptr || h->np <= 0 || h->np > G16_MAXP) return SREC_BAD_ARG;
+    G16Args g{};
+    int blocks = 0;
+    // small-N problems (backward-data, N = D): 64-row tiles keep every CU busy
+    long t128 = 0;
+    for (int p = 0; p < h->np; ++p) t128 += (long)cdiv(h->M[p], 128) * cdiv(h->N[p], 128);
+    const int tm = t128 >= 384 ? 128 : 64;
+    if (int rc = fill(g, desc_, tm, 128, false, blocks)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)NS * (tm + 128) * 32 * 2;
+    if (h->c16) {
+        if (tm == 128) {
+            static std::atomic<unsigned long long> o{0};
+            if (int rc = optin(gemm16_nt_kernel<128, 128, true>, (int)lds, o)) return rc;
+            hipLaunchKernelGGL((gemm16_nt_kernel<128, 128, true>), dim3(blocks), dim3(256), lds, st, g);
+        } else {
+            hipLaunchKernelGGL((gemm16_nt_kernel<64, 128, true>), dim3(blocks), dim3(256), lds, st, g);
+        }
+    } else {
+        if (tm == 128) {
+            static std::atomic<unsigned long long> o{0};
+            if (int rc = optin(gemm16_nt_kernel<128, 128, false>, (int)lds, o)) return rc;
+            hipLaunchKernelGGL((gemm16_nt_kernel<128, 128, false>), dim3(blocks), dim3(256), lds, st, g);
+        } else {
+            hipLaunchKernelGGL((gemm16_nt_kernel<64, 128, false>), dim3(blocks), dim3(256), lds, st, g);
+        }
+    }
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// C_p [M, N] = sum_s sum_{m < min(K, *dyn)} A_ps [m, M] B_ps [m, N]  (fp32 output; M, N % 8 == 0)
+extern "C" int srec_gemm16_tn(const void* desc_, void* stream) {
+    G16Args g{};
+    int blocks = 0;
+    if (int rc = fill(g, desc_, 128, 128, true, blocks)) return rc;
+    const size_t lds = (size_t)NS * 2 * 32 * 128 * 2;
+    hipLaunchKernelGGL(gemm16_tn_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, g);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// out [C, n] = sum over the R slabs of part [C, R, n] (split weight-gradient products of one module), n % 4 == 0
+extern "C" int srec_sum_slabs(const float* part, int C, int R, long n, float* out, void* stream) {
+    if (C <= 0 || R <= 0 || n <= 0) return 0;
+    if (n & 3) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n / 4 + 255) / 256), C), dim3(256), 0, (hipStream_t)stream, part, R, n,
+                       out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, int d, void* dst16, void* stream) {
+    if (n <= 0) return 0;
+    if ((d & 3) || (ld & 3)) return SREC_BAD_ARG;
+    const long items = (long)n * d / 4;
+    hipLaunchKernelGGL(rows_bf16_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, n,
+                       dyn, d, (unsigned short*)dst16);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// n <= 8 weight matrices W_i [R_i, C_i] fp32 (contiguous) -> bf16 copy W16_i and transposed bf16 copy WT16_i [C_i, R_i]
+// (WT16 entries may be NULL).  W / W16 / WT16 / R / Cc are HOST arrays of n entries.
+extern "C" int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc,
+                                 void* stream) {
+    if (n <= 0) return 0;
+    if (n > 8 || W == nullptr || W16 == nullptr || WT16 == nullptr) return SREC_BAD_ARG;
+    WArgs a{};
+    a.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        a.W[i] = ((const float* const*)W)[i];
+        a.W16[i] = ((unsigned short* const*)W16)[i];
+        a.WT16[i] = ((unsigned short* const*)WT16)[i];
+        a.R[i] = R[i]; a.Cc[i] = Cc[i];
+        if (a.W[i] == nullptr || a.W16[i] == nullptr || R[i] <= 0 || Cc[i] <= 0) return SREC_BAD_ARG;
+        a.start[i] = blocks;
+        blocks += cdiv(R[i], 64) * cdiv(Cc[i], 64);
+    }
+    a.start[n] = blocks;
+    hipLaunchKernelGGL(weights_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

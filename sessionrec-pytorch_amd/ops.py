@@ -1223,6 +1223,54 @@ def gemm_group(mode, probs, lda, ldb, ldc, beta=0.0, a16=False, c16=False):
     lib.srec_gemm_group_bf16(_ct.addressof(g), mode, stream())
 
 
+class GemmGroup16(_ct.Structure):
+    """host mirror of srec_gemm16_group (include/srec_hg.h)"""
+    _fields_ = [('np', _ct.c_int), ('lda', _ct.c_int), ('ldb', _ct.c_int), ('ldc', _ct.c_int), ('beta', _ct.c_float),
+                ('c16', _ct.c_int),
+                ('M', _ct.c_int * 16), ('N', _ct.c_int * 16), ('K', _ct.c_int * 16), ('nseg', _ct.c_int * 16),
+                ('A', (_ct.c_void_p * 4) * 16), ('B', (_ct.c_void_p * 4) * 16), ('C', _ct.c_void_p * 16),
+                ('dyn', _ct.c_void_p * 16)]
+
+
+def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False):
+    """one grouped launch of the bf16-in-HBM GEMMs (csrc/gemm16.hip).  probs: [(M, N, K, [(A16, B16), ...], C, dyn)].
+    kind 'nt': C [M, N] (+)= sum_s A_s [M, K] B_s [N, K]^T (c16: bf16 output);  'tn': C [M, N] = sum_s A_s [K, M]^T B_s [K, N]
+    (reduction over the K rows, clamped by dyn)."""
+    assert 0 < len(probs) <= 16
+    g = GemmGroup16()
+    g.np, g.lda, g.ldb, g.ldc, g.beta, g.c16 = len(probs), lda, ldb, ldc, beta, int(c16)
+    for p, (M, N, K, segs, C, dyn) in enumerate(probs):
+        g.M[p], g.N[p], g.K[p], g.nseg[p], g.C[p], g.dyn[p] = M, N, K, len(segs), ptr(C), ptr(dyn)
+        for si, (A, B) in enumerate(segs):
+            g.A[p][si], g.B[p][si] = ptr(A), ptr(B)
+    (lib.srec_gemm16_nt if kind == 'nt' else lib.srec_gemm16_tn)(_ct.addressof(g), stream())
+
+
+def rows_bf16(x, dyn=None):
+    """bf16 copy of fp32 rows [n, d] (zero rows past the live count)"""
+    x = _rows(x)
+    n, d = x.shape
+    out = torch.empty(n, d, device=x.device, dtype=torch.bfloat16)
+    lib.srec_rows_bf16(ptr(x), _ld(x), n, ptr(dyn), d, ptr(out), stream())
+    return out
+
+
+def weights_bf16(ws, transposed=True):
+    """[(W16, WT16)] bf16 copies (and transposed copies) of up to 8 contiguous fp32 matrices, one launch"""
+    n = len(ws)
+    assert 0 < n <= 8
+    dev = ws[0].device
+    w16 = [torch.empty(w.shape, device=dev, dtype=torch.bfloat16) for w in ws]
+    wt16 = [torch.empty(w.shape[1], w.shape[0], device=dev, dtype=torch.bfloat16) if transposed else None for w in ws]
+    arr = _ct.c_void_p * n
+    a_w, a_16 = arr(*[w.data_ptr() for w in ws]), arr(*[w.data_ptr() for w in w16])      # kept alive across the call
+    a_t = arr(*[(w.data_ptr() if w is not None else None) for w in wt16])
+    a_r, a_c = (_ct.c_int * n)(*[w.shape[0] for w in ws]), (_ct.c_int * n)(*[w.shape[1] for w in ws])
+    lib.srec_weights_bf16(n, _ct.addressof(a_w), _ct.addressof(a_16), _ct.addressof(a_t), _ct.addressof(a_r),
+                          _ct.addressof(a_c), stream())
+    return w16, wt16
+
+
 class HgPlan:
     """Static topology of one MSHGNN layer call (built by msgifsr.MSHGNN from the FlatBatch).
     types:   [(row0, ncap, dyn_n, seg)]                          node types, stacked rows
@@ -1235,6 +1283,15 @@ class HgPlan:
         self.H, self.D, self.slope, self.B, self.dynB = H, D, slope, B, dynB
         self.types, self.modules, self.blocks, self.insts = types, modules, blocks, insts
         assert len(types) <= 4 and len(modules) <= 8 and len(blocks) <= 16 and len(insts) <= 16
+
+    def pieces(self, m):
+        """[(row offset inside module m's projection, first stacked row, rows, dyn)] - one piece per node type the module
+        covers: GEMM problems are cut at type boundaries so that every piece carries its own live row count (the shared
+        'inter' module spans all types; as ONE problem it would multiply the capacity padding between them too)"""
+        r0, nr, dyn = self.modules[m]
+        out = [(t0 - r0, t0, nc, dyn_t) for (t0, nc, dyn_t, _) in self.types if r0 <= t0 and t0 + nc <= r0 + nr]
+        assert sum(p[2] for p in out) == nr, 'a module projects whole node types'
+        return out
 
     def scratch_layout(self):
         """-> (n_floats, offsets) of the small per-call scratch: eL,eR,wL,wR per block; A,DP,der per instance"""
@@ -1362,7 +1419,23 @@ class HGATLayer(torch.autograd.Function):
         # bf16 GEMM path: the projections (and their gradients) are STORED as bf16 too - every pass over them is HBM bound
         P = [torch.empty(nr, HD, device=dev, dtype=torch.bfloat16 if grouped else torch.float32)
              for (r0, nr, dyn) in plan.modules]
-        if grouped:
+        g16 = None
+        if grouped and D % 64 == 0 and all(params[4 * m].is_contiguous() for m in range(nm)):
+            # every GEMM operand as bf16 in HBM (csrc/gemm16.hip): the small weights once per call (+ transposed copies for
+            # the backward-data product), the module inputs in one pass
+            w16, wt16 = weights_bf16([params[4 * m] for m in range(nm)])
+            if dstate is not None:
+                x16 = rows_bf16(xcs.view(2 * NT, D)).view(2, NT, D)
+                xin16 = lambda m: x16[plan.mod_conv[m]]
+            else:
+                x16 = rows_bf16(x)
+                xin16 = lambda m: x16
+            probs = [(nc, HD, D, [(xin16(m)[t0:t0 + nc], w16[m])], P[m][o:o + nc], dyn_t)
+                     for m in range(nm) for (o, t0, nc, dyn_t) in plan.pieces(m)]
+            for i in range(0, len(probs), 16):
+                gemm16('nt', probs[i:i + 16], D, D, HD, c16=True)
+            g16 = (x16, wt16)
+        elif grouped:
             gemm_group(0, [(nr, HD, D, [(xin(m)[r0:r0 + nr], params[4 * m])], P[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], D, D, HD, c16=True)
         else:
@@ -1376,7 +1449,7 @@ class HGATLayer(torch.autograd.Function):
         desc = plan.fill(HgDesc(), small, lay, P, None, flat, None, dstate)
         lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
         ctx.save_for_backward(x, small, arg, *P, *params)
-        ctx.plan, ctx.lay, ctx.grouped, ctx.dstate = plan, lay, grouped, dstate
+        ctx.plan, ctx.lay, ctx.grouped, ctx.dstate, ctx.g16 = plan, lay, grouped, dstate, g16
         return out
 
     @staticmethod
@@ -1415,6 +1488,7 @@ class HGATLayer(torch.autograd.Function):
             full = ctx.grouped and all(any(plan.mod_conv[bm] == cv and bt == t for bm, bt in plan.blocks)
                                        for cv in (0, 1) for t in range(len(plan.types)))
             tgts = (torch.empty if full else torch.zeros)(2, NT, D, device=dev, dtype=torch.float32)
+        pend = []                                    # gemm16: the two convs' backward-data problems share ONE launch
         for cv in convs:
             # d x of one node type = sum over the modules that project it: the module sum is the K loop (segments).
             # With feature dropout the two convs see differently masked inputs: one masked contribution per conv.
@@ -1423,20 +1497,56 @@ class HGATLayer(torch.autograd.Function):
             if ctx.grouped:
                 probs = []
                 for t, (t0, nc, dyn_t, _) in enumerate(plan.types):
-                    segs = [(dP[m][t0 - plan.modules[m][0]:t0 - plan.modules[m][0] + nc], params[4 * m]) for m in mods
+                    segs = [(dP[m][t0 - plan.modules[m][0]:t0 - plan.modules[m][0] + nc], m) for m in mods
                             if plan.modules[m][0] <= t0 and t0 + nc <= plan.modules[m][0] + plan.modules[m][1]
                             and any(bm == m and bt == t for bm, bt in plan.blocks)]
                     if segs:
                         probs.append((nc, D, HD, segs, tgt[t0:t0 + nc], dyn_t))
-                if probs:
-                    gemm_group(1, probs, HD, D, D, beta=0.0 if (cv is not None and full) else 1.0, a16=True)
+                beta = 0.0 if (cv is not None and full) else 1.0
+                if probs and ctx.g16 is not None:
+                    wt16 = ctx.g16[1]
+                    pend += [((M_, N_, K_, [(A_, wt16[m_]) for A_, m_ in segs_], C_, dyn_), beta)
+                             for (M_, N_, K_, segs_, C_, dyn_) in probs]
+                elif probs:
+                    probs = [(M_, N_, K_, [(A_, params[4 * m_]) for A_, m_ in segs_], C_, dyn_)
+                             for (M_, N_, K_, segs_, C_, dyn_) in probs]
+                    gemm_group(1, probs, HD, D, D, beta=beta, a16=True)
             else:
                 for m in mods:
                     r0, nr, dyn = plan.modules[m]
                     gemm_nn(dP[m], _rows(params[4 * m]), tgt[r0:r0 + nr], dyn, 1 if dyn is not None else 0, beta=1.0)
+        while pend:
+            beta = pend[0][1]
+            batch = [pr for pr, b in pend if b == beta][:8]
+            pend = [(pr, b) for pr, b in pend if not any(pr is q for q in batch)]
+            gemm16('nt', batch, HD, HD, D, beta=beta)
         if dstate is not None:
             lib.srec_hg_drop_merge(ptr(tgts), ptr(dstate[4]), NT * D, ptr(dx), stream())
-        if ctx.grouped:
+        if ctx.g16 is not None:
+            # weight gradients, one balanced problem per (module, node type): a module that spans several types (the shared
+            # 'inter' one) writes one slab per type, summed in fixed order afterwards
+            x16 = ctx.g16[0]
+            xin16 = (lambda m: x16[plan.mod_conv[m]]) if dstate is not None else (lambda m: x16)
+            pcs = [plan.pieces(m) for m in range(nm)]
+            multi = [m for m in range(nm) if len(pcs[m]) > 1]
+            R = max([len(pcs[m]) for m in multi] + [1])
+            if multi:
+                gWm = torch.empty(len(multi), HD, D, device=dev, dtype=torch.float32)
+                slabs = torch.empty(len(multi), R, HD, D, device=dev, dtype=torch.float32)
+                if any(len(pcs[m]) < R for m in multi):
+                    slabs.zero_()
+                for i, m in enumerate(multi):
+                    gWs[m] = gWm[i]
+            probs = []
+            for m in range(nm):
+                for pi, (o, t0, nc, dyn_t) in enumerate(pcs[m]):
+                    tgt = gWs[m] if len(pcs[m]) == 1 else slabs[multi.index(m), pi]
+                    probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t))
+            for i in range(0, len(probs), 16):
+                gemm16('tn', probs[i:i + 16], HD, D, D)
+            if multi:
+                lib.srec_sum_slabs(ptr(slabs), len(multi), R, HD * D, ptr(gWm), stream())
+        elif ctx.grouped:
             gemm_group(2, [(HD, D, nr, [(dP[m], xin(m)[r0:r0 + nr])], gWs[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], HD, D, D, a16=True)
         outs = []

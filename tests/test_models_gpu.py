@@ -475,3 +475,75 @@ def test_cosine_scale_follows_the_max_norm_renorm(dev, name):
     ref.eval()
     with torch.no_grad():
         close(model(*inputs)[:len(olab)], ref(*oin), rtol=1e-4, atol=1e-4, what='log-probs after training')
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.2])
+def test_msgifsr_bf16_gemm16_path_at_d64(dev, dropout):
+    """d % 64 == 0 routes the GAT projections through the bf16-in-HBM GEMMs (csrc/gemm16.hip) - the path the benchmark
+    runs at d = 256; the d = 32 fixtures take the register-staged kernels.  MSGIFSR K3 at d = 64 against the fp32 CPU
+    oracle at the bf16 tolerance of SURVEY 8(c) (loss 5e-3 rel, encoder gradients 3e-2 norm-wise, direction cos > 0.97);
+    with dropout the product's masks are replayed in the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import collate_ref as oc, models_ref as om
+    sp, ops = pkg(), pkg('ops')
+    z, samples, _ = load_golden('msgifsr_K3_s32')
+    K, d, H, V = 3, 64, 8, 3429
+    torch.manual_seed(123)
+    ref = om.MSGIFSR(V, 'sample', d, 1, dropout=dropout, order=K, extra=False, fusion=False)
+    model = sp.MSGIFSR(V, 'sample', d, 1, dropout=dropout, order=K, extra=False, fusion=False)
+    model.load_state_dict(ref.state_dict())
+    model = model.to(dev).train()
+    ref.train()
+    (mg,), labels = _collate('msgifsr_K3_s32', samples)
+    mg, labels = mg.to(dev), labels.to(dev)
+    (og,), olab = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K)(samples)
+    og, olab = om.to_torch(og), torch.from_numpy(olab)
+    masks = None
+    ops.set_precision('bf16')
+    ops.DROP_TAP = []
+    try:
+        if dropout > 0:
+            Nk = {k: mg.count('N%d' % k) for k in range(1, K + 1)}
+            G = sum(Nk[k] * k for k in Nk)
+            row_mask = (torch.rand(G, d, generator=torch.Generator().manual_seed(5)) >= dropout).float() / (1 - dropout)
+            model.feat_drop = _Replay(row_mask.to(dev))
+        loss = model.fused_loss(mg, labels)
+        loss.backward()
+        if dropout > 0:
+            tap = ops.DROP_TAP[0]
+            rows, off = {}, 0
+            for k in range(1, K + 1):
+                m = row_mask[off:off + Nk[k] * k]
+                rows[k] = m if k == 1 else m.view(Nk[k], k, d)
+                off += Nk[k] * k
+            ms, row0, feat = tap['ms'].cpu(), 0, {0: {}, 1: {}}
+            for k in range(1, K + 1):
+                for c in (0, 1):
+                    feat[c][k] = ms[c, row0:row0 + Nk[k]]
+                row0 += Nk[k]
+            live = [key for key, nm in mg.meta['rels'] if mg.count('E_' + nm) > 0]
+            attn, i = {0: {}, 1: {}}, 0
+            for c in (0, 1):
+                for key in live:
+                    attn[c][tuple(key)] = tap['mk'][i].cpu().view(-1, H)
+                    i += 1
+            masks = dict(rows=rows, layers=[dict(conv1=dict(feat=feat[0], attn=attn[0]), conv2=dict(feat=feat[1], attn=attn[1]))])
+    finally:
+        ops.set_precision('fp32')
+        ops.DROP_TAP = None
+    rl = torch.nn.functional.nll_loss(ref(og, masks), olab)
+    rl.backward()
+    assert abs(loss.item() - rl.item()) <= 5e-3 * abs(rl.item()), (loss.item(), rl.item())
+    num = den = 0.0
+    rp = dict(ref.named_parameters())
+    for k_, p_ in model.named_parameters():
+        if k_ == 'embeddings.weight' or p_.grad is None or rp[k_].grad is None:
+            continue
+        g, r = p_.grad.double().cpu().reshape(-1), rp[k_].grad.double().reshape(-1)
+        num += float((g - r).pow(2).sum())
+        den += float(r.pow(2).sum())
+        if r.norm() > 1e-6:
+            cos = float(g @ r / (g.norm() * r.norm()))
+            assert cos > 0.97, '%s: gradient direction cos=%.4f' % (k_, cos)
+    assert (num / den) ** 0.5 < 3e-2, 'bf16 gradients off by %.3e (norm-wise)' % (num / den) ** 0.5

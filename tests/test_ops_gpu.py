@@ -786,3 +786,76 @@ def test_score_ce_at_the_c5_per_rank_shape(dev):
     loss.backward()
     assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss), (loss.item(), ref_loss)
     assert rel(srg.grad, ref_dsr) < 1e-4 and rel(vp.dE[:V], ref_dE) < 1e-4
+
+
+# ---------------------------------------------------------------------- bf16-in-HBM GEMMs (csrc/gemm16.hip)
+def test_gemm16_operand_copies(dev):
+    ops = _ops()
+    torch.manual_seed(1)
+    ws = [torch.randn(2048, 256, device=dev), torch.randn(768, 256, device=dev), torch.randn(100, 36, device=dev)]
+    w16, wt16 = ops.weights_bf16(ws)
+    for w, a, b in zip(ws, w16, wt16):
+        assert torch.equal(a, w.bfloat16()) and torch.equal(b, w.bfloat16().t().contiguous())
+    x = torch.randn(777, 64, device=dev)
+    dyn = torch.tensor([700], device=dev, dtype=torch.int32)
+    y = ops.rows_bf16(x, dyn)
+    ref = x.bfloat16()
+    ref[700:] = 0
+    assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize('c16', [True, False])
+def test_gemm16_nt(dev, c16):
+    """grouped NT product with bf16 operands == fp32 matmul of the same bf16 values (fp32 accumulation order only);
+    K-segments are summed, dyn clamps the output rows, beta accumulates, ragged M / N tiles are masked"""
+    ops = _ops()
+    torch.manual_seed(2)
+    bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).bfloat16()
+    for shapes in ([(300, 2048, 256), (1000, 2048, 256)], [(3850, 2048, 256)] * 3, [(130, 136, 64)]):
+        probs, refs = [], []
+        for (M, N, K) in shapes:
+            A, B = bf(M, K), bf(N, K)
+            dyn = torch.tensor([max(1, M - 77)], device=dev, dtype=torch.int32) if M > 200 else None
+            C = torch.full((M, N), 3.0, device=dev, dtype=torch.bfloat16 if c16 else torch.float32)
+            r = A.float() @ B.float().t()
+            if dyn is not None:
+                r[M - 77:] = 0
+            probs.append((M, N, K, [(A, B)], C, dyn))
+            refs.append(r)
+        ops.gemm16('nt', probs, shapes[0][2], shapes[0][2], shapes[0][1], c16=c16)
+        for (M, N, K, _, C, _), r in zip(probs, refs):
+            if c16:
+                close(C.float(), r.bfloat16().float(), what='nt16 c16', rtol=1e-2, atol=1e-2)     # one bf16 ulp
+            else:
+                close(C, r, what='nt16 f32', rtol=1e-4, atol=1e-3)
+    if not c16:   # segments + beta (backward-data: sum over modules, accumulated onto the residual gradient)
+        M, N, K = 1500, 256, 2048
+        A1, A2, B1, B2 = bf(M, K), bf(M, K), bf(N, K), bf(N, K)
+        C = torch.randn(M, N, device=dev)
+        ref = C + A1.float() @ B1.float().t() + A2.float() @ B2.float().t()
+        dyn = torch.tensor([1400], device=dev, dtype=torch.int32)
+        ref[1400:] = C[1400:]                                   # beta != 0: rows past the live count are left alone
+        ops.gemm16('nt', [(M, N, K, [(A1, B1), (A2, B2)], C, dyn)], K, K, N, beta=1.0)
+        close(C, ref, what='nt16 segments + beta', rtol=1e-4, atol=2e-3)
+
+
+def test_gemm16_tn(dev):
+    """weight-gradient product C = A^T B over the live rows, operands row-major bf16 (16-bit transposing LDS reads)"""
+    ops = _ops()
+    torch.manual_seed(3)
+    bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).bfloat16()
+    probs, refs = [], []
+    for (R, N1, N2, live) in ((1391, 2048, 256, None), (3850, 2048, 256, 3333), (64, 2048, 256, 1), (500, 768, 256, 0),
+                              (257, 136, 72, 200)):
+        A, B = bf(R, N1), bf(R, N2)
+        dyn = torch.tensor([live], device=dev, dtype=torch.int32) if live is not None else None
+        n = R if live is None else live
+        C = torch.full((N1, N2), 9.0, device=dev)
+        ops.gemm16('tn', [(N1, N2, R, [(A, B)], C, dyn)], N1, N2, N2)
+        close(C, A[:n].float().t() @ B[:n].float(), what='tn16 R=%d live=%s' % (R, live), rtol=1e-4, atol=2e-3)
+    # grouped: several modules in one launch
+    As, Bs = [bf(1000, 2048), bf(1300, 2048)], [bf(1000, 256), bf(1300, 256)]
+    Cs = [torch.empty(2048, 256, device=dev) for _ in range(2)]
+    ops.gemm16('tn', [(2048, 256, 1000, [(As[0], Bs[0])], Cs[0], None), (2048, 256, 1300, [(As[1], Bs[1])], Cs[1], None)], 2048, 256, 256)
+    for A, B, C in zip(As, Bs, Cs):
+        close(C, A.float().t() @ B.float(), what='tn16 grouped', rtol=1e-4, atol=2e-3)

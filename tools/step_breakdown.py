@@ -12,7 +12,7 @@ def short(k):
     return k[:70]
 GROUPS = [('scoring', r'flash_ce|ce_reduce|ce_mean|dsr_reduce|bf16_prepare|rownorm_project|row_invnorm'),
           ('adam', r'adam'),
-          ('gat_gemm', r'gemm_group'),
+          ('gat_gemm', r'gemm_group|gemm16|rows_bf16|weights_bf16'),
           ('gat_graph', r'hg_'),
           ('gru_expander', r'gru_|gram_|gemm_bf16_tn|splitk|gemm_bf16_nt|gemm_f32'),
           ('readout/rows', r'seg_attn|normalize|gather_rows|scatter_add|col_sum|renorm|mask_scale'),
