@@ -259,10 +259,11 @@ int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_o
 /* feature-dropout glue of a layer call in one pass each (GATConv feat_drop, gatconv.py:268-283): from uniform draws u
  * [2, rows, D] (one mask per conv) and cnt [2, rows] (relation instances of the conv into each row): ms = mask / (1-p),
  * xc = x * ms (the convs' dropped inputs), rm = cnt0 ms0 + cnt1 ms1, xres = x * rm (summed identity residuals);
- * backward: dx += t0 * ms0 + t1 * ms1 (the convs' masked data gradients). */
+ * backward: dx += (sum_s t[0][s]) * ms0 + (sum_s t[1][s]) * ms1 (the convs' masked data gradients, t [2, S, n]: S partial sums
+ * per conv, one per GAT module projecting the row's node type). */
 int srec_hg_drop_prep(const float* x, const float* u, const float* cnt, int rows, int D, float p, float* ms, float* xc,
                       float* rm, float* xres, void* stream);
-int srec_hg_drop_merge(const float* t, const float* ms, long n, float* dx, void* stream);
+int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, void* stream);
 /* attention-dropout multipliers (gatconv.py:300): out[i] = u[i] >= p ? 1/(1-p) : 0 from uniform draws u */
 int srec_mask_scale(const float* u, long n, float p, float* out, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
@@ -290,6 +291,16 @@ int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, int d, void*
 /* out [C, n] = sum_r part [C, R, n] in fixed order (the row-split weight-gradient products of one module), n % 4 == 0 */
 int srec_sum_slabs(const float* part, int C, int R, long n, float* out, void* stream);
 int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, void* stream);
+
+/* k-gram GRU of the SemanticExpander, all orders per launch (grux.hip; msgifsr.py:25,32-45): desc = host
+ * srec_gru_step_desc (srec_hg.h).  d % 4 == 0 and 256 % (d / 4) == 0. */
+int srec_gru_step_fwd(const void* desc, void* stream);
+int srec_gru_step_bwd(const void* desc, void* stream);
+/* out[p] [ncol] = column sums of part[p] [rows[p], ncol] for np <= 4 problems in one launch (the GRU bias gradients from the
+ * per-block partial rows of srec_gru_step_bwd); part / out: HOST arrays of np device pointers, rows: HOST int array */
+int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);
+/* np <= 8 outputs out_i [n_i] = sum_r part_i [R_i, n_i] in one launch (row-split weight gradients); HOST arrays */
+int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, void* stream);
 
 /* ---- evaluation: K best items per session without the (B, V) score matrix (topk.hip) -----------------------------
  * Replaces `logits = model(...); logits.topk(20)` of train.py:36-55 for models whose score is one soft-max

@@ -90,12 +90,51 @@ typedef struct {
 typedef struct {
     int np, lda, ldb, ldc;
     float beta;
-    int c16;                       /* C outputs are bf16 (nt only) */
+    int c16;                       /* bit 0: C outputs are bf16 (nt only); bit 1: leave output rows past *dyn unwritten */
     int M[SREC_G16_MAXP], N[SREC_G16_MAXP], K[SREC_G16_MAXP], nseg[SREC_G16_MAXP];
     const void* A[SREC_G16_MAXP][SREC_G16_MAXS];
     const void* B[SREC_G16_MAXP][SREC_G16_MAXS];
     void* C[SREC_G16_MAXP];
     const int* dyn[SREC_G16_MAXP];
+    int koff[SREC_G16_MAXP];       /* tn only: this problem reduces rows koff .. koff + K of a longer operand whose live
+                                      row count is *dyn: live rows here = clamp(*dyn - koff, 0, K) (row-split products) */
+    int nsplit[SREC_G16_MAXP];     /* tn only (0 / 1 = off): split the reduction rows into nsplit pieces (64-row multiples), piece
+                                      s writing its own slab C + s * M * ldc (caller sums the slabs: srec_sum_slabs_multi) */
 } srec_gemm16_group;
+
+/* one time step of the k-gram GRU (msgifsr.py:25,32-45) for up to 4 orders at once: srec_gru_step_fwd / _bwd (srec.h,
+ * csrc/grux.hip).  Problem p = order k[p] with n[p] nodes (live prefix *dyn[p]), hidden size d, at time step t[p].
+ * x rows are node-major: row (node * k + t). */
+#define SREC_GRU_MAXP 4
+typedef struct {
+    int np, d;
+    int n[SREC_GRU_MAXP], k[SREC_GRU_MAXP], t[SREC_GRU_MAXP];
+    const int* dyn[SREC_GRU_MAXP];
+    /* forward: GI [n k, 3 d] = x W_ih^T (no bias), GH [n, 3 d] = h_{t-1} W_hh^T (no bias; NULL at t = 0), Hp = h_{t-1};
+     * writes Hn [n, d] (+ bf16 copy Hn16, nullable), gates [n, 4 d] = r, z, n, gh_n + b_hh_n; when out != NULL and
+     * t == k - 1 also out [n, d] = 0.5 mean_t X[n, t, :] + 0.5 Hn (X [n, k, d]) */
+    const float* GI[SREC_GRU_MAXP];
+    const float* GH[SREC_GRU_MAXP];
+    const float* bih[SREC_GRU_MAXP];
+    const float* bhh[SREC_GRU_MAXP];
+    const float* Hp[SREC_GRU_MAXP];
+    float* Hn[SREC_GRU_MAXP];
+    void* Hn16[SREC_GRU_MAXP];
+    float* gates[SREC_GRU_MAXP];
+    const float* X[SREC_GRU_MAXP];
+    float* out[SREC_GRU_MAXP];
+    /* backward: d h_t comes from dH [n, d], or (t == k - 1 and dout != NULL) as 0.5 dout with the mean term 0.5 dout / k
+     * written to all k rows of dX [n k, d]; writes dGI16 rows (node k + t) [n k, 3 d] and dGH16 [n, 3 d] (bf16, nullable),
+     * dHp [n, d] = d h_t * z (nullable: the direct term of d h_{t-1}), and one row of column sums (d gi | d gh) [6 d] per
+     * max(8, 1024 / d)-node block into bias_part at row part_row0 + block */
+    const float* dH[SREC_GRU_MAXP];
+    const float* dout[SREC_GRU_MAXP];
+    void* dGI16[SREC_GRU_MAXP];
+    void* dGH16[SREC_GRU_MAXP];
+    float* dHp[SREC_GRU_MAXP];
+    float* dX[SREC_GRU_MAXP];
+    float* bias_part[SREC_GRU_MAXP];
+    int part_row0[SREC_GRU_MAXP];
+} srec_gru_step_desc;
 
 #endif

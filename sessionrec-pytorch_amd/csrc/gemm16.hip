@@ -36,9 +36,10 @@ struct G16Args {
     const unsigned short* B[G16_MAXP][G16_MAXS];
     void* C[G16_MAXP];
     const int* dyn[G16_MAXP];
-    int M[G16_MAXP], N[G16_MAXP], K[G16_MAXP], nseg[G16_MAXP], start[G16_MAXP + 1];
+    int M[G16_MAXP], N[G16_MAXP], K[G16_MAXP], nseg[G16_MAXP], koff[G16_MAXP], nsplit[G16_MAXP], start[G16_MAXP + 1];
     int np, lda, ldb, ldc;
     float beta;
+    int keep_dead;                // leave output rows past the live count unwritten (nobody reads them)
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -59,14 +60,16 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // wait until at most `ahead` later stages (IPS LDS-DMA instructions each, per wave) are still in flight
-template <int IPS>
+template <int IPS, int PDV>
 __device__ __forceinline__ void wait_stage(int ahead) {
-    if (ahead >= 2) wait_vm<2 * IPS>();
-    else if (ahead == 1) wait_vm<IPS>();
+    if (PDV >= 5 && ahead >= 4) wait_vm<(4 * IPS > 63 ? 63 : 4 * IPS)>();
+    else if (PDV >= 4 && ahead >= 3) wait_vm<(3 * IPS > 63 ? 63 : 3 * IPS)>();
+    else if (PDV >= 3 && ahead >= 2) wait_vm<2 * IPS>();
+    else if (PDV >= 2 && ahead >= 1) wait_vm<IPS>();
     else wait_vm<0>();
 }
 
-constexpr int NS = 4, PD = 3;        // LDS ring: 4 stages, 3 stages of LDS-DMA in flight ahead of the MFMAs
+constexpr int NS = 4, PD = 3;        // default LDS ring: 4 stages, 3 stages of LDS-DMA in flight ahead of the MFMAs
 
 // -------------------------------------------------------------------------------------------------- nt16
 // C16: the accumulator is D^T (rows of D <-> B rows = output columns, lane <-> A row = output row): the bf16 output
@@ -76,12 +79,15 @@ constexpr int NS = 4, PD = 3;        // LDS ring: 4 stages, 3 stages of LDS-DMA 
 // barriers - a 4-stage ring keeps 3 stages in flight per workgroup, and 16 KB stages leave room for 2-3 workgroups
 // per CU.  Piece p of tile row r sits in slot p ^ ((r >> 2) & 3): the 16 lanes of every ds_read_b128 group hit 16
 // distinct 16-B slots.
-template <int TM, int TN, bool C16>
+template <int TM, int TN, bool C16, int BK = 32, int NS = 4>
 __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
-    constexpr int BK = 32;
+    constexpr int PD = NS - 1;
+    constexpr int RPI = 512 / BK;                        // tile rows per DMA instruction (1 KiB)
+    constexpr int PPR = BK / 8;                          // 16-B pieces per tile row
+    constexpr int FS = BK == 32 ? 2 : 1;                 // swizzle: slot = piece ^ ((row >> FS) & (PPR - 1))
     constexpr int IM = TM / 64, IN = TN / 64;            // 32x32 accumulators per wave and dimension (2 x 2 waves)
     constexpr int STG = (TM + TN) * BK;                  // bf16 elements per stage
-    constexpr int NIA = TM / 16, NI = (TM + TN) / 16;    // DMA instructions per stage: A, total
+    constexpr int NIA = TM / RPI, NI = (TM + TN) / RPI;  // DMA instructions per stage: A, total
     constexpr int IPS = NI / 4;                          // ... per wave
     static_assert(NI % 4 == 0, "every wave must issue the same number of DMA instructions per stage");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     float* __restrict__ C = static_cast<float*>(g.C[p]);
     unsigned short* __restrict__ C16p = static_cast<unsigned short*>(g.C[p]);
     if (m0 >= Ml) {                                      // tile of capacity padding: zero rows when overwriting
-        if (C16 || g.beta == 0.f)
+        if (!g.keep_dead && (C16 || g.beta == 0.f))
             for (int i = tid; i < TM * TN / 4; i += 256) {
                 const int r = m0 + (i * 4) / TN, c = n0 + (i * 4) % TN;
                 if (r < M && c + 3 < N) {
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     // DMA instruction i covers tile rows 16 i .. 16 i + 15 of the concatenated (A rows, then B rows) stage; lane -> (row
     // l >> 2, slot l & 3).  Rows past an operand are clamped to its last row (their products land in rows / columns the
     // epilogue does not store).
-    const int rl = lane >> 2, sl = lane & 3;
+    const int rl = lane / PPR, sl = lane % PPR;
     auto stage = [&](int it) {
         const int s = it / nk, k0 = (it - s * nk) * BK;
         const unsigned short* Ab = g.A[p][s] + (size_t)m0 * g.lda + k0;
@@ -137,8 +143,8 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
 #pragma unroll
         for (int ii = 0; ii < IPS; ++ii) {
             const int i = ii * 4 + wave;                 // wave-uniform
-            const int r = 16 * (i < NIA ? i : i - NIA) + rl;
-            const unsigned pc = (unsigned)((sl ^ ((r >> 2) & 3)) * 8);
+            const int r = RPI * (i < NIA ? i : i - NIA) + rl;
+            const unsigned pc = (unsigned)((sl ^ ((r >> FS) & (PPR - 1))) * 8);
             if (i < NIA) glds16(Ab, ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.lda + pc) * 2u, dst + (unsigned)i * 1024u);
             else glds16(Bb, ((unsigned)min(r, N - 1 - n0) * (unsigned)g.ldb + pc) * 2u, dst + (unsigned)i * 1024u);
         }
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
 
     for (int s = 0; s < PD && s < total; ++s) stage(s);
     for (int it = 0; it < total; ++it) {
-        wait_stage<IPS>(min(total - it - 1, PD - 1));          // this wave's pieces of stage `it` have landed ...
+        wait_stage<IPS, PD>(min(total - it - 1, PD - 1));      // this wave's pieces of stage `it` have landed ...
         __syncthreads();                                       // ... everyone's have; stage it - 1's buffer is free again
         if (it + PD < total) stage(it + PD);
         const unsigned short* As = smem + (it % NS) * STG;
@@ -157,12 +163,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
 #pragma unroll
             for (int i = 0; i < IM; ++i) {
                 const int r = wm * (TM / 2) + i * 32 + l31;
-                a[i] = *reinterpret_cast<const bf16x8*>(As + r * BK + (((2 * ks + half) ^ ((r >> 2) & 3)) << 3));
+                a[i] = *reinterpret_cast<const bf16x8*>(As + r * BK + (((2 * ks + half) ^ ((r >> FS) & (PPR - 1))) << 3));
             }
 #pragma unroll
             for (int j = 0; j < IN; ++j) {
                 const int r = wn * (TN / 2) + j * 32 + l31;
-                b[j] = *reinterpret_cast<const bf16x8*>(Bs + r * BK + (((2 * ks + half) ^ ((r >> 2) & 3)) << 3));
+                b[j] = *reinterpret_cast<const bf16x8*>(Bs + r * BK + (((2 * ks + half) ^ ((r >> FS) & (PPR - 1))) << 3));
             }
 #pragma unroll
             for (int i = 0; i < IM; ++i)
@@ -192,12 +198,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
                     v.y = srec_pack_bf16(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                     *reinterpret_cast<uint2*>(patch + (i * 32 + l31) * LDP + j * 32 + 8 * q + 4 * half) = v;
                 }
-        constexpr int PPR = WC / 8;                                    // 16-B pieces per row
+        constexpr int PPW = WC / 8;                                    // 16-B pieces per patch row
 #pragma unroll
-        for (int t = 0; t < WR * PPR / 64; ++t) {
-            const int idx = t * 64 + lane, rr = idx / PPR, pc = idx % PPR;
+        for (int t = 0; t < WR * PPW / 64; ++t) {
+            const int idx = t * 64 + lane, rr = idx / PPW, pc = idx % PPW;
             const int row = m0 + wm * WR + rr, col = n0 + wn * WC + pc * 8;
-            if (row >= M) continue;
+            if (row >= M || (g.keep_dead && row >= Ml)) continue;
             uint4 v = *reinterpret_cast<const uint4*>(patch + rr * LDP + pc * 8);
             if (row >= Ml) v = make_uint4(0u, 0u, 0u, 0u);
             if (col + 7 < N) {
@@ -241,10 +247,13 @@ __device__ __forceinline__ uint2 lds_tr16(unsigned addr) {
     return v;
 }
 
+template <int BR, int NS>
 __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
-    constexpr int T = 128, BR = 32;                      // output tile, reduction rows per stage
+    constexpr int T = 128;                               // output tile; BR = reduction rows per stage
+    constexpr int PD = NS - 1;
     constexpr int STG = 2 * BR * T;                      // bf16 elements per stage (A tile + B tile)
-    constexpr int IPS = (2 * BR / 4) / 4;                // DMA instructions (4 rows each) per stage and wave
+    constexpr int NIO = BR / 4;                          // DMA instructions (4 rows each) per operand and stage
+    constexpr int IPS = 2 * NIO / 4;                     // ... per stage and wave
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int bid = (int)blockIdx.x;
     int p = 0;
@@ -252,13 +261,18 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
     for (int i = 1; i < G16_MAXP; ++i)
         if (i < g.np && bid >= g.start[i]) p = i;
     const int N1 = g.M[p], N2 = g.N[p];
-    const int tn = (N2 + T - 1) / T, tile = bid - g.start[p];
+    const int tn = (N2 + T - 1) / T, ntile = ((N1 + T - 1) / T) * tn;
+    const int split = (bid - g.start[p]) / ntile, tile = (bid - g.start[p]) % ntile;
     const int i0 = (tile / tn) * T, j0 = (tile % tn) * T;
-    const int Kr = dyn_count(g.dyn[p], g.K[p]);          // live reduction rows
+    // row split s of nsplit: reduction rows [s chunk, (s + 1) chunk) of the problem, written to slab s of C
+    const int chunk = ((g.K[p] + g.nsplit[p] - 1) / g.nsplit[p] + 63) / 64 * 64;
+    const int kbeg = split * chunk, klen = max(0, min(chunk, g.K[p] - kbeg));
+    // live reduction rows: rows koff .. koff + K of an operand with *dyn live rows in total
+    const int Kr = g.dyn[p] == nullptr ? klen : max(0, min(klen, *g.dyn[p] - g.koff[p] - kbeg));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    float* __restrict__ C = static_cast<float*>(g.C[p]);
+    float* __restrict__ C = static_cast<float*>(g.C[p]) + (size_t)split * N1 * g.ldc;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
     const int nst = (Kr + BR - 1) / BR;
     const int total = nst * g.nseg[p];
     const unsigned lds0 = lds_addr(smem);
-    // DMA instruction i (0..15): operand i >> 3, reduction rows 4 (i & 7) .. + 3; lane -> (row l >> 4, slot l & 15)
+    // DMA instruction i: operand i / NIO, reduction rows 4 (i % NIO) .. + 3; lane -> (row l >> 4, slot l & 15)
     const int rl = lane >> 4, sl = lane & 15;
     auto stage = [&](int it) {
         const int s = it / nst, r0 = (it - s * nst) * BR;
@@ -280,8 +294,8 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
 #pragma unroll
         for (int ii = 0; ii < IPS; ++ii) {
             const int i = ii * 4 + wave;
-            const int gr = min(r0 + 4 * (i & 7) + rl, Kr - 1);
-            if (i < 8) glds16(g.A[p][s], ((unsigned)gr * (unsigned)g.lda + (unsigned)min(i0 + pc * 8, N1 - 8)) * 2u, dst + (unsigned)i * 1024u);
+            const int gr = kbeg + min(r0 + 4 * (i % NIO) + rl, Kr - 1);
+            if (i < NIO) glds16(g.A[p][s], ((unsigned)gr * (unsigned)g.lda + (unsigned)min(i0 + pc * 8, N1 - 8)) * 2u, dst + (unsigned)i * 1024u);
             else glds16(g.B[p][s], ((unsigned)gr * (unsigned)g.ldb + (unsigned)min(j0 + pc * 8, N2 - 8)) * 2u, dst + (unsigned)i * 1024u);
         }
     };
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
 
     for (int s = 0; s < PD && s < total; ++s) stage(s);
     for (int it = 0; it < total; ++it) {
-        wait_stage<IPS>(min(total - it - 1, PD - 1));
+        wait_stage<IPS, PD>(min(total - it - 1, PD - 1));
         __syncthreads();
         if (it + PD < total) stage(it + PD);
         const int r0 = (it % nst) * BR;
@@ -424,18 +438,22 @@ int fill(G16Args& g, const void* desc_, int tm, int tn, bool tnmode, int& blocks
     const srec_gemm16_group* d = (const srec_gemm16_group*)desc_;
     if (d == nullptr || d->np <= 0 || d->np > G16_MAXP || (d->lda & 7) || (d->ldb & 7)) return SREC_BAD_ARG;
     g.np = d->np; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc; g.beta = d->beta;
+    g.keep_dead = (d->c16 >> 1) & 1;
     blocks = 0;
     for (int p = 0; p < d->np; ++p) {
         if (d->nseg[p] <= 0 || d->nseg[p] > G16_MAXS || d->M[p] <= 0 || d->N[p] <= 0 || d->K[p] <= 0) return SREC_BAD_ARG;
         if (!tnmode && (d->K[p] & 31)) return SREC_BAD_ARG;                 // 32-deep k-steps
         if (tnmode && ((d->M[p] & 7) || (d->N[p] & 7) || d->M[p] < 8 || d->N[p] < 8)) return SREC_BAD_ARG;
         g.M[p] = d->M[p]; g.N[p] = d->N[p]; g.K[p] = d->K[p]; g.nseg[p] = d->nseg[p]; g.C[p] = d->C[p]; g.dyn[p] = d->dyn[p];
+        g.koff[p] = tnmode ? d->koff[p] : 0;
+        g.nsplit[p] = tnmode && d->nsplit[p] > 1 ? d->nsplit[p] : 1;
+        if (g.koff[p] < 0 || g.nsplit[p] > 64) return SREC_BAD_ARG;
         for (int s = 0; s < d->nseg[p]; ++s) {
             if (((uintptr_t)d->A[p][s] & 15) || ((uintptr_t)d->B[p][s] & 15)) return SREC_BAD_ARG;
             g.A[p][s] = (const unsigned short*)d->A[p][s]; g.B[p][s] = (const unsigned short*)d->B[p][s];
         }
         g.start[p] = blocks;
-        blocks += cdiv(d->M[p], tm) * cdiv(d->N[p], tn);
+        blocks += cdiv(d->M[p], tm) * cdiv(d->N[p], tn) * g.nsplit[p];
     }
     g.start[d->np] = blocks;
     return 0;
@@ -458,27 +476,44 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     // small-N problems (backward-data, N = D): 64-row tiles keep every CU busy
     long t128 = 0;
     for (int p = 0; p < h->np; ++p) t128 += (long)cdiv(h->M[p], 128) * cdiv(h->N[p], 128);
-    const int tm = t128 >= 384 ? 128 : 64;
-    if (int rc = fill(g, desc_, tm, 128, false, blocks)) return rc;
+    // skinny outputs (backward-data: N = D) take 64-row tiles: twice the workgroups over the same HBM stream
+    int nmax = 0;
+    for (int p = 0; p < h->np; ++p) nmax = h->N[p] > nmax ? h->N[p] : nmax;
+    const int variant = (h->c16 >> 4) & 15;              // experiments (tools/gemm16_bench.py); 0 = tuned default
+    const int tm = (variant & 8) ? ((variant & 4) ? 128 : 64) : ((t128 >= 384 && nmax > 256) ? 128 : 64);
+    // tiny products (the GRU hidden-state GEMMs: ~2k x 256 outputs): 64 x 64 tiles double the workgroups in flight
+    long t64x128 = 0;
+    for (int p = 0; p < h->np; ++p) t64x128 += (long)cdiv(h->M[p], 64) * cdiv(h->N[p], 128);
+    const int tn = (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
+    if (int rc = fill(g, desc_, tm, tn, false, blocks)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)NS * (tm + 128) * 32 * 2;
-    if (h->c16) {
-        if (tm == 128) {
-            static std::atomic<unsigned long long> o{0};
-            if (int rc = optin(gemm16_nt_kernel<128, 128, true>, (int)lds, o)) return rc;
-            hipLaunchKernelGGL((gemm16_nt_kernel<128, 128, true>), dim3(blocks), dim3(256), lds, st, g);
-        } else {
-            hipLaunchKernelGGL((gemm16_nt_kernel<64, 128, true>), dim3(blocks), dim3(256), lds, st, g);
-        }
+    const bool c16 = h->c16 & 1;
+    static std::atomic<unsigned long long> optin_mask[32];
+#define SREC_G16(TMV, TNV, C16V, BKV, NSV, slot)                                                                       \
+    do {                                                                                                               \
+        const size_t lds = (size_t)NSV * (TMV + TNV) * BKV * 2;                                                        \
+        if (int rc = optin(gemm16_nt_kernel<TMV, TNV, C16V, BKV, NSV>, (int)lds, optin_mask[slot])) return rc;         \
+        hipLaunchKernelGGL((gemm16_nt_kernel<TMV, TNV, C16V, BKV, NSV>), dim3(blocks), dim3(256), lds, st, g);         \
+    } while (0)
+    // measured at the bench's GAT shapes (tools/gemm16_bench.py): every ring lands at 33-40 us for the 16-GFLOP forward
+    // (the LDS fill rate, ~8 TB/s, bounds all of them; deeper rings lose more in occupancy than they gain in flight):
+    // defaults = 3 x 32-deep stages for the bf16-output forward, 2 x 64-deep stages for backward-data
+    const int ring = (variant & 8) ? (variant & 3) : (c16 ? 3 : 1);     // 0: BK 32 x 4 stages, 1: BK 64 x 2, 2: BK 32 x 2, 3: BK 32 x 3
+    // few workgroups (<= 1.5 per CU): LDS is plentiful and every workgroup is latency bound on its own DMA - a 4-stage
+    // ring keeps three 64-deep stages in flight instead of one
+    const bool deep = blocks <= 384 && !(variant & 8);
+    if (tn == 64) {
+        if (c16) SREC_G16(64, 64, true, 64, 2, 16); else if (deep) SREC_G16(64, 64, false, 64, 4, 18); else SREC_G16(64, 64, false, 64, 2, 17);
+    } else if (deep && tm == 64 && !c16) {
+        SREC_G16(64, 128, false, 64, 4, 19);
+    } else if (tm == 128) {
+        if (c16) { if (ring == 0) SREC_G16(128, 128, true, 32, 4, 0); else if (ring == 1) SREC_G16(128, 128, true, 64, 2, 1); else if (ring == 2) SREC_G16(128, 128, true, 32, 2, 2); else SREC_G16(128, 128, true, 32, 3, 3); }
+        else { if (ring == 0) SREC_G16(128, 128, false, 32, 4, 4); else if (ring == 1) SREC_G16(128, 128, false, 64, 2, 5); else if (ring == 2) SREC_G16(128, 128, false, 32, 2, 6); else SREC_G16(128, 128, false, 32, 3, 7); }
     } else {
-        if (tm == 128) {
-            static std::atomic<unsigned long long> o{0};
-            if (int rc = optin(gemm16_nt_kernel<128, 128, false>, (int)lds, o)) return rc;
-            hipLaunchKernelGGL((gemm16_nt_kernel<128, 128, false>), dim3(blocks), dim3(256), lds, st, g);
-        } else {
-            hipLaunchKernelGGL((gemm16_nt_kernel<64, 128, false>), dim3(blocks), dim3(256), lds, st, g);
-        }
+        if (c16) { if (ring == 0) SREC_G16(64, 128, true, 32, 4, 8); else if (ring == 1) SREC_G16(64, 128, true, 64, 2, 9); else if (ring == 2) SREC_G16(64, 128, true, 32, 2, 10); else SREC_G16(64, 128, true, 32, 3, 11); }
+        else { if (ring == 0) SREC_G16(64, 128, false, 32, 4, 12); else if (ring == 1) SREC_G16(64, 128, false, 64, 2, 13); else if (ring == 2) SREC_G16(64, 128, false, 32, 2, 14); else SREC_G16(64, 128, false, 32, 3, 15); }
     }
+#undef SREC_G16
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -488,8 +523,18 @@ extern "C" int srec_gemm16_tn(const void* desc_, void* stream) {
     G16Args g{};
     int blocks = 0;
     if (int rc = fill(g, desc_, 128, 128, true, blocks)) return rc;
-    const size_t lds = (size_t)NS * 2 * 32 * 128 * 2;
-    hipLaunchKernelGGL(gemm16_tn_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, g);
+    const int variant = (((const srec_gemm16_group*)desc_)->c16 >> 4) & 15;
+    hipStream_t st = (hipStream_t)stream;
+    static std::atomic<unsigned long long> om[4];
+#define SREC_TN(BRV, NSV, slot)                                                                                        \
+    do {                                                                                                               \
+        const size_t lds = (size_t)NSV * 2 * BRV * 128 * 2;                                                            \
+        if (int rc = optin(gemm16_tn_kernel<BRV, NSV>, (int)lds, om[slot])) return rc;                                 \
+        hipLaunchKernelGGL((gemm16_tn_kernel<BRV, NSV>), dim3(blocks), dim3(256), lds, st, g);                         \
+    } while (0)
+    // default: 2 stages of 64 reduction rows (34 us at the bench shapes vs 37-38 for the 32-row rings)
+    if (variant == 1) SREC_TN(32, 2, 1); else if (variant == 3) SREC_TN(32, 3, 3); else if (variant == 4) SREC_TN(32, 4, 0); else SREC_TN(64, 2, 2);
+#undef SREC_TN
     SREC_LAUNCH_CHECK();
     return 0;
 }

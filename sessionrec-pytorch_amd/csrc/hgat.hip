@@ -907,16 +907,25 @@ __global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __
     *reinterpret_cast<float4*>(xres + i) = make_float4(xv.x * r.x, xv.y * r.y, xv.z * r.z, xv.w * r.w);
 }
 
-// dx += t[0] * ms[0] + t[1] * ms[1]   (the two convs' masked data gradients)
-__global__ void hg_drop_merge_kernel(const float* __restrict__ t, const float* __restrict__ ms, long n, float* __restrict__ dx) {
+// dx += (sum_s t[0][s]) * ms[0] + (sum_s t[1][s]) * ms[1]   (the two convs' masked data gradients, each given as S
+// partial sums - one per GAT module that projects the row's node type)
+__global__ void hg_drop_merge_kernel(const float* __restrict__ t, int S, const float* __restrict__ ms, long n,
+                                     float* __restrict__ dx) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    const float4 a = *reinterpret_cast<const float4*>(t + i), b = *reinterpret_cast<const float4*>(t + n + i);
+    float4 a = *reinterpret_cast<const float4*>(t + i), b = *reinterpret_cast<const float4*>(t + (size_t)S * n + i);
+    for (int s = 1; s < S; ++s) {
+        const float4 a2 = *reinterpret_cast<const float4*>(t + (size_t)s * n + i);
+        const float4 b2 = *reinterpret_cast<const float4*>(t + (size_t)(S + s) * n + i);
+        a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+        b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+    }
     const float4 m0 = *reinterpret_cast<const float4*>(ms + i), m1 = *reinterpret_cast<const float4*>(ms + n + i);
     float4 d = *reinterpret_cast<float4*>(dx + i);
     d.x += a.x * m0.x + b.x * m1.x; d.y += a.y * m0.y + b.y * m1.y; d.z += a.z * m0.z + b.z * m1.z; d.w += a.w * m0.w + b.w * m1.w;
     *reinterpret_cast<float4*>(dx + i) = d;
 }
+
 }  // namespace
 
 // x [rows, D] contiguous, u [2, rows, D] uniform draws, cnt [2, rows]; outputs ms / xc [2, rows, D], rm / xres [rows, D].
@@ -949,12 +958,12 @@ extern "C" int srec_mask_scale(const float* u, long n, float p, float* out, void
     return 0;
 }
 
-// dx [n] += t[0] * ms[0] + t[1] * ms[1], t / ms [2, n]; n % 4 == 0
-extern "C" int srec_hg_drop_merge(const float* t, const float* ms, long n, float* dx, void* stream) {
+// dx [n] += (sum_s t[0][s]) * ms[0] + (sum_s t[1][s]) * ms[1], t [2, S, n], ms [2, n]; n % 4 == 0
+extern "C" int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, void* stream) {
     if (n <= 0) return 0;
-    if (n & 3) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(hg_drop_merge_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, ms,
-                       n, dx);
+    if ((n & 3) || S < 1) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(hg_drop_merge_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, S,
+                       ms, n, dx);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -301,11 +301,17 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         dB = mg.dynp('B')
         ncap = mg.meta['ncap']                             # block size of order k (capacity in padded layouts)
         pieces = ops.split_rows(rows, [ncap[k] * k for k in range(1, K + 1)])
+        fast = None
+        if K > 1 and K <= 5 and ops.gru_expand_fast_ok(d, self.reducer):
+            # bf16 path: every order's k-gram GRU in one autograd node, one launch per time step for all orders
+            fast = ops.gru_expand_all([pieces[k - 1] for k in range(2, K + 1)], [self.expander.GRUs[k - 2] for k in range(2, K + 1)],
+                                      list(range(2, K + 1)), [mg.dynp('N%d' % k) for k in range(2, K + 1)],
+                                      [mg.dynp('GK%d' % k) for k in range(2, K + 1)])
         for k in range(1, K + 1):
             nk = ncap[k]
             x = pieces[k - 1]
             dk = mg.dynp('N%d' % k)
-            f = x if k == 1 else self.expander(x, k, dk, mg.dynp('GK%d' % k))
+            f = x if k == 1 else (fast[k - 2] if fast is not None else self.expander(x, k, dk, mg.dynp('GK%d' % k)))
             feats[k] = ops.normalize(f, 0, dk) if self.norm else f
         self._s1_feat = feats[1]                           # the session's own item rows (normalised): `extra` in-session logits
         if len(self.layers) > 0:

@@ -872,6 +872,177 @@ def gru_expand(x, gru, k, dyn_n=None, dyn_rows=None, combine=True):
                            combine)
 
 
+class GruStepDesc(_ct.Structure):
+    """host mirror of srec_gru_step_desc (include/srec_hg.h)"""
+    _fields_ = ([('np', _ct.c_int), ('d', _ct.c_int), ('n', _ct.c_int * 4), ('k', _ct.c_int * 4), ('t', _ct.c_int * 4),
+                 ('dyn', _ct.c_void_p * 4)] +
+                [(nm, _ct.c_void_p * 4) for nm in ('GI', 'GH', 'bih', 'bhh', 'Hp', 'Hn', 'Hn16', 'gates', 'X', 'out',
+                                                   'dH', 'dout', 'dGI16', 'dGH16', 'dHp', 'dX', 'bias_part')] +
+                [('part_row0', _ct.c_int * 4)])
+
+
+def gru_expand_fast_ok(d, reducer):
+    return PRECISION['matmul'] == 'bf16' and reducer == 'mean' and d % 64 == 0 and d <= 1024 and 256 % (d // 4) == 0
+
+
+class GRUExpandAll(torch.autograd.Function):
+    """SemanticExpander (msgifsr.py:32-45, reducer 'mean') for ALL orders k >= 2 of a batch as one autograd node on the bf16
+    path (csrc/grux.hip + csrc/gemm16.hip): one grouped GEMM and one fused gate kernel per time step serve every order;
+    in the backward the hidden-state gradient is accumulated by the backward-data GEMM itself (beta = 1), the bias
+    gradients come from per-block partial sums of the gate kernels, the weight gradients from row-split products."""
+
+    @staticmethod
+    def forward(ctx, ks, dyn_ns, dyn_rows, *args):
+        P = len(ks)
+        xs = [a.contiguous() for a in args[:P]]
+        params = args[P:]
+        Wih, bih, Whh, bhh = ([params[4 * p + j].contiguous() for p in range(P)] for j in range(4))
+        d = xs[0].shape[1]
+        d3, dev, st = 3 * d, xs[0].device, stream()
+        ns = [x.shape[0] // k for x, k in zip(xs, ks)]
+        w16, wt16 = weights_bf16([w for p in range(P) for w in (Wih[p], Whh[p])])
+        Wih16, Whh16 = w16[0::2], w16[1::2]
+        # bf16 copy of the gathered rows: one pass when the orders' rows are adjacent pieces of one buffer
+        esz = xs[0].element_size()
+        adjacent = all(xs[p + 1].data_ptr() == xs[p].data_ptr() + xs[p].numel() * esz for p in range(P - 1))
+        tot = sum(x.shape[0] for x in xs)
+        x16all = torch.empty(tot, d, device=dev, dtype=torch.bfloat16)
+        offs, o = [], 0
+        for x in xs:
+            offs.append(o)
+            o += x.shape[0]
+        if adjacent:
+            lib.srec_rows_bf16(ptr(xs[0]), d, tot, None, d, ptr(x16all), st)
+        else:
+            for x, o in zip(xs, offs):
+                lib.srec_rows_bf16(ptr(x), d, x.shape[0], None, d, x16all[o:].data_ptr(), st)
+        x16 = [x16all[o:o + x.shape[0]] for x, o in zip(xs, offs)]
+        GI = [torch.empty(x.shape[0], d3, device=dev, dtype=torch.float32) for x in xs]
+        gemm16('nt', [(xs[p].shape[0], d3, d, [(x16[p], Wih16[p])], GI[p], dyn_rows[p]) for p in range(P)], d, d, d3,
+               keep_dead=True)
+        H = [torch.empty(ks[p], ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
+        H16 = [torch.empty(max(ks[p] - 1, 1), ns[p], d, device=dev, dtype=torch.bfloat16) for p in range(P)]
+        gates = [torch.empty(ks[p], ns[p], 4 * d, device=dev, dtype=torch.float32) for p in range(P)]
+        GH = [torch.empty(ns[p], d3, device=dev, dtype=torch.float32) for p in range(P)]
+        outs = [torch.empty(ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
+        for t in range(max(ks)):
+            act = [p for p in range(P) if t < ks[p]]
+            if t > 0:
+                gemm16('nt', [(ns[p], d3, d, [(H16[p][t - 1], Whh16[p])], GH[p], dyn_ns[p]) for p in act], d, d, d3,
+                       keep_dead=True)
+            q = GruStepDesc()
+            q.np, q.d = len(act), d
+            for i, p in enumerate(act):
+                q.n[i], q.k[i], q.t[i], q.dyn[i] = ns[p], ks[p], t, ptr(dyn_ns[p])
+                q.GI[i], q.bih[i], q.bhh[i] = ptr(GI[p]), ptr(bih[p]), ptr(bhh[p])
+                if t > 0:
+                    q.GH[i], q.Hp[i] = ptr(GH[p]), ptr(H[p][t - 1])
+                q.Hn[i], q.gates[i] = ptr(H[p][t]), ptr(gates[p][t])
+                if t < ks[p] - 1:
+                    q.Hn16[i] = ptr(H16[p][t])
+                else:
+                    q.X[i], q.out[i] = ptr(xs[p]), ptr(outs[p])
+            lib.srec_gru_step_fwd(_ct.addressof(q), st)
+        ctx.save_for_backward(*x16, *H, *H16, *gates, *wt16)
+        ctx.meta = (ks, dyn_ns, dyn_rows, ns, d, [tuple(w.shape) for w in Wih])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ks, dyn_ns, dyn_rows, ns, d, _ = ctx.meta
+        P = len(ks)
+        sv = ctx.saved_tensors
+        x16, H, H16, gates = sv[:P], sv[P:2 * P], sv[2 * P:3 * P], sv[3 * P:4 * P]
+        wt16 = sv[4 * P:]
+        WihT16, WhhT16 = wt16[0::2], wt16[1::2]
+        d3, dev, st = 3 * d, H[0].device, stream()
+        gs = [g.contiguous() if g is not None else torch.zeros(ns[p], d, device=dev) for p, g in enumerate(gs)]
+        rows = [ns[p] * ks[p] for p in range(P)]
+        dXall = torch.empty(sum(rows), d, device=dev, dtype=torch.float32)
+        offs, o = [], 0
+        for r in rows:
+            offs.append(o)
+            o += r
+        dX = [dXall[o:o + r] for o, r in zip(offs, rows)]
+        dGI16 = [torch.empty(rows[p], d3, device=dev, dtype=torch.bfloat16) for p in range(P)]
+        dGH16 = [torch.empty(max(ks[p] - 1, 1), ns[p], d3, device=dev, dtype=torch.bfloat16) for p in range(P)]   # slot t - 1
+        rb = max(8, 1024 // d)                           # nodes per block of the step kernel
+        nblk = [(ns[p] + rb - 1) // rb for p in range(P)]
+        part = [torch.empty(ks[p] * nblk[p], 6 * d, device=dev, dtype=torch.float32) for p in range(P)]
+        dHcur = [None] * P
+        for t in range(max(ks) - 1, -1, -1):
+            act = [p for p in range(P) if t < ks[p]]
+            q = GruStepDesc()
+            q.np, q.d = len(act), d
+            nxt = {}
+            for i, p in enumerate(act):
+                q.n[i], q.k[i], q.t[i], q.dyn[i] = ns[p], ks[p], t, ptr(dyn_ns[p])
+                q.gates[i] = ptr(gates[p][t])
+                if t == ks[p] - 1:
+                    q.dout[i], q.dX[i] = ptr(gs[p]), ptr(dX[p])
+                else:
+                    q.dH[i] = ptr(dHcur[p])
+                q.dGI16[i] = ptr(dGI16[p])
+                if t > 0:
+                    q.Hp[i] = ptr(H[p][t - 1])
+                    q.dGH16[i] = ptr(dGH16[p][t - 1])
+                    nxt[p] = torch.empty(ns[p], d, device=dev, dtype=torch.float32)
+                    q.dHp[i] = ptr(nxt[p])
+                q.bias_part[i], q.part_row0[i] = ptr(part[p]), t * nblk[p]
+            lib.srec_gru_step_bwd(_ct.addressof(q), st)
+            if t > 0:          # d h_{t-1} += d(gh_t) W_hh
+                gemm16('nt', [(ns[p], d, d3, [(dGH16[p][t - 1], WhhT16[p])], nxt[p], dyn_ns[p]) for p in act], d3, d3, d,
+                       beta=1.0)
+                for p in act:
+                    dHcur[p] = nxt[p]
+        # d x += d(gi) W_ih  (onto the mean term the last-step kernels wrote)
+        gemm16('nt', [(rows[p], d, d3, [(dGI16[p], WihT16[p])], dX[p], dyn_rows[p]) for p in range(P)], d3, d3, d, beta=1.0)
+        # weight gradients: the reduction runs over rows - split in-kernel into ~512-row pieces (hundreds of short workgroups
+        # instead of a dozen long ones), each writing its own slab; the slabs are summed in fixed order
+        probs, slabs = [], []
+        gWih = [torch.empty(d3, d, device=dev, dtype=torch.float32) for _ in range(P)]
+        gWhh = [torch.empty(d3, d, device=dev, dtype=torch.float32) for _ in range(P)]
+        for p in range(P):
+            nsp = max(1, (rows[p] + 511) // 512)
+            sl = torch.empty(nsp, d3, d, device=dev, dtype=torch.float32) if nsp > 1 else gWih[p].unsqueeze(0)
+            probs.append((d3, d, rows[p], [(dGI16[p], x16[p])], sl, dyn_rows[p], 0, nsp))
+            if nsp > 1:
+                slabs.append((sl, gWih[p]))
+            nsp = max(1, (ns[p] + 511) // 512)
+            sl = torch.empty(nsp, d3, d, device=dev, dtype=torch.float32) if nsp > 1 else gWhh[p].unsqueeze(0)
+            segs = [(dGH16[p][t - 1], H16[p][t - 1]) for t in range(1, ks[p])]
+            probs.append((d3, d, ns[p], segs, sl, dyn_ns[p], 0, nsp))
+            if nsp > 1:
+                slabs.append((sl, gWhh[p]))
+        for i in range(0, len(probs), 16):
+            gemm16('tn', probs[i:i + 16], d3, d, d)
+        for i in range(0, len(slabs), 8):
+            chunk = slabs[i:i + 8]
+            m = len(chunk)
+            arr = _ct.c_void_p * m
+            a_p, a_o = arr(*[sl.data_ptr() for sl, _ in chunk]), arr(*[o_.data_ptr() for _, o_ in chunk])
+            a_r, a_n = (_ct.c_int * m)(*[sl.shape[0] for sl, _ in chunk]), (_ct.c_long * m)(*[o_.numel() for _, o_ in chunk])
+            lib.srec_sum_slabs_multi(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o), st)
+        # bias gradients from the partial rows
+        gb = [torch.empty(6 * d, device=dev, dtype=torch.float32) for _ in range(P)]
+        arr = _ct.c_void_p * P
+        a_p, a_o = arr(*[t_.data_ptr() for t_ in part]), arr(*[t_.data_ptr() for t_ in gb])
+        a_r = (_ct.c_int * P)(*[t_.shape[0] for t_ in part])
+        lib.srec_gru_bias_final(P, _ct.addressof(a_p), _ct.addressof(a_r), 6 * d, _ct.addressof(a_o), st)
+        grads = []
+        for p in range(P):
+            grads += [gWih[p], gb[p][:d3], gWhh[p], gb[p][d3:]]
+        return (None, None, None) + tuple(dX) + tuple(grads)
+
+
+def gru_expand_all(xs, grus, ks, dyn_ns, dyn_rows):
+    """xs[i]: [N_k k, d] gathered rows of order ks[i] (>= 2) -> [N_k, d] expander outputs, all orders in one node"""
+    params = []
+    for g in grus:
+        params += [g.weight_ih_l0, g.bias_ih_l0, g.weight_hh_l0, g.bias_hh_l0]
+    return GRUExpandAll.apply(tuple(ks), tuple(dyn_ns), tuple(dyn_rows), *xs, *params)
+
+
 def gram_combine(X, Hl, k, dyn=None):
     return GramCombine.apply(X, Hl, k, dyn)
 
@@ -1229,18 +1400,21 @@ class GemmGroup16(_ct.Structure):
                 ('c16', _ct.c_int),
                 ('M', _ct.c_int * 16), ('N', _ct.c_int * 16), ('K', _ct.c_int * 16), ('nseg', _ct.c_int * 16),
                 ('A', (_ct.c_void_p * 4) * 16), ('B', (_ct.c_void_p * 4) * 16), ('C', _ct.c_void_p * 16),
-                ('dyn', _ct.c_void_p * 16)]
+                ('dyn', _ct.c_void_p * 16), ('koff', _ct.c_int * 16), ('nsplit', _ct.c_int * 16)]
 
 
-def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False):
+def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, variant=0):
     """one grouped launch of the bf16-in-HBM GEMMs (csrc/gemm16.hip).  probs: [(M, N, K, [(A16, B16), ...], C, dyn)].
     kind 'nt': C [M, N] (+)= sum_s A_s [M, K] B_s [N, K]^T (c16: bf16 output);  'tn': C [M, N] = sum_s A_s [K, M]^T B_s [K, N]
     (reduction over the K rows, clamped by dyn)."""
     assert 0 < len(probs) <= 16
     g = GemmGroup16()
-    g.np, g.lda, g.ldb, g.ldc, g.beta, g.c16 = len(probs), lda, ldb, ldc, beta, int(c16)
-    for p, (M, N, K, segs, C, dyn) in enumerate(probs):
+    g.np, g.lda, g.ldb, g.ldc, g.beta, g.c16 = len(probs), lda, ldb, ldc, beta, int(c16) | (2 if keep_dead else 0) | (variant << 4)
+    for p, pr in enumerate(probs):
+        M, N, K, segs, C, dyn = pr[:6]
         g.M[p], g.N[p], g.K[p], g.nseg[p], g.C[p], g.dyn[p] = M, N, K, len(segs), ptr(C), ptr(dyn)
+        g.koff[p] = pr[6] if len(pr) > 6 else 0          # tn: first reduction row of this piece of a row-split product
+        g.nsplit[p] = pr[7] if len(pr) > 7 else 1        # tn: in-kernel row split, C = [nsplit, M, N] slabs
         for si, (A, B) in enumerate(segs):
             g.A[p][si], g.B[p][si] = ptr(A), ptr(B)
     (lib.srec_gemm16_nt if kind == 'nt' else lib.srec_gemm16_tn)(_ct.addressof(g), stream())
@@ -1433,7 +1607,8 @@ class HGATLayer(torch.autograd.Function):
             probs = [(nc, HD, D, [(xin16(m)[t0:t0 + nc], w16[m])], P[m][o:o + nc], dyn_t)
                      for m in range(nm) for (o, t0, nc, dyn_t) in plan.pieces(m)]
             for i in range(0, len(probs), 16):
-                gemm16('nt', probs[i:i + 16], D, D, HD, c16=True)
+                # rows past a type's live count are never read (every hgat.hip kernel walks the live prefix only)
+                gemm16('nt', probs[i:i + 16], D, D, HD, c16=True, keep_dead=True)
             g16 = (x16, wt16)
         elif grouped:
             gemm_group(0, [(nr, HD, D, [(xin(m)[r0:r0 + nr], params[4 * m])], P[m], dyn)
@@ -1482,17 +1657,25 @@ class HGATLayer(torch.autograd.Function):
         gWs = [torch.empty_like(params[4 * m]) for m in range(nm)]
         convs = (0, 1) if dstate is not None else (None,)
         tgts = None
+        S = 1
         if dstate is not None:
             # every node type is projected by some module of each conv in the usual plans: the grouped GEMM then writes all
             # rows (beta = 0 zeroes rows past the live count) and the buffers need no fill
             full = ctx.grouped and all(any(plan.mod_conv[bm] == cv and bt == t for bm, bt in plan.blocks)
                                        for cv in (0, 1) for t in range(len(plan.types)))
-            tgts = (torch.empty if full else torch.zeros)(2, NT, D, device=dev, dtype=torch.float32)
+            # gemm16: when every (conv, type) is projected by the same number S of modules (intra_k + the shared 'inter'),
+            # each module's product goes to its own partial buffer (S x more, S x shorter reduction loops in flight) and
+            # the merge kernel sums them
+            nsegs = {sum(1 for m in range(nm) if plan.mod_conv[m] == cv and any(bm == m and bt == t for bm, bt in plan.blocks))
+                     for cv in (0, 1) for t in range(len(plan.types))}
+            if ctx.g16 is not None and full and len(nsegs) == 1 and 1 < min(nsegs) <= 4:
+                S = min(nsegs)
+            tgts = (torch.empty if full else torch.zeros)(2, S, NT, D, device=dev, dtype=torch.float32)
         pend = []                                    # gemm16: the two convs' backward-data problems share ONE launch
         for cv in convs:
             # d x of one node type = sum over the modules that project it: the module sum is the K loop (segments).
             # With feature dropout the two convs see differently masked inputs: one masked contribution per conv.
-            tgt = dx if cv is None else tgts[cv]
+            tgt = dx if cv is None else tgts[cv, 0]
             mods = [m for m in range(nm) if cv is None or plan.mod_conv[m] == cv]
             if ctx.grouped:
                 probs = []
@@ -1501,15 +1684,20 @@ class HGATLayer(torch.autograd.Function):
                             if plan.modules[m][0] <= t0 and t0 + nc <= plan.modules[m][0] + plan.modules[m][1]
                             and any(bm == m and bt == t for bm, bt in plan.blocks)]
                     if segs:
-                        probs.append((nc, D, HD, segs, tgt[t0:t0 + nc], dyn_t))
+                        probs.append((nc, D, HD, segs, tgt[t0:t0 + nc], dyn_t, t0))
                 beta = 0.0 if (cv is not None and full) else 1.0
-                if probs and ctx.g16 is not None:
+                if probs and ctx.g16 is not None and S > 1:
+                    wt16 = ctx.g16[1]
+                    for (M_, N_, K_, segs_, C_, dyn_, t0) in probs:
+                        for j, (A_, m_) in enumerate(segs_):
+                            pend.append(((M_, N_, K_, [(A_, wt16[m_])], tgts[cv, j, t0:t0 + M_], dyn_), 0.0))
+                elif probs and ctx.g16 is not None:
                     wt16 = ctx.g16[1]
                     pend += [((M_, N_, K_, [(A_, wt16[m_]) for A_, m_ in segs_], C_, dyn_), beta)
-                             for (M_, N_, K_, segs_, C_, dyn_) in probs]
+                             for (M_, N_, K_, segs_, C_, dyn_, _t0) in probs]
                 elif probs:
                     probs = [(M_, N_, K_, [(A_, params[4 * m_]) for A_, m_ in segs_], C_, dyn_)
-                             for (M_, N_, K_, segs_, C_, dyn_) in probs]
+                             for (M_, N_, K_, segs_, C_, dyn_, _t0) in probs]
                     gemm_group(1, probs, HD, D, D, beta=beta, a16=True)
             else:
                 for m in mods:
@@ -1517,11 +1705,11 @@ class HGATLayer(torch.autograd.Function):
                     gemm_nn(dP[m], _rows(params[4 * m]), tgt[r0:r0 + nr], dyn, 1 if dyn is not None else 0, beta=1.0)
         while pend:
             beta = pend[0][1]
-            batch = [pr for pr, b in pend if b == beta][:8]
+            batch = [pr for pr, b in pend if b == beta][:16]
             pend = [(pr, b) for pr, b in pend if not any(pr is q for q in batch)]
             gemm16('nt', batch, HD, HD, D, beta=beta)
         if dstate is not None:
-            lib.srec_hg_drop_merge(ptr(tgts), ptr(dstate[4]), NT * D, ptr(dx), stream())
+            lib.srec_hg_drop_merge(ptr(tgts), S, ptr(dstate[4]), NT * D, ptr(dx), stream())
         if ctx.g16 is not None:
             # weight gradients, one balanced problem per (module, node type): a module that spans several types (the shared
             # 'inter' one) writes one slab per type, summed in fixed order afterwards

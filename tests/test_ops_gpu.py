@@ -859,3 +859,60 @@ def test_gemm16_tn(dev):
     ops.gemm16('tn', [(2048, 256, 1000, [(As[0], Bs[0])], Cs[0], None), (2048, 256, 1300, [(As[1], Bs[1])], Cs[1], None)], 2048, 256, 256)
     for A, B, C in zip(As, Bs, Cs):
         close(C, A.float().t() @ B.float(), what='tn16 grouped', rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize('d,padded', [(64, False), (256, True), (128, True)])
+def test_gru_expand_all_matches_per_order_fp32_path(dev, d, padded):
+    """csrc/grux.hip + gemm16.hip (all orders per launch, bf16 operands) against the per-order exact-fp32 GRUExpand node
+    (itself pinned by the msgifsr_K2 / K3 fixtures): outputs and every gradient at the bf16 tolerance of SURVEY 8(c)
+    (norm-wise 2e-2); capacity-padded nodes produce exact zeros and receive no gradient."""
+    ops = _ops()
+    torch.manual_seed(d)
+    ks, caps, lives = [2, 3], [300, 280], [300, 280]
+    if padded:
+        caps, lives = [512, 512], [401, 333]
+    grus = [torch.nn.GRU(d, d, 1, True, True).to(dev) for _ in ks]
+    for g in grus:
+        for w in g.parameters():
+            w.data.uniform_(-1 / d ** 0.5, 1 / d ** 0.5)
+    G = sum(c * k for c, k in zip(caps, ks))
+    rows = torch.randn(G, d, device=dev) * 0.5
+    offs = [0, caps[0] * ks[0]]
+    dyn_n = [torch.tensor([l], device=dev, dtype=torch.int32) if padded else None for l in lives]
+    dyn_r = [torch.tensor([l * k], device=dev, dtype=torch.int32) if padded else None for l, k in zip(lives, ks)]
+    if padded:
+        for o, c, l, k in zip(offs, caps, lives, ks):
+            rows[o + l * k:o + c * k] = 0
+    gout = [torch.randn(c, d, device=dev) for c in caps]
+
+    def run(fast):
+        r = rows.clone().requires_grad_()
+        xs = [r[o:o + c * k] for o, c, k in zip(offs, caps, ks)]
+        for g in grus:
+            g.zero_grad()
+        if fast:
+            outs = ops.gru_expand_all(xs, grus, ks, dyn_n, dyn_r)
+        else:
+            outs = [ops.gru_expand(x, g, k, dn, dr) for x, g, k, dn, dr in zip(xs, grus, ks, dyn_n, dyn_r)]
+        torch.autograd.backward(list(outs), gout)
+        return [o.detach().clone() for o in outs], r.grad.clone(), [[p.grad.clone() for p in g.parameters()] for g in grus]
+
+    ref = run(False)
+    ops.set_precision('bf16')
+    try:
+        assert ops.gru_expand_fast_ok(d, 'mean')
+        got = run(True)
+    finally:
+        ops.set_precision('fp32')
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
+    for p in range(2):
+        assert rel(got[0][p], ref[0][p]) < 1e-2, ('out', p, rel(got[0][p], ref[0][p]))
+        if padded:
+            assert got[0][p][lives[p]:].abs().max().item() == 0.0
+    assert rel(got[1], ref[1]) < 2e-2, ('dx', rel(got[1], ref[1]))
+    if padded:
+        for o, c, l, k in zip(offs, caps, lives, ks):
+            assert got[1][o + l * k:o + c * k].abs().max().item() == 0.0
+    for p in range(2):
+        for a, b, nm in zip(got[2][p], ref[2][p], ('Wih', 'Whh', 'bih', 'bhh')):
+            assert rel(a, b) < 2e-2, (p, nm, rel(a, b))

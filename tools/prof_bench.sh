@@ -11,4 +11,6 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$t
 grep '^{' $out/${tag}_bench.log | tail -1 > $out/${tag}_bench.json
 f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$f" $out/${tag}_kernel_stats.csv
+t=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
+[ -n "$t" ] && python /root/repo/tools/step_trace.py "$t" > $out/${tag}_step_trace.txt
 python /root/repo/tools/step_breakdown.py $out/${tag}_kernel_stats.csv 27 | head -60
