@@ -91,6 +91,15 @@ int srec_gather_rows(const float* src, int ld_src, const int* idx, float* out, i
                      const int* dyn, int d, void* stream);
 int srec_scatter_add_sorted(const float* g, int ld_g, const int* items, const int* ptr, const int* pos, float* dst,
                             int ld_dst, int u_cap, const int* dyn, int d, int accumulate, void* stream);
+/* the lookup with its feature dropout fused (msgifsr.py:247 `dropout(embedding(iid))`): out[r, c] *= mask(r * d + c), mask =
+ * 1 / (1 - p) with probability 1 - p else 0, from a counter-based hash keyed by (seed, *counter, salt) - counter (nullable) is a
+ * device int that is constant within a training step and changes between steps (the optimizer's step count).  The backward
+ * re-derives the same mask while it sums the gradient rows (g must be contiguous: ld_g == d). */
+int srec_gather_rows_drop(const float* src, int ld_src, const int* idx, float* out, int ld_out, int n_cap, const int* dyn,
+                          int d, float p, int seed, const int* counter, int salt, void* stream);
+int srec_scatter_add_sorted_drop(const float* g, int ld_g, const int* items, const int* ptr, const int* pos, float* dst,
+                                 int ld_dst, int u_cap, const int* dyn, int d, int accumulate, float p, int seed,
+                                 const int* counter, int salt, void* stream);
 /* Embedding(max_norm) in-place renorm, idx distinct or NULL (= all rows): lessr.py:126 msgifsr.py:162 */
 int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, const int* dyn, int d, float max_norm,
                      void* stream);
@@ -256,16 +265,15 @@ int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, i
  *        d_attn_l / d_attn_r / d_bias of every module.  ws: srec_hg_ws_floats() floats of scratch. */
 int srec_hg_ws_floats(const void* desc, long* n_floats);
 int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg, void* stream);
-/* feature-dropout glue of a layer call in one pass each (GATConv feat_drop, gatconv.py:268-283): from uniform draws u
- * [2, rows, D] (one mask per conv) and cnt [2, rows] (relation instances of the conv into each row): ms = mask / (1-p),
+/* feature-dropout glue of a layer call in one pass each (GATConv feat_drop, gatconv.py:268-283): masks from the counter-based
+ * hash of srec_gather_rows_drop (one mask per conv) and cnt [2, rows] (relation instances of the conv into each row): ms = mask / (1-p),
  * xc = x * ms (the convs' dropped inputs), rm = cnt0 ms0 + cnt1 ms1, xres = x * rm (summed identity residuals);
  * backward: dx += (sum_s t[0][s]) * ms0 + (sum_s t[1][s]) * ms1 (the convs' masked data gradients, t [2, S, n]: S partial sums
  * per conv, one per GAT module projecting the row's node type). */
-int srec_hg_drop_prep(const float* x, const float* u, const float* cnt, int rows, int D, float p, float* ms, float* xc,
-                      float* rm, float* xres, void* stream);
+/* ... and, in the same launch, the attention-dropout multipliers (gatconv.py:300) mk [na] = 0 or 1 / (1 - pa) (pa = 0: none) */
+int srec_hg_drop_prep(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter, int salt,
+                      float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk, void* stream);
 int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, void* stream);
-/* attention-dropout multipliers (gatconv.py:300): out[i] = u[i] >= p ? 1/(1-p) : 0 from uniform draws u */
-int srec_mask_scale(const float* u, long n, float p, float* out, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
                 int ld_dx, float* ws, void* stream);
 

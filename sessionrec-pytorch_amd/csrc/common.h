@@ -57,4 +57,23 @@ static __device__ __forceinline__ int dyn_count(const int* dyn, int n_static) {
 }
 static __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// ---- dropout masks without a generator state: a counter-based hash.  key = f(host seed, per-step device counter, call-site
+// salt); element i of the masked tensor keeps its value (scaled by 1 / (1 - p)) iff hash(key, i) / 2^24 >= p.  The forward
+// and the backward of a step recompute the same mask from the same (key, i) - nothing is stored, nothing is exchanged with
+// the framework's Philox state (whose two per-replay fill kernels a captured step would otherwise carry).  The step counter
+// is the optimizer's device-side step count (NULL: 0): constant inside a step, different in the next, replay-safe.
+struct srec_rng { unsigned seed; const int* counter; unsigned salt; float p; };
+__device__ __forceinline__ unsigned srec_hash32(unsigned x) {          // "lowbias32" integer finaliser
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned srec_rng_key(const srec_rng& r) {
+    const unsigned c = r.counter != nullptr ? (unsigned)*r.counter : 0u;
+    return srec_hash32(r.seed ^ srec_hash32(c * 0x9E3779B9u + r.salt * 0x85EBCA6Bu + 0x165667B1u));
+}
+__device__ __forceinline__ float srec_keep(unsigned key, unsigned idx, float p, float scale) {
+    const unsigned h = srec_hash32(key ^ (idx * 0x9E3779B1u + 0x7F4A7C15u));
+    return (float)(h >> 8) * (1.f / 16777216.f) >= p ? scale : 0.f;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

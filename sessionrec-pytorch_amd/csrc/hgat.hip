@@ -885,19 +885,30 @@ namespace {
 //   xc[c] = x * ms[c]                  the dropped inputs of the conv's GAT modules
 //   rm    = cnt[0] * ms[0] + cnt[1] * ms[1]      per-element residual scale (cnt[c][row] = instances of conv c into the row)
 //   xres  = x * rm
-__global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ cnt,
-                                    long n, int D, long rows, float p, float* __restrict__ ms, float* __restrict__ xc,
-                                    float* __restrict__ rm, float* __restrict__ xres) {
+// blocks [0, nb1): feature masks of the two convs and the masked inputs; blocks [nb1, ...): attention-dropout multipliers
+// mk [na] (all relation instances back to back).  Masks come from the counter-based hash of common.h.
+__global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __restrict__ cnt, long n, int D, long rows,
+                                    float p, srec_rng rng, float* __restrict__ ms, float* __restrict__ xc,
+                                    float* __restrict__ rm, float* __restrict__ xres, int nb1, float pa, long na,
+                                    float* __restrict__ mk) {
+    const unsigned key = srec_rng_key(rng);
+    if ((int)blockIdx.x >= nb1) {
+        const long j = ((long)((int)blockIdx.x - nb1) * blockDim.x + threadIdx.x) * 4;
+        const float sa = 1.f / (1.f - pa);
+        for (int e = 0; e < 4; ++e)
+            if (j + e < na) mk[j + e] = srec_keep(key ^ 0xA5A5A5A5u, (unsigned)(j + e), pa, sa);
+        return;
+    }
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    const float sc = 1.f / (1.f - p);
+    const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const long row = i / D;
     const float c0 = cnt[row], c1 = cnt[rows + row];
     const float4 xv = *reinterpret_cast<const float4*>(x + i);
-    const float4 u0 = *reinterpret_cast<const float4*>(u + i), u1 = *reinterpret_cast<const float4*>(u + n + i);
     float4 m0, m1;
-    m0.x = u0.x >= p ? sc : 0.f; m0.y = u0.y >= p ? sc : 0.f; m0.z = u0.z >= p ? sc : 0.f; m0.w = u0.w >= p ? sc : 0.f;
-    m1.x = u1.x >= p ? sc : 0.f; m1.y = u1.y >= p ? sc : 0.f; m1.z = u1.z >= p ? sc : 0.f; m1.w = u1.w >= p ? sc : 0.f;
+    const unsigned i0 = (unsigned)i, i1 = (unsigned)(n + i);
+    m0.x = srec_keep(key, i0, p, sc); m0.y = srec_keep(key, i0 + 1, p, sc); m0.z = srec_keep(key, i0 + 2, p, sc); m0.w = srec_keep(key, i0 + 3, p, sc);
+    m1.x = srec_keep(key, i1, p, sc); m1.y = srec_keep(key, i1 + 1, p, sc); m1.z = srec_keep(key, i1 + 2, p, sc); m1.w = srec_keep(key, i1 + 3, p, sc);
     *reinterpret_cast<float4*>(ms + i) = m0;
     *reinterpret_cast<float4*>(ms + n + i) = m1;
     *reinterpret_cast<float4*>(xc + i) = make_float4(xv.x * m0.x, xv.y * m0.y, xv.z * m0.z, xv.w * m0.w);
@@ -928,32 +939,19 @@ __global__ void hg_drop_merge_kernel(const float* __restrict__ t, int S, const f
 
 }  // namespace
 
-// x [rows, D] contiguous, u [2, rows, D] uniform draws, cnt [2, rows]; outputs ms / xc [2, rows, D], rm / xres [rows, D].
-extern "C" int srec_hg_drop_prep(const float* x, const float* u, const float* cnt, int rows, int D, float p, float* ms,
-                                 float* xc, float* rm, float* xres, void* stream) {
+// x [rows, D] contiguous, cnt [2, rows]; outputs ms / xc [2, rows, D], rm / xres [rows, D] and (pa > 0) the attention-dropout
+// multipliers mk [na] - all masks from the counter-based hash keyed by (seed, *counter, salt).
+extern "C" int srec_hg_drop_prep(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter,
+                                 int salt, float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk,
+                                 void* stream) {
     if (rows <= 0) return 0;
-    if (D <= 0 || (D & 3) || p < 0.f || p >= 1.f) return SREC_BAD_ARG;
+    if (D <= 0 || (D & 3) || p < 0.f || p >= 1.f || pa < 0.f || pa >= 1.f) return SREC_BAD_ARG;
     const long n = (long)rows * D;
-    hipLaunchKernelGGL(hg_drop_prep_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, u,
-                       cnt, n, D, (long)rows, p, ms, xc, rm, xres);
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
-
-namespace {
-__global__ void mask_scale_kernel(const float* __restrict__ u, long n, float p, float sc, float* __restrict__ out) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = u[i] >= p ? sc : 0.f;
-}
-}  // namespace
-
-// out[i] = u[i] >= p ? 1 / (1 - p) : 0  - the attention-dropout multipliers of a layer call from uniform draws (one pass
-// instead of compare / cast / scale)
-extern "C" int srec_mask_scale(const float* u, long n, float p, float* out, void* stream) {
-    if (n <= 0) return 0;
-    if (p < 0.f || p >= 1.f) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(mask_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, n, p,
-                       1.f / (1.f - p), out);
+    if (2 * n > 0xffffffffL || na > 0xffffffffL) return SREC_BAD_ARG;
+    const int nb1 = (int)((n / 4 + 255) / 256);
+    const int nb2 = (pa > 0.f && na > 0 && mk != nullptr) ? (int)(((na + 3) / 4 + 255) / 256) : 0;
+    hipLaunchKernelGGL(hg_drop_prep_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, (hipStream_t)stream, x, cnt, n, D,
+                       (long)rows, p, srec_rng{(unsigned)seed, counter, (unsigned)salt, p}, ms, xc, rm, xres, nb1, pa, na, mk);
     SREC_LAUNCH_CHECK();
     return 0;
 }

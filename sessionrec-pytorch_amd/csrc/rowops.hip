@@ -15,17 +15,29 @@ namespace {
 
 constexpr int WPB = 4;   // waves (rows) per 256-thread block
 
+// rng.p > 0: feature dropout fused into the lookup (msgifsr.py:247 dropout(embedding(iid))): element (row, c) of the
+// OUTPUT is masked with index row * d + c
 __global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, const int* __restrict__ idx,
                                    float* __restrict__ out, int ld_out, int n_cap, const int* __restrict__ dyn,
-                                   int d) {
+                                   int d, srec_rng rng) {
     const int row = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n_cap) return;
     const int n = dyn_count(dyn, n_cap);
     const int s = row < n ? idx[row] : -1;            // negative index (row owned by another shard) -> zero row
     const bool live = s >= 0;
+    const bool drop = rng.p > 0.f;
+    const unsigned key = drop ? srec_rng_key(rng) : 0u;
+    const float sc = drop ? 1.f / (1.f - rng.p) : 1.f;
     for (int c = lane * 4; c < d; c += 256) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) v = *reinterpret_cast<const float4*>(src + (size_t)s * ld_src + c);
+        if (live) {
+            v = *reinterpret_cast<const float4*>(src + (size_t)s * ld_src + c);
+            if (drop) {
+                const unsigned i0 = (unsigned)row * (unsigned)d + (unsigned)c;
+                v.x *= srec_keep(key, i0, rng.p, sc); v.y *= srec_keep(key, i0 + 1, rng.p, sc);
+                v.z *= srec_keep(key, i0 + 2, rng.p, sc); v.w *= srec_keep(key, i0 + 3, rng.p, sc);
+            }
+        }
         *reinterpret_cast<float4*>(out + (size_t)row * ld_out + c) = v;
     }
 }
@@ -34,11 +46,33 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, co
 __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g, const int* __restrict__ items,
                                           const int* __restrict__ ptr, const int* __restrict__ pos,
                                           float* __restrict__ dst, int ld_dst, int u_cap,
-                                          const int* __restrict__ dyn, int d, int accumulate) {
+                                          const int* __restrict__ dyn, int d, int accumulate, srec_rng rng) {
     const int u = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (u >= dyn_count(dyn, u_cap)) return;
     const int beg = ptr[u], end = ptr[u + 1], item = items[u];
     if (item < 0) return;                             // row owned by another shard
+    if (rng.p > 0.f) {
+        // backward of the fused lookup dropout: the gradient row of position p is masked with the forward's mask
+        const unsigned key = srec_rng_key(rng);
+        const float sc = 1.f / (1.f - rng.p);
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = beg; e < end; ++e) {
+                const int pp = pos[e];
+                const float4 v = *reinterpret_cast<const float4*>(g + (size_t)pp * ld_g + c);
+                const unsigned i0 = (unsigned)pp * (unsigned)d + (unsigned)c;
+                s.x += v.x * srec_keep(key, i0, rng.p, sc); s.y += v.y * srec_keep(key, i0 + 1, rng.p, sc);
+                s.z += v.z * srec_keep(key, i0 + 2, rng.p, sc); s.w += v.w * srec_keep(key, i0 + 3, rng.p, sc);
+            }
+            float4* o = reinterpret_cast<float4*>(dst + (size_t)item * ld_dst + c);
+            if (accumulate) {
+                const float4 t = *o;
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            *o = s;
+        }
+        return;
+    }
     for (int c = lane * 4; c < d; c += 256) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         int e = beg;
@@ -342,7 +376,19 @@ extern "C" int srec_gather_rows(const float* src, int ld_src, const int* idx, fl
     if (n_cap <= 0) return 0;
     if (bad_row_args(d, ld_src) || (ld_out & 3)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx,
-                       out, ld_out, n_cap, dyn, d);
+                       out, ld_out, n_cap, dyn, d, srec_rng{0u, nullptr, 0u, 0.f});
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ... with feature dropout (probability p, mask key from (seed, *counter, salt): common.h) fused into the written rows
+extern "C" int srec_gather_rows_drop(const float* src, int ld_src, const int* idx, float* out, int ld_out, int n_cap,
+                                     const int* dyn, int d, float p, int seed, const int* counter, int salt,
+                                     void* stream) {
+    if (n_cap <= 0) return 0;
+    if (bad_row_args(d, ld_src) || (ld_out & 3) || p < 0.f || p >= 1.f || (long)n_cap * d > 0xffffffffL) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx,
+                       out, ld_out, n_cap, dyn, d, srec_rng{(unsigned)seed, counter, (unsigned)salt, p});
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -353,7 +399,20 @@ extern "C" int srec_scatter_add_sorted(const float* g, int ld_g, const int* item
     if (u_cap <= 0) return 0;
     if (bad_row_args(d, ld_g) || (ld_dst & 3)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(scatter_add_sorted_kernel, dim3(cdiv(u_cap, WPB)), dim3(256), 0, (hipStream_t)stream, g, ld_g,
-                       items, ptr, pos, dst, ld_dst, u_cap, dyn, d, accumulate);
+                       items, ptr, pos, dst, ld_dst, u_cap, dyn, d, accumulate, srec_rng{0u, nullptr, 0u, 0.f});
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ... reading g through the dropout mask of srec_gather_rows_drop (same p / seed / counter / salt; position index = pos)
+extern "C" int srec_scatter_add_sorted_drop(const float* g, int ld_g, const int* items, const int* ptr, const int* pos,
+                                            float* dst, int ld_dst, int u_cap, const int* dyn, int d, int accumulate,
+                                            float p, int seed, const int* counter, int salt, void* stream) {
+    if (u_cap <= 0) return 0;
+    if (bad_row_args(d, ld_g) || (ld_dst & 3) || p < 0.f || p >= 1.f || ld_g != d) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(scatter_add_sorted_kernel, dim3(cdiv(u_cap, WPB)), dim3(256), 0, (hipStream_t)stream, g, ld_g,
+                       items, ptr, pos, dst, ld_dst, u_cap, dyn, d, accumulate,
+                       srec_rng{(unsigned)seed, counter, (unsigned)salt, p});
     SREC_LAUNCH_CHECK();
     return 0;
 }

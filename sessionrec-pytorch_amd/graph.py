@@ -43,6 +43,17 @@ class GraphedTrainStep:
             self._restore(model, optimizer, snap_p, snap_b, snap_o)
         # ---- capture
         optimizer.zero_grad(set_to_none=True)
+        # cosine-scored models: every replayed step takes its column scale 12 / ||E_v|| from the fused Adam pass of the step
+        # before.  Compute the FIRST one here, outside the graph, so the captured step does not carry a row_invnorm pass it
+        # would then replay (and overwrite Adam's result with the same values) for ever.
+        ms = model.__dict__.get('_srec_state')
+        if ms is not None and getattr(model, '_cosine', lambda: None)() is not None and hasattr(model, '_col_scale'):
+            with torch.no_grad():
+                if hasattr(model, '_prepare_table'):
+                    model._prepare_table()               # Embedding(max_norm) renorm first: the scale is that of the rows read
+                ms['cs_fresh'] = False
+                model._col_scale(ms)
+            ms['cs_fresh'] = ms.get('cs') is not None
         import os
         try:                                             # the hipGraph_t stays queryable (node_counts); SREC_KEEP_GRAPH=0 opts out
             self.graph = torch.cuda.CUDAGraph(keep_graph=os.environ.get('SREC_KEEP_GRAPH', '1') != '0')

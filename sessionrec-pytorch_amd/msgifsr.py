@@ -137,7 +137,9 @@ class MSHGNN(nn.Module):
                         blocks.append((m, k - 1))
                 insts.append((m, blk_id[(m, src_t)], blk_id[(m, dst_t)], self._graph(mg, name, ci == 1)))
         slope = self.conv1.mods['intra1'].negative_slope
-        return ops.HgPlan(8, D, slope, mg.B, mg.dynp('B'), types, mods, blocks, insts, mod_conv), params
+        plan = ops.HgPlan(8, D, slope, mg.B, mg.dynp('B'), types, mods, blocks, insts, mod_conv)
+        plan.layer_id = getattr(self, '_layer_id', 0)
+        return plan, params
 
     def forward_stacked(self, mg, x):
         """x: [NT, d] node features of all orders stacked (order-1 rows first) -> [NT, d]; one batched pass"""
@@ -231,6 +233,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         self.layers = nn.ModuleList([
             MSHGNN(embedding_dim, embedding_dim, dropout=dropout, order=order, activation=nn.PReLU(embedding_dim))
             for _ in range(num_layers)])
+        for li, layer in enumerate(self.layers):
+            layer._layer_id = li
         self.readout = AttnReadout(embedding_dim, embedding_dim, embedding_dim, feat_drop=dropout, order=order)
         self.feat_drop = nn.Dropout(dropout)
         self.fc_sr = nn.ModuleList([nn.Linear(2 * embedding_dim, embedding_dim, bias=False) for _ in range(order)])
@@ -295,8 +299,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         W = self._table()
         d = self.embedding_dim
         rows = self._lookup(mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
-                            None, mg.dynp('U'))            # padded slots of gidx are -1 -> zero rows
-        rows = self.feat_drop(rows)
+                            None, mg.dynp('U'), drop=self.feat_drop)     # padded slots of gidx are -1 -> zero rows; the
+        #                                                                  feature dropout of msgifsr.py:247 rides in the gather
         feats = {}
         dB = mg.dynp('B')
         ncap = mg.meta['ncap']                             # block size of order k (capacity in padded layouts)

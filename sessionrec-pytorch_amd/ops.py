@@ -199,6 +199,18 @@ def linear_cat(xs, weight, bias=None, dyn=None, exact=False):
     return LinearCat.apply(weight, bias, dyn, exact, *xs)
 
 
+# ------------------------------------------------------------------------------------------ dropout masks
+RNG_COUNTER = {}     # str(device) -> int32[1] device tensor: the optimizer's step count (FusedAdam registers it)
+
+
+def rng_args(device):
+    """(seed, counter pointer) of the counter-based dropout masks (csrc/common.h srec_rng): the host seed follows
+    torch.manual_seed, the device counter is constant inside a training step and changes between steps (also under
+    hipGraph replay, where the kernel arguments are frozen)."""
+    c = RNG_COUNTER.get(str(device))
+    return int(torch.initial_seed() & 0x7fffffff), (c.data_ptr() if c is not None else None)
+
+
 class TableGrad:
     """Dense gradient buffer of the item table, shared by the scoring backward (writes every row)
     and the embedding-lookup backward (adds its rows in place): no dense+dense autograd sum."""
@@ -213,11 +225,19 @@ class EmbeddingLookup(torch.autograd.Function):
     into TableGrad when the fused loss owns the table gradient, else returned as a dense grad."""
 
     @staticmethod
-    def forward(ctx, table, idx, uniq, tgrad, dyn_n, dyn_u):
+    def forward(ctx, table, idx, uniq, tgrad, dyn_n, dyn_u, drop=None):
         n = idx.numel()
         d = table.shape[1]
         out = torch.empty(n, d, device=table.device, dtype=torch.float32)
-        lib.srec_gather_rows(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, ptr(dyn_n), d, stream())
+        ctx.drop = None
+        if drop is not None and drop[0] > 0:
+            # feature dropout fused into the lookup (msgifsr.py:247): mask recomputed by the backward, nothing stored
+            seed, cnt = rng_args(table.device)
+            ctx.drop = (float(drop[0]), seed, cnt, int(drop[1]))
+            lib.srec_gather_rows_drop(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, ptr(dyn_n), d, ctx.drop[0],
+                                      seed, cnt, ctx.drop[3], stream())
+        else:
+            lib.srec_gather_rows(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, ptr(dyn_n), d, stream())
         ctx.uniq, ctx.tgrad, ctx.dyn_u, ctx.shape = uniq, tgrad, dyn_u, tuple(table.shape)
         return out
 
@@ -227,6 +247,15 @@ class EmbeddingLookup(torch.autograd.Function):
         tg = ctx.tgrad
         g = _rows(g)
         V, d = ctx.shape
+        if ctx.drop is not None:
+            g = g.contiguous()
+            pdrop, seed, cnt, salt = ctx.drop
+
+            def first_level(gp, ldg, it, pt, ps, dst, ldd, ucap, dyn, acc):
+                lib.srec_scatter_add_sorted_drop(gp, ldg, it, pt, ps, dst, ldd, ucap, dyn, d, acc, pdrop, seed, cnt, salt, stream())
+        else:
+            def first_level(gp, ldg, it, pt, ps, dst, ldd, ucap, dyn, acc):
+                lib.srec_scatter_add_sorted(gp, ldg, it, pt, ps, dst, ldd, ucap, dyn, d, acc, stream())
         if tg is not None:
             dst, acc, ret = tg.buf, 1, None
         else:
@@ -238,18 +267,18 @@ class EmbeddingLookup(torch.autograd.Function):
             C = chunk_ptr.numel() - 1
             part = torch.empty(max(C, 1), d, device=g.device, dtype=torch.float32)
             ar = _arange(C + 1, g.device)
-            lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, d,
-                                        0, stream())          # padded chunks are empty segments -> zero rows
-            lib.srec_scatter_add_sorted(ptr(part), d, ptr(items), ptr(cptr), ptr(ar), ptr(dst), dst.stride(0),
+            first_level(ptr(g), _ld(g), ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, 0)   # padded chunks are
+            lib.srec_scatter_add_sorted(ptr(part), d, ptr(items), ptr(cptr), ptr(ar), ptr(dst), dst.stride(0),   # empty segments
                                         items.numel(), ptr(ctx.dyn_u), d, acc, stream())
         else:
-            lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(items), ptr(uptr), ptr(upos), ptr(dst), dst.stride(0),
-                                        items.numel(), ptr(ctx.dyn_u), d, acc, stream())
-        return ret, None, None, None, None, None
+            first_level(ptr(g), _ld(g), ptr(items), ptr(uptr), ptr(upos), ptr(dst), dst.stride(0), items.numel(),
+                        ptr(ctx.dyn_u), acc)
+        return ret, None, None, None, None, None, None
 
 
-def embedding_lookup(table, idx, uniq, tgrad=None, dyn_n=None, dyn_u=None):
-    return EmbeddingLookup.apply(table, idx, uniq, tgrad, dyn_n, dyn_u)
+def embedding_lookup(table, idx, uniq, tgrad=None, dyn_n=None, dyn_u=None, drop=None):
+    """drop = (p, salt): feature dropout of the looked-up rows fused into the gather (and its backward)"""
+    return EmbeddingLookup.apply(table, idx, uniq, tgrad, dyn_n, dyn_u, drop)
 
 
 class RowGather(torch.autograd.Function):
@@ -1454,6 +1483,7 @@ class HgPlan:
 
     def __init__(self, H, D, slope, B, dynB, types, modules, blocks, insts, mod_conv=None):
         self.mod_conv = mod_conv if mod_conv is not None else [0] * len(modules)      # 0: conv1, 1: conv2 (reversed graph)
+        self.layer_id = 0                                 # dropout-mask salt: distinct per MSHGNN layer of a model
         self.H, self.D, self.slope, self.B, self.dynB = H, D, slope, B, dynB
         self.types, self.modules, self.blocks, self.insts = types, modules, blocks, insts
         assert len(types) <= 4 and len(modules) <= 8 and len(blocks) <= 16 and len(insts) <= 16
@@ -1570,21 +1600,23 @@ class HGATLayer(torch.autograd.Function):
         dstate = None
         if drop is not None and (drop[0] > 0 or drop[1] > 0):
             pf, pa = drop
-            # both convs' masks from ONE random draw; the per-row instance counts depend on the plan only (cached)
-            u = torch.rand(2, NT, D, device=dev) if pf > 0 else torch.ones(2, NT, D, device=dev)
+            # both convs' feature masks and every instance's attention mask in ONE launch (counter-based hash: no generator
+            # state, replay-safe); the per-row instance counts depend on the plan only (cached)
             cnt = _inst_counts(plan, NT, dev)
-            ms, xcs = torch.empty_like(u), torch.empty_like(u)
+            ms = torch.empty(2, NT, D, device=dev, dtype=torch.float32)
+            xcs = torch.empty_like(ms)
             rm, xres = torch.empty(NT, D, device=dev), torch.empty(NT, D, device=dev)
             xcont = x.contiguous()
-            lib.srec_hg_drop_prep(ptr(xcont), ptr(u), ptr(cnt), NT, D, float(pf), ptr(ms), ptr(xcs), ptr(rm), ptr(xres), stream())
-            xc = [xcs[0], xcs[1]]
-            mk = None
+            mk, allm, na = None, None, 0
             if pa > 0:
                 sizes = [max(gr[4].numel(), 1) * H for (_, _, _, gr) in plan.insts]
-                ua = torch.rand(sum(sizes), device=dev)
-                allm = torch.empty_like(ua)
-                lib.srec_mask_scale(ptr(ua), ua.numel(), float(pa), ptr(allm), stream())
+                na = sum(sizes)
+                allm = torch.empty(na, device=dev, dtype=torch.float32)
                 mk = list(torch.split(allm, sizes))
+            seed, rc = rng_args(dev)
+            lib.srec_hg_drop_prep(ptr(xcont), ptr(cnt), NT, D, float(pf), seed, rc, 101 + 2 * plan.layer_id, ptr(ms), ptr(xcs),
+                                  ptr(rm), ptr(xres), float(pa), na, ptr(allm), stream())
+            xc = [xcs[0], xcs[1]]
             dstate = (xc, xres, rm, mk, ms)
             if DROP_TAP is not None:
                 DROP_TAP.append(dict(ms=ms.clone(), mk=[m.clone() for m in mk] if mk is not None else None))

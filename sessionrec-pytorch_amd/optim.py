@@ -68,10 +68,14 @@ class FusedAdam(torch.optim.Optimizer):
         captured step itself (srec_adam_hyper), so a replayed graph or a host running ahead cannot mix steps."""
         key = (gi, off)
         if key not in self._hyper:
+            from . import ops
             self._hyper[key] = dict(counter=torch.zeros(1, dtype=torch.int32, device=device),
                                     cfg=torch.zeros(5, dtype=torch.float64, device=device),
                                     hyper=torch.zeros(8, dtype=torch.float32, device=device), cfg_host=None,
                                     fresh=True)
+            if key == (0, 0) or str(device) not in ops.RNG_COUNTER:
+                # the dropout masks of a step are keyed by the optimizer's device-side step count (ops.rng_args)
+                ops.RNG_COUNTER[str(device)] = self._hyper[key]['counter']
         return self._hyper[key]
 
     def _cfg(self, group):

@@ -73,11 +73,16 @@ class _ScoringMixin:
     shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
     graph_capable = False      # True: every kernel of the step reads its live extents from the padded batch (hipGraph replay)
 
-    def _lookup(self, idx, uniq, tgrad, dyn_n=None, dyn_u=None):
-        """item rows for the batch: local gather, or the collective lookup when the table is sharded"""
+    def _lookup(self, idx, uniq, tgrad, dyn_n=None, dyn_u=None, drop=None):
+        """item rows for the batch: local gather, or the collective lookup when the table is sharded.  drop: an nn.Dropout
+        applied to the rows - fused into the gather kernels on the single-device path."""
+        p = drop.p if isinstance(drop, nn.Dropout) and drop.training else 0.0
         if self.shard is not None:
-            return self.shard.lookup(self._table(), idx, uniq)
-        return ops.embedding_lookup(self._table(), idx, uniq, tgrad, dyn_n, dyn_u)
+            rows = self.shard.lookup(self._table(), idx, uniq)
+            return drop(rows) if drop is not None else rows
+        if drop is not None and not isinstance(drop, nn.Dropout):
+            return drop(ops.embedding_lookup(self._table(), idx, uniq, tgrad, dyn_n, dyn_u))    # replaced module (tests)
+        return ops.embedding_lookup(self._table(), idx, uniq, tgrad, dyn_n, dyn_u, (p, 7) if p > 0 else None)
 
     def fused_loss(self, *inputs_and_labels, dynB=None):
         *inputs, labels = inputs_and_labels

@@ -916,3 +916,48 @@ def test_gru_expand_all_matches_per_order_fp32_path(dev, d, padded):
     for p in range(2):
         for a, b, nm in zip(got[2][p], ref[2][p], ('Wih', 'Whh', 'bih', 'bhh')):
             assert rel(a, b) < 2e-2, (p, nm, rel(a, b))
+
+
+def test_lookup_with_fused_dropout(dev):
+    """feature dropout fused into the embedding gather and its backward (msgifsr.py:247): the output is table[idx] times a
+    0 / (1 / (1 - p)) mask with keep-rate 1 - p, the backward applies the SAME mask (recomputed from the counter-based
+    hash), the mask follows torch.manual_seed and changes with the device step counter"""
+    ops = _ops()
+    torch.manual_seed(4)
+    V, d, n, p = 500, 64, 3000, 0.3
+    table = (torch.rand(V, d, device=dev) + 0.5).requires_grad_()
+    idx = torch.randint(0, V, (n,), device=dev, dtype=torch.int32)
+    items, inv = torch.unique(idx.long(), return_inverse=True)
+    pos = torch.argsort(idx.long(), stable=True).int()
+    uptr = torch.zeros(items.numel() + 1, dtype=torch.int32, device=dev)
+    uptr[1:] = torch.bincount(inv).cumsum(0).int()
+    uniq = (items.int(), uptr, pos)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    old = ops.RNG_COUNTER.get(str(dev))
+    ops.RNG_COUNTER[str(dev)] = counter
+    try:
+        outs = []
+        for seed, cnt in ((11, 0), (11, 0), (12, 0), (11, 1)):
+            torch.manual_seed(seed)
+            counter.fill_(cnt)
+            table.grad = None
+            out = ops.embedding_lookup(table, idx, uniq, None, None, None, (p, 7))
+            mask = (out / table[idx.long()]).detach()
+            keep = (mask > 0)
+            assert torch.allclose(mask[keep], torch.full_like(mask[keep], 1 / (1 - p)), rtol=1e-5)
+            assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+            g = torch.randn(n, d, device=dev)
+            out.backward(g)
+            ref = torch.zeros(V, d, device=dev).index_add_(0, idx.long(), g * mask)
+            close(table.grad, ref, what='dropout lookup backward', rtol=1e-5, atol=1e-5)
+            outs.append(mask)
+        assert torch.equal(outs[0], outs[1])                     # same seed, same step: same mask
+        assert not torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[3])
+        # rows and columns are not correlated: every row / column keeps about 1 - p
+        k = (outs[0] > 0).float()
+        assert (k.mean(0) - (1 - p)).abs().max() < 0.05 and (k.mean(1) - (1 - p)).abs().max() < 0.25
+    finally:
+        if old is None:
+            ops.RNG_COUNTER.pop(str(dev), None)
+        else:
+            ops.RNG_COUNTER[str(dev)] = old

@@ -14,7 +14,7 @@ def main():
     batches, _ = bench.make_batches('MSGIFSR', 3, 6, 512, 37484, 20, 123, padded=True)
     batches = [([x.to(dev) for x in inp], lab.to(dev)) for inp, lab in batches]
     torch.manual_seed(123)
-    model = bench.build_model(sp, 'MSGIFSR', 37484, 256, 3).to(dev)
+    model = bench.build_model(sp, "MSGIFSR", 37484, 256, 3, 0.1).to(dev)
     model.train()
     opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model)
 

@@ -21,3 +21,13 @@ for r in rows[lo:hi]:
     tot += (e - s) / 1e3
     prev_end = e
 print('kernels %d, busy %.1f us, span %.1f us' % (hi - lo, tot, (int(rows[hi - 1]['End_Timestamp']) - t0) / 1e3))
+# large gaps of the last few steps (a gap inside a replayed graph = a node that is not a kernel: memset / memcpy)
+print('gaps > 3 us per step (start offset, gap, next kernel):')
+for a, b in list(zip(ends[:-1], ends[1:]))[-6:]:
+    t0s = int(rows[a + 1]['Start_Timestamp'])
+    out = []
+    for i in range(a + 2, b + 1):
+        gap = (int(rows[i]['Start_Timestamp']) - int(rows[i - 1]['End_Timestamp'])) / 1e3
+        if gap > 3.0:
+            out.append('%.0f:%.1f:%s' % ((int(rows[i]['Start_Timestamp']) - t0s) / 1e3, gap, re.sub(r'\(.*$', '', rows[i]['Kernel_Name'])[-28:]))
+    print('  ', ' | '.join(out))
