@@ -139,7 +139,7 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20, force_fp32=False):
         ops._ce_bwd(sr, table, None, labels, lse, None, None, None, ws, None, tb, dE, dsr, parts)
 
     def bwd_kernel():         # the backward launch alone: session copies already prepared, slabs left unreduced
-        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), ptr(ws.srT16), ws.Bp, ptr(tb.E16), ptr(tb.ET16), tb.Vp, None,
+        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), None, ws.Bp, ptr(tb.E16), None, tb.Vp, None,
                                    ptr(labels), ptr(lse), None, None, None, B, V, d, None, ptr(dE), dE.stride(0),
                                    ptr(ws.dsr_part), ptr(dsr), 3 | 8, stream())
     fwd()

@@ -67,12 +67,14 @@ int srec_score_logp(const float* sr, int ld_sr, const float* E, int ld_e, const 
                     int V, int d, const int* dynB, float* logp, long ld_logp, void* stream);
 
 /* bf16-operand variant of the fused scoring (score_ce_bf16.hip; BASELINE config C3 "bf16"): same call sites as
- * srec_score_ce_fwd/bwd.  srec_bf16_prepare rounds rows [R,d] fp32 (RNE) into a row-major copy dst16 [Rp, d_pad] and
- * a transposed copy dstT16 [d_pad, Rp] (zero for rows >= live R / columns >= d; Rp % 128 == 0; d <= 256, d % 4 == 0;
- * d_pad from srec_ce_plan_bf16); call it once per step for the table and once per head for the session vectors.
+ * srec_score_ce_fwd/bwd.  srec_bf16_prepare rounds rows [R,d] fp32 (RNE) into a row-major copy dst16 [Rp, d_pad] (zero for
+ * rows >= live R / columns >= d; Rp % 128 == 0; d <= 256, d % 4 == 0; d_pad from srec_ce_plan_bf16) and, when dstT16 != NULL,
+ * a transposed copy [d_pad, Rp] (no longer read by the scoring kernels: pass NULL); call it once per step for the table and
+ * once per head for the session vectors.
  * ws_stats >= 2 * n_stat_slabs * B floats, ws_dsr >= n_ranges * B * d floats.  Soft-max statistics, exp and all
  * accumulation stay fp32; dE / dsr are fp32.  The backward runs both parts in one launch (parts bits as above;
- * bit3 = leave the d-sr partial slabs in ws_dsr unreduced). */
+ * bit3 = leave the d-sr partial slabs in ws_dsr unreduced); it reads only the row-major copies (srT16 / ET16 are ignored and
+ * may be NULL: the transposed MFMA fragments are taken from the row-major LDS image by ds_read_b64_tr_b16). */
 int srec_bf16_prepare(const float* src, int ld, int R, const int* dynR, int d, void* dst16, void* dstT16, int Rp,
                       void* stream);
 int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_ranges, int* d_pad);

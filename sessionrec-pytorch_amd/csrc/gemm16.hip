@@ -241,10 +241,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
 // within a 16-lane group lane i supplies the address of (row i >> 2, 4 contiguous columns 4 (i & 3) ..) and receives
 // (rows 0..3, column i) - measured lane map, tools/probes/tr_probe.hip.  The four rows of a group are 256 B apart, i.e.
 // on the same banks: piece p of row r is stored in slot p ^ (4 (r & 3)), which moves them to the four 64-B quarters.
-__device__ __forceinline__ uint2 lds_tr16(unsigned addr) {
-    uint2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
+typedef short short4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const unsigned short* base, unsigned byte_off) {
+    // compiler builtin (not inline asm): hipcc tracks the read in lgkmcnt and schedules it against the MFMAs itself
+    const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) short4_t*)(reinterpret_cast<const char*>(base) + byte_off));
+    return __builtin_bit_cast(uint2, v);
 }
 
 template <int BR, int NS>
@@ -313,7 +315,8 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
         __syncthreads();
         if (it + PD < total) stage(it + PD);
         const int r0 = (it % nst) * BR;
-        const unsigned abase = lds0 + (unsigned)((it % NS) * STG) * 2u, bbase = abase + (unsigned)(BR * T) * 2u;
+        const unsigned short* abase = smem + (it % NS) * STG;
+        const unsigned short* bbase = abase + BR * T;
         const bool tail = r0 + BR > Kr;                  // the last stage of a segment may hold clamped (repeated) rows
 #pragma unroll
         for (int ks = 0; ks < BR / 16; ++ks) {
@@ -323,10 +326,9 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
             for (int f = 0; f < 2; ++f)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    ra[f][e] = lds_tr16(abase + tr_off(wm * 64 + f * 32 + tcol, kb + 4 * e + tr));
-                    rb[f][e] = lds_tr16(bbase + tr_off(wn * 64 + f * 32 + tcol, kb + 4 * e + tr));
+                    ra[f][e] = lds_tr16(abase, tr_off(wm * 64 + f * 32 + tcol, kb + 4 * e + tr));
+                    rb[f][e] = lds_tr16(bbase, tr_off(wn * 64 + f * 32 + tcol, kb + 4 * e + tr));
                 }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (tail) {                                  // rows at or past the live count contribute nothing: zero the A side
                 const int nvalid = Kr - r0 - kb;         // this lane's element q of read e is row kb + 4 e + q
 #pragma unroll

@@ -3,17 +3,19 @@
 //
 // Design (gfx950): with v_mfma_f32_32x32x16_bf16 the matrix pipe is 16x faster than fp32, so the kernel is
 // shaped around LDS traffic and occupancy instead:
-//   * operands are pre-rounded ONCE per step into zero-padded bf16 copies (srec_bf16_prepare): row-major
-//     [rows, D] feeds S, a TRANSPOSED copy [D, rows] feeds ACC += P Y.  D = d padded to 32/64/128/256.
+//   * operands are pre-rounded ONCE per step into zero-padded bf16 copies (srec_bf16_prepare), row-major [rows, D] only,
+//     D = d padded to 32/64/128/256: the same LDS image feeds S (ds_read_b128 along k = D) and ACC += P Y, whose B
+//     fragments (8 consecutive STREAMED rows of one column) are gathered by ds_read_b64_tr_b16 transposing reads - no
+//     transposed copy in HBM, half the chunk traffic of the first version of this kernel.
 //   * every wave OWNS 32 rows (items for dE, sessions for d sr / forward) as ready-made MFMA fragments in
 //     registers and keeps its 32 x D accumulator in registers; a workgroup is 4 independent waves (128 owner
 //     rows) that only share the streamed chunk in LDS.  256 VGPRs -> two workgroups per CU.
 //   * the product is computed TRANSPOSED, S^T = Y X^T (streamed rows x owner rows): the MFMA result layout
 //     (lane = owner row, registers = streamed rows) is exactly the A-operand layout of the second product, so P
 //     never touches LDS - it is exponentiated, rounded to bf16 and fed back from registers.  The k-order this
-//     implies (register r <-> streamed row (r&3) + 8(r>>2) + 4(lane>>5)) is baked into the transposed copy by
-//     swapping bits 2 and 3 of the row index, so the matching B fragments are single ds_read_b128.
-//   * streamed chunks (32 rows, both layouts) go global -> LDS by LDS-DMA (global_load_lds_dwordx4), double
+//     implies (register r <-> streamed row (r&3) + 8(r>>2) + 4(lane>>5)) is matched on the B side by pointing the
+//     two transposing reads of a fragment at rows 16 t + 4 half + {0..3} and 16 t + 8 + 4 half + {0..3}.
+//   * streamed chunks (32 rows) go global -> LDS by LDS-DMA (global_load_lds_dwordx4), double
 //     buffered, one barrier per chunk, no staging registers and no ds_write pass.  LDS-DMA fills lane-linear,
 //     so the tiles are unpadded and bank conflicts are removed by an XOR swizzle applied to the SOURCE address
 //     of each 16-B piece and to the fragment reads (piece p of row r sits at p ^ f(r)); with f below the 16
@@ -30,8 +32,11 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
 
 constexpr int CH = 32;    // streamed rows per chunk
+constexpr int NSC = 2, PDC = 1;   // chunk ring: buffers, chunks in flight.  Measured at C3 (r02n): a 4-deep ring (3 chunks in flight)
+                                  // changes nothing (98 vs 96 us) - the chunk loop is not waiting for its DMA
 constexpr int SB = 512;   // streamed rows per side-data block (lse / labels / column scales in LDS)
 constexpr int OWN = 128;  // owner rows per workgroup (4 waves x 32)
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -53,9 +58,10 @@ __global__ void bf16_prepare_kernel(const float* __restrict__ src, int ld, int R
         const int r = r0 + rr, c = c0 + tc;
         unsigned short v = 0;
         if (r < Rl && c < d) v = f2bf(src[(size_t)r * ld + c]);
-        tile[rr][tc] = v;
+        if (dstT16 != nullptr) tile[rr][tc] = v;
         if (c < Dp) dst16[(size_t)r * Dp + c] = v;
     }
+    if (dstT16 == nullptr) return;
     __syncthreads();
     for (int cc = tr; cc < 64; cc += 4) {
         const int c = c0 + cc;
@@ -89,10 +95,10 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     constexpr int D = NT * 32, KS = D / 16, PR = D / 8;          // PR: 16-B pieces per row-major row
     constexpr int RBS = PR >= 16 ? 1 : 16 / PR, FM = (PR >= 16 ? 16 : PR) - 1;
     constexpr int YS = CH * D;                                    // elements of one row-major chunk (= one transposed)
-    constexpr int BUF = KIND == KIND_FWD ? YS : 2 * YS;
+    constexpr int BUF = YS;                                       // ONE row-major image per chunk serves both products
     constexpr int NI = D / 16;                                    // 1-KiB LDS-DMA instructions per layout per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-    float* sideF = reinterpret_cast<float*>(smem16 + 2 * BUF);   // [SB] lse (dE) or column scale (d sr, fwd)
+    float* sideF = reinterpret_cast<float*>(smem16 + NSC * BUF); // [SB] lse (dE) or column scale (d sr, fwd)
     int* sideI = reinterpret_cast<int*>(sideF + SB);             // [SB] labels (dE)
     float* sideGa = reinterpret_cast<float*>(sideI + SB);        // [SB] per-session coefficients (dE, order fusion)
     float* sideGc = sideGa + SB;
@@ -122,8 +128,6 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     }
     const unsigned short* X16 = role_de ? a.E16 : a.S16;
     const unsigned short* Y16 = role_de ? a.S16 : a.E16;
-    const unsigned short* YT16 = role_de ? a.ST16 : a.ET16;
-    const int Yp = role_de ? a.Bp : a.Vp;
     const int xi = x0 + wave * 32 + l31;                          // this lane's owner row (column of S^T)
 
     // owner rows as MFMA B-fragments of S^T = Y X^T: row xi, k = ks*16 + 8*half .. +7 (padded copy: no masks)
@@ -180,20 +184,12 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 glds(Y16 + (size_t)(y0 + i * RPI) * D, voff, lds0 + (unsigned)(bufsel * BUF + i * 512) * 2u);
             }
         }
-        if (KIND == KIND_BWD) {
-            const int g = (lane & 3) ^ ((lane >> 4) & 3);
-            const unsigned voff = ((unsigned)(lane >> 2) * (unsigned)Yp + (unsigned)g * 8u) * 2u;
-#pragma unroll
-            for (int ii = 0; ii < (NI + 3) / 4; ++ii) {
-                const int i = ii * 4 + wave;
-                if (i < NI)
-                    glds(YT16 + (size_t)(i * 16) * Yp + y0, voff, lds0 + (unsigned)(bufsel * BUF + YS + i * 512) * 2u);
-            }
-        }
     };
 
+    // LDS ring of NSC chunk images, PDC chunks of LDS-DMA in flight ahead of the one being multiplied
+    constexpr int IPS = NI >= 4 ? NI / 4 : 1;                     // DMA instructions per chunk of the busiest wave
     const int nchunks = yend > ybeg ? (yend - ybeg + CH - 1) / CH : 0;
-    if (nchunks > 0) stage(ybeg, 0, lane);
+    for (int pc = 0; pc < PDC && pc < nchunks; ++pc) stage(ybeg + pc * CH, pc, lane);
     int lane_v = lane;   // re-derived per chunk (see the asm below): keeps ~40 loop-invariant address registers
                          // from being hoisted out of the chunk loop - the kernel lives at the 256-VGPR limit
 
@@ -202,8 +198,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         asm volatile("" : "+v"(lane_v));
         const int l31v = lane_v & 31, halfv = lane_v >> 5;
         const int fsw = (l31v / RBS) & FM;                        // read-side swizzle of this lane's row-major row
-        const int tsw = (l31v >> 2) & 3;                          // ... of its transposed rows
-        unsigned short* cur = smem16 + (c & 1) * BUF;
+        unsigned short* cur = smem16 + (c % NSC) * BUF;
         const int sbase = (c % (SB / CH)) * CH;                   // offset of this chunk inside the side block
         if (sbase == 0) {
             if (c > 0) __syncthreads();                           // everyone is done with the previous side block
@@ -222,9 +217,14 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of chunk c has landed ...
-        __syncthreads();                                          // ... everyone's has; the other buffer is free again
-        if (c + 1 < nchunks) stage(y0 + CH, (c & 1) ^ 1, lane_v);
+        {                                                         // this wave's share of chunk c has landed ...
+            const int ahead = min(nchunks - c - 1, PDC - 1);      // (later chunks may stay in flight)
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * IPS) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(IPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                          // ... everyone's has; chunk c - 1's buffer is free again
+        if (c + PDC < nchunks) stage(y0 + PDC * CH, (c + PDC) % NSC, lane_v);
 
         // ---- S^T = Y X^T : 32 streamed rows x 32 owner rows per wave, K = D.  Fragment reads run PF steps ahead of
         // the MFMAs that consume them (LDS latency ~ 4 MFMA issue slots).
@@ -338,26 +338,42 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 for (int e = 0; e < 8; ++e) w[e] = p[8 * t + e];
                 pf[t] = __builtin_convertvector(w, bf16x8);       // v_cvt_pk_bf16_f32 (RNE)
             }
-            // ---- ACC (32 owner rows x D) += P Y, K = 32 streamed rows in 2 steps; B fragments prefetched PFB ahead
+            // ---- ACC (32 owner rows x D) += P Y, K = 32 streamed rows in 2 steps.  B fragment (k-step t, column block cb):
+            // lane <-> column cb*32 + l31, k slots 0..3 / 4..7 <-> streamed rows 16t + 4 half + {0..3} / 16t + 8 + 4 half +
+            // {0..3} (the register order of P above).  One ds_read_b64_tr_b16 per 4 rows: inside a 16-lane group lane i
+            // points at (row base + (i >> 2), columns 4 (i & 3) .. + 3 of the group's 16) and receives (rows base .. + 3,
+            // column i) - measured lane map, tools/probes/tr_probe.hip.  Fragments prefetched PFB ahead of their MFMAs.
             {
                 constexpr int NB = 2 * NT, PFB = NB < PFD ? NB : PFD;
-                const unsigned short* yt = cur + YS + l31v * CH;
-                const int off0 = ((0 + halfv) ^ tsw) << 3, off1 = ((2 + halfv) ^ tsw) << 3;
+                const int ti = lane_v & 15, trow = ti >> 2;
+                const int tcol = 16 * ((lane_v >> 4) & 1) + 4 * (ti & 3);
+                const int e0row = 4 * halfv + trow;               // + 16 t (+ 8 for the second read)
+                auto frag = [&](int j) {
+                    const int cb = j % NT, t = j / NT;
+                    const int col = cb * 32 + tcol;
+                    uint2 rr[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int row = 16 * t + 8 * e + e0row;
+                        const int slot = (col >> 3) ^ ((row / RBS) & FM);
+                        const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(cur + row * D + (slot << 3) + (col & 7)));
+                        rr[e] = __builtin_bit_cast(uint2, v);
+                    }
+                    return __builtin_bit_cast(bf16x8, make_uint4(rr[0].x, rr[0].y, rr[1].x, rr[1].y));
+                };
                 bf16x8 bf[PFB];
 #pragma unroll
-                for (int j = 0; j < PFB; ++j)
-                    bf[j] = *reinterpret_cast<const bf16x8*>(yt + (j % NT) * 32 * CH + (j / NT ? off1 : off0));
+                for (int j = 0; j < PFB; ++j) bf[j] = frag(j);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     acc[j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[j / NT], bf[j % PFB], acc[j % NT], 0, 0, 0);
-                    if (j + PFB < NB)
-                        bf[j % PFB] = *reinterpret_cast<const bf16x8*>(yt + ((j + PFB) % NT) * 32 * CH +
-                                                                       ((j + PFB) / NT ? off1 : off0));
+                    if (j + PFB < NB) bf[j % PFB] = frag(j + PFB);
                 }
 #pragma unroll
                 for (int j = 0; j < NB - PFB; ++j) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             }
         }
@@ -399,7 +415,7 @@ template <int NTV, int KIND>
 int launch_b(const BArgs& a, int nblocks, hipStream_t st) {
     if (KIND == KIND_BWD && a.ga != nullptr) return launch_b<NTV, KIND == KIND_BWD ? KIND_BWD_G : KIND>(a, nblocks, st);
     constexpr int D = NTV * 32;
-    constexpr size_t lds = (size_t)(KIND == KIND_FWD ? 2 : 4) * CH * D * sizeof(unsigned short) + 4 * SB * sizeof(float) + (SB / CH) * sizeof(int);
+    constexpr size_t lds = (size_t)NSC * CH * D * sizeof(unsigned short) + 4 * SB * sizeof(float) + (SB / CH) * sizeof(int);
     static std::atomic<unsigned long long> optin{0};   // per (kernel instantiation, device)
     if (int rc = srec_lds_optin((const void*)flash_ce_bf16_kernel<NTV, KIND>, (int)lds, optin)) return rc;
     hipLaunchKernelGGL((flash_ce_bf16_kernel<NTV, KIND>), dim3(nblocks), dim3(256), lds, st, a);

@@ -504,12 +504,11 @@ class CEWorkspace:
         self.sr_key = None
         if _bf16_dim_ok(d):
             self.sr16 = torch.zeros(self.Bp, dp.value, device=device, dtype=torch.bfloat16)
-            self.srT16 = torch.zeros(dp.value, self.Bp, device=device, dtype=torch.bfloat16)
 
 
 class TableBF16:
-    """bf16 copies of the item table for the bf16 scoring kernels: E16 [Vp, d] and its transpose ET16 [d, Vp],
-    refreshed once per step (one pass over the table) by srec_bf16_prepare."""
+    """bf16 copy of the item table for the bf16 scoring kernels: E16 [Vp, d_pad] (row-major only: the backward takes its
+    transposed fragments with transposing LDS reads), refreshed once per step (one pass over the table)."""
 
     def __init__(self, table):
         import ctypes
@@ -518,11 +517,10 @@ class TableBF16:
         lib.srec_ce_plan_bf16(1, V, d, ctypes.addressof(nt), ctypes.addressof(nr), ctypes.addressof(dp))
         self.Vp = (V + 127) // 128 * 128
         self.E16 = torch.zeros(self.Vp, dp.value, device=table.device, dtype=torch.bfloat16)
-        self.ET16 = torch.zeros(dp.value, self.Vp, device=table.device, dtype=torch.bfloat16)
 
     def refresh(self, table):
         V, d = table.shape
-        lib.srec_bf16_prepare(ptr(table), table.stride(0), V, None, d, ptr(self.E16), ptr(self.ET16), self.Vp, stream())
+        lib.srec_bf16_prepare(ptr(table), table.stride(0), V, None, d, ptr(self.E16), None, self.Vp, stream())
         return self
 
 
@@ -536,7 +534,7 @@ def _prepare_sr(sr, ws, dynB):
     key = (sr.data_ptr(), sr._version, tuple(sr.shape))
     if ws.sr_key != key:
         B, d = sr.shape
-        lib.srec_bf16_prepare(ptr(sr), _ld(sr), B, ptr(dynB), d, ptr(ws.sr16), ptr(ws.srT16), ws.Bp, stream())
+        lib.srec_bf16_prepare(ptr(sr), _ld(sr), B, ptr(dynB), d, ptr(ws.sr16), None, ws.Bp, stream())
         ws.sr_key = key
 
 
@@ -558,7 +556,7 @@ def _ce_bwd(sr, table, cs, labels, lse, gl, ga, gc, ws, dynB, tb, dE, dsr, parts
     V = table.shape[0]
     if tb is not None:
         _prepare_sr(sr, ws, dynB)
-        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), ptr(ws.srT16), ws.Bp, ptr(tb.E16), ptr(tb.ET16), tb.Vp, ptr(cs),
+        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), None, ws.Bp, ptr(tb.E16), None, tb.Vp, ptr(cs),
                                    ptr(labels), ptr(lse), ptr(gl), ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE),
                                    dE.stride(0), ptr(ws.dsr_part), ptr(dsr), parts, stream())
     else:
