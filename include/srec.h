@@ -113,6 +113,13 @@ int srec_normalize_fwd(const float* X, int ld_x, float* Y, int ld_y, float* inv,
                        int eps_mode, float eps, void* stream);
 int srec_normalize_bwd(const float* Y, int ld_y, const float* dY, int ld_dy, const float* inv, float* dX, int ld_dx,
                        int n_cap, const int* dyn, int d, void* stream);
+/* the same for np <= 4 row blocks of different tensors normalised into ONE stacked matrix Y [sum n_p, d] (MSGIFSR: the
+ * per-order features of msgifsr.py:253 feed the batched MSHGNN layer stacked) - one launch instead of np + a concatenation.
+ * X / dX / dyn: HOST arrays of np device pointers (dyn entries nullable), ld / n: HOST int arrays. */
+int srec_normalize_group_fwd(int np, const void* X, const int* ld, const int* n, const void* dyn, float* Y, int ld_y,
+                             float* inv, int d, int eps_mode, float eps, void* stream);
+int srec_normalize_group_bwd(int np, const void* dX, const int* ld, const int* n, const void* dyn, const float* Y, int ld_y,
+                             const float* dY, int ld_dy, const float* inv, int d, void* stream);
 /* chain rule of the catalog-row normalisation on the dense dE: G_v -= e_v <e_v, G_v> */
 int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g, int n, int d,
                          void* stream);

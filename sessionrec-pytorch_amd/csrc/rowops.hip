@@ -457,6 +457,113 @@ extern "C" int srec_normalize_bwd(const float* Y, int ld_y, const float* dY, int
     return 0;
 }
 
+namespace {
+// normalisation of up to 4 row blocks of different tensors into / out of ONE stacked matrix (the node features of
+// MSGIFSR's orders: msgifsr.py:253 per order, concatenated for the batched MSHGNN layer): block p = rows [row0, row0 + n)
+// of the stacked side, its own tensor X[p] / dX[p] on the other side, its own live count
+struct NormGroup {
+    const float* X[4]; float* dX[4];
+    const int* dyn[4];
+    int ld[4], n[4], row0[4];
+    int np;
+};
+__global__ void normalize_group_fwd_kernel(NormGroup g, float* __restrict__ Y, int ld_y, float* __restrict__ inv, int d,
+                                           int eps_mode, float eps) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < g.np && i >= g.row0[q]) p = q;
+    const int li = i - g.row0[p];
+    if (li >= g.n[p]) return;
+    const bool live = li < dyn_count(g.dyn[p], g.n[p]);
+    const float* x = g.X[p] + (size_t)li * g.ld[p];
+    float iv = 0.f;
+    if (live) iv = inv_norm(row_sumsq(x, d, lane), eps_mode, eps);
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            v = *reinterpret_cast<const float4*>(x + c);
+            v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
+        }
+        *reinterpret_cast<float4*>(Y + (size_t)i * ld_y + c) = v;
+    }
+    if (lane == 0) inv[i] = iv;
+}
+__global__ void normalize_group_bwd_kernel(NormGroup g, const float* __restrict__ Y, int ld_y, const float* __restrict__ dY,
+                                           int ld_dy, const float* __restrict__ inv, int d) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < g.np && i >= g.row0[q]) p = q;
+    const int li = i - g.row0[p];
+    if (li >= g.n[p]) return;
+    const bool live = li < dyn_count(g.dyn[p], g.n[p]);
+    float* dx = g.dX[p] + (size_t)li * g.ld[p];
+    float dot = 0.f;
+    if (live)
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)i * ld_y + c);
+            const float4 gg = *reinterpret_cast<const float4*>(dY + (size_t)i * ld_dy + c);
+            dot += y.x * gg.x + y.y * gg.y + y.z * gg.z + y.w * gg.w;
+        }
+    dot = wave_sum(dot);
+    const float iv = live ? inv[i] : 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)i * ld_y + c);
+            const float4 gg = *reinterpret_cast<const float4*>(dY + (size_t)i * ld_dy + c);
+            o = make_float4(iv * (gg.x - y.x * dot), iv * (gg.y - y.y * dot), iv * (gg.z - y.z * dot), iv * (gg.w - y.w * dot));
+        }
+        *reinterpret_cast<float4*>(dx + c) = o;
+    }
+}
+int fill_norm_group(NormGroup& g, int np, const void* X, const int* ld, const int* n, const void* dyn, int d, int* total) {
+    if (np <= 0 || np > 4 || X == nullptr || ld == nullptr || n == nullptr) return SREC_BAD_ARG;
+    g.np = np;
+    int r = 0;
+    for (int p = 0; p < np; ++p) {
+        g.X[p] = ((const float* const*)X)[p];
+        g.dX[p] = ((float* const*)X)[p];
+        g.dyn[p] = dyn != nullptr ? ((const int* const*)dyn)[p] : nullptr;
+        g.ld[p] = ld[p]; g.n[p] = n[p]; g.row0[p] = r;
+        if (g.X[p] == nullptr || n[p] <= 0 || bad_row_args(d, ld[p])) return SREC_BAD_ARG;
+        r += n[p];
+    }
+    *total = r;
+    return 0;
+}
+}  // namespace
+
+// Y [sum n_p, d] (stacked, ld_y) = row-normalised X_p [n_p, d]; inv [sum n_p].  X / dyn: HOST arrays of np <= 4 device pointers
+// (dyn entries nullable), ld / n: HOST int arrays.  Rows past a block's live count are written as zeros.
+extern "C" int srec_normalize_group_fwd(int np, const void* X, const int* ld, const int* n, const void* dyn, float* Y,
+                                        int ld_y, float* inv, int d, int eps_mode, float eps, void* stream) {
+    NormGroup g{};
+    int total = 0;
+    if (int rc = fill_norm_group(g, np, X, ld, n, dyn, d, &total)) return rc;
+    if (ld_y & 3) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(normalize_group_fwd_kernel, dim3(cdiv(total, WPB)), dim3(256), 0, (hipStream_t)stream, g, Y, ld_y, inv,
+                       d, eps_mode, eps);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// dX_p [n_p, d] = inv (dY - Y (Y . dY)) for the rows of block p of the stacked Y / dY
+extern "C" int srec_normalize_group_bwd(int np, const void* dX, const int* ld, const int* n, const void* dyn, const float* Y,
+                                        int ld_y, const float* dY, int ld_dy, const float* inv, int d, void* stream) {
+    NormGroup g{};
+    int total = 0;
+    if (int rc = fill_norm_group(g, np, dX, ld, n, dyn, d, &total)) return rc;
+    if ((ld_y & 3) || (ld_dy & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(normalize_group_bwd_kernel, dim3(cdiv(total, WPB)), dim3(256), 0, (hipStream_t)stream, g, Y, ld_y, dY,
+                       ld_dy, inv, d);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g,
                                     int n, int d, void* stream) {
     if (n <= 0) return 0;

@@ -311,16 +311,27 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             fast = ops.gru_expand_all([pieces[k - 1] for k in range(2, K + 1)], [self.expander.GRUs[k - 2] for k in range(2, K + 1)],
                                       list(range(2, K + 1)), [mg.dynp('N%d' % k) for k in range(2, K + 1)],
                                       [mg.dynp('GK%d' % k) for k in range(2, K + 1)])
+        raw = {}
         for k in range(1, K + 1):
-            nk = ncap[k]
             x = pieces[k - 1]
             dk = mg.dynp('N%d' % k)
-            f = x if k == 1 else (fast[k - 2] if fast is not None else self.expander(x, k, dk, mg.dynp('GK%d' % k)))
-            feats[k] = ops.normalize(f, 0, dk) if self.norm else f
+            raw[k] = x if k == 1 else (fast[k - 2] if fast is not None else self.expander(x, k, dk, mg.dynp('GK%d' % k)))
+        stacked0 = None
+        if self.norm and 1 < K <= 4 and len(self.layers) > 0:
+            # all orders normalised straight into the stacked matrix the batched layer reads: one launch, no concatenation
+            stacked0 = ops.normalize_stack([raw[k] for k in range(1, K + 1)], 0, [mg.dynp('N%d' % k) for k in range(1, K + 1)])
+            o = 0
+            for k in range(1, K + 1):
+                feats[k] = stacked0[o:o + ncap[k]]
+                o += ncap[k]
+        else:
+            for k in range(1, K + 1):
+                feats[k] = ops.normalize(raw[k], 0, mg.dynp('N%d' % k)) if self.norm else raw[k]
         self._s1_feat = feats[1]                           # the session's own item rows (normalised): `extra` in-session logits
         if len(self.layers) > 0:
             # all orders stacked once; every layer is one batched pass over all relations (ops.hgat_layer)
-            stacked = feats[1] if K == 1 else torch.cat([feats[k] for k in range(1, K + 1)], 0)
+            stacked = stacked0 if stacked0 is not None else (
+                feats[1] if K == 1 else torch.cat([feats[k] for k in range(1, K + 1)], 0))
             for layer in self.layers:
                 stacked = layer.forward_stacked(mg, stacked)
             if self.norm:

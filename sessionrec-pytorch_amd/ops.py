@@ -414,6 +414,50 @@ def normalize(x, eps_mode=0, dyn=None):
     return Normalize.apply(x, eps_mode, dyn)
 
 
+class NormalizeStack(torch.autograd.Function):
+    """stacked [sum n_p, d] = concatenation of the row-normalised x_p (np <= 4 tensors, each with its own live count): one
+    launch forward, one backward, no concatenation kernel (the per-order features MSGIFSR feeds its batched MSHGNN layer)"""
+
+    @staticmethod
+    def forward(ctx, eps_mode, dyns, *xs):
+        xs = [_rows(x) for x in xs]
+        P, d, dev = len(xs), xs[0].shape[1], xs[0].device
+        ns = [x.shape[0] for x in xs]
+        y = torch.empty(sum(ns), d, device=dev, dtype=torch.float32)
+        inv = torch.empty(sum(ns), device=dev, dtype=torch.float32)
+        arr = _ct.c_void_p * P
+        a_x, a_d = arr(*[x.data_ptr() for x in xs]), arr(*[ptr(t) for t in dyns])
+        a_l, a_n = (_ct.c_int * P)(*[_ld(x) for x in xs]), (_ct.c_int * P)(*ns)
+        lib.srec_normalize_group_fwd(P, _ct.addressof(a_x), _ct.addressof(a_l), _ct.addressof(a_n), _ct.addressof(a_d), ptr(y),
+                                     d, ptr(inv), d, eps_mode, 1e-12, stream())
+        ctx.save_for_backward(y, inv)
+        ctx.meta = (ns, dyns)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, inv = ctx.saved_tensors
+        ns, dyns = ctx.meta
+        gy = _rows(gy)
+        P, d = len(ns), y.shape[1]
+        dxall = torch.empty_like(y)                       # the blocks' gradients, adjacent (SplitRows.backward can alias them)
+        dxs, o = [], 0
+        for n in ns:
+            dxs.append(dxall[o:o + n])
+            o += n
+        arr = _ct.c_void_p * P
+        a_x, a_d = arr(*[t.data_ptr() for t in dxs]), arr(*[ptr(t) for t in dyns])
+        a_l, a_n = (_ct.c_int * P)(*([d] * P)), (_ct.c_int * P)(*ns)
+        lib.srec_normalize_group_bwd(P, _ct.addressof(a_x), _ct.addressof(a_l), _ct.addressof(a_n), _ct.addressof(a_d), ptr(y), d,
+                                     ptr(gy), _ld(gy), ptr(inv), d, stream())
+        return (None, None) + tuple(dxs)
+
+
+def normalize_stack(xs, eps_mode=0, dyns=None):
+    dyns = tuple(dyns) if dyns is not None else (None,) * len(xs)
+    return NormalizeStack.apply(eps_mode, dyns, *xs)
+
+
 class SegAttn(torch.autograd.Function):
     """alpha = softmax_session(fc_e(sigmoid(U + Vq[b])));  out_b = sum_i alpha_i x_i"""
 
@@ -581,6 +625,7 @@ class ScoreCE(torch.autograd.Function):
         ctx.save_for_backward(sr, table, cs, labels, lse)
         ctx.ws, ctx.tgrad, ctx.dynB, ctx.cs_inv_scale, ctx.tb = ws, tgrad, dynB, cs_inv_scale, tb
         ctx.mark_non_differentiable(lse)
+        ctx.set_materialize_grads(False)       # no zero-filled [B] gradient for the unused lse output (a fill kernel per step)
         return loss, lse
 
     @staticmethod

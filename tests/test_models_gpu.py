@@ -332,10 +332,12 @@ def test_mshgnn_layer_dropout_gradients_by_finite_differences(dev):
             if abs(num - ana) > 3e-2 * max(abs(num), abs(ana)) + 3e-3:
                 bad.append((tuple(t.shape), idx, num, ana))
             checked += 1
-    # the layer takes a max over heads: a central difference that straddles an arg-max flip of ONE output element is off by
-    # a few per cent whatever the implementation (the exact check of this path is the replayed-mask comparison with the
-    # oracle, test_msgifsr_dropout_path_matches_oracle_with_replayed_masks); allow isolated kinks, not systematic error
-    assert checked >= 10 and len(bad) <= max(1, checked // 25), bad
+    # the layer is piecewise smooth (max over heads, LeakyReLU on every edge logit): a central difference that straddles a
+    # kink is off by a few per cent whatever the implementation (the exact check of this path is the replayed-mask
+    # comparison with the oracle, test_msgifsr_dropout_path_matches_oracle_with_replayed_masks); allow a few kinks of
+    # < 10 %, no systematic error
+    assert checked >= 10 and len(bad) <= max(1, checked // 8), bad
+    assert all(abs(num - ana) <= 0.1 * max(abs(num), abs(ana)) + 3e-3 for _, _, num, ana in bad), bad
 
 
 class _Replay(torch.nn.Module):
