@@ -120,6 +120,8 @@ int srec_normalize_group_fwd(int np, const void* X, const int* ld, const int* n,
                              float* inv, int d, int eps_mode, float eps, void* stream);
 int srec_normalize_group_bwd(int np, const void* dX, const int* ld, const int* n, const void* dyn, const float* Y, int ld_y,
                              const float* dY, int ld_dy, const float* inv, int d, void* stream);
+/* out [n, da + db] = [a | b]: the feature-axis concatenation in front of fc_sr (srgnn.py:143, msgifsr.py:270-272) */
+int srec_cat_cols(const float* a, int lda, int da, const float* b, int ldb, int db, int n, float* out, void* stream);
 /* chain rule of the catalog-row normalisation on the dense dE: G_v -= e_v <e_v, G_v> */
 int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g, int n, int d,
                          void* stream);

@@ -378,6 +378,18 @@ def collate_native(kind, seqs, order=1, caps=None):
     return FlatBatch(torch.from_numpy(buf), layout, meta)
 
 
+def _attach_labels(fb, lab):
+    """append the batch's labels (int32) to the FIRST input's flat buffer as field 'labels': a captured training step then
+    receives graph AND labels with one host-to-device copy and reads int32 labels in place (graph.GraphedTrainStep)"""
+    off = int(fb.buf.numel())
+    n = int(lab.numel())
+    pad = (-n) % 4
+    ext = torch.cat([fb.buf, lab.to(torch.int32), torch.zeros(pad, dtype=torch.int32)]) if pad else torch.cat([fb.buf, lab.to(torch.int32)])
+    layout = dict(fb.layout)
+    layout['labels'] = (off, n, None)
+    return FlatBatch(ext, layout, fb.meta)
+
+
 def _labels(labels, caps):
     lab = np.asarray(labels, dtype=np.int64)
     if caps and len(lab) < caps['B']:
@@ -404,7 +416,10 @@ def collate_fn_factory(*seq_to_graph_fns, caps=None):
                     if fb is None:
                         fb = batch_homogeneous([fn(s) for s in seqs], use)
                     inputs.append(fb)
-                return inputs, _labels(labels, use)
+                lab = _labels(labels, use)
+                if use is not None:
+                    inputs[0] = _attach_labels(inputs[0], lab)
+                return inputs, lab
             except CapacityExceeded:
                 if use is None:
                     raise
@@ -429,7 +444,10 @@ def collate_fn_factory_ccs(seq_to_graph_fns, order, caps=None):
                     if fb is None:
                         fb = batch_ccs([fn(s, order) for s in seqs], use)
                     inputs.append(fb)
-                return inputs, _labels(labels, use)
+                lab = _labels(labels, use)
+                if use is not None:
+                    inputs[0] = _attach_labels(inputs[0], lab)
+                return inputs, lab
             except CapacityExceeded:
                 if use is None:
                     raise

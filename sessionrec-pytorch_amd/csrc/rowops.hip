@@ -564,6 +564,32 @@ extern "C" int srec_normalize_group_bwd(int np, const void* dX, const int* ld, c
     return 0;
 }
 
+namespace {
+// out[r, :] = [a[r, :da] | b[r, :db]]
+__global__ void cat_cols_kernel(const float* __restrict__ a, int lda, int da, const float* __restrict__ b, int ldb, int db,
+                                int n, float* __restrict__ out) {
+    const int w = da + db;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (long)n * w) return;
+    const int r = (int)(i / w), c = (int)(i % w);
+    const float4 v = c < da ? *reinterpret_cast<const float4*>(a + (size_t)r * lda + c)
+                            : *reinterpret_cast<const float4*>(b + (size_t)r * ldb + (c - da));
+    *reinterpret_cast<float4*>(out + i) = v;
+}
+}  // namespace
+
+// out [n, da + db] = [a | b] (feature-axis concatenation feeding fc_sr: srgnn.py:143, msgifsr.py:270-272); da, db % 4 == 0
+extern "C" int srec_cat_cols(const float* a, int lda, int da, const float* b, int ldb, int db, int n, float* out,
+                             void* stream) {
+    if (n <= 0) return 0;
+    if ((da & 3) || (db & 3) || (lda & 3) || (ldb & 3) || da <= 0 || db <= 0) return SREC_BAD_ARG;
+    const long items = (long)n * (da + db) / 4;
+    hipLaunchKernelGGL(cat_cols_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, lda, da, b,
+                       ldb, db, n, out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g,
                                     int n, int d, void* stream) {
     if (n <= 0) return 0;

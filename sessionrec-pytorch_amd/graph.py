@@ -20,7 +20,11 @@ class GraphedTrainStep:
         assert all(x.meta.get('padded') for x in inputs), 'graph capture needs capacity-padded batches (collate caps=...)'
         self.model, self.opt, self.after_backward = model, optimizer, after_backward
         self.static_inputs = [FlatBatch(x.buf.clone(), x.layout, dict(x.meta)) for x in inputs]
-        self.static_labels = labels.to(torch.int32)      # the kernels read int32 labels: the copy per step converts
+        # the kernels read int32 labels.  Padded batches carry them inside the first input's flat buffer (collate
+        # _attach_labels): the static labels are then a VIEW of the static batch buffer - no second copy, no int64 -> int32
+        # conversion kernel per step
+        self.labels_in_batch = self.static_inputs[0].has('labels') and self.static_inputs[0].cap('labels') == labels.numel()
+        self.static_labels = (self.static_inputs[0].field('labels') if self.labels_in_batch else labels.to(torch.int32))
         self._one = torch.ones((), device=labels.device, dtype=torch.float32)   # backward root: no fill kernel per replay
         self._sig = [self._signature(x) for x in inputs]
         # ---- eager warm-up on a side stream (lazy allocations, LDS opt-in attributes, Adam state), then undo
@@ -148,7 +152,8 @@ class GraphedTrainStep:
                 raise RuntimeError('batch layout / relation pattern differs from the captured one')
             st.buf.copy_(x.buf, non_blocking=True)
             st.meta['counts'] = x.meta['counts']
-        self.static_labels.copy_(labels, non_blocking=True)
+        if not (self.labels_in_batch and inputs[0].has('labels')):
+            self.static_labels.copy_(labels, non_blocking=True)
         self.opt.advance(self.work)
         self.graph.replay()
         return self.loss

@@ -354,7 +354,9 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         sr_g = self.readout(mg, allf, feat_vs, live)
         srs = []
         for i in live:
-            s = ops.linear_cat([feat_vs[i], sr_g[i]], self.fc_sr[i].weight, None, dB, exact=True)
+            # fc_sr(cat[x_last, sr_g]) as ONE K = 2 d product (and one backward-data / one weight-gradient product) instead of
+            # two K = d segments each: these B-row GEMMs are launch bound, the 1 MB concatenation is not
+            s = ops.linear(ops.cat_cols(feat_vs[i], sr_g[i]), self.fc_sr[i].weight, None, dB, exact=True)
             srs.append(ops.normalize(s, 0, dB) if self.norm else s)
         if self.fusion and K > 1:
             return srs                                     # one session vector per order (IFR mixture)

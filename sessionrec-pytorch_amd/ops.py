@@ -199,6 +199,27 @@ def linear_cat(xs, weight, bias=None, dyn=None, exact=False):
     return LinearCat.apply(weight, bias, dyn, exact, *xs)
 
 
+class CatCols(torch.autograd.Function):
+    """[a | b] along the feature axis; the backward hands out the two column halves of the incoming gradient as views"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _rows(a), _rows(b)
+        n, da, db = a.shape[0], a.shape[1], b.shape[1]
+        out = torch.empty(n, da + db, device=a.device, dtype=torch.float32)
+        lib.srec_cat_cols(ptr(a), _ld(a), da, ptr(b), _ld(b), db, n, ptr(out), stream())
+        ctx.da = da
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.da], g[:, ctx.da:]
+
+
+def cat_cols(a, b):
+    return CatCols.apply(a, b)
+
+
 # ------------------------------------------------------------------------------------------ dropout masks
 RNG_COUNTER = {}     # str(device) -> int32[1] device tensor: the optimizer's step count (FusedAdam registers it)
 
