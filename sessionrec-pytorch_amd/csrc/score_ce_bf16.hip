@@ -348,16 +348,34 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 const int ti = lane_v & 15, trow = ti >> 2;
                 const int tcol = 16 * ((lane_v >> 4) & 1) + 4 * (ti & 3);
                 const int e0row = 4 * halfv + trow;               // + 16 t (+ 8 for the second read)
+                // Address of read e of fragment (cb, t): row = 16 t + 8 e + e0row, 16-B slot = piece ^ f(row) with piece =
+                // 4 cb + (tcol >> 3).  For D >= 128 (f(row) = row & 15) the XOR splits into a compile-time part and a lane
+                // part that overlap in ONE bit (value 4: cb & 1 against half): two per-lane base pointers (even / odd column
+                // block) + immediate offsets - no per-read address arithmetic, which at D = 256 (256 VGPRs) meant spills,
+                // and a spill reload inside the chunk loop is a vmcnt(0): it drains the LDS-DMA ring.
+                const unsigned short* tb0;
+                const unsigned short* tb1;
+                if (NT >= 4) {
+                    const int L = (tcol >> 3) ^ e0row;            // 0..7
+                    tb0 = cur + e0row * D + (L << 3) + (tcol & 7);
+                    tb1 = cur + e0row * D + ((L ^ 4) << 3) + (tcol & 7);
+                } else {
+                    tb0 = tb1 = cur;
+                }
                 auto frag = [&](int j) {
                     const int cb = j % NT, t = j / NT;
-                    const int col = cb * 32 + tcol;
                     uint2 rr[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const int row = 16 * t + 8 * e + e0row;
-                        const int slot = (col >> 3) ^ ((row / RBS) & FM);
-                        const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) short4_t*)(cur + row * D + (slot << 3) + (col & 7)));
+                        const unsigned short* ap;
+                        if (NT >= 4) {
+                            const int K = (4 * cb) ^ (8 * e);     // compile-time after unrolling
+                            ap = ((cb & 1) ? tb1 : tb0) + (16 * t + 8 * e) * D + ((K & ~4) << 3);
+                        } else {
+                            const int col = cb * 32 + tcol, row = 16 * t + 8 * e + e0row;
+                            ap = cur + row * D + ((((col >> 3) ^ ((row / RBS) & FM))) << 3) + (col & 7);
+                        }
+                        const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)ap);
                         rr[e] = __builtin_bit_cast(uint2, v);
                     }
                     return __builtin_bit_cast(bf16x8, make_uint4(rr[0].x, rr[0].y, rr[1].x, rr[1].y));
