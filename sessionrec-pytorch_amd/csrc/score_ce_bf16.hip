@@ -85,7 +85,18 @@ struct BArgs {
     int n_ranges, chunks_per_range, n_sess_tiles;
 };
 
-enum { KIND_FWD = 0, KIND_BWD = 1, KIND_BWD_G = 2 };   // _G: per-session coefficients ga / gc (order fusion)
+enum { KIND_FWD = 0, KIND_BWD = 1, KIND_BWD_G = 2 };
+
+#ifdef SREC_FLASH_TIMING   // development probe (tools/flash_timing.py): per-phase clocks of wave 0 of two workgroups
+__device__ unsigned long long g_flash_tim[2][8];
+#define TIM_DECL unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_a[6] = {0, 0, 0, 0, 0, 0}; \
+    const bool tim_on = KIND == KIND_BWD && (blockIdx.x == 8 || (int)blockIdx.x == a.n_de_pad + 8)
+#define TIM(i) do { __builtin_amdgcn_sched_barrier(0); tim_t[i] = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TIM_DECL
+#define TIM(i)
+#endif   // _G: per-session coefficients ga / gc (order fusion)
 
 template <int NT, int KIND_>
 __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
@@ -94,6 +105,12 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     constexpr bool has_g = KIND_ == KIND_BWD_G;
     constexpr int D = NT * 32, KS = D / 16, PR = D / 8;          // PR: 16-B pieces per row-major row
     constexpr int RBS = PR >= 16 ? 1 : 16 / PR, FM = (PR >= 16 ? 16 : PR) - 1;
+    // swizzle g(row): piece p of chunk row r sits in 16-B slot p ^ g(r).  D >= 128: the low row bits go to slot bits 2-3
+    // and row bits 2-3 to slot bits 0-1 - 16 distinct rows of one piece (a ds_read_b128 lane group of product 1) AND
+    // 4 consecutive rows x 4 consecutive pieces (one half-wave of a transposing read of product 2) both cover 16
+    // distinct slots.  (g(r) = r & 15 served only the first: the transposing reads ran 4-way bank-conflicted,
+    // SQ_LDS_BANK_CONFLICT = 57 % of SQ_LDS_IDX_ACTIVE; now 0.)
+    auto swz = [](int row) { return PR >= 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row / RBS) & FM); };
     constexpr int YS = CH * D;                                    // elements of one row-major chunk (= one transposed)
     constexpr int BUF = YS;                                       // ONE row-major image per chunk serves both products
     constexpr int NI = D / 16;                                    // 1-KiB LDS-DMA instructions per layout per chunk
@@ -108,6 +125,8 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int Bd = dyn_count(a.dynB, a.B);
+    TIM_DECL;
+    TIM(6);
 
     bool role_de = false;
     int x0, ybeg, yend, range = 0;
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         for (int ii = 0; ii < (NI + 3) / 4; ++ii) {
             const int i = ii * 4 + wave;
             if (i < NI) {
-                const int g = pos ^ (((i * RPI + row_l) / RBS) & FM);
+                const int g = pos ^ swz(i * RPI + row_l);
                 const unsigned voff = (unsigned)(row_l * D + g * 8) * 2u;
                 glds(Y16 + (size_t)(y0 + i * RPI) * D, voff, lds0 + (unsigned)(bufsel * BUF + i * 512) * 2u);
             }
@@ -193,11 +212,16 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     int lane_v = lane;   // re-derived per chunk (see the asm below): keeps ~40 loop-invariant address registers
                          // from being hoisted out of the chunk loop - the kernel lives at the 256-VGPR limit
 
+    TIM(7);
+#ifdef SREC_FLASH_TIMING
+    const unsigned long long tim_loop0 = tim_t[7];
+#endif
     for (int c = 0; c < nchunks; ++c) {
+        TIM(0);
         const int y0 = ybeg + c * CH;
         asm volatile("" : "+v"(lane_v));
         const int l31v = lane_v & 31, halfv = lane_v >> 5;
-        const int fsw = (l31v / RBS) & FM;                        // read-side swizzle of this lane's row-major row
+        const int fsw = swz(l31v);                                // read-side swizzle of this lane's row-major row
         unsigned short* cur = smem16 + (c % NSC) * BUF;
         const int sbase = (c % (SB / CH)) * CH;                   // offset of this chunk inside the side block
         if (sbase == 0) {
@@ -224,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();                                          // ... everyone's has; chunk c - 1's buffer is free again
+        TIM(1);
         if (c + PDC < nchunks) stage(y0 + PDC * CH, (c + PDC) % NSC, lane_v);
+        TIM(2);
 
         // ---- S^T = Y X^T : 32 streamed rows x 32 owner rows per wave, K = D.  Fragment reads run PF steps ahead of
         // the MFMAs that consume them (LDS latency ~ 4 MFMA issue slots).
@@ -250,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
             }
         }
+        TIM(3);
         // register r of s <-> streamed row (r&3) + 8*(r>>2) + 4*half, owner row = xi
         if (KIND == KIND_FWD) {
             const int nvalid = yend - y0 - 4 * half;              // rows >= this are beyond the range
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 for (int e = 0; e < 8; ++e) w[e] = p[8 * t + e];
                 pf[t] = __builtin_convertvector(w, bf16x8);       // v_cvt_pk_bf16_f32 (RNE)
             }
+            TIM(4);
             // ---- ACC (32 owner rows x D) += P Y, K = 32 streamed rows in 2 steps.  B fragment (k-step t, column block cb):
             // lane <-> column cb*32 + l31, k slots 0..3 / 4..7 <-> streamed rows 16t + 4 half + {0..3} / 16t + 8 + 4 half +
             // {0..3} (the register order of P above).  One ds_read_b64_tr_b16 per 4 rows: inside a 16-lane group lane i
@@ -348,34 +376,27 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 const int ti = lane_v & 15, trow = ti >> 2;
                 const int tcol = 16 * ((lane_v >> 4) & 1) + 4 * (ti & 3);
                 const int e0row = 4 * halfv + trow;               // + 16 t (+ 8 for the second read)
-                // Address of read e of fragment (cb, t): row = 16 t + 8 e + e0row, 16-B slot = piece ^ f(row) with piece =
-                // 4 cb + (tcol >> 3).  For D >= 128 (f(row) = row & 15) the XOR splits into a compile-time part and a lane
-                // part that overlap in ONE bit (value 4: cb & 1 against half): two per-lane base pointers (even / odd column
-                // block) + immediate offsets - no per-read address arithmetic, which at D = 256 (256 VGPRs) meant spills,
-                // and a spill reload inside the chunk loop is a vmcnt(0): it drains the LDS-DMA ring.
-                const unsigned short* tb0;
-                const unsigned short* tb1;
-                if (NT >= 4) {
-                    const int L = (tcol >> 3) ^ e0row;            // 0..7
-                    tb0 = cur + e0row * D + (L << 3) + (tcol & 7);
-                    tb1 = cur + e0row * D + ((L ^ 4) << 3) + (tcol & 7);
-                } else {
-                    tb0 = tb1 = cur;
-                }
+                // Address of read e of fragment (cb, t): row = 16 t + 8 e + e0row, piece = 4 cb + 2 b4 + plb (b4 = lane bit 4,
+                // plb = bit 1 of the lane's column quad), slot = piece ^ g(row) = [cb2][cb1 ^ trow1][cb0 ^ trow0][b4 ^ e][plb ^ half]
+                // for D >= 128.  The XOR is bitwise on the byte offset (rows are 512 / 256 B, slots 16 B): ONE per-lane
+                // offset, xor-ed with the compile-time pattern 64 (cb & 3) + 32 e, the rest (cb >> 2, t, e row offsets) in
+                // the instruction's immediate offset - 8 distinct addresses per chunk.
+                const unsigned abase = (unsigned)(((c % NSC) * BUF + e0row * D + (tcol & 7)) * 2
+                                                  + ((((trow << 2) | (tcol >> 3)) ^ halfv) << 4));
                 auto frag = [&](int j) {
                     const int cb = j % NT, t = j / NT;
                     uint2 rr[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const unsigned short* ap;
+                        __attribute__((address_space(3))) short4_t* ap;
                         if (NT >= 4) {
-                            const int K = (4 * cb) ^ (8 * e);     // compile-time after unrolling
-                            ap = ((cb & 1) ? tb1 : tb0) + (16 * t + 8 * e) * D + ((K & ~4) << 3);
+                            const unsigned x = abase ^ (unsigned)(64 * (cb & 3) + 32 * e);
+                            ap = (__attribute__((address_space(3))) short4_t*)(size_t)(lds0 + x + (unsigned)((cb >> 2) * 256 + (16 * t + 8 * e) * D * 2));
                         } else {
                             const int col = cb * 32 + tcol, row = 16 * t + 8 * e + e0row;
-                            ap = cur + row * D + ((((col >> 3) ^ ((row / RBS) & FM))) << 3) + (col & 7);
+                            ap = (__attribute__((address_space(3))) short4_t*)(cur + row * D + (((col >> 3) ^ swz(row)) << 3) + (col & 7));
                         }
-                        const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)ap);
+                        const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ap);
                         rr[e] = __builtin_bit_cast(uint2, v);
                     }
                     return __builtin_bit_cast(bf16x8, make_uint4(rr[0].x, rr[0].y, rr[1].x, rr[1].y));
@@ -395,7 +416,15 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 }
             }
         }
+#ifdef SREC_FLASH_TIMING
+        TIM(5);
+        for (int i = 0; i < 5; ++i) tim_a[i] += tim_t[i + 1] - tim_t[i];
+#endif
     }
+#ifdef SREC_FLASH_TIMING
+    TIM(0);
+    const unsigned long long tim_loop1 = tim_t[0];
+#endif
 
     if (KIND == KIND_FWD) {
         // the two halves of a wave hold disjoint rows of the same session: merge, one partial per (range, session)
@@ -427,6 +456,17 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
             }
         }
     }
+#ifdef SREC_FLASH_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TIM(1);
+    if (tim_on && tid == 0) {
+        unsigned long long* o = g_flash_tim[role_de ? 0 : 1];
+        for (int i = 0; i < 5; ++i) o[i] = tim_a[i];
+        o[5] = tim_loop0 - tim_t[6];         // prologue
+        o[6] = tim_t[1] - tim_loop1;         // epilogue (stores drained)
+        o[7] = tim_t[1] - tim_t[6];          // workgroup lifetime
+    }
+#endif
 }
 
 template <int NTV, int KIND>
@@ -465,13 +505,24 @@ void pick_ranges_b(int B, int V, int slots, int rmax, int* n_ranges, int* chunks
     *n_ranges = cdiv(chunks, cpr);
 }
 
-constexpr int FWD_SLOTS = 512, FWD_RMAX = 1024, BWD_SLOTS = 512, BWD_RMAX = 64;
+constexpr int FWD_SLOTS = 512, FWD_RMAX = 1024, BWD_RMAX = 64;
+constexpr int XCDS = 8, XCD_SLOTS = 64;                   // 32 CUs x 2 resident workgroups per XCD
 
-inline int bwd_slots(int V, int d, bool with_de) {
-    const int slots = BWD_SLOTS;                          // workgroups resident at once (2 per CU)
-    if (!with_de) return slots;
-    const int rem = cdiv(V, OWN) % slots;
-    return rem == 0 ? slots : slots - rem;                // fill the residency the item tiles leave free
+// Item ranges of the backward's session-owner workgroups.  Workgroups go to the XCDs round-robin by index and a
+// workgroup waits for a slot on ITS XCD: 293 item tiles + 54 ranges x 4 session tiles (509 of the chip's 512 slots)
+// put 65 live workgroups on five of the XCDs, whose 65th then ran after the first had finished - the launch took two
+// workgroup lifetimes (95 us) instead of one (68 us).  So count per XCD: ranges per XCD = free slots of the fullest
+// XCD / session tiles.
+void pick_ranges_bwd(int B, int V, bool with_de, int* n_ranges, int* chunks_per_range) {
+    const int T = cdiv(B, OWN);
+    int free_slots = XCD_SLOTS;
+    if (with_de) {
+        const int de0 = cdiv(cdiv(V, OWN), XCDS) % XCD_SLOTS;   // item tiles on XCD 0 (the fullest) in the last round
+        free_slots = de0 == 0 ? XCD_SLOTS : XCD_SLOTS - de0;
+    }
+    int per_xcd = free_slots / T;
+    if (per_xcd < 1) per_xcd = 1;
+    pick_ranges_b(B, V, XCDS * per_xcd * T, BWD_RMAX, n_ranges, chunks_per_range);
 }
 
 inline bool bad_d(int d) { return d <= 0 || d > 256 || (d & 3); }
@@ -491,14 +542,20 @@ extern "C" int srec_bf16_prepare(const float* src, int ld, int R, const int* dyn
     return 0;
 }
 
+#ifdef SREC_FLASH_TIMING
+extern "C" int srec_flash_timing(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_flash_tim), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
+
 // workspace plan: ws_stats >= 2 * n_stat_slabs * B floats, ws_dsr >= n_ranges * B * d floats, copies [.., d_pad]
 extern "C" int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_ranges, int* d_pad) {
     if (bad_d(d) || B <= 0 || V <= 0) return SREC_BAD_ARG;
     int R, cpr, R2;
     pick_ranges_b(B, V, FWD_SLOTS, FWD_RMAX, &R, &cpr);
     *n_stat_slabs = R;
-    pick_ranges_b(B, V, bwd_slots(V, d, true), BWD_RMAX, &R, &cpr);
-    pick_ranges_b(B, V, bwd_slots(V, d, false), BWD_RMAX, &R2, &cpr);
+    pick_ranges_bwd(B, V, true, &R, &cpr);
+    pick_ranges_bwd(B, V, false, &R2, &cpr);
     *n_ranges = R > R2 ? R : R2;
     *d_pad = dpad(d);
     return 0;
@@ -545,7 +602,7 @@ extern "C" int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int B
     a.n_de_pad = with_de ? 8 * cdiv(cdiv(V, OWN), 8) : 0;
     int nblocks = a.n_de_pad;
     if (with_dsr) {
-        pick_ranges_b(B, V, bwd_slots(V, d, with_de), BWD_RMAX, &a.n_ranges, &a.chunks_per_range);
+        pick_ranges_bwd(B, V, with_de, &a.n_ranges, &a.chunks_per_range);
         nblocks += 8 * cdiv(a.n_ranges, 8) * a.n_sess_tiles;
     } else {
         a.n_ranges = 0; a.chunks_per_range = 1;
