@@ -294,6 +294,12 @@ int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int 
  * reduction-major (weight gradient; dyn clamps the reduction).  dyn clamps the output rows in modes 0 / 1. */
 int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
 
+/* grouped exact-fp32 GEMM (csrc/gemm.hip): desc = srec_gemm_f32_group (srec_hg.h), every problem as srec_gemm_f32.  One
+ * launch for all tiles of all problems (+ one reduce launch when a long-K problem was k-split into slabs of ws).
+ * Replaces the chain of cuBLAS calls of the attention read-out / session-vector head (msgifsr.py:127-146,272-279;
+ * srgnn.py:73-88,123-127) and their backward. */
+int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream);
+
 /* bf16-in-HBM grouped GEMMs (gemm16.hip): the GAT fc projections and their backward (gatconv.py:166-175,282-283) with every
  * operand already stored as bf16 - LDS-DMA staging, no conversion pass.  desc: host srec_gemm16_group (srec_hg.h, up to 16
  * problems per launch).

@@ -102,6 +102,23 @@ typedef struct {
                                       s writing its own slab C + s * M * ldc (caller sums the slabs: srec_sum_slabs_multi) */
 } srec_gemm16_group;
 
+/* problem table of srec_gemm_f32_group_run (srec.h, csrc/gemm.hip): up to 16 independent exact-fp32 products, each with
+ * the operand conventions of srec_gemm_f32 (C = alpha A B^T + beta C + bias; per operand one unit stride; dyn_mode 1 clamps
+ * M, 2 clamps K).  nsplit and ws are chosen / filled by the launcher. */
+#define SREC_GEMM32_MAXP 16
+typedef struct {
+    int np;
+    const float* A[SREC_GEMM32_MAXP]; int a_rs[SREC_GEMM32_MAXP], a_cs[SREC_GEMM32_MAXP];
+    const float* B[SREC_GEMM32_MAXP]; int b_rs[SREC_GEMM32_MAXP], b_cs[SREC_GEMM32_MAXP];
+    float* C[SREC_GEMM32_MAXP]; int ldc[SREC_GEMM32_MAXP];
+    const float* bias[SREC_GEMM32_MAXP];
+    int M[SREC_GEMM32_MAXP], N[SREC_GEMM32_MAXP], K[SREC_GEMM32_MAXP];
+    const int* dyn[SREC_GEMM32_MAXP]; int dyn_mode[SREC_GEMM32_MAXP];
+    float alpha[SREC_GEMM32_MAXP], beta[SREC_GEMM32_MAXP];
+    int nsplit[SREC_GEMM32_MAXP];
+    float* ws;
+} srec_gemm_f32_group;
+
 /* one time step of the k-gram GRU (msgifsr.py:25,32-45) for up to 4 orders at once: srec_gru_step_fwd / _bwd (srec.h,
  * csrc/grux.hip).  Problem p = order k[p] with n[p] nodes (live prefix *dyn[p]), hidden size d, at time step t[p].
  * x rows are node-major: row (node * k + t). */

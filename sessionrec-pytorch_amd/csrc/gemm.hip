@@ -19,38 +19,49 @@
 // can be replayed for batches of different size) may clamp M or K.
 // Skinny products (weight gradients: K = #nodes) are split along K into scratch slabs + a
 // deterministic reduce so that >= 2 workgroups per CU are in flight.
+#include <utility>
 #include "common.h"
+#include "../../include/srec_hg.h"
 
 namespace {
 
-constexpr int BK = 16;
+template <int BM> struct TileK { static constexpr int value = BM >= 128 ? 16 : 32; };   // k-depth of one LDS tile: the
+// global loads of tile t + 1 are issued before the MFMAs of tile t, so a tile has to hold about one load latency of
+// matrix work (64 x 64 x 16 = 512 cycles per wave did not: the small-grid products ran at ~0.75 us per k-tile)
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(
+// One BM x BN output tile (bx, by) of split bz / nsplit.  As / Bs: the workgroup's double-buffered LDS tiles.
+template <int BM, int BN, bool A_KC, bool B_KC, int BK = TileK<BM>::value>
+__device__ __forceinline__ void gemm_f32_tile(
     const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
     float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
-    const int* __restrict__ dyn, int dyn_mode, float alpha, float beta, float* __restrict__ part) {
-    constexpr int SA = BM + 4, SB = BN + 4;
+    const int* __restrict__ dyn, int dyn_mode, float alpha, float beta, float* __restrict__ part,
+    int bx, int by, int bz, int nsplit, float (*As)[BK][BM + 4], float (*Bs)[BK][BN + 4]) {
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 MFMA tiles per wave
     constexpr int LA = BM * BK / 4 / 256, LB = BN * BK / 4 / 256;   // float4 loads per thread
-    __shared__ __attribute__((aligned(16))) float As[2][BK][SA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][SB];
+    // LDS layout per operand: reduction-major [k][row + 4 pad] when the operand's ROWS are contiguous in memory (float4 of
+    // 4 rows stored as is, ds_read_b32 over 32 consecutive rows); row-major [row][BK] when k is contiguous (float4 of 4 k
+    // stored as is, one ds_read_b128 per 4 MFMAs), 16-B pieces XOR-swizzled by the row so that the rows of one
+    // ds_read_b128 lane group fall into distinct banks.  (The first version transposed k-contiguous float4s into the
+    // reduction-major layout with 4 ds_write_b32 each, 4-way bank conflicted.)
+    constexpr int PP = BK / 4, RPB = 64 / BK;          // pieces per row; rows per 256 B of LDS
+    auto swz = [](int row) { return (row / RPB) & (PP - 1); };
+    auto fa = [&](int buf) { return &As[buf][0][0]; };
+    auto fb = [&](int buf) { return &Bs[buf][0][0]; };
 
     const int Mfull = M, Kfull = K;
     if (dyn_mode == 1) M = dyn_count(dyn, M);
     if (dyn_mode == 2) K = dyn_count(dyn, K);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
 
-    // split-K: blockIdx.z owns the k-range [kbeg, kend); raw partial sums go to part[z][Mfull][N]
-    const int nsplit = gridDim.z;
+    // split-K: split bz owns the k-range [kbeg, kend); raw partial sums go to part[z][Mfull][N]
     int kbeg = 0, kend = K;
     if (nsplit > 1) {
         const int kper = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
-        kbeg = blockIdx.z * kper;
+        kbeg = bz * kper;
         kend = min(K, kbeg + kper);
-        C = part + (size_t)blockIdx.z * Mfull * N;
+        C = part + (size_t)bz * Mfull * N;
         ldc = N; bias = nullptr; alpha = 1.f; beta = 0.f;
     }
 
@@ -122,9 +133,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
             int idx = tid + p * 256;
             const float4 v = masked(ra[p], va[p]);
             if (A_KC) {
-                int m = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
-                As[buf][k + 0][m] = v.x; As[buf][k + 1][m] = v.y;
-                As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
+                const int m = idx / PP, pc = idx % PP;
+                *reinterpret_cast<float4*>(fa(buf) + m * BK + ((pc ^ swz(m)) << 2)) = v;
             } else {
                 int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
                 *reinterpret_cast<float4*>(&As[buf][k][m]) = v;
@@ -135,9 +145,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
             int idx = tid + p * 256;
             const float4 v = masked(rb[p], vb[p]);
             if (B_KC) {
-                int n = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
-                Bs[buf][k + 0][n] = v.x; Bs[buf][k + 1][n] = v.y;
-                Bs[buf][k + 2][n] = v.z; Bs[buf][k + 3][n] = v.w;
+                const int n = idx / PP, pc = idx % PP;
+                *reinterpret_cast<float4*>(fb(buf) + n * BK + ((pc ^ swz(n)) << 2)) = v;
             } else {
                 int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
                 *reinterpret_cast<float4*>(&Bs[buf][k][n]) = v;
@@ -156,18 +165,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+        // k-steps in groups of 8: MFMA e of group j takes k = 8 j + 4 half + e from BOTH operands (any pairing of the
+        // tile's k values with (lane half, step) is a valid order of the sum) - a k-contiguous operand then needs ONE
+        // ds_read_b128 per lane per 4 MFMAs.
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
+        for (int j8 = 0; j8 < BK / 8; ++j8) {
+            float a[TM][4], b[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk * 2 + half][wm * (BM / 2) + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) {
+                const int m = wm * (BM / 2) + i * 32 + l31;
+                if (A_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(fa(buf) + m * BK + (((2 * j8 + half) ^ swz(m)) << 2));
+                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+                } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk * 2 + half][wn * (BN / 2) + j * 32 + l31];
+                    for (int e = 0; e < 4; ++e) a[i][e] = As[buf][8 * j8 + 4 * half + e][m];
+                }
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * (BN / 2) + j * 32 + l31;
+                if (B_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(fb(buf) + n * BK + (((2 * j8 + half) ^ swz(n)) << 2));
+                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) b[j][e] = Bs[buf][8 * j8 + 4 * half + e][n];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
@@ -195,6 +227,86 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
                 }
             }
         }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(
+    const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
+    float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
+    const int* __restrict__ dyn, int dyn_mode, float alpha, float beta, float* __restrict__ part) {
+    constexpr int BK = TileK<BM>::value;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
+    gemm_f32_tile<BM, BN, A_KC, B_KC>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, part,
+                                      blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, As, Bs);
+}
+
+// ---- grouped launch: up to SREC_GEMM32_MAXP independent products (any mix of the three operand layouts) in ONE grid.
+// The session-vector head of the models is a chain of small fp32 products (B x d x d; a few microseconds of matrix
+// work each) next to one or two larger ones over all the nodes: launched one by one they cost a kernel node each plus a
+// split-K reduce each; grouped, the small ones run in the shadow of the large ones.
+struct GroupK {
+    srec_gemm_f32_group g;
+    int tile_end[SREC_GEMM32_MAXP];      // prefix sums of workgroups per problem
+    int tiles_n[SREC_GEMM32_MAXP], tiles_mn[SREC_GEMM32_MAXP];
+    long ws_off[SREC_GEMM32_MAXP];       // slab offsets (floats) of the split problems
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GroupK k) {
+    constexpr int BK = TileK<64>::value;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][64 + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][64 + 4];
+    int p = 0;
+    while (p + 1 < k.g.np && (int)blockIdx.x >= k.tile_end[p]) ++p;
+    const int t = blockIdx.x - (p > 0 ? k.tile_end[p - 1] : 0);
+    const int bz = t / k.tiles_mn[p], r = t % k.tiles_mn[p];
+    const int by = r / k.tiles_n[p], bx = r % k.tiles_n[p];
+    const srec_gemm_f32_group& g = k.g;
+    const int nsplit = g.nsplit[p] > 1 ? g.nsplit[p] : 1;
+    float* part = k.g.ws + k.ws_off[p];
+#define SREC_TILE(AK, BK_)                                                                                             \
+    gemm_f32_tile<64, 64, AK, BK_>(g.A[p], g.a_rs[p], g.a_cs[p], g.B[p], g.b_rs[p], g.b_cs[p], g.C[p], g.ldc[p],         \
+                                   g.bias[p], g.M[p], g.N[p], g.K[p], g.dyn[p], g.dyn_mode[p], g.alpha[p], g.beta[p], \
+                                   part, bx, by, bz, nsplit, As, Bs)
+    const bool akc = g.a_cs[p] == 1, bkc = g.b_cs[p] == 1;     // uniform per workgroup
+    if (akc && bkc) SREC_TILE(true, true);
+    else if (akc) SREC_TILE(true, false);
+    else if (bkc) SREC_TILE(false, true);
+    else SREC_TILE(false, false);
+#undef SREC_TILE
+}
+
+// the split problems of a group, reduced in one launch: blockIdx.y = problem
+__global__ void splitk_reduce_group_kernel(GroupK k) {
+    const int p = blockIdx.y;
+    const srec_gemm_f32_group& g = k.g;
+    const int nsplit = g.nsplit[p];
+    if (nsplit <= 1) return;
+    const int M = g.M[p], N = g.N[p];
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (size_t)M * N) return;
+    const float* part = g.ws + k.ws_off[p];
+    const int row = (int)(i / N), col = (int)(i % N);
+    const int Ml = g.dyn_mode[p] == 1 ? dyn_count(g.dyn[p], M) : M;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < nsplit; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * M * N + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* c = g.C[p] + (size_t)row * g.ldc[p] + col;
+    const float alpha = g.alpha[p], beta = g.beta[p];
+    const float* bias = g.bias[p];
+    if (row >= Ml) {
+        if (beta == 0.f) { c[0] = 0.f; c[1] = 0.f; c[2] = 0.f; c[3] = 0.f; }
+        return;
+    }
+    float o[4] = {alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (bias != nullptr) o[j] += bias[col + j];
+        if (beta != 0.f) o[j] += beta * c[j];
+        c[j] = o[j];
+    }
 }
 
 // C = alpha * sum_z part[z] + bias + beta * C   (rows >= live M are zeroed when beta == 0)
@@ -277,4 +389,81 @@ extern "C" int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B,
     }
     return launch<64, 64>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, ws, nsplit,
                           st);
+}
+
+// Grouped form of srec_gemm_f32 (same operand conventions per problem).  The split of skinny long-K problems is chosen
+// here (g->nsplit is ignored on input); ws / ws_floats = the shared slab workspace.
+extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream) {
+    const srec_gemm_f32_group* gin = (const srec_gemm_f32_group*)desc;
+    if (gin->np <= 0) return 0;
+    if (gin->np > SREC_GEMM32_MAXP) return SREC_BAD_ARG;
+    GroupK k;
+    k.g = *gin;
+    k.g.ws = ws;
+    {   // Workgroups start in index order: the problems with the longest per-workgroup k-loop go first, so that an unsplit
+        // long-K product is not left running alone after the large products have drained.
+        int order[SREC_GEMM32_MAXP];
+        for (int p = 0; p < gin->np; ++p) order[p] = p;
+        for (int i = 1; i < gin->np; ++i)
+            for (int j = i; j > 0 && gin->K[order[j]] > gin->K[order[j - 1]]; --j) std::swap(order[j], order[j - 1]);
+        for (int q = 0; q < gin->np; ++q) {
+            const int p = order[q];
+            srec_gemm_f32_group& g = k.g;
+            g.A[q] = gin->A[p]; g.a_rs[q] = gin->a_rs[p]; g.a_cs[q] = gin->a_cs[p];
+            g.B[q] = gin->B[p]; g.b_rs[q] = gin->b_rs[p]; g.b_cs[q] = gin->b_cs[p];
+            g.C[q] = gin->C[p]; g.ldc[q] = gin->ldc[p]; g.bias[q] = gin->bias[p];
+            g.M[q] = gin->M[p]; g.N[q] = gin->N[p]; g.K[q] = gin->K[p];
+            g.dyn[q] = gin->dyn[p]; g.dyn_mode[q] = gin->dyn_mode[p];
+            g.alpha[q] = gin->alpha[p]; g.beta[q] = gin->beta[p];
+        }
+    }
+    long total64 = 0;
+    for (int p = 0; p < k.g.np; ++p) {
+        const srec_gemm_f32_group& g = k.g;
+        if (g.M[p] <= 0 || g.N[p] <= 0) return SREC_BAD_ARG;
+        if ((g.a_rs[p] != 1 && g.a_cs[p] != 1) || (g.b_rs[p] != 1 && g.b_cs[p] != 1)) return SREC_BAD_ARG;
+        const int a_ld = (g.a_cs[p] == 1) ? g.a_rs[p] : g.a_cs[p], b_ld = (g.b_cs[p] == 1) ? g.b_rs[p] : g.b_cs[p];
+        if ((a_ld & 3) || (b_ld & 3)) return SREC_BAD_ARG;
+        if ((g.a_cs[p] == 1 && (g.K[p] & 3)) || (g.a_cs[p] != 1 && (g.M[p] & 3))) return SREC_BAD_ARG;
+        if ((g.b_cs[p] == 1 && (g.K[p] & 3)) || (g.b_cs[p] != 1 && (g.N[p] & 3))) return SREC_BAD_ARG;
+        if (((uintptr_t)g.A[p] & 15) || ((uintptr_t)g.B[p] & 15)) return SREC_BAD_ARG;
+        total64 += (long)cdiv(g.M[p], 64) * cdiv(g.N[p], 64);
+    }
+    long ws_used = 0;
+    int end = 0, max_red = 0, any_split = 0;
+    for (int p = 0; p < k.g.np; ++p) {
+        srec_gemm_f32_group& g = k.g;
+        const int tm = cdiv(g.M[p], 64), tn = cdiv(g.N[p], 64);
+        const long tiles = (long)tm * tn;
+        int nsplit = 1;
+        // problems with few output tiles get a k-split (>= 64 of K per workgroup): always for long K (weight gradients over
+        // all the nodes), for short K only when the group does not fill the chip anyway (a small product beside a large one
+        // runs in its shadow and saves the reduce)
+        if (ws != nullptr && tiles < 128 && (g.K[p] >= 1024 || (g.K[p] >= 256 && total64 < 512)) && (g.N[p] & 3) == 0 && (g.ldc[p] & 3) == 0 &&
+            ((uintptr_t)g.C[p] & 15) == 0) {
+            nsplit = (int)(512 / tiles);
+            if (nsplit > g.K[p] / 64) nsplit = g.K[p] / 64;
+            if (nsplit > 32) nsplit = 32;
+            while (nsplit > 1 && ws_used + (long)nsplit * g.M[p] * g.N[p] > ws_floats) --nsplit;
+            if (nsplit < 1) nsplit = 1;
+        }
+        g.nsplit[p] = nsplit;
+        k.ws_off[p] = ws_used;
+        if (nsplit > 1) {
+            ws_used += (long)nsplit * g.M[p] * g.N[p];
+            any_split = 1;
+            const int red = (int)(((size_t)g.M[p] * g.N[p] / 4 + 255) / 256);
+            if (red > max_red) max_red = red;
+        }
+        k.tiles_n[p] = tn;
+        k.tiles_mn[p] = (int)tiles;
+        end += (int)tiles * nsplit;
+        k.tile_end[p] = end;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(end), dim3(256), 0, st, k);
+    if (any_split)
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(max_red, k.g.np), dim3(256), 0, st, k);
+    SREC_LAUNCH_CHECK();
+    return 0;
 }

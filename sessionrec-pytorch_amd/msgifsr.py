@@ -351,13 +351,20 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             allf, picked = ops.permute_and_pick(stacked, mg.cat_perm, mg.field('cat_inv'),
                                                 [mg.field('lastcat%d' % (i + 1)) for i in live], mg.dynp('NT'), dB)
             feat_vs = dict(zip(live, picked))
-        sr_g = self.readout(mg, allf, feat_vs, live)
         srs = []
-        for i in live:
-            # fc_sr(cat[x_last, sr_g]) as ONE K = 2 d product (and one backward-data / one weight-gradient product) instead of
-            # two K = d segments each: these B-row GEMMs are launch bound, the 1 MB concatenation is not
-            s = ops.linear(ops.cat_cols(feat_vs[i], sr_g[i]), self.fc_sr[i].weight, None, dB, exact=True)
-            srs.append(ops.normalize(s, 0, dB) if self.norm else s)
+        if len(live) <= 4 and not __import__('os').environ.get('SREC_UNFUSED_HEAD'):
+            # read-out + fc_sr(cat[x_last, sr_g]) of every live order as grouped exact-fp32 launches (ops.ReadoutHead):
+            # these B-row products are launch bound one by one
+            ro = self.readout
+            ss = ops.readout_head(allf, mg.cat_seg, mg.dynp('NT'), dB,
+                                  [(feat_vs[i], ro.fc_u[i].weight, ro.fc_u[i].bias, ro.fc_v[i].weight, ro.fc_e[i].weight,
+                                    self.fc_sr[i].weight) for i in live])
+            srs = [ops.normalize(s, 0, dB) if self.norm else s for s in ss]
+        else:
+            sr_g = self.readout(mg, allf, feat_vs, live)
+            for i in live:
+                s = ops.linear(ops.cat_cols(feat_vs[i], sr_g[i]), self.fc_sr[i].weight, None, dB, exact=True)
+                srs.append(ops.normalize(s, 0, dB) if self.norm else s)
         if self.fusion and K > 1:
             return srs                                     # one session vector per order (IFR mixture)
         return srs[0]

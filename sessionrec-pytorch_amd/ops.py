@@ -518,6 +518,164 @@ def seg_attn(U, Vq, we, X, seg, dynB=None):
     return SegAttn.apply(U, Vq, we, X, seg, dynB)
 
 
+class GemmF32Group(_ct.Structure):
+    """host mirror of srec_gemm_f32_group (include/srec_hg.h)"""
+    _fields_ = [('np', _ct.c_int),
+                ('A', _ct.c_void_p * 16), ('a_rs', _ct.c_int * 16), ('a_cs', _ct.c_int * 16),
+                ('B', _ct.c_void_p * 16), ('b_rs', _ct.c_int * 16), ('b_cs', _ct.c_int * 16),
+                ('C', _ct.c_void_p * 16), ('ldc', _ct.c_int * 16), ('bias', _ct.c_void_p * 16),
+                ('M', _ct.c_int * 16), ('N', _ct.c_int * 16), ('K', _ct.c_int * 16),
+                ('dyn', _ct.c_void_p * 16), ('dyn_mode', _ct.c_int * 16),
+                ('alpha', _ct.c_float * 16), ('beta', _ct.c_float * 16), ('nsplit', _ct.c_int * 16), ('ws', _ct.c_void_p)]
+
+
+def gemm_f32_group(probs):
+    """ONE launch of up to 16 independent exact-fp32 products (csrc/gemm.hip, srec_gemm_f32_group_run).  A problem is
+    (kind, a, b, out, bias, dyn, beta):  'nt' out[M,N] = a[M,K] b[N,K]^T + bias (dyn clamps M);  'nn' out[M,K] = a[M,N] b[N,K]
+    (dyn clamps M);  'tn' out[N,K] = a[M,N]^T b[M,K] (dyn clamps the reduction rows M).  (+ beta * out)"""
+    assert 0 < len(probs) <= 16
+    g = GemmF32Group()
+    g.np = len(probs)
+    for p, (kind, a, b, out, bias, dyn, beta) in enumerate(probs):
+        if kind == 'nt':
+            M, K = a.shape
+            N = b.shape[0]
+            g.a_rs[p], g.a_cs[p], g.b_rs[p], g.b_cs[p], mode = _ld(a), 1, _ld(b), 1, 1
+        elif kind == 'nn':
+            M, K = a.shape
+            N = b.shape[1]
+            g.a_rs[p], g.a_cs[p], g.b_rs[p], g.b_cs[p], mode = _ld(a), 1, 1, _ld(b), 1
+        else:
+            K, M = a.shape
+            N = b.shape[1]
+            g.a_rs[p], g.a_cs[p], g.b_rs[p], g.b_cs[p], mode = 1, _ld(a), 1, _ld(b), 2
+        g.A[p], g.B[p], g.C[p], g.ldc[p], g.bias[p] = ptr(a), ptr(b), ptr(out), _ld(out), ptr(bias)
+        g.M[p], g.N[p], g.K[p] = M, N, K
+        g.dyn[p], g.dyn_mode[p] = ptr(dyn), (mode if dyn is not None else 0)
+        g.alpha[p], g.beta[p] = 1.0, beta
+    lib.srec_gemm_f32_group_run(_ct.addressof(g), *_gemm_ws(probs[0][1].device), stream())
+
+
+_ONES4 = {}
+
+
+def _ones4(n, device):
+    t = _ONES4.get(str(device))
+    if t is None or t.shape[0] < n:
+        t = _ONES4[str(device)] = torch.ones(n, 4, device=device, dtype=torch.float32)
+    return t
+
+
+class ReadoutHead(torch.autograd.Function):
+    """Attention read-out + session-vector projection of MSGIFSR (msgifsr.py:127-146 AttnReadout, :272-279 fc_sr) for
+    every live order, exact fp32, as grouped launches:
+        U_i = allf Wu_i^T + bu_i;  Vq_i = v_i Wv_i^T;  alpha_i = softmax_session(we_i . sigmoid(U_i + Vq_i[b]));
+        g_i = sum alpha_i allf;  s_i = [v_i | g_i] Wsr_i^T
+    forward: 1 grouped GEMM (all U, Vq) + per order (read-out kernel, concat) + 1 grouped GEMM (all s);
+    backward: 1 grouped GEMM (d cat, d Wsr) + per order read-out backward + 1 grouped GEMM (+ 1 slab reduce) for
+    d allf += dU Wu, d Wu, d v += dVq Wv, d Wv + the two bias / fc_e column sums.  The same products launched one by one
+    were 9 GEMM + 7 split-K reduce + 2 accumulate nodes of the captured step."""
+
+    @staticmethod
+    def forward(ctx, allf, seg, dT, dB, *flat):
+        n = len(flat) // 6
+        allf = _rows(allf)
+        NT, D = allf.shape
+        dev = allf.device
+        per = []
+        for i in range(n):
+            v, Wu, bu, Wv, we, Wsr = flat[6 * i:6 * i + 6]
+            per.append((_rows(v), _rows(Wu), bu, _rows(Wv), we.reshape(-1).contiguous(), _rows(Wsr)))
+        B = per[0][0].shape[0]
+        h = per[0][1].shape[0]
+        Us = [torch.empty(NT, h, device=dev, dtype=torch.float32) for _ in range(n)]
+        Vqs = [torch.empty(B, h, device=dev, dtype=torch.float32) for _ in range(n)]
+        probs = []
+        for i, (v, Wu, bu, Wv, we, Wsr) in enumerate(per):
+            probs.append(('nt', allf, Wu, Us[i], bu, dT, 0.0))
+            probs.append(('nt', v, Wv, Vqs[i], None, dB, 0.0))
+        gemm_f32_group(probs)
+        alphas, cats, outs, probs = [], [], [], []
+        for i, (v, Wu, bu, Wv, we, Wsr) in enumerate(per):
+            alpha = torch.empty(NT, device=dev, dtype=torch.float32)
+            srg = torch.empty(B, D, device=dev, dtype=torch.float32)
+            lib.srec_seg_attn_fwd(ptr(Us[i]), h, ptr(Vqs[i]), h, ptr(we), ptr(allf), _ld(allf), ptr(seg), B, ptr(dB), h, D,
+                                  ptr(alpha), ptr(srg), D, stream())
+            cat = torch.empty(B, v.shape[1] + D, device=dev, dtype=torch.float32)
+            lib.srec_cat_cols(ptr(v), _ld(v), v.shape[1], ptr(srg), D, D, B, ptr(cat), stream())
+            out = torch.empty(B, Wsr.shape[0], device=dev, dtype=torch.float32)
+            probs.append(('nt', cat, Wsr, out, None, dB, 0.0))
+            alphas.append(alpha)
+            cats.append(cat)
+            outs.append(out)
+        gemm_f32_group(probs)
+        ctx.save_for_backward(allf, seg, *[t for i in range(n) for t in (per[i][0], per[i][1], per[i][3], per[i][4], per[i][5],
+                                                                        Us[i], Vqs[i], alphas[i], cats[i])])
+        ctx.n, ctx.dT, ctx.dB = n, dT, dB
+        ctx.has_bu = [per[i][2] is not None for i in range(n)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        allf, seg, *rest = ctx.saved_tensors
+        n, dT, dB = ctx.n, ctx.dT, ctx.dB
+        NT, D = allf.shape
+        dev = allf.device
+        per = [rest[9 * i:9 * i + 9] for i in range(n)]
+        B = per[0][0].shape[0]
+        h = per[0][1].shape[0]
+        gcats, gWsrs, probs = [], [], []
+        for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat) in enumerate(per):
+            g = _rows(gs[i])
+            gcat = torch.empty_like(cat)
+            gWsr = torch.empty_like(Wsr)
+            probs.append(('nn', g, Wsr, gcat, None, dB, 0.0))
+            probs.append(('tn', g, cat, gWsr, None, dB, 0.0))
+            gcats.append(gcat)
+            gWsrs.append(gWsr)
+        gemm_f32_group(probs)
+        g_allf = None
+        probs, grads, extra = [], [], []
+        for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat) in enumerate(per):
+            dv = v.shape[1]
+            gsrg = gcats[i][:, dv:]
+            dX = torch.empty(NT, D, device=dev, dtype=torch.float32)      # rows behind the live nodes zeroed in-kernel
+            dU = torch.empty(NT, h, device=dev, dtype=torch.float32)
+            dVq = torch.empty(B, h, device=dev, dtype=torch.float32)
+            dwp = torch.empty(B, h, device=dev, dtype=torch.float32)
+            lib.srec_seg_attn_bwd(ptr(gsrg), _ld(gsrg), ptr(allf), _ld(allf), ptr(alpha), ptr(U), h, ptr(Vq), h, ptr(we),
+                                  ptr(seg), B, ptr(dB), h, D, NT, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp), h, stream())
+            gWu, gWv = torch.empty_like(Wu), torch.empty_like(Wv)
+            gv = gcats[i][:, :dv]                                         # d v: the concat half, + dVq Wv in place
+            probs.append(('nn', dU, Wu, dX, None, dT, 1.0))               # d allf (this order) = read-out term + dU Wu
+            probs.append(('tn', dU, allf, gWu, None, dT, 0.0))
+            probs.append(('nn', dVq, Wv, gv, None, dB, 1.0))
+            probs.append(('tn', dVq, v, gWv, None, dB, 0.0))
+            # column sums (d bu = sum_n dU, d we = sum_b dwp) as products with a block of ones, inside the same launch:
+            # as col_sum calls they were two kernel nodes each
+            ones = _ones4(max(NT, B), dev)
+            sums = torch.empty(8, h, device=dev, dtype=torch.float32)
+            gbu = None
+            if ctx.has_bu[i]:
+                probs.append(('tn', ones[:NT], dU, sums[:4], None, dT, 0.0))
+                gbu = sums[0]
+            probs.append(('tn', ones[:B], dwp, sums[4:], None, dB, 0.0))
+            grads.append((gv, gWu, gbu, gWv, sums[4:5], gWsrs[i]))
+            extra.append(dX)
+        per_launch = 12 if len(probs) > 16 else 16          # whole orders per launch (6 problems each)
+        for c in range(0, len(probs), per_launch):
+            gemm_f32_group(probs[c:c + per_launch])
+        g_allf = extra[0]
+        for dX in extra[1:]:
+            g_allf = g_allf + dX
+        return (g_allf, None, None, None) + tuple(t for gr in grads for t in gr)
+
+
+def readout_head(allf, seg, dT, dB, per_order):
+    """per_order: [(v_i, Wu_i, bu_i, Wv_i, we_i, Wsr_i)] -> tuple of s_i [B, d] (before the optional normalisation)"""
+    return ReadoutHead.apply(allf, seg, dT, dB, *[t for po in per_order for t in po])
+
+
 class SegMeanAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, H, F, seg, B, dynB):

@@ -70,23 +70,44 @@ def _oracle_fp64_final(name, init, samples, V):
         labels = torch.from_numpy(labels)
         opt = torch.optim.Adam(train.fix_weight_decay(m), lr=1e-3, weight_decay=1e-4)
         m.train()
-        for _ in range(3):
+        grads0, risky = {}, 0
+        for step in range(3):
             opt.zero_grad()
             torch.nn.functional.nll_loss(m(*inputs), labels).backward()
+            for k, p in m.named_parameters():
+                if p.grad is None or float(p.grad.abs().max()) == 0.0:
+                    continue
+                if step == 0:
+                    grads0[k] = p.grad.detach().clone()
+                # components that fp32 cannot tell from zero (|g| below ~10 ulp of the tensor's gradient scale): Adam turns
+                # their SIGN into a step of up to lr, in either fp32 implementation, by luck of the summation order
+                risky += int(((p.grad != 0) & (p.grad.abs() < 1e-6 * p.grad.abs().mean())).sum())
             opt.step()
     finally:
         torch.set_default_dtype(torch.float32)
-    return {k: v.detach() for k, v in m.state_dict().items()}
+    return {k: v.detach() for k, v in m.state_dict().items()}, grads0, risky
 
 
-def roundoff_close(mine, ref32, truth64, what):
+def roundoff_close(mine, ref32, truth64, what, risky=0, lr=1e-3, steps=3):
     """`mine` (fp32 HIP) must be as close to the float64 trajectory as the reference's own fp32 run is:
     Adam divides by sqrt(v), so fp32 summation-order noise in near-zero gradient components becomes a
-    visible fraction of a step in BOTH fp32 implementations."""
+    visible fraction of a step in BOTH fp32 implementations.
+    risky > 0: the float64 run saw gradient components below fp32 resolution (see _oracle_fp64_final).  Either fp32
+    run may then take such a component's Adam step with the other sign (an O(lr) difference in ONE weight, e.g. fc_sr of
+    msgifsr_K1_edge: |g| ~ 1e-8 against a tensor scale of 0.17), after which every later gradient differs at the 1e-3
+    relative level.  The trajectory check is then the bounded-divergence form (the amplification-free check of the same
+    round-off is the step-0 gradient yardstick in the test body)."""
     mine = torch.as_tensor(mine).detach().double().cpu()
     ref32 = torch.as_tensor(ref32).detach().double().cpu()
     t = truth64.double().cpu()
     e_mine, e_ref = (mine - t).abs(), (ref32 - t).abs()
+    if risky:
+        frac = (e_mine <= 1e-5 + 1e-3 * t.abs()).double().mean().item()
+        assert frac >= 0.999, '%s: only %.5f of the elements within 1e-5 of the float64 trajectory' % (what, frac)
+        assert e_mine.max().item() <= lr * steps, '%s: max |err| %.3e' % (what, e_mine.max().item())
+        assert e_mine.mean().item() <= 3.0 * e_ref.mean().item() + 1e-6, \
+            '%s: mean |err| vs fp64 %.3e (reference fp32 run: %.3e)' % (what, e_mine.mean().item(), e_ref.mean().item())
+        return
     # (+2e-8 absolute: about one ulp of a 0.1-sized parameter; and a small tensor's mean may be carried by ONE component
     # whose near-zero gradient flipped the sign of an Adam step - that component is bounded by the max check below)
     floor = max(2e-8, 4e-6 / max(e_mine.numel(), 1))
@@ -173,15 +194,34 @@ def test_model_matches_reference_fixture(dev, name):
             for k in z.files:
                 if k.startswith('grad/') and not k.startswith('grad/embedding'):
                     grad_close(params[k[5:]], z[k], 'fused ' + k)
+            grads_fused = {k: p.grad.detach().clone() for k, p in params.items() if p.grad is not None}
         opt.step()
         losses.append(loss.item())
     close(torch.tensor(losses), torch.from_numpy(z['losses']).float(), rtol=1e-5, atol=1e-5, what='loss trace')
     sd = model.state_dict()
-    truth = _oracle_fp64_final(name, init, samples, V)
+    truth, grads64, risky = _oracle_fp64_final(name, init, samples, V)
+    # round-off yardstick without Adam's amplification: the fused path's step-0 gradients are as close to the float64
+    # gradients as the reference's own fp32 gradients are - within one order of magnitude per tensor (a cancelling sum
+    # such as a bias gradient loses more in the MFMA's sequential accumulation than in torch's pairwise one; bf16
+    # operands anywhere on the path would be off by three orders)
+    for k, g64 in grads64.items():
+        if 'grad/' + k not in z.files or k.startswith('embedding') or k not in grads_fused:
+            continue
+        e_mine = (grads_fused[k].double().cpu() - g64).abs().mean().item()
+        e_ref = (torch.from_numpy(z['grad/' + k]).double() - g64).abs().mean().item()
+        assert e_mine <= 10.0 * e_ref + 1e-9 * float(g64.abs().mean()) + 1e-12, \
+            'step-0 grad %s: mean |err| vs fp64 %.3e (reference fp32 gradients: %.3e)' % (k, e_mine, e_ref)
+    print('fp32-unresolvable gradient components in the float64 run:', risky)
     for k in z.files:
         if k.startswith('final/') and k[6:] in sd and sd[k[6:]].dtype == torch.float32:
-            roundoff_close(sd[k[6:]], z[k], truth[k[6:]], k)
-    # 4) evaluation ranking
+            roundoff_close(sd[k[6:]], z[k], truth[k[6:]], k, risky)
+    # 4) evaluation ranking - from the REFERENCE's trained weights where the fixture holds all of them, so that this check
+    # sees the evaluation path and not the round-off the three training steps above accumulated (checked there)
+    finals = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('final/')}
+    if all(k in finals for k, v in sd.items() if v.dtype == torch.float32 and 'running' not in k and k in dict(model.named_parameters())):
+        model.load_state_dict({**sd, **{k: v.to(dev) for k, v in finals.items() if k in sd}})
+        pkg('ops').weights_changed()
+        model.__dict__.pop('_srec_state', None)
     model.eval()
     with torch.no_grad():
         ev = model(*inputs)

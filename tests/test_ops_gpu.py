@@ -961,3 +961,92 @@ def test_lookup_with_fused_dropout(dev):
             ops.RNG_COUNTER.pop(str(dev), None)
         else:
             ops.RNG_COUNTER[str(dev)] = old
+
+
+def test_gemm_f32_group_mixed_layouts(dev):
+    """one grouped launch of exact-fp32 products in all three operand layouts, with bias, beta, dynamic row counts, a strided
+    output view and a long-K weight gradient (k-split into slabs + grouped reduce)"""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    NT, B, d = 3000, 512, 256
+    allf, Wu, bu, v, Wv = r(NT, d), r(d, d), r(d), r(B, d), r(d, d)
+    dU, dVq = r(NT, d), r(B, d)
+    liveT = torch.tensor([2777], device=dev, dtype=torch.int32)
+    liveB = torch.tensor([500], device=dev, dtype=torch.int32)
+    U, Vq = torch.full((NT, d), 7.0, device=dev), torch.empty(B, d, device=dev)
+    dX0 = r(NT, d)
+    dX0[2777:] = 0
+    dX = dX0.clone()
+    gWu = torch.empty(d, d, device=dev)
+    wide0 = r(B, 2 * d)
+    wide = wide0.clone()
+    gWv = torch.empty(d, d, device=dev)
+    small = torch.empty(36, 8, device=dev)
+    sa, sb = r(36, 12), r(8, 12)
+    ops.gemm_f32_group([('nt', allf, Wu, U, bu, liveT, 0.0), ('nt', v, Wv, Vq, None, liveB, 0.0),
+                        ('nn', dU, Wu, dX, None, liveT, 1.0), ('tn', dU, allf, gWu, None, liveT, 0.0),
+                        ('nn', dVq, Wv, wide[:, :d], None, liveB, 1.0), ('tn', dVq, v, gWv, None, liveB, 0.0),
+                        ('nt', sa, sb, small, None, None, 0.0)])
+    ref = allf @ Wu.t() + bu
+    ref[2777:] = 0
+    close(U, ref, what='U', atol=5e-5)
+    ref = v @ Wv.t()
+    ref[500:] = 0
+    close(Vq, ref, what='Vq', atol=5e-5)
+    ref = dX0 + dU @ Wu
+    ref[2777:] = 0
+    close(dX, ref, what='dX', atol=5e-5)
+    close(gWu, dU[:2777].t() @ allf[:2777], what='gWu', atol=2e-4)
+    ref = wide0.clone()
+    ref[:500, :d] += (dVq @ Wv)[:500]
+    close(wide, ref, what='strided accumulate', atol=5e-5)
+    close(gWv, dVq[:500].t() @ v[:500], what='gWv', atol=1e-4)
+    close(small, sa @ sb.t(), what='small')
+
+
+@pytest.mark.parametrize('n_orders', [1, 2])
+def test_readout_head_matches_unfused_ops(dev, n_orders):
+    """ops.readout_head (grouped launches) against the same head assembled from ops.linear / seg_attn / cat_cols"""
+    ops = _ops()
+    torch.manual_seed(11)
+    B, d = 96, 64
+    lens = torch.randint(1, 9, (B,))
+    seg = torch.zeros(B + 1, dtype=torch.int32)
+    seg[1:] = lens.cumsum(0)
+    NT = int(seg[-1]) + 13                                  # padded capacity behind the live nodes
+    seg_d = seg.to(dev)
+    dT = torch.tensor([int(seg[-1])], device=dev, dtype=torch.int32)
+    dB = torch.tensor([B], device=dev, dtype=torch.int32)
+    allf0 = torch.randn(NT, d, device=dev)
+    allf0[int(seg[-1]):] = 0
+
+    def params():
+        return [t.requires_grad_() for t in (torch.randn(B, d, device=dev), torch.randn(d, d, device=dev) * 0.2,
+                                             torch.randn(d, device=dev) * 0.2, torch.randn(d, d, device=dev) * 0.2,
+                                             torch.randn(1, d, device=dev) * 0.2, torch.randn(d, 2 * d, device=dev) * 0.2)]
+    per = [params() for _ in range(n_orders)]
+    wts = [torch.randn(B, d, device=dev) for _ in range(n_orders)]
+
+    def run(fused):
+        allf = allf0.clone().requires_grad_()
+        if fused:
+            ss = ops.readout_head(allf, seg_d, dT, dB, per)
+        else:
+            ss = []
+            for v, Wu, bu, Wv, we, Wsr in per:
+                U = ops.linear(allf, Wu, bu, dT, exact=True)
+                Vq = ops.linear(v, Wv, None, dB, exact=True)
+                srg = ops.seg_attn(U, Vq, we, allf, seg_d, dB)
+                ss.append(ops.linear(ops.cat_cols(v, srg), Wsr, None, dB, exact=True))
+        loss = sum((s * w).sum() for s, w in zip(ss, wts))
+        leaves = [allf] + [t for po in per for t in po]
+        grads = torch.autograd.grad(loss, leaves)
+        return [s.detach() for s in ss], grads
+    s1, g1 = run(True)
+    s0, g0 = run(False)
+    for a, b in zip(s1, s0):
+        close(a, b, what='s', atol=2e-5)
+    names = ['allf'] + ['%s%d' % (nm, i) for i in range(n_orders) for nm in ('v', 'Wu', 'bu', 'Wv', 'we', 'Wsr')]
+    for nm, a, b in zip(names, g1, g0):
+        close(a, b, what='grad ' + nm, rtol=2e-4, atol=1e-4)
