@@ -106,6 +106,9 @@ int srec_scatter_add_sorted_drop(const float* g, int ld_g, const int* items, con
 int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, const int* dyn, int d, float max_norm,
                      void* stream);
 /* out[v] = scale / norm(E_v); eps_mode 0: max(norm,eps) (F.normalize), 1: norm+eps (niser.py:151) */
+/* the renorm of every row (max_norm > 0; <= 0: none) + the bf16 operand copy dst16 [>= n, Dp] (Dp >= d, Dp % 4 == 0,
+ * columns d .. Dp zero) of the table the bf16 scoring kernels read, in one pass (d <= 1024) */
+int srec_renorm_rows_bf16(float* W, int ld, int n, int d, float max_norm, void* dst16, int Dp, void* stream);
 int srec_row_invnorm(const float* W, int ld, int n, int d, int eps_mode, float eps, float scale, float* out,
                      void* stream);
 /* row L2 normalisation of node / session features: niser.py:135,142,148  msgifsr.py:253,263,273 */

@@ -126,6 +126,43 @@ __global__ void renorm_rows_kernel(float* __restrict__ W, int ld, const int* __r
     }
 }
 
+// Embedding(max_norm) renorm of EVERY row (max_norm > 0) fused with the per-step bf16 operand copy of the table for the
+// bf16 scoring kernels: one pass over the table instead of renorm + a separate conversion pass.  dst16 [>= n, Dp], zero
+// in the columns d .. Dp.  One wave per row, the row is held in registers between the norm and the two writes (d <= 1024).
+__global__ void renorm_rows_bf16_kernel(float* __restrict__ W, int ld, int n, int d, float max_norm,
+                                        unsigned short* __restrict__ dst16, int Dp) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float* p = W + (size_t)i * ld;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + j * 256;
+        v[j] = c < d ? *reinterpret_cast<const float4*>(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    if (max_norm > 0.f) {
+        const float nrm = sqrtf(wave_sum(s));
+        if (nrm > max_norm) {
+            const float sc = max_norm / (nrm + 1e-7f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane * 4 + j * 256;
+                v[j].x *= sc; v[j].y *= sc; v[j].z *= sc; v[j].w *= sc;
+                if (c < d) *reinterpret_cast<float4*>(p + c) = v[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane * 4 + j * 256;
+        if (c < Dp)
+            *reinterpret_cast<uint2*>(dst16 + (size_t)i * Dp + c) =
+                make_uint2(srec_pack_bf16(v[j].x, v[j].y), srec_pack_bf16(v[j].z, v[j].w));
+    }
+}
+
 // eps_mode 0: 1/max(||x||, eps) (F.normalize)   1: 1/(||x|| + eps) (niser.py)
 __device__ __forceinline__ float inv_norm(float sumsq, int eps_mode, float eps) {
     const float n = sqrtf(sumsq);
@@ -423,6 +460,15 @@ extern "C" int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, con
     if (bad_row_args(d, ld)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(renorm_rows_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, W, ld, idx, n_cap,
                        dyn, d, max_norm);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_renorm_rows_bf16(float* W, int ld, int n, int d, float max_norm, void* dst16, int Dp, void* stream) {
+    if (n <= 0) return 0;
+    if (bad_row_args(d, ld) || d > 1024 || Dp < d || (Dp & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(renorm_rows_bf16_kernel, dim3(cdiv(n, WPB)), dim3(256), 0, (hipStream_t)stream, W, ld, n, d, max_norm,
+                       (unsigned short*)dst16, Dp);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -289,7 +289,16 @@ class MSGIFSR(_ScoringMixin, nn.Module):
     def _prepare_table(self):
         # training entry: the renorm runs here, ahead of the cosine column scale (the scale must be that of the rows
         # the scoring kernels read: msgifsr.py:162 renormalises inside the lookup, :276-279 normalises the result)
-        self._renorm()
+        W = self._table()
+        if self.shard is None and self.training and ops.use_bf16_scoring(W.shape[1]) and W.is_cuda:
+            # bf16 scoring: the renorm and the table's bf16 operand copy in one pass over the rows
+            st = self._state(1)
+            if st.get('tb16') is None:
+                st['tb16'] = ops.TableBF16(W)
+            st['tb16'].refresh(W, 1.0)
+            self._tb16_fresh = True
+        else:
+            self._renorm()
         self._table_ready = True
 
     def session_repr(self, mg, tgrad=None):

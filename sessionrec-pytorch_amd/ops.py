@@ -741,9 +741,17 @@ class TableBF16:
         self.Vp = (V + 127) // 128 * 128
         self.E16 = torch.zeros(self.Vp, dp.value, device=table.device, dtype=torch.bfloat16)
 
-    def refresh(self, table):
+    def refresh(self, table, max_norm=0.0):
+        """one streaming pass: bf16 copy of every row; max_norm > 0: Embedding(max_norm)'s in-place renorm of the fp32 rows
+        in the same pass (msgifsr.py:162 / lessr.py:126)"""
         V, d = table.shape
-        lib.srec_bf16_prepare(ptr(table), table.stride(0), V, None, d, ptr(self.E16), None, self.Vp, stream())
+        if d <= 1024:
+            with torch.no_grad():
+                lib.srec_renorm_rows_bf16(ptr(table), table.stride(0), V, d, float(max_norm), ptr(self.E16), self.E16.shape[1],
+                                          stream())
+        else:
+            assert max_norm <= 0
+            lib.srec_bf16_prepare(ptr(table), table.stride(0), V, None, d, ptr(self.E16), None, self.Vp, stream())
         return self
 
 

@@ -108,6 +108,8 @@ class _ScoringMixin:
             return None
         if st.get('tb16') is None:
             st['tb16'] = ops.TableBF16(W)
+        if self.__dict__.pop('_tb16_fresh', False):      # _prepare_table wrote the copy together with the renorm
+            return st['tb16']
         return st['tb16'].refresh(W)
 
     def topk(self, *inputs, k=20):

@@ -1050,3 +1050,23 @@ def test_readout_head_matches_unfused_ops(dev, n_orders):
     names = ['allf'] + ['%s%d' % (nm, i) for i in range(n_orders) for nm in ('v', 'Wu', 'bu', 'Wv', 'we', 'Wsr')]
     for nm, a, b in zip(names, g1, g0):
         close(a, b, what='grad ' + nm, rtol=2e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('d,Dp,max_norm', [(256, 256, 1.0), (100, 128, 1.0), (64, 64, 0.0), (516, 516, 2.0)])
+def test_renorm_rows_bf16_one_pass(dev, d, Dp, max_norm):
+    """Embedding(max_norm) renorm (lessr.py:126 / msgifsr.py:162) + the bf16 operand copy of the table in one pass"""
+    L = importlib.import_module('sessionrec-pytorch_amd._lib')
+    torch.manual_seed(d)
+    V = 777
+    W = torch.randn(V, d, device=dev) * (2.0 / d ** 0.5)          # norms scattered around 2: some above, some below
+    W[5] *= 0.01
+    ref = W.clone()
+    if max_norm > 0:
+        n = ref.norm(dim=1, keepdim=True)
+        ref = torch.where(n > max_norm, ref * (max_norm / (n + 1e-7)), ref)
+    out16 = torch.full((V + 3, Dp), 7.0, device=dev, dtype=torch.bfloat16)
+    L.lib.srec_renorm_rows_bf16(L.ptr(W), W.stride(0), V, d, max_norm, L.ptr(out16), Dp, L.stream())
+    close(W, ref, what='renormed rows', rtol=1e-6, atol=1e-7)
+    assert torch.equal(out16[:V, :d], W.bfloat16()), 'bf16 copy is the RNE rounding of the renormed rows'
+    assert float(out16[:V, d:].abs().max() if Dp > d else 0.0) == 0.0
+    assert float((out16[V:] - 7.0).abs().max()) == 0.0             # rows past n untouched
