@@ -396,7 +396,7 @@ struct WArgs {
     int n;
 };
 __global__ void weights_bf16_kernel(WArgs a) {
-    __shared__ unsigned short tile[64][66];
+    __shared__ unsigned short tile[64][68];
     int t = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i)
@@ -404,8 +404,33 @@ __global__ void weights_bf16_kernel(WArgs a) {
     const int R = a.R[t], Cc = a.Cc[t];
     const int tc = (Cc + 63) / 64, b = blockIdx.x - a.start[t];
     const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
-    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const float* __restrict__ W = a.W[t];
+    if (((R | Cc) & 3) == 0) {
+        // 4 columns per thread: float4 in, 8-byte bf16 stores in both layouts (2-byte stores ran at a third of this rate)
+        const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+        for (int rr = y; rr < 64; rr += 16) {
+            const int r = r0 + rr, c = c0 + 4 * x;
+            uint2 v = make_uint2(0u, 0u);
+            if (r < R && c < Cc) {
+                const float4 f = *reinterpret_cast<const float4*>(W + (size_t)r * Cc + c);
+                v = make_uint2(srec_pack_bf16(f.x, f.y), srec_pack_bf16(f.z, f.w));
+                *reinterpret_cast<uint2*>(a.W16[t] + (size_t)r * Cc + c) = v;
+            }
+            *reinterpret_cast<uint2*>(&tile[rr][4 * x]) = v;
+        }
+        if (a.WT16[t] == nullptr) return;
+        __syncthreads();
+        for (int cc = y; cc < 64; cc += 16) {
+            const int c = c0 + cc, r = r0 + 4 * x;
+            if (c < Cc && r < R) {
+                const unsigned lo = tile[4 * x][cc] | ((unsigned)tile[4 * x + 1][cc] << 16);
+                const unsigned hi = tile[4 * x + 2][cc] | ((unsigned)tile[4 * x + 3][cc] << 16);
+                *reinterpret_cast<uint2*>(a.WT16[t] + (size_t)c * R + r) = make_uint2(lo, hi);
+            }
+        }
+        return;
+    }
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     for (int rr = y; rr < 64; rr += 4) {
         const int r = r0 + rr, c = c0 + x;
         unsigned short v = 0;
