@@ -10,12 +10,13 @@ def short(k):
     k = re.sub(r'\(.*$', '', k)
     k = k.replace('at::native::', 'aten::')
     return k[:70]
-GROUPS = [('scoring', r'flash_ce|ce_reduce|ce_mean|dsr_reduce|bf16_prepare|rownorm_project|row_invnorm'),
+GROUPS = [('scoring', r'flash_ce|ce_reduce|ce_mean|dsr_reduce|bf16_prepare|rownorm_project|row_invnorm|renorm_rows_bf16'),
           ('adam', r'adam'),
-          ('gat_gemm', r'gemm_group|gemm16|rows_bf16|weights_bf16'),
+          ('readout head', r'gemm_f32_group|splitk_reduce_group|seg_attn|cat_cols'),
+          ('bf16 GEMMs (GAT + GRU)', r'gemm_group|gemm16|rows_bf16|weights_bf16|sum_slabs'),
           ('gat_graph', r'hg_'),
-          ('gru_expander', r'gru_|gram_|gemm_bf16_tn|splitk|gemm_bf16_nt|gemm_f32'),
-          ('readout/rows', r'seg_attn|normalize|gather_rows|scatter_add|col_sum|renorm|mask_scale'),
+          ('gru steps', r'gru_|gram_|gemm_bf16_tn|splitk|gemm_bf16_nt|gemm_f32'),
+          ('rows', r'normalize|gather_rows|scatter_add|col_sum|renorm|mask_scale|permute|pick'),
           ('aten', r'at::native|aten|rocclr')]
 per, tot, other = collections.OrderedDict(), 0.0, []
 for r in rows:
