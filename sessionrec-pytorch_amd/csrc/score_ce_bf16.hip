@@ -104,13 +104,6 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     constexpr int KIND = KIND_ == KIND_FWD ? KIND_FWD : KIND_BWD;
     constexpr bool has_g = KIND_ == KIND_BWD_G;
     constexpr int D = NT * 32, KS = D / 16, PR = D / 8;          // PR: 16-B pieces per row-major row
-    constexpr int RBS = PR >= 16 ? 1 : 16 / PR, FM = (PR >= 16 ? 16 : PR) - 1;
-    // swizzle g(row): piece p of chunk row r sits in 16-B slot p ^ g(r).  D >= 128: the low row bits go to slot bits 2-3
-    // and row bits 2-3 to slot bits 0-1 - 16 distinct rows of one piece (a ds_read_b128 lane group of product 1) AND
-    // 4 consecutive rows x 4 consecutive pieces (one half-wave of a transposing read of product 2) both cover 16
-    // distinct slots.  (g(r) = r & 15 served only the first: the transposing reads ran 4-way bank-conflicted,
-    // SQ_LDS_BANK_CONFLICT = 57 % of SQ_LDS_IDX_ACTIVE; now 0.)
-    auto swz = [](int row) { return PR >= 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row / RBS) & FM); };
     constexpr int YS = CH * D;                                    // elements of one row-major chunk (= one transposed)
     constexpr int BUF = YS;                                       // ONE row-major image per chunk serves both products
     constexpr int NI = D / 16;                                    // 1-KiB LDS-DMA instructions per layout per chunk
@@ -191,17 +184,21 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
     };
+    // Chunk image in LDS, k-major in 16-element blocks: block ks (1 KiB) = [32 chunk rows][k = 16 ks .. + 15], row r
+    // stored at position r ^ 4 (ks & 1).  One LDS-DMA instruction fills one block (lane L <- row L >> 1, 16-B half L & 1).
+    //   * product 1 reads block ks with one ds_read_b128 per lane (row l31, half = lane half): 64 lanes = the block's
+    //     1 KiB, contiguous -> conflict free, address = per-lane base (even / odd ks) + immediate 1 KiB ks;
+    //   * product 2's transposing reads take 4 rows x 32 B from each of the two blocks of a 32-column group per half-wave:
+    //     the row flip of the odd blocks puts those 2 x 128 B into disjoint bank halves, address = ONE per-lane base +
+    //     immediate (column block, k-step, read).
+    // No XOR between lane and compile-time parts anywhere: nothing to compute per read.
     auto stage = [&](int y0, int bufsel, int lane) {
-        constexpr int RPI = 64 / PR > 0 ? 64 / PR : 1;           // row-major rows per DMA instruction (D <= 256: >= 2)
-        const int row_l = lane / PR, pos = lane % PR;
+        const int rowl = (lane >> 1) ^ (4 * (wave & 1));          // instruction i = 4 ii + wave fills block i: i & 1 == wave & 1
+        const unsigned voff = (unsigned)(rowl * D + (lane & 1) * 8) * 2u;
 #pragma unroll
         for (int ii = 0; ii < (NI + 3) / 4; ++ii) {
             const int i = ii * 4 + wave;
-            if (i < NI) {
-                const int g = pos ^ swz(i * RPI + row_l);
-                const unsigned voff = (unsigned)(row_l * D + g * 8) * 2u;
-                glds(Y16 + (size_t)(y0 + i * RPI) * D, voff, lds0 + (unsigned)(bufsel * BUF + i * 512) * 2u);
-            }
+            if (i < NI) glds(Y16 + (size_t)y0 * D + i * 16, voff, lds0 + (unsigned)(bufsel * BUF + i * 512) * 2u);
         }
     };
 
@@ -221,7 +218,6 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         const int y0 = ybeg + c * CH;
         asm volatile("" : "+v"(lane_v));
         const int l31v = lane_v & 31, halfv = lane_v >> 5;
-        const int fsw = swz(l31v);                                // read-side swizzle of this lane's row-major row
         unsigned short* cur = smem16 + (c % NSC) * BUF;
         const int sbase = (c % (SB / CH)) * CH;                   // offset of this chunk inside the side block
         if (sbase == 0) {
@@ -259,16 +255,17 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         {
             constexpr int PF = KS < PFD ? KS : PFD;
-            const unsigned short* yb = cur + l31v * D;
+            const unsigned short* ybe = cur + l31v * 16 + halfv * 8;          // even blocks
+            const unsigned short* ybo = cur + (l31v ^ 4) * 16 + halfv * 8;    // odd blocks (rows flipped by 4)
             bf16x8 af[PF];
 #pragma unroll
             for (int j = 0; j < PF; ++j)
-                af[j] = *reinterpret_cast<const bf16x8*>(yb + (((2 * j + halfv) ^ fsw) << 3));
+                af[j] = *reinterpret_cast<const bf16x8*>(((j & 1) ? ybo : ybe) + j * 512);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks % PF], xf[ks], s, 0, 0, 0);
                 if (ks + PF < KS)
-                    af[ks % PF] = *reinterpret_cast<const bf16x8*>(yb + (((2 * (ks + PF) + halfv) ^ fsw) << 3));
+                    af[ks % PF] = *reinterpret_cast<const bf16x8*>((((ks + PF) & 1) ? ybo : ybe) + (ks + PF) * 512);
             }
 #pragma unroll
             for (int ks = 0; ks < KS - PF; ++ks) {
@@ -373,30 +370,17 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
             // column i) - measured lane map, tools/probes/tr_probe.hip.  Fragments prefetched PFB ahead of their MFMAs.
             {
                 constexpr int NB = 2 * NT, PFB = NB < PFD ? NB : PFD;
-                const int ti = lane_v & 15, trow = ti >> 2;
-                const int tcol = 16 * ((lane_v >> 4) & 1) + 4 * (ti & 3);
-                const int e0row = 4 * halfv + trow;               // + 16 t (+ 8 for the second read)
-                // Address of read e of fragment (cb, t): row = 16 t + 8 e + e0row, piece = 4 cb + 2 b4 + plb (b4 = lane bit 4,
-                // plb = bit 1 of the lane's column quad), slot = piece ^ g(row) = [cb2][cb1 ^ trow1][cb0 ^ trow0][b4 ^ e][plb ^ half]
-                // for D >= 128.  The XOR is bitwise on the byte offset (rows are 512 / 256 B, slots 16 B): ONE per-lane
-                // offset, xor-ed with the compile-time pattern 64 (cb & 3) + 32 e, the rest (cb >> 2, t, e row offsets) in
-                // the instruction's immediate offset - 8 distinct addresses per chunk.
-                const unsigned abase = (unsigned)(((c % NSC) * BUF + e0row * D + (tcol & 7)) * 2
-                                                  + ((((trow << 2) | (tcol >> 3)) ^ halfv) << 4));
+                const int ti = lane_v & 15, trow = ti >> 2, b4 = (lane_v >> 4) & 1;
+                // read e of fragment (cb, t): rows 16 t + 8 e + 4 half + {0..3} of the 16-column group 2 cb + b4 (= block ks);
+                // lane i of the group addresses row (i >> 2), elements 4 (i & 3) .. + 3 of the block row
+                const unsigned short* tb = cur + b4 * 512 + (4 * (halfv ^ b4) + trow) * 16 + 4 * (ti & 3);
                 auto frag = [&](int j) {
                     const int cb = j % NT, t = j / NT;
                     uint2 rr[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        __attribute__((address_space(3))) short4_t* ap;
-                        if (NT >= 4) {
-                            const unsigned x = abase ^ (unsigned)(64 * (cb & 3) + 32 * e);
-                            ap = (__attribute__((address_space(3))) short4_t*)(size_t)(lds0 + x + (unsigned)((cb >> 2) * 256 + (16 * t + 8 * e) * D * 2));
-                        } else {
-                            const int col = cb * 32 + tcol, row = 16 * t + 8 * e + e0row;
-                            ap = (__attribute__((address_space(3))) short4_t*)(cur + row * D + (((col >> 3) ^ swz(row)) << 3) + (col & 7));
-                        }
-                        const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(ap);
+                        const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_t*)(tb + cb * 1024 + (16 * t + 8 * e) * 16));
                         rr[e] = __builtin_bit_cast(uint2, v);
                     }
                     return __builtin_bit_cast(bf16x8, make_uint4(rr[0].x, rr[0].y, rr[1].x, rr[1].y));
