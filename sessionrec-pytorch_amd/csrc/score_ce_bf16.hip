@@ -89,6 +89,7 @@ enum { KIND_FWD = 0, KIND_BWD = 1, KIND_BWD_G = 2 };
 
 #ifdef SREC_FLASH_TIMING   // development probe (tools/flash_timing.py): per-phase clocks of wave 0 of two workgroups
 __device__ unsigned long long g_flash_tim[2][8];
+__device__ unsigned long long g_flash_blk[1024][2];    // wall-clock (s_memrealtime, 100 MHz) start / end of every workgroup
 #define TIM_DECL unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_a[6] = {0, 0, 0, 0, 0, 0}; \
     const bool tim_on = KIND == KIND_BWD && (blockIdx.x == 8 || (int)blockIdx.x == a.n_de_pad + 8)
 #define TIM(i) do { __builtin_amdgcn_sched_barrier(0); tim_t[i] = __builtin_readcyclecounter(); \
@@ -120,6 +121,9 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     const int Bd = dyn_count(a.dynB, a.B);
     TIM_DECL;
     TIM(6);
+#ifdef SREC_FLASH_TIMING
+    if (KIND == KIND_BWD && threadIdx.x == 0 && blockIdx.x < 1024) g_flash_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     bool role_de = false;
     int x0, ybeg, yend, range = 0;
@@ -191,10 +195,14 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     //   * product 2's transposing reads take 4 rows x 32 B from each of the two blocks of a 32-column group per half-wave:
     //     the row flip of the odd blocks puts those 2 x 128 B into disjoint bank halves, address = ONE per-lane base +
     //     immediate (column block, k-step, read).
+    // The two 16-B halves of a block row are swapped in rows 8..15 and 24..31: the 16 rows of a ds_read_b128 lane group
+    // ({0-3, 12-15, 20-27}, ...) then cover all 16 slots of the 256-B bank cycle (un-swapped: 2-way conflicts, 2.4 M of 7.9 M
+    // LDS cycles by SQ_LDS_BANK_CONFLICT).  For the transposing reads that swap depends on the read index e only (row bit
+    // 3): two per-lane bases.
     // No XOR between lane and compile-time parts anywhere: nothing to compute per read.
     auto stage = [&](int y0, int bufsel, int lane) {
         const int rowl = (lane >> 1) ^ (4 * (wave & 1));          // instruction i = 4 ii + wave fills block i: i & 1 == wave & 1
-        const unsigned voff = (unsigned)(rowl * D + (lane & 1) * 8) * 2u;
+        const unsigned voff = (unsigned)(rowl * D + (((lane & 1) ^ ((lane >> 4) & 1)) * 8)) * 2u;   // 16-B halves of rows 8..15, 24..31 swapped
 #pragma unroll
         for (int ii = 0; ii < (NI + 3) / 4; ++ii) {
             const int i = ii * 4 + wave;
@@ -255,8 +263,9 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         {
             constexpr int PF = KS < PFD ? KS : PFD;
-            const unsigned short* ybe = cur + l31v * 16 + halfv * 8;          // even blocks
-            const unsigned short* ybo = cur + (l31v ^ 4) * 16 + halfv * 8;    // odd blocks (rows flipped by 4)
+            const int hsw = halfv ^ ((l31v >> 3) & 1);
+            const unsigned short* ybe = cur + l31v * 16 + hsw * 8;            // even blocks
+            const unsigned short* ybo = cur + (l31v ^ 4) * 16 + hsw * 8;      // odd blocks (rows flipped by 4)
             bf16x8 af[PF];
 #pragma unroll
             for (int j = 0; j < PF; ++j)
@@ -374,13 +383,14 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 // read e of fragment (cb, t): rows 16 t + 8 e + 4 half + {0..3} of the 16-column group 2 cb + b4 (= block ks);
                 // lane i of the group addresses row (i >> 2), elements 4 (i & 3) .. + 3 of the block row
                 const unsigned short* tb = cur + b4 * 512 + (4 * (halfv ^ b4) + trow) * 16 + 4 * (ti & 3);
+                const unsigned short* tb1 = cur + b4 * 512 + (4 * (halfv ^ b4) + trow) * 16 + 4 * ((ti & 3) ^ 2);   // reads e = 1: rows 8..15 / 24..31
                 auto frag = [&](int j) {
                     const int cb = j % NT, t = j / NT;
                     uint2 rr[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) short4_t*)(tb + cb * 1024 + (16 * t + 8 * e) * 16));
+                            (__attribute__((address_space(3))) short4_t*)((e ? tb1 : tb) + cb * 1024 + (16 * t + 8 * e) * 16));
                         rr[e] = __builtin_bit_cast(uint2, v);
                     }
                     return __builtin_bit_cast(bf16x8, make_uint4(rr[0].x, rr[0].y, rr[1].x, rr[1].y));
@@ -423,26 +433,52 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         return;
     }
     const int d = a.d;
+    float* const outp = role_de ? a.dE : a.part_dsr + (size_t)range * a.B * d;
+    const int ld_out = role_de ? a.ld_de : d, nrows = role_de ? a.V : a.B;
+    const bool accum = role_de && a.acc_dE;
+    if (d == D && (ld_out & 3) == 0 && ((size_t)outp & 15) == 0) {
+        // Rows leave as 16-byte stores (a 1 KiB row per wave instruction at D = 256) through a per-wave LDS patch of 8 rows
+        // (the chunk ring is free now): the accumulator layout has ONE float of a row per lane, and 4-byte stores of 128
+        // instructions per wave made this epilogue store-issue bound (21 k cycles of a 80 - 115 k-cycle workgroup life).
+        __syncthreads();                                          // every wave is done with the last chunk image
+        float* patch = reinterpret_cast<float*>(smem16) + wave * 8 * D;
 #pragma unroll
-    for (int cb = 0; cb < NT; ++cb) {
-        const int col = cb * 32 + l31;
-        if (col >= d) continue;
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int xr = x0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (role_de) {
-                if (xr < a.V) {
-                    float* q = a.dE + (size_t)xr * a.ld_de + col;
-                    *q = a.acc_dE ? *q + acc[cb][r] : acc[cb][r];
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cb = 0; cb < NT; ++cb) patch[(e + 4 * half) * D + cb * 32 + l31] = acc[cb][4 * q + e];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int idx = k * 256 + lane * 4, rl = idx / D, col = idx % D;
+                const int xr = x0 + wave * 32 + 8 * q + rl;
+                float4 v = *reinterpret_cast<const float4*>(patch + idx);
+                if (xr < nrows) {
+                    float4* g = reinterpret_cast<float4*>(outp + (size_t)xr * ld_out + col);
+                    if (accum) { const float4 o = *g; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *g = v;
                 }
-            } else if (xr < a.B) {
-                a.part_dsr[((size_t)range * a.B + xr) * d + col] = acc[cb][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb) {
+            const int col = cb * 32 + l31;
+            if (col >= d) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int xr = x0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (xr < nrows) {
+                    float* q = outp + (size_t)xr * ld_out + col;
+                    *q = accum ? *q + acc[cb][r] : acc[cb][r];
+                }
             }
         }
     }
 #ifdef SREC_FLASH_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TIM(1);
+    if (KIND == KIND_BWD && tid == 0 && blockIdx.x < 1024) g_flash_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
     if (tim_on && tid == 0) {
         unsigned long long* o = g_flash_tim[role_de ? 0 : 1];
         for (int i = 0; i < 5; ++i) o[i] = tim_a[i];
@@ -529,6 +565,9 @@ extern "C" int srec_bf16_prepare(const float* src, int ld, int R, const int* dyn
 #ifdef SREC_FLASH_TIMING
 extern "C" int srec_flash_timing(unsigned long long* out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_flash_tim), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+extern "C" int srec_flash_blocks(unsigned long long* out2048) {
+    return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_flash_blk), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -33,7 +33,9 @@ ops._ce_fwd(sr, table, None, labels, ws, None, tb, ws.lab_logit, lse, lossvec, l
 dll = L.lib.load()
 out = (ctypes.c_ulonglong * 16)()
 names = ['wait+barrier', 'stage issue', 'product 1 (S)', 'exp / P', 'product 2 (acc)', 'prologue', 'epilogue', 'lifetime']
-for parts in (3, 3, 1, 2):
+import numpy as np
+blk = (ctypes.c_ulonglong * 2048)()
+for parts in (3, 3, 3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     ops._ce_bwd(sr, table, None, labels, lse, None, None, None, ws, None, tb, dE, dsr, parts)
@@ -43,3 +45,15 @@ for parts in (3, 3, 1, 2):
     print('parts', parts, 'events: %.1f us' % (e0.elapsed_time(e1) * 1e3))
     for r, role in enumerate(('item tile (dE)', 'session tile (d sr)')):
         print('   ', role, {n: out[r * 8 + i] for i, n in enumerate(names)})
+    dll.srec_flash_blocks(blk)
+    b = np.array(list(blk), dtype=np.int64).reshape(1024, 2)
+    live = b[:, 1] > b[:, 0]
+    t0 = b[live, 0].min()
+    st, en = (b[:, 0] - t0) * 0.01, (b[:, 1] - t0) * 0.01      # us (100 MHz)
+    nde = 296
+    for nm, sl in (('item tiles', slice(0, nde)), ('session tiles', slice(nde, 1024))):
+        m = live[sl]
+        if m.any():
+            print('    %-13s n %3d  start %.1f..%.1f us  end %.1f..%.1f (mean %.1f)  life mean %.1f max %.1f' % (
+                nm, m.sum(), st[sl][m].min(), st[sl][m].max(), en[sl][m].min(), en[sl][m].max(), en[sl][m].mean(),
+                (en[sl][m] - st[sl][m]).mean(), (en[sl][m] - st[sl][m]).max()))
