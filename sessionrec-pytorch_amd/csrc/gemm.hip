@@ -429,7 +429,7 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
         if (((uintptr_t)g.A[p] & 15) || ((uintptr_t)g.B[p] & 15)) return SREC_BAD_ARG;
         total64 += (long)cdiv(g.M[p], 64) * cdiv(g.N[p], 64);
     }
-    long ws_used = 0;
+    long ws_used = 0, ws_plan = 0;
     int end = 0, max_red = 0, any_split = 0;
     for (int p = 0; p < k.g.np; ++p) {
         srec_gemm_f32_group& g = k.g;
@@ -444,10 +444,34 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
             nsplit = (int)(512 / tiles);
             if (nsplit > g.K[p] / 64) nsplit = g.K[p] / 64;
             if (nsplit > 32) nsplit = 32;
-            while (nsplit > 1 && ws_used + (long)nsplit * g.M[p] * g.N[p] > ws_floats) --nsplit;
+            while (nsplit > 1 && ws_plan + (long)nsplit * g.M[p] * g.N[p] > ws_floats) --nsplit;
             if (nsplit < 1) nsplit = 1;
         }
         g.nsplit[p] = nsplit;
+        if (nsplit > 1) ws_plan += (long)nsplit * g.M[p] * g.N[p];     // (trimming below only shrinks it)
+        k.tiles_n[p] = tn;
+        k.tiles_mn[p] = (int)tiles;
+        end += (int)tiles * nsplit;
+    }
+    {   // 34 KB of LDS -> 4 workgroups per CU = 128 slots per XCD, 1024 on the chip; workgroups are latency bound, so a grid a
+        // little over a multiple of that pays a whole extra round (the head's backward group: 1172 workgroups, 40 us): trim
+        // the k-splits until the grid fits the rounds it almost fits
+        const int slots = 1024, rounds = end / slots;
+        if (rounds >= 1 && end % slots != 0 && end % slots < slots * 35 / 100) {
+            bool moved = true;
+            while (end > rounds * slots && moved) {
+                moved = false;
+                int best = -1;
+                for (int p = 0; p < k.g.np; ++p)
+                    if (k.g.nsplit[p] > 2 && (best < 0 || k.g.nsplit[p] * k.tiles_mn[p] > k.g.nsplit[best] * k.tiles_mn[best])) best = p;
+                if (best >= 0) { --k.g.nsplit[best]; end -= k.tiles_mn[best]; moved = true; }
+            }
+        }
+    }
+    end = 0;
+    for (int p = 0; p < k.g.np; ++p) {
+        srec_gemm_f32_group& g = k.g;
+        const int nsplit = g.nsplit[p];
         k.ws_off[p] = ws_used;
         if (nsplit > 1) {
             ws_used += (long)nsplit * g.M[p] * g.N[p];
@@ -455,9 +479,7 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
             const int red = (int)(((size_t)g.M[p] * g.N[p] / 4 + 255) / 256);
             if (red > max_red) max_red = red;
         }
-        k.tiles_n[p] = tn;
-        k.tiles_mn[p] = (int)tiles;
-        end += (int)tiles * nsplit;
+        end += k.tiles_mn[p] * nsplit;
         k.tile_end[p] = end;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -507,10 +507,19 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     int nmax = 0;
     for (int p = 0; p < h->np; ++p) nmax = h->N[p] > nmax ? h->N[p] : nmax;
     const int variant = (h->c16 >> 4) & 15;              // experiments (tools/gemm16_bench.py); 0 = tuned default
-    const int tm = (variant & 8) ? ((variant & 4) ? 128 : 64) : ((t128 >= 384 && nmax > 256) ? 128 : 64);
+    int tm = (variant & 8) ? ((variant & 4) ? 128 : 64) : ((t128 >= 384 && nmax > 256) ? 128 : 64);
     // tiny products (the GRU hidden-state GEMMs: ~2k x 256 outputs): 64 x 64 tiles double the workgroups in flight
     long t64x128 = 0;
     for (int p = 0; p < h->np; ++p) t64x128 += (long)cdiv(h->M[p], 64) * cdiv(h->N[p], 128);
+    // Workgroups are dealt to the 8 XCDs round-robin and a workgroup is latency bound on its own DMA ring (a lone one takes
+    // as long as one of three on its CU), so a launch costs (rounds on the fullest XCD) x (workgroup life).  The fp32-output
+    // kernels: 64 x 128 tiles with 2 x 64-deep stages = 48 KB -> 3 per CU = 96 slots per XCD; 128 x 128 = 64 KB -> 2 per CU =
+    // 64 slots, workgroup life +5 % for twice the work (tools/gemm16_bench.py).  The step's backward-data launch (960 64-row
+    // tiles = 120 per XCD) ran 1.25 -> 2 rounds: 77 us; as 480 128-row tiles (60 per XCD) it is one round.
+    if (!(variant & 8) && !(h->c16 & 1) && tm == 64 && t64x128 > 384) {
+        const long r64 = cdiv((int)cdiv((int)t64x128, 8), 96), r128 = cdiv((int)cdiv((int)t128, 8), 64);
+        if (r128 * 105 < r64 * 100) tm = 128;
+    }
     const int tn = (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
     if (int rc = fill(g, desc_, tm, tn, false, blocks)) return rc;
     hipStream_t st = (hipStream_t)stream;
