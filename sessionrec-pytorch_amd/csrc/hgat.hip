@@ -23,6 +23,7 @@ namespace {
 constexpr int WPB = 4;
 constexpr int MAXDEG = 128;
 constexpr int MAXH = 8;
+constexpr int SEGCAP = 1025;   // session offsets staged in LDS by hg_agg / hg_pre (batches of up to 1024 sessions)
 constexpr int NCHUNK = 16;
 constexpr int MAXT = SREC_HG_MAXT, MAXM = SREC_HG_MAXM, MAXB = SREC_HG_MAXB, MAXI = SREC_HG_MAXI;
 
@@ -158,12 +159,43 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
     __shared__ float sc[MAXH][MAXDEG];
     __shared__ int su[MAXH][MAXDEG];
     __shared__ float comb[MAXH][256];
+    __shared__ int sseg[SEGCAP];
     const int row = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int H = a.H, D = a.D, HD = H * D;
     const int t = find_range(a.row0, a.nt, row);
     const int v = row - a.row0[t];
     const bool live = v < dyn_count(a.dyn_n[t], a.ncap[t]);
     const int c = lane * 4;
+    // Session of this node and the mean of the session's input rows (msgifsr.py:86-89) FIRST: the session offsets are staged
+    // in LDS by the whole workgroup (one load round trip; B <= SEGCAP - 1) and searched there, and the session's rows are then
+    // fetched four at a time.  Behind the aggregation this was a tail of 9 dependent global loads (the binary search) + one
+    // dependent load per session node, in a kernel whose workgroups are pure latency chains.
+    float smean = 0.f;
+    {
+        const int nB = dyn_count(a.dynB, a.B);
+        const int* seg = a.seg[t];
+        const bool staged = nB < SEGCAP;
+        if (staged)
+            for (int i = tid; i <= nB; i += 512) sseg[i] = seg[i];
+        __syncthreads();
+        if (live && tid < D) {
+            int lo = 0, hi = nB;                            // session b with seg[b] <= v < seg[b+1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((staged ? sseg[mid] : seg[mid]) <= v) lo = mid; else hi = mid;
+            }
+            const int s0 = staged ? sseg[lo] : seg[lo], s1 = staged ? sseg[lo + 1] : seg[lo + 1];
+            const float* xp = a.x + (size_t)a.row0[t] * a.ld_x + tid;
+            int j = s0;
+            for (; j + 3 < s1; j += 4) {
+                const float x0 = xp[(size_t)j * a.ld_x], x1 = xp[(size_t)(j + 1) * a.ld_x], x2 = xp[(size_t)(j + 2) * a.ld_x],
+                            x3 = xp[(size_t)(j + 3) * a.ld_x];
+                smean += x0; smean += x1; smean += x2; smean += x3;      // same order as one by one
+            }
+            for (; j < s1; ++j) smean += xp[(size_t)j * a.ld_x];
+            smean /= (float)(s1 - s0 > 0 ? s1 - s0 : 1);
+        }
+    }
     if (w < H) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         // Fast path (the usual case: a handful of in-edges per relation): lane = (instance slot q = lane >> 3, edge j =
@@ -293,17 +325,7 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
             best = -INFINITY;
             for (int h = 0; h < H; ++h)
                 if (comb[h][tid] > best) { best = comb[h][tid]; bi = h; }
-            // + mean of the session's input features (nodes of this type)
-            const int* seg = a.seg[t];
-            int lo = 0, hi = dyn_count(a.dynB, a.B);       // session b with seg[b] <= v < seg[b+1]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (seg[mid] <= v) lo = mid; else hi = mid;
-            }
-            const int s0 = seg[lo], s1 = seg[lo + 1];
-            float mean = 0.f;
-            for (int j = s0; j < s1; ++j) mean += a.x[(size_t)(a.row0[t] + j) * a.ld_x + tid];
-            best += mean / (float)(s1 - s0 > 0 ? s1 - s0 : 1);
+            best += smean;                                 // + mean of the session's input features (nodes of this type)
         }
         a.out[(size_t)row * a.ld_out + tid] = best;
         a.arg[(size_t)row * D + tid] = (unsigned char)bi;
@@ -334,12 +356,26 @@ __global__ void hg_pre_kernel(PreArgs a) {
     if (live) {
         const int* seg = a.seg[t];
         int lo = 0, hi = dyn_count(a.dynB, a.B);
+        // 4-ary search: the three probes of a level are independent loads - 5 round trips for 512 sessions instead of 9
+        while (hi - lo > 3) {
+            const int q = (hi - lo) >> 2, m1 = lo + q, m2 = lo + 2 * q, m3 = lo + 3 * q;
+            const int v1 = seg[m1], v2 = seg[m2], v3 = seg[m3];
+            if (v3 <= v) lo = m3; else if (v2 <= v) { lo = m2; hi = m3; } else if (v1 <= v) { lo = m1; hi = m2; } else hi = m1;
+        }
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (seg[mid] <= v) lo = mid; else hi = mid;
         }
         const int s0 = seg[lo], s1 = seg[lo + 1];
-        for (int j = s0; j < s1; ++j) {
+        int j = s0;
+        for (; j + 3 < s1; j += 4) {                       // four rows in flight, added in row order
+            float4 gv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] = *reinterpret_cast<const float4*>(a.g + (size_t)(a.row0[t] + j + e) * a.ld_g + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o.x += gv[e].x; o.y += gv[e].y; o.z += gv[e].z; o.w += gv[e].w; }
+        }
+        for (; j < s1; ++j) {
             const float4 gv = *reinterpret_cast<const float4*>(a.g + (size_t)(a.row0[t] + j) * a.ld_g + c);
             o.x += gv.x; o.y += gv.y; o.z += gv.z; o.w += gv.w;
         }
