@@ -242,6 +242,7 @@ def launch_ranks(n, argv):
     import subprocess
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL / xGMI peer mappings need it on this driver
+    env.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')        # RCCL's version banner (NCCL_DEBUG=VERSION) must not land on stdout
     env.setdefault('OMP_NUM_THREADS', '8')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
@@ -326,7 +327,21 @@ def run_timed(step, dev_batches, warmup, steps, repeats, dist, dev):
     return regions, loss
 
 
+_JSON_OUT = None
+
+
+def emit(obj):
+    """the one JSON line of this process, on the ORIGINAL stdout"""
+    f = _JSON_OUT or sys.stdout
+    f.write(json.dumps(obj) + '\n')
+    f.flush()
+
+
 def main():
+    # stdout carries exactly one JSON line.  RCCL prints its version banner with plain printf at communicator teardown
+    # (NCCL_DEBUG=VERSION in this image), i.e. AFTER the line: from here on file descriptor 1 of this process is stderr, and the
+    # JSON line goes to a private duplicate of the original stdout.
+    global _JSON_OUT
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
@@ -362,6 +377,9 @@ def main():
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    sys.stdout.flush()                                    # (a rank process from here on: the launcher parent keeps its stdout)
+    _JSON_OUT = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -380,8 +398,8 @@ def main():
         seen = torch.ones(1, device=dev)
         dist.all_reduce(seen)                    # every rank contributes 1: the sum is the number of live ranks
         if rank == 0:
-            print(json.dumps(dict(launch_only=True, n_gpus=world, gpus_requested=args.gpus, ranks_seen=int(seen.item()),
-                                  world_size=dist.get_world_size(), backend=dist.get_backend())), flush=True)
+            emit(dict(launch_only=True, n_gpus=world, gpus_requested=args.gpus, ranks_seen=int(seen.item()),
+                                  world_size=dist.get_world_size(), backend=dist.get_backend()))
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -406,7 +424,7 @@ def main():
         torch.manual_seed(123)
         model = build_model(sp, 'SRGNN', V, d, 1).to(dev)
         kt = time_dominant_kernel(model, B, V, d, dev, iters=5)
-        print(json.dumps(kt))
+        emit(kt)
         return
     n_batches = min(args.steps + args.warmup, 48)      # distinct resident batches; longer runs cycle through them
     padded = True
@@ -479,8 +497,8 @@ def main():
         ops.set_precision(args.precision)
 
     if rank == 0 and args.step_only:
-        print(json.dumps(dict(step_only=True, ms_per_step=dt / args.steps * 1e3, value=Bg * args.steps / dt, launches=nodes,
-                              final_loss=final_loss)), flush=True)
+        emit(dict(step_only=True, ms_per_step=dt / args.steps * 1e3, value=Bg * args.steps / dt, launches=nodes,
+                  final_loss=final_loss))
     elif rank == 0:
         Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
         kt = time_dominant_kernel(model, Bg, Vk, d, dev)
@@ -545,7 +563,7 @@ def main():
                                             'encoder replicated, %s' % (world, 'each rank encodes its slice of one 512-session batch' if strong else 'each rank feeds its own batch')) if world > 1 else 'single GPU',
                                final_loss=final_loss),
                    roofline=roof, fp32=fp32, cpu_baseline=cpu)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()                      # the other ranks wait for rank 0's kernel timing / CPU baseline
         dist.destroy_process_group()
