@@ -384,13 +384,40 @@ def permute_and_pick(x, perm, inv, picks, dyn_n=None, dyn_b=None):
     return outs[0], list(outs[1:])
 
 
+class _GradArena:
+    """gradient buffer of a row-split tensor, shared through the pieces: a consumer whose backward produces the gradient of a
+    piece (normalize_stack, gru_expand_all) writes it straight into that piece's rows of ONE buffer, and SplitRows.backward
+    hands the buffer on instead of concatenating (the concatenation was the last aten kernel of the captured step)."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device, self.buf = tuple(shape), device, None
+
+    def rows(self, off, n):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, device=self.device, dtype=torch.float32)
+        return self.buf[off:off + n]
+
+
+def _arena_tag(x):
+    """(arena, first row) of a tensor that SplitRows handed out, else None"""
+    return getattr(x, '_srec_arena', None)
+
+
+def _arena_rows(tag, n, d, device):
+    """gradient rows for a piece: inside its arena when it has one"""
+    if tag is not None and len(tag[0].shape) == 2 and tag[0].shape[1] == d:
+        return tag[0].rows(tag[1], n)
+    return torch.empty(n, d, device=device, dtype=torch.float32)
+
+
 class SplitRows(torch.autograd.Function):
-    """row-range views x[o_i : o_i + n_i]; the backward is ONE concatenation instead of a zero-fill, a slice copy and
-    an add per piece (autograd's SliceBackward)."""
+    """row-range views x[o_i : o_i + n_i]; the backward is ONE buffer (filled in place by the consumers, see _GradArena)
+    or one concatenation, instead of a zero-fill, a slice copy and an add per piece (autograd's SliceBackward)."""
 
     @staticmethod
     def forward(ctx, x, sizes):
         ctx.sizes, ctx.shape = sizes, x.shape
+        ctx.arena = _GradArena(x.shape, x.device)
         outs, off = [], 0
         for n in sizes:
             outs.append(x[off:off + n])
@@ -400,13 +427,29 @@ class SplitRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        gs = [g if g is not None else torch.zeros((n,) + tuple(ctx.shape[1:]), device=next(t for t in gs if t is not None).device)
-              for g, n in zip(gs, ctx.sizes)]
+        buf = ctx.arena.buf
+        if buf is not None and all(g is not None for g in gs):
+            off, esz, ok = 0, buf.element_size() * (buf.stride(0) if buf.dim() > 1 else 1), True
+            for g, n in zip(gs, ctx.sizes):
+                ok = ok and g.shape[0] == n and g.is_contiguous() and g.data_ptr() == buf.data_ptr() + off * esz
+                off += n
+            if ok:
+                return buf, None
+        dev = next(t for t in gs if t is not None).device
+        gs = [g if g is not None else torch.zeros((n,) + tuple(ctx.shape[1:]), device=dev) for g, n in zip(gs, ctx.sizes)]
         return torch.cat(gs, 0), None
 
 
 def split_rows(x, sizes):
-    return SplitRows.apply(x, tuple(sizes))
+    outs = SplitRows.apply(x, tuple(sizes))
+    fn = outs[0].grad_fn if len(outs) else None
+    arena = getattr(fn, 'arena', None)               # the node's ctx attributes are visible on grad_fn
+    if arena is not None:
+        off = 0
+        for o, n in zip(outs, sizes):
+            o._srec_arena = (arena, off)
+            off += n
+    return outs
 
 
 class Normalize(torch.autograd.Function):
@@ -441,6 +484,7 @@ class NormalizeStack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eps_mode, dyns, *xs):
+        ctx.tags = [_arena_tag(x) for x in xs]              # pieces of a split tensor: their gradients go into its buffer
         xs = [_rows(x) for x in xs]
         P, d, dev = len(xs), xs[0].shape[1], xs[0].device
         ns = [x.shape[0] for x in xs]
@@ -461,10 +505,10 @@ class NormalizeStack(torch.autograd.Function):
         ns, dyns = ctx.meta
         gy = _rows(gy)
         P, d = len(ns), y.shape[1]
-        dxall = torch.empty_like(y)                       # the blocks' gradients, adjacent (SplitRows.backward can alias them)
+        dxall = torch.empty_like(y)
         dxs, o = [], 0
-        for n in ns:
-            dxs.append(dxall[o:o + n])
+        for n, tag in zip(ns, ctx.tags):
+            dxs.append(_arena_rows(tag, n, d, y.device) if tag is not None else dxall[o:o + n])
             o += n
         arr = _ct.c_void_p * P
         a_x, a_d = arr(*[t.data_ptr() for t in dxs]), arr(*[ptr(t) for t in dyns])
@@ -1153,6 +1197,7 @@ class GRUExpandAll(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ks, dyn_ns, dyn_rows, *args):
         P = len(ks)
+        ctx.tags = [_arena_tag(a) for a in args[:P]]        # pieces of a split tensor: their gradients go into its buffer
         xs = [a.contiguous() for a in args[:P]]
         params = args[P:]
         Wih, bih, Whh, bhh = ([params[4 * p + j].contiguous() for p in range(P)] for j in range(4))
@@ -1217,12 +1262,15 @@ class GRUExpandAll(torch.autograd.Function):
         d3, dev, st = 3 * d, H[0].device, stream()
         gs = [g.contiguous() if g is not None else torch.zeros(ns[p], d, device=dev) for p, g in enumerate(gs)]
         rows = [ns[p] * ks[p] for p in range(P)]
-        dXall = torch.empty(sum(rows), d, device=dev, dtype=torch.float32)
-        offs, o = [], 0
-        for r in rows:
-            offs.append(o)
-            o += r
-        dX = [dXall[o:o + r] for o, r in zip(offs, rows)]
+        if all(t is not None for t in ctx.tags):
+            dX = [_arena_rows(t, r, d, dev) for t, r in zip(ctx.tags, rows)]
+        else:
+            dXall = torch.empty(sum(rows), d, device=dev, dtype=torch.float32)
+            offs, o = [], 0
+            for r in rows:
+                offs.append(o)
+                o += r
+            dX = [dXall[o:o + r] for o, r in zip(offs, rows)]
         dGI16 = [torch.empty(rows[p], d3, device=dev, dtype=torch.bfloat16) for p in range(P)]
         dGH16 = [torch.empty(max(ks[p] - 1, 1), ns[p], d3, device=dev, dtype=torch.bfloat16) for p in range(P)]   # slot t - 1
         rb = max(8, 1024 // d)                           # nodes per block of the step kernel
