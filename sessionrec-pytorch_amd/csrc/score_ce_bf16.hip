@@ -83,6 +83,7 @@ struct BArgs {
     float* part_dsr;
     int n_de_pad;                // item-tile workgroups (padded to a multiple of 8); 0 = none
     int n_ranges, chunks_per_range, n_sess_tiles;
+    int rx_pref[9];              // backward: item ranges are counted per XCD (prefix sums; rx_pref[8] = slots enumerated)
 };
 
 enum { KIND_FWD = 0, KIND_BWD = 1, KIND_BWD_G = 2 };
@@ -136,7 +137,13 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         const int b = blockIdx.x - (KIND == KIND_BWD ? a.n_de_pad : 0);
         const int xcd = b & 7, j = b >> 3;
         const int tile = j % a.n_sess_tiles;
-        range = (j / a.n_sess_tiles) * 8 + xcd;
+        if (KIND == KIND_BWD) {                                   // the k-th range of this XCD (XCDs have different numbers)
+            const int kth = j / a.n_sess_tiles;
+            if (kth >= a.rx_pref[xcd + 1] - a.rx_pref[xcd]) return;
+            range = a.rx_pref[xcd] + kth;
+        } else {
+            range = (j / a.n_sess_tiles) * 8 + xcd;
+        }
         if (range >= a.n_ranges) return;
         x0 = tile * OWN;
         ybeg = range * a.chunks_per_range * CH;
@@ -533,16 +540,39 @@ constexpr int XCDS = 8, XCD_SLOTS = 64;                   // 32 CUs x 2 resident
 // put 65 live workgroups on five of the XCDs, whose 65th then ran after the first had finished - the launch took two
 // workgroup lifetimes (95 us) instead of one (68 us).  So count per XCD: ranges per XCD = free slots of the fullest
 // XCD / session tiles.
-void pick_ranges_bwd(int B, int V, bool with_de, int* n_ranges, int* chunks_per_range) {
-    const int T = cdiv(B, OWN);
-    int free_slots = XCD_SLOTS;
-    if (with_de) {
-        const int de0 = cdiv(cdiv(V, OWN), XCDS) % XCD_SLOTS;   // item tiles on XCD 0 (the fullest) in the last round
-        free_slots = de0 == 0 ? XCD_SLOTS : XCD_SLOTS - de0;
+// rx_pref (nullable): prefix sums of the ranges per XCD; returns the largest per-XCD count.  An XCD hosts
+// floor(free slots / session tiles) ranges, free = 64 - (its item tiles in the last round): at V = 37 484 five XCDs carry 37
+// item tiles (6 ranges) and three carry 36 (7 ranges) - 51 ranges instead of 8 x 6.
+int pick_ranges_bwd(int B, int V, bool with_de, int* n_ranges, int* chunks_per_range, int* rx_pref = nullptr) {
+    const int T = cdiv(B, OWN), chunks = cdiv(V, CH), de_tiles = cdiv(V, OWN);
+    int rx[XCDS], total = 0;
+    for (int x = 0; x < XCDS; ++x) {
+        int free_slots = XCD_SLOTS;
+        if (with_de) {
+            const int cnt = x < de_tiles ? (de_tiles - x + XCDS - 1) / XCDS : 0;
+            if (cnt % XCD_SLOTS) free_slots = XCD_SLOTS - cnt % XCD_SLOTS;
+        }
+        rx[x] = free_slots / T;
+        total += rx[x];
     }
-    int per_xcd = free_slots / T;
-    if (per_xcd < 1) per_xcd = 1;
-    pick_ranges_b(B, V, XCDS * per_xcd * T, BWD_RMAX, n_ranges, chunks_per_range);
+    if (total == 0) { for (int x = 0; x < XCDS; ++x) rx[x] = 1; total = XCDS; }
+    int cap = BWD_RMAX < chunks ? BWD_RMAX : chunks;
+    while (total > cap) {                                  // trim the fullest XCDs first
+        int best = 0;
+        for (int x = 1; x < XCDS; ++x) if (rx[x] > rx[best]) best = x;
+        --rx[best]; --total;
+    }
+    const int cpr = cdiv(chunks, total);
+    *chunks_per_range = cpr;
+    *n_ranges = cdiv(chunks, cpr);                         // ranges behind this one are empty: their workgroups exit
+    int mx = 0, acc = 0;
+    for (int x = 0; x < XCDS; ++x) {
+        if (rx_pref != nullptr) rx_pref[x] = acc;
+        acc += rx[x];
+        if (rx[x] > mx) mx = rx[x];
+    }
+    if (rx_pref != nullptr) rx_pref[XCDS] = acc;
+    return mx;
 }
 
 inline bool bad_d(int d) { return d <= 0 || d > 256 || (d & 3); }
@@ -625,8 +655,8 @@ extern "C" int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int B
     a.n_de_pad = with_de ? 8 * cdiv(cdiv(V, OWN), 8) : 0;
     int nblocks = a.n_de_pad;
     if (with_dsr) {
-        pick_ranges_bwd(B, V, with_de, &a.n_ranges, &a.chunks_per_range);
-        nblocks += 8 * cdiv(a.n_ranges, 8) * a.n_sess_tiles;
+        const int rmax = pick_ranges_bwd(B, V, with_de, &a.n_ranges, &a.chunks_per_range, a.rx_pref);
+        nblocks += 8 * rmax * a.n_sess_tiles;
     } else {
         a.n_ranges = 0; a.chunks_per_range = 1;
     }
