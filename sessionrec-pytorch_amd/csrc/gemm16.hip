@@ -69,6 +69,14 @@ __device__ __forceinline__ void wait_stage(int ahead) {
     else wait_vm<0>();
 }
 
+#ifdef SREC_G16_TIMING   // development probe (tools/g16_timing.py): phase clocks of wave 0 + wall-clock life of every workgroup
+__device__ unsigned long long g_g16_tim[8];
+__device__ unsigned long long g_g16_blk[8192][2];
+#define G16T(i) do { __builtin_amdgcn_sched_barrier(0); g16t[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define G16T(i)
+#endif
+
 constexpr int NS = 4, PD = 3;        // default LDS ring: 4 stages, 3 stages of LDS-DMA in flight ahead of the MFMAs
 
 // -------------------------------------------------------------------------------------------------- nt16
@@ -93,6 +101,11 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
 
     const int bid = (int)blockIdx.x;
+#ifdef SREC_G16_TIMING
+    unsigned long long g16t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g16w = 0, g16d = 0, g16c = 0;
+    if (threadIdx.x == 0 && bid < 8192) g_g16_blk[bid][0] = __builtin_amdgcn_s_memrealtime();
+    G16T(0);
+#endif
     int p = 0;
 #pragma unroll
     for (int i = 1; i < G16_MAXP; ++i)
@@ -135,26 +148,48 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     // l >> 2, slot l & 3).  Rows past an operand are clamped to its last row (their products land in rows / columns the
     // epilogue does not store).
     const int rl = lane / PPR, sl = lane % PPR;
+    // Issue state of the ring (wave-uniform): the operand bases of the current K segment live in SGPRs and advance by BK per
+    // stage; the per-lane source offsets do not depend on k.  (Recomputing segment = it / nk and re-reading g.A[p][s] from
+    // the kernel arguments for every stage put an integer division and a scalar-memory round trip in front of every
+    // group of LDS-DMA instructions: 720 cycles per stage next to 256 cycles of MFMA, tools/g16_timing.py.)
+    unsigned voff[IPS];
+#pragma unroll
+    for (int ii = 0; ii < IPS; ++ii) {
+        const int i = ii * 4 + wave;                     // wave-uniform
+        const int r = RPI * (i < NIA ? i : i - NIA) + rl;
+        const unsigned pc = (unsigned)((sl ^ ((r >> FS) & (PPR - 1))) * 8);
+        voff[ii] = i < NIA ? ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.lda + pc) * 2u
+                           : ((unsigned)min(r, N - 1 - n0) * (unsigned)g.ldb + pc) * 2u;
+    }
+    int is_seg = 0, is_k = 0;
+    const unsigned short* Aseg = g.A[p][0] + (size_t)m0 * g.lda;
+    const unsigned short* Bseg = g.B[p][0] + (size_t)n0 * g.ldb;
     auto stage = [&](int it) {
-        const int s = it / nk, k0 = (it - s * nk) * BK;
-        const unsigned short* Ab = g.A[p][s] + (size_t)m0 * g.lda + k0;
-        const unsigned short* Bb = g.B[p][s] + (size_t)n0 * g.ldb + k0;
         const unsigned dst = lds0 + (unsigned)((it % NS) * STG) * 2u;
 #pragma unroll
         for (int ii = 0; ii < IPS; ++ii) {
-            const int i = ii * 4 + wave;                 // wave-uniform
-            const int r = RPI * (i < NIA ? i : i - NIA) + rl;
-            const unsigned pc = (unsigned)((sl ^ ((r >> FS) & (PPR - 1))) * 8);
-            if (i < NIA) glds16(Ab, ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.lda + pc) * 2u, dst + (unsigned)i * 1024u);
-            else glds16(Bb, ((unsigned)min(r, N - 1 - n0) * (unsigned)g.ldb + pc) * 2u, dst + (unsigned)i * 1024u);
+            const int i = ii * 4 + wave;
+            glds16((i < NIA ? Aseg : Bseg) + is_k, voff[ii], dst + (unsigned)i * 1024u);
+        }
+        is_k += BK;
+        if (is_k >= K) {                                 // next K segment (another module's projection / weight)
+            is_k = 0;
+            if (++is_seg < g.nseg[p]) {
+                Aseg = g.A[p][is_seg] + (size_t)m0 * g.lda;
+                Bseg = g.B[p][is_seg] + (size_t)n0 * g.ldb;
+            }
         }
     };
 
     for (int s = 0; s < PD && s < total; ++s) stage(s);
+    G16T(1);
     for (int it = 0; it < total; ++it) {
+        G16T(2);
         wait_stage<IPS, PD>(min(total - it - 1, PD - 1));      // this wave's pieces of stage `it` have landed ...
         __syncthreads();                                       // ... everyone's have; stage it - 1's buffer is free again
+        G16T(3);
         if (it + PD < total) stage(it + PD);
+        G16T(4);
         const unsigned short* As = smem + (it % NS) * STG;
         const unsigned short* Bs = As + TM * BK;
 #pragma unroll
@@ -177,7 +212,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
                     acc[i][j] = C16 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+#ifdef SREC_G16_TIMING
+        G16T(5);
+        g16w += g16t[3] - g16t[2]; g16d += g16t[4] - g16t[3]; g16c += g16t[5] - g16t[4];
+#endif
     }
+    G16T(6);
 
     if (C16) {
         // acc[i][j] = D^T: lane <-> output row, register r <-> output column (r & 3) + 8 (r >> 2) + 4 half.  The 4 KB row
@@ -214,6 +254,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
                     if (col + k < N) C16p[(size_t)row * g.ldc + col + k] = e[k];
             }
         }
+#ifdef SREC_G16_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G16T(7);
+        if (threadIdx.x == 0 && bid < 8192) g_g16_blk[bid][1] = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && bid == 17) { g_g16_tim[0] = g16t[1] - g16t[0]; g_g16_tim[1] = g16w; g_g16_tim[2] = g16d; g_g16_tim[3] = g16c; g_g16_tim[4] = g16t[7] - g16t[6]; g_g16_tim[5] = g16t[7] - g16t[0]; g_g16_tim[6] = total; }
+#endif
         return;
     }
 #pragma unroll
@@ -232,6 +278,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
                 }
             }
         }
+#ifdef SREC_G16_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G16T(7);
+    if (threadIdx.x == 0 && bid < 8192) g_g16_blk[bid][1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && bid == 17) { g_g16_tim[0] = g16t[1] - g16t[0]; g_g16_tim[1] = g16w; g_g16_tim[2] = g16d; g_g16_tim[3] = g16c; g_g16_tim[4] = g16t[7] - g16t[6]; g_g16_tim[5] = g16t[7] - g16t[0]; g_g16_tim[6] = total; }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------- tn16
@@ -553,6 +605,17 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     SREC_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SREC_G16_TIMING
+extern "C" int srec_g16_timing(unsigned long long* tim8, unsigned long long* blk) {
+    if (hipMemcpyFromSymbol(tim8, HIP_SYMBOL(g_g16_tim), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(blk, HIP_SYMBOL(g_g16_blk), sizeof(unsigned long long) * 16384) == hipSuccess ? 0 : 1;
+}
+extern "C" int srec_g16_timing_reset() {
+    static unsigned long long z[16384];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_g16_blk), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // C_p [M, N] = sum_s sum_{m < min(K, *dyn)} A_ps [m, M] B_ps [m, N]  (fp32 output; M, N % 8 == 0)
 extern "C" int srec_gemm16_tn(const void* desc_, void* stream) {
