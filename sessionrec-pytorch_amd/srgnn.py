@@ -207,8 +207,16 @@ class SRGNN(_ScoringMixin, nn.Module):
         if self.use_gnn_output:
             for layer in self.layers:
                 feat = layer(mg, feat)
-        sr_g = self.readout(mg, feat)
         sr_l = ops.row_gather(feat, mg.last, dB)
+        ro = self.readout
+        if feat.is_cuda and not (self.training and ro.feat_drop.p > 0):
+            # read-out + fc_sr as grouped exact-fp32 launches (ops.ReadoutHead, as in MSGIFSR).  fc_v's bias rides on the U
+            # product instead: sigmoid(U + (Vq + b)) = sigmoid((U + b) + Vq), and d b = sum_n dU = sum_b dVq.  (With read-out
+            # dropout the fc_v input is the DROPPED last-node row while fc_sr takes the clean one: separate ops below.)
+            (s,) = ops.readout_head(feat, mg.seg, dN, dB, [(sr_l, ro.fc_u.weight, ro.fc_v.bias, ro.fc_v.weight, ro.fc_e.weight,
+                                                            self.fc_sr.weight)])
+            return self._post(s, dB)
+        sr_g = ro(mg, feat)
         return self._post(ops.linear_cat([sr_l, sr_g], self.fc_sr.weight, None, dB, exact=True), dB)
 
     def forward(self, mg, sg=None):
