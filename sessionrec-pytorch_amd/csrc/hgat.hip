@@ -23,6 +23,7 @@ namespace {
 constexpr int WPB = 4;
 constexpr int MAXDEG = 128;
 constexpr int MAXH = 8;
+constexpr int NCHUNK_C = 32;  // row chunks of the column-thread sums (hg_colsum_cols_kernel)
 constexpr int SEGCAP = 1025;   // session offsets staged in LDS by hg_agg / hg_pre (batches of up to 1024 sessions)
 constexpr int NCHUNK = 16;
 constexpr int MAXT = SREC_HG_MAXT, MAXM = SREC_HG_MAXM, MAXB = SREC_HG_MAXB, MAXI = SREC_HG_MAXI;
@@ -672,13 +673,95 @@ __global__ void hg_colsum_part_kernel(ColArgs a) {
     }
 }
 
+// H == 8, D <= 256: ONE thread per feature column carries all heads, one job per node type (bias sums) and per projection
+// BLOCK (Z sums), 64 row chunks each.  The head-per-workgroup version above re-reads every x / g row once per head out of
+// L2 (~310 MB for 39 MB of rows: 31 us, whatever its launch shape); with all heads on the column's thread a row is read
+// once, and the parallelism that version got from the head dimension comes from finer row chunks and 16 rows of loads in
+// flight per thread.  The per-(row, head) factors of a 16-row tile go through LDS (broadcast reads).
+__global__ __launch_bounds__(256) void hg_colsum_cols_kernel(ColArgs a) {
+    __shared__ __attribute__((aligned(16))) float sw[16][16];
+    const int D = a.D, HD = 8 * D;
+    const int c = threadIdx.x, job = blockIdx.y, chunk = blockIdx.x;
+    const bool cok = c < D;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { s0[h] = 0.f; s1[h] = 0.f; }
+    if (job < a.nt) {
+        const int t = job;
+        const int n = dyn_count(a.dyn_t[t], a.ncap_t[t]);
+        const int per = (n + NCHUNK_C - 1) / NCHUNK_C, r0 = chunk * per, r1 = min(n, r0 + per);
+        if (cok)
+            for (int r = r0; r < r1; r += 8) {
+                float gv[8]; int av[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const size_t row = (size_t)(a.row0[t] + min(r + e, r1 - 1));
+                    gv[e] = a.g[row * a.ld_g + c];
+                    av[e] = r + e < r1 ? (int)a.arg[row * D + c] : -1;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) s0[h] += av[e] == h ? gv[e] : 0.f;
+            }
+    } else {
+        const int b = job - a.nt;
+        const int n = dyn_count(a.dyn_b[b], a.ncap_b[b]);
+        const int per = (n + NCHUNK_C - 1) / NCHUNK_C, r0 = chunk * per, r1 = min(n, r0 + per);
+        const float* __restrict__ xb = a.xb[b] + (size_t)a.row0_b[b] * a.ld_x + (cok ? c : 0);
+        const float* __restrict__ wL = a.wL[b];
+        const float* __restrict__ wR = a.wR[b];
+        for (int r = r0; r < r1; r += 16) {
+            float xv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xv[e] = (cok && r + e < r1) ? xb[(size_t)(r + e) * a.ld_x] : 0.f;
+            __syncthreads();                               // the previous tile's factors have been read
+            {
+                const int row = threadIdx.x >> 4, k = threadIdx.x & 15;
+                float w = 0.f;
+                if (r + row < r1) w = k < 8 ? wL[(size_t)(r + row) * 8 + k] : wR[(size_t)(r + row) * 8 + k - 8];
+                sw[row][k] = w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float4 l0 = *reinterpret_cast<const float4*>(&sw[e][0]), l1 = *reinterpret_cast<const float4*>(&sw[e][4]);
+                const float4 q0 = *reinterpret_cast<const float4*>(&sw[e][8]), q1 = *reinterpret_cast<const float4*>(&sw[e][12]);
+                s0[0] += xv[e] * l0.x; s0[1] += xv[e] * l0.y; s0[2] += xv[e] * l0.z; s0[3] += xv[e] * l0.w;
+                s0[4] += xv[e] * l1.x; s0[5] += xv[e] * l1.y; s0[6] += xv[e] * l1.z; s0[7] += xv[e] * l1.w;
+                s1[0] += xv[e] * q0.x; s1[1] += xv[e] * q0.y; s1[2] += xv[e] * q0.z; s1[3] += xv[e] * q0.w;
+                s1[4] += xv[e] * q1.x; s1[5] += xv[e] * q1.y; s1[6] += xv[e] * q1.z; s1[7] += xv[e] * q1.w;
+            }
+        }
+    }
+    if (cok) {
+        float* p = a.part + ((size_t)job * NCHUNK_C + chunk) * 2 * HD + c;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) { p[h * D] = s0[h]; p[HD + h * D] = s1[h]; }
+    }
+}
+
 // out o < nm: d_bias[m][h*D + c] = sum over the module's instances of CS_{dst type};  o >= nm: Z[m] ([2][H][D])
 struct ColFinalArgs {
     float* out[2 * MAXM];
     int njob[2 * MAXM], jobs[2 * MAXM][8];
-    int nm, H, D;
+    int nm, H, D, nchunk;
     const float* part;
 };
+
+// s + p[0] + p[stride] + ... (n terms, added in that order): eight loads in flight instead of one dependent load per term
+__device__ __forceinline__ float chunk_sum(const float* __restrict__ p, int n, size_t stride, float s) {
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p[(size_t)(k + e) * stride];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    for (; k < n; ++k) s += p[(size_t)k * stride];
+    return s;
+}
 
 __global__ void hg_colsum_final_kernel(ColFinalArgs a) {
     const int HD = a.H * a.D, o = blockIdx.y;
@@ -688,15 +771,15 @@ __global__ void hg_colsum_final_kernel(ColFinalArgs a) {
         if (idx >= HD) return;
         float s = 0.f;
         for (int q = 0; q < a.njob[o]; ++q) {
-            const float* p = a.part + (size_t)a.jobs[o][q] * NCHUNK * 2 * HD + idx;
-            for (int k = 0; k < NCHUNK; ++k) s += p[(size_t)k * 2 * HD];
+            s = chunk_sum(a.part + (size_t)a.jobs[o][q] * a.nchunk * 2 * HD + idx, a.nchunk, 2 * HD, s);
         }
         a.out[o][idx] = s;
     } else {
         if (idx >= 2 * HD) return;
-        const float* p = a.part + (size_t)a.jobs[o][0] * NCHUNK * 2 * HD + idx;
         float s = 0.f;
-        for (int k = 0; k < NCHUNK; ++k) s += p[(size_t)k * 2 * HD];
+        for (int q = 0; q < a.njob[o]; ++q) {                     // one job per module, or one per projection block of it
+            s = chunk_sum(a.part + (size_t)a.jobs[o][q] * a.nchunk * 2 * HD + idx, a.nchunk, 2 * HD, s);
+        }
         a.out[o][idx] = s;                                        // Z [lr][h][c] = the slab order (16-byte reads in hg_dattn)
     }
 }
@@ -738,7 +821,8 @@ bool bad_desc(const srec_hg_desc* d) {
 extern "C" int srec_hg_ws_floats(const void* desc_, long* n_floats) {
     const srec_hg_desc* d = (const srec_hg_desc*)desc_;
     if (bad_desc(d) || n_floats == nullptr) return SREC_BAD_ARG;
-    *n_floats = (long)(d->n_types + d->n_mods) * NCHUNK * 2 * d->H * d->D;
+    const long a = (long)(d->n_types + d->n_mods) * NCHUNK, b = (long)(d->n_types + d->n_blocks) * NCHUNK_C;
+    *n_floats = (a > b ? a : b) * 2 * d->H * d->D;
     return 0;
 }
 
@@ -886,15 +970,25 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             r += d->ncap[t];
         }
         a.row0[d->n_types] = r;
-        const int njobs = d->n_types + d->n_mods;
-        hipLaunchKernelGGL(hg_colsum_part_kernel, dim3(cdiv(HD, 64), NCHUNK, njobs), dim3(256), 0, st, a);
+        const bool cols = H == 8 && D <= 256;             // column-thread sums: jobs = node types + projection blocks
         ColFinalArgs f{};
         f.nm = d->n_mods; f.H = H; f.D = D; f.part = ws;
+        if (cols) {
+            hipLaunchKernelGGL(hg_colsum_cols_kernel, dim3(NCHUNK_C, d->n_types + d->n_blocks), dim3(256), 0, st, a);
+            f.nchunk = NCHUNK_C;
+        } else {
+            hipLaunchKernelGGL(hg_colsum_part_kernel, dim3(cdiv(HD, 64), NCHUNK, d->n_types + d->n_mods), dim3(256), 0, st, a);
+            f.nchunk = NCHUNK;
+        }
         for (int m = 0; m < d->n_mods; ++m) {
             f.out[m] = d->d_bias[m];
             f.out[d->n_mods + m] = d->Z[m];
-            f.njob[d->n_mods + m] = 1;
-            f.jobs[d->n_mods + m][0] = d->n_types + m;
+            if (cols) {
+                for (int q = 0; q < a.mod_nb[m]; ++q) f.jobs[d->n_mods + m][f.njob[d->n_mods + m]++] = d->n_types + a.mod_blk[m][q];
+            } else {
+                f.njob[d->n_mods + m] = 1;
+                f.jobs[d->n_mods + m][0] = d->n_types + m;
+            }
         }
         for (int i = 0; i < d->n_inst; ++i) {
             const int m = d->inst_mod[i], t = d->blk_type[d->inst_dblk[i]];
