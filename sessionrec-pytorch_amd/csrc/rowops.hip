@@ -57,12 +57,23 @@ __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g,
         const float sc = 1.f / (1.f - rng.p);
         for (int c = lane * 4; c < d; c += 256) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = beg; e < end; ++e) {
-                const int pp = pos[e];
-                const float4 v = *reinterpret_cast<const float4*>(g + (size_t)pp * ld_g + c);
+            auto add = [&](int pp, const float4& v) {
                 const unsigned i0 = (unsigned)pp * (unsigned)d + (unsigned)c;
                 s.x += v.x * srec_keep(key, i0, rng.p, sc); s.y += v.y * srec_keep(key, i0 + 1, rng.p, sc);
                 s.z += v.z * srec_keep(key, i0 + 2, rng.p, sc); s.w += v.w * srec_keep(key, i0 + 3, rng.p, sc);
+            };
+            int e = beg;
+            for (; e + 4 <= end; e += 4) {            // four row loads in flight, added in position order
+                const int p0 = pos[e], p1 = pos[e + 1], p2 = pos[e + 2], p3 = pos[e + 3];
+                const float4 v0 = *reinterpret_cast<const float4*>(g + (size_t)p0 * ld_g + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(g + (size_t)p1 * ld_g + c);
+                const float4 v2 = *reinterpret_cast<const float4*>(g + (size_t)p2 * ld_g + c);
+                const float4 v3 = *reinterpret_cast<const float4*>(g + (size_t)p3 * ld_g + c);
+                add(p0, v0); add(p1, v1); add(p2, v2); add(p3, v3);
+            }
+            for (; e < end; ++e) {
+                const int pp = pos[e];
+                add(pp, *reinterpret_cast<const float4*>(g + (size_t)pp * ld_g + c));
             }
             float4* o = reinterpret_cast<float4*>(dst + (size_t)item * ld_dst + c);
             if (accumulate) {
@@ -76,6 +87,15 @@ __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g,
     for (int c = lane * 4; c < d; c += 256) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         int e = beg;
+        for (; e + 16 <= end; e += 16) {              // a Zipf-hot item has hundreds of pieces and ONE wavefront sums them: 16 row
+            int pp[16]; float4 v[16];                 // loads in flight, added in order
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pp[k] = pos[e + k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(g + (size_t)pp[k] * ld_g + c);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+        }
         for (; e + 4 <= end; e += 4) {                // four row loads in flight (a popular item has dozens of pieces)
             const int p0 = pos[e], p1 = pos[e + 1], p2 = pos[e + 2], p3 = pos[e + 3];
             const float4 v0 = *reinterpret_cast<const float4*>(g + (size_t)p0 * ld_g + c);
