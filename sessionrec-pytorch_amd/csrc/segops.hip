@@ -25,17 +25,44 @@ __global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const
     const bool live = b < dyn_count(dynB, B);
     const int base = live ? seg[b] : 0;
     const int n = live ? min(seg[b + 1] - base, MAXN) : 0;
-    for (int i = w; i < n; i += WPB) {
-        float acc = 0.f;
-        for (int k = lane * 4; k < h; k += 256) {
-            const float4 u = *reinterpret_cast<const float4*>(U + (size_t)(base + i) * ld_u + k);
-            const float4 v = *reinterpret_cast<const float4*>(Vq + (size_t)b * ld_v + k);
-            const float4 wk = *reinterpret_cast<const float4*>(we + k);
-            acc += wk.x * sigmoidf_(u.x + v.x) + wk.y * sigmoidf_(u.y + v.y) + wk.z * sigmoidf_(u.z + v.z) +
-                   wk.w * sigmoidf_(u.w + v.w);
+    if (h <= 256) {
+        // the usual case (hidden size <= 256: one float4 per lane): the rows of this wave's nodes are fetched four at a time
+        const int k = lane * 4;
+        const bool kok = k < h;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), wk = v;
+        if (kok) {
+            v = *reinterpret_cast<const float4*>(Vq + (size_t)b * ld_v + k);
+            wk = *reinterpret_cast<const float4*>(we + k);
         }
-        acc = wave_sum(acc);
-        if (lane == 0) e[i] = acc;
+        for (int i0 = w; i0 < n; i0 += 4 * WPB) {
+            float4 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(i0 + j * WPB, n - 1);
+                u[j] = kok ? *reinterpret_cast<const float4*>(U + (size_t)(base + i) * ld_u + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * WPB;
+                float acc = kok ? wk.x * sigmoidf_(u[j].x + v.x) + wk.y * sigmoidf_(u[j].y + v.y) + wk.z * sigmoidf_(u[j].z + v.z) +
+                                      wk.w * sigmoidf_(u[j].w + v.w) : 0.f;
+                acc = wave_sum(acc);
+                if (lane == 0 && i < n) e[i] = acc;
+            }
+        }
+    } else {
+        for (int i = w; i < n; i += WPB) {
+            float acc = 0.f;
+            for (int k = lane * 4; k < h; k += 256) {
+                const float4 u = *reinterpret_cast<const float4*>(U + (size_t)(base + i) * ld_u + k);
+                const float4 v = *reinterpret_cast<const float4*>(Vq + (size_t)b * ld_v + k);
+                const float4 wk = *reinterpret_cast<const float4*>(we + k);
+                acc += wk.x * sigmoidf_(u.x + v.x) + wk.y * sigmoidf_(u.y + v.y) + wk.z * sigmoidf_(u.z + v.z) +
+                       wk.w * sigmoidf_(u.w + v.w);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) e[i] = acc;
+        }
     }
     __syncthreads();
     if (w == 0) {
@@ -55,7 +82,16 @@ __global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const
     __syncthreads();
     for (int c = tid; c < D; c += 256) {
         float o = 0.f;
-        for (int i = 0; i < n; ++i) o += e[i] * X[(size_t)(base + i) * ld_x + c];
+        const float* xp = X + (size_t)base * ld_x + c;
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {                     // eight node rows in flight, added in node order (an in-order wave
+            float xv[8];                                 // otherwise pays one memory round trip per node)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] = xp[(size_t)(i + k) * ld_x];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o += e[i + k] * xv[k];
+        }
+        for (; i < n; ++i) o += e[i] * xp[(size_t)i * ld_x];
         out[(size_t)b * ld_out + c] = o;
     }
 }
@@ -110,8 +146,24 @@ __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, c
         const float vq = Vq[(size_t)b * ld_v + k];
         const float wk = we[k];
         float dv = 0.f, dw = 0.f;
-        for (int i = 0; i < n; ++i) {
-            const float sg = sigmoidf_(U[(size_t)(base + i) * ld_u + k] + vq);
+        const float* up = U + (size_t)base * ld_u + k;
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {                     // eight node rows in flight, accumulated in node order
+            float uv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) uv[j] = up[(size_t)(i + j) * ld_u];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sg = sigmoidf_(uv[j] + vq);
+                const float dei = de[i + j];
+                dw += dei * sg;
+                const float dp = dei * wk * sg * (1.f - sg);
+                dU[(size_t)(base + i + j) * ld_du + k] = dp;
+                dv += dp;
+            }
+        }
+        for (; i < n; ++i) {
+            const float sg = sigmoidf_(up[(size_t)i * ld_u] + vq);
             const float dei = de[i];
             dw += dei * sg;
             const float dp = dei * wk * sg * (1.f - sg);
