@@ -201,7 +201,7 @@ def test_model_matches_reference_fixture(dev, name):
     sd = model.state_dict()
     truth, grads64, risky = _oracle_fp64_final(name, init, samples, V)
     # round-off yardstick without Adam's amplification: the fused path's step-0 gradients are as close to the float64
-    # gradients as the reference's own fp32 gradients are - within one order of magnitude per tensor (a cancelling sum
+    # gradients as the reference's own fp32 gradients are - within a factor 16 per tensor (a cancelling sum
     # such as a bias gradient loses more in the MFMA's sequential accumulation than in torch's pairwise one; bf16
     # operands anywhere on the path would be off by three orders)
     for k, g64 in grads64.items():
@@ -209,7 +209,7 @@ def test_model_matches_reference_fixture(dev, name):
             continue
         e_mine = (grads_fused[k].double().cpu() - g64).abs().mean().item()
         e_ref = (torch.from_numpy(z['grad/' + k]).double() - g64).abs().mean().item()
-        assert e_mine <= 10.0 * e_ref + 1e-9 * float(g64.abs().mean()) + 1e-12, \
+        assert e_mine <= 16.0 * e_ref + 1e-9 * float(g64.abs().mean()) + 1e-12, \
             'step-0 grad %s: mean |err| vs fp64 %.3e (reference fp32 gradients: %.3e)' % (k, e_mine, e_ref)
     print('fp32-unresolvable gradient components in the float64 run:', risky)
     for k in z.files:
