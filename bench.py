@@ -486,7 +486,7 @@ def main():
     nodes = gstep.node_counts() if graphed and hasattr(gstep, 'node_counts') else None
 
     fp32 = None
-    if not args.no_fp32 and args.precision != 'fp32':
+    if not args.no_fp32 and args.precision != 'fp32' and world == 1:      # (side run on one GPU only: N > 1 times the job once)
         # the reference's own arithmetic (fp32 operands everywhere) on the same batches, same launch mode, same run
         del step, gstep
         m32, s32, step32, g32, _ = setup('fp32')
@@ -546,7 +546,7 @@ def main():
                     frac=flop / t / 1e12 / peak, traffic=traffic, traffic_unit='bytes/launch', traffic_source=tsrc,
                     algorithmic_bytes=alg_bytes, algorithmic_flop=flop, kernel_ms=kms, step=step_roof)
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU baseline belongs to the N = 1 line (rank 0)
             full = samples if not strong else samples      # the CPU oracle runs whole 512-session batches
             cpu = cpu_baseline(args.model, full, V, d, args.order, state, dropout=args.dropout)
         scaling = 'strong' if strong else 'weak'
