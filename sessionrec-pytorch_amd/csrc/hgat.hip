@@ -155,8 +155,21 @@ struct AggArgs {
     float slope;
 };
 
+#ifdef SREC_HG_TIMING   // development probe (tools/hg_timing.py)
+__device__ unsigned long long g_hg_blk[16384][2];
+__device__ unsigned long long g_hg_tim[16];
+#define HGT(i) do { __builtin_amdgcn_sched_barrier(0); hgt[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HGT(i)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
+#ifdef SREC_HG_TIMING
+    unsigned long long hgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_hg_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+    HGT(0);
+#endif
     __shared__ float sc[MAXH][MAXDEG];
     __shared__ int su[MAXH][MAXDEG];
     __shared__ float comb[MAXH][256];
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
             smean /= (float)(s1 - s0 > 0 ? s1 - s0 : 1);
         }
     }
+    HGT(1);
     if (w < H) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         // Fast path (the usual case: a handful of in-edges per relation): lane = (instance slot q = lane >> 3, edge j =
@@ -235,6 +249,7 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
                     const float* mk = a.Mk[i];
                     if (mk != nullptr) pm *= mk[(size_t)e * H + w];
                 }
+                HGT(2);
                 unsigned long long mask = __ballot(valid);
                 const bool cok = c < D;                                    // every lane stays in the loop: it feeds the shuffles
                 while (mask != 0ull) {
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { acc.x += pp[u] * f[u].x; acc.y += pp[u] * f[u].y; acc.z += pp[u] * f[u].z; acc.w += pp[u] * f[u].w; }
                 }
+                HGT(3);
                 if (c < D)
                     for (int q2 = 0; q2 < a.ninst[t]; ++q2) {
                         const float4 bv = *reinterpret_cast<const float4*>(a.bias[a.inst[t][q2]] + w * D + c);
@@ -318,7 +334,9 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
         }
         if (c < D) *reinterpret_cast<float4*>(&comb[w][c]) = acc;
     }
+    HGT(4);
     __syncthreads();
+    HGT(5);
     if (tid < D) {
         float best = 0.f;
         int bi = 0;
@@ -331,7 +349,19 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
         a.out[(size_t)row * a.ld_out + tid] = best;
         a.arg[(size_t)row * D + tid] = (unsigned char)bi;
     }
+#ifdef SREC_HG_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HGT(6);
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_hg_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 100) for (int i = 0; i < 7; ++i) g_hg_tim[i] = hgt[i] - hgt[0];
+#endif
 }
+#ifdef SREC_HG_TIMING
+extern "C" int srec_hg_timing(unsigned long long* tim16, unsigned long long* blk) {
+    if (hipMemcpyFromSymbol(tim16, HIP_SYMBOL(g_hg_tim), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(blk, HIP_SYMBOL(g_hg_blk), sizeof(unsigned long long) * 32768) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------ backward
 struct PreArgs {
