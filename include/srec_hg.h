@@ -36,7 +36,7 @@ typedef struct {
     void* dP[SREC_HG_MAXM];
     const float* W[SREC_HG_MAXM];      /* fc.weight [H*D, D] fp32 */
     float* V[SREC_HG_MAXM];            /* scratch [2][D][H]: attention vectors folded into W (forward) */
-    float* Z[SREC_HG_MAXM];            /* scratch [2][H][D]: x^T wL / x^T wR (backward) */
+    float* Z[SREC_HG_MAXM];            /* scratch [2][H][D]: x^T wL / x^T wR (backward); during the forward Z[t][0 .. H D) holds the summed bias rows of node type t */
     const float* attn_l[SREC_HG_MAXM];
     const float* attn_r[SREC_HG_MAXM];
     const float* bias[SREC_HG_MAXM];

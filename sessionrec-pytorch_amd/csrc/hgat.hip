@@ -64,6 +64,11 @@ struct FoldArgs {
     const float* W[MAXM]; const float* al[MAXM]; const float* ar[MAXM];
     float* V[MAXM];
     int H, D;
+    // per node type t < nt: bsum[t][h D + c] = sum of the bias vectors of the relation instances into t (the workgroups
+    // (m, h) with m < nt compute it on the side: hg_agg then reads ONE bias row per (node, head) instead of one per instance)
+    int nt, tn[MAXT];
+    const float* tb[MAXT][8];
+    float* bsum[MAXT];
 };
 
 // block = (module, head); 1024 threads = 4 row groups x 256 columns: four times the loads in flight of one row loop
@@ -90,6 +95,11 @@ __global__ __launch_bounds__(1024) void hg_fold_kernel(FoldArgs a) {
         sr += red[1][0][c] + red[1][1][c] + red[1][2][c];
         a.V[m][(size_t)c * H + h] = sl;
         a.V[m][(size_t)(D + c) * H + h] = sr;
+    }
+    if (jg == 1 && c < D && m < a.nt && a.bsum[m] != nullptr) {
+        float b = 0.f;
+        for (int q = 0; q < a.tn[m]; ++q) b += a.tb[m][q][h * D + c];      // instance order = the order hg_agg used
+        a.bsum[m][h * D + c] = b;
     }
 }
 
@@ -143,6 +153,7 @@ struct AggArgs {
     int nt, B;
     const int* dynB;
     // instances
+    const float* bsum[MAXT];            // per node type: the summed bias rows of its instances (hg_fold_kernel)
     const void* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* bias[MAXI];
     const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
     float* A[MAXI];
@@ -274,11 +285,10 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
                     for (int u = 0; u < 4; ++u) { acc.x += pp[u] * f[u].x; acc.y += pp[u] * f[u].y; acc.z += pp[u] * f[u].z; acc.w += pp[u] * f[u].w; }
                 }
                 HGT(3);
-                if (c < D)
-                    for (int q2 = 0; q2 < a.ninst[t]; ++q2) {
-                        const float4 bv = *reinterpret_cast<const float4*>(a.bias[a.inst[t][q2]] + w * D + c);
-                        acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
-                    }
+                if (c < D && a.ninst[t] > 0) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bsum[t] + w * D + c);
+                    acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+                }
             }
         }
         if (live) {
@@ -316,10 +326,12 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
                         const float4 f = ld4(ps + (size_t)su[w][j] * HD);
                         acc.x += p * f.x; acc.y += p * f.y; acc.z += p * f.z; acc.w += p * f.w;
                     }
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bias[i] + w * D + c);
-                    acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
+            if (!fast && c < D && a.ninst[t] > 0) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bsum[t] + w * D + c);
+                acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
             }
             if (c < D) {
                 if (a.xres != nullptr) {
@@ -867,6 +879,15 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         FoldArgs f{};
         f.H = H; f.D = D;
         for (int m = 0; m < d->n_mods; ++m) { f.W[m] = d->W[m]; f.al[m] = d->attn_l[m]; f.ar[m] = d->attn_r[m]; f.V[m] = d->V[m]; }
+        // bias sums per node type, kept in the first H D floats of the backward's Z scratch (free during the forward)
+        if (d->n_types > d->n_mods) return SREC_BAD_ARG;
+        f.nt = d->n_types;
+        for (int t = 0; t < d->n_types; ++t) { f.tn[t] = 0; f.bsum[t] = d->Z[t]; }
+        for (int i = 0; i < d->n_inst; ++i) {
+            const int t = d->blk_type[d->inst_dblk[i]];
+            if (f.tn[t] >= 8) return SREC_BAD_ARG;
+            f.tb[t][f.tn[t]++] = d->bias[d->inst_mod[i]];
+        }
         hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H), dim3(1024), 0, st, f);
     }
     if (d->n_blocks > 0) {
@@ -893,6 +914,7 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         if (d->row0[t] != rows) return SREC_BAD_ARG;            // types must tile the stacked matrix
         g.seg[t] = d->seg[t]; g.dyn_n[t] = d->dyn_n[t]; g.row0[t] = d->row0[t]; g.ncap[t] = d->ncap[t];
         g.ninst[t] = 0;
+        g.bsum[t] = d->Z[t];
         rows += d->ncap[t];
     }
     g.row0[d->n_types] = rows;

