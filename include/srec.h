@@ -114,6 +114,10 @@ int srec_row_invnorm(const float* W, int ld, int n, int d, int eps_mode, float e
 /* row L2 normalisation of node / session features: niser.py:135,142,148  msgifsr.py:253,263,273 */
 int srec_normalize_fwd(const float* X, int ld_x, float* Y, int ld_y, float* inv, int n_cap, const int* dyn, int d,
                        int eps_mode, float eps, void* stream);
+/* the same + a bf16 copy dst16 [>= n_cap, Dp] of the normalised rows (zero rows past the live count; columns d .. Dp are
+ * not written): the session-vector operand of srec_score_ce_*_bf16 without a conversion pass of its own */
+int srec_normalize_fwd_bf16(const float* X, int ld_x, float* Y, int ld_y, float* inv, int n_cap, const int* dyn, int d,
+                            int eps_mode, float eps, void* dst16, int Dp, void* stream);
 int srec_normalize_bwd(const float* Y, int ld_y, const float* dY, int ld_dy, const float* inv, float* dX, int ld_dx,
                        int n_cap, const int* dyn, int d, void* stream);
 /* the same for np <= 4 row blocks of different tensors normalised into ONE stacked matrix Y [sum n_p, d] (MSGIFSR: the

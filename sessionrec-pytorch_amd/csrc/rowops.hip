@@ -197,9 +197,11 @@ __global__ void row_invnorm_kernel(const float* __restrict__ W, int ld, int n, i
     if (lane == 0) out[i] = scale * inv_norm(s, eps_mode, eps);
 }
 
+// dst16 (nullable): bf16 copy of the normalised rows, row stride Dp (the session-vector operand of the bf16 scoring kernels:
+// the normalised session vector is what they multiply, so the conversion pass of its own disappears)
 __global__ void normalize_fwd_kernel(const float* __restrict__ X, int ld_x, float* __restrict__ Y, int ld_y,
                                      float* __restrict__ inv, int n_cap, const int* __restrict__ dyn, int d,
-                                     int eps_mode, float eps) {
+                                     int eps_mode, float eps, unsigned short* __restrict__ dst16, int Dp) {
     const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n_cap) return;
     const bool live = i < dyn_count(dyn, n_cap);
@@ -212,6 +214,8 @@ __global__ void normalize_fwd_kernel(const float* __restrict__ X, int ld_x, floa
             v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
         }
         *reinterpret_cast<float4*>(Y + (size_t)i * ld_y + c) = v;
+        if (dst16 != nullptr)
+            *reinterpret_cast<uint2*>(dst16 + (size_t)i * Dp + c) = make_uint2(srec_pack_bf16(v.x, v.y), srec_pack_bf16(v.z, v.w));
     }
     if (lane == 0) inv[i] = iv;
 }
@@ -508,7 +512,17 @@ extern "C" int srec_normalize_fwd(const float* X, int ld_x, float* Y, int ld_y, 
     if (n_cap <= 0) return 0;
     if (bad_row_args(d, ld_x) || (ld_y & 3)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(normalize_fwd_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, X, ld_x, Y, ld_y,
-                       inv, n_cap, dyn, d, eps_mode, eps);
+                       inv, n_cap, dyn, d, eps_mode, eps, (unsigned short*)nullptr, 0);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_normalize_fwd_bf16(const float* X, int ld_x, float* Y, int ld_y, float* inv, int n_cap, const int* dyn,
+                                       int d, int eps_mode, float eps, void* dst16, int Dp, void* stream) {
+    if (n_cap <= 0) return 0;
+    if (bad_row_args(d, ld_x) || (ld_y & 3) || dst16 == nullptr || Dp < d || (Dp & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(normalize_fwd_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, X, ld_x, Y, ld_y,
+                       inv, n_cap, dyn, d, eps_mode, eps, (unsigned short*)dst16, Dp);
     SREC_LAUNCH_CHECK();
     return 0;
 }

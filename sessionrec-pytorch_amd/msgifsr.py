@@ -368,7 +368,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             ss = ops.readout_head(allf, mg.cat_seg, mg.dynp('NT'), dB,
                                   [(feat_vs[i], ro.fc_u[i].weight, ro.fc_u[i].bias, ro.fc_v[i].weight, ro.fc_e[i].weight,
                                     self.fc_sr[i].weight) for i in live])
-            srs = [ops.normalize(s, 0, dB) if self.norm else s for s in ss]
+            ws = getattr(self, '_sr_ws', None) if len(ss) == 1 else None      # one head: its vector is the scoring operand
+            srs = [ops.normalize(s, 0, dB, ws) if self.norm else s for s in ss]
         else:
             sr_g = self.readout(mg, allf, feat_vs, live)
             for i in live:

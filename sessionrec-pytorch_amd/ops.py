@@ -454,12 +454,19 @@ def split_rows(x, sizes):
 
 class Normalize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps_mode, dyn):
+    def forward(ctx, x, eps_mode, dyn, ws=None):
         x = _rows(x)
         n, d = x.shape
         y = torch.empty(n, d, device=x.device, dtype=torch.float32)
         inv = torch.empty(n, device=x.device, dtype=torch.float32)
-        lib.srec_normalize_fwd(ptr(x), _ld(x), ptr(y), d, ptr(inv), n, ptr(dyn), d, eps_mode, 1e-12, stream())
+        sr16 = getattr(ws, 'sr16', None)
+        if sr16 is not None and n <= sr16.shape[0] and d <= sr16.shape[1]:
+            # ws: the scoring workspace this session vector is headed for - its bf16 operand copy is written here
+            lib.srec_normalize_fwd_bf16(ptr(x), _ld(x), ptr(y), d, ptr(inv), n, ptr(dyn), d, eps_mode, 1e-12, ptr(sr16),
+                                        sr16.shape[1], stream())
+            ws.sr_fresh = (y.data_ptr(), n, d)
+        else:
+            lib.srec_normalize_fwd(ptr(x), _ld(x), ptr(y), d, ptr(inv), n, ptr(dyn), d, eps_mode, 1e-12, stream())
         ctx.save_for_backward(y, inv)
         ctx.dyn = dyn
         return y
@@ -471,11 +478,12 @@ class Normalize(torch.autograd.Function):
         n, d = y.shape
         gx = torch.empty_like(y)
         lib.srec_normalize_bwd(ptr(y), d, ptr(gy), _ld(gy), ptr(inv), ptr(gx), d, n, ptr(ctx.dyn), d, stream())
-        return gx, None, None
+        return gx, None, None, None
 
 
-def normalize(x, eps_mode=0, dyn=None):
-    return Normalize.apply(x, eps_mode, dyn)
+def normalize(x, eps_mode=0, dyn=None, ws=None):
+    """ws (a CEWorkspace in bf16 scoring mode): also write the bf16 operand copy of the rows into ws.sr16"""
+    return Normalize.apply(x, eps_mode, dyn, ws)
 
 
 class NormalizeStack(torch.autograd.Function):
@@ -817,8 +825,12 @@ def _ce_fwd(sr, table, cs, labels, ws, dynB, tb, lab, lse, lossvec, loss):
     B, d = sr.shape
     V = table.shape[0]
     if tb is not None:
-        ws.sr_key = None
-        _prepare_sr(sr, ws, dynB)
+        if getattr(ws, 'sr_fresh', None) == (sr.data_ptr(), sr.shape[0], sr.shape[1]):
+            ws.sr_key = (sr.data_ptr(), sr._version, tuple(sr.shape))     # written by the normalisation that produced sr
+        else:
+            ws.sr_key = None
+            _prepare_sr(sr, ws, dynB)
+        ws.sr_fresh = None
         lib.srec_score_ce_fwd_bf16(ptr(ws.sr16), ws.Bp, ptr(tb.E16), tb.Vp, ptr(cs), ptr(labels), B, V, d, ptr(dynB),
                                    ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
     else:

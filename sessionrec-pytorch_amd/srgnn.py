@@ -94,7 +94,12 @@ class _ScoringMixin:
         cs, inv_scale = self._col_scale(st)
         if self.shard is not None:
             self.shard.labels_hint = labels          # gathered together with the lookup's request lists
-        sr = self.session_repr(*inputs, tgrad=st['tgrad'])
+        # bf16 scoring on one device: the model's final normalisation writes the session vectors' bf16 operand copy itself
+        self._sr_ws = st['ws'][B] if (self.shard is None and ops.use_bf16_scoring(self._table().shape[1])) else None
+        try:
+            sr = self.session_repr(*inputs, tgrad=st['tgrad'])
+        finally:
+            self._sr_ws = None
         if self.shard is not None:
             return self.shard.loss(sr, self._table(), cs, labels, inv_scale)
         loss, _ = ops.score_ce(sr, self._table(), cs, labels.to(torch.int32), st['ws'][B], st['tgrad'], dynB, inv_scale,
@@ -250,4 +255,4 @@ class NISER(SRGNN):
         return ops.normalize(feat, 1, dyn) if self.norm else feat
 
     def _post(self, sr, dyn=None):
-        return ops.normalize(sr, 1, dyn) if self.norm else sr
+        return ops.normalize(sr, 1, dyn, getattr(self, '_sr_ws', None)) if self.norm else sr
