@@ -354,9 +354,14 @@ class PermuteAndPick(torch.autograd.Function):
         x = _rows(x)
         d = x.shape[1]
         outs = []
-        for idx, dyn in [(perm, dyn_n)] + [(p, dyn_b) for p in picks]:
-            o = torch.empty(idx.numel(), d, device=x.device, dtype=torch.float32)
-            lib.srec_gather_rows(ptr(x), _ld(x), ptr(idx), ptr(o), d, idx.numel(), ptr(dyn), d, stream())
+        for k, (idx, dyn) in enumerate([(perm, dyn_n)] + [(p, dyn_b) for p in picks]):
+            if k == 0:
+                o = torch.empty(idx.numel(), d, device=x.device, dtype=torch.float32)
+            else:
+                # a pick is the left half of a [n, 2 d] buffer: the read-out head (ReadoutHead) puts the session's attention
+                # read-out into the right half and has its fc_sr input [x_last | sr_g] without a concatenation kernel
+                o = torch.empty(idx.numel(), 2 * d, device=x.device, dtype=torch.float32)[:, :d]
+            lib.srec_gather_rows(ptr(x), _ld(x), ptr(idx), ptr(o), _ld(o), idx.numel(), ptr(dyn), d, stream())
             outs.append(o)
         ctx.save_for_backward(inv, *picks)
         ctx.nrows, ctx.dyn_b = x.shape[0], dyn_b
@@ -650,11 +655,22 @@ class ReadoutHead(torch.autograd.Function):
         alphas, cats, outs, probs = [], [], [], []
         for i, (v, Wu, bu, Wv, we, Wsr) in enumerate(per):
             alpha = torch.empty(NT, device=dev, dtype=torch.float32)
-            srg = torch.empty(B, D, device=dev, dtype=torch.float32)
-            lib.srec_seg_attn_fwd(ptr(Us[i]), h, ptr(Vqs[i]), h, ptr(we), ptr(allf), _ld(allf), ptr(seg), B, ptr(dB), h, D,
-                                  ptr(alpha), ptr(srg), D, stream())
-            cat = torch.empty(B, v.shape[1] + D, device=dev, dtype=torch.float32)
-            lib.srec_cat_cols(ptr(v), _ld(v), v.shape[1], ptr(srg), D, D, B, ptr(cat), stream())
+            dv = v.shape[1]
+            cat = None
+            if B > 1 and v.stride(0) == dv + D and v.stride(1) == 1:
+                try:                                       # v already is the left half of a [B, dv + D] buffer (permute_and_pick)
+                    cat = v.as_strided((B, dv + D), (dv + D, 1))
+                except RuntimeError:
+                    cat = None
+            if cat is not None:
+                lib.srec_seg_attn_fwd(ptr(Us[i]), h, ptr(Vqs[i]), h, ptr(we), ptr(allf), _ld(allf), ptr(seg), B, ptr(dB), h, D,
+                                      ptr(alpha), cat[:, dv:].data_ptr(), dv + D, stream())
+            else:
+                srg = torch.empty(B, D, device=dev, dtype=torch.float32)
+                lib.srec_seg_attn_fwd(ptr(Us[i]), h, ptr(Vqs[i]), h, ptr(we), ptr(allf), _ld(allf), ptr(seg), B, ptr(dB), h, D,
+                                      ptr(alpha), ptr(srg), D, stream())
+                cat = torch.empty(B, dv + D, device=dev, dtype=torch.float32)
+                lib.srec_cat_cols(ptr(v), _ld(v), dv, ptr(srg), D, D, B, ptr(cat), stream())
             out = torch.empty(B, Wsr.shape[0], device=dev, dtype=torch.float32)
             probs.append(('nt', cat, Wsr, out, None, dB, 0.0))
             alphas.append(alpha)
