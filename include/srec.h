@@ -102,6 +102,9 @@ int srec_gather_rows_drop(const float* src, int ld_src, const int* idx, float* o
 int srec_scatter_add_sorted_drop(const float* g, int ld_g, const int* items, const int* ptr, const int* pos, float* dst,
                                  int ld_dst, int u_cap, const int* dyn, int d, int accumulate, float p, int seed,
                                  const int* counter, int salt, void* stream);
+int srec_scatter_add_sorted_ex(const float* g, int ld_g, const int* items, const int* ptr, const int* pos, float* dst,
+                               int ld_dst, int u_cap, const int* dyn, int d, int accumulate, float p, int seed,
+                               const int* counter, int salt, const float* projW, int ld_w, float* radial, void* stream);
 /* Embedding(max_norm) in-place renorm, idx distinct or NULL (= all rows): lessr.py:126 msgifsr.py:162 */
 int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, const int* dyn, int d, float max_norm,
                      void* stream);
@@ -132,6 +135,11 @@ int srec_cat_cols(const float* a, int lda, int da, const float* b, int ldb, int 
 /* chain rule of the catalog-row normalisation on the dense dE: G_v -= e_v <e_v, G_v> */
 int srec_rownorm_project(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g, int n, int d,
                          void* stream);
+/* deferred form of the projection: the scoring backward leaves dE unprojected, later additions to it (lookup gradients)
+ * record their radial part radial[v] += <W_v, l_v> (srec_scatter_add_sorted_ex), and either this call or the optimizer's row pass
+ * (srec_adam_rows_proj) applies G_v -= W_v (<W_v, G_v> - radial[v]) inv_v^2 and clears radial */
+int srec_rownorm_project_radial(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g, int n, int d,
+                                float* radial, void* stream);
 /* out[c] (+)= sum_r w[r, c/D] * X[r,c] (wgt NULL -> plain column sums: bias / fc_e / attention-vector
  * gradients).  Two deterministic stages; ws = 128*ncol floats of scratch (16-byte aligned). */
 int srec_col_sum(const float* X, int ld, const float* wgt, int H, int D, int n_cap, const int* dyn, int ncol,
@@ -273,6 +281,9 @@ int srec_adam_multi(const void* desc, const float* hyper, void* stream);
 int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
                    int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
                    float cs_eps, void* stream);
+int srec_adam_rows_proj(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper, int use_wd,
+                        float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
+                        const float* proj_cs, float proj_inv_scale, float* radial, void* stream);
 
 /* ---- MSGIFSR MSHGNN layer, all relations of both HeteroGraphConvs in one batched pass (hgat.hip) ------------------
  * Replaces msgifsr.py:70-89 (conv1(g) + conv2(reverse g), relation sum, head max, + session mean) around the fc GEMMs

@@ -63,16 +63,39 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict__ G, float* __restrict__ M,
                                  float* __restrict__ Vv, int n, int d, int ld, const float* __restrict__ hyper,
                                  int use_wd, float max_norm, int renorm_write, float* __restrict__ cs_out, float cs_scale,
-                                 int eps_mode, float cs_eps) {
+                                 int eps_mode, float cs_eps, const float* __restrict__ proj_cs = nullptr,
+                                 float proj_inv_scale = 0.f, float* __restrict__ radial = nullptr) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const Hyper h = load_hyper(hyper);
     const float wd = use_wd ? h.wd : 0.f, step = h.step, rs2 = h.bc2s;
     const size_t off = (size_t)i * ld;
+    // proj_cs != NULL: the chain rule of the catalog-row normalisation (rownorm_project) is applied HERE, to the gradient row as
+    // it is read: g = G - W (<W, G> - radial) inv^2, inv = proj_cs * proj_inv_scale (the column scale of this step's forward;
+    // read before cs_out - possibly the same array - is rewritten below).  radial [n] holds <W, l> of whatever was added to G
+    // after the scoring gradient (the lookup gradients, srec_scatter_add_sorted_ex) and is cleared for the next step.  Saves
+    // the separate pass over the table gradient (read G + W, write G: 115 MB at C3).
+    float pcoef = 0.f;
+    if (proj_cs != nullptr) {
+        float dot = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 pp = *reinterpret_cast<const float4*>(W + off + c);
+            const float4 gg = *reinterpret_cast<const float4*>(G + off + c);
+            dot += pp.x * gg.x + pp.y * gg.y + pp.z * gg.z + pp.w * gg.w;
+        }
+        dot = wave_sum(dot);
+        const float iv = proj_cs[i] * proj_inv_scale;
+        if (radial != nullptr) {
+            dot -= radial[i];
+            if (lane == 0) radial[i] = 0.f;
+        }
+        pcoef = dot * iv * iv;
+    }
     float ss = 0.f;
     for (int c = lane * 4; c < d; c += 256) {
         float4 pp = *reinterpret_cast<float4*>(W + off + c);
-        const float4 gg = *reinterpret_cast<const float4*>(G + off + c);
+        float4 gg = *reinterpret_cast<const float4*>(G + off + c);
+        gg.x -= pp.x * pcoef; gg.y -= pp.y * pcoef; gg.z -= pp.z * pcoef; gg.w -= pp.w * pcoef;
         float4 mm = *reinterpret_cast<float4*>(M + off + c);
         float4 vv = *reinterpret_cast<float4*>(Vv + off + c);
         adam1(pp.x, gg.x, mm.x, vv.x, h, wd, step, rs2);
@@ -268,7 +291,21 @@ extern "C" int srec_adam_rows(float* W, const float* G, float* M, float* V, int 
     if (n <= 0) return 0;
     if (d <= 0 || (d & 3) || (ld & 3)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(adam_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld,
-                       hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps);
+                       hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, (const float*)nullptr, 0.f,
+                       (float*)nullptr);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// srec_adam_rows with the row-normalisation projection of the gradient fused in (see adam_rows_kernel)
+extern "C" int srec_adam_rows_proj(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
+                                   int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
+                                   float cs_eps, const float* proj_cs, float proj_inv_scale, float* radial, void* stream) {
+    if (n <= 0) return 0;
+    if (d <= 0 || (d & 3) || (ld & 3) || proj_cs == nullptr) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld,
+                       hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, proj_cs, proj_inv_scale,
+                       radial);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -46,11 +46,16 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, co
 __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g, const int* __restrict__ items,
                                           const int* __restrict__ ptr, const int* __restrict__ pos,
                                           float* __restrict__ dst, int ld_dst, int u_cap,
-                                          const int* __restrict__ dyn, int d, int accumulate, srec_rng rng) {
+                                          const int* __restrict__ dyn, int d, int accumulate, srec_rng rng,
+                                          const float* __restrict__ projW = nullptr, int ld_w = 0,
+                                          float* __restrict__ radial = nullptr) {
+    // radial (nullable; deferred row-normalisation projection, see srec_adam_rows_proj): radial[item] += <W_item, sum> - the
+    // part of THIS gradient along the item's row, which the projection applied later to the whole buffer must not remove
     const int u = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (u >= dyn_count(dyn, u_cap)) return;
     const int beg = ptr[u], end = ptr[u + 1], item = items[u];
     if (item < 0) return;                             // row owned by another shard
+    float rdot = 0.f;
     if (rng.p > 0.f) {
         // backward of the fused lookup dropout: the gradient row of position p is masked with the forward's mask
         const unsigned key = srec_rng_key(rng);
@@ -75,12 +80,20 @@ __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g,
                 const int pp = pos[e];
                 add(pp, *reinterpret_cast<const float4*>(g + (size_t)pp * ld_g + c));
             }
+            if (radial != nullptr) {
+                const float4 wv = *reinterpret_cast<const float4*>(projW + (size_t)item * ld_w + c);
+                rdot += wv.x * s.x + wv.y * s.y + wv.z * s.z + wv.w * s.w;
+            }
             float4* o = reinterpret_cast<float4*>(dst + (size_t)item * ld_dst + c);
             if (accumulate) {
                 const float4 t = *o;
                 s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
             }
             *o = s;
+        }
+        if (radial != nullptr) {
+            rdot = wave_sum(rdot);
+            if (lane == 0) radial[item] += rdot;
         }
         return;
     }
@@ -111,12 +124,20 @@ __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g,
             const float4 v = *reinterpret_cast<const float4*>(g + (size_t)pos[e] * ld_g + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+        if (radial != nullptr) {
+            const float4 wv = *reinterpret_cast<const float4*>(projW + (size_t)item * ld_w + c);
+            rdot += wv.x * s.x + wv.y * s.y + wv.z * s.z + wv.w * s.w;
+        }
         float4* o = reinterpret_cast<float4*>(dst + (size_t)item * ld_dst + c);
         if (accumulate) {
             const float4 t = *o;
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         *o = s;
+    }
+    if (radial != nullptr) {
+        rdot = wave_sum(rdot);
+        if (lane == 0) radial[item] += rdot;
     }
 }
 
@@ -251,7 +272,8 @@ __global__ void normalize_bwd_kernel(const float* __restrict__ Y, int ld_y, cons
 
 // G_v <- G_v - e_v (e_v . G_v),  e_v = W_v * inv_v   (inv = cs / scale)
 __global__ void rownorm_project_kernel(const float* __restrict__ W, int ld_w, const float* __restrict__ cs,
-                                       float inv_scale, float* __restrict__ G, int ld_g, int n, int d) {
+                                       float inv_scale, float* __restrict__ G, int ld_g, int n, int d,
+                                       float* __restrict__ radial = nullptr) {
     const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const float iv = cs[i] * inv_scale;
@@ -261,7 +283,12 @@ __global__ void rownorm_project_kernel(const float* __restrict__ W, int ld_w, co
         const float4 g = *reinterpret_cast<const float4*>(G + (size_t)i * ld_g + c);
         dot += w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w;
     }
-    dot = wave_sum(dot) * iv * iv;
+    dot = wave_sum(dot);
+    if (radial != nullptr) {                           // the part of G that was added after the scoring gradient stays
+        dot -= radial[i];
+        if (lane == 0) radial[i] = 0.f;
+    }
+    dot *= iv * iv;
     for (int c = lane * 4; c < d; c += 256) {
         const float4 w = *reinterpret_cast<const float4*>(W + (size_t)i * ld_w + c);
         float4 g = *reinterpret_cast<float4*>(G + (size_t)i * ld_g + c);
@@ -478,6 +505,21 @@ extern "C" int srec_scatter_add_sorted_drop(const float* g, int ld_g, const int*
     return 0;
 }
 
+// the general form: dropout mask (p = 0: none) and the radial side sum (radial = NULL: none) of the deferred projection
+extern "C" int srec_scatter_add_sorted_ex(const float* g, int ld_g, const int* items, const int* ptr, const int* pos,
+                                          float* dst, int ld_dst, int u_cap, const int* dyn, int d, int accumulate,
+                                          float p, int seed, const int* counter, int salt, const float* projW, int ld_w,
+                                          float* radial, void* stream) {
+    if (u_cap <= 0) return 0;
+    if (bad_row_args(d, ld_g) || (ld_dst & 3) || p < 0.f || p >= 1.f || (p > 0.f && ld_g != d)) return SREC_BAD_ARG;
+    if (radial != nullptr && (projW == nullptr || (ld_w & 3))) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(scatter_add_sorted_kernel, dim3(cdiv(u_cap, WPB)), dim3(256), 0, (hipStream_t)stream, g, ld_g,
+                       items, ptr, pos, dst, ld_dst, u_cap, dyn, d, accumulate,
+                       srec_rng{(unsigned)seed, counter, (unsigned)salt, p}, projW, ld_w, radial);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, const int* dyn, int d, float max_norm,
                                 void* stream) {
     if (n_cap <= 0) return 0;
@@ -675,7 +717,18 @@ extern "C" int srec_rownorm_project(const float* W, int ld_w, const float* cs, f
     if (n <= 0) return 0;
     if (bad_row_args(d, ld_w) || (ld_g & 3)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(rownorm_project_kernel, dim3(cdiv(n, WPB)), dim3(256), 0, (hipStream_t)stream, W, ld_w, cs,
-                       inv_scale, G, ld_g, n, d);
+                       inv_scale, G, ld_g, n, d, (float*)nullptr);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// the deferred form: G holds scoring gradient + later additions whose radial sums sit in radial [n] (cleared here)
+extern "C" int srec_rownorm_project_radial(const float* W, int ld_w, const float* cs, float inv_scale, float* G, int ld_g,
+                                           int n, int d, float* radial, void* stream) {
+    if (n <= 0) return 0;
+    if (bad_row_args(d, ld_w) || (ld_g & 3)) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(rownorm_project_kernel, dim3(cdiv(n, WPB)), dim3(256), 0, (hipStream_t)stream, W, ld_w, cs,
+                       inv_scale, G, ld_g, n, d, radial);
     SREC_LAUNCH_CHECK();
     return 0;
 }

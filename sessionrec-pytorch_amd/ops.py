@@ -236,9 +236,26 @@ class TableGrad:
     """Dense gradient buffer of the item table, shared by the scoring backward (writes every row)
     and the embedding-lookup backward (adds its rows in place): no dense+dense autograd sum."""
 
-    def __init__(self, weight):
+    def __init__(self, weight, defer=False):
         self.buf = torch.zeros_like(weight)
         self.fresh = False       # True once the scoring backward has overwritten it this step
+        # Deferred row-normalisation projection (cosine-scored models, FusedAdam(fuse_projection=True)): the scoring backward
+        # leaves `buf` unprojected and records pending = (table, cs, inv_scale); the lookup backward adds its rows AND their
+        # radial sums radial[v] += <W_v, l_v>; the optimizer's row pass applies g = G - W (<W, G> - radial) inv^2 while it reads
+        # the gradient (srec_adam_rows_proj) - one pass over the table gradient less per step.  Any other reader of the
+        # gradient calls materialize() first.
+        self.defer = defer
+        self.pending = None
+        self.radial = torch.zeros(weight.shape[0], device=weight.device, dtype=torch.float32) if defer else None
+
+    def materialize(self):
+        """apply a pending projection to `buf` (after it, buf is the true table gradient)"""
+        if self.pending is not None:
+            table, cs, inv_scale = self.pending
+            lib.srec_rownorm_project_radial(ptr(table), table.stride(0), ptr(cs), float(inv_scale), ptr(self.buf),
+                                            self.buf.stride(0), table.shape[0], table.shape[1], ptr(self.radial), stream())
+            self.pending = None
+        return self.buf
 
 
 class EmbeddingLookup(torch.autograd.Function):
@@ -277,6 +294,9 @@ class EmbeddingLookup(torch.autograd.Function):
         else:
             def first_level(gp, ldg, it, pt, ps, dst, ldd, ucap, dyn, acc):
                 lib.srec_scatter_add_sorted(gp, ldg, it, pt, ps, dst, ldd, ucap, dyn, d, acc, stream())
+        radial = ptable = None
+        if tg is not None and tg.pending is not None:     # deferred projection: this gradient's radial part is recorded
+            radial, ptable = tg.radial, tg.pending[0]
         if tg is not None:
             dst, acc, ret = tg.buf, 1, None
         else:
@@ -289,8 +309,18 @@ class EmbeddingLookup(torch.autograd.Function):
             part = torch.empty(max(C, 1), d, device=g.device, dtype=torch.float32)
             ar = _arange(C + 1, g.device)
             first_level(ptr(g), _ld(g), ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, 0)   # padded chunks are
-            lib.srec_scatter_add_sorted(ptr(part), d, ptr(items), ptr(cptr), ptr(ar), ptr(dst), dst.stride(0),   # empty segments
-                                        items.numel(), ptr(ctx.dyn_u), d, acc, stream())
+            if radial is not None:                                                                          # empty segments
+                lib.srec_scatter_add_sorted_ex(ptr(part), d, ptr(items), ptr(cptr), ptr(ar), ptr(dst), dst.stride(0),
+                                               items.numel(), ptr(ctx.dyn_u), d, acc, 0.0, 0, None, 0, ptr(ptable),
+                                               ptable.stride(0), ptr(radial), stream())
+            else:
+                lib.srec_scatter_add_sorted(ptr(part), d, ptr(items), ptr(cptr), ptr(ar), ptr(dst), dst.stride(0),
+                                            items.numel(), ptr(ctx.dyn_u), d, acc, stream())
+        elif radial is not None:
+            pdrop, seed, cnt, salt = ctx.drop if ctx.drop is not None else (0.0, 0, None, 0)
+            lib.srec_scatter_add_sorted_ex(ptr(g), _ld(g), ptr(items), ptr(uptr), ptr(upos), ptr(dst), dst.stride(0),
+                                           items.numel(), ptr(ctx.dyn_u), d, acc, pdrop, seed, cnt, salt, ptr(ptable),
+                                           ptable.stride(0), ptr(radial), stream())
         else:
             first_level(ptr(g), _ld(g), ptr(items), ptr(uptr), ptr(upos), ptr(dst), dst.stride(0), items.numel(),
                         ptr(ctx.dyn_u), acc)
@@ -896,7 +926,9 @@ class ScoreCE(torch.autograd.Function):
         gl = gloss.reshape(1).to(torch.float32).contiguous()
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         _ce_bwd(sr, table, cs, labels, lse, gl, None, None, ws, ctx.dynB, ctx.tb, tg.buf, dsr, 3)
-        if cs is not None:      # rows were L2-normalised before scoring: project out the radial part
+        if cs is not None and tg.defer:
+            tg.pending = (table, cs, ctx.cs_inv_scale)     # applied by the optimizer's row pass (or TableGrad.materialize)
+        elif cs is not None:    # rows were L2-normalised before scoring: project out the radial part
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(tg.buf),
                                      tg.buf.stride(0), V, d, stream())
         tg.fresh = True
@@ -935,7 +967,9 @@ class ScoreStats(torch.autograd.Function):
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         parts = 3 | (4 if tg.fresh else 0)
         _ce_bwd(sr, table, cs, labels, lse, None, ga, gc, ws, ctx.dynB, ctx.tb, tg.buf, dsr, parts)
-        if cs is not None:      # projection is linear and idempotent: safe after every accumulation
+        if cs is not None and tg.defer:
+            tg.pending = (table, cs, ctx.cs_inv_scale)     # linear: once, over the sum of the heads' contributions
+        elif cs is not None:    # projection is linear and idempotent: safe after every accumulation
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), ctx.cs_inv_scale, ptr(tg.buf),
                                      tg.buf.stride(0), V, d, stream())
         tg.fresh = True

@@ -27,10 +27,17 @@ class _AdamMultiDesc(_ct.Structure):
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, model=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, model=None, fuse_projection=False):
+        """fuse_projection (cosine-scored models on one device): the chain rule of the catalog-row normalisation is applied
+        to the table gradient inside this optimizer's row pass instead of a separate pass after the scoring backward
+        (ops.TableGrad: defer / pending / radial)."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.model = model
+        if fuse_projection and model is not None and getattr(model, 'shard', None) is None and hasattr(model, '_cosine') \
+                and model._cosine() is not None and model._table().is_cuda:
+            model._defer_projection = True
+            model.__dict__.pop('_srec_state', None)          # the gradient buffer is re-created with the side array
         self._hyper = {}            # (group index, step offset) -> device step state
         self._frozen = None         # parameter lists frozen by a captured graph
 
@@ -52,6 +59,8 @@ class FusedAdam(torch.optim.Optimizer):
         if self.grad_override and id(p) in self.grad_override:
             g = self.grad_override[id(p)]      # all-reduced bucket view: present even when THIS rank's batch gave no gradient
         if table is not None and p is table and tgrad is not None:
+            if g is not None:
+                tgrad.materialize()           # a deferred projection applies to the scoring gradient only
             g = tgrad.buf if g is None else g.add_(tgrad.buf)
         if g is None and id(p) in zero_ids:
             # zero (not None) gradient in the reference: weight decay only.  One static all-zero buffer per parameter
@@ -225,9 +234,18 @@ class FusedAdam(torch.optim.Optimizer):
                     # Embedding(max_norm) renorm stays in forward (reference state after step()): renorm_write = 0; the
                     # column scale of the next step is nevertheless that of the rows as the next forward will see them
                     mn = float(getattr(model, '_max_norm', 0.0) or 0.0) if cs_out is not None else 0.0
-                    lib.srec_adam_rows(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
-                                       p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, 0, ptr(cs_out), cs_scale,
-                                       eps_mode, 1e-12, stream())
+                    pend = tgrad.pending if (tgrad is not None and g.data_ptr() == tgrad.buf.data_ptr()) else None
+                    if pend is not None:
+                        lib.srec_adam_rows_proj(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
+                                                p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, 0, ptr(cs_out), cs_scale,
+                                                eps_mode, 1e-12, ptr(pend[1]), float(pend[2]), ptr(tgrad.radial), stream())
+                        tgrad.pending = None
+                    else:
+                        if tgrad is not None:
+                            tgrad.materialize()
+                        lib.srec_adam_rows(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
+                                           p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, 0, ptr(cs_out), cs_scale,
+                                           eps_mode, 1e-12, stream())
                     if cs_out is not None:
                         st['cs_fresh'] = True
                 else:

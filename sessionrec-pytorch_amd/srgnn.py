@@ -37,7 +37,7 @@ class _ScoringMixin:
         if st.get('dev') != dev:
             st.clear()
             st['dev'] = dev
-            st['tgrad'] = ops.TableGrad(self._table())
+            st['tgrad'] = ops.TableGrad(self._table(), defer=bool(getattr(self, '_defer_projection', False)))
             st['ws'] = {}
             st['cs'] = None
             st['cs_fresh'] = False
@@ -48,7 +48,9 @@ class _ScoringMixin:
 
     @property
     def table_grad(self):
-        return self._state(1)['tgrad']
+        tg = self._state(1)['tgrad']
+        tg.materialize()               # (a projection left to the optimizer is applied before anybody else looks)
+        return tg
 
     def _col_scale(self, st):
         cos = self._cosine()

@@ -596,3 +596,68 @@ def test_msgifsr_bf16_gemm16_path_at_d64(dev, dropout):
             cos = float(g @ r / (g.norm() * r.norm()))
             assert cos > 0.97, '%s: gradient direction cos=%.4f' % (k_, cos)
     assert (num / den) ** 0.5 < 3e-2, 'bf16 gradients off by %.3e (norm-wise)' % (num / den) ** 0.5
+
+
+@pytest.mark.parametrize('name,graph', [('niser_s32', False), ('msgifsr_K3_s32', False), ('msgifsr_K3_fus_s32', False),
+                                        ('msgifsr_K2_edge', True), ('niser_edge', True)])
+def test_projection_fused_into_the_optimizer_equals_the_separate_pass(dev, name, graph):
+    """FusedAdam(fuse_projection=True): the chain rule of the catalog-row normalisation applied inside the optimizer's row
+    pass (deferred projection + radial side sums of the lookup gradients) gives the trajectory of the separate
+    srec_rownorm_project pass, and model.table_grad shows the projected gradient either way."""
+    import copy
+    train, optim = pkg('train'), pkg('optim')
+    z, samples, init = load_golden(name)
+    V = init[[k for k in init if k.startswith('embedding')][0]].shape[0]
+    base = _build(name, init, V, dev)
+    for m in base.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.2                                   # the lookup-gradient scatter runs through its dropout branch too
+    models = [copy.deepcopy(base), copy.deepcopy(base)]
+    inputs, labels = _collate(name, samples)
+    if graph:
+        c = pkg('collate')
+        caps = c.default_caps(len(samples), 12)
+        fac = c.collate_fn_factory if name.startswith(('srgnn', 'niser')) else None
+        if fac is not None:
+            inputs, labels = c.collate_fn_factory(c.seq_to_session_graph, caps=caps)(samples)
+        else:
+            K = int(name.split('_')[1][1:])
+            inputs, labels = c.collate_fn_factory_ccs((c.seq_to_ccs_graph,), K, caps=caps)(samples)
+    inputs = [x.to(dev) for x in inputs]
+    labels = labels.to(dev)
+    opts = [optim.FusedAdam(train.fix_weight_decay(m), lr=1e-3, weight_decay=1e-4, model=m, fuse_projection=f)
+            for m, f in zip(models, (False, True))]
+    assert models[1].table_grad.defer and not models[0].table_grad.defer
+    steps = []
+    for m, o in zip(models, opts):
+        m.train()
+        if graph:
+            G = pkg('graph')
+            torch.manual_seed(5)
+            gs = G.GraphedTrainStep(m, o, inputs, labels)
+            steps.append(lambda gs=gs: gs(inputs, labels).clone())
+        else:
+            def one(m=m, o=o):
+                o.zero_grad()
+                loss = m.fused_loss(*inputs, labels)
+                loss.backward()
+                g = m.table_grad.buf.clone() if not graph else None
+                o.step()
+                return loss, g
+            steps.append(one)
+    runs = []
+    for st in steps:                                    # one after the other: the dropout masks are keyed by the step counter
+        pkg('ops').RNG_COUNTER.clear()                  # of the optimizer registered on the device
+        out = []
+        for it in range(3):
+            torch.manual_seed(100 + it)
+            out.append(st())
+        runs.append(out)
+    for it in range(3):
+        r0, r1 = runs[0][it], runs[1][it]
+        l0, l1 = (r0[0], r1[0]) if not graph else (r0.clone(), r1.clone())
+        close(l1, l0, rtol=1e-6, atol=1e-6, what='loss step %d' % it)
+        if not graph and it == 0:
+            close(r1[1], r0[1], rtol=1e-5, atol=1e-8, what='projected table gradient')
+    for (k, p), (_, q) in zip(models[1].named_parameters(), models[0].named_parameters()):
+        adam_close(p, q, lr=1e-3, steps=3, what=k)
