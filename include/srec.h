@@ -339,6 +339,11 @@ int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, c
  * srec_gru_step_desc (srec_hg.h).  d % 4 == 0 and 256 % (d / 4) == 0. */
 int srec_gru_step_fwd(const void* desc, void* stream);
 int srec_gru_step_bwd(const void* desc, void* stream);
+/* forward of ALL time steps in one launch (csrc/gruf.hip; d = 128 / 256): desc = HOST srec_gru_fused_desc (srec_hg.h);
+ * srec_gru_wfrag: n <= 8 GRU weights W_i [3 d, d] fp32 -> fragment-major bf16 copies dst_i [3 d d] (W, dst: HOST arrays of
+ * device pointers), the B operands the fused forward streams */
+int srec_gru_fused_fwd(const void* desc, void* stream);
+int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void* stream);
 /* out[p] [ncol] = column sums of part[p] [rows[p], ncol] for np <= 4 problems in one launch (the GRU bias gradients from the
  * per-block partial rows of srec_gru_step_bwd); part / out: HOST arrays of np device pointers, rows: HOST int array */
 int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);

@@ -154,4 +154,26 @@ typedef struct {
     int part_row0[SREC_GRU_MAXP];
 } srec_gru_step_desc;
 
+/* the whole k-gram GRU forward (all time steps, up to 4 orders) in one launch: srec_gru_fused_fwd (srec.h, csrc/gruf.hip;
+ * msgifsr.py:25,32-45), d = 128 or 256.  Problem p = order k[p] with n[p] nodes (live prefix *dyn[p]); x rows node-major
+ * (node * k + t).  Reads X [n k, d] fp32 and the fragment-major bf16 weights of srec_gru_wfrag; writes X16 [n k, d] (bf16
+ * copy of X), H [k, n, d] fp32 hidden states, H16 [k - 1, n, d] their bf16 copies (steps 0 .. k - 2), gates [k, n, 4 d] =
+ * r, z, n, gh_n + b_hh_n (live rows), out [n, d] = 0.5 mean_t X[n, t, :] + 0.5 h_{k-1}; rows past the live prefix: H, H16,
+ * out = 0. */
+typedef struct {
+    int np, d;
+    int n[SREC_GRU_MAXP], k[SREC_GRU_MAXP];
+    const int* dyn[SREC_GRU_MAXP];
+    const float* X[SREC_GRU_MAXP];
+    void* X16[SREC_GRU_MAXP];
+    const void* Wih_f[SREC_GRU_MAXP];
+    const void* Whh_f[SREC_GRU_MAXP];
+    const float* bih[SREC_GRU_MAXP];
+    const float* bhh[SREC_GRU_MAXP];
+    float* H[SREC_GRU_MAXP];
+    void* H16[SREC_GRU_MAXP];
+    float* gates[SREC_GRU_MAXP];
+    float* out[SREC_GRU_MAXP];
+} srec_gru_fused_desc;
+
 #endif

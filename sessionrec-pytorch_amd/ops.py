@@ -8,6 +8,7 @@ launched through libsrec_hip.so.  CPU tensors raise (no fallback).
 extent of a capacity-padded dimension (see batch.FlatBatch.dyn).
 """
 import ctypes as _ct
+import os
 
 import torch
 
@@ -1246,6 +1247,26 @@ class GruStepDesc(_ct.Structure):
                 [('part_row0', _ct.c_int * 4)])
 
 
+class GruFusedDesc(_ct.Structure):
+    """host mirror of srec_gru_fused_desc (include/srec_hg.h)"""
+    _fields_ = ([('np', _ct.c_int), ('d', _ct.c_int), ('n', _ct.c_int * 4), ('k', _ct.c_int * 4), ('dyn', _ct.c_void_p * 4)] +
+                [(nm, _ct.c_void_p * 4) for nm in ('X', 'X16', 'Wih_f', 'Whh_f', 'bih', 'bhh', 'H', 'H16', 'gates', 'out')])
+
+
+def gru_wfrag(ws):
+    """fragment-major bf16 copies of GRU weights [3 d, d] (the B operands of the fused forward, csrc/gruf.hip), one launch"""
+    n, d = len(ws), ws[0].shape[1]
+    outs = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
+    arr = _ct.c_void_p * n
+    a_w, a_o = arr(*[w.data_ptr() for w in ws]), arr(*[o.data_ptr() for o in outs])
+    lib.srec_gru_wfrag(n, _ct.addressof(a_w), _ct.addressof(a_o), d, stream())
+    return outs
+
+
+def gru_fused_ok(d, P):
+    return d in (128, 256) and P <= 4 and not os.environ.get('SREC_UNFUSED_GRU')
+
+
 def gru_expand_fast_ok(d, reducer):
     return PRECISION['matmul'] == 'bf16' and reducer == 'mean' and d % 64 == 0 and d <= 1024 and 256 % (d // 4) == 0
 
@@ -1257,18 +1278,9 @@ class GRUExpandAll(torch.autograd.Function):
     gradients come from per-block partial sums of the gate kernels, the weight gradients from row-split products."""
 
     @staticmethod
-    def forward(ctx, ks, dyn_ns, dyn_rows, *args):
-        P = len(ks)
-        ctx.tags = [_arena_tag(a) for a in args[:P]]        # pieces of a split tensor: their gradients go into its buffer
-        xs = [a.contiguous() for a in args[:P]]
-        params = args[P:]
-        Wih, bih, Whh, bhh = ([params[4 * p + j].contiguous() for p in range(P)] for j in range(4))
-        d = xs[0].shape[1]
-        d3, dev, st = 3 * d, xs[0].device, stream()
-        ns = [x.shape[0] // k for x, k in zip(xs, ks)]
-        w16, wt16 = weights_bf16([w for p in range(P) for w in (Wih[p], Whh[p])])
-        Wih16, Whh16 = w16[0::2], w16[1::2]
-        # bf16 copy of the gathered rows: one pass when the orders' rows are adjacent pieces of one buffer
+    def _rows16(xs, d, dev, st):
+        """bf16 copy of the gathered rows: one pass when the orders' rows are adjacent pieces of one buffer"""
+        P = len(xs)
         esz = xs[0].element_size()
         adjacent = all(xs[p + 1].data_ptr() == xs[p].data_ptr() + xs[p].numel() * esz for p in range(P - 1))
         tot = sum(x.shape[0] for x in xs)
@@ -1283,14 +1295,48 @@ class GRUExpandAll(torch.autograd.Function):
             for x, o in zip(xs, offs):
                 lib.srec_rows_bf16(ptr(x), d, x.shape[0], None, d, x16all[o:].data_ptr(), st)
         x16 = [x16all[o:o + x.shape[0]] for x, o in zip(xs, offs)]
-        GI = [torch.empty(x.shape[0], d3, device=dev, dtype=torch.float32) for x in xs]
-        gemm16('nt', [(xs[p].shape[0], d3, d, [(x16[p], Wih16[p])], GI[p], dyn_rows[p]) for p in range(P)], d, d, d3,
-               keep_dead=True)
+        return x16all, x16
+
+    @staticmethod
+    def forward(ctx, ks, dyn_ns, dyn_rows, *args):
+        P = len(ks)
+        ctx.tags = [_arena_tag(a) for a in args[:P]]        # pieces of a split tensor: their gradients go into its buffer
+        xs = [a.contiguous() for a in args[:P]]
+        params = args[P:]
+        Wih, bih, Whh, bhh = ([params[4 * p + j].contiguous() for p in range(P)] for j in range(4))
+        d = xs[0].shape[1]
+        d3, dev, st = 3 * d, xs[0].device, stream()
+        ns = [x.shape[0] // k for x, k in zip(xs, ks)]
+        w16, wt16 = weights_bf16([w for p in range(P) for w in (Wih[p], Whh[p])])
+        Wih16, Whh16 = w16[0::2], w16[1::2]
         H = [torch.empty(ks[p], ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
         H16 = [torch.empty(max(ks[p] - 1, 1), ns[p], d, device=dev, dtype=torch.bfloat16) for p in range(P)]
         gates = [torch.empty(ks[p], ns[p], 4 * d, device=dev, dtype=torch.float32) for p in range(P)]
-        GH = [torch.empty(ns[p], d3, device=dev, dtype=torch.float32) for p in range(P)]
         outs = [torch.empty(ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
+        if gru_fused_ok(d, P):
+            # the whole recurrence in one launch (csrc/gruf.hip): a workgroup owns 32 nodes, the weights stream from L2
+            wf = gru_wfrag([w for p in range(P) for w in (Wih[p], Whh[p])])
+            x16all = torch.empty(sum(x.shape[0] for x in xs), d, device=dev, dtype=torch.bfloat16)
+            x16, o = [], 0
+            for x in xs:
+                x16.append(x16all[o:o + x.shape[0]])
+                o += x.shape[0]
+            q = GruFusedDesc()
+            q.np, q.d = P, d
+            for p in range(P):
+                q.n[p], q.k[p], q.dyn[p] = ns[p], ks[p], ptr(dyn_ns[p])
+                q.X[p], q.X16[p], q.Wih_f[p], q.Whh_f[p] = ptr(xs[p]), ptr(x16[p]), ptr(wf[2 * p]), ptr(wf[2 * p + 1])
+                q.bih[p], q.bhh[p], q.H[p], q.H16[p] = ptr(bih[p]), ptr(bhh[p]), ptr(H[p]), ptr(H16[p])
+                q.gates[p], q.out[p] = ptr(gates[p]), ptr(outs[p])
+            lib.srec_gru_fused_fwd(_ct.addressof(q), st)
+            ctx.save_for_backward(*x16, *H, *H16, *gates, *wt16)
+            ctx.meta = (ks, dyn_ns, dyn_rows, ns, d, [tuple(w.shape) for w in Wih])
+            return tuple(outs)
+        x16all, x16 = GRUExpandAll._rows16(xs, d, dev, st)
+        GI = [torch.empty(x.shape[0], d3, device=dev, dtype=torch.float32) for x in xs]
+        gemm16('nt', [(xs[p].shape[0], d3, d, [(x16[p], Wih16[p])], GI[p], dyn_rows[p]) for p in range(P)], d, d, d3,
+               keep_dead=True)
+        GH = [torch.empty(ns[p], d3, device=dev, dtype=torch.float32) for p in range(P)]
         for t in range(max(ks)):
             act = [p for p in range(P) if t < ks[p]]
             if t > 0:

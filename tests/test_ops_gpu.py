@@ -918,6 +918,58 @@ def test_gru_expand_all_matches_per_order_fp32_path(dev, d, padded):
             assert rel(a, b) < 2e-2, (p, nm, rel(a, b))
 
 
+@pytest.mark.parametrize('d,padded', [(256, True), (128, True), (256, False)])
+def test_gru_fused_forward_equals_the_step_path(dev, d, padded, monkeypatch):
+    """csrc/gruf.hip (whole recurrence in one launch: a workgroup owns 32 nodes, weights streamed fragment-major) against
+    the step-by-step bf16 path (grux.hip + gemm16.hip) it replaces: same operands, same rounding points, only the order of
+    the fp32 partial sums differs - outputs, saved state (through the shared backward: every gradient) at 1e-4."""
+    ops = _ops()
+    torch.manual_seed(d + 7)
+    ks, caps, lives = [2, 3], [333, 290], [333, 290]          # not multiples of the 32-node tile
+    if padded:
+        caps, lives = [512, 480], [401, 37]
+    grus = [torch.nn.GRU(d, d, 1, True, True).to(dev) for _ in ks]
+    for g in grus:
+        for w in g.parameters():
+            w.data.uniform_(-1 / d ** 0.5, 1 / d ** 0.5)
+    G = sum(c * k for c, k in zip(caps, ks))
+    rows = torch.randn(G, d, device=dev) * 0.5
+    offs = [0, caps[0] * ks[0]]
+    dyn_n = [torch.tensor([l], device=dev, dtype=torch.int32) if padded else None for l in lives]
+    dyn_r = [torch.tensor([l * k], device=dev, dtype=torch.int32) if padded else None for l, k in zip(lives, ks)]
+    gout = [torch.randn(c, d, device=dev) for c in caps]
+
+    def run():
+        r = rows.clone().requires_grad_()
+        xs = [r[o:o + c * k] for o, c, k in zip(offs, caps, ks)]
+        for g in grus:
+            g.zero_grad()
+        outs = ops.gru_expand_all(xs, grus, ks, dyn_n, dyn_r)
+        torch.autograd.backward(list(outs), gout)
+        return [o.detach().clone() for o in outs], r.grad.clone(), [[p.grad.clone() for p in g.parameters()] for g in grus]
+
+    ops.set_precision('bf16')
+    try:
+        monkeypatch.setenv('SREC_UNFUSED_GRU', '1')
+        assert not ops.gru_fused_ok(d, 2)
+        ref = run()
+        monkeypatch.delenv('SREC_UNFUSED_GRU')
+        assert ops.gru_fused_ok(d, 2)
+        got = run()
+    finally:
+        ops.set_precision('fp32')
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
+    for p in range(2):
+        assert rel(got[0][p], ref[0][p]) < 1e-4, ('out', p, rel(got[0][p], ref[0][p]))
+        assert (got[0][p] - ref[0][p]).abs().max().item() < 1e-4
+        if padded:
+            assert got[0][p][lives[p]:].abs().max().item() == 0.0
+    assert rel(got[1], ref[1]) < 1e-3, ('dx', rel(got[1], ref[1]))
+    for p in range(2):
+        for a, b, nm in zip(got[2][p], ref[2][p], ('Wih', 'Whh', 'bih', 'bhh')):
+            assert rel(a, b) < 1e-3, (p, nm, rel(a, b))
+
+
 def test_lookup_with_fused_dropout(dev):
     """feature dropout fused into the embedding gather and its backward (msgifsr.py:247): the output is table[idx] times a
     0 / (1 / (1 - p)) mask with keep-rate 1 - p, the backward applies the SAME mask (recomputed from the counter-based
