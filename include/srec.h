@@ -344,6 +344,10 @@ int srec_gru_step_bwd(const void* desc, void* stream);
  * device pointers), the B operands the fused forward streams */
 int srec_gru_fused_fwd(const void* desc, void* stream);
 int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void* stream);
+/* backward of all time steps in one launch (csrc/grufb.hip): desc = HOST srec_gru_fused_bwd_desc; srec_gru_wfrag_t: the
+ * fragment-major weight copies for its backward-data products (B operand = W [3 d, d] itself, reduction over its rows) */
+int srec_gru_fused_bwd(const void* desc, void* stream);
+int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, void* stream);
 /* out[p] [ncol] = column sums of part[p] [rows[p], ncol] for np <= 4 problems in one launch (the GRU bias gradients from the
  * per-block partial rows of srec_gru_step_bwd); part / out: HOST arrays of np device pointers, rows: HOST int array */
 int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);

@@ -176,4 +176,26 @@ typedef struct {
     float* out[SREC_GRU_MAXP];
 } srec_gru_fused_desc;
 
+/* the whole k-gram GRU backward except the weight gradients, in one launch: srec_gru_fused_bwd (srec.h, csrc/grufb.hip), d = 128
+ * or 256; problems as srec_gru_fused_desc.  Reads the saved gates [k, n, 4 d] and H [k, n, d], dout [n, d] (gradient of the
+ * expander output) and the fragment-major weights of srec_gru_wfrag_t; writes dGI16 [n k, 3 d] (row node k + t) and dGH16
+ * [k - 1, n, 3 d] (slot t - 1), bf16 operands of the weight-gradient GEMMs, dX [n k, d] = 0.5 dout / k + d(gi) W_ih, and one
+ * row [6 d] = column sums (d gi | d gh) per 32-node workgroup into bias_part at row part_row0 + workgroup.  Rows past the live
+ * prefix: zeros. */
+typedef struct {
+    int np, d;
+    int n[SREC_GRU_MAXP], k[SREC_GRU_MAXP];
+    const int* dyn[SREC_GRU_MAXP];
+    const float* gates[SREC_GRU_MAXP];
+    const float* H[SREC_GRU_MAXP];
+    const float* dout[SREC_GRU_MAXP];
+    const void* Wih_f[SREC_GRU_MAXP];
+    const void* Whh_f[SREC_GRU_MAXP];
+    void* dGI16[SREC_GRU_MAXP];
+    void* dGH16[SREC_GRU_MAXP];
+    float* dX[SREC_GRU_MAXP];
+    float* bias_part[SREC_GRU_MAXP];
+    int part_row0[SREC_GRU_MAXP];
+} srec_gru_fused_bwd_desc;
+
 #endif

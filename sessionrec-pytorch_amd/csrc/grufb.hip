@@ -1,0 +1,336 @@
+// k-gram GRU of MSGIFSR's SemanticExpander (msgifsr.py:25,32-45): backward of ALL time steps and orders in ONE launch (bf16
+// path, d = 128 or 256) - the counterpart of gruf.hip.  What stays outside: the weight gradients (row reductions over all
+// nodes: gemm16_tn on the bf16 d(gi) / d(gh) this kernel writes) and the final bias-gradient reduction.
+//
+// The step-by-step backward (grux.hip) is 3 gate kernels + 2 hidden-state GEMMs + the d x GEMM, ~100 us of latency-bound
+// launches.  Per node the chain d h_t -> d(gi_t), d(gh_t) -> d h_{t-1} = d h_t z + d(gh_t) W_hh, d x_t = d(gi_t) W_ih is
+// independent, so a workgroup OWNS 32 nodes and walks t = k - 1 .. 0:
+//   E  gate derivatives, one thread per (node, 4 columns), 16-byte coalesced reads of the saved gates / h_{t-1}; d h_t comes
+//      from LDS (fp32 [32, d]; 0.5 d out at the last step).  Results: the bf16 A operands of the two products in LDS
+//      (d(gi) and d(gh) share their r / z parts: tiles RZ [32, 2 d], N_i [32, d], N_h [32, d], 16-B pieces XOR-swizzled by
+//      row & 15), the same values as rows of dGI16 / dGH16 in HBM (operands of the weight-gradient GEMM), the direct term
+//      d h_t z into the LDS d h tile, and running column sums (bias gradients);
+//   G  wave w owns the output columns [w d/4, (w + 1) d/4) of BOTH products (2 JB blocks each): 3 d / 16 k-steps, the B
+//      fragments (W_ih, W_hh in fragment-major order for this product, srec_gru_wfrag mode 1) streamed from L2 through a
+//      register ring exactly as in the forward;
+//   S  d x_t = 0.5 d out / k + d(gi_t) W_ih leaves through a per-wave LDS patch as 16-byte row stores; d(gh_t) W_hh is added
+//      onto the direct term in the LDS d h tile (ds_add_f32) for the next step.
+// Bias gradients: per-thread column sums over its rows and all steps, reduced over the row groups through LDS, one row
+// [6 d] (d b_ih | d b_hh) per workgroup into bias_part (summed by srec_gru_bias_final).
+#include "common.h"
+#include "../../include/srec_hg.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int GB_MAXP = SREC_GRU_MAXP;
+constexpr int RT = 32;             // nodes per workgroup
+constexpr int NS = 4, PF = NS - 1; // register ring: stages, k-steps of B fragments in flight
+
+struct BwdArgs {
+    srec_gru_fused_bwd_desc d;
+    int start[GB_MAXP + 1];
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int JB>
+__global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
+    constexpr int D = 128 * JB, KS = D / 16, TPR = D / 4, RPP = 256 / TPR, NP = RT / RPP;
+    constexpr int PS = 32 * JB + 8;              // patch row stride (floats): rows r, r + 4 land in opposite bank halves
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
+    unsigned short* rz = sm;                     // [RT][2 D] bf16, swizzled
+    unsigned short* ni = sm + RT * 2 * D;        // [RT][D]
+    unsigned short* nh = ni + RT * D;            // [RT][D]
+    float* dht = reinterpret_cast<float*>(nh + RT * D);         // [RT][D] fp32: d h_t
+    float* patches = dht + RT * D;               // [4 waves][RT][PS]
+    const srec_gru_fused_bwd_desc& q = a.d;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < GB_MAXP; ++i)
+        if (i < q.np && (int)blockIdx.x >= a.start[i]) p = i;
+    const int n = q.n[p], k = q.k[p];
+    const int tile = (int)blockIdx.x - a.start[p];
+    const int node0 = tile * RT;
+    if (node0 >= n) return;
+    const int nl = dyn_count(q.dyn[p], n);
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* gates = q.gates[p];
+    const float* H = q.H[p];
+    const float* dout = q.dout[p];
+    unsigned short* dGI16 = (unsigned short*)q.dGI16[p];
+    unsigned short* dGH16 = (unsigned short*)q.dGH16[p];
+    float* dX = q.dX[p];
+    float* part = q.bias_part[p] + (size_t)(q.part_row0[p] + tile) * 6 * D;
+    const int erow = tid / TPR, ec = (tid % TPR) * 4;           // phase E: this thread's row (per pass) and 4 columns
+
+    if (node0 >= nl) {                           // capacity padding: zero operands and gradients, no arithmetic
+        const int rows = min(RT, n - node0);
+        for (int i = tid; i < rows * TPR; i += 256) {
+            const int row = i / TPR, c = (i % TPR) * 4;
+            const size_t node = (size_t)(node0 + row);
+            for (int t = 0; t < k; ++t) {
+                for (int g = 0; g < 3; ++g) {
+                    *reinterpret_cast<uint2*>(dGI16 + (node * k + t) * 3 * D + g * D + c) = make_uint2(0u, 0u);
+                    if (t > 0) *reinterpret_cast<uint2*>(dGH16 + ((size_t)(t - 1) * n + node) * 3 * D + g * D + c) = make_uint2(0u, 0u);
+                }
+                *reinterpret_cast<float4*>(dX + (node * k + t) * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int i = tid; i < 6 * D; i += 256) part[i] = 0.f;
+        return;
+    }
+
+    float* patch = patches + wave * RT * PS;
+    const int cbase = wave * 32 * JB;
+    const unsigned short* wf_ih = (const unsigned short*)q.Wih_f[p] + (size_t)wave * 3 * KS * JB * 512;
+    const unsigned short* wf_hh = (const unsigned short*)q.Whh_f[p] + (size_t)wave * 3 * KS * JB * 512;
+    const bool full = node0 + RT <= nl;
+    const float ik = 0.5f / (float)k;
+    float si[12], shn[4];                        // column sums: d(gi) r, z, n and the n part of d(gh), this thread's 4 columns
+#pragma unroll
+    for (int e = 0; e < 12; ++e) si[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) shn[e] = 0.f;
+
+    for (int t = k - 1; t >= 0; --t) {
+        // (re-derived behind an opaque asm every step: keeps the per-element addresses from being hoisted and spilled)
+        int tid_v = tid;
+        asm volatile("" : "+v"(tid_v));
+        const int er = tid_v / TPR, c = (tid_v % TPR) * 4;
+        const bool has_h = t > 0;
+        // ---- E: gate derivatives
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = i * RPP + er;
+            const int node = node0 + row;
+            float4 dpr = make_float4(0.f, 0.f, 0.f, 0.f), dpz = dpr, dpn = dpr, dgn = dpr, dhz = dpr;
+            if (full || node < nl) {
+                const float* g = gates + ((size_t)t * n + node) * 4 * D + c;
+                const float4 r = ld4(g), z = ld4(g + D), nn = ld4(g + 2 * D), hn = ld4(g + 3 * D);
+                float4 hp = make_float4(0.f, 0.f, 0.f, 0.f), dh;
+                if (has_h) hp = ld4(H + ((size_t)(t - 1) * n + node) * D + c);
+                if (t == k - 1) {
+                    const float4 go = ld4(dout + (size_t)node * D + c);
+                    dh = make_float4(0.5f * go.x, 0.5f * go.y, 0.5f * go.z, 0.5f * go.w);
+                } else {
+                    dh = *reinterpret_cast<const float4*>(dht + row * D + c);
+                }
+#define GB_LANE(e)                                                                 \
+    {                                                                              \
+        const float dn = dh.e * (1.f - z.e), dz = dh.e * (hp.e - nn.e);            \
+        dpn.e = dn * (1.f - nn.e * nn.e);                                          \
+        dpr.e = dpn.e * hn.e * r.e * (1.f - r.e);                                  \
+        dpz.e = dz * z.e * (1.f - z.e);                                            \
+        dgn.e = dpn.e * r.e;                                                       \
+        dhz.e = dh.e * z.e;                                                        \
+    }
+                GB_LANE(x) GB_LANE(y) GB_LANE(z) GB_LANE(w)
+#undef GB_LANE
+            }
+            const uint2 br = make_uint2(srec_pack_bf16(dpr.x, dpr.y), srec_pack_bf16(dpr.z, dpr.w));
+            const uint2 bz = make_uint2(srec_pack_bf16(dpz.x, dpz.y), srec_pack_bf16(dpz.z, dpz.w));
+            const uint2 bn = make_uint2(srec_pack_bf16(dpn.x, dpn.y), srec_pack_bf16(dpn.z, dpn.w));
+            const uint2 bg = make_uint2(srec_pack_bf16(dgn.x, dgn.y), srec_pack_bf16(dgn.z, dgn.w));
+            const int sw = row & 15, pc = c >> 3, ho = c & 4;
+            *reinterpret_cast<uint2*>(rz + row * 2 * D + ((pc ^ sw) * 8) + ho) = br;
+            *reinterpret_cast<uint2*>(rz + row * 2 * D + (((D / 8 + pc) ^ sw) * 8) + ho) = bz;
+            *reinterpret_cast<uint2*>(ni + row * D + ((pc ^ sw) * 8) + ho) = bn;
+            if (has_h) {
+                *reinterpret_cast<uint2*>(nh + row * D + ((pc ^ sw) * 8) + ho) = bg;
+                *reinterpret_cast<float4*>(dht + row * D + c) = dhz;
+            }
+            if (full || node < n) {
+                unsigned short* gi = dGI16 + ((size_t)node * k + t) * 3 * D + c;
+                *reinterpret_cast<uint2*>(gi) = br;
+                *reinterpret_cast<uint2*>(gi + D) = bz;
+                *reinterpret_cast<uint2*>(gi + 2 * D) = bn;
+                if (has_h) {
+                    unsigned short* gh = dGH16 + ((size_t)(t - 1) * n + node) * 3 * D + c;
+                    *reinterpret_cast<uint2*>(gh) = br;
+                    *reinterpret_cast<uint2*>(gh + D) = bz;
+                    *reinterpret_cast<uint2*>(gh + 2 * D) = bg;
+                }
+            }
+            si[0] += dpr.x; si[1] += dpr.y; si[2] += dpr.z; si[3] += dpr.w;
+            si[4] += dpz.x; si[5] += dpz.y; si[6] += dpz.z; si[7] += dpz.w;
+            si[8] += dpn.x; si[9] += dpn.y; si[10] += dpn.z; si[11] += dpn.w;
+            shn[0] += dgn.x; shn[1] += dgn.y; shn[2] += dgn.z; shn[3] += dgn.w;
+        }
+        __syncthreads();                         // A tiles and the direct term of d h_{t-1} published
+
+        // ---- G: d x_t = d(gi_t) W_ih, d h_{t-1} += d(gh_t) W_hh; this wave's 32 JB output columns of both
+        f32x16 ax[JB], ah[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ax[j][r] = ah[j][r] = 0.f;
+        auto products = [&](auto HH) {
+            constexpr bool HAS_H = decltype(HH)::value;
+            constexpr int NF = HAS_H ? 2 * JB : JB;
+            constexpr int T = 3 * KS;
+            bf16x8 Bq[NS][NF];
+            auto load = [&](int i, int slot) {
+                i = min(i, T - 1);
+                const unsigned short* s0 = wf_ih + (size_t)i * JB * 512 + lane * 8;
+                const unsigned short* s1 = wf_hh + (size_t)i * JB * 512 + lane * 8;
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    Bq[slot][j] = *reinterpret_cast<const bf16x8*>(s0 + j * 512);
+                    if (HAS_H) Bq[slot][JB + j] = *reinterpret_cast<const bf16x8*>(s1 + j * 512);
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < PF; ++i) load(i, i);
+#pragma unroll 1
+            for (int ib = 0; ib < T; ib += NS) {
+                const bool npart = ib >= 2 * KS; // k-steps 0 .. 2 KS - 1: the shared r / z part; then the n parts
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    load(ib + u + PF, (u + PF) % NS);
+                    const int s = ib + u;
+                    bf16x8 Ai, Ah;
+                    if (!npart) {
+                        Ai = *reinterpret_cast<const bf16x8*>(rz + l31 * 2 * D + (((2 * s + half) ^ (l31 & 15)) * 8));
+                        Ah = Ai;
+                    } else {
+                        const int s2 = s - 2 * KS;
+                        Ai = *reinterpret_cast<const bf16x8*>(ni + l31 * D + (((2 * s2 + half) ^ (l31 & 15)) * 8));
+                        if (HAS_H) Ah = *reinterpret_cast<const bf16x8*>(nh + l31 * D + (((2 * s2 + half) ^ (l31 & 15)) * 8));
+                    }
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) {
+                        ax[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ai, Bq[u][j], ax[j], 0, 0, 0);
+                        if (HAS_H) ah[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bq[u][JB + j], ah[j], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        if (has_h) products(std::true_type{});
+        else products(std::false_type{});
+
+        // ---- S: d x_t rows out through the wave's patch (16-byte stores); d(gh_t) W_hh onto the direct term in LDS
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        const int l31v = lane_v & 31, halfv = lane_v >> 5;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
+                patch[row * PS + 32 * j + l31v] = ax[j][r];
+                if (has_h) atomicAdd(dht + row * D + cbase + 32 * j + l31v, ah[j][r]);
+            }
+        constexpr int QPR = 8 * JB;              // float4 per patch row
+#pragma unroll
+        for (int i = 0; i < RT * QPR / 64; ++i) {
+            const int idx = i * 64 + lane_v;
+            const int row = idx / QPR, c4 = (idx % QPR) * 4;
+            const int node = node0 + row;
+            if (full || node < n) {
+                float4 v = *reinterpret_cast<const float4*>(patch + row * PS + c4);
+                if (full || node < nl) {
+                    const float4 go = ld4(dout + (size_t)node * D + cbase + c4);
+                    v.x += ik * go.x; v.y += ik * go.y; v.z += ik * go.z; v.w += ik * go.w;
+                } else {
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *reinterpret_cast<float4*>(dX + ((size_t)node * k + t) * D + cbase + c4) = v;
+            }
+        }
+        __syncthreads();                         // A tiles free again; d h_{t-1} complete
+    }
+
+    // ---- bias gradients: column sums over the row groups
+    float* red = reinterpret_cast<float*>(sm);   // [RPP][16][TPR] floats (<= 16 KiB), the A tiles are dead
+#pragma unroll
+    for (int e = 0; e < 12; ++e) red[(erow * 16 + e) * TPR + tid % TPR] = si[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(erow * 16 + 12 + e) * TPR + tid % TPR] = shn[e];
+    __syncthreads();
+    for (int o = tid; o < 6 * D; o += 256) {
+        // o = half * 3 D + gate * D + col; d(gh) shares its r / z sums with d(gi)
+        const int hh = o / (3 * D), gate = (o % (3 * D)) / D, col = o % D;
+        const int e = (hh == 1 && gate == 2 ? 12 : 4 * gate) + (col & 3);
+        float s = 0.f;
+#pragma unroll
+        for (int rg = 0; rg < RPP; ++rg) s += red[(rg * 16 + e) * TPR + (col >> 2)];
+        part[o] = s;
+    }
+    (void)ec;
+}
+
+struct WfbArgs {
+    int d, jb;
+    const float* W[2 * GB_MAXP];
+    unsigned short* dst[2 * GB_MAXP];
+};
+
+// fragment-major bf16 copy of a GRU weight W [3 d, d] for the backward-data products d(g) W: fragment ((w 3 KS + s) JB + j)
+// = the MFMA B operand of wave w, k-step s, output column block j: lane l <- W[16 s + 8 (l >> 5) .. + 7][w d/4 + 32 j + (l & 31)]
+__global__ __launch_bounds__(256) void gru_wfrag_t_kernel(WfbArgs a) {
+    const int d = a.d, JB = a.jb, KS3 = 3 * d / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * d * d / 8) return;
+    const int lane = idx & 63, frag = idx >> 6;
+    const int j = frag % JB, ws = frag / JB, s = ws % KS3, w = ws / KS3;
+    const int col = w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
+    const float* src = a.W[blockIdx.y] + (size_t)kk * d + col;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * d];
+    uint4 o;
+    o.x = srec_pack_bf16(v[0], v[1]); o.y = srec_pack_bf16(v[2], v[3]);
+    o.z = srec_pack_bf16(v[4], v[5]); o.w = srec_pack_bf16(v[6], v[7]);
+    *reinterpret_cast<uint4*>(a.dst[blockIdx.y] + (size_t)idx * 8) = o;
+}
+
+}  // namespace
+
+// as srec_gru_wfrag, for the backward-data products of srec_gru_fused_bwd (B operand = W itself, k = its rows)
+extern "C" int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, void* stream) {
+    if (n <= 0) return 0;
+    if (n > 2 * GB_MAXP || W == nullptr || dst == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
+    WfbArgs a{};
+    a.d = d; a.jb = d / 128;
+    for (int i = 0; i < n; ++i) {
+        a.W[i] = ((const float* const*)W)[i]; a.dst[i] = ((unsigned short* const*)dst)[i];
+        if (a.W[i] == nullptr || a.dst[i] == nullptr) return SREC_BAD_ARG;
+    }
+    hipLaunchKernelGGL(gru_wfrag_t_kernel, dim3((3 * d * d / 8 + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// desc: HOST srec_gru_fused_bwd_desc (srec_hg.h)
+extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
+    const srec_gru_fused_bwd_desc* q = (const srec_gru_fused_bwd_desc*)desc;
+    if (q == nullptr || q->np <= 0 || q->np > GB_MAXP || (q->d != 128 && q->d != 256)) return SREC_BAD_ARG;
+    BwdArgs a{};
+    a.d = *q;
+    int blocks = 0;
+    for (int p = 0; p < q->np; ++p) {
+        if (q->n[p] < 0 || q->k[p] < 1 || q->gates[p] == nullptr || q->H[p] == nullptr || q->dout[p] == nullptr ||
+            q->Wih_f[p] == nullptr || q->Whh_f[p] == nullptr || q->dGI16[p] == nullptr || q->dGH16[p] == nullptr ||
+            q->dX[p] == nullptr || q->bias_part[p] == nullptr)
+            return SREC_BAD_ARG;
+        a.start[p] = blocks;
+        blocks += (q->n[p] + RT - 1) / RT;
+    }
+    for (int p = q->np; p <= GB_MAXP; ++p) a.start[p] = blocks;
+    if (blocks == 0) return 0;
+    const int JB = q->d / 128, D = q->d;
+    const size_t lds = (size_t)RT * 4 * D * 2 + (size_t)RT * D * 4 + (size_t)4 * RT * (32 * JB + 8) * 4;
+    static std::atomic<unsigned long long> om[2];
+    if (JB == 2) {
+        if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<2>, (int)lds, om[1])) return rc;
+        hipLaunchKernelGGL(gru_fused_bwd_kernel<2>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<1>, (int)lds, om[0])) return rc;
+        hipLaunchKernelGGL(gru_fused_bwd_kernel<1>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+    }
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

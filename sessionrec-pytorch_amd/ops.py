@@ -1253,6 +1253,23 @@ class GruFusedDesc(_ct.Structure):
                 [(nm, _ct.c_void_p * 4) for nm in ('X', 'X16', 'Wih_f', 'Whh_f', 'bih', 'bhh', 'H', 'H16', 'gates', 'out')])
 
 
+class GruFusedBwdDesc(_ct.Structure):
+    """host mirror of srec_gru_fused_bwd_desc (include/srec_hg.h)"""
+    _fields_ = ([('np', _ct.c_int), ('d', _ct.c_int), ('n', _ct.c_int * 4), ('k', _ct.c_int * 4), ('dyn', _ct.c_void_p * 4)] +
+                [(nm, _ct.c_void_p * 4) for nm in ('gates', 'H', 'dout', 'Wih_f', 'Whh_f', 'dGI16', 'dGH16', 'dX', 'bias_part')] +
+                [('part_row0', _ct.c_int * 4)])
+
+
+def gru_wfrag_t(ws):
+    """fragment-major bf16 copies of GRU weights [3 d, d] for the backward-data products (csrc/grufb.hip), one launch"""
+    n, d = len(ws), ws[0].shape[1]
+    outs = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
+    arr = _ct.c_void_p * n
+    a_w, a_o = arr(*[w.data_ptr() for w in ws]), arr(*[o.data_ptr() for o in outs])
+    lib.srec_gru_wfrag_t(n, _ct.addressof(a_w), _ct.addressof(a_o), d, stream())
+    return outs
+
+
 def gru_wfrag(ws):
     """fragment-major bf16 copies of GRU weights [3 d, d] (the B operands of the fused forward, csrc/gruf.hip), one launch"""
     n, d = len(ws), ws[0].shape[1]
@@ -1307,15 +1324,18 @@ class GRUExpandAll(torch.autograd.Function):
         d = xs[0].shape[1]
         d3, dev, st = 3 * d, xs[0].device, stream()
         ns = [x.shape[0] // k for x, k in zip(xs, ks)]
-        w16, wt16 = weights_bf16([w for p in range(P) for w in (Wih[p], Whh[p])])
-        Wih16, Whh16 = w16[0::2], w16[1::2]
+        ctx.fused = gru_fused_ok(d, P)
+        if not ctx.fused:
+            w16, wt16 = weights_bf16([w for p in range(P) for w in (Wih[p], Whh[p])])
+            Wih16, Whh16 = w16[0::2], w16[1::2]
         H = [torch.empty(ks[p], ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
         H16 = [torch.empty(max(ks[p] - 1, 1), ns[p], d, device=dev, dtype=torch.bfloat16) for p in range(P)]
         gates = [torch.empty(ks[p], ns[p], 4 * d, device=dev, dtype=torch.float32) for p in range(P)]
         outs = [torch.empty(ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
-        if gru_fused_ok(d, P):
+        if ctx.fused:
             # the whole recurrence in one launch (csrc/gruf.hip): a workgroup owns 32 nodes, the weights stream from L2
             wf = gru_wfrag([w for p in range(P) for w in (Wih[p], Whh[p])])
+            wft = gru_wfrag_t([w for p in range(P) for w in (Wih[p], Whh[p])])       # for the backward (csrc/grufb.hip)
             x16all = torch.empty(sum(x.shape[0] for x in xs), d, device=dev, dtype=torch.bfloat16)
             x16, o = [], 0
             for x in xs:
@@ -1329,7 +1349,7 @@ class GRUExpandAll(torch.autograd.Function):
                 q.bih[p], q.bhh[p], q.H[p], q.H16[p] = ptr(bih[p]), ptr(bhh[p]), ptr(H[p]), ptr(H16[p])
                 q.gates[p], q.out[p] = ptr(gates[p]), ptr(outs[p])
             lib.srec_gru_fused_fwd(_ct.addressof(q), st)
-            ctx.save_for_backward(*x16, *H, *H16, *gates, *wt16)
+            ctx.save_for_backward(*x16, *H, *H16, *gates, *wft)
             ctx.meta = (ks, dyn_ns, dyn_rows, ns, d, [tuple(w.shape) for w in Wih])
             return tuple(outs)
         x16all, x16 = GRUExpandAll._rows16(xs, d, dev, st)
@@ -1381,6 +1401,18 @@ class GRUExpandAll(torch.autograd.Function):
             dX = [dXall[o:o + r] for o, r in zip(offs, rows)]
         dGI16 = [torch.empty(rows[p], d3, device=dev, dtype=torch.bfloat16) for p in range(P)]
         dGH16 = [torch.empty(max(ks[p] - 1, 1), ns[p], d3, device=dev, dtype=torch.bfloat16) for p in range(P)]   # slot t - 1
+        if ctx.fused:
+            # every time step of every order in one launch (csrc/grufb.hip); wt16 = the fragment-major weights here
+            part = [torch.empty((ns[p] + 31) // 32, 6 * d, device=dev, dtype=torch.float32) for p in range(P)]
+            q = GruFusedBwdDesc()
+            q.np, q.d = P, d
+            for p in range(P):
+                q.n[p], q.k[p], q.dyn[p] = ns[p], ks[p], ptr(dyn_ns[p])
+                q.gates[p], q.H[p], q.dout[p] = ptr(gates[p]), ptr(H[p]), ptr(gs[p])
+                q.Wih_f[p], q.Whh_f[p] = ptr(wt16[2 * p]), ptr(wt16[2 * p + 1])
+                q.dGI16[p], q.dGH16[p], q.dX[p], q.bias_part[p], q.part_row0[p] = ptr(dGI16[p]), ptr(dGH16[p]), ptr(dX[p]), ptr(part[p]), 0
+            lib.srec_gru_fused_bwd(_ct.addressof(q), st)
+            return GRUExpandAll._weight_grads(ctx, x16, H16, dGI16, dGH16, part, dX)
         rb = max(8, 1024 // d)                           # nodes per block of the step kernel
         nblk = [(ns[p] + rb - 1) // rb for p in range(P)]
         part = [torch.empty(ks[p] * nblk[p], 6 * d, device=dev, dtype=torch.float32) for p in range(P)]
@@ -1412,6 +1444,14 @@ class GRUExpandAll(torch.autograd.Function):
                     dHcur[p] = nxt[p]
         # d x += d(gi) W_ih  (onto the mean term the last-step kernels wrote)
         gemm16('nt', [(rows[p], d, d3, [(dGI16[p], WihT16[p])], dX[p], dyn_rows[p]) for p in range(P)], d3, d3, d, beta=1.0)
+        return GRUExpandAll._weight_grads(ctx, x16, H16, dGI16, dGH16, part, dX)
+
+    @staticmethod
+    def _weight_grads(ctx, x16, H16, dGI16, dGH16, part, dX):
+        ks, dyn_ns, dyn_rows, ns, d, _ = ctx.meta
+        P = len(ks)
+        d3, dev, st = 3 * d, dX[0].device, stream()
+        rows = [ns[p] * ks[p] for p in range(P)]
         # weight gradients: the reduction runs over rows - split in-kernel into ~512-row pieces (hundreds of short workgroups
         # instead of a dozen long ones), each writing its own slab; the slabs are summed in fixed order
         probs, slabs = [], []
