@@ -348,6 +348,8 @@ int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void* stream);
  * fragment-major weight copies for its backward-data products (B operand = W [3 d, d] itself, reduction over its rows) */
 int srec_gru_fused_bwd(const void* desc, void* stream);
 int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, void* stream);
+/* both copies of the same weights in one launch */
+int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream);
 /* out[p] [ncol] = column sums of part[p] [rows[p], ncol] for np <= 4 problems in one launch (the GRU bias gradients from the
  * per-block partial rows of srec_gru_step_bwd); part / out: HOST arrays of np device pointers, rows: HOST int array */
 int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);

@@ -35,6 +35,15 @@ struct BwdArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+#ifdef SREC_GRUF_TIMING   // development probe (tools/gruf_timing.py): phase clocks of wave 0 of one workgroup, workgroup lives
+__device__ unsigned long long g_grub_tim[16];
+__device__ unsigned long long g_grub_blk[1024][2];
+#define GBT(i) do { __builtin_amdgcn_sched_barrier(0); if (tim_on) tim_t[i] += __builtin_readcyclecounter() - tim_c; \
+    tim_c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GBT(i)
+#endif
+
 template <int JB>
 __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     constexpr int D = 128 * JB, KS = D / 16, TPR = D / 4, RPP = 256 / TPR, NP = RT / RPP;
@@ -43,8 +52,9 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     unsigned short* rz = sm;                     // [RT][2 D] bf16, swizzled
     unsigned short* ni = sm + RT * 2 * D;        // [RT][D]
     unsigned short* nh = ni + RT * D;            // [RT][D]
-    float* dht = reinterpret_cast<float*>(nh + RT * D);         // [RT][D] fp32: d h_t
-    float* patches = dht + RT * D;               // [4 waves][RT][PS]
+    float* dht = reinterpret_cast<float*>(nh + RT * D);         // [RT][DS] fp32: d(gh_{t+1}) W_hh, the product part of d h_t
+    constexpr int DS = D + 8;                    // d h tile row stride (floats): rows r, r + 4 in opposite bank halves
+    float* patches = dht + RT * DS;              // [4 waves][RT][PS]
     const srec_gru_fused_bwd_desc& q = a.d;
     int p = 0;
 #pragma unroll
@@ -83,6 +93,11 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
         return;
     }
 
+#ifdef SREC_GRUF_TIMING
+    const bool tim_on = (int)blockIdx.x == a.start[a.d.np - 1] + 1;     // a workgroup of the last (longest) order
+    unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_c = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_grub_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
     float* patch = patches + wave * RT * PS;
     const int cbase = wave * 32 * JB;
     const unsigned short* wf_ih = (const unsigned short*)q.Wih_f[p] + (size_t)wave * 3 * KS * JB * 512;
@@ -95,28 +110,56 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) shn[e] = 0.f;
 
+    // inputs of phase E (saved gates, h_{t-1}): the first half of the rows is fetched one step ahead, behind the d x store of
+    // the step before (all of them would not fit the register file next to the products' operand ring); the
+    // direct term d h_t z stays in this thread's registers (phase E of step t - 1 runs on the same (node, columns))
+    float4 pr[NP], pz[NP], pn[NP], phn[NP], php[NP], dhz[NP];
+    auto fetch = [&](int t, auto LO, auto HI) {
+#pragma unroll
+        for (int i = decltype(LO)::value; i < decltype(HI)::value; ++i) {
+            const int node = node0 + i * RPP + erow;
+            pr[i] = pz[i] = pn[i] = phn[i] = php[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (full || node < nl) {
+                const float* g = gates + ((size_t)t * n + node) * 4 * D + ec;
+                pr[i] = ld4(g); pz[i] = ld4(g + D); pn[i] = ld4(g + 2 * D); phn[i] = ld4(g + 3 * D);
+                if (t > 0) php[i] = ld4(H + ((size_t)(t - 1) * n + node) * D + ec);
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dhz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    using I0 = std::integral_constant<int, 0>;
+    using IH = std::integral_constant<int, NP / 2>;
+    using IN = std::integral_constant<int, NP>;
+    fetch(k - 1, I0{}, IH{});
+    constexpr int QPR = 8 * JB;                  // float4 per patch row
+    constexpr int NQ = RT * QPR / 64;
+
     for (int t = k - 1; t >= 0; --t) {
         // (re-derived behind an opaque asm every step: keeps the per-element addresses from being hoisted and spilled)
         int tid_v = tid;
         asm volatile("" : "+v"(tid_v));
         const int er = tid_v / TPR, c = (tid_v % TPR) * 4;
         const bool has_h = t > 0;
-        // ---- E: gate derivatives
+        unsigned short* dGI16t = dGI16 + (size_t)t * 3 * D;                    // uniform bases + 32-bit element offsets
+        unsigned short* dGH16t = dGH16 + (size_t)(has_h ? t - 1 : 0) * n * 3 * D;
+        float* dXt = dX + (size_t)t * D;
+        // ---- E: gate derivatives (second half of the rows: fetched now, consumed behind the first half)
+        fetch(t, IH{}, IN{});
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = i * RPP + er;
             const int node = node0 + row;
-            float4 dpr = make_float4(0.f, 0.f, 0.f, 0.f), dpz = dpr, dpn = dpr, dgn = dpr, dhz = dpr;
+            float4 dpr = make_float4(0.f, 0.f, 0.f, 0.f), dpz = dpr, dpn = dpr, dgn = dpr;
             if (full || node < nl) {
-                const float* g = gates + ((size_t)t * n + node) * 4 * D + c;
-                const float4 r = ld4(g), z = ld4(g + D), nn = ld4(g + 2 * D), hn = ld4(g + 3 * D);
-                float4 hp = make_float4(0.f, 0.f, 0.f, 0.f), dh;
-                if (has_h) hp = ld4(H + ((size_t)(t - 1) * n + node) * D + c);
+                const float4 r = pr[i], z = pz[i], nn = pn[i], hn = phn[i], hp = php[i];
+                float4 dh;
                 if (t == k - 1) {
                     const float4 go = ld4(dout + (size_t)node * D + c);
                     dh = make_float4(0.5f * go.x, 0.5f * go.y, 0.5f * go.z, 0.5f * go.w);
                 } else {
-                    dh = *reinterpret_cast<const float4*>(dht + row * D + c);
+                    const float4 pd = *reinterpret_cast<const float4*>(dht + row * DS + c);
+                    dh = make_float4(dhz[i].x + pd.x, dhz[i].y + pd.y, dhz[i].z + pd.z, dhz[i].w + pd.w);
                 }
 #define GB_LANE(e)                                                                 \
     {                                                                              \
@@ -125,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
         dpr.e = dpn.e * hn.e * r.e * (1.f - r.e);                                  \
         dpz.e = dz * z.e * (1.f - z.e);                                            \
         dgn.e = dpn.e * r.e;                                                       \
-        dhz.e = dh.e * z.e;                                                        \
+        dhz[i].e = dh.e * z.e;                                                     \
     }
                 GB_LANE(x) GB_LANE(y) GB_LANE(z) GB_LANE(w)
 #undef GB_LANE
@@ -138,20 +181,17 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
             *reinterpret_cast<uint2*>(rz + row * 2 * D + ((pc ^ sw) * 8) + ho) = br;
             *reinterpret_cast<uint2*>(rz + row * 2 * D + (((D / 8 + pc) ^ sw) * 8) + ho) = bz;
             *reinterpret_cast<uint2*>(ni + row * D + ((pc ^ sw) * 8) + ho) = bn;
-            if (has_h) {
-                *reinterpret_cast<uint2*>(nh + row * D + ((pc ^ sw) * 8) + ho) = bg;
-                *reinterpret_cast<float4*>(dht + row * D + c) = dhz;
-            }
+            if (has_h) *reinterpret_cast<uint2*>(nh + row * D + ((pc ^ sw) * 8) + ho) = bg;
             if (full || node < n) {
-                unsigned short* gi = dGI16 + ((size_t)node * k + t) * 3 * D + c;
-                *reinterpret_cast<uint2*>(gi) = br;
-                *reinterpret_cast<uint2*>(gi + D) = bz;
-                *reinterpret_cast<uint2*>(gi + 2 * D) = bn;
+                const unsigned go = (unsigned)node * k * 3 * D + c;
+                *reinterpret_cast<uint2*>(dGI16t + go) = br;
+                *reinterpret_cast<uint2*>(dGI16t + go + D) = bz;
+                *reinterpret_cast<uint2*>(dGI16t + go + 2 * D) = bn;
                 if (has_h) {
-                    unsigned short* gh = dGH16 + ((size_t)(t - 1) * n + node) * 3 * D + c;
-                    *reinterpret_cast<uint2*>(gh) = br;
-                    *reinterpret_cast<uint2*>(gh + D) = bz;
-                    *reinterpret_cast<uint2*>(gh + 2 * D) = bg;
+                    const unsigned ho2 = (unsigned)node * 3 * D + c;
+                    *reinterpret_cast<uint2*>(dGH16t + ho2) = br;
+                    *reinterpret_cast<uint2*>(dGH16t + ho2 + D) = bz;
+                    *reinterpret_cast<uint2*>(dGH16t + ho2 + 2 * D) = bg;
                 }
             }
             si[0] += dpr.x; si[1] += dpr.y; si[2] += dpr.z; si[3] += dpr.w;
@@ -159,9 +199,19 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
             si[8] += dpn.x; si[9] += dpn.y; si[10] += dpn.z; si[11] += dpn.w;
             shn[0] += dgn.x; shn[1] += dgn.y; shn[2] += dgn.z; shn[3] += dgn.w;
         }
+        GBT(0);
         __syncthreads();                         // A tiles and the direct term of d h_{t-1} published
+        GBT(1);
 
         // ---- G: d x_t = d(gi_t) W_ih, d h_{t-1} += d(gh_t) W_hh; this wave's 32 JB output columns of both
+        float4 gmean[NQ];                        // d out of this wave's columns in the d x store layout (mean term 0.5 d out / k):
+#pragma unroll                                   // fetched here, ahead of the next step's gate inputs (loads return in order)
+        for (int i = 0; i < NQ; ++i) {
+            const int idx = i * 64 + (tid_v & 63);
+            const int node = node0 + idx / QPR, c4 = (idx % QPR) * 4;
+            gmean[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (full || node < nl) gmean[i] = ld4(dout + (unsigned)node * D + cbase + c4);
+        }
         f32x16 ax[JB], ah[JB];
 #pragma unroll
         for (int j = 0; j < JB; ++j)
@@ -205,13 +255,20 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
                         ax[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ai, Bq[u][j], ax[j], 0, 0, 0);
                         if (HAS_H) ah[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bq[u][JB + j], ah[j], 0, 0, 0);
                     }
+                    // keep the issue order: next stage's loads, this k-step's A reads, its MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x020, NF, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
                 }
             }
         };
         if (has_h) products(std::true_type{});
         else products(std::false_type{});
 
-        // ---- S: d x_t rows out through the wave's patch (16-byte stores); d(gh_t) W_hh onto the direct term in LDS
+        GBT(2);
+        // ---- S: next step's gate inputs on their way; d x_t rows out through the wave's patch (16-byte stores);
+        //      d(gh_t) W_hh into the LDS d h tile (plain stores: the direct term waits in registers)
+        if (has_h) fetch(t - 1, I0{}, IH{});
         int lane_v = lane;
         asm volatile("" : "+v"(lane_v));
         const int l31v = lane_v & 31, halfv = lane_v >> 5;
@@ -221,26 +278,23 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
                 patch[row * PS + 32 * j + l31v] = ax[j][r];
-                if (has_h) atomicAdd(dht + row * D + cbase + 32 * j + l31v, ah[j][r]);
+                if (has_h) dht[row * DS + cbase + 32 * j + l31v] = ah[j][r];
             }
-        constexpr int QPR = 8 * JB;              // float4 per patch row
 #pragma unroll
-        for (int i = 0; i < RT * QPR / 64; ++i) {
+        for (int i = 0; i < NQ; ++i) {
             const int idx = i * 64 + lane_v;
             const int row = idx / QPR, c4 = (idx % QPR) * 4;
             const int node = node0 + row;
             if (full || node < n) {
                 float4 v = *reinterpret_cast<const float4*>(patch + row * PS + c4);
-                if (full || node < nl) {
-                    const float4 go = ld4(dout + (size_t)node * D + cbase + c4);
-                    v.x += ik * go.x; v.y += ik * go.y; v.z += ik * go.z; v.w += ik * go.w;
-                } else {
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                *reinterpret_cast<float4*>(dX + ((size_t)node * k + t) * D + cbase + c4) = v;
+                if (full || node < nl) { v.x += ik * gmean[i].x; v.y += ik * gmean[i].y; v.z += ik * gmean[i].z; v.w += ik * gmean[i].w; }
+                else v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(dXt + (unsigned)node * k * D + cbase + c4) = v;
             }
         }
+        GBT(3);
         __syncthreads();                         // A tiles free again; d h_{t-1} complete
+        GBT(4);
     }
 
     // ---- bias gradients: column sums over the row groups
@@ -260,6 +314,13 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
         part[o] = s;
     }
     (void)ec;
+#ifdef SREC_GRUF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GBT(5);
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_grub_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    if (tim_on && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_grub_tim[i] = tim_t[i];
+#endif
 }
 
 struct WfbArgs {
@@ -287,7 +348,69 @@ __global__ __launch_bounds__(256) void gru_wfrag_t_kernel(WfbArgs a) {
     *reinterpret_cast<uint4*>(a.dst[blockIdx.y] + (size_t)idx * 8) = o;
 }
 
+struct WfBothArgs {
+    int d, jb;
+    const float* W[2 * GB_MAXP];
+    unsigned short* dstf[2 * GB_MAXP];
+    unsigned short* dstb[2 * GB_MAXP];
+};
+
+// both fragment-major copies of a GRU weight in one launch: blockIdx.z = 0 the forward layout (gruf.hip: fragment ((w KS + s)
+// 3 JB + g JB + j), lane l <- W[g d + w d/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]), 1 the backward-data layout above
+__global__ __launch_bounds__(256) void gru_wfrag_both_kernel(WfBothArgs a) {
+    const int d = a.d, JB = a.jb;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * d * d / 8) return;
+    const int lane = idx & 63, frag = idx >> 6;
+    float v[8];
+    unsigned short* dst;
+    if (blockIdx.z == 0) {
+        const int KS = d / 16, NF = 3 * JB;
+        const int f = frag % NF, ws = frag / NF, s = ws % KS, w = ws / KS, g = f / JB, j = f % JB;
+        const int nrow = g * d + w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
+        const float* src = a.W[blockIdx.y] + (size_t)nrow * d + kk;
+        const float4 v0 = ld4(src), v1 = ld4(src + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        dst = a.dstf[blockIdx.y];
+    } else {
+        const int KS3 = 3 * d / 16;
+        const int j = frag % JB, ws = frag / JB, s = ws % KS3, w = ws / KS3;
+        const int col = w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
+        const float* src = a.W[blockIdx.y] + (size_t)kk * d + col;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * d];
+        dst = a.dstb[blockIdx.y];
+    }
+    uint4 o;
+    o.x = srec_pack_bf16(v[0], v[1]); o.y = srec_pack_bf16(v[2], v[3]);
+    o.z = srec_pack_bf16(v[4], v[5]); o.w = srec_pack_bf16(v[6], v[7]);
+    *reinterpret_cast<uint4*>(dst + (size_t)idx * 8) = o;
+}
+
 }  // namespace
+
+// srec_gru_wfrag and srec_gru_wfrag_t of the same n <= 8 weights in ONE launch (dst_fwd, dst_bwd: HOST arrays of device pointers)
+extern "C" int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream) {
+    if (n <= 0) return 0;
+    if (n > 2 * GB_MAXP || W == nullptr || dst_fwd == nullptr || dst_bwd == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
+    WfBothArgs a{};
+    a.d = d; a.jb = d / 128;
+    for (int i = 0; i < n; ++i) {
+        a.W[i] = ((const float* const*)W)[i];
+        a.dstf[i] = ((unsigned short* const*)dst_fwd)[i]; a.dstb[i] = ((unsigned short* const*)dst_bwd)[i];
+        if (a.W[i] == nullptr || a.dstf[i] == nullptr || a.dstb[i] == nullptr) return SREC_BAD_ARG;
+    }
+    hipLaunchKernelGGL(gru_wfrag_both_kernel, dim3((3 * d * d / 8 + 255) / 256, n, 2), dim3(256), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+#ifdef SREC_GRUF_TIMING
+extern "C" int srec_grub_timing(unsigned long long* tim16, unsigned long long* blk) {
+    if (hipMemcpyFromSymbol(tim16, HIP_SYMBOL(g_grub_tim), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(blk, HIP_SYMBOL(g_grub_blk), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // as srec_gru_wfrag, for the backward-data products of srec_gru_fused_bwd (B operand = W itself, k = its rows)
 extern "C" int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, void* stream) {
@@ -322,7 +445,7 @@ extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
     for (int p = q->np; p <= GB_MAXP; ++p) a.start[p] = blocks;
     if (blocks == 0) return 0;
     const int JB = q->d / 128, D = q->d;
-    const size_t lds = (size_t)RT * 4 * D * 2 + (size_t)RT * D * 4 + (size_t)4 * RT * (32 * JB + 8) * 4;
+    const size_t lds = (size_t)RT * 4 * D * 2 + (size_t)RT * (D + 8) * 4 + (size_t)4 * RT * (32 * JB + 8) * 4;
     static std::atomic<unsigned long long> om[2];
     if (JB == 2) {
         if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<2>, (int)lds, om[1])) return rc;

@@ -1270,6 +1270,17 @@ def gru_wfrag_t(ws):
     return outs
 
 
+def gru_wfrag_both(ws):
+    """gru_wfrag and gru_wfrag_t of the same weights in one launch -> (forward copies, backward copies)"""
+    n, d = len(ws), ws[0].shape[1]
+    of = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
+    ob = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
+    arr = _ct.c_void_p * n
+    a_w, a_f, a_b = arr(*[w.data_ptr() for w in ws]), arr(*[o.data_ptr() for o in of]), arr(*[o.data_ptr() for o in ob])
+    lib.srec_gru_wfrag_both(n, _ct.addressof(a_w), _ct.addressof(a_f), _ct.addressof(a_b), d, stream())
+    return of, ob
+
+
 def gru_wfrag(ws):
     """fragment-major bf16 copies of GRU weights [3 d, d] (the B operands of the fused forward, csrc/gruf.hip), one launch"""
     n, d = len(ws), ws[0].shape[1]
@@ -1334,8 +1345,11 @@ class GRUExpandAll(torch.autograd.Function):
         outs = [torch.empty(ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
         if ctx.fused:
             # the whole recurrence in one launch (csrc/gruf.hip): a workgroup owns 32 nodes, the weights stream from L2
-            wf = gru_wfrag([w for p in range(P) for w in (Wih[p], Whh[p])])
-            wft = gru_wfrag_t([w for p in range(P) for w in (Wih[p], Whh[p])])       # for the backward (csrc/grufb.hip)
+            ws = [w for p in range(P) for w in (Wih[p], Whh[p])]
+            if any(ctx.needs_input_grad):
+                wf, wft = gru_wfrag_both(ws)         # wft: the backward's copies (csrc/grufb.hip)
+            else:
+                wf, wft = gru_wfrag(ws), []
             x16all = torch.empty(sum(x.shape[0] for x in xs), d, device=dev, dtype=torch.bfloat16)
             x16, o = [], 0
             for x in xs:

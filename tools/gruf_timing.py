@@ -5,11 +5,12 @@ import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 pk = os.path.join(root, 'sessionrec-pytorch_amd')
-objs = [o for o in glob.glob(pk + '/csrc/*.o') if not o.endswith('gruf.o')]
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DSREC_GRUF_TIMING',
-                       '-c', pk + '/csrc/gruf.hip', '-o', '/tmp/gruf_tim.o'])
+objs = [o for o in glob.glob(pk + '/csrc/*.o') if not (o.endswith('gruf.o') or o.endswith('grufb.o'))]
+for nm in ('gruf', 'grufb'):
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DSREC_GRUF_TIMING',
+                           '-c', pk + '/csrc/%s.hip' % nm, '-o', '/tmp/%s_tim.o' % nm])
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', '/tmp/libsrec_gruftim.so',
-                       '/tmp/gruf_tim.o'] + objs)
+                       '/tmp/gruf_tim.o', '/tmp/grufb_tim.o'] + objs)
 L = importlib.import_module('sessionrec-pytorch_amd._lib')
 L.LIB_PATH = '/tmp/libsrec_gruftim.so'
 import torch
@@ -45,3 +46,21 @@ nb2 = (ns[0] + 31) // 32
 print('order 2 lives: mean %.1f us; order 3 lives: mean %.1f us' % (life[:nb2].mean(), life[nb2:live.sum()].mean()))
 print('order-3 workgroup, wave 0, cycles summed over the 3 time steps: stage x %d, barrier %d, k-loop %d, gates+stores %d, '
       'h tile %d, drain %d' % tuple(tim[i] for i in range(6)))
+
+# ---- backward
+xs = [x.requires_grad_() for x in xs]
+gout = [torch.randn(n, d, device=dev) for n in ns]
+for _ in range(3):
+    outs = ops.gru_expand_all(xs, grus, ks, [None, None], [None, None])
+    torch.autograd.backward(list(outs), gout)
+torch.cuda.synchronize()
+assert dll.srec_grub_timing(tim, blk) == 0
+b = np.array(list(blk), dtype=np.int64).reshape(1024, 2)
+live = b[:, 1] > b[:, 0]
+t0 = b[live, 0].min()
+st, en = (b[live, 0] - t0) * 0.01, (b[live, 1] - t0) * 0.01
+life = en - st
+print('backward: %d workgroups, span %.1f us, life: mean %.2f median %.2f max %.2f us' % (live.sum(), en.max(), life.mean(), np.median(life), life.max()))
+print('order 2 lives: mean %.1f us; order 3 lives: mean %.1f us' % (life[:nb2].mean(), life[nb2:live.sum()].mean()))
+print('order-3 workgroup, wave 0, cycles summed over the 3 time steps: gate derivatives %d, barrier %d, products %d, '
+      'd x store + d h add %d, barrier %d, bias sums %d' % tuple(tim[i] for i in range(6)))
