@@ -347,6 +347,9 @@ int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void* stream);
 /* backward of all time steps in one launch (csrc/grufb.hip): desc = HOST srec_gru_fused_bwd_desc; srec_gru_wfrag_t: the
  * fragment-major weight copies for its backward-data products (B operand = W [3 d, d] itself, reduction over its rows) */
 int srec_gru_fused_bwd(const void* desc, void* stream);
+/* nodes per workgroup (16 / 32) both use for np problems of n[p] nodes; bias_part of the backward holds one row [6 d] per
+ * workgroup: sum_p ceil(n[p] / nodes) rows */
+int srec_gru_fused_nodes(int np, const int* n, int* nodes);
 int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, void* stream);
 /* both copies of the same weights in one launch */
 int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream);

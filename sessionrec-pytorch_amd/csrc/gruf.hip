@@ -43,9 +43,14 @@ __device__ unsigned long long g_gruf_blk[1024][2];
 #define GFT(i)
 #endif
 
-template <int JB>
+// NR: nodes per workgroup, 32 or 16.  With 16 the lower half of every 32-row MFMA tile is idle (its A rows are whatever LDS
+// holds, its results are never read) - the k-loops are bound by the weight stream, not by the MFMAs, so halving the nodes
+// halves staging and gate epilogues at an unchanged k-loop and puts a workgroup on twice as many CUs (the bench batch has
+// 111 32-node tiles for 256 CUs).
+template <int JB, int NR>
 __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
     constexpr int D = 128 * JB, KS = D / 16, NF = 3 * JB;
+    constexpr int NRR = NR / 2;                  // accumulator registers per block that hold live nodes (rows (r&3) + 8 (r>>2) + 4 half)
     extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
     unsigned short* xt = sm;                     // [RT][D] bf16, swizzled
     unsigned short* ht = sm + RT * D;
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
     for (int i = 1; i < GF_MAXP; ++i)
         if (i < q.np && (int)blockIdx.x >= a.start[i]) p = i;
     const int n = q.n[p], k = q.k[p];
-    const int node0 = ((int)blockIdx.x - a.start[p]) * RT;
+    const int node0 = ((int)blockIdx.x - a.start[p]) * NR;
     if (node0 >= n) return;
     const int nl = dyn_count(q.dyn[p], n);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
     float* out = q.out[p];
 
     if (node0 >= nl) {                           // capacity padding: zero rows, no arithmetic
-        const int rows = min(RT, n - node0);
+        const int rows = min(NR, n - node0);
         for (int i = tid; i < rows * (D / 4); i += 256) {
             const int row = i / (D / 4), c = (i % (D / 4)) * 4;
             const size_t node = (size_t)(node0 + row);
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
 
     // x_t of the 32 nodes: fetched one time step ahead (the loads fly under the previous step's products), rounded to bf16
     // into LDS (swizzled) and into the bf16 copy the weight-gradient GEMM reads
-    constexpr int XV = RT * D / 4 / 256;         // float4 per thread and tile
+    constexpr int XV = NR * D / 4 / 256;         // float4 per thread and tile
     float4 xv[XV];
     auto fetch_x = [&](int t) {
 #pragma unroll
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
         }
     };
     fetch_x(0);
-    const bool full = node0 + RT <= nl;          // every node of the tile is live: no per-row predicates
+    const bool full = node0 + NR <= nl;          // every node of the tile is live: no per-row predicates
     for (int t = 0; t < k; ++t) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
                 // wave's LDS patches so that they leave as 16-byte stores, 8 rows x 128 B per instruction (as 4-byte stores
                 // in the result layout the 192 store instructions per wave and step were 2/3 of the kernel)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < NRR; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
                     const float rr = sig(ar[j][r] + b_r[j]);
                     const float zz = sig(az[j][r] + b_z[j]);
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
                     pp[0] = h; pp[32 * PS] = rr; pp[2 * 32 * PS] = zz; pp[3 * 32 * PS] = nn; pp[4 * 32 * PS] = hn;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NR / 8; ++i) {
                     const int row = 8 * i + (lane_v >> 3), c4 = (lane_v & 7) * 4;
                     const int node = node0 + row;
                     if (F || node < n) {
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
             for (int j = 0; j < JB; ++j) {
                 const int col = cbase + 32 * j + l31v;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < NRR; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
                     ht[row * D + (((col >> 3) ^ (row & 15)) * 8) + (col & 7)] = srec_f2bf(hprev[j][r]);
                 }
@@ -319,6 +324,8 @@ extern "C" int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void
     return 0;
 }
 
+extern "C" int srec_gru_fused_nodes(int np, const int* n, int* nodes);      // grufb.hip
+
 // desc: HOST srec_gru_fused_desc (srec_hg.h)
 extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
     const srec_gru_fused_desc* q = (const srec_gru_fused_desc*)desc;
@@ -334,19 +341,27 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
         a.start[p] = blocks;
         blocks += (q->n[p] + RT - 1) / RT;
     }
+    // 16-node workgroups while 32-node ones would leave half of the chip idle
+    int NRv = 32;
+    if (int rc = srec_gru_fused_nodes(q->np, q->n, &NRv)) return rc;
+    if (NRv == 16) {
+        blocks = 0;
+        for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + 15) / 16; }
+    }
     a.start[q->np] = blocks;
     for (int p = q->np + 1; p <= GF_MAXP; ++p) a.start[p] = blocks;
     if (blocks == 0) return 0;
-    const int JB = q->d / 128, D = q->d, NF = 3 * JB;
+    const int JB = q->d / 128, D = q->d;
     const size_t lds = (size_t)(2 * RT * D) * 2 + 4 * 5 * 32 * 40 * 4;
-    static std::atomic<unsigned long long> om[2];
-    if (JB == 2) {
-        if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<2>, (int)lds, om[1])) return rc;
-        hipLaunchKernelGGL(gru_fused_fwd_kernel<2>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
-    } else {
-        if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<1>, (int)lds, om[0])) return rc;
-        hipLaunchKernelGGL(gru_fused_fwd_kernel<1>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
-    }
+    static std::atomic<unsigned long long> om[4];
+#define SREC_GF(JBV, NRV, slot)                                                                                        \
+    do {                                                                                                               \
+        if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<JBV, NRV>, (int)lds, om[slot])) return rc;       \
+        hipLaunchKernelGGL((gru_fused_fwd_kernel<JBV, NRV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);    \
+    } while (0)
+    if (JB == 2) { if (NRv == 16) SREC_GF(2, 16, 0); else SREC_GF(2, 32, 1); }
+    else { if (NRv == 16) SREC_GF(1, 16, 2); else SREC_GF(1, 32, 3); }
+#undef SREC_GF
     SREC_LAUNCH_CHECK();
     return 0;
 }

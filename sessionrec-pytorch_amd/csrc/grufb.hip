@@ -20,6 +20,7 @@
 #include "common.h"
 #include "../../include/srec_hg.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -44,9 +45,11 @@ __device__ unsigned long long g_grub_blk[1024][2];
 #define GBT(i)
 #endif
 
-template <int JB>
+// NR: nodes per workgroup, 32 or 16 (16: the lower half of every 32-row MFMA tile idles - see gruf.hip)
+template <int JB, int NR>
 __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
-    constexpr int D = 128 * JB, KS = D / 16, TPR = D / 4, RPP = 256 / TPR, NP = RT / RPP;
+    constexpr int D = 128 * JB, KS = D / 16, TPR = D / 4, RPP = 256 / TPR, NP = NR / RPP;
+    constexpr int NRR = NR / 2;                  // accumulator registers per block that hold live nodes
     constexpr int PS = 32 * JB + 8;              // patch row stride (floats): rows r, r + 4 land in opposite bank halves
     extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
     unsigned short* rz = sm;                     // [RT][2 D] bf16, swizzled
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
         if (i < q.np && (int)blockIdx.x >= a.start[i]) p = i;
     const int n = q.n[p], k = q.k[p];
     const int tile = (int)blockIdx.x - a.start[p];
-    const int node0 = tile * RT;
+    const int node0 = tile * NR;
     if (node0 >= n) return;
     const int nl = dyn_count(q.dyn[p], n);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     const int erow = tid / TPR, ec = (tid % TPR) * 4;           // phase E: this thread's row (per pass) and 4 columns
 
     if (node0 >= nl) {                           // capacity padding: zero operands and gradients, no arithmetic
-        const int rows = min(RT, n - node0);
+        const int rows = min(NR, n - node0);
         for (int i = tid; i < rows * TPR; i += 256) {
             const int row = i / TPR, c = (i % TPR) * 4;
             const size_t node = (size_t)(node0 + row);
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     const int cbase = wave * 32 * JB;
     const unsigned short* wf_ih = (const unsigned short*)q.Wih_f[p] + (size_t)wave * 3 * KS * JB * 512;
     const unsigned short* wf_hh = (const unsigned short*)q.Whh_f[p] + (size_t)wave * 3 * KS * JB * 512;
-    const bool full = node0 + RT <= nl;
+    const bool full = node0 + NR <= nl;
     const float ik = 0.5f / (float)k;
     float si[12], shn[4];                        // column sums: d(gi) r, z, n and the n part of d(gh), this thread's 4 columns
 #pragma unroll
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     using IN = std::integral_constant<int, NP>;
     fetch(k - 1, I0{}, IH{});
     constexpr int QPR = 8 * JB;                  // float4 per patch row
-    constexpr int NQ = RT * QPR / 64;
+    constexpr int NQ = NR * QPR / 64;
 
     for (int t = k - 1; t >= 0; --t) {
         // (re-derived behind an opaque asm every step: keeps the per-element addresses from being hoisted and spilled)
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < JB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < NRR; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
                 patch[row * PS + 32 * j + l31v] = ax[j][r];
                 if (has_h) dht[row * DS + cbase + 32 * j + l31v] = ah[j][r];
@@ -427,6 +430,19 @@ extern "C" int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, vo
     return 0;
 }
 
+// nodes per workgroup (16 or 32) srec_gru_fused_fwd / _bwd use for np problems of n[p] nodes: 16-node workgroups while
+// 32-node ones would leave much of the chip idle.  bias_part of srec_gru_fused_bwd holds one row per workgroup:
+// sum_p ceil(n[p] / nodes) rows.  (SREC_GRU_NR = 16 / 32: development override.)
+extern "C" int srec_gru_fused_nodes(int np, const int* n, int* nodes) {
+    if (np < 0 || np > GB_MAXP || (np > 0 && n == nullptr) || nodes == nullptr) return SREC_BAD_ARG;
+    const char* nr_env = getenv("SREC_GRU_NR");
+    const int nr_e = nr_env ? atoi(nr_env) : 0;
+    int blocks = 0;
+    for (int p = 0; p < np; ++p) blocks += (n[p] + RT - 1) / RT;
+    *nodes = nr_e == 16 || nr_e == 32 ? nr_e : (blocks <= 192 ? 16 : 32);
+    return 0;
+}
+
 // desc: HOST srec_gru_fused_bwd_desc (srec_hg.h)
 extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
     const srec_gru_fused_bwd_desc* q = (const srec_gru_fused_bwd_desc*)desc;
@@ -442,18 +458,27 @@ extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
         a.start[p] = blocks;
         blocks += (q->n[p] + RT - 1) / RT;
     }
+    // 16-node workgroups while 32-node ones would leave half of the chip idle (the caller sizes bias_part for either:
+    // one row per 16 nodes is always enough)
+    int NRv = 32;
+    if (int rc = srec_gru_fused_nodes(q->np, q->n, &NRv)) return rc;
+    if (NRv == 16) {
+        blocks = 0;
+        for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + 15) / 16; }
+    }
     for (int p = q->np; p <= GB_MAXP; ++p) a.start[p] = blocks;
     if (blocks == 0) return 0;
     const int JB = q->d / 128, D = q->d;
     const size_t lds = (size_t)RT * 4 * D * 2 + (size_t)RT * (D + 8) * 4 + (size_t)4 * RT * (32 * JB + 8) * 4;
-    static std::atomic<unsigned long long> om[2];
-    if (JB == 2) {
-        if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<2>, (int)lds, om[1])) return rc;
-        hipLaunchKernelGGL(gru_fused_bwd_kernel<2>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
-    } else {
-        if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<1>, (int)lds, om[0])) return rc;
-        hipLaunchKernelGGL(gru_fused_bwd_kernel<1>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
-    }
+    static std::atomic<unsigned long long> om[4];
+#define SREC_GB(JBV, NRV, slot)                                                                                        \
+    do {                                                                                                               \
+        if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<JBV, NRV>, (int)lds, om[slot])) return rc;       \
+        hipLaunchKernelGGL((gru_fused_bwd_kernel<JBV, NRV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);    \
+    } while (0)
+    if (JB == 2) { if (NRv == 16) SREC_GB(2, 16, 0); else SREC_GB(2, 32, 1); }
+    else { if (NRv == 16) SREC_GB(1, 16, 2); else SREC_GB(1, 32, 3); }
+#undef SREC_GB
     SREC_LAUNCH_CHECK();
     return 0;
 }
