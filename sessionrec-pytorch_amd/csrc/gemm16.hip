@@ -40,6 +40,7 @@ struct G16Args {
     int np, lda, ldb, ldc;
     float beta;
     int keep_dead;                // leave output rows past the live count unwritten (nobody reads them)
+    int per_xcd;                  // > 0: XCD-aware tile order (see xcd_tile), tiles per XCD
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -54,6 +55,15 @@ __device__ __forceinline__ void glds16(const unsigned short* sbase, unsigned vof
     const unsigned dst_s = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);   // wave-uniform by construction: pin it to an SGPR
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst_s) : "memory");
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin by index, and every XCD has its own L2.  With tile = blockIdx the tiles that
+// share an operand slab (the two 128-column tiles of a row block in backward-data, the two column tiles of a dP slab in the
+// weight gradient) sit on different XCDs and each pulls its own copy from HBM (PMC: 177 MB of reads for the 63 MB dP).  XCD x
+// takes the x-th CONSECUTIVE run of tiles instead: siblings run side by side behind one L2.
+__device__ __forceinline__ int xcd_tile(const G16Args& g) {
+    const int b = (int)blockIdx.x;
+    return g.per_xcd > 0 ? (b & 7) * g.per_xcd + (b >> 3) : b;
 }
 
 template <int N>
@@ -100,7 +110,8 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     static_assert(NI % 4 == 0, "every wave must issue the same number of DMA instructions per stage");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
 
-    const int bid = (int)blockIdx.x;
+    const int bid = xcd_tile(g);
+    if (bid >= g.start[g.np]) return;
 #ifdef SREC_G16_TIMING
     unsigned long long g16t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g16w = 0, g16d = 0, g16c = 0;
     if (threadIdx.x == 0 && bid < 8192) g_g16_blk[bid][0] = __builtin_amdgcn_s_memrealtime();
@@ -309,7 +320,8 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
     constexpr int NIO = BR / 4;                          // DMA instructions (4 rows each) per operand and stage
     constexpr int IPS = 2 * NIO / 4;                     // ... per stage and wave
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int bid = (int)blockIdx.x;
+    const int bid = xcd_tile(g);
+    if (bid >= g.start[g.np]) return;
     int p = 0;
 #pragma unroll
     for (int i = 1; i < G16_MAXP; ++i)
@@ -574,6 +586,10 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     }
     const int tn = (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
     if (int rc = fill(g, desc_, tm, tn, false, blocks)) return rc;
+    // fp32-output launches (backward-data: two column tiles share every dP row block): 38.7 -> 34.5 us at the bench shapes; the
+    // bf16-output forward (sixteen column tiles per row block, all of x fits any L2) measured 1.5 us slower that way.  Bit 9:
+    // plain tile order (experiments)
+    if (!(h->c16 & 1) && !((h->c16 >> 9) & 1)) { g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd; }
     hipStream_t st = (hipStream_t)stream;
     const bool c16 = h->c16 & 1;
     static std::atomic<unsigned long long> optin_mask[32];
@@ -622,6 +638,7 @@ extern "C" int srec_gemm16_tn(const void* desc_, void* stream) {
     G16Args g{};
     int blocks = 0;
     if (int rc = fill(g, desc_, 128, 128, true, blocks)) return rc;
+    if (!((((const srec_gemm16_group*)desc_)->c16 >> 9) & 1)) { g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd; }
     const int variant = (((const srec_gemm16_group*)desc_)->c16 >> 4) & 15;
     hipStream_t st = (hipStream_t)stream;
     static std::atomic<unsigned long long> om[4];
