@@ -120,14 +120,21 @@ class HipLocal:
         lib.srec_inverse_index(ptr(uptr), ptr(upos), U, n, ptr(inv), stream())
         return inv
 
-    def gather_masked(self, table, idx):
+    fused_dropout = True           # gather_masked / segment_rows take drop = (p, seed, counter, salt): the lookup's feature
+    #                                dropout rides in the last gather and in the first level of its backward (ops.EmbeddingLookup)
+
+    def gather_masked(self, table, idx, drop=None):
         from ._lib import lib, ptr, stream
         n, d = idx.numel(), table.shape[1]
         out = torch.empty(n, d, device=table.device, dtype=torch.float32)
-        lib.srec_gather_rows(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, None, d, stream())
+        if drop is not None:
+            lib.srec_gather_rows_drop(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, None, d, drop[0], drop[1],
+                                      drop[2], drop[3], stream())
+        else:
+            lib.srec_gather_rows(ptr(table), table.stride(0), ptr(idx), ptr(out), d, n, None, d, stream())
         return out
 
-    def segment_rows(self, g, uniq):
+    def segment_rows(self, g, uniq, drop=None):
         """one summed row per distinct item of the local batch: [U, d].  With the (cptr, chunk_ptr) pair of the FlatBatch
         the sum runs in two balanced levels (<= 16 positions per wavefront, then the pieces of each item): a
         Zipf-popular item would otherwise serialise ~1000 row reads in one wavefront."""
@@ -141,11 +148,19 @@ class HipLocal:
             C = chunk_ptr.numel() - 1
             part = torch.empty(max(C, 1), d, device=g.device, dtype=torch.float32)
             ar = self.ops._arange(max(C, U) + 1, g.device)
-            lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, d, 0, stream())
+            if drop is not None:
+                lib.srec_scatter_add_sorted_drop(ptr(g), d, ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, d, 0,
+                                                 drop[0], drop[1], drop[2], drop[3], stream())
+            else:
+                lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(chunk_ptr), ptr(upos), ptr(part), d, C, None, d, 0, stream())
             lib.srec_scatter_add_sorted(ptr(part), d, ptr(ar), ptr(cptr), ptr(ar), ptr(out), d, U, None, d, 0, stream())
         else:
             ar = self.ops._arange(U + 1, g.device)
-            lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(uptr), ptr(upos), ptr(out), d, U, None, d, 0, stream())
+            if drop is not None:
+                lib.srec_scatter_add_sorted_drop(ptr(g), d, ptr(ar), ptr(uptr), ptr(upos), ptr(out), d, U, None, d, 0,
+                                                 drop[0], drop[1], drop[2], drop[3], stream())
+            else:
+                lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(uptr), ptr(upos), ptr(out), d, U, None, d, 0, stream())
         return out
 
     def add_rows(self, rows, items_local, dst):
@@ -251,7 +266,7 @@ class ShardedLookup(torch.autograd.Function):
     not (positions) x d - ~4x less at the MSGIFSR shapes, where every click is looked up once per n-gram order."""
 
     @staticmethod
-    def forward(ctx, shard, items_pad, inv, uniq, dE, lo, local, group, vp=None):
+    def forward(ctx, shard, items_pad, inv, uniq, dE, lo, local, group, vp=None, drop=None):
         n_loc = shard.shape[0]
         # ONE integer exchange per step: the padded distinct-item list (used again by the backward) and, when the caller has
         # announced them (VocabParallel.labels_hint), the labels of the loss - a few KB each, i.e. latencies on xGMI
@@ -266,13 +281,20 @@ class ShardedLookup(torch.autograd.Function):
             vp.lab_all = packed[:, ucap:].reshape(-1)
         rows_all = local.gather_masked(shard, local.localize(ctx.items_all, lo, n_loc))       # [w * ucap, d]
         mine = reduce_scatter_sum(rows_all, group)                                            # [ucap, d]: my items' rows
-        out = local.gather_masked(mine, inv)                                                  # [n, d]: my positions
+        ctx.drop = None
+        if drop is not None and drop[0] > 0:       # feature dropout of the looked-up rows (msgifsr.py:247) fused into the gather
+            seed, cnt = local.ops.rng_args(shard.device)
+            ctx.drop = (float(drop[0]), seed, cnt, int(drop[1]))
+            out = local.gather_masked(mine, inv, ctx.drop)                                    # [n, d]: my positions
+        else:
+            out = local.gather_masked(mine, inv)
         ctx.uniq, ctx.ucap, ctx.dE, ctx.lo, ctx.local, ctx.group, ctx.n_loc = uniq, ucap, dE, lo, local, group, n_loc
         return out
 
     @staticmethod
     def backward(ctx, g):
-        rows = ctx.local.segment_rows(g, ctx.uniq)            # [U, d]: one summed row per distinct item of my batch
+        # [U, d]: one summed row per distinct item of my batch (the dropout mask re-derived while summing)
+        rows = ctx.local.segment_rows(g, ctx.uniq, ctx.drop) if ctx.drop is not None else ctx.local.segment_rows(g, ctx.uniq)
         U, ucap = rows.shape[0], ctx.ucap
         if U < ucap:
             rows = torch.cat([rows, rows.new_zeros(ucap - U, rows.shape[1])])
@@ -280,7 +302,7 @@ class ShardedLookup(torch.autograd.Function):
         rel = ctx.local.localize(ctx.items_all, ctx.lo, ctx.n_loc)
         for r in range(_world(ctx.group)):                   # rank by rank: distinct items within each call
             ctx.local.add_rows(rows_all[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], ctx.dE)
-        return (None,) * 9
+        return (None,) * 10
 
 
 class ShardedScoreCE(torch.autograd.Function):
@@ -385,7 +407,7 @@ class VocabParallel:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return (int(t.item()) + 255) // 256 * 256
 
-    def lookup(self, table, idx, uniq):
+    def lookup(self, table, idx, uniq, drop=None):
         items, uptr, upos = uniq[:3]
         n, U = idx.numel(), items.numel()
         ucap = self.capacity(U)
@@ -394,7 +416,7 @@ class VocabParallel:
         inv = self.local.inverse_index(uptr, upos, U, n)      # position -> slot of its item in `items`
         uq = (items, uptr[:U + 1], upos) + tuple(uniq[3:])
         self.lab_all = None
-        rows = ShardedLookup.apply(table, items_pad, inv, uq, self.dE, self.lo, self.local, self.group, self)
+        rows = ShardedLookup.apply(table, items_pad, inv, uq, self.dE, self.lo, self.local, self.group, self, drop)
         self.labels_hint = None
         return rows
 

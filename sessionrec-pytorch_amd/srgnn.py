@@ -80,8 +80,9 @@ class _ScoringMixin:
         applied to the rows - fused into the gather kernels on the single-device path."""
         p = drop.p if isinstance(drop, nn.Dropout) and drop.training else 0.0
         if self.shard is not None:
-            rows = self.shard.lookup(self._table(), idx, uniq)
-            return drop(rows) if drop is not None else rows
+            fused = p > 0 and getattr(self.shard.local, 'fused_dropout', False)      # HipLocal: the mask rides in the gather
+            rows = self.shard.lookup(self._table(), idx, uniq, (p, 7) if fused else None)
+            return rows if (fused or drop is None) else drop(rows)
         if drop is not None and not isinstance(drop, nn.Dropout):
             return drop(ops.embedding_lookup(self._table(), idx, uniq, tgrad, dyn_n, dyn_u))    # replaced module (tests)
         return ops.embedding_lookup(self._table(), idx, uniq, tgrad, dyn_n, dyn_u, (p, 7) if p > 0 else None)
