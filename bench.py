@@ -452,7 +452,7 @@ def main():
             t = torch.tensor([cap], device=dev)        # request length on every rank: no per-step size exchange
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             shard = D.VocabParallel(model, idx_cap=int(t.item()))
-        opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=shard is None)
+        opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
         replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
         model.train()
 

@@ -163,13 +163,18 @@ class HipLocal:
                 lib.srec_scatter_add_sorted(ptr(g), d, ptr(ar), ptr(uptr), ptr(upos), ptr(out), d, U, None, d, 0, stream())
         return out
 
-    def add_rows(self, rows, items_local, dst):
-        """dst[items_local[u]] += rows[u] for items_local[u] >= 0 (distinct within the call)"""
+    def add_rows(self, rows, items_local, dst, proj=None):
+        """dst[items_local[u]] += rows[u] for items_local[u] >= 0 (distinct within the call).  proj = (table, radial): the
+        deferred row-normalisation projection is pending on dst (ops.TableGrad) - the rows' radial parts are recorded"""
         from ._lib import lib, ptr, stream
         U, d = rows.shape
         ar = self.ops._arange(U + 1, rows.device)
-        lib.srec_scatter_add_sorted(ptr(rows), d, ptr(items_local), ptr(ar), ptr(ar), ptr(dst), dst.stride(0), U, None,
-                                    d, 1, stream())
+        if proj is not None:
+            lib.srec_scatter_add_sorted_ex(ptr(rows), d, ptr(items_local), ptr(ar), ptr(ar), ptr(dst), dst.stride(0), U, None,
+                                           d, 1, 0.0, 0, None, 0, ptr(proj[0]), proj[0].stride(0), ptr(proj[1]), stream())
+        else:
+            lib.srec_scatter_add_sorted(ptr(rows), d, ptr(items_local), ptr(ar), ptr(ar), ptr(dst), dst.stride(0), U, None,
+                                        d, 1, stream())
 
     def _tb(self, table, refresh):
         """bf16 operand copies of this rank's shard when set_precision('bf16') is on (refreshed once per step)"""
@@ -193,17 +198,19 @@ class HipLocal:
         self.ops._ce_fwd(sr, table, cs, labels_local, ws, None, self._tb(table, True), ws.lab_logit, lse, lossvec, loss)
         return lse, ws.lab_logit.clone()
 
-    def ce_bwd(self, sr, table, cs, labels_local, lse, gscale, dE, ws, cs_inv_scale):
+    def ce_bwd(self, sr, table, cs, labels_local, lse, gscale, dE, ws, cs_inv_scale, defer_tg=None):
         from ._lib import lib, ptr, stream
         B, d = sr.shape
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         self.ops._ce_bwd(sr, table, cs, labels_local, lse, gscale, None, None, ws, None, self._tb(table, False), dE, dsr, 3)
-        if cs is not None:
+        if cs is not None and defer_tg is not None:
+            defer_tg.pending = (table, cs, cs_inv_scale)      # applied by the optimizer's row pass (ops.TableGrad)
+        elif cs is not None:
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), cs_inv_scale, ptr(dE), dE.stride(0),
                                      table.shape[0], d, stream())
         return dsr
 
-    def stats_bwd(self, sr, table, cs, labels_local, lse, ga, gc, dE, ws, cs_inv_scale, accumulate):
+    def stats_bwd(self, sr, table, cs, labels_local, lse, ga, gc, dE, ws, cs_inv_scale, accumulate, defer_tg=None):
         """d z[b, v] = ga[b] * softmax(z_b)[v] - gc[b] * [v == label_b] through this rank's rows: dE (+)= dz^T sr,
         returns the partial d sr = dz E_local"""
         from ._lib import lib, ptr, stream
@@ -211,7 +218,9 @@ class HipLocal:
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         self.ops._ce_bwd(sr, table, cs, labels_local, lse, None, ga, gc, ws, None, self._tb(table, False), dE, dsr,
                          3 | (4 if accumulate else 0))
-        if cs is not None:
+        if cs is not None and defer_tg is not None:
+            defer_tg.pending = (table, cs, cs_inv_scale)      # linear: once, over the sum of the heads' contributions
+        elif cs is not None:
             lib.srec_rownorm_project(ptr(table), table.stride(0), ptr(cs), cs_inv_scale, ptr(dE), dE.stride(0),
                                      table.shape[0], d, stream())
         return dsr
@@ -289,6 +298,7 @@ class ShardedLookup(torch.autograd.Function):
         else:
             out = local.gather_masked(mine, inv)
         ctx.uniq, ctx.ucap, ctx.dE, ctx.lo, ctx.local, ctx.group, ctx.n_loc = uniq, ucap, dE, lo, local, group, n_loc
+        ctx.vp, ctx.shard = vp, shard
         return out
 
     @staticmethod
@@ -300,8 +310,13 @@ class ShardedLookup(torch.autograd.Function):
             rows = torch.cat([rows, rows.new_zeros(ucap - U, rows.shape[1])])
         rows_all = all_gather_cat(rows, ctx.group)
         rel = ctx.local.localize(ctx.items_all, ctx.lo, ctx.n_loc)
+        tg = ctx.vp.tgrad if ctx.vp is not None else None
+        proj = (ctx.shard, tg.radial) if (tg is not None and tg.pending is not None) else None
         for r in range(_world(ctx.group)):                   # rank by rank: distinct items within each call
-            ctx.local.add_rows(rows_all[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], ctx.dE)
+            if proj is not None:
+                ctx.local.add_rows(rows_all[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], ctx.dE, proj)
+            else:
+                ctx.local.add_rows(rows_all[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], ctx.dE)
         return (None,) * 10
 
 
@@ -309,7 +324,7 @@ class ShardedScoreCE(torch.autograd.Function):
     """mean CE over the GLOBAL batch (world*B sessions) against the row-sharded catalog."""
 
     @staticmethod
-    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group, lab_all=None):
+    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group, lab_all=None, tgrad=None):
         n_loc = shard.shape[0]
         sr_all = all_gather_cat(sr.contiguous(), group)
         if lab_all is None:                                            # not exchanged with the lookup's request lists
@@ -318,19 +333,22 @@ class ShardedScoreCE(torch.autograd.Function):
         lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
         lse, lab_logit, loss, gw = _merge_stats(lse_r, lab_logit, group, local, lab_all)
         ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse, gw)
-        ctx.misc = (dE, ws, cs_inv_scale, local, group)
+        ctx.misc = (dE, ws, cs_inv_scale, local, group, tgrad)
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
         sr_all, shard, cs, lab_loc, lse, gw = ctx.saved_tensors
-        dE, ws, cs_inv_scale, local, group = ctx.misc
+        dE, ws, cs_inv_scale, local, group, tgrad = ctx.misc
         # d z[b, v] = g_b (softmax_b[v] - [v == label_b]) with g_b = gloss / n_live on live sessions, 0 on the capacity
         # padding of a rank's partial batch (the mean runs over the live sessions of the GLOBAL batch)
         g = (gw * gloss.reshape(()).to(torch.float32)).contiguous()
-        dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False)
+        if tgrad is not None and tgrad.defer:
+            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False, tgrad)
+        else:
+            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False)
         dsr = reduce_scatter_sum(dsr_part, group)
-        return dsr, None, None, None, None, None, None, None, None, None, None
+        return (dsr,) + (None,) * 11
 
 
 class ShardedScoreStats(torch.autograd.Function):
@@ -358,7 +376,10 @@ class ShardedScoreStats(torch.autograd.Function):
         dE, ws, cs_inv_scale, local, group, tgrad = ctx.misc
         ga = all_gather_cat(dlse.contiguous().float(), group)
         gc = all_gather_cat((-dlab).contiguous().float(), group)
-        dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, ga, gc, dE, ws, cs_inv_scale, tgrad.fresh)
+        if tgrad.defer:
+            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, ga, gc, dE, ws, cs_inv_scale, tgrad.fresh, tgrad)
+        else:
+            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, ga, gc, dE, ws, cs_inv_scale, tgrad.fresh)
         tgrad.fresh = True
         dsr = reduce_scatter_sum(dsr_part, group)
         return (dsr,) + (None,) * 10
@@ -432,7 +453,7 @@ class VocabParallel:
         if lab_all is not None and lab_all.numel() != B:
             lab_all = None
         out = ShardedScoreCE.apply(sr, live, csl, labels, dE, self.lo, self._ws[key], cs_inv_scale, self.local, self.group,
-                                   lab_all)
+                                   lab_all, self.tgrad)
         self.tgrad.fresh = True                      # the backward of `out` overwrites every live row of dE
         return out
 

@@ -28,16 +28,23 @@ class _AdamMultiDesc(_ct.Structure):
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, model=None, fuse_projection=False):
-        """fuse_projection (cosine-scored models on one device): the chain rule of the catalog-row normalisation is applied
+        """fuse_projection (cosine-scored models; one device or a row-sharded table): the chain rule of the catalog-row normalisation is applied
         to the table gradient inside this optimizer's row pass instead of a separate pass after the scoring backward
         (ops.TableGrad: defer / pending / radial)."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.model = model
-        if fuse_projection and model is not None and getattr(model, 'shard', None) is None and hasattr(model, '_cosine') \
-                and model._cosine() is not None and model._table().is_cuda:
+        if fuse_projection and model is not None and hasattr(model, '_cosine') and model._cosine() is not None \
+                and model._table().is_cuda:
             model._defer_projection = True
-            model.__dict__.pop('_srec_state', None)          # the gradient buffer is re-created with the side array
+            shard = getattr(model, 'shard', None)
+            if shard is None:
+                model.__dict__.pop('_srec_state', None)      # the gradient buffer is re-created with the side array
+            elif getattr(shard.local, 'fused_dropout', False):   # row-sharded table (HIP kernels): its gradient buffer is
+                tg = shard.tgrad                                 # shared with the collectives - switched over in place
+                tg.defer = True
+                if tg.radial is None:
+                    tg.radial = torch.zeros(tg.buf.shape[0], device=tg.buf.device, dtype=torch.float32)
         self._hyper = {}            # (group index, step offset) -> device step state
         self._frozen = None         # parameter lists frozen by a captured graph
 

@@ -78,7 +78,7 @@ class TrainRunner:
         self.fused = th.device(device).type == 'cuda' and hasattr(model, 'fused_loss')
         if self.fused:
             from .optim import FusedAdam
-            self.optimizer = FusedAdam(params, lr=lr, weight_decay=weight_decay, model=model, fuse_projection=shard is None)
+            self.optimizer = FusedAdam(params, lr=lr, weight_decay=weight_decay, model=model, fuse_projection=True)
         else:
             self.optimizer = optim.Adam(params, lr=lr, weight_decay=weight_decay)
         self.scheduler = optim.lr_scheduler.StepLR(self.optimizer, step_size=3, gamma=0.1)

@@ -598,6 +598,47 @@ def test_msgifsr_bf16_gemm16_path_at_d64(dev, dropout):
     assert (num / den) ** 0.5 < 3e-2, 'bf16 gradients off by %.3e (norm-wise)' % (num / den) ** 0.5
 
 
+@pytest.mark.parametrize('name', ['niser_s32', 'msgifsr_K3_s32', 'msgifsr_K3_fus_s32'])
+def test_projection_fused_in_the_row_sharded_path(dev, name):
+    """the same with the table row-sharded (dist.VocabParallel on a one-rank world: the code every rank of an N-GPU job runs):
+    the sharded scoring backward leaves the projection pending, the sharded lookup backward records the radial parts of the
+    rows it adds, the optimizer's row pass applies it - trajectory of the separate-pass run; the lookup's feature dropout
+    rides in the sharded gather in both."""
+    import copy
+    train, optim, D = pkg('train'), pkg('optim'), pkg('dist')
+    z, samples, init = load_golden(name)
+    V = init[[k for k in init if k.startswith('embedding')][0]].shape[0]
+    base = _build(name, init, V, dev)
+    for m in base.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.2
+    models = [copy.deepcopy(base), copy.deepcopy(base)]
+    inputs, labels = _collate(name, samples)
+    inputs = [x.to(dev) for x in inputs]
+    labels = labels.to(dev)
+    shards = [D.VocabParallel(m) for m in models]
+    opts = [optim.FusedAdam(train.fix_weight_decay(m), lr=1e-3, weight_decay=1e-4, model=m, fuse_projection=f)
+            for m, f in zip(models, (False, True))]
+    assert shards[1].tgrad.defer and not shards[0].tgrad.defer
+    runs = []
+    for m, o in zip(models, opts):                      # one after the other: the masks are keyed by the step counter
+        m.train()
+        pkg('ops').RNG_COUNTER.clear()
+        out = []
+        for it in range(3):
+            torch.manual_seed(100 + it)
+            o.zero_grad()
+            loss = m.fused_loss(*inputs, labels)
+            loss.backward()
+            o.step()
+            out.append(loss.detach().clone())
+        runs.append(out)
+    for it in range(3):
+        close(runs[1][it], runs[0][it], rtol=1e-6, atol=1e-6, what='loss step %d' % it)
+    for (k, p), (_, q) in zip(models[1].named_parameters(), models[0].named_parameters()):
+        adam_close(p, q, lr=1e-3, steps=3, what=k)
+
+
 @pytest.mark.parametrize('name,graph', [('niser_s32', False), ('msgifsr_K3_s32', False), ('msgifsr_K3_fus_s32', False),
                                         ('msgifsr_K2_edge', True), ('niser_edge', True)])
 def test_projection_fused_into_the_optimizer_equals_the_separate_pass(dev, name, graph):
