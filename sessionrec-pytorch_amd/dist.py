@@ -191,12 +191,13 @@ class HipLocal:
     def ce_fwd(self, sr, table, cs, labels_local, ws):
         B, d = sr.shape
         dev = sr.device
-        lse = torch.empty(B, device=dev, dtype=torch.float32)
+        # (lse, label logit) as the two rows of ONE buffer: it is what _merge_stats all-gathers (no stack / clone launches)
+        pair = torch.empty(2, B, device=dev, dtype=torch.float32)
+        pair[1].zero_()
         lossvec = torch.empty(B, device=dev, dtype=torch.float32)
         loss = torch.empty((), device=dev, dtype=torch.float32)
-        ws.lab_logit.zero_()
-        self.ops._ce_fwd(sr, table, cs, labels_local, ws, None, self._tb(table, True), ws.lab_logit, lse, lossvec, loss)
-        return lse, ws.lab_logit.clone()
+        self.ops._ce_fwd(sr, table, cs, labels_local, ws, None, self._tb(table, True), pair[1], pair[0], lossvec, loss)
+        return pair[0], pair[1]
 
     def ce_bwd(self, sr, table, cs, labels_local, lse, gscale, dE, ws, cs_inv_scale, defer_tg=None):
         from ._lib import lib, ptr, stream
@@ -261,7 +262,13 @@ def _merge_stats(lse_r, lab_logit_r, group, local=None, lab_all=None):
         return lse, lab, ((lse - lab) * gw).sum(), gw
     if _world(group) == 1 and not (FORCE and dist.is_initialized()):
         return torch_merge(lse_r, lab_logit_r)
-    st = all_gather_cat(torch.stack([lse_r, lab_logit_r]).unsqueeze(0), group)     # [w, 2, B]
+    B = lse_r.numel()
+    if lse_r.is_contiguous() and lab_logit_r.is_contiguous() and lab_logit_r.data_ptr() == lse_r.data_ptr() + 4 * B \
+            and lse_r.dtype == torch.float32:
+        pair = lse_r.as_strided((1, 2, B), (2 * B, B, 1))                      # HipLocal.ce_fwd: already adjacent rows
+    else:
+        pair = torch.stack([lse_r, lab_logit_r]).unsqueeze(0)
+    st = all_gather_cat(pair, group)                                           # [w, 2, B]
     if local is not None and hasattr(local, 'merge_stats'):
         return local.merge_stats(st, lab_all)
     return torch_merge(torch.logsumexp(st[:, 0], dim=0).contiguous(), st[:, 1].sum(0))
@@ -288,7 +295,8 @@ class ShardedLookup(torch.autograd.Function):
         ctx.items_all = packed[:, :ucap].reshape(-1)
         if lab is not None:
             vp.lab_all = packed[:, ucap:].reshape(-1)
-        rows_all = local.gather_masked(shard, local.localize(ctx.items_all, lo, n_loc))       # [w * ucap, d]
+        ctx.rel = local.localize(ctx.items_all, lo, n_loc)     # local row of every requested item (-1: another rank's); reused by the backward
+        rows_all = local.gather_masked(shard, ctx.rel)                                        # [w * ucap, d]
         mine = reduce_scatter_sum(rows_all, group)                                            # [ucap, d]: my items' rows
         ctx.drop = None
         if drop is not None and drop[0] > 0:       # feature dropout of the looked-up rows (msgifsr.py:247) fused into the gather
@@ -309,7 +317,7 @@ class ShardedLookup(torch.autograd.Function):
         if U < ucap:
             rows = torch.cat([rows, rows.new_zeros(ucap - U, rows.shape[1])])
         rows_all = all_gather_cat(rows, ctx.group)
-        rel = ctx.local.localize(ctx.items_all, ctx.lo, ctx.n_loc)
+        rel = ctx.rel
         tg = ctx.vp.tgrad if ctx.vp is not None else None
         proj = (ctx.shard, tg.radial) if (tg is not None and tg.pending is not None) else None
         for r in range(_world(ctx.group)):                   # rank by rank: distinct items within each call
