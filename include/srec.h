@@ -302,6 +302,9 @@ int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_o
 /* ... and, in the same launch, the attention-dropout multipliers (gatconv.py:300) mk [na] = 0 or 1 / (1 - pa) (pa = 0: none) */
 int srec_hg_drop_prep(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter, int salt,
                       float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk, void* stream);
+/* ... and, in the same pass, xc16 [2, rows, D] = bf16(xc): the operand copy the bf16 projection GEMM reads */
+int srec_hg_drop_prep16(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter, int salt,
+                        float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk, void* xc16, void* stream);
 int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
                 int ld_dx, float* ws, void* stream);

@@ -1072,7 +1072,7 @@ namespace {
 __global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __restrict__ cnt, long n, int D, long rows,
                                     float p, srec_rng rng, float* __restrict__ ms, float* __restrict__ xc,
                                     float* __restrict__ rm, float* __restrict__ xres, int nb1, float pa, long na,
-                                    float* __restrict__ mk) {
+                                    float* __restrict__ mk, unsigned short* __restrict__ xc16) {
     const unsigned key = srec_rng_key(rng);
     if ((int)blockIdx.x >= nb1) {
         const long j = ((long)((int)blockIdx.x - nb1) * blockDim.x + threadIdx.x) * 4;
@@ -1093,8 +1093,14 @@ __global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __
     m1.x = srec_keep(key, i1, p, sc); m1.y = srec_keep(key, i1 + 1, p, sc); m1.z = srec_keep(key, i1 + 2, p, sc); m1.w = srec_keep(key, i1 + 3, p, sc);
     *reinterpret_cast<float4*>(ms + i) = m0;
     *reinterpret_cast<float4*>(ms + n + i) = m1;
-    *reinterpret_cast<float4*>(xc + i) = make_float4(xv.x * m0.x, xv.y * m0.y, xv.z * m0.z, xv.w * m0.w);
-    *reinterpret_cast<float4*>(xc + n + i) = make_float4(xv.x * m1.x, xv.y * m1.y, xv.z * m1.z, xv.w * m1.w);
+    const float4 x0 = make_float4(xv.x * m0.x, xv.y * m0.y, xv.z * m0.z, xv.w * m0.w);
+    const float4 x1 = make_float4(xv.x * m1.x, xv.y * m1.y, xv.z * m1.z, xv.w * m1.w);
+    *reinterpret_cast<float4*>(xc + i) = x0;
+    *reinterpret_cast<float4*>(xc + n + i) = x1;
+    if (xc16 != nullptr) {                       // the bf16 operand copy of the projections' GEMM, written here (no rows_bf16 pass)
+        *reinterpret_cast<uint2*>(xc16 + i) = make_uint2(srec_pack_bf16(x0.x, x0.y), srec_pack_bf16(x0.z, x0.w));
+        *reinterpret_cast<uint2*>(xc16 + n + i) = make_uint2(srec_pack_bf16(x1.x, x1.y), srec_pack_bf16(x1.z, x1.w));
+    }
     const float4 r = make_float4(c0 * m0.x + c1 * m1.x, c0 * m0.y + c1 * m1.y, c0 * m0.z + c1 * m1.z, c0 * m0.w + c1 * m1.w);
     *reinterpret_cast<float4*>(rm + i) = r;
     *reinterpret_cast<float4*>(xres + i) = make_float4(xv.x * r.x, xv.y * r.y, xv.z * r.z, xv.w * r.w);
@@ -1123,9 +1129,9 @@ __global__ void hg_drop_merge_kernel(const float* __restrict__ t, int S, const f
 
 // x [rows, D] contiguous, cnt [2, rows]; outputs ms / xc [2, rows, D], rm / xres [rows, D] and (pa > 0) the attention-dropout
 // multipliers mk [na] - all masks from the counter-based hash keyed by (seed, *counter, salt).
-extern "C" int srec_hg_drop_prep(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter,
-                                 int salt, float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk,
-                                 void* stream) {
+static int hg_drop_prep_run(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter,
+                            int salt, float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk,
+                            unsigned short* xc16, void* stream) {
     if (rows <= 0) return 0;
     if (D <= 0 || (D & 3) || p < 0.f || p >= 1.f || pa < 0.f || pa >= 1.f) return SREC_BAD_ARG;
     const long n = (long)rows * D;
@@ -1133,9 +1139,22 @@ extern "C" int srec_hg_drop_prep(const float* x, const float* cnt, int rows, int
     const int nb1 = (int)((n / 4 + 255) / 256);
     const int nb2 = (pa > 0.f && na > 0 && mk != nullptr) ? (int)(((na + 3) / 4 + 255) / 256) : 0;
     hipLaunchKernelGGL(hg_drop_prep_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, (hipStream_t)stream, x, cnt, n, D,
-                       (long)rows, p, srec_rng{(unsigned)seed, counter, (unsigned)salt, p}, ms, xc, rm, xres, nb1, pa, na, mk);
+                       (long)rows, p, srec_rng{(unsigned)seed, counter, (unsigned)salt, p}, ms, xc, rm, xres, nb1, pa, na, mk, xc16);
     SREC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int srec_hg_drop_prep(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter,
+                                 int salt, float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk,
+                                 void* stream) {
+    return hg_drop_prep_run(x, cnt, rows, D, p, seed, counter, salt, ms, xc, rm, xres, pa, na, mk, nullptr, stream);
+}
+// ... and xc16 [2, rows, D] = bf16(xc): the operand copy the bf16 projection GEMM reads (saves the srec_rows_bf16 pass)
+extern "C" int srec_hg_drop_prep16(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter,
+                                   int salt, float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk,
+                                   void* xc16, void* stream) {
+    if (xc16 == nullptr) return SREC_BAD_ARG;
+    return hg_drop_prep_run(x, cnt, rows, D, p, seed, counter, salt, ms, xc, rm, xres, pa, na, mk, (unsigned short*)xc16, stream);
 }
 
 // dx [n] += (sum_s t[0][s]) * ms[0] + (sum_s t[1][s]) * ms[1], t [2, S, n], ms [2, n]; n % 4 == 0

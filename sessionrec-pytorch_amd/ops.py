@@ -2057,8 +2057,15 @@ class HGATLayer(torch.autograd.Function):
                 allm = torch.empty(na, device=dev, dtype=torch.float32)
                 mk = list(torch.split(allm, sizes))
             seed, rc = rng_args(dev)
-            lib.srec_hg_drop_prep(ptr(xcont), ptr(cnt), NT, D, float(pf), seed, rc, 101 + 2 * plan.layer_id, ptr(ms), ptr(xcs),
-                                  ptr(rm), ptr(xres), float(pa), na, ptr(allm), stream())
+            # the bf16 GEMM path reads bf16(xcs): written by the same pass
+            x16_pre = None
+            if PRECISION['matmul'] == 'bf16' and D % 64 == 0 and nm <= 8 and all(params[4 * m].is_contiguous() for m in range(nm)):
+                x16_pre = torch.empty(2, NT, D, device=dev, dtype=torch.bfloat16)
+                lib.srec_hg_drop_prep16(ptr(xcont), ptr(cnt), NT, D, float(pf), seed, rc, 101 + 2 * plan.layer_id, ptr(ms),
+                                        ptr(xcs), ptr(rm), ptr(xres), float(pa), na, ptr(allm), ptr(x16_pre), stream())
+            else:
+                lib.srec_hg_drop_prep(ptr(xcont), ptr(cnt), NT, D, float(pf), seed, rc, 101 + 2 * plan.layer_id, ptr(ms),
+                                      ptr(xcs), ptr(rm), ptr(xres), float(pa), na, ptr(allm), stream())
             xc = [xcs[0], xcs[1]]
             dstate = (xc, xres, rm, mk, ms)
             if DROP_TAP is not None:
@@ -2074,7 +2081,7 @@ class HGATLayer(torch.autograd.Function):
             # the backward-data product), the module inputs in one pass
             w16, wt16 = weights_bf16([params[4 * m] for m in range(nm)])
             if dstate is not None:
-                x16 = rows_bf16(xcs.view(2 * NT, D)).view(2, NT, D)
+                x16 = x16_pre if x16_pre is not None else rows_bf16(xcs.view(2 * NT, D)).view(2, NT, D)
                 xin16 = lambda m: x16[plan.mod_conv[m]]
             else:
                 x16 = rows_bf16(x)
