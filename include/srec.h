@@ -352,7 +352,9 @@ int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void* stream);
 int srec_gru_fused_bwd(const void* desc, void* stream);
 /* nodes per workgroup (16 / 32) both use for np problems of n[p] nodes; bias_part of the backward holds one row [6 d] per
  * workgroup: sum_p ceil(n[p] / nodes) rows */
-int srec_gru_fused_nodes(int np, const int* n, int* nodes);
+int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes);
+/* waves per workgroup (4 / 8) of both and of the fragment-major weight copies for hidden size d */
+int srec_gru_fused_waves(int d, int* waves);
 int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, void* stream);
 /* both copies of the same weights in one launch */
 int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream);

@@ -22,6 +22,9 @@
 #include "../../include/srec_hg.h"
 #include <type_traits>
 
+extern "C" int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes);      // grufb.hip
+extern "C" int srec_gru_fused_waves(int d, int* waves);
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -47,9 +50,12 @@ __device__ unsigned long long g_gruf_blk[1024][2];
 // holds, its results are never read) - the k-loops are bound by the weight stream, not by the MFMAs, so halving the nodes
 // halves staging and gate epilogues at an unchanged k-loop and puts a workgroup on twice as many CUs (the bench batch has
 // 111 32-node tiles for 256 CUs).
-template <int JB, int NR>
-__global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
-    constexpr int D = 128 * JB, KS = D / 16, NF = 3 * JB;
+// NW: waves per workgroup, 4 or 8 (D = 256 only).  With 8 each wave owns d / 8 = 32 columns (one block): the same weight bytes
+// per node as with 4, half the gate epilogue per wave and twice the loads in flight for the k-loop; 256 registers per wave.
+template <int DD, int NR, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_kernel(FusedArgs a) {
+    constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;   // JB: 32-column blocks per wave
+    constexpr int KS = D / 16, NF = 3 * JB;
     constexpr int NRR = NR / 2;                  // accumulator registers per block that hold live nodes (rows (r&3) + 8 (r>>2) + 4 half)
     extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
     unsigned short* xt = sm;                     // [RT][D] bf16, swizzled
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
 
     if (node0 >= nl) {                           // capacity padding: zero rows, no arithmetic
         const int rows = min(NR, n - node0);
-        for (int i = tid; i < rows * (D / 4); i += 256) {
+        for (int i = tid; i < rows * (D / 4); i += NT) {
             const int row = i / (D / 4), c = (i % (D / 4)) * 4;
             const size_t node = (size_t)(node0 + row);
             for (int t = 0; t < k; ++t) {
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
     unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_c = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_gruf_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    float* patch = reinterpret_cast<float*>(sm + 2 * RT * D) + wave * 5 * 32 * PS;      // this wave's 5 [32][PS] patches
+    float* patch = reinterpret_cast<float*>(sm + 2 * RT * D) + wave * NR * PS;          // this wave's [NR][PS] patch
     const int cbase = wave * 32 * JB;
     float b_r[JB], b_z[JB], b_in[JB], b_hn[JB];
 #pragma unroll
@@ -114,12 +120,12 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
 
     // x_t of the 32 nodes: fetched one time step ahead (the loads fly under the previous step's products), rounded to bf16
     // into LDS (swizzled) and into the bf16 copy the weight-gradient GEMM reads
-    constexpr int XV = NR * D / 4 / 256;         // float4 per thread and tile
+    constexpr int XV = NR * D / 4 / NT;          // float4 per thread and tile
     float4 xv[XV];
     auto fetch_x = [&](int t) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
-            const int idx = i * 256 + tid;
+            const int idx = i * NT + tid;
             const int row = idx / (D / 4), c4 = idx % (D / 4);
             const int node = node0 + row;
             xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
     for (int t = 0; t < k; ++t) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
-            const int idx = i * 256 + tid;
+            const int idx = i * NT + tid;
             const int row = idx / (D / 4), c4 = idx % (D / 4);
             const int node = node0 + row;
             uint2 o;
@@ -205,9 +211,10 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
             constexpr bool F = decltype(FULL)::value;
 #pragma unroll
             for (int j = 0; j < JB; ++j) {
-                // gate math in the MFMA result layout (lane = column, register = node); the five results go through this
-                // wave's LDS patches so that they leave as 16-byte stores, 8 rows x 128 B per instruction (as 4-byte stores
-                // in the result layout the 192 store instructions per wave and step were 2/3 of the kernel)
+                // gate math in the MFMA result layout (lane = column, register = node); the five results go one after the other
+                // through this wave's LDS patch so that they leave as 16-byte stores, 8 rows x 128 B per instruction (as 4-byte
+                // stores in the result layout the 192 store instructions per wave and step were 2/3 of the kernel)
+                float v5[5][NRR];
 #pragma unroll
                 for (int r = 0; r < NRR; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
@@ -217,34 +224,39 @@ __global__ __launch_bounds__(256, 1) void gru_fused_fwd_kernel(FusedArgs a) {
                     const float nn = 2.f * sig(2.f * (ain[j][r] + b_in[j] + rr * hn)) - 1.f;
                     const float h = (F || node0 + row < nl) ? (1.f - zz) * nn + zz * hprev[j][r] : 0.f;
                     hprev[j][r] = h;
-                    float* pp = patch + row * PS + l31v;
-                    pp[0] = h; pp[32 * PS] = rr; pp[2 * 32 * PS] = zz; pp[3 * 32 * PS] = nn; pp[4 * 32 * PS] = hn;
+                    v5[0][r] = h; v5[1][r] = rr; v5[2][r] = zz; v5[3][r] = nn; v5[4][r] = hn;
                 }
 #pragma unroll
-                for (int i = 0; i < NR / 8; ++i) {
-                    const int row = 8 * i + (lane_v >> 3), c4 = (lane_v & 7) * 4;
-                    const int node = node0 + row;
-                    if (F || node < n) {
-                        const float* pr = patch + row * PS + c4;
-                        const float4 hv = *reinterpret_cast<const float4*>(pr);
-                        const unsigned off = (unsigned)node * D + cbase + 32 * j + c4;
-                        *reinterpret_cast<float4*>(Ht + off) = hv;
-                        if (!last) *reinterpret_cast<uint2*>(H16t + off) = make_uint2(srec_pack_bf16(hv.x, hv.y), srec_pack_bf16(hv.z, hv.w));
-                        const unsigned goff = (unsigned)node * (4 * D) + cbase + 32 * j + c4;
+                for (int ten = 0; ten < 5; ++ten) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<float4*>(Gt + goff + g * D) = *reinterpret_cast<const float4*>(pr + (1 + g) * 32 * PS);
-                        if (last) {
-                            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (F || node < nl) {
-                                const unsigned xo = (unsigned)node * k * D + cbase + 32 * j + c4;
-                                for (int tt = 0; tt < k; ++tt) {
-                                    const float4 v = *reinterpret_cast<const float4*>(X + xo + tt * D);
-                                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                    for (int r = 0; r < NRR; ++r)
+                        patch[((r & 3) + 8 * (r >> 2) + 4 * halfv) * PS + l31v] = v5[ten][r];
+#pragma unroll
+                    for (int i = 0; i < NR / 8; ++i) {
+                        const int row = 8 * i + (lane_v >> 3), c4 = (lane_v & 7) * 4;
+                        const int node = node0 + row;
+                        if (F || node < n) {
+                            const float4 hv = *reinterpret_cast<const float4*>(patch + row * PS + c4);
+                            if (ten == 0) {
+                                const unsigned off = (unsigned)node * D + cbase + 32 * j + c4;
+                                *reinterpret_cast<float4*>(Ht + off) = hv;
+                                if (!last) *reinterpret_cast<uint2*>(H16t + off) = make_uint2(srec_pack_bf16(hv.x, hv.y), srec_pack_bf16(hv.z, hv.w));
+                                if (last) {
+                                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    if (F || node < nl) {
+                                        const unsigned xo = (unsigned)node * k * D + cbase + 32 * j + c4;
+                                        for (int tt = 0; tt < k; ++tt) {
+                                            const float4 v = *reinterpret_cast<const float4*>(X + xo + tt * D);
+                                            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                                        }
+                                        o = make_float4(ik * o.x + 0.5f * hv.x, ik * o.y + 0.5f * hv.y, ik * o.z + 0.5f * hv.z, ik * o.w + 0.5f * hv.w);
+                                    }
+                                    *reinterpret_cast<float4*>(out + off) = o;
                                 }
-                                o = make_float4(ik * o.x + 0.5f * hv.x, ik * o.y + 0.5f * hv.y, ik * o.z + 0.5f * hv.z, ik * o.w + 0.5f * hv.w);
+                            } else {
+                                const unsigned goff = (unsigned)node * (4 * D) + cbase + 32 * j + c4;
+                                *reinterpret_cast<float4*>(Gt + goff + (ten - 1) * D) = hv;
                             }
-                            *reinterpret_cast<float4*>(out + off) = o;
                         }
                     }
                 }
@@ -314,7 +326,9 @@ extern "C" int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void
     if (n <= 0) return 0;
     if (n > 2 * GF_MAXP || W == nullptr || dst == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
     WfArgs a{};
-    a.d = d; a.jb = d / 128;
+    int nw = 4;
+    if (int rc = srec_gru_fused_waves(d, &nw)) return rc;
+    a.d = d; a.jb = d / (32 * nw);
     for (int i = 0; i < n; ++i) {
         a.W[i] = ((const float* const*)W)[i]; a.dst[i] = ((unsigned short* const*)dst)[i];
         if (a.W[i] == nullptr || a.dst[i] == nullptr) return SREC_BAD_ARG;
@@ -324,7 +338,6 @@ extern "C" int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void
     return 0;
 }
 
-extern "C" int srec_gru_fused_nodes(int np, const int* n, int* nodes);      // grufb.hip
 
 // desc: HOST srec_gru_fused_desc (srec_hg.h)
 extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
@@ -343,7 +356,7 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
     }
     // 16-node workgroups while 32-node ones would leave half of the chip idle
     int NRv = 32;
-    if (int rc = srec_gru_fused_nodes(q->np, q->n, &NRv)) return rc;
+    if (int rc = srec_gru_fused_nodes(q->np, q->n, q->d, &NRv)) return rc;
     if (NRv == 16) {
         blocks = 0;
         for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + 15) / 16; }
@@ -351,16 +364,19 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
     a.start[q->np] = blocks;
     for (int p = q->np + 1; p <= GF_MAXP; ++p) a.start[p] = blocks;
     if (blocks == 0) return 0;
-    const int JB = q->d / 128, D = q->d;
-    const size_t lds = (size_t)(2 * RT * D) * 2 + 4 * 5 * 32 * 40 * 4;
-    static std::atomic<unsigned long long> om[4];
-#define SREC_GF(JBV, NRV, slot)                                                                                        \
+    const int D = q->d;
+    int NWv = 4;
+    if (int rc = srec_gru_fused_waves(D, &NWv)) return rc;
+    const size_t lds = (size_t)(2 * RT * D) * 2 + (size_t)NWv * NRv * 40 * 4;
+    static std::atomic<unsigned long long> om[6];
+#define SREC_GF(DDV, NRV, NWV, slot)                                                                                   \
     do {                                                                                                               \
-        if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<JBV, NRV>, (int)lds, om[slot])) return rc;       \
-        hipLaunchKernelGGL((gru_fused_fwd_kernel<JBV, NRV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);    \
+        if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<DDV, NRV, NWV>, (int)lds, om[slot])) return rc;  \
+        hipLaunchKernelGGL((gru_fused_fwd_kernel<DDV, NRV, NWV>), dim3(blocks), dim3(64 * NWV), lds, (hipStream_t)stream, a); \
     } while (0)
-    if (JB == 2) { if (NRv == 16) SREC_GF(2, 16, 0); else SREC_GF(2, 32, 1); }
-    else { if (NRv == 16) SREC_GF(1, 16, 2); else SREC_GF(1, 32, 3); }
+    if (D == 256 && NWv == 8) { if (NRv == 16) SREC_GF(2, 16, 8, 4); else SREC_GF(2, 32, 8, 5); }
+    else if (D == 256) { if (NRv == 16) SREC_GF(2, 16, 4, 0); else SREC_GF(2, 32, 4, 1); }
+    else { if (NRv == 16) SREC_GF(1, 16, 4, 2); else SREC_GF(1, 32, 4, 3); }
 #undef SREC_GF
     SREC_LAUNCH_CHECK();
     return 0;

@@ -46,9 +46,12 @@ __device__ unsigned long long g_grub_blk[1024][2];
 #endif
 
 // NR: nodes per workgroup, 32 or 16 (16: the lower half of every 32-row MFMA tile idles - see gruf.hip)
-template <int JB, int NR>
-__global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
-    constexpr int D = 128 * JB, KS = D / 16, TPR = D / 4, RPP = 256 / TPR, NP = NR / RPP;
+// NW: waves per workgroup, 4 or 8 (D = 256; each wave then owns d / 8 = 32 output columns of both products - see gruf.hip)
+template <int DD, int NR, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
+    constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;   // JB: 32-column blocks per wave
+    constexpr int KS = D / 16, TPR = D / 4, RPP = NT / TPR, NP = NR / RPP;
+    static_assert(NP >= 2 && NP % 2 == 0, "phase E fetches its rows in two halves");
     constexpr int NRR = NR / 2;                  // accumulator registers per block that hold live nodes
     constexpr int PS = 32 * JB + 8;              // patch row stride (floats): rows r, r + 4 land in opposite bank halves
     extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     unsigned short* nh = ni + RT * D;            // [RT][D]
     float* dht = reinterpret_cast<float*>(nh + RT * D);         // [RT][DS] fp32: d(gh_{t+1}) W_hh, the product part of d h_t
     constexpr int DS = D + 8;                    // d h tile row stride (floats): rows r, r + 4 in opposite bank halves
-    float* patches = dht + RT * DS;              // [4 waves][RT][PS]
+    float* patches = dht + RT * DS;              // [NW waves][RT][PS]
     const srec_gru_fused_bwd_desc& q = a.d;
     int p = 0;
 #pragma unroll
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
 
     if (node0 >= nl) {                           // capacity padding: zero operands and gradients, no arithmetic
         const int rows = min(NR, n - node0);
-        for (int i = tid; i < rows * TPR; i += 256) {
+        for (int i = tid; i < rows * TPR; i += NT) {
             const int row = i / TPR, c = (i % TPR) * 4;
             const size_t node = (size_t)(node0 + row);
             for (int t = 0; t < k; ++t) {
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
                 *reinterpret_cast<float4*>(dX + (node * k + t) * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        for (int i = tid; i < 6 * D; i += 256) part[i] = 0.f;
+        for (int i = tid; i < 6 * D; i += NT) part[i] = 0.f;
         return;
     }
 
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[(erow * 16 + 12 + e) * TPR + tid % TPR] = shn[e];
     __syncthreads();
-    for (int o = tid; o < 6 * D; o += 256) {
+    for (int o = tid; o < 6 * D; o += NT) {
         // o = half * 3 D + gate * D + col; d(gh) shares its r / z sums with d(gi)
         const int hh = o / (3 * D), gate = (o % (3 * D)) / D, col = o % D;
         const int e = (hh == 1 && gate == 2 ? 12 : 4 * gate) + (col & 3);
@@ -325,6 +328,10 @@ __global__ __launch_bounds__(256, 1) void gru_fused_bwd_kernel(BwdArgs a) {
         for (int i = 0; i < 8; ++i) g_grub_tim[i] = tim_t[i];
 #endif
 }
+
+}  // namespace
+extern "C" int srec_gru_fused_waves(int d, int* waves);
+namespace {
 
 struct WfbArgs {
     int d, jb;
@@ -397,7 +404,9 @@ extern "C" int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, co
     if (n <= 0) return 0;
     if (n > 2 * GB_MAXP || W == nullptr || dst_fwd == nullptr || dst_bwd == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
     WfBothArgs a{};
-    a.d = d; a.jb = d / 128;
+    int nw = 4;
+    if (int rc = srec_gru_fused_waves(d, &nw)) return rc;
+    a.d = d; a.jb = d / (32 * nw);
     for (int i = 0; i < n; ++i) {
         a.W[i] = ((const float* const*)W)[i];
         a.dstf[i] = ((unsigned short* const*)dst_fwd)[i]; a.dstb[i] = ((unsigned short* const*)dst_bwd)[i];
@@ -420,7 +429,9 @@ extern "C" int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, vo
     if (n <= 0) return 0;
     if (n > 2 * GB_MAXP || W == nullptr || dst == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
     WfbArgs a{};
-    a.d = d; a.jb = d / 128;
+    int nw = 4;
+    if (int rc = srec_gru_fused_waves(d, &nw)) return rc;
+    a.d = d; a.jb = d / (32 * nw);
     for (int i = 0; i < n; ++i) {
         a.W[i] = ((const float* const*)W)[i]; a.dst[i] = ((unsigned short* const*)dst)[i];
         if (a.W[i] == nullptr || a.dst[i] == nullptr) return SREC_BAD_ARG;
@@ -433,12 +444,24 @@ extern "C" int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, vo
 // nodes per workgroup (16 or 32) srec_gru_fused_fwd / _bwd use for np problems of n[p] nodes: 16-node workgroups while
 // 32-node ones would leave much of the chip idle.  bias_part of srec_gru_fused_bwd holds one row per workgroup:
 // sum_p ceil(n[p] / nodes) rows.  (SREC_GRU_NR = 16 / 32: development override.)
-extern "C" int srec_gru_fused_nodes(int np, const int* n, int* nodes) {
+extern "C" int srec_gru_fused_waves(int d, int* waves) {
+    if (waves == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
+    const char* e = getenv("SREC_GRU_NW");               // development override: 4 / 8
+    const int v = e ? atoi(e) : 0;
+    *waves = d == 256 ? (v == 4 ? 4 : 8) : 4;
+    return 0;
+}
+
+extern "C" int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes) {
     if (np < 0 || np > GB_MAXP || (np > 0 && n == nullptr) || nodes == nullptr) return SREC_BAD_ARG;
+    int nw = 4;
+    if (int rc = srec_gru_fused_waves(d, &nw)) return rc;
     const char* nr_env = getenv("SREC_GRU_NR");
     const int nr_e = nr_env ? atoi(nr_env) : 0;
     int blocks = 0;
     for (int p = 0; p < np; ++p) blocks += (n[p] + RT - 1) / RT;
+    // measured at the bench shapes (ms per step, one box): 4 waves x 16 nodes 0.954, 8 x 32 0.947, 8 x 16 0.942
+    (void)nw;
     *nodes = nr_e == 16 || nr_e == 32 ? nr_e : (blocks <= 192 ? 16 : 32);
     return 0;
 }
@@ -461,23 +484,27 @@ extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
     // 16-node workgroups while 32-node ones would leave half of the chip idle (the caller sizes bias_part for either:
     // one row per 16 nodes is always enough)
     int NRv = 32;
-    if (int rc = srec_gru_fused_nodes(q->np, q->n, &NRv)) return rc;
+    if (int rc = srec_gru_fused_nodes(q->np, q->n, q->d, &NRv)) return rc;
     if (NRv == 16) {
         blocks = 0;
         for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + 15) / 16; }
     }
     for (int p = q->np; p <= GB_MAXP; ++p) a.start[p] = blocks;
     if (blocks == 0) return 0;
-    const int JB = q->d / 128, D = q->d;
-    const size_t lds = (size_t)RT * 4 * D * 2 + (size_t)RT * (D + 8) * 4 + (size_t)4 * RT * (32 * JB + 8) * 4;
-    static std::atomic<unsigned long long> om[4];
-#define SREC_GB(JBV, NRV, slot)                                                                                        \
+    const int D = q->d;
+    int NWv = 4;
+    if (int rc = srec_gru_fused_waves(D, &NWv)) return rc;
+    const int JBw = D / (32 * NWv);
+    const size_t lds = (size_t)RT * 4 * D * 2 + (size_t)RT * (D + 8) * 4 + (size_t)NWv * RT * (32 * JBw + 8) * 4;
+    static std::atomic<unsigned long long> om[6];
+#define SREC_GB(DDV, NRV, NWV, slot)                                                                                   \
     do {                                                                                                               \
-        if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<JBV, NRV>, (int)lds, om[slot])) return rc;       \
-        hipLaunchKernelGGL((gru_fused_bwd_kernel<JBV, NRV>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);    \
+        if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<DDV, NRV, NWV>, (int)lds, om[slot])) return rc;  \
+        hipLaunchKernelGGL((gru_fused_bwd_kernel<DDV, NRV, NWV>), dim3(blocks), dim3(64 * NWV), lds, (hipStream_t)stream, a); \
     } while (0)
-    if (JB == 2) { if (NRv == 16) SREC_GB(2, 16, 0); else SREC_GB(2, 32, 1); }
-    else { if (NRv == 16) SREC_GB(1, 16, 2); else SREC_GB(1, 32, 3); }
+    if (D == 256 && NWv == 8) { if (NRv == 16) SREC_GB(2, 16, 8, 4); else SREC_GB(2, 32, 8, 5); }
+    else if (D == 256) { if (NRv == 16) SREC_GB(2, 16, 4, 0); else SREC_GB(2, 32, 4, 1); }
+    else { if (NRv == 16) SREC_GB(1, 16, 4, 2); else SREC_GB(1, 32, 4, 3); }
 #undef SREC_GB
     SREC_LAUNCH_CHECK();
     return 0;

@@ -1418,7 +1418,7 @@ class GRUExpandAll(torch.autograd.Function):
         if ctx.fused:
             # every time step of every order in one launch (csrc/grufb.hip); wt16 = the fragment-major weights here
             nr_c, ns_c = _ct.c_int(0), (_ct.c_int * P)(*ns)
-            lib.srec_gru_fused_nodes(P, _ct.addressof(ns_c), _ct.addressof(nr_c))   # nodes per workgroup: one partial bias row each
+            lib.srec_gru_fused_nodes(P, _ct.addressof(ns_c), d, _ct.addressof(nr_c))   # nodes per workgroup: one partial bias row each
             nr = nr_c.value
             part = [torch.empty((ns[p] + nr - 1) // nr, 6 * d, device=dev, dtype=torch.float32) for p in range(P)]
             q = GruFusedBwdDesc()

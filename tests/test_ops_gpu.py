@@ -918,14 +918,16 @@ def test_gru_expand_all_matches_per_order_fp32_path(dev, d, padded):
             assert rel(a, b) < 2e-2, (p, nm, rel(a, b))
 
 
-@pytest.mark.parametrize('d,padded,nodes', [(256, True, 16), (128, True, 32), (256, False, 32), (128, False, 16)])
-def test_gru_fused_forward_equals_the_step_path(dev, d, padded, nodes, monkeypatch):
+@pytest.mark.parametrize('d,padded,nodes,waves', [(256, True, 16, 4), (128, True, 32, 4), (256, False, 32, 4), (128, False, 16, 4),
+                                                  (256, True, 32, 8), (256, False, 16, 8)])
+def test_gru_fused_forward_equals_the_step_path(dev, d, padded, nodes, waves, monkeypatch):
     """csrc/gruf.hip (whole recurrence in one launch: a workgroup owns 32 nodes, weights streamed fragment-major) against
     the step-by-step bf16 path (grux.hip + gemm16.hip) it replaces: same operands, same rounding points, only the order of
     the fp32 partial sums differs - outputs and every gradient of the fused backward (csrc/grufb.hip) at 1e-4 / 1e-3; both
-    workgroup sizes (16 / 32 nodes: the launcher picks by node count, SREC_GRU_NR forces one)."""
+    workgroup shapes (16 / 32 nodes, 4 / 8 waves: the launcher picks, SREC_GRU_NR / SREC_GRU_NW force one)."""
     ops = _ops()
     monkeypatch.setenv('SREC_GRU_NR', str(nodes))
+    monkeypatch.setenv('SREC_GRU_NW', str(waves))        # waves per workgroup (8: d = 256 only)
     torch.manual_seed(d + 7)
     ks, caps, lives = [2, 3], [333, 290], [333, 290]          # not multiples of the 32-node tile
     if padded:
