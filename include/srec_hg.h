@@ -157,7 +157,7 @@ typedef struct {
 /* the whole k-gram GRU forward (all time steps, up to 4 orders) in one launch: srec_gru_fused_fwd (srec.h, csrc/gruf.hip;
  * msgifsr.py:25,32-45), d = 128 or 256.  Problem p = order k[p] with n[p] nodes (live prefix *dyn[p]); x rows node-major
  * (node * k + t).  Reads X [n k, d] fp32 and the fragment-major bf16 weights of srec_gru_wfrag; writes X16 [n k, d] (bf16
- * copy of X), H [k, n, d] fp32 hidden states, H16 [k - 1, n, d] their bf16 copies (steps 0 .. k - 2), gates [k, n, 4 d] =
+ * copy of X), H [k, n, d] fp32 hidden states, H16 [k - 1, n, d] their bf16 copies (steps 0 .. k - 2), gates [k, n, 4 d] fp16 =
  * r, z, n, gh_n + b_hh_n (live rows), out [n, d] = 0.5 mean_t X[n, t, :] + 0.5 h_{k-1}; rows past the live prefix: H, H16,
  * out = 0. */
 typedef struct {
@@ -172,12 +172,12 @@ typedef struct {
     const float* bhh[SREC_GRU_MAXP];
     float* H[SREC_GRU_MAXP];
     void* H16[SREC_GRU_MAXP];
-    float* gates[SREC_GRU_MAXP];
+    void* gates[SREC_GRU_MAXP];              /* fp16 */
     float* out[SREC_GRU_MAXP];
 } srec_gru_fused_desc;
 
 /* the whole k-gram GRU backward except the weight gradients, in one launch: srec_gru_fused_bwd (srec.h, csrc/grufb.hip), d = 128
- * or 256; problems as srec_gru_fused_desc.  Reads the saved gates [k, n, 4 d] and H [k, n, d], dout [n, d] (gradient of the
+ * or 256; problems as srec_gru_fused_desc.  Reads the saved gates [k, n, 4 d] (fp16) and H [k, n, d], dout [n, d] (gradient of the
  * expander output) and the fragment-major weights of srec_gru_wfrag_t; writes dGI16 [n k, 3 d] (row node k + t) and dGH16
  * [k - 1, n, 3 d] (slot t - 1), bf16 operands of the weight-gradient GEMMs, dX [n k, d] = 0.5 dout / k + d(gi) W_ih, and one
  * row [6 d] = column sums (d gi | d gh) per 32-node workgroup into bias_part at row part_row0 + workgroup.  Rows past the live
@@ -186,7 +186,7 @@ typedef struct {
     int np, d;
     int n[SREC_GRU_MAXP], k[SREC_GRU_MAXP];
     const int* dyn[SREC_GRU_MAXP];
-    const float* gates[SREC_GRU_MAXP];
+    const void* gates[SREC_GRU_MAXP];        /* fp16, as srec_gru_fused_fwd saved them */
     const float* H[SREC_GRU_MAXP];
     const float* dout[SREC_GRU_MAXP];
     const void* Wih_f[SREC_GRU_MAXP];

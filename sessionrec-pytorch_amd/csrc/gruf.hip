@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_kernel(FusedArgs a) 
         const float ik = 0.5f / (float)k;
         float* Ht = H + (size_t)t * n * D;
         unsigned short* H16t = H16 + (size_t)t * n * D;
-        float* Gt = q.gates[p] + (size_t)t * n * 4 * D;
+        _Float16* Gt = (_Float16*)q.gates[p] + (size_t)t * n * 4 * D;       // saved as fp16: half the bytes of the largest output
         auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); };
         // (the lane id is re-derived behind an opaque asm every time step: hipcc otherwise hoists the ~250 per-element store
         // addresses out of the time loop - and spills them all to scratch)
@@ -255,7 +255,9 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_kernel(FusedArgs a) 
                                 }
                             } else {
                                 const unsigned goff = (unsigned)node * (4 * D) + cbase + 32 * j + c4;
-                                *reinterpret_cast<float4*>(Gt + goff + (ten - 1) * D) = hv;
+                                typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                                const h4_t hq = {(_Float16)hv.x, (_Float16)hv.y, (_Float16)hv.z, (_Float16)hv.w};
+                                *reinterpret_cast<h4_t*>(Gt + goff + (ten - 1) * D) = hq;
                             }
                         }
                     }

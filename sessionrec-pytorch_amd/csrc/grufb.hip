@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     const int nl = dyn_count(q.dyn[p], n);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* gates = q.gates[p];
+    const _Float16* gates = (const _Float16*)q.gates[p];        // saved as fp16 by the fused forward (values in [-1, 1] + gh_n)
     const float* H = q.H[p];
     const float* dout = q.dout[p];
     unsigned short* dGI16 = (unsigned short*)q.dGI16[p];
@@ -119,15 +119,23 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     // inputs of phase E (saved gates, h_{t-1}): the first half of the rows is fetched one step ahead, behind the d x store of
     // the step before (all of them would not fit the register file next to the products' operand ring); the
     // direct term d h_t z stays in this thread's registers (phase E of step t - 1 runs on the same (node, columns))
-    float4 pr[NP], pz[NP], pn[NP], phn[NP], php[NP], dhz[NP];
+    uint2 pr[NP], pz[NP], pn[NP], phn[NP];      // 4 fp16 each
+    float4 php[NP], dhz[NP];
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    auto h4f = [](uint2 u) {
+        const h4_t v = __builtin_bit_cast(h4_t, u);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    };
     auto fetch = [&](int t, auto LO, auto HI) {
 #pragma unroll
         for (int i = decltype(LO)::value; i < decltype(HI)::value; ++i) {
             const int node = node0 + i * RPP + erow;
-            pr[i] = pz[i] = pn[i] = phn[i] = php[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pr[i] = pz[i] = pn[i] = phn[i] = make_uint2(0u, 0u);
+            php[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (full || node < nl) {
-                const float* g = gates + ((size_t)t * n + node) * 4 * D + ec;
-                pr[i] = ld4(g); pz[i] = ld4(g + D); pn[i] = ld4(g + 2 * D); phn[i] = ld4(g + 3 * D);
+                const _Float16* g = gates + ((size_t)t * n + node) * 4 * D + ec;
+                pr[i] = *reinterpret_cast<const uint2*>(g); pz[i] = *reinterpret_cast<const uint2*>(g + D);
+                pn[i] = *reinterpret_cast<const uint2*>(g + 2 * D); phn[i] = *reinterpret_cast<const uint2*>(g + 3 * D);
                 if (t > 0) php[i] = ld4(H + ((size_t)(t - 1) * n + node) * D + ec);
             }
         }
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
             const int node = node0 + row;
             float4 dpr = make_float4(0.f, 0.f, 0.f, 0.f), dpz = dpr, dpn = dpr, dgn = dpr;
             if (full || node < nl) {
-                const float4 r = pr[i], z = pz[i], nn = pn[i], hn = phn[i], hp = php[i];
+                const float4 r = h4f(pr[i]), z = h4f(pz[i]), nn = h4f(pn[i]), hn = h4f(phn[i]), hp = php[i];
                 float4 dh;
                 if (t == k - 1) {
                     const float4 go = ld4(dout + (size_t)node * D + c);

@@ -1341,7 +1341,8 @@ class GRUExpandAll(torch.autograd.Function):
             Wih16, Whh16 = w16[0::2], w16[1::2]
         H = [torch.empty(ks[p], ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
         H16 = [torch.empty(max(ks[p] - 1, 1), ns[p], d, device=dev, dtype=torch.bfloat16) for p in range(P)]
-        gates = [torch.empty(ks[p], ns[p], 4 * d, device=dev, dtype=torch.float32) for p in range(P)]
+        # saved gates: fp16 on the fused path (values in [-1, 1] and gh_n; half the bytes of the expander's largest tensor)
+        gates = [torch.empty(ks[p], ns[p], 4 * d, device=dev, dtype=torch.float16 if ctx.fused else torch.float32) for p in range(P)]
         outs = [torch.empty(ns[p], d, device=dev, dtype=torch.float32) for p in range(P)]
         if ctx.fused:
             # the whole recurrence in one launch (csrc/gruf.hip): a workgroup owns 32 nodes, the weights stream from L2

@@ -923,7 +923,7 @@ def test_gru_expand_all_matches_per_order_fp32_path(dev, d, padded):
 def test_gru_fused_forward_equals_the_step_path(dev, d, padded, nodes, waves, monkeypatch):
     """csrc/gruf.hip (whole recurrence in one launch: a workgroup owns 32 nodes, weights streamed fragment-major) against
     the step-by-step bf16 path (grux.hip + gemm16.hip) it replaces: same operands, same rounding points, only the order of
-    the fp32 partial sums differs - outputs and every gradient of the fused backward (csrc/grufb.hip) at 1e-4 / 1e-3; both
+    the fp32 partial sums differs - outputs at 1e-4 and every gradient of the fused backward (csrc/grufb.hip) at 1.5e-3 / 3e-3; all
     workgroup shapes (16 / 32 nodes, 4 / 8 waves: the launcher picks, SREC_GRU_NR / SREC_GRU_NW force one)."""
     ops = _ops()
     monkeypatch.setenv('SREC_GRU_NR', str(nodes))
@@ -968,10 +968,12 @@ def test_gru_fused_forward_equals_the_step_path(dev, d, padded, nodes, waves, mo
         assert (got[0][p] - ref[0][p]).abs().max().item() < 1e-4
         if padded:
             assert got[0][p][lives[p]:].abs().max().item() == 0.0
-    assert rel(got[1], ref[1]) < 1e-3, ('dx', rel(got[1], ref[1]))
+    # the fused path saves its gates as fp16 (2^-11 relative; the step path fp32): 4.5e-4 on d x, 1.1e-3 on the weight gradients -
+    # below the bf16 rounding (2^-9) of the d(gi) / d(gh) operands both paths feed to the weight-gradient GEMM
+    assert rel(got[1], ref[1]) < 1.5e-3, ('dx', rel(got[1], ref[1]))
     for p in range(2):
         for a, b, nm in zip(got[2][p], ref[2][p], ('Wih', 'Whh', 'bih', 'bhh')):
-            assert rel(a, b) < 1e-3, (p, nm, rel(a, b))
+            assert rel(a, b) < 3e-3, (p, nm, rel(a, b))
 
 
 def test_lookup_with_fused_dropout(dev):
