@@ -145,6 +145,13 @@ int srec_rownorm_project_radial(const float* W, int ld_w, const float* cs, float
 int srec_col_sum(const float* X, int ld, const float* wgt, int H, int D, int n_cap, const int* dyn, int ncol,
                  float* out, int accumulate, float* ws, void* stream);
 
+/* Static per-session budgets of the one-wavefront-per-session / per-destination kernels (LDS arrays): nodes of one session in
+ * a read-out (srec_seg_attn_*), node degree per relation (srec_gat_*, srec_hg_*), in-degree in LESSR's shortcut graph
+ * (srec_sgat_*).  HOST pointers (nullable).  The reference has no such limit (DGL's degree buckets grow with the data,
+ * collate.py:87-217 builds any session length); the host mirror checks every batch against these when it is collated and
+ * raises instead of truncating (ops.check_limits). */
+int srec_limits(int* max_session_nodes, int* max_degree, int* max_degree_sgat);
+
 /* ---- per-session kernels (segops.hip): one wavefront per session ------------------------------------
  * attention readout core: srgnn.py:79-86 niser.py:77-84 lessr.py:106-113 msgifsr.py:139-146 */
 int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const float* X, int ld_x,

@@ -378,6 +378,18 @@ def collate_native(kind, seqs, order=1, caps=None):
     return FlatBatch(torch.from_numpy(buf), layout, meta)
 
 
+def _annotate_limits(fb):
+    """meta['max_deg'] = largest in- / out-degree of a node within one relation (meta['max_nodes'], the longest session's
+    node count, is set by the builders): what ops.check_limits holds against the kernels' per-session LDS budgets"""
+    md = 0
+    buf = fb.buf.numpy()
+    for name, (off, cap, _) in fb.layout.items():
+        if name.endswith(('in_ptr', 'out_ptr')) and cap > 1:
+            md = max(md, int(np.diff(buf[off:off + cap]).max()))
+    fb.meta['max_deg'] = md
+    return fb
+
+
 def _attach_labels(fb, lab):
     """append the batch's labels (int32) to the FIRST input's flat buffer as field 'labels': a captured training step then
     receives graph AND labels with one host-to-device copy and reads int32 labels in place (graph.GraphedTrainStep)"""
@@ -415,7 +427,7 @@ def collate_fn_factory(*seq_to_graph_fns, caps=None):
                     fb = collate_native(kinds[fn], seqs, 1, use) if fn in kinds else None
                     if fb is None:
                         fb = batch_homogeneous([fn(s) for s in seqs], use)
-                    inputs.append(fb)
+                    inputs.append(_annotate_limits(fb))
                 lab = _labels(labels, use)
                 if use is not None:
                     inputs[0] = _attach_labels(inputs[0], lab)
@@ -443,7 +455,7 @@ def collate_fn_factory_ccs(seq_to_graph_fns, order, caps=None):
                     fb = collate_native('ccs', seqs, order, use) if fn is seq_to_ccs_graph else None
                     if fb is None:
                         fb = batch_ccs([fn(s, order) for s in seqs], use)
-                    inputs.append(fb)
+                    inputs.append(_annotate_limits(fb))
                 lab = _labels(labels, use)
                 if use is not None:
                     inputs[0] = _attach_labels(inputs[0], lab)

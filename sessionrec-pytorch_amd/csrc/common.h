@@ -25,6 +25,14 @@ __device__ __forceinline__ unsigned short srec_f2bf(float a) { return (unsigned 
 
 #define SREC_BAD_ARG 1001
 
+// Static LDS budgets of the one-wavefront-per-session / per-destination kernels (srec_limits): the host checks a batch
+// against them when it is collated (collate.py) and before a model's forward (ops.check_limits), so an oversized session
+// is a clean error instead of a silently truncated reduction.  Sessions of <= 50 clicks (config C5) at order 3 have at
+// most 50 + 49 + 48 = 147 read-out nodes and degree <= 50.
+#define SREC_MAX_SESSION_NODES 256     // nodes of ONE session in a read-out (all n-gram orders of MSGIFSR concatenated)
+#define SREC_MAX_DEGREE 128            // in- / out-degree of a node in one relation (GAT kernels)
+#define SREC_MAX_DEGREE_SGAT 256       // in-degree in LESSR's shortcut graph (SGAT)
+
 // > 64 KiB of dynamic LDS needs hipFuncSetAttribute once PER DEVICE (function attributes are per device; one process
 // may drive several GPUs): `done` is a per-kernel bit mask indexed by the current device ordinal.
 #include <atomic>

@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int WPB = 4;
-constexpr int MAXDEG = 128;
+constexpr int MAXDEG = SREC_MAX_DEGREE;
 constexpr int MAXH = 8;
 
 // out[n,h] = sum_d X[n,h,d] * a[h,d]

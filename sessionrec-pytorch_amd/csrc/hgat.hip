@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int WPB = 4;
-constexpr int MAXDEG = 128;
+constexpr int MAXDEG = SREC_MAX_DEGREE;
 constexpr int MAXH = 8;
 constexpr int NCHUNK_C = 32;  // row chunks of the column-thread sums (hg_colsum_cols_kernel)
 constexpr int SEGCAP = 1025;   // session offsets staged in LDS by hg_agg / hg_pre (batches of up to 1024 sessions)

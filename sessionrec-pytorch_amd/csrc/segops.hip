@@ -12,7 +12,7 @@
 namespace {
 
 constexpr int WPB = 4;
-constexpr int MAXN = 256;   // max nodes of one session (host checks)
+constexpr int MAXN = SREC_MAX_SESSION_NODES;   // max nodes of one session (host checks: srec_limits)
 
 // One 256-thread workgroup per session: the 4 waves split the session's nodes for the per-node dot products
 // (float4 per lane along the hidden dim), the soft-max is one wave, the weighted sums run one column per thread.
@@ -309,5 +309,13 @@ extern "C" int srec_seg_mean_add_bwd(const float* dout, int ld_do, const int* se
     hipLaunchKernelGGL(seg_mean_add_bwd_kernel, dim3(cdiv(B, WPB)), dim3(256), 0, (hipStream_t)stream, dout, ld_do, seg,
                        B, dynB, D, dF, ld_df);
     SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// the static budgets above, for the host-side checks (collate.py / ops.check_limits)
+extern "C" int srec_limits(int* max_session_nodes, int* max_degree, int* max_degree_sgat) {
+    if (max_session_nodes != nullptr) *max_session_nodes = SREC_MAX_SESSION_NODES;
+    if (max_degree != nullptr) *max_degree = SREC_MAX_DEGREE;
+    if (max_degree_sgat != nullptr) *max_degree_sgat = SREC_MAX_DEGREE_SGAT;
     return 0;
 }

@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int WPB = 4;
-constexpr int MAXDEG = 256;
+constexpr int MAXDEG = SREC_MAX_DEGREE_SGAT;
 
 __global__ void sgat_fwd_kernel(const float* __restrict__ Q, int ld_q, const float* __restrict__ K, int ld_k,
                                 const float* __restrict__ we, const float* __restrict__ Vf, int ld_v,

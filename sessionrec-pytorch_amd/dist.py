@@ -32,49 +32,171 @@ FORCE = bool(os.environ.get('SREC_FORCE_COLLECTIVES'))
 
 
 # ------------------------------------------------------------------------------- collectives
+# `group` is a torch.distributed process group (None = the default one) OR an object with `srec_loopback = True`
+# (RecordingGroup / ReplayGroup below): the single-GPU rehearsal of one rank of an N-rank job.
+STATS = {'count': 0, 'bytes': 0}      # collectives issued through this module and their payload (bytes of the full exchanged
+#                                       buffer as this rank sees it): bench.py reports them per step
+
+
+def _loop(group):
+    return group is not None and getattr(group, 'srec_loopback', False)
+
+
 def _world(group=None):
+    if _loop(group):
+        return group.world
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
 def _rank(group=None):
+    if _loop(group):
+        return group.rank
     return dist.get_rank(group) if dist.is_initialized() else 0
+
+
+def _active(group=None):
+    """collectives are issued: more than one rank, or forced on a 1-rank communicator"""
+    return _world(group) > 1 or (FORCE and dist.is_initialized())
+
+
+def _count(nbytes):
+    STATS['count'] += 1
+    STATS['bytes'] += int(nbytes)
+
+
+def _host_staged(t, group):
+    """gloo moves host memory: device tensors are staged through the host (the W-ranks-on-one-GPU tests; production = RCCL)"""
+    return t.is_cuda and dist.get_backend(group) != 'nccl'
 
 
 def all_gather_cat(t, group=None):
     """[n, ...] per rank -> [world*n, ...] (same n everywhere)"""
-    w = _world(group)
-    if w == 1 and not (FORCE and dist.is_initialized()):
+    if not _active(group):
         return t
     t = t.contiguous()
-    out = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-    if dist.get_backend(group) == 'nccl':
-        dist.all_gather_into_tensor(out, t, group=group)
-    else:
-        dist.all_gather(list(out.chunk(w, 0)), t, group=group)
-    return out
+    _count(_world(group) * t.numel() * t.element_size())
+    return group.collective('all_gather', t) if _loop(group) else all_gather_cat_pg(t, group)
 
 
 def reduce_scatter_sum(t, group=None):
     """[world*n, ...] per rank -> [n, ...]: rank r receives the sum over ranks of block r"""
-    w = _world(group)
-    if w == 1 and not (FORCE and dist.is_initialized()):
+    if not _active(group):
         return t
     t = t.contiguous()
-    n = t.shape[0] // w
-    if dist.get_backend(group) == 'nccl':
-        out = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=group)
-        return out
-    t = t.clone()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)       # gloo has no reduce-scatter
-    r = _rank(group)
-    return t[r * n:(r + 1) * n].clone()
+    _count(t.numel() * t.element_size())
+    return group.collective('reduce_scatter', t) if _loop(group) else reduce_scatter_pg(t, group)
+
+
+def all_reduce_(t, op=None, group=None, always=False):
+    """in-place all-reduce (SUM unless `op`) through the job's backend.  always: also on a 1-rank world without FORCE"""
+    if not (_active(group) or (always and (dist.is_initialized() or _loop(group)))):
+        return t
+    op = dist.ReduceOp.SUM if op is None else op
+    _count(t.numel() * t.element_size())
+    if _loop(group):
+        t.copy_(group.collective('all_reduce:' + {dist.ReduceOp.MAX: 'MAX', dist.ReduceOp.MIN: 'MIN'}.get(op, 'SUM'), t))
+        return t
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=op, group=group)
+    return t
 
 
 def all_reduce_sum(t, group=None):
-    if _world(group) > 1 or (FORCE and dist.is_initialized()):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
+    return all_reduce_(t, None, group)
+
+
+# ---- single-GPU rehearsal of ONE rank of an N-rank job: record what the collectives returned on that rank in a real
+#      multi-process run (RecordingGroup wraps the process group), then replay that rank's step alone - eagerly or under
+#      hipGraph capture - with the recorded results standing in for the other ranks (ReplayGroup).  What a rank computes
+#      between two collectives depends only on its own inputs and on what the collectives handed it, so the replayed step
+#      runs the very kernels, with the very operands (shard offset > 0, foreign item ids, other ranks' session vectors),
+#      that the rank ran inside the job.
+class RecordingGroup:
+    srec_loopback = True
+
+    def __init__(self, group=None):
+        self.pg, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
+        self.tape = []
+
+    def collective(self, kind, t):
+        if kind == 'all_gather':
+            out = all_gather_cat_pg(t, self.pg)
+        elif kind == 'reduce_scatter':
+            out = reduce_scatter_pg(t, self.pg)
+        else:
+            out = t.clone()
+            h = out.cpu() if _host_staged(out, self.pg) else out
+            dist.all_reduce(h, op=getattr(dist.ReduceOp, kind.split(':')[1]), group=self.pg)
+            out.copy_(h)
+        self.tape.append((kind, t.detach().clone().cpu(), out.detach().clone().cpu()))
+        return out
+
+
+class ReplayGroup:
+    """answers the collectives of rank `rank` from a RecordingGroup tape (load(tape); a tape holds one step and is cycled when
+    the step is run again).  Outside stream capture every call checks that the rank hands in what it handed in when the
+    tape was made; under capture the recorded result is copied out of a static device tensor (a memcpy node in the graph
+    where the job has its RCCL call)."""
+    srec_loopback = True
+
+    def __init__(self, world, rank, device, rtol=1e-4, atol=1e-6):
+        self.world, self.rank, self.device, self.rtol, self.atol = world, rank, device, rtol, atol
+        self.kinds, self.inputs, self.outputs = [], [], []
+        self.pos = self.checked = 0
+
+    def load(self, tape):
+        self.kinds = [k for k, _, _ in tape]
+        self.inputs = [i for _, i, _ in tape]
+        self.outputs = [o.to(self.device) for _, _, o in tape]   # static device tensors: a captured copy reads them
+        self.pos = 0
+        return self
+
+    def collective(self, kind, t):
+        i = self.pos % len(self.kinds)
+        self.pos += 1
+        assert kind == self.kinds[i], 'collective %d is %s, the recorded step issued %s' % (i, kind, self.kinds[i])
+        out = self.outputs[i]
+        assert t.dtype == out.dtype, (i, kind, t.dtype, out.dtype)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            a, b = t.detach().cpu(), self.inputs[i]
+            assert a.shape == b.shape, (i, kind, a.shape, b.shape)
+            if a.dtype.is_floating_point:
+                err = (a - b).abs().max().item() if a.numel() else 0.0
+                tol = max(self.atol, self.rtol * (float(b.abs().max()) if b.numel() else 0.0))
+                assert torch.allclose(a, b, rtol=self.rtol, atol=tol), \
+                    'collective %d (%s): this rank hands in something else than in the recorded run (max |diff| %.3e)' % (i, kind, err)
+            else:
+                assert torch.equal(a, b), 'collective %d (%s): integer payload differs from the recorded run' % (i, kind)
+            self.checked += 1
+        return out.clone()
+
+
+def all_gather_cat_pg(t, pg):
+    w = dist.get_world_size(pg)
+    shape = (w * t.shape[0],) + tuple(t.shape[1:])
+    src = t.cpu() if _host_staged(t, pg) else t
+    out = torch.empty(shape, dtype=t.dtype, device=src.device)
+    if dist.get_backend(pg) == 'nccl':
+        dist.all_gather_into_tensor(out, src, group=pg)
+    else:
+        dist.all_gather(list(out.chunk(w, 0)), src, group=pg)
+    return out.to(t.device)
+
+
+def reduce_scatter_pg(t, pg):
+    w, r = dist.get_world_size(pg), dist.get_rank(pg)
+    n = t.shape[0] // w
+    if dist.get_backend(pg) == 'nccl':
+        out = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=pg)
+        return out
+    h = t.cpu() if t.is_cuda else t.clone()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=pg)
+    return h[r * n:(r + 1) * n].clone().to(t.device)
 
 
 def shard_bounds(V, world, rank):
@@ -217,6 +339,8 @@ class HipLocal:
         from ._lib import lib, ptr, stream
         B, d = sr.shape
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
+        if defer_tg is not None and not accumulate:
+            defer_tg.overwritten()                     # stale pending / radial of a backward no optimizer step consumed
         self.ops._ce_bwd(sr, table, cs, labels_local, lse, None, ga, gc, ws, None, self._tb(table, False), dE, dsr,
                          3 | (4 if accumulate else 0))
         if cs is not None and defer_tg is not None:
@@ -260,7 +384,7 @@ def _merge_stats(lse_r, lab_logit_r, group, local=None, lab_all=None):
             live = (lab_all >= 0).to(lse.dtype)
         gw = live / live.sum().clamp(min=1.0)
         return lse, lab, ((lse - lab) * gw).sum(), gw
-    if _world(group) == 1 and not (FORCE and dist.is_initialized()):
+    if not _active(group):
         return torch_merge(lse_r, lab_logit_r)
     B = lse_r.numel()
     if lse_r.is_contiguous() and lab_logit_r.is_contiguous() and lab_logit_r.data_ptr() == lse_r.data_ptr() + 4 * B \
@@ -320,6 +444,8 @@ class ShardedLookup(torch.autograd.Function):
         rel = ctx.rel
         tg = ctx.vp.tgrad if ctx.vp is not None else None
         proj = (ctx.shard, tg.radial) if (tg is not None and tg.pending is not None) else None
+        if proj is not None:
+            tg.radial_dirty = True
         for r in range(_world(ctx.group)):                   # rank by rank: distinct items within each call
             if proj is not None:
                 ctx.local.add_rows(rows_all[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], ctx.dE, proj)
@@ -433,7 +559,7 @@ class VocabParallel:
             return self.idx_cap
         t = torch.tensor([n], dtype=torch.int64, device=self.dE.device)
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            all_reduce_(t, dist.ReduceOp.MAX, self.group)
         return (int(t.item()) + 255) // 256 * 256
 
     def lookup(self, table, idx, uniq, drop=None):
@@ -494,7 +620,7 @@ class VocabParallel:
             ws = self._workspace(B, table, sr.device)
             none = torch.full((B,), -1, dtype=torch.int32, device=sr.device)
             lse_r, _ = self.local.ce_fwd(sr_all, live, csl, none, ws)
-            gathered = self.world > 1 or (FORCE and dist.is_initialized())
+            gathered = _active(self.group)
             lse = torch.logsumexp(all_gather_cat(lse_r.unsqueeze(0), self.group), dim=0).contiguous() if gathered else lse_r
             cols = self.local.logp_cols(sr_all, live, csl, lse)                    # [B, n_live]
             if gathered:
@@ -527,7 +653,7 @@ class VocabParallel:
         if kk < k:                                   # a shard with fewer than k live rows: pad with -inf
             val = torch.cat([val, val.new_full((B, k - kk), float('-inf'))], 1)
             idx = torch.cat([idx, idx.new_full((B, k - kk), 2 ** 62)], 1)
-        if self.world > 1 or (FORCE and dist.is_initialized()):
+        if _active(self.group):
             w = self.world
             val = all_gather_cat(val, self.group).view(w, B, k).permute(1, 0, 2).reshape(B, w * k)
             idx = all_gather_cat(idx, self.group).view(w, B, k).permute(1, 0, 2).reshape(B, w * k)
@@ -543,54 +669,83 @@ class VocabParallel:
     def sync_replicated_grads(self, params, optimizer=None):
         """sum the replicated-parameter gradients over ranks in ONE flat bucket whose layout is the same on every rank.
         `params` is the model's replicated parameter list (same order everywhere).  Which of them carry a gradient can
-        differ between ranks (MSHGNN only instantiates the GAT modules of relations with live edges in THIS rank's
-        batch), so the set is agreed on once - the union over ranks at the first call, a host-side all-reduce of a
-        presence mask, outside any graph capture - and from then on the bucket always holds exactly those parameters,
-        a rank without a gradient for one contributing zeros.  With `optimizer` (FusedAdam) the reduced bucket is handed
-        over as the gradient source (views), so nothing is copied back per parameter."""
-        if self.world == 1 and not (FORCE and dist.is_initialized()):
+        differ between ranks and between steps (MSHGNN only instantiates the GAT modules of relations with live edges in
+        THIS rank's batch).  The bucket holds the parameters that had a gradient on ANY rank when the layout was agreed
+        on (first call: all-reduce(MAX) of a presence mask, outside any graph capture), a rank without a gradient for one
+        contributing zeros, followed by a tail of flags that rides in the same all-reduce: one presence count per
+        bucketed parameter and one count of ranks holding a gradient for a parameter OUTSIDE the layout.  Eager steps
+        read the tail back (one host sync): a parameter nobody had a gradient for this step is skipped like on one
+        device (no weight decay on a zero gradient), and a late parameter makes every rank re-agree on the layout and
+        repeat the exchange - the same decision everywhere, because it is taken on all-reduced values.  A captured
+        step replays the layout and the skip pattern of its capture.  With `optimizer` (FusedAdam) the reduced bucket is
+        handed over as the gradient source (views), so nothing is copied back per parameter."""
+        if not _active(self.group):
             return
         params = list(params)
         key = tuple(id(p) for p in params)
-        if getattr(self, '_bucket_key', None) != key:
-            if params and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+        capturing = bool(params) and params[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        dev = params[0].device if params else self.dE.device
+
+        def agree():
+            if capturing:
                 raise RuntimeError('the gradient bucket layout must be agreed on by an eager step before graph capture')
-            dev = params[0].device if params else self.dE.device
             present = torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], device=dev)
             if self.world > 1:
-                dist.all_reduce(present, op=dist.ReduceOp.MAX, group=self.group)
-            self._bucket_live = [p for p, f in zip(params, present.tolist()) if f > 0]
+                all_reduce_(present, dist.ReduceOp.MAX, self.group)
+            old = getattr(self, '_bucket_ids', set()) if getattr(self, '_bucket_key', None) == key else set()
+            self._bucket_live = [p for p, f in zip(params, present.tolist()) if f > 0 or id(p) in old]
             self._bucket_ids = {id(p) for p in self._bucket_live}
             self._bucket_key = key
             self._bucket_zero = {}
-        ps = self._bucket_live
-        late = [p for p in params if p.grad is not None and id(p) not in self._bucket_ids]
-        if late:
-            raise RuntimeError('%d replicated parameters received a gradient on this rank that no rank had when the bucket '
-                               'layout was agreed on (a relation without edges in the first batches?)' % len(late))
-        if not ps:
-            return
-        pieces = []
-        for p in ps:
-            if p.grad is not None:
-                pieces.append(p.grad.reshape(-1))
-            else:                                      # this rank's batch gave it no gradient: zeros (static buffer)
-                z = self._bucket_zero.get(id(p))
-                if z is None:
-                    z = self._bucket_zero[id(p)] = torch.zeros(p.numel(), device=p.device, dtype=p.dtype)
-                pieces.append(z)
-        flat = torch.cat(pieces)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._bucket_flags = None
+        if getattr(self, '_bucket_key', None) != key:
+            agree()
+        for attempt in (0, 1):
+            ps = self._bucket_live
+            n_late = sum(1 for p in params if p.grad is not None and id(p) not in self._bucket_ids)
+            if n_late and capturing:
+                raise RuntimeError('%d replicated parameters carry a gradient that the captured bucket layout has no room for' % n_late)
+            pieces = []
+            for p in ps:
+                if p.grad is not None:
+                    pieces.append(p.grad.reshape(-1))
+                else:                                      # this rank's batch gave it no gradient: zeros (static buffer)
+                    z = self._bucket_zero.get(id(p))
+                    if z is None:
+                        z = self._bucket_zero[id(p)] = torch.zeros(p.numel(), device=p.device, dtype=p.dtype)
+                    pieces.append(z)
+            pat = tuple(p.grad is not None for p in ps) + (n_late,)
+            fl = self._bucket_flags
+            if fl is None or fl[0] != pat:                 # the tail changes only when this rank's presence pattern does
+                if capturing and fl is not None:
+                    raise RuntimeError('gradient presence pattern changed between the warm-up and the capture')
+                fl = self._bucket_flags = (pat, torch.tensor([1.0 if f else 0.0 for f in pat[:-1]] + [float(n_late)],
+                                                            device=dev, dtype=torch.float32))
+            flat = torch.cat(pieces + [fl[1]])
+            all_reduce_(flat, None, self.group)
+            nfl = len(ps) + 1
+            seen = None
+            if not capturing:
+                seen = flat[-nfl:].tolist()
+                if seen[-1] > 0 and attempt == 0:          # somebody holds a gradient the layout has no slot for: everybody
+                    agree()                                # sees the same count - re-agree and repeat the exchange
+                    continue
+                self._bucket_seen = seen
+            break
+        seen = getattr(self, '_bucket_seen', None)
         off = 0
         views = {}
-        for p in ps:
+        for i, p in enumerate(ps):
             n = p.numel()
-            views[id(p)] = flat[off:off + n].view_as(p)
+            if seen is None or seen[i] > 0:                # nobody had a gradient this step: skipped, as on one device
+                views[id(p)] = flat[off:off + n].view_as(p)
             off += n
         if optimizer is not None and hasattr(optimizer, 'grad_override'):
             optimizer.grad_override = views
         else:
             for p in ps:
+                if id(p) not in views:
+                    continue
                 if p.grad is None:
                     p.grad = views[id(p)].clone()
                 else:

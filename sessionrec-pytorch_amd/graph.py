@@ -130,7 +130,7 @@ class GraphedTrainStep:
         if ms is not None:
             ms['cs_fresh'] = False
             if ms.get('tgrad') is not None:
-                ms['tgrad'].fresh = False
+                ms['tgrad'].reset()                      # fresh flag, pending projection, radial sums of the warm-up
 
     @staticmethod
     def _signature(x):

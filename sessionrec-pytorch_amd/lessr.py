@@ -121,6 +121,10 @@ class LESSR(_ScoringMixin, nn.Module):
         with torch.no_grad():                    # Embedding(max_norm=1): in-place renorm before the lookup
             lib.srec_renorm_rows(ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], 1.0, stream())
         dN, dB = mg.dynp('N'), mg.dynp('B')
+        if mg.buf.is_cuda:
+            ops.check_limits(mg)
+            if sg is not None:
+                ops.check_limits(sg, 'sgat_deg')
         feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
                             dN, mg.dynp('U'))
         for i, layer in enumerate(self.layers):

@@ -303,6 +303,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
 
     def session_repr(self, mg, tgrad=None):
         K = self.order
+        if mg.buf.is_cuda:
+            ops.check_limits(mg)
         if not self.__dict__.pop('_table_ready', False):
             self._renorm(mg)
         W = self._table()

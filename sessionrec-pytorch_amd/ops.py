@@ -54,6 +54,32 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+_LIMITS = None
+
+
+def limits():
+    """static per-session budgets of the kernels (include/srec.h srec_limits)"""
+    global _LIMITS
+    if _LIMITS is None:
+        a, b, c = _ct.c_int(), _ct.c_int(), _ct.c_int()
+        lib.srec_limits(_ct.addressof(a), _ct.addressof(b), _ct.addressof(c))
+        _LIMITS = dict(nodes=a.value, deg=b.value, sgat_deg=c.value)
+    return _LIMITS
+
+
+def check_limits(mg, deg='deg'):
+    """a batch whose longest session / largest node degree exceeds what the per-session kernels hold in LDS is refused here
+    (collate records both in FlatBatch.meta): a clean error, never a silently truncated soft-max"""
+    L, m = limits(), mg.meta
+    if m.get('max_nodes', 0) > L['nodes']:
+        raise ValueError('a session of this batch has %d read-out nodes; the per-session kernels hold at most %d '
+                         '(SREC_MAX_SESSION_NODES, csrc/common.h): truncate sessions (the reference preprocessing keeps the '
+                         'last 20 clicks, preprocess.py:45-50) or lower the n-gram order' % (m['max_nodes'], L['nodes']))
+    if m.get('max_deg', 0) > L[deg]:
+        raise ValueError('a node of this batch has degree %d in one relation; the graph-attention kernels hold at most %d '
+                         '(csrc/common.h): truncate sessions' % (m['max_deg'], L[deg]))
+
+
 PRECISION = {'matmul': 'fp32'}      # 'fp32': exact fp32 MFMA everywhere; 'bf16': bf16-operand MFMA for the
                                     # forward / backward-data products and the scoring kernels (config C3)
 _WT_CACHE = {}
@@ -222,15 +248,25 @@ def cat_cols(a, b):
 
 
 # ------------------------------------------------------------------------------------------ dropout masks
-RNG_COUNTER = {}     # str(device) -> int32[1] device tensor: the optimizer's step count (FusedAdam registers it)
+RNG_COUNTER = {}     # str(device) -> int32[1] device tensor: the device-side step counter in effect.  A model installs the
+#                      counter of ITS FusedAdam at the start of every forward (srgnn._ScoringMixin._lookup); models trained
+#                      with another optimizer have none.
 
 
 def rng_args(device):
-    """(seed, counter pointer) of the counter-based dropout masks (csrc/common.h srec_rng): the host seed follows
-    torch.manual_seed, the device counter is constant inside a training step and changes between steps (also under
-    hipGraph replay, where the kernel arguments are frozen)."""
+    """(nonce, counter pointer) of the counter-based dropout masks (csrc/common.h srec_rng).  The nonce is a fresh draw
+    from torch's CPU generator per call: it follows torch.manual_seed and renews the masks on every eager forward -
+    with any optimizer, and for each of several micro-batches per optimizer step.  The callers keep it for their
+    backward, which recomputes the mask.  Under hipGraph replay the kernel arguments (the nonce) are frozen; there the
+    device counter, advanced by the captured optimizer step itself, renews the masks - a capture without one would
+    replay ONE mask for ever and is refused."""
     c = RNG_COUNTER.get(str(device))
-    return int(torch.initial_seed() & 0x7fffffff), (c.data_ptr() if c is not None else None)
+    dev = torch.device(device)
+    if c is None and dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('dropout inside a captured step needs a device-side step counter: construct FusedAdam(..., '
+                           'model=model) before capturing (a frozen nonce alone would replay the same mask every step)')
+    nonce = int(torch.randint(0, 0x7fffffff, (1,)).item())
+    return nonce, (c.data_ptr() if c is not None else None)
 
 
 class TableGrad:
@@ -248,6 +284,22 @@ class TableGrad:
         self.defer = defer
         self.pending = None
         self.radial = torch.zeros(weight.shape[0], device=weight.device, dtype=torch.float32) if defer else None
+        self.radial_dirty = False    # a lookup backward has added radial sums that no row pass has consumed yet
+
+    def overwritten(self):
+        """the scoring backward has just overwritten every row of `buf` (non-accumulating): whatever an earlier backward
+        left behind - a pending projection that no optimizer step consumed, radial sums of lookup gradients that went
+        into the old contents (a skipped / NaN-guarded step, two backwards before a step, a training loss evaluated
+        without stepping) - belongs to the old contents and goes with them"""
+        self.pending = None
+        if self.radial is not None and self.radial_dirty:     # (never in the regular backward -> step sequence: no fill
+            self.radial.zero_()                               #  kernel in a captured step)
+        self.radial_dirty = False
+
+    def reset(self):
+        """forget the current contents (optimizer.zero_grad, the undo of a graph-capture warm-up)"""
+        self.fresh = False
+        self.overwritten()
 
     def materialize(self):
         """apply a pending projection to `buf` (after it, buf is the true table gradient)"""
@@ -256,6 +308,7 @@ class TableGrad:
             lib.srec_rownorm_project_radial(ptr(table), table.stride(0), ptr(cs), float(inv_scale), ptr(self.buf),
                                             self.buf.stride(0), table.shape[0], table.shape[1], ptr(self.radial), stream())
             self.pending = None
+            self.radial_dirty = False
         return self.buf
 
 
@@ -298,6 +351,7 @@ class EmbeddingLookup(torch.autograd.Function):
         radial = ptable = None
         if tg is not None and tg.pending is not None:     # deferred projection: this gradient's radial part is recorded
             radial, ptable = tg.radial, tg.pending[0]
+            tg.radial_dirty = True
         if tg is not None:
             dst, acc, ret = tg.buf, 1, None
         else:
@@ -926,6 +980,7 @@ class ScoreCE(torch.autograd.Function):
         tg, ws = ctx.tgrad, ctx.ws
         gl = gloss.reshape(1).to(torch.float32).contiguous()
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
+        tg.overwritten()
         _ce_bwd(sr, table, cs, labels, lse, gl, None, None, ws, ctx.dynB, ctx.tb, tg.buf, dsr, 3)
         if cs is not None and tg.defer:
             tg.pending = (table, cs, ctx.cs_inv_scale)     # applied by the optimizer's row pass (or TableGrad.materialize)
@@ -967,6 +1022,8 @@ class ScoreStats(torch.autograd.Function):
         gc = (-dlab).contiguous().float()
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         parts = 3 | (4 if tg.fresh else 0)
+        if not tg.fresh:
+            tg.overwritten()
         _ce_bwd(sr, table, cs, labels, lse, None, ga, gc, ws, ctx.dynB, ctx.tb, tg.buf, dsr, parts)
         if cs is not None and tg.defer:
             tg.pending = (table, cs, ctx.cs_inv_scale)     # linear: once, over the sum of the heads' contributions

@@ -48,6 +48,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._hyper = {}            # (group index, step offset) -> device step state
         self._frozen = None         # parameter lists frozen by a captured graph
 
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+        st = self.model.__dict__.get('_srec_state') if self.model is not None else None
+        if st is not None and st.get('tgrad') is not None:
+            st['tgrad'].reset()             # incl. a deferred projection / radial sums of a backward that was never stepped
+
     # ------------------------------------------------------------------ helpers
     def _table_info(self):
         model = self.model
@@ -89,8 +95,12 @@ class FusedAdam(torch.optim.Optimizer):
                                     cfg=torch.zeros(5, dtype=torch.float64, device=device),
                                     hyper=torch.zeros(8, dtype=torch.float32, device=device), cfg_host=None,
                                     fresh=True)
-            if key == (0, 0) or str(device) not in ops.RNG_COUNTER:
-                # the dropout masks of a step are keyed by the optimizer's device-side step count (ops.rng_args)
+            if key == (0, 0):
+                # the dropout masks of a captured step are keyed by this optimizer's device-side step count (ops.rng_args):
+                # registered on the MODEL, which installs it at the start of each of its forwards - two optimizers in one
+                # process (two models) each drive their own model's masks
+                if self.model is not None:
+                    self.model.__dict__['_srec_rng_counter'] = self._hyper[key]['counter']
                 ops.RNG_COUNTER[str(device)] = self._hyper[key]['counter']
         return self._hyper[key]
 
@@ -247,6 +257,7 @@ class FusedAdam(torch.optim.Optimizer):
                                                 p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, 0, ptr(cs_out), cs_scale,
                                                 eps_mode, 1e-12, ptr(pend[1]), float(pend[2]), ptr(tgrad.radial), stream())
                         tgrad.pending = None
+                        tgrad.radial_dirty = False
                     else:
                         if tgrad is not None:
                             tgrad.materialize()

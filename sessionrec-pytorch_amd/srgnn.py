@@ -79,6 +79,14 @@ class _ScoringMixin:
         """item rows for the batch: local gather, or the collective lookup when the table is sharded.  drop: an nn.Dropout
         applied to the rows - fused into the gather kernels on the single-device path."""
         p = drop.p if isinstance(drop, nn.Dropout) and drop.training else 0.0
+        # the device step counter the dropout masks of THIS model's forward are keyed by (ops.rng_args): that of its own
+        # FusedAdam, or none (another optimizer: the per-call nonce alone renews the masks)
+        W = self._table()
+        c = self.__dict__.get('_srec_rng_counter')
+        if c is not None and c.device == W.device:
+            ops.RNG_COUNTER[str(W.device)] = c
+        else:
+            ops.RNG_COUNTER.pop(str(W.device), None)
         if self.shard is not None:
             fused = p > 0 and getattr(self.shard.local, 'fused_dropout', False)      # HipLocal: the mask rides in the gather
             rows = self.shard.lookup(self._table(), idx, uniq, (p, 7) if fused else None)
@@ -209,6 +217,8 @@ class SRGNN(_ScoringMixin, nn.Module):
 
     def session_repr(self, mg, sg=None, tgrad=None):
         dN, dB = mg.dynp('N'), mg.dynp('B')
+        if mg.buf.is_cuda:
+            ops.check_limits(mg)
         feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
                             dN, mg.dynp('U'))
         feat = self._pre(self.feat_drop(feat), dN)

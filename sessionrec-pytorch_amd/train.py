@@ -105,6 +105,17 @@ class TrainRunner:
                 # constructor has put parameters, buffers and optimizer state back: same trajectory)
                 print('hipGraph capture failed (%s: %s); eager launches' % (type(e).__name__, e))
                 self.graph = False
+            if self.shard is not None and self.shard.world > 1:
+                # the ranks decide TOGETHER: a rank replaying a captured step next to a rank that fell back to eager launches
+                # would still issue the same collectives, but a rank whose capture failed has also skipped the warm-up's
+                # exchanges - from here on either all replay or all launch eagerly
+                import torch.distributed as dist
+                from .dist import all_reduce_
+                ok = th.tensor([1.0 if self._gstep is not None else 0.0], device=self.device)
+                all_reduce_(ok, dist.ReduceOp.MIN, self.shard.group)
+                if ok.item() < 1.0:
+                    self._gstep, self.graph = None, False
+            if self._gstep is None:
                 return None
         try:
             return self._gstep(inputs, labels)

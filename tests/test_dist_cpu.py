@@ -405,14 +405,19 @@ def _bucket_worker(rank, world, port, q):
         ps[0].grad = None if rank == 0 else torch.full((3,), 7.0)
         vp.sync_replicated_grads(ps, opt)
         got2 = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps) if id(p) in opt.grad_override}
-        # a parameter outside the agreed bucket that suddenly has a gradient must fail loudly, not be dropped
-        ps[3].grad = torch.ones(5)
-        try:
-            vp.sync_replicated_grads(ps, opt)
-            late = False
-        except RuntimeError:
-            late = True
-        q.put((rank, {k: v.tolist() for k, v in got.items()}, {k: v.tolist() for k, v in got2.items()}, late))
+        # a parameter outside the agreed layout that receives a gradient later, on ONE rank only: every rank sees the
+        # all-reduced "late" count in the bucket's flag tail, re-agrees on the layout and repeats the exchange (no hang,
+        # nothing dropped)
+        if rank == 1:
+            ps[3].grad = torch.ones(5)
+        vp.sync_replicated_grads(ps, opt)
+        got3 = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps) if id(p) in opt.grad_override}
+        # a bucketed parameter nobody has a gradient for this step is skipped (one device: grad None -> no update)
+        ps[1].grad = None
+        vp.sync_replicated_grads(ps, opt)
+        got4 = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps) if id(p) in opt.grad_override}
+        q.put((rank, {k: v.tolist() for k, v in got.items()}, {k: v.tolist() for k, v in got2.items()},
+               {k: v.tolist() for k, v in got3.items()}, sorted(got4)))
     finally:
         dist.destroy_process_group()
 
@@ -431,11 +436,12 @@ def test_replicated_gradient_bucket_is_rank_independent():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, got, got2, late in res:
+    for rank, got, got2, got3, keys4 in res:
         assert sorted(got) == [0, 1, 2], got
         assert got[0] == [3.0] * 3 and got[1] == [[10.0, 10.0]] * 2 and got[2] == [100.0] * 4
-        assert got2[0] == [7.0] * 3 and got2[1] == ([[10.0, 10.0]] * 2 if True else None)
-        assert late
+        assert got2[0] == [7.0] * 3 and got2[1] == [[10.0, 10.0]] * 2
+        assert sorted(got3) == [0, 1, 2, 3] and got3[3] == [1.0] * 5 and got3[0] == [7.0] * 3, got3
+        assert keys4 == [0, 2, 3], keys4
 
 
 def test_bench_gpus_flag_launches_that_many_ranks():
