@@ -229,6 +229,60 @@ def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=12.0, dr
                        % (n, B, model_name, V, d, cores))
 
 
+def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4):
+    """The metric as the reference's loop defines it (train.py:92-110): wall time of `for batch in train_loader:` -
+    DataLoader worker processes building the session graphs (native collate, csrc/collate.cpp), pinned batches, the
+    asynchronous H2D copy, and the hipGraph replay of the whole step inside TrainRunner.train_step - on the same synthetic
+    split, the launcher's own capacities (collate.estimate_caps) and loader settings (main_msgifsr.py:148-166: sequential,
+    4 workers, pin_memory).  The first `warm` batches (worker start-up, graph capture) are outside the timed region."""
+    from torch.utils.data import DataLoader, SequentialSampler
+    ds = importlib.import_module('sessionrec-pytorch_amd.dataset')
+    col = importlib.import_module('sessionrec-pytorch_amd.collate')
+    train = importlib.import_module('sessionrec-pytorch_amd.train')
+    rng = np.random.default_rng(321)
+    sessions = synth_sessions(int(n_batches * B / 4.5) + 64, V, 6.2, 20, rng)
+    arr = np.empty(len(sessions), dtype=object)
+    arr[:] = sessions
+    data = ds.AugmentedDataset(arr)
+    n_batches = min(n_batches, len(data) // B)
+    data.index = data.index[:n_batches * B]
+    caps = col.estimate_caps(data, B)
+    if args.model in ('SRGNN', 'NISER'):
+        fn = col.collate_fn_factory(col.seq_to_session_graph, caps=caps)
+    elif args.model == 'LESSR':
+        fn = col.collate_fn_factory(col.seq_to_eop_multigraph, caps=caps)
+    else:
+        fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), args.order, caps=caps)
+    loader = DataLoader(data, batch_size=B, sampler=SequentialSampler(data), num_workers=workers, collate_fn=fn,
+                        pin_memory=True, persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
+    torch.manual_seed(123)
+    model = build_model(sp, args.model, V, d, args.order, args.dropout)
+    model.load_state_dict(state)
+    model = model.to(dev).train()
+    runner = train.TrainRunner('synthetic', model, loader, None, device=dev, lr=1e-3, weight_decay=1e-4)
+    it = iter(loader)
+    loss = None
+    for _ in range(warm):
+        inputs, labels = train.prepare_batch(next(it), dev)
+        loss = runner.train_step(inputs, labels)
+    torch.cuda.synchronize()
+    g0, e0 = runner.graph_steps, runner.eager_steps
+    n, t0 = 0, time.perf_counter()
+    for batch in it:
+        inputs, labels = train.prepare_batch(batch, dev)
+        loss = runner.train_step(inputs, labels)
+        n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    final = float(loss.item())
+    del it, loader
+    return dict(value=n * B / dt, unit='sessions/s', ms_per_step=dt / n * 1e3, steps=n, workers=workers, collate='native'
+                if col._native() is not None else 'python', pinned=True, caps=caps,
+                graph_steps=runner.graph_steps - g0, eager_steps=runner.eager_steps - e0, final_loss=final,
+                note='wall time of the DataLoader loop (train.py:92-110 equivalent): worker collate + pinned H2D copy + '
+                     'hipGraph replay per batch, evaluation excluded')
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -357,6 +411,8 @@ def main():
                          'train.py:94-101); rank r encodes the contiguous slice r of every global batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 side run (the reference arithmetic) of the same step')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the DataLoader-inclusive run of the same workload')
+    ap.add_argument('--e2e-workers', type=int, default=4, help='DataLoader worker processes of the end-to-end run')
     ap.add_argument('--dropout', type=float, default=0.1,
                     help='MSGIFSR feature / attention dropout (0.1 = --feat-drop default of the reference launcher, main_msgifsr.py:42)')
     ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
@@ -372,7 +428,7 @@ def main():
                          'gloo on a box without GPUs)')
     args = ap.parse_args()
     if args.step_only:
-        args.no_cpu_baseline = args.no_fp32 = True
+        args.no_cpu_baseline = args.no_fp32 = args.no_end_to_end = True
         args.repeats = 1
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -479,6 +535,23 @@ def main():
         return model, shard, step, graphed, gstep
 
     model, shard, step, graphed, gstep = setup(args.precision)
+    # every rank contributes 1 through the job's own backend (RCCL): the sum is the number of ranks the collectives reach
+    ranks_seen = 1
+    if dist is not None:
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
+    coll = None
+    if shard is not None:
+        D = importlib.import_module('sessionrec-pytorch_amd.dist')
+        if graphed and getattr(gstep, 'collectives', None):
+            coll = dict(gstep.collectives, captured_in_graph=True)
+        else:
+            D.STATS['count'] = D.STATS['bytes'] = 0
+            step(dev_batches[0])
+            coll = dict(D.STATS, captured_in_graph=False)
+        coll['per'] = 'training step and rank'
+        coll['backend'] = dist.get_backend()
     regions, loss = run_timed(step, dev_batches, args.warmup, args.steps, max(args.repeats, 1), dist, dev)
     final_loss = loss.item()
     dt = sorted(regions)[len(regions) // 2]              # median region
@@ -495,6 +568,12 @@ def main():
                     launch='hipGraph replay' if g32 else 'eager')
         del m32, s32, step32
         ops.set_precision(args.precision)
+
+    e2e = None
+    if not args.no_end_to_end and world == 1 and not args.shard:
+        ops.set_precision(args.precision)
+        e2e = end_to_end(args, sp, state, V, d, B, dev, workers=args.e2e_workers)
+        e2e['vs_value'] = e2e['value'] / (Bg * args.steps / dt)
 
     if rank == 0 and args.step_only:
         emit(dict(step_only=True, ms_per_step=dt / args.steps * 1e3, value=Bg * args.steps / dt, launches=nodes,
@@ -551,7 +630,7 @@ def main():
             cpu = cpu_baseline(args.model, full, V, d, args.order, state, dropout=args.dropout)
         scaling = 'strong' if strong else 'weak'
         out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=Bg * args.steps / dt,
-                   unit='sessions/s', n_gpus=world, ranks_seen=(dist.get_world_size() if dist is not None else 1),
+                   unit='sessions/s', n_gpus=world, ranks_seen=ranks_seen, collectives=coll,
                    steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, repeats_ms_per_step=ms, spread_ms=max(ms) - min(ms),
                    higher_is_better=True, scaling=scaling, vs_baseline=None,
@@ -562,7 +641,7 @@ def main():
                                global_batch=Bg, parallelism=('item table row-sharded x%d (vocab-parallel scoring, RCCL all-gather/reduce-scatter), '
                                             'encoder replicated, %s' % (world, 'each rank encodes its slice of one 512-session batch' if strong else 'each rank feeds its own batch')) if world > 1 else 'single GPU',
                                final_loss=final_loss),
-                   roofline=roof, fp32=fp32, cpu_baseline=cpu)
+                   roofline=roof, fp32=fp32, end_to_end=e2e, cpu_baseline=cpu)
         emit(out)
     if dist is not None:
         dist.barrier()                      # the other ranks wait for rank 0's kernel timing / CPU baseline

@@ -96,10 +96,15 @@ __global__ __launch_bounds__(1024) void hg_fold_kernel(FoldArgs a) {
         a.V[m][(size_t)c * H + h] = sl;
         a.V[m][(size_t)(D + c) * H + h] = sr;
     }
-    if (jg == 1 && c < D && m < a.nt && a.bsum[m] != nullptr) {
-        float b = 0.f;
-        for (int q = 0; q < a.tn[m]; ++q) b += a.tb[m][q][h * D + c];      // instance order = the order hg_agg used
-        a.bsum[m][h * D + c] = b;
+    if (jg == 1 && c < D) {
+        // node types are dealt to the module workgroups round-robin: a tiny batch may have fewer live modules than types
+        const int nmods = (int)gridDim.x / H;
+        for (int t = m; t < a.nt; t += nmods) {
+            if (a.bsum[t] == nullptr) continue;
+            float b = 0.f;
+            for (int q = 0; q < a.tn[t]; ++q) b += a.tb[t][q][h * D + c];  // instance order = the order hg_agg used
+            a.bsum[t][h * D + c] = b;
+        }
     }
 }
 
@@ -880,7 +885,6 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         f.H = H; f.D = D;
         for (int m = 0; m < d->n_mods; ++m) { f.W[m] = d->W[m]; f.al[m] = d->attn_l[m]; f.ar[m] = d->attn_r[m]; f.V[m] = d->V[m]; }
         // bias sums per node type, kept in the first H D floats of the backward's Z scratch (free during the forward)
-        if (d->n_types > d->n_mods) return SREC_BAD_ARG;
         f.nt = d->n_types;
         for (int t = 0; t < d->n_types; ++t) { f.tn[t] = 0; f.bsum[t] = d->Z[t]; }
         for (int i = 0; i < d->n_inst; ++i) {
@@ -888,6 +892,9 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
             if (f.tn[t] >= 8) return SREC_BAD_ARG;
             f.tb[t][f.tn[t]++] = d->bias[d->inst_mod[i]];
         }
+        // (the caller provides Z slots for max(n_mods, n_types): a batch of very short sessions has fewer live modules than types)
+        for (int t = 0; t < d->n_types; ++t)
+            if (f.tn[t] > 0 && f.bsum[t] == nullptr) return SREC_BAD_ARG;
         hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H), dim3(1024), 0, st, f);
     }
     if (d->n_blocks > 0) {

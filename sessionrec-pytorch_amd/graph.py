@@ -65,6 +65,8 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
         self._pending_advance = None
         work = None
+        from . import dist as _dist
+        c0 = dict(_dist.STATS)
         try:
             with torch.cuda.graph(self.graph):
                 self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
@@ -84,6 +86,8 @@ class GraphedTrainStep:
             self._restore(model, optimizer, snap_p, snap_b, snap_o)
             optimizer.zero_grad(set_to_none=True)
             raise
+        # collectives captured inside the step (row-sharded table): count and payload bytes of ONE step
+        self.collectives = {k: _dist.STATS[k] - c0[k] for k in c0}
         for _, _, items in work:
             for _, _, st in items:
                 st['step'] -= 1

@@ -2006,7 +2006,8 @@ class HgPlan:
             for nm in ('eL', 'eR', 'wL', 'wR'):
                 lay[(nm, b)] = off
                 off += n
-        for m in range(len(self.modules)):
+        # (Z slot t < n_types also holds the summed bias row of node type t during the forward: slots for max(modules, types))
+        for m in range(max(len(self.modules), len(self.types))):
             for nm in ('V', 'Z'):
                 lay[(nm, m)] = off
                 off += 2 * self.D * H
@@ -2043,6 +2044,8 @@ class HgPlan:
             if dP is not None:
                 d.dP[m] = ptr(dP[m])
                 d.d_attn_l[m], d.d_attn_r[m], d.d_bias[m] = (grads[m, j].data_ptr() for j in range(3))
+        for m in range(len(self.modules), len(self.types)):
+            d.Z[m] = base + 4 * lay[('Z', m)]
         for b, (m, t) in enumerate(self.blocks):
             d.blk_mod[b], d.blk_type[b] = m, t
             d.blk_row[b] = self.types[t][0] - self.modules[m][0]

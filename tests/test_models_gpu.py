@@ -526,18 +526,25 @@ def test_cosine_scale_follows_the_max_norm_renorm(dev, name):
         close(model(*inputs)[:len(olab)], ref(*oin), rtol=1e-4, atol=1e-4, what='log-probs after training')
 
 
-@pytest.mark.parametrize('dropout', [0.0, 0.2])
-def test_msgifsr_bf16_gemm16_path_at_d64(dev, dropout):
+@pytest.mark.parametrize('d,dropout,big', [(64, 0.0, False), (64, 0.2, False), (128, 0.0, False), (128, 0.2, False),
+                                            (256, 0.0, False), (256, 0.2, False), (256, 0.1, True), (128, 0.0, True)])
+def test_msgifsr_bf16_gemm16_path_against_the_oracle(dev, d, dropout, big):
     """d % 64 == 0 routes the GAT projections through the bf16-in-HBM GEMMs (csrc/gemm16.hip) - the path the benchmark
-    runs at d = 256; the d = 32 fixtures take the register-staged kernels.  MSGIFSR K3 at d = 64 against the fp32 CPU
-    oracle at the bf16 tolerance of SURVEY 8(c) (loss 5e-3 rel, encoder gradients 3e-2 norm-wise, direction cos > 0.97);
-    with dropout the product's masks are replayed in the oracle."""
+    runs at d = 256; the d = 32 fixtures take the register-staged kernels.  d = 128 / 256 also take the kernels that exist
+    only at those widths: the fused k-gram GRU recurrence (gruf.hip / grufb.hip, fp16 saved gates) and the 128 x 128
+    gemm16 tiles.  MSGIFSR K3 against the fp32 CPU oracle (msgifsr.py:241-273) at the bf16 tolerance of SURVEY 8(c)
+    (loss 5e-3 rel, encoder gradients 3e-2 norm-wise, direction cos > 0.97); with dropout the product's masks are
+    replayed in the oracle.  big: 512 synthetic sessions (the benchmarked batch size: full tiles, several workgroups per
+    kernel) instead of the fixture's 32."""
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import collate_ref as oc, models_ref as om
     sp, ops = pkg(), pkg('ops')
     z, samples, _ = load_golden('msgifsr_K3_s32')
-    K, d, H, V = 3, 64, 8, 3429
+    K, H, V = 3, 8, 3429
+    if big:
+        from dist_gpu_worker import synth_samples
+        samples = synth_samples(512, V, 11)
     torch.manual_seed(123)
     ref = om.MSGIFSR(V, 'sample', d, 1, dropout=dropout, order=K, extra=False, fusion=False)
     model = sp.MSGIFSR(V, 'sample', d, 1, dropout=dropout, order=K, extra=False, fusion=False)
@@ -549,6 +556,8 @@ def test_msgifsr_bf16_gemm16_path_at_d64(dev, dropout):
     (og,), olab = oc.collate_fn_factory_ccs((oc.seq_to_ccs_graph,), K)(samples)
     og, olab = om.to_torch(og), torch.from_numpy(olab)
     masks = None
+    if d >= 128:
+        assert ops.gru_fused_ok(d, K - 1), 'the fused GRU kernels must be the ones under test at d = %d' % d
     ops.set_precision('bf16')
     ops.DROP_TAP = []
     try:
