@@ -152,7 +152,7 @@ class ReplayGroup:
         self.kinds = [k for k, _, _ in tape]
         self.inputs = [i for _, i, _ in tape]
         self.outputs = [o.to(self.device) for _, _, o in tape]   # static device tensors: a captured copy reads them
-        self.pos = 0
+        self.pos = self.checked = 0
         return self
 
     def collective(self, kind, t):

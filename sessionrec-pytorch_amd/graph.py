@@ -16,7 +16,17 @@ from .batch import FlatBatch
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, inputs, labels, after_backward=None, warmup=2):
-        """inputs: list of capacity-padded FlatBatch on the GPU (their layout fixes the graph), labels (B,)"""
+        """inputs: list of capacity-padded FlatBatch on the GPU (their layout fixes the graph), labels (B,).
+
+        No tensor that carries the autograd graph of an EARLIER forward of `model` may be alive when this is called (a loss
+        kept in a variable, an activation stored on a module): such a graph keeps the parameters' AccumulateGrad nodes -
+        and the stream they were created on, typically the default stream - alive, autograd then synchronises the
+        capturing stream with that stream inside the capture, and hipStreamEndCapture crashes (PyTorch warns about
+        exactly this: "may ... break CUDA graph capture if the AccumulateGrad node's stream is the default stream").
+        `del loss` / `.detach()` what you keep.  The warm-up below and the capture share ONE side stream, so graphs the
+        warm-up leaves behind are harmless."""
+        import gc
+        gc.collect()                                     # reference cycles that still hold an earlier forward's graph
         assert all(x.meta.get('padded') for x in inputs), 'graph capture needs capacity-padded batches (collate caps=...)'
         self.model, self.opt, self.after_backward = model, optimizer, after_backward
         self.static_inputs = [FlatBatch(x.buf.clone(), x.layout, dict(x.meta)) for x in inputs]
@@ -33,8 +43,8 @@ class GraphedTrainStep:
         snap_p = [p.detach().clone() for p in model.parameters()]
         snap_b = [b.detach().clone() for b in model.buffers()]
         T0 = getattr(optimizer, '_T', 0)
+        s = self._stream = torch.cuda.Stream()
         try:
-            s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(warmup):
@@ -67,19 +77,28 @@ class GraphedTrainStep:
         work = None
         from . import dist as _dist
         c0 = dict(_dist.STATS)
+        err = None
         try:
-            with torch.cuda.graph(self.graph):
-                self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
-                self.loss.backward(self._one)
-                if self.after_backward is not None:
-                    self.after_backward()
-                work = optimizer._work()
-                optimizer._frozen = work
-                # the step counters that matter live on the device and are advanced by the captured step itself; the
-                # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
-                # capture and take it back afterwards
-                optimizer.advance(work)
-                optimizer.launch(work)
+            with torch.cuda.graph(self.graph, stream=self._stream):
+                try:
+                    self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
+                    self.loss.backward(self._one)
+                    if self.after_backward is not None:
+                        self.after_backward()
+                    work = optimizer._work()
+                    optimizer._frozen = work
+                    # the step counters that matter live on the device and are advanced by the captured step itself; the
+                    # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
+                    # capture and take it back afterwards
+                    optimizer.advance(work)
+                    optimizer.launch(work)
+                except BaseException as e:               # leave the capture context normally and raise afterwards: the undo
+                    err = e                              # below must not run while the stream is still capturing
+                    if os.environ.get('SREC_DEBUG_CAPTURE'):
+                        import traceback
+                        traceback.print_exception(type(e), e, e.__traceback__)
+            if err is not None:
+                raise err
         except BaseException:
             # capture refused: nothing ran on the device, but host bookkeeping may be half advanced - undo it all
             optimizer._frozen = None

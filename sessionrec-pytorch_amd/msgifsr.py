@@ -100,8 +100,14 @@ class MSHGNN(nn.Module):
         return (f(name + '_out_ptr'), f(name + '_out_idx'), f(name + '_in_ptr'), f(name + '_in_idx'),
                 f(name + '_dst'), f(name + '_src'))
 
-    def plan(self, mg, D):
-        """static topology of this layer for one FlatBatch (ops.HgPlan): types, modules, projection blocks, instances"""
+    def plan(self, mg, D, all_rels=False):
+        """static topology of this layer for one FlatBatch (ops.HgPlan): types, modules, projection blocks, instances.
+        all_rels: treat every relation of the schema as live, also one without edges in THIS batch.  HeteroGraphConv
+        skips a relation that has no edges in the (whole) batch, and a relation that is not skipped gives EVERY
+        destination node its identity residual and bias, edges or not (gatconv.py:306-311) - a session's result depends
+        on whether some other session of the batch has such an edge.  A rank of a multi-GPU job encodes a slice of the
+        global batch, so "live" must mean live in the GLOBAL batch: any training batch has edges of every relation
+        somewhere (one session of order + 1 clicks suffices), hence all relations, with no per-step exchange of flags."""
         K = self.order
         types, r = [], 0
         for k in range(1, K + 1):
@@ -111,7 +117,7 @@ class MSHGNN(nn.Module):
         NT = r
         mods, mod_id, blocks, blk_id, insts, params, mod_conv = [], {}, [], {}, [], [], []
         used = {}                                            # (conv index, etype) -> set of node types it touches
-        live = [((s, et, d_), name) for (s, et, d_), name in mg.meta['rels'] if mg.count('E_' + name) > 0]
+        live = [((s, et, d_), name) for (s, et, d_), name in mg.meta['rels'] if all_rels or mg.count('E_' + name) > 0]
         for ci in (0, 1):
             for (s, et, d_), name in live:
                 used.setdefault((ci, et), set()).update((s, d_))
@@ -141,9 +147,9 @@ class MSHGNN(nn.Module):
         plan.layer_id = getattr(self, '_layer_id', 0)
         return plan, params
 
-    def forward_stacked(self, mg, x):
+    def forward_stacked(self, mg, x, all_rels=False):
         """x: [NT, d] node features of all orders stacked (order-1 rows first) -> [NT, d]; one batched pass"""
-        plan, params = self.plan(mg, x.shape[1])
+        plan, params = self.plan(mg, x.shape[1], all_rels)
         mod = self.conv1.mods['intra1']
         drop = (mod.feat_drop, mod.attn_drop) if self.training and (mod.feat_drop > 0 or mod.attn_drop > 0) else None
         return ops.hgat_layer(x, plan, params, drop)
@@ -338,13 +344,19 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         else:
             for k in range(1, K + 1):
                 feats[k] = ops.normalize(raw[k], 0, mg.dynp('N%d' % k)) if self.norm else raw[k]
-        self._s1_feat = feats[1]                           # the session's own item rows (normalised): `extra` in-session logits
+        # the session's own item rows (normalised): `extra` in-session logits.  Kept ONLY for `extra`: a tensor stored on the
+        # module keeps the autograd graph of the last forward alive, and with it the AccumulateGrad nodes of every parameter
+        # upstream (the k-gram GRUs) together with the stream they were created on - an eager step on the default stream
+        # followed by a hipGraph capture then makes the engine synchronise the capturing stream with the default stream and
+        # hipStreamEndCapture crashes (found by tests/test_dist_gpu.py's replayed rank)
+        self._s1_feat = feats[1] if self.extra else None
         if len(self.layers) > 0:
             # all orders stacked once; every layer is one batched pass over all relations (ops.hgat_layer)
             stacked = stacked0 if stacked0 is not None else (
                 feats[1] if K == 1 else torch.cat([feats[k] for k in range(1, K + 1)], 0))
+            multi = self.shard is not None and self.shard.world > 1       # (see MSHGNN.plan: live = live in the GLOBAL batch)
             for layer in self.layers:
-                stacked = layer.forward_stacked(mg, stacked)
+                stacked = layer.forward_stacked(mg, stacked, multi)
             if self.norm:
                 stacked = ops.normalize(stacked, 0, mg.dynp('N1') if K == 1 else None)   # padded rows are exact zeros
         else:

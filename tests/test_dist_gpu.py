@@ -145,10 +145,10 @@ def test_sharded_ranks_on_one_gpu_match_the_single_device_step(dev, tmp_path, na
     counts = {out['steps'][1]['collectives']['count'] for out in res}
     assert len(counts) == 1 and min(counts) >= 5, counts
     if opts.get('dead'):
-        # the short-session rank had no gradient for the GAT modules of the relations its batch lacks ...
-        assert any('intra3' in k or 'intra2' in k for k in res[1]['steps'][0]['local_none']), res[1]['steps'][0]['local_none']
-        assert not any('intra3' in k for k in res[0]['steps'][0]['local_none'])
-        # ... and still ends on the single-device parameters (checked by _compare through the zero-filled bucket slots)
+        # the short-session rank has no edges of the higher-order relations; in a multi-rank job every relation of the schema
+        # counts as live (it is, in the global batch: msgifsr.MSHGNN.plan), so its nodes still get those relations' residual
+        # and bias terms and the rank still lands on the single-device parameters (checked by _compare)
+        assert any('intra3' in k for k in ref[0]['grads'])
 
 
 @pytest.mark.parametrize('precision,world', [('fp32', 2), ('bf16', 2), ('bf16', 8)])
@@ -193,6 +193,7 @@ def test_one_rank_of_the_job_replayed_under_hipgraph_capture(dev, tmp_path, name
     opt.step()
     assert group.pos == len(group.kinds) and group.checked == len(group.kinds)
     assert abs(loss.item() - job['steps'][0]['loss']) <= 1e-6 * max(1.0, abs(job['steps'][0]['loss']))
+    del loss          # (a live loss of an eager default-stream step must not outlive into the capture: graph.GraphedTrainStep)
     close(model._table().detach()[:vp.n_live], job['steps'][0]['table'], rtol=1e-6, atol=1e-7, what='table rows after the eager step')
     # step 2, captured (one eager warm-up lap with checks, one capture lap) and replayed
     group.load(job['steps'][1]['tape'])

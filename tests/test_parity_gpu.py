@@ -72,7 +72,7 @@ def _long_sessions(n, V, lo, hi, seed, hub=False):
     for _ in range(n):
         L = int(rng.integers(lo, hi + 1))
         # a small item pool per session: revisits, repeated 2- and 3-grams, nodes of high degree
-        pool = rng.integers(0, V, size=max(3, L // 3))
+        pool = rng.integers(0, V, size=max(3, int(L * 0.7)))
         seq = pool[rng.integers(0, len(pool), size=L)].tolist()
         out.append((seq, int(rng.integers(0, V))))
     return out
@@ -86,7 +86,7 @@ def test_sessions_of_up_to_50_clicks_match_the_oracle(dev, kind):
     model, ref, fn, ofn = _pair(kind, V, d)
     samples = _long_sessions(12, V, 35, 50, 3) + [([5], 9), ([7, 7, 7, 7], 1)]
     inputs, _ = fn(samples)
-    assert inputs[0].meta['max_nodes'] > 25 and inputs[0].meta['max_deg'] >= 2
+    assert inputs[0].meta['max_nodes'] >= 20 and inputs[0].meta['max_deg'] >= 2, inputs[0].meta
     _step_vs_oracle(dev, model, ref, fn, ofn, samples, kind + ' len<=50')
 
 
