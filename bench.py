@@ -100,6 +100,10 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False
             mxU = max(mxU, cnt.get('U', 1))
         r256 = lambda v: (v + 255) // 256 * 256
         caps = dict(B=B, N=r256(mxN), E=r256(mxE), U=r256(mxU))
+        if os.environ.get('SREC_BENCH_CAPS'):              # experiment: looser capacities (what a launcher's estimate gives)
+            c = int(os.environ['SREC_BENCH_CAPS'])
+            caps = dict(B=B, N=max(c, caps['N']), E=max(c, caps['E']), U=max(c, caps['U']))
+        print('bench caps', caps, file=sys.stderr)
     fn = factory(caps)
     return [fn(s) for s in mine], samples
 
@@ -246,7 +250,8 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
     data = ds.AugmentedDataset(arr)
     n_batches = min(n_batches, len(data) // B)
     data.index = data.index[:n_batches * B]
-    caps = col.estimate_caps(data, B)
+    caps = (col.estimate_caps(data, B) if args.model == 'LESSR' else                     # the launcher's own capacities
+            col.measure_caps(data, B, 'ccs' if args.model == 'MSGIFSR' else 'session', args.order))   # (src/scripts/common.py)
     if args.model in ('SRGNN', 'NISER'):
         fn = col.collate_fn_factory(col.seq_to_session_graph, caps=caps)
     elif args.model == 'LESSR':
@@ -260,25 +265,52 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
     model.load_state_dict(state)
     model = model.to(dev).train()
     runner = train.TrainRunner('synthetic', model, loader, None, device=dev, lr=1e-3, weight_decay=1e-4)
+    probe = None
+    if getattr(args, 'e2e_probe', False):
+        # where the loop's time goes: (a) the loader alone (worker collate + pinning, nothing consumed on the GPU), (b) the
+        # training step fed from pre-collated pinned batches (no loader: host-side step overhead + H2D + replay)
+        it0 = iter(loader)
+        for _ in range(warm):
+            next(it0)
+        t0, nb = time.perf_counter(), 0
+        held = []
+        for batch in it0:
+            nb += 1
+            if len(held) < 64:
+                held.append(batch)
+        t_loader = (time.perf_counter() - t0) / max(nb, 1)
+        del it0
+        probe = dict(loader_only_ms_per_batch=t_loader * 1e3)
     it = iter(loader)
     loss = None
     for _ in range(warm):
-        inputs, labels = train.prepare_batch(next(it), dev)
+        inputs, labels = next(it)
         loss = runner.train_step(inputs, labels)
     torch.cuda.synchronize()
     g0, e0 = runner.graph_steps, runner.eager_steps
     n, t0 = 0, time.perf_counter()
-    for batch in it:
-        inputs, labels = train.prepare_batch(batch, dev)
+    for batch in it:                                      # TrainRunner.train's loop body (train.py:94-101)
+        inputs, labels = batch
         loss = runner.train_step(inputs, labels)
         n += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     final = float(loss.item())
+    if probe is not None:
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(256):
+                inputs, labels = held[i % len(held)]
+                loss = runner.train_step(inputs, labels)
+            t_host = time.perf_counter() - t0                 # host has issued 256 steps
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+        probe.update(precollated_ms_per_step=t_all / 256 * 1e3, precollated_host_issue_ms_per_step=t_host / 256 * 1e3)
     del it, loader
     return dict(value=n * B / dt, unit='sessions/s', ms_per_step=dt / n * 1e3, steps=n, workers=workers, collate='native'
                 if col._native() is not None else 'python', pinned=True, caps=caps,
-                graph_steps=runner.graph_steps - g0, eager_steps=runner.eager_steps - e0, final_loss=final,
+                graph_steps=runner.graph_steps - g0, eager_steps=runner.eager_steps - e0, final_loss=final, probe=probe,
                 note='wall time of the DataLoader loop (train.py:92-110 equivalent): worker collate + pinned H2D copy + '
                      'hipGraph replay per batch, evaluation excluded')
 
@@ -413,6 +445,7 @@ def main():
     ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 side run (the reference arithmetic) of the same step')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the DataLoader-inclusive run of the same workload')
     ap.add_argument('--e2e-workers', type=int, default=4, help='DataLoader worker processes of the end-to-end run')
+    ap.add_argument('--e2e-probe', action='store_true', help='end-to-end run: also time the loader alone and the step fed from pre-collated batches')
     ap.add_argument('--dropout', type=float, default=0.1,
                     help='MSGIFSR feature / attention dropout (0.1 = --feat-drop default of the reference launcher, main_msgifsr.py:42)')
     ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16'],

@@ -100,6 +100,7 @@ typedef struct {
                                       row count is *dyn: live rows here = clamp(*dyn - koff, 0, K) (row-split products) */
     int nsplit[SREC_G16_MAXP];     /* tn only (0 / 1 = off): split the reduction rows into nsplit pieces (64-row multiples), piece
                                       s writing its own slab C + s * M * ldc (caller sums the slabs: srec_sum_slabs_multi) */
+    int lda_p[SREC_G16_MAXP], ldb_p[SREC_G16_MAXP], ldc_p[SREC_G16_MAXP];   /* per-problem leading dimensions; 0 = the group's */
 } srec_gemm16_group;
 
 /* problem table of srec_gemm_f32_group_run (srec.h, csrc/gemm.hip): up to 16 independent exact-fp32 products, each with

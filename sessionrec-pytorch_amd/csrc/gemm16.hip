@@ -38,6 +38,7 @@ struct G16Args {
     const int* dyn[G16_MAXP];
     int M[G16_MAXP], N[G16_MAXP], K[G16_MAXP], nseg[G16_MAXP], koff[G16_MAXP], nsplit[G16_MAXP], start[G16_MAXP + 1];
     int np, lda, ldb, ldc;
+    int ldap[G16_MAXP], ldbp[G16_MAXP], ldcp[G16_MAXP];   // per-problem leading dimensions (the group's lda / ldb / ldc unless overridden)
     float beta;
     int keep_dead;                // leave output rows past the live count unwritten (nobody reads them)
     int per_xcd;                  // > 0: XCD-aware tile order (see xcd_tile), tiles per XCD
@@ -135,11 +136,11 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
             for (int i = tid; i < TM * TN / 4; i += 256) {
                 const int r = m0 + (i * 4) / TN, c = n0 + (i * 4) % TN;
                 if (r < M && c + 3 < N) {
-                    if (C16) *reinterpret_cast<uint2*>(C16p + (size_t)r * g.ldc + c) = make_uint2(0u, 0u);
-                    else *reinterpret_cast<float4*>(C + (size_t)r * g.ldc + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (C16) *reinterpret_cast<uint2*>(C16p + (size_t)r * g.ldcp[p] + c) = make_uint2(0u, 0u);
+                    else *reinterpret_cast<float4*>(C + (size_t)r * g.ldcp[p] + c) = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else if (r < M) {
                     for (int e = 0; e < 4; ++e)
-                        if (c + e < N) { if (C16) C16p[(size_t)r * g.ldc + c + e] = 0; else C[(size_t)r * g.ldc + c + e] = 0.f; }
+                        if (c + e < N) { if (C16) C16p[(size_t)r * g.ldcp[p] + c + e] = 0; else C[(size_t)r * g.ldcp[p] + c + e] = 0.f; }
                 }
             }
         return;
@@ -169,12 +170,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
         const int i = ii * 4 + wave;                     // wave-uniform
         const int r = RPI * (i < NIA ? i : i - NIA) + rl;
         const unsigned pc = (unsigned)((sl ^ ((r >> FS) & (PPR - 1))) * 8);
-        voff[ii] = i < NIA ? ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.lda + pc) * 2u
-                           : ((unsigned)min(r, N - 1 - n0) * (unsigned)g.ldb + pc) * 2u;
+        voff[ii] = i < NIA ? ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.ldap[p] + pc) * 2u
+                           : ((unsigned)min(r, N - 1 - n0) * (unsigned)g.ldbp[p] + pc) * 2u;
     }
     int is_seg = 0, is_k = 0;
-    const unsigned short* Aseg = g.A[p][0] + (size_t)m0 * g.lda;
-    const unsigned short* Bseg = g.B[p][0] + (size_t)n0 * g.ldb;
+    const unsigned short* Aseg = g.A[p][0] + (size_t)m0 * g.ldap[p];
+    const unsigned short* Bseg = g.B[p][0] + (size_t)n0 * g.ldbp[p];
     auto stage = [&](int it) {
         const unsigned dst = lds0 + (unsigned)((it % NS) * STG) * 2u;
 #pragma unroll
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
         if (is_k >= K) {                                 // next K segment (another module's projection / weight)
             is_k = 0;
             if (++is_seg < g.nseg[p]) {
-                Aseg = g.A[p][is_seg] + (size_t)m0 * g.lda;
-                Bseg = g.B[p][is_seg] + (size_t)n0 * g.ldb;
+                Aseg = g.A[p][is_seg] + (size_t)m0 * g.ldap[p];
+                Bseg = g.B[p][is_seg] + (size_t)n0 * g.ldbp[p];
             }
         }
     };
@@ -258,11 +259,11 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
             uint4 v = *reinterpret_cast<const uint4*>(patch + rr * LDP + pc * 8);
             if (row >= Ml) v = make_uint4(0u, 0u, 0u, 0u);
             if (col + 7 < N) {
-                *reinterpret_cast<uint4*>(C16p + (size_t)row * g.ldc + col) = v;
+                *reinterpret_cast<uint4*>(C16p + (size_t)row * g.ldcp[p] + col) = v;
             } else {
                 const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
                 for (int k = 0; k < 8; ++k)
-                    if (col + k < N) C16p[(size_t)row * g.ldc + col + k] = e[k];
+                    if (col + k < N) C16p[(size_t)row * g.ldcp[p] + col + k] = e[k];
             }
         }
 #ifdef SREC_G16_TIMING
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < M) {
-                    float* q = C + (size_t)row * g.ldc + col;
+                    float* q = C + (size_t)row * g.ldcp[p] + col;
                     if (row < Ml) *q = g.beta != 0.f ? acc[i][j][r] + g.beta * *q : acc[i][j][r];
                     else if (g.beta == 0.f) *q = 0.f;
                 }
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    float* __restrict__ C = static_cast<float*>(g.C[p]) + (size_t)split * N1 * g.ldc;
+    float* __restrict__ C = static_cast<float*>(g.C[p]) + (size_t)split * N1 * g.ldcp[p];
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -361,8 +362,8 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
         for (int ii = 0; ii < IPS; ++ii) {
             const int i = ii * 4 + wave;
             const int gr = kbeg + min(r0 + 4 * (i % NIO) + rl, Kr - 1);
-            if (i < NIO) glds16(g.A[p][s], ((unsigned)gr * (unsigned)g.lda + (unsigned)min(i0 + pc * 8, N1 - 8)) * 2u, dst + (unsigned)i * 1024u);
-            else glds16(g.B[p][s], ((unsigned)gr * (unsigned)g.ldb + (unsigned)min(j0 + pc * 8, N2 - 8)) * 2u, dst + (unsigned)i * 1024u);
+            if (i < NIO) glds16(g.A[p][s], ((unsigned)gr * (unsigned)g.ldap[p] + (unsigned)min(i0 + pc * 8, N1 - 8)) * 2u, dst + (unsigned)i * 1024u);
+            else glds16(g.B[p][s], ((unsigned)gr * (unsigned)g.ldbp[p] + (unsigned)min(j0 + pc * 8, N2 - 8)) * 2u, dst + (unsigned)i * 1024u);
         }
     };
     // per-lane LDS byte offsets of the transposing reads: fragment f (32 columns) of an operand tile, reduction rows
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < N1) {
-                    float* q = C + (size_t)row * g.ldc + col;
+                    float* q = C + (size_t)row * g.ldcp[p] + col;
                     *q = g.beta != 0.f ? acc[i][j][r] + g.beta * *q : acc[i][j][r];
                 }
             }
@@ -536,6 +537,9 @@ int fill(G16Args& g, const void* desc_, int tm, int tn, bool tnmode, int& blocks
         if (!tnmode && (d->K[p] & 31)) return SREC_BAD_ARG;                 // 32-deep k-steps
         if (tnmode && ((d->M[p] & 7) || (d->N[p] & 7) || d->M[p] < 8 || d->N[p] < 8)) return SREC_BAD_ARG;
         g.M[p] = d->M[p]; g.N[p] = d->N[p]; g.K[p] = d->K[p]; g.nseg[p] = d->nseg[p]; g.C[p] = d->C[p]; g.dyn[p] = d->dyn[p];
+        g.ldap[p] = d->lda_p[p] > 0 ? d->lda_p[p] : d->lda; g.ldbp[p] = d->ldb_p[p] > 0 ? d->ldb_p[p] : d->ldb;
+        g.ldcp[p] = d->ldc_p[p] > 0 ? d->ldc_p[p] : d->ldc;
+        if ((g.ldap[p] & 7) || (g.ldbp[p] & 7)) return SREC_BAD_ARG;
         g.koff[p] = tnmode ? d->koff[p] : 0;
         g.nsplit[p] = tnmode && d->nsplit[p] > 1 ? d->nsplit[p] : 1;
         if (g.koff[p] < 0 || g.nsplit[p] > 64) return SREC_BAD_ARG;

@@ -784,3 +784,207 @@ extern "C" int srec_inverse_index(const int* ptr, const int* pos, int U, int n, 
     SREC_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- MSGIFSR after its last MSHGNN layer (msgifsr.py:260-264, 131-147): L2-normalise every node row, lay the nodes out
+// per session [s1 | s2 | ...] (the read-out's concatenation, cat_perm) and pick each order's last node - ONE launch instead
+// of normalize + permutation gather + pick gather (+ the bf16 hi / lo split of both outputs for the head's split products),
+// and ONE launch for the three backward kernels (inverse-permutation gather, pick scatter-add, normalize backward).
+namespace {
+struct NppArgs {
+    const float* x; int ld_x;                 // stacked rows [NTs, D] (order-1 rows first)
+    const int* perm;                          // [n_cap] concatenated row -> stacked row (-1: capacity padding)
+    const int* dyn_t;                         // live concatenated rows
+    int n_cap, D, eps_mode; float eps;
+    float* allf; float* invr;                 // [n_cap, D] normalised rows in concatenated order, their 1 / norm
+    unsigned short* a_hi; unsigned short* a_lo;   // nullable: bf16 hi / lo split of allf
+    int npick, B; const int* dyn_b;
+    const int* pick[4];                       // [B] stacked row of each session's last node of that order
+    float* pout[4]; int ld_p[4];              // [B, D] (row stride ld_p)
+    unsigned short* p_hi[4]; unsigned short* p_lo[4]; int ld16[4];
+};
+
+__device__ __forceinline__ void npp_row(const float* __restrict__ xr, bool live, int D, int eps_mode, float eps, int lane,
+                                        float* __restrict__ out, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                        float* __restrict__ inv_out) {
+    float iv = 0.f;
+    if (live) iv = inv_norm(row_sumsq(xr, D, lane), eps_mode, eps);
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            v = *reinterpret_cast<const float4*>(xr + c);
+            v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
+        }
+        *reinterpret_cast<float4*>(out + c) = v;
+        if (hi != nullptr) {
+            const unsigned h0 = srec_pack_bf16(v.x, v.y), h1 = srec_pack_bf16(v.z, v.w);
+            *reinterpret_cast<uint2*>(hi + c) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(lo + c) = make_uint2(
+                srec_pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u)),
+                srec_pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u)));
+        }
+    }
+    if (inv_out != nullptr && lane == 0) *inv_out = iv;
+}
+
+// one wavefront per output row: rows [0, n_cap) of allf, then npick x B pick rows
+__global__ void norm_perm_pick_fwd_kernel(NppArgs a) {
+    const int i = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i < a.n_cap) {
+        const int src = i < dyn_count(a.dyn_t, a.n_cap) ? a.perm[i] : -1;
+        npp_row(a.x + (size_t)(src >= 0 ? src : 0) * a.ld_x, src >= 0, a.D, a.eps_mode, a.eps, lane, a.allf + (size_t)i * a.D,
+                a.a_hi != nullptr ? a.a_hi + (size_t)i * a.D : nullptr, a.a_lo != nullptr ? a.a_lo + (size_t)i * a.D : nullptr,
+                a.invr + i);
+        return;
+    }
+    const int j = i - a.n_cap, k = j / a.B, b = j - k * a.B;
+    if (k >= a.npick) return;
+    const int src = b < dyn_count(a.dyn_b, a.B) ? a.pick[k][b] : -1;
+    npp_row(a.x + (size_t)(src >= 0 ? src : 0) * a.ld_x, src >= 0, a.D, a.eps_mode, a.eps, lane, a.pout[k] + (size_t)b * a.ld_p[k],
+            a.p_hi[k] != nullptr ? a.p_hi[k] + (size_t)b * a.ld16[k] : nullptr,
+            a.p_lo[k] != nullptr ? a.p_lo[k] + (size_t)b * a.ld16[k] : nullptr, nullptr);
+}
+
+struct NppBwdArgs {
+    const float* allf; const float* invr; const float* g_allf; int ld_g;      // concatenated order
+    const int* perm; const int* cat_seg; int B; const int* dyn_b; int D;
+    int npick; const int* pick[4]; const float* g_pick[4]; int ld_gp[4];     // pick k: stacked row of session b, its gradient row
+    float* dx; int ld_dx;                                                       // stacked order, every row written
+    int nt; int row0[4], ncap[4]; const int* dyn_n[4];                          // node types: padded stacked rows are zeroed
+    int n_rows;                                                                 // stacked rows in total
+};
+
+// workgroups [0, B): session b - its concatenated rows [cat_seg[b], cat_seg[b+1]): total gradient of a normalised row = the
+// read-out's gradient of that row (+ the pick gradient when the row is the session's last node of an order), through the
+// normalisation, written to the row's place in the stacked matrix.  Workgroups behind them zero the capacity padding of the
+// stacked matrix (64 rows each).
+__global__ void norm_perm_pick_bwd_kernel(NppBwdArgs a) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= a.B) {
+        const int r0 = ((int)blockIdx.x - a.B) * 64;
+        for (int rr = w; rr < 64; rr += WPB) {
+            const int r = r0 + rr;
+            if (r >= a.n_rows) break;
+            int t = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (q < a.nt && r >= a.row0[q]) t = q;
+            if (r - a.row0[t] < dyn_count(a.dyn_n[t], a.ncap[t])) continue;          // live row: a session workgroup owns it
+            for (int c = lane * 4; c < a.D; c += 256)
+                *reinterpret_cast<float4*>(a.dx + (size_t)r * a.ld_dx + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const int b = blockIdx.x;
+    if (b >= dyn_count(a.dyn_b, a.B)) return;
+    const int beg = a.cat_seg[b], end = a.cat_seg[b + 1];
+    int last[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) last[k] = k < a.npick ? a.pick[k][b] : -1;
+    for (int r = beg + w; r < end; r += WPB) {
+        const int src = a.perm[r];
+        if (src < 0) continue;
+        const float iv = a.invr[r];
+        float4 y[1], g[1];
+        float dot = 0.f;
+        // D <= 256: one float4 per lane (the general loop below covers wider rows)
+        if (a.D <= 256) {
+            const int c = lane * 4;
+            const bool ok = c < a.D;
+            y[0] = ok ? *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[0] = ok ? *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < a.npick && last[k] == src && ok && a.g_pick[k] != nullptr) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.g_pick[k] + (size_t)b * a.ld_gp[k] + c);
+                    g[0].x += p.x; g[0].y += p.y; g[0].z += p.z; g[0].w += p.w;
+                }
+            dot = wave_sum(y[0].x * g[0].x + y[0].y * g[0].y + y[0].z * g[0].z + y[0].w * g[0].w);
+            if (ok)
+                *reinterpret_cast<float4*>(a.dx + (size_t)src * a.ld_dx + c) =
+                    make_float4(iv * (g[0].x - y[0].x * dot), iv * (g[0].y - y[0].y * dot), iv * (g[0].z - y[0].z * dot),
+                                iv * (g[0].w - y[0].w * dot));
+            continue;
+        }
+        for (int c = lane * 4; c < a.D; c += 256) {
+            const float4 yy = *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c);
+            float4 gg = *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c);
+            for (int k = 0; k < a.npick; ++k)
+                if (last[k] == src && a.g_pick[k] != nullptr) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.g_pick[k] + (size_t)b * a.ld_gp[k] + c);
+                    gg.x += p.x; gg.y += p.y; gg.z += p.z; gg.w += p.w;
+                }
+            dot += yy.x * gg.x + yy.y * gg.y + yy.z * gg.z + yy.w * gg.w;
+        }
+        dot = wave_sum(dot);
+        for (int c = lane * 4; c < a.D; c += 256) {
+            const float4 yy = *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c);
+            float4 gg = *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c);
+            for (int k = 0; k < a.npick; ++k)
+                if (last[k] == src && a.g_pick[k] != nullptr) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.g_pick[k] + (size_t)b * a.ld_gp[k] + c);
+                    gg.x += p.x; gg.y += p.y; gg.z += p.z; gg.w += p.w;
+                }
+            *reinterpret_cast<float4*>(a.dx + (size_t)src * a.ld_dx + c) =
+                make_float4(iv * (gg.x - yy.x * dot), iv * (gg.y - yy.y * dot), iv * (gg.z - yy.z * dot), iv * (gg.w - yy.w * dot));
+        }
+    }
+}
+}  // namespace
+
+// allf [n_cap, D] = normalised rows of x in concatenated order (perm), invr [n_cap] their 1 / norm; pick k < npick <= 4:
+// pout_k [B, D] (row stride ld_p[k]) = normalised row pick_k[b] of x.  a_hi / a_lo, p_hi / p_lo (nullable; p_* are HOST arrays
+// of npick pointers that may hold NULLs): bf16 hi / lo splits of the outputs (csrc/split16.hip).  pick / pout / ld_p / ld16 are
+// HOST arrays.  Replaces F.normalize + the per-session concatenation + filter_nodes(last) of msgifsr.py:131-147,260-264.
+extern "C" int srec_norm_perm_pick_fwd(const float* x, int ld_x, const int* perm, int n_cap, const int* dyn_t, int D,
+                                       int eps_mode, float eps, float* allf, float* invr, void* a_hi, void* a_lo, int npick,
+                                       int B, const int* dyn_b, const void* pick, const void* pout, const int* ld_p,
+                                       const void* p_hi, const void* p_lo, const int* ld16, void* stream) {
+    if (n_cap <= 0) return 0;
+    if (npick < 0 || npick > 4 || (D & 3) || (ld_x & 3) || ((a_hi == nullptr) != (a_lo == nullptr))) return SREC_BAD_ARG;
+    NppArgs a{};
+    a.x = x; a.ld_x = ld_x; a.perm = perm; a.dyn_t = dyn_t; a.n_cap = n_cap; a.D = D; a.eps_mode = eps_mode; a.eps = eps;
+    a.allf = allf; a.invr = invr; a.a_hi = (unsigned short*)a_hi; a.a_lo = (unsigned short*)a_lo;
+    a.npick = npick; a.B = B; a.dyn_b = dyn_b;
+    for (int k = 0; k < npick; ++k) {
+        a.pick[k] = ((const int* const*)pick)[k];
+        a.pout[k] = ((float* const*)pout)[k];
+        a.ld_p[k] = ld_p[k];
+        a.p_hi[k] = p_hi != nullptr ? ((unsigned short* const*)p_hi)[k] : nullptr;
+        a.p_lo[k] = p_lo != nullptr ? ((unsigned short* const*)p_lo)[k] : nullptr;
+        a.ld16[k] = ld16 != nullptr ? ld16[k] : 0;
+        if (a.pick[k] == nullptr || a.pout[k] == nullptr || (a.ld_p[k] & 3) || ((a.p_hi[k] == nullptr) != (a.p_lo[k] == nullptr)) ||
+            (a.p_hi[k] != nullptr && (a.ld16[k] & 3)))
+            return SREC_BAD_ARG;
+    }
+    const int rows = n_cap + npick * B;
+    hipLaunchKernelGGL(norm_perm_pick_fwd_kernel, dim3(cdiv(rows, WPB)), dim3(256), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx [n_rows, D] (stacked order, EVERY row written: capacity padding as zeros) = gradient of x given g_allf (gradient of the
+// concatenated normalised rows) and the pick gradients g_pick_k [B, D] (HOST array of npick pointers, entries may be NULL).
+// row0 / ncap / dyn_n (HOST arrays of nt <= 4 entries): the node types' row ranges and live counts inside the stacked matrix.
+extern "C" int srec_norm_perm_pick_bwd(const float* allf, const float* invr, const float* g_allf, int ld_g, const int* perm,
+                                       const int* cat_seg, int B, const int* dyn_b, int D, int npick, const void* pick,
+                                       const void* g_pick, const int* ld_gp, float* dx, int ld_dx, int nt, const int* row0,
+                                       const int* ncap, const void* dyn_n, int n_rows, void* stream) {
+    if (B <= 0 || n_rows <= 0) return 0;
+    if (npick < 0 || npick > 4 || nt <= 0 || nt > 4 || (D & 3) || (ld_g & 3) || (ld_dx & 3)) return SREC_BAD_ARG;
+    NppBwdArgs a{};
+    a.allf = allf; a.invr = invr; a.g_allf = g_allf; a.ld_g = ld_g; a.perm = perm; a.cat_seg = cat_seg; a.B = B; a.dyn_b = dyn_b;
+    a.D = D; a.npick = npick; a.dx = dx; a.ld_dx = ld_dx; a.nt = nt; a.n_rows = n_rows;
+    for (int k = 0; k < npick; ++k) {
+        a.pick[k] = ((const int* const*)pick)[k];
+        a.g_pick[k] = g_pick != nullptr ? ((const float* const*)g_pick)[k] : nullptr;
+        a.ld_gp[k] = ld_gp != nullptr ? ld_gp[k] : D;
+        if (a.pick[k] == nullptr || (a.ld_gp[k] & 3)) return SREC_BAD_ARG;
+    }
+    for (int t = 0; t < nt; ++t) {
+        a.row0[t] = row0[t]; a.ncap[t] = ncap[t];
+        a.dyn_n[t] = dyn_n != nullptr ? ((const int* const*)dyn_n)[t] : nullptr;
+    }
+    hipLaunchKernelGGL(norm_perm_pick_bwd_kernel, dim3(B + cdiv(n_rows, 64)), dim3(256), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

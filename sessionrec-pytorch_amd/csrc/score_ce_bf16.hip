@@ -641,6 +641,8 @@ extern "C" int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16,
     a.part_m = ws_stats; a.part_l = ws_stats + (size_t)nt * B; a.lab_logit = lab_logit;
     int rc = launch_kind<KIND_FWD>(a, 8 * cdiv(nt, 8) * a.n_sess_tiles, st);
     if (rc) return rc;
+    // (one single-workgroup launch for both was measured: 16.8 us against 5 + 5 - a lone workgroup cannot hide the latency
+    // of its ~100 loads per session behind other workgroups; profiles/r03b_*)
     hipLaunchKernelGGL(ce_reduce_stats_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, a.part_m, a.part_l, lab_logit, nt, B,
                        dynB, lse, lossvec);
     hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, lossvec, B, dynB, loss);

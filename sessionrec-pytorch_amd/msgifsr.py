@@ -357,7 +357,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             multi = self.shard is not None and self.shard.world > 1       # (see MSHGNN.plan: live = live in the GLOBAL batch)
             for layer in self.layers:
                 stacked = layer.forward_stacked(mg, stacked, multi)
-            if self.norm:
+            fuse_npp = self.norm and 1 < K <= 4 and stacked.is_cuda
+            if self.norm and not fuse_npp:
                 stacked = ops.normalize(stacked, 0, mg.dynp('N1') if K == 1 else None)   # padded rows are exact zeros
         else:
             h = feats
@@ -370,6 +371,18 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         if K == 1:
             allf = stacked
             feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1)), dB) for i in live}
+        elif len(self.layers) > 0 and fuse_npp:
+            # normalisation + per-session concatenation + last-node picks (+ the operand copies of the head's split products)
+            # in one launch (ops.NormPermutePick)
+            types, r0 = [], 0
+            for k in range(1, K + 1):
+                types.append((r0, ncap[k], mg.dynp('N%d' % k)))
+                r0 += ncap[k]
+            d_ = stacked.shape[1]
+            allf, picked = ops.norm_permute_pick(stacked, mg.cat_perm, mg.cat_seg, [mg.field('lastcat%d' % (i + 1)) for i in live],
+                                                 types, mg.dynp('NT'), dB, 0,
+                                                 split=ops.readout_head_split_ok(d_, d_, d_, d_) and len(list(live)) <= 4)
+            feat_vs = dict(zip(live, picked))
         else:
             allf, picked = ops.permute_and_pick(stacked, mg.cat_perm, mg.field('cat_inv'),
                                                 [mg.field('lastcat%d' % (i + 1)) for i in live], mg.dynp('NT'), dB)

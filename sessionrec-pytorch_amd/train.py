@@ -99,8 +99,9 @@ class TrainRunner:
         from .graph import GraphedTrainStep
         if self._gstep is None:
             try:
-                self._gstep = GraphedTrainStep(self.model, self.optimizer, inputs, labels, after_backward=self._sync_grads
-                                               if self.shard is not None else None)
+                dev_in = [x.to(self.device) for x in inputs]
+                self._gstep = GraphedTrainStep(self.model, self.optimizer, dev_in, labels.to(self.device),
+                                               after_backward=self._sync_grads if self.shard is not None else None)
             except Exception as e:                     # capture refused: stay eager for the rest of the run (the
                 # constructor has put parameters, buffers and optimizer state back: same trajectory)
                 print('hipGraph capture failed (%s: %s); eager launches' % (type(e).__name__, e))
@@ -132,11 +133,16 @@ class TrainRunner:
             print(*a)
 
     def train_step(self, inputs, labels):
+        """inputs / labels as the collate function returned them (host, pinned) or already on the device.  A replayed step
+        takes a host batch straight into the graph's static buffer (GraphedTrainStep._stage: the PCIe copy overlaps the
+        previous step); an eager step moves it to the device here."""
         loss = self._graph_step(inputs, labels)
         if loss is not None:
             self.graph_steps += 1
             return loss
         self.eager_steps += 1
+        if th.device(self.device).type == 'cuda' and any(getattr(x, 'buf', None) is not None and not x.buf.is_cuda for x in inputs):
+            inputs, labels = prepare_batch((inputs, labels), self.device)
         self.optimizer.zero_grad()
         if self.fused:
             loss = self.model.fused_loss(*inputs, labels)
@@ -226,7 +232,9 @@ class TrainRunner:
                         mean_loss += v / log_interval
                     pending.clear()
             for batch in self.train_loader:
-                inputs, labels = prepare_batch(batch, self.device)
+                inputs, labels = batch                   # (host batches: train_step moves / stages them as its path needs)
+                if not self.fused:
+                    inputs, labels = prepare_batch(batch, self.device)
                 pending.append(self.train_step(inputs, labels).detach().clone())   # a replayed step returns its static tensor
                 if (self.batch > 0 and self.batch % log_interval == 0) or len(pending) >= 256:
                     flush()

@@ -145,10 +145,15 @@ def run(model_name):
         if model_name == 'LESSR':
             caps = dict(caps, E=caps['N'] * max(7, max_len))
     elif device.type == 'cuda' and not args.no_graph and not getattr(args, 'extra', False):
-        from src.utils.data.collate import estimate_caps
-        caps = estimate_caps(train_set, args.batch_size, shuffled=shuffled)     # capacity-padded training batches -> whole-step hipGraph replay
-        if model_name == 'LESSR':                            # shortcut graphs: up to L(L+1)/2 edges per session
-            caps = dict(caps, E=caps['N'] * 7)
+        from src.utils.data.collate import estimate_caps, measure_caps
+        # capacity-padded training batches -> whole-step hipGraph replay.  MSGIFSR / SRGNN / NISER: capacities MEASURED on the
+        # epoch's largest batches (tight: kernels whose grid follows the capacity pay for slack); LESSR: the click-count bound
+        if model_name == 'LESSR':
+            caps = estimate_caps(train_set, args.batch_size, shuffled=shuffled)
+            caps = dict(caps, E=caps['N'] * 7)               # shortcut graphs: up to L(L+1)/2 edges per session
+        else:
+            caps = measure_caps(train_set, args.batch_size, 'ccs' if model_name == 'MSGIFSR' else 'session',
+                                getattr(args, 'order', 1), shuffled=shuffled)
     print(len(train_set))
     print(len(test_set))
     if model_name == 'LESSR':

@@ -1110,6 +1110,79 @@ def test_readout_head_matches_unfused_ops(dev, n_orders):
         close(a, b, what='grad ' + nm, rtol=2e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('n_orders,B,d', [(1, 512, 256), (2, 96, 64), (3, 40, 128)])
+def test_readout_head_bf16_split_matches_exact_fp32(dev, n_orders, B, d):
+    """bf16 mode: the head's products run as 3-term bf16 hi / lo splits on the bf16 MFMA (ops.ReadoutHeadSplit,
+    csrc/split16.hip) instead of fp32 MFMA - "exact fp32 work on the bf16 pipe".  Against the exact-fp32 grouped head on
+    the same inputs: outputs and every gradient within 1e-4 of the tensor's scale element-wise (three dropped lo x lo
+    terms of 2^-18 each and 2^-18 split residuals per operand, summed over K <= 512 with random signs), i.e. ~250 x
+    tighter than the single-bf16 rounding (2^-9) the head cannot afford; padded layout (live counts below capacity)."""
+    ops = _ops()
+    torch.manual_seed(5)
+    lens = torch.randint(1, 15, (B,))
+    seg = torch.zeros(B + 1, dtype=torch.int32)
+    live_B = B - 3
+    seg[1:] = lens.cumsum(0)
+    seg[live_B + 1:] = seg[live_B]                          # capacity padding: empty sessions behind the live ones
+    n_live = int(seg[live_B])
+    NT = n_live + 77
+    seg_d = seg.to(dev)
+    dT = torch.tensor([n_live], device=dev, dtype=torch.int32)
+    dB = torch.tensor([live_B], device=dev, dtype=torch.int32)
+    allf0 = torch.randn(NT, d, device=dev)
+    allf0 = allf0 / allf0.norm(dim=1, keepdim=True)
+    allf0[n_live:] = 0
+    sc = 1.0 / d ** 0.5
+
+    def params():
+        vv = torch.randn(B, d, device=dev)
+        vv = vv / vv.norm(dim=1, keepdim=True)
+        return [t.requires_grad_() for t in (vv, (torch.rand(d, d, device=dev) * 2 - 1) * sc, (torch.rand(d, device=dev) * 2 - 1) * sc,
+                                             (torch.rand(d, d, device=dev) * 2 - 1) * sc, (torch.rand(1, d, device=dev) * 2 - 1) * sc,
+                                             (torch.rand(d, 2 * d, device=dev) * 2 - 1) * sc)]
+    per = [params() for _ in range(n_orders)]
+    wts = [torch.randn(B, d, device=dev) for _ in range(n_orders)]
+    for w in wts:
+        w[live_B:] = 0
+
+    def run(split):
+        allf = allf0.clone().requires_grad_()
+        ops.set_precision('bf16' if split else 'fp32')
+        try:
+            fn = ops.ReadoutHeadSplit if split else ops.ReadoutHead
+            ss = fn.apply(allf, seg_d, dT, dB, *[t for po in per for t in po])
+            loss = sum((s * w).sum() for s, w in zip(ss, wts))
+            leaves = [allf] + [t for po in per for t in po]
+            grads = torch.autograd.grad(loss, leaves)
+        finally:
+            ops.set_precision('fp32')
+        return [s.detach() for s in ss], grads
+    s1, g1 = run(True)
+    s0, g0 = run(False)
+
+    def near(a, b, what, tol=1e-4, rtol=3e-5):
+        a, b = a.double().cpu(), b.double().cpu()
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= tol * max(scale, 1e-30), '%s: max |err| %.3e against scale %.3e' % (what, err, scale)
+        rel = float((a - b).norm() / b.norm().clamp(min=1e-30))
+        assert rel < rtol, '%s: relative error %.3e' % (what, rel)
+    for i, (a, b) in enumerate(zip(s1, s0)):
+        near(a[:live_B], b[:live_B], 's%d' % i)
+    names = ['allf'] + ['%s%d' % (nm, i) for i in range(n_orders) for nm in ('v', 'Wu', 'bu', 'Wv', 'we', 'Wsr')]
+    for nm, a, b in zip(names, g1, g0):
+        if nm.startswith('v'):
+            a, b = a[:live_B], b[:live_B]
+        # d bu = sum_b dVq and d fc_e = sum_b (...) are column sums over the sessions that cancel to ~1e-3 of their summands:
+        # the split's 2^-17 is relative to the summands (the exact-fp32 head's own round-off is of the same order there)
+        if nm.startswith(('bu', 'we')):
+            near(a, b, 'grad ' + nm, tol=2e-3, rtol=5e-4)
+        elif nm.startswith('W'):                       # sums over sessions / nodes of products of either sign: ~10 x cancellation
+            near(a, b, 'grad ' + nm, tol=5e-4, rtol=3e-4)
+        else:
+            near(a, b, 'grad ' + nm)
+
+
 @pytest.mark.parametrize('d,Dp,max_norm', [(256, 256, 1.0), (100, 128, 1.0), (64, 64, 0.0), (516, 516, 2.0)])
 def test_renorm_rows_bf16_one_pass(dev, d, Dp, max_norm):
     """Embedding(max_norm) renorm (lessr.py:126 / msgifsr.py:162) + the bf16 operand copy of the table in one pass"""
