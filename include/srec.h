@@ -356,7 +356,7 @@ int srec_norm_perm_pick_fwd(const float* x, int ld_x, const int* perm, int n_cap
                             float eps, float* allf, float* invr, void* a_hi, void* a_lo, int npick, int B, const int* dyn_b,
                             const void* pick, const void* pout, const int* ld_p, const void* p_hi, const void* p_lo,
                             const int* ld16, void* stream);
-int srec_norm_perm_pick_bwd(const float* allf, const float* invr, const float* g_allf, int ld_g, const int* perm,
+int srec_norm_perm_pick_bwd(const float* allf, const float* invr, const float* g_allf, int ld_g, const int* perm, int n_cap,
                             const int* cat_seg, int B, const int* dyn_b, int D, int npick, const void* pick, const void* g_pick,
                             const int* ld_gp, float* dx, int ld_dx, int nt, const int* row0, const int* ncap, const void* dyn_n,
                             int n_rows, void* stream);

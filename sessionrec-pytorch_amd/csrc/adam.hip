@@ -129,7 +129,7 @@ __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict_
 // out new gradient buffers; a captured hipGraph bakes it into the kernel node).  Workgroup b owns a 4096-element chunk
 // of one tensor: blk0[] is the prefix sum of chunks, found by a scalar binary search; float4 accesses when the four
 // pointers are 16-B aligned, scalar otherwise / for the tail.
-constexpr int MT = 48;
+constexpr int MT = 88;      // 88 x 40 B of descriptor + masks: inside the 4 KB kernel-argument budget
 constexpr int MCHUNK = 4096;
 struct MultiArgs {
     float* p[MT];
@@ -138,7 +138,7 @@ struct MultiArgs {
     float* v[MT];
     int n[MT];
     int blk0[MT + 1];
-    unsigned long long wd_mask;
+    unsigned long long wd_mask[2];
     const float* hyper;
     int nt;
 };
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(MultiArgs a) {
     float* __restrict__ v = a.v[t];
     const int n = a.n[t];
     const Hyper h = load_hyper(a.hyper);
-    const float wd = ((a.wd_mask >> t) & 1ull) ? h.wd : 0.f, step = h.step, rs2 = h.bc2s;
+    const float wd = ((a.wd_mask[t >> 6] >> (t & 63)) & 1ull) ? h.wd : 0.f, step = h.step, rs2 = h.bc2s;
     const int e0 = ((int)blockIdx.x - a.blk0[t]) * MCHUNK;
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
 #pragma unroll
@@ -200,7 +200,7 @@ extern "C" int srec_adam_multi(const void* desc_, const float* hyper, void* stre
                 return SREC_BAD_ARG;
             a.p[t] = d->p[s]; a.g[t] = d->g[s]; a.m[t] = d->m[s]; a.v[t] = d->v[s];
             a.n[t] = (int)d->numel[s];
-            if (d->use_wd[s]) a.wd_mask |= 1ull << t;
+            if (d->use_wd[s]) a.wd_mask[t >> 6] |= 1ull << (t & 63);
             a.blk0[t] = blocks;
             blocks += (a.n[t] + MCHUNK - 1) / MCHUNK;
         }

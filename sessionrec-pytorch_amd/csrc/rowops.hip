@@ -853,14 +853,18 @@ struct NppBwdArgs {
     int n_rows;                                                                 // stacked rows in total
 };
 
-// workgroups [0, B): session b - its concatenated rows [cat_seg[b], cat_seg[b+1]): total gradient of a normalised row = the
-// read-out's gradient of that row (+ the pick gradient when the row is the session's last node of an order), through the
-// normalisation, written to the row's place in the stacked matrix.  Workgroups behind them zero the capacity padding of the
-// stacked matrix (64 rows each).
-__global__ void norm_perm_pick_bwd_kernel(NppBwdArgs a) {
+// one wavefront per concatenated row r (workgroups [0, ceil(n_cap / 4))): the row's session is found by a binary search in
+// the LDS-staged cat_seg (one load round trip per workgroup), the total gradient of the normalised row = the read-out's
+// gradient of that row (+ the pick gradient when the row is its session's last node of an order) goes through the
+// normalisation and is written to the row's place in the stacked matrix.  (A workgroup per SESSION walking its rows one
+// after the other measured 14 us whatever the batch: a chain of dependent loads per row.)  Workgroups behind them zero the
+// capacity padding of the stacked matrix (64 rows each).
+constexpr int NPP_SEG = 2048;
+__global__ void norm_perm_pick_bwd_kernel(NppBwdArgs a, int n_cap, int row_blocks) {
+    __shared__ int sseg[NPP_SEG];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((int)blockIdx.x >= a.B) {
-        const int r0 = ((int)blockIdx.x - a.B) * 64;
+    if ((int)blockIdx.x >= row_blocks) {
+        const int r0 = ((int)blockIdx.x - row_blocks) * 64;
         for (int rr = w; rr < 64; rr += WPB) {
             const int r = r0 + rr;
             if (r >= a.n_rows) break;
@@ -868,65 +872,52 @@ __global__ void norm_perm_pick_bwd_kernel(NppBwdArgs a) {
 #pragma unroll
             for (int q = 1; q < 4; ++q)
                 if (q < a.nt && r >= a.row0[q]) t = q;
-            if (r - a.row0[t] < dyn_count(a.dyn_n[t], a.ncap[t])) continue;          // live row: a session workgroup owns it
+            if (r - a.row0[t] < dyn_count(a.dyn_n[t], a.ncap[t])) continue;          // live row: a row wavefront owns it
             for (int c = lane * 4; c < a.D; c += 256)
                 *reinterpret_cast<float4*>(a.dx + (size_t)r * a.ld_dx + c) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         return;
     }
-    const int b = blockIdx.x;
-    if (b >= dyn_count(a.dyn_b, a.B)) return;
-    const int beg = a.cat_seg[b], end = a.cat_seg[b + 1];
-    int last[4];
+    const int nB = dyn_count(a.dyn_b, a.B);
+    const bool staged = nB < NPP_SEG;
+    if (staged)
+        for (int i = threadIdx.x; i <= nB; i += blockDim.x) sseg[i] = a.cat_seg[i];
+    const int r = blockIdx.x * WPB + w;
+    const int src = r < n_cap ? a.perm[r] : -1;                   // (in flight next to the staging loads)
+    __syncthreads();
+    if (src < 0 || nB <= 0) return;
+    int lo = 0, hi = nB;                                          // session b with cat_seg[b] <= r < cat_seg[b + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((staged ? sseg[mid] : a.cat_seg[mid]) <= r) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    if (r >= (staged ? sseg[nB] : a.cat_seg[nB])) return;         // behind the last live session
+    int hit = -1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) last[k] = k < a.npick ? a.pick[k][b] : -1;
-    for (int r = beg + w; r < end; r += WPB) {
-        const int src = a.perm[r];
-        if (src < 0) continue;
-        const float iv = a.invr[r];
-        float4 y[1], g[1];
-        float dot = 0.f;
-        // D <= 256: one float4 per lane (the general loop below covers wider rows)
-        if (a.D <= 256) {
-            const int c = lane * 4;
-            const bool ok = c < a.D;
-            y[0] = ok ? *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            g[0] = ok ? *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < a.npick && last[k] == src && ok && a.g_pick[k] != nullptr) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.g_pick[k] + (size_t)b * a.ld_gp[k] + c);
-                    g[0].x += p.x; g[0].y += p.y; g[0].z += p.z; g[0].w += p.w;
-                }
-            dot = wave_sum(y[0].x * g[0].x + y[0].y * g[0].y + y[0].z * g[0].z + y[0].w * g[0].w);
-            if (ok)
-                *reinterpret_cast<float4*>(a.dx + (size_t)src * a.ld_dx + c) =
-                    make_float4(iv * (g[0].x - y[0].x * dot), iv * (g[0].y - y[0].y * dot), iv * (g[0].z - y[0].z * dot),
-                                iv * (g[0].w - y[0].w * dot));
-            continue;
+    for (int k = 0; k < 4; ++k)
+        if (k < a.npick && a.g_pick[k] != nullptr && a.pick[k][b] == src) hit = k;
+    const float iv = a.invr[r];
+    float dot = 0.f;
+    for (int c = lane * 4; c < a.D; c += 256) {
+        const float4 yy = *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c);
+        float4 gg = *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c);
+        if (hit >= 0) {
+            const float4 p = *reinterpret_cast<const float4*>(a.g_pick[hit] + (size_t)b * a.ld_gp[hit] + c);
+            gg.x += p.x; gg.y += p.y; gg.z += p.z; gg.w += p.w;
         }
-        for (int c = lane * 4; c < a.D; c += 256) {
-            const float4 yy = *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c);
-            float4 gg = *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c);
-            for (int k = 0; k < a.npick; ++k)
-                if (last[k] == src && a.g_pick[k] != nullptr) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.g_pick[k] + (size_t)b * a.ld_gp[k] + c);
-                    gg.x += p.x; gg.y += p.y; gg.z += p.z; gg.w += p.w;
-                }
-            dot += yy.x * gg.x + yy.y * gg.y + yy.z * gg.z + yy.w * gg.w;
+        dot += yy.x * gg.x + yy.y * gg.y + yy.z * gg.z + yy.w * gg.w;
+    }
+    dot = wave_sum(dot);
+    for (int c = lane * 4; c < a.D; c += 256) {
+        const float4 yy = *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c);
+        float4 gg = *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c);
+        if (hit >= 0) {
+            const float4 p = *reinterpret_cast<const float4*>(a.g_pick[hit] + (size_t)b * a.ld_gp[hit] + c);
+            gg.x += p.x; gg.y += p.y; gg.z += p.z; gg.w += p.w;
         }
-        dot = wave_sum(dot);
-        for (int c = lane * 4; c < a.D; c += 256) {
-            const float4 yy = *reinterpret_cast<const float4*>(a.allf + (size_t)r * a.D + c);
-            float4 gg = *reinterpret_cast<const float4*>(a.g_allf + (size_t)r * a.ld_g + c);
-            for (int k = 0; k < a.npick; ++k)
-                if (last[k] == src && a.g_pick[k] != nullptr) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.g_pick[k] + (size_t)b * a.ld_gp[k] + c);
-                    gg.x += p.x; gg.y += p.y; gg.z += p.z; gg.w += p.w;
-                }
-            *reinterpret_cast<float4*>(a.dx + (size_t)src * a.ld_dx + c) =
-                make_float4(iv * (gg.x - yy.x * dot), iv * (gg.y - yy.y * dot), iv * (gg.z - yy.z * dot), iv * (gg.w - yy.w * dot));
-        }
+        *reinterpret_cast<float4*>(a.dx + (size_t)src * a.ld_dx + c) =
+            make_float4(iv * (gg.x - yy.x * dot), iv * (gg.y - yy.y * dot), iv * (gg.z - yy.z * dot), iv * (gg.w - yy.w * dot));
     }
 }
 }  // namespace
@@ -966,7 +957,7 @@ extern "C" int srec_norm_perm_pick_fwd(const float* x, int ld_x, const int* perm
 // concatenated normalised rows) and the pick gradients g_pick_k [B, D] (HOST array of npick pointers, entries may be NULL).
 // row0 / ncap / dyn_n (HOST arrays of nt <= 4 entries): the node types' row ranges and live counts inside the stacked matrix.
 extern "C" int srec_norm_perm_pick_bwd(const float* allf, const float* invr, const float* g_allf, int ld_g, const int* perm,
-                                       const int* cat_seg, int B, const int* dyn_b, int D, int npick, const void* pick,
+                                       int n_cap, const int* cat_seg, int B, const int* dyn_b, int D, int npick, const void* pick,
                                        const void* g_pick, const int* ld_gp, float* dx, int ld_dx, int nt, const int* row0,
                                        const int* ncap, const void* dyn_n, int n_rows, void* stream) {
     if (B <= 0 || n_rows <= 0) return 0;
@@ -984,7 +975,10 @@ extern "C" int srec_norm_perm_pick_bwd(const float* allf, const float* invr, con
         a.row0[t] = row0[t]; a.ncap[t] = ncap[t];
         a.dyn_n[t] = dyn_n != nullptr ? ((const int* const*)dyn_n)[t] : nullptr;
     }
-    hipLaunchKernelGGL(norm_perm_pick_bwd_kernel, dim3(B + cdiv(n_rows, 64)), dim3(256), 0, (hipStream_t)stream, a);
+    // (a pick row matched by several orders: only with one pick list per order, as here - at most one k matches a row's type)
+    const int row_blocks = cdiv(n_cap, WPB);
+    hipLaunchKernelGGL(norm_perm_pick_bwd_kernel, dim3(row_blocks + cdiv(n_rows, 64)), dim3(256), 0, (hipStream_t)stream, a,
+                       n_cap, row_blocks);
     SREC_LAUNCH_CHECK();
     return 0;
 }

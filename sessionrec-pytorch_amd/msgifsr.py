@@ -309,6 +309,9 @@ class MSGIFSR(_ScoringMixin, nn.Module):
 
     def session_repr(self, mg, tgrad=None):
         K = self.order
+        # every parameter of this model feeds exactly one backward node per layer / order: the slab sums that finish their
+        # gradients may wait for ONE launch at the end of the backward pass (ops.defer_slab_sum)
+        ops.DEFER['on'] = bool(mg.buf.is_cuda and self.training)
         if mg.buf.is_cuda:
             ops.check_limits(mg)
         if not self.__dict__.pop('_table_ready', False):

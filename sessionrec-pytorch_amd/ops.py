@@ -479,6 +479,51 @@ def permute_and_pick(x, perm, inv, picks, dyn_n=None, dyn_b=None):
     return outs[0], list(outs[1:])
 
 
+# ------------------------------------------------------------------------------------------ deferred slab sums
+# Several backward nodes end in "out = sum over R partial slabs" kernels whose results only the optimizer reads (weight
+# gradients of the row-split GEMMs, the GRU bias gradients).  Each is a ~5 us kernel node of the captured step whatever its
+# size.  With DEFER['on'] (set by a model whose parameters each feed exactly ONE backward node, so autograd never adds to
+# these tensors before they are complete) a node registers (slabs, out) here instead of launching, and ONE launch at the end
+# of the backward pass (autograd's queue_callback) - or at the latest when the optimizer collects the gradients - sums them
+# all: the gradients are complete when backward() returns, as before.
+DEFER = {'on': False}
+_DEFERRED = []
+
+
+def defer_slab_sum(part, out):
+    """out [n] (any shape, contiguous) = sum over the leading dimension of part [R, n...]: now, or deferred"""
+    if not DEFER['on']:
+        _launch_slab_sums([(part, out)])
+        return
+    if not _DEFERRED:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+        except RuntimeError:                        # not inside a backward pass: nothing to wait for
+            _launch_slab_sums([(part, out)])
+            return
+    # (an ALIAS of out: autograd takes a returned gradient as it is only when nothing else refers to the tensor object -
+    #  with a second reference AccumulateGrad would clone it, before the sum has been written)
+    _DEFERRED.append((part, out.detach()))
+
+
+def _launch_slab_sums(tasks):
+    for i in range(0, len(tasks), 8):
+        chunk = tasks[i:i + 8]
+        m = len(chunk)
+        arr = _ct.c_void_p * m
+        a_p, a_o = arr(*[sl.data_ptr() for sl, _ in chunk]), arr(*[o_.data_ptr() for _, o_ in chunk])
+        a_r, a_n = (_ct.c_int * m)(*[sl.shape[0] for sl, _ in chunk]), (_ct.c_long * m)(*[o_.numel() for _, o_ in chunk])
+        lib.srec_sum_slabs_multi(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o), stream())
+
+
+def flush_deferred():
+    DEFER['on'] = False                             # the next training forward of a single-use model switches it on again
+    if _DEFERRED:
+        tasks = list(_DEFERRED)
+        _DEFERRED.clear()
+        _launch_slab_sums(tasks)
+
+
 class NormPermutePick(torch.autograd.Function):
     """(allf, v_0, v_1, ...) = (normalize(x)[perm], normalize(x)[pick_0], ...): MSGIFSR between its last MSHGNN layer and the
     read-out (msgifsr.py:260-264 F.normalize, :131-147 per-session concatenation and last-node picks) in ONE launch, and its
@@ -525,7 +570,8 @@ class NormPermutePick(torch.autograd.Function):
         tarr = _ct.c_void_p * nt
         a_dyn = tarr(*[ptr(t[2]) for t in types])
         a_r0, a_nc = (_ct.c_int * nt)(*[t[0] for t in types]), (_ct.c_int * nt)(*[t[1] for t in types])
-        lib.srec_norm_perm_pick_bwd(ptr(allf), ptr(invr), ptr(g_allf), _ld(g_allf), ptr(perm), ptr(cat_seg), B, ptr(dyn_b), D, P,
+        lib.srec_norm_perm_pick_bwd(ptr(allf), ptr(invr), ptr(g_allf), _ld(g_allf), ptr(perm), perm.numel(), ptr(cat_seg), B,
+                                    ptr(dyn_b), D, P,
                                     _ct.addressof(a_pick), _ct.addressof(a_g), _ct.addressof(a_ld), ptr(dx), D, nt,
                                     _ct.addressof(a_r0), _ct.addressof(a_nc), _ct.addressof(a_dyn), NTs, stream())
         return (dx,) + (None,) * (7 + P)
@@ -1832,15 +1878,13 @@ class GRUExpandAll(torch.autograd.Function):
                 slabs.append((sl, gWhh[p]))
         for i in range(0, len(probs), 16):
             gemm16('tn', probs[i:i + 16], d3, d, d)
-        for i in range(0, len(slabs), 8):
-            chunk = slabs[i:i + 8]
-            m = len(chunk)
-            arr = _ct.c_void_p * m
-            a_p, a_o = arr(*[sl.data_ptr() for sl, _ in chunk]), arr(*[o_.data_ptr() for _, o_ in chunk])
-            a_r, a_n = (_ct.c_int * m)(*[sl.shape[0] for sl, _ in chunk]), (_ct.c_long * m)(*[o_.numel() for _, o_ in chunk])
-            lib.srec_sum_slabs_multi(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o), st)
         # bias gradients from the partial rows
         gb = [torch.empty(6 * d, device=dev, dtype=torch.float32) for _ in range(P)]
+        # the weight-gradient slab sums join the ONE end-of-backward launch (defer_slab_sum); the bias partials keep their own
+        # kernel: hundreds of partial rows of only 6 d columns - as a task of the generic slab sum (one thread per 4 columns
+        # walking all rows) they made that launch 44 us (profiles/r03d), gru_bias_final splits the rows over 16 lanes: 5 us
+        for sl, o_ in slabs:
+            defer_slab_sum(sl, o_)
         arr = _ct.c_void_p * P
         a_p, a_o = arr(*[t_.data_ptr() for t_ in part]), arr(*[t_.data_ptr() for t_ in gb])
         a_r = (_ct.c_int * P)(*[t_.shape[0] for t_ in part])
@@ -2564,7 +2608,10 @@ class HGATLayer(torch.autograd.Function):
                     probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t))
             for i in range(0, len(probs), 16):
                 gemm16('tn', probs[i:i + 16], HD, D, D)
-            if multi:
+            if multi and DEFER['on']:
+                for i in range(len(multi)):
+                    defer_slab_sum(slabs[i], gWm[i])
+            elif multi:
                 lib.srec_sum_slabs(ptr(slabs), len(multi), R, HD * D, ptr(gWm), stream())
         elif ctx.grouped:
             gemm_group(2, [(HD, D, nr, [(dP[m], xin(m)[r0:r0 + nr])], gWs[m], dyn)

@@ -163,6 +163,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _work(self):
         """[(group idx, group, [(p, g, state)])] for every parameter that has a gradient now"""
+        from . import ops
+        ops.flush_deferred()                  # (normally already done by the end-of-backward callback)
         table, tgrad, _ = self._table_info()
         zero_ids = {}
         if self.model is not None and hasattr(self.model, 'zero_grad_params'):
@@ -228,6 +230,9 @@ class FusedAdam(torch.optim.Optimizer):
             arr = _ct.c_void_p * n
             cs, cf, hy = (arr(*[e[k].data_ptr() for e in chunk]) for k in ('counter', 'cfg', 'hyper'))
             lib.srec_adam_hyper_multi(n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), stream())
+        # small tensors of ALL groups that step together: groups which differ only in weight decay (fix_weight_decay: the
+        # biases / norms are the same Adam with wd 0) share ONE multi-tensor launch - the kernel takes the decay per tensor
+        merged = {}                          # (lr, betas, eps, slot) -> [gi of the hyper to use, wd of it, rows]
         for gi, group, items in work:
             if not items:
                 continue
@@ -269,16 +274,29 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     lib.srec_adam_flat(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.numel(),
                                        ptr(hyper), use_wd, stream())
-            for slot, rows in multi.items():      # every small tensor of the group in ONE launch (by-value descriptor)
-                nt = len(rows)
-                arr = (_ct.c_void_p * nt)
-                desc = _AdamMultiDesc(
-                    nt, (_ct.c_int * nt)(*([use_wd] * nt)), (_ct.c_long * nt)(*[p.numel() for p, _, _ in rows]),
-                    arr(*[p.data_ptr() for p, _, _ in rows]), arr(*[g.data_ptr() for _, g, _ in rows]),
-                    arr(*[st_['exp_avg'].data_ptr() for _, _, st_ in rows]),
-                    arr(*[st_['exp_avg_sq'].data_ptr() for _, _, st_ in rows]))
-                hyper = self._buffers(gi, slot, rows[0][0].device)['hyper']
-                lib.srec_adam_multi(_ct.addressof(desc), ptr(hyper), stream())
+            for slot, rows in multi.items():
+                b1, b2 = group['betas']
+                key = (float(group['lr']), float(b1), float(b2), float(group['eps']), slot, str(rows[0][0].device))
+                wd = float(group['weight_decay'])
+                ent = merged.get(key)
+                if ent is not None and wd != 0 and ent[1] != 0 and ent[1] != wd:
+                    key = key + (wd,)                # two different non-zero decays: separate launches
+                    ent = merged.get(key)
+                if ent is None:
+                    ent = merged[key] = [gi, wd, []]
+                elif wd != 0 and ent[1] == 0:
+                    ent[0], ent[1] = gi, wd          # the launch reads the hyper-parameters of the group that decays
+                ent[2] += [(p, g, st_, use_wd) for p, g, st_ in rows]
+        for key, (gi, _, rows) in merged.items():    # every small tensor that steps together in ONE launch (by-value descriptor)
+            slot = key[4]
+            nt = len(rows)
+            arr = (_ct.c_void_p * nt)
+            a_wd, a_n = (_ct.c_int * nt)(*[r[3] for r in rows]), (_ct.c_long * nt)(*[r[0].numel() for r in rows])
+            a_p, a_g = arr(*[r[0].data_ptr() for r in rows]), arr(*[r[1].data_ptr() for r in rows])
+            a_m, a_v = arr(*[r[2]['exp_avg'].data_ptr() for r in rows]), arr(*[r[2]['exp_avg_sq'].data_ptr() for r in rows])
+            desc = _AdamMultiDesc(nt, a_wd, a_n, a_p, a_g, a_m, a_v)
+            hyper = self._buffers(gi, slot, rows[0][0].device)['hyper']
+            lib.srec_adam_multi(_ct.addressof(desc), ptr(hyper), stream())
         if tgrad is not None:
             tgrad.fresh = False
         from . import ops
