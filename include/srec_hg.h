@@ -67,6 +67,10 @@ typedef struct {
     float* DP[SREC_HG_MAXI];
     float* der[SREC_HG_MAXI];
     const float* Mk[SREC_HG_MAXI];
+    /* per (node type, session) mean of the layer's input rows [B, D] and the session of every stacked row [sum ncap] - scratch
+     * written by srec_hg_fwd (msgifsr.py:86-89 segment_mean + broadcast), read again by srec_hg_bwd */
+    float* smean[SREC_HG_MAXT];
+    int* sess;
 } srec_hg_desc;
 
 /* problem table of srec_gemm_group_bf16 (srec.h) */
@@ -101,6 +105,8 @@ typedef struct {
     int nsplit[SREC_G16_MAXP];     /* tn only (0 / 1 = off): split the reduction rows into nsplit pieces (64-row multiples), piece
                                       s writing its own slab C + s * M * ldc (caller sums the slabs: srec_sum_slabs_multi) */
     int lda_p[SREC_G16_MAXP], ldb_p[SREC_G16_MAXP], ldc_p[SREC_G16_MAXP];   /* per-problem leading dimensions; 0 = the group's */
+    int mhint[SREC_G16_MAXP];      /* nt: expected live rows (*dyn) of a capacity-padded problem, 0 = unknown: tile shape and tile
+                                      order are chosen for the live work, not for the capacity */
 } srec_gemm16_group;
 
 /* problem table of srec_gemm_f32_group_run (srec.h, csrc/gemm.hip): up to 16 independent exact-fp32 products, each with

@@ -42,6 +42,7 @@ struct G16Args {
     float beta;
     int keep_dead;                // leave output rows past the live count unwritten (nobody reads them)
     int per_xcd;                  // > 0: XCD-aware tile order (see xcd_tile), tiles per XCD
+    int xcd_gs;                   // > 0: sibling groups of xcd_gs tiles dealt to the XCDs round-robin instead of runs
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -62,8 +63,15 @@ __device__ __forceinline__ void glds16(const unsigned short* sbase, unsigned vof
 // share an operand slab (the two 128-column tiles of a row block in backward-data, the two column tiles of a dP slab in the
 // weight gradient) sit on different XCDs and each pulls its own copy from HBM (PMC: 177 MB of reads for the 63 MB dP).  XCD x
 // takes the x-th CONSECUTIVE run of tiles instead: siblings run side by side behind one L2.
+// Capacity-padded problems end in tiles of dead rows; consecutive runs then hand some XCDs mostly dead tiles (backward-data at
+// 45 % padding: 61 -> 85 us, profiles/r03e_caps).  With a host hint that the padding is large the sibling GROUPS (xcd_gs tiles that
+// share an operand slab) are dealt round-robin instead: siblings still sit behind one L2, dead tails spread over all XCDs.
 __device__ __forceinline__ int xcd_tile(const G16Args& g) {
     const int b = (int)blockIdx.x;
+    if (g.xcd_gs > 0) {
+        const int x = b & 7, l = b >> 3;
+        return ((l / g.xcd_gs) * 8 + x) * g.xcd_gs + l % g.xcd_gs;
+    }
     return g.per_xcd > 0 ? (b & 7) * g.per_xcd + (b >> 3) : b;
 }
 
@@ -569,8 +577,10 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     G16Args g{};
     int blocks = 0;
     // small-N problems (backward-data, N = D): 64-row tiles keep every CU busy
-    long t128 = 0;
-    for (int p = 0; p < h->np; ++p) t128 += (long)cdiv(h->M[p], 128) * cdiv(h->N[p], 128);
+    // (tile-shape heuristics count LIVE rows where the caller knows them: mhint = expected *dyn of a capacity-padded problem)
+    auto Mh = [&](int p) { return (h->mhint[p] > 0 && h->mhint[p] < h->M[p]) ? h->mhint[p] : h->M[p]; };
+    long t128 = 0, rows_cap = 0, rows_live = 0;
+    for (int p = 0; p < h->np; ++p) { t128 += (long)cdiv(Mh(p), 128) * cdiv(h->N[p], 128); rows_cap += h->M[p]; rows_live += Mh(p); }
     // skinny outputs (backward-data: N = D) take 64-row tiles: twice the workgroups over the same HBM stream
     int nmax = 0;
     for (int p = 0; p < h->np; ++p) nmax = h->N[p] > nmax ? h->N[p] : nmax;
@@ -578,7 +588,7 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     int tm = (variant & 8) ? ((variant & 4) ? 128 : 64) : ((t128 >= 384 && nmax > 256) ? 128 : 64);
     // tiny products (the GRU hidden-state GEMMs: ~2k x 256 outputs): 64 x 64 tiles double the workgroups in flight
     long t64x128 = 0;
-    for (int p = 0; p < h->np; ++p) t64x128 += (long)cdiv(h->M[p], 64) * cdiv(h->N[p], 128);
+    for (int p = 0; p < h->np; ++p) t64x128 += (long)cdiv(Mh(p), 64) * cdiv(h->N[p], 128);
     // Workgroups are dealt to the 8 XCDs round-robin and a workgroup is latency bound on its own DMA ring (a lone one takes
     // as long as one of three on its CU), so a launch costs (rounds on the fullest XCD) x (workgroup life).  The fp32-output
     // kernels: 64 x 128 tiles with 2 x 64-deep stages = 48 KB -> 3 per CU = 96 slots per XCD; 128 x 128 = 64 KB -> 2 per CU =
@@ -593,7 +603,17 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     // fp32-output launches (backward-data: two column tiles share every dP row block): 38.7 -> 34.5 us at the bench shapes; the
     // bf16-output forward (sixteen column tiles per row block, all of x fits any L2) measured 1.5 us slower that way.  Bit 9:
     // plain tile order (experiments)
-    if (!(h->c16 & 1) && !((h->c16 >> 9) & 1)) { g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd; }
+    if (!(h->c16 & 1) && !((h->c16 >> 9) & 1)) {
+        bool same_tn = true;
+        const int tn0 = cdiv(h->N[0], tn);
+        for (int p = 1; p < h->np; ++p) same_tn = same_tn && cdiv(h->N[p], tn) == tn0;
+        if (same_tn && rows_live * 10 < rows_cap * 9) {          // > 10 % capacity padding: round-robin sibling groups
+            g.xcd_gs = tn0;
+            blocks = cdiv(blocks, 8 * tn0) * 8 * tn0;
+        } else {
+            g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool c16 = h->c16 & 1;
     static std::atomic<unsigned long long> optin_mask[32];

@@ -116,6 +116,13 @@ struct DotsArgs {
     int start[MAXB + 1];     // first thread block of each projection block
     int nb, H, D;
     const float* x[MAXB]; int ld_x;          // the module's (possibly feature-dropped) input rows
+    // workgroups behind the projection blocks: (node type t, session b) - the mean of the session's INPUT rows of that type
+    // (msgifsr.py:86-89) and the session of every node, computed once per session here instead of once per NODE inside hg_agg
+    // (where the session search + the row loop were 8.6 k of a workgroup's 20 k cycles, tools/hg_timing.py)
+    int nt, B; const int* dynB;
+    const int* seg[MAXT]; int trow0[MAXT];
+    const float* xm;                         // layer input rows (not dropped)
+    float* smean[MAXT]; int* sess;
 };
 
 // workgroup = 16 nodes of a projection block x 16 outputs (l/r x head): the block's folded vectors V sit in LDS,
@@ -125,6 +132,25 @@ struct DotsArgs {
 constexpr int DOTS_NODES = 16;
 __global__ __launch_bounds__(256) void hg_dots_kernel(DotsArgs a) {
     extern __shared__ float vt[];                              // [16][D + 4]
+    if ((int)blockIdx.x >= a.start[a.nb]) {
+        const int e = (int)blockIdx.x - a.start[a.nb], t = e / a.B, sb = e - t * a.B;
+        if (t >= a.nt || sb >= dyn_count(a.dynB, a.B)) return;
+        const int s0 = a.seg[t][sb], s1 = a.seg[t][sb + 1];
+        for (int j = s0 + (int)threadIdx.x; j < s1; j += 256) a.sess[a.trow0[t] + j] = sb;
+        for (int c = threadIdx.x; c < a.D; c += 256) {
+            const float* xp = a.xm + (size_t)a.trow0[t] * a.ld_x + c;
+            float m = 0.f;
+            int j = s0;
+            for (; j + 3 < s1; j += 4) {
+                const float x0 = xp[(size_t)j * a.ld_x], x1 = xp[(size_t)(j + 1) * a.ld_x], x2 = xp[(size_t)(j + 2) * a.ld_x],
+                            x3 = xp[(size_t)(j + 3) * a.ld_x];
+                m += x0; m += x1; m += x2; m += x3;                          // row order, as one by one
+            }
+            for (; j < s1; ++j) m += xp[(size_t)j * a.ld_x];
+            a.smean[t][(size_t)sb * a.D + c] = m / (float)(s1 - s0 > 0 ? s1 - s0 : 1);
+        }
+        return;
+    }
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
     const int H = a.H, D = a.D, LDV = D + 4;
     for (int i = threadIdx.x; i < 2 * D * H; i += 256) {
@@ -164,6 +190,7 @@ struct AggArgs {
     float* A[MAXI];
     const float* Mk[MAXI];              // attention dropout: 0 or 1/(1-p) per (edge, head); NULL = none
     const float* x; int ld_x;
+    const float* smean[MAXT]; const int* sess;   // per (type, session) mean of the input rows, session of every stacked row (hg_dots)
     const float* xres;                  // residual rows already summed over the instances (feature dropout); NULL -> n_inst * x
     float* out; int ld_out;
     unsigned char* arg;
@@ -189,43 +216,14 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
     __shared__ float sc[MAXH][MAXDEG];
     __shared__ int su[MAXH][MAXDEG];
     __shared__ float comb[MAXH][256];
-    __shared__ int sseg[SEGCAP];
     const int row = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int H = a.H, D = a.D, HD = H * D;
     const int t = find_range(a.row0, a.nt, row);
     const int v = row - a.row0[t];
     const bool live = v < dyn_count(a.dyn_n[t], a.ncap[t]);
     const int c = lane * 4;
-    // Session of this node and the mean of the session's input rows (msgifsr.py:86-89) FIRST: the session offsets are staged
-    // in LDS by the whole workgroup (one load round trip; B <= SEGCAP - 1) and searched there, and the session's rows are then
-    // fetched four at a time.  Behind the aggregation this was a tail of 9 dependent global loads (the binary search) + one
-    // dependent load per session node, in a kernel whose workgroups are pure latency chains.
-    float smean = 0.f;
-    {
-        const int nB = dyn_count(a.dynB, a.B);
-        const int* seg = a.seg[t];
-        const bool staged = nB < SEGCAP;
-        if (staged)
-            for (int i = tid; i <= nB; i += 512) sseg[i] = seg[i];
-        __syncthreads();
-        if (live && tid < D) {
-            int lo = 0, hi = nB;                            // session b with seg[b] <= v < seg[b+1]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if ((staged ? sseg[mid] : seg[mid]) <= v) lo = mid; else hi = mid;
-            }
-            const int s0 = staged ? sseg[lo] : seg[lo], s1 = staged ? sseg[lo + 1] : seg[lo + 1];
-            const float* xp = a.x + (size_t)a.row0[t] * a.ld_x + tid;
-            int j = s0;
-            for (; j + 3 < s1; j += 4) {
-                const float x0 = xp[(size_t)j * a.ld_x], x1 = xp[(size_t)(j + 1) * a.ld_x], x2 = xp[(size_t)(j + 2) * a.ld_x],
-                            x3 = xp[(size_t)(j + 3) * a.ld_x];
-                smean += x0; smean += x1; smean += x2; smean += x3;      // same order as one by one
-            }
-            for (; j < s1; ++j) smean += xp[(size_t)j * a.ld_x];
-            smean /= (float)(s1 - s0 > 0 ? s1 - s0 : 1);
-        }
-    }
+    // the session of this node (its mean row is added at the very end): one early load, hidden behind the edge chains
+    const int sb = live ? a.sess[row] : 0;
     HGT(1);
     if (w < H) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -361,7 +359,7 @@ __global__ __launch_bounds__(512) void hg_agg_kernel(AggArgs a) {
             best = -INFINITY;
             for (int h = 0; h < H; ++h)
                 if (comb[h][tid] > best) { best = comb[h][tid]; bi = h; }
-            best += smean;                                 // + mean of the session's input features (nodes of this type)
+            best += a.smean[t][(size_t)sb * D + tid];      // + mean of the session's input features (nodes of this type)
         }
         a.out[(size_t)row * a.ld_out + tid] = best;
         a.arg[(size_t)row * D + tid] = (unsigned char)bi;
@@ -389,6 +387,7 @@ struct PreArgs {
     const float* g; int ld_g;
     const float* rm;                    // [NT, D] per-element residual scale (feature dropout); NULL -> n_inst
     float* dx; int ld_dx;
+    const int* sess;                    // session of every stacked row (written by the forward's hg_dots launch)
 };
 
 // dx[row,:] = nres * g[row,:] + (1/n_session) * sum_{rows of the session} g   (residual + session-mean terms)
@@ -403,17 +402,7 @@ __global__ void hg_pre_kernel(PreArgs a) {
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         const int* seg = a.seg[t];
-        int lo = 0, hi = dyn_count(a.dynB, a.B);
-        // 4-ary search: the three probes of a level are independent loads - 5 round trips for 512 sessions instead of 9
-        while (hi - lo > 3) {
-            const int q = (hi - lo) >> 2, m1 = lo + q, m2 = lo + 2 * q, m3 = lo + 3 * q;
-            const int v1 = seg[m1], v2 = seg[m2], v3 = seg[m3];
-            if (v3 <= v) lo = m3; else if (v2 <= v) { lo = m2; hi = m3; } else if (v1 <= v) { lo = m1; hi = m2; } else hi = m1;
-        }
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (seg[mid] <= v) lo = mid; else hi = mid;
-        }
+        const int lo = a.sess[row];                        // (one load instead of a 5-round-trip search of the offsets)
         const int s0 = seg[lo], s1 = seg[lo + 1];
         int j = s0;
         for (; j + 3 < s1; j += 4) {                       // four rows in flight, added in row order
@@ -897,7 +886,10 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
             if (f.tn[t] > 0 && f.bsum[t] == nullptr) return SREC_BAD_ARG;
         hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H), dim3(1024), 0, st, f);
     }
-    if (d->n_blocks > 0) {
+    if (d->sess == nullptr || d->B <= 0) return SREC_BAD_ARG;
+    for (int t = 0; t < d->n_types; ++t)
+        if (d->smean[t] == nullptr) return SREC_BAD_ARG;
+    {
         DotsArgs a{};
         a.nb = d->n_blocks; a.H = H; a.D = D; a.ld_x = ld_x;
         int blocks = 0;
@@ -911,11 +903,16 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
             blocks += cdiv(d->ncap[t], DOTS_NODES);
         }
         a.start[d->n_blocks] = blocks;
+        // + one workgroup per (node type, session): session means and the node -> session map (see DotsArgs)
+        a.nt = d->n_types; a.B = d->B; a.dynB = d->dynB; a.xm = x; a.sess = d->sess;
+        for (int t = 0; t < d->n_types; ++t) { a.seg[t] = d->seg[t]; a.trow0[t] = d->row0[t]; a.smean[t] = d->smean[t]; }
+        blocks += d->n_types * d->B;
         if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), (size_t)16 * (D + 4) * 4, st, a);
     }
     AggArgs g{};
     g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;
-    g.x = x; g.ld_x = ld_x; g.out = out; g.ld_out = ld_out; g.arg = arg; g.xres = d->xres;
+    g.x = x; g.ld_x = ld_x; g.out = out; g.ld_out = ld_out; g.arg = arg; g.xres = d->xres; g.sess = d->sess;
+    for (int t = 0; t < d->n_types; ++t) g.smean[t] = d->smean[t];
     int rows = 0;
     for (int t = 0; t < d->n_types; ++t) {
         if (d->row0[t] != rows) return SREC_BAD_ARG;            // types must tile the stacked matrix
@@ -955,6 +952,8 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
     {
         PreArgs a{};
         a.nt = d->n_types; a.B = d->B; a.D = D; a.dynB = d->dynB; a.g = g; a.ld_g = ld_g; a.dx = dx; a.ld_dx = ld_dx; a.rm = d->rm;
+        a.sess = d->sess;
+        if (d->sess == nullptr) return SREC_BAD_ARG;
         for (int t = 0; t < d->n_types; ++t) {
             a.seg[t] = d->seg[t]; a.dyn_n[t] = d->dyn_n[t]; a.row0[t] = d->row0[t]; a.ncap[t] = d->ncap[t];
             a.ninst[t] = ninst_t[t];

@@ -145,6 +145,9 @@ class MSHGNN(nn.Module):
         slope = self.conv1.mods['intra1'].negative_slope
         plan = ops.HgPlan(8, D, slope, mg.B, mg.dynp('B'), types, mods, blocks, insts, mod_conv)
         plan.layer_id = getattr(self, '_layer_id', 0)
+        # host-side live node counts of THIS batch per type (first stacked row -> count): hints for the GEMM tile heuristics -
+        # a captured step keeps the choice of the batch it was captured on, the kernels themselves read the device counts
+        plan.live = {t[0]: mg.count('N%d' % (k + 1)) for k, t in enumerate(types)}
         return plan, params
 
     def forward_stacked(self, mg, x, all_rels=False):

@@ -2231,7 +2231,8 @@ class HgDesc(_ct.Structure):
                 [(n, _ct.c_int * 16) for n in ('blk_mod', 'blk_type', 'blk_row')] +
                 [(n, _ct.c_void_p * 16) for n in ('eL', 'eR', 'wL', 'wR')] +
                 [(n, _ct.c_int * 16) for n in ('inst_mod', 'inst_sblk', 'inst_dblk')] +
-                [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der', 'Mk')])
+                [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der', 'Mk')] +
+                [('smean', _ct.c_void_p * 4), ('sess', _ct.c_void_p)])
 
 
 class GemmGroup(_ct.Structure):
@@ -2261,7 +2262,7 @@ class GemmGroup16(_ct.Structure):
                 ('M', _ct.c_int * 16), ('N', _ct.c_int * 16), ('K', _ct.c_int * 16), ('nseg', _ct.c_int * 16),
                 ('A', (_ct.c_void_p * 4) * 16), ('B', (_ct.c_void_p * 4) * 16), ('C', _ct.c_void_p * 16),
                 ('dyn', _ct.c_void_p * 16), ('koff', _ct.c_int * 16), ('nsplit', _ct.c_int * 16),
-                ('lda_p', _ct.c_int * 16), ('ldb_p', _ct.c_int * 16), ('ldc_p', _ct.c_int * 16)]
+                ('lda_p', _ct.c_int * 16), ('ldb_p', _ct.c_int * 16), ('ldc_p', _ct.c_int * 16), ('mhint', _ct.c_int * 16)]
 
 
 def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, variant=0):
@@ -2278,6 +2279,8 @@ def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, var
         g.nsplit[p] = pr[7] if len(pr) > 7 else 1        # tn: in-kernel row split, C = [nsplit, M, N] slabs
         if len(pr) > 8 and pr[8] is not None:            # per-problem (lda, ldb, ldc); 0 = the group's
             g.lda_p[p], g.ldb_p[p], g.ldc_p[p] = pr[8]
+        if len(pr) > 9 and pr[9]:                        # nt: expected live rows of a capacity-padded problem
+            g.mhint[p] = int(pr[9])
         for si, (A, B) in enumerate(segs):
             g.A[p][si], g.B[p][si] = ptr(A), ptr(B)
     (lib.srec_gemm16_nt if kind == 'nt' else lib.srec_gemm16_tn)(_ct.addressof(g), stream())
@@ -2350,6 +2353,11 @@ class HgPlan:
             for nm, n in (('A', E), ('DP', E), ('der', nd)):
                 lay[(nm, i)] = off
                 off += n
+        for t in range(len(self.types)):                   # session means of the input rows per node type [B, D]
+            lay[('smean', t)] = off
+            off += self.B * self.D
+        lay[('sess', 0)] = off                             # session of every stacked row (int32)
+        off += sum(tp[1] for tp in self.types)
         return off, lay
 
     def fill(self, desc, small, lay, P, dP, params, grads, drop=None):
@@ -2379,6 +2387,9 @@ class HgPlan:
                 d.d_attn_l[m], d.d_attn_r[m], d.d_bias[m] = (grads[m, j].data_ptr() for j in range(3))
         for m in range(len(self.modules), len(self.types)):
             d.Z[m] = base + 4 * lay[('Z', m)]
+        for t in range(len(self.types)):
+            d.smean[t] = base + 4 * lay[('smean', t)]
+        d.sess = base + 4 * lay[('sess', 0)]
         for b, (m, t) in enumerate(self.blocks):
             d.blk_mod[b], d.blk_type[b] = m, t
             d.blk_row[b] = self.types[t][0] - self.modules[m][0]
@@ -2480,7 +2491,8 @@ class HGATLayer(torch.autograd.Function):
             else:
                 x16 = rows_bf16(x)
                 xin16 = lambda m: x16
-            probs = [(nc, HD, D, [(xin16(m)[t0:t0 + nc], w16[m])], P[m][o:o + nc], dyn_t)
+            live = getattr(plan, 'live', {})             # host-side live row counts per type start (tile heuristics only)
+            probs = [(nc, HD, D, [(xin16(m)[t0:t0 + nc], w16[m])], P[m][o:o + nc], dyn_t, 0, 1, None, live.get(t0, 0))
                      for m in range(nm) for (o, t0, nc, dyn_t) in plan.pieces(m)]
             for i in range(0, len(probs), 16):
                 # rows past a type's live count are never read (every hgat.hip kernel walks the live prefix only)
@@ -2564,12 +2576,14 @@ class HGATLayer(torch.autograd.Function):
                 beta = 0.0 if (cv is not None and full) else 1.0
                 if probs and ctx.g16 is not None and S > 1:
                     wt16 = ctx.g16[1]
+                    live = getattr(plan, 'live', {})
                     for (M_, N_, K_, segs_, C_, dyn_, t0) in probs:
                         for j, (A_, m_) in enumerate(segs_):
-                            pend.append(((M_, N_, K_, [(A_, wt16[m_])], tgts[cv, j, t0:t0 + M_], dyn_), 0.0))
+                            pend.append(((M_, N_, K_, [(A_, wt16[m_])], tgts[cv, j, t0:t0 + M_], dyn_, 0, 1, None, live.get(t0, 0)), 0.0))
                 elif probs and ctx.g16 is not None:
                     wt16 = ctx.g16[1]
-                    pend += [((M_, N_, K_, [(A_, wt16[m_]) for A_, m_ in segs_], C_, dyn_), beta)
+                    live = getattr(plan, 'live', {})
+                    pend += [((M_, N_, K_, [(A_, wt16[m_]) for A_, m_ in segs_], C_, dyn_, 0, 1, None, live.get(_t0, 0)), beta)
                              for (M_, N_, K_, segs_, C_, dyn_, _t0) in probs]
                 elif probs:
                     probs = [(M_, N_, K_, [(A_, params[4 * m_]) for A_, m_ in segs_], C_, dyn_)
