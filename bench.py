@@ -233,6 +233,10 @@ def cpu_baseline(model_name, samples, V, d, order, state_dict, budget_s=12.0, dr
                        % (n, B, model_name, V, d, cores))
 
 
+def FlatBatchCopy(x):
+    return type(x)(x.buf.clone().pin_memory(), x.layout, dict(x.meta))
+
+
 def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4):
     """The metric as the reference's loop defines it (train.py:92-110): wall time of `for batch in train_loader:` -
     DataLoader worker processes building the session graphs (native collate, csrc/collate.cpp), pinned batches, the
@@ -258,8 +262,18 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
         fn = col.collate_fn_factory(col.seq_to_eop_multigraph, caps=caps)
     else:
         fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), args.order, caps=caps)
-    loader = DataLoader(data, batch_size=B, sampler=SequentialSampler(data), num_workers=workers, collate_fn=fn,
-                        pin_memory=True, persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
+    loader, which = None, 'torch DataLoader (pin_memory)'
+    if getattr(args, 'e2e_loader', 'ring') == 'ring' and args.model != 'LESSR':
+        # the launchers' default (src/scripts/common.py --loader ring): workers collate straight into a shared pinned ring
+        from torch.utils.data import BatchSampler
+        ring = importlib.import_module('sessionrec-pytorch_amd.loader')
+        loader = ring.ring_loader_or_none(data, BatchSampler(SequentialSampler(data), B, drop_last=False),
+                                          'ccs' if args.model == 'MSGIFSR' else 'session', args.order, caps, workers)
+        which = 'pinned ring (loader.PinnedRingLoader)'
+    if loader is None:
+        loader = DataLoader(data, batch_size=B, sampler=SequentialSampler(data), num_workers=workers, collate_fn=fn,
+                            pin_memory=True, persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
+        which = 'torch DataLoader (pin_memory)'
     torch.manual_seed(123)
     model = build_model(sp, args.model, V, d, args.order, args.dropout)
     model.load_state_dict(state)
@@ -276,8 +290,8 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
         held = []
         for batch in it0:
             nb += 1
-            if len(held) < 64:
-                held.append(batch)
+            if len(held) < 64:                          # (copies: a ring loader's batches are views of slots it reuses)
+                held.append(([FlatBatchCopy(x) for x in batch[0]], batch[1]))
         t_loader = (time.perf_counter() - t0) / max(nb, 1)
         del it0
         probe = dict(loader_only_ms_per_batch=t_loader * 1e3)
@@ -288,6 +302,7 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
         loss = runner.train_step(inputs, labels)
     torch.cuda.synchronize()
     g0, e0 = runner.graph_steps, runner.eager_steps
+    w0 = dict(getattr(loader, 'stats', {}))
     n, t0 = 0, time.perf_counter()
     for batch in it:                                      # TrainRunner.train's loop body (train.py:94-101)
         inputs, labels = batch
@@ -296,6 +311,7 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     final = float(loss.item())
+    waits = {k: round((v - w0[k]) / max(n, 1) * 1e3, 4) for k, v in getattr(loader, 'stats', {}).items()}   # ms per step
     if probe is not None:
         for rep in range(2):
             torch.cuda.synchronize()
@@ -307,9 +323,46 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
             torch.cuda.synchronize()
             t_all = time.perf_counter() - t0
         probe.update(precollated_ms_per_step=t_all / 256 * 1e3, precollated_host_issue_ms_per_step=t_host / 256 * 1e3)
-    del it, loader
+        gs = runner._gstep
+        if gs is not None:
+            # what separates a fed step from the bare replay loop: (a) replay only, (b) + the device-to-device copy into the
+            # static buffer, (c) + an event wait on another stream, (d) fed from pinned host batches (= precollated above)
+            dev_held = [([x.to(dev) for x in b[0]], b[1].to(dev)) for b in held[:8]]
+            side, legs = torch.cuda.Stream(), {}
+
+            def timed(fn, n=512):
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for i in range(n):
+                        fn(i)
+                    torch.cuda.synchronize()
+                    dt_ = (time.perf_counter() - t) / n * 1e3
+                return dt_
+
+            def replay_only(i):
+                gs.opt.advance(gs.work)
+                gs.graph.replay()
+
+            def with_d2d(i):
+                gs(*dev_held[i % len(dev_held)])
+
+            def with_event(i):
+                ev = torch.cuda.Event()
+                ev.record(side)
+                torch.cuda.current_stream().wait_event(ev)
+                gs.opt.advance(gs.work)
+                gs.graph.replay()
+            legs['replay_only'] = timed(replay_only)
+            legs['replay_plus_d2d_copy'] = timed(with_d2d)
+            legs['replay_plus_event_wait'] = timed(with_event)
+            probe['gap_ms_per_step'] = legs
+    del it
+    if hasattr(loader, 'close'):
+        loader.close()
+    del loader
     return dict(value=n * B / dt, unit='sessions/s', ms_per_step=dt / n * 1e3, steps=n, workers=workers, collate='native'
-                if col._native() is not None else 'python', pinned=True, caps=caps,
+                if col._native() is not None else 'python', loader=which, loader_waits_ms_per_step=waits or None, pinned=True, caps=caps,
                 graph_steps=runner.graph_steps - g0, eager_steps=runner.eager_steps - e0, final_loss=final, probe=probe,
                 note='wall time of the DataLoader loop (train.py:92-110 equivalent): worker collate + pinned H2D copy + '
                      'hipGraph replay per batch, evaluation excluded')
@@ -444,6 +497,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 side run (the reference arithmetic) of the same step')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the DataLoader-inclusive run of the same workload')
+    ap.add_argument('--e2e-loader', default='ring', choices=['ring', 'torch'],
+                    help='loader of the end-to-end run: the shared pinned ring (launcher default) or torch DataLoader')
     ap.add_argument('--e2e-workers', type=int, default=4, help='DataLoader worker processes of the end-to-end run')
     ap.add_argument('--e2e-probe', action='store_true', help='end-to-end run: also time the loader alone and the step fed from pre-collated batches')
     ap.add_argument('--dropout', type=float, default=0.1,

@@ -152,6 +152,11 @@ int srec_col_sum(const float* X, int ld, const float* wgt, int H, int D, int n_c
  * raises instead of truncating (ops.check_limits). */
 int srec_limits(int* max_session_nodes, int* max_degree, int* max_degree_sgat);
 
+/* Batch intake of a replayed step (graph.GraphedTrainStep._stage; replaces the `x.to(device)` of the reference's
+ * prepare_batch, /root/reference/src/utils/train.py:26-30, for capacity-padded batches): dst [n] (device) = src [n] int32 words
+ * read by a kernel from page-locked HOST memory (or device memory); both 16-byte aligned.  Ordered on `stream`. */
+int srec_copy_words(const int* src, int* dst, long n, void* stream);
+
 /* ---- per-session kernels (segops.hip): one wavefront per session ------------------------------------
  * attention readout core: srgnn.py:79-86 niser.py:77-84 lessr.py:106-113 msgifsr.py:139-146 */
 int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const float* X, int ld_x,

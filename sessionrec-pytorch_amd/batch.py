@@ -78,10 +78,16 @@ class FlatBatch:
         if torch.device(device) == self.buf.device:
             return self
         # a pinned buffer (DataLoader(pin_memory=True)) is copied asynchronously: the host goes on to the next batch
-        return FlatBatch(self.buf.to(device, non_blocking=non_blocking or self.buf.is_pinned()), self.layout, self.meta)
+        pinned = self.buf.is_pinned()
+        out = FlatBatch(self.buf.to(device, non_blocking=non_blocking or pinned), self.layout, self.meta)
+        if pinned:
+            ev = torch.cuda.Event()                    # (a slot of loader.PinnedRingLoader is reused only after this copy)
+            ev.record()
+            self.meta['_copied'] = ev
+        return out
 
     def pin_memory(self):
-        return FlatBatch(self.buf.pin_memory(), self.layout, self.meta)
+        return FlatBatch(self.buf if self.buf.is_pinned() else self.buf.pin_memory(), self.layout, self.meta)
 
     @property
     def device(self):

@@ -324,19 +324,35 @@ def _ccs_schema(K):
     return names, shapes, counts, rels
 
 
-def collate_native(kind, seqs, order=1, caps=None):
-    """kind: 'session' | 'eop' | 'shortcut' | 'ccs' -> FlatBatch built by csrc/collate.cpp (or None if unavailable)"""
+class FlatSeqs:
+    """a batch of click sequences already in the builder's input form: flat int64 clicks + int64 offsets [B + 1]
+    (loader.PinnedRingLoader gathers it from the flattened dataset with numpy - no per-sample Python objects)"""
+
+    def __init__(self, flat, offs):
+        self.flat, self.offs = np.ascontiguousarray(flat, dtype=np.int64), np.ascontiguousarray(offs, dtype=np.int64)
+
+    def __len__(self):
+        return len(self.offs) - 1
+
+
+def collate_native(kind, seqs, order=1, caps=None, into=None):
+    """kind: 'session' | 'eop' | 'shortcut' | 'ccs' -> FlatBatch built by csrc/collate.cpp (or None if unavailable).
+    into (optional): a writable int32 numpy array (e.g. a slot of a pinned shared ring, loader.PinnedRingLoader) the
+    builder writes the batch INTO - the FlatBatch then is a view of it, nothing is copied; too small -> ValueError."""
     import ctypes
     dll = _native()
     if dll is None:
         return None
     B = len(seqs)
-    import itertools
-    lens = np.fromiter(map(len, seqs), dtype=np.int64, count=B)
-    offs = np.zeros(B + 1, dtype=np.int64)
-    np.cumsum(lens, out=offs[1:])
-    flat = np.fromiter(itertools.chain.from_iterable(seqs), dtype=np.int64, count=int(offs[-1]))   # (C-level iteration:
-    #                                                                  a generator expression costs ~0.2 us per click here)
+    if isinstance(seqs, FlatSeqs):
+        flat, offs = seqs.flat, seqs.offs
+    else:
+        import itertools
+        lens = np.fromiter(map(len, seqs), dtype=np.int64, count=B)
+        offs = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        flat = np.fromiter(itertools.chain.from_iterable(seqs), dtype=np.int64, count=int(offs[-1]))   # (C-level iteration:
+        #                                                              a generator expression costs ~0.2 us per click here)
     kid = {'session': 0, 'eop': 1, 'shortcut': 2, 'ccs': 3}[kind]
     if kind == 'ccs':
         names, shapes, cnames, rels = _ccs_schema(order)
@@ -353,9 +369,9 @@ def collate_native(kind, seqs, order=1, caps=None):
     info = np.zeros(3 * (len(names) + 4), dtype=np.int64)
     nf = ctypes.c_int(0)
     for _ in range(2):
-        out = np.empty(guess, dtype=np.int32)
+        out = into if into is not None else np.empty(guess, dtype=np.int32)
         n = dll.srec_collate(kid, flat.ctypes.data, offs.ctypes.data, B, order,
-                             None if capv is None else capv.ctypes.data, out.ctypes.data, guess, info.ctypes.data,
+                             None if capv is None else capv.ctypes.data, out.ctypes.data, len(out), info.ctypes.data,
                              len(names) + 4, ctypes.addressof(nf))
         if n > 0:
             break
@@ -363,9 +379,11 @@ def collate_native(kind, seqs, order=1, caps=None):
             if caps is not None:
                 raise CapacityExceeded('native collate: the batch does not fit the capacities %r' % (caps,))
             raise ValueError('native collate failed: empty session or order > 6')
+        if into is not None:
+            raise ValueError('native collate: the batch needs %d int32, the given buffer holds %d' % (-n, len(out)))
         guess = -n + 16
     assert nf.value == len(names), (nf.value, len(names))
-    buf = out[:n].copy()
+    buf = out[:n] if into is not None else out[:n].copy()
     layout = {nm: (int(info[3 * i]), int(info[3 * i + 1]), shapes.get(nm)) for i, nm in enumerate(names)}
     counts = {cn: int(buf[i]) for i, cn in enumerate(cnames)}
     meta = dict(kind=kind, B=caps['B'] if caps else B, padded=caps is not None, counts=counts,
@@ -402,6 +420,20 @@ def _attach_labels(fb, lab):
     layout = dict(fb.layout)
     layout['labels'] = (off, n, None)
     return FlatBatch(ext, layout, fb.meta)
+
+
+def _attach_labels_inplace(fb, lab, room):
+    """the same when the batch lives in a larger caller-owned buffer `room` (int32 numpy array whose head fb.buf views): the
+    labels are written behind the batch inside that buffer - no concatenation"""
+    off, n = int(fb.buf.numel()), int(lab.numel())
+    tot = off + ((n + 3) & ~3)
+    if tot > len(room):
+        raise ValueError('no room for the labels behind the batch')
+    room[off:off + n] = lab.numpy().astype(np.int32)
+    room[off + n:tot] = 0
+    layout = dict(fb.layout)
+    layout['labels'] = (off, n, None)
+    return FlatBatch(torch.from_numpy(room[:tot]), layout, fb.meta)
 
 
 def _labels(labels, caps):

@@ -982,3 +982,30 @@ extern "C" int srec_norm_perm_pick_bwd(const float* allf, const float* invr, con
     SREC_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- batch intake: pinned host words -> device, as a KERNEL ---------------------------------------------------------------
+// A captured training step takes its batch (one int32 buffer, ~1 MB: batch.py) from page-locked host memory.  The copy is done
+// by a kernel that loads the host words over PCIe itself (page-locked memory is mapped into the device's address space) and
+// stores them in HBM: it is ordered on the compute stream like any other kernel of the step - no DMA engine, no cross-stream
+// event between a copy queue and the replayed graph.  16-byte loads, one per lane and iteration, ~n/4/256 workgroups so that
+// enough reads are in flight to cover the link's latency.
+namespace {
+__global__ void copy_words_kernel(const int4* __restrict__ src, int4* __restrict__ dst, long n4, const int* __restrict__ src_tail,
+                                  int* __restrict__ dst_tail, int tail) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+}  // namespace
+
+// dst [n] (device) = src [n] (page-locked host memory or device memory), int32 words; both 16-byte aligned
+extern "C" int srec_copy_words(const int* src, int* dst, long n, void* stream) {
+    if (n <= 0) return 0;
+    if (src == nullptr || dst == nullptr || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return SREC_BAD_ARG;
+    const long n4 = n / 4;
+    const int tail = (int)(n - 4 * n4);
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)(n4 > 0 ? (n4 + 255) / 256 : 1)), dim3(256), 0, (hipStream_t)stream,
+                       (const int4*)src, (int4*)dst, n4, src + 4 * n4, dst + 4 * n4, tail);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

@@ -9,9 +9,19 @@ batch header in device memory (`dyn*` arguments of include/srec.h), so the same 
 valid for every batch that fits the capacities.  (MI355X guide: capture launch-bound inner loops in
 hipGraphs; no tracing compiler involved - the graph is the recorded launch sequence of our own C ABI.)
 """
+import os
+
 import torch
 
 from .batch import FlatBatch
+
+
+# how a replayed step takes a pinned host batch (measured, profiles/r03_notes.md: loop time per step at a 0.928 ms replay):
+#   'kernel' 0.971 ms  a kernel on the compute stream loads the batch over PCIe itself (srec_copy_words)        <- default
+#   'main'   0.992 ms  hipMemcpyAsync on the compute stream
+#   'side'   1.001 ms  hipMemcpyAsync on a side stream into a staging ring + device-to-device copy (also the route of
+#                      pageable host batches, which a kernel cannot read)
+_STAGE_MODE = os.environ.get('SREC_STAGE_MODE', 'kernel')
 
 
 class GraphedTrainStep:
@@ -172,11 +182,34 @@ class GraphedTrainStep:
         return loss
 
     def _stage(self, i, x):
-        """host (pinned) batch buffer -> the static device buffer of input i, with the PCIe transfer OFF the compute stream:
-        the H2D copy runs on a side stream into a small ring of device staging buffers - concurrently with the replay of
-        the previous step, the host runs ahead of the GPU - and the compute stream only does the device-to-device copy
-        (microseconds) before its replay.  A staging slot is rewritten only after the compute stream has consumed it."""
+        """host batch buffer -> the static device buffer of input i.  Page-locked batches (loader.PinnedRingLoader slots,
+        DataLoader(pin_memory=True)): one kernel on the compute stream reads the words over PCIe and writes the static
+        buffer (ops.copy_words) - no DMA engine, no cross-stream event in front of the replay.  Other host batches: the
+        H2D copy runs on a side stream into a small ring of device staging buffers and the compute stream does a
+        device-to-device copy; a staging slot is rewritten only after the compute stream has consumed it.  Either way
+        the batch carries an event (meta['_copied']) after which its host buffer may be rewritten."""
         st = self.static_inputs[i]
+        mode = _STAGE_MODE if x.buf.is_pinned() else 'side'
+        if mode in ('kernel', 'main'):
+            n = x.buf.numel()
+            if mode == 'kernel':
+                from . import ops
+                ops.copy_words(x.buf, st.buf, n)
+            else:
+                st.buf[:n].copy_(x.buf, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            x.meta['_copied'] = done
+            # the host buffer must outlive the copy.  torch's pinned allocator only knows about ITS OWN asynchronous copies: a
+            # DataLoader(pin_memory=True) batch dropped by the caller would be recycled for the next batch while the kernel
+            # has not read it yet (the host runs steps ahead of the GPU) - keep the tensor until its event has completed
+            fly = self.__dict__.setdefault('_inflight', [])
+            fly.append((done, x.buf))
+            while fly and (len(fly) > 64 or fly[0][0].query()):
+                if not fly[0][0].query():
+                    fly[0][0].synchronize()
+                fly.pop(0)
+            return
         ring = self.__dict__.setdefault('_ring', {})
         if i not in ring:
             ring[i] = dict(bufs=[torch.empty_like(st.buf) for _ in range(3)], used=[None] * 3, n=0,
@@ -191,6 +224,7 @@ class GraphedTrainStep:
             r['bufs'][j][:x.buf.numel()].copy_(x.buf, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(r['stream'])
+        x.meta['_copied'] = ready                          # the host buffer may be rewritten once this has completed
         main.wait_event(ready)
         st.buf.copy_(r['bufs'][j], non_blocking=True)
         done = torch.cuda.Event()

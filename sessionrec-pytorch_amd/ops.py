@@ -67,6 +67,12 @@ def limits():
     return _LIMITS
 
 
+def copy_words(src, dst, n):
+    """dst[:n] (device int32) = src[:n] (page-locked host or device int32) by a kernel on the current stream (srec_copy_words)"""
+    assert dst.is_cuda and src.dtype == dst.dtype == torch.int32 and (src.is_cuda or src.is_pinned())
+    lib.srec_copy_words(src.data_ptr(), dst.data_ptr(), int(n), stream())
+
+
 def check_limits(mg, deg='deg'):
     """a batch whose longest session / largest node degree exceeds what the per-session kernels hold in LDS is refused here
     (collate records both in FlatBatch.meta): a clean error, never a silently truncated soft-max"""

@@ -44,6 +44,9 @@ def parse(model):
                    help='(not in the reference) eager launches instead of replaying one captured hipGraph per training step')
     p.add_argument('--checkpoint', default=None,
                    help='(not in the reference) write a resumable checkpoint here after every epoch; resume from it if present')
+    p.add_argument('--loader', default='ring', choices=['ring', 'torch'],
+                   help='(not in the reference) ring: worker processes collate straight into a shared pinned ring '
+                        '(sessionrec-pytorch_amd/loader.py); torch: torch.utils.data.DataLoader as in the reference')
     p.add_argument('--metrics-log', default=None, help='(not in the reference) append one JSON line per logged interval / epoch')
     p.add_argument('--gpus', type=int, default=int(os.environ.get('SREC_GPUS', '1')),
                    help='(not in the reference) train on this many GPUs of the node: item table row-sharded over them (RCCL), '
@@ -173,6 +176,16 @@ def run(model_name):
         cls = NISER if model_name == 'NISER' else SRGNN
         model = cls(num_items, args.embedding_dim, args.num_layers, feat_drop=args.feat_drop)
     pin = device.type == 'cuda'          # pinned batches: asynchronous H2D copies
+
+    def ring(batch_sampler):
+        # single-graph capacity-padded training batches: built by the workers INSIDE a shared pinned ring (no pickling, no
+        # pinning pass in this process); anything else keeps the DataLoader
+        if args.loader != 'ring' or device.type != 'cuda' or (model_name == 'LESSR' and args.num_layers > 1):
+            return None
+        from importlib import import_module
+        kind = {'MSGIFSR': 'ccs', 'LESSR': 'eop'}.get(model_name, 'session')
+        return import_module('sessionrec-pytorch_amd.loader').ring_loader_or_none(
+            train_set, batch_sampler, kind, getattr(args, 'order', 1), caps, args.num_workers)
     pw = args.num_workers > 0            # keep the loader processes across epochs (a respawn costs seconds per epoch)
     # reference loaders: LESSR / MSGIFSR train in time order (SequentialSampler), NISER shuffles; test shuffles
     if sharded:
@@ -182,19 +195,23 @@ def run(model_name):
         RankSlice = import_module('sessionrec-pytorch_amd.dataset').RankSliceBatchSampler
         base = (RandomSampler(train_set, generator=th.Generator().manual_seed(123)) if shuffled
                 else SequentialSampler(train_set))
-        train_loader = DataLoader(train_set, batch_sampler=RankSlice(base, args.batch_size, rank, world),
-                                  num_workers=args.num_workers, collate_fn=train_collate_fn, pin_memory=pin,
-                                  persistent_workers=pw)
+        slices = RankSlice(base, args.batch_size, rank, world)
+        train_loader = ring(slices) or DataLoader(train_set, batch_sampler=slices, num_workers=args.num_workers,
+                                                  collate_fn=train_collate_fn, pin_memory=pin, persistent_workers=pw)
         # evaluation: every rank scores the same sessions against its rows (order does not enter the metrics)
         test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers,
                                  collate_fn=collate_fn, persistent_workers=pw)
     elif model_name in ('LESSR', 'MSGIFSR'):
-        train_loader = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.num_workers,
-                                  collate_fn=train_collate_fn, sampler=SequentialSampler(train_set), pin_memory=pin, persistent_workers=pw)
+        from torch.utils.data import BatchSampler
+        train_loader = (ring(BatchSampler(SequentialSampler(train_set), args.batch_size, drop_last=False)) or
+                        DataLoader(train_set, batch_size=args.batch_size, num_workers=args.num_workers, collate_fn=train_collate_fn,
+                                   sampler=SequentialSampler(train_set), pin_memory=pin, persistent_workers=pw))
         test_loader = None
     else:
-        train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
-                                  collate_fn=train_collate_fn, pin_memory=pin, persistent_workers=pw)
+        from torch.utils.data import BatchSampler, RandomSampler
+        train_loader = (ring(BatchSampler(RandomSampler(train_set), args.batch_size, drop_last=False)) or
+                        DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
+                                   collate_fn=train_collate_fn, pin_memory=pin, persistent_workers=pw))
         test_loader = None
     if test_loader is None:
         test_loader = DataLoader(test_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,

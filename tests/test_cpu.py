@@ -413,3 +413,46 @@ def test_oracle_srgnn_layer_reproduces_the_reference_layer(name):
     close(x.grad, z['dfeat'], what='layer d feat', atol=1e-6)
     for k, p in layer.named_parameters():
         close(p.grad, z['grad/' + k], what='layer grad ' + k, atol=2e-6)
+
+
+@pytest.mark.parametrize('sliced', [False, True])
+def test_pinned_ring_loader_yields_the_dataloader_batches(sliced):
+    """loader.PinnedRingLoader (workers write native-collated batches into a shared ring) against
+    DataLoader(batch_sampler, collate_fn_factory_ccs(caps)): same batches, same order, same buffers, labels included;
+    two epochs over a ring smaller than the epoch (slot reuse), one oversized batch (exact-layout fallback)"""
+    from torch.utils.data import BatchSampler, DataLoader, SequentialSampler
+    C, L, DS = pkg('collate'), pkg('loader'), pkg('dataset')
+    if C._native() is None:
+        pytest.skip('libsrec_collate.so not built')
+    rng = np.random.RandomState(5)
+    sessions = [rng.randint(1, 300, size=rng.randint(2, 12)).tolist() for _ in range(150)]
+    sessions[40] = rng.randint(1, 300, size=60).tolist()               # long prefixes: some batches overflow the capacities
+    ds = DS.AugmentedDataset(sessions)
+    bs = 16
+    caps = C.default_caps(bs, 12)
+    sampler = BatchSampler(SequentialSampler(ds), bs, drop_last=False)
+    if sliced:          # rank 0 of 6 of a multi-rank job: its slice of the 3-sample last batch is empty -> a filler sample
+        ds.index = ds.index[:len(ds) - (len(ds) - 3) % bs]
+        assert len(ds) % bs == 3
+        sampler = DS.RankSliceBatchSampler(SequentialSampler(ds), bs, 0, 6)
+        caps = C.default_caps(bs // 6 + 1, 61)
+    ref = list(DataLoader(ds, batch_sampler=sampler, collate_fn=C.collate_fn_factory_ccs((C.seq_to_ccs_graph,), 3, caps)))
+    ld = L.PinnedRingLoader(ds, sampler, 'ccs', order=3, caps=caps, num_workers=2, slots=4)
+    try:
+        assert len(ld) == len(ref)
+        exact = 0
+        for epoch in range(2):
+            n = 0
+            for (inp, lab), (rinp, rlab) in zip(ld, ref):
+                fb, rfb = inp[0], rinp[0]
+                assert torch.equal(lab, rlab)
+                assert fb.layout == rfb.layout and torch.equal(fb.buf, rfb.buf)
+                assert fb.meta['counts'] == rfb.meta['counts'] and fb.meta.get('padded') == rfb.meta.get('padded')
+                assert fb.meta['max_deg'] == rfb.meta['max_deg'] and fb.meta['max_nodes'] == rfb.meta['max_nodes']
+                exact += not fb.meta.get('padded')
+                n += 1
+            assert n == len(ref)
+        assert sliced or exact >= 2                                    # the overflowing batches came through, unpadded
+        assert not sliced or int(ref[-1][1][0]) == -1                  # (the filler sample of the last slice)
+    finally:
+        ld.close()

@@ -1201,3 +1201,20 @@ def test_renorm_rows_bf16_one_pass(dev, d, Dp, max_norm):
     assert torch.equal(out16[:V, :d], W.bfloat16()), 'bf16 copy is the RNE rounding of the renormed rows'
     assert float(out16[:V, d:].abs().max() if Dp > d else 0.0) == 0.0
     assert float((out16[V:] - 7.0).abs().max()) == 0.0             # rows past n untouched
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 1027, 300001])
+def test_copy_words_reads_pinned_host_memory(dev, n):
+    """srec_copy_words: the batch intake of a replayed step - a kernel that loads page-locked HOST words (rowops.hip)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n)
+    src = torch.randint(-2 ** 31, 2 ** 31 - 1, (n + 8,), dtype=torch.int32, generator=g).pin_memory()
+    dst = torch.full((n + 8,), 77, dtype=torch.int32, device=dev)
+    ops.copy_words(src, dst, n)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:n].cpu(), src[:n]) and bool((dst[n:] == 77).all())
+    dst2 = torch.zeros(n + 4, dtype=torch.int32, device=dev)
+    ops.copy_words(dst, dst2, n)                                  # device source
+    assert torch.equal(dst2[:n].cpu(), src[:n]) and bool((dst2[n:] == 0).all())
+    with pytest.raises(AssertionError):
+        ops.copy_words(torch.zeros(8, dtype=torch.int32), dst, 8)  # pageable host memory: refused, a kernel cannot read it

@@ -150,3 +150,42 @@ def test_train_runner_replays_the_captured_step(dev, model_name, tmp_path):
     second = train.TrainRunner('sample', copy.deepcopy(m0), padded, exact[:2], dev, checkpoint=ck, **kw)
     second.train(2, log_interval=100)
     assert second.graph_steps == n - 1 and second.loss_trace == eager.loss_trace[n:]
+
+
+@pytest.mark.parametrize('model_name', ['MSGIFSR', 'NISER'])
+def test_training_from_the_pinned_ring_loader_matches_the_dataloader(dev, model_name):
+    """loader.PinnedRingLoader feeding TrainRunner.train_step (captured steps staged from the pinned ring slots, a ring of
+    only 4 slots so every slot is rewritten many times while steps are in flight) against the same steps fed by the torch
+    DataLoader: identical loss traces and parameters - no slot is overwritten before the copy that reads it."""
+    from torch.utils.data import BatchSampler, DataLoader, SequentialSampler
+    sp, ds, col, train, L = pkg(), pkg('dataset'), pkg('collate'), pkg('train'), pkg('loader')
+    rng = np.random.RandomState(11)
+    V, B = 500, 64
+    sessions = [rng.randint(1, V, size=rng.randint(2, 14)).tolist() for _ in range(700)]
+    data = ds.AugmentedDataset(sessions)
+    data.index = data.index[:60 * B]
+    kind, order = ('ccs', 2) if model_name == 'MSGIFSR' else ('session', 1)
+    caps = col.measure_caps(data, B, kind, order)
+    sampler = BatchSampler(SequentialSampler(data), B, drop_last=False)
+    fn = (col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), order, caps=caps) if kind == 'ccs'
+          else col.collate_fn_factory(col.seq_to_session_graph, caps=caps))
+
+    def run(loader):
+        torch.manual_seed(7)
+        model = (sp.MSGIFSR(V, 'x', 32, 1, dropout=0.0, order=2, extra=False, fusion=False) if kind == 'ccs'
+                 else sp.NISER(V, 32, 1, feat_drop=0.0)).to(dev).train()
+        runner = train.TrainRunner('x', model, loader, None, dev, lr=1e-3, weight_decay=1e-4)
+        losses = [runner.train_step(inp, lab).detach().clone() for inp, lab in loader]
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), {k: v.detach().cpu() for k, v in model.state_dict().items()}, runner
+    ring = L.PinnedRingLoader(data, sampler, kind, order=order, caps=caps, num_workers=2, slots=4)
+    try:
+        assert ring.pinned and ring.ring_t[:16].is_pinned()
+        l_ring, p_ring, r_ring = run(ring)
+    finally:
+        ring.close()
+    l_ref, p_ref, r_ref = run(DataLoader(data, batch_sampler=sampler, collate_fn=fn, num_workers=0, pin_memory=True))
+    assert r_ring.graph_steps >= 50 and r_ring.graph_steps == r_ref.graph_steps
+    assert torch.allclose(l_ring, l_ref, rtol=1e-5, atol=1e-6), (l_ring - l_ref).abs().max()
+    for k in p_ref:
+        assert torch.allclose(p_ring[k].float(), p_ref[k].float(), rtol=1e-4, atol=2e-6), k
