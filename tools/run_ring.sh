@@ -1,10 +1,7 @@
 mkdir -p gpurun_out
-for m in side kernel main; do
-SREC_STAGE_MODE=$m python bench.py --e2e-loader ring --e2e-probe > gpurun_out/r03_stage_$m.json 2> gpurun_out/r03_stage_$m.err || tail -20 gpurun_out/r03_stage_$m.err
+for m in 0 1 0 1; do
+SREC_EARLY_ADAM=$m SREC_DEBUG_CAPTURE=1 python bench.py --no-end-to-end 2> gpurun_out/early_$m.err | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('early=$m', j['ms_per_step'], j['value'], j.get('kernels_per_step'), j.get('launch_mode'))"
+grep -i "error\|fail\|Traceback" gpurun_out/early_$m.err | head -5
 done
-python - <<'PY'
-import json
-for m in ('side','kernel','main'):
-    j=json.loads(open('gpurun_out/r03_stage_%s.json'%m).read().strip().splitlines()[-1])
-    e=j['end_to_end']; print(m, round(j['ms_per_step'],4), round(e['ms_per_step'],4), e['final_loss'], e['loader_waits_ms_per_step'], e['probe'])
-PY
