@@ -43,6 +43,7 @@ struct G16Args {
     int keep_dead;                // leave output rows past the live count unwritten (nobody reads them)
     int per_xcd;                  // > 0: XCD-aware tile order (see xcd_tile), tiles per XCD
     int xcd_gs;                   // > 0: sibling groups of xcd_gs tiles dealt to the XCDs round-robin instead of runs
+    int dbg;                      // development: phases of gemm16_fwd_wres_kernel switched off (tools/fwd_wres_bench.py)
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -304,6 +305,134 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     if (threadIdx.x == 0 && bid < 8192) g_g16_blk[bid][1] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && bid == 17) { g_g16_tim[0] = g16t[1] - g16t[0]; g_g16_tim[1] = g16w; g_g16_tim[2] = g16d; g_g16_tim[3] = g16c; g_g16_tim[4] = g16t[7] - g16t[6]; g_g16_tim[5] = g16t[7] - g16t[0]; g_g16_tim[6] = total; }
 #endif
+}
+
+// -------------------------------------------------------------------------------------------------- nt16, weights in registers
+// The forward projections P_m = x_m W_m^T are short reductions (K = D <= 256) into wide outputs (N = H D = 2048): with output
+// tiles, every 128 x 128 tile re-stages its 64 KB A block and its 64 KB W block through LDS - 245 MB of LDS-DMA for 63 MB of
+// output, and the launch is bound by the rate at which a CU issues 1-KiB LDS-DMA pieces (~115 cycles each, tools/g16_timing.py),
+// not by bytes or MFMAs.  Here a wave OWNS 64 output columns for its whole life: their W rows (64 x K bf16 = 32 KB at K = 256)
+// sit in 128 VGPRs as ready-made MFMA fragments, loaded once straight from L2; the workgroup (4 waves = 256 consecutive
+// columns = one head at D = 256) streams 32-row chunks of x through a small LDS ring, every chunk is read by all four waves.
+// LDS-DMA pieces: 16 per 32 rows and column group instead of 64 -> a quarter of the issue slots; per MFMA half the LDS
+// fragment reads (one A fragment feeds both column halves).  Workgroups that share rows (the 8 column groups of one row
+// group) are consecutive slots of ONE XCD: x is pulled from HBM once.
+// Accumulator transposed as in nt16<C16> (lane = output row), leaves through a per-wave LDS patch as 16-B stores.
+template <int KD, int NSTG>
+__global__ __launch_bounds__(256, 2) void gemm16_fwd_wres_kernel(G16Args g, int cpw, int tiles_per_xcd) {
+    constexpr int KS = KD / 16;                          // MFMA k-steps
+    constexpr int PPR = KD / 8;                          // 16-B pieces per x row
+    constexpr int RPI = 512 / KD;                        // x rows per 1-KiB DMA instruction
+    constexpr int NI = 32 / RPI, IPS = NI / 4;           // DMA instructions per chunk: all, per wave
+    constexpr int STG = 32 * KD;                         // bf16 elements per stage
+    constexpr int LDP = 64 + 8;                          // patch row (bf16 elements): 144 B, conflict-free 8-B writes
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    if (slot >= tiles_per_xcd) return;
+    const int bid = xcd * tiles_per_xcd + slot;
+    if (bid >= g.start[g.np]) return;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < G16_MAXP; ++i)
+        if (i < g.np && bid >= g.start[i]) p = i;
+    const int M = g.M[p], N = g.N[p];
+    const int ncg = N / 256, tile = bid - g.start[p];
+    const int m0 = (tile / ncg) * (32 * cpw), nb = (tile % ncg) * 256;
+    const int Ml = dyn_count(g.dyn[p], M);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n0 = nb + wave * 64;
+    unsigned short* __restrict__ Cp = static_cast<unsigned short*>(g.C[p]);
+    const int ldc = g.ldcp[p];
+    const int rows_here = min(32 * cpw, M - m0);
+    if (m0 >= Ml) {                                      // row group of capacity padding
+        if (!g.keep_dead)
+            for (int i = tid; i < rows_here * 32; i += 256)          // 32 16-B pieces per 256-column row slice
+                *reinterpret_cast<uint4*>(Cp + (size_t)(m0 + i / 32) * ldc + nb + (i % 32) * 8) = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    // this wave's W rows as the FIRST MFMA operand (rows of D^T = output columns): row n0 + 32 cg + l31, k = 16 ks + 8 half ..
+    bf16x8 wf[2][KS];
+    {
+        const unsigned short* wp = g.B[p][0] + (size_t)(n0 + l31) * g.ldbp[p] + 8 * half;
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                wf[cg][ks] = *reinterpret_cast<const bf16x8*>(wp + (size_t)cg * 32 * g.ldbp[p] + ks * 16);
+    }
+    const int nch = min(cpw, (Ml - m0 + 31) / 32);
+    const unsigned lds0 = lds_addr(smem);
+    unsigned short* patch = smem + NSTG * STG + wave * (32 * LDP);
+    // DMA instruction i of a chunk: x rows RPI i .. of the chunk; lane -> (row l / PPR, slot l % PPR); piece = slot ^ (row & 15)
+    // (the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots of the 256-B bank cycle)
+    const int rl = lane / PPR, sl = lane % PPR;
+    const unsigned short* Ab = g.A[p][0];
+    const unsigned lda = (unsigned)g.ldap[p];
+    auto stage = [&](int c) {
+        const unsigned dst = lds0 + (unsigned)((c % NSTG) * STG) * 2u;
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) {
+            const int i = ii * 4 + wave;
+            const int r = RPI * i + rl;                  // row inside the chunk
+            const int gr = min(m0 + 32 * c + r, Ml - 1);
+            glds16(Ab, ((unsigned)gr * lda + (unsigned)((sl ^ (r & 15)) * 8)) * 2u, dst + (unsigned)i * 1024u);
+        }
+    };
+    constexpr int PDW = NSTG - 1;
+    const int dbg = g.dbg;
+    for (int c = 0; c < PDW && c < nch && !(dbg & 2); ++c) stage(c);
+    for (int c = 0; c < nch; ++c) {
+        wait_stage<IPS, PDW>(min(nch - c - 1, PDW - 1));
+        __syncthreads();
+        if (c + PDW < nch && !(dbg & 2)) stage(c + PDW);
+        const unsigned short* As = smem + (c % NSTG) * STG;
+        f32x16 acc[2];
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cg][r] = 0.f;
+        constexpr int PF = 4;
+        bf16x8 af[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) af[j] = *reinterpret_cast<const bf16x8*>(As + l31 * KD + (((2 * j + half) ^ (l31 & 15)) << 3));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (!(dbg & 4)) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], af[ks % PF], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], af[ks % PF], acc[1], 0, 0, 0);
+            }
+            if (ks + PF < KS)
+                af[ks % PF] = *reinterpret_cast<const bf16x8*>(As + l31 * KD + (((2 * (ks + PF) + half) ^ (l31 & 15)) << 3));
+        }
+        // epilogue of the chunk: acc[cg] = D^T, lane <-> output row l31, register r <-> column 32 cg + (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 v;
+                v.x = srec_pack_bf16(acc[cg][4 * q], acc[cg][4 * q + 1]);
+                v.y = srec_pack_bf16(acc[cg][4 * q + 2], acc[cg][4 * q + 3]);
+                *reinterpret_cast<uint2*>(patch + l31 * LDP + cg * 32 + 8 * q + 4 * half) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = t * 64 + lane, rr = idx >> 3, pc = idx & 7;
+            const int row = m0 + 32 * c + rr;
+            uint4 v = *reinterpret_cast<const uint4*>(patch + rr * LDP + pc * 8);
+            if (row >= M || (g.keep_dead && row >= Ml) || (dbg & 1)) continue;
+            if (row >= Ml) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc + n0 + pc * 8) = v;
+        }
+        __builtin_amdgcn_wave_barrier();                 // (the next chunk's patch writes come after these reads)
+    }
+    // rows of this group behind the live count (the chunk loop stopped at the last live chunk)
+    if (!g.keep_dead)
+        for (int i = tid + 32 * nch * 32; i < rows_here * 32; i += 256)
+            *reinterpret_cast<uint4*>(Cp + (size_t)(m0 + i / 32) * ldc + nb + (i % 32) * 8) = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // -------------------------------------------------------------------------------------------------- tn16
@@ -597,6 +726,37 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     if (!(variant & 8) && !(h->c16 & 1) && tm == 64 && t64x128 > 384) {
         const long r64 = cdiv((int)cdiv((int)t64x128, 8), 96), r128 = cdiv((int)cdiv((int)t128, 8), 64);
         if (r128 * 105 < r64 * 100) tm = 128;
+    }
+    // forward projections (bf16 output, one K segment, K = 128 / 256, N a multiple of 256): the weights-in-registers kernel
+    // (c16 bit 10 keeps the tiled kernel: A/B measurements, tools/gemm16_bench.py)
+    if ((h->c16 & 1) && !((h->c16 >> 10) & 1) && !(variant & 8)) {
+        bool ok = true;
+        for (int p = 0; p < h->np; ++p)
+            ok = ok && h->nseg[p] == 1 && (h->K[p] == 256 || h->K[p] == 128) && h->K[p] == h->K[0] && (h->N[p] & 255) == 0 &&
+                 ((h->ldc_p[p] > 0 ? h->ldc_p[p] : h->ldc) & 7) == 0 && (((uintptr_t)h->C[p]) & 15) == 0;
+        if (ok) {
+            // chunks (32 rows) per workgroup: ~2 workgroups per CU over the LIVE rows
+            long units = 0;
+            for (int p = 0; p < h->np; ++p) units += (long)cdiv(Mh(p), 32) * (h->N[p] / 256);
+            int cpw = (int)cdiv((int)units, 512);
+            cpw = cpw < 2 ? 2 : (cpw > 16 ? 16 : cpw);
+            if (int rc = fill(g, desc_, 32 * cpw, 256, false, blocks)) return rc;
+            g.dbg = (h->c16 >> 11) & 7;
+            const int tiles_per_xcd = cdiv(blocks, 8);
+            hipStream_t st0 = (hipStream_t)stream;
+            static std::atomic<unsigned long long> om2[2];
+            if (h->K[0] == 256) {
+                const size_t lds = (size_t)3 * 32 * 256 * 2 + 4 * 32 * 72 * 2;
+                if (int rc = optin(gemm16_fwd_wres_kernel<256, 3>, (int)lds, om2[0])) return rc;
+                hipLaunchKernelGGL((gemm16_fwd_wres_kernel<256, 3>), dim3(8 * tiles_per_xcd), dim3(256), lds, st0, g, cpw, tiles_per_xcd);
+            } else {
+                const size_t lds = (size_t)4 * 32 * 128 * 2 + 4 * 32 * 72 * 2;
+                if (int rc = optin(gemm16_fwd_wres_kernel<128, 4>, (int)lds, om2[1])) return rc;
+                hipLaunchKernelGGL((gemm16_fwd_wres_kernel<128, 4>), dim3(8 * tiles_per_xcd), dim3(256), lds, st0, g, cpw, tiles_per_xcd);
+            }
+            SREC_LAUNCH_CHECK();
+            return 0;
+        }
     }
     const int tn = (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
     if (int rc = fill(g, desc_, tm, tn, false, blocks)) return rc;

@@ -828,6 +828,22 @@ def test_gemm16_nt(dev, c16):
                 close(C.float(), r.bfloat16().float(), what='nt16 c16', rtol=1e-2, atol=1e-2)     # one bf16 ulp
             else:
                 close(C, r, what='nt16 f32', rtol=1e-4, atol=1e-3)
+    if c16:
+        # forward projections: the weights-in-registers kernel (K = 128 / 256, N % 256 == 0) against the tiled kernel
+        # (variant 64) - same products, same k order: bit-identical; dead rows zeroed / left alone (keep_dead)
+        for (M, N, K, live) in ((2560, 2048, 256, 2371), (777, 1024, 128, 500), (96, 256, 256, 96), (4000, 2048, 256, 31)):
+            A, B = bf(M, K), bf(N, K)
+            dyn = torch.tensor([live], device=dev, dtype=torch.int32)
+            outs = []
+            for variant, keep in ((0, False), (64, False), (0, True)):
+                C = torch.full((M, N), 3.0, device=dev, dtype=torch.bfloat16)
+                ops.gemm16('nt', [(M, N, K, [(A, B)], C, dyn)], K, K, N, c16=True, keep_dead=keep, variant=variant)
+                outs.append(C)
+            r = (A.float() @ B.float().t()).bfloat16()
+            r[live:] = 0
+            close(outs[0].float(), r.float(), what='fwd wres %r' % ((M, N, K),), rtol=1e-2, atol=1e-2)
+            assert torch.equal(outs[0], outs[1]), (M, N, K)
+            assert torch.equal(outs[2][:live], outs[0][:live]) and bool((outs[2][live:] == 3.0).all())
     if not c16:   # segments + beta (backward-data: sum over modules, accumulated onto the residual gradient)
         M, N, K = 1500, 256, 2048
         A1, A2, B1, B2 = bf(M, K), bf(M, K), bf(N, K), bf(N, K)
