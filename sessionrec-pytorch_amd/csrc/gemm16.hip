@@ -43,7 +43,6 @@ struct G16Args {
     int keep_dead;                // leave output rows past the live count unwritten (nobody reads them)
     int per_xcd;                  // > 0: XCD-aware tile order (see xcd_tile), tiles per XCD
     int xcd_gs;                   // > 0: sibling groups of xcd_gs tiles dealt to the XCDs round-robin instead of runs
-    int dbg;                      // development: phases of gemm16_fwd_wres_kernel switched off (tools/fwd_wres_bench.py)
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -381,12 +380,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_fwd_wres_kernel(G16Args g, int 
         }
     };
     constexpr int PDW = NSTG - 1;
-    const int dbg = g.dbg;
-    for (int c = 0; c < PDW && c < nch && !(dbg & 2); ++c) stage(c);
+    for (int c = 0; c < PDW && c < nch; ++c) stage(c);
     for (int c = 0; c < nch; ++c) {
         wait_stage<IPS, PDW>(min(nch - c - 1, PDW - 1));
         __syncthreads();
-        if (c + PDW < nch && !(dbg & 2)) stage(c + PDW);
+        if (c + PDW < nch) stage(c + PDW);
         const unsigned short* As = smem + (c % NSTG) * STG;
         f32x16 acc[2];
 #pragma unroll
@@ -399,10 +397,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_fwd_wres_kernel(G16Args g, int 
         for (int j = 0; j < PF; ++j) af[j] = *reinterpret_cast<const bf16x8*>(As + l31 * KD + (((2 * j + half) ^ (l31 & 15)) << 3));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (!(dbg & 4)) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], af[ks % PF], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], af[ks % PF], acc[1], 0, 0, 0);
-            }
             if (ks + PF < KS)
                 af[ks % PF] = *reinterpret_cast<const bf16x8*>(As + l31 * KD + (((2 * (ks + PF) + half) ^ (l31 & 15)) << 3));
         }
@@ -423,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_fwd_wres_kernel(G16Args g, int 
             const int idx = t * 64 + lane, rr = idx >> 3, pc = idx & 7;
             const int row = m0 + 32 * c + rr;
             uint4 v = *reinterpret_cast<const uint4*>(patch + rr * LDP + pc * 8);
-            if (row >= M || (g.keep_dead && row >= Ml) || (dbg & 1)) continue;
+            if (row >= M || (g.keep_dead && row >= Ml) ) continue;
             if (row >= Ml) v = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc + n0 + pc * 8) = v;
         }
@@ -727,9 +723,11 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
         const long r64 = cdiv((int)cdiv((int)t64x128, 8), 96), r128 = cdiv((int)cdiv((int)t128, 8), 64);
         if (r128 * 105 < r64 * 100) tm = 128;
     }
-    // forward projections (bf16 output, one K segment, K = 128 / 256, N a multiple of 256): the weights-in-registers kernel
-    // (c16 bit 10 keeps the tiled kernel: A/B measurements, tools/gemm16_bench.py)
-    if ((h->c16 & 1) && !((h->c16 >> 10) & 1) && !(variant & 8)) {
+    // forward projections (bf16 output, one K segment, K = 128 / 256, N a multiple of 256): c16 bit 10 selects the
+    // weights-in-registers kernel.  Measured (tools/fwd_wres_bench.py, profiles/r03_notes.md): bit-identical results, 50 vs 53 us
+    // at the step's capacities, 39 vs 34 us at loose ones, no difference inside the step (0.935 vs 0.934 ms) - a quarter of
+    // the LDS-DMA pieces did not move the launch, so the piece rate is not what bounds it; the tiled kernel stays the default
+    if ((h->c16 & 1) && ((h->c16 >> 10) & 1) && !(variant & 8)) {
         bool ok = true;
         for (int p = 0; p < h->np; ++p)
             ok = ok && h->nseg[p] == 1 && (h->K[p] == 256 || h->K[p] == 128) && h->K[p] == h->K[0] && (h->N[p] & 255) == 0 &&
@@ -741,7 +739,6 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
             int cpw = (int)cdiv((int)units, 512);
             cpw = cpw < 2 ? 2 : (cpw > 16 ? 16 : cpw);
             if (int rc = fill(g, desc_, 32 * cpw, 256, false, blocks)) return rc;
-            g.dbg = (h->c16 >> 11) & 7;
             const int tiles_per_xcd = cdiv(blocks, 8);
             hipStream_t st0 = (hipStream_t)stream;
             static std::atomic<unsigned long long> om2[2];

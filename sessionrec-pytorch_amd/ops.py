@@ -2271,6 +2271,9 @@ class GemmGroup16(_ct.Structure):
                 ('lda_p', _ct.c_int * 16), ('ldb_p', _ct.c_int * 16), ('ldc_p', _ct.c_int * 16), ('mhint', _ct.c_int * 16)]
 
 
+_FWD_VARIANT = 64 if os.environ.get('SREC_FWD_WRES') == '1' else 0     # 64: the weights-in-registers forward kernel (A/B runs)
+
+
 def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, variant=0):
     """one grouped launch of the bf16-in-HBM GEMMs (csrc/gemm16.hip).  probs: [(M, N, K, [(A16, B16), ...], C, dyn)].
     kind 'nt': C [M, N] (+)= sum_s A_s [M, K] B_s [N, K]^T (c16: bf16 output);  'tn': C [M, N] = sum_s A_s [K, M]^T B_s [K, N]
@@ -2502,7 +2505,7 @@ class HGATLayer(torch.autograd.Function):
                      for m in range(nm) for (o, t0, nc, dyn_t) in plan.pieces(m)]
             for i in range(0, len(probs), 16):
                 # rows past a type's live count are never read (every hgat.hip kernel walks the live prefix only)
-                gemm16('nt', probs[i:i + 16], D, D, HD, c16=True, keep_dead=True)
+                gemm16('nt', probs[i:i + 16], D, D, HD, c16=True, keep_dead=True, variant=_FWD_VARIANT)
             g16 = (x16, wt16)
         elif grouped:
             gemm_group(0, [(nr, HD, D, [(xin(m)[r0:r0 + nr], params[4 * m])], P[m], dyn)

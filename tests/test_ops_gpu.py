@@ -829,13 +829,13 @@ def test_gemm16_nt(dev, c16):
             else:
                 close(C, r, what='nt16 f32', rtol=1e-4, atol=1e-3)
     if c16:
-        # forward projections: the weights-in-registers kernel (K = 128 / 256, N % 256 == 0) against the tiled kernel
-        # (variant 64) - same products, same k order: bit-identical; dead rows zeroed / left alone (keep_dead)
+        # forward projections: the weights-in-registers kernel (variant 64; K = 128 / 256, N % 256 == 0) against the tiled
+        # kernel - same products, same k order: bit-identical; dead rows zeroed / left alone (keep_dead)
         for (M, N, K, live) in ((2560, 2048, 256, 2371), (777, 1024, 128, 500), (96, 256, 256, 96), (4000, 2048, 256, 31)):
             A, B = bf(M, K), bf(N, K)
             dyn = torch.tensor([live], device=dev, dtype=torch.int32)
             outs = []
-            for variant, keep in ((0, False), (64, False), (0, True)):
+            for variant, keep in ((64, False), (0, False), (64, True)):
                 C = torch.full((M, N), 3.0, device=dev, dtype=torch.bfloat16)
                 ops.gemm16('nt', [(M, N, K, [(A, B)], C, dyn)], K, K, N, c16=True, keep_dead=keep, variant=variant)
                 outs.append(C)
