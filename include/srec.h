@@ -335,6 +335,10 @@ int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
  * Replaces the chain of cuBLAS calls of the attention read-out / session-vector head (msgifsr.py:127-146,272-279;
  * srgnn.py:73-88,123-127) and their backward. */
 int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream);
+/* The same with the split-K sums of skinny problems done INSIDE the launch (the workgroup that arrives last at an output tile
+ * adds the partial tiles in slab order: bit-identical to the separate reduce launch, one kernel node less per group).
+ * tickets: n_tickets device ints, all zero before the first call, owned by this entry point (left zero by every launch). */
+int srec_gemm_f32_group_run_fused(const void* desc, float* ws, long ws_floats, int* tickets, int n_tickets, void* stream);
 
 /* bf16-in-HBM grouped GEMMs (gemm16.hip): the GAT fc projections and their backward (gatconv.py:166-175,282-283) with every
  * operand already stored as bf16 - LDS-DMA staging, no conversion pass.  desc: host srec_gemm16_group (srec_hg.h, up to 16

@@ -38,6 +38,13 @@ def _ws(n, device):
 _GEMM_WS = {}
 
 
+_GEMM_TK = {}
+# in-kernel split-K sums (srec_gemm_f32_group_run_fused): bit-identical, one node less per group - and 1.067 vs 0.936 ms per step:
+# the device-scope release / acquire fences that make the partial tiles visible across the 8 XCDs' L2s write back and invalidate
+# whole L2s, once per workgroup (profiles/r03_notes.md).  Off unless asked for.
+_GEMM_FUSED_REDUCE = os.environ.get('SREC_GEMM_FUSED_REDUCE', '0') == '1'
+
+
 def _gemm_ws(device):
     t = _GEMM_WS.get(str(device))
     if t is None:
@@ -819,7 +826,14 @@ def gemm_f32_group(probs):
         g.M[p], g.N[p], g.K[p] = M, N, K
         g.dyn[p], g.dyn_mode[p] = ptr(dyn), (mode if dyn is not None else 0)
         g.alpha[p], g.beta[p] = 1.0, beta
-    lib.srec_gemm_f32_group_run(_ct.addressof(g), *_gemm_ws(probs[0][1].device), stream())
+    dev = probs[0][1].device
+    tk = _GEMM_TK.get(str(dev))
+    if tk is None:          # arrival counters of the in-kernel split-K sums: zero once, left zero by every launch
+        tk = _GEMM_TK[str(dev)] = torch.zeros(4096, device=dev, dtype=torch.int32)
+    if _GEMM_FUSED_REDUCE:
+        lib.srec_gemm_f32_group_run_fused(_ct.addressof(g), *_gemm_ws(dev), tk.data_ptr(), tk.numel(), stream())
+    else:
+        lib.srec_gemm_f32_group_run(_ct.addressof(g), *_gemm_ws(dev), stream())
 
 
 _ONES4 = {}

@@ -1234,3 +1234,40 @@ def test_copy_words_reads_pinned_host_memory(dev, n):
     assert torch.equal(dst2[:n].cpu(), src[:n]) and bool((dst2[n:] == 0).all())
     with pytest.raises(AssertionError):
         ops.copy_words(torch.zeros(8, dtype=torch.int32), dst, 8)  # pageable host memory: refused, a kernel cannot read it
+
+
+def test_gemm_f32_group_in_kernel_split_k_sums_equal_the_reduce_launch(dev):
+    """srec_gemm_f32_group_run_fused: the workgroup arriving last at an output tile adds the split-K partial tiles in slab
+    order - bit-identical to the separate reduce launch, repeatable (the arrival counters return to zero), with bias /
+    beta / dynamic row counts / strided outputs"""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    NT, B, d = 7000, 512, 256
+    allf, dU, v, dVq, cat, Wsr, bias = r(NT, d), r(NT, d), r(B, d), r(B, d), r(B, 2 * d), r(d, 2 * d), r(d)
+    liveT = torch.tensor([6543], device=dev, dtype=torch.int32)
+    liveB = torch.tensor([501], device=dev, dtype=torch.int32)
+    acc0 = r(B, d)
+
+    def run(fused):
+        old = ops._GEMM_FUSED_REDUCE
+        ops._GEMM_FUSED_REDUCE = fused
+        try:
+            gWu, gWv, out = torch.empty(d, d, device=dev), torch.empty(d, d, device=dev), torch.full((B, d), 5.0, device=dev)
+            acc = acc0.clone()
+            ops.gemm_f32_group([('tn', dU, allf, gWu, None, liveT, 0.0), ('tn', dVq, v, gWv, None, liveB, 0.0),
+                                ('nt', cat, Wsr, out, bias, liveB, 0.0), ('nt', cat, Wsr, acc, None, liveB, 1.0)])
+            return gWu, gWv, out, acc
+        finally:
+            ops._GEMM_FUSED_REDUCE = old
+    ref = run(False)
+    for rep in range(4):
+        got = run(True)
+        for a, b, nm in zip(got, ref, ('gWu', 'gWv', 'out', 'acc')):
+            assert torch.equal(a, b), (rep, nm, (a - b).abs().max().item())
+    tk = ops._GEMM_TK[str(dev)]
+    assert int(tk.abs().sum()) == 0
+    close(ref[0], dU[:6543].t() @ allf[:6543], what='gWu', atol=5e-4)
+    o = cat @ Wsr.t() + bias
+    o[501:] = 0
+    close(ref[2], o, what='out', atol=1e-4)
