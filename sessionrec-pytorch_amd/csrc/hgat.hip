@@ -378,6 +378,250 @@ extern "C" int srec_hg_timing(unsigned long long* tim16, unsigned long long* blk
 }
 #endif
 
+// One WAVEFRONT per destination node, all heads in the lane (H = 8, D % 8 == 0): lane = (head parity = lane >> 5, columns
+// 8 (lane & 31) .. + 7), i.e. a lane accumulates heads parity, parity + 2, + 4, + 6 of its 8 columns (32 registers) and an edge
+// costs FOUR 16-byte row loads per lane.  Against the 8-wave workgroup above (wave = head) the dependent chain in_ptr -> in_idx ->
+// esrc -> logits -> soft-max runs ONCE per node instead of once per head-wave (lane = (instance, edge) as in its fast path, the
+// 8 logits of an edge are two 16-byte loads), the head-max is in registers (one exchange between the wave's halves, no LDS, no
+// barrier), bias / residual / session mean are read once.  Same summation order per output element as hg_agg_kernel:
+// bit-identical results (tests/test_ops_gpu.py).
+template <typename T> struct Row8;
+template <> struct Row8<unsigned short> {
+    uint4 v;
+    __device__ __forceinline__ void load(const unsigned short* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void get(float (&f)[8]) const {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+};
+template <> struct Row8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void zero() { a = b = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void get(float (&f)[8]) const {
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+};
+__device__ __forceinline__ float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+constexpr int AGG_EIF = 2;          // edges (x 4 row loads of 16 bytes) in flight per wave
+
+template <typename T>
+__global__ __launch_bounds__(256) void hg_agg_node_kernel(AggArgs a) {
+    __shared__ float sc[WPB][MAXH][MAXDEG];                        // general path only (a relation with > 8 in-edges)
+    __shared__ int su[WPB][MAXDEG];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * WPB + w;
+    if (row >= a.row0[a.nt]) return;
+    constexpr int H = MAXH;
+    const int D = a.D, HD = H * D;
+    const int t = find_range(a.row0, a.nt, row);
+    const int v = row - a.row0[t];
+    const bool live = v < dyn_count(a.dyn_n[t], a.ncap[t]);
+    const int half = lane >> 5, c = (lane & 31) * 8;
+    const bool cok = c < D;
+    const int sb = live ? a.sess[row] : 0;                          // early: hidden behind the edge chains
+    float acc[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[k][x] = 0.f;
+    if (live) {
+        const int q = lane >> 3, j = lane & 7;
+        int i = -1, beg = 0, deg = 0;
+        if (q < a.ninst[t]) {
+            i = a.inst[t][q];
+            beg = a.in_ptr[i][v];
+            deg = a.in_ptr[i][v + 1] - beg;
+        }
+        const bool fast = a.ninst[t] <= 8 && __ballot(deg > 8) == 0ull;
+        if (fast) {
+            const bool valid = i >= 0 && j < deg;
+            int e = 0, src = 0;
+            float pm[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) pm[h] = -INFINITY;
+            if (valid) {
+                e = a.in_idx[i][beg + j];
+                src = a.esrc[i][e];
+                float el[8], er[8];
+                ld8f(a.eLs[i] + (size_t)src * H, el);
+                ld8f(a.eRd[i] + (size_t)v * H, er);
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const float sv = el[h] + er[h];
+                    pm[h] = sv > 0.f ? sv : a.slope * sv;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const float sv = pm[h];
+                float m = sv;
+                m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+                const float ex = valid ? expf(sv - m) : 0.f;
+                float z = ex;
+                z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64); z += __shfl_xor(z, 4, 64);
+                pm[h] = valid ? ex / z : 0.f;
+            }
+            if (valid) {
+                float* ap = a.A[i] + (size_t)e * H;                  // soft-max values (the backward needs them)
+                *reinterpret_cast<float4*>(ap) = make_float4(pm[0], pm[1], pm[2], pm[3]);
+                *reinterpret_cast<float4*>(ap + 4) = make_float4(pm[4], pm[5], pm[6], pm[7]);
+                if (a.Mk[i] != nullptr) {
+                    float mk[8];
+                    ld8f(a.Mk[i] + (size_t)e * H, mk);
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) pm[h] *= mk[h];
+                }
+            }
+            unsigned long long mask = __ballot(valid);
+            while (mask != 0ull) {
+                Row8<T> f[AGG_EIF][4];
+                float pp[AGG_EIF][4];
+#pragma unroll
+                for (int u = 0; u < AGG_EIF; ++u) {
+                    const bool on = mask != 0ull;
+                    const int l = on ? __builtin_ctzll(mask) : 0;
+                    if (on) mask &= mask - 1ull;
+                    const int ii = __builtin_amdgcn_readlane(i, l), ss = __builtin_amdgcn_readlane(src, l);
+                    const T* rp = static_cast<const T*>(a.Ps[ii >= 0 ? ii : 0]) + (size_t)ss * HD + half * D + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float p0 = rdlane(pm[2 * k], l), p1 = rdlane(pm[2 * k + 1], l);
+                        pp[u][k] = on ? (half ? p1 : p0) : 0.f;
+                        if (on && cok) f[u][k].load(rp + 2 * k * D); else f[u][k].zero();
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < AGG_EIF; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float fv[8];
+                        f[u][k].get(fv);
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) acc[k][x] += pp[u][k] * fv[x];
+                    }
+            }
+        } else {
+            for (int qq = 0; qq < a.ninst[t]; ++qq) {
+                const int ig = a.inst[t][qq];
+                const int* ip = a.in_ptr[ig];
+                const int bg = ip[v], dg = min(ip[v + 1] - bg, MAXDEG);
+                const int* idx = a.in_idx[ig] + bg;
+                for (int jj = lane; jj < dg; jj += 64) su[w][jj] = a.esrc[ig][idx[jj]];
+                __builtin_amdgcn_wave_barrier();
+                const float* mk = a.Mk[ig];
+                for (int h = 0; h < H; ++h) {
+                    const float erv = a.eRd[ig][(size_t)v * H + h];
+                    float m = -INFINITY;
+                    for (int jj = lane; jj < dg; jj += 64) {
+                        float s = a.eLs[ig][(size_t)su[w][jj] * H + h] + erv;
+                        s = s > 0.f ? s : a.slope * s;
+                        sc[w][h][jj] = s;
+                        m = fmaxf(m, s);
+                    }
+                    m = wave_max(m);
+                    float z = 0.f;
+                    for (int jj = lane; jj < dg; jj += 64) z += expf(sc[w][h][jj] - m);
+                    z = wave_sum(z);
+                    const float iz = dg > 0 ? 1.f / z : 0.f;
+                    for (int jj = lane; jj < dg; jj += 64) {
+                        const float p = expf(sc[w][h][jj] - m) * iz;
+                        a.A[ig][(size_t)idx[jj] * H + h] = p;
+                        sc[w][h][jj] = mk != nullptr ? p * mk[(size_t)idx[jj] * H + h] : p;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (cok) {
+                    const T* ps = static_cast<const T*>(a.Ps[ig]) + half * D + c;
+                    for (int jj = 0; jj < dg; ++jj) {
+                        const T* rp = ps + (size_t)su[w][jj] * HD;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            Row8<T> f;
+                            f.load(rp + 2 * k * D);
+                            float fv[8];
+                            f.get(fv);
+                            const float p = sc[w][2 * k + half][jj];
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) acc[k][x] += p * fv[x];
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (cok) {
+            if (a.ninst[t] > 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float bv[8];
+                    ld8f(a.bsum[t] + (2 * k + half) * D + c, bv);
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) acc[k][x] += bv[x];
+                }
+            }
+            float xv[8];
+            if (a.xres != nullptr) {
+                ld8f(a.xres + (size_t)row * a.ld_x + c, xv);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) acc[k][x] += xv[x];
+            } else {
+                const float nres = (float)a.ninst[t];
+                ld8f(a.x + (size_t)row * a.ld_x + c, xv);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) acc[k][x] += nres * xv[x];
+            }
+        }
+    }
+    // head-max: this lane's four heads (ascending, first maximum wins as in a scan over h = 0 .. 7), then the other parity's
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        float b = -INFINITY;
+        int bh = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (acc[k][x] > b) { b = acc[k][x]; bh = 2 * k + half; }
+        const float ob = __shfl_xor(b, 32, 64);
+        const int oh = __shfl_xor(bh, 32, 64);
+        // the scan picks the lowest head among equal maxima; a lane half that saw only NaN / -inf keeps (-inf, 0)
+        if (ob > b || (ob == b && oh < bh)) { b = ob; bh = oh; }
+        best[x] = b; bi[x] = bh;
+    }
+    if (half == 0 && cok) {
+        float o[8];
+        unsigned lo = 0u, hi = 0u;
+        if (live) {
+            float sm[8];
+            ld8f(a.smean[t] + (size_t)sb * D + c, sm);
+#pragma unroll
+            for (int x = 0; x < 8; ++x) o[x] = best[x] + sm[x];   // + mean of the session's input features (nodes of this type)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { lo |= (unsigned)bi[x] << (8 * x); hi |= (unsigned)bi[4 + x] << (8 * x); }
+        } else {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) o[x] = 0.f;
+        }
+        float* op = a.out + (size_t)row * a.ld_out + c;
+        *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        *reinterpret_cast<uint2*>(a.arg + (size_t)row * D + c) = make_uint2(lo, hi);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 struct PreArgs {
     const int* seg[MAXT]; const int* dyn_n[MAXT];
@@ -932,7 +1176,19 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         g.A[i] = d->A[i]; g.Mk[i] = d->Mk[i];
     }
     if (rows > 0) {
-        if (d->p16) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
+        // wave-per-node kernel: 8 heads, 8-column lanes, 16-byte loads of the per-(node | edge, head) arrays
+        const char* env = getenv("SREC_HG_AGG");                 // "old": the 8-wave workgroup per node (A/B, tests); read per call
+        const bool force_old = env != nullptr && env[0] == 'o';
+        auto al16 = [](const void* p) { return ((size_t)p & 15) == 0; };
+        bool node = !force_old && H == MAXH && (D & 7) == 0 && (ld_x & 3) == 0 && (ld_out & 3) == 0 && al16(out) && al16(arg) &&
+                    al16(x) && al16(g.xres);
+        for (int t = 0; node && t < d->n_types; ++t) node = al16(g.smean[t]) && (g.ninst[t] == 0 || al16(g.bsum[t]));
+        for (int i = 0; node && i < d->n_inst; ++i)
+            node = al16(g.Ps[i]) && al16(g.eLs[i]) && al16(g.eRd[i]) && al16(g.A[i]) && al16(g.Mk[i]);
+        if (node) {
+            if (d->p16) hipLaunchKernelGGL(hg_agg_node_kernel<unsigned short>, dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
+            else hipLaunchKernelGGL(hg_agg_node_kernel<float>, dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
+        } else if (d->p16) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
         else hipLaunchKernelGGL(hg_agg_kernel<float>, dim3(rows), dim3(512), 0, st, g);
     }
     SREC_LAUNCH_CHECK();
