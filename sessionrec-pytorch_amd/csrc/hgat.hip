@@ -411,10 +411,8 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
-constexpr int AGG_EIF = 2;          // edges (x 4 row loads of 16 bytes) in flight per wave
-
-template <typename T>
-__global__ __launch_bounds__(256) void hg_agg_node_kernel(AggArgs a) {
+template <typename T, int AGG_EIF, int WV>   // AGG_EIF: edges (x 4 row loads of 16 bytes) in flight per wave; WV: waves per SIMD
+__global__ __launch_bounds__(256, WV) void hg_agg_node_kernel(AggArgs a) {
     __shared__ float sc[WPB][MAXH][MAXDEG];                        // general path only (a relation with > 8 in-edges)
     __shared__ int su[WPB][MAXDEG];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -803,14 +801,25 @@ struct SrcArgs {
 //                 sum_{e in out(u)} A[e,h] * dT[dst_e,h,:] + del[u,h] * a_l[h,:]   (del = sum of DP over out-edges)
 //             + sum over the instances that use it as DESTINATION of der[u,h] * a_r[h,:];  wL / wR = summed del / der.
 // dT[dst,h,c] = g[dst,c] * [arg[dst,c] == h]: the row g[dst,:] is read once per edge, not once per head.
+// Workgroup = WPB_SRC nodes of ONE block: the block's attention vectors a_l | a_r (2 x H*D floats, 16 KB at H = 8, D = 256)
+// are staged in LDS once per workgroup - read per wave from L2 they were 17 of the kernel's 58 us (knock-out runs, r03 notes).
+constexpr int WPB_SRC = 4;
 template <typename T>
-__global__ void hg_bwd_src_kernel(SrcArgs a) {
+__global__ __launch_bounds__(64 * WPB_SRC) void hg_bwd_src_kernel(SrcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float alr[];       // [2][H*D]
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
     const int lane = threadIdx.x & 63;
-    const int u = ((int)blockIdx.x - a.start[b]) * WPB + (threadIdx.x >> 6);
+    const int u = ((int)blockIdx.x - a.start[b]) * WPB_SRC + (threadIdx.x >> 6);
     const int H = a.H, D = a.D, HD = H * D;
-    if (u >= a.ncap[b]) return;
-    const bool live = u < dyn_count(a.dyn[b], a.ncap[b]);
+    {
+        const float* al = a.al[b]; const float* ar = a.ar[b];
+        for (int i = threadIdx.x * 4; i < HD; i += 64 * WPB_SRC * 4) {
+            *reinterpret_cast<float4*>(alr + i) = *reinterpret_cast<const float4*>(al + i);
+            *reinterpret_cast<float4*>(alr + HD + i) = *reinterpret_cast<const float4*>(ar + i);
+        }
+    }
+    const bool in_range = u < a.ncap[b];
+    const bool live = in_range && u < dyn_count(a.dyn[b], a.ncap[b]);
     const int c = lane * 4, hl = lane & 7, jl = lane >> 3;
     float4 o[MAXH];
 #pragma unroll
@@ -834,12 +843,23 @@ __global__ void hg_bwd_src_kernel(SrcArgs a) {
                     const uchar4 bi = *reinterpret_cast<const uchar4*>(a.arg + row * D + c);
                     const float* ae = a.A[i] + (size_t)e * H;
                     const float* me = a.Mk[i] != nullptr ? a.Mk[i] + (size_t)e * H : nullptr;
+                    float p[MAXH];
+                    if (H == MAXH) {                   // the 8 soft-max values (and multipliers) of an edge: 16-byte loads
+                        const float4 a0 = *reinterpret_cast<const float4*>(ae), a1 = *reinterpret_cast<const float4*>(ae + 4);
+                        p[0] = a0.x; p[1] = a0.y; p[2] = a0.z; p[3] = a0.w; p[4] = a1.x; p[5] = a1.y; p[6] = a1.z; p[7] = a1.w;
+                        if (me != nullptr) {
+                            const float4 m0 = *reinterpret_cast<const float4*>(me), m1 = *reinterpret_cast<const float4*>(me + 4);
+                            p[0] *= m0.x; p[1] *= m0.y; p[2] *= m0.z; p[3] *= m0.w; p[4] *= m1.x; p[5] *= m1.y; p[6] *= m1.z; p[7] *= m1.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < MAXH; ++h) p[h] = h < H ? (me != nullptr ? ae[h] * me[h] : ae[h]) : 0.f;
+                    }
 #pragma unroll
                     for (int h = 0; h < MAXH; ++h) {
                         if (h < H) {
-                            const float p = me != nullptr ? ae[h] * me[h] : ae[h];
-                            o[h].x += bi.x == h ? p * gv.x : 0.f; o[h].y += bi.y == h ? p * gv.y : 0.f;
-                            o[h].z += bi.z == h ? p * gv.z : 0.f; o[h].w += bi.w == h ? p * gv.w : 0.f;
+                            o[h].x += bi.x == h ? p[h] * gv.x : 0.f; o[h].y += bi.y == h ? p[h] * gv.y : 0.f;
+                            o[h].z += bi.z == h ? p[h] * gv.z : 0.f; o[h].w += bi.w == h ? p[h] * gv.w : 0.f;
                         }
                     }
                 }
@@ -848,14 +868,16 @@ __global__ void hg_bwd_src_kernel(SrcArgs a) {
         if (hl < H)
             for (int q = 0; q < a.ndst[b]; ++q) wr += a.der[a.dst[b][q]][(size_t)u * H + hl];
     }
+    __syncthreads();                                   // a_l | a_r are in LDS
+    if (!in_range) return;
     T* dp = static_cast<T*>(a.dP[b]) + (size_t)u * HD + c;
 #pragma unroll
     for (int h = 0; h < MAXH; ++h) {
         if (h < H) {
             const float wlh = __shfl(wl, h, 64), wrh = __shfl(wr, h, 64);
             if (c < D) {
-                const float4 l4 = *reinterpret_cast<const float4*>(a.al[b] + h * D + c);
-                const float4 r4 = *reinterpret_cast<const float4*>(a.ar[b] + h * D + c);
+                const float4 l4 = *reinterpret_cast<const float4*>(alr + h * D + c);
+                const float4 r4 = *reinterpret_cast<const float4*>(alr + HD + h * D + c);
                 float4 v = o[h];
                 v.x += wlh * l4.x + wrh * r4.x; v.y += wlh * l4.y + wrh * r4.y;
                 v.z += wlh * l4.z + wrh * r4.z; v.w += wlh * l4.w + wrh * r4.w;
@@ -1186,8 +1208,17 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         for (int i = 0; node && i < d->n_inst; ++i)
             node = al16(g.Ps[i]) && al16(g.eLs[i]) && al16(g.eRd[i]) && al16(g.A[i]) && al16(g.Mk[i]);
         if (node) {
-            if (d->p16) hipLaunchKernelGGL(hg_agg_node_kernel<unsigned short>, dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
-            else hipLaunchKernelGGL(hg_agg_node_kernel<float>, dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
+            const char* ee = getenv("SREC_HG_EIF");
+            const int eif = ee ? atoi(ee) : 15;
+#define AGGL(E, W) hipLaunchKernelGGL((hg_agg_node_kernel<unsigned short, E, W>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g)
+            if (!d->p16) hipLaunchKernelGGL((hg_agg_node_kernel<float, 2, 3>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
+            else if (eif == 14) AGGL(1, 4);
+            else if (eif == 15) AGGL(1, 5);
+            else if (eif == 16) AGGL(1, 6);
+            else if (eif == 18) AGGL(1, 8);
+            else if (eif == 25) AGGL(2, 5);
+            else if (eif == 26) AGGL(2, 6);
+            else AGGL(2, 4);
         } else if (d->p16) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
         else hipLaunchKernelGGL(hg_agg_kernel<float>, dim3(rows), dim3(512), 0, st, g);
     }
@@ -1249,7 +1280,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             a.dyn[b] = d->dyn_n[t]; a.ncap[b] = d->ncap[t];
             a.nsrc[b] = a.ndst[b] = 0;
             a.start[b] = blocks;
-            blocks += cdiv(d->ncap[t], WPB);
+            blocks += cdiv(d->ncap[t], WPB_SRC);
         }
         a.start[d->n_blocks] = blocks;
         for (int i = 0; i < d->n_inst; ++i) {
@@ -1262,8 +1293,9 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             a.row0_d[i] = d->row0[d->blk_type[db]];
         }
         if (blocks > 0) {
-            if (d->p16) hipLaunchKernelGGL(hg_bwd_src_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(hg_bwd_src_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+            const size_t lds = (size_t)2 * HD * sizeof(float);
+            if (d->p16) hipLaunchKernelGGL(hg_bwd_src_kernel<unsigned short>, dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
+            else hipLaunchKernelGGL(hg_bwd_src_kernel<float>, dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
         }
     }
     {
