@@ -1011,8 +1011,16 @@ def weights_split(ws):
     return out
 
 
+def _head_terms():
+    """K-segments of a read-out head product: 3 = hi/lo split (~2^-16, SREC_HEAD_SPLIT=1), 1 = plain bf16 operands like
+    every other encoder GEMM of the bf16 mode (SREC_HEAD_SPLIT=bf16)"""
+    return 1 if os.environ.get('SREC_HEAD_SPLIT') == 'bf16' else 3
+
+
 def _seg3(a, b):
     """the three K-segments of a split product: a b^T ~ a_hi b_hi^T + a_hi b_lo^T + a_lo b_hi^T; a, b = (hi, lo)"""
+    if _head_terms() == 1:
+        return [(a[0], b[0])]
     return [(a[0], b[0]), (a[0], b[1]), (a[1], b[0])]
 
 
@@ -1142,8 +1150,8 @@ class ReadoutHeadSplit(torch.autograd.Function):
             tn_probs.append((h, D, NT, _seg3((dU16[0], dU16[1]), a16), slabs, dT, 0, nsplit))
             tn_probs.append((h, D, B, _seg3((dV16[0], dV16[1]), c16), gWv, dB, 0, 1, (h, 2 * D, D)))
             tn_probs.append((Do, 2 * D, B, _seg3((g16[i, 0], g16[i, 1]), c16), gWsr, dB, 0, 1, (Do, 2 * D, 2 * D)))
-            tn_probs.append((8, h, B, [(ones, dV16[0]), (ones, dV16[1])], sums[:8], dB, 0, 1, (8, h, h)))
-            tn_probs.append((8, h, B, [(ones, dW16[0]), (ones, dW16[1])], sums[8:], dB, 0, 1, (8, h, h)))
+            tn_probs.append((8, h, B, [(ones, dV16[0]), (ones, dV16[1])][:(1 if _head_terms() == 1 else 2)], sums[:8], dB, 0, 1, (8, h, h)))
+            tn_probs.append((8, h, B, [(ones, dW16[0]), (ones, dW16[1])][:(1 if _head_terms() == 1 else 2)], sums[8:], dB, 0, 1, (8, h, h)))
             finals.append((gWu, slabs, gWv, gWsr, sums))
             dXs.append(dX)
         for c in range(0, len(nt_probs), 16):
