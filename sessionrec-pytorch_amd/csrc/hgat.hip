@@ -71,11 +71,16 @@ struct FoldArgs {
     float* bsum[MAXT];
 };
 
-// block = (module, head); 1024 threads = 4 row groups x 256 columns: four times the loads in flight of one row loop
-__global__ __launch_bounds__(1024) void hg_fold_kernel(FoldArgs a) {
-    __shared__ float red[2][3][256];
-    const int m = blockIdx.x / a.H, h = blockIdx.x % a.H, c = threadIdx.x & 255, jg = threadIdx.x >> 8;
+// block = (module, head, 64-column slice); 256 threads = 4 row groups x 64 columns.  (One 1024-thread block per (module, head)
+// - 64 workgroups - kept 3/4 of the CUs idle: 12 us for 16 MB of weights; same per-thread row order, so the same sums.)
+constexpr int FOLD_COLS = 64;
+__global__ __launch_bounds__(256) void hg_fold_kernel(FoldArgs a) {
+    __shared__ float red[2][3][FOLD_COLS];
     const int H = a.H, D = a.D;
+    const int ncq = (D + FOLD_COLS - 1) / FOLD_COLS;
+    const int cq = blockIdx.x % ncq, mh = blockIdx.x / ncq;
+    const int m = mh / H, h = mh % H, cl = threadIdx.x & (FOLD_COLS - 1), jg = threadIdx.x / FOLD_COLS;
+    const int c = cq * FOLD_COLS + cl;
     float sl = 0.f, sr = 0.f;
     if (c < D) {
         const float* W = a.W[m] + (size_t)h * D * D + c;
@@ -88,17 +93,17 @@ __global__ __launch_bounds__(1024) void hg_fold_kernel(FoldArgs a) {
             sr += w * ar[j];
         }
     }
-    if (jg > 0) { red[0][jg - 1][c] = sl; red[1][jg - 1][c] = sr; }
+    if (jg > 0) { red[0][jg - 1][cl] = sl; red[1][jg - 1][cl] = sr; }
     __syncthreads();
     if (jg == 0 && c < D) {
-        sl += red[0][0][c] + red[0][1][c] + red[0][2][c];
-        sr += red[1][0][c] + red[1][1][c] + red[1][2][c];
+        sl += red[0][0][cl] + red[0][1][cl] + red[0][2][cl];
+        sr += red[1][0][cl] + red[1][1][cl] + red[1][2][cl];
         a.V[m][(size_t)c * H + h] = sl;
         a.V[m][(size_t)(D + c) * H + h] = sr;
     }
     if (jg == 1 && c < D) {
         // node types are dealt to the module workgroups round-robin: a tiny batch may have fewer live modules than types
-        const int nmods = (int)gridDim.x / H;
+        const int nmods = (int)gridDim.x / (H * ncq);
         for (int t = m; t < a.nt; t += nmods) {
             if (a.bsum[t] == nullptr) continue;
             float b = 0.f;
@@ -202,8 +207,16 @@ struct AggArgs {
 __device__ unsigned long long g_hg_blk[16384][2];
 __device__ unsigned long long g_hg_tim[16];
 #define HGT(i) do { __builtin_amdgcn_sched_barrier(0); hgt[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HGT_BEGIN() unsigned long long hgt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_hg_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime(); HGT(0)
+#define HGT_W(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); HGT(i); } while (0)
+#define HGT_END() do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_hg_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0 && blockIdx.x == 100) for (int i_ = 0; i_ < 7; ++i_) g_hg_tim[i_] = hgt[i_] - hgt[0]; } while (0)
 #else
 #define HGT(i)
+#define HGT_BEGIN()
+#define HGT_W(i)
+#define HGT_END()
 #endif
 
 template <typename T>
@@ -687,6 +700,10 @@ struct DstArgs {
     float slope;
     const float* g; int ld_g;
     const unsigned char* arg;
+    // node types (hg_bwd_dst_node_kernel: one wavefront per destination NODE over all instances into its type)
+    const int* dyn_t[MAXT];
+    int row0_t[MAXT + 1], ncap_t[MAXT], ninst_t[MAXT], inst_t[MAXT][8];
+    int nt;
 };
 
 // per (instance, destination), ALL heads in one wavefront: d(pre-activation score) of every in-edge -> DP[e,h];
@@ -778,6 +795,231 @@ __global__ void hg_bwd_dst_kernel(DstArgs a) {
     }
     dsum += __shfl_xor(dsum, 8, 64); dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
     if (jl == 0) a.der[i][(size_t)v * H + hl] = dsum;
+}
+
+// the 8 per-head sums of ph over the wave in 10 shuffles (see hg_bwd_dst_kernel); lane l < 8 ends with head *hb
+__device__ __forceinline__ float head_sums8(const float (&ph)[MAXH], int lane, int* hb) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float q4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float keep = b0 ? ph[k + 4] : ph[k], send = b0 ? ph[k] : ph[k + 4];
+        q4[k] = keep + __shfl_xor(send, 1, 64);
+    }
+    float q2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float keep = b1 ? q4[k + 2] : q4[k], send = b1 ? q4[k] : q4[k + 2];
+        q2[k] = keep + __shfl_xor(send, 2, 64);
+    }
+    float t = (b2 ? q2[1] : q2[0]) + __shfl_xor(b2 ? q2[0] : q2[1], 4, 64);
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    *hb = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
+    return t;
+}
+
+// One wavefront per destination NODE, all relation instances into its type side by side (H = 8; lane = (instance slot
+// lane >> 3, in-edge lane & 7) for the per-edge arrays, as in hg_agg_node_kernel): 14 x fewer wavefronts than one per
+// (instance, destination) - most of which only found an empty edge list -, the chains in_ptr -> in_idx -> esrc of all
+// instances run in parallel, g / arg of the node are read once, the 8 values of an (edge, head) array are 16-byte accesses.
+// Same arithmetic per edge and the same reduction trees as hg_bwd_dst_kernel: bit-identical DP / der.  A node with more than
+// 8 in-edges in some relation takes the per-instance loop (the body of hg_bwd_dst_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void hg_bwd_dst_node_kernel(DstArgs a) {
+    __shared__ float da[WPB][MAXDEG][MAXH];
+    __shared__ int su[WPB][MAXDEG];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // w in an SGPR: row, type, node are wave-uniform
+    HGT_BEGIN();
+    const int row = blockIdx.x * WPB + w;
+    if (row >= a.row0_t[a.nt]) return;
+    const int t = find_range(a.row0_t, a.nt, row);
+    const int v = row - a.row0_t[t];
+    const int H = a.H, D = a.D, HD = H * D;
+    const int ni = a.ninst_t[t];
+    if (v >= dyn_count(a.dyn_t[t], a.ncap_t[t])) {
+        for (int q = 0; q < ni; ++q)
+            if (lane < H) a.der[a.inst_t[t][q]][(size_t)v * H + lane] = 0.f;
+        return;
+    }
+    const int q = lane >> 3, j = lane & 7;
+    int i = -1, beg = 0, deg = 0;
+    if (q < ni && q < 8) {
+        i = a.inst_t[t][q];
+        beg = a.in_ptr[i][v];
+        deg = a.in_ptr[i][v + 1] - beg;
+    }
+    const int c = lane * 4;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 a4 = make_uchar4(0, 0, 0, 0);
+    if (c < D) {
+        g4 = *reinterpret_cast<const float4*>(a.g + (size_t)row * a.ld_g + c);
+        a4 = *reinterpret_cast<const uchar4*>(a.arg + (size_t)row * D + c);
+    }
+    const bool valid = i >= 0 && j < deg;
+    HGT_W(1);
+    int e = 0, src = 0;
+    if (valid) {
+        e = a.in_idx[i][beg + j];
+        src = a.esrc[i][e];
+    }
+    HGT_W(2);
+    // (host: this kernel is launched only when H == 8 and every type has <= 8 instances)
+    if (__ballot(deg > 8) != 0ull) {                               // general path: one instance after the other
+        for (int qq = 0; qq < ni; ++qq) {
+            const int ig = a.inst_t[t][qq];
+            const int bg = a.in_ptr[ig][v];
+            const int dg = min(a.in_ptr[ig][v + 1] - bg, MAXDEG);
+            const int* idx = a.in_idx[ig] + bg;
+            for (int jj = lane; jj < dg; jj += 64) su[w][jj] = a.esrc[ig][idx[jj]];
+            __builtin_amdgcn_wave_barrier();
+            const T* P = static_cast<const T*>(a.Ps[ig]);
+            for (int jj = 0; jj < dg; ++jj) {
+                float ph[MAXH];
+#pragma unroll
+                for (int h = 0; h < MAXH; ++h) ph[h] = 0.f;
+                if (c < D) {
+                    const T* pr = P + (size_t)su[w][jj] * HD + c;
+                    const float v0 = g4.x * ld1(pr + a4.x * D), v1 = g4.y * ld1(pr + a4.y * D + 1);
+                    const float v2 = g4.z * ld1(pr + a4.z * D + 2), v3 = g4.w * ld1(pr + a4.w * D + 3);
+#pragma unroll
+                    for (int h = 0; h < MAXH; ++h)
+                        ph[h] = (a4.x == h ? v0 : 0.f) + (a4.y == h ? v1 : 0.f) + (a4.z == h ? v2 : 0.f) + (a4.w == h ? v3 : 0.f);
+                }
+                int hb;
+                float ts = head_sums8(ph, lane, &hb);
+                if (lane < MAXH) {
+                    if (a.Mk[ig] != nullptr && hb < H) ts *= a.Mk[ig][(size_t)idx[jj] * H + hb];
+                    da[w][jj][hb] = ts;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int hl = lane & 7, jl = lane >> 3;
+            if (hl < H) {
+                float tsum = 0.f;
+                for (int jj = jl; jj < dg; jj += 8) tsum += a.A[ig][(size_t)idx[jj] * H + hl] * da[w][jj][hl];
+                tsum += __shfl_xor(tsum, 8, 64); tsum += __shfl_xor(tsum, 16, 64); tsum += __shfl_xor(tsum, 32, 64);
+                const float erv = a.eRd[ig][(size_t)v * H + hl];
+                float dsum = 0.f;
+                for (int jj = jl; jj < dg; jj += 8) {
+                    const int ee = idx[jj];
+                    const float p = a.A[ig][(size_t)ee * H + hl];
+                    const float pre = a.eLs[ig][(size_t)su[w][jj] * H + hl] + erv;
+                    const float dp = p * (da[w][jj][hl] - tsum) * (pre > 0.f ? 1.f : a.slope);
+                    a.DP[ig][(size_t)ee * H + hl] = dp;
+                    dsum += dp;
+                }
+                dsum += __shfl_xor(dsum, 8, 64); dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
+                if (jl == 0) a.der[ig][(size_t)v * H + hl] = dsum;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // the per-edge arrays of this lane's (instance, edge): requested before the gather loop, used after it
+    float pa[8], mk[8], el[8], er[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { pa[h] = 0.f; mk[h] = 1.f; el[h] = 0.f; er[h] = 0.f; }
+    if (valid) {
+        ld8f(a.A[i] + (size_t)e * 8, pa);
+        if (a.Mk[i] != nullptr) ld8f(a.Mk[i] + (size_t)e * 8, mk);
+        ld8f(a.eLs[i] + (size_t)src * 8, el);
+    }
+    if (i >= 0 && j == 0) ld8f(a.eRd[i] + (size_t)v * 8, er);
+    HGT_W(3);
+    // The masked dot products <g[v,:] [arg[v,:] == h], P[src,h,:]> of every in-edge.  The source's projection row is read WHOLE
+    // in the layout of hg_agg_node_kernel (lane = head parity x 8 columns: four 16-byte loads, 32 cache lines per edge) and the
+    // elements of the winning head are picked in registers: gathering the 256 wanted elements one by one (hg_bwd_dst_kernel)
+    // touches the same 32 lines once per load instruction - 4 x the L1 traffic for 1/8 of the bytes.
+    unsigned long long mask = __ballot(valid);
+    const int half = lane >> 5, c8 = (lane & 31) * 8;
+    const bool cok8 = c8 < D;
+    float wsel[4][8];                                                // g[v, c] where head 2 k + half won column c, else 0
+    {
+        float gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        uint2 aq = make_uint2(0xffffffffu, 0xffffffffu);
+        if (cok8) {
+            ld8f(a.g + (size_t)row * a.ld_g + c8, gq);
+            aq = *reinterpret_cast<const uint2*>(a.arg + (size_t)row * D + c8);
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int hx = (int)(((x < 4 ? aq.x : aq.y) >> (8 * (x & 3))) & 0xffu);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wsel[k][x] = hx == 2 * k + half ? gq[x] : 0.f;
+        }
+    }
+    constexpr int DIF = 2;                                           // edges (x 4 row loads) in flight together
+    while (mask != 0ull) {
+        int ls[DIF];
+        Row8<T> f[DIF][4];
+#pragma unroll
+        for (int u = 0; u < DIF; ++u) {
+            const bool on = mask != 0ull;
+            const int l = on ? __builtin_ctzll(mask) : 0;
+            if (on) mask &= mask - 1ull;
+            ls[u] = on ? l : -1;
+            const int ii = __builtin_amdgcn_readlane(i, l), ss = __builtin_amdgcn_readlane(src, l);
+            const T* rp = static_cast<const T*>(a.Ps[ii >= 0 ? ii : 0]) + (size_t)ss * HD + half * D + c8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (on && cok8) f[u][k].load(rp + 2 * k * D); else f[u][k].zero();
+        }
+#pragma unroll
+        for (int u = 0; u < DIF; ++u) {
+            if (ls[u] < 0) break;                                    // wave-uniform
+            float ph[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float fv[8];
+                f[u][k].get(fv);
+                float sacc = 0.f;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) sacc += wsel[k][x] * fv[x];
+                ph[k] = sacc;
+            }
+            // four sums over the 32 lanes of a half in 6 shuffles: reduce-scatter over lane bits 0-1, plain sums over bits 2-4
+            const bool b0 = lane & 1, b1 = lane & 2;
+            const float k0 = b0 ? ph[2] : ph[0], s0 = b0 ? ph[0] : ph[2];
+            const float k1 = b0 ? ph[3] : ph[1], s1 = b0 ? ph[1] : ph[3];
+            const float q0 = k0 + __shfl_xor(s0, 1, 64), q1 = k1 + __shfl_xor(s1, 1, 64);
+            float ts = (b1 ? q1 : q0) + __shfl_xor(b1 ? q0 : q1, 2, 64);
+            ts += __shfl_xor(ts, 4, 64); ts += __shfl_xor(ts, 8, 64); ts += __shfl_xor(ts, 16, 64);
+            const int hb = 2 * ((b0 ? 2 : 0) + (b1 ? 1 : 0)) + half;
+            if ((lane & 28) == 0) da[w][ls[u]][hb] = ts;             // slot = the (instance, edge) lane
+        }
+    }
+    HGT_W(4);
+    __builtin_amdgcn_wave_barrier();
+    float dv[8];
+    ld8f(&da[w][lane][0], dv);
+    float dp[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const float d_a = valid ? dv[h] * mk[h] : 0.f;               // d a = d a_dropped * mask
+        float tsum = valid ? pa[h] * d_a : 0.f;
+        tsum += __shfl_xor(tsum, 1, 64); tsum += __shfl_xor(tsum, 2, 64); tsum += __shfl_xor(tsum, 4, 64);
+        const float erv = __shfl(er[h], lane & ~7, 64);
+        const float pre = el[h] + erv;
+        dp[h] = valid ? pa[h] * (d_a - tsum) * (pre > 0.f ? 1.f : a.slope) : 0.f;
+    }
+    if (valid) {
+        float* o = a.DP[i] + (size_t)e * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(dp[4], dp[5], dp[6], dp[7]);
+    }
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        float dsum = dp[h];
+        dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
+        dp[h] = dsum;
+    }
+    if (i >= 0 && j == 0) {
+        float* o = a.der[i] + (size_t)v * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(dp[4], dp[5], dp[6], dp[7]);
+    }
+    HGT_W(5);
+    HGT_END();
 }
 
 struct SrcArgs {
@@ -1150,7 +1392,7 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         // (the caller provides Z slots for max(n_mods, n_types): a batch of very short sessions has fewer live modules than types)
         for (int t = 0; t < d->n_types; ++t)
             if (f.tn[t] > 0 && f.bsum[t] == nullptr) return SREC_BAD_ARG;
-        hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H), dim3(1024), 0, st, f);
+        hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H * cdiv(D, FOLD_COLS)), dim3(256), 0, st, f);
     }
     if (d->sess == nullptr || d->B <= 0) return SREC_BAD_ARG;
     for (int t = 0; t < d->n_types; ++t)
@@ -1264,7 +1506,27 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             blocks += cdiv(d->ncap[t], WPB);
         }
         a.start[d->n_inst] = blocks;
-        if (blocks > 0) {
+        // one wavefront per destination node over all its instances (H == 8, <= 8 instances per type, 16-byte aligned arrays)
+        const char* env = getenv("SREC_HG_AGG");                 // "old": per-(instance, destination) wavefronts (A/B, tests)
+        auto al16 = [](const void* p) { return ((size_t)p & 15) == 0; };
+        bool node = !(env != nullptr && env[0] == 'o') && H == MAXH;
+        a.nt = d->n_types;
+        int trows = 0;
+        for (int t = 0; t < d->n_types; ++t) {
+            a.dyn_t[t] = d->dyn_n[t]; a.row0_t[t] = d->row0[t]; a.ncap_t[t] = d->ncap[t]; a.ninst_t[t] = 0;
+            trows += d->ncap[t];
+        }
+        a.row0_t[d->n_types] = trows;
+        for (int i = 0; i < d->n_inst; ++i) {
+            const int t = d->blk_type[d->inst_dblk[i]];
+            if (a.ninst_t[t] >= 8) { node = false; continue; }
+            a.inst_t[t][a.ninst_t[t]++] = i;
+            node = node && al16(a.A[i]) && al16(a.Mk[i]) && al16(a.eLs[i]) && al16(a.eRd[i]) && al16(a.DP[i]) && al16(a.der[i]);
+        }
+        if (node && trows > 0) {
+            if (d->p16) hipLaunchKernelGGL(hg_bwd_dst_node_kernel<unsigned short>, dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(hg_bwd_dst_node_kernel<float>, dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
+        } else if (blocks > 0) {
             if (d->p16) hipLaunchKernelGGL(hg_bwd_dst_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(hg_bwd_dst_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
         }

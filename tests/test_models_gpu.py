@@ -386,9 +386,9 @@ def test_mshgnn_layer_dropout_gradients_by_finite_differences(dev):
 
 @pytest.mark.parametrize('case', ['fixture_fp32', 'long_sessions_fp32', 'c3_shape_bf16'])
 def test_hg_agg_wave_per_node_equals_the_workgroup_kernel(dev, case, monkeypatch):
-    """hg_agg_node_kernel (one wavefront per destination node, all heads in the lane) against hg_agg_kernel (8-wave
-    workgroup, wave = head; SREC_HG_AGG=old): same summation order per output element, so the layer output, the saved
-    soft-max values (through the backward) and every gradient must be bit-identical - with feature + attention dropout,
+    """hg_agg_node_kernel / hg_bwd_dst_node_kernel (one wavefront per destination node, all heads in the lane, all relation
+    instances side by side) against hg_agg_kernel (8-wave workgroup, wave = head) / hg_bwd_dst_kernel (one wavefront per
+    (instance, destination)) (SREC_HG_AGG=old): layer output bit-identical, gradients to round-off - with feature + attention dropout,
     on the d = 32 fixture batch, on sessions of 35 - 50 clicks (relations with more than 8 in-edges: the general path) and
     on a 512-session batch at d = 256 with bf16 projections (the benchmarked shape).  msgifsr.py:70-91, gatconv.py:267-311."""
     import numpy as np
@@ -434,10 +434,16 @@ def test_hg_agg_wave_per_node_equals_the_workgroup_kernel(dev, case, monkeypatch
     finally:
         ops.set_precision('fp32')
     assert res['old'][0].abs().max() > 0
-    for i, (a, b) in enumerate(zip(res['old'], res['node'])):
+    # forward: same summation order per output element -> bit-identical.  backward: hg_bwd_dst_node_kernel sums the masked dot
+    # products of an edge in another lane order (whole-row loads, 8 columns per lane) -> fp32 round-off apart (and the bf16
+    # rounding of dP on top in bf16 mode)
+    assert torch.equal(res['old'][0], res['node'][0]), (res['old'][0] - res['node'][0]).abs().max().item()
+    tol = 2e-3 if case.endswith('bf16') else 2e-6
+    for i, (a, b) in enumerate(zip(res['old'][1:], res['node'][1:])):
         assert (a is None) == (b is None)
-        if a is not None:
-            assert torch.equal(a, b), 'tensor %d differs: max abs %.3e' % (i, (a - b).abs().max().item())
+        if a is not None and a.norm() > 0:
+            rel = ((a - b).norm() / a.norm()).item()
+            assert rel < tol, 'gradient %d differs: norm-wise %.3e' % (i, rel)
 
 
 class _Replay(torch.nn.Module):
