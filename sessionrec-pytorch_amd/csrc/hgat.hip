@@ -824,8 +824,8 @@ __device__ __forceinline__ float head_sums8(const float (&ph)[MAXH], int lane, i
 // instances run in parallel, g / arg of the node are read once, the 8 values of an (edge, head) array are 16-byte accesses.
 // Same arithmetic per edge and the same reduction trees as hg_bwd_dst_kernel: bit-identical DP / der.  A node with more than
 // 8 in-edges in some relation takes the per-instance loop (the body of hg_bwd_dst_kernel).
-template <typename T>
-__global__ __launch_bounds__(256) void hg_bwd_dst_node_kernel(DstArgs a) {
+template <typename T, int DIF, int WV>   // DIF: edges (x 4 row loads) in flight together; WV: waves per SIMD
+__global__ __launch_bounds__(256, WV) void hg_bwd_dst_node_kernel(DstArgs a) {
     __shared__ float da[WPB][MAXDEG][MAXH];
     __shared__ int su[WPB][MAXDEG];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // w in an SGPR: row, type, node are wave-uniform
@@ -925,7 +925,12 @@ __global__ __launch_bounds__(256) void hg_bwd_dst_node_kernel(DstArgs a) {
         ld8f(a.eLs[i] + (size_t)src * 8, el);
     }
     if (i >= 0 && j == 0) ld8f(a.eRd[i] + (size_t)v * 8, er);
-    HGT_W(3);
+    unsigned pos = 0u;                                               // bit h: pre-activation score of (edge, head h) > 0
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const float erv = __shfl(er[h], lane & ~7, 64);
+        pos |= (el[h] + erv > 0.f ? 1u : 0u) << h;
+    }
     // The masked dot products <g[v,:] [arg[v,:] == h], P[src,h,:]> of every in-edge.  The source's projection row is read WHOLE
     // in the layout of hg_agg_node_kernel (lane = head parity x 8 columns: four 16-byte loads, 32 cache lines per edge) and the
     // elements of the winning head are picked in registers: gathering the 256 wanted elements one by one (hg_bwd_dst_kernel)
@@ -933,7 +938,8 @@ __global__ __launch_bounds__(256) void hg_bwd_dst_node_kernel(DstArgs a) {
     unsigned long long mask = __ballot(valid);
     const int half = lane >> 5, c8 = (lane & 31) * 8;
     const bool cok8 = c8 < D;
-    float wsel[4][8];                                                // g[v, c] where head 2 k + half won column c, else 0
+    float gsel[8];                                                   // g[v, c] where a head of this lane's parity won column c, else 0
+    int kx[8];                                                       // ... and which of the lane's four heads it was
     {
         float gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         uint2 aq = make_uint2(0xffffffffu, 0xffffffffu);
@@ -944,11 +950,10 @@ __global__ __launch_bounds__(256) void hg_bwd_dst_node_kernel(DstArgs a) {
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const int hx = (int)(((x < 4 ? aq.x : aq.y) >> (8 * (x & 3))) & 0xffu);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wsel[k][x] = hx == 2 * k + half ? gq[x] : 0.f;
+            gsel[x] = (hx & 1) == half && hx < 8 ? gq[x] : 0.f;
+            kx[x] = hx >> 1;
         }
     }
-    constexpr int DIF = 2;                                           // edges (x 4 row loads) in flight together
     while (mask != 0ull) {
         int ls[DIF];
         Row8<T> f[DIF][4];
@@ -974,7 +979,7 @@ __global__ __launch_bounds__(256) void hg_bwd_dst_node_kernel(DstArgs a) {
                 f[u][k].get(fv);
                 float sacc = 0.f;
 #pragma unroll
-                for (int x = 0; x < 8; ++x) sacc += wsel[k][x] * fv[x];
+                for (int x = 0; x < 8; ++x) sacc += (kx[x] == k ? gsel[x] : 0.f) * fv[x];
                 ph[k] = sacc;
             }
             // four sums over the 32 lanes of a half in 6 shuffles: reduce-scatter over lane bits 0-1, plain sums over bits 2-4
@@ -998,9 +1003,7 @@ __global__ __launch_bounds__(256) void hg_bwd_dst_node_kernel(DstArgs a) {
         const float d_a = valid ? dv[h] * mk[h] : 0.f;               // d a = d a_dropped * mask
         float tsum = valid ? pa[h] * d_a : 0.f;
         tsum += __shfl_xor(tsum, 1, 64); tsum += __shfl_xor(tsum, 2, 64); tsum += __shfl_xor(tsum, 4, 64);
-        const float erv = __shfl(er[h], lane & ~7, 64);
-        const float pre = el[h] + erv;
-        dp[h] = valid ? pa[h] * (d_a - tsum) * (pre > 0.f ? 1.f : a.slope) : 0.f;
+        dp[h] = valid ? pa[h] * (d_a - tsum) * ((pos >> h) & 1u ? 1.f : a.slope) : 0.f;
     }
     if (valid) {
         float* o = a.DP[i] + (size_t)e * 8;
@@ -1046,9 +1049,10 @@ struct SrcArgs {
 // Workgroup = WPB_SRC nodes of ONE block: the block's attention vectors a_l | a_r (2 x H*D floats, 16 KB at H = 8, D = 256)
 // are staged in LDS once per workgroup - read per wave from L2 they were 17 of the kernel's 58 us (knock-out runs, r03 notes).
 constexpr int WPB_SRC = 4;
-template <typename T>
-__global__ __launch_bounds__(64 * WPB_SRC) void hg_bwd_src_kernel(SrcArgs a) {
+template <typename T, int WV, bool DER_FIRST>
+__global__ __launch_bounds__(64 * WPB_SRC, WV) void hg_bwd_src_kernel(SrcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float alr[];       // [2][H*D]
+    HGT_BEGIN();
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
     const int lane = threadIdx.x & 63;
     const int u = ((int)blockIdx.x - a.start[b]) * WPB_SRC + (threadIdx.x >> 6);
@@ -1067,7 +1071,80 @@ __global__ __launch_bounds__(64 * WPB_SRC) void hg_bwd_src_kernel(SrcArgs a) {
 #pragma unroll
     for (int h = 0; h < MAXH; ++h) o[h] = make_float4(0.f, 0.f, 0.f, 0.f);
     float wl = 0.f, wr = 0.f;                          // lane holds head hl = lane & 7
-    if (live) {
+    if (DER_FIRST && live && hl < H)                   // (independent of the edge chains below: requested first)
+        for (int q = 0; q < a.ndst[b]; ++q) wr += a.der[a.dst[b][q]][(size_t)u * H + hl];
+    // Fast path (H = 8, <= 16 out-edges per instance): lane = (source-instance slot lane >> 4, out-edge lane & 15), so the
+    // chains out_ptr -> out_idx -> edst and the per-edge arrays (DP, A, Mk) of ALL instances are fetched side by side, and the
+    // destination rows g / arg are then read with every address already in registers.  The loop below it walks instance after
+    // instance and edge after edge with three dependent loads each (out_idx -> edst -> g row): ~18 memory round trips for a
+    // node with two source instances of two edges, the bulk of this kernel's 54 us.
+    bool fast = false;
+    if (H == MAXH) {
+        const int sl = lane >> 4, j = lane & 15;
+        int i = -1, beg = 0, deg = 0;
+        if (live && sl < a.nsrc[b]) {
+            i = a.src[b][sl];
+            beg = a.out_ptr[i][u];
+            deg = a.out_ptr[i][u + 1] - beg;
+        }
+        fast = __ballot(deg > 16) == 0ull;
+        if (fast) {
+            const bool valid = i >= 0 && j < deg;
+            int drow = 0;
+            float p8[8], d8[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) { p8[h] = 0.f; d8[h] = 0.f; }
+            if (valid) {
+                const int e = a.out_idx[i][beg + j];
+                drow = a.row0_d[i] + a.edst[i][e];
+                ld8f(a.DP[i] + (size_t)e * 8, d8);
+                ld8f(a.A[i] + (size_t)e * 8, p8);
+                if (a.Mk[i] != nullptr) {
+                    float m8[8];
+                    ld8f(a.Mk[i] + (size_t)e * 8, m8);
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) p8[h] *= m8[h];
+                }
+            }
+            HGT_W(1);
+            {   // del[u, h] = sum of DP over all out-edges: 8 wave sums in 10 shuffles, then head h to the lanes with hl == h
+                int hb;
+                const float ts = head_sums8(d8, lane, &hb);
+                const int rev = ((hl & 1) << 2) | (hl & 2) | ((hl & 4) >> 2);    // lane rev holds head hl
+                wl = __shfl(ts, rev, 64);
+            }
+            unsigned long long mask = __ballot(valid);
+            while (mask != 0ull) {
+                constexpr int SIF = 2;                   // destination rows in flight
+                float4 gv[SIF]; uchar4 bi[SIF]; int ls[SIF];
+#pragma unroll
+                for (int x = 0; x < SIF; ++x) {
+                    const bool on = mask != 0ull;
+                    const int l = on ? __builtin_ctzll(mask) : 0;
+                    if (on) mask &= mask - 1ull;
+                    ls[x] = on ? l : -1;
+                    const size_t row = (size_t)__builtin_amdgcn_readlane(drow, l);
+                    gv[x] = make_float4(0.f, 0.f, 0.f, 0.f); bi[x] = make_uchar4(255, 255, 255, 255);
+                    if (on && c < D) {
+                        gv[x] = *reinterpret_cast<const float4*>(a.g + row * a.ld_g + c);
+                        bi[x] = *reinterpret_cast<const uchar4*>(a.arg + row * D + c);
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < SIF; ++x) {
+                    if (ls[x] < 0) break;                // wave-uniform
+#pragma unroll
+                    for (int h = 0; h < MAXH; ++h) {
+                        const float ph = rdlane(p8[h], ls[x]);
+                        o[h].x += bi[x].x == h ? ph * gv[x].x : 0.f; o[h].y += bi[x].y == h ? ph * gv[x].y : 0.f;
+                        o[h].z += bi[x].z == h ? ph * gv[x].z : 0.f; o[h].w += bi[x].w == h ? ph * gv[x].w : 0.f;
+                    }
+                }
+            }
+            HGT_W(2);
+        }
+    }
+    if (live && !fast) {
         for (int q = 0; q < a.nsrc[b]; ++q) {
             const int i = a.src[b][q];
             const int beg = a.out_ptr[i][u], deg = a.out_ptr[i][u + 1] - beg;
@@ -1107,10 +1184,12 @@ __global__ __launch_bounds__(64 * WPB_SRC) void hg_bwd_src_kernel(SrcArgs a) {
                 }
             }
         }
-        if (hl < H)
-            for (int q = 0; q < a.ndst[b]; ++q) wr += a.der[a.dst[b][q]][(size_t)u * H + hl];
     }
+    if (!DER_FIRST && live && hl < H)
+        for (int q = 0; q < a.ndst[b]; ++q) wr += a.der[a.dst[b][q]][(size_t)u * H + hl];
+    HGT_W(3);
     __syncthreads();                                   // a_l | a_r are in LDS
+    HGT_W(4);
     if (!in_range) return;
     T* dp = static_cast<T*>(a.dP[b]) + (size_t)u * HD + c;
 #pragma unroll
@@ -1131,6 +1210,8 @@ __global__ __launch_bounds__(64 * WPB_SRC) void hg_bwd_src_kernel(SrcArgs a) {
         a.wL[b][(size_t)u * H + lane] = wl;
         a.wR[b][(size_t)u * H + lane] = wr;
     }
+    HGT_W(5);
+    HGT_END();
 }
 
 // two-stage ordered reductions over the nodes:
@@ -1450,17 +1531,9 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         for (int i = 0; node && i < d->n_inst; ++i)
             node = al16(g.Ps[i]) && al16(g.eLs[i]) && al16(g.eRd[i]) && al16(g.A[i]) && al16(g.Mk[i]);
         if (node) {
-            const char* ee = getenv("SREC_HG_EIF");
-            const int eif = ee ? atoi(ee) : 15;
-#define AGGL(E, W) hipLaunchKernelGGL((hg_agg_node_kernel<unsigned short, E, W>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g)
-            if (!d->p16) hipLaunchKernelGGL((hg_agg_node_kernel<float, 2, 3>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
-            else if (eif == 14) AGGL(1, 4);
-            else if (eif == 15) AGGL(1, 5);
-            else if (eif == 16) AGGL(1, 6);
-            else if (eif == 18) AGGL(1, 8);
-            else if (eif == 25) AGGL(2, 5);
-            else if (eif == 26) AGGL(2, 6);
-            else AGGL(2, 4);
+            // (same box, rocprof: 1 edge in flight at 5 waves per SIMD 31.6 us; 2 edges at 4: 32.5; anything that spills: 38 - 97)
+            if (d->p16) hipLaunchKernelGGL((hg_agg_node_kernel<unsigned short, 1, 5>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
+            else hipLaunchKernelGGL((hg_agg_node_kernel<float, 2, 3>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
         } else if (d->p16) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
         else hipLaunchKernelGGL(hg_agg_kernel<float>, dim3(rows), dim3(512), 0, st, g);
     }
@@ -1524,8 +1597,9 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             node = node && al16(a.A[i]) && al16(a.Mk[i]) && al16(a.eLs[i]) && al16(a.eRd[i]) && al16(a.DP[i]) && al16(a.der[i]);
         }
         if (node && trows > 0) {
-            if (d->p16) hipLaunchKernelGGL(hg_bwd_dst_node_kernel<unsigned short>, dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(hg_bwd_dst_node_kernel<float>, dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
+            // (same box, rocprof: 2 edges in flight at 4 waves per SIMD 28.2 us; 1 edge 30.2; 5 waves per SIMD spill: 32.7 / 36.1)
+            if (d->p16) hipLaunchKernelGGL((hg_bwd_dst_node_kernel<unsigned short, 2, 4>), dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((hg_bwd_dst_node_kernel<float, 1, 3>), dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
         } else if (blocks > 0) {
             if (d->p16) hipLaunchKernelGGL(hg_bwd_dst_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(hg_bwd_dst_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
@@ -1556,8 +1630,9 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
         }
         if (blocks > 0) {
             const size_t lds = (size_t)2 * HD * sizeof(float);
-            if (d->p16) hipLaunchKernelGGL(hg_bwd_src_kernel<unsigned short>, dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
-            else hipLaunchKernelGGL(hg_bwd_src_kernel<float>, dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
+            // (same box, rocprof: 6 waves per SIMD 47.9 us; 5: 50.3; 7: 49.4; 8 (spills): 58.6; der loads first: +1 - 2 us)
+            if (d->p16) hipLaunchKernelGGL((hg_bwd_src_kernel<unsigned short, 6, false>), dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
+            else hipLaunchKernelGGL((hg_bwd_src_kernel<float, 4, false>), dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
         }
     }
     {

@@ -1,4 +1,4 @@
-"""Development probe for hg_bwd_dst_node (the LAST launch that writes the probe buffers; csrc/hgat.hip, -DSREC_HG_TIMING): wall-clock life of every workgroup and the phase clocks of
+"""Development probe for hg_bwd_src (the LAST launch that writes the probe buffers; csrc/hgat.hip, -DSREC_HG_TIMING): wall-clock life of every workgroup and the phase clocks of
 one, for one eager MSGIFSR forward on a bench batch.  usage (GPU box): python tools/hg_timing.py"""
 import ctypes, glob, importlib, os, subprocess, sys
 import numpy as np
@@ -39,7 +39,7 @@ life = en - st
 print('%d workgroups, span %.1f us, life: mean %.2f median %.2f p90 %.2f max %.2f us' % (live.sum(), en.max(), life.mean(), np.median(life), np.percentile(life, 90), life.max()))
 ts = np.linspace(0, en.max(), 10)
 print('alive at t:', ' '.join('%.0fus:%d' % (t, int(((st <= t) & (en > t)).sum())) for t in ts))
-print('hg_bwd_dst_node, workgroup 100, wave 0 (cycles from start, every phase drained): in_ptr/deg %d, in_idx+esrc %d, A/Mk/eL loads %d, gather loop %d, math+stores %d' % (
+print('hg_bwd_src, workgroup 100, wave 0 (cycles from start, every phase drained): metadata %d, edge loop %d, der loads %d, barrier %d, dense term + stores %d' % (
     tim[1], tim[2], tim[3], tim[4], tim[5]))
 short = life < 1.5
 print('workgroups with life < 1.5 us (capacity padding): %d' % short.sum())
