@@ -130,13 +130,16 @@ struct DotsArgs {
     float* smean[MAXT]; int* sess;
 };
 
-// workgroup = 16 nodes of a projection block x 16 outputs (l/r x head): the block's folded vectors V sit in LDS,
-// transposed to [output][D + 4] so a thread reads its 4 consecutive columns as one conflict-free 16-byte read; the node
-// row comes from HBM as float4 (the 16 threads of a node read the same addresses).  A [N, D] x [D, 16] product:
-// 64 LDS reads + 64 loads + 256 FMA per thread instead of 320 scattered loads.
-constexpr int DOTS_NODES = 16;
+// workgroup = 64 nodes of a projection block x 16 outputs (l/r x head), one 16-node tile per wave on the fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation): the block's folded vectors V sit in LDS, transposed to
+// [output][D + 4] so a lane reads 4 consecutive k of its output as one conflict-free 16-byte read; a lane (node l & 15, k-slot
+// l >> 4) reads 16 bytes of its node row per 16-k block - both operands use the k-order (16 j + 4 (l >> 4) + t), which a
+// reduction does not care about.  A [N, D] x [D, 16] product: 16 row loads + 16 LDS reads + 64 MFMAs per wave and 16 nodes
+// (round 2's thread-per-output loop: 64 + 64 + 256 FMA per thread, 16 nodes per workgroup and a 16-KB V staging each: 25 us).
+constexpr int DOTS_NODES = 64;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void hg_dots_kernel(DotsArgs a) {
-    extern __shared__ float vt[];                              // [16][D + 4]
+    extern __shared__ float vt[];                              // [16][D + 4] + 16 (a k tail past D reads finite values: its A side is 0)
     if ((int)blockIdx.x >= a.start[a.nb]) {
         const int e = (int)blockIdx.x - a.start[a.nb], t = e / a.B, sb = e - t * a.B;
         if (t >= a.nt || sb >= dyn_count(a.dynB, a.B)) return;
@@ -158,27 +161,41 @@ __global__ __launch_bounds__(256) void hg_dots_kernel(DotsArgs a) {
     }
     const int b = find_range(a.start, a.nb, (int)blockIdx.x);
     const int H = a.H, D = a.D, LDV = D + 4;
+    const int Dp = (D + 15) & ~15;                             // k padded to whole 16-blocks (zeros)
+    for (int i = threadIdx.x; i < 16 * LDV + 16; i += 256) vt[i] = 0.f;    // heads >= H: zero rows; finite tail
+    __syncthreads();
     for (int i = threadIdx.x; i < 2 * D * H; i += 256) {
         const int lr = i / (D * H), c = (i / H) % D, h = i % H;
         vt[(lr * 8 + h) * LDV + c] = a.V[b][i];
     }
     __syncthreads();
-    const int n = ((int)blockIdx.x - a.start[b]) * DOTS_NODES + (threadIdx.x >> 4);
-    const int o = threadIdx.x & 15, lr = o >> 3, h = o & 7;
-    if (n >= a.ncap[b] || h >= H) return;
-    float s = 0.f;
-    if (n < dyn_count(a.dyn[b], a.ncap[b])) {
-        const float* xr = a.x[b] + (size_t)(a.row0[b] + n) * a.ld_x;
-        const float* v = vt + o * LDV;
-        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int c = 0; c < D; c += 4) {
-            const float4 xv = *reinterpret_cast<const float4*>(xr + c);
-            const float4 vv = *reinterpret_cast<const float4*>(v + c);
-            s += xv.x * vv.x; s1 += xv.y * vv.y; s2 += xv.z * vv.z; s3 += xv.w * vv.w;
-        }
-        s += s1 + s2 + s3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = ((int)blockIdx.x - a.start[b]) * DOTS_NODES + wave * 16;
+    if (n0 >= a.ncap[b]) return;
+    const int nl = dyn_count(a.dyn[b], a.ncap[b]);
+    const int r = lane & 15, kq = lane >> 4;
+    const bool rlive = n0 + r < nl;
+    const float* xr = a.x[b] + (size_t)(a.row0[b] + n0 + r) * a.ld_x + 4 * kq;
+    const float* v = vt + r * LDV + 4 * kq;                    // B operand: output column r of this lane
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Dp; k0 += 16) {
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rlive && k0 + 4 * kq < D) xv = *reinterpret_cast<const float4*>(xr + k0);
+        const float4 vv = *reinterpret_cast<const float4*>(v + k0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, vv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, vv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, vv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, vv.w, acc, 0, 0, 0);
     }
-    (lr ? a.eR[b] : a.eL[b])[(size_t)n * H + h] = s;
+    // acc[q] = result (node n0 + 4 (lane >> 4) + q, output lane & 15)
+    const int o = lane & 15, lr = o >> 3, h = o & 7;
+    if (h >= H) return;
+    float* out = lr ? a.eR[b] : a.eL[b];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = n0 + 4 * (lane >> 4) + q;
+        if (n < a.ncap[b]) out[(size_t)n * H + h] = acc[q];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -1496,7 +1513,7 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
         a.nt = d->n_types; a.B = d->B; a.dynB = d->dynB; a.xm = x; a.sess = d->sess;
         for (int t = 0; t < d->n_types; ++t) { a.seg[t] = d->seg[t]; a.trow0[t] = d->row0[t]; a.smean[t] = d->smean[t]; }
         blocks += d->n_types * d->B;
-        if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), (size_t)16 * (D + 4) * 4, st, a);
+        if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), (size_t)(16 * (D + 4) + 16) * 4, st, a);
     }
     AggArgs g{};
     g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;
