@@ -1056,6 +1056,7 @@ struct SrcArgs {
     int nb, H, D;
     const float* g; int ld_g;
     const unsigned char* arg;
+    int skip_dead;                      // dP rows past the live count stay unwritten (their readers stop at the live rows)
 };
 
 // per (projection block, node u), ALL heads in one wavefront:
@@ -1208,6 +1209,10 @@ __global__ __launch_bounds__(64 * WPB_SRC, WV) void hg_bwd_src_kernel(SrcArgs a)
     __syncthreads();                                   // a_l | a_r are in LDS
     HGT_W(4);
     if (!in_range) return;
+    if (!live && a.skip_dead) {                        // 29 % of the rows at the bench capacities: 36 MB of zeros not written
+        if (lane < H) { a.wL[b][(size_t)u * H + lane] = 0.f; a.wR[b][(size_t)u * H + lane] = 0.f; }
+        return;
+    }
     T* dp = static_cast<T*>(a.dP[b]) + (size_t)u * HD + c;
 #pragma unroll
     for (int h = 0; h < MAXH; ++h) {
@@ -1474,7 +1479,7 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     if (bad_desc(d) || (ld_x & 3)) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int H = d->H, D = d->D, HD = H * D;
-    const size_t esz = d->p16 ? 2 : 4;
+    const size_t esz = (d->p16 & 1) ? 2 : 4;
     if (d->n_mods > 0) {
         FoldArgs f{};
         f.H = H; f.D = D;
@@ -1549,9 +1554,9 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
             node = al16(g.Ps[i]) && al16(g.eLs[i]) && al16(g.eRd[i]) && al16(g.A[i]) && al16(g.Mk[i]);
         if (node) {
             // (same box, rocprof: 1 edge in flight at 5 waves per SIMD 31.6 us; 2 edges at 4: 32.5; anything that spills: 38 - 97)
-            if (d->p16) hipLaunchKernelGGL((hg_agg_node_kernel<unsigned short, 1, 5>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
+            if (d->p16 & 1) hipLaunchKernelGGL((hg_agg_node_kernel<unsigned short, 1, 5>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
             else hipLaunchKernelGGL((hg_agg_node_kernel<float, 2, 3>), dim3(cdiv(rows, WPB)), dim3(64 * WPB), 0, st, g);
-        } else if (d->p16) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
+        } else if (d->p16 & 1) hipLaunchKernelGGL(hg_agg_kernel<unsigned short>, dim3(rows), dim3(512), 0, st, g);
         else hipLaunchKernelGGL(hg_agg_kernel<float>, dim3(rows), dim3(512), 0, st, g);
     }
     SREC_LAUNCH_CHECK();
@@ -1564,7 +1569,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
     if (bad_desc(d) || (ld_g & 3) || (ld_dx & 3) || (ld_x & 3) || ws == nullptr) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int H = d->H, D = d->D, HD = H * D;
-    const size_t esz = d->p16 ? 2 : 4;
+    const size_t esz = (d->p16 & 1) ? 2 : 4;
     int ninst_t[MAXT] = {0, 0, 0, 0};
     for (int i = 0; i < d->n_inst; ++i) ninst_t[d->blk_type[d->inst_dblk[i]]]++;
     int rows = 0;
@@ -1615,16 +1620,17 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
         }
         if (node && trows > 0) {
             // (same box, rocprof: 2 edges in flight at 4 waves per SIMD 28.2 us; 1 edge 30.2; 5 waves per SIMD spill: 32.7 / 36.1)
-            if (d->p16) hipLaunchKernelGGL((hg_bwd_dst_node_kernel<unsigned short, 2, 4>), dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
+            if (d->p16 & 1) hipLaunchKernelGGL((hg_bwd_dst_node_kernel<unsigned short, 2, 4>), dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((hg_bwd_dst_node_kernel<float, 1, 3>), dim3(cdiv(trows, WPB)), dim3(256), 0, st, a);
         } else if (blocks > 0) {
-            if (d->p16) hipLaunchKernelGGL(hg_bwd_dst_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
+            if (d->p16 & 1) hipLaunchKernelGGL(hg_bwd_dst_kernel<unsigned short>, dim3(blocks), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(hg_bwd_dst_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
         }
     }
     if (d->n_blocks > 0) {
         SrcArgs a{};
         a.nb = d->n_blocks; a.H = H; a.D = D; a.g = g; a.ld_g = ld_g; a.arg = arg;
+        a.skip_dead = (d->p16 & 2) ? 1 : 0;
         int blocks = 0;
         for (int b = 0; b < d->n_blocks; ++b) {
             const int m = d->blk_mod[b], t = d->blk_type[b];
@@ -1648,7 +1654,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
         if (blocks > 0) {
             const size_t lds = (size_t)2 * HD * sizeof(float);
             // (same box, rocprof: 6 waves per SIMD 47.9 us; 5: 50.3; 7: 49.4; 8 (spills): 58.6; der loads first: +1 - 2 us)
-            if (d->p16) hipLaunchKernelGGL((hg_bwd_src_kernel<unsigned short, 6, false>), dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
+            if (d->p16 & 1) hipLaunchKernelGGL((hg_bwd_src_kernel<unsigned short, 6, false>), dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
             else hipLaunchKernelGGL((hg_bwd_src_kernel<float, 4, false>), dim3(blocks), dim3(64 * WPB_SRC), lds, st, a);
         }
     }

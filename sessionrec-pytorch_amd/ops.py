@@ -2565,6 +2565,8 @@ class HGATLayer(torch.autograd.Function):
         dx = torch.empty(NT, D, device=dev, dtype=torch.float32)
         flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
         desc = plan.fill(HgDesc(), small, lay, P, dP, flat, grads, dstate)
+        if ctx.g16 is not None and desc.p16:
+            desc.p16 |= 2           # both gemm16 consumers of dP stop at the live rows: srec_hg_bwd leaves capacity-padding rows unwritten
         n = _ct.c_long()
         lib.srec_hg_ws_floats(_ct.addressof(desc), _ct.addressof(n))
         key = (dev.index, n.value)
