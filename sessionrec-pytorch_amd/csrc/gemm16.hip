@@ -465,7 +465,9 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
     const int split = (bid - g.start[p]) / ntile, tile = (bid - g.start[p]) % ntile;
     const int i0 = (tile / tn) * T, j0 = (tile % tn) * T;
     // row split s of nsplit: reduction rows [s chunk, (s + 1) chunk) of the problem, written to slab s of C
-    const int chunk = ((g.K[p] + g.nsplit[p] - 1) / g.nsplit[p] + 63) / 64 * 64;
+    // (the LIVE rows are split: with capacity padding an even split of K would leave the last slabs' workgroups idle)
+    const int Klive = g.dyn[p] == nullptr ? g.K[p] : max(0, min(g.K[p], *g.dyn[p] - g.koff[p]));
+    const int chunk = ((Klive + g.nsplit[p] - 1) / g.nsplit[p] + 63) / 64 * 64;
     const int kbeg = split * chunk, klen = max(0, min(chunk, g.K[p] - kbeg));
     // live reduction rows: rows koff .. koff + K of an operand with *dyn live rows in total
     const int Kr = g.dyn[p] == nullptr ? klen : max(0, min(klen, *g.dyn[p] - g.koff[p] - kbeg));

@@ -2639,27 +2639,28 @@ class HGATLayer(torch.autograd.Function):
             x16 = ctx.g16[0]
             xin16 = (lambda m: x16[plan.mod_conv[m]]) if dstate is not None else (lambda m: x16)
             pcs = [plan.pieces(m) for m in range(nm)]
-            multi = [m for m in range(nm) if len(pcs[m]) > 1]
-            R = max([len(pcs[m]) for m in multi] + [1])
+            # SREC_WGRAD_SPLIT=s: every (module, piece) product also splits its reduction rows in-kernel into s slabs (more, shorter
+            # workgroups for a launch that otherwise has 384 of them on 256 CUs); the slab sums ride in the deferred launch
+            wsplit = max(1, int(os.environ.get('SREC_WGRAD_SPLIT', '1')))
+            multi = [m for m in range(nm) if len(pcs[m]) * wsplit > 1]
+            slabs = {}
             if multi:
                 gWm = torch.empty(len(multi), HD, D, device=dev, dtype=torch.float32)
-                slabs = torch.empty(len(multi), R, HD, D, device=dev, dtype=torch.float32)
-                if any(len(pcs[m]) < R for m in multi):
-                    slabs.zero_()
                 for i, m in enumerate(multi):
                     gWs[m] = gWm[i]
+                    slabs[m] = torch.empty(len(pcs[m]) * wsplit, HD, D, device=dev, dtype=torch.float32)
             probs = []
             for m in range(nm):
                 for pi, (o, t0, nc, dyn_t) in enumerate(pcs[m]):
-                    tgt = gWs[m] if len(pcs[m]) == 1 else slabs[multi.index(m), pi]
-                    probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t))
+                    tgt = gWs[m] if m not in slabs else slabs[m][pi * wsplit:(pi + 1) * wsplit]
+                    probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t, 0, wsplit))
             for i in range(0, len(probs), 16):
-                gemm16('tn', probs[i:i + 16], HD, D, D)
+                gemm16('tn', probs[i:i + 16], HD, D, D, variant=int(os.environ.get('SREC_WGRAD_VAR', '0')))
             if multi and DEFER['on']:
-                for i in range(len(multi)):
-                    defer_slab_sum(slabs[i], gWm[i])
+                for i, m in enumerate(multi):
+                    defer_slab_sum(slabs[m], gWm[i])
             elif multi:
-                lib.srec_sum_slabs(ptr(slabs), len(multi), R, HD * D, ptr(gWm), stream())
+                _launch_slab_sums([(slabs[m], gWm[i]) for i, m in enumerate(multi)])
         elif ctx.grouped:
             gemm_group(2, [(HD, D, nr, [(dP[m], xin(m)[r0:r0 + nr])], gWs[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], HD, D, D, a16=True)
