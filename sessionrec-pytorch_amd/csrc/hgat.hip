@@ -1604,7 +1604,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
         // one wavefront per destination node over all its instances (H == 8, <= 8 instances per type, 16-byte aligned arrays)
         const char* env = getenv("SREC_HG_AGG");                 // "old": per-(instance, destination) wavefronts (A/B, tests)
         auto al16 = [](const void* p) { return ((size_t)p & 15) == 0; };
-        bool node = !(env != nullptr && env[0] == 'o') && H == MAXH;
+        bool node = !(env != nullptr && env[0] == 'o') && H == MAXH && (D & 7) == 0 && al16(g) && al16(arg);   // 8-column lanes
         a.nt = d->n_types;
         int trows = 0;
         for (int t = 0; t < d->n_types; ++t) {

@@ -90,6 +90,18 @@ def test_sessions_of_up_to_50_clicks_match_the_oracle(dev, kind):
     _step_vs_oracle(dev, model, ref, fn, ofn, samples, kind + ' len<=50')
 
 
+@pytest.mark.parametrize('d', [36, 40, 48])
+def test_msgifsr_widths_off_the_kernel_fast_paths_match_the_oracle(dev, d):
+    """embedding widths that leave the fast paths of the MSHGNN layer kernels: d % 16 != 0 exercises the zero-padded k tail
+    of the matrix-pipe attention-logit product (hg_dots), d % 8 != 0 (36) falls back from the wavefront-per-node kernels
+    (8-column lanes) to the workgroup-per-node ones; fp32 mode, product vs the CPU oracle (msgifsr.py:70-91,
+    gatconv.py:267-311)."""
+    V = 300
+    model, ref, fn, ofn = _pair('msgifsr', V, d)
+    samples = _long_sessions(24, V, 2, 14, 11) + [([5], 9), ([7, 7, 7, 7], 1)]
+    _step_vs_oracle(dev, model, ref, fn, ofn, samples, 'msgifsr d=%d' % d)
+
+
 def test_oversized_sessions_are_refused_not_truncated(dev):
     """the per-session kernels keep a session's nodes / a node's edge list in fixed LDS arrays (srec_limits); a batch beyond
     them must raise on the host before any kernel runs"""
