@@ -356,6 +356,10 @@ int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, int d, void*
 /* out [C, n] = sum_r part [C, R, n] in fixed order (the row-split weight-gradient products of one module), n % 4 == 0 */
 int srec_sum_slabs(const float* part, int C, int R, long n, float* out, void* stream);
 int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, void* stream);
+/* the same, the transposed copies in MFMA-fragment-major order (B operands of srec_gemm16_nt with c16 bit 11: fragment
+ * (c / 32, r / 16) of W_i^T = 64 lanes x 8 bf16, lane (c % 32) + 32 ((r / 8) % 2)); R_i % 16 == 0, C_i % 32 == 0.
+ * Replaces the transposed weight operand of the backward-data product of gatconv.py:267-270 (fc) under autograd. */
+int srec_weights_bf16_frag(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, void* stream);
 /* MSGIFSR after its last MSHGNN layer in ONE launch each way (csrc/rowops.hip): F.normalize of every node row
  * (msgifsr.py:260-263), the per-session concatenation of all orders' nodes (msgifsr.py:135, perm = cat_perm of the FlatBatch)
  * and the last-node picks (filter_nodes, msgifsr.py:264): allf [n_cap, D], invr [n_cap] = 1 / norm, pout_k [B, D]; optional

@@ -306,6 +306,125 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
 #endif
 }
 
+// -------------------------------------------------------------------------------------------------- nt16, B operand straight from L2
+// Backward-data of the GAT projections (C [M, 256] fp32 = sum_s dP_s [M, 2048] W_s): a long reduction into a skinny output.  The
+// tiled kernel above stages BOTH operands through LDS: per 64-deep k-step a 64 x 128 tile pulls 8 KB of dP and 16 KB of W^T by
+// LDS-DMA and has ONE stage in flight (48 KB of LDS -> 3 workgroups per CU), i.e. every k-step costs a memory latency.  Here
+// the weights come in FRAGMENT-MAJOR order (srec_weights_bf16_frag: the 64 lanes x 16 B of one MFMA B operand contiguous,
+// fragments ordered column block / k-step) and go straight from L2 into the registers that feed the MFMAs - plain coalesced
+// 1-KiB loads through a register ring, no LDS write, no LDS read, no barrier dependency; only the 8-KB dP stages go through the
+// LDS-DMA ring.  PD stages of both operands are in flight per workgroup (the tiled kernel: one), the LDS-DMA pieces per stage
+// drop from 24 to 8 and the LDS fragment reads from 12 to 4 per k-step and wave.
+// vmcnt bookkeeping: the DMA instructions are inline asm the compiler does not count, the B loads are compiler loads the asm
+// waits do not know.  Both only ever make a wait MORE conservative: every issue group is [2 DMA, 8 B loads] in program order
+// ("memory"-clobbering asm keeps the loads from moving across), so "stage it's DMA has landed" = at most 8 + (PD - 1) * 10
+// younger operations outstanding; the tail re-issues the last group instead of branching, so the count never changes.
+template <int PD>
+__global__ __launch_bounds__(256, 3) void gemm16_nt_bfrag_kernel(G16Args g) {
+    constexpr int TM = 64, TN = 128, BK = 64, NSA = PD + 1;
+    constexpr int PPR = BK / 8, RPI = 512 / BK, FS = 1;              // as gemm16_nt_kernel at BK = 64
+    constexpr int STG = TM * BK;                                      // bf16 elements per A stage (8 KB)
+    constexpr int IPS = (TM / RPI) / 4;                               // DMA instructions per stage and wave (2)
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int bid = xcd_tile(g);
+    if (bid >= g.start[g.np]) return;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < G16_MAXP; ++i)
+        if (i < g.np && bid >= g.start[i]) p = i;
+    const int M = g.M[p], N = g.N[p], K = g.K[p];
+    const int tn = N / TN, tile = bid - g.start[p];
+    const int m0 = (tile / tn) * TM, n0 = (tile % tn) * TN;
+    const int Ml = dyn_count(g.dyn[p], M);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    float* __restrict__ C = static_cast<float*>(g.C[p]);
+    if (m0 >= Ml) {                                      // tile of capacity padding: zero rows when overwriting
+        if (!g.keep_dead && g.beta == 0.f)
+            for (int i = tid; i < TM * TN / 4; i += 256) {
+                const int r = m0 + (i * 4) / TN, c = n0 + (i * 4) % TN;
+                if (r < M) *reinterpret_cast<float4*>(C + (size_t)r * g.ldcp[p] + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        return;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = K / BK, total = nk * g.nseg[p];
+    const unsigned lds0 = lds_addr(smem);
+    const int rl = lane / PPR, sl = lane % PPR;
+    unsigned voff[IPS];
+#pragma unroll
+    for (int ii = 0; ii < IPS; ++ii) {
+        const int r = RPI * (ii * 4 + wave) + rl;
+        voff[ii] = ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.ldap[p] + (unsigned)((sl ^ ((r >> FS) & (PPR - 1))) * 8)) * 2u;
+    }
+    // issue stream (wave-uniform): K segment and k of the next group; B: fragment (column block cb, k-step s) of a segment at
+    // ((cb * (K / 16) + s) * 64 + lane) * 8
+    int is_seg = 0, is_k = 0, is_it = 0;
+    const unsigned short* Aseg = g.A[p][0] + (size_t)m0 * g.ldap[p];
+    const size_t cbs = (size_t)(K / 16) * 512;                       // elements between column blocks
+    const unsigned short* Bseg = g.B[p][0] + (size_t)((n0 + wn * 64) / 32) * cbs + lane * 8;
+    bf16x8 Bq[NSA][4][2];
+    auto issue = [&](int slot) {
+        const unsigned dst = lds0 + (unsigned)((is_it % NSA) * STG) * 2u;
+#pragma unroll
+        for (int ii = 0; ii < IPS; ++ii) glds16(Aseg + is_k, voff[ii], dst + (unsigned)(ii * 4 + wave) * 1024u);
+        const unsigned short* bp = Bseg + (size_t)(is_k / 16) * 512;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Bq[slot][ks][j] = *reinterpret_cast<const bf16x8*>(bp + ks * 512 + j * cbs);
+        if (is_it + 1 < total) {                         // (the tail re-issues the last group: same instruction counts)
+            ++is_it;
+            is_k += BK;
+            if (is_k >= K) {
+                is_k = 0;
+                ++is_seg;
+                Aseg = g.A[p][is_seg] + (size_t)m0 * g.ldap[p];
+                Bseg = g.B[p][is_seg] + (size_t)((n0 + wn * 64) / 32) * cbs + lane * 8;
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PD; ++s) issue(s);
+    for (int it0 = 0; it0 < total; it0 += NSA) {
+#pragma unroll
+        for (int u = 0; u < NSA; ++u) {
+            const int it = it0 + u;
+            if (it < total) {                            // wave-uniform
+                wait_vm<8 + (PD - 1) * (IPS + 8)>();     // this wave's DMA pieces of stage `it` have landed ...
+                __syncthreads();                         // ... everyone's have; stage it - 1's buffer is free again
+                issue((u + PD) % NSA);
+                const unsigned short* As = smem + (it % NSA) * STG;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int r = wm * 32 + l31;
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + r * BK + (((2 * ks + half) ^ ((r >> FS) & (PPR - 1))) << 3));
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bq[u][ks][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bq[u][ks][1], acc[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < M) {
+                float* q = C + (size_t)row * g.ldcp[p] + col;
+                if (row < Ml) *q = g.beta != 0.f ? acc[j][r] + g.beta * *q : acc[j][r];
+                else if (g.beta == 0.f && !g.keep_dead) *q = 0.f;
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- nt16, weights in registers
 // The forward projections P_m = x_m W_m^T are short reductions (K = D <= 256) into wide outputs (N = H D = 2048): with output
 // tiles, every 128 x 128 tile re-stages its 64 KB A block and its 64 KB W block through LDS - 245 MB of LDS-DMA for 63 MB of
@@ -594,6 +713,7 @@ struct WArgs {
     unsigned short* WT16[8];
     int R[8], Cc[8], start[9];
     int n;
+    int frag;                     // WT16 in MFMA-fragment-major order (gemm16_nt_bfrag_kernel) instead of row-major [C, R]
 };
 __global__ void weights_bf16_kernel(WArgs a) {
     __shared__ unsigned short tile[64][68];
@@ -625,7 +745,10 @@ __global__ void weights_bf16_kernel(WArgs a) {
             if (c < Cc && r < R) {
                 const unsigned lo = tile[4 * x][cc] | ((unsigned)tile[4 * x + 1][cc] << 16);
                 const unsigned hi = tile[4 * x + 2][cc] | ((unsigned)tile[4 * x + 3][cc] << 16);
-                *reinterpret_cast<uint2*>(a.WT16[t] + (size_t)c * R + r) = make_uint2(lo, hi);
+                // fragment-major: element (n = c, k = r) of W^T sits in fragment (c / 32, r / 16), lane (c % 32) + 32 ((r / 8) % 2), slot r % 8
+                const size_t off = a.frag ? ((size_t)((c >> 5) * (R >> 4) + (r >> 4)) * 64 + (c & 31) + 32 * ((r >> 3) & 1)) * 8 + (r & 7)
+                                          : (size_t)c * R + r;
+                *reinterpret_cast<uint2*>(a.WT16[t] + off) = make_uint2(lo, hi);
             }
         }
         return;
@@ -757,6 +880,25 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
             return 0;
         }
     }
+    if ((h->c16 >> 11) & 1) {
+        // B operands in fragment-major order (srec_weights_bf16_frag): the backward-data kernel that feeds them from L2 into
+        // registers.  fp32 output, 64 x 128 tiles, N % 128 == 0, K % 64 == 0 - anything else cannot read this layout
+        if (h->c16 & 1) return SREC_BAD_ARG;
+        for (int p = 0; p < h->np; ++p)
+            if ((h->N[p] & 127) || (h->K[p] & 63)) return SREC_BAD_ARG;
+        if (int rc = fill(g, desc_, 64, 128, false, blocks)) return rc;
+        bool same_tn = true;
+        const int tn0 = h->N[0] / 128;
+        for (int p = 1; p < h->np; ++p) same_tn = same_tn && h->N[p] / 128 == tn0;
+        if (same_tn && rows_live * 10 < rows_cap * 9) { g.xcd_gs = tn0; blocks = cdiv(blocks, 8 * tn0) * 8 * tn0; }
+        else { g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd; }
+        hipStream_t stf = (hipStream_t)stream;
+        if (variant == 3) hipLaunchKernelGGL((gemm16_nt_bfrag_kernel<3>), dim3(blocks), dim3(256), (size_t)4 * 64 * 64 * 2, stf, g);
+        else if (variant == 1) hipLaunchKernelGGL((gemm16_nt_bfrag_kernel<1>), dim3(blocks), dim3(256), (size_t)2 * 64 * 64 * 2, stf, g);
+        else hipLaunchKernelGGL((gemm16_nt_bfrag_kernel<2>), dim3(blocks), dim3(256), (size_t)3 * 64 * 64 * 2, stf, g);
+        SREC_LAUNCH_CHECK();
+        return 0;
+    }
     const int tn = (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
     if (int rc = fill(g, desc_, tm, tn, false, blocks)) return rc;
     // fp32-output launches (backward-data: two column tiles share every dP row block): 38.7 -> 34.5 us at the bench shapes; the
@@ -860,12 +1002,26 @@ extern "C" int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, i
 
 // n <= 8 weight matrices W_i [R_i, C_i] fp32 (contiguous) -> bf16 copy W16_i and transposed bf16 copy WT16_i [C_i, R_i]
 // (WT16 entries may be NULL).  W / W16 / WT16 / R / Cc are HOST arrays of n entries.
+static int weights_bf16_impl(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, int frag,
+                             void* stream);
 extern "C" int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc,
                                  void* stream) {
+    return weights_bf16_impl(n, W, W16, WT16, R, Cc, 0, stream);
+}
+// the same with the transposed copies in MFMA-fragment-major order (B operands of srec_gemm16_nt with c16 bit 11):
+// fragment (c / 32, r / 16) of W_i^T = 64 lanes x 8 elements, lane (c % 32) + 32 ((r / 8) % 2); R_i % 16 == 0, C_i % 32 == 0
+extern "C" int srec_weights_bf16_frag(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc,
+                                      void* stream) {
+    for (int i = 0; i < n && i < 8; ++i)
+        if ((R[i] & 15) || (Cc[i] & 31)) return SREC_BAD_ARG;
+    return weights_bf16_impl(n, W, W16, WT16, R, Cc, 1, stream);
+}
+static int weights_bf16_impl(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, int frag,
+                             void* stream) {
     if (n <= 0) return 0;
     if (n > 8 || W == nullptr || W16 == nullptr || WT16 == nullptr) return SREC_BAD_ARG;
     WArgs a{};
-    a.n = n;
+    a.n = n; a.frag = frag;
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
         a.W[i] = ((const float* const*)W)[i];

@@ -2296,13 +2296,13 @@ class GemmGroup16(_ct.Structure):
 _FWD_VARIANT = 64 if os.environ.get('SREC_FWD_WRES') == '1' else 0     # 64: the weights-in-registers forward kernel (A/B runs)
 
 
-def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, variant=0):
+def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, variant=0, bfrag=False):
     """one grouped launch of the bf16-in-HBM GEMMs (csrc/gemm16.hip).  probs: [(M, N, K, [(A16, B16), ...], C, dyn)].
     kind 'nt': C [M, N] (+)= sum_s A_s [M, K] B_s [N, K]^T (c16: bf16 output);  'tn': C [M, N] = sum_s A_s [K, M]^T B_s [K, N]
     (reduction over the K rows, clamped by dyn)."""
     assert 0 < len(probs) <= 16
     g = GemmGroup16()
-    g.np, g.lda, g.ldb, g.ldc, g.beta, g.c16 = len(probs), lda, ldb, ldc, beta, int(c16) | (2 if keep_dead else 0) | (variant << 4)
+    g.np, g.lda, g.ldb, g.ldc, g.beta, g.c16 = len(probs), lda, ldb, ldc, beta, int(c16) | (2 if keep_dead else 0) | (variant << 4) | (2048 if bfrag else 0)
     for p, pr in enumerate(probs):
         M, N, K, segs, C, dyn = pr[:6]
         g.M[p], g.N[p], g.K[p], g.nseg[p], g.C[p], g.dyn[p] = M, N, K, len(segs), ptr(C), ptr(dyn)
@@ -2326,7 +2326,7 @@ def rows_bf16(x, dyn=None):
     return out
 
 
-def weights_bf16(ws, transposed=True):
+def weights_bf16(ws, transposed=True, frag=False):
     """[(W16, WT16)] bf16 copies (and transposed copies) of up to 8 contiguous fp32 matrices, one launch"""
     n = len(ws)
     assert 0 < n <= 8
@@ -2337,7 +2337,7 @@ def weights_bf16(ws, transposed=True):
     a_w, a_16 = arr(*[w.data_ptr() for w in ws]), arr(*[w.data_ptr() for w in w16])      # kept alive across the call
     a_t = arr(*[(w.data_ptr() if w is not None else None) for w in wt16])
     a_r, a_c = (_ct.c_int * n)(*[w.shape[0] for w in ws]), (_ct.c_int * n)(*[w.shape[1] for w in ws])
-    lib.srec_weights_bf16(n, _ct.addressof(a_w), _ct.addressof(a_16), _ct.addressof(a_t), _ct.addressof(a_r),
+    (lib.srec_weights_bf16_frag if frag else lib.srec_weights_bf16)(n, _ct.addressof(a_w), _ct.addressof(a_16), _ct.addressof(a_t), _ct.addressof(a_r),
                           _ct.addressof(a_c), stream())
     return w16, wt16
 
@@ -2515,7 +2515,10 @@ class HGATLayer(torch.autograd.Function):
         if grouped and D % 64 == 0 and all(params[4 * m].is_contiguous() for m in range(nm)):
             # every GEMM operand as bf16 in HBM (csrc/gemm16.hip): the small weights once per call (+ transposed copies for
             # the backward-data product), the module inputs in one pass
-            w16, wt16 = weights_bf16([params[4 * m] for m in range(nm)])
+            # SREC_DGRAD_BFRAG=1 (D = 128 / 256): the transposed copies in MFMA-fragment-major order for the backward-data kernel
+            # that feeds the weights from L2 straight into registers (csrc/gemm16.hip gemm16_nt_bfrag_kernel)
+            bfrag = D % 128 == 0 and HD % 64 == 0 and os.environ.get('SREC_DGRAD_BFRAG', '0') not in ('0', '')
+            w16, wt16 = weights_bf16([params[4 * m] for m in range(nm)], frag=bfrag)
             if dstate is not None:
                 x16 = x16_pre if x16_pre is not None else rows_bf16(xcs.view(2 * NT, D)).view(2, NT, D)
                 xin16 = lambda m: x16[plan.mod_conv[m]]
@@ -2528,7 +2531,7 @@ class HGATLayer(torch.autograd.Function):
             for i in range(0, len(probs), 16):
                 # rows past a type's live count are never read (every hgat.hip kernel walks the live prefix only)
                 gemm16('nt', probs[i:i + 16], D, D, HD, c16=True, keep_dead=True, variant=_FWD_VARIANT)
-            g16 = (x16, wt16)
+            g16 = (x16, wt16, bfrag)
         elif grouped:
             gemm_group(0, [(nr, HD, D, [(xin(m)[r0:r0 + nr], params[4 * m])], P[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], D, D, HD, c16=True)
@@ -2630,7 +2633,7 @@ class HGATLayer(torch.autograd.Function):
             beta = pend[0][1]
             batch = [pr for pr, b in pend if b == beta][:16]
             pend = [(pr, b) for pr, b in pend if not any(pr is q for q in batch)]
-            gemm16('nt', batch, HD, HD, D, beta=beta)
+            gemm16('nt', batch, HD, HD, D, beta=beta, bfrag=ctx.g16[2], variant=int(os.environ.get('SREC_DGRAD_PD', '0')) if ctx.g16[2] else 0)
         if dstate is not None:
             lib.srec_hg_drop_merge(ptr(tgts), S, ptr(dstate[4]), NT * D, ptr(dx), stream())
         if ctx.g16 is not None:

@@ -855,6 +855,39 @@ def test_gemm16_nt(dev, c16):
         close(C, ref, what='nt16 segments + beta', rtol=1e-4, atol=2e-3)
 
 
+def test_gemm16_nt_fragment_major_weights(dev):
+    """backward-data product with the weights in MFMA-fragment-major order fed straight from L2 into registers
+    (gemm16_nt_bfrag_kernel, srec_weights_bf16_frag) against the tiled kernel with row-major W^T: same products, same k order ->
+    bit-identical; K segments, live-row clamp, beta, capacity-padding tiles, d = 128 and 256 (gatconv.py:267-270 under autograd)"""
+    ops = _ops()
+    torch.manual_seed(4)
+    for D, rows in ((256, (1500, 2560, 70)), (128, (900, 333))):
+        HD = 8 * D
+        Ws = [torch.randn(HD, D, device=dev) * 0.1 for _ in range(3)]
+        _, wt = ops.weights_bf16(Ws)
+        _, wf = ops.weights_bf16(Ws, frag=True)
+        for w, f in zip(wt, wf):                      # a permutation of the same elements
+            assert f.numel() == w.numel() and torch.equal(f.reshape(-1).sort().values, w.reshape(-1).sort().values)
+        for beta in (0.0, 1.0):
+            for pd in (0, 1):
+                outs = []
+                for frag in (False, True):
+                    probs = []
+                    for i, M in enumerate(rows):
+                        torch.manual_seed(100 + i)
+                        A = [(torch.randn(M, HD, device=dev) * 0.5).bfloat16() for _ in range(2)]
+                        C = torch.full((M, D), 2.0, device=dev)
+                        dyn = torch.tensor([max(1, M - 37 * (i + 1))], device=dev, dtype=torch.int32)
+                        B = wf if frag else wt
+                        probs.append((M, D, HD, [(A[0], B[i % 3]), (A[1], B[(i + 1) % 3])], C, dyn))
+                    ops.gemm16('nt', probs, HD, HD, D, beta=beta, bfrag=frag, variant=pd if frag else 0)
+                    outs.append([pr[4] for pr in probs])
+                for a, b, pr in zip(outs[0], outs[1], probs):
+                    live = int(pr[5].item())
+                    assert torch.equal(a[:live], b[:live]), (D, beta, pd, (a[:live] - b[:live]).abs().max().item())
+                    assert torch.equal(a[live:], b[live:])
+
+
 def test_gemm16_tn(dev):
     """weight-gradient product C = A^T B over the live rows, operands row-major bf16 (16-bit transposing LDS reads)"""
     ops = _ops()
