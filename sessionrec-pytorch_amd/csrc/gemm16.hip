@@ -846,7 +846,10 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     // tiles = 120 per XCD) ran 1.25 -> 2 rounds: 77 us; as 480 128-row tiles (60 per XCD) it is one round.
     if (!(variant & 8) && !(h->c16 & 1) && tm == 64 && t64x128 > 384) {
         const long r64 = cdiv((int)cdiv((int)t64x128, 8), 96), r128 = cdiv((int)cdiv((int)t128, 8), 64);
-        if (r128 * 105 < r64 * 100) tm = 128;
+        // ... and when the rounds tie, the 128-row tiles win on BYTES: these launches run at what the L2s deliver to the CUs
+        // (8 - 12 TB/s in every variant, profiles/r03_notes.md) and a 128 x 128 tile fetches 2/3 of the operand bytes of two
+        // 64 x 128 tiles per output - as long as there is at least one workgroup per CU (65.4 -> 55.1 us at the bench shapes)
+        if (r128 * 105 < r64 * 100 || (r128 <= r64 && t128 >= 256)) tm = 128;
     }
     // forward projections (bf16 output, one K segment, K = 128 / 256, N a multiple of 256): c16 bit 10 selects the
     // weights-in-registers kernel.  Measured (tools/fwd_wres_bench.py, profiles/r03_notes.md): bit-identical results, 50 vs 53 us

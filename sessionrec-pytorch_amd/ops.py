@@ -2633,7 +2633,7 @@ class HGATLayer(torch.autograd.Function):
             beta = pend[0][1]
             batch = [pr for pr, b in pend if b == beta][:16]
             pend = [(pr, b) for pr, b in pend if not any(pr is q for q in batch)]
-            gemm16('nt', batch, HD, HD, D, beta=beta, bfrag=ctx.g16[2], variant=int(os.environ.get('SREC_DGRAD_PD', '0')) if ctx.g16[2] else 0)
+            gemm16('nt', batch, HD, HD, D, beta=beta, bfrag=ctx.g16[2], variant=int(os.environ.get('SREC_DGRAD_PD', '0')) if ctx.g16[2] else int(os.environ.get('SREC_DGRAD_VAR', '0')))
         if dstate is not None:
             lib.srec_hg_drop_merge(ptr(tgts), S, ptr(dstate[4]), NT * D, ptr(dx), stream())
         if ctx.g16 is not None:
