@@ -106,17 +106,21 @@ constexpr int NS = 4, PD = 3;        // default LDS ring: 4 stages, 3 stages of 
 // barriers - a 4-stage ring keeps 3 stages in flight per workgroup, and 16 KB stages leave room for 2-3 workgroups
 // per CU.  Piece p of tile row r sits in slot p ^ ((r >> 2) & 3): the 16 lanes of every ds_read_b128 group hit 16
 // distinct 16-B slots.
-template <int TM, int TN, bool C16, int BK = 32, int NS = 4>
-__global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
+// NW: waves per workgroup, 2 x (NW / 2): 4, or 8 for the 128 x 256 tile that covers the whole skinny output of a backward-data
+// problem (the dP row block is fetched once instead of once per 128-column sibling tile: profiles/r03_pmc_gemm_gru.json had 195 MB
+// of HBM traffic for a 90-MB dP)
+template <int TM, int TN, bool C16, int BK = 32, int NS = 4, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm16_nt_kernel(G16Args g) {
+    constexpr int WN = NW / 2, NT = 64 * NW;          // waves along N, threads
     constexpr int PD = NS - 1;
     constexpr int RPI = 512 / BK;                        // tile rows per DMA instruction (1 KiB)
     constexpr int PPR = BK / 8;                          // 16-B pieces per tile row
     constexpr int FS = BK == 32 ? 2 : 1;                 // swizzle: slot = piece ^ ((row >> FS) & (PPR - 1))
-    constexpr int IM = TM / 64, IN = TN / 64;            // 32x32 accumulators per wave and dimension (2 x 2 waves)
+    constexpr int IM = TM / 64, IN = TN / (32 * WN);     // 32x32 accumulators per wave and dimension (2 x WN waves)
     constexpr int STG = (TM + TN) * BK;                  // bf16 elements per stage
     constexpr int NIA = TM / RPI, NI = (TM + TN) / RPI;  // DMA instructions per stage: A, total
-    constexpr int IPS = NI / 4;                          // ... per wave
-    static_assert(NI % 4 == 0, "every wave must issue the same number of DMA instructions per stage");
+    constexpr int IPS = NI / NW;                         // ... per wave
+    static_assert(NI % NW == 0, "every wave must issue the same number of DMA instructions per stage");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
 
     const int bid = xcd_tile(g);
@@ -136,12 +140,12 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     const int Ml = dyn_count(g.dyn[p], M);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN, half = lane >> 5, l31 = lane & 31;
     float* __restrict__ C = static_cast<float*>(g.C[p]);
     unsigned short* __restrict__ C16p = static_cast<unsigned short*>(g.C[p]);
     if (m0 >= Ml) {                                      // tile of capacity padding: zero rows when overwriting
         if (!g.keep_dead && (C16 || g.beta == 0.f))
-            for (int i = tid; i < TM * TN / 4; i += 256) {
+            for (int i = tid; i < TM * TN / 4; i += NT) {
                 const int r = m0 + (i * 4) / TN, c = n0 + (i * 4) % TN;
                 if (r < M && c + 3 < N) {
                     if (C16) *reinterpret_cast<uint2*>(C16p + (size_t)r * g.ldcp[p] + c) = make_uint2(0u, 0u);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     unsigned voff[IPS];
 #pragma unroll
     for (int ii = 0; ii < IPS; ++ii) {
-        const int i = ii * 4 + wave;                     // wave-uniform
+        const int i = ii * NW + wave;                    // wave-uniform
         const int r = RPI * (i < NIA ? i : i - NIA) + rl;
         const unsigned pc = (unsigned)((sl ^ ((r >> FS) & (PPR - 1))) * 8);
         voff[ii] = i < NIA ? ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.ldap[p] + pc) * 2u
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
         const unsigned dst = lds0 + (unsigned)((it % NS) * STG) * 2u;
 #pragma unroll
         for (int ii = 0; ii < IPS; ++ii) {
-            const int i = ii * 4 + wave;
+            const int i = ii * NW + wave;
             glds16((i < NIA ? Aseg : Bseg) + is_k, voff[ii], dst + (unsigned)i * 1024u);
         }
         is_k += BK;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
             }
 #pragma unroll
             for (int j = 0; j < IN; ++j) {
-                const int r = wn * (TN / 2) + j * 32 + l31;
+                const int r = wn * (TN / WN) + j * 32 + l31;
                 b[j] = *reinterpret_cast<const bf16x8*>(Bs + r * BK + (((2 * ks + half) ^ ((r >> FS) & (PPR - 1))) << 3));
             }
 #pragma unroll
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
         // stride of P makes per-lane stores 16-B fragments of 32 different rows per instruction (the forward measured
         // bound by write transactions, not bytes): every wave transposes its tile through its own LDS patch (rows padded
         // to 144 B: conflict-free 8-B writes) and stores 16 B per lane = 8 full 128-B row segments per instruction.
-        constexpr int WR = TM / 2, WC = TN / 2, LDP = WC + 8;         // wave tile, padded LDS row (bf16 elements)
+        constexpr int WR = TM / 2, WC = TN / WN, LDP = WC + 8;        // wave tile, padded LDS row (bf16 elements)
         __syncthreads();                                               // every wave is done with the ring buffers
         unsigned short* patch = smem + wave * (WR * LDP);
 #pragma unroll
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(G16Args g) {
     for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int j = 0; j < IN; ++j) {
-            const int col = n0 + wn * (TN / 2) + j * 32 + l31;
+            const int col = n0 + wn * (TN / WN) + j * 32 + l31;
             if (col >= N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -902,7 +906,12 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
         SREC_LAUNCH_CHECK();
         return 0;
     }
-    const int tn = (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
+    // skinny fp32 outputs of exactly 256 columns in 128-row tiles (the GAT backward-data launch at d = 256): one 8-wave workgroup
+    // covers the whole row block - dP is fetched once instead of once per 128-column sibling.  Measured 64 us against 55 - 60 for
+    // the 128 x 128 tiles (180 workgroups on 256 CUs): opt-in, variant 7
+    bool wide = !(h->c16 & 1) && tm == 128 && variant == 7;
+    for (int p = 0; wide && p < h->np; ++p) wide = h->N[p] == 256 && (h->K[p] & 63) == 0;
+    const int tn = wide ? 256 : (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
     if (int rc = fill(g, desc_, tm, tn, false, blocks)) return rc;
     // fp32-output launches (backward-data: two column tiles share every dP row block): 38.7 -> 34.5 us at the bench shapes; the
     // bf16-output forward (sixteen column tiles per row block, all of x fits any L2) measured 1.5 us slower that way.  Bit 9:
@@ -927,6 +936,13 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
         if (int rc = optin(gemm16_nt_kernel<TMV, TNV, C16V, BKV, NSV>, (int)lds, optin_mask[slot])) return rc;         \
         hipLaunchKernelGGL((gemm16_nt_kernel<TMV, TNV, C16V, BKV, NSV>), dim3(blocks), dim3(256), lds, st, g);         \
     } while (0)
+    if (wide) {                                          // 128 x 256 tiles, 8 waves: see the selection above
+        const size_t lds = (size_t)2 * (128 + 256) * 64 * 2;
+        if (int rc = optin(gemm16_nt_kernel<128, 256, false, 64, 2, 8>, (int)lds, optin_mask[20])) return rc;
+        hipLaunchKernelGGL((gemm16_nt_kernel<128, 256, false, 64, 2, 8>), dim3(blocks), dim3(512), lds, st, g);
+        SREC_LAUNCH_CHECK();
+        return 0;
+    }
     // measured at the bench's GAT shapes (tools/gemm16_bench.py): every ring lands at 33-40 us for the 16-GFLOP forward
     // (the LDS fill rate, ~8 TB/s, bounds all of them; deeper rings lose more in occupancy than they gain in flight):
     // defaults = 3 x 32-deep stages for the bf16-output forward, 2 x 64-deep stages for backward-data
