@@ -2293,7 +2293,7 @@ class GemmGroup16(_ct.Structure):
                 ('lda_p', _ct.c_int * 16), ('ldb_p', _ct.c_int * 16), ('ldc_p', _ct.c_int * 16), ('mhint', _ct.c_int * 16)]
 
 
-_FWD_VARIANT = 64 if os.environ.get('SREC_FWD_WRES') == '1' else 0     # 64: the weights-in-registers forward kernel (A/B runs)
+_FWD_VARIANT = 64 if os.environ.get('SREC_FWD_WRES') == '1' else (5 if os.environ.get('SREC_FWD_XCDCOLS') == '1' else 0)     # 64: the weights-in-registers forward kernel, 5: column tiles dealt to the XCDs (A/B runs)
 
 
 def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, variant=0, bfrag=False):
