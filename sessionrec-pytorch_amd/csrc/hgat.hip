@@ -13,8 +13,13 @@
 // prefix dyn_n[t].  Module m's projection P[m] = x[rows of m] W_m^T is [rows_m, H*D]; a projection BLOCK is the
 // row range of one type inside one module's projection (the shared 'inter' module projects every type at once).
 // A relation INSTANCE (conv, relation) reads its source block and writes into its destination type.
-// Grid geometry: one wavefront per (node, head) for the logits / gradient passes; one 8-wave workgroup per
-// destination node for the fused aggregation (wave h = head h, the head-max goes through 8 KB of LDS).
+// Grid geometry (H = 8, D % 8 == 0; round 3): ONE WAVEFRONT PER NODE with all heads in the lane for the fused aggregation
+// (hg_agg_node_kernel) and the score gradients (hg_bwd_dst_node_kernel: all relation instances of the node side by side),
+// one wavefront per (projection block, node) for the projection gradients (hg_bwd_src_kernel), the attention logits on the
+// fp32 matrix pipe (hg_dots_kernel).  These kernels are bound by memory latency x occupancy (a dependent load costs 1.2 - 1.7 us
+// behind the cold per-XCD L2s of a fresh kernel), so they are built for few dependent hops and many resident waves.  The
+// round-2 shapes - an 8-wave workgroup per destination node (wave = head, head-max through 8 KB of LDS), a wavefront per
+// (instance, destination) - remain as the fallbacks for other H / D.
 #include "common.h"
 #include "../../include/srec_hg.h"
 
