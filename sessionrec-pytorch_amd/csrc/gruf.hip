@@ -11,9 +11,11 @@
 //     ds_read_b128 lane groups are conflict-free; x_t is rounded on the way in (its bf16 copy for the weight-gradient GEMM
 //     is written from here: no separate conversion pass), h_t is written back by the gate epilogue;
 //   * the weights are streamed from L2 - both orders' matrices are 1.5 MB - in FRAGMENT-MAJOR order (srec_gru_wfrag: the 64
-//     lanes x 16 B of one MFMA B operand contiguous, fragments ordered wave / k-step / gate / column block): one LDS-DMA
-//     instruction (global_load_lds_dwordx4, 1 KiB lane-linear) lands one fragment exactly as ds_read_b128 wants it.  Every
-//     wave runs a private 4-stage ring (3 k-steps = 18 KiB in flight), counted vmcnt waits, no barrier in the k-loop;
+//     lanes x 16 B of one MFMA B operand contiguous, fragments ordered wave / k-step / gate / column block): one plain
+//     coalesced 1-KiB load puts a fragment straight into the registers that feed the MFMAs (the copy IS the operand; the first
+//     version went through LDS-DMA + ds_read_b128).  Every wave runs a private 4-stage REGISTER ring (3 k-steps in flight),
+//     no barrier in the k-loop.  At 113 16-node workgroups per order x 1.15 / 1.9 MB this stream is 345 MB per launch =
+//     ~9 TB/s over the 37 us: the launch runs at what the L2s deliver to the CUs (profiles/r03_notes.md);
 //   * the gate math is the epilogue of the step's products; H, the bf16 copy of H, the saved gates and (last step) the
 //     expander output 0.5 mean_t x + 0.5 h_last leave as 128-byte row segments.
 // Arithmetic = the step kernels': bf16 operands, fp32 accumulation, fp32 gates (the r / z pre-activations are summed in a
