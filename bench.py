@@ -311,7 +311,8 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     final = float(loss.item())
-    waits = {k: round((v - w0[k]) / max(n, 1) * 1e3, 4) for k, v in getattr(loader, 'stats', {}).items()}   # ms per step
+    # (the loader counts cumulative seconds under keys ending in _s: reported here as milliseconds per step, keys renamed)
+    waits = {(k[:-2] if k.endswith('_s') else k): round((v - w0[k]) / max(n, 1) * 1e3, 4) for k, v in getattr(loader, 'stats', {}).items()}
     if probe is not None:
         for rep in range(2):
             torch.cuda.synchronize()
@@ -366,6 +367,45 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
                 graph_steps=runner.graph_steps - g0, eager_steps=runner.eager_steps - e0, final_loss=final, probe=probe,
                 note='wall time of the DataLoader loop (train.py:92-110 equivalent): worker collate + pinned H2D copy + '
                      'hipGraph replay per batch, evaluation excluded')
+
+
+def quality(sp, dev, precision):
+    """Recall@20 / MRR@20 after training (the second half of BASELINE.json's metric), on the one real split the image holds:
+    the reference's shipped datasets/sample.  The pinned recipe of tests/golden/trained_metrics.json (MSGIFSR order 2, d 64,
+    1 layer, dropout 0, batch 512 in time order, 3 epochs through TrainRunner: train.py:56-127) trained on the HIP path in
+    this run's arithmetic mode, next to the committed numbers of the CPU ORACLE trained by the reference's own loop on the
+    same batches from the same seeded weights (tests/golden/make_trained_metrics.py)."""
+    ops = importlib.import_module('sessionrec-pytorch_amd.ops')
+    ds = importlib.import_module('sessionrec-pytorch_amd.dataset')
+    col = importlib.import_module('sessionrec-pytorch_amd.collate')
+    train = importlib.import_module('sessionrec-pytorch_amd.train')
+    pin = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'trained_metrics.json')))
+    cfg = pin['msgifsr_o2_d64']
+    tr, te, V = ds.read_dataset(os.path.join(ROOT, 'datasets', 'sample'))
+    train_set, test_set = ds.AugmentedDataset(tr), ds.AugmentedDataset(te)
+    cf = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), cfg['order'])
+    B = cfg['batch_size']
+    mk = lambda data: [cf([data[i] for i in range(b, min(len(data), b + B))]) for b in range(0, len(data), B)]
+    trl, tel = mk(train_set), mk(test_set)
+    ops.set_precision(precision)
+    torch.manual_seed(cfg['seed'])
+    model = sp.MSGIFSR(V, 'sample', cfg['embedding_dim'], cfg['num_layers'], dropout=0.0, order=cfg['order'], extra=False,
+                       fusion=False).to(dev)
+    runner = train.TrainRunner('sample', model, trl, tel, dev, lr=1e-3, weight_decay=1e-4, patience=99)
+    t0 = time.perf_counter()
+    _out, sys.stdout = sys.stdout, open(os.devnull, 'w')          # (the loop prints the reference's per-epoch lines)
+    try:
+        runner.train(len(cfg['epochs']) - 1, log_interval=10 ** 9)
+    finally:
+        sys.stdout = _out
+    mrr, hit = train.evaluate(model, tel, dev)
+    omrr, ohit = cfg['epochs'][-1]
+    return dict(split='datasets/sample (the reference\'s shipped split: %d train / %d test samples, %d items)' % (len(train_set), len(test_set), V),
+                model='MSGIFSR order %d, d %d, %d epochs, batch %d, dropout 0 (the pinned recipe of tests/golden/trained_metrics.json)'
+                      % (cfg['order'], cfg['embedding_dim'], len(cfg['epochs']) - 1, B),
+                precision=precision, recall_at_20=100 * hit, mrr_at_20=100 * mrr, oracle_recall_at_20=100 * ohit,
+                oracle_mrr_at_20=100 * omrr, unit='percent', delta_recall_pt=100 * (hit - ohit), delta_mrr_pt=100 * (mrr - omrr),
+                oracle='CPU oracle (oracle/models_ref.py) trained by the reference loop, fp32', train_seconds=time.perf_counter() - t0)
 
 
 def _free_port():
@@ -435,6 +475,19 @@ def encoder_flop(model_name, counts, d, order, H=8):
     return 3 * f
 
 
+def _all_reduce(dist, t, op=None):
+    """all-reduce of a small device tensor through the job's backend.  RCCL takes device memory; the gloo dry run (N rank
+    processes on ONE GPU: SREC_BENCH_BACKEND=gloo, tests/test_dist_gpu.py) stages through the host"""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend() != 'nccl':
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def run_timed(step, dev_batches, warmup, steps, repeats, dist, dev):
     """W untimed steps, then `repeats` regions of exactly K steps, each bracketed by barrier + synchronize on both sides,
     max over ranks.  -> (seconds of each region, last loss)"""
@@ -460,8 +513,7 @@ def run_timed(step, dev_batches, warmup, steps, repeats, dist, dev):
         dt = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
+            dt = _all_reduce(dist, t, dist.ReduceOp.MAX).item()
         regions.append(dt)
     return regions, loss
 
@@ -497,6 +549,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 side run (the reference arithmetic) of the same step')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the DataLoader-inclusive run of the same workload')
+    ap.add_argument('--no-quality', action='store_true', help='skip the trained Recall@20 / MRR@20 run on datasets/sample')
     ap.add_argument('--e2e-loader', default='ring', choices=['ring', 'torch'],
                     help='loader of the end-to-end run: the shared pinned ring (launcher default) or torch DataLoader')
     ap.add_argument('--e2e-workers', type=int, default=4, help='DataLoader worker processes of the end-to-end run')
@@ -516,7 +569,7 @@ def main():
                          'gloo on a box without GPUs)')
     args = ap.parse_args()
     if args.step_only:
-        args.no_cpu_baseline = args.no_fp32 = args.no_end_to_end = True
+        args.no_cpu_baseline = args.no_fp32 = args.no_end_to_end = args.no_quality = True
         args.repeats = 1
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -534,13 +587,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl' if has_gpu else 'gloo', rank=rank, world_size=world)
+        # SREC_BENCH_BACKEND=gloo: the N-rank dry run on a box with ONE GPU - every rank on cuda:0, collectives staged through
+        # the host (sessionrec-pytorch_amd/dist.py) - so that the whole N > 1 line (ranks_seen, collectives, scaling, the
+        # eager fallback when the collectives cannot be captured) has been produced before an 8-GPU node ever runs it
+        backend = os.environ.get('SREC_BENCH_BACKEND') or ('nccl' if has_gpu else 'gloo')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        if has_gpu and backend != 'nccl':
+            local = local % torch.cuda.device_count()
     if args.launch_only:
         dev = torch.device('cuda', local) if has_gpu else torch.device('cpu')
         if has_gpu:
             torch.cuda.set_device(local)
-        seen = torch.ones(1, device=dev)
-        dist.all_reduce(seen)                    # every rank contributes 1: the sum is the number of live ranks
+        seen = _all_reduce(dist, torch.ones(1, device=dev))   # every rank contributes 1: the sum is the number of live ranks
         if rank == 0:
             emit(dict(launch_only=True, n_gpus=world, gpus_requested=args.gpus, ranks_seen=int(seen.item()),
                                   world_size=dist.get_world_size(), backend=dist.get_backend()))
@@ -594,7 +652,7 @@ def main():
             D = importlib.import_module('sessionrec-pytorch_amd.dist')
             cap = batches[0][0][0].cap('uniq_items')   # only the distinct items of a batch are exchanged; equal padded
             t = torch.tensor([cap], device=dev)        # request length on every rank: no per-step size exchange
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            _all_reduce(dist, t, dist.ReduceOp.MAX)
             shard = D.VocabParallel(model, idx_cap=int(t.item()))
         opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
         replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
@@ -619,16 +677,21 @@ def main():
             except Exception as e:                         # capture of the collectives refused: eager launches
                 if shard is None:
                     raise
-                print('graph capture with RCCL failed (%s: %s); running eager' % (type(e).__name__, e), file=sys.stderr, flush=True)
+                print('graph capture with the collectives failed (%s: %s); running eager' % (type(e).__name__, str(e)[:300]),
+                      file=sys.stderr, flush=True)
+            if shard is not None and world > 1:
+                # the ranks decide TOGETHER (as TrainRunner does): a rank whose capture failed has skipped the exchanges of
+                # the capture lap - from here on either all replay or all launch eagerly
+                ok = _all_reduce(dist, torch.tensor([1.0 if graphed else 0.0], device=dev), dist.ReduceOp.MIN)
+                if ok.item() < 1.0:
+                    step, graphed, gstep = eager, False, None
         return model, shard, step, graphed, gstep
 
     model, shard, step, graphed, gstep = setup(args.precision)
     # every rank contributes 1 through the job's own backend (RCCL): the sum is the number of ranks the collectives reach
     ranks_seen = 1
     if dist is not None:
-        seen = torch.ones(1, device=dev)
-        dist.all_reduce(seen)
-        ranks_seen = int(seen.item())
+        ranks_seen = int(_all_reduce(dist, torch.ones(1, device=dev)).item())
     coll = None
     if shard is not None:
         D = importlib.import_module('sessionrec-pytorch_amd.dist')
@@ -662,6 +725,14 @@ def main():
         ops.set_precision(args.precision)
         e2e = end_to_end(args, sp, state, V, d, B, dev, workers=args.e2e_workers)
         e2e['vs_value'] = e2e['value'] / (Bg * args.steps / dt)
+
+    qual = None
+    if not args.no_quality and world == 1 and not args.shard:
+        try:
+            qual = quality(sp, dev, args.precision)
+        except FileNotFoundError as e:                   # (a checkout without datasets/sample or the pin file)
+            qual = dict(error=str(e))
+        ops.set_precision(args.precision)
 
     if rank == 0 and args.step_only:
         emit(dict(step_only=True, ms_per_step=dt / args.steps * 1e3, value=Bg * args.steps / dt, launches=nodes,
@@ -729,7 +800,7 @@ def main():
                                global_batch=Bg, parallelism=('item table row-sharded x%d (vocab-parallel scoring, RCCL all-gather/reduce-scatter), '
                                             'encoder replicated, %s' % (world, 'each rank encodes its slice of one 512-session batch' if strong else 'each rank feeds its own batch')) if world > 1 else 'single GPU',
                                final_loss=final_loss),
-                   roofline=roof, fp32=fp32, end_to_end=e2e, cpu_baseline=cpu)
+                   roofline=roof, fp32=fp32, end_to_end=e2e, quality=qual, cpu_baseline=cpu)
         emit(out)
     if dist is not None:
         dist.barrier()                      # the other ranks wait for rank 0's kernel timing / CPU baseline

@@ -1,0 +1,405 @@
+// Attention read-out + session vector of MSGIFSR (msgifsr.py:124-155 AttnReadout, :269-273 fc_sr + F.normalize) for a GROUP OF
+// SESSIONS per workgroup, forward in ONE launch (bf16 mode, d = 128 or 256):
+//     Vq_b = v_b Wv^T;  U_i = x_i Wu^T + bu;  e_i = we . sigmoid(U_i + Vq_b(i));  alpha = softmax over the session's nodes;
+//     g_b = sum_i alpha_i x_i;  s_b = [v_b | g_b] Wsr^T;  y_b = s_b / max(|s_b|, eps)   (+ the bf16 operand copy of y for the
+//     scoring kernels)
+// As grouped batch-wide launches (ops.ReadoutHead: {U, Vq} GEMM, read-out kernel, {s} GEMM, split-K sum, normalise) these are
+// five latency-bound kernel nodes of ~50 us for 0.9 GFLOP.  Here a workgroup OWNS HS = 8 consecutive sessions - their rows
+// of the per-session concatenation `allf` are contiguous - and runs the whole chain on them:
+//   * every product is computed TRANSPOSED on the bf16 matrix pipe, D^T = W . X^T with v_mfma_f32_32x32x16_bf16: the A
+//     operand is a 32-column block of the weight, the B operand 32 rows of activations, so the result puts a ROW in the lane
+//     and 16 hidden columns in its registers: the per-row reductions that follow (we . sigmoid(.), |s|^2) are sums over a
+//     lane's own registers + one exchange between the wave halves - no LDS transpose, and U never exists in memory;
+//   * exact-fp32 results on bf16 operands: both operands are split x = hi + lo (bf16 each, |lo| <= 2^-9 |x|) and the
+//     product is the three terms hi hi + lo hi + hi lo (the dropped lo lo term is 2^-18 relative).  fp32 MFMA runs at 1/16
+//     of the bf16 rate on gfx950: three bf16 products cost 3/16 - the kernel is then bound by what feeds the pipe;
+//   * the weights stream from L2 in FRAGMENT-MAJOR hi / lo copies (srec_head_wfrag, once per step: the 64 lanes x 16 B of one
+//     MFMA operand contiguous, ordered wave / k-step / {hi, lo} / column block), plain 1-KiB coalesced loads straight into
+//     the registers that feed the MFMAs through a 4-stage register ring (the idiom of gruf.hip); 64 workgroups x
+//     (Wv 256 KB + ~3 chunks x Wu 256 KB + Wsr 512 KB) ~ 100 MB out of L2 per launch at B = 512, d = 256;
+//   * activations (32-row chunks of the group's node rows, the 8 query rows, the [v | g] rows) are split while they are staged
+//     into LDS (row-major bf16, 16-B pieces XOR-swizzled by the row: conflict-free ds_read_b128).
+// Saved for the backward: alpha [NT], cat = [v | g] [B, 2 d], Vq [B, d], y [B, d], 1 / |s| [B]; U only on request (the
+// grouped backward of ops.ReadoutHead reads it; the fused backward recomputes it).
+#include "common.h"
+#include "../../include/srec_hg.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int HS = SREC_HEAD_SESSIONS;   // sessions per workgroup
+constexpr int NW = 4;                    // waves per workgroup: wave w owns the hidden / output columns [w d/4, (w+1) d/4)
+constexpr int NS = 4, PF = NS - 1;       // register ring of weight fragments: stages, k-steps in flight
+constexpr int MAXN = SREC_MAX_SESSION_NODES;
+constexpr int VQ_PAD = 8;                // floats of padding per Vq row in LDS: (session, wave half) -> distinct 16-B slots
+
+struct HeadArgs {
+    srec_head_desc d;
+};
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = srec_pack_bf16(a, b);
+    const float ah = __builtin_bit_cast(float, hi << 16), bh = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = srec_pack_bf16(a - ah, b - bh);
+}
+
+// 4 consecutive fp32 -> the hi / lo tiles (row-major [rows][W] bf16, 16-B pieces swizzled by row & 15), column c (multiple of 4)
+__device__ __forceinline__ void stage4(unsigned short* hi_t, unsigned short* lo_t, int W, int row, int c, float4 v) {
+    uint2 h, l;
+    split2(v.x, v.y, h.x, l.x);
+    split2(v.z, v.w, h.y, l.y);
+    const int off = row * W + (((c >> 3) ^ (row & 15)) * 8) + (c & 4);
+    *reinterpret_cast<uint2*>(hi_t + off) = h;
+    *reinterpret_cast<uint2*>(lo_t + off) = l;
+}
+
+template <int DD>
+__global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
+    constexpr int D = 128 * DD, JB = D / (32 * NW), KS = D / 16, NF = 2 * JB;     // NF: fragments per (wave, k-step): hi | lo
+    constexpr int NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
+    unsigned short* x_hi = sm;                               // [32][D]   node-row chunk
+    unsigned short* x_lo = x_hi + 32 * D;
+    unsigned short* c_hi = x_lo + 32 * D;                    // [HS][2 D] [v | g] of the group's sessions
+    unsigned short* c_lo = c_hi + HS * 2 * D;
+    float* vq = reinterpret_cast<float*>(c_lo + HS * 2 * D); // [HS][D + VQ_PAD]
+    float* e = vq + HS * (D + VQ_PAD);                       // [HS * MAXN] logits, then soft-max weights, of the group's rows
+    float* epart = e + HS * MAXN;                            // [NW][32]
+    int* segs = reinterpret_cast<int*>(epart + NW * 32);     // [HS + 1] first row of each session (+ end), relative to r0
+    int* rsess = segs + HS + 1;                              // [32] session (0 .. HS-1) of each row of the chunk
+
+    const srec_head_desc& q = a.d;
+    const int hd = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * HS;
+    const int Bl = dyn_count(q.dynB, q.B);
+    const int ns = max(0, min(HS, Bl - b0));                 // live sessions of this group
+    float* cat = q.cat[hd];
+    float* Y = q.y[hd];
+    unsigned short* Y16 = (unsigned short*)q.y16[hd];
+    const int ld16 = q.ld16;
+
+    if (ns < HS) {
+        // capacity padding: zero rows where the grouped path writes zeros (read-out half of cat, y, 1/|s|, the bf16 operand)
+        for (int i = tid; i < (HS - ns) * (D / 4); i += NT) {
+            const int b = b0 + ns + i / (D / 4), c = (i % (D / 4)) * 4;
+            if (b < q.B) {
+                *reinterpret_cast<float4*>(cat + (size_t)b * 2 * D + D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(Y + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (Y16 != nullptr) *reinterpret_cast<uint2*>(Y16 + (size_t)b * ld16 + c) = make_uint2(0u, 0u);
+                if (q.Vq[hd] != nullptr) *reinterpret_cast<float4*>(q.Vq[hd] + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int i = tid; i < HS - ns; i += NT)
+            if (b0 + ns + i < q.B) q.inv[hd][b0 + ns + i] = 0.f;
+        if (ns == 0) return;
+    }
+    const int r0 = q.seg[b0];
+    if (tid <= HS) segs[tid] = q.seg[b0 + min(tid, ns)] - r0;
+    const int nrows = q.seg[b0 + ns] - r0;
+
+    const int cbase = wave * 32 * JB;
+    const float* X = q.X;
+    const int ld_x = q.ld_x;
+
+    // ---- the group's query rows v_b (left half of cat) into the [v | g] tile
+    for (int i = tid; i < HS * (D / 4); i += NT) {
+        const int row = i / (D / 4), c = (i % (D / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < ns) v = *reinterpret_cast<const float4*>(cat + (size_t)(b0 + row) * 2 * D + c);
+        stage4(c_hi, c_lo, 2 * D, row, c, v);
+    }
+    // first chunk of node rows: in flight under the Vq product
+    constexpr int XV = 32 * D / 4 / NT;
+    float4 xv[XV];
+    auto fetch_x = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int idx = i * NT + tid;
+            const int row = idx / (D / 4), c4 = idx % (D / 4);
+            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + row < nrows) xv[i] = *reinterpret_cast<const float4*>(X + (size_t)(r0 + c0 + row) * ld_x + c4 * 4);
+        }
+    };
+    fetch_x(0);
+    __syncthreads();
+
+    // D^T (+)= W . B^T over T k-steps: A = fragment-major weight (hi | lo per column block) through the register ring, B = the
+    // hi / lo LDS tile `bh` / `bl` (row stride W, row = brow)
+    f32x16 acc[JB];
+    auto product = [&](const unsigned short* wf, const int T, const unsigned short* bh, const unsigned short* bl, const int W,
+                       const int brow) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        bf16x8 Aq[NS][NF];
+        const unsigned short* wsrc = wf + (size_t)wave * T * NF * 512 + lane * 8;
+        auto load = [&](int i, int slot) {
+            i = min(i, T - 1);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) Aq[slot][f] = *reinterpret_cast<const bf16x8*>(wsrc + ((size_t)i * NF + f) * 512);
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load(i, i);
+#pragma unroll 1
+        for (int ib = 0; ib < T; ib += NS) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                load(ib + u + PF, (u + PF) % NS);
+                const int s = ib + u;
+                const int off = brow * W + (((2 * s + half) ^ (brow & 15)) * 8);
+                const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(bh + off);
+                const bf16x8 Bl_ = *reinterpret_cast<const bf16x8*>(bl + off);
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][JB + j], Bh, acc[j], 0, 0, 0);      // lo hi
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bl_, acc[j], 0, 0, 0);          // hi lo
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bh, acc[j], 0, 0, 0);           // hi hi
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, NF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * JB, 0);
+            }
+        }
+    };
+
+    // ---- Vq^T = Wv . v^T: lane = session (l31 & (HS - 1)), registers = this wave's hidden columns
+    product((const unsigned short*)q.Wv_f[hd], KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
+    if (l31 < HS) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = cbase + 32 * j + 8 * g + 4 * half;
+                const float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+                *reinterpret_cast<float4*>(vq + l31 * (D + VQ_PAD) + col) = v;
+                if (q.Vq[hd] != nullptr && l31 < ns) *reinterpret_cast<float4*>(q.Vq[hd] + (size_t)(b0 + l31) * D + col) = v;
+            }
+    }
+    // bias and attention vector of this lane's hidden columns
+    float bu_[JB][16], we_[JB][16];
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = cbase + 32 * j + 8 * g + 4 * half;
+            const float4 wv = *reinterpret_cast<const float4*>(q.we[hd] + col);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q.bu[hd] != nullptr) bv = *reinterpret_cast<const float4*>(q.bu[hd] + col);
+            we_[j][4 * g] = wv.x; we_[j][4 * g + 1] = wv.y; we_[j][4 * g + 2] = wv.z; we_[j][4 * g + 3] = wv.w;
+            bu_[j][4 * g] = bv.x; bu_[j][4 * g + 1] = bv.y; bu_[j][4 * g + 2] = bv.z; bu_[j][4 * g + 3] = bv.w;
+        }
+
+    // ---- node rows in chunks of 32: U^T = Wu . X^T, e_i = we . sigmoid(U_i + bu + Vq_b(i))
+    float* Uout = q.U[hd];
+    for (int c0 = 0; c0 < nrows; c0 += 32) {
+        __syncthreads();                         // the previous chunk's tile / rsess / epart have been read; vq is published
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int idx = i * NT + tid;
+            stage4(x_hi, x_lo, D, idx / (D / 4), (idx % (D / 4)) * 4, xv[i]);
+        }
+        if (tid < 32) {
+            int s = 0;
+#pragma unroll
+            for (int k = 1; k < HS; ++k) s += (c0 + tid >= segs[k]) ? 1 : 0;
+            rsess[tid] = min(s, ns - 1);
+        }
+        if (c0 + 32 < nrows) fetch_x(c0 + 32);
+        __syncthreads();
+        product((const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31);
+        const int row = c0 + l31;
+        const float* vrow = vq + rsess[l31] * (D + VQ_PAD);
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = cbase + 32 * j + 8 * g + 4 * half;
+                const float4 vv = *reinterpret_cast<const float4*>(vrow + col);
+                const float u0 = acc[j][4 * g] + bu_[j][4 * g], u1 = acc[j][4 * g + 1] + bu_[j][4 * g + 1];
+                const float u2 = acc[j][4 * g + 2] + bu_[j][4 * g + 2], u3 = acc[j][4 * g + 3] + bu_[j][4 * g + 3];
+                part += we_[j][4 * g] * sigmoidf_(u0 + vv.x) + we_[j][4 * g + 1] * sigmoidf_(u1 + vv.y) +
+                        we_[j][4 * g + 2] * sigmoidf_(u2 + vv.z) + we_[j][4 * g + 3] * sigmoidf_(u3 + vv.w);
+                if (Uout != nullptr && row < nrows)
+                    *reinterpret_cast<float4*>(Uout + (size_t)(r0 + row) * D + col) = make_float4(u0, u1, u2, u3);
+            }
+        part += __shfl_xor(part, 32, 64);
+        if (half == 0) epart[wave * 32 + l31] = part;
+        __syncthreads();
+        if (tid < 32 && c0 + tid < nrows) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += epart[w * 32 + tid];
+            e[c0 + tid] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- soft-max over each session's rows, read-out row g_b = sum_i alpha_i x_i (node order, as seg_attn_fwd sums it)
+    for (int sb = wave; sb < ns; sb += NW) {
+        const int base = segs[sb], n = min(segs[sb + 1] - base, MAXN);
+        float m = -INFINITY;
+        for (int i = lane; i < n; i += 64) m = fmaxf(m, e[base + i]);
+        m = wave_max(m);
+        float ssum = 0.f;
+        for (int i = lane; i < n; i += 64) ssum += expf(e[base + i] - m);
+        ssum = wave_sum(ssum);
+        const float inv = n > 0 ? 1.f / ssum : 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const float al = expf(e[base + i] - m) * inv;
+            e[base + i] = al;
+            q.alpha[hd][r0 + base + i] = al;
+        }
+        __builtin_amdgcn_s_waitcnt(0);           // this wave's LDS writes of alpha before its own reads below (one wave per session)
+        const int c = lane * 4;
+        if (c < D) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* xp = X + (size_t)(r0 + base) * ld_x + c;
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float4*>(xp + (size_t)(i + k) * ld_x);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float al = e[base + i + k];
+                    o.x += al * t[k].x; o.y += al * t[k].y; o.z += al * t[k].z; o.w += al * t[k].w;
+                }
+            }
+            for (; i < n; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(xp + (size_t)i * ld_x);
+                const float al = e[base + i];
+                o.x += al * t.x; o.y += al * t.y; o.z += al * t.z; o.w += al * t.w;
+            }
+            *reinterpret_cast<float4*>(cat + (size_t)(b0 + sb) * 2 * D + D + c) = o;
+            stage4(c_hi, c_lo, 2 * D, sb, D + c, o);
+        }
+    }
+    if (ns < HS) {                               // tile rows of the group's padding sessions: zeros (their lanes are never read)
+        for (int i = tid; i < (HS - ns) * (D / 4); i += NT)
+            stage4(c_hi, c_lo, 2 * D, ns + i / (D / 4), D + (i % (D / 4)) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    __syncthreads();
+
+    // ---- s^T = Wsr . [v | g]^T (K = 2 d), y = s / max(|s|, eps)
+    product((const unsigned short*)q.Wsr_f[hd], 2 * KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ss += acc[j][r] * acc[j][r];
+    ss += __shfl_xor(ss, 32, 64);
+    if (half == 0 && l31 < HS) epart[wave * 32 + l31] = ss;
+    __syncthreads();
+    if (l31 < ns) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += epart[w * 32 + l31];
+        const float nrm = sqrtf(tot);
+        const float iv = q.eps_mode == 0 ? 1.f / fmaxf(nrm, q.eps) : 1.f / (nrm + q.eps);
+        const int b = b0 + l31;
+        if (wave == 0 && half == 0) q.inv[hd][b] = iv;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = cbase + 32 * j + 8 * g + 4 * half;
+                const float4 v = make_float4(acc[j][4 * g] * iv, acc[j][4 * g + 1] * iv, acc[j][4 * g + 2] * iv, acc[j][4 * g + 3] * iv);
+                *reinterpret_cast<float4*>(Y + (size_t)b * D + col) = v;
+                if (Y16 != nullptr)
+                    *reinterpret_cast<uint2*>(Y16 + (size_t)b * ld16 + col) = make_uint2(srec_pack_bf16(v.x, v.y), srec_pack_bf16(v.z, v.w));
+            }
+    }
+}
+
+struct WfragArgs {
+    int n;
+    const float* W[SREC_HEAD_MAXW];
+    unsigned short* dst[SREC_HEAD_MAXW];
+    int rows[SREC_HEAD_MAXW], cols[SREC_HEAD_MAXW], trans[SREC_HEAD_MAXW];
+};
+
+// hi / lo fragment-major copy of an operand matrix M [N, K] (trans = 0: M = W [rows = N, cols = K] as stored; trans = 1:
+// M = W^T of the stored W [rows = K, cols = N]): fragment (((w KS + s) 2 + t) JB + j), JB = N / 128, KS = K / 16, holds for lane l
+// the 8 bf16 of t(M[w N/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]), t = hi / lo
+__global__ __launch_bounds__(256) void head_wfrag_kernel(WfragArgs a) {
+    const int m = blockIdx.y;
+    const int N = a.trans[m] ? a.cols[m] : a.rows[m], K = a.trans[m] ? a.rows[m] : a.cols[m];
+    const int JB = N / (32 * NW), KS = K / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // (w, s, j, lane)
+    if (idx >= N * K / 8) return;
+    const int lane = idx & 63, f = idx >> 6;
+    const int j = f % JB, ws = f / JB, s = ws % KS, w = ws / KS;
+    const int nrow = w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
+    float v[8];
+    const float* W = a.W[m];
+    if (!a.trans[m]) {
+        const float4 v0 = *reinterpret_cast<const float4*>(W + (size_t)nrow * K + kk), v1 = *reinterpret_cast<const float4*>(W + (size_t)nrow * K + kk + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = W[(size_t)(kk + i) * N + nrow];
+    }
+    uint4 h, l;
+    split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y); split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
+    unsigned short* dst = a.dst[m] + ((((size_t)(w * KS + s) * 2) * JB + j) * 64 + lane) * 8;
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + (size_t)JB * 512) = l;
+}
+
+}  // namespace
+
+// n <= SREC_HEAD_MAXW matrices W_i [rows_i, cols_i] fp32 row-major (HOST arrays) -> hi / lo fragment-major bf16 copies dst_i
+// [2 rows_i cols_i] of W_i (trans_i = 0) or W_i^T (trans_i = 1) as the A operands of srec_head_fwd; operand rows % 128 == 0,
+// operand columns % 16 == 0.  One launch.
+extern "C" int srec_head_wfrag(int n, const void* W, const void* dst, const int* rows, const int* cols, const int* trans,
+                               void* stream) {
+    if (n <= 0) return 0;
+    if (n > SREC_HEAD_MAXW || W == nullptr || dst == nullptr || rows == nullptr || cols == nullptr || trans == nullptr) return SREC_BAD_ARG;
+    WfragArgs a{};
+    a.n = n;
+    int maxe = 0;
+    for (int i = 0; i < n; ++i) {
+        a.W[i] = ((const float* const*)W)[i]; a.dst[i] = ((unsigned short* const*)dst)[i];
+        a.rows[i] = rows[i]; a.cols[i] = cols[i]; a.trans[i] = trans[i];
+        const int N = trans[i] ? cols[i] : rows[i], K = trans[i] ? rows[i] : cols[i];
+        if (a.W[i] == nullptr || a.dst[i] == nullptr || N <= 0 || K <= 0 || (N % 128) || (K % 16)) return SREC_BAD_ARG;
+        maxe = max(maxe, N * K / 8);
+    }
+    hipLaunchKernelGGL(head_wfrag_kernel, dim3((maxe + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// desc: HOST srec_head_desc (srec_hg.h)
+extern "C" int srec_head_fwd(const void* desc, void* stream) {
+    const srec_head_desc* q = (const srec_head_desc*)desc;
+    if (q == nullptr || q->nh <= 0 || q->nh > SREC_HEAD_MAXH || (q->d != 128 && q->d != 256) || q->B <= 0) return SREC_BAD_ARG;
+    if (q->X == nullptr || q->seg == nullptr || (q->ld_x & 3)) return SREC_BAD_ARG;
+    for (int h = 0; h < q->nh; ++h) {
+        if (q->cat[h] == nullptr || q->Wu_f[h] == nullptr || q->Wv_f[h] == nullptr || q->Wsr_f[h] == nullptr ||
+            q->we[h] == nullptr || q->alpha[h] == nullptr || q->y[h] == nullptr || q->inv[h] == nullptr)
+            return SREC_BAD_ARG;
+        if (q->y16[h] != nullptr && (q->ld16 & 3)) return SREC_BAD_ARG;
+    }
+    HeadArgs a{};
+    a.d = *q;
+    const int D = q->d;
+    const size_t lds = (size_t)(2 * 32 * D + 2 * HS * 2 * D) * 2 + (size_t)(HS * (D + VQ_PAD) + HS * MAXN + NW * 32) * 4 +
+                       (size_t)(HS + 1 + 32) * 4;
+    const dim3 grid((q->B + HS - 1) / HS, q->nh);
+    static std::atomic<unsigned long long> om[2];
+    if (D == 256) {
+        if (int rc = srec_lds_optin((const void*)head_fwd_kernel<2>, (int)lds, om[0])) return rc;
+        hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
+    } else {
+        if (int rc = srec_lds_optin((const void*)head_fwd_kernel<1>, (int)lds, om[1])) return rc;
+        hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
+    }
+    SREC_LAUNCH_CHECK();
+    return 0;
+}

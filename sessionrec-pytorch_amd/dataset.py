@@ -148,8 +148,22 @@ class RankSliceBatchSampler:
     loss) so that every rank takes part in every step's collectives.  `sampler` must produce the same order on every
     rank (SequentialSampler, or a RandomSampler with an identically seeded generator)."""
 
-    def __init__(self, sampler, batch_size, rank, world):
+    def __init__(self, sampler, batch_size, rank, world, prefix_len=None, need_len=None):
+        """prefix_len (optional): array of the click count of every sample (AugmentedDataset.index[:, 1]); need_len: the
+        click count a GLOBAL batch must reach somewhere for every relation of the model's schema to have an edge in it
+        (MSGIFSR: order + 1).  HeteroGraphConv skips a relation without edges in the batch (msgifsr.py:60-64) and a rank
+        sees only its slice, so the multi-rank path treats every relation as live (msgifsr.MSHGNN.plan all_rels); a global
+        batch that breaks the assumption - in practice a tiny last batch of 1-2-click prefixes - is COUNTED here
+        (`short_batches`, reported by the launcher): on it the multi-rank step adds the residual and bias of the edgeless
+        relations where the single-device step would not."""
         self.sampler, self.batch_size, self.rank, self.world = sampler, batch_size, rank, world
+        self.prefix_len, self.need_len = prefix_len, need_len
+        self.short_batches = 0
+
+    def _check(self, batch):
+        if self.prefix_len is not None and self.need_len is not None and \
+                int(np.asarray(self.prefix_len)[np.asarray(batch)].max()) < self.need_len:
+            self.short_batches += 1
 
     def __len__(self):
         return (len(self.sampler) + self.batch_size - 1) // self.batch_size
@@ -164,9 +178,11 @@ class RankSliceBatchSampler:
         for i in self.sampler:
             batch.append(int(i))
             if len(batch) == self.batch_size:
+                self._check(batch)
                 yield self.slice_of(batch)
                 batch = []
         if batch:
+            self._check(batch)
             yield self.slice_of(batch)
 
     def per_rank_capacity(self):

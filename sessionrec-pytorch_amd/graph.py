@@ -234,9 +234,11 @@ class GraphedTrainStep:
     def __call__(self, inputs, labels):
         """inputs: capacity-padded FlatBatches with the captured layout, on the device or still on the host (pinned: the
         DataLoader's batches go straight from pinned memory into the graph's static buffer, see _stage)"""
+        from . import ops
         for i, (st, x, sig) in enumerate(zip(self.static_inputs, inputs, self._sig)):
             if self._signature(x) != sig:
                 raise RuntimeError('batch layout / relation pattern differs from the captured one')
+            ops.check_limits(x)          # the kernels clamp to their per-session budgets: an oversized session is an error
             if x.buf.is_cuda:
                 st.buf.copy_(x.buf, non_blocking=True)
             else:

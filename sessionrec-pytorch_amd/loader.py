@@ -96,12 +96,12 @@ def _worker(wid, kind, order, caps, dataset, ring, words, tasks, results):
         t = tasks.get()
         if t is None:
             return
-        k, slot, indices = t
+        gen, k, slot, indices = t
         try:
             room = ring[slot * words:(slot + 1) * words]
-            results.put((k, slot) + _build(kind, order, caps, dataset, indices, room))
+            results.put((gen, k, slot) + _build(kind, order, caps, dataset, indices, room))
         except BaseException as e:                           # the main process re-raises
-            results.put((k, slot, e))
+            results.put((gen, k, slot, e))
 
 
 class PinnedRingLoader:
@@ -145,6 +145,8 @@ class PinnedRingLoader:
             p.start()
         self.stats = dict(wait_workers_s=0.0, wait_copy_s=0.0)           # where the consumer waited (seconds, cumulative)
         self._busy = {}                                                   # slot -> the FlatBatch last yielded from it
+        self._gen = 0                # iteration counter: tasks and results carry it, results of an abandoned iteration are dropped
+        self._owed = 0               # tasks handed to the workers whose results have not been taken off the queue yet
 
     def __len__(self):
         return len(self.batch_sampler)
@@ -159,7 +161,21 @@ class PinnedRingLoader:
                 ev.synchronize()
                 self.stats['wait_copy_s'] += time.perf_counter() - t0
 
+    def _drain(self):
+        """an iteration abandoned early (break, an exception in the consumer, a worker error re-raised here) leaves tasks with
+        the workers: their results must not be taken for batches of the next iteration, and the workers must have stopped
+        writing into the ring before its slots are handed out again - wait for every owed result and drop it"""
+        while self._owed > 0:
+            try:
+                self._results.get(timeout=120)
+            except _queue.Empty:
+                raise RuntimeError('PinnedRingLoader: %d results of an abandoned iteration never arrived' % self._owed)
+            self._owed -= 1
+
     def __iter__(self):
+        self._drain()
+        self._gen += 1
+        gen = self._gen
         it = iter(self.batch_sampler)
         issued = done = 0
         ready, exhausted = {}, False
@@ -175,7 +191,8 @@ class PinnedRingLoader:
                 return False
             slot = issued % self.slots
             self._release(slot)
-            self._tasks.put((issued, slot, [int(i) for i in idx]))
+            self._tasks.put((gen, issued, slot, [int(i) for i in idx]))
+            self._owed += 1
             issued += 1
             return True
         for _ in range(self.slots - 2):                    # (two slots stay with the batch in hand and the one before it)
@@ -189,6 +206,10 @@ class PinnedRingLoader:
                 except _queue.Empty:
                     raise RuntimeError('PinnedRingLoader: no batch from the workers for 120 s')
                 self.stats['wait_workers_s'] += time.perf_counter() - t0
+                self._owed -= 1
+                if r[0] != gen:                                           # (cannot happen after _drain; belt and braces)
+                    continue
+                r = r[1:]
                 if isinstance(r[2], BaseException):
                     raise r[2]
                 ready[r[0]] = r

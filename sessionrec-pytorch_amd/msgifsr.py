@@ -311,10 +311,17 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         self._table_ready = True
 
     def session_repr(self, mg, tgrad=None):
-        K = self.order
         # every parameter of this model feeds exactly one backward node per layer / order: the slab sums that finish their
-        # gradients may wait for ONE launch at the end of the backward pass (ops.defer_slab_sum)
+        # gradients may wait for ONE launch at the end of the backward pass.  The permission holds for the nodes created by
+        # THIS forward only (they snapshot it: ops.defer_scope) and is withdrawn when the forward returns
         ops.DEFER['on'] = bool(mg.buf.is_cuda and self.training)
+        try:
+            return self._session_repr(mg, tgrad)
+        finally:
+            ops.DEFER['on'] = False
+
+    def _session_repr(self, mg, tgrad=None):
+        K = self.order
         if mg.buf.is_cuda:
             ops.check_limits(mg)
         if not self.__dict__.pop('_table_ready', False):

@@ -80,10 +80,15 @@ def copy_words(src, dst, n):
     lib.srec_copy_words(src.data_ptr(), dst.data_ptr(), int(n), stream())
 
 
-def check_limits(mg, deg='deg'):
+def check_limits(mg, deg=None):
     """a batch whose longest session / largest node degree exceeds what the per-session kernels hold in LDS is refused here
-    (collate records both in FlatBatch.meta): a clean error, never a silently truncated soft-max"""
+    (collate records both in FlatBatch.meta): a clean error, never a silently truncated soft-max.  Host-only (two meta
+    values): called by the models' forward AND by graph.GraphedTrainStep for every replayed batch - a replay never runs
+    the models' Python again.  deg: which degree budget applies (default: by the batch kind - LESSR's shortcut graphs
+    go through the SGAT kernels)"""
     L, m = limits(), mg.meta
+    if deg is None:
+        deg = 'sgat_deg' if m.get('kind') == 'shortcut' else 'deg'
     if m.get('max_nodes', 0) > L['nodes']:
         raise ValueError('a session of this batch has %d read-out nodes; the per-session kernels hold at most %d '
                          '(SREC_MAX_SESSION_NODES, csrc/common.h): truncate sessions (the reference preprocessing keeps the '
@@ -269,9 +274,31 @@ RNG_COUNTER = {}     # str(device) -> int32[1] device tensor: the device-side st
 #                      with another optimizer have none.
 
 
+_NONCE = {'seed': None, 'gen': None}
+
+
+def seed_dropout(seed=None):
+    """(re)start the nonce stream of the dropout masks: from `seed`, or from torch.initial_seed().  Called implicitly when
+    torch.initial_seed() has CHANGED since the last draw (torch.manual_seed with another value); a program that re-seeds
+    with the SAME value to replay a run's masks calls it explicitly (re-seeding with an equal value is not observable)."""
+    base = torch.initial_seed()
+    _NONCE['seed'] = base
+    _NONCE['gen'] = torch.Generator().manual_seed((base if seed is None else int(seed)) ^ 0x5DEECE66D)
+
+
+def _nonce():
+    """a fresh 31-bit draw from a PRIVATE generator seeded from torch.initial_seed(): the nonces follow torch.manual_seed
+    but never advance torch's global CPU stream - the stream RandomSampler (NISER / SRGNN shuffling) and user code draw
+    from - so the batch order of a seeded run does not depend on how many dropout call sites a step has (eager vs
+    replayed steps, model configurations)."""
+    if _NONCE['gen'] is None or _NONCE['seed'] != torch.initial_seed():
+        seed_dropout()
+    return int(torch.randint(0, 0x7fffffff, (1,), generator=_NONCE['gen']).item())
+
+
 def rng_args(device):
     """(nonce, counter pointer) of the counter-based dropout masks (csrc/common.h srec_rng).  The nonce is a fresh draw
-    from torch's CPU generator per call: it follows torch.manual_seed and renews the masks on every eager forward -
+    from a private CPU generator per call (_nonce): it follows torch.manual_seed and renews the masks on every eager forward -
     with any optimizer, and for each of several micro-batches per optimizer step.  The callers keep it for their
     backward, which recomputes the mask.  Under hipGraph replay the kernel arguments (the nonce) are frozen; there the
     device counter, advanced by the captured optimizer step itself, renews the masks - a capture without one would
@@ -281,8 +308,7 @@ def rng_args(device):
     if c is None and dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
         raise RuntimeError('dropout inside a captured step needs a device-side step counter: construct FusedAdam(..., '
                            'model=model) before capturing (a frozen nonce alone would replay the same mask every step)')
-    nonce = int(torch.randint(0, 0x7fffffff, (1,)).item())
-    return nonce, (c.data_ptr() if c is not None else None)
+    return _nonce(), (c.data_ptr() if c is not None else None)
 
 
 class TableGrad:
@@ -494,18 +520,38 @@ def permute_and_pick(x, perm, inv, picks, dyn_n=None, dyn_b=None):
 
 # ------------------------------------------------------------------------------------------ deferred slab sums
 # Several backward nodes end in "out = sum over R partial slabs" kernels whose results only the optimizer reads (weight
-# gradients of the row-split GEMMs, the GRU bias gradients).  Each is a ~5 us kernel node of the captured step whatever its
-# size.  With DEFER['on'] (set by a model whose parameters each feed exactly ONE backward node, so autograd never adds to
-# these tensors before they are complete) a node registers (slabs, out) here instead of launching, and ONE launch at the end
-# of the backward pass (autograd's queue_callback) - or at the latest when the optimizer collects the gradients - sums them
-# all: the gradients are complete when backward() returns, as before.
+# gradients of the row-split GEMMs).  Each is a ~5 us kernel node of the captured step whatever its size.  A node may
+# register (slabs, out) here instead of launching, and ONE launch at the end of the backward pass (autograd's
+# queue_callback) sums them all: the gradients are complete when backward() returns, as before.
+# Deferring hands autograd a gradient tensor that is not written yet, which is only safe when AccumulateGrad takes the
+# buffer over as it is: the target parameter has no gradient yet (otherwise `p.grad += out` would read the unwritten
+# buffer: a second backward before a step, zero_grad(set_to_none=False)) and no hook that reads it.  So the permission is
+# scoped twice: a model switches DEFER['on'] for the duration of ITS training forward (every parameter of it feeds exactly
+# one backward node per layer / order), the forward of a node snapshots it (ctx.defer = defer_scope()), and the backward
+# asks can_defer(ctx.defer, params) when it gets there - anything else launches the sum on the spot.
 DEFER = {'on': False}
 _DEFERRED = []
 
 
-def defer_slab_sum(part, out):
-    """out [n] (any shape, contiguous) = sum over the leading dimension of part [R, n...]: now, or deferred"""
-    if not DEFER['on']:
+def defer_scope():
+    """snapshot for an autograd node's forward: may its backward defer its slab sums at all?"""
+    return bool(DEFER['on'])
+
+
+def can_defer(flag, params):
+    """backward-time check: every target parameter still without a gradient and without tensor hooks"""
+    if not flag:
+        return False
+    for q in params:
+        if q.grad is not None or getattr(q, '_backward_hooks', None) or getattr(q, '_post_accumulate_grad_hooks', None):
+            return False
+    return True
+
+
+def defer_slab_sum(part, out, ok=True):
+    """out [n] (any shape, contiguous) = sum over the leading dimension of part [R, n...]: now, or (ok) deferred to the
+    end of the running backward pass"""
+    if not ok:
         _launch_slab_sums([(part, out)])
         return
     if not _DEFERRED:
@@ -530,7 +576,6 @@ def _launch_slab_sums(tasks):
 
 
 def flush_deferred():
-    DEFER['on'] = False                             # the next training forward of a single-use model switches it on again
     if _DEFERRED:
         tasks = list(_DEFERRED)
         _DEFERRED.clear()
@@ -1748,6 +1793,7 @@ class GRUExpandAll(torch.autograd.Function):
         ctx.tags = [_arena_tag(a) for a in args[:P]]        # pieces of a split tensor: their gradients go into its buffer
         xs = [a.contiguous() for a in args[:P]]
         params = args[P:]
+        ctx.defer, ctx.wparams = defer_scope(), [params[4 * p + j] for p in range(P) for j in (0, 2)]
         Wih, bih, Whh, bhh = ([params[4 * p + j].contiguous() for p in range(P)] for j in range(4))
         d = xs[0].shape[1]
         d3, dev, st = 3 * d, xs[0].device, stream()
@@ -1911,8 +1957,9 @@ class GRUExpandAll(torch.autograd.Function):
         # the weight-gradient slab sums join the ONE end-of-backward launch (defer_slab_sum); the bias partials keep their own
         # kernel: hundreds of partial rows of only 6 d columns - as a task of the generic slab sum (one thread per 4 columns
         # walking all rows) they made that launch 44 us (profiles/r03d), gru_bias_final splits the rows over 16 lanes: 5 us
+        ok = can_defer(ctx.defer, ctx.wparams)
         for sl, o_ in slabs:
-            defer_slab_sum(sl, o_)
+            defer_slab_sum(sl, o_, ok)
         arr = _ct.c_void_p * P
         a_p, a_o = arr(*[t_.data_ptr() for t_ in part]), arr(*[t_.data_ptr() for t_ in gb])
         a_r = (_ct.c_int * P)(*[t_.shape[0] for t_ in part])
@@ -2547,6 +2594,7 @@ class HGATLayer(torch.autograd.Function):
         lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
         ctx.save_for_backward(x, small, arg, *P, *params)
         ctx.plan, ctx.lay, ctx.grouped, ctx.dstate, ctx.g16 = plan, lay, grouped, dstate, g16
+        ctx.defer, ctx.wparams = defer_scope(), [params[4 * m] for m in range(len(plan.modules))]
         return out
 
     @staticmethod
@@ -2659,7 +2707,7 @@ class HGATLayer(torch.autograd.Function):
                     probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t, 0, wsplit))
             for i in range(0, len(probs), 16):
                 gemm16('tn', probs[i:i + 16], HD, D, D, variant=int(os.environ.get('SREC_WGRAD_VAR', '0')))
-            if multi and DEFER['on']:
+            if multi and can_defer(ctx.defer, [ctx.wparams[m] for m in multi]):
                 for i, m in enumerate(multi):
                     defer_slab_sum(slabs[m], gWm[i])
             elif multi:

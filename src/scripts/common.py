@@ -195,7 +195,8 @@ def run(model_name):
         RankSlice = import_module('sessionrec-pytorch_amd.dataset').RankSliceBatchSampler
         base = (RandomSampler(train_set, generator=th.Generator().manual_seed(123)) if shuffled
                 else SequentialSampler(train_set))
-        slices = RankSlice(base, args.batch_size, rank, world)
+        slices = RankSlice(base, args.batch_size, rank, world, prefix_len=train_set.index[:, 1],
+                           need_len=(args.order + 1) if model_name == 'MSGIFSR' else None)
         train_loader = ring(slices) or DataLoader(train_set, batch_sampler=slices, num_workers=args.num_workers,
                                                   collate_fn=train_collate_fn, pin_memory=pin, persistent_workers=pw)
         # evaluation: every rank scores the same sessions against its rows (order does not enter the metrics)
@@ -209,8 +210,11 @@ def run(model_name):
         test_loader = None
     else:
         from torch.utils.data import BatchSampler, RandomSampler
-        train_loader = (ring(BatchSampler(RandomSampler(train_set), args.batch_size, drop_last=False)) or
-                        DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
+        # (the shuffle has its own seeded generator: the batch order of a run does not depend on what else draws from
+        #  torch's global stream)
+        shuffle = RandomSampler(train_set, generator=th.Generator().manual_seed(123))
+        train_loader = (ring(BatchSampler(shuffle, args.batch_size, drop_last=False)) or
+                        DataLoader(train_set, batch_size=args.batch_size, sampler=shuffle, num_workers=args.num_workers,
                                    collate_fn=train_collate_fn, pin_memory=pin, persistent_workers=pw))
         test_loader = None
     if test_loader is None:
@@ -231,6 +235,9 @@ def run(model_name):
     mrr, hit = runner.train(args.epochs, args.log_interval)
     if runner.graph_steps:
         print(f'training steps: {runner.graph_steps} hipGraph replays, {runner.eager_steps} eager')
+    if sharded and getattr(slices, 'short_batches', 0):
+        print(f'note: {slices.short_batches} global batches had no session of {slices.need_len} clicks - on those the row-sharded '
+              'step keeps the residual / bias of relations without edges (single-device skips them: dataset.RankSliceBatchSampler)')
     print('MRR@20\tHR@20')
     print(f'{mrr * 100:.3f}%\t{hit * 100:.3f}%')
     if sharded:

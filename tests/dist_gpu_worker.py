@@ -64,7 +64,7 @@ def make_case(case):
             samples = long_ + short
     else:                                              # 'synth': MSGIFSR at a synthetic shape (C3: V 37484, d 256, order 3)
         V, d, K = case['V'], case['d'], case['order']
-        samples = synth_samples(case['B'], V, 123, max_len=case.get('max_len', 20))
+        samples = synth_samples(case['B'], V, 123, max_len=case.get('max_len', 20), mean_len=case.get('mean_len', 6.2))
         name = 'msgifsr'
 
         def build():
@@ -76,6 +76,46 @@ def make_case(case):
             return col.collate_fn_factory(col.seq_to_session_graph, caps=caps)
         return col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), K, caps=caps)
     return build, collate, samples, V
+
+
+def touched_items(samples):
+    """every item id the global batch reads or predicts (table rows whose gradient has a lookup / label part)"""
+    t = set()
+    for seq, lab in samples:
+        t.update(int(i) for i in seq)
+        if lab >= 0:
+            t.add(int(lab))
+    return torch.tensor(sorted(t), dtype=torch.int64)
+
+
+def digest_rows(n, lo, touched):
+    """rows of a shard [lo, lo + n) whose full contents are compared in the big (C5) cases: a stride sample of ~4096 rows
+    plus every touched row of the shard (local indices)"""
+    tl = touched[(touched >= lo) & (touched < lo + n)] - lo
+    return torch.unique(torch.cat([torch.arange(0, n, max(1, n // 4096)), tl]))
+
+
+def digest(mat, idx):
+    """what leaves the process for a [n, d] matrix too large to be saved whole (C5: 1.25 M x 256 per rank, 10 M x 256 on
+    the single device): float64 row sums and row norms of EVERY row + the full rows `idx`"""
+    n = mat.shape[0]
+    rs = torch.empty(n, dtype=torch.float64, device=mat.device)
+    rn = torch.empty(n, dtype=torch.float64, device=mat.device)
+    for c in range(0, n, 1 << 20):
+        blk = mat[c:c + (1 << 20)].double()
+        rs[c:c + (1 << 20)] = blk.sum(1)
+        rn[c:c + (1 << 20)] = blk.norm(dim=1)
+    return dict(rowsum=rs.cpu(), rownorm=rn.cpu(), idx=idx.cpu(), rows=mat[idx.to(mat.device)].detach().cpu().clone())
+
+
+def build_on(build, dev, big):
+    """big: parameters are created ON the device (a 10 M x 256 table is 10 GB: no host copy per rank process); the seeded
+    draws then come from the device generator - the same in every process on the same GPU"""
+    if big:
+        with torch.device(dev):
+            model = build()
+        return model.to(dev)
+    return build().to(dev)
 
 
 def rank_slice(samples, world, rank, partial):
@@ -108,16 +148,22 @@ def run_rank(rank, world, port, case, outdir):
         partial = bool(case.get('partial'))
         mine, n = rank_slice(samples, world, rank, partial)
         caps = None
+        big = bool(case.get('big'))
+        touched = touched_items(samples) if big else None
         if case.get('padded'):
             caps = pkg('collate').default_caps(n, case.get('max_len', 20))
         elif len(mine) < n:                            # exact layouts: filler sessions with label -1 (RankSliceBatchSampler)
             mine = mine + [(mine[0][0], -1)] * (n - len(mine))
         inputs, labels = collate(caps)(mine)
         inputs, labels = [x.to(dev) for x in inputs], labels.to(dev)
-        model = build().to(dev)
+        model = build_on(build, dev, big)
         group = D.RecordingGroup() if case.get('record') else None
         idx_cap = inputs[0].cap('uniq_items') if caps is not None else None
         vp = D.VocabParallel(model, group=group, idx_cap=idx_cap)
+        if big:
+            torch.cuda.empty_cache()                   # (the full table this rank was cut from: 10 GB per process)
+            rows = digest_rows(vp.n_live, vp.lo, touched)
+        keep = (lambda m: digest(m, rows)) if big else (lambda m: m.detach().cpu().clone())
         opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
         replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
         names = {id(p): k for k, p in model.named_parameters()}
@@ -140,10 +186,10 @@ def run_rank(rank, world, port, case, outdir):
             rec = dict(loss=lval, local_none=local_none, collectives=dict(D.STATS))
             if step == 0:
                 tg = model.table_grad                  # (materialises a projection left to the optimizer)
-                rec['dE'] = tg.buf[:vp.n_live].detach().cpu().clone()
+                rec['dE'] = keep(tg.buf[:vp.n_live])
                 rec['grads'] = {names[i]: g.detach().cpu().clone() for i, g in (opt.grad_override or {}).items()}
             opt.step()
-            rec['table'] = model._table().detach()[:vp.n_live].cpu().clone()
+            rec['table'] = keep(model._table().detach()[:vp.n_live])
             rec['params'] = {k: p.detach().cpu().clone() for k, p in model.named_parameters() if p is not model._table()}
             if group is not None:
                 rec['tape'] = list(group.tape)

@@ -456,3 +456,68 @@ def test_pinned_ring_loader_yields_the_dataloader_batches(sliced):
         assert not sliced or int(ref[-1][1][0]) == -1                  # (the filler sample of the last slice)
     finally:
         ld.close()
+
+
+def test_pinned_ring_loader_survives_an_abandoned_iteration():
+    """an iteration left early (break in the consumer) leaves tasks with the workers; the next iteration must start from
+    batch 0 with its OWN results (generation tag + drain), not with leftovers of the abandoned one"""
+    from torch.utils.data import BatchSampler, DataLoader, SequentialSampler
+    C, L, DS = pkg('collate'), pkg('loader'), pkg('dataset')
+    if C._native() is None:
+        pytest.skip('libsrec_collate.so not built')
+    rng = np.random.RandomState(9)
+    ds = DS.AugmentedDataset([rng.randint(1, 300, size=rng.randint(2, 12)).tolist() for _ in range(120)])
+    bs = 16
+    caps = C.default_caps(bs, 12)
+    sampler = BatchSampler(SequentialSampler(ds), bs, drop_last=False)
+    ref = list(DataLoader(ds, batch_sampler=sampler, collate_fn=C.collate_fn_factory_ccs((C.seq_to_ccs_graph,), 2, caps)))
+    ld = L.PinnedRingLoader(ds, sampler, 'ccs', order=2, caps=caps, num_workers=2, slots=6)
+    try:
+        for stop in (3, 1, 0):
+            for k, (inp, lab) in enumerate(ld):
+                assert torch.equal(lab, ref[k][1]) and torch.equal(inp[0].buf, ref[k][0][0].buf), (stop, k)
+                if k == stop:
+                    break                                              # tasks for batches k+1.. are already with the workers
+        n = 0
+        for (inp, lab), (rinp, rlab) in zip(ld, ref):
+            assert torch.equal(lab, rlab) and torch.equal(inp[0].buf, rinp[0].buf), n
+            n += 1
+        assert n == len(ref) and ld._owed == 0
+    finally:
+        ld.close()
+
+
+def test_seeded_init_equals_the_oracle():
+    """the product's constructors draw from torch's RNG in the oracle's order: the same seed gives the same initial weights
+    (what tests/test_trained_metrics_gpu.py and the launcher comparison with tests/golden/trained_metrics.json rely on)"""
+    from oracle import models_ref as om
+    sp = pkg()
+    V = 500
+    for mk_o, mk_p in [(lambda: om.MSGIFSR(V, 'x', 64, 1, order=2, extra=False, fusion=False),
+                        lambda: sp.MSGIFSR(V, 'x', 64, 1, order=2, extra=False, fusion=False)),
+                       (lambda: om.MSGIFSR(V, 'x', 32, 1, order=3, extra=True, fusion=True),
+                        lambda: sp.MSGIFSR(V, 'x', 32, 1, order=3, extra=True, fusion=True)),
+                       (lambda: om.SRGNN(V, 64, 2), lambda: sp.SRGNN(V, 64, 2)),
+                       (lambda: om.NISER(V, 64, 2), lambda: sp.NISER(V, 64, 2)),
+                       (lambda: om.LESSR(V, 32, 3), lambda: sp.LESSR(V, 32, 3))]:
+        torch.manual_seed(123)
+        a = mk_o().state_dict()
+        torch.manual_seed(123)
+        b = mk_p().state_dict()
+        assert list(a) == list(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_rank_slice_sampler_counts_batches_without_a_long_session():
+    """dataset.RankSliceBatchSampler(prefix_len, need_len): global batches in which no session reaches order + 1 clicks (the
+    multi-rank path's "every relation is live" assumption, msgifsr.MSHGNN.plan) are counted for the launcher's note"""
+    DS = pkg('dataset')
+    from torch.utils.data import SequentialSampler
+    sessions = [[1, 2, 3, 4, 5]] * 3 + [[7, 8]] * 9
+    ds = DS.AugmentedDataset(sessions)
+    s = DS.RankSliceBatchSampler(SequentialSampler(ds), 4, 0, 2, prefix_len=ds.index[:, 1], need_len=4)
+    out = list(s)
+    assert len(out) == len(s) == (len(ds) + 3) // 4
+    # samples 0..11 are the prefixes of the three long sessions (one of 4 clicks in every batch of four), the rest 1-click
+    assert s.short_batches == len(out) - 3

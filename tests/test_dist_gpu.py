@@ -14,7 +14,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from dist_gpu_worker import live_samples, make_case, rank_slice, run_rank
+from dist_gpu_worker import build_on, digest, digest_rows, live_samples, make_case, rank_slice, run_rank, touched_items
 from test_models_gpu import adam_close
 from util import close, pkg
 
@@ -36,7 +36,7 @@ def _launch(world, case, tmp_path):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=600)
+        p.join(timeout=1500)
     codes = [p.exitcode for p in procs]
     for p in procs:
         if p.is_alive():
@@ -163,6 +163,175 @@ def test_sharded_ranks_at_the_benchmarked_shape(dev, tmp_path, precision, world)
         pkg('ops').set_precision('fp32')
 
 
+# ---- config C5 (BASELINE.json configs[4]): synthetic 10 M-item catalog, sessions of <= 50 clicks, d = 256, 8 row shards.
+#      Neither a rank's 1.25 M x 256 rows nor the single device's 10 M x 256 (2.56 G elements: 64-bit offsets) travel whole;
+#      every matrix is compared through float64 row sums + row norms of ALL rows and the full contents of a stride sample of
+#      ~4096 rows + every row the batch touches (dist_gpu_worker.digest).
+def _plain_big(case, world, dev, steps):
+    D, ops, train, optim = pkg('dist'), pkg('ops'), pkg('train'), pkg('optim')
+    ops.set_precision(case.get('precision', 'fp32'))
+    build, collate, samples, V = make_case(case)
+    live = live_samples(samples, world, False)
+    touched = touched_items(samples)
+    inputs, labels = collate(None)(live)
+    inputs, labels = [x.to(dev) for x in inputs], labels.to(dev)
+    model = build_on(build, dev, True)
+    opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
+    model.train()
+
+    def per_shard(mat):
+        out = []
+        for r in range(world):
+            lo, hi, _ = D.shard_bounds(V, world, r)
+            out.append(digest(mat[lo:hi], digest_rows(hi - lo, lo, touched)))
+        return out
+    recs = []
+    for step in range(steps):
+        opt.zero_grad()
+        loss = model.fused_loss(*inputs, labels)
+        loss.backward()
+        rec = dict(loss=float(loss.item()))
+        if step == 0:
+            rec['dE'] = per_shard(model.table_grad.buf)
+            rec['grads'] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()
+                            if p.grad is not None and p is not model._table()}
+        opt.step()
+        rec['table'] = per_shard(model._table().detach())
+        rec['params'] = {k: p.detach().cpu().clone() for k, p in model.named_parameters() if p is not model._table()}
+        recs.append(rec)
+    model.eval()
+    v, i = model.topk(*inputs, k=20)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    return recs, dict(topk=(v.cpu(), i.cpu())), live, peak
+
+
+def _vec_close(a, b, tol, what):
+    rel = float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+    assert rel <= tol, '%s: norm-wise relative error %.3e > %.1e' % (what, rel, tol)
+
+
+def _compare_big(case, world, res, ref, extra, bf16):
+    samples = make_case(case)[2]
+    tol = 2e-3 if bf16 else 1e-5                          # norm-wise, whole vectors / row blocks
+    off = 0
+    for r, out in enumerate(res):
+        s0, r0 = out['steps'][0], ref[0]
+        assert abs(s0['loss'] - r0['loss']) <= (5e-4 if bf16 else 1e-5) * max(1.0, abs(r0['loss'])), (r, s0['loss'], r0['loss'])
+        a, b = s0['dE'], r0['dE'][r]
+        assert torch.equal(a['idx'], b['idx']) and a['rows'].shape[0] > 4000
+        _vec_close(a['rowsum'], b['rowsum'], tol * 5, 'rank %d: row sums of the table gradient (all %d rows)' % (r, len(a['rowsum'])))
+        _vec_close(a['rownorm'], b['rownorm'], tol, 'rank %d: row norms of the table gradient' % r)
+        if bf16:
+            _vec_close(a['rows'], b['rows'], tol, 'rank %d: sampled + touched rows of the table gradient' % r)
+        else:
+            close(a['rows'], b['rows'], rtol=1e-4, atol=1e-7, what='rank %d: sampled + touched rows of the table gradient' % r)
+        for k, g in r0['grads'].items():
+            assert k in s0['grads'], 'rank %d: replicated gradient %s missing from the bucket' % (r, k)
+            if bf16:
+                _vec_close(s0['grads'][k], g, 5e-3, 'rank %d: all-reduced gradient of %s' % (r, k))
+            else:
+                close(s0['grads'][k], g, rtol=1e-4, atol=1e-7, what='rank %d: all-reduced gradient of %s' % (r, k))
+        for si, (s, rr) in enumerate(zip(out['steps'], ref)):
+            assert abs(s['loss'] - rr['loss']) <= (5e-4 if bf16 else 4e-5) * max(1.0, abs(rr['loss'])), (r, si, s['loss'], rr['loss'])
+            ta, tb = s['table'], rr['table'][r]
+            if bf16:
+                # Adam's first steps move every element by ~lr whatever its gradient: bf16 round-off in a near-zero gradient
+                # component flips its sign - bounded movement, and the rows' norms barely change
+                assert float((ta['rows'] - tb['rows']).abs().max()) <= 2.2e-3 * (si + 1)
+                _vec_close(ta['rownorm'], tb['rownorm'], 1e-3, 'rank %d step %d: row norms of the table' % (r, si))
+            else:
+                adam_close(ta['rows'], tb['rows'], steps=si + 1, what='rank %d step %d: sampled + touched table rows' % (r, si))
+                _vec_close(ta['rownorm'], tb['rownorm'], 1e-5, 'rank %d step %d: row norms of the table' % (r, si))
+                for k, p in rr['params'].items():
+                    adam_close(s['params'][k], p, steps=si + 1, what='rank %d step %d: %s' % (r, si, k))
+        n_live = len(rank_slice(samples, world, r, False)[0])
+        v, i = out['topk']
+        rv, ri = extra['topk']
+        hits = sum(len(set(i[b].tolist()) & set(ri[off + b].tolist())) for b in range(n_live)) / (20.0 * n_live)
+        assert hits >= (0.97 if bf16 else 0.995), 'rank %d: top-20 sets overlap %.4f' % (r, hits)
+        if not bf16:
+            close(v[:n_live], rv[off:off + n_live], rtol=1e-5, atol=1e-5, what='rank %d: top-20 scores' % r)
+        off += n_live
+
+
+C5 = dict(kind='synth', d=256, order=3, B=512, max_len=50, mean_len=14.0, padded=True, big=True)
+
+
+@pytest.mark.parametrize('precision,world,V,steps', [('bf16', 8, 10_000_000, 1), ('fp32', 2, 1_000_000, 2)])
+def test_sharded_ranks_at_the_c5_shape(dev, tmp_path, precision, world, V, steps):
+    """config C5 on the one GPU: 8 rank processes x 1.25 M rows (bf16, the benchmarked arithmetic) against the single-device
+    step over all 10 M rows - 2.56 G table elements, i.e. every kernel that walks the table runs past 32-bit element
+    offsets (lookup over 10 M ids, adam_rows, renorm + bf16 copy, flash-CE, top-k) - and a 2-shard fp32 run at 1 M rows
+    with the tight tolerances.  /root/reference/src/utils/train.py:94-101, src/models/msgifsr.py:276-321."""
+    case = dict(C5, V=V, precision=precision, steps=steps)
+    smp = make_case(case)[2]
+    assert max(len(s) for s, _ in smp) >= 40              # the batch really holds long sessions
+    try:
+        res = _launch(world, case, tmp_path)
+        ref, extra, live, peak = _plain_big(case, world, dev, steps)
+        _compare_big(case, world, res, ref, extra, bf16=(precision == 'bf16'))
+        print('single-device peak memory %.1f GiB' % peak)
+        # 7 collectives per step (+ the one-off agreement on the gradient-bucket layout in the first step)
+        counts = {out['steps'][-1]['collectives']['count'] for out in res}
+        assert counts == ({8} if steps == 1 else {7}), counts
+    finally:
+        pkg('ops').set_precision('fp32')
+        torch.cuda.empty_cache()
+
+
+def test_rank_5_of_the_c5_job_replayed_under_hipgraph_capture(dev, tmp_path):
+    """rank 5 of the 8-rank C5 job (rows [6.25 M, 7.5 M) of the 10 M-row table, bf16), re-run alone from the recorded
+    collective results: step 1 eagerly, step 2 captured + replayed - the launch mode of bench.py on an 8-GPU node."""
+    D, G, ops, train, optim = pkg('dist'), pkg('graph'), pkg('ops'), pkg('train'), pkg('optim')
+    world, rank = 8, 5
+    case = dict(C5, V=10_000_000, precision='bf16', steps=2, record=True)
+    try:
+        res = _launch(world, case, tmp_path)
+        job = res[rank]
+        ops.set_precision('bf16')
+        build, collate, samples, V = make_case(case)
+        mine, n = rank_slice(samples, world, rank, False)
+        caps = pkg('collate').default_caps(n, case['max_len'])
+        inputs, labels = collate(caps)(mine)
+        inputs, labels = [x.to(dev) for x in inputs], labels.to(dev)
+        model = build_on(build, dev, True)
+        group = D.ReplayGroup(world, rank, dev, rtol=2e-3, atol=1e-5).load(job['steps'][0]['tape'])
+        vp = D.VocabParallel(model, group=group, idx_cap=inputs[0].cap('uniq_items'))
+        torch.cuda.empty_cache()
+        assert (vp.lo, vp.hi) == (job['lo'], job['hi']) == (6_250_000, 7_500_000)
+        rows = job['steps'][0]['table']['idx'].to(dev)
+        opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
+        replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
+        model.train()
+        opt.zero_grad()
+        loss = model.fused_loss(*inputs, labels)
+        loss.backward()
+        vp.sync_replicated_grads(replicated, opt)
+        opt.step()
+        assert group.pos == len(group.kinds) and group.checked == len(group.kinds)
+        assert abs(loss.item() - job['steps'][0]['loss']) <= 1e-5 * max(1.0, abs(job['steps'][0]['loss']))
+        del loss
+        # same kernels on the same inputs as inside the job (up to the order in which 8 processes' atomics-free reductions
+        # ran: none): the rows agree to fp32 round-off
+        close(model._table().detach()[rows], job['steps'][0]['table']['rows'], rtol=1e-5, atol=1e-6, what='table rows after the eager step')
+        group.load(job['steps'][1]['tape'])
+        gs = G.GraphedTrainStep(model, opt, inputs, labels, after_backward=lambda: vp.sync_replicated_grads(replicated, opt),
+                                warmup=1)
+        loss2 = gs(inputs, labels)
+        torch.cuda.synchronize()
+        assert abs(loss2.item() - job['steps'][1]['loss']) <= 1e-5 * max(1.0, abs(job['steps'][1]['loss'])), \
+            (loss2.item(), job['steps'][1]['loss'])
+        close(model._table().detach()[rows], job['steps'][1]['table']['rows'], rtol=1e-5, atol=1e-6, what='table rows after the replayed step')
+        rn = model._table().detach()[:vp.n_live].double().norm(dim=1).cpu()
+        _vec_close(rn, job['steps'][1]['table']['rownorm'], 1e-6, 'row norms of all 1.25 M rows after the replayed step')
+        nodes = gs.node_counts()
+        if nodes is not None:
+            assert nodes['kernel'] > 10
+    finally:
+        ops.set_precision('fp32')
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('name,world,rank', [('msgifsr_K3_s32', 2, 1), ('msgifsr_K3_s32', 8, 5), ('niser_s32', 2, 1)])
 def test_one_rank_of_the_job_replayed_under_hipgraph_capture(dev, tmp_path, name, world, rank):
     """rank `rank` of a W-rank job, re-run alone from the recorded collective results: step 1 eagerly (every collective
@@ -211,3 +380,33 @@ def test_one_rank_of_the_job_replayed_under_hipgraph_capture(dev, tmp_path, name
     nodes = gs.node_counts()
     if nodes is not None:
         assert nodes['kernel'] > 10
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu(dev):
+    """`python bench.py --gpus 2` for real (not --launch-only): the launcher re-executes itself under torch.distributed.run
+    with two ranks, both on cuda:0, collectives over gloo staged through the host (SREC_BENCH_BACKEND=gloo) - the complete
+    N-rank line (`n_gpus`, `ranks_seen`, `collectives`, `scaling`, `config.global_batch`) is produced once before an 8-GPU
+    node ever runs it.  Host-staged collectives cannot be captured in a hipGraph, so this run also takes bench.py's
+    "capture of the collectives refused" branch: both ranks agree to fall back, and the EAGER steps with the 7 collectives
+    train to a finite loss."""
+    import json
+    import subprocess
+    import sys
+    from util import ROOT
+    env = dict(os.environ, SREC_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--repeats', '1', '--no-cpu-baseline'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['scaling'] == 'weak'
+    assert out['unit'] == 'sessions/s' and out['value'] > 0 and out['steps'] == 3
+    assert out['config']['global_batch'] == 1024 and 'row-sharded x2' in out['config']['parallelism']
+    c = out['collectives']
+    assert c['count'] == 7 and c['backend'] == 'gloo' and c['captured_in_graph'] is False and c['bytes'] > 0
+    assert out['launch'] == 'eager' and 'graph capture with the collectives failed' in p.stderr
+    assert 1.0 < out['config']['final_loss'] < 12.0          # ~ln V at the start of training
+    assert out['roofline']['frac'] > 0 and out['cpu_baseline'] is None and out['fp32'] is None

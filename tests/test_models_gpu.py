@@ -6,7 +6,7 @@ parameters after 3 Adam steps atol 2e-6 (lr 1e-3 => an update is ~1e-3)."""
 import pytest
 import torch
 
-from util import close, load_golden, pkg
+from util import close, load_golden, pkg, reseed
 
 pytestmark = pytest.mark.gpu
 
@@ -344,7 +344,7 @@ def test_mshgnn_layer_dropout_gradients_by_finite_differences(dev):
     params = [p.detach().clone().requires_grad_() for p in params]
 
     def f(x, ps):
-        torch.manual_seed(11)
+        reseed(11)
         # summed in float64: an fp32 sum of ~1 500 terms (|f| ~ 50, ulp 4e-6) quantises a central difference at 2e-3 steps
         return (ops.hgat_layer(x, plan, ps, (0.3, 0.3)).double() * R.double()).sum()
 
@@ -427,7 +427,7 @@ def test_hg_agg_wave_per_node_equals_the_workgroup_kernel(dev, case, monkeypatch
             monkeypatch.setenv('SREC_HG_AGG', mode)
             ps = [p.detach().clone().requires_grad_() for p in params]
             x = x0.clone().requires_grad_()
-            torch.manual_seed(11)
+            reseed(11)
             out = ops.hgat_layer(x, plan, ps, (0.3, 0.3))
             (out * R).sum().backward()
             res[mode] = [out.detach(), x.grad] + [p.grad for p in ps]
@@ -514,7 +514,7 @@ def test_msgifsr_dropout_path_matches_oracle_with_replayed_masks(dev, name):
 
     ops.DROP_TAP = []
     try:
-        torch.manual_seed(21)
+        reseed(21)
         loss = model.fused_loss(mg, labels)
         loss.backward()
         assert len(ops.DROP_TAP) == 1
@@ -698,7 +698,7 @@ def test_projection_fused_in_the_row_sharded_path(dev, name):
         pkg('ops').RNG_COUNTER.clear()
         out = []
         for it in range(3):
-            torch.manual_seed(100 + it)
+            reseed(100 + it)
             o.zero_grad()
             loss = m.fused_loss(*inputs, labels)
             loss.backward()
@@ -746,7 +746,7 @@ def test_projection_fused_into_the_optimizer_equals_the_separate_pass(dev, name,
         m.train()
         if graph:
             G = pkg('graph')
-            torch.manual_seed(5)
+            reseed(5)
             gs = G.GraphedTrainStep(m, o, inputs, labels)
             steps.append(lambda gs=gs: gs(inputs, labels).clone())
         else:
@@ -763,7 +763,7 @@ def test_projection_fused_into_the_optimizer_equals_the_separate_pass(dev, name,
         pkg('ops').RNG_COUNTER.clear()                  # of the optimizer registered on the device
         out = []
         for it in range(3):
-            torch.manual_seed(100 + it)
+            reseed(100 + it)
             out.append(st())
         runs.append(out)
     for it in range(3):

@@ -29,3 +29,11 @@ def close(a, b, rtol=1e-4, atol=1e-5, what=''):
     # element-wise rtol plus an absolute floor tied to the tensor's scale (fp32 accumulation-order noise)
     atol = max(atol, 2e-6 * ref)
     assert torch.allclose(a, b, rtol=rtol, atol=atol), '%s: max abs err %.3e (ref max %.3e)' % (what, err, ref)
+
+
+def reseed(seed):
+    """torch.manual_seed + a restart of the HIP path's dropout nonce stream (ops.seed_dropout: the nonces come from a
+    private generator so that they never advance torch's global stream; re-seeding with an EQUAL value is not observable
+    from there, a test that replays masks says so explicitly)"""
+    torch.manual_seed(seed)
+    pkg('ops').seed_dropout()

@@ -14,6 +14,7 @@ def main(precision):
     inp, lab = batches[0]
     inp, lab = [x.to(dev) for x in inp], lab.to(dev)
     torch.manual_seed(123)
+    importlib.import_module("sessionrec-pytorch_amd.ops").seed_dropout()   # (same seed value as the previous run: explicit restart)
     model = bench.build_model(sp, 'MSGIFSR', 37484, 256, 3).to(dev)
     model.train()
     res = []
