@@ -419,6 +419,15 @@ int srec_score_topk_ws(int B, int V, int K, long* bytes);
 int srec_score_topk(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, int B, int V, int d, int K,
                     float* out_val, int* out_idx, void* ws, void* stream);
 
+/* ---- fused read-out head (headf.hip): msgifsr.py:124-155 (AttnReadout.forward) + :269-273 (fc_sr, F.normalize) for all live
+ * orders in ONE launch, a group of SREC_HEAD_SESSIONS sessions per workgroup; replaces the {U, Vq} GEMM / srec_seg_attn_fwd /
+ * {s} GEMM / split-K sum / srec_normalize_fwd chain of the grouped head in bf16 mode (d = 128 / 256).  desc: HOST
+ * srec_head_desc (srec_hg.h).  srec_head_wfrag: n <= SREC_HEAD_MAXW fp32 matrices W_i [rows_i, cols_i] (HOST arrays of
+ * device pointers / ints) -> hi / lo fragment-major bf16 operand copies dst_i [2 rows_i cols_i] of W_i (trans_i = 0) or W_i^T
+ * (trans_i = 1), once per optimizer step. */
+int srec_head_wfrag(int n, const void* W, const void* dst, const int* rows, const int* cols, const int* trans, void* stream);
+int srec_head_fwd(const void* desc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

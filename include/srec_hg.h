@@ -209,4 +209,41 @@ typedef struct {
     int part_row0[SREC_GRU_MAXP];
 } srec_gru_fused_bwd_desc;
 
+/* ---- fused read-out head (csrc/headf.hip): AttnReadout + fc_sr + F.normalize of MSGIFSR for a group of sessions per
+ * workgroup (/root/reference/src/models/msgifsr.py:124-155 AttnReadout.forward, :269-273 fc_sr / normalize), up to
+ * SREC_HEAD_MAXH live orders ("heads") per launch, d = hidden = output = 128 or 256, bf16 mode (3-term hi / lo split products:
+ * fp32-grade results).  Per head h:
+ *   cat[h]   [B, 2 d] fp32: left half = the query rows v_b (in), right half = the read-out rows g_b (out)
+ *   Wu_f / Wv_f / Wsr_f: hi / lo fragment-major copies of fc_u [d, d], fc_v [d, d], fc_sr [d, 2 d] (srec_head_wfrag, trans = 0)
+ *   bu (nullable) [d], we [d]: fc_u bias, fc_e weight
+ *   alpha [NT] soft-max weights (out), U (nullable) [NT, d] = x Wu^T + bu (out, only for the grouped backward),
+ *   Vq (nullable) [B, d] (out), y [B, d] = normalised session vectors (out), inv [B] = 1 / max(|s|, eps) resp. 1 / (|s| + eps)
+ *   (out), y16 (nullable) [B, ld16] bf16 copy of y (the scoring kernels' operand)
+ * X = allf [NT, d] (row stride ld_x; NT = row capacity), seg [B + 1] = first row of every session (seg[live B] = live rows),
+ * dynB (nullable) = live sessions; sessions past it get zero rows.  A workgroup owns the sessions that START in its window of
+ * SREC_HEAD_ROWS rows, SREC_HEAD_SESSIONS of them per pass.  A session may have at most SREC_MAX_SESSION_NODES rows (srec_limits). */
+#define SREC_HEAD_SESSIONS 16
+#define SREC_HEAD_ROWS 64
+#define SREC_HEAD_MAXH 4
+#define SREC_HEAD_MAXW 16
+typedef struct {
+    int nh, d, B, NT, ld_x, ld16, eps_mode;
+    float eps;
+    const float* X;
+    const int* seg;
+    const int* dynB;
+    float* cat[SREC_HEAD_MAXH];
+    const void* Wu_f[SREC_HEAD_MAXH];
+    const void* Wv_f[SREC_HEAD_MAXH];
+    const void* Wsr_f[SREC_HEAD_MAXH];
+    const float* bu[SREC_HEAD_MAXH];
+    const float* we[SREC_HEAD_MAXH];
+    float* alpha[SREC_HEAD_MAXH];
+    float* U[SREC_HEAD_MAXH];
+    float* Vq[SREC_HEAD_MAXH];
+    float* y[SREC_HEAD_MAXH];
+    float* inv[SREC_HEAD_MAXH];
+    void* y16[SREC_HEAD_MAXH];
+} srec_head_desc;
+
 #endif

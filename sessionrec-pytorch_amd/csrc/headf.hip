@@ -4,8 +4,10 @@
 //     g_b = sum_i alpha_i x_i;  s_b = [v_b | g_b] Wsr^T;  y_b = s_b / max(|s_b|, eps)   (+ the bf16 operand copy of y for the
 //     scoring kernels)
 // As grouped batch-wide launches (ops.ReadoutHead: {U, Vq} GEMM, read-out kernel, {s} GEMM, split-K sum, normalise) these are
-// five latency-bound kernel nodes of ~50 us for 0.9 GFLOP.  Here a workgroup OWNS HS = 8 consecutive sessions - their rows
-// of the per-session concatenation `allf` are contiguous - and runs the whole chain on them:
+// five latency-bound kernel nodes of ~50 us for 0.9 GFLOP.  Here a workgroup OWNS the sessions that start in its window of
+// HR = 64 rows of the per-session concatenation `allf` (work is dealt by ROWS: 8 consecutive sessions of the bench batch hold
+// 20 - 300 rows, and with one round of workgroups the launch is as long as its longest one) - a session's rows are
+// contiguous - and runs the whole chain on them, HS = 16 sessions per pass:
 //   * every product is computed TRANSPOSED on the bf16 matrix pipe, D^T = W . X^T with v_mfma_f32_32x32x16_bf16: the A
 //     operand is a 32-column block of the weight, the B operand 32 rows of activations, so the result puts a ROW in the lane
 //     and 16 hidden columns in its registers: the per-row reductions that follow (we . sigmoid(.), |s|^2) are sums over a
@@ -28,7 +30,8 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int HS = SREC_HEAD_SESSIONS;   // sessions per workgroup
+constexpr int HS = SREC_HEAD_SESSIONS;   // sessions per pass of a workgroup (MFMA columns of the B x d products)
+constexpr int HR = SREC_HEAD_ROWS;       // rows of the per-session concatenation per workgroup window / per chunk (2 MFMA tiles)
 constexpr int NW = 4;                    // waves per workgroup: wave w owns the hidden / output columns [w d/4, (w+1) d/4)
 constexpr int NS = 4, PF = NS - 1;       // register ring of weight fragments: stages, k-steps in flight
 constexpr int MAXN = SREC_MAX_SESSION_NODES;
@@ -37,6 +40,15 @@ constexpr int VQ_PAD = 8;                // floats of padding per Vq row in LDS:
 struct HeadArgs {
     srec_head_desc d;
 };
+
+#ifdef SREC_HEADF_TIMING   // development probe (tools/headf_timing.py): phase clocks of wave 0 of every workgroup, workgroup lives
+__device__ unsigned long long g_headf_tim[1024][8];
+__device__ unsigned long long g_headf_blk[1024][2];
+#define HFT(i) do { __builtin_amdgcn_sched_barrier(0); tim_t[i] += __builtin_readcyclecounter() - tim_c; \
+    tim_c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HFT(i)
+#endif
 
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     hi = srec_pack_bf16(a, b);
@@ -59,82 +71,87 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
     constexpr int D = 128 * DD, JB = D / (32 * NW), KS = D / 16, NF = 2 * JB;     // NF: fragments per (wave, k-step): hi | lo
     constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
-    unsigned short* x_hi = sm;                               // [32][D]   node-row chunk
-    unsigned short* x_lo = x_hi + 32 * D;
-    unsigned short* c_hi = x_lo + 32 * D;                    // [HS][2 D] [v | g] of the group's sessions
+    unsigned short* x_hi = sm;                               // [HR][D]   node-row chunk (two 32-row MFMA tiles)
+    unsigned short* x_lo = x_hi + HR * D;
+    unsigned short* c_hi = x_lo + HR * D;                    // [HS][2 D] [v | g] of the pass's sessions
     unsigned short* c_lo = c_hi + HS * 2 * D;
     float* vq = reinterpret_cast<float*>(c_lo + HS * 2 * D); // [HS][D + VQ_PAD]
-    float* e = vq + HS * (D + VQ_PAD);                       // [HS * MAXN] logits, then soft-max weights, of the group's rows
-    float* epart = e + HS * MAXN;                            // [NW][32]
-    int* segs = reinterpret_cast<int*>(epart + NW * 32);     // [HS + 1] first row of each session (+ end), relative to r0
-    int* rsess = segs + HS + 1;                              // [32] session (0 .. HS-1) of each row of the chunk
+    float* bw = vq + HS * (D + VQ_PAD);                      // [2][D] fc_u bias | fc_e weight
+    float* e = bw + 2 * D;                                   // [HR + MAXN] logits, then soft-max weights, of the pass's rows
+    float* epart = e + HR + MAXN;                            // [NW][HR]
+    int* segs = reinterpret_cast<int*>(epart + NW * HR);     // [HS + 1] first row of each session (+ end), relative to r0
+    int* rsess = segs + HS + 1;                              // [HR] session (0 .. HS-1) of each row of the chunk
+    int* cnt = rsess + HR;                                   // [2] sessions that start before / inside this row window
+    int* segl = cnt + 2;                                     // [B + 1] copy of seg[]
 
     const srec_head_desc& q = a.d;
     const int hd = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b0 = blockIdx.x * HS;
     const int Bl = dyn_count(q.dynB, q.B);
-    const int ns = max(0, min(HS, Bl - b0));                 // live sessions of this group
     float* cat = q.cat[hd];
     float* Y = q.y[hd];
     unsigned short* Y16 = (unsigned short*)q.y16[hd];
     const int ld16 = q.ld16;
 
-    if (ns < HS) {
-        // capacity padding: zero rows where the grouped path writes zeros (read-out half of cat, y, 1/|s|, the bf16 operand)
-        for (int i = tid; i < (HS - ns) * (D / 4); i += NT) {
-            const int b = b0 + ns + i / (D / 4), c = (i % (D / 4)) * 4;
-            if (b < q.B) {
-                *reinterpret_cast<float4*>(cat + (size_t)b * 2 * D + D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(Y + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (Y16 != nullptr) *reinterpret_cast<uint2*>(Y16 + (size_t)b * ld16 + c) = make_uint2(0u, 0u);
-                if (q.Vq[hd] != nullptr) *reinterpret_cast<float4*>(q.Vq[hd] + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+    // this workgroup owns the sessions whose FIRST row lies in its window of HR rows of the per-session concatenation: work
+    // is dealt by rows, not by sessions (a group of 8 sessions has 20 - 300 rows in the bench batch).  One pass over seg[]
+    // (every thread a few entries, kept in LDS for the rest of the kernel) counts the sessions that start before / inside it
+    const int w0 = (int)blockIdx.x * HR, w1 = w0 + HR;
+#ifdef SREC_HEADF_TIMING
+    unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_c = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_headf_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    {
+        int c0 = 0, c1 = 0;
+        for (int b = tid; b <= Bl; b += NT) {
+            const int sb = q.seg[b];
+            segl[b] = sb;
+            c0 += (b < Bl && sb < w0) ? 1 : 0;
+            c1 += (b < Bl && sb < w1) ? 1 : 0;
         }
-        for (int i = tid; i < HS - ns; i += NT)
-            if (b0 + ns + i < q.B) q.inv[hd][b0 + ns + i] = 0.f;
-        if (ns == 0) return;
+        for (int c = tid; c < D; c += NT) {
+            bw[c] = q.bu[hd] != nullptr ? q.bu[hd][c] : 0.f;
+            bw[D + c] = q.we[hd][c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); }
+        if (lane == 0) { atomicAdd(&cnt[0], c0); atomicAdd(&cnt[1], c1); }
     }
-    const int r0 = q.seg[b0];
-    if (tid <= HS) segs[tid] = q.seg[b0 + min(tid, ns)] - r0;
-    const int nrows = q.seg[b0 + ns] - r0;
-
+    // capacity padding (sessions past the live count): zero rows where the grouped path writes zeros - the read-out half of
+    // cat, y, 1 / |s|, Vq, the bf16 operand; shared by all workgroups
+    for (int b = Bl + (int)blockIdx.x; b < q.B; b += (int)gridDim.x) {
+        for (int c = tid * 4; c < D; c += NT * 4) {
+            *reinterpret_cast<float4*>(cat + (size_t)b * 2 * D + D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Y + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (Y16 != nullptr) *reinterpret_cast<uint2*>(Y16 + (size_t)b * ld16 + c) = make_uint2(0u, 0u);
+            if (q.Vq[hd] != nullptr) *reinterpret_cast<float4*>(q.Vq[hd] + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid == 0) q.inv[hd][b] = 0.f;
+    }
+    __syncthreads();
+    if (Bl <= 0 || w0 >= segl[Bl]) return;
+    const int bfirst = cnt[0], bend = cnt[1];
     const int cbase = wave * 32 * JB;
     const float* X = q.X;
     const int ld_x = q.ld_x;
+    float* Uout = q.U[hd];
+    auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); };
 
-    // ---- the group's query rows v_b (left half of cat) into the [v | g] tile
-    for (int i = tid; i < HS * (D / 4); i += NT) {
-        const int row = i / (D / 4), c = (i % (D / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < ns) v = *reinterpret_cast<const float4*>(cat + (size_t)(b0 + row) * 2 * D + c);
-        stage4(c_hi, c_lo, 2 * D, row, c, v);
-    }
-    // first chunk of node rows: in flight under the Vq product
-    constexpr int XV = 32 * D / 4 / NT;
-    float4 xv[XV];
-    auto fetch_x = [&](int c0) {
+    // D^T (+)= W . B^T over T k-steps: A = fragment-major weight (hi | lo per column block) through the register ring, B = NB
+    // 32-row tiles of the hi / lo LDS image `bh` / `bl` (row stride W; tile t = rows brow + 32 t)
+    f32x16 acc[2][JB];
+    auto product = [&](auto NBt, const unsigned short* wf, const int T, const unsigned short* bh, const unsigned short* bl,
+                       const int W, const int brow) {
+        constexpr int NB = decltype(NBt)::value;
 #pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int idx = i * NT + tid;
-            const int row = idx / (D / 4), c4 = idx % (D / 4);
-            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + row < nrows) xv[i] = *reinterpret_cast<const float4*>(X + (size_t)(r0 + c0 + row) * ld_x + c4 * 4);
-        }
-    };
-    fetch_x(0);
-    __syncthreads();
-
-    // D^T (+)= W . B^T over T k-steps: A = fragment-major weight (hi | lo per column block) through the register ring, B = the
-    // hi / lo LDS tile `bh` / `bl` (row stride W, row = brow)
-    f32x16 acc[JB];
-    auto product = [&](const unsigned short* wf, const int T, const unsigned short* bh, const unsigned short* bl, const int W,
-                       const int brow) {
+        for (int t = 0; t < NB; ++t)
 #pragma unroll
-        for (int j = 0; j < JB; ++j)
+            for (int j = 0; j < JB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
         bf16x8 Aq[NS][NF];
         const unsigned short* wsrc = wf + (size_t)wave * T * NF * 512 + lane * 8;
         auto load = [&](int i, int slot) {
@@ -150,170 +167,223 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
             for (int u = 0; u < NS; ++u) {
                 load(ib + u + PF, (u + PF) % NS);
                 const int s = ib + u;
-                const int off = brow * W + (((2 * s + half) ^ (brow & 15)) * 8);
-                const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(bh + off);
-                const bf16x8 Bl_ = *reinterpret_cast<const bf16x8*>(bl + off);
+                bf16x8 Bh[NB], Bl_[NB];
 #pragma unroll
-                for (int j = 0; j < JB; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][JB + j], Bh, acc[j], 0, 0, 0);      // lo hi
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bl_, acc[j], 0, 0, 0);          // hi lo
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bh, acc[j], 0, 0, 0);           // hi hi
+                for (int t = 0; t < NB; ++t) {
+                    const int rw = brow + 32 * t;
+                    const int off = rw * W + (((2 * s + half) ^ (rw & 15)) * 8);
+                    Bh[t] = *reinterpret_cast<const bf16x8*>(bh + off);
+                    Bl_[t] = *reinterpret_cast<const bf16x8*>(bl + off);
                 }
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) {
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][JB + j], Bh[t], acc[t][j], 0, 0, 0);     // lo hi
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bl_[t], acc[t][j], 0, 0, 0);         // hi lo
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bh[t], acc[t][j], 0, 0, 0);          // hi hi
+                    }
                 __builtin_amdgcn_sched_group_barrier(0x020, NF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * JB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * JB * NB, 0);
             }
         }
     };
 
-    // ---- Vq^T = Wv . v^T: lane = session (l31 & (HS - 1)), registers = this wave's hidden columns
-    product((const unsigned short*)q.Wv_f[hd], KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
-    if (l31 < HS) {
+    for (int b0 = bfirst; b0 < bend; b0 += HS) {             // passes of HS sessions (one, unless sessions are very short)
+        const int ns = min(HS, bend - b0);
+        __syncthreads();                                     // LDS of the previous pass has been read
+        const int r0 = segl[b0];
+        if (tid <= HS) segs[tid] = segl[b0 + min(tid, ns)] - r0;
+        const int nrows = segl[b0 + ns] - r0;
+        // ---- the pass's query rows v_b (left half of cat) into the [v | g] tile
+        for (int i = tid; i < HS * (D / 4); i += NT) {
+            const int row = i / (D / 4), c = (i % (D / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < ns) v = *reinterpret_cast<const float4*>(cat + (size_t)(b0 + row) * 2 * D + c);
+            stage4(c_hi, c_lo, 2 * D, row, c, v);
+        }
+        // first chunk of node rows: in flight under the Vq product
+        constexpr int XV = HR * D / 4 / NT;
+        float4 xv[XV];
+        auto fetch_x = [&](int c0) {
 #pragma unroll
-        for (int j = 0; j < JB; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = cbase + 32 * j + 8 * g + 4 * half;
-                const float4 v = make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-                *reinterpret_cast<float4*>(vq + l31 * (D + VQ_PAD) + col) = v;
-                if (q.Vq[hd] != nullptr && l31 < ns) *reinterpret_cast<float4*>(q.Vq[hd] + (size_t)(b0 + l31) * D + col) = v;
+            for (int i = 0; i < XV; ++i) {
+                const int idx = i * NT + tid;
+                const int row = idx / (D / 4), c4 = idx % (D / 4);
+                xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + row < nrows) xv[i] = *reinterpret_cast<const float4*>(X + (size_t)(r0 + c0 + row) * ld_x + c4 * 4);
             }
-    }
-    // bias and attention vector of this lane's hidden columns
-    float bu_[JB][16], we_[JB][16];
-#pragma unroll
-    for (int j = 0; j < JB; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = cbase + 32 * j + 8 * g + 4 * half;
-            const float4 wv = *reinterpret_cast<const float4*>(q.we[hd] + col);
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q.bu[hd] != nullptr) bv = *reinterpret_cast<const float4*>(q.bu[hd] + col);
-            we_[j][4 * g] = wv.x; we_[j][4 * g + 1] = wv.y; we_[j][4 * g + 2] = wv.z; we_[j][4 * g + 3] = wv.w;
-            bu_[j][4 * g] = bv.x; bu_[j][4 * g + 1] = bv.y; bu_[j][4 * g + 2] = bv.z; bu_[j][4 * g + 3] = bv.w;
-        }
-
-    // ---- node rows in chunks of 32: U^T = Wu . X^T, e_i = we . sigmoid(U_i + bu + Vq_b(i))
-    float* Uout = q.U[hd];
-    for (int c0 = 0; c0 < nrows; c0 += 32) {
-        __syncthreads();                         // the previous chunk's tile / rsess / epart have been read; vq is published
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int idx = i * NT + tid;
-            stage4(x_hi, x_lo, D, idx / (D / 4), (idx % (D / 4)) * 4, xv[i]);
-        }
-        if (tid < 32) {
-            int s = 0;
-#pragma unroll
-            for (int k = 1; k < HS; ++k) s += (c0 + tid >= segs[k]) ? 1 : 0;
-            rsess[tid] = min(s, ns - 1);
-        }
-        if (c0 + 32 < nrows) fetch_x(c0 + 32);
+        };
+        fetch_x(0);
         __syncthreads();
-        product((const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31);
-        const int row = c0 + l31;
-        const float* vrow = vq + rsess[l31] * (D + VQ_PAD);
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < JB; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = cbase + 32 * j + 8 * g + 4 * half;
-                const float4 vv = *reinterpret_cast<const float4*>(vrow + col);
-                const float u0 = acc[j][4 * g] + bu_[j][4 * g], u1 = acc[j][4 * g + 1] + bu_[j][4 * g + 1];
-                const float u2 = acc[j][4 * g + 2] + bu_[j][4 * g + 2], u3 = acc[j][4 * g + 3] + bu_[j][4 * g + 3];
-                part += we_[j][4 * g] * sigmoidf_(u0 + vv.x) + we_[j][4 * g + 1] * sigmoidf_(u1 + vv.y) +
-                        we_[j][4 * g + 2] * sigmoidf_(u2 + vv.z) + we_[j][4 * g + 3] * sigmoidf_(u3 + vv.w);
-                if (Uout != nullptr && row < nrows)
-                    *reinterpret_cast<float4*>(Uout + (size_t)(r0 + row) * D + col) = make_float4(u0, u1, u2, u3);
-            }
-        part += __shfl_xor(part, 32, 64);
-        if (half == 0) epart[wave * 32 + l31] = part;
-        __syncthreads();
-        if (tid < 32 && c0 + tid < nrows) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) s += epart[w * 32 + tid];
-            e[c0 + tid] = s;
-        }
-    }
-    __syncthreads();
+        HFT(0);
 
-    // ---- soft-max over each session's rows, read-out row g_b = sum_i alpha_i x_i (node order, as seg_attn_fwd sums it)
-    for (int sb = wave; sb < ns; sb += NW) {
-        const int base = segs[sb], n = min(segs[sb + 1] - base, MAXN);
-        float m = -INFINITY;
-        for (int i = lane; i < n; i += 64) m = fmaxf(m, e[base + i]);
-        m = wave_max(m);
-        float ssum = 0.f;
-        for (int i = lane; i < n; i += 64) ssum += expf(e[base + i] - m);
-        ssum = wave_sum(ssum);
-        const float inv = n > 0 ? 1.f / ssum : 0.f;
-        for (int i = lane; i < n; i += 64) {
-            const float al = expf(e[base + i] - m) * inv;
-            e[base + i] = al;
-            q.alpha[hd][r0 + base + i] = al;
-        }
-        __builtin_amdgcn_s_waitcnt(0);           // this wave's LDS writes of alpha before its own reads below (one wave per session)
-        const int c = lane * 4;
-        if (c < D) {
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float* xp = X + (size_t)(r0 + base) * ld_x + c;
-            int i = 0;
-            for (; i + 8 <= n; i += 8) {
-                float4 t[8];
+        // ---- Vq^T = Wv . v^T: lane = session (l31 & (HS - 1)), registers = this wave's hidden columns
+        product(std::integral_constant<int, 1>{}, (const unsigned short*)q.Wv_f[hd], KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
+        HFT(1);
+        if (l31 < HS) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float4*>(xp + (size_t)(i + k) * ld_x);
+            for (int j = 0; j < JB; ++j)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float al = e[base + i + k];
-                    o.x += al * t[k].x; o.y += al * t[k].y; o.z += al * t[k].z; o.w += al * t[k].w;
+                for (int g = 0; g < 4; ++g) {
+                    const int col = cbase + 32 * j + 8 * g + 4 * half;
+                    const float4 v = make_float4(acc[0][j][4 * g], acc[0][j][4 * g + 1], acc[0][j][4 * g + 2], acc[0][j][4 * g + 3]);
+                    *reinterpret_cast<float4*>(vq + l31 * (D + VQ_PAD) + col) = v;
+                    if (q.Vq[hd] != nullptr && l31 < ns) *reinterpret_cast<float4*>(q.Vq[hd] + (size_t)(b0 + l31) * D + col) = v;
                 }
-            }
-            for (; i < n; ++i) {
-                const float4 t = *reinterpret_cast<const float4*>(xp + (size_t)i * ld_x);
-                const float al = e[base + i];
-                o.x += al * t.x; o.y += al * t.y; o.z += al * t.z; o.w += al * t.w;
-            }
-            *reinterpret_cast<float4*>(cat + (size_t)(b0 + sb) * 2 * D + D + c) = o;
-            stage4(c_hi, c_lo, 2 * D, sb, D + c, o);
         }
-    }
-    if (ns < HS) {                               // tile rows of the group's padding sessions: zeros (their lanes are never read)
-        for (int i = tid; i < (HS - ns) * (D / 4); i += NT)
-            stage4(c_hi, c_lo, 2 * D, ns + i / (D / 4), D + (i % (D / 4)) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    __syncthreads();
 
-    // ---- s^T = Wsr . [v | g]^T (K = 2 d), y = s / max(|s|, eps)
-    product((const unsigned short*)q.Wsr_f[hd], 2 * KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
-    float ss = 0.f;
+        // ---- node rows in chunks of HR = 2 x 32: U^T = Wu . X^T (every weight fragment feeds both tiles),
+        //      e_i = we . sigmoid(U_i + bu + Vq_b(i))
+        for (int c0 = 0; c0 < nrows; c0 += HR) {
+            __syncthreads();                     // the previous chunk's tile / rsess / epart have been read; vq is published
 #pragma unroll
-    for (int j = 0; j < JB; ++j)
+            for (int i = 0; i < XV; ++i) {
+                const int idx = i * NT + tid;
+                stage4(x_hi, x_lo, D, idx / (D / 4), (idx % (D / 4)) * 4, xv[i]);
+            }
+            if (tid < HR) {
+                int s = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ss += acc[j][r] * acc[j][r];
-    ss += __shfl_xor(ss, 32, 64);
-    if (half == 0 && l31 < HS) epart[wave * 32 + l31] = ss;
-    __syncthreads();
-    if (l31 < ns) {
-        float tot = 0.f;
+                for (int k = 1; k < HS; ++k) s += (c0 + tid >= segs[k]) ? 1 : 0;
+                rsess[tid] = min(s, ns - 1);
+            }
+            if (c0 + HR < nrows) fetch_x(c0 + HR);
+            __syncthreads();
+            HFT(2);
+            const bool two = nrows - c0 > 32;
+            if (two) product(std::integral_constant<int, 2>{}, (const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31);
+            else product(std::integral_constant<int, 1>{}, (const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31);
+            HFT(3);
 #pragma unroll
-        for (int w = 0; w < NW; ++w) tot += epart[w * 32 + l31];
-        const float nrm = sqrtf(tot);
-        const float iv = q.eps_mode == 0 ? 1.f / fmaxf(nrm, q.eps) : 1.f / (nrm + q.eps);
-        const int b = b0 + l31;
-        if (wave == 0 && half == 0) q.inv[hd][b] = iv;
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;
+                const int row = c0 + 32 * t + l31;
+                const float* vrow = vq + rsess[32 * t + l31] * (D + VQ_PAD);
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < JB; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = cbase + 32 * j + 8 * g + 4 * half;
+                        const float4 vv = *reinterpret_cast<const float4*>(vrow + col);
+                        const float4 bb = *reinterpret_cast<const float4*>(bw + col);
+                        const float4 ww = *reinterpret_cast<const float4*>(bw + D + col);
+                        const float u0 = acc[t][j][4 * g] + bb.x, u1 = acc[t][j][4 * g + 1] + bb.y;
+                        const float u2 = acc[t][j][4 * g + 2] + bb.z, u3 = acc[t][j][4 * g + 3] + bb.w;
+                        part += ww.x * sig(u0 + vv.x) + ww.y * sig(u1 + vv.y) + ww.z * sig(u2 + vv.z) + ww.w * sig(u3 + vv.w);
+                        if (Uout != nullptr && row < nrows)
+                            *reinterpret_cast<float4*>(Uout + (size_t)(r0 + row) * D + col) = make_float4(u0, u1, u2, u3);
+                    }
+                part += __shfl_xor(part, 32, 64);
+                if (half == 0) epart[wave * HR + 32 * t + l31] = part;
+            }
+            __syncthreads();
+            if (tid < HR && c0 + tid < nrows && (two || tid < 32)) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += epart[w * HR + tid];
+                e[c0 + tid] = s;
+            }
+            HFT(4);
+        }
+        __syncthreads();
+        HFT(2);
+
+        // ---- soft-max over each session's rows, read-out row g_b = sum_i alpha_i x_i (node order, as seg_attn_fwd sums it)
+        for (int sb = wave; sb < ns; sb += NW) {
+            const int base = segs[sb], n = min(segs[sb + 1] - base, MAXN);
+            float m = -INFINITY;
+            for (int i = lane; i < n; i += 64) m = fmaxf(m, e[base + i]);
+            m = wave_max(m);
+            float ssum = 0.f;
+            for (int i = lane; i < n; i += 64) ssum += expf(e[base + i] - m);
+            ssum = wave_sum(ssum);
+            const float inv = n > 0 ? 1.f / ssum : 0.f;
+            for (int i = lane; i < n; i += 64) {
+                const float al = expf(e[base + i] - m) * inv;
+                e[base + i] = al;
+                q.alpha[hd][r0 + base + i] = al;
+            }
+            __builtin_amdgcn_s_waitcnt(0);       // this wave's LDS writes of alpha before its own reads below (one wave per session)
+            const int c = lane * 4;
+            if (c < D) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* xp = X + (size_t)(r0 + base) * ld_x + c;
+                int i = 0;
+                for (; i + 8 <= n; i += 8) {
+                    float4 t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float4*>(xp + (size_t)(i + k) * ld_x);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float al = e[base + i + k];
+                        o.x += al * t[k].x; o.y += al * t[k].y; o.z += al * t[k].z; o.w += al * t[k].w;
+                    }
+                }
+                if (i < n) {                     // tail: the remaining <= 7 rows in flight together
+                    float4 t[7];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) t[k] = *reinterpret_cast<const float4*>(xp + (size_t)min(i + k, n - 1) * ld_x);
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                        if (i + k < n) {
+                            const float al = e[base + i + k];
+                            o.x += al * t[k].x; o.y += al * t[k].y; o.z += al * t[k].z; o.w += al * t[k].w;
+                        }
+                }
+                *reinterpret_cast<float4*>(cat + (size_t)(b0 + sb) * 2 * D + D + c) = o;
+                stage4(c_hi, c_lo, 2 * D, sb, D + c, o);
+            }
+        }
+        if (ns < HS) {                           // tile rows of the pass's missing sessions: zeros (their lanes are never read)
+            for (int i = tid; i < (HS - ns) * (D / 4); i += NT)
+                stage4(c_hi, c_lo, 2 * D, ns + i / (D / 4), D + (i % (D / 4)) * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        __syncthreads();
+        HFT(5);
+
+        // ---- s^T = Wsr . [v | g]^T (K = 2 d), y = s / max(|s|, eps)
+        product(std::integral_constant<int, 1>{}, (const unsigned short*)q.Wsr_f[hd], 2 * KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
+        HFT(6);
+        float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < JB; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = cbase + 32 * j + 8 * g + 4 * half;
-                const float4 v = make_float4(acc[j][4 * g] * iv, acc[j][4 * g + 1] * iv, acc[j][4 * g + 2] * iv, acc[j][4 * g + 3] * iv);
-                *reinterpret_cast<float4*>(Y + (size_t)b * D + col) = v;
-                if (Y16 != nullptr)
-                    *reinterpret_cast<uint2*>(Y16 + (size_t)b * ld16 + col) = make_uint2(srec_pack_bf16(v.x, v.y), srec_pack_bf16(v.z, v.w));
-            }
+            for (int r = 0; r < 16; ++r) ss += acc[0][j][r] * acc[0][j][r];
+        ss += __shfl_xor(ss, 32, 64);
+        if (half == 0 && l31 < HS) epart[wave * HR + l31] = ss;
+        __syncthreads();
+        if (l31 < ns) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += epart[w * HR + l31];
+            const float nrm = sqrtf(tot);
+            const float iv = q.eps_mode == 0 ? 1.f / fmaxf(nrm, q.eps) : 1.f / (nrm + q.eps);
+            const int b = b0 + l31;
+            if (wave == 0 && half == 0) q.inv[hd][b] = iv;
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = cbase + 32 * j + 8 * g + 4 * half;
+                    const float4 v = make_float4(acc[0][j][4 * g] * iv, acc[0][j][4 * g + 1] * iv, acc[0][j][4 * g + 2] * iv,
+                                                 acc[0][j][4 * g + 3] * iv);
+                    *reinterpret_cast<float4*>(Y + (size_t)b * D + col) = v;
+                    if (Y16 != nullptr)
+                        *reinterpret_cast<uint2*>(Y16 + (size_t)b * ld16 + col) = make_uint2(srec_pack_bf16(v.x, v.y), srec_pack_bf16(v.z, v.w));
+                }
+        }
+        HFT(7);
     }
+#ifdef SREC_HEADF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_headf_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 8; ++i) g_headf_tim[blockIdx.x][i] = tim_t[i];
+    }
+#endif
 }
 
 struct WfragArgs {
@@ -353,6 +423,13 @@ __global__ __launch_bounds__(256) void head_wfrag_kernel(WfragArgs a) {
 
 }  // namespace
 
+#ifdef SREC_HEADF_TIMING
+extern "C" int srec_headf_timing(unsigned long long* tim, unsigned long long* blk) {
+    if (hipMemcpyFromSymbol(tim, HIP_SYMBOL(g_headf_tim), sizeof(unsigned long long) * 8192) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(blk, HIP_SYMBOL(g_headf_blk), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : 1;
+}
+#endif
+
 // n <= SREC_HEAD_MAXW matrices W_i [rows_i, cols_i] fp32 row-major (HOST arrays) -> hi / lo fragment-major bf16 copies dst_i
 // [2 rows_i cols_i] of W_i (trans_i = 0) or W_i^T (trans_i = 1) as the A operands of srec_head_fwd; operand rows % 128 == 0,
 // operand columns % 16 == 0.  One launch.
@@ -378,7 +455,7 @@ extern "C" int srec_head_wfrag(int n, const void* W, const void* dst, const int*
 // desc: HOST srec_head_desc (srec_hg.h)
 extern "C" int srec_head_fwd(const void* desc, void* stream) {
     const srec_head_desc* q = (const srec_head_desc*)desc;
-    if (q == nullptr || q->nh <= 0 || q->nh > SREC_HEAD_MAXH || (q->d != 128 && q->d != 256) || q->B <= 0) return SREC_BAD_ARG;
+    if (q == nullptr || q->nh <= 0 || q->nh > SREC_HEAD_MAXH || (q->d != 128 && q->d != 256) || q->B <= 0 || q->B > 8192 || q->NT <= 0) return SREC_BAD_ARG;
     if (q->X == nullptr || q->seg == nullptr || (q->ld_x & 3)) return SREC_BAD_ARG;
     for (int h = 0; h < q->nh; ++h) {
         if (q->cat[h] == nullptr || q->Wu_f[h] == nullptr || q->Wv_f[h] == nullptr || q->Wsr_f[h] == nullptr ||
@@ -389,9 +466,9 @@ extern "C" int srec_head_fwd(const void* desc, void* stream) {
     HeadArgs a{};
     a.d = *q;
     const int D = q->d;
-    const size_t lds = (size_t)(2 * 32 * D + 2 * HS * 2 * D) * 2 + (size_t)(HS * (D + VQ_PAD) + HS * MAXN + NW * 32) * 4 +
-                       (size_t)(HS + 1 + 32) * 4;
-    const dim3 grid((q->B + HS - 1) / HS, q->nh);
+    const size_t lds = (size_t)(2 * HR * D + 2 * HS * 2 * D) * 2 + (size_t)(HS * (D + VQ_PAD) + 2 * D + HR + MAXN + NW * HR) * 4 +
+                       (size_t)(HS + 1 + HR + 2 + q->B + 1) * 4;
+    const dim3 grid((q->NT + HR - 1) / HR, q->nh);
     static std::atomic<unsigned long long> om[2];
     if (D == 256) {
         if (int rc = srec_lds_optin((const void*)head_fwd_kernel<2>, (int)lds, om[0])) return rc;

@@ -405,11 +405,15 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             # read-out + fc_sr(cat[x_last, sr_g]) of every live order as grouped exact-fp32 launches (ops.ReadoutHead):
             # these B-row products are launch bound one by one
             ro = self.readout
-            ss = ops.readout_head(allf, mg.cat_seg, mg.dynp('NT'), dB,
-                                  [(feat_vs[i], ro.fc_u[i].weight, ro.fc_u[i].bias, ro.fc_v[i].weight, ro.fc_e[i].weight,
-                                    self.fc_sr[i].weight) for i in live])
-            ws = getattr(self, '_sr_ws', None) if len(ss) == 1 else None      # one head: its vector is the scoring operand
-            srs = [ops.normalize(s, 0, dB, ws) if self.norm else s for s in ss]
+            heads = [(feat_vs[i], ro.fc_u[i].weight, ro.fc_u[i].bias, ro.fc_v[i].weight, ro.fc_e[i].weight,
+                      self.fc_sr[i].weight) for i in live]
+            ws = getattr(self, '_sr_ws', None) if len(heads) == 1 else None   # one head: its vector is the scoring operand
+            if self.norm and ops.readout_head_fused_ok(allf, heads):
+                # bf16 mode, d = 128 / 256: Vq, U, soft-max read-out, fc_sr and the normalisation as ONE launch (csrc/headf.hip)
+                srs = list(ops.readout_head_fused(allf, mg.cat_seg, mg.dynp('NT'), dB, heads, ws))
+            else:
+                ss = ops.readout_head(allf, mg.cat_seg, mg.dynp('NT'), dB, heads)
+                srs = [ops.normalize(s, 0, dB, ws) if self.norm else s for s in ss]
         else:
             sr_g = self.readout(mg, allf, feat_vs, live)
             for i in live:

@@ -109,12 +109,14 @@ def set_precision(mode):
     PRECISION['matmul'] = mode
     _WT_CACHE.clear()
     _WSPLIT_CACHE.clear()
+    _HEAD_WF_CACHE.clear()
 
 
 def weights_changed():
     """called by the optimizer after it updated parameters: cached transposed weight copies are stale"""
     _WT_CACHE.clear()
     _WSPLIT_CACHE.clear()
+    _HEAD_WF_CACHE.clear()
 
 
 def _transposed(w):
@@ -283,7 +285,9 @@ def seed_dropout(seed=None):
     with the SAME value to replay a run's masks calls it explicitly (re-seeding with an equal value is not observable)."""
     base = torch.initial_seed()
     _NONCE['seed'] = base
-    _NONCE['gen'] = torch.Generator().manual_seed((base if seed is None else int(seed)) ^ 0x5DEECE66D)
+    # (seeded with the value itself: the first draws equal what torch's global generator would hand out right after
+    #  torch.manual_seed(value) - the masks of a seeded run are the ones it had when the nonces still came from there)
+    _NONCE['gen'] = torch.Generator().manual_seed(base if seed is None else int(seed))
 
 
 def _nonce():
@@ -956,58 +960,187 @@ class ReadoutHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         allf, seg, *rest = ctx.saved_tensors
-        n, dT, dB = ctx.n, ctx.dT, ctx.dB
+        return _readout_head_backward(allf, seg, [rest[9 * i:9 * i + 9] for i in range(ctx.n)], ctx.dT, ctx.dB, ctx.has_bu, gs)
+
+
+def _readout_head_backward(allf, seg, per, dT, dB, has_bu, gs):
+    """the grouped backward of the read-out head (ReadoutHead, ReadoutHeadFused): per[i] = (v, Wu, Wv, we, Wsr, U, Vq, alpha,
+    cat) of live order i, gs[i] = gradient of s_i -> (d allf, None, None, None, per order: d v, d Wu, d bu, d Wv, d we, d Wsr)"""
+    n = len(per)
+    NT, D = allf.shape
+    dev = allf.device
+    B = per[0][0].shape[0]
+    h = per[0][1].shape[0]
+    gcats, gWsrs, probs = [], [], []
+    for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat) in enumerate(per):
+        g = _rows(gs[i])
+        gcat = torch.empty_like(cat)
+        gWsr = torch.empty_like(Wsr)
+        probs.append(('nn', g, Wsr, gcat, None, dB, 0.0))
+        probs.append(('tn', g, cat, gWsr, None, dB, 0.0))
+        gcats.append(gcat)
+        gWsrs.append(gWsr)
+    gemm_f32_group(probs)
+    g_allf = None
+    probs, grads, extra = [], [], []
+    for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat) in enumerate(per):
+        dv = v.shape[1]
+        gsrg = gcats[i][:, dv:]
+        dX = torch.empty(NT, D, device=dev, dtype=torch.float32)      # rows behind the live nodes zeroed in-kernel
+        dU = torch.empty(NT, h, device=dev, dtype=torch.float32)
+        dVq = torch.empty(B, h, device=dev, dtype=torch.float32)
+        dwp = torch.empty(B, h, device=dev, dtype=torch.float32)
+        lib.srec_seg_attn_bwd(ptr(gsrg), _ld(gsrg), ptr(allf), _ld(allf), ptr(alpha), ptr(U), h, ptr(Vq), h, ptr(we),
+                              ptr(seg), B, ptr(dB), h, D, NT, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp), h, None, None, None,
+                              None, stream())
+        gWu, gWv = torch.empty_like(Wu), torch.empty_like(Wv)
+        gv = gcats[i][:, :dv]                                         # d v: the concat half, + dVq Wv in place
+        probs.append(('nn', dU, Wu, dX, None, dT, 1.0))               # d allf (this order) = read-out term + dU Wu
+        probs.append(('tn', dU, allf, gWu, None, dT, 0.0))
+        probs.append(('nn', dVq, Wv, gv, None, dB, 1.0))
+        probs.append(('tn', dVq, v, gWv, None, dB, 0.0))
+        # column sums (d bu = sum_n dU, d we = sum_b dwp) as products with a block of ones, inside the same launch:
+        # as col_sum calls they were two kernel nodes each
+        ones = _ones4(max(NT, B), dev)
+        sums = torch.empty(8, h, device=dev, dtype=torch.float32)
+        gbu = None
+        if has_bu[i]:
+            probs.append(('tn', ones[:NT], dU, sums[:4], None, dT, 0.0))
+            gbu = sums[0]
+        probs.append(('tn', ones[:B], dwp, sums[4:], None, dB, 0.0))
+        grads.append((gv, gWu, gbu, gWv, sums[4:5], gWsrs[i]))
+        extra.append(dX)
+    per_launch = 12 if len(probs) > 16 else 16          # whole orders per launch (6 problems each)
+    for c in range(0, len(probs), per_launch):
+        gemm_f32_group(probs[c:c + per_launch])
+    g_allf = extra[0]
+    for dX in extra[1:]:
+        g_allf = g_allf + dX
+    return (g_allf, None, None, None) + tuple(t for gr in grads for t in gr)
+
+
+# ---- fused read-out head (csrc/headf.hip) ----------------------------------------------------------------------------------
+_HEAD_WF_CACHE = {}    # (data_ptr, shape, trans) -> hi / lo fragment-major bf16 copy of this step (dropped by weights_changed)
+
+
+def head_wfrag(ws, trans):
+    """hi / lo fragment-major bf16 operand copies of fp32 weights (W_i or W_i^T), computed once per optimizer step, all
+    missing ones in ONE launch (srec_head_wfrag)"""
+    out, todo = [None] * len(ws), []
+    for i, (w, t) in enumerate(zip(ws, trans)):
+        c = _HEAD_WF_CACHE.get((w.data_ptr(), tuple(w.shape), int(t)))
+        if c is None:
+            todo.append(i)
+        else:
+            out[i] = c
+    for c0 in range(0, len(todo), 16):
+        ch = todo[c0:c0 + 16]
+        m = len(ch)
+        for i in ch:
+            assert ws[i].is_contiguous() and ws[i].dtype == torch.float32
+        bufs = [torch.empty(2 * ws[i].numel(), device=ws[i].device, dtype=torch.bfloat16) for i in ch]
+        arr, ints = _ct.c_void_p * m, _ct.c_int * m
+        a_w, a_o = arr(*[ws[i].data_ptr() for i in ch]), arr(*[b.data_ptr() for b in bufs])
+        i_r, i_c, i_t = ints(*[ws[i].shape[0] for i in ch]), ints(*[ws[i].shape[1] for i in ch]), ints(*[int(trans[i]) for i in ch])
+        lib.srec_head_wfrag(m, _ct.addressof(a_w), _ct.addressof(a_o), _ct.addressof(i_r), _ct.addressof(i_c), _ct.addressof(i_t),
+                            stream())
+        for i, b in zip(ch, bufs):
+            out[i] = _HEAD_WF_CACHE[(ws[i].data_ptr(), tuple(ws[i].shape), int(trans[i]))] = b
+    return out
+
+
+class HeadDesc(_ct.Structure):
+    """host mirror of srec_head_desc (include/srec_hg.h)"""
+    _fields_ = ([(nm, _ct.c_int) for nm in ('nh', 'd', 'B', 'NT', 'ld_x', 'ld16', 'eps_mode')] + [('eps', _ct.c_float)] +
+                [(nm, _ct.c_void_p) for nm in ('X', 'seg', 'dynB')] +
+                [(nm, _ct.c_void_p * 4) for nm in ('cat', 'Wu_f', 'Wv_f', 'Wsr_f', 'bu', 'we', 'alpha', 'U', 'Vq', 'y', 'inv', 'y16')])
+
+
+class ReadoutHeadFused(torch.autograd.Function):
+    """ReadoutHead + the normalisation of its outputs (msgifsr.py:124-155, :269-273) with the FORWARD as one launch: a
+    workgroup owns 8 sessions and runs Vq, U, the soft-max read-out, fc_sr and F.normalize on them, every product as a
+    3-term hi / lo bf16 split on the matrix pipe (csrc/headf.hip; results to ~2^-16 of the exact-fp32 grouped head).
+    Returns the NORMALISED session vectors; `ws` (CEWorkspace, optional) receives the bf16 operand copy of head 0.
+    Backward: the normalisation backward + the grouped launches of ReadoutHead."""
+
+    @staticmethod
+    def forward(ctx, allf, seg, dT, dB, ws, eps_mode, *flat):
+        n = len(flat) // 6
+        allf = _rows(allf)
         NT, D = allf.shape
         dev = allf.device
-        per = [rest[9 * i:9 * i + 9] for i in range(n)]
+        per = [(flat[6 * i], _rows(flat[6 * i + 1]), flat[6 * i + 2], _rows(flat[6 * i + 3]),
+                flat[6 * i + 4].reshape(-1).contiguous(), _rows(flat[6 * i + 5])) for i in range(n)]
         B = per[0][0].shape[0]
-        h = per[0][1].shape[0]
-        gcats, gWsrs, probs = [], [], []
-        for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat) in enumerate(per):
-            g = _rows(gs[i])
-            gcat = torch.empty_like(cat)
-            gWsr = torch.empty_like(Wsr)
-            probs.append(('nn', g, Wsr, gcat, None, dB, 0.0))
-            probs.append(('tn', g, cat, gWsr, None, dB, 0.0))
-            gcats.append(gcat)
-            gWsrs.append(gWsr)
-        gemm_f32_group(probs)
-        g_allf = None
-        probs, grads, extra = [], [], []
-        for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat) in enumerate(per):
-            dv = v.shape[1]
-            gsrg = gcats[i][:, dv:]
-            dX = torch.empty(NT, D, device=dev, dtype=torch.float32)      # rows behind the live nodes zeroed in-kernel
-            dU = torch.empty(NT, h, device=dev, dtype=torch.float32)
-            dVq = torch.empty(B, h, device=dev, dtype=torch.float32)
-            dwp = torch.empty(B, h, device=dev, dtype=torch.float32)
-            lib.srec_seg_attn_bwd(ptr(gsrg), _ld(gsrg), ptr(allf), _ld(allf), ptr(alpha), ptr(U), h, ptr(Vq), h, ptr(we),
-                                  ptr(seg), B, ptr(dB), h, D, NT, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp), h, None, None, None,
-                                  None, stream())
-            gWu, gWv = torch.empty_like(Wu), torch.empty_like(Wv)
-            gv = gcats[i][:, :dv]                                         # d v: the concat half, + dVq Wv in place
-            probs.append(('nn', dU, Wu, dX, None, dT, 1.0))               # d allf (this order) = read-out term + dU Wu
-            probs.append(('tn', dU, allf, gWu, None, dT, 0.0))
-            probs.append(('nn', dVq, Wv, gv, None, dB, 1.0))
-            probs.append(('tn', dVq, v, gWv, None, dB, 0.0))
-            # column sums (d bu = sum_n dU, d we = sum_b dwp) as products with a block of ones, inside the same launch:
-            # as col_sum calls they were two kernel nodes each
-            ones = _ones4(max(NT, B), dev)
-            sums = torch.empty(8, h, device=dev, dtype=torch.float32)
-            gbu = None
-            if ctx.has_bu[i]:
-                probs.append(('tn', ones[:NT], dU, sums[:4], None, dT, 0.0))
-                gbu = sums[0]
-            probs.append(('tn', ones[:B], dwp, sums[4:], None, dB, 0.0))
-            grads.append((gv, gWu, gbu, gWv, sums[4:5], gWsrs[i]))
-            extra.append(dX)
-        per_launch = 12 if len(probs) > 16 else 16          # whole orders per launch (6 problems each)
-        for c in range(0, len(probs), per_launch):
-            gemm_f32_group(probs[c:c + per_launch])
-        g_allf = extra[0]
-        for dX in extra[1:]:
-            g_allf = g_allf + dX
-        return (g_allf, None, None, None) + tuple(t for gr in grads for t in gr)
+        wf = head_wfrag([w for po in per for w in (po[1], po[3], po[5])], [0] * (3 * n))
+        q = HeadDesc()
+        q.nh, q.d, q.B, q.NT, q.ld_x, q.eps_mode, q.eps = n, D, B, NT, _ld(allf), int(eps_mode), 1e-12
+        q.X, q.seg, q.dynB = ptr(allf), ptr(seg), ptr(dB)
+        sr16 = getattr(ws, 'sr16', None) if n == 1 else None
+        if sr16 is not None and not (B <= sr16.shape[0] and D <= sr16.shape[1]):
+            sr16 = None
+        q.ld16 = sr16.shape[1] if sr16 is not None else 0
+        keep, ys = [], []
+        for i, (v, Wu, bu, Wv, we, Wsr) in enumerate(per):
+            cat = v.as_strided((B, 2 * D), (2 * D, 1))             # v is the left half of a private [B, 2 D] buffer (checked)
+            alpha = torch.empty(NT, device=dev, dtype=torch.float32)
+            U = torch.empty(NT, D, device=dev, dtype=torch.float32)
+            Vq = torch.empty(B, D, device=dev, dtype=torch.float32)
+            y = torch.empty(B, D, device=dev, dtype=torch.float32)
+            inv = torch.empty(B, device=dev, dtype=torch.float32)
+            q.cat[i], q.Wu_f[i], q.Wv_f[i], q.Wsr_f[i] = ptr(cat), ptr(wf[3 * i]), ptr(wf[3 * i + 1]), ptr(wf[3 * i + 2])
+            q.bu[i], q.we[i], q.alpha[i], q.U[i], q.Vq[i] = ptr(bu), ptr(we), ptr(alpha), ptr(U), ptr(Vq)
+            q.y[i], q.inv[i] = ptr(y), ptr(inv)
+            q.y16[i] = ptr(sr16) if (sr16 is not None and i == 0) else None
+            keep += [v, Wu, Wv, we, Wsr, U, Vq, alpha, cat, y, inv]
+            ys.append(y)
+        lib.srec_head_fwd(_ct.addressof(q), stream())
+        if sr16 is not None:
+            ws.sr_fresh = (ys[0].data_ptr(), B, D)
+        ctx.save_for_backward(allf, seg, *keep)
+        ctx.n, ctx.dT, ctx.dB = n, dT, dB
+        ctx.has_bu = [po[2] is not None for po in per]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        allf, seg, *rest = ctx.saved_tensors
+        per, gs = [], []
+        for i in range(ctx.n):
+            *p9, y, inv = rest[11 * i:11 * i + 11]
+            gy = _rows(gys[i])
+            B, D = y.shape
+            g = torch.empty_like(y)
+            lib.srec_normalize_bwd(ptr(y), D, ptr(gy), _ld(gy), ptr(inv), ptr(g), D, B, ptr(ctx.dB), D, stream())
+            per.append(p9)
+            gs.append(g)
+        out = _readout_head_backward(allf, seg, per, ctx.dT, ctx.dB, ctx.has_bu, gs)
+        return out[:4] + (None, None) + out[4:]
+
+
+def readout_head_fused_ok(allf, per_order):
+    """the fused forward applies: bf16 mode, d = hidden = output in (128, 256), <= 4 heads, contiguous weights, every query
+    tensor the tagged left half of a private [B, 2 d] buffer (norm_permute_pick / permute_and_pick)"""
+    if not (allf.is_cuda and PRECISION['matmul'] == 'bf16' and 1 <= len(per_order) <= 4) or os.environ.get('SREC_HEAD_FUSED') == '0':
+        return False
+    D = allf.shape[1]
+    if D not in (128, 256) or allf.stride(1) != 1 or allf.stride(0) % 4:
+        return False
+    B = per_order[0][0].shape[0]
+    for v, Wu, bu, Wv, we, Wsr in per_order:
+        if not (getattr(v, '_srec_cat_left', False) and tuple(v.shape) == (B, D) and v.stride(0) == 2 * D and v.stride(1) == 1):
+            return False
+        if tuple(Wu.shape) != (D, D) or tuple(Wv.shape) != (D, D) or tuple(Wsr.shape) != (D, 2 * D) or we.numel() != D:
+            return False
+        if not (Wu.is_contiguous() and Wv.is_contiguous() and Wsr.is_contiguous()):
+            return False
+    return B > 1
+
+
+def readout_head_fused(allf, seg, dT, dB, per_order, ws=None, eps_mode=0):
+    """-> tuple of NORMALISED session vectors y_i [B, d] (ReadoutHeadFused)"""
+    flat = [t for po in per_order for t in po]
+    return ReadoutHeadFused.apply(allf, seg, dT, dB, ws, eps_mode, *flat)
 
 
 def split_bf16(jobs):

@@ -243,7 +243,15 @@ def _compare_big(case, world, res, ref, extra, bf16):
                 adam_close(ta['rows'], tb['rows'], steps=si + 1, what='rank %d step %d: sampled + touched table rows' % (r, si))
                 _vec_close(ta['rownorm'], tb['rownorm'], 1e-5, 'rank %d step %d: row norms of the table' % (r, si))
                 for k, p in rr['params'].items():
-                    adam_close(s['params'][k], p, steps=si + 1, what='rank %d step %d: %s' % (r, si, k))
+                    # 512 sessions of up to 49 clicks: ~7 k node rows feed every encoder gradient, and the two ranks' halves are
+                    # summed in another order than on one device.  Adam's first steps move an element by ~lr whatever its
+                    # size, so a gradient component that cancels to ~0 may step with either sign (the gradients themselves
+                    # are compared above at 1e-4): 99.9 % of the elements within 2e-6, none further than a full flip
+                    a_, b_ = s['params'][k].float(), p.float()
+                    err = (a_ - b_).abs()
+                    frac = (err <= 2e-6 + 1e-4 * b_.abs()).float().mean().item()
+                    assert frac >= 0.999, 'rank %d step %d: %s: only %.5f of the elements within 2e-6' % (r, si, k, frac)
+                    assert err.max().item() <= 2.02e-3 * (si + 1), 'rank %d step %d: %s: max err %.3e' % (r, si, k, err.max().item())
         n_live = len(rank_slice(samples, world, r, False)[0])
         v, i = out['topk']
         rv, ri = extra['topk']
@@ -298,7 +306,7 @@ def test_rank_5_of_the_c5_job_replayed_under_hipgraph_capture(dev, tmp_path):
         group = D.ReplayGroup(world, rank, dev, rtol=2e-3, atol=1e-5).load(job['steps'][0]['tape'])
         vp = D.VocabParallel(model, group=group, idx_cap=inputs[0].cap('uniq_items'))
         torch.cuda.empty_cache()
-        assert (vp.lo, vp.hi) == (job['lo'], job['hi']) == (6_250_000, 7_500_000)
+        assert (vp.lo, vp.hi) == (job['lo'], job['hi']) == D.shard_bounds(V, world, rank)[:2] and vp.lo > 6_000_000
         rows = job['steps'][0]['table']['idx'].to(dev)
         opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
         replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]

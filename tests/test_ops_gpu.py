@@ -1046,6 +1046,7 @@ def test_lookup_with_fused_dropout(dev):
         outs = []
         for seed, cnt in ((11, 0), (11, 0), (12, 0), (11, 1)):
             torch.manual_seed(seed)
+            ops.seed_dropout()                                   # (an equal seed value is not observable: explicit restart)
             counter.fill_(cnt)
             table.grad = None
             out = ops.embedding_lookup(table, idx, uniq, None, None, None, (p, 7))
@@ -1227,6 +1228,104 @@ def test_readout_head_bf16_split_matches_exact_fp32(dev, n_orders, B, d):
         if nm.startswith(('bu', 'we')):
             near(a, b, 'grad ' + nm, tol=2e-3, rtol=5e-4)
         elif nm.startswith('W'):                       # sums over sessions / nodes of products of either sign: ~10 x cancellation
+            near(a, b, 'grad ' + nm, tol=5e-4, rtol=3e-4)
+        else:
+            near(a, b, 'grad ' + nm)
+
+
+@pytest.mark.parametrize('n_orders,B,d,maxlen', [(1, 512, 256, 15), (1, 509, 256, 40), (3, 40, 128, 15), (2, 21, 256, 70)])
+def test_fused_readout_head_matches_the_exact_fp32_grouped_head(dev, n_orders, B, d, maxlen):
+    """csrc/headf.hip (ops.ReadoutHeadFused: Vq, U, soft-max read-out, fc_sr, F.normalize of a group of 8 sessions per
+    workgroup in ONE launch, every product a 3-term hi / lo bf16 split) against the exact-fp32 grouped head
+    (ops.ReadoutHead) followed by ops.normalize, msgifsr.py:124-155 + :269-273: normalised session vectors, the bf16
+    operand copy, the saved soft-max weights, and every gradient (the backward shares the grouped launches, fed with the
+    fused forward's saved tensors).  Padded layouts: live sessions / rows below capacity, B not a multiple of the group
+    size, sessions longer than one 32-row chunk, sessions of a single node."""
+    ops = _ops()
+    torch.manual_seed(5)
+    lens = torch.randint(1, maxlen, (B,))
+    lens[::7] = 1
+    seg = torch.zeros(B + 1, dtype=torch.int32)
+    live_B = B - 3
+    seg[1:] = lens.cumsum(0)
+    seg[live_B + 1:] = seg[live_B]                          # capacity padding: empty sessions behind the live ones
+    n_live = int(seg[live_B])
+    NT = n_live + 77
+    seg_d = seg.to(dev)
+    dT = torch.tensor([n_live], device=dev, dtype=torch.int32)
+    dB = torch.tensor([live_B], device=dev, dtype=torch.int32)
+    allf0 = torch.randn(NT, d, device=dev)
+    allf0 = allf0 / allf0.norm(dim=1, keepdim=True)
+    allf0[n_live:] = 0
+    sc = 1.0 / d ** 0.5
+    v0 = []
+    for _ in range(n_orders):
+        vv = torch.randn(B, d, device=dev)
+        vv = vv / vv.norm(dim=1, keepdim=True)
+        vv[live_B:] = 0
+        v0.append(vv)
+    par = [[((torch.rand(d, d, device=dev) * 2 - 1) * sc), ((torch.rand(d, device=dev) * 2 - 1) * sc),
+            ((torch.rand(d, d, device=dev) * 2 - 1) * sc), ((torch.rand(1, d, device=dev) * 2 - 1) * sc),
+            ((torch.rand(d, 2 * d, device=dev) * 2 - 1) * sc)] for _ in range(n_orders)]
+    gws = [torch.randn(B, d, device=dev) for _ in range(n_orders)]
+    for w in gws:
+        w[live_B:] = 0
+
+    class WS:
+        sr16 = None
+        sr_fresh = None
+
+    def run(fused):
+        allf = allf0.clone().requires_grad_()
+        vs, per = [], []
+        for i in range(n_orders):
+            buf = torch.full((B, 2 * d), 7.0, device=dev)      # the right half is overwritten by the head
+            buf[:, :d] = v0[i]
+            vleaf = buf.requires_grad_()
+            v = vleaf[:, :d]
+            v._srec_cat_left = True
+            vs.append(vleaf)
+            per.append([v] + [t.clone().requires_grad_() for t in par[i]])
+        ws = WS()
+        ops.set_precision('bf16' if fused else 'fp32')
+        try:
+            if fused:
+                ws.sr16 = torch.zeros(B + 5, d, device=dev, dtype=torch.bfloat16)
+                assert ops.readout_head_fused_ok(allf, per)
+                ys = ops.readout_head_fused(allf, seg_d, dT, dB, per, ws if n_orders == 1 else None)
+            else:
+                ss = ops.ReadoutHead.apply(allf, seg_d, dT, dB, *[t for po in per for t in po])
+                ys = [ops.normalize(s_, 0, dB) for s_ in ss]
+            loss = sum((y * w).sum() for y, w in zip(ys, gws))
+            leaves = [allf] + [t for i in range(n_orders) for t in [vs[i]] + per[i][1:]]
+            grads = torch.autograd.grad(loss, leaves)
+        finally:
+            ops.set_precision('fp32')
+        return [y.detach() for y in ys], grads, ws
+
+    y1, g1, ws1 = run(True)
+    y0, g0, _ = run(False)
+
+    def near(a, b, what, tol=1e-4, rtol=3e-5):
+        a, b = a.double().cpu(), b.double().cpu()
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= tol * max(scale, 1e-30), '%s: max |err| %.3e against scale %.3e' % (what, err, scale)
+        rel = float((a - b).norm() / b.norm().clamp(min=1e-30))
+        assert rel < rtol, '%s: relative error %.3e' % (what, rel)
+    for i, (a, b) in enumerate(zip(y1, y0)):
+        near(a[:live_B], b[:live_B], 'y%d' % i)
+        assert float(a[live_B:].abs().max()) == 0.0            # capacity padding: zero rows
+    if n_orders == 1:
+        assert ws1.sr_fresh == (y1[0].data_ptr(), B, d)
+        assert torch.equal(ws1.sr16[:B].float(), y1[0].to(torch.bfloat16).float())      # the scoring operand = bf16(y)
+    names = ['allf'] + ['%s%d' % (nm, i) for i in range(n_orders) for nm in ('cat', 'Wu', 'bu', 'Wv', 'we', 'Wsr')]
+    for nm, a, b in zip(names, g1, g0):
+        if nm.startswith('cat'):
+            a, b = a[:live_B, :d], b[:live_B, :d]              # d v (the right half of the buffer is not an input)
+        if nm.startswith(('bu', 'we')):                        # column sums that cancel to ~1e-3 of their summands
+            near(a, b, 'grad ' + nm, tol=2e-3, rtol=5e-4)
+        elif nm.startswith('W'):
             near(a, b, 'grad ' + nm, tol=5e-4, rtol=3e-4)
         else:
             near(a, b, 'grad ' + nm)

@@ -66,7 +66,7 @@ def test_trained_metrics_match_the_oracle_trained_model(dev, case, precision):
     got = _train(dev, case, precision)
     want = PIN[case]['epochs'][1:]                      # [0] = the untrained model
     assert len(got) == len(want)
-    assert want[-1][1] > 0.3                            # the pinned model did learn (HR@20 > 30 %)
+    assert want[-1][1] > 0.2                            # the pinned model did learn (HR@20: 39 % MSGIFSR, 23 % the 1-layer SRGNN)
     for e, ((m, h), (wm, wh)) in enumerate(zip(got, want)):
         assert abs(m - wm) <= 0.003 and abs(h - wh) <= 0.003, \
             '%s %s epoch %d: MRR@20 %.3f%% HR@20 %.3f%% vs oracle-trained %.3f%% / %.3f%%' % (case, precision, e, 100 * m, 100 * h,
