@@ -100,9 +100,6 @@ def make_batches(model_name, order, n_batches, B, V, max_len, seed, padded=False
             mxU = max(mxU, cnt.get('U', 1))
         r256 = lambda v: (v + 255) // 256 * 256
         caps = dict(B=B, N=r256(mxN), E=r256(mxE), U=r256(mxU))
-        if os.environ.get('SREC_BENCH_CAPS'):              # experiment: looser capacities (what a launcher's estimate gives)
-            c = int(os.environ['SREC_BENCH_CAPS'])
-            caps = dict(B=B, N=max(c, caps['N']), E=max(c, caps['E']), U=max(c, caps['U']))
         print('bench caps', caps, file=sys.stderr)
     fn = factory(caps)
     return [fn(s) for s in mine], samples
@@ -538,7 +535,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps each; value = the median region')
-    ap.add_argument('--model', default=os.environ.get('SREC_BENCH_MODEL', 'MSGIFSR'))
+    ap.add_argument('--model', default='MSGIFSR')
     ap.add_argument('--order', type=int, default=3)
     ap.add_argument('--dim', type=int, default=256)
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)

@@ -160,12 +160,11 @@ int srec_copy_words(const int* src, int* dst, long n, void* stream);
 /* ---- per-session kernels (segops.hip): one wavefront per session ------------------------------------
  * attention readout core: srgnn.py:79-86 niser.py:77-84 lessr.py:106-113 msgifsr.py:139-146 */
 int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const float* X, int ld_x,
-                      const int* seg, int B, const int* dynB, int h, int D, float* alpha, float* out, int ld_out,
-                      const float* bu, void* out_hi, void* out_lo, int ld16, void* stream);
+                      const int* seg, int B, const int* dynB, int h, int D, float* alpha, float* out, int ld_out, void* stream);
 int srec_seg_attn_bwd(const float* dout, int ld_do, const float* X, int ld_x, const float* alpha, const float* U,
                       int ld_u, const float* Vq, int ld_v, const float* we, const int* seg, int B, const int* dynB,
                       int h, int D, int n_cap, float* dX, int ld_dx, float* dU, int ld_du, float* dVq, int ld_dv,
-                      float* dwe_part, int ld_dw, const float* bu, void* dU16, void* dV16, void* dW16, void* stream);
+                      float* dwe_part, int ld_dw, void* stream);
 /* (bu, nullable: bias of the U product added inside, sigmoid(U + bu + Vq[b]) - msgifsr.py:114-115 puts the bias on fc_u;
  * out_hi / out_lo [B, ld16] and dU16 [2][n_cap, h] / dV16, dW16 [2][B, h], nullable: bf16 hi / lo splits of the outputs, the
  * operand copies of the 3-term split products of the read-out head - csrc/split16.hip; dU may be NULL when dU16 is given) */
@@ -335,11 +334,6 @@ int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
  * Replaces the chain of cuBLAS calls of the attention read-out / session-vector head (msgifsr.py:127-146,272-279;
  * srgnn.py:73-88,123-127) and their backward. */
 int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream);
-/* The same with the split-K sums of skinny problems done INSIDE the launch (the workgroup that arrives last at an output tile
- * adds the partial tiles in slab order: bit-identical to the separate reduce launch, one kernel node less per group).
- * tickets: n_tickets device ints, all zero before the first call, owned by this entry point (left zero by every launch). */
-int srec_gemm_f32_group_run_fused(const void* desc, float* ws, long ws_floats, int* tickets, int n_tickets, void* stream);
-
 /* bf16-in-HBM grouped GEMMs (gemm16.hip): the GAT fc projections and their backward (gatconv.py:166-175,282-283) with every
  * operand already stored as bf16 - LDS-DMA staging, no conversion pass.  desc: host srec_gemm16_group (srec_hg.h, up to 16
  * problems per launch).
@@ -356,35 +350,17 @@ int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, int d, void*
 /* out [C, n] = sum_r part [C, R, n] in fixed order (the row-split weight-gradient products of one module), n % 4 == 0 */
 int srec_sum_slabs(const float* part, int C, int R, long n, float* out, void* stream);
 int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, void* stream);
-/* the same, the transposed copies in MFMA-fragment-major order (B operands of srec_gemm16_nt with c16 bit 11: fragment
- * (c / 32, r / 16) of W_i^T = 64 lanes x 8 bf16, lane (c % 32) + 32 ((r / 8) % 2)); R_i % 16 == 0, C_i % 32 == 0.
- * Replaces the transposed weight operand of the backward-data product of gatconv.py:267-270 (fc) under autograd. */
-int srec_weights_bf16_frag(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, void* stream);
 /* MSGIFSR after its last MSHGNN layer in ONE launch each way (csrc/rowops.hip): F.normalize of every node row
  * (msgifsr.py:260-263), the per-session concatenation of all orders' nodes (msgifsr.py:135, perm = cat_perm of the FlatBatch)
- * and the last-node picks (filter_nodes, msgifsr.py:264): allf [n_cap, D], invr [n_cap] = 1 / norm, pout_k [B, D]; optional
- * bf16 hi / lo splits of the outputs for the head's split products.  pick / pout / ld_p / p_hi / p_lo / ld16 / g_pick / ld_gp /
- * row0 / ncap / dyn_n are HOST arrays.  The backward writes EVERY row of dx [n_rows, D] (capacity padding as zeros). */
+ * and the last-node picks (filter_nodes, msgifsr.py:264): allf [n_cap, D], invr [n_cap] = 1 / norm, pout_k [B, D].
+ * pick / pout / ld_p / g_pick / ld_gp / row0 / ncap / dyn_n are HOST arrays.  The backward writes EVERY row of dx [n_rows, D] (capacity padding as zeros). */
 int srec_norm_perm_pick_fwd(const float* x, int ld_x, const int* perm, int n_cap, const int* dyn_t, int D, int eps_mode,
-                            float eps, float* allf, float* invr, void* a_hi, void* a_lo, int npick, int B, const int* dyn_b,
-                            const void* pick, const void* pout, const int* ld_p, const void* p_hi, const void* p_lo,
-                            const int* ld16, void* stream);
+                            float eps, float* allf, float* invr, int npick, int B, const int* dyn_b, const void* pick,
+                            const void* pout, const int* ld_p, void* stream);
 int srec_norm_perm_pick_bwd(const float* allf, const float* invr, const float* g_allf, int ld_g, const int* perm, int n_cap,
                             const int* cat_seg, int B, const int* dyn_b, int D, int npick, const void* pick, const void* g_pick,
                             const int* ld_gp, float* dx, int ld_dx, int nt, const int* row0, const int* ncap, const void* dyn_n,
                             int n_rows, void* stream);
-/* Exact-fp32 products on the bf16 matrix pipe (csrc/split16.hip): x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
- * a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi (2^-17 relative) as the three K-segments of ONE srec_gemm16_* problem.  Used by the
- * read-out / session-vector head (msgifsr.py:124-155,269-273; srgnn.py:76-91,142-144) in bf16 mode instead of fp32 MFMA.
- *   srec_split_bf16: nj <= 8 jobs, hi_j / lo_j [n_j, ld16_j] = split of src_j [n_j, d_j] (row stride ld_j; zero rows past
- *     *dyn_j).  HOST arrays of nj entries.
- *   srec_weights_split_bf16: n <= 8 matrices W_i [R_i, C_i] -> hi / lo copies and their transposes hiT / loT [C_i, R_i]
- *     (hiT / loT may be NULL arrays or hold NULLs). */
-int srec_split_bf16(int nj, const void* src, const int* ld, const int* n, const void* dyn, const int* d, const void* hi,
-                    const void* lo, const int* ld16, void* stream);
-int srec_weights_split_bf16(int n, const void* W, const int* R, const int* Cc, const void* hi, const void* lo, const void* hiT,
-                            const void* loT, void* stream);
-
 /* k-gram GRU of the SemanticExpander, all orders per launch (grux.hip; msgifsr.py:25,32-45): desc = host
  * srec_gru_step_desc (srec_hg.h).  d % 4 == 0 and 256 % (d / 4) == 0. */
 int srec_gru_step_fwd(const void* desc, void* stream);

@@ -95,10 +95,7 @@ typedef struct {
 typedef struct {
     int np, lda, ldb, ldc;
     float beta;
-    int c16;                       /* bit 0: C outputs are bf16 (nt only); bit 1: leave output rows past *dyn unwritten; bits 4-7:
-                                      kernel variant (development; 0 = tuned default); bit 9: plain tile order; bit 10: forward kernel
-                                      with the weights in registers; bit 11 (nt, fp32 output, N % 128 == 0, K % 64 == 0): the B operands
-                                      are in MFMA-fragment-major order (srec_weights_bf16_frag) */
+    int c16;                       /* bit 0: C outputs are bf16 (nt only); bit 1: leave output rows past *dyn unwritten */
     int M[SREC_G16_MAXP], N[SREC_G16_MAXP], K[SREC_G16_MAXP], nseg[SREC_G16_MAXP];
     const void* A[SREC_G16_MAXP][SREC_G16_MAXS];
     const void* B[SREC_G16_MAXP][SREC_G16_MAXS];

@@ -250,10 +250,6 @@ struct GroupK {
     int tile_end[SREC_GEMM32_MAXP];      // prefix sums of workgroups per problem
     int tiles_n[SREC_GEMM32_MAXP], tiles_mn[SREC_GEMM32_MAXP];
     long ws_off[SREC_GEMM32_MAXP];       // slab offsets (floats) of the split problems
-    // in-kernel split-K fix-up: one arrival counter per output tile of a split problem (all zero between launches); the
-    // workgroup that arrives LAST at a tile adds the nsplit partial tiles in slab order and writes C - no reduce launch
-    int* tickets;
-    int tk_off[SREC_GEMM32_MAXP];
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GroupK k) {
@@ -278,49 +274,6 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GroupK k) {
     else if (bkc) SREC_TILE(false, true);
     else SREC_TILE(false, false);
 #undef SREC_TILE
-    if (nsplit <= 1 || k.tickets == nullptr) return;
-    // ---- fix-up.  Every workgroup of the tile has written its partial tile to its slab; the partials become visible device-wide
-    // (the slabs of one tile come from workgroups on different XCDs = different L2s) by the release fence in front of the
-    // arrival count, the last arrival acquires them.  The sum runs over the slabs in index order whoever arrives last:
-    // bit-identical to splitk_reduce_group_kernel, deterministic.
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int* tk = k.tickets + k.tk_off[p] + r;
-        const int seen = atomicAdd(tk, 1);
-        s_last = seen == nsplit - 1;
-        if (s_last) *tk = 0;                               // ready for the next launch (nobody else touches it any more)
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const int M = g.M[p], N = g.N[p];
-    const int Ml = g.dyn_mode[p] == 1 ? dyn_count(g.dyn[p], M) : M;
-    const float alpha = g.alpha[p], beta = g.beta[p];
-    const float* __restrict__ bias = g.bias[p];
-    for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
-        const int row = by * 64 + (idx >> 4), col = bx * 64 + ((idx & 15) << 2);
-        if (row >= M || col >= N) continue;
-        const size_t i = (size_t)row * N + col;
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < nsplit; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * M * N + i);
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-        }
-        float* c = g.C[p] + (size_t)row * g.ldc[p] + col;
-        if (row >= Ml) {
-            if (beta == 0.f) *reinterpret_cast<float4*>(c) = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        float o[4] = {alpha * sum.x, alpha * sum.y, alpha * sum.z, alpha * sum.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (bias != nullptr) o[j] += bias[col + j];
-            if (beta != 0.f) o[j] += beta * c[j];
-        }
-        *reinterpret_cast<float4*>(c) = make_float4(o[0], o[1], o[2], o[3]);
-    }
 }
 
 // the split problems of a group, reduced in one launch: blockIdx.y = problem
@@ -440,17 +393,9 @@ extern "C" int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B,
 
 // Grouped form of srec_gemm_f32 (same operand conventions per problem).  The split of skinny long-K problems is chosen
 // here (g->nsplit is ignored on input); ws / ws_floats = the shared slab workspace.
-static int gemm_f32_group_run_impl(const void* desc, float* ws, long ws_floats, int* tickets, int n_tickets, void* stream);
+// (split-K sums inside the launch - "the last workgroup to arrive at a tile adds the slabs" - were measured at +130 us per
+// step: the device-scope fences write back / invalidate whole L2s, profiles/r03_notes.md; the reduce stays a launch of its own)
 extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream) {
-    return gemm_f32_group_run_impl(desc, ws, ws_floats, nullptr, 0, stream);
-}
-// the same with the split-K sums done inside the launch: tickets = n_tickets device ints, ALL ZERO before the first call and
-// used by nothing else (every launch leaves them zero again); one per output tile of a split problem - a group that needs
-// more than n_tickets falls back to the separate reduce launch
-extern "C" int srec_gemm_f32_group_run_fused(const void* desc, float* ws, long ws_floats, int* tickets, int n_tickets, void* stream) {
-    return gemm_f32_group_run_impl(desc, ws, ws_floats, tickets, n_tickets, stream);
-}
-static int gemm_f32_group_run_impl(const void* desc, float* ws, long ws_floats, int* tickets, int n_tickets, void* stream) {
     const srec_gemm_f32_group* gin = (const srec_gemm_f32_group*)desc;
     if (gin->np <= 0) return 0;
     if (gin->np > SREC_GEMM32_MAXP) return SREC_BAD_ARG;
@@ -526,13 +471,10 @@ static int gemm_f32_group_run_impl(const void* desc, float* ws, long ws_floats, 
         }
     }
     end = 0;
-    int n_tk = 0;
     for (int p = 0; p < k.g.np; ++p) {
         srec_gemm_f32_group& g = k.g;
         const int nsplit = g.nsplit[p];
         k.ws_off[p] = ws_used;
-        k.tk_off[p] = n_tk;
-        if (nsplit > 1) n_tk += k.tiles_mn[p];
         if (nsplit > 1) {
             ws_used += (long)nsplit * g.M[p] * g.N[p];
             any_split = 1;
@@ -543,9 +485,8 @@ static int gemm_f32_group_run_impl(const void* desc, float* ws, long ws_floats, 
         k.tile_end[p] = end;
     }
     hipStream_t st = (hipStream_t)stream;
-    k.tickets = (tickets != nullptr && n_tk <= n_tickets) ? tickets : nullptr;
     hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(end), dim3(256), 0, st, k);
-    if (any_split && k.tickets == nullptr)
+    if (any_split)
         hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(max_red, k.g.np), dim3(256), 0, st, k);
     SREC_LAUNCH_CHECK();
     return 0;

@@ -43,8 +43,6 @@ struct G16Args {
     int keep_dead;                // leave output rows past the live count unwritten (nobody reads them)
     int per_xcd;                  // > 0: XCD-aware tile order (see xcd_tile), tiles per XCD
     int xcd_gs;                   // > 0: sibling groups of xcd_gs tiles dealt to the XCDs round-robin instead of runs
-    int xcd_cols;                 // > 0: column tiles are dealt to the XCDs (XCD x owns xcd_cols consecutive column tiles of EVERY row block):
-    int cs[G16_MAXP + 1];         //      prefix sums of (row blocks x xcd_cols) slots per problem
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -70,19 +68,6 @@ __device__ __forceinline__ void glds16(const unsigned short* sbase, unsigned vof
 // share an operand slab) are dealt round-robin instead: siblings still sit behind one L2, dead tails spread over all XCDs.
 __device__ __forceinline__ int xcd_tile(const G16Args& g) {
     const int b = (int)blockIdx.x;
-    if (g.xcd_cols > 0) {
-        // wide bf16 outputs (the forward projections, N = 8 x xcd_cols column tiles): the weight rows of a column tile are read
-        // by ONE XCD for all row blocks (each L2 holds 1/8 of every weight matrix instead of all of them: the forward pulled
-        // 8 x 8 MB of weights out of HBM, profiles/r03_pmc_gemm_gru.json)
-        const int x = b & 7, sl = b >> 3;
-        int p = 0;
-#pragma unroll
-        for (int i = 1; i < G16_MAXP; ++i)
-            if (i < g.np && sl >= g.cs[i]) p = i;
-        if (sl >= g.cs[g.np]) return g.start[g.np];             // padding slot: no tile
-        const int q = sl - g.cs[p];
-        return g.start[p] + (q / g.xcd_cols) * (8 * g.xcd_cols) + x * g.xcd_cols + q % g.xcd_cols;
-    }
     if (g.xcd_gs > 0) {
         const int x = b & 7, l = b >> 3;
         return ((l / g.xcd_gs) * 8 + x) * g.xcd_gs + l % g.xcd_gs;
@@ -121,9 +106,7 @@ constexpr int NS = 4, PD = 3;        // default LDS ring: 4 stages, 3 stages of 
 // barriers - a 4-stage ring keeps 3 stages in flight per workgroup, and 16 KB stages leave room for 2-3 workgroups
 // per CU.  Piece p of tile row r sits in slot p ^ ((r >> 2) & 3): the 16 lanes of every ds_read_b128 group hit 16
 // distinct 16-B slots.
-// NW: waves per workgroup, 2 x (NW / 2): 4, or 8 for the 128 x 256 tile that covers the whole skinny output of a backward-data
-// problem (the dP row block is fetched once instead of once per 128-column sibling tile: profiles/r03_pmc_gemm_gru.json had 195 MB
-// of HBM traffic for a 90-MB dP)
+// NW: waves per workgroup, 2 x (NW / 2)
 template <int TM, int TN, bool C16, int BK = 32, int NS = 4, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm16_nt_kernel(G16Args g) {
     constexpr int WN = NW / 2, NT = 64 * NW;          // waves along N, threads
@@ -325,250 +308,6 @@ __global__ __launch_bounds__(64 * NW) void gemm16_nt_kernel(G16Args g) {
 #endif
 }
 
-// -------------------------------------------------------------------------------------------------- nt16, B operand straight from L2
-// Backward-data of the GAT projections (C [M, 256] fp32 = sum_s dP_s [M, 2048] W_s): a long reduction into a skinny output.  The
-// tiled kernel above stages BOTH operands through LDS: per 64-deep k-step a 64 x 128 tile pulls 8 KB of dP and 16 KB of W^T by
-// LDS-DMA and has ONE stage in flight (48 KB of LDS -> 3 workgroups per CU), i.e. every k-step costs a memory latency.  Here
-// the weights come in FRAGMENT-MAJOR order (srec_weights_bf16_frag: the 64 lanes x 16 B of one MFMA B operand contiguous,
-// fragments ordered column block / k-step) and go straight from L2 into the registers that feed the MFMAs - plain coalesced
-// 1-KiB loads through a register ring, no LDS write, no LDS read, no barrier dependency; only the 8-KB dP stages go through the
-// LDS-DMA ring.  PD stages of both operands are in flight per workgroup (the tiled kernel: one), the LDS-DMA pieces per stage
-// drop from 24 to 8 and the LDS fragment reads from 12 to 4 per k-step and wave.
-// vmcnt bookkeeping: the DMA instructions are inline asm the compiler does not count, the B loads are compiler loads the asm
-// waits do not know.  Both only ever make a wait MORE conservative: every issue group is [2 DMA, 8 B loads] in program order
-// ("memory"-clobbering asm keeps the loads from moving across), so "stage it's DMA has landed" = at most 8 + (PD - 1) * 10
-// younger operations outstanding; the tail re-issues the last group instead of branching, so the count never changes.
-template <int PD>
-__global__ __launch_bounds__(256, 3) void gemm16_nt_bfrag_kernel(G16Args g) {
-    constexpr int TM = 64, TN = 128, BK = 64, NSA = PD + 1;
-    constexpr int PPR = BK / 8, RPI = 512 / BK, FS = 1;              // as gemm16_nt_kernel at BK = 64
-    constexpr int STG = TM * BK;                                      // bf16 elements per A stage (8 KB)
-    constexpr int IPS = (TM / RPI) / 4;                               // DMA instructions per stage and wave (2)
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int bid = xcd_tile(g);
-    if (bid >= g.start[g.np]) return;
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < G16_MAXP; ++i)
-        if (i < g.np && bid >= g.start[i]) p = i;
-    const int M = g.M[p], N = g.N[p], K = g.K[p];
-    const int tn = N / TN, tile = bid - g.start[p];
-    const int m0 = (tile / tn) * TM, n0 = (tile % tn) * TN;
-    const int Ml = dyn_count(g.dyn[p], M);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    float* __restrict__ C = static_cast<float*>(g.C[p]);
-    if (m0 >= Ml) {                                      // tile of capacity padding: zero rows when overwriting
-        if (!g.keep_dead && g.beta == 0.f)
-            for (int i = tid; i < TM * TN / 4; i += 256) {
-                const int r = m0 + (i * 4) / TN, c = n0 + (i * 4) % TN;
-                if (r < M) *reinterpret_cast<float4*>(C + (size_t)r * g.ldcp[p] + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        return;
-    }
-    f32x16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int nk = K / BK, total = nk * g.nseg[p];
-    const unsigned lds0 = lds_addr(smem);
-    const int rl = lane / PPR, sl = lane % PPR;
-    unsigned voff[IPS];
-#pragma unroll
-    for (int ii = 0; ii < IPS; ++ii) {
-        const int r = RPI * (ii * 4 + wave) + rl;
-        voff[ii] = ((unsigned)min(r, Ml - 1 - m0) * (unsigned)g.ldap[p] + (unsigned)((sl ^ ((r >> FS) & (PPR - 1))) * 8)) * 2u;
-    }
-    // issue stream (wave-uniform): K segment and k of the next group; B: fragment (column block cb, k-step s) of a segment at
-    // ((cb * (K / 16) + s) * 64 + lane) * 8
-    int is_seg = 0, is_k = 0, is_it = 0;
-    const unsigned short* Aseg = g.A[p][0] + (size_t)m0 * g.ldap[p];
-    const size_t cbs = (size_t)(K / 16) * 512;                       // elements between column blocks
-    const unsigned short* Bseg = g.B[p][0] + (size_t)((n0 + wn * 64) / 32) * cbs + lane * 8;
-    bf16x8 Bq[NSA][4][2];
-    auto issue = [&](int slot) {
-        const unsigned dst = lds0 + (unsigned)((is_it % NSA) * STG) * 2u;
-#pragma unroll
-        for (int ii = 0; ii < IPS; ++ii) glds16(Aseg + is_k, voff[ii], dst + (unsigned)(ii * 4 + wave) * 1024u);
-        const unsigned short* bp = Bseg + (size_t)(is_k / 16) * 512;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) Bq[slot][ks][j] = *reinterpret_cast<const bf16x8*>(bp + ks * 512 + j * cbs);
-        if (is_it + 1 < total) {                         // (the tail re-issues the last group: same instruction counts)
-            ++is_it;
-            is_k += BK;
-            if (is_k >= K) {
-                is_k = 0;
-                ++is_seg;
-                Aseg = g.A[p][is_seg] + (size_t)m0 * g.ldap[p];
-                Bseg = g.B[p][is_seg] + (size_t)((n0 + wn * 64) / 32) * cbs + lane * 8;
-            }
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < PD; ++s) issue(s);
-    for (int it0 = 0; it0 < total; it0 += NSA) {
-#pragma unroll
-        for (int u = 0; u < NSA; ++u) {
-            const int it = it0 + u;
-            if (it < total) {                            // wave-uniform
-                wait_vm<8 + (PD - 1) * (IPS + 8)>();     // this wave's DMA pieces of stage `it` have landed ...
-                __syncthreads();                         // ... everyone's have; stage it - 1's buffer is free again
-                issue((u + PD) % NSA);
-                const unsigned short* As = smem + (it % NSA) * STG;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int r = wm * 32 + l31;
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + r * BK + (((2 * ks + half) ^ ((r >> FS) & (PPR - 1))) << 3));
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bq[u][ks][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bq[u][ks][1], acc[1], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < M) {
-                float* q = C + (size_t)row * g.ldcp[p] + col;
-                if (row < Ml) *q = g.beta != 0.f ? acc[j][r] + g.beta * *q : acc[j][r];
-                else if (g.beta == 0.f && !g.keep_dead) *q = 0.f;
-            }
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------- nt16, weights in registers
-// The forward projections P_m = x_m W_m^T are short reductions (K = D <= 256) into wide outputs (N = H D = 2048): with output
-// tiles, every 128 x 128 tile re-stages its 64 KB A block and its 64 KB W block through LDS - 245 MB of LDS-DMA for 63 MB of
-// output, and the launch is bound by the rate at which a CU issues 1-KiB LDS-DMA pieces (~115 cycles each, tools/g16_timing.py),
-// not by bytes or MFMAs.  Here a wave OWNS 64 output columns for its whole life: their W rows (64 x K bf16 = 32 KB at K = 256)
-// sit in 128 VGPRs as ready-made MFMA fragments, loaded once straight from L2; the workgroup (4 waves = 256 consecutive
-// columns = one head at D = 256) streams 32-row chunks of x through a small LDS ring, every chunk is read by all four waves.
-// LDS-DMA pieces: 16 per 32 rows and column group instead of 64 -> a quarter of the issue slots; per MFMA half the LDS
-// fragment reads (one A fragment feeds both column halves).  Workgroups that share rows (the 8 column groups of one row
-// group) are consecutive slots of ONE XCD: x is pulled from HBM once.
-// Accumulator transposed as in nt16<C16> (lane = output row), leaves through a per-wave LDS patch as 16-B stores.
-template <int KD, int NSTG>
-__global__ __launch_bounds__(256, 2) void gemm16_fwd_wres_kernel(G16Args g, int cpw, int tiles_per_xcd) {
-    constexpr int KS = KD / 16;                          // MFMA k-steps
-    constexpr int PPR = KD / 8;                          // 16-B pieces per x row
-    constexpr int RPI = 512 / KD;                        // x rows per 1-KiB DMA instruction
-    constexpr int NI = 32 / RPI, IPS = NI / 4;           // DMA instructions per chunk: all, per wave
-    constexpr int STG = 32 * KD;                         // bf16 elements per stage
-    constexpr int LDP = 64 + 8;                          // patch row (bf16 elements): 144 B, conflict-free 8-B writes
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    if (slot >= tiles_per_xcd) return;
-    const int bid = xcd * tiles_per_xcd + slot;
-    if (bid >= g.start[g.np]) return;
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < G16_MAXP; ++i)
-        if (i < g.np && bid >= g.start[i]) p = i;
-    const int M = g.M[p], N = g.N[p];
-    const int ncg = N / 256, tile = bid - g.start[p];
-    const int m0 = (tile / ncg) * (32 * cpw), nb = (tile % ncg) * 256;
-    const int Ml = dyn_count(g.dyn[p], M);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int n0 = nb + wave * 64;
-    unsigned short* __restrict__ Cp = static_cast<unsigned short*>(g.C[p]);
-    const int ldc = g.ldcp[p];
-    const int rows_here = min(32 * cpw, M - m0);
-    if (m0 >= Ml) {                                      // row group of capacity padding
-        if (!g.keep_dead)
-            for (int i = tid; i < rows_here * 32; i += 256)          // 32 16-B pieces per 256-column row slice
-                *reinterpret_cast<uint4*>(Cp + (size_t)(m0 + i / 32) * ldc + nb + (i % 32) * 8) = make_uint4(0u, 0u, 0u, 0u);
-        return;
-    }
-    // this wave's W rows as the FIRST MFMA operand (rows of D^T = output columns): row n0 + 32 cg + l31, k = 16 ks + 8 half ..
-    bf16x8 wf[2][KS];
-    {
-        const unsigned short* wp = g.B[p][0] + (size_t)(n0 + l31) * g.ldbp[p] + 8 * half;
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                wf[cg][ks] = *reinterpret_cast<const bf16x8*>(wp + (size_t)cg * 32 * g.ldbp[p] + ks * 16);
-    }
-    const int nch = min(cpw, (Ml - m0 + 31) / 32);
-    const unsigned lds0 = lds_addr(smem);
-    unsigned short* patch = smem + NSTG * STG + wave * (32 * LDP);
-    // DMA instruction i of a chunk: x rows RPI i .. of the chunk; lane -> (row l / PPR, slot l % PPR); piece = slot ^ (row & 15)
-    // (the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots of the 256-B bank cycle)
-    const int rl = lane / PPR, sl = lane % PPR;
-    const unsigned short* Ab = g.A[p][0];
-    const unsigned lda = (unsigned)g.ldap[p];
-    auto stage = [&](int c) {
-        const unsigned dst = lds0 + (unsigned)((c % NSTG) * STG) * 2u;
-#pragma unroll
-        for (int ii = 0; ii < IPS; ++ii) {
-            const int i = ii * 4 + wave;
-            const int r = RPI * i + rl;                  // row inside the chunk
-            const int gr = min(m0 + 32 * c + r, Ml - 1);
-            glds16(Ab, ((unsigned)gr * lda + (unsigned)((sl ^ (r & 15)) * 8)) * 2u, dst + (unsigned)i * 1024u);
-        }
-    };
-    constexpr int PDW = NSTG - 1;
-    for (int c = 0; c < PDW && c < nch; ++c) stage(c);
-    for (int c = 0; c < nch; ++c) {
-        wait_stage<IPS, PDW>(min(nch - c - 1, PDW - 1));
-        __syncthreads();
-        if (c + PDW < nch) stage(c + PDW);
-        const unsigned short* As = smem + (c % NSTG) * STG;
-        f32x16 acc[2];
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cg][r] = 0.f;
-        constexpr int PF = 4;
-        bf16x8 af[PF];
-#pragma unroll
-        for (int j = 0; j < PF; ++j) af[j] = *reinterpret_cast<const bf16x8*>(As + l31 * KD + (((2 * j + half) ^ (l31 & 15)) << 3));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], af[ks % PF], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], af[ks % PF], acc[1], 0, 0, 0);
-            if (ks + PF < KS)
-                af[ks % PF] = *reinterpret_cast<const bf16x8*>(As + l31 * KD + (((2 * (ks + PF) + half) ^ (l31 & 15)) << 3));
-        }
-        // epilogue of the chunk: acc[cg] = D^T, lane <-> output row l31, register r <-> column 32 cg + (r & 3) + 8 (r >> 2) + 4 half
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint2 v;
-                v.x = srec_pack_bf16(acc[cg][4 * q], acc[cg][4 * q + 1]);
-                v.y = srec_pack_bf16(acc[cg][4 * q + 2], acc[cg][4 * q + 3]);
-                *reinterpret_cast<uint2*>(patch + l31 * LDP + cg * 32 + 8 * q + 4 * half) = v;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int idx = t * 64 + lane, rr = idx >> 3, pc = idx & 7;
-            const int row = m0 + 32 * c + rr;
-            uint4 v = *reinterpret_cast<const uint4*>(patch + rr * LDP + pc * 8);
-            if (row >= M || (g.keep_dead && row >= Ml) ) continue;
-            if (row >= Ml) v = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc + n0 + pc * 8) = v;
-        }
-        __builtin_amdgcn_wave_barrier();                 // (the next chunk's patch writes come after these reads)
-    }
-    // rows of this group behind the live count (the chunk loop stopped at the last live chunk)
-    if (!g.keep_dead)
-        for (int i = tid + 32 * nch * 32; i < rows_here * 32; i += 256)
-            *reinterpret_cast<uint4*>(Cp + (size_t)(m0 + i / 32) * ldc + nb + (i % 32) * 8) = make_uint4(0u, 0u, 0u, 0u);
-}
-
 // -------------------------------------------------------------------------------------------------- tn16
 // C[N1, N2] = sum_{m < live} A[m, N1] B[m, N2]; tile 128 x 128, reduction staged 32 rows at a time through the same
 // 4-stage ring.  Both operand tiles sit in LDS ROW-major ([32 reduction rows][128 columns], 256-B rows, filled by
@@ -732,7 +471,6 @@ struct WArgs {
     unsigned short* WT16[8];
     int R[8], Cc[8], start[9];
     int n;
-    int frag;                     // WT16 in MFMA-fragment-major order (gemm16_nt_bfrag_kernel) instead of row-major [C, R]
 };
 __global__ void weights_bf16_kernel(WArgs a) {
     __shared__ unsigned short tile[64][68];
@@ -764,10 +502,7 @@ __global__ void weights_bf16_kernel(WArgs a) {
             if (c < Cc && r < R) {
                 const unsigned lo = tile[4 * x][cc] | ((unsigned)tile[4 * x + 1][cc] << 16);
                 const unsigned hi = tile[4 * x + 2][cc] | ((unsigned)tile[4 * x + 3][cc] << 16);
-                // fragment-major: element (n = c, k = r) of W^T sits in fragment (c / 32, r / 16), lane (c % 32) + 32 ((r / 8) % 2), slot r % 8
-                const size_t off = a.frag ? ((size_t)((c >> 5) * (R >> 4) + (r >> 4)) * 64 + (c & 31) + 32 * ((r >> 3) & 1)) * 8 + (r & 7)
-                                          : (size_t)c * R + r;
-                *reinterpret_cast<uint2*>(a.WT16[t] + off) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2*>(a.WT16[t] + (size_t)c * R + r) = make_uint2(lo, hi);
             }
         }
         return;
@@ -853,8 +588,7 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     // skinny outputs (backward-data: N = D) take 64-row tiles: twice the workgroups over the same HBM stream
     int nmax = 0;
     for (int p = 0; p < h->np; ++p) nmax = h->N[p] > nmax ? h->N[p] : nmax;
-    const int variant = (h->c16 >> 4) & 15;              // experiments (tools/gemm16_bench.py); 0 = tuned default
-    int tm = (variant & 8) ? ((variant & 4) ? 128 : 64) : ((t128 >= 384 && nmax > 256) ? 128 : 64);
+    int tm = (t128 >= 384 && nmax > 256) ? 128 : 64;
     // tiny products (the GRU hidden-state GEMMs: ~2k x 256 outputs): 64 x 64 tiles double the workgroups in flight
     long t64x128 = 0;
     for (int p = 0; p < h->np; ++p) t64x128 += (long)cdiv(Mh(p), 64) * cdiv(h->N[p], 128);
@@ -863,75 +597,20 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
     // kernels: 64 x 128 tiles with 2 x 64-deep stages = 48 KB -> 3 per CU = 96 slots per XCD; 128 x 128 = 64 KB -> 2 per CU =
     // 64 slots, workgroup life +5 % for twice the work (tools/gemm16_bench.py).  The step's backward-data launch (960 64-row
     // tiles = 120 per XCD) ran 1.25 -> 2 rounds: 77 us; as 480 128-row tiles (60 per XCD) it is one round.
-    if (!(variant & 8) && !(h->c16 & 1) && tm == 64 && t64x128 > 384) {
+    if (!(h->c16 & 1) && tm == 64 && t64x128 > 384) {
         const long r64 = cdiv((int)cdiv((int)t64x128, 8), 96), r128 = cdiv((int)cdiv((int)t128, 8), 64);
         // ... and when the rounds tie, the 128-row tiles win on BYTES: these launches run at what the L2s deliver to the CUs
-        // (8 - 12 TB/s in every variant, profiles/r03_notes.md) and a 128 x 128 tile fetches 2/3 of the operand bytes of two
+        // (8 - 12 TB/s in every staging variant, profiles/r03_notes.md) and a 128 x 128 tile fetches 2/3 of the operand bytes of two
         // 64 x 128 tiles per output - as long as there is at least one workgroup per CU (65.4 -> 55.1 us at the bench shapes)
         if (r128 * 105 < r64 * 100 || (r128 <= r64 && t128 >= 256)) tm = 128;
     }
-    // forward projections (bf16 output, one K segment, K = 128 / 256, N a multiple of 256): c16 bit 10 selects the
-    // weights-in-registers kernel.  Measured (tools/fwd_wres_bench.py, profiles/r03_notes.md): bit-identical results, 50 vs 53 us
-    // at the step's capacities, 39 vs 34 us at loose ones, no difference inside the step (0.935 vs 0.934 ms) - a quarter of
-    // the LDS-DMA pieces did not move the launch, so the piece rate is not what bounds it; the tiled kernel stays the default
-    if ((h->c16 & 1) && ((h->c16 >> 10) & 1) && !(variant & 8)) {
-        bool ok = true;
-        for (int p = 0; p < h->np; ++p)
-            ok = ok && h->nseg[p] == 1 && (h->K[p] == 256 || h->K[p] == 128) && h->K[p] == h->K[0] && (h->N[p] & 255) == 0 &&
-                 ((h->ldc_p[p] > 0 ? h->ldc_p[p] : h->ldc) & 7) == 0 && (((uintptr_t)h->C[p]) & 15) == 0;
-        if (ok) {
-            // chunks (32 rows) per workgroup: ~2 workgroups per CU over the LIVE rows
-            long units = 0;
-            for (int p = 0; p < h->np; ++p) units += (long)cdiv(Mh(p), 32) * (h->N[p] / 256);
-            int cpw = (int)cdiv((int)units, 512);
-            cpw = cpw < 2 ? 2 : (cpw > 16 ? 16 : cpw);
-            if (int rc = fill(g, desc_, 32 * cpw, 256, false, blocks)) return rc;
-            const int tiles_per_xcd = cdiv(blocks, 8);
-            hipStream_t st0 = (hipStream_t)stream;
-            static std::atomic<unsigned long long> om2[2];
-            if (h->K[0] == 256) {
-                const size_t lds = (size_t)3 * 32 * 256 * 2 + 4 * 32 * 72 * 2;
-                if (int rc = optin(gemm16_fwd_wres_kernel<256, 3>, (int)lds, om2[0])) return rc;
-                hipLaunchKernelGGL((gemm16_fwd_wres_kernel<256, 3>), dim3(8 * tiles_per_xcd), dim3(256), lds, st0, g, cpw, tiles_per_xcd);
-            } else {
-                const size_t lds = (size_t)4 * 32 * 128 * 2 + 4 * 32 * 72 * 2;
-                if (int rc = optin(gemm16_fwd_wres_kernel<128, 4>, (int)lds, om2[1])) return rc;
-                hipLaunchKernelGGL((gemm16_fwd_wres_kernel<128, 4>), dim3(8 * tiles_per_xcd), dim3(256), lds, st0, g, cpw, tiles_per_xcd);
-            }
-            SREC_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    if ((h->c16 >> 11) & 1) {
-        // B operands in fragment-major order (srec_weights_bf16_frag): the backward-data kernel that feeds them from L2 into
-        // registers.  fp32 output, 64 x 128 tiles, N % 128 == 0, K % 64 == 0 - anything else cannot read this layout
-        if (h->c16 & 1) return SREC_BAD_ARG;
-        for (int p = 0; p < h->np; ++p)
-            if ((h->N[p] & 127) || (h->K[p] & 63)) return SREC_BAD_ARG;
-        if (int rc = fill(g, desc_, 64, 128, false, blocks)) return rc;
-        bool same_tn = true;
-        const int tn0 = h->N[0] / 128;
-        for (int p = 1; p < h->np; ++p) same_tn = same_tn && h->N[p] / 128 == tn0;
-        if (same_tn && rows_live * 10 < rows_cap * 9) { g.xcd_gs = tn0; blocks = cdiv(blocks, 8 * tn0) * 8 * tn0; }
-        else { g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd; }
-        hipStream_t stf = (hipStream_t)stream;
-        if (variant == 3) hipLaunchKernelGGL((gemm16_nt_bfrag_kernel<3>), dim3(blocks), dim3(256), (size_t)4 * 64 * 64 * 2, stf, g);
-        else if (variant == 1) hipLaunchKernelGGL((gemm16_nt_bfrag_kernel<1>), dim3(blocks), dim3(256), (size_t)2 * 64 * 64 * 2, stf, g);
-        else hipLaunchKernelGGL((gemm16_nt_bfrag_kernel<2>), dim3(blocks), dim3(256), (size_t)3 * 64 * 64 * 2, stf, g);
-        SREC_LAUNCH_CHECK();
-        return 0;
-    }
-    // skinny fp32 outputs of exactly 256 columns in 128-row tiles (the GAT backward-data launch at d = 256): one 8-wave workgroup
-    // covers the whole row block - dP is fetched once instead of once per 128-column sibling.  Measured 64 us against 55 - 60 for
-    // the 128 x 128 tiles (180 workgroups on 256 CUs): opt-in, variant 7
-    bool wide = !(h->c16 & 1) && tm == 128 && variant == 7;
-    for (int p = 0; wide && p < h->np; ++p) wide = h->N[p] == 256 && (h->K[p] & 63) == 0;
-    const int tn = wide ? 256 : (tm == 64 && t64x128 < 192 && !(variant & 8)) ? 64 : 128;
+    // (measured and removed again, numbers in profiles/r03_notes.md: a forward kernel with the weights in registers, a
+    //  backward-data kernel fed with fragment-major weights from L2, 128 x 256 8-wave tiles, column tiles dealt to XCDs)
+    const int tn = (tm == 64 && t64x128 < 192) ? 64 : 128;
     if (int rc = fill(g, desc_, tm, tn, false, blocks)) return rc;
     // fp32-output launches (backward-data: two column tiles share every dP row block): 38.7 -> 34.5 us at the bench shapes; the
-    // bf16-output forward (sixteen column tiles per row block, all of x fits any L2) measured 1.5 us slower that way.  Bit 9:
-    // plain tile order (experiments)
-    if (!(h->c16 & 1) && !((h->c16 >> 9) & 1)) {
+    // bf16-output forward (sixteen column tiles per row block, all of x fits any L2) measured 1.5 us slower that way
+    if (!(h->c16 & 1)) {
         bool same_tn = true;
         const int tn0 = cdiv(h->N[0], tn);
         for (int p = 1; p < h->np; ++p) same_tn = same_tn && cdiv(h->N[p], tn) == tn0;
@@ -942,53 +621,28 @@ extern "C" int srec_gemm16_nt(const void* desc_, void* stream) {
             g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd;
         }
     }
-    if ((h->c16 & 1) && variant == 5) {
-        // bf16-output launches whose problems all have 8 k column tiles (the forward projections: 16 tiles of 128): column
-        // tiles to XCDs (xcd_tile).  Measured 47.0 against 45.4 us for the plain order: opt-in (variant 5)
-        bool ok = true;
-        const int tn0 = cdiv(h->N[0], tn);
-        for (int p = 0; p < h->np; ++p) ok = ok && cdiv(h->N[p], tn) == tn0;
-        if (ok && tn0 >= 8 && (tn0 & 7) == 0) {
-            g.xcd_cols = tn0 / 8;
-            int acc = 0;
-            for (int p = 0; p < h->np; ++p) { g.cs[p] = acc; acc += cdiv(h->M[p], tm) * g.xcd_cols; }
-            g.cs[h->np] = acc;
-            blocks = 8 * acc;
-        }
-    }
     hipStream_t st = (hipStream_t)stream;
     const bool c16 = h->c16 & 1;
-    static std::atomic<unsigned long long> optin_mask[32];
+    static std::atomic<unsigned long long> optin_mask[8];
 #define SREC_G16(TMV, TNV, C16V, BKV, NSV, slot)                                                                       \
     do {                                                                                                               \
         const size_t lds = (size_t)NSV * (TMV + TNV) * BKV * 2;                                                        \
         if (int rc = optin(gemm16_nt_kernel<TMV, TNV, C16V, BKV, NSV>, (int)lds, optin_mask[slot])) return rc;         \
         hipLaunchKernelGGL((gemm16_nt_kernel<TMV, TNV, C16V, BKV, NSV>), dim3(blocks), dim3(256), lds, st, g);         \
     } while (0)
-    if (wide) {                                          // 128 x 256 tiles, 8 waves: see the selection above
-        const size_t lds = (size_t)2 * (128 + 256) * 64 * 2;
-        if (int rc = optin(gemm16_nt_kernel<128, 256, false, 64, 2, 8>, (int)lds, optin_mask[20])) return rc;
-        hipLaunchKernelGGL((gemm16_nt_kernel<128, 256, false, 64, 2, 8>), dim3(blocks), dim3(512), lds, st, g);
-        SREC_LAUNCH_CHECK();
-        return 0;
-    }
     // measured at the bench's GAT shapes (tools/gemm16_bench.py): every ring lands at 33-40 us for the 16-GFLOP forward
-    // (the LDS fill rate, ~8 TB/s, bounds all of them; deeper rings lose more in occupancy than they gain in flight):
-    // defaults = 3 x 32-deep stages for the bf16-output forward, 2 x 64-deep stages for backward-data
-    const int ring = (variant & 8) ? (variant & 3) : (c16 ? 3 : 1);     // 0: BK 32 x 4 stages, 1: BK 64 x 2, 2: BK 32 x 2, 3: BK 32 x 3
-    // few workgroups (<= 1.5 per CU): LDS is plentiful and every workgroup is latency bound on its own DMA - a 4-stage
-    // ring keeps three 64-deep stages in flight instead of one
-    const bool deep = blocks <= 384 && !(variant & 8);
+    // (deeper rings lose more in occupancy than they gain in flight): 3 x 32-deep stages for the bf16-output forward,
+    // 2 x 64-deep stages for backward-data.  Few workgroups (<= 1.5 per CU): LDS is plentiful and every workgroup is latency
+    // bound on its own DMA - a 4-stage ring keeps three 64-deep stages in flight instead of one
+    const bool deep = blocks <= 384;
     if (tn == 64) {
-        if (c16) SREC_G16(64, 64, true, 64, 2, 16); else if (deep) SREC_G16(64, 64, false, 64, 4, 18); else SREC_G16(64, 64, false, 64, 2, 17);
+        if (c16) SREC_G16(64, 64, true, 64, 2, 0); else if (deep) SREC_G16(64, 64, false, 64, 4, 1); else SREC_G16(64, 64, false, 64, 2, 2);
     } else if (deep && tm == 64 && !c16) {
-        SREC_G16(64, 128, false, 64, 4, 19);
+        SREC_G16(64, 128, false, 64, 4, 3);
     } else if (tm == 128) {
-        if (c16) { if (ring == 0) SREC_G16(128, 128, true, 32, 4, 0); else if (ring == 1) SREC_G16(128, 128, true, 64, 2, 1); else if (ring == 2) SREC_G16(128, 128, true, 32, 2, 2); else SREC_G16(128, 128, true, 32, 3, 3); }
-        else { if (ring == 0) SREC_G16(128, 128, false, 32, 4, 4); else if (ring == 1) SREC_G16(128, 128, false, 64, 2, 5); else if (ring == 2) SREC_G16(128, 128, false, 32, 2, 6); else SREC_G16(128, 128, false, 32, 3, 7); }
+        if (c16) SREC_G16(128, 128, true, 32, 3, 4); else SREC_G16(128, 128, false, 64, 2, 5);
     } else {
-        if (c16) { if (ring == 0) SREC_G16(64, 128, true, 32, 4, 8); else if (ring == 1) SREC_G16(64, 128, true, 64, 2, 9); else if (ring == 2) SREC_G16(64, 128, true, 32, 2, 10); else SREC_G16(64, 128, true, 32, 3, 11); }
-        else { if (ring == 0) SREC_G16(64, 128, false, 32, 4, 12); else if (ring == 1) SREC_G16(64, 128, false, 64, 2, 13); else if (ring == 2) SREC_G16(64, 128, false, 32, 2, 14); else SREC_G16(64, 128, false, 32, 3, 15); }
+        if (c16) SREC_G16(64, 128, true, 32, 3, 6); else SREC_G16(64, 128, false, 64, 2, 7);
     }
 #undef SREC_G16
     SREC_LAUNCH_CHECK();
@@ -1011,19 +665,13 @@ extern "C" int srec_gemm16_tn(const void* desc_, void* stream) {
     G16Args g{};
     int blocks = 0;
     if (int rc = fill(g, desc_, 128, 128, true, blocks)) return rc;
-    if (!((((const srec_gemm16_group*)desc_)->c16 >> 9) & 1)) { g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd; }
-    const int variant = (((const srec_gemm16_group*)desc_)->c16 >> 4) & 15;
+    g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd;
     hipStream_t st = (hipStream_t)stream;
-    static std::atomic<unsigned long long> om[4];
-#define SREC_TN(BRV, NSV, slot)                                                                                        \
-    do {                                                                                                               \
-        const size_t lds = (size_t)NSV * 2 * BRV * 128 * 2;                                                            \
-        if (int rc = optin(gemm16_tn_kernel<BRV, NSV>, (int)lds, om[slot])) return rc;                                 \
-        hipLaunchKernelGGL((gemm16_tn_kernel<BRV, NSV>), dim3(blocks), dim3(256), lds, st, g);                         \
-    } while (0)
-    // default: 2 stages of 64 reduction rows (34 us at the bench shapes vs 37-38 for the 32-row rings)
-    if (variant == 1) SREC_TN(32, 2, 1); else if (variant == 3) SREC_TN(32, 3, 3); else if (variant == 4) SREC_TN(32, 4, 0); else SREC_TN(64, 2, 2);
-#undef SREC_TN
+    static std::atomic<unsigned long long> om;
+    // 2 stages of 64 reduction rows (34 us at the bench shapes vs 37-38 for the 32-row rings)
+    const size_t lds = (size_t)2 * 2 * 64 * 128 * 2;
+    if (int rc = optin(gemm16_tn_kernel<64, 2>, (int)lds, om)) return rc;
+    hipLaunchKernelGGL((gemm16_tn_kernel<64, 2>), dim3(blocks), dim3(256), lds, st, g);
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -1050,26 +698,12 @@ extern "C" int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, i
 
 // n <= 8 weight matrices W_i [R_i, C_i] fp32 (contiguous) -> bf16 copy W16_i and transposed bf16 copy WT16_i [C_i, R_i]
 // (WT16 entries may be NULL).  W / W16 / WT16 / R / Cc are HOST arrays of n entries.
-static int weights_bf16_impl(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, int frag,
-                             void* stream);
 extern "C" int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc,
                                  void* stream) {
-    return weights_bf16_impl(n, W, W16, WT16, R, Cc, 0, stream);
-}
-// the same with the transposed copies in MFMA-fragment-major order (B operands of srec_gemm16_nt with c16 bit 11):
-// fragment (c / 32, r / 16) of W_i^T = 64 lanes x 8 elements, lane (c % 32) + 32 ((r / 8) % 2); R_i % 16 == 0, C_i % 32 == 0
-extern "C" int srec_weights_bf16_frag(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc,
-                                      void* stream) {
-    for (int i = 0; i < n && i < 8; ++i)
-        if ((R[i] & 15) || (Cc[i] & 31)) return SREC_BAD_ARG;
-    return weights_bf16_impl(n, W, W16, WT16, R, Cc, 1, stream);
-}
-static int weights_bf16_impl(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc, int frag,
-                             void* stream) {
     if (n <= 0) return 0;
     if (n > 8 || W == nullptr || W16 == nullptr || WT16 == nullptr) return SREC_BAD_ARG;
     WArgs a{};
-    a.n = n; a.frag = frag;
+    a.n = n;
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
         a.W[i] = ((const float* const*)W)[i];

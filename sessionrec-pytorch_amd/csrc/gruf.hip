@@ -378,8 +378,7 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
         if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<DDV, NRV, NWV>, (int)lds, om[slot])) return rc;  \
         hipLaunchKernelGGL((gru_fused_fwd_kernel<DDV, NRV, NWV>), dim3(blocks), dim3(64 * NWV), lds, (hipStream_t)stream, a); \
     } while (0)
-    if (D == 256 && NWv == 8) { if (NRv == 16) SREC_GF(2, 16, 8, 4); else SREC_GF(2, 32, 8, 5); }
-    else if (D == 256) { if (NRv == 16) SREC_GF(2, 16, 4, 0); else SREC_GF(2, 32, 4, 1); }
+    if (D == 256) { if (NRv == 16) SREC_GF(2, 16, 8, 4); else SREC_GF(2, 32, 8, 5); }
     else { if (NRv == 16) SREC_GF(1, 16, 4, 2); else SREC_GF(1, 32, 4, 3); }
 #undef SREC_GF
     SREC_LAUNCH_CHECK();

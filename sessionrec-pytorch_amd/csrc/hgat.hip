@@ -1549,10 +1549,8 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     }
     if (rows > 0) {
         // wave-per-node kernel: 8 heads, 8-column lanes, 16-byte loads of the per-(node | edge, head) arrays
-        const char* env = getenv("SREC_HG_AGG");                 // "old": the 8-wave workgroup per node (A/B, tests); read per call
-        const bool force_old = env != nullptr && env[0] == 'o';
         auto al16 = [](const void* p) { return ((size_t)p & 15) == 0; };
-        bool node = !force_old && H == MAXH && (D & 7) == 0 && (ld_x & 3) == 0 && (ld_out & 3) == 0 && al16(out) && al16(arg) &&
+        bool node = H == MAXH && (D & 7) == 0 && (ld_x & 3) == 0 && (ld_out & 3) == 0 && al16(out) && al16(arg) &&
                     al16(x) && al16(g.xres);
         for (int t = 0; node && t < d->n_types; ++t) node = al16(g.smean[t]) && (g.ninst[t] == 0 || al16(g.bsum[t]));
         for (int i = 0; node && i < d->n_inst; ++i)
@@ -1607,9 +1605,8 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
         }
         a.start[d->n_inst] = blocks;
         // one wavefront per destination node over all its instances (H == 8, <= 8 instances per type, 16-byte aligned arrays)
-        const char* env = getenv("SREC_HG_AGG");                 // "old": per-(instance, destination) wavefronts (A/B, tests)
         auto al16 = [](const void* p) { return ((size_t)p & 15) == 0; };
-        bool node = !(env != nullptr && env[0] == 'o') && H == MAXH && (D & 7) == 0 && al16(g) && al16(arg);   // 8-column lanes
+        bool node = H == MAXH && (D & 7) == 0 && al16(g) && al16(arg);   // 8-column lanes
         a.nt = d->n_types;
         int trows = 0;
         for (int t = 0; t < d->n_types; ++t) {

@@ -787,7 +787,7 @@ extern "C" int srec_inverse_index(const int* ptr, const int* pos, int U, int n, 
 
 // ---- MSGIFSR after its last MSHGNN layer (msgifsr.py:260-264, 131-147): L2-normalise every node row, lay the nodes out
 // per session [s1 | s2 | ...] (the read-out's concatenation, cat_perm) and pick each order's last node - ONE launch instead
-// of normalize + permutation gather + pick gather (+ the bf16 hi / lo split of both outputs for the head's split products),
+// of normalize + permutation gather + pick gather,
 // and ONE launch for the three backward kernels (inverse-permutation gather, pick scatter-add, normalize backward).
 namespace {
 struct NppArgs {
@@ -796,16 +796,13 @@ struct NppArgs {
     const int* dyn_t;                         // live concatenated rows
     int n_cap, D, eps_mode; float eps;
     float* allf; float* invr;                 // [n_cap, D] normalised rows in concatenated order, their 1 / norm
-    unsigned short* a_hi; unsigned short* a_lo;   // nullable: bf16 hi / lo split of allf
     int npick, B; const int* dyn_b;
     const int* pick[4];                       // [B] stacked row of each session's last node of that order
     float* pout[4]; int ld_p[4];              // [B, D] (row stride ld_p)
-    unsigned short* p_hi[4]; unsigned short* p_lo[4]; int ld16[4];
 };
 
 __device__ __forceinline__ void npp_row(const float* __restrict__ xr, bool live, int D, int eps_mode, float eps, int lane,
-                                        float* __restrict__ out, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-                                        float* __restrict__ inv_out) {
+                                        float* __restrict__ out, float* __restrict__ inv_out) {
     float iv = 0.f;
     if (live) iv = inv_norm(row_sumsq(xr, D, lane), eps_mode, eps);
     for (int c = lane * 4; c < D; c += 256) {
@@ -815,13 +812,6 @@ __device__ __forceinline__ void npp_row(const float* __restrict__ xr, bool live,
             v.x *= iv; v.y *= iv; v.z *= iv; v.w *= iv;
         }
         *reinterpret_cast<float4*>(out + c) = v;
-        if (hi != nullptr) {
-            const unsigned h0 = srec_pack_bf16(v.x, v.y), h1 = srec_pack_bf16(v.z, v.w);
-            *reinterpret_cast<uint2*>(hi + c) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(lo + c) = make_uint2(
-                srec_pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u)),
-                srec_pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u)));
-        }
     }
     if (inv_out != nullptr && lane == 0) *inv_out = iv;
 }
@@ -832,7 +822,6 @@ __global__ void norm_perm_pick_fwd_kernel(NppArgs a) {
     if (i < a.n_cap) {
         const int src = i < dyn_count(a.dyn_t, a.n_cap) ? a.perm[i] : -1;
         npp_row(a.x + (size_t)(src >= 0 ? src : 0) * a.ld_x, src >= 0, a.D, a.eps_mode, a.eps, lane, a.allf + (size_t)i * a.D,
-                a.a_hi != nullptr ? a.a_hi + (size_t)i * a.D : nullptr, a.a_lo != nullptr ? a.a_lo + (size_t)i * a.D : nullptr,
                 a.invr + i);
         return;
     }
@@ -840,8 +829,7 @@ __global__ void norm_perm_pick_fwd_kernel(NppArgs a) {
     if (k >= a.npick) return;
     const int src = b < dyn_count(a.dyn_b, a.B) ? a.pick[k][b] : -1;
     npp_row(a.x + (size_t)(src >= 0 ? src : 0) * a.ld_x, src >= 0, a.D, a.eps_mode, a.eps, lane, a.pout[k] + (size_t)b * a.ld_p[k],
-            a.p_hi[k] != nullptr ? a.p_hi[k] + (size_t)b * a.ld16[k] : nullptr,
-            a.p_lo[k] != nullptr ? a.p_lo[k] + (size_t)b * a.ld16[k] : nullptr, nullptr);
+            nullptr);
 }
 
 struct NppBwdArgs {
@@ -923,29 +911,21 @@ __global__ void norm_perm_pick_bwd_kernel(NppBwdArgs a, int n_cap, int row_block
 }  // namespace
 
 // allf [n_cap, D] = normalised rows of x in concatenated order (perm), invr [n_cap] their 1 / norm; pick k < npick <= 4:
-// pout_k [B, D] (row stride ld_p[k]) = normalised row pick_k[b] of x.  a_hi / a_lo, p_hi / p_lo (nullable; p_* are HOST arrays
-// of npick pointers that may hold NULLs): bf16 hi / lo splits of the outputs (csrc/split16.hip).  pick / pout / ld_p / ld16 are
-// HOST arrays.  Replaces F.normalize + the per-session concatenation + filter_nodes(last) of msgifsr.py:131-147,260-264.
+// pout_k [B, D] (row stride ld_p[k]) = normalised row pick_k[b] of x.  pick / pout / ld_p are HOST arrays.  Replaces F.normalize + the per-session concatenation + filter_nodes(last) of msgifsr.py:131-147,260-264.
 extern "C" int srec_norm_perm_pick_fwd(const float* x, int ld_x, const int* perm, int n_cap, const int* dyn_t, int D,
-                                       int eps_mode, float eps, float* allf, float* invr, void* a_hi, void* a_lo, int npick,
-                                       int B, const int* dyn_b, const void* pick, const void* pout, const int* ld_p,
-                                       const void* p_hi, const void* p_lo, const int* ld16, void* stream) {
+                                       int eps_mode, float eps, float* allf, float* invr, int npick, int B, const int* dyn_b,
+                                       const void* pick, const void* pout, const int* ld_p, void* stream) {
     if (n_cap <= 0) return 0;
-    if (npick < 0 || npick > 4 || (D & 3) || (ld_x & 3) || ((a_hi == nullptr) != (a_lo == nullptr))) return SREC_BAD_ARG;
+    if (npick < 0 || npick > 4 || (D & 3) || (ld_x & 3)) return SREC_BAD_ARG;
     NppArgs a{};
     a.x = x; a.ld_x = ld_x; a.perm = perm; a.dyn_t = dyn_t; a.n_cap = n_cap; a.D = D; a.eps_mode = eps_mode; a.eps = eps;
-    a.allf = allf; a.invr = invr; a.a_hi = (unsigned short*)a_hi; a.a_lo = (unsigned short*)a_lo;
+    a.allf = allf; a.invr = invr;
     a.npick = npick; a.B = B; a.dyn_b = dyn_b;
     for (int k = 0; k < npick; ++k) {
         a.pick[k] = ((const int* const*)pick)[k];
         a.pout[k] = ((float* const*)pout)[k];
         a.ld_p[k] = ld_p[k];
-        a.p_hi[k] = p_hi != nullptr ? ((unsigned short* const*)p_hi)[k] : nullptr;
-        a.p_lo[k] = p_lo != nullptr ? ((unsigned short* const*)p_lo)[k] : nullptr;
-        a.ld16[k] = ld16 != nullptr ? ld16[k] : 0;
-        if (a.pick[k] == nullptr || a.pout[k] == nullptr || (a.ld_p[k] & 3) || ((a.p_hi[k] == nullptr) != (a.p_lo[k] == nullptr)) ||
-            (a.p_hi[k] != nullptr && (a.ld16[k] & 3)))
-            return SREC_BAD_ARG;
+        if (a.pick[k] == nullptr || a.pout[k] == nullptr || (a.ld_p[k] & 3)) return SREC_BAD_ARG;
     }
     const int rows = n_cap + npick * B;
     hipLaunchKernelGGL(norm_perm_pick_fwd_kernel, dim3(cdiv(rows, WPB)), dim3(256), 0, (hipStream_t)stream, a);

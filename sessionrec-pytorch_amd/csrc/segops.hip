@@ -19,11 +19,7 @@ constexpr int MAXN = SREC_MAX_SESSION_NODES;   // max nodes of one session (host
 __global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const float* __restrict__ Vq, int ld_v,
                                     const float* __restrict__ we, const float* __restrict__ X, int ld_x,
                                     const int* __restrict__ seg, int B, const int* __restrict__ dynB, int h, int D,
-                                    float* __restrict__ alpha, float* __restrict__ out, int ld_out,
-                                    const float* __restrict__ bu, unsigned short* __restrict__ out_hi,
-                                    unsigned short* __restrict__ out_lo, int ld16) {
-    // bu (nullable): bias of the U product, added here (sigmoid(U + bu + Vq[b])) when the GEMM that wrote U has no bias
-    // epilogue; out_hi / out_lo (nullable): the bf16 hi / lo split of the read-out row (operand copies of the next product)
+                                    float* __restrict__ alpha, float* __restrict__ out, int ld_out) {
     __shared__ float e[MAXN];
     const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const bool live = b < dyn_count(dynB, B);
@@ -37,10 +33,6 @@ __global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const
         if (kok) {
             v = *reinterpret_cast<const float4*>(Vq + (size_t)b * ld_v + k);
             wk = *reinterpret_cast<const float4*>(we + k);
-            if (bu != nullptr) {
-                const float4 bb = *reinterpret_cast<const float4*>(bu + k);
-                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-            }
         }
         for (int i0 = w; i0 < n; i0 += 4 * WPB) {
             float4 u[4];
@@ -63,12 +55,8 @@ __global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const
             float acc = 0.f;
             for (int k = lane * 4; k < h; k += 256) {
                 const float4 u = *reinterpret_cast<const float4*>(U + (size_t)(base + i) * ld_u + k);
-                float4 v = *reinterpret_cast<const float4*>(Vq + (size_t)b * ld_v + k);
+                const float4 v = *reinterpret_cast<const float4*>(Vq + (size_t)b * ld_v + k);
                 const float4 wk = *reinterpret_cast<const float4*>(we + k);
-                if (bu != nullptr) {
-                    const float4 bb = *reinterpret_cast<const float4*>(bu + k);
-                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-                }
                 acc += wk.x * sigmoidf_(u.x + v.x) + wk.y * sigmoidf_(u.y + v.y) + wk.z * sigmoidf_(u.z + v.z) +
                        wk.w * sigmoidf_(u.w + v.w);
             }
@@ -105,28 +93,17 @@ __global__ void seg_attn_fwd_kernel(const float* __restrict__ U, int ld_u, const
         }
         for (; i < n; ++i) o += e[i] * xp[(size_t)i * ld_x];
         out[(size_t)b * ld_out + c] = o;
-        if (out_hi != nullptr) {
-            const unsigned short hv = srec_f2bf(o);
-            out_hi[(size_t)b * ld16 + c] = hv;
-            out_lo[(size_t)b * ld16 + c] = srec_f2bf(o - __uint_as_float((unsigned)hv << 16));
-        }
     }
 }
 
 // grid = B + 1: workgroup b < live B owns session b; all workgroups share the zeroing of the rows of dX / dU behind
 // the last live node (padded layouts), so the outputs need no host-side zero fill.
-template <bool W16>
 __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, const float* __restrict__ X, int ld_x,
                                     const float* __restrict__ alpha, const float* __restrict__ U, int ld_u,
                                     const float* __restrict__ Vq, int ld_v, const float* __restrict__ we,
                                     const int* __restrict__ seg, int B, const int* __restrict__ dynB, int h, int D,
                                     int n_cap, float* __restrict__ dX, int ld_dx, float* __restrict__ dU, int ld_du,
-                                    float* __restrict__ dVq, int ld_dv, float* __restrict__ dwe_part, int ld_dw,
-                                    const float* __restrict__ bu, unsigned short* __restrict__ dU16,
-                                    unsigned short* __restrict__ dV16, unsigned short* __restrict__ dW16) {
-    // bu: see the forward.  dU16 / dV16 / dW16 (nullable): bf16 hi / lo splits of dU [n_cap, h], dVq [B, h], dwe_part [B, h]
-    // (hi plane, then the lo plane n_cap * h resp. B * h elements behind it) - the operands of the split products that
-    // follow; dU (fp32) may then be NULL
+                                    float* __restrict__ dVq, int ld_dv, float* __restrict__ dwe_part, int ld_dw) {
     __shared__ float de[MAXN];
     __shared__ float al[MAXN];
     const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -134,16 +111,12 @@ __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, c
     // rows behind the last live node: every workgroup zeroes its share (row r0 + b, r0 + b + grid, ...)
     for (int r = seg[Bd] + b; r < n_cap; r += gridDim.x) {
         for (int c = tid; c < D; c += 256) dX[(size_t)r * ld_dx + c] = 0.f;
-        if (!W16 || dU != nullptr) for (int k = tid; k < h; k += 256) dU[(size_t)r * ld_du + k] = 0.f;
-        if (W16 && dU16 != nullptr)
-            for (int k = tid; k < h; k += 256) { dU16[(size_t)r * h + k] = 0; dU16[(size_t)(n_cap + r) * h + k] = 0; }
+        for (int k = tid; k < h; k += 256) dU[(size_t)r * ld_du + k] = 0.f;
     }
     if (b >= Bd) {
         if (b < B)
             for (int k = tid; k < h; k += 256) {
                 dVq[(size_t)b * ld_dv + k] = 0.f; dwe_part[(size_t)b * ld_dw + k] = 0.f;
-                if (W16 && dV16 != nullptr) { dV16[(size_t)b * h + k] = 0; dV16[(size_t)(B + b) * h + k] = 0; }
-                if (W16 && dW16 != nullptr) { dW16[(size_t)b * h + k] = 0; dW16[(size_t)(B + b) * h + k] = 0; }
             }
         return;
     }
@@ -171,13 +144,8 @@ __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, c
         for (int i = lane; i < n; i += 64) de[i] = al[i] * (de[i] - s);     // d e_i
     }
     __syncthreads();
-    auto put16 = [&](unsigned short* base16, size_t plane, size_t idx, float v) {
-        const unsigned short hv = srec_f2bf(v);
-        base16[idx] = hv;
-        base16[plane + idx] = srec_f2bf(v - __uint_as_float((unsigned)hv << 16));
-    };
     for (int k = tid; k < h; k += 256) {
-        const float vq = Vq[(size_t)b * ld_v + k] + (bu != nullptr ? bu[k] : 0.f);
+        const float vq = Vq[(size_t)b * ld_v + k];
         const float wk = we[k];
         float dv = 0.f, dw = 0.f;
         const float* up = U + (size_t)base * ld_u + k;
@@ -192,8 +160,7 @@ __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, c
                 const float dei = de[i + j];
                 dw += dei * sg;
                 const float dp = dei * wk * sg * (1.f - sg);
-                if (!W16 || dU != nullptr) dU[(size_t)(base + i + j) * ld_du + k] = dp;
-                if (W16 && dU16 != nullptr) put16(dU16, (size_t)n_cap * h, (size_t)(base + i + j) * h + k, dp);
+                dU[(size_t)(base + i + j) * ld_du + k] = dp;
                 dv += dp;
             }
         }
@@ -202,14 +169,11 @@ __global__ void seg_attn_bwd_kernel(const float* __restrict__ dout, int ld_do, c
             const float dei = de[i];
             dw += dei * sg;
             const float dp = dei * wk * sg * (1.f - sg);
-            if (!W16 || dU != nullptr) dU[(size_t)(base + i) * ld_du + k] = dp;
-            if (W16 && dU16 != nullptr) put16(dU16, (size_t)n_cap * h, (size_t)(base + i) * h + k, dp);
+            dU[(size_t)(base + i) * ld_du + k] = dp;
             dv += dp;
         }
         dVq[(size_t)b * ld_dv + k] = dv;
         dwe_part[(size_t)b * ld_dw + k] = dw;
-        if (W16 && dV16 != nullptr) put16(dV16, (size_t)B * h, (size_t)b * h + k, dv);
-        if (W16 && dW16 != nullptr) put16(dW16, (size_t)B * h, (size_t)b * h + k, dw);
     }
 }
 
@@ -308,13 +272,12 @@ extern "C" int srec_edge_agg(const float* X, int ld_x, const int* ptr, const int
 
 extern "C" int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const float* X,
                                  int ld_x, const int* seg, int B, const int* dynB, int h, int D, float* alpha,
-                                 float* out, int ld_out, const float* bu, void* out_hi, void* out_lo, int ld16, void* stream) {
+                                 float* out, int ld_out, void* stream) {
     if (B <= 0) return 0;
     if ((D & 3) || (ld_x & 3) || (ld_out & 3)) return SREC_BAD_ARG;
     if ((h & 3) || (ld_u & 3) || (ld_v & 3)) return SREC_BAD_ARG;
-    if ((out_hi == nullptr) != (out_lo == nullptr)) return SREC_BAD_ARG;
     hipLaunchKernelGGL(seg_attn_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, U, ld_u, Vq, ld_v, we, X, ld_x, seg,
-                       B, dynB, h, D, alpha, out, ld_out, bu, (unsigned short*)out_hi, (unsigned short*)out_lo, ld16);
+                       B, dynB, h, D, alpha, out, ld_out);
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -322,19 +285,11 @@ extern "C" int srec_seg_attn_fwd(const float* U, int ld_u, const float* Vq, int 
 extern "C" int srec_seg_attn_bwd(const float* dout, int ld_do, const float* X, int ld_x, const float* alpha,
                                  const float* U, int ld_u, const float* Vq, int ld_v, const float* we, const int* seg,
                                  int B, const int* dynB, int h, int D, int n_cap, float* dX, int ld_dx, float* dU, int ld_du,
-                                 float* dVq, int ld_dv, float* dwe_part, int ld_dw, const float* bu, void* dU16,
-                                 void* dV16, void* dW16, void* stream) {
+                                 float* dVq, int ld_dv, float* dwe_part, int ld_dw, void* stream) {
     if (B <= 0) return 0;
-    if ((D & 3) || (ld_x & 3) || (ld_do & 3) || (ld_dx & 3)) return SREC_BAD_ARG;
-    if (dU == nullptr && dU16 == nullptr) return SREC_BAD_ARG;
-    if (dU16 != nullptr || dV16 != nullptr || dW16 != nullptr)
-        hipLaunchKernelGGL(seg_attn_bwd_kernel<true>, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, dout, ld_do, X, ld_x, alpha, U,
-                           ld_u, Vq, ld_v, we, seg, B, dynB, h, D, n_cap, dX, ld_dx, dU, ld_du, dVq, ld_dv, dwe_part, ld_dw, bu,
-                           (unsigned short*)dU16, (unsigned short*)dV16, (unsigned short*)dW16);
-    else
-        hipLaunchKernelGGL(seg_attn_bwd_kernel<false>, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, dout, ld_do, X, ld_x, alpha,
-                           U, ld_u, Vq, ld_v, we, seg, B, dynB, h, D, n_cap, dX, ld_dx, dU, ld_du, dVq, ld_dv, dwe_part, ld_dw, bu,
-                           (unsigned short*)nullptr, (unsigned short*)nullptr, (unsigned short*)nullptr);
+    if ((D & 3) || (ld_x & 3) || (ld_do & 3) || (ld_dx & 3) || dU == nullptr) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(seg_attn_bwd_kernel, dim3(B + 1), dim3(256), 0, (hipStream_t)stream, dout, ld_do, X, ld_x, alpha, U,
+                       ld_u, Vq, ld_v, we, seg, B, dynB, h, D, n_cap, dX, ld_dx, dU, ld_du, dVq, ld_dv, dwe_part, ld_dw);
     SREC_LAUNCH_CHECK();
     return 0;
 }

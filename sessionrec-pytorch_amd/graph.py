@@ -21,7 +21,7 @@ from .batch import FlatBatch
 #   'main'   0.992 ms  hipMemcpyAsync on the compute stream
 #   'side'   1.001 ms  hipMemcpyAsync on a side stream into a staging ring + device-to-device copy (also the route of
 #                      pageable host batches, which a kernel cannot read)
-_STAGE_MODE = os.environ.get('SREC_STAGE_MODE', 'kernel')
+_STAGE_MODE = 'kernel'
 
 
 class GraphedTrainStep:
@@ -79,8 +79,8 @@ class GraphedTrainStep:
                 model._col_scale(ms)
             ms['cs_fresh'] = ms.get('cs') is not None
         import os
-        try:                                             # the hipGraph_t stays queryable (node_counts); SREC_KEEP_GRAPH=0 opts out
-            self.graph = torch.cuda.CUDAGraph(keep_graph=os.environ.get('SREC_KEEP_GRAPH', '1') != '0')
+        try:                                             # the hipGraph_t stays queryable (node_counts)
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         except TypeError:
             self.graph = torch.cuda.CUDAGraph()
         self._pending_advance = None

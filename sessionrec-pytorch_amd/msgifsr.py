@@ -385,23 +385,20 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             allf = stacked
             feat_vs = {i: ops.row_gather(stacked, mg.field('lastcat%d' % (i + 1)), dB) for i in live}
         elif len(self.layers) > 0 and fuse_npp:
-            # normalisation + per-session concatenation + last-node picks (+ the operand copies of the head's split products)
-            # in one launch (ops.NormPermutePick)
+            # normalisation + per-session concatenation + last-node picks in one launch (ops.NormPermutePick)
             types, r0 = [], 0
             for k in range(1, K + 1):
                 types.append((r0, ncap[k], mg.dynp('N%d' % k)))
                 r0 += ncap[k]
-            d_ = stacked.shape[1]
             allf, picked = ops.norm_permute_pick(stacked, mg.cat_perm, mg.cat_seg, [mg.field('lastcat%d' % (i + 1)) for i in live],
-                                                 types, mg.dynp('NT'), dB, 0,
-                                                 split=ops.readout_head_split_ok(d_, d_, d_, d_) and len(list(live)) <= 4)
+                                                 types, mg.dynp('NT'), dB, 0)
             feat_vs = dict(zip(live, picked))
         else:
             allf, picked = ops.permute_and_pick(stacked, mg.cat_perm, mg.field('cat_inv'),
                                                 [mg.field('lastcat%d' % (i + 1)) for i in live], mg.dynp('NT'), dB)
             feat_vs = dict(zip(live, picked))
         srs = []
-        if len(live) <= 4 and not __import__('os').environ.get('SREC_UNFUSED_HEAD'):
+        if len(live) <= 4:
             # read-out + fc_sr(cat[x_last, sr_g]) of every live order as grouped exact-fp32 launches (ops.ReadoutHead):
             # these B-row products are launch bound one by one
             ro = self.readout

@@ -38,11 +38,6 @@ def _ws(n, device):
 _GEMM_WS = {}
 
 
-_GEMM_TK = {}
-# in-kernel split-K sums (srec_gemm_f32_group_run_fused): bit-identical, one node less per group - and 1.067 vs 0.936 ms per step:
-# the device-scope release / acquire fences that make the partial tiles visible across the 8 XCDs' L2s write back and invalidate
-# whole L2s, once per workgroup (profiles/r03_notes.md).  Off unless asked for.
-_GEMM_FUSED_REDUCE = os.environ.get('SREC_GEMM_FUSED_REDUCE', '0') == '1'
 
 
 def _gemm_ws(device):
@@ -98,24 +93,23 @@ def check_limits(mg, deg=None):
                          '(csrc/common.h): truncate sessions' % (m['max_deg'], L[deg]))
 
 
+FUSED_GRU = True        # tests flip these two to compare the fused kernels (gruf.hip / grufb.hip, headf.hip) with the
+FUSED_HEAD = True       # step-by-step / grouped launch sequences they replace; the product path never does
 PRECISION = {'matmul': 'fp32'}      # 'fp32': exact fp32 MFMA everywhere; 'bf16': bf16-operand MFMA for the
                                     # forward / backward-data products and the scoring kernels (config C3)
 _WT_CACHE = {}
-_WSPLIT_CACHE = {}     # fp32 weight -> (hi, lo, hiT, loT) bf16 splits of this step (split16.hip)
 
 
 def set_precision(mode):
     assert mode in ('fp32', 'bf16')
     PRECISION['matmul'] = mode
     _WT_CACHE.clear()
-    _WSPLIT_CACHE.clear()
     _HEAD_WF_CACHE.clear()
 
 
 def weights_changed():
     """called by the optimizer after it updated parameters: cached transposed weight copies are stale"""
     _WT_CACHE.clear()
-    _WSPLIT_CACHE.clear()
     _HEAD_WF_CACHE.clear()
 
 
@@ -589,32 +583,24 @@ def flush_deferred():
 class NormPermutePick(torch.autograd.Function):
     """(allf, v_0, v_1, ...) = (normalize(x)[perm], normalize(x)[pick_0], ...): MSGIFSR between its last MSHGNN layer and the
     read-out (msgifsr.py:260-264 F.normalize, :131-147 per-session concatenation and last-node picks) in ONE launch, and its
-    backward (inverse permutation, pick scatter-add, normalisation backward) in one.  split: also the bf16 hi / lo splits of
-    the outputs (the operand copies of the head's split products, ops.ReadoutHeadSplit)."""
+    backward (inverse permutation, pick scatter-add, normalisation backward) in one."""
 
     @staticmethod
-    def forward(ctx, x, perm, cat_seg, dyn_t, dyn_b, types, eps_mode, split, *picks):
+    def forward(ctx, x, perm, cat_seg, dyn_t, dyn_b, types, eps_mode, *picks):
         x = _rows(x)
         NTs, D = x.shape
         n_cap, B, P = perm.numel(), picks[0].numel(), len(picks)
         dev = x.device
         allf = torch.empty(n_cap, D, device=dev, dtype=torch.float32)
         invr = torch.empty(n_cap, device=dev, dtype=torch.float32)
-        a16 = torch.empty(2, n_cap, D, device=dev, dtype=torch.bfloat16) if split else None
         bufs = [torch.empty(B, 2 * D, device=dev, dtype=torch.float32) for _ in range(P)]   # v = left half of [v | read-out]
-        c16 = [torch.empty(2, B, 2 * D, device=dev, dtype=torch.bfloat16) for _ in range(P)] if split else None
         arr, ints = _ct.c_void_p * P, _ct.c_int * P
         a_pick, a_out = arr(*[p.data_ptr() for p in picks]), arr(*[b.data_ptr() for b in bufs])
-        a_hi = arr(*[(c16[k][0].data_ptr() if split else None) for k in range(P)])
-        a_lo = arr(*[(c16[k][1].data_ptr() if split else None) for k in range(P)])
         a_ld = ints(*([2 * D] * P))                         # (ctypes arrays must outlive the call: no temporaries in addressof)
         lib.srec_norm_perm_pick_fwd(ptr(x), _ld(x), ptr(perm), n_cap, ptr(dyn_t), D, eps_mode, 1e-12, ptr(allf), ptr(invr),
-                                    ptr(a16[0]) if split else None, ptr(a16[1]) if split else None, P, B, ptr(dyn_b),
-                                    _ct.addressof(a_pick), _ct.addressof(a_out), _ct.addressof(a_ld),
-                                    _ct.addressof(a_hi), _ct.addressof(a_lo), _ct.addressof(a_ld), stream())
+                                    P, B, ptr(dyn_b), _ct.addressof(a_pick), _ct.addressof(a_out), _ct.addressof(a_ld), stream())
         ctx.save_for_backward(perm, cat_seg, allf, invr, *picks)
         ctx.meta = (NTs, D, B, dyn_b, types)
-        ctx.a16, ctx.c16 = a16, c16
         return (allf,) + tuple(b[:, :D] for b in bufs)
 
     @staticmethod
@@ -636,19 +622,13 @@ class NormPermutePick(torch.autograd.Function):
                                     ptr(dyn_b), D, P,
                                     _ct.addressof(a_pick), _ct.addressof(a_g), _ct.addressof(a_ld), ptr(dx), D, nt,
                                     _ct.addressof(a_r0), _ct.addressof(a_nc), _ct.addressof(a_dyn), NTs, stream())
-        return (dx,) + (None,) * (7 + P)
+        return (dx,) + (None,) * (6 + P)
 
 
-def norm_permute_pick(x, perm, cat_seg, picks, types, dyn_t=None, dyn_b=None, eps_mode=0, split=False):
-    """types: [(first stacked row, capacity, dyn live count)] of the node types stacked in x.  -> (allf, [v_k]); with
-    `split` the outputs carry their bf16 hi / lo operand copies (`_srec_split`: (hi, lo) of allf; `_srec_cat16`: the
-    [2, B, 2 D] hi / lo planes whose left halves hold v_k) for ops.ReadoutHeadSplit."""
-    outs = NormPermutePick.apply(x, perm, cat_seg, dyn_t, dyn_b, tuple(types), eps_mode, bool(split), *picks)
-    fn = outs[0].grad_fn
-    if split and fn is not None and getattr(fn, 'a16', None) is not None:
-        outs[0]._srec_split = (fn.a16[0], fn.a16[1])
-        for k, o in enumerate(outs[1:]):
-            o._srec_cat16 = fn.c16[k]
+def norm_permute_pick(x, perm, cat_seg, picks, types, dyn_t=None, dyn_b=None, eps_mode=0):
+    """types: [(first stacked row, capacity, dyn live count)] of the node types stacked in x.  -> (allf, [v_k]); every v_k is
+    the tagged left half of a private [B, 2 D] buffer whose right half the read-out head fills"""
+    outs = NormPermutePick.apply(x, perm, cat_seg, dyn_t, dyn_b, tuple(types), eps_mode, *picks)
     for o in outs[1:]:
         o._srec_cat_left = True
     return outs[0], list(outs[1:])
@@ -813,7 +793,7 @@ class SegAttn(torch.autograd.Function):
         alpha = torch.empty(N, device=X.device, dtype=torch.float32)      # live nodes written, padded never read
         out = torch.empty(B, D, device=X.device, dtype=torch.float32)
         lib.srec_seg_attn_fwd(ptr(U), _ld(U), ptr(Vq), _ld(Vq), ptr(we), ptr(X), _ld(X), ptr(seg), B, ptr(dynB), h, D,
-                              ptr(alpha), ptr(out), D, None, None, None, 0, stream())
+                              ptr(alpha), ptr(out), D, stream())
         ctx.save_for_backward(U, Vq, we, X, alpha, seg)
         ctx.dynB = dynB
         return out
@@ -830,7 +810,7 @@ class SegAttn(torch.autograd.Function):
         dwp = torch.empty(B, h, device=X.device, dtype=torch.float32)
         lib.srec_seg_attn_bwd(ptr(gout), _ld(gout), ptr(X), _ld(X), ptr(alpha), ptr(U), _ld(U), ptr(Vq), _ld(Vq),
                               ptr(we), ptr(seg), B, ptr(ctx.dynB), h, D, N, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp),
-                              h, None, None, None, None, stream())
+                              h, stream())
         dwe = torch.empty(h, device=X.device, dtype=torch.float32)
         col_sum(dwp, B, h, dwe, ctx.dynB)
         return dU, dVq, dwe.view(1, h), dX, None, None
@@ -876,13 +856,7 @@ def gemm_f32_group(probs):
         g.dyn[p], g.dyn_mode[p] = ptr(dyn), (mode if dyn is not None else 0)
         g.alpha[p], g.beta[p] = 1.0, beta
     dev = probs[0][1].device
-    tk = _GEMM_TK.get(str(dev))
-    if tk is None:          # arrival counters of the in-kernel split-K sums: zero once, left zero by every launch
-        tk = _GEMM_TK[str(dev)] = torch.zeros(4096, device=dev, dtype=torch.int32)
-    if _GEMM_FUSED_REDUCE:
-        lib.srec_gemm_f32_group_run_fused(_ct.addressof(g), *_gemm_ws(dev), tk.data_ptr(), tk.numel(), stream())
-    else:
-        lib.srec_gemm_f32_group_run(_ct.addressof(g), *_gemm_ws(dev), stream())
+    lib.srec_gemm_f32_group_run(_ct.addressof(g), *_gemm_ws(dev), stream())
 
 
 _ONES4 = {}
@@ -938,11 +912,11 @@ class ReadoutHead(torch.autograd.Function):
                     cat = None
             if cat is not None:
                 lib.srec_seg_attn_fwd(ptr(Us[i]), h, ptr(Vqs[i]), h, ptr(we), ptr(allf), _ld(allf), ptr(seg), B, ptr(dB), h, D,
-                                      ptr(alpha), cat[:, dv:].data_ptr(), dv + D, None, None, None, 0, stream())
+                                      ptr(alpha), cat[:, dv:].data_ptr(), dv + D, stream())
             else:
                 srg = torch.empty(B, D, device=dev, dtype=torch.float32)
                 lib.srec_seg_attn_fwd(ptr(Us[i]), h, ptr(Vqs[i]), h, ptr(we), ptr(allf), _ld(allf), ptr(seg), B, ptr(dB), h, D,
-                                      ptr(alpha), ptr(srg), D, None, None, None, 0, stream())
+                                      ptr(alpha), ptr(srg), D, stream())
                 cat = torch.empty(B, dv + D, device=dev, dtype=torch.float32)
                 lib.srec_cat_cols(ptr(v), _ld(v), dv, ptr(srg), D, D, B, ptr(cat), stream())
             out = torch.empty(B, Wsr.shape[0], device=dev, dtype=torch.float32)
@@ -991,8 +965,7 @@ def _readout_head_backward(allf, seg, per, dT, dB, has_bu, gs):
         dVq = torch.empty(B, h, device=dev, dtype=torch.float32)
         dwp = torch.empty(B, h, device=dev, dtype=torch.float32)
         lib.srec_seg_attn_bwd(ptr(gsrg), _ld(gsrg), ptr(allf), _ld(allf), ptr(alpha), ptr(U), h, ptr(Vq), h, ptr(we),
-                              ptr(seg), B, ptr(dB), h, D, NT, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp), h, None, None, None,
-                              None, stream())
+                              ptr(seg), B, ptr(dB), h, D, NT, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp), h, stream())
         gWu, gWv = torch.empty_like(Wu), torch.empty_like(Wv)
         gv = gcats[i][:, :dv]                                         # d v: the concat half, + dVq Wv in place
         probs.append(('nn', dU, Wu, dX, None, dT, 1.0))               # d allf (this order) = read-out term + dU Wu
@@ -1121,7 +1094,7 @@ class ReadoutHeadFused(torch.autograd.Function):
 def readout_head_fused_ok(allf, per_order):
     """the fused forward applies: bf16 mode, d = hidden = output in (128, 256), <= 4 heads, contiguous weights, every query
     tensor the tagged left half of a private [B, 2 d] buffer (norm_permute_pick / permute_and_pick)"""
-    if not (allf.is_cuda and PRECISION['matmul'] == 'bf16' and 1 <= len(per_order) <= 4) or os.environ.get('SREC_HEAD_FUSED') == '0':
+    if not (allf.is_cuda and PRECISION['matmul'] == 'bf16' and 1 <= len(per_order) <= 4 and FUSED_HEAD):
         return False
     D = allf.shape[1]
     if D not in (128, 256) or allf.stride(1) != 1 or allf.stride(0) % 4:
@@ -1143,227 +1116,10 @@ def readout_head_fused(allf, seg, dT, dB, per_order, ws=None, eps_mode=0):
     return ReadoutHeadFused.apply(allf, seg, dT, dB, ws, eps_mode, *flat)
 
 
-def split_bf16(jobs):
-    """jobs: [(src fp32 [n, d] (row-strided), dyn, hi, lo)] with hi / lo bf16 [n, d] views (row stride = their ld16): the
-    hi / lo split of every src in ONE launch (csrc/split16.hip)"""
-    for c0 in range(0, len(jobs), 8):
-        ch = jobs[c0:c0 + 8]
-        n = len(ch)
-        arr, ints = _ct.c_void_p * n, _ct.c_int * n
-        a_s, a_h, a_l = (arr(*[j[k].data_ptr() for j in ch]) for k in (0, 2, 3))
-        a_d = arr(*[ptr(j[1]) for j in ch])
-        i_ld, i_n = ints(*[_ld(j[0]) for j in ch]), ints(*[j[0].shape[0] for j in ch])      # kept alive across the call
-        i_d, i_l16 = ints(*[j[0].shape[1] for j in ch]), ints(*[_ld(j[2]) for j in ch])
-        lib.srec_split_bf16(n, _ct.addressof(a_s), _ct.addressof(i_ld), _ct.addressof(i_n), _ct.addressof(a_d),
-                            _ct.addressof(i_d), _ct.addressof(a_h), _ct.addressof(a_l), _ct.addressof(i_l16), stream())
-
-
-def weights_split(ws):
-    """[(hi, lo, hiT, loT)] bf16 splits (and transposed splits) of fp32 weight matrices, computed once per step (the cache
-    is dropped by weights_changed() after every optimizer step); <= 8 matrices per launch"""
-    out, todo = [None] * len(ws), []
-    for i, w in enumerate(ws):
-        c = _WSPLIT_CACHE.get((w.data_ptr(), tuple(w.shape)))
-        if c is None:
-            todo.append(i)
-        else:
-            out[i] = c
-    for c0 in range(0, len(todo), 8):
-        ch = todo[c0:c0 + 8]
-        n = len(ch)
-        bufs = []
-        for i in ch:
-            R, C = ws[i].shape
-            b = torch.empty(4, R * C, device=ws[i].device, dtype=torch.bfloat16)
-            bufs.append((b[0].view(R, C), b[1].view(R, C), b[2].view(C, R), b[3].view(C, R)))
-        arr, ints = _ct.c_void_p * n, _ct.c_int * n
-        a_w = arr(*[_rows(ws[i]).data_ptr() for i in ch])
-        a_hi, a_lo, a_ht, a_lt = (arr(*[b[k].data_ptr() for b in bufs]) for k in range(4))
-        for i in ch:
-            assert ws[i].is_contiguous()
-        i_r, i_c = ints(*[ws[i].shape[0] for i in ch]), ints(*[ws[i].shape[1] for i in ch])
-        lib.srec_weights_split_bf16(n, _ct.addressof(a_w), _ct.addressof(i_r), _ct.addressof(i_c), _ct.addressof(a_hi),
-                                    _ct.addressof(a_lo), _ct.addressof(a_ht), _ct.addressof(a_lt), stream())
-        for i, b in zip(ch, bufs):
-            out[i] = _WSPLIT_CACHE[(ws[i].data_ptr(), tuple(ws[i].shape))] = b
-    return out
-
-
-def _head_terms():
-    """K-segments of a read-out head product: 3 = hi/lo split (~2^-16, SREC_HEAD_SPLIT=1), 1 = plain bf16 operands like
-    every other encoder GEMM of the bf16 mode (SREC_HEAD_SPLIT=bf16)"""
-    return 1 if os.environ.get('SREC_HEAD_SPLIT') == 'bf16' else 3
-
-
-def _seg3(a, b):
-    """the three K-segments of a split product: a b^T ~ a_hi b_hi^T + a_hi b_lo^T + a_lo b_hi^T; a, b = (hi, lo)"""
-    if _head_terms() == 1:
-        return [(a[0], b[0])]
-    return [(a[0], b[0]), (a[0], b[1]), (a[1], b[0])]
-
-
-_ONES16 = {}
-
-
-def _ones16(n, device):
-    t = _ONES16.get(str(device))
-    if t is None or t.shape[0] < n:
-        t = _ONES16[str(device)] = torch.ones(max(n, 1024), 8, device=device, dtype=torch.bfloat16)
-    return t
-
-
-class ReadoutHeadSplit(torch.autograd.Function):
-    """ReadoutHead (same arguments, same results to ~2^-16) with every product on the bf16 matrix pipe as a 3-term hi / lo
-    split (csrc/split16.hip): fp32 MFMA runs at 1/16 of the bf16 rate on gfx950, three bf16 products cost 3/16.  The
-    operand copies are written by their producers where there is one (the read-out kernels emit the splits of the
-    read-out rows and of dU / dVq / d fc_e), by srec_split_bf16 otherwise; the fc_u bias is added inside the read-out
-    kernel; column sums (d bias, d fc_e) are products with a block of ones in the weight-gradient launch.
-    forward: split(allf, v) - weights split - {U, Vq} - read-out - {s};  backward: split(g) - {d cat} - read-out backward
-    - {d allf += dU Wu, d v += dVq Wv} - {d Wu, d Wv, d Wsr, sums} - slab sum."""
-
-    @staticmethod
-    def forward(ctx, allf, seg, dT, dB, *flat):
-        n = len(flat) // 6
-        ctx.allf_in, ctx.v_in = allf, [flat[6 * i] for i in range(n)]
-        allf = _rows(allf)
-        NT, D = allf.shape
-        dev, bf = allf.device, torch.bfloat16
-        per = [flat[6 * i:6 * i + 6] for i in range(n)]
-        B, h, Do = per[0][0].shape[0], per[0][1].shape[0], per[0][5].shape[0]
-        jobs = []
-        a16 = getattr(ctx.allf_in, '_srec_split', None)             # written by the producer (ops.norm_permute_pick) ...
-        if a16 is None or a16[0].shape != (NT, D):
-            buf = torch.empty(2, NT, D, device=dev, dtype=bf)          # ... or split here
-            a16 = (buf[0], buf[1])
-            jobs.append((allf, dT, a16[0], a16[1]))
-        cat16 = []
-        for i in range(n):
-            c = getattr(ctx.v_in[i], '_srec_cat16', None)
-            if c is None or tuple(c.shape) != (2, B, 2 * D):
-                c = torch.empty(2, B, 2 * D, device=dev, dtype=bf)
-                jobs.append((per[i][0], dB, c[0][:, :D], c[1][:, :D]))
-            cat16.append(c)
-        if jobs:
-            split_bf16(jobs)
-        wsp = weights_split([w for i in range(n) for w in (per[i][1], per[i][3], per[i][5])])
-        Us = [torch.empty(NT, h, device=dev, dtype=torch.float32) for _ in range(n)]
-        Vqs = [torch.empty(B, h, device=dev, dtype=torch.float32) for _ in range(n)]
-        probs = []
-        for i in range(n):
-            wu, wv = wsp[3 * i], wsp[3 * i + 1]
-            probs.append((NT, h, D, _seg3(a16, wu), Us[i], dT))
-            probs.append((B, h, D, _seg3((cat16[i][0], cat16[i][1]), wv), Vqs[i], dB, 0, 1, (2 * D, 0, 0)))
-        for c in range(0, len(probs), 16):
-            gemm16('nt', probs[c:c + 16], D, D, h)
-        alphas, outs, probs = [], [], []
-        srg = torch.empty(B, D, device=dev, dtype=torch.float32)            # fp32 read-out rows: only their splits are used
-        for i in range(n):
-            v, Wu, bu, Wv, we, Wsr = per[i]
-            we = we.reshape(-1).contiguous()
-            alpha = torch.empty(NT, device=dev, dtype=torch.float32)
-            lib.srec_seg_attn_fwd(ptr(Us[i]), h, ptr(Vqs[i]), h, ptr(we), ptr(allf), _ld(allf), ptr(seg), B, ptr(dB), h, D,
-                                  ptr(alpha), ptr(srg), D, ptr(bu), cat16[i][0][:, D:].data_ptr(), cat16[i][1][:, D:].data_ptr(),
-                                  2 * D, stream())
-            out = torch.empty(B, Do, device=dev, dtype=torch.float32)
-            probs.append((B, Do, 2 * D, _seg3((cat16[i][0], cat16[i][1]), wsp[3 * i + 2]), out, dB))
-            alphas.append(alpha)
-            outs.append(out)
-        gemm16('nt', probs, 2 * D, 2 * D, Do)
-        ctx.save_for_backward(allf, seg, a16[0], a16[1], *[t for i in range(n) for t in (per[i][4].reshape(-1), Us[i], Vqs[i], alphas[i], cat16[i])],
-                              *[b for i in range(n) if per[i][2] is not None for b in (per[i][2],)])
-        ctx.n, ctx.dT, ctx.dB, ctx.wsp = n, dT, dB, wsp
-        ctx.has_bu = [per[i][2] is not None for i in range(n)]
-        ctx.dims = (B, h, Do)
-        ctx.allf_in = ctx.v_in = None
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *gs):
-        allf, seg, a_hi, a_lo, *rest = ctx.saved_tensors
-        a16 = (a_hi, a_lo)
-        n, dT, dB, wsp = ctx.n, ctx.dT, ctx.dB, ctx.wsp
-        B, h, Do = ctx.dims
-        NT, D = allf.shape
-        dev, bf = allf.device, torch.bfloat16
-        per = [rest[5 * i:5 * i + 5] for i in range(n)]
-        bus, k = [], 5 * n
-        for i in range(n):
-            bus.append(rest[k] if ctx.has_bu[i] else None)
-            k += 1 if ctx.has_bu[i] else 0
-        g16 = torch.empty(n, 2, B, Do, device=dev, dtype=bf)
-        split_bf16([(_rows(gs[i]), dB, g16[i, 0], g16[i, 1]) for i in range(n)])
-        gl = [torch.empty(B, D, device=dev, dtype=torch.float32) for _ in range(n)]      # d v (left half of d cat)
-        gr = [torch.empty(B, D, device=dev, dtype=torch.float32) for _ in range(n)]      # d read-out (right half)
-        probs = []
-        for i in range(n):
-            hiT, loT = wsp[3 * i + 2][2], wsp[3 * i + 2][3]                                 # Wsr^T [2 D, Do]
-            g = (g16[i, 0], g16[i, 1])
-            probs.append((B, D, Do, _seg3(g, (hiT[:D], loT[:D])), gl[i], dB))
-            probs.append((B, D, Do, _seg3(g, (hiT[D:], loT[D:])), gr[i], dB))
-        for c in range(0, len(probs), 16):
-            gemm16('nt', probs[c:c + 16], Do, Do, D)
-        dXs, d16, nt_probs, tn_probs, finals = [], [], [], [], []
-        ones = _ones16(B, dev)
-        nsplit = max(1, min(16, (NT + 1023) // 1024))
-        for i in range(n):
-            we, U, Vq, alpha, cat16 = per[i]
-            dX = torch.empty(NT, D, device=dev, dtype=torch.float32)      # rows behind the live nodes zeroed in-kernel
-            dVq = torch.empty(B, h, device=dev, dtype=torch.float32)
-            dwp = torch.empty(B, h, device=dev, dtype=torch.float32)
-            dU16 = torch.empty(2, NT, h, device=dev, dtype=bf)
-            dV16 = torch.empty(2, B, h, device=dev, dtype=bf)
-            dW16 = torch.empty(2, B, h, device=dev, dtype=bf)
-            lib.srec_seg_attn_bwd(ptr(gr[i]), D, ptr(allf), _ld(allf), ptr(alpha), ptr(U), h, ptr(Vq), h, ptr(we), ptr(seg), B,
-                                  ptr(dB), h, D, NT, ptr(dX), D, None, h, ptr(dVq), h, ptr(dwp), h, ptr(bus[i]), ptr(dU16),
-                                  ptr(dV16), ptr(dW16), stream())
-            wu, wv = wsp[3 * i], wsp[3 * i + 1]
-            nt_probs.append((NT, D, h, _seg3((dU16[0], dU16[1]), (wu[2], wu[3])), dX, dT))          # d allf += dU Wu
-            nt_probs.append((B, D, h, _seg3((dV16[0], dV16[1]), (wv[2], wv[3])), gl[i], dB))        # d v += dVq Wv
-            gWu = torch.empty(h, D, device=dev, dtype=torch.float32)
-            slabs = torch.empty(nsplit, h, D, device=dev, dtype=torch.float32) if nsplit > 1 else gWu
-            gWv = torch.empty(h, D, device=dev, dtype=torch.float32)
-            gWsr = torch.empty(Do, 2 * D, device=dev, dtype=torch.float32)
-            sums = torch.empty(16, h, device=dev, dtype=torch.float32)
-            c16 = (cat16[0], cat16[1])
-            tn_probs.append((h, D, NT, _seg3((dU16[0], dU16[1]), a16), slabs, dT, 0, nsplit))
-            tn_probs.append((h, D, B, _seg3((dV16[0], dV16[1]), c16), gWv, dB, 0, 1, (h, 2 * D, D)))
-            tn_probs.append((Do, 2 * D, B, _seg3((g16[i, 0], g16[i, 1]), c16), gWsr, dB, 0, 1, (Do, 2 * D, 2 * D)))
-            tn_probs.append((8, h, B, [(ones, dV16[0]), (ones, dV16[1])][:(1 if _head_terms() == 1 else 2)], sums[:8], dB, 0, 1, (8, h, h)))
-            tn_probs.append((8, h, B, [(ones, dW16[0]), (ones, dW16[1])][:(1 if _head_terms() == 1 else 2)], sums[8:], dB, 0, 1, (8, h, h)))
-            finals.append((gWu, slabs, gWv, gWsr, sums))
-            dXs.append(dX)
-        for c in range(0, len(nt_probs), 16):
-            gemm16('nt', nt_probs[c:c + 16], h, h, D, beta=1.0)
-        for c in range(0, len(tn_probs), 15):
-            gemm16('tn', tn_probs[c:c + 15], h, D, D)
-        grads = []
-        for i, (gWu, slabs, gWv, gWsr, sums) in enumerate(finals):
-            if nsplit > 1:
-                lib.srec_sum_slabs(ptr(slabs), 1, nsplit, h * D, ptr(gWu), stream())
-            grads.append((gl[i], gWu, sums[0] if ctx.has_bu[i] else None, gWv, sums[8:9], gWsr))
-        g_allf = dXs[0]
-        for dX in dXs[1:]:
-            g_allf = g_allf + dX
-        return (g_allf, None, None, None) + tuple(t for gr_ in grads for t in gr_)
-
-
-def readout_head_split_ok(D, h, Do, dv):
-    # OFF by default: measured at C3 (profiles/r03a_*) the split head takes 160 us against 132 us for the fp32-MFMA launches -
-    # its products are small (<= 4.5 GFLOP in total), gemm16 runs them at ~10 % of the bf16 peak (265 TFLOP/s on the largest),
-    # three times the work does not pay and the extra operand-copy / slab-sum launches cost ~5 us each.  SREC_HEAD_SPLIT=1
-    # selects it (tests/test_ops_gpu.py::test_readout_head_bf16_split_matches_exact_fp32 keeps it correct).
-    return (PRECISION['matmul'] == 'bf16' and D % 64 == 0 and h % 64 == 0 and Do % 8 == 0 and dv == D
-            and bool(os.environ.get('SREC_HEAD_SPLIT')))
-
-
 def readout_head(allf, seg, dT, dB, per_order):
-    """per_order: [(v_i, Wu_i, bu_i, Wv_i, we_i, Wsr_i)] -> tuple of s_i [B, d] (before the optional normalisation).
-    bf16 mode: the products run as 3-term bf16 splits (ReadoutHeadSplit); SREC_HEAD_FP32=1 keeps the fp32-MFMA launches."""
+    """per_order: [(v_i, Wu_i, bu_i, Wv_i, we_i, Wsr_i)] -> tuple of s_i [B, d] (before the optional normalisation): the grouped
+    exact-fp32 launches (ReadoutHead).  bf16 mode at d = 128 / 256 takes readout_head_fused instead."""
     flat = [t for po in per_order for t in po]
-    v, Wu, _, _, _, Wsr = per_order[0]
-    if allf.is_cuda and readout_head_split_ok(allf.shape[1], Wu.shape[0], Wsr.shape[0], v.shape[1]) and Wsr.shape[1] == 2 * allf.shape[1] \
-            and all(po[1].is_contiguous() and po[3].is_contiguous() and po[5].is_contiguous() for po in per_order):
-        return ReadoutHeadSplit.apply(allf, seg, dT, dB, *flat)
     return ReadoutHead.apply(allf, seg, dT, dB, *flat)
 
 
@@ -1887,7 +1643,7 @@ def gru_wfrag(ws):
 
 
 def gru_fused_ok(d, P):
-    return d in (128, 256) and P <= 4 and not os.environ.get('SREC_UNFUSED_GRU')
+    return d in (128, 256) and P <= 4 and FUSED_GRU
 
 
 def gru_expand_fast_ok(d, reducer):
@@ -2473,16 +2229,13 @@ class GemmGroup16(_ct.Structure):
                 ('lda_p', _ct.c_int * 16), ('ldb_p', _ct.c_int * 16), ('ldc_p', _ct.c_int * 16), ('mhint', _ct.c_int * 16)]
 
 
-_FWD_VARIANT = 64 if os.environ.get('SREC_FWD_WRES') == '1' else (5 if os.environ.get('SREC_FWD_XCDCOLS') == '1' else 0)     # 64: the weights-in-registers forward kernel, 5: column tiles dealt to the XCDs (A/B runs)
-
-
-def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False, variant=0, bfrag=False):
+def gemm16(kind, probs, lda, ldb, ldc, beta=0.0, c16=False, keep_dead=False):
     """one grouped launch of the bf16-in-HBM GEMMs (csrc/gemm16.hip).  probs: [(M, N, K, [(A16, B16), ...], C, dyn)].
     kind 'nt': C [M, N] (+)= sum_s A_s [M, K] B_s [N, K]^T (c16: bf16 output);  'tn': C [M, N] = sum_s A_s [K, M]^T B_s [K, N]
     (reduction over the K rows, clamped by dyn)."""
     assert 0 < len(probs) <= 16
     g = GemmGroup16()
-    g.np, g.lda, g.ldb, g.ldc, g.beta, g.c16 = len(probs), lda, ldb, ldc, beta, int(c16) | (2 if keep_dead else 0) | (variant << 4) | (2048 if bfrag else 0)
+    g.np, g.lda, g.ldb, g.ldc, g.beta, g.c16 = len(probs), lda, ldb, ldc, beta, int(c16) | (2 if keep_dead else 0)
     for p, pr in enumerate(probs):
         M, N, K, segs, C, dyn = pr[:6]
         g.M[p], g.N[p], g.K[p], g.nseg[p], g.C[p], g.dyn[p] = M, N, K, len(segs), ptr(C), ptr(dyn)
@@ -2506,7 +2259,7 @@ def rows_bf16(x, dyn=None):
     return out
 
 
-def weights_bf16(ws, transposed=True, frag=False):
+def weights_bf16(ws, transposed=True):
     """[(W16, WT16)] bf16 copies (and transposed copies) of up to 8 contiguous fp32 matrices, one launch"""
     n = len(ws)
     assert 0 < n <= 8
@@ -2517,8 +2270,7 @@ def weights_bf16(ws, transposed=True, frag=False):
     a_w, a_16 = arr(*[w.data_ptr() for w in ws]), arr(*[w.data_ptr() for w in w16])      # kept alive across the call
     a_t = arr(*[(w.data_ptr() if w is not None else None) for w in wt16])
     a_r, a_c = (_ct.c_int * n)(*[w.shape[0] for w in ws]), (_ct.c_int * n)(*[w.shape[1] for w in ws])
-    (lib.srec_weights_bf16_frag if frag else lib.srec_weights_bf16)(n, _ct.addressof(a_w), _ct.addressof(a_16), _ct.addressof(a_t), _ct.addressof(a_r),
-                          _ct.addressof(a_c), stream())
+    lib.srec_weights_bf16(n, _ct.addressof(a_w), _ct.addressof(a_16), _ct.addressof(a_t), _ct.addressof(a_r), _ct.addressof(a_c), stream())
     return w16, wt16
 
 
@@ -2695,10 +2447,7 @@ class HGATLayer(torch.autograd.Function):
         if grouped and D % 64 == 0 and all(params[4 * m].is_contiguous() for m in range(nm)):
             # every GEMM operand as bf16 in HBM (csrc/gemm16.hip): the small weights once per call (+ transposed copies for
             # the backward-data product), the module inputs in one pass
-            # SREC_DGRAD_BFRAG=1 (D = 128 / 256): the transposed copies in MFMA-fragment-major order for the backward-data kernel
-            # that feeds the weights from L2 straight into registers (csrc/gemm16.hip gemm16_nt_bfrag_kernel)
-            bfrag = D % 128 == 0 and HD % 64 == 0 and os.environ.get('SREC_DGRAD_BFRAG', '0') not in ('0', '')
-            w16, wt16 = weights_bf16([params[4 * m] for m in range(nm)], frag=bfrag)
+            w16, wt16 = weights_bf16([params[4 * m] for m in range(nm)])
             if dstate is not None:
                 x16 = x16_pre if x16_pre is not None else rows_bf16(xcs.view(2 * NT, D)).view(2, NT, D)
                 xin16 = lambda m: x16[plan.mod_conv[m]]
@@ -2710,8 +2459,8 @@ class HGATLayer(torch.autograd.Function):
                      for m in range(nm) for (o, t0, nc, dyn_t) in plan.pieces(m)]
             for i in range(0, len(probs), 16):
                 # rows past a type's live count are never read (every hgat.hip kernel walks the live prefix only)
-                gemm16('nt', probs[i:i + 16], D, D, HD, c16=True, keep_dead=True, variant=_FWD_VARIANT)
-            g16 = (x16, wt16, bfrag)
+                gemm16('nt', probs[i:i + 16], D, D, HD, c16=True, keep_dead=True)
+            g16 = (x16, wt16)
         elif grouped:
             gemm_group(0, [(nr, HD, D, [(xin(m)[r0:r0 + nr], params[4 * m])], P[m], dyn)
                            for m, (r0, nr, dyn) in enumerate(plan.modules)], D, D, HD, c16=True)
@@ -2814,7 +2563,7 @@ class HGATLayer(torch.autograd.Function):
             beta = pend[0][1]
             batch = [pr for pr, b in pend if b == beta][:16]
             pend = [(pr, b) for pr, b in pend if not any(pr is q for q in batch)]
-            gemm16('nt', batch, HD, HD, D, beta=beta, bfrag=ctx.g16[2], variant=int(os.environ.get('SREC_DGRAD_PD', '0')) if ctx.g16[2] else int(os.environ.get('SREC_DGRAD_VAR', '0')))
+            gemm16('nt', batch, HD, HD, D, beta=beta)
         if dstate is not None:
             lib.srec_hg_drop_merge(ptr(tgts), S, ptr(dstate[4]), NT * D, ptr(dx), stream())
         if ctx.g16 is not None:
@@ -2823,23 +2572,20 @@ class HGATLayer(torch.autograd.Function):
             x16 = ctx.g16[0]
             xin16 = (lambda m: x16[plan.mod_conv[m]]) if dstate is not None else (lambda m: x16)
             pcs = [plan.pieces(m) for m in range(nm)]
-            # SREC_WGRAD_SPLIT=s: every (module, piece) product also splits its reduction rows in-kernel into s slabs (more, shorter
-            # workgroups for a launch that otherwise has 384 of them on 256 CUs); the slab sums ride in the deferred launch
-            wsplit = max(1, int(os.environ.get('SREC_WGRAD_SPLIT', '1')))
-            multi = [m for m in range(nm) if len(pcs[m]) * wsplit > 1]
+            multi = [m for m in range(nm) if len(pcs[m]) > 1]
             slabs = {}
             if multi:
                 gWm = torch.empty(len(multi), HD, D, device=dev, dtype=torch.float32)
                 for i, m in enumerate(multi):
                     gWs[m] = gWm[i]
-                    slabs[m] = torch.empty(len(pcs[m]) * wsplit, HD, D, device=dev, dtype=torch.float32)
+                    slabs[m] = torch.empty(len(pcs[m]), HD, D, device=dev, dtype=torch.float32)
             probs = []
             for m in range(nm):
                 for pi, (o, t0, nc, dyn_t) in enumerate(pcs[m]):
-                    tgt = gWs[m] if m not in slabs else slabs[m][pi * wsplit:(pi + 1) * wsplit]
-                    probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t, 0, wsplit))
+                    tgt = gWs[m] if m not in slabs else slabs[m][pi:pi + 1]
+                    probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t, 0, 1))
             for i in range(0, len(probs), 16):
-                gemm16('tn', probs[i:i + 16], HD, D, D, variant=int(os.environ.get('SREC_WGRAD_VAR', '0')))
+                gemm16('tn', probs[i:i + 16], HD, D, D)
             if multi and can_defer(ctx.defer, [ctx.wparams[m] for m in multi]):
                 for i, m in enumerate(multi):
                     defer_slab_sum(slabs[m], gWm[i])

@@ -384,68 +384,6 @@ def test_mshgnn_layer_dropout_gradients_by_finite_differences(dev):
     assert all(abs(num - ana) <= 0.1 * max(abs(num), abs(ana)) + 3e-3 for _, _, num, ana in bad), bad
 
 
-@pytest.mark.parametrize('case', ['fixture_fp32', 'long_sessions_fp32', 'c3_shape_bf16'])
-def test_hg_agg_wave_per_node_equals_the_workgroup_kernel(dev, case, monkeypatch):
-    """hg_agg_node_kernel / hg_bwd_dst_node_kernel (one wavefront per destination node, all heads in the lane, all relation
-    instances side by side) against hg_agg_kernel (8-wave workgroup, wave = head) / hg_bwd_dst_kernel (one wavefront per
-    (instance, destination)) (SREC_HG_AGG=old): layer output bit-identical, gradients to round-off - with feature + attention dropout,
-    on the d = 32 fixture batch, on sessions of 35 - 50 clicks (relations with more than 8 in-edges: the general path) and
-    on a 512-session batch at d = 256 with bf16 projections (the benchmarked shape).  msgifsr.py:70-91, gatconv.py:267-311."""
-    import numpy as np
-    ops, sp, col = pkg('ops'), pkg(), pkg('collate')
-    if case == 'fixture_fp32':
-        z, samples, init = load_golden('msgifsr_K3_s32')
-        d, V = 32, init[[k for k in init if k.startswith('embedding')][0]].shape[0]
-    elif case == 'long_sessions_fp32':
-        rng = np.random.default_rng(3)
-        d, V, samples = 32, 400, []
-        for _ in range(12):
-            L = int(rng.integers(35, 51))
-            pool = rng.integers(0, V, size=max(3, int(L * 0.3)))          # few distinct items: high in-degrees
-            samples.append((pool[rng.integers(0, len(pool), size=L)].tolist(), int(rng.integers(0, V))))
-        samples += [([5], 9), ([7, 7, 7, 7], 1)]
-    else:
-        import bench
-        d, V = 256, 37484
-        _, smp = bench.make_batches('MSGIFSR', 3, 1, 512, V, 20, 123)
-        samples = smp[0]
-    torch.manual_seed(5)
-    model = sp.MSGIFSR(V, 'sample', d, 1, order=3).to(dev)
-    (mg,), _ = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), 3)(samples)
-    mg = mg.to(dev)
-    layer = model.layers[0]
-    NT = sum(mg.meta['ncap'][k] for k in (1, 2, 3))
-    x0 = torch.randn(NT, d, device=dev) * 0.5
-    R = torch.randn(NT, d, device=dev)
-    if case == 'long_sessions_fp32':
-        assert mg.meta['max_deg'] > 8, mg.meta
-    ops.set_precision('bf16' if case.endswith('bf16') else 'fp32')
-    try:
-        plan, params = layer.plan(mg, d)
-        res = {}
-        for mode in ('old', 'node'):
-            monkeypatch.setenv('SREC_HG_AGG', mode)
-            ps = [p.detach().clone().requires_grad_() for p in params]
-            x = x0.clone().requires_grad_()
-            reseed(11)
-            out = ops.hgat_layer(x, plan, ps, (0.3, 0.3))
-            (out * R).sum().backward()
-            res[mode] = [out.detach(), x.grad] + [p.grad for p in ps]
-    finally:
-        ops.set_precision('fp32')
-    assert res['old'][0].abs().max() > 0
-    # forward: same summation order per output element -> bit-identical.  backward: hg_bwd_dst_node_kernel sums the masked dot
-    # products of an edge in another lane order (whole-row loads, 8 columns per lane) -> fp32 round-off apart (and the bf16
-    # rounding of dP on top in bf16 mode)
-    assert torch.equal(res['old'][0], res['node'][0]), (res['old'][0] - res['node'][0]).abs().max().item()
-    tol = 2e-3 if case.endswith('bf16') else 2e-6
-    for i, (a, b) in enumerate(zip(res['old'][1:], res['node'][1:])):
-        assert (a is None) == (b is None)
-        if a is not None and a.norm() > 0:
-            rel = ((a - b).norm() / a.norm()).item()
-            assert rel < tol, 'gradient %d differs: norm-wise %.3e' % (i, rel)
-
-
 class _Replay(torch.nn.Module):
     """dropout stand-in: multiplies by a fixed mask (so both implementations see the same dropped rows)"""
 

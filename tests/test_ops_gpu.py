@@ -967,20 +967,21 @@ def test_gru_expand_all_matches_per_order_fp32_path(dev, d, padded):
             assert rel(a, b) < 2e-2, (p, nm, rel(a, b))
 
 
-@pytest.mark.parametrize('d,padded,nodes,waves', [(256, True, 16, 4), (128, True, 32, 4), (256, False, 32, 4), (128, False, 16, 4),
-                                                  (256, True, 32, 8), (256, False, 16, 8)])
-def test_gru_fused_forward_equals_the_step_path(dev, d, padded, nodes, waves, monkeypatch):
-    """csrc/gruf.hip (whole recurrence in one launch: a workgroup owns 32 nodes, weights streamed fragment-major) against
+@pytest.mark.parametrize('d,padded,big', [(256, True, False), (128, True, False), (256, False, True), (128, False, True),
+                                          (256, True, True), (128, False, False)])
+def test_gru_fused_forward_equals_the_step_path(dev, d, padded, big, monkeypatch):
+    """csrc/gruf.hip (whole recurrence in one launch: a workgroup owns 16 or 32 nodes, weights streamed fragment-major) against
     the step-by-step bf16 path (grux.hip + gemm16.hip) it replaces: same operands, same rounding points, only the order of
-    the fp32 partial sums differs - outputs at 1e-4 and every gradient of the fused backward (csrc/grufb.hip) at 1.5e-3 / 3e-3; all
-    workgroup shapes (16 / 32 nodes, 4 / 8 waves: the launcher picks, SREC_GRU_NR / SREC_GRU_NW force one)."""
+    the fp32 partial sums differs - outputs at 1e-4 and every gradient of the fused backward (csrc/grufb.hip) at 1.5e-3 / 3e-3.
+    Both workgroup shapes: the launcher takes 16-node workgroups while 32-node ones would leave most of the chip idle
+    (<= 192 tiles: the small cases) and 32-node ones beyond (`big`)."""
     ops = _ops()
-    monkeypatch.setenv('SREC_GRU_NR', str(nodes))
-    monkeypatch.setenv('SREC_GRU_NW', str(waves))        # waves per workgroup (8: d = 256 only)
     torch.manual_seed(d + 7)
     ks, caps, lives = [2, 3], [333, 290], [333, 290]          # not multiples of the 32-node tile
     if padded:
         caps, lives = [512, 480], [401, 37]
+    if big:
+        caps, lives = [c * 10 + 3 for c in caps], [l * 10 + 3 for l in lives]
     grus = [torch.nn.GRU(d, d, 1, True, True).to(dev) for _ in ks]
     for g in grus:
         for w in g.parameters():
@@ -1003,10 +1004,10 @@ def test_gru_fused_forward_equals_the_step_path(dev, d, padded, nodes, waves, mo
 
     ops.set_precision('bf16')
     try:
-        monkeypatch.setenv('SREC_UNFUSED_GRU', '1')
+        monkeypatch.setattr(ops, 'FUSED_GRU', False)
         assert not ops.gru_fused_ok(d, 2)
         ref = run()
-        monkeypatch.delenv('SREC_UNFUSED_GRU')
+        monkeypatch.setattr(ops, 'FUSED_GRU', True)
         assert ops.gru_fused_ok(d, 2)
         got = run()
     finally:
@@ -1160,79 +1161,6 @@ def test_readout_head_matches_unfused_ops(dev, n_orders):
         close(a, b, what='grad ' + nm, rtol=2e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('n_orders,B,d', [(1, 512, 256), (2, 96, 64), (3, 40, 128)])
-def test_readout_head_bf16_split_matches_exact_fp32(dev, n_orders, B, d):
-    """bf16 mode: the head's products run as 3-term bf16 hi / lo splits on the bf16 MFMA (ops.ReadoutHeadSplit,
-    csrc/split16.hip) instead of fp32 MFMA - "exact fp32 work on the bf16 pipe".  Against the exact-fp32 grouped head on
-    the same inputs: outputs and every gradient within 1e-4 of the tensor's scale element-wise (three dropped lo x lo
-    terms of 2^-18 each and 2^-18 split residuals per operand, summed over K <= 512 with random signs), i.e. ~250 x
-    tighter than the single-bf16 rounding (2^-9) the head cannot afford; padded layout (live counts below capacity)."""
-    ops = _ops()
-    torch.manual_seed(5)
-    lens = torch.randint(1, 15, (B,))
-    seg = torch.zeros(B + 1, dtype=torch.int32)
-    live_B = B - 3
-    seg[1:] = lens.cumsum(0)
-    seg[live_B + 1:] = seg[live_B]                          # capacity padding: empty sessions behind the live ones
-    n_live = int(seg[live_B])
-    NT = n_live + 77
-    seg_d = seg.to(dev)
-    dT = torch.tensor([n_live], device=dev, dtype=torch.int32)
-    dB = torch.tensor([live_B], device=dev, dtype=torch.int32)
-    allf0 = torch.randn(NT, d, device=dev)
-    allf0 = allf0 / allf0.norm(dim=1, keepdim=True)
-    allf0[n_live:] = 0
-    sc = 1.0 / d ** 0.5
-
-    def params():
-        vv = torch.randn(B, d, device=dev)
-        vv = vv / vv.norm(dim=1, keepdim=True)
-        return [t.requires_grad_() for t in (vv, (torch.rand(d, d, device=dev) * 2 - 1) * sc, (torch.rand(d, device=dev) * 2 - 1) * sc,
-                                             (torch.rand(d, d, device=dev) * 2 - 1) * sc, (torch.rand(1, d, device=dev) * 2 - 1) * sc,
-                                             (torch.rand(d, 2 * d, device=dev) * 2 - 1) * sc)]
-    per = [params() for _ in range(n_orders)]
-    wts = [torch.randn(B, d, device=dev) for _ in range(n_orders)]
-    for w in wts:
-        w[live_B:] = 0
-
-    def run(split):
-        allf = allf0.clone().requires_grad_()
-        ops.set_precision('bf16' if split else 'fp32')
-        try:
-            fn = ops.ReadoutHeadSplit if split else ops.ReadoutHead
-            ss = fn.apply(allf, seg_d, dT, dB, *[t for po in per for t in po])
-            loss = sum((s * w).sum() for s, w in zip(ss, wts))
-            leaves = [allf] + [t for po in per for t in po]
-            grads = torch.autograd.grad(loss, leaves)
-        finally:
-            ops.set_precision('fp32')
-        return [s.detach() for s in ss], grads
-    s1, g1 = run(True)
-    s0, g0 = run(False)
-
-    def near(a, b, what, tol=1e-4, rtol=3e-5):
-        a, b = a.double().cpu(), b.double().cpu()
-        scale = float(b.abs().max())
-        err = float((a - b).abs().max())
-        assert err <= tol * max(scale, 1e-30), '%s: max |err| %.3e against scale %.3e' % (what, err, scale)
-        rel = float((a - b).norm() / b.norm().clamp(min=1e-30))
-        assert rel < rtol, '%s: relative error %.3e' % (what, rel)
-    for i, (a, b) in enumerate(zip(s1, s0)):
-        near(a[:live_B], b[:live_B], 's%d' % i)
-    names = ['allf'] + ['%s%d' % (nm, i) for i in range(n_orders) for nm in ('v', 'Wu', 'bu', 'Wv', 'we', 'Wsr')]
-    for nm, a, b in zip(names, g1, g0):
-        if nm.startswith('v'):
-            a, b = a[:live_B], b[:live_B]
-        # d bu = sum_b dVq and d fc_e = sum_b (...) are column sums over the sessions that cancel to ~1e-3 of their summands:
-        # the split's 2^-17 is relative to the summands (the exact-fp32 head's own round-off is of the same order there)
-        if nm.startswith(('bu', 'we')):
-            near(a, b, 'grad ' + nm, tol=2e-3, rtol=5e-4)
-        elif nm.startswith('W'):                       # sums over sessions / nodes of products of either sign: ~10 x cancellation
-            near(a, b, 'grad ' + nm, tol=5e-4, rtol=3e-4)
-        else:
-            near(a, b, 'grad ' + nm)
-
-
 @pytest.mark.parametrize('n_orders,B,d,maxlen', [(1, 512, 256, 15), (1, 509, 256, 40), (3, 40, 128, 15), (2, 21, 256, 70)])
 def test_fused_readout_head_matches_the_exact_fp32_grouped_head(dev, n_orders, B, d, maxlen):
     """csrc/headf.hip (ops.ReadoutHeadFused: Vq, U, soft-max read-out, fc_sr, F.normalize of a group of 8 sessions per
@@ -1368,10 +1296,9 @@ def test_copy_words_reads_pinned_host_memory(dev, n):
         ops.copy_words(torch.zeros(8, dtype=torch.int32), dst, 8)  # pageable host memory: refused, a kernel cannot read it
 
 
-def test_gemm_f32_group_in_kernel_split_k_sums_equal_the_reduce_launch(dev):
-    """srec_gemm_f32_group_run_fused: the workgroup arriving last at an output tile adds the split-K partial tiles in slab
-    order - bit-identical to the separate reduce launch, repeatable (the arrival counters return to zero), with bias /
-    beta / dynamic row counts / strided outputs"""
+def test_gemm_f32_group_split_k_with_bias_beta_and_dynamic_rows(dev):
+    """srec_gemm_f32_group_run: long-K problems are k-split into slabs and summed in slab order by the reduce launch -
+    repeatable bit for bit, with bias / beta / dynamic row counts next to unsplit problems in one group"""
     ops = _ops()
     g = torch.Generator(device='cpu').manual_seed(9)
     r = lambda *s: torch.randn(*s, generator=g).to(dev)
@@ -1381,24 +1308,17 @@ def test_gemm_f32_group_in_kernel_split_k_sums_equal_the_reduce_launch(dev):
     liveB = torch.tensor([501], device=dev, dtype=torch.int32)
     acc0 = r(B, d)
 
-    def run(fused):
-        old = ops._GEMM_FUSED_REDUCE
-        ops._GEMM_FUSED_REDUCE = fused
-        try:
-            gWu, gWv, out = torch.empty(d, d, device=dev), torch.empty(d, d, device=dev), torch.full((B, d), 5.0, device=dev)
-            acc = acc0.clone()
-            ops.gemm_f32_group([('tn', dU, allf, gWu, None, liveT, 0.0), ('tn', dVq, v, gWv, None, liveB, 0.0),
-                                ('nt', cat, Wsr, out, bias, liveB, 0.0), ('nt', cat, Wsr, acc, None, liveB, 1.0)])
-            return gWu, gWv, out, acc
-        finally:
-            ops._GEMM_FUSED_REDUCE = old
-    ref = run(False)
-    for rep in range(4):
-        got = run(True)
+    def run():
+        gWu, gWv, out = torch.empty(d, d, device=dev), torch.empty(d, d, device=dev), torch.full((B, d), 5.0, device=dev)
+        acc = acc0.clone()
+        ops.gemm_f32_group([('tn', dU, allf, gWu, None, liveT, 0.0), ('tn', dVq, v, gWv, None, liveB, 0.0),
+                            ('nt', cat, Wsr, out, bias, liveB, 0.0), ('nt', cat, Wsr, acc, None, liveB, 1.0)])
+        return gWu, gWv, out, acc
+    ref = run()
+    for rep in range(3):
+        got = run()
         for a, b, nm in zip(got, ref, ('gWu', 'gWv', 'out', 'acc')):
             assert torch.equal(a, b), (rep, nm, (a - b).abs().max().item())
-    tk = ops._GEMM_TK[str(dev)]
-    assert int(tk.abs().sum()) == 0
     close(ref[0], dU[:6543].t() @ allf[:6543], what='gWu', atol=5e-4)
     o = cat @ Wsr.t() + bias
     o[501:] = 0

@@ -1,5 +1,5 @@
 """times the bf16-in-HBM GEMMs at the bench's GAT shapes (12 problems: 3 node types x (intra, inter) x 2 convs), per kernel
-variant: python tools/gemm16_bench.py"""
+python tools/gemm16_bench.py"""
 import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,23 +37,11 @@ dP = [bf(cap, HD) for _ in range(12)]
 tg = [torch.empty(cap, D, device=dev) for _ in range(12)]
 gW = [torch.empty(HD, D, device=dev) for _ in range(12)]
 live_rows = 4 * sum(lives)
-DEFAULT_ONLY = bool(os.environ.get('G16_DEFAULT_ONLY'))     # PMC target: the tuned defaults alone
-for variant in ([0] if DEFAULT_ONLY else [0, 32, 1, 32 | 1, 8 | 1, 32 | 8 | 1, 12 | 1, 32 | 12 | 1]):      # + 32: plain (not XCD-aware) tile order
-    res = {}
-    fwd = lambda: ops.gemm16('nt', [(cap, HD, D, [(x16[i], w16[i])], P[i], dyns[i % 3]) for i in range(12)], D, D, HD,
-                             c16=True, keep_dead=True, variant=variant)
-    dgr = lambda: ops.gemm16('nt', [(cap, D, HD, [(dP[i], wt16[i])], tg[i], dyns[i % 3]) for i in range(12)], HD, HD, D,
-                             variant=variant)
-    try:
-        res['fwd'] = timed(fwd)
-        res['dgrad'] = timed(dgr)
-    except Exception as e:
-        res['err'] = str(e)[:80]
-    print('variant %2d (%s tile order, tile %s, ring %s): ' % (variant, 'plain' if variant & 32 else 'XCD-aware', {0: 'auto', 8: '64', 12: '128'}[variant & 12],
-                                                 ['BK32x4', 'BK64x2', 'BK32x2', 'BK32x3'][variant & 3]),
-          ' '.join('%s %.1f us' % kv if not isinstance(kv[1], str) else '%s %s' % kv for kv in res.items()), flush=True)
-for v, nm in (((0, 'BR64x2 (default)'),) if DEFAULT_ONLY else ((0, 'BR32x4'), (2, 'BR64x2'), (32 | 2, 'BR64x2 plain tile order'), (32, 'BR32x4 plain tile order'))):
-    wg = lambda: ops.gemm16('tn', [(HD, D, cap, [(dP[i], x16[i])], gW[i], dyns[i % 3]) for i in range(12)], HD, D, D, variant=v)
-    print('wgrad tn16 %s: %.1f us' % (nm, timed(wg)))
+res = {}
+fwd = lambda: ops.gemm16('nt', [(cap, HD, D, [(x16[i], w16[i])], P[i], dyns[i % 3]) for i in range(12)], D, D, HD,
+                         c16=True, keep_dead=True)
+dgr = lambda: ops.gemm16('nt', [(cap, D, HD, [(dP[i], wt16[i])], tg[i], dyns[i % 3]) for i in range(12)], HD, HD, D)
+wg = lambda: ops.gemm16('tn', [(HD, D, cap, [(dP[i], x16[i])], gW[i], dyns[i % 3]) for i in range(12)], HD, D, D)
+print('fwd %.1f us, dgrad %.1f us, wgrad %.1f us' % (timed(fwd), timed(dgr), timed(wg)), flush=True)
 fl = 2.0 * live_rows * D * HD
 print('flop per product %.2f GF; at 1 PF/s = %.1f us; P bytes %.0f MB' % (fl / 1e9, fl / 1e15 * 1e6, live_rows * HD * 2 / 1e6))
