@@ -403,6 +403,9 @@ int srec_score_topk(const float* sr, int ld_sr, const float* E, int ld_e, const 
  * (trans_i = 1), once per optimizer step. */
 int srec_head_wfrag(int n, const void* W, const void* dst, const int* rows, const int* cols, const int* trans, void* stream);
 int srec_head_fwd(const void* desc, void* stream);
+/* per-session half of the head's backward (normalise-backward, d cat product, attention read-out backward); desc: HOST
+ * srec_head_bwd_desc (srec_hg.h) */
+int srec_head_bwd(const void* desc, void* stream);
 
 #ifdef __cplusplus
 }

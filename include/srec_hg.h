@@ -243,4 +243,31 @@ typedef struct {
     void* y16[SREC_HEAD_MAXH];
 } srec_head_desc;
 
+/* the per-session half of the head's backward in one launch (srec_head_bwd, csrc/headf.hip): normalise-backward, d cat = g_s Wsr
+ * and the attention read-out backward (msgifsr.py:139-146 under autograd).  Per head: gy [B, d] (row stride ld_gy) = gradient of
+ * the normalised session vectors, y / inv / alpha / U / Vq as srec_head_fwd wrote them, WsrT_f = hi / lo fragment-major copy of
+ * fc_sr^T [2 d, d] (srec_head_wfrag, trans = 1), we [d].  Out: gs [B, d] = gradient of s, gcat [B, 2 d] = gs Wsr (left half:
+ * direct part of d v, right half: d read-out), dX [NT, d] = alpha_i * d read-out of the row's session, dU [NT, d], dVq [B, d],
+ * dwp [B, d] = per-session sums of d e sigma (d fc_e = their column sum); rows / sessions past the live counts: zeros. */
+typedef struct {
+    int nh, d, B, NT, ld_x, ld_gy;
+    const float* X;
+    const int* seg;
+    const int* dynB;
+    const float* gy[SREC_HEAD_MAXH];
+    const float* y[SREC_HEAD_MAXH];
+    const float* inv[SREC_HEAD_MAXH];
+    const void* WsrT_f[SREC_HEAD_MAXH];
+    const float* alpha[SREC_HEAD_MAXH];
+    const float* U[SREC_HEAD_MAXH];
+    const float* Vq[SREC_HEAD_MAXH];
+    const float* we[SREC_HEAD_MAXH];
+    float* gs[SREC_HEAD_MAXH];
+    float* gcat[SREC_HEAD_MAXH];
+    float* dX[SREC_HEAD_MAXH];
+    float* dU[SREC_HEAD_MAXH];
+    float* dVq[SREC_HEAD_MAXH];
+    float* dwp[SREC_HEAD_MAXH];
+} srec_head_bwd_desc;
+
 #endif

@@ -66,6 +66,63 @@ __device__ __forceinline__ void stage4(unsigned short* hi_t, unsigned short* lo_
     *reinterpret_cast<uint2*>(lo_t + off) = l;
 }
 
+// D^T (+)= W . B^T over T k-steps on the bf16 matrix pipe, three terms of the hi / lo split per k-step: A = fragment-major weight
+// (per wave and k-step: JBV hi fragments, then JBV lo fragments - the wave's JBV 32-row blocks of the operand matrix) through
+// a register ring of NS stages fed by plain 1-KiB loads, B = NB 32-row tiles of the hi / lo LDS image bh / bl (row stride W
+// elements, 16-B pieces swizzled by row & 15; tile t = rows brow + 32 t).  Result: lane = B row, registers = operand rows
+// (r & 3) + 8 (r >> 2) + 4 half of block j.  ZERO: start from zero accumulators (else: accumulate onto acc).
+template <int NB, int JBV, bool ZERO = true>
+__device__ __forceinline__ void hl_product(f32x16 (&acc)[2][JBV], const unsigned short* __restrict__ wf, const int T,
+                                           const unsigned short* bh, const unsigned short* bl, const int W, const int brow,
+                                           const int wave, const int lane) {
+    constexpr int NFV = 2 * JBV;
+    const int half = lane >> 5;
+    if (ZERO) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int j = 0; j < JBV; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+    }
+    bf16x8 Aq[NS][NFV];
+    const unsigned short* wsrc = wf + (size_t)wave * T * NFV * 512 + lane * 8;
+    auto load = [&](int i, int slot) {
+        i = min(i, T - 1);
+#pragma unroll
+        for (int f = 0; f < NFV; ++f) Aq[slot][f] = *reinterpret_cast<const bf16x8*>(wsrc + ((size_t)i * NFV + f) * 512);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load(i, i);
+#pragma unroll 1
+    for (int ib = 0; ib < T; ib += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            load(ib + u + PF, (u + PF) % NS);
+            const int s = ib + u;
+            bf16x8 Bh[NB], Bl_[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                const int rw = brow + 32 * t;
+                const int off = rw * W + (((2 * s + half) ^ (rw & 15)) * 8);
+                Bh[t] = *reinterpret_cast<const bf16x8*>(bh + off);
+                Bl_[t] = *reinterpret_cast<const bf16x8*>(bl + off);
+            }
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int j = 0; j < JBV; ++j) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][JBV + j], Bh[t], acc[t][j], 0, 0, 0);     // lo hi
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bl_[t], acc[t][j], 0, 0, 0);          // hi lo
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bh[t], acc[t][j], 0, 0, 0);           // hi hi
+                }
+            __builtin_amdgcn_sched_group_barrier(0x020, NFV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * JBV * NB, 0);
+        }
+    }
+}
+
 template <int DD>
 __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
     constexpr int D = 128 * DD, JB = D / (32 * NW), KS = D / 16, NF = 2 * JB;     // NF: fragments per (wave, k-step): hi | lo
@@ -140,55 +197,7 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
     float* Uout = q.U[hd];
     auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); };
 
-    // D^T (+)= W . B^T over T k-steps: A = fragment-major weight (hi | lo per column block) through the register ring, B = NB
-    // 32-row tiles of the hi / lo LDS image `bh` / `bl` (row stride W; tile t = rows brow + 32 t)
     f32x16 acc[2][JB];
-    auto product = [&](auto NBt, const unsigned short* wf, const int T, const unsigned short* bh, const unsigned short* bl,
-                       const int W, const int brow) {
-        constexpr int NB = decltype(NBt)::value;
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-#pragma unroll
-            for (int j = 0; j < JB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
-        bf16x8 Aq[NS][NF];
-        const unsigned short* wsrc = wf + (size_t)wave * T * NF * 512 + lane * 8;
-        auto load = [&](int i, int slot) {
-            i = min(i, T - 1);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) Aq[slot][f] = *reinterpret_cast<const bf16x8*>(wsrc + ((size_t)i * NF + f) * 512);
-        };
-#pragma unroll
-        for (int i = 0; i < PF; ++i) load(i, i);
-#pragma unroll 1
-        for (int ib = 0; ib < T; ib += NS) {
-#pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                load(ib + u + PF, (u + PF) % NS);
-                const int s = ib + u;
-                bf16x8 Bh[NB], Bl_[NB];
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    const int rw = brow + 32 * t;
-                    const int off = rw * W + (((2 * s + half) ^ (rw & 15)) * 8);
-                    Bh[t] = *reinterpret_cast<const bf16x8*>(bh + off);
-                    Bl_[t] = *reinterpret_cast<const bf16x8*>(bl + off);
-                }
-#pragma unroll
-                for (int t = 0; t < NB; ++t)
-#pragma unroll
-                    for (int j = 0; j < JB; ++j) {
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][JB + j], Bh[t], acc[t][j], 0, 0, 0);     // lo hi
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bl_[t], acc[t][j], 0, 0, 0);         // hi lo
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[u][j], Bh[t], acc[t][j], 0, 0, 0);          // hi hi
-                    }
-                __builtin_amdgcn_sched_group_barrier(0x020, NF, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * JB * NB, 0);
-            }
-        }
-    };
 
     for (int b0 = bfirst; b0 < bend; b0 += HS) {             // passes of HS sessions (one, unless sessions are very short)
         const int ns = min(HS, bend - b0);
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
         HFT(0);
 
         // ---- Vq^T = Wv . v^T: lane = session (l31 & (HS - 1)), registers = this wave's hidden columns
-        product(std::integral_constant<int, 1>{}, (const unsigned short*)q.Wv_f[hd], KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
+        hl_product<1, JB>(acc, (const unsigned short*)q.Wv_f[hd], KS, c_hi, c_lo, 2 * D, l31 & (HS - 1), wave, lane);
         HFT(1);
         if (l31 < HS) {
 #pragma unroll
@@ -253,8 +262,8 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
             __syncthreads();
             HFT(2);
             const bool two = nrows - c0 > 32;
-            if (two) product(std::integral_constant<int, 2>{}, (const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31);
-            else product(std::integral_constant<int, 1>{}, (const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31);
+            if (two) hl_product<2, JB>(acc, (const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31, wave, lane);
+            else hl_product<1, JB>(acc, (const unsigned short*)q.Wu_f[hd], KS, x_hi, x_lo, D, l31, wave, lane);
             HFT(3);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
         HFT(5);
 
         // ---- s^T = Wsr . [v | g]^T (K = 2 d), y = s / max(|s|, eps)
-        product(std::integral_constant<int, 1>{}, (const unsigned short*)q.Wsr_f[hd], 2 * KS, c_hi, c_lo, 2 * D, l31 & (HS - 1));
+        hl_product<1, JB>(acc, (const unsigned short*)q.Wsr_f[hd], 2 * KS, c_hi, c_lo, 2 * D, l31 & (HS - 1), wave, lane);
         HFT(6);
         float ss = 0.f;
 #pragma unroll
@@ -376,6 +385,247 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
                 }
         }
         HFT(7);
+    }
+#ifdef SREC_HEADF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_headf_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 8; ++i) g_headf_tim[blockIdx.x][i] = tim_t[i];
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------- backward, first half
+// Everything of the head's backward that is per SESSION, in one launch over the same row windows as the forward (it replaces
+// normalise-backward, the {d cat} GEMM + its split-K sum and srec_seg_attn_bwd of the grouped path, 43 us in four launches):
+//     g_s = (g_y - y <y, g_y>) / |s|;   d cat = g_s Wsr  (transposed split product, Wsr^T streamed fragment-major: left half =
+//     the direct part of d v, right half = d g);   d alpha_i = <d g_b, x_i>,  d e_i = alpha_i (d alpha_i - sum_j alpha_j d alpha_j);
+//     dX_i = alpha_i d g_b;   dU_i = d e_i we sigma'(U_i + Vq_b),  dVq_b = sum_i dU_i,  dwp_b = sum_i d e_i sigma(U_i + Vq_b)
+// The batch-wide products that remain (d allf += dU Wu, d v += dVq Wv, the weight gradients and the two column sums) stay one
+// grouped launch + one split-K sum (ops.ReadoutHeadFused.backward).  The row phases run over ALL rows of a pass at once (no
+// loop over sessions: every dependent trip to memory costs 1 - 2 us inside a step).
+struct HeadBwdArgs {
+    srec_head_bwd_desc d;
+};
+
+template <int DD>
+__global__ __launch_bounds__(64 * NW, 1) void head_bwd_kernel(HeadBwdArgs a) {
+    constexpr int D = 128 * DD, KS = D / 16, NT = 64 * NW;
+    constexpr int JB4 = 2 * D / (32 * NW);                   // 32-row blocks of Wsr^T [2 D, D] per wave
+    constexpr int GP = D + 8;                                // row stride (floats) of the d g tile
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
+    unsigned short* g_hi = sm;                               // [HS][D] g_s of the pass's sessions
+    unsigned short* g_lo = g_hi + HS * D;
+    float* dg = reinterpret_cast<float*>(g_lo + HS * D);     // [HS][GP] d g = right half of d cat
+    float* vql = dg + HS * GP;                               // [HS][D] Vq of the pass's sessions
+    float* de = vql + HS * D;                                // [HR + MAXN] d alpha, then d e, of the pass's rows
+    float* al = de + HR + MAXN;                              // [HR + MAXN] alpha
+    int* segs = reinterpret_cast<int*>(al + HR + MAXN);      // [HS + 1]
+    int* cnt = segs + HS + 1;                                // [2]
+    int* rs = cnt + 2;                                       // [HR + MAXN] session (0 .. HS-1) of each row of the pass
+    int* segl = rs + HR + MAXN;                              // [B + 1]
+
+    const srec_head_bwd_desc& q = a.d;
+    const int hd = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Bl = dyn_count(q.dynB, q.B);
+    const float* X = q.X;
+    const int ld_x = q.ld_x;
+    float* dX = q.dX[hd];
+    float* dU = q.dU[hd];
+    const int w0 = (int)blockIdx.x * HR, w1 = w0 + HR;
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    {
+        int c0 = 0, c1 = 0;
+        for (int b = tid; b <= Bl; b += NT) {
+            const int sb = q.seg[b];
+            segl[b] = sb;
+            c0 += (b < Bl && sb < w0) ? 1 : 0;
+            c1 += (b < Bl && sb < w1) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); }
+        if (lane == 0) { atomicAdd(&cnt[0], c0); atomicAdd(&cnt[1], c1); }
+    }
+    // capacity padding: sessions past the live count get zero rows of g_s, d cat, dVq, dwp (shared by all workgroups) ...
+    for (int b = Bl + (int)blockIdx.x; b < q.B; b += (int)gridDim.x)
+        for (int c = tid * 4; c < D; c += NT * 4) {
+            *reinterpret_cast<float4*>(q.gs[hd] + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(q.gcat[hd] + (size_t)b * 2 * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(q.gcat[hd] + (size_t)b * 2 * D + D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(q.dVq[hd] + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(q.dwp[hd] + (size_t)b * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    __syncthreads();
+    // ... and the rows behind the last live node zero rows of dX / dU: every workgroup its own window
+    const int ntl = Bl > 0 ? segl[Bl] : 0;
+    for (int r = max(w0, ntl) + (tid >> 6); r < min(w1, q.NT); r += NW) {
+        const int c = lane * 4;
+        if (c < D) {
+            *reinterpret_cast<float4*>(dX + (size_t)r * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(dU + (size_t)r * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (Bl <= 0 || w0 >= ntl) return;
+#ifdef SREC_HEADF_TIMING
+    unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_c = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_headf_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int bfirst = cnt[0], bend = cnt[1];
+    auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); };
+    f32x16 acc[2][JB4];
+
+    for (int b0 = bfirst; b0 < bend; b0 += HS) {
+        const int ns = min(HS, bend - b0);
+        __syncthreads();
+        const int r0 = segl[b0];
+        if (tid <= HS) segs[tid] = segl[b0 + min(tid, ns)] - r0;
+        const int nrows = segl[b0 + ns] - r0;
+        // ---- g_s = (g_y - y <y, g_y>) / |s|: one wavefront per session row, a wave's HS / NW rows requested together
+        {
+            constexpr int SPW = HS / NW;
+            const int c = lane * 4;
+            float4 yv[SPW], gv[SPW];
+            float iv[SPW];
+#pragma unroll
+            for (int k = 0; k < SPW; ++k) {
+                const int sb = wave + NW * k;
+                yv[k] = gv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                iv[k] = 0.f;
+                if (sb < ns && c < D) {
+                    yv[k] = *reinterpret_cast<const float4*>(q.y[hd] + (size_t)(b0 + sb) * D + c);
+                    gv[k] = *reinterpret_cast<const float4*>(q.gy[hd] + (size_t)(b0 + sb) * q.ld_gy + c);
+                }
+                if (sb < ns) iv[k] = q.inv[hd][b0 + sb];
+            }
+#pragma unroll
+            for (int k = 0; k < SPW; ++k) {
+                const int sb = wave + NW * k;
+                const float dot = wave_sum(yv[k].x * gv[k].x + yv[k].y * gv[k].y + yv[k].z * gv[k].z + yv[k].w * gv[k].w);
+                const float4 o = make_float4(iv[k] * (gv[k].x - yv[k].x * dot), iv[k] * (gv[k].y - yv[k].y * dot),
+                                             iv[k] * (gv[k].z - yv[k].z * dot), iv[k] * (gv[k].w - yv[k].w * dot));
+                if (c < D) {
+                    if (sb < ns) *reinterpret_cast<float4*>(q.gs[hd] + (size_t)(b0 + sb) * D + c) = o;
+                    stage4(g_hi, g_lo, D, sb, c, o);
+                }
+            }
+        }
+        // Vq rows of the pass (the column loop below switches session without a trip to memory), the pass's soft-max weights
+        for (int i = tid; i < HS * (D / 4); i += NT) {
+            const int sb = i / (D / 4), c = (i % (D / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sb < ns) v = *reinterpret_cast<const float4*>(q.Vq[hd] + (size_t)(b0 + sb) * D + c);
+            *reinterpret_cast<float4*>(vql + sb * D + c) = v;
+        }
+        for (int i = tid; i < nrows; i += NT) al[i] = q.alpha[hd][r0 + i];
+        __syncthreads();
+        for (int i = tid; i < nrows; i += NT) {          // (segs is published by the barrier above)
+            int sb = 0;
+#pragma unroll
+            for (int k = 1; k < HS; ++k) sb += (i >= segs[k]) ? 1 : 0;
+            rs[i] = min(sb, ns - 1);
+        }
+        HFT(0);
+        // ---- d cat^T = Wsr^T . g_s^T: lane = session, registers = this wave's columns of [d v | d g]
+        hl_product<1, JB4>(acc, (const unsigned short*)q.WsrT_f[hd], KS, g_hi, g_lo, D, l31 & (HS - 1), wave, lane);
+        if (l31 < ns) {
+            float* gc = q.gcat[hd] + (size_t)(b0 + l31) * 2 * D;
+#pragma unroll
+            for (int j = 0; j < JB4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = (wave * JB4 + j) * 32 + 8 * g + 4 * half;        // column of d cat
+                    const float4 v = make_float4(acc[0][j][4 * g], acc[0][j][4 * g + 1], acc[0][j][4 * g + 2], acc[0][j][4 * g + 3]);
+                    *reinterpret_cast<float4*>(gc + col) = v;
+                    if (col >= D) *reinterpret_cast<float4*>(dg + l31 * GP + (col - D)) = v;
+                }
+        }
+        __syncthreads();
+        HFT(1);
+        // ---- d alpha_i = <d g_b, x_i>, dX_i = alpha_i d g_b: one wavefront per row, 8 rows in flight per wave
+        {
+            const int c = lane * 4;
+            for (int i0 = wave; i0 < nrows; i0 += 8 * NW) {
+                float4 xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = min(i0 + k * NW, nrows - 1);
+                    xv[k] = c < D ? *reinterpret_cast<const float4*>(X + (size_t)(r0 + i) * ld_x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k * NW;
+                    const int sb = rs[min(i, nrows - 1)];
+                    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < D) gv = *reinterpret_cast<const float4*>(dg + sb * GP + c);
+                    const float d_ = wave_sum(gv.x * xv[k].x + gv.y * xv[k].y + gv.z * xv[k].z + gv.w * xv[k].w);
+                    if (i < nrows) {
+                        const float a_ = al[i];
+                        if (lane == 0) de[i] = d_;
+                        if (c < D) *reinterpret_cast<float4*>(dX + (size_t)(r0 + i) * D + c) = make_float4(a_ * gv.x, a_ * gv.y, a_ * gv.z, a_ * gv.w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        HFT(2);
+        // d e_i = alpha_i (d alpha_i - sum_j alpha_j d alpha_j): one wavefront per session
+        for (int sb = wave; sb < ns; sb += NW) {
+            const int base = segs[sb], n = min(segs[sb + 1] - base, MAXN);
+            float ssum = 0.f;
+            for (int i = lane; i < n; i += 64) ssum += al[base + i] * de[base + i];
+            ssum = wave_sum(ssum);
+            for (int i = lane; i < n; i += 64) de[base + i] = al[base + i] * (de[base + i] - ssum);
+        }
+        __syncthreads();
+        HFT(3);
+        // ---- dU, dVq, dwp: one hidden column per thread over all rows of the pass in node order (the sums of a session as
+        //      srec_seg_attn_bwd forms them), 8 rows in registers, the next 8 requested before these are used
+        for (int k = tid; k < D; k += NT) {
+            const float wk = q.we[hd][k];
+            const float* up = q.U[hd] + (size_t)r0 * D + k;
+            float* dup = dU + (size_t)r0 * D + k;
+            float uv[8], un[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) uv[j] = up[(size_t)min(j, nrows - 1) * D];
+            int sb = 0, send = segs[1];
+            float vqk = vql[k];
+            float dv = 0.f, dw = 0.f;
+            for (int i = 0; i < nrows; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) un[j] = up[(size_t)min(i + 8 + j, nrows - 1) * D];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = i + j;
+                    if (r < nrows) {
+                        while (r >= send) {              // uniform over the workgroup: the rows of session sb are done
+                            q.dVq[hd][(size_t)(b0 + sb) * D + k] = dv;
+                            q.dwp[hd][(size_t)(b0 + sb) * D + k] = dw;
+                            dv = dw = 0.f;
+                            ++sb;
+                            send = segs[sb + 1];
+                            vqk = vql[min(sb, HS - 1) * D + k];
+                        }
+                        const float sg = sig(uv[j] + vqk);
+                        const float dei = de[r];
+                        dw += dei * sg;
+                        const float dp = dei * wk * sg * (1.f - sg);
+                        dup[(size_t)r * D] = dp;
+                        dv += dp;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) uv[j] = un[j];
+            }
+            for (; sb < ns; ++sb) {                      // the last session (and empty ones behind it)
+                q.dVq[hd][(size_t)(b0 + sb) * D + k] = dv;
+                q.dwp[hd][(size_t)(b0 + sb) * D + k] = dw;
+                dv = dw = 0.f;
+            }
+        }
+        HFT(4);
     }
 #ifdef SREC_HEADF_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -477,6 +727,28 @@ extern "C" int srec_head_fwd(const void* desc, void* stream) {
         if (int rc = srec_lds_optin((const void*)head_fwd_kernel<1>, (int)lds, om[1])) return rc;
         hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
     }
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// desc: HOST srec_head_bwd_desc (srec_hg.h)
+extern "C" int srec_head_bwd(const void* desc, void* stream) {
+    const srec_head_bwd_desc* q = (const srec_head_bwd_desc*)desc;
+    if (q == nullptr || q->nh <= 0 || q->nh > SREC_HEAD_MAXH || (q->d != 128 && q->d != 256) || q->B <= 0 || q->B > 8192 || q->NT <= 0)
+        return SREC_BAD_ARG;
+    if (q->X == nullptr || q->seg == nullptr || (q->ld_x & 3) || (q->ld_gy & 3)) return SREC_BAD_ARG;
+    for (int h = 0; h < q->nh; ++h)
+        if (q->gy[h] == nullptr || q->y[h] == nullptr || q->inv[h] == nullptr || q->WsrT_f[h] == nullptr || q->alpha[h] == nullptr ||
+            q->U[h] == nullptr || q->Vq[h] == nullptr || q->we[h] == nullptr || q->gs[h] == nullptr || q->gcat[h] == nullptr ||
+            q->dX[h] == nullptr || q->dU[h] == nullptr || q->dVq[h] == nullptr || q->dwp[h] == nullptr)
+            return SREC_BAD_ARG;
+    HeadBwdArgs a{};
+    a.d = *q;
+    const int D = q->d;
+    const size_t lds = (size_t)(2 * HS * D) * 2 + (size_t)(HS * (D + 8) + HS * D + 3 * (HR + MAXN)) * 4 + (size_t)(HS + 1 + 2 + q->B + 1) * 4;
+    const dim3 grid((q->NT + HR - 1) / HR, q->nh);
+    if (D == 256) hipLaunchKernelGGL(head_bwd_kernel<2>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(head_bwd_kernel<1>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -1029,6 +1029,13 @@ class HeadDesc(_ct.Structure):
                 [(nm, _ct.c_void_p * 4) for nm in ('cat', 'Wu_f', 'Wv_f', 'Wsr_f', 'bu', 'we', 'alpha', 'U', 'Vq', 'y', 'inv', 'y16')])
 
 
+class HeadBwdDesc(_ct.Structure):
+    """host mirror of srec_head_bwd_desc (include/srec_hg.h)"""
+    _fields_ = ([(nm, _ct.c_int) for nm in ('nh', 'd', 'B', 'NT', 'ld_x', 'ld_gy')] + [(nm, _ct.c_void_p) for nm in ('X', 'seg', 'dynB')] +
+                [(nm, _ct.c_void_p * 4) for nm in ('gy', 'y', 'inv', 'WsrT_f', 'alpha', 'U', 'Vq', 'we', 'gs', 'gcat', 'dX', 'dU',
+                                                   'dVq', 'dwp')])
+
+
 class ReadoutHeadFused(torch.autograd.Function):
     """ReadoutHead + the normalisation of its outputs (msgifsr.py:124-155, :269-273) with the FORWARD as one launch: a
     workgroup owns 8 sessions and runs Vq, U, the soft-max read-out, fc_sr and F.normalize on them, every product as a
@@ -1045,7 +1052,11 @@ class ReadoutHeadFused(torch.autograd.Function):
         per = [(flat[6 * i], _rows(flat[6 * i + 1]), flat[6 * i + 2], _rows(flat[6 * i + 3]),
                 flat[6 * i + 4].reshape(-1).contiguous(), _rows(flat[6 * i + 5])) for i in range(n)]
         B = per[0][0].shape[0]
-        wf = head_wfrag([w for po in per for w in (po[1], po[3], po[5])], [0] * (3 * n))
+        # fragment-major hi / lo copies of fc_u, fc_v, fc_sr - and of fc_sr^T for the backward - in ONE launch per step
+        need_bwd = any(ctx.needs_input_grad)
+        wf = head_wfrag([w for po in per for w in (po[1], po[3], po[5])] + ([po[5] for po in per] if need_bwd else []),
+                        [0] * (3 * n) + ([1] * n if need_bwd else []))
+        ctx.wft = wf[3 * n:] if need_bwd else None
         q = HeadDesc()
         q.nh, q.d, q.B, q.NT, q.ld_x, q.eps_mode, q.eps = n, D, B, NT, _ld(allf), int(eps_mode), 1e-12
         q.X, q.seg, q.dynB = ptr(allf), ptr(seg), ptr(dB)
@@ -1077,18 +1088,59 @@ class ReadoutHeadFused(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gys):
+        """one launch for everything per session (normalise-backward, d cat = g_s Wsr, the attention read-out backward:
+        srec_head_bwd), then the batch-wide products as ONE grouped exact-fp32 launch + its split-K sum:
+        d allf += dU Wu, d v += dVq Wv, d Wu, d Wv, d Wsr and the two column sums (d bu, d we)"""
         allf, seg, *rest = ctx.saved_tensors
-        per, gs = [], []
-        for i in range(ctx.n):
-            *p9, y, inv = rest[11 * i:11 * i + 11]
+        n, dT, dB = ctx.n, ctx.dT, ctx.dB
+        NT, D = allf.shape
+        dev = allf.device
+        per = [rest[11 * i:11 * i + 11] for i in range(n)]
+        B = per[0][0].shape[0]
+        wft = ctx.wft if ctx.wft is not None else head_wfrag([po[4] for po in per], [1] * n)   # fc_sr^T [2 D, D], fragment-major
+        q = HeadBwdDesc()
+        gy0 = _rows(gys[0])
+        q.nh, q.d, q.B, q.NT, q.ld_x, q.ld_gy = n, D, B, NT, _ld(allf), _ld(gy0)
+        q.X, q.seg, q.dynB = ptr(allf), ptr(seg), ptr(dB)
+        outs = []
+        for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat, y, inv) in enumerate(per):
             gy = _rows(gys[i])
-            B, D = y.shape
-            g = torch.empty_like(y)
-            lib.srec_normalize_bwd(ptr(y), D, ptr(gy), _ld(gy), ptr(inv), ptr(g), D, B, ptr(ctx.dB), D, stream())
-            per.append(p9)
-            gs.append(g)
-        out = _readout_head_backward(allf, seg, per, ctx.dT, ctx.dB, ctx.has_bu, gs)
-        return out[:4] + (None, None) + out[4:]
+            if _ld(gy) != q.ld_gy:
+                gy = gy.contiguous() if q.ld_gy == D else gy0.new_empty(B, q.ld_gy)[:, :D].copy_(gy)
+            gs, gcat = torch.empty(B, D, device=dev, dtype=torch.float32), torch.empty(B, 2 * D, device=dev, dtype=torch.float32)
+            dX, dU = torch.empty(NT, D, device=dev, dtype=torch.float32), torch.empty(NT, D, device=dev, dtype=torch.float32)
+            dVq, dwp = torch.empty(B, D, device=dev, dtype=torch.float32), torch.empty(B, D, device=dev, dtype=torch.float32)
+            q.gy[i], q.y[i], q.inv[i], q.WsrT_f[i], q.alpha[i] = ptr(gy), ptr(y), ptr(inv), ptr(wft[i]), ptr(alpha)
+            q.U[i], q.Vq[i], q.we[i] = ptr(U), ptr(Vq), ptr(we)
+            q.gs[i], q.gcat[i], q.dX[i], q.dU[i], q.dVq[i], q.dwp[i] = ptr(gs), ptr(gcat), ptr(dX), ptr(dU), ptr(dVq), ptr(dwp)
+            outs.append((gy, gs, gcat, dX, dU, dVq, dwp))
+        lib.srec_head_bwd(_ct.addressof(q), stream())
+        probs, grads = [], []
+        for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat, y, inv) in enumerate(per):
+            gy, gs, gcat, dX, dU, dVq, dwp = outs[i]
+            gWu, gWv, gWsr = torch.empty_like(Wu), torch.empty_like(Wv), torch.empty_like(Wsr)
+            gv = gcat[:, :D]                                              # d v: the concat half, + dVq Wv in place
+            probs.append(('nn', dU, Wu, dX, None, dT, 1.0))               # d allf (this order) = read-out term + dU Wu
+            probs.append(('tn', dU, allf, gWu, None, dT, 0.0))
+            probs.append(('nn', dVq, Wv, gv, None, dB, 1.0))
+            probs.append(('tn', dVq, v, gWv, None, dB, 0.0))
+            probs.append(('tn', gs, cat, gWsr, None, dB, 0.0))
+            # column sums as products with a block of ones inside the same launch: d bu = sum_n dU = sum_b dVq, d we = sum_b dwp
+            ones = _ones4(B, dev)
+            sums = torch.empty(8, D, device=dev, dtype=torch.float32)
+            gbu = None
+            if ctx.has_bu[i]:
+                probs.append(('tn', ones[:B], dVq, sums[:4], None, dB, 0.0))
+                gbu = sums[0]
+            probs.append(('tn', ones[:B], dwp, sums[4:], None, dB, 0.0))
+            grads.append((gv, gWu, gbu, gWv, sums[4:5], gWsr))
+        per_launch = 14 if len(probs) > 16 else 16          # whole orders per launch (7 problems each)
+        for c in range(0, len(probs), per_launch):
+            gemm_f32_group(probs[c:c + per_launch])
+        g_allf = outs[0][3]
+        for o in outs[1:]:
+            g_allf = g_allf + o[3]
+        return (g_allf, None, None, None, None, None) + tuple(t for gr in grads for t in gr)
 
 
 def readout_head_fused_ok(allf, per_order):

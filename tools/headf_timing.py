@@ -69,3 +69,25 @@ print('phase cycles (wave 0): mean over workgroups | slowest workgroup (%d rows)
 for i, nm in enumerate(names):
     print('  %-24s %8d | %8d' % (nm, tl[:, i].mean(), tl[order[0], i]))
 print('  %-24s %8d | %8d' % ('sum', tl.sum(1).mean(), tl[order[0]].sum()))
+
+# ---- backward (same probe arrays, overwritten by the backward kernel)
+allf_g = allf.clone().requires_grad_()
+ys = ops.readout_head_fused(allf_g, seg, dT, dB, per)
+gy = torch.randn_like(ys[0])
+for _ in range(3):
+    torch.autograd.grad(ys, [allf_g], [gy], retain_graph=True)
+torch.cuda.synchronize()
+assert dll.srec_headf_timing(tim, blk) == 0
+b = np.array(list(blk), dtype=np.int64).reshape(1024, 2)
+t = np.array(list(tim), dtype=np.int64).reshape(1024, 8)
+live = b[:, 1] > b[:, 0]
+t0 = b[live, 0].min()
+st, en = (b[live, 0] - t0) * 0.01, (b[live, 1] - t0) * 0.01
+life = en - st
+print('backward: %d workgroups, span %.1f us, life: mean %.2f median %.2f max %.2f us' % (live.sum(), en.max(), life.mean(), np.median(life), life.max()))
+names = ['g_s / staging', 'd cat product', 'd alpha, dX rows', 'd e', 'dU / dVq / dwp columns']
+tl = t[live]
+order = np.argsort(-life)
+for i, nm in enumerate(names):
+    print('  %-24s %8d | %8d' % (nm, tl[:, i].mean(), tl[order[0], i]))
+print('  %-24s %8d | %8d' % ('sum', tl[:, :5].sum(1).mean(), tl[order[0], :5].sum()))

@@ -13,4 +13,5 @@ f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$f" $out/${tag}_kernel_stats.csv
 t=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 [ -n "$t" ] && python /root/repo/tools/step_trace.py "$t" > $out/${tag}_step_trace.txt
-python /root/repo/tools/step_breakdown.py $out/${tag}_kernel_stats.csv 27 | head -60
+[ -n "$t" ] && python /root/repo/tools/step_breakdown.py "$t" > $out/${tag}_breakdown.txt
+head -70 $out/${tag}_breakdown.txt
