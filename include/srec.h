@@ -156,6 +156,10 @@ int srec_limits(int* max_session_nodes, int* max_degree, int* max_degree_sgat);
  * prepare_batch, /root/reference/src/utils/train.py:26-30, for capacity-padded batches): dst [n] (device) = src [n] int32 words
  * read by a kernel from page-locked HOST memory (or device memory); both 16-byte aligned.  Ordered on `stream`. */
 int srec_copy_words(const int* src, int* dst, long n, void* stream);
+/* the same INSIDE a captured step: the source of this replay is looked up in a mailbox of M entries {address lo, address hi,
+ * words, expected counter} in page-locked host memory at index *counter % M (counter: the optimizer's device-side step count),
+ * so no copy command precedes the graph launch; *err (device) = 1 when the entry's expected counter differs. */
+int srec_copy_words_mailbox(const int* mailbox, int M, const int* counter, int* dst, long cap, int* err, void* stream);
 
 /* ---- per-session kernels (segops.hip): one wavefront per session ------------------------------------
  * attention readout core: srgnn.py:79-86 niser.py:77-84 lessr.py:106-113 msgifsr.py:139-146 */

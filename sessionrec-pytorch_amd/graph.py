@@ -22,6 +22,7 @@ from .batch import FlatBatch
 #   'side'   1.001 ms  hipMemcpyAsync on a side stream into a staging ring + device-to-device copy (also the route of
 #                      pageable host batches, which a kernel cannot read)
 _STAGE_MODE = 'kernel'
+_MAILBOX = 64          # entries of the batch mailbox of a captured step (replays the host may run ahead of the GPU)
 
 
 class GraphedTrainStep:
@@ -84,6 +85,7 @@ class GraphedTrainStep:
         except TypeError:
             self.graph = torch.cuda.CUDAGraph()
         self._pending_advance = None
+        self._setup_mailbox(optimizer, labels.device)
         work = None
         from . import dist as _dist
         c0 = dict(_dist.STATS)
@@ -91,6 +93,7 @@ class GraphedTrainStep:
         try:
             with torch.cuda.graph(self.graph, stream=self._stream):
                 try:
+                    self._capture_intake()
                     self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
                     self.loss.backward(self._one)
                     if self.after_backward is not None:
@@ -128,6 +131,47 @@ class GraphedTrainStep:
                 self.graph.instantiate()
             except Exception:
                 pass
+
+    def _setup_mailbox(self, optimizer, device):
+        """Batch intake as the FIRST kernels of the captured step: each reads where this replay's batch lives from a mailbox
+        in page-locked host memory (index = the optimizer's device-side step count mod _MAILBOX, filled by __call__ before
+        the launch) and copies it into the static buffer - no copy command in front of the graph launch (a device-to-device
+        copy + the gap behind it cost ~12 us per step).  Needs FusedAdam's device counter and 16-byte granular buffers."""
+        self._mb = None
+        ent = getattr(optimizer, '_hyper', {}).get((0, 0)) if isinstance(getattr(optimizer, '_hyper', None), dict) else None
+        if ent is None or any(x.buf.numel() % 4 for x in self.static_inputs):
+            return
+        n = len(self.static_inputs)
+        box = torch.zeros(n, _MAILBOX, 4, dtype=torch.int32).pin_memory()
+        box[:, :, 3] = -1                                  # (no entry carries a valid counter value yet)
+        self._mb = dict(box=box, np=box.numpy(), counter=ent['counter'], err=torch.zeros(1, dtype=torch.int32, device=device),
+                        events=[], held=[], calls=0)
+
+    def _capture_intake(self):
+        if self._mb is None:
+            return
+        from ._lib import lib, stream
+        for i, st in enumerate(self.static_inputs):
+            lib.srec_copy_words_mailbox(self._mb['box'][i].data_ptr(), _MAILBOX, self._mb['counter'].data_ptr(), st.buf.data_ptr(),
+                                        st.buf.numel(), self._mb['err'].data_ptr(), stream())
+
+    def _post(self, i, x, T):
+        """entry T % _MAILBOX of input i <- (address, words, T); the batch buffer must stay untouched until the replay has
+        read it: device tensors are kept alive here, pinned host slots carry the event their owner waits for"""
+        buf = x.buf
+        if not (buf.is_cuda or buf.is_pinned()) or buf.numel() % 4 or buf.data_ptr() % 16:
+            # pageable (or oddly sized) host batch: through a device staging ring, the mailbox then points at the ring slot
+            ring = self.__dict__.setdefault('_mbring', {})
+            if i not in ring:
+                ring[i] = [torch.empty_like(self.static_inputs[i].buf) for _ in range(4)]
+            slot = ring[i][T % 4]
+            slot[:buf.numel()].copy_(buf, non_blocking=False)
+            buf = slot
+        a = buf.data_ptr()
+        lo, hi = a & 0xffffffff, (a >> 32) & 0xffffffff
+        self._mb['np'][i, T % _MAILBOX] = (lo - ((lo & 0x80000000) << 1), hi - ((hi & 0x80000000) << 1),
+                                           min(buf.numel(), self.static_inputs[i].buf.numel()), T)
+        return buf
 
     def node_counts(self):
         """{'kernel': n, 'memcpy': n, 'memset': n, 'other': n} of the captured step (hipGraphGetNodes on the raw hipGraph_t)
@@ -235,11 +279,16 @@ class GraphedTrainStep:
         """inputs: capacity-padded FlatBatches with the captured layout, on the device or still on the host (pinned: the
         DataLoader's batches go straight from pinned memory into the graph's static buffer, see _stage)"""
         from . import ops
+        mb = self._mb
+        T = getattr(self.opt, '_T', 0)                   # the device step counter's value when this replay starts
+        keep = []
         for i, (st, x, sig) in enumerate(zip(self.static_inputs, inputs, self._sig)):
             if self._signature(x) != sig:
                 raise RuntimeError('batch layout / relation pattern differs from the captured one')
             ops.check_limits(x)          # the kernels clamp to their per-session budgets: an oversized session is an error
-            if x.buf.is_cuda:
+            if mb is not None:
+                keep.append(self._post(i, x, T))
+            elif x.buf.is_cuda:
                 st.buf.copy_(x.buf, non_blocking=True)
             else:
                 self._stage(i, x)
@@ -248,4 +297,28 @@ class GraphedTrainStep:
             self.static_labels.copy_(labels, non_blocking=True)
         self.opt.advance(self.work)
         self.graph.replay()
+        if mb is not None:
+            # The replay has been queued.  Its batch buffers may be rewritten once it has run, and the host must not lap the
+            # mailbox (entry T is rewritten _MAILBOX replays later): an event marks the spot - after every replay fed from host
+            # memory (the loader waits for it before it reuses the slot), every 8th replay otherwise (an event record is a
+            # command of its own between two graph launches)
+            mb['calls'] += 1
+            mb['held'].append(keep)
+            host_fed = any(not b.is_cuda for b in keep)
+            if host_fed or mb['calls'] % 8 == 0:
+                done = torch.cuda.Event()
+                done.record()
+                if host_fed:
+                    for x in inputs:
+                        x.meta['_copied'] = done
+                ev = mb['events']
+                ev.append((done, mb['held']))
+                mb['held'] = []
+                limit = (_MAILBOX - 4) if host_fed else (_MAILBOX - 4) // 8
+                while ev and (len(ev) > limit or ev[0][0].query()):
+                    if not ev[0][0].query():
+                        ev[0][0].synchronize()
+                    ev.pop(0)
+            if mb['calls'] % 512 == 0 and int(mb['err'].item()):
+                raise RuntimeError('a replayed step found another step count in its batch mailbox than the host wrote')
         return self.loss

@@ -259,7 +259,8 @@ def _compare_big(case, world, res, ref, extra, bf16):
         hits = sum(len(set(i[b].tolist()) & set(ri[off + b].tolist())) for b in range(n_live)) / (20.0 * n_live)
         assert hits >= (0.97 if bf16 else 0.995), 'rank %d: top-20 sets overlap %.4f' % (r, hits)
         if not bf16:
-            close(v[:n_live], rv[off:off + n_live], rtol=1e-5, atol=1e-5, what='rank %d: top-20 scores' % r)
+            # (scores 12 cos(.) of models that have taken two Adam steps from weights equal to ~1e-6)
+            close(v[:n_live], rv[off:off + n_live], rtol=1e-4, atol=1e-4, what='rank %d: top-20 scores' % r)
         off += n_live
 
 
