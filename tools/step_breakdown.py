@@ -21,7 +21,7 @@ def short(k):
 
 GROUPS = [('scoring', r'flash_ce|ce_reduce|ce_mean|dsr_reduce|bf16_prepare|rownorm_project|row_invnorm|renorm_rows_bf16'),
           ('adam', r'adam'),
-          ('readout head', r'head_fwd|head_wfrag|gemm_f32_group|splitk_reduce_group|seg_attn|cat_cols|normalize_fwd|normalize_bwd'),
+          ('readout head', r'head_fwd|head_bwd|head_wfrag|gemm_f32_group|splitk_reduce_group|seg_attn|cat_cols|normalize_fwd|normalize_bwd'),
           ('bf16 GEMMs (GAT + GRU)', r'gemm_group|gemm16|rows_bf16|weights_bf16|sum_slabs'),
           ('gat_graph', r'hg_'),
           ('gru', r'gru_|gram_|gemm_bf16_tn|splitk|gemm_bf16_nt|gemm_f32'),
