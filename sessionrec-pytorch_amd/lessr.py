@@ -31,7 +31,7 @@ class EOPA(nn.Module):
             ft = self.feat_drop(feat)
             GI = ops.linear(ft, self.gru.weight_ih_l0, self.gru.bias_ih_l0, dN)
             neigh = ops.gru_seq(GI, self.gru.weight_hh_l0, self.gru.bias_hh_l0, _graph(mg), dN, mg.dynp('E'))
-            rst = ops.linear_cat([feat, neigh], torch.cat([self.fc_self.weight, self.fc_neigh.weight], 1), None, dN)
+            rst = ops.linear_sum([feat, neigh], [self.fc_self.weight, self.fc_neigh.weight], None, dN)
         else:
             rst = ops.linear(feat, self.fc_self.weight, None, dN)
         if self.activation is not None:

@@ -233,6 +233,50 @@ class LinearCat(torch.autograd.Function):
         return (gw, gb, None, None) + tuple(gxs)
 
 
+class LinearSum(torch.autograd.Function):
+    """y = sum_i x_i @ W_i^T (+ b): nn.Linear(cat(x_i, dim=1)) with the weight kept as separate blocks W_i [out, k_i] - no
+    concatenation of weights in the forward, no slicing of a combined weight gradient in the backward (LESSR's EOPA:
+    fc_self(feat) + fc_neigh(neigh), lessr.py:36-38)"""
+
+    @staticmethod
+    def forward(ctx, bias, dyn, n, *args):
+        xs, ws = [_rows(x) for x in args[:n]], [_rows(w) for w in args[n:]]
+        M, N = xs[0].shape[0], ws[0].shape[0]
+        y = torch.empty(M, N, device=xs[0].device, dtype=torch.float32)
+        for i, (x, w) in enumerate(zip(xs, ws)):
+            gemm_nt(x, w, y, bias if i == 0 else None, dyn, 1 if dyn is not None else 0, 0.0 if i == 0 else 1.0)
+        ctx.save_for_backward(*xs, *ws)
+        ctx.dyn, ctx.n, ctx.has_bias = dyn, n, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, dyn = ctx.n, ctx.dyn
+        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        gy = _rows(gy)
+        gxs, gws = [], []
+        for i, (x, w) in enumerate(zip(xs, ws)):
+            gx = None
+            if ctx.needs_input_grad[3 + i]:
+                gx = torch.empty_like(x, memory_format=torch.contiguous_format)
+                gemm_nn(gy, w, gx, dyn, 1 if dyn is not None else 0)
+            gw = None
+            if ctx.needs_input_grad[3 + n + i]:
+                gw = torch.empty_like(w)
+                gemm_tn(gy, x, gw, dyn)
+            gxs.append(gx)
+            gws.append(gw)
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[0]:
+            gb = torch.empty(ws[0].shape[0], device=gy.device, dtype=torch.float32)
+            col_sum(gy, gy.shape[0], ws[0].shape[0], gb, dyn)
+        return (gb, None, None) + tuple(gxs) + tuple(gws)
+
+
+def linear_sum(xs, ws, bias=None, dyn=None):
+    return LinearSum.apply(bias, dyn, len(xs), *xs, *ws)
+
+
 def linear(x, weight, bias=None, dyn=None, exact=False):
     """exact=True: fp32 MFMA regardless of set_precision (the readout / session-vector head, whose output is scaled
     by 12 before the soft-max in NISER / MSGIFSR)"""
@@ -2115,9 +2159,11 @@ class GRUSeq(torch.autograd.Function):
         Whh = Whh.contiguous()
         WhhT = Whh.t().contiguous()
         neigh = torch.empty(N, D, device=dev, dtype=torch.float32)
-        gates = torch.zeros(max(E, 1), D3, device=dev, dtype=torch.float32)
-        Hprev = torch.zeros(max(E, 1), D, device=dev, dtype=torch.float32)
-        ghn = torch.zeros(max(E, 1), D, device=dev, dtype=torch.float32)
+        # edge records: every live edge is an in-edge of exactly one live node and is written by the kernel; every reader
+        # (the backward kernel, the dyn-clamped weight-gradient products) stops at the live edges - no zero fill
+        gates = torch.empty(max(E, 1), D3, device=dev, dtype=torch.float32)
+        Hprev = torch.empty(max(E, 1), D, device=dev, dtype=torch.float32)
+        ghn = torch.empty(max(E, 1), D, device=dev, dtype=torch.float32)
         lib.srec_gru_seq_fwd(ptr(GI), _ld(GI), ptr(WhhT), ptr(bhh), ptr(in_ptr), ptr(in_idx), ptr(esrc), N, ptr(dyn), D,
                              ptr(neigh), D, ptr(gates), ptr(Hprev), ptr(ghn), stream())
         ctx.save_for_backward(Whh, gates, Hprev, ghn)
@@ -2131,17 +2177,17 @@ class GRUSeq(torch.autograd.Function):
         N, D, E = ctx.shape
         dev = Whh.device
         dneigh = _rows(dneigh)
-        dGIe = torch.zeros(max(E, 1), 3 * D, device=dev, dtype=torch.float32)
-        dGHe = torch.zeros(max(E, 1), 3 * D, device=dev, dtype=torch.float32)
+        dGIe = torch.empty(max(E, 1), 3 * D, device=dev, dtype=torch.float32)
+        dGHe = torch.empty(max(E, 1), 3 * D, device=dev, dtype=torch.float32)
         lib.srec_gru_seq_bwd(ptr(dneigh), _ld(dneigh), ptr(Whh), ptr(gates), ptr(Hprev), ptr(ghn), ptr(in_ptr),
                              ptr(in_idx), N, ptr(ctx.dyn), D, ptr(dGIe), ptr(dGHe), stream())
         # per-source sum of the edge records (out-edge CSR), then weight gradients as GEMMs over the E records
-        dGI = torch.zeros(N, 3 * D, device=dev, dtype=torch.float32)
+        dGI = torch.empty(N, 3 * D, device=dev, dtype=torch.float32)      # every live row written (rows past dyn: never read)
         ar = _arange(N + 1, dev)
         lib.srec_scatter_add_sorted(ptr(dGIe), 3 * D, ptr(ar), ptr(out_ptr), ptr(out_idx), ptr(dGI), 3 * D, N,
                                     ptr(ctx.dyn), 3 * D, 0, stream())
-        dWhh = torch.zeros(3 * D, D, device=dev, dtype=torch.float32)
-        dbhh = torch.zeros(3 * D, device=dev, dtype=torch.float32)
+        dWhh = (torch.empty if E > 0 else torch.zeros)(3 * D, D, device=dev, dtype=torch.float32)
+        dbhh = (torch.empty if E > 0 else torch.zeros)(3 * D, device=dev, dtype=torch.float32)
         if E > 0:
             gemm_tn(dGHe[:E], Hprev[:E], dWhh, ctx.dynE)       # padded edge records are zero rows
             col_sum(dGHe, E, 3 * D, dbhh, ctx.dynE)

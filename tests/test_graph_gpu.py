@@ -153,3 +153,47 @@ def test_sharded_single_rank_with_padded_batch(dev):
     l2.backward()
     close(l2, l1, rtol=1e-6, atol=1e-6, what='loss')
     close(vp.dE[:V], plain.table_grad.buf, rtol=1e-4, atol=1e-7, what='table grad')
+
+
+@pytest.mark.parametrize('kind', ['niser', 'lessr'])
+def test_mailbox_intake_from_device_pinned_and_pageable_batches(dev, kind):
+    """Batch intake of a replayed step (graph.GraphedTrainStep, csrc/rowops.hip copy_words_mailbox_kernel): the first
+    kernel of the captured step looks the batch up in a page-locked mailbox at the optimizer's device step count.  200
+    replays queued WITHOUT synchronisation - more than three laps of the 64-entry mailbox - fed in turn from device
+    tensors, page-locked host buffers (a loader slot, read over PCIe inside the graph) and pageable host buffers (staged)
+    end on the parameters of the same 200 steps with a device sync after each; eager steps in between (a batch with
+    another layout) keep the mailbox index in step with the device counter; the mismatch flag stays clear."""
+    c, train, optim, G = pkg('collate'), pkg('train'), pkg('optim'), pkg('graph')
+    rng = np.random.default_rng(9)
+    V = 400
+    caps = c.default_caps(32, 12)
+    if kind == 'lessr':
+        caps = dict(caps, E=caps['N'] * 7)
+    finals = []
+    host_batches = None
+    for sync in (True, False):
+        torch.manual_seed(0)
+        model, mk = _setup(kind, dev, V)
+        if host_batches is None:
+            host_batches = [mk(caps)(_samples(rng, 32, V)) for _ in range(40)]
+            odd = mk(None)(_samples(rng, 32, V))                 # exact layout: cannot replay, runs eagerly
+        runner = train.TrainRunner('x', model, [], None, dev, lr=1e-2, weight_decay=1e-4)
+        model.train()
+        for k in range(200):
+            xs, lab = host_batches[k % len(host_batches)]
+            if k % 3 == 0:
+                xs, lab = [x.to(dev) for x in xs], lab.to(dev)
+            elif k % 3 == 1:
+                xs = [type(x)(x.buf.pin_memory(), x.layout, dict(x.meta)) for x in xs]
+            if k in (50, 51, 130):
+                runner.train_step(*odd)                            # an eager step between replays
+            runner.train_step(xs, lab)
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        gs = runner._gstep
+        assert gs is not None and gs._mb is not None and runner.graph_steps == 200 and runner.eager_steps == 3
+        assert int(gs._mb['err'].item()) == 0
+        finals.append({k_: v.detach().clone() for k_, v in model.state_dict().items()})
+    for k_ in finals[0]:
+        assert torch.equal(finals[0][k_], finals[1][k_]), k_
