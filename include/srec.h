@@ -226,9 +226,13 @@ int srec_edge_agg(const float* X, int ld_x, const int* ptr, const int* idx, cons
                   int n_cap, const int* dyn, int D, float* out, int ld_o, void* stream);
 
 /* ---- LESSR (bn.hip, gruseq.hip, sgat.hip) -------------------------------------------------------------
- * BatchNorm1d lessr.py:12,32,56,66,90,105,162,179 (ws = 32*D floats); PReLU lessr.py:140,149,159 */
-int srec_bn_stats(const float* X, int ld, int n_cap, const int* dyn, int D, float* mean, float* var, float* rmean,
-                  float* rvar, float momentum, float* ws, void* stream);
+ * BatchNorm1d lessr.py:12,32,56,66,90,105,162,179 (ws = 64*D floats); PReLU lessr.py:140,149,159 (ws = 32*D).
+ * srec_bn_fwd_train: training mode in two launches - batch statistics over the live rows, y, mean / biased var [D] for the
+ * backward, and nn.BatchNorm1d's buffer updates (running_mean / running_var with the unbiased variance, nbt =
+ * num_batches_tracked (int64) += 1; all three nullable).  srec_bn_apply_fwd: eval mode (given statistics). */
+int srec_bn_fwd_train(const float* X, int ld_x, int n_cap, const int* dyn, int D, const float* gamma, const float* beta,
+                      float eps, float momentum, float* rmean, float* rvar, long long* nbt, float* mean, float* var,
+                      float* Y, int ld_y, float* ws, void* stream);
 int srec_bn_apply_fwd(const float* X, int ld_x, const float* mean, const float* var, float eps, const float* gamma,
                       const float* beta, int n_cap, const int* dyn, int D, float* Y, int ld_y, void* stream);
 int srec_bn_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const float* mean, const float* var, float eps,
@@ -237,12 +241,13 @@ int srec_bn_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const floa
 int srec_prelu_fwd(const float* X, int ld_x, const float* a, int n_cap, const int* dyn, int D, float* Y, int ld_y,
                    void* stream);
 int srec_prelu_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const float* a, int n_cap, const int* dyn,
-                   int D, float* dX, int ld_dx, float* T, int ld_t, void* stream);
+                   int D, float* dX, int ld_dx, float* da, float* ws, void* stream);
 /* EOPA: per node GRU over in-neighbours in edge-id order (lessr.py:20-27,35).  GI [Nsrc,3D] = ft W_ih^T + b_ih;
- * WhhT [D,3D] k-major copy, Whh [3D,D] as stored; gates [E,3D], Hprev/ghn [E,D], dGIe/dGHe [E,3D] by edge id. */
-int srec_gru_seq_fwd(const float* GI, int ld_gi, const float* WhhT, const float* bhh, const int* in_ptr,
-                     const int* in_idx, const int* esrc, int n_cap, const int* dyn, int D, float* neigh, int ld_n,
-                     float* gates, float* Hprev, float* ghn, void* stream);
+ * Whh [3D,D] as stored, WhhT [D,3D] k-major copy (read only when D > 32, else nullable: W_hh is held in registers);
+ * gates [E,3D], Hprev/ghn [E,D], dGIe/dGHe [E,3D] by edge id. */
+int srec_gru_seq_fwd(const float* GI, int ld_gi, const float* Whh, const float* WhhT, const float* bhh,
+                     const int* in_ptr, const int* in_idx, const int* esrc, int n_cap, const int* dyn, int D,
+                     float* neigh, int ld_n, float* gates, float* Hprev, float* ghn, void* stream);
 int srec_gru_seq_bwd(const float* dneigh, int ld_dn, const float* Whh, const float* gates, const float* Hprev,
                      const float* ghn, const int* in_ptr, const int* in_idx, int n_cap, const int* dyn, int D,
                      float* dGIe, float* dGHe, void* stream);

@@ -18,7 +18,7 @@ _CT = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float,
     'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p, 'const int*': ctypes.c_void_p,
     'int*': ctypes.c_void_p, 'void*': ctypes.c_void_p, 'const float* const*': ctypes.c_void_p,
-    'unsigned char*': ctypes.c_void_p, 'const unsigned char*': ctypes.c_void_p, 'const long long*': ctypes.c_void_p, 'const void*': ctypes.c_void_p, 'long*': ctypes.c_void_p, 'const long*': ctypes.c_void_p,
+    'unsigned char*': ctypes.c_void_p, 'const unsigned char*': ctypes.c_void_p, 'const long long*': ctypes.c_void_p, 'long long*': ctypes.c_void_p, 'const void*': ctypes.c_void_p, 'long*': ctypes.c_void_p, 'const long*': ctypes.c_void_p,
 }
 
 

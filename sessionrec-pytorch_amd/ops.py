@@ -163,11 +163,45 @@ def gemm_tn(g, x, out, dyn=None, beta=0.0):
                       2 if dyn is not None else 0, 1.0, beta, *_gemm_ws(g.device), stream())
 
 
+_SMALL_LINEAR = 128 * 256       # weight elements up to which a linear layer is launch-bound, not flop-bound
+
+
+def _small_linear(*ws):
+    return sum(w.numel() for w in ws) <= _SMALL_LINEAR
+
+
+def _linear_backward_group(gy, xs, ws, gws, need_x, need_b, dyn):
+    """backward of y = sum_i x_i W_i^T + b as ONE grouped exact-fp32 launch (+ its slab sum): d x_i = gy W_i, d W_i =
+    gy^T x_i into gws[i] (None: not needed), d b = column sums of gy as a product with a block of ones - instead of a GEMM
+    per product, a split-K sum per weight gradient and two column-sum launches.  -> ([d x_i], d b)"""
+    M, N = gy.shape
+    probs, gxs = [], []
+    for x, w, gw, nx in zip(xs, ws, gws, need_x):
+        gx = None
+        if nx:
+            gx = torch.empty_like(x, memory_format=torch.contiguous_format)
+            probs.append(('nn', gy, w, gx, None, dyn, 0.0))
+        if gw is not None:
+            probs.append(('tn', gy, x, gw, None, dyn, 0.0))
+        gxs.append(gx)
+    gb = None
+    if need_b:
+        sums = torch.empty(4, N, device=gy.device, dtype=torch.float32)
+        probs.append(('tn', _ones4(M, gy.device)[:M], gy, sums, None, dyn, 0.0))
+        gb = sums[0]
+    for c in range(0, len(probs), 16):
+        gemm_f32_group(probs[c:c + 16])
+    return gxs, gb
+
+
 class LinearCat(torch.autograd.Function):
-    """y = sum_i x_i @ W[:, off_i:off_i+k_i]^T + b   == nn.Linear(cat(x_i, dim=1)) without the concat."""
+    """y = sum_i x_i @ W[:, off_i:off_i+k_i]^T + b   == nn.Linear(cat(x_i, dim=1)) without the concat.  Exact fp32 products
+    when asked for (exact) and for small weights (launch-bound either way: one rounding fewer, and the backward becomes
+    one grouped launch)."""
 
     @staticmethod
     def forward(ctx, weight, bias, dyn, exact, *xs):
+        exact = exact or _small_linear(weight)
         ctx.exact = exact
         if exact and PRECISION['matmul'] != 'fp32':         # session-vector head: exact fp32 MFMA even in bf16 mode
             prev, PRECISION['matmul'] = PRECISION['matmul'], 'fp32'
@@ -213,6 +247,14 @@ class LinearCat(torch.autograd.Function):
         gy = _rows(gy)
         need_x = ctx.needs_input_grad[4:]
         gw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        if _small_linear(w) and gy.shape[0] > 0:
+            offs = [0]
+            for x in xs:
+                offs.append(offs[-1] + x.shape[1])
+            gxs, gb = _linear_backward_group(gy, xs, [w[:, a:b] for a, b in zip(offs, offs[1:])],
+                                             [None if gw is None else gw[:, a:b] for a, b in zip(offs, offs[1:])], need_x,
+                                             ctx.has_bias and ctx.needs_input_grad[1], dyn)
+            return (gw, gb, None, None) + tuple(gxs)
         gb = None
         gxs = []
         off = 0
@@ -243,8 +285,15 @@ class LinearSum(torch.autograd.Function):
         xs, ws = [_rows(x) for x in args[:n]], [_rows(w) for w in args[n:]]
         M, N = xs[0].shape[0], ws[0].shape[0]
         y = torch.empty(M, N, device=xs[0].device, dtype=torch.float32)
-        for i, (x, w) in enumerate(zip(xs, ws)):
-            gemm_nt(x, w, y, bias if i == 0 else None, dyn, 1 if dyn is not None else 0, 0.0 if i == 0 else 1.0)
+        ctx.small = _small_linear(*ws)
+        prev = PRECISION['matmul']
+        if ctx.small:
+            PRECISION['matmul'] = 'fp32'
+        try:
+            for i, (x, w) in enumerate(zip(xs, ws)):
+                gemm_nt(x, w, y, bias if i == 0 else None, dyn, 1 if dyn is not None else 0, 0.0 if i == 0 else 1.0)
+        finally:
+            PRECISION['matmul'] = prev
         ctx.save_for_backward(*xs, *ws)
         ctx.dyn, ctx.n, ctx.has_bias = dyn, n, bias is not None
         return y
@@ -254,6 +303,11 @@ class LinearSum(torch.autograd.Function):
         n, dyn = ctx.n, ctx.dyn
         xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
         gy = _rows(gy)
+        if ctx.small and gy.shape[0] > 0:
+            gws = [torch.empty_like(w) if ctx.needs_input_grad[3 + n + i] else None for i, w in enumerate(ws)]
+            gxs, gb = _linear_backward_group(gy, xs, ws, gws, ctx.needs_input_grad[3:3 + n],
+                                             ctx.has_bias and ctx.needs_input_grad[0], dyn)
+            return (gb, None, None) + tuple(gxs) + tuple(gws)
         gxs, gws = [], []
         for i, (x, w) in enumerate(zip(xs, ws)):
             gx = None
@@ -2074,21 +2128,22 @@ class BatchNorm(torch.autograd.Function):
     """nn.BatchNorm1d over the live rows (training: batch statistics + running-stat update)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, dyn):
+    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, training, momentum, eps, dyn):
         x = _rows(x)
         n, D = x.shape
         dev = x.device
-        ws = _ws(32 * D, dev)
+        y = torch.empty(n, D, device=dev, dtype=torch.float32)
         if training:
             mean = torch.empty(D, device=dev, dtype=torch.float32)
             var = torch.empty(D, device=dev, dtype=torch.float32)
-            lib.srec_bn_stats(ptr(x), _ld(x), n, ptr(dyn), D, ptr(mean), ptr(var), ptr(rmean), ptr(rvar),
-                              float(momentum), ptr(ws), stream())
+            assert nbt is None or nbt.dtype == torch.int64
+            lib.srec_bn_fwd_train(ptr(x), _ld(x), n, ptr(dyn), D, ptr(gamma), ptr(beta), float(eps), float(momentum),
+                                  ptr(rmean), ptr(rvar), ptr(nbt), ptr(mean), ptr(var), ptr(y), D, ptr(_ws(64 * D, dev)),
+                                  stream())
         else:
             mean, var = rmean, rvar
-        y = torch.empty(n, D, device=dev, dtype=torch.float32)
-        lib.srec_bn_apply_fwd(ptr(x), _ld(x), ptr(mean), ptr(var), float(eps), ptr(gamma), ptr(beta), n, ptr(dyn), D,
-                              ptr(y), D, stream())
+            lib.srec_bn_apply_fwd(ptr(x), _ld(x), ptr(mean), ptr(var), float(eps), ptr(gamma), ptr(beta), n, ptr(dyn), D,
+                                  ptr(y), D, stream())
         ctx.save_for_backward(x, mean, var, gamma)
         ctx.meta = (training, eps, dyn)
         return y
@@ -2104,16 +2159,16 @@ class BatchNorm(torch.autograd.Function):
         dg = torch.empty(D, device=dev, dtype=torch.float32)
         db = torch.empty(D, device=dev, dtype=torch.float32)
         lib.srec_bn_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(mean), ptr(var), float(eps), ptr(gamma),
-                        1 if training else 0, n, ptr(dyn), D, ptr(dx), D, ptr(dg), ptr(db), ptr(_ws(32 * D, dev)),
+                        1 if training else 0, n, ptr(dyn), D, ptr(dx), D, ptr(dg), ptr(db), ptr(_ws(64 * D, dev)),
                         stream())
-        return dx, dg, db, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
 def batch_norm(x, bn, dyn=None):
     """bn: an nn.BatchNorm1d used as parameter / running-stat container"""
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
-    return BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, dyn)
+    track = bn.training and bn.track_running_stats
+    return BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked if track else None,
+                           bn.training, bn.momentum, bn.eps, dyn)
 
 
 class PReLU(torch.autograd.Function):
@@ -2133,10 +2188,9 @@ class PReLU(torch.autograd.Function):
         gy = _rows(gy)
         n, D = x.shape
         dx = torch.empty(n, D, device=x.device, dtype=torch.float32)
-        T = torch.empty(n, D, device=x.device, dtype=torch.float32)
-        lib.srec_prelu_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(a), n, ptr(ctx.dyn), D, ptr(dx), D, ptr(T), D, stream())
         da = torch.empty(D, device=x.device, dtype=torch.float32)
-        col_sum(T, n, D, da, ctx.dyn)
+        lib.srec_prelu_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(a), n, ptr(ctx.dyn), D, ptr(dx), D, ptr(da),
+                           ptr(_ws(32 * D, x.device)), stream())
         return dx, da, None
 
 
@@ -2157,14 +2211,14 @@ class GRUSeq(torch.autograd.Function):
         E = esrc.numel()
         dev = GI.device
         Whh = Whh.contiguous()
-        WhhT = Whh.t().contiguous()
+        WhhT = Whh.t().contiguous() if D > 32 else None      # D <= 32: the kernel keeps W_hh's rows in registers
         neigh = torch.empty(N, D, device=dev, dtype=torch.float32)
         # edge records: every live edge is an in-edge of exactly one live node and is written by the kernel; every reader
         # (the backward kernel, the dyn-clamped weight-gradient products) stops at the live edges - no zero fill
         gates = torch.empty(max(E, 1), D3, device=dev, dtype=torch.float32)
         Hprev = torch.empty(max(E, 1), D, device=dev, dtype=torch.float32)
         ghn = torch.empty(max(E, 1), D, device=dev, dtype=torch.float32)
-        lib.srec_gru_seq_fwd(ptr(GI), _ld(GI), ptr(WhhT), ptr(bhh), ptr(in_ptr), ptr(in_idx), ptr(esrc), N, ptr(dyn), D,
+        lib.srec_gru_seq_fwd(ptr(GI), _ld(GI), ptr(Whh), ptr(WhhT), ptr(bhh), ptr(in_ptr), ptr(in_idx), ptr(esrc), N, ptr(dyn), D,
                              ptr(neigh), D, ptr(gates), ptr(Hprev), ptr(ghn), stream())
         ctx.save_for_backward(Whh, gates, Hprev, ghn)
         ctx.graph, ctx.dyn, ctx.dynE, ctx.shape = graph, dyn, dynE, (N, D, E)
@@ -2188,7 +2242,12 @@ class GRUSeq(torch.autograd.Function):
                                     ptr(ctx.dyn), 3 * D, 0, stream())
         dWhh = (torch.empty if E > 0 else torch.zeros)(3 * D, D, device=dev, dtype=torch.float32)
         dbhh = (torch.empty if E > 0 else torch.zeros)(3 * D, device=dev, dtype=torch.float32)
-        if E > 0:
+        if E > 0 and _small_linear(Whh):                       # one grouped launch: d W_hh and d b_hh (product with ones)
+            sums = torch.empty(4, 3 * D, device=dev, dtype=torch.float32)
+            gemm_f32_group([('tn', dGHe[:E], Hprev[:E], dWhh, None, ctx.dynE, 0.0),
+                            ('tn', _ones4(E, dev)[:E], dGHe[:E], sums, None, ctx.dynE, 0.0)])
+            dbhh = sums[0]
+        elif E > 0:
             gemm_tn(dGHe[:E], Hprev[:E], dWhh, ctx.dynE)       # padded edge records are zero rows
             col_sum(dGHe, E, 3 * D, dbhh, ctx.dynE)
         return dGI, dWhh, dbhh, None, None, None

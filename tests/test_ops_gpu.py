@@ -436,6 +436,106 @@ def test_batch_norm_prelu(dev):
     close(a.grad, a2.grad, what='prelu da', atol=1e-4)
 
 
+@pytest.mark.parametrize('n,cap,D', [(200, 200, 96), (1000, 1280, 24), (17, 64, 300), (4097, 4097, 32)])
+def test_batch_norm_chunk_statistics(dev, n, cap, D):
+    """two-launch BatchNorm (per-chunk sum / M2 partials, combined inside the normalising kernel) == nn.BatchNorm1d on the
+    live rows: capacity-padded input with a device-side row count, fewer rows than chunks, a column mean 100 x its
+    deviation (the M2 combination must not cancel), running statistics and num_batches_tracked after two steps."""
+    ops = _ops()
+    torch.manual_seed(n + D)
+    x = torch.randn(cap, D, device=dev) * torch.linspace(0.5, 3, D, device=dev) + torch.linspace(-5, 5, D, device=dev)
+    x[:, 0] = 100.0 + torch.randn(cap, device=dev)
+    x[n:] = 7e5                                               # padding rows: never read
+    dyn = torch.tensor([n], dtype=torch.int32, device=dev)
+    bn1, bn2 = torch.nn.BatchNorm1d(D).to(dev), torch.nn.BatchNorm1d(D).to(dev).double()      # yardstick: fp64
+    for step in range(2):
+        x1, x2 = x.clone().requires_grad_(), x[:n].double().requires_grad_()
+        y1, y2 = ops.batch_norm(x1, bn1, dyn), bn2(x2)
+        close(y1[:n], y2, what='y', atol=2e-4)                # column 0: x - mean loses 7 bits to the cancellation, both sides
+        assert cap == n or float(y1.detach()[n:].abs().max()) == 0.0
+        g = torch.randn(cap, D, device=dev)
+        y1.backward(g)
+        y2.backward(g[:n].double())
+        close(x1.grad[:n], x2.grad, what='dx', atol=2e-4)
+        close(bn1.weight.grad, bn2.weight.grad, what='dgamma', atol=2e-3, rtol=1e-4)
+        close(bn1.bias.grad, bn2.bias.grad, what='dbeta', atol=2e-4, rtol=1e-4)
+        bn1.zero_grad(); bn2.zero_grad()
+    close(bn1.running_mean, bn2.running_mean, what='running mean', rtol=1e-5)
+    close(bn1.running_var, bn2.running_var, what='running var', rtol=1e-4)
+    assert int(bn1.num_batches_tracked) == int(bn2.num_batches_tracked) == 2
+    a = torch.rand(D, device=dev, requires_grad=True)
+    x1 = x.clone().requires_grad_()
+    y = ops.prelu(x1, a, dyn)
+    a2, x2 = a.detach().clone().requires_grad_(), x[:n].clone().requires_grad_()
+    r = torch.nn.functional.prelu(x2, a2)
+    g = torch.randn(cap, D, device=dev)
+    y.backward(g)
+    r.backward(g[:n])
+    close(y[:n], r, what='prelu')
+    close(x1.grad[:n], x2.grad, what='prelu dx')
+    assert cap == n or float(x1.grad[n:].abs().max()) == 0.0
+    close(a.grad, a2.grad, what='prelu da', rtol=1e-4, atol=1e-3 * float(a2.grad.abs().max()))
+
+
+@pytest.mark.parametrize('D', [16, 24, 32, 48])
+def test_gru_seq_matches_a_gru_cell_loop(dev, D):
+    """EOPA's per-node GRU over the in-edges in edge-id order (lessr.py:20-27,35) vs a torch loop of GRU-cell steps on the
+    precomputed input projections: last hidden state per node, dGI, dW_hh, db_hh.  D <= 32 runs the register-resident
+    kernels, D = 48 the streaming ones; in-degrees 0 .. 9, 40 padded nodes."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(D)
+    N, cap = 300, 340
+    deg = torch.randint(0, 10, (N,), generator=g)
+    deg[5] = 0
+    edst = torch.repeat_interleave(torch.arange(N), deg)
+    E = int(edst.numel())
+    perm = torch.randperm(E, generator=g)
+    edst = edst[perm]                                         # edge ids in random order over the destinations
+    esrc = torch.randint(0, N, (E,), generator=g)
+
+    def csr(key):
+        order = torch.sort(key, stable=True).indices          # edges of one node in edge-id order
+        ptr = torch.zeros(cap + 1, dtype=torch.int64)
+        ptr[1:N + 1] = torch.cumsum(torch.bincount(key, minlength=N), 0)
+        ptr[N + 1:] = ptr[N]
+        return ptr.to(torch.int32).to(dev), order.to(torch.int32).to(dev)
+    in_ptr, in_idx = csr(edst)
+    out_ptr, out_idx = csr(esrc)
+    graph = (in_ptr, in_idx, out_ptr, out_idx, esrc.to(torch.int32).to(dev), edst.to(torch.int32).to(dev))
+    dyn = torch.tensor([N], dtype=torch.int32, device=dev)
+    dynE = torch.tensor([E], dtype=torch.int32, device=dev)
+    GI = torch.randn(cap, 3 * D, generator=g).to(dev)
+    Whh = (torch.randn(3 * D, D, generator=g) / D ** 0.5).to(dev)
+    bhh = (torch.randn(3 * D, generator=g) * 0.1).to(dev)
+    gy = torch.randn(cap, D, generator=g).to(dev)
+
+    a = [t.clone().requires_grad_() for t in (GI, Whh, bhh)]
+    out = ops.gru_seq(a[0], a[1], a[2], graph, dyn, dynE)
+    out.backward(gy)
+
+    b = [t.double().clone().requires_grad_() for t in (GI, Whh, bhh)]
+    rows = []
+    ins = [[] for _ in range(N)]
+    for e in range(E):
+        ins[int(edst[e])].append(e)
+    for v in range(N):
+        h = torch.zeros(D, dtype=torch.float64, device=dev)
+        for e in ins[v]:
+            gi, gh = b[0][int(esrc[e])], b[1] @ h + b[2]
+            r = torch.sigmoid(gi[:D] + gh[:D])
+            z = torch.sigmoid(gi[D:2 * D] + gh[D:2 * D])
+            n = torch.tanh(gi[2 * D:] + r * gh[2 * D:])
+            h = (1 - z) * n + z * h
+        rows.append(h)
+    ref = torch.stack(rows)
+    ref.backward(gy[:N].double())
+    close(out[:N], ref.float(), what='neigh', atol=2e-5)
+    assert float(out[N:].abs().max()) == 0.0
+    close(a[0].grad[:N], b[0].grad[:N].float(), what='dGI', atol=2e-5)
+    close(a[1].grad, b[1].grad.float(), what='dWhh', atol=2e-4, rtol=1e-4)
+    close(a[2].grad, b[2].grad.float(), what='dbhh', atol=2e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize('M,N,K', [(1, 4, 32), (200, 96, 64), (3000, 2048, 256), (513, 256, 2048)])
 def test_gemm_bf16_matches_bf16_rounded_reference(dev, M, N, K):
     """bf16-operand MFMA with fp32 accumulation == fp32 matmul of bf16-rounded operands (tolerance: fp32
