@@ -100,6 +100,15 @@ __device__ unsigned long long g_flash_blk[1024][2];    // wall-clock (s_memrealt
 #define TIM(i)
 #endif   // _G: per-session coefficients ga / gc (order fusion)
 
+// development probe (tools/flash_knockout.py): builds of the backward with one cost removed - bit 0: no exp (P = its
+// argument), 1: no accumulate product, 2: no S product, 3: no result stores, 4: fragments from registers instead of LDS.
+// Results are garbage; only the launch time is read.
+#ifndef SREC_FLASH_KO
+#define SREC_FLASH_KO 0
+#endif
+constexpr int KO = SREC_FLASH_KO;
+#define KO_EXP2(x) ((KO & 1) ? (x) : __builtin_amdgcn_exp2f(x))
+
 template <int NT, int KIND_>
 __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     constexpr int PFD = (NT == 8 && KIND_ != KIND_FWD) ? 2 : 4;   // fragment prefetch depth (D = 256 backward sits at 256 VGPRs)
@@ -288,12 +297,13 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
             bf16x8 af[PF];
 #pragma unroll
             for (int j = 0; j < PF; ++j)
-                af[j] = *reinterpret_cast<const bf16x8*>(((j & 1) ? ybo : ybe) + j * 512);
+                af[j] = (KO & 16) ? xf[j] : *reinterpret_cast<const bf16x8*>(((j & 1) ? ybo : ybe) + j * 512);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks % PF], xf[ks], s, 0, 0, 0);
+                if (!(KO & 4)) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks % PF], xf[ks], s, 0, 0, 0);
                 if (ks + PF < KS)
-                    af[ks % PF] = *reinterpret_cast<const bf16x8*>((((ks + PF) & 1) ? ybo : ybe) + (ks + PF) * 512);
+                    af[ks % PF] = (KO & 16) ? xf[(ks + PF) % KS]
+                                            : *reinterpret_cast<const bf16x8*>((((ks + PF) & 1) ? ybo : ybe) + (ks + PF) * 512);
             }
 #pragma unroll
             for (int ks = 0; ks < KS - PF; ++ks) {
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * q + e;
-                        p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(csL2, s[r], -lv[e])) * (av[e] * csL);
+                        p[r] = KO_EXP2(__builtin_fmaf(csL2, s[r], -lv[e])) * (av[e] * csL);
                     }
                 }
                 if (sideHit[sbase >> 5]) {                        // some label of this chunk lies in this item tile
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * q + e;
-                        p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cv[e], s[r], -lseL)) * (gaS * cv[e]);
+                        p[r] = KO_EXP2(__builtin_fmaf(cv[e], s[r], -lseL)) * (gaS * cv[e]);
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(labrel >= 0 && labrel < 28 + 4) != 0) {
@@ -405,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 const unsigned short* tb1 = cur + b4 * 512 + (4 * (halfv ^ b4) + trow) * 16 + 4 * ((ti & 3) ^ 2);   // reads e = 1: rows 8..15 / 24..31
                 auto frag = [&](int j) {
                     const int cb = j % NT, t = j / NT;
+                    if (KO & 16) return xf[j % KS];
                     uint2 rr[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
@@ -419,7 +430,8 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                 for (int j = 0; j < PFB; ++j) bf[j] = frag(j);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    acc[j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[j / NT], bf[j % PFB], acc[j % NT], 0, 0, 0);
+                    if (!(KO & 2)) acc[j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[j / NT], bf[j % PFB], acc[j % NT], 0, 0, 0);
+                    else acc[j % NT][0] += p[j % 16] + __builtin_bit_cast(float4, bf[j % PFB]).x;
                     if (j + PFB < NB) bf[j % PFB] = frag(j + PFB);
                 }
 #pragma unroll
@@ -451,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         }
         return;
     }
+    if ((KO & 8) && acc[0][0] != 12345.678f) return;          // (keeps the accumulators alive)
     const int d = a.d;
     float* const outp = role_de ? a.dE : a.part_dsr + (size_t)range * a.B * d;
     const int ld_out = role_de ? a.ld_de : d, nrows = role_de ? a.V : a.B;
