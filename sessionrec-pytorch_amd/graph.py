@@ -22,6 +22,7 @@ from .batch import FlatBatch
 #   'side'   1.001 ms  hipMemcpyAsync on a side stream into a staging ring + device-to-device copy (also the route of
 #                      pageable host batches, which a kernel cannot read)
 _STAGE_MODE = 'kernel'
+_STAGE_SLOTS = 16      # device staging buffers per input for host-fed batches (a slot is rewritten 16 replays later)
 _MAILBOX = 64          # entries of the batch mailbox of a captured step (replays the host may run ahead of the GPU)
 
 
@@ -157,15 +158,38 @@ class GraphedTrainStep:
 
     def _post(self, i, x, T):
         """entry T % _MAILBOX of input i <- (address, words, T); the batch buffer must stay untouched until the replay has
-        read it: device tensors are kept alive here, pinned host slots carry the event their owner waits for"""
+        read it: device tensors are kept alive here.  A HOST batch goes through a ring of _STAGE_SLOTS device buffers first:
+        the H2D copy runs on a side stream - i.e. under the replays the GPU is still working on, the host being ahead of it -
+        and the host waits for it (tens of us) before it queues this replay, so the captured step finds its batch in HBM
+        and nothing in front of the graph launch waits across streams.  (The intake kernel reading the page-locked slot over
+        PCIe itself put ~35 us of transfer at the head of every step: end to end 0.887 against 0.855 ms of replay.)"""
         buf = x.buf
-        if not (buf.is_cuda or buf.is_pinned()) or buf.numel() % 4 or buf.data_ptr() % 16:
-            # pageable (or oddly sized) host batch: through a device staging ring, the mailbox then points at the ring slot
-            ring = self.__dict__.setdefault('_mbring', {})
-            if i not in ring:
-                ring[i] = [torch.empty_like(self.static_inputs[i].buf) for _ in range(4)]
-            slot = ring[i][T % 4]
-            slot[:buf.numel()].copy_(buf, non_blocking=False)
+        if not buf.is_cuda or buf.numel() % 4 or buf.data_ptr() % 16:
+            stg = self.__dict__.setdefault('_stg', dict(ring={}, marks=[], stream=None, used=False))
+            if i not in stg['ring']:
+                stg['ring'][i] = [torch.empty_like(self.static_inputs[i].buf) for _ in range(_STAGE_SLOTS)]
+            if stg['stream'] is None:
+                stg['stream'] = torch.cuda.Stream(device=self.static_inputs[i].buf.device)
+            # slot T % _STAGE_SLOTS was read by replay T - _STAGE_SLOTS: a mark (an event every 4th replay) at or behind it
+            marks = stg['marks']
+            if marks and marks[-1][0] >= T:                  # the step counter went back (a restored checkpoint)
+                marks.clear()
+                torch.cuda.current_stream().synchronize()
+            while marks and marks[0][0] < T - _STAGE_SLOTS:
+                marks.pop(0)
+            if marks:
+                marks[0][1].synchronize()                    # T - 16 <= its replay < T: normally long complete
+            elif T >= _STAGE_SLOTS:
+                torch.cuda.current_stream().synchronize()    # (staging starts in the middle of a run: no mark yet)
+            slot = stg['ring'][i][T % _STAGE_SLOTS]
+            n = min(buf.numel(), slot.numel())
+            with torch.cuda.stream(stg['stream']):
+                slot[:n].copy_(buf[:n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stg['stream'])
+            ev.synchronize()
+            x.meta['_copied'] = ev                           # the host buffer may be rewritten (it already has been read)
+            stg['used'] = True
             buf = slot
         a = buf.data_ptr()
         lo, hi = a & 0xffffffff, (a >> 32) & 0xffffffff
@@ -299,22 +323,24 @@ class GraphedTrainStep:
         self.graph.replay()
         if mb is not None:
             # The replay has been queued.  Its batch buffers may be rewritten once it has run, and the host must not lap the
-            # mailbox (entry T is rewritten _MAILBOX replays later): an event marks the spot - after every replay fed from host
-            # memory (the loader waits for it before it reuses the slot), every 8th replay otherwise (an event record is a
-            # command of its own between two graph launches)
+            # mailbox (entry T is rewritten _MAILBOX replays later) nor a staging slot of host-fed batches: an event marks the
+            # spot every 8th replay (every 4th while batches come from the host; an event record is a command of its own
+            # between two graph launches)
             mb['calls'] += 1
             mb['held'].append(keep)
-            host_fed = any(not b.is_cuda for b in keep)
-            if host_fed or mb['calls'] % 8 == 0:
+            stg = self.__dict__.get('_stg')
+            staged = stg is not None and stg['used']
+            if staged:
+                stg['used'] = False
+            if mb['calls'] % 8 == 0 or (staged and T % 4 == 0):
                 done = torch.cuda.Event()
                 done.record()
-                if host_fed:
-                    for x in inputs:
-                        x.meta['_copied'] = done
+                if staged:
+                    stg['marks'].append((T, done))
                 ev = mb['events']
                 ev.append((done, mb['held']))
                 mb['held'] = []
-                limit = (_MAILBOX - 4) if host_fed else (_MAILBOX - 4) // 8
+                limit = (_MAILBOX - 4) // 8
                 while ev and (len(ev) > limit or ev[0][0].query()):
                     if not ev[0][0].query():
                         ev[0][0].synchronize()
