@@ -112,7 +112,10 @@ typedef struct {
 
 /* problem table of srec_gemm_f32_group_run (srec.h, csrc/gemm.hip): up to 16 independent exact-fp32 products, each with
  * the operand conventions of srec_gemm_f32 (C = alpha A B^T + beta C + bias; per operand one unit stride; dyn_mode 1 clamps
- * M, 2 clamps K).  nsplit and ws are chosen / filled by the launcher. */
+ * M, 2 clamps K).  nsplit and ws are chosen / filled by the launcher.  split3 != 0: the products run on the bf16 matrix
+ * pipe as three terms of a hi / lo split of both operands (hi hi + lo hi + hi lo, split in registers on the way from LDS to
+ * the MFMA): results to ~2^-17 relative of the fp32 product at 1/5 of the matrix-pipe time - the bf16 mode's read-out head
+ * backward; 0: v_mfma_f32_32x32x2_f32, exact. */
 #define SREC_GEMM32_MAXP 16
 typedef struct {
     int np;
@@ -125,6 +128,7 @@ typedef struct {
     float alpha[SREC_GEMM32_MAXP], beta[SREC_GEMM32_MAXP];
     int nsplit[SREC_GEMM32_MAXP];
     float* ws;
+    int split3;
 } srec_gemm_f32_group;
 
 /* one time step of the k-gram GRU (msgifsr.py:25,32-45) for up to 4 orders at once: srec_gru_step_fwd / _bwd (srec.h,

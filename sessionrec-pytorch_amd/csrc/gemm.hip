@@ -25,12 +25,27 @@
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 8 fp32 -> bf16 hi (round to nearest even) and bf16 lo = bf16(x - hi): x = hi + lo to ~2^-17 relative
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = srec_pack_bf16(v[2 * i], v[2 * i + 1]);
+        const float a = __builtin_bit_cast(float, h[i] << 16), b = __builtin_bit_cast(float, h[i] & 0xffff0000u);
+        l[i] = srec_pack_bf16(v[2 * i] - a, v[2 * i + 1] - b);
+    }
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
 template <int BM> struct TileK { static constexpr int value = BM >= 128 ? 16 : 32; };   // k-depth of one LDS tile: the
 // global loads of tile t + 1 are issued before the MFMAs of tile t, so a tile has to hold about one load latency of
 // matrix work (64 x 64 x 16 = 512 cycles per wave did not: the small-grid products ran at ~0.75 us per k-tile)
 
 // One BM x BN output tile (bx, by) of split bz / nsplit.  As / Bs: the workgroup's double-buffered LDS tiles.
-template <int BM, int BN, bool A_KC, bool B_KC, int BK = TileK<BM>::value>
+template <int BM, int BN, bool A_KC, bool B_KC, bool S3 = false, int BK = TileK<BM>::value>
 __device__ __forceinline__ void gemm_f32_tile(
     const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
     float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
@@ -168,6 +183,56 @@ __device__ __forceinline__ void gemm_f32_tile(
         // k-steps in groups of 8: MFMA e of group j takes k = 8 j + 4 half + e from BOTH operands (any pairing of the
         // tile's k values with (lane half, step) is a valid order of the sum) - a k-contiguous operand then needs ONE
         // ds_read_b128 per lane per 4 MFMAs.
+        if constexpr (S3) {
+            // two groups of 8 k-values = one 16-deep bf16 MFMA step: a lane's 4 + 4 values of an operand are its 8 k slots
+            // (the same k <-> (lane half, slot) map on both operands), split into hi / lo in registers
+#pragma unroll
+            for (int j16 = 0; j16 < BK / 16; ++j16) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = wm * (BM / 2) + i * 32 + l31;
+                    float v[8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int j8 = 2 * j16 + g;
+                        if (A_KC) {
+                            const float4 q = *reinterpret_cast<const float4*>(fa(buf) + m * BK + (((2 * j8 + half) ^ swz(m)) << 2));
+                            v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[4 * g + e] = As[buf][8 * j8 + 4 * half + e][m];
+                        }
+                    }
+                    split8(v, ah[i], al[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = wn * (BN / 2) + j * 32 + l31;
+                    float v[8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int j8 = 2 * j16 + g;
+                        if (B_KC) {
+                            const float4 q = *reinterpret_cast<const float4*>(fb(buf) + n * BK + (((2 * j8 + half) ^ swz(n)) << 2));
+                            v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[4 * g + e] = Bs[buf][8 * j8 + 4 * half + e][n];
+                        }
+                    }
+                    split8(v, bh[j], bl[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int j8 = 0; j8 < BK / 8; ++j8) {
             float a[TM][4], b[TN][4];
@@ -200,6 +265,7 @@ __device__ __forceinline__ void gemm_f32_tile(
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
@@ -252,6 +318,7 @@ struct GroupK {
     long ws_off[SREC_GEMM32_MAXP];       // slab offsets (floats) of the split problems
 };
 
+template <bool S3>
 __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GroupK k) {
     constexpr int BK = TileK<64>::value;
     __shared__ __attribute__((aligned(16))) float As[2][BK][64 + 4];
@@ -265,7 +332,7 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GroupK k) {
     const int nsplit = g.nsplit[p] > 1 ? g.nsplit[p] : 1;
     float* part = k.g.ws + k.ws_off[p];
 #define SREC_TILE(AK, BK_)                                                                                             \
-    gemm_f32_tile<64, 64, AK, BK_>(g.A[p], g.a_rs[p], g.a_cs[p], g.B[p], g.b_rs[p], g.b_cs[p], g.C[p], g.ldc[p],         \
+    gemm_f32_tile<64, 64, AK, BK_, S3>(g.A[p], g.a_rs[p], g.a_cs[p], g.B[p], g.b_rs[p], g.b_cs[p], g.C[p], g.ldc[p],         \
                                    g.bias[p], g.M[p], g.N[p], g.K[p], g.dyn[p], g.dyn_mode[p], g.alpha[p], g.beta[p], \
                                    part, bx, by, bz, nsplit, As, Bs)
     const bool akc = g.a_cs[p] == 1, bkc = g.b_cs[p] == 1;     // uniform per workgroup
@@ -485,7 +552,8 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
         k.tile_end[p] = end;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(end), dim3(256), 0, st, k);
+    if (gin->split3) hipLaunchKernelGGL(gemm_f32_group_kernel<true>, dim3(end), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(gemm_f32_group_kernel<false>, dim3(end), dim3(256), 0, st, k);
     if (any_split)
         hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(max_red, k.g.np), dim3(256), 0, st, k);
     SREC_LAUNCH_CHECK();

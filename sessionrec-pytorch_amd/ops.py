@@ -926,16 +926,18 @@ class GemmF32Group(_ct.Structure):
                 ('C', _ct.c_void_p * 16), ('ldc', _ct.c_int * 16), ('bias', _ct.c_void_p * 16),
                 ('M', _ct.c_int * 16), ('N', _ct.c_int * 16), ('K', _ct.c_int * 16),
                 ('dyn', _ct.c_void_p * 16), ('dyn_mode', _ct.c_int * 16),
-                ('alpha', _ct.c_float * 16), ('beta', _ct.c_float * 16), ('nsplit', _ct.c_int * 16), ('ws', _ct.c_void_p)]
+                ('alpha', _ct.c_float * 16), ('beta', _ct.c_float * 16), ('nsplit', _ct.c_int * 16), ('ws', _ct.c_void_p),
+                ('split3', _ct.c_int)]
 
 
-def gemm_f32_group(probs):
-    """ONE launch of up to 16 independent exact-fp32 products (csrc/gemm.hip, srec_gemm_f32_group_run).  A problem is
+def gemm_f32_group(probs, split3=False):
+    """ONE launch of up to 16 independent exact-fp32 products (csrc/gemm.hip, srec_gemm_f32_group_run; split3: as 3-term
+    hi / lo bf16 splits on the bf16 matrix pipe, ~2^-17 relative).  A problem is
     (kind, a, b, out, bias, dyn, beta):  'nt' out[M,N] = a[M,K] b[N,K]^T + bias (dyn clamps M);  'nn' out[M,K] = a[M,N] b[N,K]
     (dyn clamps M);  'tn' out[N,K] = a[M,N]^T b[M,K] (dyn clamps the reduction rows M).  (+ beta * out)"""
     assert 0 < len(probs) <= 16
     g = GemmF32Group()
-    g.np = len(probs)
+    g.np, g.split3 = len(probs), int(split3)
     for p, (kind, a, b, out, bias, dyn, beta) in enumerate(probs):
         if kind == 'nt':
             M, K = a.shape
@@ -1234,7 +1236,7 @@ class ReadoutHeadFused(torch.autograd.Function):
             grads.append((gv, gWu, gbu, gWv, sums[4:5], gWsr))
         per_launch = 14 if len(probs) > 16 else 16          # whole orders per launch (7 problems each)
         for c in range(0, len(probs), per_launch):
-            gemm_f32_group(probs[c:c + per_launch])
+            gemm_f32_group(probs[c:c + per_launch], split3=True)      # (the forward's products are 3-term splits too)
         g_allf = outs[0][3]
         for o in outs[1:]:
             g_allf = g_allf + o[3]

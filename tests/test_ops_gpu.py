@@ -1179,6 +1179,33 @@ def test_gemm_f32_group_mixed_layouts(dev):
     close(small, sa @ sb.t(), what='small')
 
 
+def test_gemm_f32_group_three_term_split(dev):
+    """split3: the grouped products on the bf16 matrix pipe as hi hi + lo hi + hi lo of operands split in registers - against
+    the fp64 product: every layout, dynamic row counts, beta, a k-split weight gradient; norm-wise within 2e-5 (2^-17 per
+    operand pair, the lo lo term dropped) where the plain bf16 product is at 3e-3"""
+    ops = _ops()
+    g = torch.Generator(device='cpu').manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    NT, B, d = 5000, 512, 256
+    allf, Wu, bu, v, Wv, dU, dVq = r(NT, d), r(d, d), r(d), r(B, d), r(d, d), r(NT, d), r(B, d)
+    allf[:, 3] *= 1e3                                            # a column 1000 x the others: the split is per element
+    liveT = torch.tensor([4321], device=dev, dtype=torch.int32)
+    liveB = torch.tensor([500], device=dev, dtype=torch.int32)
+    U, dX0, gWu, gWv = torch.empty(NT, d, device=dev), r(NT, d), torch.empty(d, d, device=dev), torch.empty(d, d, device=dev)
+    dX = dX0.clone()
+    ops.gemm_f32_group([('nt', allf, Wu, U, bu, liveT, 0.0), ('nn', dU, Wu, dX, None, liveT, 1.0),
+                        ('tn', dU, allf, gWu, None, liveT, 0.0), ('tn', dVq, v, gWv, None, liveB, 0.0)], split3=True)
+    D = lambda t: t.double()
+
+    def rel(a, b):
+        return float((D(a) - b).norm() / b.norm())
+    assert rel(U[:4321], D(allf[:4321]) @ D(Wu).t() + D(bu)) < 2e-5
+    assert float(U[4321:].abs().max()) == 0.0
+    assert rel(dX[:4321], D(dX0[:4321]) + D(dU[:4321]) @ D(Wu)) < 2e-5
+    assert rel(gWu, D(dU[:4321]).t() @ D(allf[:4321])) < 2e-5
+    assert rel(gWv, D(dVq[:500]).t() @ D(v[:500])) < 2e-5
+
+
 @pytest.mark.parametrize('n_orders', [1, 2])
 def test_readout_head_matches_unfused_ops(dev, n_orders):
     """ops.readout_head (grouped launches) against the same head assembled from ops.linear / seg_attn / cat_cols"""
