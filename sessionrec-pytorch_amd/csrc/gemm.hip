@@ -356,7 +356,8 @@ __global__ void splitk_reduce_group_kernel(GroupK k) {
     const int row = (int)(i / N), col = (int)(i % N);
     const int Ml = g.dyn_mode[p] == 1 ? dyn_count(g.dyn[p], M) : M;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < nsplit; ++z) {
+#pragma unroll 8
+    for (int z = 0; z < nsplit; ++z) {                       // (8 slab loads in flight: the launch is a latency chain)
         const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * M * N + i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -385,6 +386,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit,
     const int row = (int)(i / N), col = (int)(i % N);
     const int Ml = dyn_mode == 1 ? dyn_count(dyn, M) : M;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
     for (int z = 0; z < nsplit; ++z) {
         const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * M * N + i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -545,7 +547,7 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
         if (nsplit > 1) {
             ws_used += (long)nsplit * g.M[p] * g.N[p];
             any_split = 1;
-            const int red = (int)(((size_t)g.M[p] * g.N[p] / 4 + 255) / 256);
+            const int red = (int)(((size_t)g.M[p] * g.N[p] / 4 + 63) / 64);      // one-wave workgroups: 4 x the CUs at work
             if (red > max_red) max_red = red;
         }
         end += k.tiles_mn[p] * nsplit;
@@ -555,7 +557,7 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
     if (gin->split3) hipLaunchKernelGGL(gemm_f32_group_kernel<true>, dim3(end), dim3(256), 0, st, k);
     else hipLaunchKernelGGL(gemm_f32_group_kernel<false>, dim3(end), dim3(256), 0, st, k);
     if (any_split)
-        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(max_red, k.g.np), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(max_red, k.g.np), dim3(64), 0, st, k);
     SREC_LAUNCH_CHECK();
     return 0;
 }
