@@ -19,6 +19,7 @@
 // can be replayed for batches of different size) may clamp M or K.
 // Skinny products (weight gradients: K = #nodes) are split along K into scratch slabs + a
 // deterministic reduce so that >= 2 workgroups per CU are in flight.
+#include <type_traits>
 #include <utility>
 #include "common.h"
 #include "../../include/srec_hg.h"
@@ -98,28 +99,32 @@ __device__ __forceinline__ void gemm_f32_tile(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[LA], rb[LB];
-    int va[LA], vb[LB];          // number of valid leading elements (0..4) of each prefetched float4
+    // TWO register stages of prefetched k-tiles: tile kt + 1 waits in one while tile kt + 2 is in flight into the other, so a
+    // tile's loads have two iterations to land (with one stage the 3-term-split products - ~100 matrix-pipe cycles per
+    // k-tile - ran at one global-load latency per k-tile)
+    float4 ra[2][LA], rb[2][LB];
+    int va[2][LA], vb[2][LB];    // number of valid leading elements (0..4) of each prefetched float4
     // Loads are UNCONDITIONAL from clamped (always valid) addresses; the masking happens when the registers
     // are written to LDS, AFTER the MFMAs of the current tile.  (Predicated loads make hipcc wait vmcnt(0)
     // inside every exec-mask branch: 4 dependent L2/HBM round trips per k-tile instead of one in flight
     // under the matrix cores.)
     const int Mc = M > 0 ? M - 1 : 0, Nc = N - 1;
     auto nvalid = [](int first, int limit, bool ok) { return ok ? max(0, min(4, limit - first)) : 0; };
-    auto gload = [&](int k0) {
+    auto gload = [&](int k0, auto stage) {
+        constexpr int S = decltype(stage)::value;
 #pragma unroll
         for (int p = 0; p < LA; ++p) {
             int idx = tid + p * 256;
             if (A_KC) {
                 const int m = m0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
                 const int kc = min(k, Kfull - 4);
-                ra[p] = *reinterpret_cast<const float4*>(A + (size_t)min(m, Mc) * a_rs + kc);
-                va[p] = nvalid(k, K, m < M && kc == k);
+                ra[S][p] = *reinterpret_cast<const float4*>(A + (size_t)min(m, Mc) * a_rs + kc);
+                va[S][p] = nvalid(k, K, m < M && kc == k);
             } else {
                 const int k = k0 + idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
                 const int mc = min(m, Mfull - 4);
-                ra[p] = *reinterpret_cast<const float4*>(A + (size_t)min(k, Kfull - 1) * a_cs + mc);
-                va[p] = nvalid(m, M, k < K && mc == m);
+                ra[S][p] = *reinterpret_cast<const float4*>(A + (size_t)min(k, Kfull - 1) * a_cs + mc);
+                va[S][p] = nvalid(m, M, k < K && mc == m);
             }
         }
 #pragma unroll
@@ -128,13 +133,13 @@ __device__ __forceinline__ void gemm_f32_tile(
             if (B_KC) {
                 const int n = n0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
                 const int kc = min(k, Kfull - 4);
-                rb[p] = *reinterpret_cast<const float4*>(B + (size_t)min(n, Nc) * b_rs + kc);
-                vb[p] = nvalid(k, K, n < N && kc == k);
+                rb[S][p] = *reinterpret_cast<const float4*>(B + (size_t)min(n, Nc) * b_rs + kc);
+                vb[S][p] = nvalid(k, K, n < N && kc == k);
             } else {
                 const int k = k0 + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
                 const int nc = min(n, N - 4);
-                rb[p] = *reinterpret_cast<const float4*>(B + (size_t)min(k, Kfull - 1) * b_cs + nc);
-                vb[p] = nvalid(n, N, k < K && nc == n);
+                rb[S][p] = *reinterpret_cast<const float4*>(B + (size_t)min(k, Kfull - 1) * b_cs + nc);
+                vb[S][p] = nvalid(n, N, k < K && nc == n);
             }
         }
     };
@@ -142,11 +147,12 @@ __device__ __forceinline__ void gemm_f32_tile(
         v.x = nv > 0 ? v.x : 0.f; v.y = nv > 1 ? v.y : 0.f; v.z = nv > 2 ? v.z : 0.f; v.w = nv > 3 ? v.w : 0.f;
         return v;
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto stage) {
+        constexpr int S = decltype(stage)::value;
 #pragma unroll
         for (int p = 0; p < LA; ++p) {
             int idx = tid + p * 256;
-            const float4 v = masked(ra[p], va[p]);
+            const float4 v = masked(ra[S][p], va[S][p]);
             if (A_KC) {
                 const int m = idx / PP, pc = idx % PP;
                 *reinterpret_cast<float4*>(fa(buf) + m * BK + ((pc ^ swz(m)) << 2)) = v;
@@ -158,7 +164,7 @@ __device__ __forceinline__ void gemm_f32_tile(
 #pragma unroll
         for (int p = 0; p < LB; ++p) {
             int idx = tid + p * 256;
-            const float4 v = masked(rb[p], vb[p]);
+            const float4 v = masked(rb[S][p], vb[S][p]);
             if (B_KC) {
                 const int n = idx / PP, pc = idx % PP;
                 *reinterpret_cast<float4*>(fb(buf) + n * BK + ((pc ^ swz(n)) << 2)) = v;
@@ -171,15 +177,18 @@ __device__ __forceinline__ void gemm_f32_tile(
 
     K = kend;                                          // loads are bounded by this split's k-range
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    using St0 = std::integral_constant<int, 0>;
+    using St1 = std::integral_constant<int, 1>;
     if (nk > 0) {
-        gload(kbeg);
-        lstore(0);
+        gload(kbeg, St0{});
+        lstore(0, St0{});
+        if (nk > 1) gload(kbeg + BK, St1{});             // tile 1 -> stage 1, tile 2 -> stage 0 (free again)
+        if (nk > 2) gload(kbeg + 2 * BK, St0{});
     }
     __syncthreads();
     const int half = lane >> 5, l31 = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
+    auto ktile = [&](const int kt, auto nxt) {           // nxt: the register stage that holds tile kt + 1
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
         // k-steps in groups of 8: MFMA e of group j takes k = 8 j + 4 half + e from BOTH operands (any pairing of the
         // tile's k values with (lane half, step) is a valid order of the sum) - a k-contiguous operand then needs ONE
         // ds_read_b128 per lane per 4 MFMAs.
@@ -267,8 +276,13 @@ __device__ __forceinline__ void gemm_f32_tile(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 1 < nk) lstore(buf ^ 1, nxt);
+        if (kt + 3 < nk) gload(kbeg + (kt + 3) * BK, nxt);
         __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        ktile(kt, St1{});
+        if (kt + 1 < nk) ktile(kt + 1, St0{});
     }
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -517,6 +531,11 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
             if (nsplit > 32) nsplit = 32;
             while (nsplit > 1 && ws_plan + (long)nsplit * g.M[p] * g.N[p] > ws_floats) --nsplit;
             if (nsplit < 1) nsplit = 1;
+        } else if (ws != nullptr && tiles < 128 && g.K[p] >= 512 && (g.N[p] & 3) == 0 && (g.ldc[p] & 3) == 0 &&
+                   ((uintptr_t)g.C[p] & 15) == 0 && ws_plan + (long)(g.K[p] / 256) * g.M[p] * g.N[p] <= ws_floats) {
+            // a full chip: still cut a medium k-loop down to the 8 k-tiles of the large products beside it - the launch is one
+            // round of workgroups and lasts as long as its longest k-loop (the head's K = 512 weight gradients: 16 k-tiles)
+            nsplit = g.K[p] / 256;
         }
         g.nsplit[p] = nsplit;
         if (nsplit > 1) ws_plan += (long)nsplit * g.M[p] * g.N[p];     // (trimming below only shrinks it)
