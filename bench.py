@@ -301,9 +301,16 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
     g0, e0 = runner.graph_steps, runner.eager_steps
     w0 = dict(getattr(loader, 'stats', {}))
     n, t0 = 0, time.perf_counter()
-    for batch in it:                                      # TrainRunner.train's loop body (train.py:94-101)
-        inputs, labels = batch
+    pending = []
+    for batch in it:                                      # TrainRunner.train's loop body (train.py:94-104), its loss
+        inputs, labels = batch                            # bookkeeping included: values read back every 256 steps
         loss = runner.train_step(inputs, labels)
+        pending.append(runner._loss_handle(loss))
+        if len(pending) >= 256:
+            ring = runner._gstep.loss_ring.tolist() if any(isinstance(v, int) for v in pending) else None
+            vals = [ring[v % len(ring)] if isinstance(v, int) else float(v) for v in pending]
+            assert all(v == v for v in vals), 'loss is NaN'
+            pending.clear()
         n += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -283,8 +283,12 @@ int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const f
  * in double from cfg = double[5] {lr, beta1, beta2, eps, weight_decay} (torch.optim.Adam's host arithmetic,
  * train.py:70-75).  Makes a captured / pipelined optimizer step independent of host timing. */
 int srec_adam_hyper(int* counter, const void* cfg, float* hyper, void* stream);
-/* ... for n <= 16 (counter, cfg, hyper) slots in one launch; the three arguments are HOST arrays of n device pointers */
-int srec_adam_hyper_multi(int n, const void* counter, const void* cfg, const void* hyper, void* stream);
+/* ... for n <= 16 (counter, cfg, hyper) slots in one launch; the three arguments are HOST arrays of n device pointers.
+ * Loss tap (tap_ring nullable): the slot whose counter is tap_counter stores *tap_src - the step's loss, train.py:99-104
+ * reads it after every step - into tap_ring[(steps taken before this one) % tap_n], so that a replayed step's loss survives
+ * the next replay without a copy command between two graph launches. */
+int srec_adam_hyper_multi(int n, const void* counter, const void* cfg, const void* hyper, const int* tap_counter,
+                          const float* tap_src, float* tap_ring, int tap_n, void* stream);
 /* one launch for many small tensors (48 per launch): desc = HOST srec_adam_multi_desc below; the pointers travel by
  * value in the kernel arguments (nothing staged in device memory; a captured hipGraph bakes them into the node) */
 typedef struct srec_adam_multi_desc {

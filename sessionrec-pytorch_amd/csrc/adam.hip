@@ -229,12 +229,18 @@ __global__ void adam_hyper_kernel(int* __restrict__ counter, const double* __res
 
 namespace {
 constexpr int HYPER_MAX = 16;
-struct HyperArgs { int* counter[HYPER_MAX]; const double* cfg[HYPER_MAX]; float* hyper[HYPER_MAX]; int n; };
+struct HyperArgs {
+    int* counter[HYPER_MAX]; const double* cfg[HYPER_MAX]; float* hyper[HYPER_MAX]; int n;
+    const int* tap_counter; const float* tap_src; float* tap_ring; int tap_n;
+};
 __global__ void adam_hyper_multi_kernel(HyperArgs a) {
     const int i = threadIdx.x;
     if (i >= a.n) return;
     const int t = *a.counter[i] + 1;
     *a.counter[i] = t;
+    // loss tap: the scalar of THIS step (the training loss) into slot (steps taken before it) % tap_n of a device ring - a
+    // replayed step overwrites its loss tensor, and a host that runs ahead would otherwise clone it after every replay
+    if (a.tap_ring != nullptr && a.counter[i] == a.tap_counter) a.tap_ring[(t - 1) % a.tap_n] = *a.tap_src;
     const double* cfg = a.cfg[i];
     float* hyper = a.hyper[i];
     const double lr = cfg[0], b1 = cfg[1], b2 = cfg[2], eps = cfg[3], wd = cfg[4];
@@ -246,12 +252,16 @@ __global__ void adam_hyper_multi_kernel(HyperArgs a) {
 }  // namespace
 
 // the same for n <= 16 (counter, cfg, hyper) slots in ONE launch (param groups x step offsets of an optimizer step);
-// counter / cfg / hyper are HOST arrays of n device pointers
-extern "C" int srec_adam_hyper_multi(int n, const void* counter, const void* cfg, const void* hyper, void* stream) {
+// counter / cfg / hyper are HOST arrays of n device pointers.  Optional loss tap (all four or none): the slot whose counter
+// is tap_counter also stores *tap_src into tap_ring[(its count before this step) % tap_n].
+extern "C" int srec_adam_hyper_multi(int n, const void* counter, const void* cfg, const void* hyper, const int* tap_counter,
+                                     const float* tap_src, float* tap_ring, int tap_n, void* stream) {
     if (n <= 0) return 0;
     if (n > HYPER_MAX || counter == nullptr || cfg == nullptr || hyper == nullptr) return SREC_BAD_ARG;
+    if (tap_ring != nullptr && (tap_counter == nullptr || tap_src == nullptr || tap_n <= 0)) return SREC_BAD_ARG;
     HyperArgs a{};
     a.n = n;
+    a.tap_counter = tap_counter; a.tap_src = tap_src; a.tap_ring = tap_ring; a.tap_n = tap_n;
     for (int i = 0; i < n; ++i) {
         a.counter[i] = ((int* const*)counter)[i];
         a.cfg[i] = ((const double* const*)cfg)[i];

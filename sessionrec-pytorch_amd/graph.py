@@ -22,6 +22,7 @@ from .batch import FlatBatch
 #   'side'   1.001 ms  hipMemcpyAsync on a side stream into a staging ring + device-to-device copy (also the route of
 #                      pageable host batches, which a kernel cannot read)
 _STAGE_MODE = 'kernel'
+LOSS_RING = 512        # slots of the device loss ring of a captured step (GraphedTrainStep.loss_ring, .last_T)
 _STAGE_SLOTS = 16      # device staging buffers per input for host-fed batches (a slot is rewritten 16 replays later)
 _MAILBOX = 64          # entries of the batch mailbox of a captured step (replays the host may run ahead of the GPU)
 
@@ -85,8 +86,12 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         except TypeError:
             self.graph = torch.cuda.CUDAGraph()
+        self.loss_ring, self.last_T = None, None
+        optimizer.loss_tap = None
         self._pending_advance = None
         self._setup_mailbox(optimizer, labels.device)
+        if self._mb is not None:                         # (allocated outside the capture: not part of the replayed step)
+            self.loss_ring = torch.zeros(LOSS_RING, device=labels.device, dtype=torch.float32)
         work = None
         from . import dist as _dist
         c0 = dict(_dist.STATS)
@@ -101,6 +106,11 @@ class GraphedTrainStep:
                         self.after_backward()
                     work = optimizer._work()
                     optimizer._frozen = work
+                    if self._mb is not None:
+                        # every replay leaves its loss in slot (step count % LOSS_RING) of a device ring (written by the
+                        # optimizer's step-scalar kernel): the caller reads losses in bulk, when it wants them, instead of
+                        # cloning the static loss tensor between two graph launches (train.py:99-104 reads it every step)
+                        optimizer.loss_tap = (self.loss.detach(), self.loss_ring)
                     # the step counters that matter live on the device and are advanced by the captured step itself; the
                     # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
                     # capture and take it back afterwards
@@ -321,6 +331,7 @@ class GraphedTrainStep:
             self.static_labels.copy_(labels, non_blocking=True)
         self.opt.advance(self.work)
         self.graph.replay()
+        self.last_T = T                                  # this replay's loss: loss_ring[T % LOSS_RING] (when there is a ring)
         if mb is not None:
             # The replay has been queued.  Its batch buffers may be rewritten once it has run, and the host must not lap the
             # mailbox (entry T is rewritten _MAILBOX replays later) nor a staging slot of host-fed batches: an event marks the

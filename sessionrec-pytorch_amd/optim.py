@@ -229,7 +229,14 @@ class FusedAdam(torch.optim.Optimizer):
             n = len(chunk)
             arr = _ct.c_void_p * n
             cs, cf, hy = (arr(*[e[k].data_ptr() for e in chunk]) for k in ('counter', 'cfg', 'hyper'))
-            lib.srec_adam_hyper_multi(n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), stream())
+            tap = getattr(self, 'loss_tap', None)           # (loss scalar, ring): graph.GraphedTrainStep's loss ring
+            first = self._hyper.get((0, 0)) if isinstance(self._hyper, dict) else None
+            if tap is not None and first is not None and any(e is first for e in chunk):
+                lib.srec_adam_hyper_multi(n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), ptr(first['counter']),
+                                          ptr(tap[0]), ptr(tap[1]), tap[1].numel(), stream())
+            else:
+                lib.srec_adam_hyper_multi(n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), None, None, None, 0,
+                                          stream())
         # small tensors of ALL groups that step together: groups which differ only in weight decay (fix_weight_decay: the
         # biases / norms are the same Adam with wd 0) share ONE multi-tensor launch - the kernel takes the decay per tensor
         merged = {}                          # (lr, betas, eps, slot) -> [gi of the hyper to use, wd of it, rows]

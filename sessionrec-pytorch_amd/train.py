@@ -132,6 +132,17 @@ class TrainRunner:
         if self.rank == 0:
             print(*a)
 
+    def _loss_handle(self, loss):
+        """what the training loop keeps of a step's loss until it reads the values back in bulk: a replayed step overwrites
+        its static loss tensor - its value waits in the captured step's device ring (graph.LOSS_RING slots, index = the
+        step's count), no copy command between two graph launches; an eager step's loss is a tensor of its own"""
+        g = self._gstep
+        if g is not None and loss is g.loss:
+            if g.loss_ring is not None:
+                return int(g.last_T)
+            return loss.detach().clone()
+        return loss.detach()
+
     def train_step(self, inputs, labels):
         """inputs / labels as the collate function returned them (host, pinned) or already on the device.  A replayed step
         takes a host batch straight into the graph's static buffer (GraphedTrainStep._stage: the PCIe copy overlaps the
@@ -226,7 +237,13 @@ class TrainRunner:
                 # line, the end of the epoch), so the host prepares batch i+1 while the GPU runs step i.
                 nonlocal mean_loss
                 if pending:
-                    for v in th.stack(pending).tolist():
+                    ring = None
+                    if any(isinstance(v, int) for v in pending):                # replayed steps: slots of the device loss ring
+                        ring = self._gstep.loss_ring.tolist()
+                    eager = [v for v in pending if not isinstance(v, int)]
+                    eager = iter(th.stack(eager).tolist()) if eager else iter(())
+                    for v in pending:
+                        v = ring[v % len(ring)] if isinstance(v, int) else next(eager)
                         assert v == v, 'loss is NaN'
                         self.loss_trace.append(v)
                         mean_loss += v / log_interval
@@ -235,7 +252,7 @@ class TrainRunner:
                 inputs, labels = batch                   # (host batches: train_step moves / stages them as its path needs)
                 if not self.fused:
                     inputs, labels = prepare_batch(batch, self.device)
-                pending.append(self.train_step(inputs, labels).detach().clone())   # a replayed step returns its static tensor
+                pending.append(self._loss_handle(self.train_step(inputs, labels)))
                 if (self.batch > 0 and self.batch % log_interval == 0) or len(pending) >= 256:
                     flush()
                 if self.batch > 0 and self.batch % log_interval == 0:

@@ -162,14 +162,16 @@ def test_mailbox_intake_from_device_pinned_and_pageable_batches(dev, kind):
     replays queued WITHOUT synchronisation - more than three laps of the 64-entry mailbox - fed in turn from device
     tensors, page-locked host buffers (a loader slot, read over PCIe inside the graph) and pageable host buffers (staged)
     end on the parameters of the same 200 steps with a device sync after each; eager steps in between (a batch with
-    another layout) keep the mailbox index in step with the device counter; the mismatch flag stays clear."""
+    another layout) keep the mailbox index in step with the device counter; the mismatch flag stays clear.  The losses of
+    the unsynchronised run, read from the captured step's device loss ring after the last replay (TrainRunner._loss_handle:
+    no clone between graph launches), equal the losses read after every step of the synchronised run."""
     c, train, optim, G = pkg('collate'), pkg('train'), pkg('optim'), pkg('graph')
     rng = np.random.default_rng(9)
     V = 400
     caps = c.default_caps(32, 12)
     if kind == 'lessr':
         caps = dict(caps, E=caps['N'] * 7)
-    finals = []
+    finals, losses = [], []
     host_batches = None
     for sync in (True, False):
         torch.manual_seed(0)
@@ -187,13 +189,23 @@ def test_mailbox_intake_from_device_pinned_and_pageable_batches(dev, kind):
                 xs = [type(x)(x.buf.pin_memory(), x.layout, dict(x.meta)) for x in xs]
             if k in (50, 51, 130):
                 runner.train_step(*odd)                            # an eager step between replays
-            runner.train_step(xs, lab)
+            loss = runner.train_step(xs, lab)
             if sync:
                 torch.cuda.synchronize()
+                mine = losses[0] if losses else losses.append([]) or losses[0]
+                mine.append(float(loss.item()))
+            else:
+                mine = losses[1] if len(losses) > 1 else losses.append([]) or losses[1]
+                mine.append(runner._loss_handle(loss))
         torch.cuda.synchronize()
         gs = runner._gstep
+        if not sync:
+            assert all(isinstance(h, int) for h in losses[1]) and gs.loss_ring is not None
+            ring = gs.loss_ring.tolist()
+            losses[1] = [ring[h % len(ring)] for h in losses[1]]
         assert gs is not None and gs._mb is not None and runner.graph_steps == 200 and runner.eager_steps == 3
         assert int(gs._mb['err'].item()) == 0
         finals.append({k_: v.detach().clone() for k_, v in model.state_dict().items()})
     for k_ in finals[0]:
         assert torch.equal(finals[0][k_], finals[1][k_]), k_
+    assert losses[0] == losses[1] and len(losses[0]) == 200
