@@ -91,6 +91,11 @@ int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int Bp, const vo
  * scatter_add_sorted: its backward as a deterministic segmented sum (items[u] distinct, pos grouped by ptr). */
 int srec_gather_rows(const float* src, int ld_src, const int* idx, float* out, int ld_out, int n_cap,
                      const int* dyn, int d, void* stream);
+/* backward of the last-node pick x[last] (srgnn.py:140 niser.py:140 lessr.py:177; `last` non-negative and strictly ascending,
+ * one entry per session): dst [nrows, d] = zeros with dst[idx[j]] = g[j] for the live j < *dyn - every row written, no
+ * separate zero fill */
+int srec_expand_rows_sorted(const float* g, int ld_g, const int* idx, int n_cap, const int* dyn, int nrows, int d,
+                            float* dst, int ld_dst, void* stream);
 int srec_scatter_add_sorted(const float* g, int ld_g, const int* items, const int* ptr, const int* pos, float* dst,
                             int ld_dst, int u_cap, const int* dyn, int d, int accumulate, void* stream);
 /* the lookup with its feature dropout fused (msgifsr.py:247 `dropout(embedding(iid))`): out[r, c] *= mask(r * d + c), mask =

@@ -42,6 +42,28 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, co
     }
 }
 
+// backward of a row pick out = x[idx] with STRICTLY ASCENDING idx (the last node of every session): dst[idx[j]] = g[j], every
+// other row of dst [nrows, d] zero - one wavefront per pick writes its row and the zero rows between the previous pick and
+// itself; the rows behind the last live pick (capacity padding included) are dealt round-robin.  No zero-fill launch.
+__global__ void expand_rows_sorted_kernel(const float* __restrict__ g, int ld_g, const int* __restrict__ idx, int n_cap,
+                                          const int* __restrict__ dyn, int nrows, int d, float* __restrict__ dst, int ld_dst) {
+    const int j = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n_cap) return;
+    const int n = dyn_count(dyn, n_cap);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n) {
+        const int hi = idx[j], lo = j > 0 ? idx[j - 1] + 1 : 0;
+        for (int r = lo; r < hi; ++r)
+            for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<float4*>(dst + (size_t)r * ld_dst + c) = z;
+        if (hi >= 0 && hi < nrows)
+            for (int c = lane * 4; c < d; c += 256)
+                *reinterpret_cast<float4*>(dst + (size_t)hi * ld_dst + c) = *reinterpret_cast<const float4*>(g + (size_t)j * ld_g + c);
+    }
+    const int tail = n > 0 ? idx[n - 1] + 1 : 0;
+    for (int r = tail + j; r < nrows; r += n_cap)
+        for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<float4*>(dst + (size_t)r * ld_dst + c) = z;
+}
+
 // dst[items[u], :] (+)= sum_{p in pos[ptr[u]:ptr[u+1]]} g[p, :]
 __global__ void scatter_add_sorted_kernel(const float* __restrict__ g, int ld_g, const int* __restrict__ items,
                                           const int* __restrict__ ptr, const int* __restrict__ pos,
@@ -477,6 +499,16 @@ extern "C" int srec_gather_rows_drop(const float* src, int ld_src, const int* id
     if (bad_row_args(d, ld_src) || (ld_out & 3) || p < 0.f || p >= 1.f || (long)n_cap * d > 0xffffffffL) return SREC_BAD_ARG;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx,
                        out, ld_out, n_cap, dyn, d, srec_rng{(unsigned)seed, counter, (unsigned)salt, p});
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int srec_expand_rows_sorted(const float* g, int ld_g, const int* idx, int n_cap, const int* dyn, int nrows, int d,
+                                       float* dst, int ld_dst, void* stream) {
+    if (n_cap <= 0 || nrows <= 0) return 0;
+    if (bad_row_args(d, ld_g) || (ld_dst & 3) || idx == nullptr) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(expand_rows_sorted_kernel, dim3(cdiv(n_cap, WPB)), dim3(256), 0, (hipStream_t)stream, g, ld_g, idx, n_cap,
+                       dyn, nrows, d, dst, ld_dst);
     SREC_LAUNCH_CHECK();
     return 0;
 }

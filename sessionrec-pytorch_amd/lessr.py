@@ -81,7 +81,7 @@ class AttnReadout(nn.Module):
             feat = ops.batch_norm(feat, self.batch_norm, dN)
         feat = self.feat_drop(feat)
         U = ops.linear(feat, self.fc_u.weight, None, dN, exact=True)
-        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB, exact=True)
+        Vq = ops.linear(ops.row_gather(feat, mg.last, dB, ascending=True), self.fc_v.weight, self.fc_v.bias, dB, exact=True)
         rst = ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg, dB)
         if self.fc_out is not None:
             rst = ops.linear(rst, self.fc_out.weight, None, dB, exact=True)
@@ -131,7 +131,7 @@ class LESSR(_ScoringMixin, nn.Module):
             out = layer(mg, feat) if i % 2 == 0 else layer(sg, feat)
             feat = torch.cat([out, feat], dim=1)
         sr_g = self.readout(mg, feat)
-        sr_l = ops.row_gather(feat, mg.last, dB)
+        sr_l = ops.row_gather(feat, mg.last, dB, ascending=True)
         sr = torch.cat([sr_l, sr_g], dim=1)
         if self.batch_norm is not None:
             sr = ops.batch_norm(sr, self.batch_norm, dB)

@@ -526,16 +526,18 @@ def embedding_lookup(table, idx, uniq, tgrad=None, dyn_n=None, dyn_u=None, drop=
 
 
 class RowGather(torch.autograd.Function):
-    """out = x[idx] for DISTINCT idx (last-node pick, permutations); backward scatters rows back."""
+    """out = x[idx] for DISTINCT idx (last-node pick, permutations); backward scatters rows back.  ascending: idx is
+    non-negative and strictly ascending (one last node per session, sessions stacked in order) - the backward is then ONE
+    launch that writes every row (srec_expand_rows_sorted) instead of a zero fill + a scatter."""
 
     @staticmethod
-    def forward(ctx, x, idx, dyn):
+    def forward(ctx, x, idx, dyn, ascending=False):
         x = _rows(x)
         n, d = idx.numel(), x.shape[1]
         out = torch.empty(n, d, device=x.device, dtype=torch.float32)
         lib.srec_gather_rows(ptr(x), _ld(x), ptr(idx), ptr(out), d, n, ptr(dyn), d, stream())
         ctx.save_for_backward(idx)
-        ctx.nrows, ctx.dyn = x.shape[0], dyn
+        ctx.nrows, ctx.dyn, ctx.ascending = x.shape[0], dyn, ascending
         return out
 
     @staticmethod
@@ -543,11 +545,15 @@ class RowGather(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         g = _rows(g)
         n, d = g.shape
+        if ctx.ascending and d % 4 == 0:
+            gx = torch.empty(ctx.nrows, d, device=g.device, dtype=torch.float32)
+            lib.srec_expand_rows_sorted(ptr(g), _ld(g), ptr(idx), n, ptr(ctx.dyn), ctx.nrows, d, ptr(gx), d, stream())
+            return gx, None, None, None
         gx = torch.zeros(ctx.nrows, d, device=g.device, dtype=torch.float32)
         ar = _arange(n + 1, g.device)
         lib.srec_scatter_add_sorted(ptr(g), _ld(g), ptr(idx), ptr(ar), ptr(ar), ptr(gx), d, n, ptr(ctx.dyn), d, 0,
                                     stream())
-        return gx, None, None
+        return gx, None, None, None
 
 
 _ARANGE = {}
@@ -562,8 +568,8 @@ def _arange(n, device):
     return t
 
 
-def row_gather(x, idx, dyn=None):
-    return RowGather.apply(x, idx, dyn)
+def row_gather(x, idx, dyn=None, ascending=False):
+    return RowGather.apply(x, idx, dyn, ascending)
 
 
 class PermuteAndPick(torch.autograd.Function):

@@ -169,7 +169,7 @@ class AttnReadout(nn.Module):
         dN, dB = mg.dynp('N'), mg.dynp('B')
         feat = self.feat_drop(feat)
         U = ops.linear(feat, self.fc_u.weight, None, dN, exact=True)
-        Vq = ops.linear(ops.row_gather(feat, mg.last, dB), self.fc_v.weight, self.fc_v.bias, dB, exact=True)
+        Vq = ops.linear(ops.row_gather(feat, mg.last, dB, ascending=True), self.fc_v.weight, self.fc_v.bias, dB, exact=True)
         return ops.seg_attn(U, Vq, self.fc_e.weight, feat, mg.seg, dB)
 
 
@@ -225,7 +225,7 @@ class SRGNN(_ScoringMixin, nn.Module):
         if self.use_gnn_output:
             for layer in self.layers:
                 feat = layer(mg, feat)
-        sr_l = ops.row_gather(feat, mg.last, dB)
+        sr_l = ops.row_gather(feat, mg.last, dB, ascending=True)
         ro = self.readout
         if feat.is_cuda and not (self.training and ro.feat_drop.p > 0):
             # read-out + fc_sr as grouped exact-fp32 launches (ops.ReadoutHead, as in MSGIFSR).  fc_v's bias rides on the U

@@ -185,6 +185,34 @@ def test_gather_scatter_normalize(dev):
     close(torch.autograd.grad(y, x, gy)[0], torch.zeros_like(x).index_add_(0, sel.long(), gy), what='row_gather bwd')
 
 
+@pytest.mark.parametrize('live,d', [(37, 96), (64, 32), (1, 256), (0, 64)])
+def test_row_gather_ascending_backward_writes_every_row(dev, live, d):
+    """the last-node pick (srgnn.py:140, lessr.py:177) with its one-launch backward (srec_expand_rows_sorted): ascending
+    picks, capacity padding (-1 entries behind the live count, rows behind the last session), a device-side live count -
+    every row of the gradient written (the buffer starts as NaN poison), equal to the scatter of the live rows"""
+    ops = _ops()
+    torch.manual_seed(live + d)
+    cap_b, nrows = 64, 700
+    lens = torch.randint(1, 12, (cap_b,))
+    seg = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+    last = torch.stack([seg[b] + torch.randint(0, int(lens[b]), ()) for b in range(cap_b)])
+    last[live:] = -1
+    idx = last.to(torch.int32).to(dev)
+    dyn = torch.tensor([live], dtype=torch.int32, device=dev)
+    x = torch.randn(nrows, d, device=dev, requires_grad=True)
+    y = ops.row_gather(x, idx, dyn, ascending=True)
+    close(y[:live], x[last[:live].to(dev)], what='pick')
+    assert live == cap_b or float(y[live:].abs().max()) == 0.0
+    gy = torch.randn(cap_b, d, device=dev)
+    poison = torch.full((nrows * d + 64,), float('nan'), device=dev)         # the allocator hands this block out again
+    del poison
+    (gx,) = torch.autograd.grad(y, x, gy)
+    ref = torch.zeros(nrows, d, device=dev)
+    if live:
+        ref.index_add_(0, last[:live].to(dev), gy[:live])
+    assert torch.equal(gx, ref)
+
+
 def test_seg_attn(dev):
     ops = _ops()
     torch.manual_seed(2)
