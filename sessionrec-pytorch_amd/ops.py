@@ -977,7 +977,8 @@ def _ones4(n, device):
 
 class ReadoutHead(torch.autograd.Function):
     """Attention read-out + session-vector projection of MSGIFSR (msgifsr.py:127-146 AttnReadout, :272-279 fc_sr) for
-    every live order, exact fp32, as grouped launches:
+    every live order as grouped launches - exact fp32 in fp32 mode, 3-term hi / lo bf16 splits (fp32-grade, ~2^-17) in
+    bf16 mode, like the fused head of d = 128 / 256:
         U_i = allf Wu_i^T + bu_i;  Vq_i = v_i Wv_i^T;  alpha_i = softmax_session(we_i . sigmoid(U_i + Vq_i[b]));
         g_i = sum alpha_i allf;  s_i = [v_i | g_i] Wsr_i^T
     forward: 1 grouped GEMM (all U, Vq) + per order (read-out kernel, concat) + 1 grouped GEMM (all s);
@@ -1003,7 +1004,7 @@ class ReadoutHead(torch.autograd.Function):
         for i, (v, Wu, bu, Wv, we, Wsr) in enumerate(per):
             probs.append(('nt', allf, Wu, Us[i], bu, dT, 0.0))
             probs.append(('nt', v, Wv, Vqs[i], None, dB, 0.0))
-        gemm_f32_group(probs)
+        gemm_f32_group(probs, split3=PRECISION['matmul'] == 'bf16')
         alphas, cats, outs, probs = [], [], [], []
         for i, (v, Wu, bu, Wv, we, Wsr) in enumerate(per):
             alpha = torch.empty(NT, device=dev, dtype=torch.float32)
@@ -1030,7 +1031,7 @@ class ReadoutHead(torch.autograd.Function):
             alphas.append(alpha)
             cats.append(cat)
             outs.append(out)
-        gemm_f32_group(probs)
+        gemm_f32_group(probs, split3=PRECISION['matmul'] == 'bf16')
         ctx.save_for_backward(allf, seg, *[t for i in range(n) for t in (per[i][0], per[i][1], per[i][3], per[i][4], per[i][5],
                                                                         Us[i], Vqs[i], alphas[i], cats[i])])
         ctx.n, ctx.dT, ctx.dB = n, dT, dB
@@ -1060,7 +1061,7 @@ def _readout_head_backward(allf, seg, per, dT, dB, has_bu, gs):
         probs.append(('tn', g, cat, gWsr, None, dB, 0.0))
         gcats.append(gcat)
         gWsrs.append(gWsr)
-    gemm_f32_group(probs)
+    gemm_f32_group(probs, split3=PRECISION['matmul'] == 'bf16')
     g_allf = None
     probs, grads, extra = [], [], []
     for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat) in enumerate(per):
@@ -1091,7 +1092,7 @@ def _readout_head_backward(allf, seg, per, dT, dB, has_bu, gs):
         extra.append(dX)
     per_launch = 12 if len(probs) > 16 else 16          # whole orders per launch (6 problems each)
     for c in range(0, len(probs), per_launch):
-        gemm_f32_group(probs[c:c + per_launch])
+        gemm_f32_group(probs[c:c + per_launch], split3=PRECISION['matmul'] == 'bf16')
     g_allf = extra[0]
     for dX in extra[1:]:
         g_allf = g_allf + dX
