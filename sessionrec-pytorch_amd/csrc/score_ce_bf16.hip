@@ -4,7 +4,7 @@
 // Design (gfx950): with v_mfma_f32_32x32x16_bf16 the matrix pipe is 16x faster than fp32, so the kernel is
 // shaped around LDS traffic and occupancy instead:
 //   * operands are pre-rounded ONCE per step into zero-padded bf16 copies (srec_bf16_prepare), row-major [rows, D] only,
-//     D = d padded to 32/64/128/256: the same LDS image feeds S (ds_read_b128 along k = D) and ACC += P Y, whose B
+//     D = d padded to 32/64/96/128/256: the same LDS image feeds S (ds_read_b128 along k = D) and ACC += P Y, whose B
 //     fragments (8 consecutive STREAMED rows of one column) are gathered by ds_read_b64_tr_b16 transposing reads - no
 //     transposed copy in HBM, half the chunk traffic of the first version of this kernel.
 //   * every wave OWNS 32 rows (items for dE, sessions for d sr / forward) as ready-made MFMA fragments in
@@ -533,13 +533,15 @@ int launch_b(const BArgs& a, int nblocks, hipStream_t st) {
     return 0;
 }
 
-inline int dpad(int d) { return d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 256; }
+// (96: BASELINE config C2, SRGNN / NISER at d = 96 - padded to 128 a quarter of both products multiplied zero columns)
+inline int dpad(int d) { return d <= 32 ? 32 : d <= 64 ? 64 : d <= 96 ? 96 : d <= 128 ? 128 : 256; }
 
 template <int KIND>
 int launch_kind(const BArgs& a, int nblocks, hipStream_t st) {
     switch (dpad(a.d)) {
         case 32: return launch_b<1, KIND>(a, nblocks, st);
         case 64: return launch_b<2, KIND>(a, nblocks, st);
+        case 96: return launch_b<3, KIND>(a, nblocks, st);
         case 128: return launch_b<4, KIND>(a, nblocks, st);
         default: return launch_b<8, KIND>(a, nblocks, st);
     }
@@ -605,7 +607,7 @@ inline bool bad_d(int d) { return d <= 0 || d > 256 || (d & 3); }
 }  // namespace
 
 // rows [R, d] fp32 -> dst16 [Rp, Dp] and dstT16 [Dp, Rp] bf16 (RNE), zero for rows >= live R and columns >= d;
-// Dp = d padded to 32/64/128/256 (srec_ce_plan_bf16), Rp % 128 == 0.  The transposed copy is stored in the
+// Dp = d padded to 32/64/96/128/256 (srec_ce_plan_bf16), Rp % 128 == 0.  The transposed copy is stored in the
 // MFMA k-order (bits 2 and 3 of the row index swapped).
 extern "C" int srec_bf16_prepare(const float* src, int ld, int R, const int* dynR, int d, void* dst16, void* dstT16,
                                  int Rp, void* stream) {
