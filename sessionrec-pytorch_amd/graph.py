@@ -16,12 +16,8 @@ import torch
 from .batch import FlatBatch
 
 
-# how a replayed step takes a pinned host batch (measured, profiles/r03_notes.md: loop time per step at a 0.928 ms replay):
-#   'kernel' 0.971 ms  a kernel on the compute stream loads the batch over PCIe itself (srec_copy_words)        <- default
-#   'main'   0.992 ms  hipMemcpyAsync on the compute stream
-#   'side'   1.001 ms  hipMemcpyAsync on a side stream into a staging ring + device-to-device copy (also the route of
-#                      pageable host batches, which a kernel cannot read)
-_STAGE_MODE = 'kernel'
+# How a replayed step takes a host batch: GraphedTrainStep._post (side-stream copy into a device ring, host-side wait, mailbox).
+# History of the alternatives, loop time per step: profiles/r03_notes.md ("gap legs"), profiles/r04_notes.md.
 LOSS_RING = 512        # slots of the device loss ring of a captured step (GraphedTrainStep.loss_ring, .last_T)
 _STAGE_SLOTS = 16      # device staging buffers per input for host-fed batches (a slot is rewritten 16 replays later)
 _MAILBOX = 64          # entries of the batch mailbox of a captured step (replays the host may run ahead of the GPU)
@@ -260,34 +256,11 @@ class GraphedTrainStep:
         return loss
 
     def _stage(self, i, x):
-        """host batch buffer -> the static device buffer of input i.  Page-locked batches (loader.PinnedRingLoader slots,
-        DataLoader(pin_memory=True)): one kernel on the compute stream reads the words over PCIe and writes the static
-        buffer (ops.copy_words) - no DMA engine, no cross-stream event in front of the replay.  Other host batches: the
-        H2D copy runs on a side stream into a small ring of device staging buffers and the compute stream does a
-        device-to-device copy; a staging slot is rewritten only after the compute stream has consumed it.  Either way
-        the batch carries an event (meta['_copied']) after which its host buffer may be rewritten."""
+        """host batch buffer -> the static device buffer of input i WITHOUT the mailbox (an optimizer that keeps no device
+        step counter): the H2D copy runs on a side stream into a small ring of device staging buffers and the compute stream
+        does a device-to-device copy; a staging slot is rewritten only after the compute stream has consumed it.  The batch
+        carries an event (meta['_copied']) after which its host buffer may be rewritten."""
         st = self.static_inputs[i]
-        mode = _STAGE_MODE if x.buf.is_pinned() else 'side'
-        if mode in ('kernel', 'main'):
-            n = x.buf.numel()
-            if mode == 'kernel':
-                from . import ops
-                ops.copy_words(x.buf, st.buf, n)
-            else:
-                st.buf[:n].copy_(x.buf, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
-            x.meta['_copied'] = done
-            # the host buffer must outlive the copy.  torch's pinned allocator only knows about ITS OWN asynchronous copies: a
-            # DataLoader(pin_memory=True) batch dropped by the caller would be recycled for the next batch while the kernel
-            # has not read it yet (the host runs steps ahead of the GPU) - keep the tensor until its event has completed
-            fly = self.__dict__.setdefault('_inflight', [])
-            fly.append((done, x.buf))
-            while fly and (len(fly) > 64 or fly[0][0].query()):
-                if not fly[0][0].query():
-                    fly[0][0].synchronize()
-                fly.pop(0)
-            return
         ring = self.__dict__.setdefault('_ring', {})
         if i not in ring:
             ring[i] = dict(bufs=[torch.empty_like(st.buf) for _ in range(3)], used=[None] * 3, n=0,
@@ -310,8 +283,7 @@ class GraphedTrainStep:
         r['used'][j] = done
 
     def __call__(self, inputs, labels):
-        """inputs: capacity-padded FlatBatches with the captured layout, on the device or still on the host (pinned: the
-        DataLoader's batches go straight from pinned memory into the graph's static buffer, see _stage)"""
+        """inputs: capacity-padded FlatBatches with the captured layout, on the device or still on the host (see _post)"""
         from . import ops
         mb = self._mb
         T = getattr(self.opt, '_T', 0)                   # the device step counter's value when this replay starts

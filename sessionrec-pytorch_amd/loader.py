@@ -12,7 +12,7 @@ the pin-memory thread maps, unpickles and copies into pinned memory - 1.0 - 1.2 
     (collate.collate_native(into=...)): no pickling of the batch, no copy, no pinning pass;
   * what travels back to the main process is (batch number, slot, element count, layout, meta) - a few hundred bytes;
   * the main process yields FlatBatch views of the pinned slots; the H2D copy of the training step reads them in place
-    (graph.GraphedTrainStep._stage).  A slot is handed to a worker again only after the copy that read it has completed
+    (graph.GraphedTrainStep._post).  A slot is handed to a worker again only after the copy that read it has completed
     (the stager leaves a HIP event on the batch; anything else that consumes a batch must be done with it by the time
     `slots` further batches have been drawn - the default keeps 8 x workers slots).
 

@@ -145,8 +145,8 @@ class TrainRunner:
 
     def train_step(self, inputs, labels):
         """inputs / labels as the collate function returned them (host, pinned) or already on the device.  A replayed step
-        takes a host batch straight into the graph's static buffer (GraphedTrainStep._stage: the PCIe copy overlaps the
-        previous step); an eager step moves it to the device here."""
+        takes a host batch in through a side-stream copy that overlaps the replays still in flight (GraphedTrainStep._post);
+        an eager step moves it to the device here."""
         loss = self._graph_step(inputs, labels)
         if loss is not None:
             self.graph_steps += 1
