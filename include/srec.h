@@ -402,8 +402,11 @@ int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* d
 /* out[p] [ncol] = column sums of part[p] [rows[p], ncol] for np <= 4 problems in one launch (the GRU bias gradients from the
  * per-block partial rows of srec_gru_step_bwd); part / out: HOST arrays of np device pointers, rows: HOST int array */
 int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);
-/* np <= 8 outputs out_i [n_i] = sum_r part_i [R_i, n_i] in one launch (row-split weight gradients); HOST arrays */
-int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, void* stream);
+/* np <= 8 outputs out_i [n_i] = sum_r part_i [R_i, n_i] in one launch (row-split weight gradients); HOST arrays.  tall
+ * (nullable HOST array): tall_i != 0 = few columns summed over hundreds of rows (the GRU bias partials of srec_gru_fused_bwd
+ * / srec_gru_step_bwd, what srec_gru_bias_final does as a launch of its own) */
+int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                         void* stream);
 
 /* ---- evaluation: K best items per session without the (B, V) score matrix (topk.hip) -----------------------------
  * Replaces `logits = model(...); logits.topk(20)` of train.py:36-55 for models whose score is one soft-max

@@ -224,13 +224,40 @@ __global__ __launch_bounds__(1024) void gru_bias_final_kernel(FinArgs a) {
     }
 }
 
-// out_i [n_i] = sum_r part_i [R_i, n_i]
-struct SlabArgs { const float* part[8]; float* out[8]; int R[8]; long n[8]; int start[9]; int np; };
+// out_i [n_i] = sum_r part_i [R_i, n_i].  tall_i: few columns, hundreds of rows (the GRU's bias partials: one row per gate-kernel
+// workgroup) - a workgroup takes 64 columns with 4 row lanes of 8 independent accumulators instead of one thread per 4 columns
+// walking all the rows
+struct SlabArgs { const float* part[8]; float* out[8]; int R[8]; long n[8]; int start[9]; int np; int tall[8]; };
 __global__ void sum_slabs_multi_kernel(SlabArgs a) {
+    __shared__ float red[4][64];
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i)
         if (i < a.np && (int)blockIdx.x >= a.start[i]) p = i;
+    if (a.tall[p]) {                                       // (uniform per workgroup)
+        const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+        const long col = (long)((int)blockIdx.x - a.start[p]) * 64 + cl;
+        const long n = a.n[p];
+        float s = 0.f;
+        if (col < n) {
+            const int R = a.R[p];
+            const float* q = a.part[p] + col;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            int r = rl;
+            for (; r + 7 * 4 < R; r += 8 * 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += q[(size_t)(r + 4 * e) * n];
+            }
+            for (; r < R; r += 4) acc[0] += q[(size_t)r * n];
+            s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
+        red[rl][cl] = s;
+        __syncthreads();
+        if (rl == 0 && col < n) a.out[p][col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        return;
+    }
     const long i = ((long)((int)blockIdx.x - a.start[p]) * blockDim.x + threadIdx.x) * 4;
     if (i >= a.n[p]) return;
     const float* q = a.part[p];
@@ -306,8 +333,10 @@ extern "C" int srec_gru_bias_final(int np, const void* part, const int* rows, in
     return 0;
 }
 
-// np <= 8 outputs out_i [n_i] = sum_r part_i [R_i, n_i] (n_i % 4 == 0) in one launch; HOST arrays
-extern "C" int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, void* stream) {
+// np <= 8 outputs out_i [n_i] = sum_r part_i [R_i, n_i] (n_i % 4 == 0) in one launch; HOST arrays.  tall (nullable): tall_i != 0
+// marks an output of few columns summed over many rows (row lanes instead of column threads)
+extern "C" int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                                    void* stream) {
     if (np <= 0) return 0;
     if (np > 8 || part == nullptr || out == nullptr) return SREC_BAD_ARG;
     SlabArgs a{};
@@ -315,9 +344,10 @@ extern "C" int srec_sum_slabs_multi(int np, const void* part, const int* R, cons
     int blocks = 0;
     for (int p = 0; p < np; ++p) {
         a.part[p] = ((const float* const*)part)[p]; a.out[p] = ((float* const*)out)[p]; a.R[p] = R[p]; a.n[p] = n[p];
+        a.tall[p] = tall != nullptr && tall[p] != 0;
         if (a.part[p] == nullptr || a.out[p] == nullptr || R[p] <= 0 || n[p] <= 0 || (n[p] & 3)) return SREC_BAD_ARG;
         a.start[p] = blocks;
-        blocks += (int)((n[p] / 4 + 255) / 256);
+        blocks += a.tall[p] ? (int)((n[p] + 63) / 64) : (int)((n[p] / 4 + 255) / 256);
     }
     a.start[np] = blocks;
     hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

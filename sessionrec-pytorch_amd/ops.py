@@ -650,21 +650,21 @@ def can_defer(flag, params):
     return True
 
 
-def defer_slab_sum(part, out, ok=True):
+def defer_slab_sum(part, out, ok=True, tall=False):
     """out [n] (any shape, contiguous) = sum over the leading dimension of part [R, n...]: now, or (ok) deferred to the
-    end of the running backward pass"""
+    end of the running backward pass.  tall: few columns, hundreds of rows (bias partials)"""
     if not ok:
-        _launch_slab_sums([(part, out)])
+        _launch_slab_sums([(part, out, tall)])
         return
     if not _DEFERRED:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
         except RuntimeError:                        # not inside a backward pass: nothing to wait for
-            _launch_slab_sums([(part, out)])
+            _launch_slab_sums([(part, out, tall)])
             return
     # (an ALIAS of out: autograd takes a returned gradient as it is only when nothing else refers to the tensor object -
     #  with a second reference AccumulateGrad would clone it, before the sum has been written)
-    _DEFERRED.append((part, out.detach()))
+    _DEFERRED.append((part, out.detach(), tall))
 
 
 def _launch_slab_sums(tasks):
@@ -672,9 +672,11 @@ def _launch_slab_sums(tasks):
         chunk = tasks[i:i + 8]
         m = len(chunk)
         arr = _ct.c_void_p * m
-        a_p, a_o = arr(*[sl.data_ptr() for sl, _ in chunk]), arr(*[o_.data_ptr() for _, o_ in chunk])
-        a_r, a_n = (_ct.c_int * m)(*[sl.shape[0] for sl, _ in chunk]), (_ct.c_long * m)(*[o_.numel() for _, o_ in chunk])
-        lib.srec_sum_slabs_multi(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o), stream())
+        a_p, a_o = arr(*[t[0].data_ptr() for t in chunk]), arr(*[t[1].data_ptr() for t in chunk])
+        a_r, a_n = (_ct.c_int * m)(*[t[0].shape[0] for t in chunk]), (_ct.c_long * m)(*[t[1].numel() for t in chunk])
+        a_t = (_ct.c_int * m)(*[int(len(t) > 2 and bool(t[2])) for t in chunk])
+        lib.srec_sum_slabs_multi(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o),
+                                 _ct.addressof(a_t), stream())
 
 
 def flush_deferred():
@@ -1842,6 +1844,7 @@ class GRUExpandAll(torch.autograd.Function):
         xs = [a.contiguous() for a in args[:P]]
         params = args[P:]
         ctx.defer, ctx.wparams = defer_scope(), [params[4 * p + j] for p in range(P) for j in (0, 2)]
+        ctx.bparams = [params[4 * p + j] for p in range(P) for j in (1, 3)]
         Wih, bih, Whh, bhh = ([params[4 * p + j].contiguous() for p in range(P)] for j in range(4))
         d = xs[0].shape[1]
         d3, dev, st = 3 * d, xs[0].device, stream()
@@ -2008,10 +2011,15 @@ class GRUExpandAll(torch.autograd.Function):
         ok = can_defer(ctx.defer, ctx.wparams)
         for sl, o_ in slabs:
             defer_slab_sum(sl, o_, ok)
-        arr = _ct.c_void_p * P
-        a_p, a_o = arr(*[t_.data_ptr() for t_ in part]), arr(*[t_.data_ptr() for t_ in gb])
-        a_r = (_ct.c_int * P)(*[t_.shape[0] for t_ in part])
-        lib.srec_gru_bias_final(P, _ct.addressof(a_p), _ct.addressof(a_r), 6 * d, _ct.addressof(a_o), st)
+        if ok and can_defer(ctx.defer, ctx.bparams):
+            # ... and so do the bias partials (hundreds of rows of 6 d columns: the "tall" tasks of srec_sum_slabs_multi)
+            for p in range(P):
+                defer_slab_sum(part[p], gb[p], True, tall=True)
+        else:
+            arr = _ct.c_void_p * P
+            a_p, a_o = arr(*[t_.data_ptr() for t_ in part]), arr(*[t_.data_ptr() for t_ in gb])
+            a_r = (_ct.c_int * P)(*[t_.shape[0] for t_ in part])
+            lib.srec_gru_bias_final(P, _ct.addressof(a_p), _ct.addressof(a_r), 6 * d, _ct.addressof(a_o), st)
         grads = []
         for p in range(P):
             grads += [gWih[p], gb[p][:d3], gWhh[p], gb[p][d3:]]
