@@ -18,6 +18,7 @@
 // Bias gradients: per-thread column sums over its rows and all steps, reduced over the row groups through LDS, one row
 // [6 d] (d b_ih | d b_hh) per workgroup into bias_part (summed by srec_gru_bias_final).
 #include "common.h"
+#include "headfrag.h"
 #include "../../include/srec_hg.h"
 #include <type_traits>
 #include <cstdlib>
@@ -371,14 +372,24 @@ struct WfBothArgs {
     const float* W[2 * GB_MAXP];
     unsigned short* dstf[2 * GB_MAXP];
     unsigned short* dstb[2 * GB_MAXP];
+    // blockIdx.z == 2: the read-out head's hi / lo fragment copies (headfrag.h) ride in the same launch
+    int nh;
+    const float* hW[SREC_HEAD_MAXW];
+    unsigned short* hdst[SREC_HEAD_MAXW];
+    int hrows[SREC_HEAD_MAXW], hcols[SREC_HEAD_MAXW], htrans[SREC_HEAD_MAXW];
 };
 
 // both fragment-major copies of a GRU weight in one launch: blockIdx.z = 0 the forward layout (gruf.hip: fragment ((w KS + s)
 // 3 JB + g JB + j), lane l <- W[g d + w d/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]), 1 the backward-data layout above
-__global__ __launch_bounds__(256) void gru_wfrag_both_kernel(WfBothArgs a) {
+__global__ __launch_bounds__(256) void gru_wfrag_both_kernel(WfBothArgs a, int n) {
     const int d = a.d, JB = a.jb;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 3 * d * d / 8) return;
+    if (blockIdx.z == 2) {
+        const int m = blockIdx.y;
+        if (m < a.nh) srec_frag::head_frag_item(a.hW[m], a.hdst[m], a.hrows[m], a.hcols[m], a.htrans[m], idx);
+        return;
+    }
+    if ((int)blockIdx.y >= n || idx >= 3 * d * d / 8) return;
     const int lane = idx & 63, frag = idx >> 6;
     float v[8];
     unsigned short* dst;
@@ -407,11 +418,26 @@ __global__ __launch_bounds__(256) void gru_wfrag_both_kernel(WfBothArgs a) {
 
 }  // namespace
 
-// srec_gru_wfrag and srec_gru_wfrag_t of the same n <= 8 weights in ONE launch (dst_fwd, dst_bwd: HOST arrays of device pointers)
-extern "C" int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream) {
+// srec_gru_wfrag and srec_gru_wfrag_t of the same n <= 8 weights in ONE launch (dst_fwd, dst_bwd: HOST arrays of device pointers).
+// nh > 0: the launch also writes the nh <= SREC_HEAD_MAXW fragment copies srec_head_wfrag would (hW / hdst: HOST arrays of device
+// pointers, hrows / hcols / htrans: HOST int arrays, trans 0 / 1) - one "weights of this step" launch instead of two.
+extern "C" int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, int nh, const void* hW,
+                                   const void* hdst, const int* hrows, const int* hcols, const int* htrans, void* stream) {
     if (n <= 0) return 0;
     if (n > 2 * GB_MAXP || W == nullptr || dst_fwd == nullptr || dst_bwd == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
+    if (nh < 0 || nh > SREC_HEAD_MAXW || (nh > 0 && (hW == nullptr || hdst == nullptr || hrows == nullptr || hcols == nullptr || htrans == nullptr)))
+        return SREC_BAD_ARG;
     WfBothArgs a{};
+    int hitems = 0;
+    a.nh = nh;
+    for (int i = 0; i < nh; ++i) {
+        a.hW[i] = ((const float* const*)hW)[i]; a.hdst[i] = ((unsigned short* const*)hdst)[i];
+        a.hrows[i] = hrows[i]; a.hcols[i] = hcols[i]; a.htrans[i] = htrans[i];
+        const int N = htrans[i] ? hcols[i] : hrows[i], K = htrans[i] ? hrows[i] : hcols[i];
+        if (a.hW[i] == nullptr || a.hdst[i] == nullptr || (htrans[i] != 0 && htrans[i] != 1) || N <= 0 || K <= 0 || (N % 128) || (K % 16))
+            return SREC_BAD_ARG;
+        hitems = max(hitems, N * K / 8);
+    }
     int nw = 4;
     if (int rc = srec_gru_fused_waves(d, &nw)) return rc;
     a.d = d; a.jb = d / (32 * nw);
@@ -420,7 +446,9 @@ extern "C" int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, co
         a.dstf[i] = ((unsigned short* const*)dst_fwd)[i]; a.dstb[i] = ((unsigned short* const*)dst_bwd)[i];
         if (a.W[i] == nullptr || a.dstf[i] == nullptr || a.dstb[i] == nullptr) return SREC_BAD_ARG;
     }
-    hipLaunchKernelGGL(gru_wfrag_both_kernel, dim3((3 * d * d / 8 + 255) / 256, n, 2), dim3(256), 0, (hipStream_t)stream, a);
+    const int items = max(3 * d * d / 8, hitems);
+    hipLaunchKernelGGL(gru_wfrag_both_kernel, dim3((items + 255) / 256, max(n, nh), nh > 0 ? 3 : 2), dim3(256), 0,
+                       (hipStream_t)stream, a, n);
     SREC_LAUNCH_CHECK();
     return 0;
 }

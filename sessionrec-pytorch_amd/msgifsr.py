@@ -336,6 +336,15 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         ncap = mg.meta['ncap']                             # block size of order k (capacity in padded layouts)
         pieces = ops.split_rows(rows, [ncap[k] * k for k in range(1, K + 1)])
         fast = None
+        if (K > 1 and mg.buf.is_cuda and self.norm and d in (128, 256) and ops.PRECISION['matmul'] == 'bf16'
+                and ops.gru_fused_ok(d, K - 1) and ops.FUSED_HEAD):
+            # the fused read-out head (below) will want fragment copies of its weights: they ride in the launch that makes the
+            # expander's copies - both are "weights of this step" passes (ops.gru_wfrag_both)
+            live = range(K) if self.fusion else (0,)
+            ro, grad = self.readout, torch.is_grad_enabled()
+            hw = [w for i in live for w in (ro.fc_u[i].weight, ro.fc_v[i].weight, self.fc_sr[i].weight)]
+            ops.HEAD_WFRAG_REQUEST.append((hw + ([self.fc_sr[i].weight for i in live] if grad else []),
+                                           [0] * len(hw) + ([1] * len(live) if grad else [])))
         if K > 1 and K <= 5 and ops.gru_expand_fast_ok(d, self.reducer):
             # bf16 path: every order's k-gram GRU in one autograd node, one launch per time step for all orders
             fast = ops.gru_expand_all([pieces[k - 1] for k in range(2, K + 1)], [self.expander.GRUs[k - 2] for k in range(2, K + 1)],
@@ -398,6 +407,7 @@ class MSGIFSR(_ScoringMixin, nn.Module):
                                                 [mg.field('lastcat%d' % (i + 1)) for i in live], mg.dynp('NT'), dB)
             feat_vs = dict(zip(live, picked))
         srs = []
+        del ops.HEAD_WFRAG_REQUEST[:]                      # (an expander path that made no fragment launch leaves it unserved)
         if len(live) <= 4:
             # read-out + fc_sr(cat[x_last, sr_g]) of every live order as grouped exact-fp32 launches (ops.ReadoutHead):
             # these B-row products are launch bound one by one

@@ -1782,14 +1782,40 @@ def gru_wfrag_t(ws):
     return outs
 
 
+HEAD_WFRAG_REQUEST = []     # [(weights, trans)] a model leaves here before its GRU expander runs: the read-out head's fragment
+#                             copies of this step then ride in the expander's fragment launch (gru_wfrag_both) - see msgifsr.py
+
+
 def gru_wfrag_both(ws):
-    """gru_wfrag and gru_wfrag_t of the same weights in one launch -> (forward copies, backward copies)"""
+    """gru_wfrag and gru_wfrag_t of the same weights in one launch -> (forward copies, backward copies); a pending
+    HEAD_WFRAG_REQUEST is served by the same launch (its copies land in the head's per-step cache)"""
     n, d = len(ws), ws[0].shape[1]
     of = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
     ob = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
     arr = _ct.c_void_p * n
     a_w, a_f, a_b = arr(*[w.data_ptr() for w in ws]), arr(*[o.data_ptr() for o in of]), arr(*[o.data_ptr() for o in ob])
-    lib.srec_gru_wfrag_both(n, _ct.addressof(a_w), _ct.addressof(a_f), _ct.addressof(a_b), d, stream())
+    hws, htr = [], []
+    while HEAD_WFRAG_REQUEST:
+        rw, rt = HEAD_WFRAG_REQUEST.pop()
+        for w, t in zip(rw, rt):
+            if (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and int(t) in (0, 1) and len(hws) < 16
+                    and (w.data_ptr(), tuple(w.shape), int(t)) not in _HEAD_WF_CACHE
+                    and (w.shape[1] if t else w.shape[0]) % 128 == 0 and (w.shape[0] if t else w.shape[1]) % 16 == 0):
+                hws.append(w)
+                htr.append(int(t))
+    m = len(hws)
+    if m:
+        bufs = [torch.empty(2 * w.numel(), device=w.device, dtype=torch.bfloat16) for w in hws]
+        harr, hint = _ct.c_void_p * m, _ct.c_int * m
+        h_w, h_o = harr(*[w.data_ptr() for w in hws]), harr(*[b.data_ptr() for b in bufs])
+        h_r, h_c, h_t = hint(*[w.shape[0] for w in hws]), hint(*[w.shape[1] for w in hws]), hint(*htr)
+        lib.srec_gru_wfrag_both(n, _ct.addressof(a_w), _ct.addressof(a_f), _ct.addressof(a_b), d, m, _ct.addressof(h_w),
+                                _ct.addressof(h_o), _ct.addressof(h_r), _ct.addressof(h_c), _ct.addressof(h_t), stream())
+        for w, t, b in zip(hws, htr, bufs):
+            _HEAD_WF_CACHE[(w.data_ptr(), tuple(w.shape), t)] = b
+    else:
+        lib.srec_gru_wfrag_both(n, _ct.addressof(a_w), _ct.addressof(a_f), _ct.addressof(a_b), d, 0, None, None, None, None,
+                                None, stream())
     return of, ob
 
 
