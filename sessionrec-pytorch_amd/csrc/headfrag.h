@@ -1,6 +1,7 @@
-// hi / lo fragment-major operand copies of the read-out head's weights (csrc/headf.hip) as a device function: shared by
-// srec_head_wfrag (headf.hip) and by srec_gru_wfrag_both (grufb.hip), which can take the head's copies along in its launch -
-// both are "once per optimizer step" passes over a few small matrices, each a kernel node of the captured step otherwise.
+// The "weights of this step" copies as device functions: the hi / lo fragment-major operand copies of the read-out head
+// (srec_head_wfrag, csrc/headf.hip) and the bf16 + transposed bf16 copies of the GEMM weights (srec_weights_bf16,
+// csrc/gemm16.hip).  Shared with srec_step_weights (csrc/grufb.hip), which runs them and the GRU fragment copies in ONE launch:
+// each is a once-per-optimizer-step pass over a few small matrices and a kernel node of the captured step otherwise.
 #pragma once
 #include "common.h"
 
@@ -38,6 +39,56 @@ __device__ __forceinline__ void head_frag_item(const float* __restrict__ W, unsi
     unsigned short* o = dst + ((((size_t)(w * KS + s) * 2) * JB + j) * 64 + lane) * 8;
     *reinterpret_cast<uint4*>(o) = h;
     *reinterpret_cast<uint4*>(o + (size_t)JB * 512) = l;
+}
+
+// tile b (64 x 64, row-major tile order) of W [R, Cc] fp32 -> W16 [R, Cc] bf16 and (WT16 nullable) WT16 [Cc, R] bf16, through the
+// workgroup's LDS tile: the operand copies of the bf16 GEMMs (srec_weights_bf16, csrc/gemm16.hip).  256 threads.
+__device__ __forceinline__ void weights_bf16_tile(const float* __restrict__ W, unsigned short* __restrict__ W16,
+                                                  unsigned short* __restrict__ WT16, int R, int Cc, int b,
+                                                  unsigned short (*tile)[68]) {
+    const int tc = (Cc + 63) / 64;
+    const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
+    if (((R | Cc) & 3) == 0) {
+        // 4 columns per thread: float4 in, 8-byte bf16 stores in both layouts (2-byte stores ran at a third of this rate)
+        const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+        for (int rr = y; rr < 64; rr += 16) {
+            const int r = r0 + rr, c = c0 + 4 * x;
+            uint2 v = make_uint2(0u, 0u);
+            if (r < R && c < Cc) {
+                const float4 f = *reinterpret_cast<const float4*>(W + (size_t)r * Cc + c);
+                v = make_uint2(srec_pack_bf16(f.x, f.y), srec_pack_bf16(f.z, f.w));
+                *reinterpret_cast<uint2*>(W16 + (size_t)r * Cc + c) = v;
+            }
+            *reinterpret_cast<uint2*>(&tile[rr][4 * x]) = v;
+        }
+        if (WT16 == nullptr) return;
+        __syncthreads();
+        for (int cc = y; cc < 64; cc += 16) {
+            const int c = c0 + cc, r = r0 + 4 * x;
+            if (c < Cc && r < R) {
+                const unsigned lo = tile[4 * x][cc] | ((unsigned)tile[4 * x + 1][cc] << 16);
+                const unsigned hi = tile[4 * x + 2][cc] | ((unsigned)tile[4 * x + 3][cc] << 16);
+                *reinterpret_cast<uint2*>(WT16 + (size_t)c * R + r) = make_uint2(lo, hi);
+            }
+        }
+        return;
+    }
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    for (int rr = y; rr < 64; rr += 4) {
+        const int r = r0 + rr, c = c0 + x;
+        unsigned short v = 0;
+        if (r < R && c < Cc) {
+            v = srec_f2bf(W[(size_t)r * Cc + c]);
+            W16[(size_t)r * Cc + c] = v;
+        }
+        tile[rr][x] = v;
+    }
+    __syncthreads();
+    if (WT16 != nullptr)
+        for (int cc = y; cc < 64; cc += 4) {
+            const int c = c0 + cc, r = r0 + x;
+            if (c < Cc && r < R) WT16[(size_t)c * R + r] = tile[x][cc];
+        }
 }
 
 }  // namespace srec_frag
