@@ -399,9 +399,6 @@ int srec_gru_fused_waves(int d, int* waves);
 int srec_gru_wfrag_t(int n, const void* W, const void* dst, int d, void* stream);
 /* both copies of the same weights in one launch */
 int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream);
-/* ... and the other per-step weight copies with them: desc = HOST srec_step_weights_desc (srec_hg.h) - GRU fragments, the
- * read-out head's hi / lo fragments (srec_head_wfrag) and the GEMM weights' bf16 / transposed copies (srec_weights_bf16) */
-int srec_step_weights(const void* desc, void* stream);
 /* out[p] [ncol] = column sums of part[p] [rows[p], ncol] for np <= 4 problems in one launch (the GRU bias gradients from the
  * per-block partial rows of srec_gru_step_bwd); part / out: HOST arrays of np device pointers, rows: HOST int array */
 int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);

@@ -274,27 +274,4 @@ typedef struct {
     float* dwp[SREC_HEAD_MAXH];
 } srec_head_bwd_desc;
 
-
-/* the "weights of this step" copies in ONE launch (srec_step_weights, csrc/grufb.hip) - each family is a once-per-optimizer-step
- * pass over a few small matrices and a kernel node of the captured step on its own:
- *   GRU:   n <= 8 weights W [3 d, d] -> the two fragment-major bf16 copies of srec_gru_wfrag_both (d = 128 / 256)
- *   head:  nh <= SREC_HEAD_MAXW matrices -> the hi / lo fragment copies of srec_head_wfrag (trans 0 / 1)
- *   gemm:  nw <= 8 matrices [wR, wC] -> bf16 copy w16 and (nullable) transposed bf16 copy wt16 of srec_weights_bf16
- * any family may be empty (count 0). */
-typedef struct {
-    int n, d;
-    const float* W[8];
-    void* dst_fwd[8];
-    void* dst_bwd[8];
-    int nh;
-    const float* hW[SREC_HEAD_MAXW];
-    void* hdst[SREC_HEAD_MAXW];
-    int hrows[SREC_HEAD_MAXW], hcols[SREC_HEAD_MAXW], htrans[SREC_HEAD_MAXW];
-    int nw;
-    const float* wW[8];
-    void* w16[8];
-    void* wt16[8];
-    int wR[8], wC[8];
-} srec_step_weights_desc;
-
 #endif

@@ -23,7 +23,6 @@
 //         row-major LDS tile by eight 16-bit LDS reads (d16 / d16_hi pairs fill the four fragment registers without
 //         a packing pass): consecutive lanes read consecutive 2-byte columns, conflict free.
 #include "common.h"
-#include "headfrag.h"
 #include "../../include/srec_hg.h"
 
 namespace {
@@ -479,7 +478,51 @@ __global__ void weights_bf16_kernel(WArgs a) {
 #pragma unroll
     for (int i = 1; i < 8; ++i)
         if (i < a.n && (int)blockIdx.x >= a.start[i]) t = i;
-    srec_frag::weights_bf16_tile(a.W[t], a.W16[t], a.WT16[t], a.R[t], a.Cc[t], blockIdx.x - a.start[t], tile);
+    const int R = a.R[t], Cc = a.Cc[t];
+    const int tc = (Cc + 63) / 64, b = blockIdx.x - a.start[t];
+    const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
+    const float* __restrict__ W = a.W[t];
+    if (((R | Cc) & 3) == 0) {
+        // 4 columns per thread: float4 in, 8-byte bf16 stores in both layouts (2-byte stores ran at a third of this rate)
+        const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+        for (int rr = y; rr < 64; rr += 16) {
+            const int r = r0 + rr, c = c0 + 4 * x;
+            uint2 v = make_uint2(0u, 0u);
+            if (r < R && c < Cc) {
+                const float4 f = *reinterpret_cast<const float4*>(W + (size_t)r * Cc + c);
+                v = make_uint2(srec_pack_bf16(f.x, f.y), srec_pack_bf16(f.z, f.w));
+                *reinterpret_cast<uint2*>(a.W16[t] + (size_t)r * Cc + c) = v;
+            }
+            *reinterpret_cast<uint2*>(&tile[rr][4 * x]) = v;
+        }
+        if (a.WT16[t] == nullptr) return;
+        __syncthreads();
+        for (int cc = y; cc < 64; cc += 16) {
+            const int c = c0 + cc, r = r0 + 4 * x;
+            if (c < Cc && r < R) {
+                const unsigned lo = tile[4 * x][cc] | ((unsigned)tile[4 * x + 1][cc] << 16);
+                const unsigned hi = tile[4 * x + 2][cc] | ((unsigned)tile[4 * x + 3][cc] << 16);
+                *reinterpret_cast<uint2*>(a.WT16[t] + (size_t)c * R + r) = make_uint2(lo, hi);
+            }
+        }
+        return;
+    }
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    for (int rr = y; rr < 64; rr += 4) {
+        const int r = r0 + rr, c = c0 + x;
+        unsigned short v = 0;
+        if (r < R && c < Cc) {
+            v = srec_f2bf(W[(size_t)r * Cc + c]);
+            a.W16[t][(size_t)r * Cc + c] = v;
+        }
+        tile[rr][x] = v;
+    }
+    __syncthreads();
+    if (a.WT16[t] != nullptr)
+        for (int cc = y; cc < 64; cc += 4) {
+            const int c = c0 + cc, r = r0 + x;
+            if (c < Cc && r < R) a.WT16[t][(size_t)c * R + r] = tile[x][cc];
+        }
 }
 
 // out[c][i] = sum_r part[c][r][i] (fixed order: deterministic), i < n (n % 4 == 0); grid.y = c

@@ -18,7 +18,6 @@
 // Bias gradients: per-thread column sums over its rows and all steps, reduced over the row groups through LDS, one row
 // [6 d] (d b_ih | d b_hh) per workgroup into bias_part (summed by srec_gru_bias_final).
 #include "common.h"
-#include "headfrag.h"
 #include "../../include/srec_hg.h"
 #include <type_traits>
 #include <cstdlib>
@@ -368,29 +367,18 @@ __global__ __launch_bounds__(256) void gru_wfrag_t_kernel(WfbArgs a) {
 }
 
 struct WfBothArgs {
-    srec_step_weights_desc q;
-    int jb;
+    int d, jb;
+    const float* W[2 * GB_MAXP];
+    unsigned short* dstf[2 * GB_MAXP];
+    unsigned short* dstb[2 * GB_MAXP];
 };
 
-// every per-step weight copy in one launch: blockIdx.z = 0 / 1 the GRU layouts (0: forward, gruf.hip: fragment ((w KS + s) 3 JB +
-// g JB + j), lane l <- W[g d + w d/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]; 1: the backward-data layout above), 2 the
-// read-out head's hi / lo fragments, 3 the bf16 / transposed copies of the GEMM weights (headfrag.h); blockIdx.y = matrix
-__global__ __launch_bounds__(256) void step_weights_kernel(WfBothArgs a) {
-    __shared__ unsigned short tile[64][68];
-    const srec_step_weights_desc& q = a.q;
-    const int idx = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
-    if (blockIdx.z == 3) {
-        if (m < q.nw && (int)blockIdx.x < ((q.wR[m] + 63) / 64) * ((q.wC[m] + 63) / 64))
-            srec_frag::weights_bf16_tile(q.wW[m], (unsigned short*)q.w16[m], (unsigned short*)q.wt16[m], q.wR[m], q.wC[m],
-                                         blockIdx.x, tile);
-        return;
-    }
-    if (blockIdx.z == 2) {
-        if (m < q.nh) srec_frag::head_frag_item(q.hW[m], (unsigned short*)q.hdst[m], q.hrows[m], q.hcols[m], q.htrans[m], idx);
-        return;
-    }
-    const int d = q.d, JB = a.jb;
-    if (m >= q.n || idx >= 3 * d * d / 8) return;
+// both fragment-major copies of a GRU weight in one launch: blockIdx.z = 0 the forward layout (gruf.hip: fragment ((w KS + s)
+// 3 JB + g JB + j), lane l <- W[g d + w d/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]), 1 the backward-data layout above
+__global__ __launch_bounds__(256) void gru_wfrag_both_kernel(WfBothArgs a) {
+    const int d = a.d, JB = a.jb;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * d * d / 8) return;
     const int lane = idx & 63, frag = idx >> 6;
     float v[8];
     unsigned short* dst;
@@ -398,18 +386,18 @@ __global__ __launch_bounds__(256) void step_weights_kernel(WfBothArgs a) {
         const int KS = d / 16, NF = 3 * JB;
         const int f = frag % NF, ws = frag / NF, s = ws % KS, w = ws / KS, g = f / JB, j = f % JB;
         const int nrow = g * d + w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
-        const float* src = q.W[m] + (size_t)nrow * d + kk;
+        const float* src = a.W[blockIdx.y] + (size_t)nrow * d + kk;
         const float4 v0 = ld4(src), v1 = ld4(src + 4);
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-        dst = (unsigned short*)q.dst_fwd[m];
+        dst = a.dstf[blockIdx.y];
     } else {
         const int KS3 = 3 * d / 16;
         const int j = frag % JB, ws = frag / JB, s = ws % KS3, w = ws / KS3;
         const int col = w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
-        const float* src = q.W[m] + (size_t)kk * d + col;
+        const float* src = a.W[blockIdx.y] + (size_t)kk * d + col;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * d];
-        dst = (unsigned short*)q.dst_bwd[m];
+        dst = a.dstb[blockIdx.y];
     }
     uint4 o;
     o.x = srec_pack_bf16(v[0], v[1]); o.y = srec_pack_bf16(v[2], v[3]);
@@ -419,51 +407,22 @@ __global__ __launch_bounds__(256) void step_weights_kernel(WfBothArgs a) {
 
 }  // namespace
 
-// desc: HOST srec_step_weights_desc (srec_hg.h)
-extern "C" int srec_step_weights(const void* desc, void* stream) {
-    const srec_step_weights_desc* q = (const srec_step_weights_desc*)desc;
-    if (q == nullptr || q->n < 0 || q->n > 8 || q->nh < 0 || q->nh > SREC_HEAD_MAXW || q->nw < 0 || q->nw > 8) return SREC_BAD_ARG;
-    if (q->n + q->nh + q->nw == 0) return 0;
-    WfBothArgs a{};
-    a.q = *q;
-    int gx = 0, gy = 0, gz = 0;
-    if (q->n > 0) {
-        if (q->d != 128 && q->d != 256) return SREC_BAD_ARG;
-        int nw = 4;
-        if (int rc = srec_gru_fused_waves(q->d, &nw)) return rc;
-        a.jb = q->d / (32 * nw);
-        for (int i = 0; i < q->n; ++i)
-            if (q->W[i] == nullptr || q->dst_fwd[i] == nullptr || q->dst_bwd[i] == nullptr) return SREC_BAD_ARG;
-        gx = (3 * q->d * q->d / 8 + 255) / 256; gy = q->n; gz = 2;
-    }
-    for (int i = 0; i < q->nh; ++i) {
-        const int t = q->htrans[i], N = t ? q->hcols[i] : q->hrows[i], K = t ? q->hrows[i] : q->hcols[i];
-        if (q->hW[i] == nullptr || q->hdst[i] == nullptr || (t != 0 && t != 1) || N <= 0 || K <= 0 || (N % 128) || (K % 16))
-            return SREC_BAD_ARG;
-        gx = max(gx, (N * K / 8 + 255) / 256);
-    }
-    if (q->nh > 0) { gy = max(gy, q->nh); gz = 3; }
-    for (int i = 0; i < q->nw; ++i) {
-        if (q->wW[i] == nullptr || q->w16[i] == nullptr || q->wR[i] <= 0 || q->wC[i] <= 0) return SREC_BAD_ARG;
-        gx = max(gx, cdiv(q->wR[i], 64) * cdiv(q->wC[i], 64));
-    }
-    if (q->nw > 0) { gy = max(gy, q->nw); gz = 4; }
-    hipLaunchKernelGGL(step_weights_kernel, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, a);
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
-
 // srec_gru_wfrag and srec_gru_wfrag_t of the same n <= 8 weights in ONE launch (dst_fwd, dst_bwd: HOST arrays of device pointers)
 extern "C" int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream) {
     if (n <= 0) return 0;
-    if (n > 2 * GB_MAXP || n > 8 || W == nullptr || dst_fwd == nullptr || dst_bwd == nullptr) return SREC_BAD_ARG;
-    srec_step_weights_desc q{};
-    q.n = n; q.d = d;
+    if (n > 2 * GB_MAXP || W == nullptr || dst_fwd == nullptr || dst_bwd == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
+    WfBothArgs a{};
+    int nw = 4;
+    if (int rc = srec_gru_fused_waves(d, &nw)) return rc;
+    a.d = d; a.jb = d / (32 * nw);
     for (int i = 0; i < n; ++i) {
-        q.W[i] = ((const float* const*)W)[i];
-        q.dst_fwd[i] = ((void* const*)dst_fwd)[i]; q.dst_bwd[i] = ((void* const*)dst_bwd)[i];
+        a.W[i] = ((const float* const*)W)[i];
+        a.dstf[i] = ((unsigned short* const*)dst_fwd)[i]; a.dstb[i] = ((unsigned short* const*)dst_bwd)[i];
+        if (a.W[i] == nullptr || a.dstf[i] == nullptr || a.dstb[i] == nullptr) return SREC_BAD_ARG;
     }
-    return srec_step_weights(&q, stream);
+    hipLaunchKernelGGL(gru_wfrag_both_kernel, dim3((3 * d * d / 8 + 255) / 256, n, 2), dim3(256), 0, (hipStream_t)stream, a);
+    SREC_LAUNCH_CHECK();
+    return 0;
 }
 
 #ifdef SREC_GRUF_TIMING

@@ -24,7 +24,6 @@
 // Saved for the backward: alpha [NT], cat = [v | g] [B, 2 d], Vq [B, d], y [B, d], 1 / |s| [B]; U only on request (the
 // grouped backward of ops.ReadoutHead reads it; the fused backward recomputes it).
 #include "common.h"
-#include "headfrag.h"
 #include "../../include/srec_hg.h"
 #include <type_traits>
 
@@ -33,7 +32,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int HS = SREC_HEAD_SESSIONS;   // sessions per pass of a workgroup (MFMA columns of the B x d products)
 constexpr int HR = SREC_HEAD_ROWS;       // rows of the per-session concatenation per workgroup window / per chunk (2 MFMA tiles)
-constexpr int NW = srec_frag::HEAD_NW;                   // waves per workgroup: wave w owns the hidden / output columns [w d/4, (w+1) d/4)
+constexpr int NW = 4;                    // waves per workgroup: wave w owns the hidden / output columns [w d/4, (w+1) d/4)
 constexpr int NS = 4, PF = NS - 1;       // register ring of weight fragments: stages, k-steps in flight
 constexpr int MAXN = SREC_MAX_SESSION_NODES;
 constexpr int VQ_PAD = 8;                // floats of padding per Vq row in LDS: (session, wave half) -> distinct 16-B slots
@@ -51,7 +50,11 @@ __device__ unsigned long long g_headf_blk[1024][2];
 #define HFT(i)
 #endif
 
-using srec_frag::split2;
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = srec_pack_bf16(a, b);
+    const float ah = __builtin_bit_cast(float, hi << 16), bh = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = srec_pack_bf16(a - ah, b - bh);
+}
 
 // 4 consecutive fp32 -> the hi / lo tiles (row-major [rows][W] bf16, 16-B pieces swizzled by row & 15), column c (multiple of 4)
 __device__ __forceinline__ void stage4(unsigned short* hi_t, unsigned short* lo_t, int W, int row, int c, float4 v) {
@@ -640,10 +643,32 @@ struct WfragArgs {
     int rows[SREC_HEAD_MAXW], cols[SREC_HEAD_MAXW], trans[SREC_HEAD_MAXW];
 };
 
-// hi / lo fragment-major copies (srec_frag::head_frag_item, headfrag.h)
+// hi / lo fragment-major copy of an operand matrix M [N, K] (trans = 0: M = W [rows = N, cols = K] as stored; trans = 1:
+// M = W^T of the stored W [rows = K, cols = N]): fragment (((w KS + s) 2 + t) JB + j), JB = N / 128, KS = K / 16, holds for lane l
+// the 8 bf16 of t(M[w N/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]), t = hi / lo
 __global__ __launch_bounds__(256) void head_wfrag_kernel(WfragArgs a) {
     const int m = blockIdx.y;
-    srec_frag::head_frag_item(a.W[m], a.dst[m], a.rows[m], a.cols[m], a.trans[m], blockIdx.x * 256 + threadIdx.x);
+    const int N = a.trans[m] ? a.cols[m] : a.rows[m], K = a.trans[m] ? a.rows[m] : a.cols[m];
+    const int JB = N / (32 * NW), KS = K / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // (w, s, j, lane)
+    if (idx >= N * K / 8) return;
+    const int lane = idx & 63, f = idx >> 6;
+    const int j = f % JB, ws = f / JB, s = ws % KS, w = ws / KS;
+    const int nrow = w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
+    float v[8];
+    const float* W = a.W[m];
+    if (!a.trans[m]) {
+        const float4 v0 = *reinterpret_cast<const float4*>(W + (size_t)nrow * K + kk), v1 = *reinterpret_cast<const float4*>(W + (size_t)nrow * K + kk + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = W[(size_t)(kk + i) * N + nrow];
+    }
+    uint4 h, l;
+    split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y); split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
+    unsigned short* dst = a.dst[m] + ((((size_t)(w * KS + s) * 2) * JB + j) * 64 + lane) * 8;
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + (size_t)JB * 512) = l;
 }
 
 }  // namespace

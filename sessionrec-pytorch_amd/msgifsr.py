@@ -150,17 +150,6 @@ class MSHGNN(nn.Module):
         plan.live = {t[0]: mg.count('N%d' % (k + 1)) for k, t in enumerate(types)}
         return plan, params
 
-    def fc_weights(self, mg, all_rels=False):
-        """the fc weights of this layer's modules in plan() order (what ops.hgat_layer hands to ops.weights_bf16)"""
-        out, seen = [], set()
-        live = [et for (s, et, d_), name in mg.meta['rels'] if all_rels or mg.count('E_' + name) > 0]
-        for ci, conv in enumerate((self.conv1, self.conv2)):
-            for et in live:
-                if (ci, et) not in seen:
-                    seen.add((ci, et))
-                    out.append(conv.mods[et].fc.weight)
-        return out
-
     def forward_stacked(self, mg, x, all_rels=False):
         """x: [NT, d] node features of all orders stacked (order-1 rows first) -> [NT, d]; one batched pass"""
         plan, params = self.plan(mg, x.shape[1], all_rels)
@@ -347,19 +336,6 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         ncap = mg.meta['ncap']                             # block size of order k (capacity in padded layouts)
         pieces = ops.split_rows(rows, [ncap[k] * k for k in range(1, K + 1)])
         fast = None
-        if (K > 1 and mg.buf.is_cuda and self.norm and d in (128, 256) and ops.PRECISION['matmul'] == 'bf16'
-                and ops.gru_fused_ok(d, K - 1) and ops.FUSED_HEAD):
-            # the fused read-out head (below) will want fragment copies of its weights: they ride in the launch that makes the
-            # expander's copies - both are "weights of this step" passes (ops.gru_wfrag_both)
-            live = range(K) if self.fusion else (0,)
-            ro, grad = self.readout, torch.is_grad_enabled()
-            hw = [w for i in live for w in (ro.fc_u[i].weight, ro.fc_v[i].weight, self.fc_sr[i].weight)]
-            ops.HEAD_WFRAG_REQUEST.append((hw + ([self.fc_sr[i].weight for i in live] if grad else []),
-                                           [0] * len(hw) + ([1] * len(live) if grad else [])))
-            if len(self.layers) > 0 and d % 64 == 0:        # ... and so do the bf16 / transposed copies of the first layer's fc weights
-                gw = self.layers[0].fc_weights(mg, self.shard is not None and self.shard.world > 1)
-                if 0 < len(gw) <= 8:
-                    ops.WEIGHTS_BF16_REQUEST.append(gw)
         if K > 1 and K <= 5 and ops.gru_expand_fast_ok(d, self.reducer):
             # bf16 path: every order's k-gram GRU in one autograd node, one launch per time step for all orders
             fast = ops.gru_expand_all([pieces[k - 1] for k in range(2, K + 1)], [self.expander.GRUs[k - 2] for k in range(2, K + 1)],
@@ -422,8 +398,6 @@ class MSGIFSR(_ScoringMixin, nn.Module):
                                                 [mg.field('lastcat%d' % (i + 1)) for i in live], mg.dynp('NT'), dB)
             feat_vs = dict(zip(live, picked))
         srs = []
-        del ops.HEAD_WFRAG_REQUEST[:]                      # (an expander path that made no fragment launch leaves them unserved)
-        del ops.WEIGHTS_BF16_REQUEST[:]
         if len(live) <= 4:
             # read-out + fc_sr(cat[x_last, sr_g]) of every live order as grouped exact-fp32 launches (ops.ReadoutHead):
             # these B-row products are launch bound one by one

@@ -105,14 +105,12 @@ def set_precision(mode):
     PRECISION['matmul'] = mode
     _WT_CACHE.clear()
     _HEAD_WF_CACHE.clear()
-    _W16_CACHE.clear()
 
 
 def weights_changed():
     """called by the optimizer after it updated parameters: cached transposed weight copies are stale"""
     _WT_CACHE.clear()
     _HEAD_WF_CACHE.clear()
-    _W16_CACHE.clear()
 
 
 def _transposed(w):
@@ -1784,67 +1782,14 @@ def gru_wfrag_t(ws):
     return outs
 
 
-HEAD_WFRAG_REQUEST = []     # [(weights, trans)] / [weights]: what a model leaves here before its GRU expander runs - the read-out
-WEIGHTS_BF16_REQUEST = []   # head's fragment copies and the GAT weights' bf16 copies of this step then ride in the expander's
-#                             fragment launch (gru_wfrag_both -> srec_step_weights) instead of a launch each; see msgifsr.py
-_W16_CACHE = {}             # (data_ptrs, shapes) -> (w16 list, wt16 list) of this step (dropped by weights_changed)
-
-
-class StepWeightsDesc(_ct.Structure):
-    """host mirror of srec_step_weights_desc (include/srec_hg.h)"""
-    _fields_ = [('n', _ct.c_int), ('d', _ct.c_int), ('W', _ct.c_void_p * 8), ('dst_fwd', _ct.c_void_p * 8), ('dst_bwd', _ct.c_void_p * 8),
-                ('nh', _ct.c_int), ('hW', _ct.c_void_p * 16), ('hdst', _ct.c_void_p * 16),
-                ('hrows', _ct.c_int * 16), ('hcols', _ct.c_int * 16), ('htrans', _ct.c_int * 16),
-                ('nw', _ct.c_int), ('wW', _ct.c_void_p * 8), ('w16', _ct.c_void_p * 8), ('wt16', _ct.c_void_p * 8),
-                ('wR', _ct.c_int * 8), ('wC', _ct.c_int * 8)]
-
-
-def _w16_key(ws):
-    return tuple((w.data_ptr(), tuple(w.shape)) for w in ws)
-
-
 def gru_wfrag_both(ws):
-    """gru_wfrag and gru_wfrag_t of the same weights in one launch -> (forward copies, backward copies); pending
-    HEAD_WFRAG_REQUEST / WEIGHTS_BF16_REQUEST entries are served by the same launch (srec_step_weights): their copies land in
-    the per-step caches head_wfrag / weights_bf16 look into"""
+    """gru_wfrag and gru_wfrag_t of the same weights in one launch -> (forward copies, backward copies)"""
     n, d = len(ws), ws[0].shape[1]
-    assert n <= 8
     of = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
     ob = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
-    q = StepWeightsDesc()
-    q.n, q.d = n, d
-    for i, w in enumerate(ws):
-        q.W[i], q.dst_fwd[i], q.dst_bwd[i] = w.data_ptr(), of[i].data_ptr(), ob[i].data_ptr()
-    hws, htr = [], []
-    while HEAD_WFRAG_REQUEST:
-        rw, rt = HEAD_WFRAG_REQUEST.pop()
-        for w, t in zip(rw, rt):
-            if (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and int(t) in (0, 1) and len(hws) < 16
-                    and (w.data_ptr(), tuple(w.shape), int(t)) not in _HEAD_WF_CACHE
-                    and (w.shape[1] if t else w.shape[0]) % 128 == 0 and (w.shape[0] if t else w.shape[1]) % 16 == 0):
-                hws.append(w)
-                htr.append(int(t))
-    hbufs = [torch.empty(2 * w.numel(), device=w.device, dtype=torch.bfloat16) for w in hws]
-    q.nh = len(hws)
-    for i, (w, t, b) in enumerate(zip(hws, htr, hbufs)):
-        q.hW[i], q.hdst[i], q.hrows[i], q.hcols[i], q.htrans[i] = w.data_ptr(), b.data_ptr(), w.shape[0], w.shape[1], t
-    gw = None
-    while WEIGHTS_BF16_REQUEST:
-        cand = WEIGHTS_BF16_REQUEST.pop()
-        if (gw is None and 0 < len(cand) <= 8 and _w16_key(cand) not in _W16_CACHE
-                and all(w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and w.dim() == 2 for w in cand)):
-            gw = cand
-    if gw is not None:
-        w16 = [torch.empty(w.shape, device=w.device, dtype=torch.bfloat16) for w in gw]
-        wt16 = [torch.empty(w.shape[1], w.shape[0], device=w.device, dtype=torch.bfloat16) for w in gw]
-        q.nw = len(gw)
-        for i, w in enumerate(gw):
-            q.wW[i], q.w16[i], q.wt16[i], q.wR[i], q.wC[i] = w.data_ptr(), w16[i].data_ptr(), wt16[i].data_ptr(), w.shape[0], w.shape[1]
-    lib.srec_step_weights(_ct.addressof(q), stream())
-    for w, t, b in zip(hws, htr, hbufs):
-        _HEAD_WF_CACHE[(w.data_ptr(), tuple(w.shape), t)] = b
-    if gw is not None:
-        _W16_CACHE[_w16_key(gw)] = (w16, wt16)
+    arr = _ct.c_void_p * n
+    a_w, a_f, a_b = arr(*[w.data_ptr() for w in ws]), arr(*[o.data_ptr() for o in of]), arr(*[o.data_ptr() for o in ob])
+    lib.srec_gru_wfrag_both(n, _ct.addressof(a_w), _ct.addressof(a_f), _ct.addressof(a_b), d, stream())
     return of, ob
 
 
@@ -2489,13 +2434,9 @@ def rows_bf16(x, dyn=None):
 
 
 def weights_bf16(ws, transposed=True):
-    """[(W16, WT16)] bf16 copies (and transposed copies) of up to 8 contiguous fp32 matrices, one launch - or none, when this
-    step's copies were made with the GRU expander's fragment copies (WEIGHTS_BF16_REQUEST)"""
+    """[(W16, WT16)] bf16 copies (and transposed copies) of up to 8 contiguous fp32 matrices, one launch"""
     n = len(ws)
     assert 0 < n <= 8
-    hit = _W16_CACHE.get(_w16_key(ws)) if transposed else None
-    if hit is not None:
-        return hit
     dev = ws[0].device
     w16 = [torch.empty(w.shape, device=dev, dtype=torch.bfloat16) for w in ws]
     wt16 = [torch.empty(w.shape[1], w.shape[0], device=dev, dtype=torch.bfloat16) if transposed else None for w in ws]
