@@ -285,7 +285,49 @@ __device__ __forceinline__ void gemm_f32_tile(
         if (kt + 1 < nk) ktile(kt + 1, St0{});
     }
 
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) - ONE float of a row per lane.  Stored as
+    // it comes that is 16 4-byte store (and, with beta, load) instructions per MFMA tile and wave, and a vector-memory
+    // instruction costs a CU ~40 cycles whatever its width (csrc/gruf.hip, score_ce_bf16.hip): the tile goes through a per-wave
+    // LDS patch (the operand tiles are free now) and leaves as 16-byte accesses, 4 per lane and MFMA tile.
+    const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0);
+    if (vec) {
+        constexpr int PS = 36;                             // patch row stride (floats): 16-byte aligned rows, conflict-free
+        float* patch = ((wave < 2) ? fa(0) : fb(0)) + (wave & 1) * (32 * PS);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PS + l31] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's patch writes have landed
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = q * 64 + lane, rl = idx >> 3, c4 = (idx & 7) * 4;
+                    const int row = m0 + wm * (BM / 2) + i * 32 + rl, col = n0 + wn * (BN / 2) + j * 32 + c4;
+                    if (row < Mfull && col < N) {
+                        float4* p = reinterpret_cast<float4*>(C + (size_t)row * ldc + col);
+                        if (row < M) {
+                            float4 v = *reinterpret_cast<const float4*>(patch + rl * PS + c4);
+                            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+                            if (bias != nullptr) {
+                                const float4 bq = *reinterpret_cast<const float4*>(bias + col);
+                                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                            }
+                            if (beta != 0.f) {
+                                const float4 o = *p;
+                                v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+                            }
+                            *p = v;
+                        } else if (beta == 0.f) {
+                            *p = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();           // (the next MFMA tile reuses the patch)
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
