@@ -284,6 +284,43 @@ __global__ __launch_bounds__(64 * NW) void gemm16_nt_kernel(G16Args g) {
 #endif
         return;
     }
+    // fp32 output (backward-data, beta = 1: d x += ...): the MFMA layout has ONE float of a row per lane - 16 four-byte loads and
+    // 16 stores per MFMA tile and wave, each a vector-memory instruction of ~40 CU cycles whatever its width.  Through a per-wave
+    // LDS patch (the ring is free now) the tile is read / written as 16-byte accesses: 4 + 4 instructions per MFMA tile.
+    if ((N & 3) == 0 && (g.ldcp[p] & 3) == 0 && ((uintptr_t)C & 15) == 0) {
+        constexpr int PS = 36;
+        __syncthreads();                                               // every wave is done with the ring buffers
+        float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PS);
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+#pragma unroll
+            for (int j = 0; j < IN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PS + l31] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int idx = q4 * 64 + lane, rl = idx >> 3, c4 = (idx & 7) * 4;
+                    const int row = m0 + wm * (TM / 2) + i * 32 + rl, col = n0 + wn * (TN / WN) + j * 32 + c4;
+                    if (row < M && col < N) {
+                        float4* q = reinterpret_cast<float4*>(C + (size_t)row * g.ldcp[p] + col);
+                        if (row < Ml) {
+                            float4 v = *reinterpret_cast<const float4*>(patch + rl * PS + c4);
+                            if (g.beta != 0.f) {
+                                const float4 o = *q;
+                                v.x += g.beta * o.x; v.y += g.beta * o.y; v.z += g.beta * o.z; v.w += g.beta * o.w;
+                            }
+                            *q = v;
+                        } else if (g.beta == 0.f) {
+                            *q = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -431,6 +468,36 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    }
+    if ((N2 & 3) == 0 && (g.ldcp[p] & 3) == 0 && ((uintptr_t)C & 15) == 0) {      // 16-byte accesses through a per-wave LDS patch
+        constexpr int PS = 36;
+        __syncthreads();                                               // every wave is done with the ring buffers
+        float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PS);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PS + l31] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int idx = q4 * 64 + lane, rl = idx >> 3, c4 = (idx & 7) * 4;
+                    const int row = i0 + wm * 64 + i * 32 + rl, col = j0 + wn * 64 + j * 32 + c4;
+                    if (row < N1 && col < N2) {
+                        float4* q = reinterpret_cast<float4*>(C + (size_t)row * g.ldcp[p] + col);
+                        float4 v = *reinterpret_cast<const float4*>(patch + rl * PS + c4);
+                        if (g.beta != 0.f) {
+                            const float4 o = *q;
+                            v.x += g.beta * o.x; v.y += g.beta * o.y; v.z += g.beta * o.z; v.w += g.beta * o.w;
+                        }
+                        *q = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
