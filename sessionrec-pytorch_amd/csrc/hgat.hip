@@ -1325,36 +1325,45 @@ __global__ void hg_colsum_part_kernel(ColArgs a) {
     }
 }
 
-// H == 8, D <= 256: ONE thread per feature column carries all heads, one job per node type (bias sums) and per projection
-// BLOCK (Z sums), 64 row chunks each.  The head-per-workgroup version above re-reads every x / g row once per head out of
-// L2 (~310 MB for 39 MB of rows: 31 us, whatever its launch shape); with all heads on the column's thread a row is read
-// once, and the parallelism that version got from the head dimension comes from finer row chunks and 16 rows of loads in
-// flight per thread.  The per-(row, head) factors of a 16-row tile go through LDS (broadcast reads).
+// H == 8, D <= 256, D % 4 == 0: a thread carries FOUR feature columns with all heads, one job per node type (bias sums) and per
+// projection BLOCK (Z sums), 32 row chunks each.  The head-per-workgroup version above re-reads every x / g row once per head out
+// of L2 (~310 MB for 39 MB of rows: 31 us, whatever its launch shape); with all heads on the column's thread a row is read
+// once.  Thread = (4 columns, row lane of 4): a 16-row tile is 4 sixteen-byte loads per thread instead of 16 four-byte ones (the
+// one-column-per-thread version was bound by the ISSUE of its loads: 68 vector-memory instructions per tile and workgroup for
+// 1 k cycles of FMAs); the per-(row, head) factors of the tile go through LDS (broadcast reads); the four row lanes are summed
+// through LDS at the end, 16 accumulators per pass.
 __global__ __launch_bounds__(256) void hg_colsum_cols_kernel(ColArgs a) {
     __shared__ __attribute__((aligned(16))) float sw[16][16];
+    __shared__ __attribute__((aligned(16))) float red4[4][64][4];
     const int D = a.D, HD = 8 * D;
-    const int c = threadIdx.x, job = blockIdx.y, chunk = blockIdx.x;
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6, c = 4 * cg;
+    const int job = blockIdx.y, chunk = blockIdx.x;
     const bool cok = c < D;
-    float s0[8], s1[8];
+    float4 s0[8], s1[8];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) { s0[h] = 0.f; s1[h] = 0.f; }
+    for (int h = 0; h < 8; ++h) { s0[h] = make_float4(0.f, 0.f, 0.f, 0.f); s1[h] = make_float4(0.f, 0.f, 0.f, 0.f); }
     if (job < a.nt) {
         const int t = job;
         const int n = dyn_count(a.dyn_t[t], a.ncap_t[t]);
         const int per = (n + NCHUNK_C - 1) / NCHUNK_C, r0 = chunk * per, r1 = min(n, r0 + per);
         if (cok)
-            for (int r = r0; r < r1; r += 8) {
-                float gv[8]; int av[8];
+            for (int r = r0 + rl; r < r1; r += 16) {
+                float4 gv[4]; unsigned av[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const size_t row = (size_t)(a.row0[t] + min(r + e, r1 - 1));
-                    gv[e] = a.g[row * a.ld_g + c];
-                    av[e] = r + e < r1 ? (int)a.arg[row * D + c] : -1;
+                for (int e = 0; e < 4; ++e) {
+                    const size_t row = (size_t)(a.row0[t] + min(r + 4 * e, r1 - 1));
+                    gv[e] = *reinterpret_cast<const float4*>(a.g + row * a.ld_g + c);
+                    av[e] = r + 4 * e < r1 ? *reinterpret_cast<const unsigned*>(a.arg + row * D + c) : 0xffffffffu;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int h = 0; h < 8; ++h) s0[h] += av[e] == h ? gv[e] : 0.f;
+                    for (int h = 0; h < 8; ++h) {
+                        s0[h].x += (av[e] & 0xffu) == (unsigned)h ? gv[e].x : 0.f;
+                        s0[h].y += ((av[e] >> 8) & 0xffu) == (unsigned)h ? gv[e].y : 0.f;
+                        s0[h].z += ((av[e] >> 16) & 0xffu) == (unsigned)h ? gv[e].z : 0.f;
+                        s0[h].w += (av[e] >> 24) == (unsigned)h ? gv[e].w : 0.f;
+                    }
             }
     } else {
         const int b = job - a.nt;
@@ -1364,9 +1373,11 @@ __global__ __launch_bounds__(256) void hg_colsum_cols_kernel(ColArgs a) {
         const float* __restrict__ wL = a.wL[b];
         const float* __restrict__ wR = a.wR[b];
         for (int r = r0; r < r1; r += 16) {
-            float xv[16];
+            float4 xv[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) xv[e] = (cok && r + e < r1) ? xb[(size_t)(r + e) * a.ld_x] : 0.f;
+            for (int e = 0; e < 4; ++e)
+                xv[e] = (cok && r + rl + 4 * e < r1) ? *reinterpret_cast<const float4*>(xb + (size_t)(r + rl + 4 * e) * a.ld_x)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();                               // the previous tile's factors have been read
             {
                 const int row = threadIdx.x >> 4, k = threadIdx.x & 15;
@@ -1376,20 +1387,35 @@ __global__ __launch_bounds__(256) void hg_colsum_cols_kernel(ColArgs a) {
             }
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float4 l0 = *reinterpret_cast<const float4*>(&sw[e][0]), l1 = *reinterpret_cast<const float4*>(&sw[e][4]);
-                const float4 q0 = *reinterpret_cast<const float4*>(&sw[e][8]), q1 = *reinterpret_cast<const float4*>(&sw[e][12]);
-                s0[0] += xv[e] * l0.x; s0[1] += xv[e] * l0.y; s0[2] += xv[e] * l0.z; s0[3] += xv[e] * l0.w;
-                s0[4] += xv[e] * l1.x; s0[5] += xv[e] * l1.y; s0[6] += xv[e] * l1.z; s0[7] += xv[e] * l1.w;
-                s1[0] += xv[e] * q0.x; s1[1] += xv[e] * q0.y; s1[2] += xv[e] * q0.z; s1[3] += xv[e] * q0.w;
-                s1[4] += xv[e] * q1.x; s1[5] += xv[e] * q1.y; s1[6] += xv[e] * q1.z; s1[7] += xv[e] * q1.w;
+            for (int e = 0; e < 4; ++e) {
+                const float* f = &sw[rl + 4 * e][0];
+                const float4 l0 = *reinterpret_cast<const float4*>(f), l1 = *reinterpret_cast<const float4*>(f + 4);
+                const float4 q0 = *reinterpret_cast<const float4*>(f + 8), q1 = *reinterpret_cast<const float4*>(f + 12);
+                const float lw[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+                const float qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    s0[h].x += xv[e].x * lw[h]; s0[h].y += xv[e].y * lw[h]; s0[h].z += xv[e].z * lw[h]; s0[h].w += xv[e].w * lw[h];
+                    s1[h].x += xv[e].x * qw[h]; s1[h].y += xv[e].y * qw[h]; s1[h].z += xv[e].z * qw[h]; s1[h].w += xv[e].w * qw[h];
+                }
             }
         }
     }
-    if (cok) {
-        float* p = a.part + ((size_t)job * NCHUNK_C + chunk) * 2 * HD + c;
+    // the four row lanes of a column group -> one partial: 16 float4 accumulators, one LDS pass each (row lanes added in order)
+    float* p = a.part + ((size_t)job * NCHUNK_C + chunk) * 2 * HD + c;
 #pragma unroll
-        for (int h = 0; h < 8; ++h) { p[h * D] = s0[h]; p[HD + h * D] = s1[h]; }
+    for (int k = 0; k < 16; ++k) {
+        const float4 v = k < 8 ? s0[k] : s1[k - 8];
+        __syncthreads();
+        *reinterpret_cast<float4*>(&red4[rl][cg][0]) = v;
+        __syncthreads();
+        if (rl == 0 && cok) {
+            const float4 v1 = *reinterpret_cast<const float4*>(&red4[1][cg][0]), v2 = *reinterpret_cast<const float4*>(&red4[2][cg][0]),
+                         v3 = *reinterpret_cast<const float4*>(&red4[3][cg][0]);
+            const float4 o = make_float4(((v.x + v1.x) + v2.x) + v3.x, ((v.y + v1.y) + v2.y) + v3.y, ((v.z + v1.z) + v2.z) + v3.z,
+                                         ((v.w + v1.w) + v2.w) + v3.w);
+            *reinterpret_cast<float4*>(p + (k < 8 ? k * D : HD + (k - 8) * D)) = o;
+        }
     }
 }
 
@@ -1678,7 +1704,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             r += d->ncap[t];
         }
         a.row0[d->n_types] = r;
-        const bool cols = H == 8 && D <= 256;             // column-thread sums: jobs = node types + projection blocks
+        const bool cols = H == 8 && D <= 256 && (D & 3) == 0 && (a.ld_x & 3) == 0 && (a.ld_g & 3) == 0;   // column-thread sums: jobs = node types + projection blocks
         ColFinalArgs f{};
         f.nm = d->n_mods; f.H = H; f.D = D; f.part = ws;
         if (cols) {
