@@ -169,9 +169,18 @@ __global__ __launch_bounds__(256) void hg_dots_kernel(DotsArgs a) {
     const int Dp = (D + 15) & ~15;                             // k padded to whole 16-blocks (zeros)
     for (int i = threadIdx.x; i < 16 * LDV + 16; i += 256) vt[i] = 0.f;    // heads >= H: zero rows; finite tail
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D * H; i += 256) {
-        const int lr = i / (D * H), c = (i / H) % D, h = i % H;
-        vt[(lr * 8 + h) * LDV + c] = a.V[b][i];
+    if ((H & 3) == 0) {                                        // 16-byte loads: 4 heads of one (l/r, column)
+        for (int i = threadIdx.x * 4; i < 2 * D * H; i += 1024) {
+            const int lr = i / (D * H), c = (i / H) % D, h = i % H;
+            const float4 q = *reinterpret_cast<const float4*>(a.V[b] + i);
+            float* d0 = vt + (lr * 8 + h) * LDV + c;
+            d0[0] = q.x; d0[LDV] = q.y; d0[2 * LDV] = q.z; d0[3 * LDV] = q.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 2 * D * H; i += 256) {
+            const int lr = i / (D * H), c = (i / H) % D, h = i % H;
+            vt[(lr * 8 + h) * LDV + c] = a.V[b][i];
+        }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
