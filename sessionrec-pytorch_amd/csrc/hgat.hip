@@ -76,44 +76,51 @@ struct FoldArgs {
     float* bsum[MAXT];
 };
 
-// block = (module, head, 64-column slice); 256 threads = 4 row groups x 64 columns.  (One 1024-thread block per (module, head)
-// - 64 workgroups - kept 3/4 of the CUs idle: 12 us for 16 MB of weights; same per-thread row order, so the same sums.)
-constexpr int FOLD_COLS = 64;
+// block = (module, head, 64-column slice); 256 threads = 16 row groups x 16 column quads: a thread reads 16 bytes of 16 rows of
+// W (one-column threads issued 64 four-byte loads per wave for the same bytes: the kernel was bound by their issue, 9.5 us for
+// 16 MB), the attention vectors of the head wait in LDS; the 16 row groups are summed through LDS in row-group order.
+// (One 1024-thread block per (module, head) - 64 workgroups - kept 3/4 of the CUs idle: 12 us.)
+constexpr int FOLD_COLS = 64, MAXD_FOLD = 256;        // (D <= 256, D % 4 == 0: checked by the launchers)
 __global__ __launch_bounds__(256) void hg_fold_kernel(FoldArgs a) {
-    __shared__ float red[2][3][FOLD_COLS];
+    __shared__ __attribute__((aligned(16))) float red[2][16][FOLD_COLS];
+    __shared__ float av[2][MAXD_FOLD];
     const int H = a.H, D = a.D;
     const int ncq = (D + FOLD_COLS - 1) / FOLD_COLS;
     const int cq = blockIdx.x % ncq, mh = blockIdx.x / ncq;
-    const int m = mh / H, h = mh % H, cl = threadIdx.x & (FOLD_COLS - 1), jg = threadIdx.x / FOLD_COLS;
-    const int c = cq * FOLD_COLS + cl;
-    float sl = 0.f, sr = 0.f;
+    const int m = mh / H, h = mh % H;
+    for (int j = threadIdx.x; j < D; j += 256) { av[0][j] = a.al[m][h * D + j]; av[1][j] = a.ar[m][h * D + j]; }
+    __syncthreads();
+    const int c4 = threadIdx.x & 15, jg = threadIdx.x >> 4;
+    const int c = cq * FOLD_COLS + 4 * c4;
+    float4 sl = make_float4(0.f, 0.f, 0.f, 0.f), sr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < D) {
         const float* W = a.W[m] + (size_t)h * D * D + c;
-        const float* al = a.al[m] + h * D;
-        const float* ar = a.ar[m] + h * D;
 #pragma unroll 8
-        for (int j = jg; j < D; j += 4) {
-            const float w = W[(size_t)j * D];
-            sl += w * al[j];
-            sr += w * ar[j];
+        for (int j = jg; j < D; j += 16) {
+            const float4 w = *reinterpret_cast<const float4*>(W + (size_t)j * D);
+            const float l = av[0][j], r = av[1][j];
+            sl.x += w.x * l; sl.y += w.y * l; sl.z += w.z * l; sl.w += w.w * l;
+            sr.x += w.x * r; sr.y += w.y * r; sr.z += w.z * r; sr.w += w.w * r;
         }
     }
-    if (jg > 0) { red[0][jg - 1][cl] = sl; red[1][jg - 1][cl] = sr; }
+    *reinterpret_cast<float4*>(&red[0][jg][4 * c4]) = sl;
+    *reinterpret_cast<float4*>(&red[1][jg][4 * c4]) = sr;
     __syncthreads();
-    if (jg == 0 && c < D) {
-        sl += red[0][0][cl] + red[0][1][cl] + red[0][2][cl];
-        sr += red[1][0][cl] + red[1][1][cl] + red[1][2][cl];
-        a.V[m][(size_t)c * H + h] = sl;
-        a.V[m][(size_t)(D + c) * H + h] = sr;
+    const int cl = threadIdx.x & (FOLD_COLS - 1), part = threadIdx.x / FOLD_COLS, cc = cq * FOLD_COLS + cl;
+    if (part < 2 && cc < D) {                            // threads 0 .. 63: V_l, 64 .. 127: V_r
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[part][g][cl];
+        a.V[m][(size_t)(part * D + cc) * H + h] = t;
     }
-    if (jg == 1 && c < D) {
+    if (part == 2 && cc < D) {
         // node types are dealt to the module workgroups round-robin: a tiny batch may have fewer live modules than types
         const int nmods = (int)gridDim.x / (H * ncq);
         for (int t = m; t < a.nt; t += nmods) {
             if (a.bsum[t] == nullptr) continue;
             float b = 0.f;
-            for (int q = 0; q < a.tn[t]; ++q) b += a.tb[t][q][h * D + c];  // instance order = the order hg_agg used
-            a.bsum[t][h * D + c] = b;
+            for (int q = 0; q < a.tn[t]; ++q) b += a.tb[t][q][h * D + cc];  // instance order = the order hg_agg used
+            a.bsum[t][h * D + cc] = b;
         }
     }
 }
