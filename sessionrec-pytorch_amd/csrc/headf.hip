@@ -581,48 +581,40 @@ __global__ __launch_bounds__(64 * NW, 1) void head_bwd_kernel(HeadBwdArgs a) {
         }
         __syncthreads();
         HFT(3);
-        // ---- dU, dVq, dwp: one hidden column per thread over all rows of the pass in node order (the sums of a session as
-        //      srec_seg_attn_bwd forms them), 8 rows in registers, the next 8 requested before these are used
-        for (int k = tid; k < D; k += NT) {
-            const float wk = q.we[hd][k];
-            const float* up = q.U[hd] + (size_t)r0 * D + k;
-            float* dup = dU + (size_t)r0 * D + k;
-            float uv[8], un[8];
+        // ---- dU, dVq, dwp: a wavefront takes whole sessions (sb = wave, wave + NW, ...: their sums are independent), a lane FOUR
+        //      hidden columns - one 16-byte load of U and one 16-byte store of dU per row (a column per thread was a 4-byte load
+        //      and a 4-byte store per row and wave: the phase was bound by the issue of ~200 vector-memory instructions per wave).
+        //      Rows in node order per session, as srec_seg_attn_bwd sums them; 8 rows in flight.
+        {
+            const int k4 = lane * 4;
+            if (k4 < D) {
+                const float4 wk = *reinterpret_cast<const float4*>(q.we[hd] + k4);
+                for (int sb = wave; sb < ns; sb += NW) {
+                    const int base = segs[sb], n = segs[sb + 1] - base;
+                    const float4 vq = *reinterpret_cast<const float4*>(vql + sb * D + k4);
+                    const float* up = q.U[hd] + (size_t)(r0 + base) * D + k4;
+                    float* dup = dU + (size_t)(r0 + base) * D + k4;
+                    float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), dw = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int i = 0; i < n; i += 8) {
+                        float4 uv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) uv[j] = up[(size_t)min(j, nrows - 1) * D];
-            int sb = 0, send = segs[1];
-            float vqk = vql[k];
-            float dv = 0.f, dw = 0.f;
-            for (int i = 0; i < nrows; i += 8) {
+                        for (int j = 0; j < 8; ++j) uv[j] = *reinterpret_cast<const float4*>(up + (size_t)min(i + j, n - 1) * D);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) un[j] = up[(size_t)min(i + 8 + j, nrows - 1) * D];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int r = i + j;
-                    if (r < nrows) {
-                        while (r >= send) {              // uniform over the workgroup: the rows of session sb are done
-                            q.dVq[hd][(size_t)(b0 + sb) * D + k] = dv;
-                            q.dwp[hd][(size_t)(b0 + sb) * D + k] = dw;
-                            dv = dw = 0.f;
-                            ++sb;
-                            send = segs[sb + 1];
-                            vqk = vql[min(sb, HS - 1) * D + k];
+                        for (int j = 0; j < 8; ++j) {
+                            if (i + j < n) {
+                                const float dei = de[base + i + j];
+                                const float4 sg = make_float4(sig(uv[j].x + vq.x), sig(uv[j].y + vq.y), sig(uv[j].z + vq.z), sig(uv[j].w + vq.w));
+                                dw.x += dei * sg.x; dw.y += dei * sg.y; dw.z += dei * sg.z; dw.w += dei * sg.w;
+                                const float4 dp = make_float4(dei * wk.x * sg.x * (1.f - sg.x), dei * wk.y * sg.y * (1.f - sg.y),
+                                                              dei * wk.z * sg.z * (1.f - sg.z), dei * wk.w * sg.w * (1.f - sg.w));
+                                *reinterpret_cast<float4*>(dup + (size_t)(i + j) * D) = dp;
+                                dv.x += dp.x; dv.y += dp.y; dv.z += dp.z; dv.w += dp.w;
+                            }
                         }
-                        const float sg = sig(uv[j] + vqk);
-                        const float dei = de[r];
-                        dw += dei * sg;
-                        const float dp = dei * wk * sg * (1.f - sg);
-                        dup[(size_t)r * D] = dp;
-                        dv += dp;
                     }
+                    *reinterpret_cast<float4*>(q.dVq[hd] + (size_t)(b0 + sb) * D + k4) = dv;
+                    *reinterpret_cast<float4*>(q.dwp[hd] + (size_t)(b0 + sb) * D + k4) = dw;
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) uv[j] = un[j];
-            }
-            for (; sb < ns; ++sb) {                      // the last session (and empty ones behind it)
-                q.dVq[hd][(size_t)(b0 + sb) * D + k] = dv;
-                q.dwp[hd][(size_t)(b0 + sb) * D + k] = dw;
-                dv = dw = 0.f;
             }
         }
         HFT(4);
