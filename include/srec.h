@@ -337,7 +337,10 @@ int srec_hg_drop_prep(const float* x, const float* cnt, int rows, int D, float p
 /* ... and, in the same pass, xc16 [2, rows, D] = bf16(xc): the operand copy the bf16 projection GEMM reads */
 int srec_hg_drop_prep16(const float* x, const float* cnt, int rows, int D, float p, int seed, const int* counter, int salt,
                         float* ms, float* xc, float* rm, float* xres, float pa, long na, float* mk, void* xc16, void* stream);
-int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, void* stream);
+/* (ms of srec_hg_drop_prep / _prep16 is nullable: srec_hg_drop_merge with ms = NULL recomputes the masks from p / seed / counter /
+ * salt, the mask tensor is then neither written nor read) */
+int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, float p, int seed, const int* counter,
+                       int salt, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
                 int ld_dx, float* ws, void* stream);
 

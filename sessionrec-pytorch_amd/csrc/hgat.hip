@@ -1789,8 +1789,10 @@ __global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __
     const unsigned i0 = (unsigned)i, i1 = (unsigned)(n + i);
     m0.x = srec_keep(key, i0, p, sc); m0.y = srec_keep(key, i0 + 1, p, sc); m0.z = srec_keep(key, i0 + 2, p, sc); m0.w = srec_keep(key, i0 + 3, p, sc);
     m1.x = srec_keep(key, i1, p, sc); m1.y = srec_keep(key, i1 + 1, p, sc); m1.z = srec_keep(key, i1 + 2, p, sc); m1.w = srec_keep(key, i1 + 3, p, sc);
-    *reinterpret_cast<float4*>(ms + i) = m0;
-    *reinterpret_cast<float4*>(ms + n + i) = m1;
+    if (ms != nullptr) {                        // (kept only on request: hg_drop_merge recomputes the masks from the hash)
+        *reinterpret_cast<float4*>(ms + i) = m0;
+        *reinterpret_cast<float4*>(ms + n + i) = m1;
+    }
     const float4 x0 = make_float4(xv.x * m0.x, xv.y * m0.y, xv.z * m0.z, xv.w * m0.w);
     const float4 x1 = make_float4(xv.x * m1.x, xv.y * m1.y, xv.z * m1.z, xv.w * m1.w);
     *reinterpret_cast<float4*>(xc + i) = x0;
@@ -1805,9 +1807,11 @@ __global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __
 }
 
 // dx += (sum_s t[0][s]) * ms[0] + (sum_s t[1][s]) * ms[1]   (the two convs' masked data gradients, each given as S
-// partial sums - one per GAT module that projects the row's node type)
+// partial sums - one per GAT module that projects the row's node type).  ms == NULL: the masks are recomputed from the
+// counter-based hash of hg_drop_prep (same p / seed / counter / salt: the device counter only moves with the optimizer step)
+// instead of being written there and read back here (2 x 11 MB at the bench shape).
 __global__ void hg_drop_merge_kernel(const float* __restrict__ t, int S, const float* __restrict__ ms, long n,
-                                     float* __restrict__ dx) {
+                                     float* __restrict__ dx, float p, srec_rng rng) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     float4 a = *reinterpret_cast<const float4*>(t + i), b = *reinterpret_cast<const float4*>(t + (size_t)S * n + i);
@@ -1817,7 +1821,16 @@ __global__ void hg_drop_merge_kernel(const float* __restrict__ t, int S, const f
         a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
         b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
     }
-    const float4 m0 = *reinterpret_cast<const float4*>(ms + i), m1 = *reinterpret_cast<const float4*>(ms + n + i);
+    float4 m0, m1;
+    if (ms != nullptr) {
+        m0 = *reinterpret_cast<const float4*>(ms + i); m1 = *reinterpret_cast<const float4*>(ms + n + i);
+    } else {
+        const unsigned key = srec_rng_key(rng);
+        const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+        const unsigned i0 = (unsigned)i, i1 = (unsigned)(n + i);
+        m0.x = srec_keep(key, i0, p, sc); m0.y = srec_keep(key, i0 + 1, p, sc); m0.z = srec_keep(key, i0 + 2, p, sc); m0.w = srec_keep(key, i0 + 3, p, sc);
+        m1.x = srec_keep(key, i1, p, sc); m1.y = srec_keep(key, i1 + 1, p, sc); m1.z = srec_keep(key, i1 + 2, p, sc); m1.w = srec_keep(key, i1 + 3, p, sc);
+    }
     float4 d = *reinterpret_cast<float4*>(dx + i);
     d.x += a.x * m0.x + b.x * m1.x; d.y += a.y * m0.y + b.y * m1.y; d.z += a.z * m0.z + b.z * m1.z; d.w += a.w * m0.w + b.w * m1.w;
     *reinterpret_cast<float4*>(dx + i) = d;
@@ -1855,12 +1868,14 @@ extern "C" int srec_hg_drop_prep16(const float* x, const float* cnt, int rows, i
     return hg_drop_prep_run(x, cnt, rows, D, p, seed, counter, salt, ms, xc, rm, xres, pa, na, mk, (unsigned short*)xc16, stream);
 }
 
-// dx [n] += (sum_s t[0][s]) * ms[0] + (sum_s t[1][s]) * ms[1], t [2, S, n], ms [2, n]; n % 4 == 0
-extern "C" int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, void* stream) {
+// dx [n] += (sum_s t[0][s]) * ms[0] + (sum_s t[1][s]) * ms[1], t [2, S, n], ms [2, n] or NULL (then the masks of
+// srec_hg_drop_prep with the same p / seed / counter / salt are recomputed); n % 4 == 0
+extern "C" int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, float p, int seed,
+                                  const int* counter, int salt, void* stream) {
     if (n <= 0) return 0;
-    if ((n & 3) || S < 1) return SREC_BAD_ARG;
+    if ((n & 3) || S < 1 || p < 0.f || p >= 1.f || 2 * n > 0xffffffffL) return SREC_BAD_ARG;
     hipLaunchKernelGGL(hg_drop_merge_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, S,
-                       ms, n, dx);
+                       ms, n, dx, p, srec_rng{(unsigned)seed, counter, (unsigned)salt, p});
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -2588,8 +2588,9 @@ class HGATLayer(torch.autograd.Function):
             # both convs' feature masks and every instance's attention mask in ONE launch (counter-based hash: no generator
             # state, replay-safe); the per-row instance counts depend on the plan only (cached)
             cnt = _inst_counts(plan, NT, dev)
-            ms = torch.empty(2, NT, D, device=dev, dtype=torch.float32)
-            xcs = torch.empty_like(ms)
+            # (the mask tensor itself is written only for the tests' tap: the backward recomputes the masks from the hash)
+            ms = torch.empty(2, NT, D, device=dev, dtype=torch.float32) if DROP_TAP is not None else None
+            xcs = torch.empty(2, NT, D, device=dev, dtype=torch.float32)
             rm, xres = torch.empty(NT, D, device=dev), torch.empty(NT, D, device=dev)
             xcont = x.contiguous()
             mk, allm, na = None, None, 0
@@ -2609,7 +2610,7 @@ class HGATLayer(torch.autograd.Function):
                 lib.srec_hg_drop_prep(ptr(xcont), ptr(cnt), NT, D, float(pf), seed, rc, 101 + 2 * plan.layer_id, ptr(ms),
                                       ptr(xcs), ptr(rm), ptr(xres), float(pa), na, ptr(allm), stream())
             xc = [xcs[0], xcs[1]]
-            dstate = (xc, xres, rm, mk, ms)
+            dstate = (xc, xres, rm, mk, ms, (float(pf), seed, rc, 101 + 2 * plan.layer_id))
             if DROP_TAP is not None:
                 DROP_TAP.append(dict(ms=ms.clone(), mk=[m.clone() for m in mk] if mk is not None else None))
         xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
@@ -2739,7 +2740,8 @@ class HGATLayer(torch.autograd.Function):
             pend = [(pr, b) for pr, b in pend if not any(pr is q for q in batch)]
             gemm16('nt', batch, HD, HD, D, beta=beta)
         if dstate is not None:
-            lib.srec_hg_drop_merge(ptr(tgts), S, ptr(dstate[4]), NT * D, ptr(dx), stream())
+            pf_, seed_, rc_, salt_ = dstate[5]
+            lib.srec_hg_drop_merge(ptr(tgts), S, ptr(dstate[4]), NT * D, ptr(dx), pf_, seed_, rc_, salt_, stream())
         if ctx.g16 is not None:
             # weight gradients, one balanced problem per (module, node type): a module that spans several types (the shared
             # 'inter' one) writes one slab per type, summed in fixed order afterwards

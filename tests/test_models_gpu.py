@@ -468,8 +468,24 @@ def test_msgifsr_dropout_path_matches_oracle_with_replayed_masks(dev, name):
                 close(g, rp[k_].grad, rtol=1e-4, atol=1e-7, what='grad ' + k_)
             elif rp[k_].grad is not None:
                 grad_close(p_, rp[k_].grad, 'grad ' + k_)
+        # the product path keeps no mask tensor (no tap): the backward recomputes the feature masks from the counter-based hash -
+        # same seed, same device counter: the gradients of the tapped run, bit for bit
+        tapped = {k_: (model.table_grad.buf if k_ == 'embeddings.weight' else p_.grad).detach().clone()
+                  for k_, p_ in model.named_parameters() if k_ == 'embeddings.weight' or p_.grad is not None}
+        ops.DROP_TAP = None
+        model.zero_grad(set_to_none=True)
+        if getattr(model, 'table_grad', None) is not None:
+            model.table_grad.reset()
+        reseed(21)
+        loss2 = model.fused_loss(mg, labels)
+        loss2.backward()
+        assert loss2.item() == loss.item()
+        for k_, p_ in model.named_parameters():
+            if k_ in tapped:
+                g = model.table_grad.buf if k_ == 'embeddings.weight' else p_.grad
+                assert torch.equal(g, tapped[k_]), 'recomputed masks: grad ' + k_
         # log-probabilities of forward() under a second set of masks
-        ops.DROP_TAP.clear()
+        ops.DROP_TAP = []
         with torch.no_grad():
             logp = model(mg)
             rlogp = ref(og, oracle_masks(ops.DROP_TAP[0]))
