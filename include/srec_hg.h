@@ -72,6 +72,12 @@ typedef struct {
      * written by srec_hg_fwd (msgifsr.py:86-89 segment_mean + broadcast), read again by srec_hg_bwd */
     float* smean[SREC_HG_MAXT];
     int* sess;
+    /* feature dropout without a stored rm (rm == NULL, rm_cnt != NULL): srec_hg_bwd recomputes rm[row, c] = cnt[0][row] m0 +
+     * cnt[1][row] m1 from the masks' hash - cnt [2, NT] and (p, seed, counter, salt) as given to srec_hg_drop_prep */
+    const float* rm_cnt;
+    const int* rm_counter;
+    float rm_p;
+    int rm_seed, rm_salt;
 } srec_hg_desc;
 
 /* problem table of srec_gemm_group_bf16 (srec.h) */

@@ -678,7 +678,8 @@ struct PreArgs {
     int nt, B, D;
     const int* dynB;
     const float* g; int ld_g;
-    const float* rm;                    // [NT, D] per-element residual scale (feature dropout); NULL -> n_inst
+    const float* rm;                    // [NT, D] per-element residual scale (feature dropout); NULL -> n_inst, or recomputed:
+    const float* rm_cnt; float rm_p; srec_rng rm_rng;    // rm_cnt [2, NT] != NULL: rm = cnt0 m0 + cnt1 m1 from the masks' hash
     float* dx; int ld_dx;
     const int* sess;                    // session of every stacked row (written by the forward's hg_dots launch)
 };
@@ -712,7 +713,19 @@ __global__ void hg_pre_kernel(PreArgs a) {
         const float inv = 1.f / (float)(s1 - s0 > 0 ? s1 - s0 : 1), nres = (float)a.ninst[t];
         const float4 gv = *reinterpret_cast<const float4*>(a.g + (size_t)row * a.ld_g + c);
         float4 rs = make_float4(nres, nres, nres, nres);
-        if (a.rm != nullptr) rs = *reinterpret_cast<const float4*>(a.rm + (size_t)row * a.D + c);
+        if (a.rm != nullptr) {
+            rs = *reinterpret_cast<const float4*>(a.rm + (size_t)row * a.D + c);
+        } else if (a.rm_cnt != nullptr) {
+            const int NT = a.row0[a.nt];
+            const float c0 = a.rm_cnt[row], c1 = a.rm_cnt[NT + row];
+            const unsigned key = srec_rng_key(a.rm_rng);
+            const float p = a.rm_p, sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+            const unsigned i0 = (unsigned)row * (unsigned)a.D + (unsigned)c, i1 = (unsigned)NT * (unsigned)a.D + i0;
+            rs.x = c0 * srec_keep(key, i0, p, sc) + c1 * srec_keep(key, i1, p, sc);
+            rs.y = c0 * srec_keep(key, i0 + 1, p, sc) + c1 * srec_keep(key, i1 + 1, p, sc);
+            rs.z = c0 * srec_keep(key, i0 + 2, p, sc) + c1 * srec_keep(key, i1 + 2, p, sc);
+            rs.w = c0 * srec_keep(key, i0 + 3, p, sc) + c1 * srec_keep(key, i1 + 3, p, sc);
+        }
         o.x = o.x * inv + rs.x * gv.x; o.y = o.y * inv + rs.y * gv.y;
         o.z = o.z * inv + rs.z * gv.z; o.w = o.w * inv + rs.w * gv.w;
     }
@@ -1621,6 +1634,7 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
     {
         PreArgs a{};
         a.nt = d->n_types; a.B = d->B; a.D = D; a.dynB = d->dynB; a.g = g; a.ld_g = ld_g; a.dx = dx; a.ld_dx = ld_dx; a.rm = d->rm;
+        a.rm_cnt = d->rm_cnt; a.rm_p = d->rm_p; a.rm_rng = srec_rng{(unsigned)d->rm_seed, d->rm_counter, (unsigned)d->rm_salt, d->rm_p};
         a.sess = d->sess;
         if (d->sess == nullptr) return SREC_BAD_ARG;
         for (int t = 0; t < d->n_types; ++t) {
@@ -1802,7 +1816,7 @@ __global__ void hg_drop_prep_kernel(const float* __restrict__ x, const float* __
         *reinterpret_cast<uint2*>(xc16 + n + i) = make_uint2(srec_pack_bf16(x1.x, x1.y), srec_pack_bf16(x1.z, x1.w));
     }
     const float4 r = make_float4(c0 * m0.x + c1 * m1.x, c0 * m0.y + c1 * m1.y, c0 * m0.z + c1 * m1.z, c0 * m0.w + c1 * m1.w);
-    *reinterpret_cast<float4*>(rm + i) = r;
+    if (rm != nullptr) *reinterpret_cast<float4*>(rm + i) = r;    // (nullable: srec_hg_bwd recomputes it, srec_hg_desc.rm_cnt)
     *reinterpret_cast<float4*>(xres + i) = make_float4(xv.x * r.x, xv.y * r.y, xv.z * r.z, xv.w * r.w);
 }
 

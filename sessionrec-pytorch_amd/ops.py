@@ -2370,7 +2370,9 @@ class HgDesc(_ct.Structure):
                 [(n, _ct.c_void_p * 16) for n in ('eL', 'eR', 'wL', 'wR')] +
                 [(n, _ct.c_int * 16) for n in ('inst_mod', 'inst_sblk', 'inst_dblk')] +
                 [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der', 'Mk')] +
-                [('smean', _ct.c_void_p * 4), ('sess', _ct.c_void_p)])
+                [('smean', _ct.c_void_p * 4), ('sess', _ct.c_void_p)] +
+                [('rm_cnt', _ct.c_void_p), ('rm_counter', _ct.c_void_p), ('rm_p', _ct.c_float), ('rm_seed', _ct.c_int),
+                 ('rm_salt', _ct.c_int)])
 
 
 class GemmGroup(_ct.Structure):
@@ -2504,6 +2506,9 @@ class HgPlan:
             for m in range(len(self.modules)):
                 d.xin[m] = ptr(xc[self.mod_conv[m]])
             d.xres, d.rm = ptr(xres), ptr(rm)
+            if rm is None and len(drop) > 6:               # rm recomputed in the backward from the masks' hash
+                pf_, seed_, rc_, salt_ = drop[5]
+                d.rm_cnt, d.rm_counter, d.rm_p, d.rm_seed, d.rm_salt = ptr(drop[6]), rc_, pf_, seed_, salt_
             for i in range(len(self.insts)):
                 d.Mk[i] = ptr(mk[i]) if mk is not None else None
         d.H, d.D, d.slope, d.B = self.H, self.D, self.slope, self.B
@@ -2591,7 +2596,7 @@ class HGATLayer(torch.autograd.Function):
             # (the mask tensor itself is written only for the tests' tap: the backward recomputes the masks from the hash)
             ms = torch.empty(2, NT, D, device=dev, dtype=torch.float32) if DROP_TAP is not None else None
             xcs = torch.empty(2, NT, D, device=dev, dtype=torch.float32)
-            rm, xres = torch.empty(NT, D, device=dev), torch.empty(NT, D, device=dev)
+            rm, xres = None, torch.empty(NT, D, device=dev)     # (rm = cnt0 m0 + cnt1 m1 is recomputed by the backward)
             xcont = x.contiguous()
             mk, allm, na = None, None, 0
             if pa > 0:
@@ -2610,7 +2615,7 @@ class HGATLayer(torch.autograd.Function):
                 lib.srec_hg_drop_prep(ptr(xcont), ptr(cnt), NT, D, float(pf), seed, rc, 101 + 2 * plan.layer_id, ptr(ms),
                                       ptr(xcs), ptr(rm), ptr(xres), float(pa), na, ptr(allm), stream())
             xc = [xcs[0], xcs[1]]
-            dstate = (xc, xres, rm, mk, ms, (float(pf), seed, rc, 101 + 2 * plan.layer_id))
+            dstate = (xc, xres, rm, mk, ms, (float(pf), seed, rc, 101 + 2 * plan.layer_id), cnt)
             if DROP_TAP is not None:
                 DROP_TAP.append(dict(ms=ms.clone(), mk=[m.clone() for m in mk] if mk is not None else None))
         xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
