@@ -330,10 +330,10 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
         probe.update(precollated_ms_per_step=t_all / 256 * 1e3, precollated_host_issue_ms_per_step=t_host / 256 * 1e3)
         gs = runner._gstep
         if gs is not None:
-            # what separates a fed step from the bare replay loop: (a) replay only, (b) + the device-to-device copy into the
-            # static buffer, (c) + an event wait on another stream, (d) fed from pinned host batches (= precollated above)
+            # what separates a step fed from the host from the replay of device-resident batches at the launcher's capacities:
+            # (a) batches already on the device (mailbox entry -> the batch itself), (b) page-locked host batches (side-stream
+            # copy + host-side wait + replay = the precollated figure above)
             dev_held = [([x.to(dev) for x in b[0]], b[1].to(dev)) for b in held[:8]]
-            side, legs = torch.cuda.Stream(), {}
 
             def timed(fn, n=512):
                 for _ in range(2):
@@ -341,27 +341,12 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
                     t = time.perf_counter()
                     for i in range(n):
                         fn(i)
+                    t_issue = (time.perf_counter() - t) / n * 1e3
                     torch.cuda.synchronize()
                     dt_ = (time.perf_counter() - t) / n * 1e3
-                return dt_
-
-            def replay_only(i):
-                gs.opt.advance(gs.work)
-                gs.graph.replay()
-
-            def with_d2d(i):
-                gs(*dev_held[i % len(dev_held)])
-
-            def with_event(i):
-                ev = torch.cuda.Event()
-                ev.record(side)
-                torch.cuda.current_stream().wait_event(ev)
-                gs.opt.advance(gs.work)
-                gs.graph.replay()
-            legs['replay_only'] = timed(replay_only)
-            legs['replay_plus_d2d_copy'] = timed(with_d2d)
-            legs['replay_plus_event_wait'] = timed(with_event)
-            probe['gap_ms_per_step'] = legs
+                return dt_, t_issue
+            on_dev = timed(lambda i: gs(*dev_held[i % len(dev_held)]))
+            probe['gap_ms_per_step'] = dict(replay_device_batches=on_dev[0], host_issue_device_batches=on_dev[1])
     del it
     if hasattr(loader, 'close'):
         loader.close()
