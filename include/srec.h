@@ -326,18 +326,6 @@ int srec_adam_rows_proj(float* W, const float* G, float* M, float* V, int n, int
  *        d_attn_l / d_attn_r / d_bias of every module.  ws: srec_hg_ws_floats() floats of scratch. */
 int srec_hg_ws_floats(const void* desc, long* n_floats);
 int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg, void* stream);
-/* the first two launches of srec_hg_fwd alone: attention vectors folded into fc (V, summed bias rows), attention logits eL / eR
- * of every projection block, session means and the row -> session map (gatconv.py:284-297 without the projections) */
-int srec_hg_logits(const void* desc, const float* x, int ld_x, void* stream);
-/* ---- the same layer per ROW WINDOW, without [N, H D] projections in memory (csrc/hgwin.hip; H = 8, D = 128 / 256, bf16 mode):
- * aggregate first (Y[v,h,:] = sum_e a_eh x_u on the 8 x narrower input rows, LDS resident), then project (W_h Y[v,h,:], weights
- * streamed fragment-major from L2), head max in registers.  srec_hg_wfrag: n <= 8 fc weights W_i [H D, D] fp32 (HOST arrays of
- * device pointers) -> F_i [H D D] bf16 (forward operand) and T_i (backward-data operand), either array nullable.
- * srec_hg_win_fwd: desc as srec_hg_fwd with x16 / Wf filled (P is not read); force_slow != 0 takes the general edge path
- * (tests).  Replaces msgifsr.py:70-89 + gatconv.py:267-311 as srec_hg_fwd does. */
-int srec_hg_wfrag(int n, const void* W, const void* F, const void* T, int H, int D, void* stream);
-int srec_hg_win_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg, int force_slow,
-                    void* stream);
 /* feature-dropout glue of a layer call in one pass each (GATConv feat_drop, gatconv.py:268-283): masks from the counter-based
  * hash of srec_gather_rows_drop (one mask per conv) and cnt [2, rows] (relation instances of the conv into each row): ms = mask / (1-p),
  * xc = x * ms (the convs' dropped inputs), rm = cnt0 ms0 + cnt1 ms1, xres = x * rm (summed identity residuals);

@@ -78,14 +78,7 @@ typedef struct {
     const int* rm_counter;
     float rm_p;
     int rm_seed, rm_salt;
-    /* row-window kernels (csrc/hgwin.hip; srec_hg_win_fwd / srec_hg_win_bwd): x16[m] = bf16 copy [NT, D] of the input rows module m
-     * projects (x, or the conv's feature-dropped rows), Wf[m] / WTf[m] = fragment-major bf16 copies of fc.weight (srec_hg_wfrag) */
-    const void* x16[SREC_HG_MAXM];
-    const void* Wf[SREC_HG_MAXM];
-    const void* WTf[SREC_HG_MAXM];
 } srec_hg_desc;
-
-#define SREC_HGWIN_ROWS 64         /* destination rows per workgroup window of the srec_hg_win_* kernels */
 
 /* problem table of srec_gemm_group_bf16 (srec.h) */
 #define SREC_GG_MAXP 8

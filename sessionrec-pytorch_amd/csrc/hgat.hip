@@ -1533,11 +1533,13 @@ extern "C" int srec_hg_ws_floats(const void* desc_, long* n_floats) {
     return 0;
 }
 
-extern "C" int srec_hg_logits(const void* desc_, const float* x, int ld_x, void* stream) {
+extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg,
+                           void* stream) {
     const srec_hg_desc* d = (const srec_hg_desc*)desc_;
     if (bad_desc(d) || (ld_x & 3)) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int H = d->H, D = d->D;
+    const int H = d->H, D = d->D, HD = H * D;
+    const size_t esz = (d->p16 & 1) ? 2 : 4;
     if (d->n_mods > 0) {
         FoldArgs f{};
         f.H = H; f.D = D;
@@ -1578,18 +1580,6 @@ extern "C" int srec_hg_logits(const void* desc_, const float* x, int ld_x, void*
         blocks += d->n_types * d->B;
         if (blocks > 0) hipLaunchKernelGGL(hg_dots_kernel, dim3(blocks), dim3(256), (size_t)(16 * (D + 4) + 16) * 4, st, a);
     }
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg,
-                           void* stream) {
-    const srec_hg_desc* d = (const srec_hg_desc*)desc_;
-    if (bad_desc(d) || (ld_x & 3)) return SREC_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int H = d->H, D = d->D, HD = H * D;
-    const size_t esz = (d->p16 & 1) ? 2 : 4;
-    if (int rc = srec_hg_logits(desc_, x, ld_x, stream)) return rc;
     AggArgs g{};
     g.nt = d->n_types; g.B = d->B; g.dynB = d->dynB; g.H = H; g.D = D; g.slope = d->slope;
     g.x = x; g.ld_x = ld_x; g.out = out; g.ld_out = ld_out; g.arg = arg; g.xres = d->xres; g.sess = d->sess;

@@ -2372,8 +2372,7 @@ class HgDesc(_ct.Structure):
                 [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der', 'Mk')] +
                 [('smean', _ct.c_void_p * 4), ('sess', _ct.c_void_p)] +
                 [('rm_cnt', _ct.c_void_p), ('rm_counter', _ct.c_void_p), ('rm_p', _ct.c_float), ('rm_seed', _ct.c_int),
-                 ('rm_salt', _ct.c_int)] +
-                [(n, _ct.c_void_p * 8) for n in ('x16', 'Wf', 'WTf')])
+                 ('rm_salt', _ct.c_int)])
 
 
 class GemmGroup(_ct.Structure):
@@ -2569,39 +2568,6 @@ def _inst_counts(plan, NT, dev):
     return cnt
 
 
-# row-window kernels of the layer (csrc/hgwin.hip): 'off' = the batched formulation with projections in HBM; 'fwd' = forward
-# through srec_hg_win_fwd (the projections are still written when a backward will need them)
-HG_WIN = {'mode': 'off', 'force_slow': 0}
-
-
-def hg_win_ok(plan, D, params):
-    """bf16 mode, 8 heads, d = 128 / 256, at most 4 GAT modules (of at most 4 relation instances each) into any node type"""
-    nm = len(plan.modules)
-    if PRECISION['matmul'] != 'bf16' or plan.H != 8 or D not in (128, 256) or nm > 8:
-        return False
-    if not all(params[4 * m].is_contiguous() for m in range(nm)):
-        return False
-    slots = {}
-    for (m, sb, db, gr) in plan.insts:
-        t = plan.blocks[db][1]
-        slots.setdefault(t, {}).setdefault(m, 0)
-        slots[t][m] += 1
-    return all(len(v) <= 4 and max(v.values()) <= 4 for v in slots.values())
-
-
-def hg_wfrag(ws, H, D, fwd=True, bwd=False):
-    """fragment-major bf16 copies of the fc weights [H D, D] (srec_hg_wfrag): -> (F [n, H D D] or None, T or None)"""
-    n, dev = len(ws), ws[0].device
-    F = torch.empty(n, H * D * D, device=dev, dtype=torch.bfloat16) if fwd else None
-    T = torch.empty(n, H * D * D, device=dev, dtype=torch.bfloat16) if bwd else None
-    arr = _ct.c_void_p * n
-    a_w = arr(*[w.data_ptr() for w in ws])
-    a_f = arr(*[F[i].data_ptr() for i in range(n)]) if fwd else None
-    a_t = arr(*[T[i].data_ptr() for i in range(n)]) if bwd else None
-    lib.srec_hg_wfrag(n, _ct.addressof(a_w), _ct.addressof(a_f) if fwd else None, _ct.addressof(a_t) if bwd else None, H, D, stream())
-    return F, T
-
-
 DROP_TAP = None      # tests: set to a list to receive {'ms': [2, NT, D], 'mk': [per instance (E*H,)]} of every dropout layer call
 
 
@@ -2654,16 +2620,11 @@ class HGATLayer(torch.autograd.Function):
                 DROP_TAP.append(dict(ms=ms.clone(), mk=[m.clone() for m in mk] if mk is not None else None))
         xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
         grouped = PRECISION['matmul'] == 'bf16' and D % 8 == 0 and _ld(x) == D and nm <= 8
-        win = HG_WIN['mode'] != 'off' and grouped and hg_win_ok(plan, D, params)
-        need_P = not win or getattr(plan, 'need_grad', True)
         # bf16 GEMM path: the projections (and their gradients) are STORED as bf16 too - every pass over them is HBM bound
-        P = [torch.empty(nr if need_P else 1, HD, device=dev, dtype=torch.bfloat16 if grouped else torch.float32)
+        P = [torch.empty(nr, HD, device=dev, dtype=torch.bfloat16 if grouped else torch.float32)
              for (r0, nr, dyn) in plan.modules]
         g16 = None
-        if win and not need_P:
-            x16 = (x16_pre if x16_pre is not None else rows_bf16(xcs.view(2 * NT, D)).view(2, NT, D)) if dstate is not None else rows_bf16(x)
-            g16 = (x16, None)
-        elif grouped and D % 64 == 0 and all(params[4 * m].is_contiguous() for m in range(nm)):
+        if grouped and D % 64 == 0 and all(params[4 * m].is_contiguous() for m in range(nm)):
             # every GEMM operand as bf16 in HBM (csrc/gemm16.hip): the small weights once per call (+ transposed copies for
             # the backward-data product), the module inputs in one pass
             w16, wt16 = weights_bf16([params[4 * m] for m in range(nm)])
@@ -2692,15 +2653,7 @@ class HGATLayer(torch.autograd.Function):
         arg = torch.empty(NT, D, device=dev, dtype=torch.uint8)
         flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
         desc = plan.fill(HgDesc(), small, lay, P, None, flat, None, dstate)
-        if win:
-            x16 = g16[0]
-            Wf, _ = hg_wfrag([params[4 * m] for m in range(nm)], H, D)
-            for m in range(nm):
-                desc.x16[m] = (x16[plan.mod_conv[m]] if dstate is not None else x16).data_ptr()
-                desc.Wf[m] = Wf[m].data_ptr()
-            lib.srec_hg_win_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), int(HG_WIN['force_slow']), stream())
-        else:
-            lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
+        lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
         ctx.save_for_backward(x, small, arg, *P, *params)
         ctx.plan, ctx.lay, ctx.grouped, ctx.dstate, ctx.g16 = plan, lay, grouped, dstate, g16
         ctx.defer, ctx.wparams = defer_scope(), [params[4 * m] for m in range(len(plan.modules))]
@@ -2833,5 +2786,4 @@ class HGATLayer(torch.autograd.Function):
 
 
 def hgat_layer(x, plan, params, drop=None):
-    plan.need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
     return HGATLayer.apply(x, plan, drop, *params)
