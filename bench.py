@@ -308,6 +308,8 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
         pending.append(runner._loss_handle(loss))
         if len(pending) >= 256:
             ring = runner._gstep.loss_ring.tolist() if any(isinstance(v, int) for v in pending) else None
+            if ring is not None:
+                runner._gstep.check()
             vals = [ring[v % len(ring)] if isinstance(v, int) else float(v) for v in pending]
             assert all(v == v for v in vals), 'loss is NaN'
             pending.clear()
@@ -315,6 +317,8 @@ def end_to_end(args, sp, state, V, d, B, dev, n_batches=600, warm=16, workers=4)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     final = float(loss.item())
+    if getattr(runner, '_gstep', None) is not None:
+        runner._gstep.check()                             # no replay of the loop ran on a stale batch
     # (the loader counts cumulative seconds under keys ending in _s: reported here as milliseconds per step, keys renamed)
     waits = {(k[:-2] if k.endswith('_s') else k): round((v - w0[k]) / max(n, 1) * 1e3, 4) for k, v in getattr(loader, 'stats', {}).items()}
     if probe is not None:

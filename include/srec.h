@@ -291,9 +291,11 @@ int srec_adam_hyper(int* counter, const void* cfg, float* hyper, void* stream);
 /* ... for n <= 16 (counter, cfg, hyper) slots in one launch; the three arguments are HOST arrays of n device pointers.
  * Loss tap (tap_ring nullable): the slot whose counter is tap_counter stores *tap_src - the step's loss, train.py:99-104
  * reads it after every step - into tap_ring[(steps taken before this one) % tap_n], so that a replayed step's loss survives
- * the next replay without a copy command between two graph launches. */
+ * the next replay without a copy command between two graph launches.  skip (nullable, device int32: the err flag of
+ * srec_copy_words_mailbox): non-zero = this step ran on a stale batch - the counters advance, the scalars written make every
+ * Adam kernel of the step the identity (parameters and moments keep their bits), the loss slot reads NaN. */
 int srec_adam_hyper_multi(int n, const void* counter, const void* cfg, const void* hyper, const int* tap_counter,
-                          const float* tap_src, float* tap_ring, int tap_n, void* stream);
+                          const float* tap_src, float* tap_ring, int tap_n, const int* skip, void* stream);
 /* one launch for many small tensors (48 per launch): desc = HOST srec_adam_multi_desc below; the pointers travel by
  * value in the kernel arguments (nothing staged in device memory; a captured hipGraph bakes them into the node) */
 typedef struct srec_adam_multi_desc {

@@ -739,8 +739,14 @@ extern "C" int srec_head_bwd(const void* desc, void* stream) {
     const int D = q->d;
     const size_t lds = (size_t)(2 * HS * D) * 2 + (size_t)(HS * (D + 8) + HS * D + 3 * (HR + MAXN)) * 4 + (size_t)(HS + 1 + 2 + q->B + 1) * 4;
     const dim3 grid((q->NT + HR - 1) / HR, q->nh);
-    if (D == 256) hipLaunchKernelGGL(head_bwd_kernel<2>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(head_bwd_kernel<1>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
+    static std::atomic<unsigned long long> omb[2];        // (B-dependent dynamic LDS: above 64 KiB it needs the per-device opt-in)
+    if (D == 256) {
+        if (int rc = srec_lds_optin((const void*)head_bwd_kernel<2>, (int)lds, omb[0])) return rc;
+        hipLaunchKernelGGL(head_bwd_kernel<2>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
+    } else {
+        if (int rc = srec_lds_optin((const void*)head_bwd_kernel<1>, (int)lds, omb[1])) return rc;
+        hipLaunchKernelGGL(head_bwd_kernel<1>, grid, dim3(64 * NW), lds, (hipStream_t)stream, a);
+    }
     SREC_LAUNCH_CHECK();
     return 0;
 }

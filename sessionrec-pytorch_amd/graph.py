@@ -83,7 +83,6 @@ class GraphedTrainStep:
         except TypeError:
             self.graph = torch.cuda.CUDAGraph()
         self.loss_ring, self.last_T = None, None
-        optimizer.loss_tap = None
         self._pending_advance = None
         self._setup_mailbox(optimizer, labels.device)
         if self._mb is not None:                         # (allocated outside the capture: not part of the replayed step)
@@ -102,16 +101,22 @@ class GraphedTrainStep:
                         self.after_backward()
                     work = optimizer._work()
                     optimizer._frozen = work
-                    if self._mb is not None:
-                        # every replay leaves its loss in slot (step count % LOSS_RING) of a device ring (written by the
-                        # optimizer's step-scalar kernel): the caller reads losses in bulk, when it wants them, instead of
-                        # cloning the static loss tensor between two graph launches (train.py:99-104 reads it every step)
-                        optimizer.loss_tap = (self.loss.detach(), self.loss_ring)
+                    # every replay leaves its loss in slot (step count % LOSS_RING) of a device ring (written by the
+                    # optimizer's step-scalar kernel): the caller reads losses in bulk, when it wants them, instead of
+                    # cloning the static loss tensor between two graph launches (train.py:99-104 reads it every step).
+                    # The tap and the intake's fault flag are arguments of THIS launch only: nothing of a graph stays behind
+                    # in the optimizer (an eager step after a refused capture would write into a dead graph's tensors)
+                    tap = (self.loss.detach(), self.loss_ring) if self._mb is not None else None
+                    skip = self._mb['err'] if self._mb is not None else None
                     # the step counters that matter live on the device and are advanced by the captured step itself; the
                     # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
                     # capture and take it back afterwards
                     optimizer.advance(work)
-                    optimizer.launch(work)
+                    optimizer.launch(work, tap=tap, skip=skip)
+                    if self._mb is not None and (0, 0) not in getattr(optimizer, '_used_keys', ()):
+                        # the mailbox and the loss ring are keyed by the (group 0, offset 0) step counter: a step that does
+                        # not advance it would look at entry 0 for ever
+                        raise RuntimeError('captured step does not advance the optimizer step counter the batch mailbox is keyed by')
                 except BaseException as e:               # leave the capture context normally and raise afterwards: the undo
                     err = e                              # below must not run while the stream is still capturing
                     if os.environ.get('SREC_DEBUG_CAPTURE'):
@@ -146,13 +151,23 @@ class GraphedTrainStep:
         copy + the gap behind it cost ~12 us per step).  Needs FusedAdam's device counter and 16-byte granular buffers."""
         self._mb = None
         ent = getattr(optimizer, '_hyper', {}).get((0, 0)) if isinstance(getattr(optimizer, '_hyper', None), dict) else None
-        if ent is None or any(x.buf.numel() % 4 for x in self.static_inputs):
+        # (the eager warm-up has just run the step: _used_keys says which counters a step of this model advances)
+        if ent is None or (0, 0) not in getattr(optimizer, '_used_keys', ()) or any(x.buf.numel() % 4 for x in self.static_inputs):
             return
         n = len(self.static_inputs)
         box = torch.zeros(n, _MAILBOX, 4, dtype=torch.int32).pin_memory()
         box[:, :, 3] = -1                                  # (no entry carries a valid counter value yet)
         self._mb = dict(box=box, np=box.numpy(), counter=ent['counter'], err=torch.zeros(1, dtype=torch.int32, device=device),
                         events=[], held=[], calls=0)
+
+    def check(self):
+        """raise if a replayed step found another step count in its mailbox entry than the host wrote (the step, and every
+        step after it, then ran on a stale batch and changed NOTHING: the optimizer's step-scalar kernel turns such a step
+        into the identity, csrc/adam.hip).  One 4-byte readback: called wherever the host synchronises anyway (TrainRunner's
+        loss flush, end of an epoch, the end of bench.py's loops), and every 512th replay."""
+        if self._mb is not None and int(self._mb['err'].item()):
+            raise RuntimeError('a replayed step found another step count in its batch mailbox than the host wrote: that step and '
+                               'every later one were skipped (parameters and optimizer state are those before it)')
 
     def _capture_intake(self):
         if self._mb is None:
@@ -189,6 +204,8 @@ class GraphedTrainStep:
                 torch.cuda.current_stream().synchronize()    # (staging starts in the middle of a run: no mark yet)
             slot = stg['ring'][i][T % _STAGE_SLOTS]
             n = min(buf.numel(), slot.numel())
+            if buf.is_cuda:                                  # (a misaligned device batch: its producer may still be writing it)
+                stg['stream'].wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stg['stream']):
                 slot[:n].copy_(buf[:n], non_blocking=True)
                 ev = torch.cuda.Event()
@@ -197,11 +214,34 @@ class GraphedTrainStep:
             x.meta['_copied'] = ev                           # the host buffer may be rewritten (it already has been read)
             stg['used'] = True
             buf = slot
+        if i == 0:
+            self._mailbox_lap(T)
         a = buf.data_ptr()
         lo, hi = a & 0xffffffff, (a >> 32) & 0xffffffff
         self._mb['np'][i, T % _MAILBOX] = (lo - ((lo & 0x80000000) << 1), hi - ((hi & 0x80000000) << 1),
                                            min(buf.numel(), self.static_inputs[i].buf.numel()), T)
         return buf
+
+    def _mailbox_lap(self, T):
+        """entry T % _MAILBOX was read by replay T - _MAILBOX: that replay must have run before the host rewrites the entry.
+        Keyed by the STEP COUNT (eager steps between replays advance T without recording events): done_T = newest step known
+        complete; otherwise the oldest recorded event at or behind step T - _MAILBOX is waited for (normally long complete)."""
+        mb = self._mb
+        ev, need = mb['events'], T - _MAILBOX
+        if mb.get('last_T', -1) >= T:                        # the step counter went back (a restored checkpoint)
+            torch.cuda.current_stream().synchronize()
+            ev.clear()
+            mb['done_T'] = T - 1
+        elif need >= 0 and mb.get('done_T', -1) < need:
+            k = next((j for j, e in enumerate(ev) if e[2] >= need), None)
+            if k is not None:
+                ev[k][0].synchronize()
+                mb['done_T'] = ev[k][2]
+                del ev[:k + 1]
+            elif mb.get('last_T', -1) >= need:               # replays in reach without an event behind them
+                torch.cuda.current_stream().synchronize()
+                mb['done_T'] = T - 1
+        mb['last_T'] = T
 
     def node_counts(self):
         """{'kernel': n, 'memcpy': n, 'memset': n, 'other': n} of the captured step (hipGraphGetNodes on the raw hipGraph_t)
@@ -321,13 +361,11 @@ class GraphedTrainStep:
                 if staged:
                     stg['marks'].append((T, done))
                 ev = mb['events']
-                ev.append((done, mb['held']))
+                ev.append((done, mb['held'], T))
                 mb['held'] = []
-                limit = (_MAILBOX - 4) // 8
-                while ev and (len(ev) > limit or ev[0][0].query()):
-                    if not ev[0][0].query():
-                        ev[0][0].synchronize()
+                while ev and ev[0][0].query():
+                    mb['done_T'] = max(mb.get('done_T', -1), ev[0][2])
                     ev.pop(0)
-            if mb['calls'] % 512 == 0 and int(mb['err'].item()):
-                raise RuntimeError('a replayed step found another step count in its batch mailbox than the host wrote')
+            if mb['calls'] % 512 == 0:
+                self.check()
         return self.loss

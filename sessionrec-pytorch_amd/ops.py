@@ -1252,6 +1252,9 @@ class ReadoutHeadFused(torch.autograd.Function):
         return (g_allf, None, None, None, None, None) + tuple(t for gr in grads for t in gr)
 
 
+HEAD_FUSED_MAX_B = 8192      # session capacity of the fused read-out head kernels (csrc/headf.hip: srec_head_fwd / srec_head_bwd)
+
+
 def readout_head_fused_ok(allf, per_order):
     """the fused forward applies: bf16 mode, d = hidden = output in (128, 256), <= 4 heads, contiguous weights, every query
     tensor the tagged left half of a private [B, 2 d] buffer (norm_permute_pick / permute_and_pick)"""
@@ -1261,6 +1264,8 @@ def readout_head_fused_ok(allf, per_order):
     if D not in (128, 256) or allf.stride(1) != 1 or allf.stride(0) % 4:
         return False
     B = per_order[0][0].shape[0]
+    if B > HEAD_FUSED_MAX_B:              # srec_head_fwd / _bwd keep a copy of seg[] in LDS: larger batches take the grouped launches
+        return False
     for v, Wu, bu, Wv, we, Wsr in per_order:
         if not (getattr(v, '_srec_cat_left', False) and tuple(v.shape) == (B, D) and v.stride(0) == 2 * D and v.stride(1) == 1):
             return False

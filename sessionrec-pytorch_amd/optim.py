@@ -210,13 +210,17 @@ class FusedAdam(torch.optim.Optimizer):
                     ent['cfg_host'] = cfg
         return work
 
-    def launch(self, work):
-        """device work only (capturable): the step-scalar kernel + the Adam kernels"""
+    def launch(self, work, tap=None, skip=None):
+        """device work only (capturable): the step-scalar kernel + the Adam kernels.
+        tap = (loss scalar, ring): the step's loss goes to ring[(step count before it) % len] (graph.GraphedTrainStep's loss
+        ring; given per call, by the captured launch only - never optimizer state that outlives its graph);
+        skip = device int32: non-zero turns the whole step into the identity (srec_adam_hyper_multi; the batch-intake fault
+        flag of a captured step)."""
         table, tgrad, st = self._table_info()
         model = self.model
         T = getattr(self, '_T', 0)
         # step scalars of every (group, step offset) slot of this step: one launch
-        ents = []
+        ents, used = [], set()
         for gi, group, items in work:
             for off in sorted({T - state['step'] for _, _, state in items}):
                 ent = self._buffers(gi, off, items[0][0].device)
@@ -224,19 +228,20 @@ class FusedAdam(torch.optim.Optimizer):
                     ent['cfg'].copy_(torch.tensor(self._cfg(group), dtype=torch.float64))
                     ent['cfg_host'] = self._cfg(group)
                 ents.append(ent)
+                used.add((gi, off))
+        self._used_keys = used                                  # (group, step offset) slots this step advanced
         for i in range(0, len(ents), 16):
             chunk = ents[i:i + 16]
             n = len(chunk)
             arr = _ct.c_void_p * n
             cs, cf, hy = (arr(*[e[k].data_ptr() for e in chunk]) for k in ('counter', 'cfg', 'hyper'))
-            tap = getattr(self, 'loss_tap', None)           # (loss scalar, ring): graph.GraphedTrainStep's loss ring
             first = self._hyper.get((0, 0)) if isinstance(self._hyper, dict) else None
             if tap is not None and first is not None and any(e is first for e in chunk):
                 lib.srec_adam_hyper_multi(n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), ptr(first['counter']),
-                                          ptr(tap[0]), ptr(tap[1]), tap[1].numel(), stream())
+                                          ptr(tap[0]), ptr(tap[1]), tap[1].numel(), ptr(skip), stream())
             else:
                 lib.srec_adam_hyper_multi(n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), None, None, None, 0,
-                                          stream())
+                                          ptr(skip), stream())
         # small tensors of ALL groups that step together: groups which differ only in weight decay (fix_weight_decay: the
         # biases / norms are the same Adam with wd 0) share ONE multi-tensor launch - the kernel takes the decay per tensor
         merged = {}                          # (lr, betas, eps, slot) -> [gi of the hyper to use, wd of it, rows]

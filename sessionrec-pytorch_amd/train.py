@@ -174,6 +174,16 @@ class TrainRunner:
         rng = dict(torch=th.get_rng_state())
         if th.cuda.is_available() and th.device(self.device).type == 'cuda':
             rng['cuda'] = th.cuda.get_rng_state(self.device)
+        if self.fused:
+            # the private generators the run draws from: the dropout nonces of the HIP path (ops._nonce) and the samplers'
+            # shuffles (src/scripts/common.py: RandomSampler(generator=...)) - neither is part of torch's global state
+            from . import ops
+            if ops._NONCE['gen'] is not None:
+                rng['nonce'] = ops._NONCE['gen'].get_state()
+                rng['nonce_seed'] = int(ops._NONCE['seed'])
+        gens = self._loader_generators()
+        if gens:
+            rng['samplers'] = [g.get_state() for g in gens]
         return dict(model=self.model.state_dict(), optimizer=self.optimizer.state_dict(),
                     scheduler=self.scheduler.state_dict(), epoch=self.epoch, batch=self.batch, best=list(self.best),
                     rng=rng)
@@ -188,11 +198,33 @@ class TrainRunner:
             th.set_rng_state(rng['torch'].cpu())
         if 'cuda' in rng and th.cuda.is_available() and th.device(self.device).type == 'cuda':
             th.cuda.set_rng_state(rng['cuda'].cpu(), self.device)
+        if 'nonce' in rng and self.fused:
+            from . import ops
+            ops.seed_dropout()
+            ops._NONCE['gen'].set_state(rng['nonce'].cpu())
+            ops._NONCE['seed'] = th.initial_seed()          # (keyed by the seed in effect now: no implicit restart at the next draw)
+        for g, st in zip(self._loader_generators(), rng.get('samplers') or []):
+            g.set_state(st.cpu())
         self._gstep = None                 # optimizer state tensors were replaced: a captured step would use stale ones
         if self.fused:
             from . import ops
             ops.weights_changed()          # cached bf16 copies / column scales belong to the old weights
             self.model.__dict__.pop('_srec_state', None)
+
+    def _loader_generators(self):
+        """the torch.Generators that shuffle the training loader (sampler / batch sampler and what they wrap), in a fixed order"""
+        out, seen, todo = [], set(), [self.train_loader]
+        while todo:
+            o = todo.pop(0)
+            if o is None or id(o) in seen:
+                continue
+            seen.add(id(o))
+            g = getattr(o, 'generator', None)
+            if isinstance(g, th.Generator) and all(g is not h for h in out):
+                out.append(g)
+            for name in ('sampler', 'batch_sampler', 'base', 'base_sampler'):
+                todo.append(getattr(o, name, None))
+        return out
 
     def _ckpt_path(self, path=None):
         """with a row-sharded table every rank owns different rows (and Adam moments): one file per rank"""
@@ -240,6 +272,7 @@ class TrainRunner:
                     ring = None
                     if any(isinstance(v, int) for v in pending):                # replayed steps: slots of the device loss ring
                         ring = self._gstep.loss_ring.tolist()
+                        self._gstep.check()                 # (the host is synchronised here anyway: batch-intake fault flag)
                     eager = [v for v in pending if not isinstance(v, int)]
                     eager = iter(th.stack(eager).tolist()) if eager else iter(())
                     for v in pending:
@@ -262,6 +295,8 @@ class TrainRunner:
                     mean_loss = 0
                 self.batch += 1
             flush()
+            if self._gstep is not None:
+                self._gstep.check()            # end of the epoch: also a run / tail shorter than a flush interval is checked
             self.scheduler.step()
             mrr, hit = evaluate(self.model, self.test_loader, self.device)
             self._print(f'Epoch {self.epoch}: MRR = {mrr * 100:.3f}%, Hit = {hit * 100:.3f}%')

@@ -209,3 +209,57 @@ def test_mailbox_intake_from_device_pinned_and_pageable_batches(dev, kind):
     for k_ in finals[0]:
         assert torch.equal(finals[0][k_], finals[1][k_]), k_
     assert losses[0] == losses[1] and len(losses[0]) == 200
+
+
+@pytest.mark.parametrize('kind', ['niser', 'msgifsr'])
+def test_mailbox_fault_is_contained(dev, kind):
+    """A replay whose mailbox entry does not carry the device's step count (here: the host's entry is corrupted after it was
+    posted) must not train on whatever batch is in the static buffer: the intake kernel raises the fault flag, the optimizer's
+    step-scalar kernel turns the step - and every later one - into the identity (parameters AND Adam moments keep their bits),
+    and the host raises at its next readback: GraphedTrainStep.check(), which TrainRunner calls at every loss flush and at
+    the end of an epoch, also for a run shorter than any polling interval."""
+    c, train, G = pkg('collate'), pkg('train'), pkg('graph')
+    rng = np.random.default_rng(4)
+    V = 400
+    caps = c.default_caps(32, 12)
+    torch.manual_seed(0)
+    model, mk = _setup(kind, dev, V)
+    batches = [[x.to(dev) for x in xs] + [lab.to(dev)] for xs, lab in (mk(caps)(_samples(rng, 32, V)) for _ in range(12))]
+    runner = train.TrainRunner('x', model, [], None, dev, lr=1e-2, weight_decay=1e-4)
+    model.train()
+    for k in range(6):
+        runner.train_step(batches[k][:-1], batches[k][-1])
+    torch.cuda.synchronize()
+    gs = runner._gstep
+    assert gs is not None and gs._mb is not None and runner.graph_steps == 6
+    gs.check()                                                   # clean so far
+    before = {k_: v.detach().clone() for k_, v in model.state_dict().items()}
+    mom = {id(p): (st['exp_avg'].clone(), st['exp_avg_sq'].clone()) for p, st in runner.optimizer.state.items() if 'exp_avg' in st}
+    # the next replay's entry gets a wrong expected count the moment before the graph is launched
+    orig_replay = gs.graph.replay
+    T = runner.optimizer._T
+
+    def corrupt_then_replay():
+        gs._mb['np'][0, T % G._MAILBOX, 3] = T + 1000
+        orig_replay()
+    gs.graph.replay = corrupt_then_replay
+    runner.train_step(batches[6][:-1], batches[6][-1])
+    gs.graph.replay = orig_replay
+    for k in range(7, 10):                                       # later replays find correct entries - and stay skipped
+        runner.train_step(batches[k][:-1], batches[k][-1])
+    torch.cuda.synchronize()
+    after = model.state_dict()
+    for k_ in before:
+        assert torch.equal(before[k_], after[k_]), k_
+    for p, st in runner.optimizer.state.items():
+        if id(p) in mom:
+            assert torch.equal(st['exp_avg'], mom[id(p)][0]) and torch.equal(st['exp_avg_sq'], mom[id(p)][1])
+    with pytest.raises(RuntimeError, match='mailbox'):
+        gs.check()
+    # the training loop's own readback raises too: a 4-batch "epoch" is far below the 512-replay polling interval
+    runner.train_loader = [(b[:-1], b[-1]) for b in batches[:4]]
+    runner.test_loader = [(batches[0][:-1], batches[0][-1])]
+    with pytest.raises(RuntimeError, match='mailbox'):
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            runner.train(1, log_interval=2)

@@ -91,6 +91,36 @@ def test_checkpoint_resume_on_the_fused_path(dev, tmp_path):
         assert torch.equal(a, b), k
 
 
+def test_checkpoint_carries_the_private_generators(dev, tmp_path):
+    """A run resumed in a NEW process continues the shuffle order and the dropout masks of the uninterrupted run: the
+    sampler's generator (src/scripts/common.py: RandomSampler(generator=...)) and the nonce stream of the HIP path's dropout
+    masks (ops._nonce) are private generators - not torch's global RNG state - and ride in the checkpoint."""
+    from torch.utils.data import DataLoader, RandomSampler
+    sp, ds, col, train, ops = pkg(), pkg('dataset'), pkg('collate'), pkg('train'), pkg('ops')
+    tr, te, V = ds.read_dataset(os.path.join(ROOT, 'datasets', 'sample'))
+    train_set = ds.AugmentedDataset(tr)
+    torch.manual_seed(5)
+    ops.seed_dropout()
+    model = sp.NISER(V, 32, 1, feat_drop=0.2).to(dev)
+    gen = torch.Generator().manual_seed(123)
+    loader = DataLoader(train_set, batch_size=32, sampler=RandomSampler(train_set, generator=gen),
+                        collate_fn=col.collate_fn_factory(col.seq_to_session_graph))
+    runner = train.TrainRunner('sample', model, loader, loader, dev, lr=1e-3, weight_decay=1e-4)
+    assert runner._loader_generators() == [gen]
+    [ops._nonce() for _ in range(3)]
+    next(iter(loader))                                            # one epoch's permutation drawn
+    ck = str(tmp_path / 'rng.pt')
+    runner.save_checkpoint(ck)
+    want_perm = list(iter(RandomSampler(train_set, generator=gen)))[:16]
+    want_nonce = [ops._nonce() for _ in range(4)]
+    # "new process": both generators somewhere else entirely
+    gen.manual_seed(999)
+    ops.seed_dropout(777)
+    runner.load_checkpoint(ck)
+    assert list(iter(RandomSampler(train_set, generator=gen)))[:16] == want_perm
+    assert [ops._nonce() for _ in range(4)] == want_nonce
+
+
 @pytest.mark.parametrize('model_name,dim', [('MSGIFSR', 256), ('NISER', 128), ('LESSR', 32)])
 def test_bf16_training_metrics_within_0p3pt_of_fp32(dev, model_name, dim):
     """Recall@20 / MRR@20 after training in bf16 mode within +-0.3 pt (absolute) of the same

@@ -41,8 +41,9 @@ print('workers %d: %.2f ms/step  ' % (W, tot / steps * 1e3) + '  '.join('%s %.2f
 g = runner._gstep
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(100):
-    g.opt.advance(g.work); g.graph.replay()
+    g(inputs, labels)                    # (through the mailbox: a raw graph.replay() would find a stale entry and skip the step)
 torch.cuda.synchronize()
+g.check()
 print('pure replay of the captured step: %.2f ms' % ((time.perf_counter() - t0) * 10), ' caps', caps)
 # collate alone, one process
 import timeit
