@@ -311,13 +311,15 @@ int srec_adam_multi(const void* desc, const float* hyper, void* stream);
 /* item table, one wavefront per row.  max_norm > 0: Embedding(max_norm) renorm of the updated row (lessr.py:126,
  * msgifsr.py:162) - written back when renorm_write != 0, otherwise W keeps the plain Adam result (the reference
  * renormalises at the start of the NEXT forward) and only cs_out (nullable; = cs_scale / norm of the row as that forward
- * will see it: niser.py:151, msgifsr.py:279) reflects it. */
+ * will see it: niser.py:151, msgifsr.py:279) reflects it.  dst16 (nullable; d <= 1024): bf16 copy [n, Dp] of the rows as
+ * written - with renorm_write = 1 this pass leaves the table exactly as the next forward's stand-alone renorm + operand-copy
+ * pass (srec_renorm_rows_bf16) would, which then need not run. */
 int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
                    int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
-                   float cs_eps, void* stream);
+                   float cs_eps, void* dst16, int Dp, void* stream);
 int srec_adam_rows_proj(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper, int use_wd,
                         float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
-                        const float* proj_cs, float proj_inv_scale, float* radial, void* stream);
+                        const float* proj_cs, float proj_inv_scale, float* radial, void* dst16, int Dp, void* stream);
 
 /* ---- MSGIFSR MSHGNN layer, all relations of both HeteroGraphConvs in one batched pass (hgat.hip) ------------------
  * Replaces msgifsr.py:70-89 (conv1(g) + conv2(reverse g), relation sum, head max, + session mean) around the fc GEMMs

@@ -60,11 +60,16 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
     }
 }
 
+// HOLD (d <= 1024): the updated row stays in registers (<= 4 float4 per lane) between the Adam arithmetic and the row-wise
+// epilogues - W is stored ONCE, already renormalised when renorm_write is set, and dst16 (nullable) receives the bf16 operand
+// copy of the row as the next forward's scoring kernels read it (zero in the columns d .. Dp): the stand-alone
+// renorm + copy pass of the next step (srec_renorm_rows_bf16: 11 us, 57 MB at C3) disappears.
+template <bool HOLD>
 __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict__ G, float* __restrict__ M,
                                  float* __restrict__ Vv, int n, int d, int ld, const float* __restrict__ hyper,
                                  int use_wd, float max_norm, int renorm_write, float* __restrict__ cs_out, float cs_scale,
-                                 int eps_mode, float cs_eps, const float* __restrict__ proj_cs = nullptr,
-                                 float proj_inv_scale = 0.f, float* __restrict__ radial = nullptr) {
+                                 int eps_mode, float cs_eps, const float* __restrict__ proj_cs, float proj_inv_scale,
+                                 float* __restrict__ radial, unsigned short* __restrict__ dst16, int Dp) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const Hyper h = load_hyper(hyper);
@@ -76,12 +81,26 @@ __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict_
     // after the scoring gradient (the lookup gradients, srec_scatter_add_sorted_ex) and is cleared for the next step.  Saves
     // the separate pass over the table gradient (read G + W, write G: 115 MB at C3).
     float pcoef = 0.f;
+    float4 pw[4], gw[4];
+    if (HOLD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + j * 256;
+            pw[j] = make_float4(0.f, 0.f, 0.f, 0.f); gw[j] = pw[j];
+            if (c < d) { pw[j] = *reinterpret_cast<const float4*>(W + off + c); gw[j] = *reinterpret_cast<const float4*>(G + off + c); }
+        }
+    }
     if (proj_cs != nullptr) {
         float dot = 0.f;
-        for (int c = lane * 4; c < d; c += 256) {
-            const float4 pp = *reinterpret_cast<const float4*>(W + off + c);
-            const float4 gg = *reinterpret_cast<const float4*>(G + off + c);
-            dot += pp.x * gg.x + pp.y * gg.y + pp.z * gg.z + pp.w * gg.w;
+        if (HOLD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dot += pw[j].x * gw[j].x + pw[j].y * gw[j].y + pw[j].z * gw[j].z + pw[j].w * gw[j].w;
+        } else {
+            for (int c = lane * 4; c < d; c += 256) {
+                const float4 pp = *reinterpret_cast<const float4*>(W + off + c);
+                const float4 gg = *reinterpret_cast<const float4*>(G + off + c);
+                dot += pp.x * gg.x + pp.y * gg.y + pp.z * gg.z + pp.w * gg.w;
+            }
         }
         dot = wave_sum(dot);
         const float iv = proj_cs[i] * proj_inv_scale;
@@ -92,6 +111,50 @@ __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict_
         pcoef = dot * iv * iv;
     }
     float ss = 0.f;
+    if (HOLD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + j * 256;
+            if (c < d) {
+                float4 pp = pw[j], gg = gw[j];
+                gg.x -= pp.x * pcoef; gg.y -= pp.y * pcoef; gg.z -= pp.z * pcoef; gg.w -= pp.w * pcoef;
+                float4 mm = *reinterpret_cast<float4*>(M + off + c);
+                float4 vv = *reinterpret_cast<float4*>(Vv + off + c);
+                adam1(pp.x, gg.x, mm.x, vv.x, h, wd, step, rs2);
+                adam1(pp.y, gg.y, mm.y, vv.y, h, wd, step, rs2);
+                adam1(pp.z, gg.z, mm.z, vv.z, h, wd, step, rs2);
+                adam1(pp.w, gg.w, mm.w, vv.w, h, wd, step, rs2);
+                ss += pp.x * pp.x + pp.y * pp.y + pp.z * pp.z + pp.w * pp.w;
+                pw[j] = pp;
+                *reinterpret_cast<float4*>(M + off + c) = mm;
+                *reinterpret_cast<float4*>(Vv + off + c) = vv;
+            }
+        }
+        float nrm = 0.f;
+        float sc = 1.f;
+        if (max_norm > 0.f || cs_out != nullptr) {
+            nrm = sqrtf(wave_sum(ss));
+            if (max_norm > 0.f && nrm > max_norm) {
+                // renorm_write == 0: W keeps the plain Adam result (the reference renormalises in the NEXT forward,
+                // msgifsr.py:162,247) and only cs is that of the row as the next forward will see it
+                const float s1 = max_norm / (nrm + 1e-7f);
+                if (renorm_write) sc = s1;
+                nrm *= s1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane * 4 + j * 256;
+            float4 pp = pw[j];
+            if (sc != 1.f) { pp.x *= sc; pp.y *= sc; pp.z *= sc; pp.w *= sc; }
+            if (c < d) *reinterpret_cast<float4*>(W + off + c) = pp;
+            if (dst16 != nullptr && c < Dp)
+                *reinterpret_cast<uint2*>(dst16 + (size_t)i * Dp + c) = make_uint2(srec_pack_bf16(pp.x, pp.y), srec_pack_bf16(pp.z, pp.w));
+        }
+        if (cs_out != nullptr && lane == 0)
+            cs_out[i] = cs_scale * (eps_mode == 0 ? 1.f / fmaxf(nrm, cs_eps) : 1.f / (nrm + cs_eps));
+        return;
+    }
     for (int c = lane * 4; c < d; c += 256) {
         float4 pp = *reinterpret_cast<float4*>(W + off + c);
         float4 gg = *reinterpret_cast<const float4*>(G + off + c);
@@ -111,8 +174,6 @@ __global__ void adam_rows_kernel(float* __restrict__ W, const float* __restrict_
     float nrm = sqrtf(wave_sum(ss));
     if (max_norm > 0.f && nrm > max_norm) {
         const float sc = max_norm / (nrm + 1e-7f);
-        // renorm_write == 0: W keeps the plain Adam result (the reference renormalises in the NEXT forward,
-        // msgifsr.py:162,247) and only cs is that of the row as the next forward will see it
         for (int c = lane * 4; renorm_write && c < d; c += 256) {       // same lane re-reads what it wrote
             float4 pp = *reinterpret_cast<float4*>(W + off + c);
             pp.x *= sc; pp.y *= sc; pp.z *= sc; pp.w *= sc;
@@ -307,27 +368,39 @@ extern "C" int srec_adam_flat(float* p, const float* g, float* m, float* v, long
     return 0;
 }
 
-extern "C" int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
-                              int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
-                              float cs_eps, void* stream) {
+static int adam_rows_run(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper, int use_wd,
+                         float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode, float cs_eps,
+                         const float* proj_cs, float proj_inv_scale, float* radial, void* dst16, int Dp, void* stream) {
     if (n <= 0) return 0;
     if (d <= 0 || (d & 3) || (ld & 3)) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(adam_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld,
-                       hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, (const float*)nullptr, 0.f,
-                       (float*)nullptr);
+    if (dst16 != nullptr && (d > 1024 || Dp < d || (Dp & 3) || Dp > 1024)) return SREC_BAD_ARG;
+    if (d <= 1024)
+        hipLaunchKernelGGL(adam_rows_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld, hyper,
+                           use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, proj_cs, proj_inv_scale, radial,
+                           (unsigned short*)dst16, Dp);
+    else
+        hipLaunchKernelGGL(adam_rows_kernel<false>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld, hyper,
+                           use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, proj_cs, proj_inv_scale, radial,
+                           (unsigned short*)nullptr, 0);
     SREC_LAUNCH_CHECK();
     return 0;
+}
+
+// dst16 (nullable; d <= 1024): bf16 copy [n, Dp] of the rows as written (Dp >= d, zero padding columns) - with renorm_write the
+// renormalised rows, i.e. what srec_renorm_rows_bf16 would produce at the start of the next forward
+extern "C" int srec_adam_rows(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
+                              int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
+                              float cs_eps, void* dst16, int Dp, void* stream) {
+    return adam_rows_run(W, G, M, V, n, d, ld, hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, nullptr,
+                         0.f, nullptr, dst16, Dp, stream);
 }
 
 // srec_adam_rows with the row-normalisation projection of the gradient fused in (see adam_rows_kernel)
 extern "C" int srec_adam_rows_proj(float* W, const float* G, float* M, float* V, int n, int d, int ld, const float* hyper,
                                    int use_wd, float max_norm, int renorm_write, float* cs_out, float cs_scale, int eps_mode,
-                                   float cs_eps, const float* proj_cs, float proj_inv_scale, float* radial, void* stream) {
-    if (n <= 0) return 0;
-    if (d <= 0 || (d & 3) || (ld & 3) || proj_cs == nullptr) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(adam_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, W, G, M, V, n, d, ld,
-                       hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, proj_cs, proj_inv_scale,
-                       radial);
-    SREC_LAUNCH_CHECK();
-    return 0;
+                                   float cs_eps, const float* proj_cs, float proj_inv_scale, float* radial, void* dst16, int Dp,
+                                   void* stream) {
+    if (proj_cs == nullptr) return SREC_BAD_ARG;
+    return adam_rows_run(W, G, M, V, n, d, ld, hyper, use_wd, max_norm, renorm_write, cs_out, cs_scale, eps_mode, cs_eps, proj_cs,
+                         proj_inv_scale, radial, dst16, Dp, stream);
 }

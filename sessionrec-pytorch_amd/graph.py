@@ -77,6 +77,21 @@ class GraphedTrainStep:
                 ms['cs_fresh'] = False
                 model._col_scale(ms)
             ms['cs_fresh'] = ms.get('cs') is not None
+        # the same for the table's renorm / bf16 operand copy: FusedAdam's row pass of step k prepares the table for step k + 1
+        # (optim.py), so the captured step carries no stand-alone pass - the FIRST replay's table is prepared here, eagerly
+        ms = model.__dict__.get('_srec_state')
+        if ms is not None and getattr(optimizer, 'folds_table_prep', lambda: False)() and hasattr(model, '_table_copy'):
+            with torch.no_grad():
+                W = model._table()
+                mn = float(getattr(model, '_max_norm', 0.0) or 0.0)
+                tb = model._table_copy(ms, W)
+                ms.pop('table_prepared', None)
+                from ._lib import lib as _lib, ptr as _ptr, stream as _stream
+                if tb is not None:
+                    tb.refresh(W, mn)
+                elif mn > 0:
+                    _lib.srec_renorm_rows(_ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], mn, _stream())
+                ms['table_prepared'] = (True, tb is not None, W._version)
         import os
         try:                                             # the hipGraph_t stays queryable (node_counts)
             self.graph = torch.cuda.CUDAGraph(keep_graph=True)

@@ -118,8 +118,9 @@ class LESSR(_ScoringMixin, nn.Module):
     def session_repr(self, mg, sg=None, tgrad=None):
         from ._lib import lib, ptr, stream
         W = self.embedding.weight
-        with torch.no_grad():                    # Embedding(max_norm=1): in-place renorm before the lookup
-            lib.srec_renorm_rows(ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], 1.0, stream())
+        if not self._take_prepared(self.__dict__.get('_srec_state'))[0]:   # (FusedAdam's row pass left the rows renormalised)
+            with torch.no_grad():                # Embedding(max_norm=1): in-place renorm before the lookup
+                lib.srec_renorm_rows(ptr(W), W.stride(0), None, W.shape[0], None, W.shape[1], 1.0, stream())
         dN, dB = mg.dynp('N'), mg.dynp('B')
         if mg.buf.is_cuda:
             ops.check_limits(mg)

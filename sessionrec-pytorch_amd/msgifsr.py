@@ -299,14 +299,17 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         # training entry: the renorm runs here, ahead of the cosine column scale (the scale must be that of the rows
         # the scoring kernels read: msgifsr.py:162 renormalises inside the lookup, :276-279 normalises the result)
         W = self._table()
+        st = self._state(1) if W.is_cuda else None
+        renormed, copied = self._take_prepared(st)        # done by the optimizer's row pass of the previous step?
         if self.shard is None and self.training and ops.use_bf16_scoring(W.shape[1]) and W.is_cuda:
             # bf16 scoring: the renorm and the table's bf16 operand copy in one pass over the rows
-            st = self._state(1)
             if st.get('tb16') is None:
                 st['tb16'] = ops.TableBF16(W)
-            st['tb16'].refresh(W, 1.0)
+                copied = False
+            if not (renormed and copied):
+                st['tb16'].refresh(W, 1.0)
             self._tb16_fresh = True
-        else:
+        elif not renormed:
             self._renorm()
         self._table_ready = True
 

@@ -48,6 +48,15 @@ class FusedAdam(torch.optim.Optimizer):
         self._hyper = {}            # (group index, step offset) -> device step state
         self._frozen = None         # parameter lists frozen by a captured graph
 
+    def folds_table_prep(self):
+        """True when launch() will leave the model's table renormalised / with its bf16 operand copy written (see launch)"""
+        m = self.model
+        if m is None or not getattr(m, '_fold_table_prep', False) or not hasattr(m, '_table'):
+            return False
+        W = m._table()
+        return bool(W.is_cuda and W.dim() == 2 and (W.shape[1] & 3) == 0 and W.shape[1] <= 1024 and W.is_contiguous()
+                    and any(p is W for g in self.param_groups for p in g['params']))
+
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=set_to_none)
         st = self.model.__dict__.get('_srec_state') if self.model is not None else None
@@ -265,22 +274,37 @@ class FusedAdam(torch.optim.Optimizer):
                     cs_out, cs_scale, eps_mode = None, 1.0, 0
                     if cos is not None and st is not None and st.get('cs') is not None:
                         cs_out, cs_scale, eps_mode = st['cs'], float(cos[0]), int(cos[1])
-                    # Embedding(max_norm) renorm stays in forward (reference state after step()): renorm_write = 0; the
-                    # column scale of the next step is nevertheless that of the rows as the next forward will see them
-                    mn = float(getattr(model, '_max_norm', 0.0) or 0.0) if cs_out is not None else 0.0
+                    # Embedding(max_norm) renorm (lessr.py:126, msgifsr.py:162: in the reference the NEXT forward's lookups do
+                    # it, before anything reads a row) and the table's bf16 operand copy for the bf16 scoring kernels are
+                    # written by THIS pass - the row is in registers - when the model folds them (`_fold_table_prep`): the
+                    # next forward's stand-alone renorm + copy pass (srec_renorm_rows_bf16) is then skipped.  Observable
+                    # difference: between a step and the next forward the stored rows are already renormalised (a
+                    # checkpoint taken there holds what the reference's next forward would have made of them).
+                    mn_model = float(getattr(model, '_max_norm', 0.0) or 0.0)
+                    mn = mn_model if cs_out is not None else 0.0
+                    fold = bool(getattr(model, '_fold_table_prep', False)) and st is not None and p.shape[1] <= 1024
+                    tb = model._table_copy(st, p) if (fold and hasattr(model, '_table_copy')) else None
+                    renorm_write = 1 if (fold and mn_model > 0) else 0
+                    if renorm_write:
+                        mn = mn_model
+                    d16, dp16 = (tb.E16, tb.E16.shape[1]) if tb is not None else (None, 0)
                     pend = tgrad.pending if (tgrad is not None and g.data_ptr() == tgrad.buf.data_ptr()) else None
                     if pend is not None:
                         lib.srec_adam_rows_proj(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
-                                                p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, 0, ptr(cs_out), cs_scale,
-                                                eps_mode, 1e-12, ptr(pend[1]), float(pend[2]), ptr(tgrad.radial), stream())
+                                                p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, renorm_write, ptr(cs_out), cs_scale,
+                                                eps_mode, 1e-12, ptr(pend[1]), float(pend[2]), ptr(tgrad.radial), ptr(d16), dp16,
+                                                stream())
                         tgrad.pending = None
                         tgrad.radial_dirty = False
                     else:
                         if tgrad is not None:
                             tgrad.materialize()
                         lib.srec_adam_rows(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
-                                           p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, 0, ptr(cs_out), cs_scale,
-                                           eps_mode, 1e-12, stream())
+                                           p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, renorm_write, ptr(cs_out), cs_scale,
+                                           eps_mode, 1e-12, ptr(d16), dp16, stream())
+                    if fold:
+                        # (renormalised rows in place, bf16 copy written): consumed by the model's next _prepare_table / _table_bf16
+                        st['table_prepared'] = (bool(renorm_write) or mn_model <= 0, tb is not None, p._version)
                     if cs_out is not None:
                         st['cs_fresh'] = True
                 else:

@@ -72,6 +72,29 @@ class _ScoringMixin:
         (Embedding(max_norm): lessr.py:126, msgifsr.py:162); called once per step ahead of everything that reads rows"""
         self._table_ready = False
 
+    # FusedAdam's row pass over the table also leaves the rows renormalised (models with max_norm) and writes the bf16 operand
+    # copy of the bf16 scoring kernels (optim.py: st['table_prepared']); the next forward then skips its stand-alone pass.
+    # One device only: the row-sharded path refreshes its shard's copy itself (dist.HipLocal._tb).
+    _fold_table_prep = True
+
+    def _table_copy(self, st, W):
+        """the TableBF16 the optimizer's row pass should fill (None: no bf16 scoring on this path)"""
+        if self.shard is not None or not ops.use_bf16_scoring(W.shape[1]) or not W.is_cuda:
+            return None
+        if st.get('tb16') is None:
+            st['tb16'] = ops.TableBF16(W)
+        return st['tb16']
+
+    def _take_prepared(self, st):
+        """(rows renormalised, bf16 copy written) by the optimizer's last row pass - consumed once, and only while the table
+        has not been written through PyTorch since (copy_ / load_state_dict bump its version counter; the HIP kernels do not)"""
+        prep = st.pop('table_prepared', None) if st is not None else None
+        if prep is None or prep[2] != self._table()._version:
+            return False, False
+        if prep[1] and self.shard is None:
+            self._tb16_fresh = True                      # consumed by _table_bf16 of this forward
+        return prep[0], prep[1] and self.shard is None
+
     shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
     graph_capable = False      # True: every kernel of the step reads its live extents from the padded batch (hipGraph replay)
 
@@ -125,6 +148,8 @@ class _ScoringMixin:
         if st.get('tb16') is None:
             st['tb16'] = ops.TableBF16(W)
         if self.__dict__.pop('_tb16_fresh', False):      # _prepare_table wrote the copy together with the renorm
+            return st['tb16']
+        if self._take_prepared(st)[1]:                   # the optimizer's row pass of the previous step wrote it
             return st['tb16']
         return st['tb16'].refresh(W)
 

@@ -373,7 +373,12 @@ def test_one_rank_of_the_job_replayed_under_hipgraph_capture(dev, tmp_path, name
     assert group.pos == len(group.kinds) and group.checked == len(group.kinds)
     assert abs(loss.item() - job['steps'][0]['loss']) <= 1e-6 * max(1.0, abs(job['steps'][0]['loss']))
     del loss          # (a live loss of an eager default-stream step must not outlive into the capture: graph.GraphedTrainStep)
-    close(model._table().detach()[:vp.n_live], job['steps'][0]['table'], rtol=1e-6, atol=1e-7, what='table rows after the eager step')
+    # (inside the job the row-normalisation projection of the table gradient ran as a separate pass - the worker materialises
+    # model.table_grad to record it - here it is fused into the optimizer's row pass: two roundings of the same algebra.  A
+    # component whose projected gradient cancels to ~eps (1e-8) turns a last-bit difference into ~0.1 % of its first Adam step
+    # of lr = 1e-3, d step / d g = eps / (|g| + eps)^2: hence 3e-6 absolute on the table here and - the second step starts
+    # from those rows - below; the replicated parameters keep the tight bound)
+    close(model._table().detach()[:vp.n_live], job['steps'][0]['table'], rtol=1e-6, atol=3e-6, what='table rows after the eager step')
     # step 2, captured (one eager warm-up lap with checks, one capture lap) and replayed
     group.load(job['steps'][1]['tape'])
     gs = G.GraphedTrainStep(model, opt, inputs, labels, after_backward=lambda: vp.sync_replicated_grads(replicated, opt),
@@ -383,7 +388,7 @@ def test_one_rank_of_the_job_replayed_under_hipgraph_capture(dev, tmp_path, name
     torch.cuda.synchronize()
     assert abs(loss2.item() - job['steps'][1]['loss']) <= 1e-6 * max(1.0, abs(job['steps'][1]['loss'])), \
         (loss2.item(), job['steps'][1]['loss'])
-    close(model._table().detach()[:vp.n_live], job['steps'][1]['table'], rtol=1e-6, atol=1e-7, what='table rows after the replayed step')
+    close(model._table().detach()[:vp.n_live], job['steps'][1]['table'], rtol=1e-6, atol=3e-6, what='table rows after the replayed step')
     for k, p in model.named_parameters():
         if p is not model._table():
             close(p, job['steps'][1]['params'][k], rtol=1e-6, atol=1e-7, what='replayed step: ' + k)

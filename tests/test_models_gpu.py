@@ -215,9 +215,22 @@ def test_model_matches_reference_fixture(dev, name):
         assert e_mine <= factor * e_ref + 1e-9 * float(g64.abs().mean()) + 1e-12, \
             'step-0 grad %s: mean |err| vs fp64 %.3e (reference fp32 gradients: %.3e)' % (k, e_mine, e_ref)
     print('fp32-unresolvable gradient components in the float64 run:', risky)
+    # The item table of the max_norm models (LESSR, MSGIFSR): Embedding(max_norm=1) renormalises rows inside the NEXT forward
+    # (lessr.py:126, msgifsr.py:162), FusedAdam's row pass does it while it has the row in registers (optim.py
+    # `_fold_table_prep`) - between a step and the next forward the stored rows here are what the reference's next forward
+    # makes of its own.  The stored reference / float64 tables therefore pass through that renorm before the comparison.
+    mn = float(getattr(model, '_max_norm', 0.0) or 0.0)
+
+    def next_forward(t):
+        t = torch.as_tensor(t).double()
+        nrm = t.norm(dim=1, keepdim=True)
+        return torch.where(nrm > mn, t * (mn / (nrm + 1e-7)), t)
     for k in z.files:
         if k.startswith('final/') and k[6:] in sd and sd[k[6:]].dtype == torch.float32:
-            roundoff_close(sd[k[6:]], z[k], truth[k[6:]], k, risky)
+            ref32, t64 = z[k], truth[k[6:]]
+            if mn > 0 and k[6:].startswith('embedding'):
+                ref32, t64 = next_forward(ref32).float().numpy(), next_forward(t64)
+            roundoff_close(sd[k[6:]], ref32, t64, k, risky)
     # 4) evaluation ranking - from the REFERENCE's trained weights where the fixture holds all of them, so that this check
     # sees the evaluation path and not the round-off the three training steps above accumulated (checked there)
     finals = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('final/')}
