@@ -55,7 +55,7 @@ int srec_ce_plan(int B, int V, int d, int* n_item_tiles, int* n_ranges);
 int srec_score_ce_fwd(const float* sr, int ld_sr, const float* E, int ld_e, const float* cs, const int* labels,
                       int B, int V, int d, const int* dynB, float* ws_stats, float* lab_logit, float* lse,
                       float* lossvec, float* loss, void* stream);
-/* ws_dsr: n_ranges*B*d floats.  gscale (nullable): upstream d loss.  Outputs dE[V,d] (every row), dsr[B,d].
+/* ws_dsr: n_ranges*B*d floats.  gscale (nullable): upstream d loss (with ga / gc given it multiplies them: no 1 / B).  Outputs dE[V,d] (every row), dsr[B,d].
  * parts: bit0 = dE kernel, bit1 = d sr kernels (3 = both), bit2 = accumulate into dE.  ga/gc (nullable): per-session coefficients
  * dS[b,v] = (ga[b] softmax[b,v] - gc[b] [v==label_b]) cs[v] for losses built from (lse_b, z[b,label_b]), e.g. the
  * order-fusion mixture of msgifsr.py:311-317. */
@@ -272,6 +272,8 @@ int srec_sgat_bwd_src(const float* dout, int ld_o, const float* A, const float* 
  * hyper (device, 8 floats) = {lr/(1-b1^t), beta1, beta2, eps, weight_decay, 1-beta1, 1-beta2, sqrt(1-b2^t)} */
 /* row-sharded item table: global ids (int64; -1 = padding) -> local row of the shard [lo, lo + n_loc) or -1 */
 int srec_localize_idx(const long long* idx, long n, long lo, int n_loc, int* out, void* stream);
+/* int32 ids (padded batches); zero (nullable): n floats cleared by the same launch (the label-logit array of the sharded forward) */
+int srec_localize_idx32(const int* idx, long n, long lo, int n_loc, int* out, float* zero, void* stream);
 
 /* inv[p] = u for the positions p = pos[ptr[u] .. ptr[u+1]) of item u < U (uniq_ptr / uniq_pos of a FlatBatch), -1 elsewhere */
 int srec_inverse_index(const int* ptr, const int* pos, int U, int n, int* inv, void* stream);
@@ -281,6 +283,8 @@ int srec_inverse_index(const int* ptr, const int* pos, int U, int n, int* inv, v
  * d loss / d (lse_b - lab_b) = 1 / n_live on live sessions, 0 on padding - the ga / gc of srec_score_ce_bwd*. */
 int srec_merge_stats(const float* st, int w, int B, const long long* lab_all, float* lse, float* lab, float* loss,
                      float* gw, void* stream);
+int srec_merge_stats32(const float* st, int w, int B, const int* lab_all, float* lse, float* lab, float* loss,
+                       float* gw, void* stream);        /* int32 labels */
 
 int srec_adam_flat(float* p, const float* g, float* m, float* v, long n, const float* hyper, int use_wd,
                    void* stream);

@@ -414,11 +414,14 @@ __global__ void col_sum_final_kernel(const float* __restrict__ part, int ncol, f
 }
 
 // out[i] = idx[i] - lo when idx[i] is a row of this shard ([lo, lo + n_loc)), else -1 (also for the -1 padding)
-__global__ void localize_idx_kernel(const long long* __restrict__ idx, long n, long long lo, int n_loc, int* __restrict__ out) {
+template <typename I>
+__global__ void localize_idx_kernel(const I* __restrict__ idx, long n, long long lo, int n_loc, int* __restrict__ out,
+                                    float* __restrict__ zero = nullptr) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long r = idx[i] - lo;
-    out[i] = (idx[i] >= 0 && r >= 0 && r < n_loc) ? (int)r : -1;
+    if (zero != nullptr) zero[i] = 0.f;
+    const long long v = (long long)idx[i], r = v - lo;
+    out[i] = (v >= 0 && r >= 0 && r < n_loc) ? (int)r : -1;
 }
 
 // st [w][2][B]: per-shard (log-sum-exp, label logit) of every session -> global lse[b] = logsumexp_r st[r][0][b],
@@ -426,7 +429,8 @@ __global__ void localize_idx_kernel(const long long* __restrict__ idx, long n, l
 // (lse - lab).  lab_all (nullable) = the gathered global labels: a session with label < 0 is capacity padding of its
 // rank's batch (dead): it is left out of the mean and gets weight 0 in gw (nullable) = d loss / d (lse_b - lab_b), i.e.
 // 1 / n_live for the live sessions - the per-session coefficients the backward kernels take as ga / gc.  One workgroup.
-__global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, const long long* __restrict__ lab_all,
+template <typename I>
+__global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, const I* __restrict__ lab_all,
                                    float* __restrict__ lse, float* __restrict__ lab, float* __restrict__ loss,
                                    float* __restrict__ gw) {
     __shared__ float red[4];
@@ -790,8 +794,19 @@ extern "C" int srec_col_sum(const float* X, int ld, const float* wgt, int H, int
 // (replaces a subtract / three compares / two ands / where / cast chain per exchange).
 extern "C" int srec_localize_idx(const long long* idx, long n, long lo, int n_loc, int* out, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(localize_idx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n,
+    hipLaunchKernelGGL(localize_idx_kernel<long long>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n,
                        (long long)lo, n_loc, out);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same for int32 ids (the request lists of capacity-padded batches travel as the int32 words they are collated as);
+// zero (nullable) [n] floats cleared by the same launch: the label-logit array of the sharded scoring forward, whose kernels write an
+// entry only where they meet the label (the labels are localised right in front of it: no fill launch of its own)
+extern "C" int srec_localize_idx32(const int* idx, long n, long lo, int n_loc, int* out, float* zero, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(localize_idx_kernel<int>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n,
+                       (long long)lo, n_loc, out, zero);
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -800,8 +815,17 @@ extern "C" int srec_localize_idx(const long long* idx, long n, long lo, int n_lo
 extern "C" int srec_merge_stats(const float* st, int w, int B, const long long* lab_all, float* lse, float* lab,
                                 float* loss, float* gw, void* stream) {
     if (w <= 0 || B <= 0) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(merge_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lab_all, lse, lab, loss,
+    hipLaunchKernelGGL(merge_stats_kernel<long long>, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lab_all, lse, lab, loss,
                        gw);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ... with int32 labels
+extern "C" int srec_merge_stats32(const float* st, int w, int B, const int* lab_all, float* lse, float* lab, float* loss,
+                                  float* gw, void* stream) {
+    if (w <= 0 || B <= 0) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(merge_stats_kernel<int>, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lab_all, lse, lab, loss, gw);
     SREC_LAUNCH_CHECK();
     return 0;
 }

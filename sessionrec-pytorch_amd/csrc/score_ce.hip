@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
     const bool x_empty = (x0 >= nx);
     const int tile_id = ITEMS_X ? blockIdx.x : 0;
 
-    float gs = 1.f;
-    if (HAS_ACC) gs = (a.gscale != nullptr ? *a.gscale : 1.f) / (float)(Bd > 0 ? Bd : 1);
+    float gs = 1.f, gm = 1.f;                  // gm: the upstream scalar on caller-given per-session coefficients ga / gc
+    if (HAS_ACC) { gm = a.gscale != nullptr ? *a.gscale : 1.f; gs = gm / (float)(Bd > 0 ? Bd : 1); }
 
     float4 regs[2 * NT];
     gload_tile<NT>(regs, Xsrc, ldx, x0, nx > 0 ? nx : 1, d, tid);
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
             xq[r] = (MODE != MODE_FWD && xi < nx) ? a.lse[xi] : 0.f;
             xlab[r] = (MODE == MODE_DSR && xi < nx) ? a.labels[xi] : -1;
         }
-        xga[r] = (MODE == MODE_DSR && a.ga != nullptr && xi < nx) ? a.ga[xi] : gs;
-        xgc[r] = (MODE == MODE_DSR && a.gc != nullptr && xi < nx) ? a.gc[xi] : gs;
+        xga[r] = (MODE == MODE_DSR && a.ga != nullptr && xi < nx) ? a.ga[xi] * gm : gs;
+        xgc[r] = (MODE == MODE_DSR && a.gc != nullptr && xi < nx) ? a.gc[xi] * gm : gs;
     }
 
     f32x16 acc[NCB];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
         } else if (MODE == MODE_DE) {
             yq = yvalid ? a.lse[yj] : 0.f;
             ylab = yvalid ? a.labels[yj] : -1;
-            if (a.ga != nullptr) { yga = yvalid ? a.ga[yj] : 0.f; ygc = yvalid ? a.gc[yj] : 0.f; }
+            if (a.ga != nullptr) { yga = yvalid ? a.ga[yj] * gm : 0.f; ygc = yvalid ? a.gc[yj] * gm : 0.f; }
         } else {
             yq = (a.cs != nullptr && yvalid) ? a.cs[yj] : 1.f;
         }

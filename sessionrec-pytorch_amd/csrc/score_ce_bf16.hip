@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         labL = a.labels[xi];
         if (KIND == KIND_BWD) {
             lseL = a.lse[xi];
-            if (has_g) { gaL = a.ga[xi]; gcL = a.gc[xi]; }
+            if (has_g) { const float gm = a.gscale != nullptr ? *a.gscale : 1.f; gaL = a.ga[xi] * gm; gcL = a.gc[xi] * gm; }
         }
     }
 
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
                     const int lab = ok ? a.labels[row] : -1;
                     sideF[i] = ok ? a.lse[row] * LOG2E : INFINITY;
                     sideI[i] = lab;
-                    if (has_g) { sideGa[i] = ok ? a.ga[row] : 0.f; sideGc[i] = ok ? a.gc[row] : 0.f; }
+                    if (has_g) { const float gm = a.gscale != nullptr ? *a.gscale : 1.f; sideGa[i] = ok ? a.ga[row] * gm : 0.f; sideGc[i] = ok ? a.gc[row] * gm : 0.f; }
                     const unsigned long long hit = __builtin_amdgcn_ballot_w64(lab >= x0 && lab < x0 + OWN);
                     if ((lane & 31) == 0) sideHit[i >> 5] = ((hit >> (lane & 32)) & 0xffffffffull) != 0;
                 } else {

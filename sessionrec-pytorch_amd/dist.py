@@ -214,12 +214,19 @@ class HipLocal:
         from . import ops
         self.ops = ops
 
-    def localize(self, idx_all, lo, n_loc):
-        """global ids (int64, -1 padding) -> int32 rows of this shard, -1 elsewhere"""
+    def localize(self, idx_all, lo, n_loc, zero=None):
+        """global ids (int64 / int32, -1 padding) -> int32 rows of this shard, -1 elsewhere.  zero: a float array of the same
+        length cleared by the same launch (int32 ids) - else by a fill"""
         from ._lib import lib, ptr, stream
         idx_all = idx_all.contiguous()
         out = torch.empty(idx_all.numel(), device=idx_all.device, dtype=torch.int32)
-        lib.srec_localize_idx(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), stream())
+        if idx_all.dtype == torch.int32:
+            assert zero is None or (zero.numel() == idx_all.numel() and zero.is_contiguous())
+            lib.srec_localize_idx32(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), ptr(zero), stream())
+        else:
+            lib.srec_localize_idx(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), stream())
+            if zero is not None:
+                zero.zero_()
         return out
 
     def merge_stats(self, st, lab_all=None):
@@ -232,7 +239,8 @@ class HipLocal:
         lab = torch.empty(B, device=st.device, dtype=torch.float32)
         gw = torch.empty(B, device=st.device, dtype=torch.float32)
         loss = torch.empty((), device=st.device, dtype=torch.float32)
-        lib.srec_merge_stats(ptr(st), w, B, ptr(lab_all), ptr(lse), ptr(lab), ptr(loss), ptr(gw), stream())
+        fn = lib.srec_merge_stats32 if (lab_all is not None and lab_all.dtype == torch.int32) else lib.srec_merge_stats
+        fn(ptr(st), w, B, ptr(lab_all), ptr(lse), ptr(lab), ptr(loss), ptr(gw), stream())
         return lse, lab, loss, gw
 
     def inverse_index(self, uptr, upos, U, n):
@@ -242,6 +250,7 @@ class HipLocal:
         lib.srec_inverse_index(ptr(uptr), ptr(upos), U, n, ptr(inv), stream())
         return inv
 
+    takes_gl = True                # stats_bwd(gl=): the upstream loss gradient as a device scalar
     fused_dropout = True           # gather_masked / segment_rows take drop = (p, seed, counter, salt): the lookup's feature
     #                                dropout rides in the last gather and in the first level of its backward (ops.EmbeddingLookup)
 
@@ -308,14 +317,17 @@ class HipLocal:
         if tb is None:
             tb = self._tb16[key] = ops.TableBF16(table)
             refresh = True
+        elif refresh and self.__dict__.pop('_tb_written', None) == (key, table._version):
+            refresh = False                    # FusedAdam's row pass of the previous step wrote the copy (optim.py)
         return tb.refresh(table) if refresh else tb
 
-    def ce_fwd(self, sr, table, cs, labels_local, ws):
+    def ce_fwd(self, sr, table, cs, labels_local, ws, pair=None):
         B, d = sr.shape
         dev = sr.device
         # (lse, label logit) as the two rows of ONE buffer: it is what _merge_stats all-gathers (no stack / clone launches)
-        pair = torch.empty(2, B, device=dev, dtype=torch.float32)
-        pair[1].zero_()
+        if pair is None:                           # (pair given: its label-logit row has been cleared by the caller's localize)
+            pair = torch.empty(2, B, device=dev, dtype=torch.float32)
+            pair[1].zero_()
         lossvec = torch.empty(B, device=dev, dtype=torch.float32)
         loss = torch.empty((), device=dev, dtype=torch.float32)
         self.ops._ce_fwd(sr, table, cs, labels_local, ws, None, self._tb(table, True), pair[1], pair[0], lossvec, loss)
@@ -333,7 +345,7 @@ class HipLocal:
                                      table.shape[0], d, stream())
         return dsr
 
-    def stats_bwd(self, sr, table, cs, labels_local, lse, ga, gc, dE, ws, cs_inv_scale, accumulate, defer_tg=None):
+    def stats_bwd(self, sr, table, cs, labels_local, lse, ga, gc, dE, ws, cs_inv_scale, accumulate, defer_tg=None, gl=None):
         """d z[b, v] = ga[b] * softmax(z_b)[v] - gc[b] * [v == label_b] through this rank's rows: dE (+)= dz^T sr,
         returns the partial d sr = dz E_local"""
         from ._lib import lib, ptr, stream
@@ -341,7 +353,7 @@ class HipLocal:
         dsr = torch.empty(B, d, device=sr.device, dtype=torch.float32)
         if defer_tg is not None and not accumulate:
             defer_tg.overwritten()                     # stale pending / radial of a backward no optimizer step consumed
-        self.ops._ce_bwd(sr, table, cs, labels_local, lse, None, ga, gc, ws, None, self._tb(table, False), dE, dsr,
+        self.ops._ce_bwd(sr, table, cs, labels_local, lse, gl, ga, gc, ws, None, self._tb(table, False), dE, dsr,
                          3 | (4 if accumulate else 0))
         if cs is not None and defer_tg is not None:
             defer_tg.pending = (table, cs, cs_inv_scale)      # linear: once, over the sum of the heads' contributions
@@ -414,7 +426,7 @@ class ShardedLookup(torch.autograd.Function):
         parts = [items_pad]
         lab = vp.labels_hint if vp is not None else None
         if lab is not None:
-            parts.append(lab.to(torch.int64))
+            parts.append(lab if lab.dtype == items_pad.dtype else lab.to(items_pad.dtype))
         packed = all_gather_cat((torch.cat(parts) if len(parts) > 1 else parts[0]).unsqueeze(0), group)    # [w, ucap (+ B)]
         ctx.items_all = packed[:, :ucap].reshape(-1)
         if lab is not None:
@@ -462,9 +474,14 @@ class ShardedScoreCE(torch.autograd.Function):
         n_loc = shard.shape[0]
         sr_all = all_gather_cat(sr.contiguous(), group)
         if lab_all is None:                                            # not exchanged with the lookup's request lists
-            lab_all = all_gather_cat(labels.to(torch.int64), group)
-        lab_loc = local.localize(lab_all, lo, n_loc)
-        lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
+            lab_all = all_gather_cat(labels if labels.dtype == torch.int32 else labels.to(torch.int64), group)
+        if getattr(local, 'takes_gl', False):      # HipLocal: the label-logit row is cleared by the launch that localises the labels
+            pair = torch.empty(2, sr_all.shape[0], device=sr_all.device, dtype=torch.float32)
+            lab_loc = local.localize(lab_all, lo, n_loc, zero=pair[1])
+            lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws, pair=pair)
+        else:
+            lab_loc = local.localize(lab_all, lo, n_loc)
+            lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws)
         lse, lab_logit, loss, gw = _merge_stats(lse_r, lab_logit, group, local, lab_all)
         ctx.save_for_backward(sr_all, shard, cs, lab_loc, lse, gw)
         ctx.misc = (dE, ws, cs_inv_scale, local, group, tgrad)
@@ -476,11 +493,16 @@ class ShardedScoreCE(torch.autograd.Function):
         dE, ws, cs_inv_scale, local, group, tgrad = ctx.misc
         # d z[b, v] = g_b (softmax_b[v] - [v == label_b]) with g_b = gloss / n_live on live sessions, 0 on the capacity
         # padding of a rank's partial batch (the mean runs over the live sessions of the GLOBAL batch)
-        g = (gw * gloss.reshape(()).to(torch.float32)).contiguous()
-        if tgrad is not None and tgrad.defer:
-            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False, tgrad)
+        kw = {}
+        if getattr(local, 'takes_gl', False):      # the HIP kernels take the upstream scalar as a pointer and multiply the
+            g = gw                                 # per-session coefficients by it themselves: no scaling launch
+            kw['gl'] = gloss.reshape(()).to(torch.float32)
         else:
-            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False)
+            g = (gw * gloss.reshape(()).to(torch.float32)).contiguous()
+        if tgrad is not None and tgrad.defer:
+            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False, tgrad, **kw)
+        else:
+            dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False, **kw)
         dsr = reduce_scatter_sum(dsr_part, group)
         return (dsr,) + (None,) * 11
 
@@ -566,8 +588,9 @@ class VocabParallel:
         items, uptr, upos = uniq[:3]
         n, U = idx.numel(), items.numel()
         ucap = self.capacity(U)
-        items64 = items.to(torch.int64)
-        items_pad = items64 if U == ucap else self._pad(items64, ucap)
+        # capacity-padded batches: the distinct-item field of the batch buffer IS the padded request list (int32, -1 in the
+        # unused slots) - no conversion, no copy; exact layouts pad a copy
+        items_pad = items if U == ucap else self._pad(items if items.dtype == torch.int32 else items.to(torch.int64), ucap)
         inv = self.local.inverse_index(uptr, upos, U, n)      # position -> slot of its item in `items`
         uq = (items, uptr[:U + 1], upos) + tuple(uniq[3:])
         self.lab_all = None

@@ -288,9 +288,13 @@ class FusedAdam(torch.optim.Optimizer):
                     if renorm_write:
                         mn = mn_model
                     d16, dp16 = (tb.E16, tb.E16.shape[1]) if tb is not None else (None, 0)
+                    # a row-sharded table is padded to whole scoring tiles: the rows past the shard's live count are zero,
+                    # get zero gradients and stay zero under Adam with coupled decay - the pass stops at the live rows
+                    shard = getattr(model, 'shard', None)
+                    n_rows = shard.n_live if (shard is not None and 0 < shard.n_live < p.shape[0]) else p.shape[0]
                     pend = tgrad.pending if (tgrad is not None and g.data_ptr() == tgrad.buf.data_ptr()) else None
                     if pend is not None:
-                        lib.srec_adam_rows_proj(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
+                        lib.srec_adam_rows_proj(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), n_rows,
                                                 p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, renorm_write, ptr(cs_out), cs_scale,
                                                 eps_mode, 1e-12, ptr(pend[1]), float(pend[2]), ptr(tgrad.radial), ptr(d16), dp16,
                                                 stream())
@@ -299,7 +303,7 @@ class FusedAdam(torch.optim.Optimizer):
                     else:
                         if tgrad is not None:
                             tgrad.materialize()
-                        lib.srec_adam_rows(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.shape[0],
+                        lib.srec_adam_rows(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), n_rows,
                                            p.shape[1], p.stride(0), ptr(hyper), use_wd, mn, renorm_write, ptr(cs_out), cs_scale,
                                            eps_mode, 1e-12, ptr(d16), dp16, stream())
                     if fold:

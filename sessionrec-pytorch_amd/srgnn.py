@@ -78,9 +78,18 @@ class _ScoringMixin:
     _fold_table_prep = True
 
     def _table_copy(self, st, W):
-        """the TableBF16 the optimizer's row pass should fill (None: no bf16 scoring on this path)"""
-        if self.shard is not None or not ops.use_bf16_scoring(W.shape[1]) or not W.is_cuda:
+        """the TableBF16 the optimizer's row pass should fill (None: no bf16 scoring on this path).  Row-sharded table: the
+        copy of this rank's LIVE rows that dist.HipLocal keeps (the scoring kernels read table[:n_live])."""
+        if not ops.use_bf16_scoring(W.shape[1]) or not W.is_cuda:
             return None
+        if self.shard is not None:
+            local, n_live = self.shard.local, self.shard.n_live
+            if not hasattr(local, '_tb') or n_live <= 0:
+                return None
+            live = W[:n_live] if n_live < W.shape[0] else W    # (the rows the scoring kernels read: VocabParallel._live)
+            tb = local._tb(live, False)
+            local._tb_written = ((live.data_ptr(), tuple(live.shape)), W._version)
+            return tb
         if st.get('tb16') is None:
             st['tb16'] = ops.TableBF16(W)
         return st['tb16']
