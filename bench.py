@@ -695,6 +695,7 @@ def main():
             step(dev_batches[0])
             coll = dict(D.STATS, captured_in_graph=False)
         coll['per'] = 'training step and rank'
+        coll['buckets'] = list(D.BUCKETS['bytes'])          # replicated-gradient all-reduces, in backward completion order
         coll['backend'] = dist.get_backend()
     regions, loss = run_timed(step, dev_batches, args.warmup, args.steps, max(args.repeats, 1), dist, dev)
     final_loss = loss.item()

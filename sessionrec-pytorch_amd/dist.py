@@ -34,6 +34,7 @@ FORCE = bool(os.environ.get('SREC_FORCE_COLLECTIVES'))
 # ------------------------------------------------------------------------------- collectives
 # `group` is a torch.distributed process group (None = the default one) OR an object with `srec_loopback = True`
 # (RecordingGroup / ReplayGroup below): the single-GPU rehearsal of one rank of an N-rank job.
+BUCKETS = {'bytes': []}                # payload of the replicated-gradient buckets of the last step (sync_replicated_grads)
 STATS = {'count': 0, 'bytes': 0}      # collectives issued through this module and their payload (bytes of the full exchanged
 #                                       buffer as this rank sees it): bench.py reports them per step
 
@@ -566,6 +567,15 @@ class VocabParallel:
         self.lab_all = None                 # ... and come back gathered for loss()
         self.eval_data_parallel = False     # evaluate(): True when every rank feeds its own equal-sized slice of a batch
         self._ws = {}
+        self.model = model
+        self._names = {id(p): n for n, p in model.named_parameters()} if hasattr(model, 'named_parameters') else {}
+        self._bucket_flat, self._bucket_early, self._bucket_zero = {}, {}, {}
+        self._side, self._side_used = None, False
+        self.early_launches = 0                # buckets whose all-reduce was issued from inside a backward pass (bucket_ready)
+        # side stream for the early buckets: on by default where the collective is RCCL between real ranks (it then runs beside
+        # the backward); a 1-rank / loopback rehearsal keeps one stream unless asked (graph branches cost there: DESIGN 7)
+        self.side_stream = bool(self.world > 1 and not _loop(group) and dist.is_initialized()
+                                and dist.get_backend(group) == 'nccl') or bool(os.environ.get('SREC_BUCKET_SIDE_STREAM'))
         model.shard = self
 
     def _pad(self, t, cap, fill=-1):
@@ -689,18 +699,86 @@ class VocabParallel:
             val, idx = val[self.rank * n_loc:(self.rank + 1) * n_loc], idx[self.rank * n_loc:(self.rank + 1) * n_loc]
         return val, idx.to(torch.int32)
 
+    # ---- replicated-parameter gradients: bucketed all-reduce, launched in backward order ----------------------------------
+    N_BUCKETS = 3
+
+    def _bucket_index(self, p, order):
+        """bucket of a replicated parameter: the model's own grouping by backward completion (model.grad_bucket(name): 0 = the
+        gradients that are complete first), else thirds of the parameter list from its end (the last layers' gradients come
+        first) - a function of the parameter list only, identical on every rank"""
+        fn = getattr(self.model, 'grad_bucket', None)
+        if fn is not None:
+            return max(0, min(self.N_BUCKETS - 1, int(fn(self._names.get(id(p), '')))))
+        i, n = order
+        return min(self.N_BUCKETS - 1, (n - 1 - i) * self.N_BUCKETS // max(n, 1))
+
+    def _bucket_pieces(self, ps):
+        pieces = []
+        for p in ps:
+            if p.grad is not None:
+                pieces.append(p.grad.reshape(-1))
+            else:                                      # this rank's batch gave it no gradient: zeros (static buffer)
+                z = self._bucket_zero.get(id(p))
+                if z is None:
+                    z = self._bucket_zero[id(p)] = torch.zeros(p.numel(), device=p.device, dtype=p.dtype)
+                pieces.append(z)
+        return pieces
+
+    def _bucket_reduce(self, k, pieces, side):
+        """concatenate into bucket k's static buffer and all-reduce it - on the side stream when `side` (the copy and the
+        collective then run beside whatever the compute stream does next; sync_replicated_grads joins before the optimizer)"""
+        n = sum(int(t.numel()) for t in pieces)
+        flat = self._bucket_flat.get(k)
+        if flat is None or flat.numel() != n:
+            flat = self._bucket_flat[k] = torch.empty(n, device=pieces[0].device, dtype=torch.float32)
+        if side:
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=flat.device)
+            self._side.wait_stream(cur)                # the gradients are complete; the buffer's last reader (Adam) is behind us
+            with torch.cuda.stream(self._side):
+                torch.cat(pieces, out=flat)
+                all_reduce_(flat, None, self.group)
+            self._side_used = True
+        else:
+            torch.cat(pieces, out=flat)
+            all_reduce_(flat, None, self.group)
+        return flat
+
+    def bucket_ready(self, k):
+        """called from inside the backward pass (ops.grad_mark placed by the model) when every gradient of bucket k has been
+        accumulated: its all-reduce is issued NOW, under the rest of the backward, instead of after it.  Only for a bucket all
+        of whose parameters carry a gradient on this rank (the steady state), never for the last bucket (it carries the
+        presence flags) - everything else is picked up by sync_replicated_grads."""
+        parts = getattr(self, '_bucket_parts', None)
+        if not _active(self.group) or parts is None or not (0 <= k < len(parts) - 1) or k in self._bucket_early or not parts[k]:
+            return
+        self.ops_flush()                               # deferred slab sums of the layers behind us: their gradients are written
+        if any(p.grad is None for p in parts[k]):
+            return
+        self._bucket_early[k] = self._bucket_reduce(k, self._bucket_pieces(parts[k]), self.side_stream)
+        self.early_launches += 1
+
+    def ops_flush(self):
+        from . import ops
+        ops.flush_deferred()
+
     def sync_replicated_grads(self, params, optimizer=None):
-        """sum the replicated-parameter gradients over ranks in ONE flat bucket whose layout is the same on every rank.
+        """sum the replicated-parameter gradients over ranks in N_BUCKETS flat buckets whose layout is the same on every
+        rank, in the order the backward pass completes them (bucket 0 first).  A bucket whose gradients were all complete
+        when the backward passed the model's marker (bucket_ready) is already on its way - on a side stream when
+        `side_stream` - ; the rest, always including the last one, are issued here, and the compute stream waits for the
+        side stream before the optimizer reads the result.
         `params` is the model's replicated parameter list (same order everywhere).  Which of them carry a gradient can
         differ between ranks and between steps (MSHGNN only instantiates the GAT modules of relations with live edges in
-        THIS rank's batch).  The bucket holds the parameters that had a gradient on ANY rank when the layout was agreed
+        THIS rank's batch).  The buckets hold the parameters that had a gradient on ANY rank when the layout was agreed
         on (first call: all-reduce(MAX) of a presence mask, outside any graph capture), a rank without a gradient for one
-        contributing zeros, followed by a tail of flags that rides in the same all-reduce: one presence count per
+        contributing zeros; the LAST bucket ends in a tail of flags that rides in its all-reduce: one presence count per
         bucketed parameter and one count of ranks holding a gradient for a parameter OUTSIDE the layout.  Eager steps
         read the tail back (one host sync): a parameter nobody had a gradient for this step is skipped like on one
         device (no weight decay on a zero gradient), and a late parameter makes every rank re-agree on the layout and
         repeat the exchange - the same decision everywhere, because it is taken on all-reduced values.  A captured
-        step replays the layout and the skip pattern of its capture.  With `optimizer` (FusedAdam) the reduced bucket is
+        step replays the layout and the skip pattern of its capture.  With `optimizer` (FusedAdam) the reduced buckets are
         handed over as the gradient source (views), so nothing is copied back per parameter."""
         if not _active(self.group):
             return
@@ -721,22 +799,21 @@ class VocabParallel:
             self._bucket_key = key
             self._bucket_zero = {}
             self._bucket_flags = None
+            n = len(params)
+            idx = {id(p): i for i, p in enumerate(params)}
+            parts = [[] for _ in range(self.N_BUCKETS)]
+            for p in self._bucket_live:
+                parts[self._bucket_index(p, (idx[id(p)], n))].append(p)
+            self._bucket_parts = parts
+            self._bucket_early = {}                        # (early results were laid out for the old partition)
         if getattr(self, '_bucket_key', None) != key:
             agree()
         for attempt in (0, 1):
             ps = self._bucket_live
+            parts = self._bucket_parts
             n_late = sum(1 for p in params if p.grad is not None and id(p) not in self._bucket_ids)
             if n_late and capturing:
                 raise RuntimeError('%d replicated parameters carry a gradient that the captured bucket layout has no room for' % n_late)
-            pieces = []
-            for p in ps:
-                if p.grad is not None:
-                    pieces.append(p.grad.reshape(-1))
-                else:                                      # this rank's batch gave it no gradient: zeros (static buffer)
-                    z = self._bucket_zero.get(id(p))
-                    if z is None:
-                        z = self._bucket_zero[id(p)] = torch.zeros(p.numel(), device=p.device, dtype=p.dtype)
-                    pieces.append(z)
             pat = tuple(p.grad is not None for p in ps) + (n_late,)
             fl = self._bucket_flags
             if fl is None or fl[0] != pat:                 # the tail changes only when this rank's presence pattern does
@@ -744,25 +821,38 @@ class VocabParallel:
                     raise RuntimeError('gradient presence pattern changed between the warm-up and the capture')
                 fl = self._bucket_flags = (pat, torch.tensor([1.0 if f else 0.0 for f in pat[:-1]] + [float(n_late)],
                                                             device=dev, dtype=torch.float32))
-            flat = torch.cat(pieces + [fl[1]])
-            all_reduce_(flat, None, self.group)
+            flats = []
+            last = len(parts) - 1
+            for k, bp in enumerate(parts):
+                if k in self._bucket_early:
+                    flats.append(self._bucket_early[k])
+                    continue
+                pieces = self._bucket_pieces(bp) + ([fl[1]] if k == last else [])
+                flats.append(self._bucket_reduce(k, pieces, False) if pieces else None)
+            self._bucket_early = {}
+            if getattr(self, '_side_used', False):         # join: the optimizer reads the early buckets on the compute stream
+                torch.cuda.current_stream().wait_stream(self._side)
+                self._side_used = False
+            BUCKETS['bytes'] = [0 if f is None else int(f.numel()) * 4 for f in flats]
             nfl = len(ps) + 1
             seen = None
             if not capturing:
-                seen = flat[-nfl:].tolist()
+                seen = flats[last][-nfl:].tolist()
                 if seen[-1] > 0 and attempt == 0:          # somebody holds a gradient the layout has no slot for: everybody
                     agree()                                # sees the same count - re-agree and repeat the exchange
                     continue
                 self._bucket_seen = seen
             break
         seen = getattr(self, '_bucket_seen', None)
-        off = 0
+        pos = {id(p): i for i, p in enumerate(ps)}
         views = {}
-        for i, p in enumerate(ps):
-            n = p.numel()
-            if seen is None or seen[i] > 0:                # nobody had a gradient this step: skipped, as on one device
-                views[id(p)] = flat[off:off + n].view_as(p)
-            off += n
+        for k, bp in enumerate(parts):
+            off = 0
+            for p in bp:
+                n = p.numel()
+                if seen is None or seen[pos[id(p)]] > 0:   # nobody had a gradient this step: skipped, as on one device
+                    views[id(p)] = flats[k][off:off + n].view_as(p)
+                off += n
         if optimizer is not None and hasattr(optimizer, 'grad_override'):
             optimizer.grad_override = views
         else:

@@ -257,6 +257,14 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         self.fusion, self.extra = fusion, extra
         self._max_norm = 1.0
 
+    @staticmethod
+    def grad_bucket(name):
+        """bucket of a replicated parameter's gradient in backward completion order (dist.VocabParallel): 0 = read-out head and
+        mixture weights (complete first), 1 = the MSHGNN layers, 2 = the k-gram expander and everything else (complete last)"""
+        if name.startswith(('readout.', 'fc_sr.', 'sc_sr.', 'alpha', 'beta')):
+            return 0
+        return 1 if name.startswith('layers.') else 2
+
     def reset_parameters(self):
         stdv = 1 / math.sqrt(self.embedding_dim)
         for w in self.parameters():
@@ -371,8 +379,15 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             stacked = stacked0 if stacked0 is not None else (
                 feats[1] if K == 1 else torch.cat([feats[k] for k in range(1, K + 1)], 0))
             multi = self.shard is not None and self.shard.world > 1       # (see MSHGNN.plan: live = live in the GLOBAL batch)
+            # row-sharded training: the replicated gradients are all-reduced in buckets as the backward completes them
+            # (dist.VocabParallel.bucket_ready): the GAT layers' when it passes below them, the read-out head's above them
+            early = getattr(self.shard, 'bucket_ready', None) if (self.shard is not None and self.training) else None
+            if early is not None:
+                stacked = ops.grad_mark(stacked, lambda: early(1))
             for layer in self.layers:
                 stacked = layer.forward_stacked(mg, stacked, multi)
+            if early is not None:
+                stacked = ops.grad_mark(stacked, lambda: early(0))
             fuse_npp = self.norm and 1 < K <= 4 and stacked.is_cuda
             if self.norm and not fuse_npp:
                 stacked = ops.normalize(stacked, 0, mg.dynp('N1') if K == 1 else None)   # padded rows are exact zeros

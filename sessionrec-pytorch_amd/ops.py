@@ -686,6 +686,26 @@ def flush_deferred():
         _launch_slab_sums(tasks)
 
 
+class GradMark(torch.autograd.Function):
+    """identity; its backward calls fn() when the gradient of x has arrived - i.e. when every node downstream of x, and the
+    AccumulateGrad nodes of their parameters (the engine runs those first), are done.  dist.VocabParallel.bucket_ready hangs
+    the early launch of a gradient bucket's all-reduce here."""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return g, None
+
+
+def grad_mark(x, fn):
+    return GradMark.apply(x, fn) if (x.requires_grad and torch.is_grad_enabled()) else x
+
+
 class NormPermutePick(torch.autograd.Function):
     """(allf, v_0, v_1, ...) = (normalize(x)[perm], normalize(x)[pick_0], ...): MSGIFSR between its last MSHGNN layer and the
     read-out (msgifsr.py:260-264 F.normalize, :131-147 per-session concatenation and last-node picks) in ONE launch, and its

@@ -189,6 +189,8 @@ def run_rank(rank, world, port, case, outdir):
                 rec['dE'] = keep(tg.buf[:vp.n_live])
                 rec['grads'] = {names[i]: g.detach().cpu().clone() for i, g in (opt.grad_override or {}).items()}
             opt.step()
+            rec['buckets'] = list(D.BUCKETS['bytes'])
+            rec['early'] = vp.early_launches
             rec['table'] = keep(model._table().detach()[:vp.n_live])
             rec['params'] = {k: p.detach().cpu().clone() for k, p in model.named_parameters() if p is not model._table()}
             if group is not None:

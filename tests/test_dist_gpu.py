@@ -144,6 +144,15 @@ def test_sharded_ranks_on_one_gpu_match_the_single_device_step(dev, tmp_path, na
     # the exchange really happened: > 0 collectives per step, the same count on every rank
     counts = {out['steps'][1]['collectives']['count'] for out in res}
     assert len(counts) == 1 and min(counts) >= 5, counts
+    # the replicated gradients travel in three buckets in backward completion order (dist.VocabParallel.sync_replicated_grads),
+    # with the same byte layout on every rank; MSGIFSR's first two (read-out head, MSHGNN layers) are issued from INSIDE the
+    # backward pass (ops.grad_mark -> bucket_ready) on every rank whose batch gives all their parameters a gradient - from the
+    # second step on (the first agrees on the layout)
+    lay = {tuple(out['steps'][1]['buckets']) for out in res}
+    assert len(lay) == 1 and len(next(iter(lay))) == 3 and sum(next(iter(lay))) > 0, lay
+    if name.startswith('msgifsr') and '_fus' not in name and '_ext' not in name and not opts:
+        assert all(b > 0 for b in next(iter(lay))), lay
+        assert all(out['steps'][1]['early'] == 2 for out in res), [out['steps'][1]['early'] for out in res]
     if opts.get('dead'):
         # the short-session rank has no edges of the higher-order relations; in a multi-rank job every relation of the schema
         # counts as live (it is, in the global batch: msgifsr.MSHGNN.plan), so its nodes still get those relations' residual
@@ -281,9 +290,10 @@ def test_sharded_ranks_at_the_c5_shape(dev, tmp_path, precision, world, V, steps
         ref, extra, live, peak = _plain_big(case, world, dev, steps)
         _compare_big(case, world, res, ref, extra, bf16=(precision == 'bf16'))
         print('single-device peak memory %.1f GiB' % peak)
-        # 7 collectives per step (+ the one-off agreement on the gradient-bucket layout in the first step)
+        # 6 exchanges of the sharded table + 3 gradient buckets per step (+ the one-off agreement on the bucket layout in the
+        # first step)
         counts = {out['steps'][-1]['collectives']['count'] for out in res}
-        assert counts == ({8} if steps == 1 else {7}), counts
+        assert counts == ({10} if steps == 1 else {9}), counts
     finally:
         pkg('ops').set_precision('fp32')
         torch.cuda.empty_cache()
@@ -361,6 +371,8 @@ def test_one_rank_of_the_job_replayed_under_hipgraph_capture(dev, tmp_path, name
     group = D.ReplayGroup(world, rank, dev).load(job['steps'][0]['tape'])
     vp = D.VocabParallel(model, group=group, idx_cap=inputs[0].cap('uniq_items'))
     assert (vp.lo, vp.hi) == (job['lo'], job['hi'])
+    # the early gradient buckets on a SIDE stream (what an RCCL job does), forked and joined inside the captured step
+    vp.side_stream = name.startswith('msgifsr')
     opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
     replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
     model.train()
@@ -395,6 +407,8 @@ def test_one_rank_of_the_job_replayed_under_hipgraph_capture(dev, tmp_path, name
     nodes = gs.node_counts()
     if nodes is not None:
         assert nodes['kernel'] > 10
+    if name.startswith('msgifsr'):
+        assert vp.early_launches >= 2 and vp._side is not None      # buckets 0 and 1 left from inside the (captured) backward
 
 
 def test_bench_two_ranks_over_gloo_on_one_gpu(dev):
@@ -402,7 +416,7 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(dev):
     with two ranks, both on cuda:0, collectives over gloo staged through the host (SREC_BENCH_BACKEND=gloo) - the complete
     N-rank line (`n_gpus`, `ranks_seen`, `collectives`, `scaling`, `config.global_batch`) is produced once before an 8-GPU
     node ever runs it.  Host-staged collectives cannot be captured in a hipGraph, so this run also takes bench.py's
-    "capture of the collectives refused" branch: both ranks agree to fall back, and the EAGER steps with the 7 collectives
+    "capture of the collectives refused" branch: both ranks agree to fall back, and the EAGER steps with the 9 collectives
     train to a finite loss."""
     import json
     import subprocess
@@ -421,7 +435,9 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(dev):
     assert out['unit'] == 'sessions/s' and out['value'] > 0 and out['steps'] == 3
     assert out['config']['global_batch'] == 1024 and 'row-sharded x2' in out['config']['parallelism']
     c = out['collectives']
-    assert c['count'] == 7 and c['backend'] == 'gloo' and c['captured_in_graph'] is False and c['bytes'] > 0
+    assert c['count'] == 9 and c['backend'] == 'gloo' and c['captured_in_graph'] is False and c['bytes'] > 0
+    # the replicated gradients travel as three all-reduces in backward completion order: read-out head, MSHGNN layers, rest
+    assert len(c['buckets']) == 3 and all(b > 0 for b in c['buckets']) and c['buckets'][1] > c['buckets'][0]
     assert out['launch'] == 'eager' and 'graph capture with the collectives failed' in p.stderr
     assert 1.0 < out['config']['final_loss'] < 12.0          # ~ln V at the start of training
     assert out['roofline']['frac'] > 0 and out['cpu_baseline'] is None and out['fp32'] is None
