@@ -828,11 +828,19 @@ class VocabParallel:
                     flats.append(self._bucket_early[k])
                     continue
                 pieces = self._bucket_pieces(bp) + ([fl[1]] if k == last else [])
-                flats.append(self._bucket_reduce(k, pieces, False) if pieces else None)
+                # (under capture also the late buckets leave on the side stream: the table's Adam pass runs beside them)
+                flats.append(self._bucket_reduce(k, pieces, self.side_stream and capturing) if pieces else None)
             self._bucket_early = {}
-            if getattr(self, '_side_used', False):         # join: the optimizer reads the early buckets on the compute stream
-                torch.cuda.current_stream().wait_stream(self._side)
+            if getattr(self, '_side_used', False):
+                # join: the early buckets become visible to the compute stream.  FusedAdam takes the join over and places it
+                # behind its row pass over the table, which needs none of these gradients (optim.FusedAdam.grad_join) - unless
+                # this (eager) step is about to read the flag tail back, which synchronises anyway
                 self._side_used = False
+                if capturing and optimizer is not None and hasattr(optimizer, '_join_grads'):
+                    side = self._side
+                    optimizer.grad_join = lambda: torch.cuda.current_stream().wait_stream(side)
+                else:
+                    torch.cuda.current_stream().wait_stream(self._side)
             BUCKETS['bytes'] = [0 if f is None else int(f.numel()) * 4 for f in flats]
             nfl = len(ps) + 1
             seen = None

@@ -312,6 +312,7 @@ class FusedAdam(torch.optim.Optimizer):
                     if cs_out is not None:
                         st['cs_fresh'] = True
                 else:
+                    self._join_grads()
                     lib.srec_adam_flat(ptr(p), ptr(g), ptr(state['exp_avg']), ptr(state['exp_avg_sq']), p.numel(),
                                        ptr(hyper), use_wd, stream())
             for slot, rows in multi.items():
@@ -327,6 +328,7 @@ class FusedAdam(torch.optim.Optimizer):
                 elif wd != 0 and ent[1] == 0:
                     ent[0], ent[1] = gi, wd          # the launch reads the hyper-parameters of the group that decays
                 ent[2] += [(p, g, st_, use_wd) for p, g, st_ in rows]
+        self._join_grads()                           # (the table's row pass above needs none of the replicated gradients)
         for key, (gi, _, rows) in merged.items():    # every small tensor that steps together in ONE launch (by-value descriptor)
             slot = key[4]
             nt = len(rows)
@@ -341,6 +343,15 @@ class FusedAdam(torch.optim.Optimizer):
             tgrad.fresh = False
         from . import ops
         ops.weights_changed()
+
+    grad_join = None          # callable: make the all-reduced replicated gradients (grad_override) visible to the compute stream -
+    #                           dist.VocabParallel leaves the join of its side stream to the optimizer, which calls it AFTER the
+    #                           table's row pass (independent of every collective) and before the first kernel that reads them
+
+    def _join_grads(self):
+        j, self.grad_join = self.grad_join, None
+        if j is not None:
+            j()
 
     @torch.no_grad()
     def step(self, closure=None):
