@@ -521,3 +521,78 @@ def test_rank_slice_sampler_counts_batches_without_a_long_session():
     assert len(out) == len(s) == (len(ds) + 3) // 4
     # samples 0..11 are the prefixes of the three long sessions (one of 4 clicks in every batch of four), the rest 1-click
     assert s.short_batches == len(out) - 3
+
+
+def test_c4_sized_ingest_index_caps_and_rank_slices(tmp_path):
+    """Config C4 (MSGIFSR on Yoochoose-1/4, the table row-sharded over 8 GPUs) on the HOST side at its real size: ~1.3 M
+    sessions -> ~6 M prefix samples through dataset.read_dataset(cache=True) (text -> binary SessionStore, then the cached
+    store), the vectorised prefix index, collate.measure_caps on the rank slices, dataset.RankSliceBatchSampler (rank 3 of 8
+    of every 512-sample batch) and 200 batches of the ring loader - bounded in time and memory (the reference's own path -
+    pandas + Python lists + per-sample Python in DataLoader workers - takes minutes and several GB here)."""
+    import resource
+    import time
+    from torch.utils.data import SequentialSampler
+    C, L, DS = pkg('collate'), pkg('loader'), pkg('dataset')
+    if C._native() is None:
+        pytest.skip('libsrec_collate.so not built')
+    rng = np.random.default_rng(123)
+    n_sess, V = 1_300_000, 37_484
+    lens = np.clip(rng.geometric(1 / 4.6, n_sess) + 1, 2, 20)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    items = np.minimum((V ** rng.random(int(offs[-1]))).astype(np.int64), V - 1)      # log-uniform ~ Zipf(1) popularity
+    d = tmp_path / 'yc14'
+    d.mkdir()
+    t0 = time.time()
+    with open(d / 'train.txt', 'w') as f:
+        txt = ','.join(map(str, items.tolist()))
+        # (one join over all clicks, then the commas at session boundaries become newlines: fast enough for 6 M clicks)
+        digits = np.char.str_len(items.astype(str)) + 1
+        ends = np.cumsum(digits)[offs[1:] - 1] - 1
+        b = bytearray(txt, 'ascii')
+        for e in ends[:-1].tolist():
+            b[e] = 10
+        f.write(b.decode('ascii') + '\n')
+    (d / 'test.txt').write_text('1,2,3\n4,5\n')
+    (d / 'num_items.txt').write_text(str(V))
+    t_write = time.time() - t0
+    t0 = time.time()
+    tr, te, nv = DS.read_dataset(d, cache=True)
+    t_first = time.time() - t0
+    t0 = time.time()
+    tr2, _, _ = DS.read_dataset(d, cache=True)
+    t_cached = time.time() - t0
+    assert nv == V and len(tr) == n_sess == len(tr2) and list(tr[7]) == items[offs[7]:offs[8]].tolist() == list(tr2[7])
+    t0 = time.time()
+    ds = DS.AugmentedDataset(tr2)
+    t_index = time.time() - t0
+    n = len(ds)
+    assert n == int((lens - 1).sum()) and n > 4_000_000
+    seq, lab = ds[n - 1]
+    assert lab == int(items[offs[-1] - 1]) and len(seq) == lens[-1] - 1
+    world, rank, gb = 8, 3, 512
+    bsamp = DS.RankSliceBatchSampler(SequentialSampler(ds), gb, rank, world, prefix_len=ds.index[:, 1], need_len=4)
+    t0 = time.time()
+    caps = C.measure_caps(ds, gb // world, 'ccs', 3)
+    t_caps = time.time() - t0
+    assert caps['B'] == gb // world and caps['N'] % 256 == 0
+    ld = L.PinnedRingLoader(ds, bsamp, 'ccs', order=3, caps=caps, num_workers=4, slots=8, pin=False)
+    t0 = time.time()
+    try:
+        seen = exact = 0
+        for k, (inp, labels) in enumerate(ld):
+            mine = bsamp.slice_of(list(range(k * gb, min(n, (k + 1) * gb))))
+            assert labels[:len(mine)].tolist() == [int(ds[i][1]) for i in mine]
+            assert inp[0].count('B') == len(mine)
+            exact += not inp[0].meta.get('padded')
+            seen += 1
+            if seen == 200:
+                break
+    finally:
+        ld.close()
+    t_loader = time.time() - t0
+    rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    print('C4-sized host path: %d sessions, %d samples; text written %.1f s, read_dataset first %.1f s / cached %.2f s, index %.1f s, '
+          'measure_caps %.2f s, 200 ring-loader batches %.2f s (%d unpadded), peak RSS %.2f GB' % (
+              n_sess, n, t_write, t_first, t_cached, t_index, t_caps, t_loader, exact, rss))
+    assert seen == 200 and exact <= 20
+    assert t_first < 60 and t_cached < 5 and t_index < 30 and t_caps < 10 and t_loader < 30 and rss < 4.0
