@@ -349,6 +349,10 @@ int srec_hg_drop_prep16(const float* x, const float* cnt, int rows, int D, float
  * salt, the mask tensor is then neither written nor read) */
 int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx, float p, int seed, const int* counter,
                        int salt, void* stream);
+/* feature-dropout calls: desc.p16 bit 2 makes srec_hg_bwd leave dx alone; after the caller's backward-data GEMMs
+ * srec_hg_pre_merge writes the whole d x in one pass (the pre-fill of srec_hg_bwd + srec_hg_drop_merge: one kernel, one pass
+ * over dx less); t [2, S, NT, D] as for srec_hg_drop_merge, masks recomputed from desc.rm_* */
+int srec_hg_pre_merge(const void* desc, const float* g, int ld_g, const float* t, int S, float* dx, int ld_dx, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
                 int ld_dx, float* ws, void* stream);
 

@@ -26,7 +26,8 @@ typedef struct {
     int H, D, n_types, n_mods, n_blocks, n_inst, B;
     float slope;
     int p16;                       /* bit 0: P / dP hold bf16 (2-byte) elements (0: fp32); bit 1 (srec_hg_bwd): leave the dP rows past
-                                      the live count unwritten - the caller's readers of dP stop at *dyn_n (srec_gemm16_group.dyn) */
+                                      the live count unwritten - the caller's readers of dP stop at *dyn_n (srec_gemm16_group.dyn);
+                                      bit 2 (srec_hg_bwd): do not write dx - the caller finishes it with srec_hg_pre_merge */
     const int* dynB;
     /* node types */
     int row0[SREC_HG_MAXT], ncap[SREC_HG_MAXT];

@@ -685,7 +685,11 @@ struct PreArgs {
 };
 
 // dx[row,:] = nres * g[row,:] + (1/n_session) * sum_{rows of the session} g   (residual + session-mean terms)
-__global__ void hg_pre_kernel(PreArgs a) {
+// MERGE: ... + (sum_s t[0][s]) * ms0 + (sum_s t[1][s]) * ms1, the two convs' masked data gradients (S partial sums each, t [2, S,
+// NT, D] contiguous; masks recomputed from the hash of hg_drop_prep as for the residual scale) - the layer's whole d x in ONE
+// pass at the end of its backward instead of a pre-fill here and a read-modify-write in hg_drop_merge (srec_hg_pre_merge)
+template <bool MERGE>
+__global__ void hg_pre_kernel(PreArgs a, const float* __restrict__ tm = nullptr, int S = 0) {
     const int row = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.row0[a.nt]) return;
     const int t = find_range(a.row0, a.nt, row);
@@ -728,6 +732,24 @@ __global__ void hg_pre_kernel(PreArgs a) {
         }
         o.x = o.x * inv + rs.x * gv.x; o.y = o.y * inv + rs.y * gv.y;
         o.z = o.z * inv + rs.z * gv.z; o.w = o.w * inv + rs.w * gv.w;
+    }
+    if (MERGE) {
+        const int NT = a.row0[a.nt];
+        const size_t n = (size_t)NT * a.D, i = (size_t)row * a.D + c;
+        float4 s0 = *reinterpret_cast<const float4*>(tm + i), s1 = *reinterpret_cast<const float4*>(tm + (size_t)S * n + i);
+        for (int s = 1; s < S; ++s) {
+            const float4 a2 = *reinterpret_cast<const float4*>(tm + (size_t)s * n + i);
+            const float4 b2 = *reinterpret_cast<const float4*>(tm + (size_t)(S + s) * n + i);
+            s0.x += a2.x; s0.y += a2.y; s0.z += a2.z; s0.w += a2.w;
+            s1.x += b2.x; s1.y += b2.y; s1.z += b2.z; s1.w += b2.w;
+        }
+        const unsigned key = srec_rng_key(a.rm_rng);
+        const float p = a.rm_p, sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+        const unsigned i0 = (unsigned)i, i1 = (unsigned)(n + i);
+        o.x += s0.x * srec_keep(key, i0, p, sc) + s1.x * srec_keep(key, i1, p, sc);
+        o.y += s0.y * srec_keep(key, i0 + 1, p, sc) + s1.y * srec_keep(key, i1 + 1, p, sc);
+        o.z += s0.z * srec_keep(key, i0 + 2, p, sc) + s1.z * srec_keep(key, i1 + 2, p, sc);
+        o.w += s0.w * srec_keep(key, i0 + 3, p, sc) + s1.w * srec_keep(key, i1 + 3, p, sc);
     }
     *reinterpret_cast<float4*>(a.dx + (size_t)row * a.ld_dx + c) = o;
 }
@@ -1621,6 +1643,39 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     return 0;
 }
 
+static int fill_pre(const srec_hg_desc* d, const float* g, int ld_g, float* dx, int ld_dx, PreArgs& a) {
+    int ninst_t[MAXT] = {0, 0, 0, 0};
+    for (int i = 0; i < d->n_inst; ++i) ninst_t[d->blk_type[d->inst_dblk[i]]]++;
+    a.nt = d->n_types; a.B = d->B; a.D = d->D; a.dynB = d->dynB; a.g = g; a.ld_g = ld_g; a.dx = dx; a.ld_dx = ld_dx; a.rm = d->rm;
+    a.rm_cnt = d->rm_cnt; a.rm_p = d->rm_p; a.rm_rng = srec_rng{(unsigned)d->rm_seed, d->rm_counter, (unsigned)d->rm_salt, d->rm_p};
+    a.sess = d->sess;
+    if (d->sess == nullptr) return SREC_BAD_ARG;
+    int rows = 0;
+    for (int t = 0; t < d->n_types; ++t) {
+        a.seg[t] = d->seg[t]; a.dyn_n[t] = d->dyn_n[t]; a.row0[t] = d->row0[t]; a.ncap[t] = d->ncap[t];
+        a.ninst[t] = ninst_t[t];
+        rows += d->ncap[t];
+    }
+    a.row0[d->n_types] = rows;
+    return 0;
+}
+
+// the layer's d x in one pass, AFTER the backward-data GEMMs of a feature-dropout call (desc.p16 bit 2 made srec_hg_bwd leave
+// d x alone): dx [NT, D] = residual + session-mean terms of g (as srec_hg_bwd would have written) + the two convs' masked data
+// gradients t [2, S, NT, D] (as srec_hg_drop_merge would have added); masks from desc.rm_p / rm_seed / rm_counter / rm_salt.
+extern "C" int srec_hg_pre_merge(const void* desc_, const float* g, int ld_g, const float* t, int S, float* dx, int ld_dx,
+                                 void* stream) {
+    const srec_hg_desc* d = (const srec_hg_desc*)desc_;
+    if (bad_desc(d) || (ld_g & 3) || (ld_dx & 3) || t == nullptr || S < 1 || d->rm_cnt == nullptr) return SREC_BAD_ARG;
+    PreArgs a{};
+    if (int rc = fill_pre(d, g, ld_g, dx, ld_dx, a)) return rc;
+    const int rows = a.row0[d->n_types];
+    if ((long)2 * rows * d->D > 0xffffffffL) return SREC_BAD_ARG;
+    if (rows > 0) hipLaunchKernelGGL(hg_pre_kernel<true>, dim3(cdiv(rows, WPB)), dim3(256), 0, (hipStream_t)stream, a, t, S);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg,
                            float* dx, int ld_dx, float* ws, void* stream) {
     const srec_hg_desc* d = (const srec_hg_desc*)desc_;
@@ -1631,19 +1686,11 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
     int ninst_t[MAXT] = {0, 0, 0, 0};
     for (int i = 0; i < d->n_inst; ++i) ninst_t[d->blk_type[d->inst_dblk[i]]]++;
     int rows = 0;
-    {
+    for (int t = 0; t < d->n_types; ++t) rows += d->ncap[t];
+    if (!(d->p16 & 4)) {                       // (bit 2: the caller finishes d x with srec_hg_pre_merge after its GEMMs)
         PreArgs a{};
-        a.nt = d->n_types; a.B = d->B; a.D = D; a.dynB = d->dynB; a.g = g; a.ld_g = ld_g; a.dx = dx; a.ld_dx = ld_dx; a.rm = d->rm;
-        a.rm_cnt = d->rm_cnt; a.rm_p = d->rm_p; a.rm_rng = srec_rng{(unsigned)d->rm_seed, d->rm_counter, (unsigned)d->rm_salt, d->rm_p};
-        a.sess = d->sess;
-        if (d->sess == nullptr) return SREC_BAD_ARG;
-        for (int t = 0; t < d->n_types; ++t) {
-            a.seg[t] = d->seg[t]; a.dyn_n[t] = d->dyn_n[t]; a.row0[t] = d->row0[t]; a.ncap[t] = d->ncap[t];
-            a.ninst[t] = ninst_t[t];
-            rows += d->ncap[t];
-        }
-        a.row0[d->n_types] = rows;
-        if (rows > 0) hipLaunchKernelGGL(hg_pre_kernel, dim3(cdiv(rows, WPB)), dim3(256), 0, st, a);
+        if (int rc = fill_pre(d, g, ld_g, dx, ld_dx, a)) return rc;
+        if (rows > 0) hipLaunchKernelGGL(hg_pre_kernel<false>, dim3(cdiv(rows, WPB)), dim3(256), 0, st, a, (const float*)nullptr, 0);
     }
     if (d->n_inst > 0) {
         DstArgs a{};

@@ -2705,6 +2705,10 @@ class HGATLayer(torch.autograd.Function):
         desc = plan.fill(HgDesc(), small, lay, P, dP, flat, grads, dstate)
         if ctx.g16 is not None and desc.p16:
             desc.p16 |= 2           # both gemm16 consumers of dP stop at the live rows: srec_hg_bwd leaves capacity-padding rows unwritten
+        # feature dropout with recomputed masks: d x is written once, after the backward-data GEMMs (srec_hg_pre_merge)
+        late_dx = dstate is not None and dstate[2] is None and len(dstate) > 6 and dstate[4] is None and _ld(g) % 4 == 0
+        if late_dx:
+            desc.p16 |= 4
         n = _ct.c_long()
         lib.srec_hg_ws_floats(_ct.addressof(desc), _ct.addressof(n))
         key = (dev.index, n.value)
@@ -2769,7 +2773,9 @@ class HGATLayer(torch.autograd.Function):
             batch = [pr for pr, b in pend if b == beta][:16]
             pend = [(pr, b) for pr, b in pend if not any(pr is q for q in batch)]
             gemm16('nt', batch, HD, HD, D, beta=beta)
-        if dstate is not None:
+        if late_dx:
+            lib.srec_hg_pre_merge(_ct.addressof(desc), ptr(g), _ld(g), ptr(tgts), S, ptr(dx), D, stream())
+        elif dstate is not None:
             pf_, seed_, rc_, salt_ = dstate[5]
             lib.srec_hg_drop_merge(ptr(tgts), S, ptr(dstate[4]), NT * D, ptr(dx), pf_, seed_, rc_, salt_, stream())
         if ctx.g16 is not None:
