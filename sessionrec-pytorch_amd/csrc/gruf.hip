@@ -292,6 +292,244 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_kernel(FusedArgs a) 
 #endif
 }
 
+// ---- 16-node workgroups with the INPUT projections of all time steps batched -----------------------------------------------
+// x_t W_ih^T has no recurrence: the rows of all k <= 4 time steps of the 16 nodes (tile row = 16 t + node: 32 - 64 rows) go
+// through ONE pass over W_ih, whose fragments then feed full 32-row MFMA tiles, instead of one half-empty pass per step.  A
+// workgroup streams W_ih + (k - 1) W_hh instead of k W_ih + (k - 1) W_hh - 2 / 3 of the bytes at order 2, 3 / 5 at order 3, and
+// this kernel runs at what the L2s deliver (see the head of the file).  The projections gi of every step wait in registers
+// (MFMA result layout: registers 8 (t & 1) .. + 7 of tile t >> 1 hold the 16 nodes of step t); the recurrent half and the gate
+// epilogue are those of gru_fused_fwd_kernel (r / z pre-activations = gi + gh, two chains added instead of one chain).
+template <int DD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd16_kernel(FusedArgs a) {
+    constexpr int NR = 16;
+    constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;
+    constexpr int KS = D / 16, NF = 3 * JB, NRR = NR / 2;
+    constexpr int KMAX = 4;                      // time steps (k-gram order) this kernel holds projections for: 2 tiles of 32 rows
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
+    unsigned short* xt = sm;                     // [64][D] bf16, swizzled: rows 16 t + node
+    unsigned short* ht = sm + 64 * D;            // [32][D]
+    constexpr int PS = 40;
+    const srec_gru_fused_desc& q = a.d;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < GF_MAXP; ++i)
+        if (i < q.np && (int)blockIdx.x >= a.start[i]) p = i;
+    const int n = q.n[p], k = q.k[p];
+    const int node0 = ((int)blockIdx.x - a.start[p]) * NR;
+    if (node0 >= n) return;
+    const int nl = dyn_count(q.dyn[p], n);
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* X = q.X[p];
+    unsigned short* X16 = (unsigned short*)q.X16[p];
+    float* H = q.H[p];
+    unsigned short* H16 = (unsigned short*)q.H16[p];
+    float* out = q.out[p];
+
+    if (node0 >= nl) {                           // capacity padding: zero rows, no arithmetic
+        const int rows = min(NR, n - node0);
+        for (int i = tid; i < rows * (D / 4); i += NT) {
+            const int row = i / (D / 4), c = (i % (D / 4)) * 4;
+            const size_t node = (size_t)(node0 + row);
+            for (int t = 0; t < k; ++t) {
+                *reinterpret_cast<float4*>(H + ((size_t)t * n + node) * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < k - 1) *reinterpret_cast<uint2*>(H16 + ((size_t)t * n + node) * D + c) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(X16 + (node * k + t) * D + c) = make_uint2(0u, 0u);
+            }
+            *reinterpret_cast<float4*>(out + node * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    float* patch = reinterpret_cast<float*>(sm + 96 * D) + wave * NR * PS;              // this wave's [NR][PS] patch
+    const int cbase = wave * 32 * JB;
+    float b_r[JB], b_z[JB], b_in[JB], b_hn[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int col = cbase + 32 * j + l31;
+        b_r[j] = q.bih[p][col] + q.bhh[p][col];
+        b_z[j] = q.bih[p][D + col] + q.bhh[p][D + col];
+        b_in[j] = q.bih[p][2 * D + col];
+        b_hn[j] = q.bhh[p][2 * D + col];
+    }
+    const unsigned short* wf_ih = (const unsigned short*)q.Wih_f[p] + (size_t)wave * KS * NF * 512 + lane * 8;
+    const unsigned short* wf_hh = (const unsigned short*)q.Whh_f[p] + (size_t)wave * KS * NF * 512 + lane * 8;
+    bf16x8 Bq[NS][NF];
+    auto load = [&](const unsigned short* wf, int i, int slot) {
+        i = min(i, KS - 1);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) Bq[slot][f] = *reinterpret_cast<const bf16x8*>(wf + ((size_t)i * NF + f) * 512);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load(wf_ih, i, i);            // (the first fragments fly under the staging of x)
+
+    // ---- x of ALL time steps: bf16 into the two LDS tiles (row 16 t + node) and into the weight-gradient GEMM's operand copy
+    for (int i = tid; i < k * NR * (D / 4); i += NT) {
+        const int c4 = i % (D / 4), rn = i / (D / 4), node_l = rn % NR, t = rn / NR;
+        const int node = node0 + node_l, row = NR * t + node_l;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (node < n) v = *reinterpret_cast<const float4*>(X + ((unsigned)node * k + t) * (size_t)D + c4 * 4);
+        uint2 o;
+        o.x = srec_pack_bf16(v.x, v.y); o.y = srec_pack_bf16(v.z, v.w);
+        const int pos = (c4 >> 1) ^ (row & 15);
+        *reinterpret_cast<uint2*>(xt + row * D + pos * 8 + (c4 & 1) * 4) = o;
+        if (node < n) *reinterpret_cast<uint2*>(X16 + ((unsigned)node * k + t) * (size_t)D + c4 * 4) = o;
+    }
+    __syncthreads();
+
+    // ---- gi of all steps: one pass over W_ih, every fragment feeds both row tiles (the second only when k > 2)
+    f32x16 gi[3][2][JB];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gi[g][tl][j][r] = 0.f;
+    const bool two = k > 2;
+#pragma unroll 1
+    for (int ib = 0; ib < KS; ib += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            load(wf_ih, ib + u + PF, (u + PF) % NS);
+            const int s = ib + u;
+            const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(xt + l31 * D + (((2 * s + half) ^ (l31 & 15)) * 8));
+            const bf16x8 A1 = *reinterpret_cast<const bf16x8*>(xt + (32 + l31) * D + (((2 * s + half) ^ (l31 & 15)) * 8));
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int j = 0; j < JB; ++j) gi[g][0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bq[u][g * JB + j], gi[g][0][j], 0, 0, 0);
+            if (two) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) gi[g][1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bq[u][g * JB + j], gi[g][1][j], 0, 0, 0);
+            }
+        }
+    }
+    // the recurrent weights' first fragments: requested now, they land under the first gate epilogue
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load(wf_hh, i, i);
+
+    float hprev[JB][NRR];
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int r = 0; r < NRR; ++r) hprev[j][r] = 0.f;
+    const bool full = node0 + NR <= nl;
+    auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); };
+    const float ik = 0.5f / (float)k;
+
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+        if (t >= k) break;
+        f32x16 ar[JB], az[JB], ahn[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ar[j][r] = az[j][r] = ahn[j][r] = 0.f;
+        if (t > 0) {
+            // h_{t-1} W_hh^T (nodes in rows 0 .. 15 of the tile; the upper half is idle)
+#pragma unroll 1
+            for (int ib = 0; ib < KS; ib += NS) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    load(wf_hh, ib + u + PF, (u + PF) % NS);
+                    const int s = ib + u;
+                    const bf16x8 A = *reinterpret_cast<const bf16x8*>(ht + l31 * D + (((2 * s + half) ^ (l31 & 15)) * 8));
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) {
+                        ar[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bq[u][j], ar[j], 0, 0, 0);
+                        az[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bq[u][JB + j], az[j], 0, 0, 0);
+                        ahn[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bq[u][2 * JB + j], ahn[j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x020, NF, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
+                }
+            }
+            if (t + 1 < k) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) load(wf_hh, i, i);            // next step's first fragments, under this epilogue
+            }
+        }
+        const bool last = t == k - 1;
+        float* Ht = H + (size_t)t * n * D;
+        unsigned short* H16t = H16 + (size_t)t * n * D;
+        _Float16* Gt = (_Float16*)q.gates[p] + (size_t)t * n * 4 * D;
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        const int l31v = lane_v & 31, halfv = lane_v >> 5;
+        constexpr int TL = 0;
+        (void)TL;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            float v5[5][NRR];
+#pragma unroll
+            for (int r = 0; r < NRR; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
+                const float gr = gi[0][t >> 1][j][8 * (t & 1) + r], gz = gi[1][t >> 1][j][8 * (t & 1) + r], gn = gi[2][t >> 1][j][8 * (t & 1) + r];
+                const float rr = sig(gr + ar[j][r] + b_r[j]);
+                const float zz = sig(gz + az[j][r] + b_z[j]);
+                const float hn = ahn[j][r] + b_hn[j];
+                const float nn = 2.f * sig(2.f * (gn + b_in[j] + rr * hn)) - 1.f;
+                const float h = (full || node0 + row < nl) ? (1.f - zz) * nn + zz * hprev[j][r] : 0.f;
+                hprev[j][r] = h;
+                v5[0][r] = h; v5[1][r] = rr; v5[2][r] = zz; v5[3][r] = nn; v5[4][r] = hn;
+            }
+#pragma unroll
+            for (int ten = 0; ten < 5; ++ten) {
+#pragma unroll
+                for (int r = 0; r < NRR; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * halfv) * PS + l31v] = v5[ten][r];
+#pragma unroll
+                for (int i = 0; i < NR / 8; ++i) {
+                    const int row = 8 * i + (lane_v >> 3), c4 = (lane_v & 7) * 4;
+                    const int node = node0 + row;
+                    if (full || node < n) {
+                        const float4 hv = *reinterpret_cast<const float4*>(patch + row * PS + c4);
+                        if (ten == 0) {
+                            const unsigned off = (unsigned)node * D + cbase + 32 * j + c4;
+                            *reinterpret_cast<float4*>(Ht + off) = hv;
+                            if (!last) *reinterpret_cast<uint2*>(H16t + off) = make_uint2(srec_pack_bf16(hv.x, hv.y), srec_pack_bf16(hv.z, hv.w));
+                            if (last) {
+                                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (full || node < nl) {
+                                    const unsigned xo = (unsigned)node * k * D + cbase + 32 * j + c4;
+                                    for (int tt = 0; tt < k; ++tt) {
+                                        const float4 v = *reinterpret_cast<const float4*>(X + xo + tt * D);
+                                        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                                    }
+                                    o = make_float4(ik * o.x + 0.5f * hv.x, ik * o.y + 0.5f * hv.y, ik * o.z + 0.5f * hv.z, ik * o.w + 0.5f * hv.w);
+                                }
+                                *reinterpret_cast<float4*>(out + off) = o;
+                            }
+                        } else {
+                            const unsigned goff = (unsigned)node * (4 * D) + cbase + 32 * j + c4;
+                            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                            const h4_t hq = {(_Float16)hv.x, (_Float16)hv.y, (_Float16)hv.z, (_Float16)hv.w};
+                            *reinterpret_cast<h4_t*>(Gt + goff + (ten - 1) * D) = hq;
+                        }
+                    }
+                }
+            }
+        }
+        if (!last) {
+            __syncthreads();                     // every wave is done reading h_{t-1}
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const int col = cbase + 32 * j + l31v;
+#pragma unroll
+                for (int r = 0; r < NRR; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
+                    ht[row * D + (((col >> 3) ^ (row & 15)) * 8) + (col & 7)] = srec_f2bf(hprev[j][r]);
+                }
+            }
+            __syncthreads();                     // h_t published
+        }
+    }
+}
+
 struct WfArgs {
     int d, jb;
     const float* W[2 * GF_MAXP];
@@ -361,6 +599,8 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
     // 16-node workgroups while 32-node ones would leave half of the chip idle
     int NRv = 32;
     if (int rc = srec_gru_fused_nodes(q->np, q->n, q->d, &NRv)) return rc;
+    bool batch = NRv == 16;                      // gru_fused_fwd16_kernel holds the projections of <= 4 time steps
+    for (int p = 0; p < q->np; ++p) batch = batch && q->k[p] <= 4;
     if (NRv == 16) {
         blocks = 0;
         for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + 15) / 16; }
@@ -378,7 +618,16 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
         if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<DDV, NRV, NWV>, (int)lds, om[slot])) return rc;  \
         hipLaunchKernelGGL((gru_fused_fwd_kernel<DDV, NRV, NWV>), dim3(blocks), dim3(64 * NWV), lds, (hipStream_t)stream, a); \
     } while (0)
-    if (D == 256) { if (NRv == 16) SREC_GF(2, 16, 8, 4); else SREC_GF(2, 32, 8, 5); }
+    if (batch) {
+        const size_t lds16 = (size_t)(96 * D) * 2 + (size_t)NWv * 16 * 40 * 4;
+        if (D == 256) {
+            if (int rc = srec_lds_optin((const void*)gru_fused_fwd16_kernel<2, 8>, (int)lds16, om[0])) return rc;
+            hipLaunchKernelGGL((gru_fused_fwd16_kernel<2, 8>), dim3(blocks), dim3(64 * 8), lds16, (hipStream_t)stream, a);
+        } else {
+            if (int rc = srec_lds_optin((const void*)gru_fused_fwd16_kernel<1, 4>, (int)lds16, om[1])) return rc;
+            hipLaunchKernelGGL((gru_fused_fwd16_kernel<1, 4>), dim3(blocks), dim3(64 * 4), lds16, (hipStream_t)stream, a);
+        }
+    } else if (D == 256) { if (NRv == 16) SREC_GF(2, 16, 8, 4); else SREC_GF(2, 32, 8, 5); }
     else { if (NRv == 16) SREC_GF(1, 16, 4, 2); else SREC_GF(1, 32, 4, 3); }
 #undef SREC_GF
     SREC_LAUNCH_CHECK();
