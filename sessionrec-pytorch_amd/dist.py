@@ -15,7 +15,8 @@ Per step and rank r (rows [lo, hi) of the table, Adam state for those rows only)
            and loss.  backward: fused kernels with the GLOBAL lse: dE for the shard is complete
            locally; d sr partials are reduce-scattered to the owners of the sessions.
   encoder  replicated parameters: gradients all-reduced (sum of per-rank contributions to the global
-           mean loss) in ONE flat bucket, then the same fused Adam everywhere.
+           mean loss) in three flat buckets in backward completion order (sync_replicated_grads), then the same fused
+           Adam everywhere.
 All exchanges are small (<= a few MB): latency-bound on xGMI, so they are few and flat (one
 collective per exchange, no ring of tiny messages).  The local compute goes through `local`, an
 object with the HIP kernels (HipLocal); tests drive the same algebra on CPU/gloo with a plain-torch
