@@ -104,6 +104,7 @@ class GraphedTrainStep:
             self.loss_ring = torch.zeros(LOSS_RING, device=labels.device, dtype=torch.float32)
         work = None
         from . import dist as _dist
+        self._quiesce_collectives()
         c0 = dict(_dist.STATS)
         err = None
         try:
@@ -158,6 +159,25 @@ class GraphedTrainStep:
                 self.graph.instantiate()
             except Exception:
                 pass
+
+    @staticmethod
+    def _quiesce_collectives():
+        """RCCL through torch.distributed: every eager collective of the warm-up left a work item with the process group's
+        watchdog thread, which polls their completion EVENTS every ~100 ms until it has retired them.  An event query from that
+        thread while this thread captures (global capture mode) invalidates the capture or aborts the process ("operation not
+        permitted on an event last recorded in a capturing stream" / "operation failed due to a previous error during
+        capture": 1 run in ~10 of `bench.py --shard`, profiles/r05_notes.md).  All device work is complete here: wait two polling
+        periods so that the watchdog's list is empty before the capture begins."""
+        import time
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            try:
+                nccl = dist.get_backend() == 'nccl'
+            except Exception:
+                nccl = False
+            if nccl:
+                torch.cuda.synchronize()
+                time.sleep(0.3)
 
     def _setup_mailbox(self, optimizer, device):
         """Batch intake as the FIRST kernels of the captured step: each reads where this replay's batch lives from a mailbox

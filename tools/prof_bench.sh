@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 out=/root/repo/gpurun_out
 mkdir -p $out
 rm -rf /tmp/prof_$tag
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --steps 20 --warmup 5 --step-only "$@" > $out/${tag}_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --steps 20 --warmup 5 --step-only "$@" > $out/${tag}_bench.log 2>&1
 grep '^{' $out/${tag}_bench.log | tail -1 > $out/${tag}_bench.json
 f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$f" $out/${tag}_kernel_stats.csv
