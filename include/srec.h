@@ -367,6 +367,11 @@ int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
  * Replaces the chain of cuBLAS calls of the attention read-out / session-vector head (msgifsr.py:127-146,272-279;
  * srgnn.py:73-88,123-127) and their backward. */
 int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream);
+/* ... with the slab sums of the plain split problems (alpha 1, beta 0, no bias, no row clamp, contiguous C: weight gradients) left
+ * to the caller where the caller allows it (slab_n[p] != 0 ON ENTRY): slab_off[p] = float offset of problem p's slabs in ws (-1:
+ * finished by the call), slab_n[p] = their count, each M N floats, to be summed into C[p] (srec_sum_slabs_multi).  ws must be
+ * private to the call until that sum has run. */
+int srec_gemm_f32_group_run_defer(const void* desc, float* ws, long ws_floats, long* slab_off, int* slab_n, void* stream);
 /* bf16-in-HBM grouped GEMMs (gemm16.hip): the GAT fc projections and their backward (gatconv.py:166-175,282-283) with every
  * operand already stored as bf16 - LDS-DMA staging, no conversion pass.  desc: host srec_gemm16_group (srec_hg.h, up to 16
  * problems per launch).

@@ -372,6 +372,7 @@ struct GroupK {
     int tile_end[SREC_GEMM32_MAXP];      // prefix sums of workgroups per problem
     int tiles_n[SREC_GEMM32_MAXP], tiles_mn[SREC_GEMM32_MAXP];
     long ws_off[SREC_GEMM32_MAXP];       // slab offsets (floats) of the split problems
+    unsigned defer_mask;                 // bit p: the slab sum of problem p is left to the caller (srec_gemm_f32_group_run_defer)
 };
 
 template <bool S3>
@@ -404,7 +405,7 @@ __global__ void splitk_reduce_group_kernel(GroupK k) {
     const int p = blockIdx.y;
     const srec_gemm_f32_group& g = k.g;
     const int nsplit = g.nsplit[p];
-    if (nsplit <= 1) return;
+    if (nsplit <= 1 || ((k.defer_mask >> p) & 1u)) return;
     const int M = g.M[p], N = g.N[p];
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= (size_t)M * N) return;
@@ -520,16 +521,33 @@ extern "C" int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B,
 // here (g->nsplit is ignored on input); ws / ws_floats = the shared slab workspace.
 // (split-K sums inside the launch - "the last workgroup to arrive at a tile adds the slabs" - were measured at +130 us per
 // step: the device-scope fences write back / invalidate whole L2s, profiles/r03_notes.md; the reduce stays a launch of its own)
+static int gemm_f32_group_go(const void* desc, float* ws, long ws_floats, long* slab_off, int* slab_n, void* stream);
+
 extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream) {
+    return gemm_f32_group_go(desc, ws, ws_floats, nullptr, nullptr, stream);
+}
+
+// the same, but the slab sums of the PLAIN split problems (alpha = 1, beta = 0, no bias, no row clamp, contiguous C: the weight
+// gradients of a backward group) are left to the caller: slab_off[p] (floats into ws; -1: problem p is finished) and slab_n[p]
+// slabs of M N floats each, to be summed into C[p] (srec_sum_slabs_multi - e.g. ONE launch at the end of the backward pass for
+// every group of it).  ws must then stay untouched until that sum has run: a private buffer of the call, not a shared one.
+extern "C" int srec_gemm_f32_group_run_defer(const void* desc, float* ws, long ws_floats, long* slab_off, int* slab_n,
+                                             void* stream) {
+    if (slab_off == nullptr || slab_n == nullptr) return SREC_BAD_ARG;
+    return gemm_f32_group_go(desc, ws, ws_floats, slab_off, slab_n, stream);
+}
+
+static int gemm_f32_group_go(const void* desc, float* ws, long ws_floats, long* slab_off, int* slab_n, void* stream) {
     const srec_gemm_f32_group* gin = (const srec_gemm_f32_group*)desc;
     if (gin->np <= 0) return 0;
     if (gin->np > SREC_GEMM32_MAXP) return SREC_BAD_ARG;
     GroupK k;
     k.g = *gin;
     k.g.ws = ws;
+    k.defer_mask = 0u;
+    int order[SREC_GEMM32_MAXP];
     {   // Workgroups start in index order: the problems with the longest per-workgroup k-loop go first, so that an unsplit
         // long-K product is not left running alone after the large products have drained.
-        int order[SREC_GEMM32_MAXP];
         for (int p = 0; p < gin->np; ++p) order[p] = p;
         for (int i = 1; i < gin->np; ++i)
             for (int j = i; j > 0 && gin->K[order[j]] > gin->K[order[j - 1]]; --j) std::swap(order[j], order[j - 1]);
@@ -605,11 +623,20 @@ extern "C" int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floa
         srec_gemm_f32_group& g = k.g;
         const int nsplit = g.nsplit[p];
         k.ws_off[p] = ws_used;
+        bool may = false;                   // slab_n[] on entry: non-zero = the caller may sum this problem's slabs later
+        if (slab_off != nullptr) { may = slab_n[order[p]] != 0; slab_off[order[p]] = -1; slab_n[order[p]] = 0; }
         if (nsplit > 1) {
             ws_used += (long)nsplit * g.M[p] * g.N[p];
-            any_split = 1;
-            const int red = (int)(((size_t)g.M[p] * g.N[p] / 4 + 63) / 64);      // one-wave workgroups: 4 x the CUs at work
-            if (red > max_red) max_red = red;
+            if (may && g.alpha[p] == 1.f && g.beta[p] == 0.f && g.bias[p] == nullptr && g.dyn_mode[p] != 1 &&
+                g.ldc[p] == g.N[p]) {
+                k.defer_mask |= 1u << p;
+                slab_off[order[p]] = k.ws_off[p];
+                slab_n[order[p]] = nsplit;
+            } else {
+                any_split = 1;
+                const int red = (int)(((size_t)g.M[p] * g.N[p] / 4 + 63) / 64);  // one-wave workgroups: 4 x the CUs at work
+                if (red > max_red) max_red = red;
+            }
         }
         end += k.tiles_mn[p] * nsplit;
         k.tile_end[p] = end;

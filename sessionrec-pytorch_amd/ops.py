@@ -170,7 +170,7 @@ def _small_linear(*ws):
     return sum(w.numel() for w in ws) <= _SMALL_LINEAR
 
 
-def _linear_backward_group(gy, xs, ws, gws, need_x, need_b, dyn):
+def _linear_backward_group(gy, xs, ws, gws, need_x, need_b, dyn, defer=False):
     """backward of y = sum_i x_i W_i^T + b as ONE grouped exact-fp32 launch (+ its slab sum): d x_i = gy W_i, d W_i =
     gy^T x_i into gws[i] (None: not needed), d b = column sums of gy as a product with a block of ones - instead of a GEMM
     per product, a split-K sum per weight gradient and two column-sum launches.  -> ([d x_i], d b)"""
@@ -189,8 +189,9 @@ def _linear_backward_group(gy, xs, ws, gws, need_x, need_b, dyn):
         sums = torch.empty(4, N, device=gy.device, dtype=torch.float32)
         probs.append(('tn', _ones4(M, gy.device)[:M], gy, sums, None, dyn, 0.0))
         gb = sums[0]
+    outs = [gw for gw in gws if gw is not None] if defer else None      # the bias sums are read on the spot (gb is a view)
     for c in range(0, len(probs), 16):
-        gemm_f32_group(probs[c:c + 16])
+        gemm_f32_group(probs[c:c + 16], defer=outs)
     return gxs, gb
 
 
@@ -203,6 +204,7 @@ class LinearCat(torch.autograd.Function):
     def forward(ctx, weight, bias, dyn, exact, *xs):
         exact = exact or _small_linear(weight)
         ctx.exact = exact
+        ctx.defer, ctx.wparams = defer_scope(), [weight] + ([bias] if bias is not None else [])
         if exact and PRECISION['matmul'] != 'fp32':         # session-vector head: exact fp32 MFMA even in bf16 mode
             prev, PRECISION['matmul'] = PRECISION['matmul'], 'fp32'
             try:
@@ -252,8 +254,9 @@ class LinearCat(torch.autograd.Function):
             for x in xs:
                 offs.append(offs[-1] + x.shape[1])
             gxs, gb = _linear_backward_group(gy, xs, [w[:, a:b] for a, b in zip(offs, offs[1:])],
-                                             [None if gw is None else gw[:, a:b] for a, b in zip(offs, offs[1:])], need_x,
-                                             ctx.has_bias and ctx.needs_input_grad[1], dyn)
+                                             [None if gw is None else (gw if len(xs) == 1 else gw[:, a:b]) for a, b in zip(offs, offs[1:])],
+                                             need_x, ctx.has_bias and ctx.needs_input_grad[1], dyn,
+                                             defer=can_defer(ctx.defer, ctx.wparams))
             return (gw, gb, None, None) + tuple(gxs)
         gb = None
         gxs = []
@@ -296,6 +299,7 @@ class LinearSum(torch.autograd.Function):
             PRECISION['matmul'] = prev
         ctx.save_for_backward(*xs, *ws)
         ctx.dyn, ctx.n, ctx.has_bias = dyn, n, bias is not None
+        ctx.defer, ctx.wparams = defer_scope(), list(args[n:]) + ([bias] if bias is not None else [])
         return y
 
     @staticmethod
@@ -306,7 +310,7 @@ class LinearSum(torch.autograd.Function):
         if ctx.small and gy.shape[0] > 0:
             gws = [torch.empty_like(w) if ctx.needs_input_grad[3 + n + i] else None for i, w in enumerate(ws)]
             gxs, gb = _linear_backward_group(gy, xs, ws, gws, ctx.needs_input_grad[3:3 + n],
-                                             ctx.has_bias and ctx.needs_input_grad[0], dyn)
+                                             ctx.has_bias and ctx.needs_input_grad[0], dyn, defer=can_defer(ctx.defer, ctx.wparams))
             return (gb, None, None) + tuple(gxs) + tuple(gws)
         gxs, gws = [], []
         for i, (x, w) in enumerate(zip(xs, ws)):
@@ -645,6 +649,8 @@ def can_defer(flag, params):
     if not flag:
         return False
     for q in params:
+        if not q.is_leaf:                           # a derived weight (folded norm, slice): its gradient is READ by the next node
+            return False
         if q.grad is not None or getattr(q, '_backward_hooks', None) or getattr(q, '_post_accumulate_grad_hooks', None):
             return False
     return True
@@ -958,8 +964,11 @@ class GemmF32Group(_ct.Structure):
                 ('split3', _ct.c_int)]
 
 
-def gemm_f32_group(probs, split3=False):
-    """ONE launch of up to 16 independent exact-fp32 products (csrc/gemm.hip, srec_gemm_f32_group_run; split3: as 3-term
+def gemm_f32_group(probs, split3=False, defer=None):
+    """defer: a list of output tensors - the split-K slab sums of the group's weight-gradient ('tn', whole contiguous output
+    tensor) problems that write one of them join the end-of-backward slab-sum launch (defer_slab_sum) instead of a reduce
+    launch behind this one; the caller has checked can_defer() for the parameters those outputs become the gradients of.
+    ONE launch of up to 16 independent exact-fp32 products (csrc/gemm.hip, srec_gemm_f32_group_run; split3: as 3-term
     hi / lo bf16 splits on the bf16 matrix pipe, ~2^-17 relative).  A problem is
     (kind, a, b, out, bias, dyn, beta):  'nt' out[M,N] = a[M,K] b[N,K]^T + bias (dyn clamps M);  'nn' out[M,K] = a[M,N] b[N,K]
     (dyn clamps M);  'tn' out[N,K] = a[M,N]^T b[M,K] (dyn clamps the reduction rows M).  (+ beta * out)"""
@@ -984,6 +993,22 @@ def gemm_f32_group(probs, split3=False):
         g.dyn[p], g.dyn_mode[p] = ptr(dyn), (mode if dyn is not None else 0)
         g.alpha[p], g.beta[p] = 1.0, beta
     dev = probs[0][1].device
+    if defer:
+        ok = [kind == 'tn' and out.is_contiguous() and out._base is None and beta == 0.0 and any(out is t for t in defer)
+              for (kind, a, b, out, bias, dyn, beta) in probs]
+        need = sum(32 * int(g.M[p]) * int(g.N[p]) for p in range(len(probs)))
+        if any(ok) and need <= (1 << 24):
+            # a PRIVATE slab buffer: it has to survive until the end of the backward pass (the shared one is rewritten by the
+            # next group); problems that may not wait (cnt[p] = 0 on entry: accumulating / clamped / strided outputs, outputs
+            # somebody reads during the backward pass) keep their reduce launch
+            ws = torch.empty(need, device=dev, dtype=torch.float32)
+            off, cnt = (_ct.c_long * 16)(), (_ct.c_int * 16)(*[int(o) for o in ok])
+            lib.srec_gemm_f32_group_run_defer(_ct.addressof(g), ptr(ws), need, _ct.addressof(off), _ct.addressof(cnt), stream())
+            for p, (kind, a, b, out, bias, dyn, beta) in enumerate(probs):
+                if off[p] >= 0 and cnt[p] > 1:
+                    n = out.numel()
+                    defer_slab_sum(ws[off[p]:off[p] + cnt[p] * n].view(cnt[p], n), out)
+            return
     lib.srec_gemm_f32_group_run(_ct.addressof(g), *_gemm_ws(dev), stream())
 
 
@@ -1213,6 +1238,8 @@ class ReadoutHeadFused(torch.autograd.Function):
         ctx.save_for_backward(allf, seg, *keep)
         ctx.n, ctx.dT, ctx.dB = n, dT, dB
         ctx.has_bu = [po[2] is not None for po in per]
+        ctx.defer = defer_scope()
+        ctx.wparams = [flat[6 * i + j] for i in range(n) for j in (1, 2, 3, 4, 5) if flat[6 * i + j] is not None]
         return tuple(ys)
 
     @staticmethod
@@ -1264,8 +1291,10 @@ class ReadoutHeadFused(torch.autograd.Function):
             probs.append(('tn', ones[:B], dwp, sums[4:], None, dB, 0.0))
             grads.append((gv, gWu, gbu, gWv, sums[4:5], gWsr))
         per_launch = 14 if len(probs) > 16 else 16          # whole orders per launch (7 problems each)
+        later = [t for gr in grads for t in (gr[1], gr[3], gr[5])] if can_defer(ctx.defer, ctx.wparams) else None
         for c in range(0, len(probs), per_launch):
-            gemm_f32_group(probs[c:c + per_launch], split3=True)      # (the forward's products are 3-term splits too)
+            gemm_f32_group(probs[c:c + per_launch], split3=True,       # (the forward's products are 3-term splits too)
+                           defer=later)
         g_allf = outs[0][3]
         for o in outs[1:]:
             g_allf = g_allf + o[3]

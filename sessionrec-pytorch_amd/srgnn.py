@@ -139,10 +139,15 @@ class _ScoringMixin:
             self.shard.labels_hint = labels          # gathered together with the lookup's request lists
         # bf16 scoring on one device: the model's final normalisation writes the session vectors' bf16 operand copy itself
         self._sr_ws = st['ws'][B] if (self.shard is None and ops.use_bf16_scoring(self._table().shape[1])) else None
+        # every parameter of these models feeds exactly one backward node: the split-K sums of the small grouped backward
+        # launches may wait for ONE launch at the end of the backward pass (ops.defer_scope; MSGIFSR switches it itself)
+        prev_defer = ops.DEFER['on']
+        ops.DEFER['on'] = bool(prev_defer or (self.training and self._table().is_cuda and getattr(self, 'defer_slab_sums', True)))
         try:
             sr = self.session_repr(*inputs, tgrad=st['tgrad'])
         finally:
             self._sr_ws = None
+            ops.DEFER['on'] = prev_defer
         if self.shard is not None:
             return self.shard.loss(sr, self._table(), cs, labels, inv_scale)
         loss, _ = ops.score_ce(sr, self._table(), cs, labels.to(torch.int32), st['ws'][B], st['tgrad'], dynB, inv_scale,
