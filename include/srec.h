@@ -367,9 +367,9 @@ int srec_gemm_group_bf16(const void* desc, int mode, void* stream);
  * Replaces the chain of cuBLAS calls of the attention read-out / session-vector head (msgifsr.py:127-146,272-279;
  * srgnn.py:73-88,123-127) and their backward. */
 int srec_gemm_f32_group_run(const void* desc, float* ws, long ws_floats, void* stream);
-/* ... with the slab sums of the plain split problems (alpha 1, beta 0, no bias, no row clamp, contiguous C: weight gradients) left
+/* ... with the slab sums of the plain split problems (alpha 1, beta 0, no bias, no row clamp: weight gradients) left
  * to the caller where the caller allows it (slab_n[p] != 0 ON ENTRY): slab_off[p] = float offset of problem p's slabs in ws (-1:
- * finished by the call), slab_n[p] = their count, each M N floats, to be summed into C[p] (srec_sum_slabs_multi).  ws must be
+ * finished by the call), slab_n[p] = their count, each M N floats (dense), to be summed into C[p] (srec_sum_slabs_multi_ld when ldc != N).  ws must be
  * private to the call until that sum has run. */
 int srec_gemm_f32_group_run_defer(const void* desc, float* ws, long ws_floats, long* slab_off, int* slab_n, void* stream);
 /* bf16-in-HBM grouped GEMMs (gemm16.hip): the GAT fc projections and their backward (gatconv.py:166-175,282-283) with every
@@ -422,11 +422,15 @@ int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* d
 /* out[p] [ncol] = column sums of part[p] [rows[p], ncol] for np <= 4 problems in one launch (the GRU bias gradients from the
  * per-block partial rows of srec_gru_step_bwd); part / out: HOST arrays of np device pointers, rows: HOST int array */
 int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);
-/* np <= 8 outputs out_i [n_i] = sum_r part_i [R_i, n_i] in one launch (row-split weight gradients); HOST arrays.  tall
+/* np <= 32 outputs out_i [n_i] = sum_r part_i [R_i, n_i] in one launch (row-split weight gradients); HOST arrays.  tall
  * (nullable HOST array): tall_i != 0 = few columns summed over hundreds of rows (the GRU bias partials of srec_gru_fused_bwd
  * / srec_gru_step_bwd, what srec_gru_bias_final does as a launch of its own) */
 int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
                          void* stream);
+/* ... with strided destinations: w_i > 0 = out_i is a block of w_i columns in rows of stride ld_i floats (a column slice of a
+ * weight gradient: the concat-free linear layers); w, ld: HOST int arrays, both or neither nullable */
+int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                            const int* w, const int* ld, void* stream);
 
 /* ---- evaluation: K best items per session without the (B, V) score matrix (topk.hip) -----------------------------
  * Replaces `logits = model(...); logits.topk(20)` of train.py:36-55 for models whose score is one soft-max

@@ -627,12 +627,12 @@ static int gemm_f32_group_go(const void* desc, float* ws, long ws_floats, long* 
         if (slab_off != nullptr) { may = slab_n[order[p]] != 0; slab_off[order[p]] = -1; slab_n[order[p]] = 0; }
         if (nsplit > 1) {
             ws_used += (long)nsplit * g.M[p] * g.N[p];
-            if (may && g.alpha[p] == 1.f && g.beta[p] == 0.f && g.bias[p] == nullptr && g.dyn_mode[p] != 1 &&
-                g.ldc[p] == g.N[p]) {
+            if (may && g.alpha[p] == 1.f && g.beta[p] == 0.f && g.bias[p] == nullptr && g.dyn_mode[p] != 1) {
                 k.defer_mask |= 1u << p;
                 slab_off[order[p]] = k.ws_off[p];
                 slab_n[order[p]] = nsplit;
             } else {
+                if (slab_off != nullptr) slab_n[order[p]] = nsplit;          // (slab_off < 0: informational)
                 any_split = 1;
                 const int red = (int)(((size_t)g.M[p] * g.N[p] / 4 + 63) / 64);  // one-wave workgroups: 4 x the CUs at work
                 if (red > max_red) max_red = red;

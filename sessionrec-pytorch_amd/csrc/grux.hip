@@ -226,15 +226,19 @@ __global__ __launch_bounds__(1024) void gru_bias_final_kernel(FinArgs a) {
 
 // out_i [n_i] = sum_r part_i [R_i, n_i].  tall_i: few columns, hundreds of rows (the GRU's bias partials: one row per gate-kernel
 // workgroup) - a workgroup takes 64 columns with 4 row lanes of 8 independent accumulators instead of one thread per 4 columns
-// walking all the rows
-struct SlabArgs { const float* part[8]; float* out[8]; int R[8]; long n[8]; int start[9]; int np; int tall[8]; };
+// walking all the rows.  w_i / ld_i: the output is a [n_i / w_i, w_i] block of a matrix with row stride ld_i (a column slice of a
+// weight gradient); w_i = 0: contiguous
+constexpr int SLAB_MAXP = 32;
+struct SlabArgs {
+    const float* part[SLAB_MAXP]; float* out[SLAB_MAXP]; long n[SLAB_MAXP]; int R[SLAB_MAXP]; int start[SLAB_MAXP + 1];
+    int w[SLAB_MAXP]; int ld[SLAB_MAXP]; unsigned tall; int np;
+};
 __global__ void sum_slabs_multi_kernel(SlabArgs a) {
     __shared__ float red[4][64];
     int p = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i)
-        if (i < a.np && (int)blockIdx.x >= a.start[i]) p = i;
-    if (a.tall[p]) {                                       // (uniform per workgroup)
+    for (int i = 1; i < a.np; ++i)
+        if ((int)blockIdx.x >= a.start[i]) p = i;
+    if ((a.tall >> p) & 1u) {                              // (uniform per workgroup)
         const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
         const long col = (long)((int)blockIdx.x - a.start[p]) * 64 + cl;
         const long n = a.n[p];
@@ -266,7 +270,9 @@ __global__ void sum_slabs_multi_kernel(SlabArgs a) {
         const float4 v = ld4(q + (size_t)r * a.n[p] + i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    *reinterpret_cast<float4*>(a.out[p] + i) = s;
+    const int w = a.w[p];
+    const long o = w > 0 ? (i / w) * (long)a.ld[p] + (i % w) : i;
+    *reinterpret_cast<float4*>(a.out[p] + o) = s;
 }
 
 int check(const srec_gru_step_desc* q) {
@@ -333,24 +339,36 @@ extern "C" int srec_gru_bias_final(int np, const void* part, const int* rows, in
     return 0;
 }
 
-// np <= 8 outputs out_i [n_i] = sum_r part_i [R_i, n_i] (n_i % 4 == 0) in one launch; HOST arrays.  tall (nullable): tall_i != 0
-// marks an output of few columns summed over many rows (row lanes instead of column threads)
-extern "C" int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
-                                    void* stream) {
+// np <= 32 outputs out_i [n_i] = sum_r part_i [R_i, n_i] (n_i % 4 == 0) in one launch; HOST arrays.  tall (nullable): tall_i != 0
+// marks an output of few columns summed over many rows (row lanes instead of column threads); w / ld (nullable, both or neither):
+// w_i > 0 = out_i is a block of w_i columns in rows of stride ld_i (both % 4 == 0; not with tall_i)
+extern "C" int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                                       const int* w, const int* ld, void* stream) {
     if (np <= 0) return 0;
-    if (np > 8 || part == nullptr || out == nullptr) return SREC_BAD_ARG;
+    if (np > SLAB_MAXP || part == nullptr || out == nullptr || (w == nullptr) != (ld == nullptr)) return SREC_BAD_ARG;
     SlabArgs a{};
     a.np = np;
     int blocks = 0;
     for (int p = 0; p < np; ++p) {
         a.part[p] = ((const float* const*)part)[p]; a.out[p] = ((float* const*)out)[p]; a.R[p] = R[p]; a.n[p] = n[p];
-        a.tall[p] = tall != nullptr && tall[p] != 0;
+        const bool tl = tall != nullptr && tall[p] != 0;
+        if (tl) a.tall |= 1u << p;
         if (a.part[p] == nullptr || a.out[p] == nullptr || R[p] <= 0 || n[p] <= 0 || (n[p] & 3)) return SREC_BAD_ARG;
+        a.w[p] = 0; a.ld[p] = 0;
+        if (w != nullptr && w[p] > 0 && ld[p] != w[p]) {
+            if (tl || (w[p] & 3) || (ld[p] & 3) || ld[p] < w[p] || n[p] % w[p]) return SREC_BAD_ARG;
+            a.w[p] = w[p]; a.ld[p] = ld[p];
+        }
         a.start[p] = blocks;
-        blocks += a.tall[p] ? (int)((n[p] + 63) / 64) : (int)((n[p] / 4 + 255) / 256);
+        blocks += tl ? (int)((n[p] + 63) / 64) : (int)((n[p] / 4 + 255) / 256);
     }
     a.start[np] = blocks;
     hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     SREC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                                    void* stream) {
+    return srec_sum_slabs_multi_ld(np, part, R, n, out, tall, nullptr, nullptr, stream);
 }

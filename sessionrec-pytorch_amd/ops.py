@@ -189,7 +189,7 @@ def _linear_backward_group(gy, xs, ws, gws, need_x, need_b, dyn, defer=False):
         sums = torch.empty(4, N, device=gy.device, dtype=torch.float32)
         probs.append(('tn', _ones4(M, gy.device)[:M], gy, sums, None, dyn, 0.0))
         gb = sums[0]
-    outs = [gw for gw in gws if gw is not None] if defer else None      # the bias sums are read on the spot (gb is a view)
+    outs = ([gw for gw in gws if gw is not None] + ([sums] if need_b else [])) if defer else None
     for c in range(0, len(probs), 16):
         gemm_f32_group(probs[c:c + 16], defer=outs)
     return gxs, gb
@@ -674,15 +674,20 @@ def defer_slab_sum(part, out, ok=True, tall=False):
 
 
 def _launch_slab_sums(tasks):
-    for i in range(0, len(tasks), 8):
-        chunk = tasks[i:i + 8]
+    """out: contiguous, or a column block [r, w] of a row-major matrix (stride(0) = ld > w: a slice of a weight gradient)"""
+    for i in range(0, len(tasks), 32):
+        chunk = tasks[i:i + 32]
         m = len(chunk)
         arr = _ct.c_void_p * m
         a_p, a_o = arr(*[t[0].data_ptr() for t in chunk]), arr(*[t[1].data_ptr() for t in chunk])
         a_r, a_n = (_ct.c_int * m)(*[t[0].shape[0] for t in chunk]), (_ct.c_long * m)(*[t[1].numel() for t in chunk])
         a_t = (_ct.c_int * m)(*[int(len(t) > 2 and bool(t[2])) for t in chunk])
-        lib.srec_sum_slabs_multi(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o),
-                                 _ct.addressof(a_t), stream())
+        wl = [(0, 0) if t[1].is_contiguous() else (t[1].shape[1], t[1].stride(0)) for t in chunk]
+        for t, (w, ld) in zip(chunk, wl):
+            assert w == 0 or (t[1].dim() == 2 and t[1].stride(1) == 1), (t[1].shape, t[1].stride())
+        a_w, a_l = (_ct.c_int * m)(*[w for w, _ in wl]), (_ct.c_int * m)(*[ld for _, ld in wl])
+        lib.srec_sum_slabs_multi_ld(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o),
+                                    _ct.addressof(a_t), _ct.addressof(a_w), _ct.addressof(a_l), stream())
 
 
 def flush_deferred():
@@ -994,9 +999,11 @@ def gemm_f32_group(probs, split3=False, defer=None):
         g.alpha[p], g.beta[p] = 1.0, beta
     dev = probs[0][1].device
     if defer:
-        ok = [kind == 'tn' and out.is_contiguous() and out._base is None and beta == 0.0 and any(out is t for t in defer)
+        ok = [kind == 'tn' and out.dim() == 2 and out.stride(1) == 1 and beta == 0.0 and any(out is t for t in defer)
               for (kind, a, b, out, bias, dyn, beta) in probs]
-        need = sum(32 * int(g.M[p]) * int(g.N[p]) for p in range(len(probs)))
+        # (the launcher only splits problems of < 128 output tiles, into <= 32 slabs)
+        need = sum(32 * int(g.M[p]) * int(g.N[p]) for p in range(len(probs))
+                   if ((int(g.M[p]) + 63) // 64) * ((int(g.N[p]) + 63) // 64) < 128)
         if any(ok) and need <= (1 << 24):
             # a PRIVATE slab buffer: it has to survive until the end of the backward pass (the shared one is rewritten by the
             # next group); problems that may not wait (cnt[p] = 0 on entry: accumulating / clamped / strided outputs, outputs
@@ -1008,11 +1015,15 @@ def gemm_f32_group(probs, split3=False, defer=None):
                 if off[p] >= 0 and cnt[p] > 1:
                     n = out.numel()
                     defer_slab_sum(ws[off[p]:off[p] + cnt[p] * n].view(cnt[p], n), out)
+            if _GROUP_DEBUG:
+                print('gemm_f32_group', [(kind, int(g.M[p]), int(g.N[p]), int(g.K[p]), bool(ok[p]), off[p], cnt[p])
+                                         for p, (kind, *_r) in enumerate(probs)], flush=True)
             return
     lib.srec_gemm_f32_group_run(_ct.addressof(g), *_gemm_ws(dev), stream())
 
 
 _ONES4 = {}
+_GROUP_DEBUG = bool(os.environ.get('SREC_GROUP_DEBUG'))
 
 
 def _ones4(n, device):
@@ -1271,7 +1282,7 @@ class ReadoutHeadFused(torch.autograd.Function):
             q.gs[i], q.gcat[i], q.dX[i], q.dU[i], q.dVq[i], q.dwp[i] = ptr(gs), ptr(gcat), ptr(dX), ptr(dU), ptr(dVq), ptr(dwp)
             outs.append((gy, gs, gcat, dX, dU, dVq, dwp))
         lib.srec_head_bwd(_ct.addressof(q), stream())
-        probs, grads = [], []
+        probs, grads, blocks = [], [], []
         for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat, y, inv) in enumerate(per):
             gy, gs, gcat, dX, dU, dVq, dwp = outs[i]
             gWu, gWv, gWsr = torch.empty_like(Wu), torch.empty_like(Wv), torch.empty_like(Wsr)
@@ -1284,14 +1295,17 @@ class ReadoutHeadFused(torch.autograd.Function):
             # column sums as products with a block of ones inside the same launch: d bu = sum_n dU = sum_b dVq, d we = sum_b dwp
             ones = _ones4(B, dev)
             sums = torch.empty(8, D, device=dev, dtype=torch.float32)
+            s_bu, s_we = sums[:4], sums[4:]
             gbu = None
             if ctx.has_bu[i]:
-                probs.append(('tn', ones[:B], dVq, sums[:4], None, dB, 0.0))
+                probs.append(('tn', ones[:B], dVq, s_bu, None, dB, 0.0))
                 gbu = sums[0]
-            probs.append(('tn', ones[:B], dwp, sums[4:], None, dB, 0.0))
+                blocks.append(s_bu)
+            probs.append(('tn', ones[:B], dwp, s_we, None, dB, 0.0))
+            blocks.append(s_we)
             grads.append((gv, gWu, gbu, gWv, sums[4:5], gWsr))
         per_launch = 14 if len(probs) > 16 else 16          # whole orders per launch (7 problems each)
-        later = [t for gr in grads for t in (gr[1], gr[3], gr[5])] if can_defer(ctx.defer, ctx.wparams) else None
+        later = ([t for gr in grads for t in (gr[1], gr[3], gr[5])] + blocks) if can_defer(ctx.defer, ctx.wparams) else None
         for c in range(0, len(probs), per_launch):
             gemm_f32_group(probs[c:c + per_launch], split3=True,       # (the forward's products are 3-term splits too)
                            defer=later)
