@@ -337,6 +337,349 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
 #endif
 }
 
+
+// ---- 16-node workgroups, k <= 4: d x for ALL time steps as one product behind the recurrence ---------------------------------
+// The step loop above streams W_ih AND W_hh through every wave once per time step (2 k - 1 passes over 1.5 d^2 bf16 each) for
+// MFMA tiles whose lower half idles.  d x_t = d(gi_t) W_ih is not part of the recurrence: here the loop keeps only
+// d h_{t-1} += d(gh_t) W_hh (k - 1 passes over W_hh), phase E leaves d(gi_t) of every step in LDS (tile row = 16 t + node: full
+// 32-row MFMA tiles, [16 k][3 d] bf16; d(gh_t) shares its r / z columns), and ONE pass over W_ih behind the loop produces the
+// d x rows of all steps: k passes over the weights instead of 2 k - 1, (k - 1) + ceil(k / 2) MFMA tiles per k-step instead of
+// 2 k - 1.  The patches of the d x store and the bias reduction reuse the d(gi) tiles once they are dead.
+template <int DD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) {
+    constexpr int NR = 16, KMAX = 4;
+    constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;
+    constexpr int KS = D / 16, TPR = D / 4, RPP = NT / TPR, NP = NR / RPP;
+    static_assert(NP >= 2 && NP % 2 == 0, "phase E fetches its rows in two halves");
+    constexpr int NRR = NR / 2;
+    constexpr int PS = 32 * JB + 8;
+    constexpr int DS = D + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm[];
+    unsigned short* gi = sm;                                     // [16 KMAX][3 D] bf16, swizzled: d(gi_t) rows of node r at 16 t + r
+    unsigned short* nh = gi + 16 * KMAX * 3 * D;                 // [16][D]: the n part of d(gh_t)
+    float* dht = reinterpret_cast<float*>(nh + NR * D);          // [16][DS] fp32: d(gh_{t+1}) W_hh
+    float* patches = reinterpret_cast<float*>(sm);               // [NW][32][PS], over the dead d(gi) tiles
+    const srec_gru_fused_bwd_desc& q = a.d;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < GB_MAXP; ++i)
+        if (i < q.np && (int)blockIdx.x >= a.start[i]) p = i;
+    const int n = q.n[p], k = q.k[p];
+    const int tile = (int)blockIdx.x - a.start[p];
+    const int node0 = tile * NR;
+    if (node0 >= n) return;
+    const int nl = dyn_count(q.dyn[p], n);
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31, l15 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const _Float16* gates = (const _Float16*)q.gates[p];
+    const float* H = q.H[p];
+    const float* dout = q.dout[p];
+    unsigned short* dGI16 = (unsigned short*)q.dGI16[p];
+    unsigned short* dGH16 = (unsigned short*)q.dGH16[p];
+    float* dX = q.dX[p];
+    float* part = q.bias_part[p] + (size_t)(q.part_row0[p] + tile) * 6 * D;
+    const int erow = tid / TPR, ec = (tid % TPR) * 4;
+
+    if (node0 >= nl) {                           // capacity padding: zero operands and gradients, no arithmetic
+        const int rows = min(NR, n - node0);
+        for (int i = tid; i < rows * TPR; i += NT) {
+            const int row = i / TPR, c = (i % TPR) * 4;
+            const size_t node = (size_t)(node0 + row);
+            for (int t = 0; t < k; ++t) {
+                for (int g = 0; g < 3; ++g) {
+                    *reinterpret_cast<uint2*>(dGI16 + (node * k + t) * 3 * D + g * D + c) = make_uint2(0u, 0u);
+                    if (t > 0) *reinterpret_cast<uint2*>(dGH16 + ((size_t)(t - 1) * n + node) * 3 * D + g * D + c) = make_uint2(0u, 0u);
+                }
+                *reinterpret_cast<float4*>(dX + (node * k + t) * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        for (int i = tid; i < 6 * D; i += NT) part[i] = 0.f;
+        return;
+    }
+
+#ifdef SREC_GRUF_TIMING
+    const bool tim_on = (int)blockIdx.x == a.start[a.d.np - 1] + 1;
+    unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_c = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_grub_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int cbase = wave * 32 * JB;
+    const unsigned short* wf_ih = (const unsigned short*)q.Wih_f[p] + (size_t)wave * 3 * KS * JB * 512;
+    const unsigned short* wf_hh = (const unsigned short*)q.Whh_f[p] + (size_t)wave * 3 * KS * JB * 512;
+    const bool full = node0 + NR <= nl;
+    const float ik = 0.5f / (float)k;
+    float si[12], shn[4];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) si[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) shn[e] = 0.f;
+
+    uint2 pr[NP], pz[NP], pn[NP], phn[NP];      // 4 fp16 each
+    float4 php[NP], dhz[NP];
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    auto h4f = [](uint2 u) {
+        const h4_t v = __builtin_bit_cast(h4_t, u);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    };
+    auto fetch = [&](int t, auto LO, auto HI) {
+#pragma unroll
+        for (int i = decltype(LO)::value; i < decltype(HI)::value; ++i) {
+            const int node = node0 + i * RPP + erow;
+            pr[i] = pz[i] = pn[i] = phn[i] = make_uint2(0u, 0u);
+            php[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (full || node < nl) {
+                const _Float16* g = gates + ((size_t)t * n + node) * 4 * D + ec;
+                pr[i] = *reinterpret_cast<const uint2*>(g); pz[i] = *reinterpret_cast<const uint2*>(g + D);
+                pn[i] = *reinterpret_cast<const uint2*>(g + 2 * D); phn[i] = *reinterpret_cast<const uint2*>(g + 3 * D);
+                if (t > 0) php[i] = ld4(H + ((size_t)(t - 1) * n + node) * D + ec);
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dhz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    using I0 = std::integral_constant<int, 0>;
+    using IH = std::integral_constant<int, NP / 2>;
+    using IN = std::integral_constant<int, NP>;
+    fetch(k - 1, I0{}, IH{});
+
+    for (int t = k - 1; t >= 0; --t) {
+        int tid_v = tid;
+        asm volatile("" : "+v"(tid_v));
+        const int er = tid_v / TPR, c = (tid_v % TPR) * 4;
+        const bool has_h = t > 0;
+        unsigned short* dGI16t = dGI16 + (size_t)t * 3 * D;
+        unsigned short* dGH16t = dGH16 + (size_t)(has_h ? t - 1 : 0) * n * 3 * D;
+        unsigned short* git = gi + (size_t)t * 16 * 3 * D;
+        // ---- E: gate derivatives
+        fetch(t, IH{}, IN{});
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = i * RPP + er;
+            const int node = node0 + row;
+            float4 dpr = make_float4(0.f, 0.f, 0.f, 0.f), dpz = dpr, dpn = dpr, dgn = dpr;
+            if (full || node < nl) {
+                const float4 r = h4f(pr[i]), z = h4f(pz[i]), nn = h4f(pn[i]), hn = h4f(phn[i]), hp = php[i];
+                float4 dh;
+                if (t == k - 1) {
+                    const float4 go = ld4(dout + (size_t)node * D + c);
+                    dh = make_float4(0.5f * go.x, 0.5f * go.y, 0.5f * go.z, 0.5f * go.w);
+                } else {
+                    const float4 pd = *reinterpret_cast<const float4*>(dht + row * DS + c);
+                    dh = make_float4(dhz[i].x + pd.x, dhz[i].y + pd.y, dhz[i].z + pd.z, dhz[i].w + pd.w);
+                }
+#define GB_LANE(e)                                                                 \
+    {                                                                              \
+        const float dn = dh.e * (1.f - z.e), dz = dh.e * (hp.e - nn.e);            \
+        dpn.e = dn * (1.f - nn.e * nn.e);                                          \
+        dpr.e = dpn.e * hn.e * r.e * (1.f - r.e);                                  \
+        dpz.e = dz * z.e * (1.f - z.e);                                            \
+        dgn.e = dpn.e * r.e;                                                       \
+        dhz[i].e = dh.e * z.e;                                                     \
+    }
+                GB_LANE(x) GB_LANE(y) GB_LANE(z) GB_LANE(w)
+#undef GB_LANE
+            }
+            const uint2 br = make_uint2(srec_pack_bf16(dpr.x, dpr.y), srec_pack_bf16(dpr.z, dpr.w));
+            const uint2 bz = make_uint2(srec_pack_bf16(dpz.x, dpz.y), srec_pack_bf16(dpz.z, dpz.w));
+            const uint2 bn = make_uint2(srec_pack_bf16(dpn.x, dpn.y), srec_pack_bf16(dpn.z, dpn.w));
+            const uint2 bg = make_uint2(srec_pack_bf16(dgn.x, dgn.y), srec_pack_bf16(dgn.z, dgn.w));
+            const int sw = row & 15, pc = c >> 3, ho = c & 4;
+            *reinterpret_cast<uint2*>(git + row * 3 * D + ((pc ^ sw) * 8) + ho) = br;
+            *reinterpret_cast<uint2*>(git + row * 3 * D + (((D / 8 + pc) ^ sw) * 8) + ho) = bz;
+            *reinterpret_cast<uint2*>(git + row * 3 * D + (((2 * D / 8 + pc) ^ sw) * 8) + ho) = bn;
+            if (has_h) *reinterpret_cast<uint2*>(nh + row * D + ((pc ^ sw) * 8) + ho) = bg;
+            if (full || node < n) {
+                const unsigned go = (unsigned)node * k * 3 * D + c;
+                *reinterpret_cast<uint2*>(dGI16t + go) = br;
+                *reinterpret_cast<uint2*>(dGI16t + go + D) = bz;
+                *reinterpret_cast<uint2*>(dGI16t + go + 2 * D) = bn;
+                if (has_h) {
+                    const unsigned ho2 = (unsigned)node * 3 * D + c;
+                    *reinterpret_cast<uint2*>(dGH16t + ho2) = br;
+                    *reinterpret_cast<uint2*>(dGH16t + ho2 + D) = bz;
+                    *reinterpret_cast<uint2*>(dGH16t + ho2 + 2 * D) = bg;
+                }
+            }
+            si[0] += dpr.x; si[1] += dpr.y; si[2] += dpr.z; si[3] += dpr.w;
+            si[4] += dpz.x; si[5] += dpz.y; si[6] += dpz.z; si[7] += dpz.w;
+            si[8] += dpn.x; si[9] += dpn.y; si[10] += dpn.z; si[11] += dpn.w;
+            shn[0] += dgn.x; shn[1] += dgn.y; shn[2] += dgn.z; shn[3] += dgn.w;
+        }
+        GBT(0);
+        __syncthreads();                         // this step's A rows and the direct term of d h_{t-1} published
+        GBT(1);
+        if (!has_h) break;
+
+        // ---- G: d h_{t-1} += d(gh_t) W_hh; this wave's 32 JB output columns (tile rows 16 .. 31 repeat 0 .. 15: ignored)
+        f32x16 ah[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ah[j][r] = 0.f;
+        {
+            constexpr int T = 3 * KS;
+            bf16x8 Bq[NS][JB];
+            auto load = [&](int i, int slot) {
+                i = min(i, T - 1);
+                const unsigned short* s1 = wf_hh + (size_t)i * JB * 512 + lane * 8;
+#pragma unroll
+                for (int j = 0; j < JB; ++j) Bq[slot][j] = *reinterpret_cast<const bf16x8*>(s1 + j * 512);
+            };
+#pragma unroll
+            for (int i = 0; i < PF; ++i) load(i, i);
+            const unsigned short* arow = git + l15 * 3 * D;
+            const unsigned short* nrow = nh + l15 * D;
+#pragma unroll 1
+            for (int ib = 0; ib < T; ib += NS) {
+                const bool npart = ib >= 2 * KS;
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    load(ib + u + PF, (u + PF) % NS);
+                    const int s = ib + u;
+                    bf16x8 Ah;
+                    if (!npart) Ah = *reinterpret_cast<const bf16x8*>(arow + (((2 * s + half) ^ l15) * 8));
+                    else Ah = *reinterpret_cast<const bf16x8*>(nrow + (((2 * (s - 2 * KS) + half) ^ l15) * 8));
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) ah[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bq[u][j], ah[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, JB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, JB, 0);
+                }
+            }
+        }
+        GBT(2);
+        // ---- S: next step's gate inputs on their way; d(gh_t) W_hh into the LDS d h tile
+        fetch(t - 1, I0{}, IH{});
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        const int l31v = lane_v & 31, halfv = lane_v >> 5;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < NRR; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
+                dht[row * DS + cbase + 32 * j + l31v] = ah[j][r];
+            }
+        GBT(3);
+        __syncthreads();                         // d h_{t-1} complete; nh free again
+        GBT(4);
+    }
+
+    // ---- X: d x rows of all steps: [16 k, 3 d] x W_ih, one pass over the weight fragments
+    const int ntb = (16 * k + 31) / 32;          // 32-row tiles (1 or 2)
+    f32x16 ax[2][JB];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ax[b][j][r] = 0.f;
+    auto xprod = [&](auto TWO) {
+        constexpr bool TW = decltype(TWO)::value;
+        constexpr int T = 3 * KS;
+        bf16x8 Bq[NS][JB];
+        auto load = [&](int i, int slot) {
+            i = min(i, T - 1);
+            const unsigned short* s0 = wf_ih + (size_t)i * JB * 512 + lane * 8;
+#pragma unroll
+            for (int j = 0; j < JB; ++j) Bq[slot][j] = *reinterpret_cast<const bf16x8*>(s0 + j * 512);
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load(i, i);
+        const int R0 = min(l31, 16 * k - 1), R1 = min(32 + l31, 16 * k - 1);     // rows past the last step repeat it: ignored
+        const unsigned short* a0 = gi + (size_t)R0 * 3 * D;
+        const unsigned short* a1 = gi + (size_t)R1 * 3 * D;
+        const int x0 = R0 & 15, x1 = R1 & 15;
+#pragma unroll 1
+        for (int ib = 0; ib < T; ib += NS) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                load(ib + u + PF, (u + PF) % NS);
+                const int s = ib + u;
+                const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(a0 + (((2 * s + half) ^ x0) * 8));
+                bf16x8 A1;
+                if (TW) A1 = *reinterpret_cast<const bf16x8*>(a1 + (((2 * s + half) ^ x1) * 8));
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    ax[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, Bq[u][j], ax[0][j], 0, 0, 0);
+                    if (TW) ax[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, Bq[u][j], ax[1][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, JB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TW ? 2 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TW ? 2 * JB : JB, 0);
+            }
+        }
+    };
+    // the mean term 0.5 d out / k of this wave's columns in the store layout: patch row r belongs to node r & 15 in either tile;
+    // requested here, it arrives behind the product
+    constexpr int XQPR = 8 * JB, XNQ = 32 * XQPR / 64;
+    float4 gmean[XNQ];
+#pragma unroll
+    for (int i = 0; i < XNQ; ++i) {
+        const int idx = i * 64 + lane;
+        const int node = node0 + ((idx / XQPR) & 15), c4 = (idx % XQPR) * 4;
+        gmean[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (full || node < nl) gmean[i] = ld4(dout + (unsigned)node * D + cbase + c4);
+    }
+    if (ntb == 2) xprod(std::true_type{});
+    else xprod(std::false_type{});
+    GBT(5);
+    __syncthreads();                             // every wave is done with the d(gi) tiles: they become the store patches
+    {
+        float* patch = patches + wave * 32 * PS;
+        constexpr int QPR = 8 * JB;              // float4 per patch row
+        constexpr int NQ = 32 * QPR / 64;
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        const int l31v = lane_v & 31, halfv = lane_v >> 5;
+        for (int b = 0; b < ntb; ++b) {
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * halfv;
+                    patch[row * PS + 32 * j + l31v] = b == 0 ? ax[0][j][r] : ax[1][j][r];
+                }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int idx = i * 64 + lane_v;
+                const int prow = idx / QPR, c4 = (idx % QPR) * 4;
+                const int R = 32 * b + prow, t = R >> 4, node = node0 + (R & 15);
+                if (t < k && (full || node < n)) {
+                    float4 v = *reinterpret_cast<const float4*>(patch + prow * PS + c4);
+                    if (full || node < nl) { v.x += ik * gmean[i].x; v.y += ik * gmean[i].y; v.z += ik * gmean[i].z; v.w += ik * gmean[i].w; }
+                    else v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(dX + ((size_t)node * k + t) * D + cbase + c4) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();                             // patches read: the bias reduction takes the same LDS
+
+    // ---- bias gradients: column sums over the row groups
+    float* red = reinterpret_cast<float*>(sm);   // [RPP][16][TPR] floats
+#pragma unroll
+    for (int e = 0; e < 12; ++e) red[(erow * 16 + e) * TPR + tid % TPR] = si[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(erow * 16 + 12 + e) * TPR + tid % TPR] = shn[e];
+    __syncthreads();
+    for (int o = tid; o < 6 * D; o += NT) {
+        const int hh = o / (3 * D), gate = (o % (3 * D)) / D, col = o % D;
+        const int e = (hh == 1 && gate == 2 ? 12 : 4 * gate) + (col & 3);
+        float s = 0.f;
+#pragma unroll
+        for (int rg = 0; rg < RPP; ++rg) s += red[(rg * 16 + e) * TPR + (col >> 2)];
+        part[o] = s;
+    }
+    (void)ec; (void)l31;
+#ifdef SREC_GRUF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GBT(6);
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_grub_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    if (tim_on && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_grub_tim[i] = tim_t[i];
+#endif
+}
+
 }  // namespace
 extern "C" int srec_gru_fused_waves(int d, int* waves);
 namespace {
@@ -506,6 +849,22 @@ extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
         if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<DDV, NRV, NWV>, (int)lds, om[slot])) return rc;  \
         hipLaunchKernelGGL((gru_fused_bwd_kernel<DDV, NRV, NWV>), dim3(blocks), dim3(64 * NWV), lds, (hipStream_t)stream, a); \
     } while (0)
+    bool batch = NRv == 16;                      // gru_fused_bwd16_kernel holds the d(gi) rows of <= 4 time steps
+    for (int p = 0; p < q->np; ++p) batch = batch && q->k[p] <= 4;
+    static const bool no16 = getenv("SREC_GRU_BWD16") != nullptr && atoi(getenv("SREC_GRU_BWD16")) == 0;   // development: A / B
+    if (batch && !no16) {
+        const size_t lds16 = (size_t)(16 * 4 * 3 * D) * 2 + (size_t)16 * D * 2 + (size_t)16 * (D + 8) * 4;
+        static std::atomic<unsigned long long> om16[2];
+        if (D == 256) {
+            if (int rc = srec_lds_optin((const void*)gru_fused_bwd16_kernel<2, 8>, (int)lds16, om16[0])) return rc;
+            hipLaunchKernelGGL((gru_fused_bwd16_kernel<2, 8>), dim3(blocks), dim3(64 * 8), lds16, (hipStream_t)stream, a);
+        } else {
+            if (int rc = srec_lds_optin((const void*)gru_fused_bwd16_kernel<1, 4>, (int)lds16, om16[1])) return rc;
+            hipLaunchKernelGGL((gru_fused_bwd16_kernel<1, 4>), dim3(blocks), dim3(64 * 4), lds16, (hipStream_t)stream, a);
+        }
+        SREC_LAUNCH_CHECK();
+        return 0;
+    }
     if (D == 256) { if (NRv == 16) SREC_GB(2, 16, 8, 4); else SREC_GB(2, 32, 8, 5); }
     else { if (NRv == 16) SREC_GB(1, 16, 4, 2); else SREC_GB(1, 32, 4, 3); }
 #undef SREC_GB
