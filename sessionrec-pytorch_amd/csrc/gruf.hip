@@ -582,11 +582,28 @@ extern "C" int srec_gru_wfrag(int n, const void* W, const void* dst, int d, void
 
 
 // desc: HOST srec_gru_fused_desc (srec_hg.h)
+// longest problems first (workgroups start in index order; see srec_gru_fused_bwd)
+static void longest_first(srec_gru_fused_desc& d) {
+    int ord[GF_MAXP];
+    for (int i = 0; i < d.np; ++i) ord[i] = i;
+    for (int i = 1; i < d.np; ++i)
+        for (int j = i; j > 0 && d.k[ord[j]] > d.k[ord[j - 1]]; --j) { const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }
+    const srec_gru_fused_desc s = d;
+    for (int q = 0; q < d.np; ++q) {
+        const int p = ord[q];
+        d.n[q] = s.n[p]; d.k[q] = s.k[p]; d.dyn[q] = s.dyn[p]; d.X[q] = s.X[p]; d.X16[q] = s.X16[p]; d.Wih_f[q] = s.Wih_f[p];
+        d.Whh_f[q] = s.Whh_f[p]; d.bih[q] = s.bih[p]; d.bhh[q] = s.bhh[p]; d.H[q] = s.H[p]; d.H16[q] = s.H16[p];
+        d.gates[q] = s.gates[p]; d.out[q] = s.out[p];
+    }
+}
+
 extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
-    const srec_gru_fused_desc* q = (const srec_gru_fused_desc*)desc;
-    if (q == nullptr || q->np <= 0 || q->np > GF_MAXP || (q->d != 128 && q->d != 256)) return SREC_BAD_ARG;
+    const srec_gru_fused_desc* q0 = (const srec_gru_fused_desc*)desc;
+    if (q0 == nullptr || q0->np <= 0 || q0->np > GF_MAXP || (q0->d != 128 && q0->d != 256)) return SREC_BAD_ARG;
     FusedArgs a{};
-    a.d = *q;
+    a.d = *q0;
+    longest_first(a.d);
+    const srec_gru_fused_desc* q = &a.d;
     int blocks = 0;
     for (int p = 0; p < q->np; ++p) {
         if (q->n[p] < 0 || q->k[p] < 1 || q->X[p] == nullptr || q->X16[p] == nullptr || q->Wih_f[p] == nullptr ||

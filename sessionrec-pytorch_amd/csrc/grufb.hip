@@ -338,6 +338,27 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
 }
 
 
+// streaming accesses of the 16-node kernel: every input row is read once and every output row written once per launch - marked
+// non-temporal so that they do not push the weight fragments (re-read by every workgroup of the XCD) out of L2
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 ldnt2(const void* p) {
+    const u2_t v = __builtin_nontemporal_load(reinterpret_cast<const u2_t*>(p));
+    return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+    const f4_t v = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stnt2(void* p, uint2 v) {
+    const u2_t w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<u2_t*>(p));
+}
+__device__ __forceinline__ void stnt4(float* p, float4 v) {
+    const f4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f4_t*>(p));
+}
+
 // ---- 16-node workgroups, k <= 4: d x for ALL time steps as one product behind the recurrence ---------------------------------
 // The step loop above streams W_ih AND W_hh through every wave once per time step (2 k - 1 passes over 1.5 d^2 bf16 each) for
 // MFMA tiles whose lower half idles.  d x_t = d(gi_t) W_ih is not part of the recurrence: here the loop keeps only
@@ -400,7 +421,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
 #ifdef SREC_GRUF_TIMING
     const bool tim_on = (int)blockIdx.x == a.start[a.d.np - 1] + 1;
     unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_c = __builtin_readcyclecounter();
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_grub_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tim_r0 = __builtin_amdgcn_s_memrealtime(), tim_c0 = tim_c;
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_grub_blk[blockIdx.x][0] = tim_r0;
 #endif
     const int cbase = wave * 32 * JB;
     const unsigned short* wf_ih = (const unsigned short*)q.Wih_f[p] + (size_t)wave * 3 * KS * JB * 512;
@@ -428,18 +450,20 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
             php[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (full || node < nl) {
                 const _Float16* g = gates + ((size_t)t * n + node) * 4 * D + ec;
-                pr[i] = *reinterpret_cast<const uint2*>(g); pz[i] = *reinterpret_cast<const uint2*>(g + D);
-                pn[i] = *reinterpret_cast<const uint2*>(g + 2 * D); phn[i] = *reinterpret_cast<const uint2*>(g + 3 * D);
-                if (t > 0) php[i] = ld4(H + ((size_t)(t - 1) * n + node) * D + ec);
+                pr[i] = ldnt2(g); pz[i] = ldnt2(g + D);
+                pn[i] = ldnt2(g + 2 * D); phn[i] = ldnt2(g + 3 * D);
+                if (t > 0) php[i] = ldnt4(H + ((size_t)(t - 1) * n + node) * D + ec);
             }
         }
     };
 #pragma unroll
     for (int i = 0; i < NP; ++i) dhz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     using I0 = std::integral_constant<int, 0>;
-    using IH = std::integral_constant<int, NP / 2>;
     using IN = std::integral_constant<int, NP>;
-    fetch(k - 1, I0{}, IH{});
+    // inputs of phase E (saved gates, h_{t-1}) for ALL rows one step ahead, requested in front of the W_hh product that hides them
+    // (the step's copy of this kernel finds none of its inputs in a cache: 54 us against 31 us for a warm loop, 41 us for an
+    // immediate second launch - profiles/r05_notes.md)
+    fetch(k - 1, I0{}, IN{});
 
     for (int t = k - 1; t >= 0; --t) {
         int tid_v = tid;
@@ -450,7 +474,6 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
         unsigned short* dGH16t = dGH16 + (size_t)(has_h ? t - 1 : 0) * n * 3 * D;
         unsigned short* git = gi + (size_t)t * 16 * 3 * D;
         // ---- E: gate derivatives
-        fetch(t, IH{}, IN{});
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = i * RPP + er;
@@ -489,14 +512,14 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
             if (has_h) *reinterpret_cast<uint2*>(nh + row * D + ((pc ^ sw) * 8) + ho) = bg;
             if (full || node < n) {
                 const unsigned go = (unsigned)node * k * 3 * D + c;
-                *reinterpret_cast<uint2*>(dGI16t + go) = br;
-                *reinterpret_cast<uint2*>(dGI16t + go + D) = bz;
-                *reinterpret_cast<uint2*>(dGI16t + go + 2 * D) = bn;
+                stnt2(dGI16t + go, br);
+                stnt2(dGI16t + go + D, bz);
+                stnt2(dGI16t + go + 2 * D, bn);
                 if (has_h) {
                     const unsigned ho2 = (unsigned)node * 3 * D + c;
-                    *reinterpret_cast<uint2*>(dGH16t + ho2) = br;
-                    *reinterpret_cast<uint2*>(dGH16t + ho2 + D) = bz;
-                    *reinterpret_cast<uint2*>(dGH16t + ho2 + 2 * D) = bg;
+                    stnt2(dGH16t + ho2, br);
+                    stnt2(dGH16t + ho2 + D, bz);
+                    stnt2(dGH16t + ho2 + 2 * D, bg);
                 }
             }
             si[0] += dpr.x; si[1] += dpr.y; si[2] += dpr.z; si[3] += dpr.w;
@@ -510,6 +533,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
         if (!has_h) break;
 
         // ---- G: d h_{t-1} += d(gh_t) W_hh; this wave's 32 JB output columns (tile rows 16 .. 31 repeat 0 .. 15: ignored)
+        fetch(t - 1, I0{}, IN{});                 // next step's gate inputs on their way
         f32x16 ah[JB];
 #pragma unroll
         for (int j = 0; j < JB; ++j)
@@ -547,8 +571,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
             }
         }
         GBT(2);
-        // ---- S: next step's gate inputs on their way; d(gh_t) W_hh into the LDS d h tile
-        fetch(t - 1, I0{}, IH{});
+        // ---- S: d(gh_t) W_hh into the LDS d h tile
         int lane_v = lane;
         asm volatile("" : "+v"(lane_v));
         const int l31v = lane_v & 31, halfv = lane_v >> 5;
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
                     float4 v = *reinterpret_cast<const float4*>(patch + prow * PS + c4);
                     if (full || node < nl) { v.x += ik * gmean[i].x; v.y += ik * gmean[i].y; v.z += ik * gmean[i].z; v.w += ik * gmean[i].w; }
                     else v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(dX + ((size_t)node * k + t) * D + cbase + c4) = v;
+                    stnt4(dX + ((size_t)node * k + t) * D + cbase + c4, v);
                 }
             }
         }
@@ -675,8 +698,11 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GBT(6);
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_grub_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-    if (tim_on && threadIdx.x == 0)
+    if (tim_on && threadIdx.x == 0) {
         for (int i = 0; i < 8; ++i) g_grub_tim[i] = tim_t[i];
+        g_grub_tim[8] = __builtin_readcyclecounter() - tim_c0;              // shader clocks ...
+        g_grub_tim[9] = __builtin_amdgcn_s_memrealtime() - tim_r0;          // ... over 100 MHz ticks of the same workgroup
+    }
 #endif
 }
 
@@ -813,12 +839,32 @@ extern "C" int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes) {
     return 0;
 }
 
+// Workgroups start in index order and an order-k workgroup lives ~k time steps: with more live workgroups than CUs (one per CU:
+// the d(gi) tiles fill most of the LDS) the ones that wait start when the first residents retire.  Longest problems first: the
+// late starters are then the SHORT ones, behind the first short residents (measured on the C3 batches whose live 16-node tiles
+// exceed 256: 52 us with the order-3 tiles last, ~36 us for the batches that fit one round - profiles/r05_notes.md).
+static void longest_first(srec_gru_fused_bwd_desc& d) {
+    int ord[GB_MAXP];
+    for (int i = 0; i < d.np; ++i) ord[i] = i;
+    for (int i = 1; i < d.np; ++i)
+        for (int j = i; j > 0 && d.k[ord[j]] > d.k[ord[j - 1]]; --j) { const int t = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = t; }
+    const srec_gru_fused_bwd_desc s = d;
+    for (int q = 0; q < d.np; ++q) {
+        const int p = ord[q];
+        d.n[q] = s.n[p]; d.k[q] = s.k[p]; d.dyn[q] = s.dyn[p]; d.gates[q] = s.gates[p]; d.H[q] = s.H[p]; d.dout[q] = s.dout[p];
+        d.Wih_f[q] = s.Wih_f[p]; d.Whh_f[q] = s.Whh_f[p]; d.dGI16[q] = s.dGI16[p]; d.dGH16[q] = s.dGH16[p]; d.dX[q] = s.dX[p];
+        d.bias_part[q] = s.bias_part[p]; d.part_row0[q] = s.part_row0[p];
+    }
+}
+
 // desc: HOST srec_gru_fused_bwd_desc (srec_hg.h)
 extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
-    const srec_gru_fused_bwd_desc* q = (const srec_gru_fused_bwd_desc*)desc;
-    if (q == nullptr || q->np <= 0 || q->np > GB_MAXP || (q->d != 128 && q->d != 256)) return SREC_BAD_ARG;
+    const srec_gru_fused_bwd_desc* q0 = (const srec_gru_fused_bwd_desc*)desc;
+    if (q0 == nullptr || q0->np <= 0 || q0->np > GB_MAXP || (q0->d != 128 && q0->d != 256)) return SREC_BAD_ARG;
     BwdArgs a{};
-    a.d = *q;
+    a.d = *q0;
+    longest_first(a.d);
+    const srec_gru_fused_bwd_desc* q = &a.d;
     int blocks = 0;
     for (int p = 0; p < q->np; ++p) {
         if (q->n[p] < 0 || q->k[p] < 1 || q->gates[p] == nullptr || q->H[p] == nullptr || q->dout[p] == nullptr ||
