@@ -264,10 +264,20 @@ __global__ void sum_slabs_multi_kernel(SlabArgs a) {
     }
     const long i = ((long)((int)blockIdx.x - a.start[p]) * blockDim.x + threadIdx.x) * 4;
     if (i >= a.n[p]) return;
-    const float* q = a.part[p];
-    float4 s = ld4(q + i);
-    for (int r = 1; r < a.R[p]; ++r) {
-        const float4 v = ld4(q + (size_t)r * a.n[p] + i);
+    const float* q = a.part[p] + i;
+    const size_t n = (size_t)a.n[p];
+    const int R = a.R[p];
+    float4 s = ld4(q);
+    int r = 1;
+    for (; r + 8 <= R; r += 8) {                 // 8 slab loads in flight (the k-split products leave 25 - 32 slabs: a latency chain
+        float4 v[8];                             // otherwise); added in slab order: the same sum as the one-by-one loop
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ld4(q + (size_t)(r + e) * n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s.x += v[e].x; s.y += v[e].y; s.z += v[e].z; s.w += v[e].w; }
+    }
+    for (; r < R; ++r) {
+        const float4 v = ld4(q + (size_t)r * n);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const int w = a.w[p];
