@@ -245,6 +245,7 @@ int srec_bn_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const floa
                 float* dgamma, float* dbeta, float* ws, void* stream);
 int srec_prelu_fwd(const float* X, int ld_x, const float* a, int n_cap, const int* dyn, int D, float* Y, int ld_y,
                    void* stream);
+/* da NULL: the 32 chunk partials of d a stay in ws [32][D] for the caller to sum (srec_sum_slabs_multi, a 'tall' task) */
 int srec_prelu_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const float* a, int n_cap, const int* dyn,
                    int D, float* dX, int ld_dx, float* da, float* ws, void* stream);
 /* EOPA: per node GRU over in-neighbours in edge-id order (lessr.py:20-27,35).  GI [Nsrc,3D] = ft W_ih^T + b_ih;

@@ -316,7 +316,7 @@ extern "C" int srec_prelu_fwd(const float* X, int ld_x, const float* a, int n_ca
     return 0;
 }
 
-// dX and d a[c] = sum dy * min(x, 0).  ws: 32*D floats
+// dX and d a[c] = sum dy * min(x, 0).  ws: 32*D floats = the chunk partials [32][D]; da NULL: they are left to the caller to sum
 extern "C" int srec_prelu_bwd(const float* dY, int ld_dy, const float* X, int ld_x, const float* a, int n_cap,
                               const int* dyn, int D, float* dX, int ld_dx, float* da, float* ws, void* stream) {
     if (n_cap <= 0) return 0;
@@ -324,7 +324,7 @@ extern "C" int srec_prelu_bwd(const float* dY, int ld_dy, const float* X, int ld
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(prelu_bwd_kernel, dim3(cdiv(D, 64), NCHUNK), dim3(256), 0, st, dY, ld_dy, X, ld_x, a, n_cap, dyn, D, dX,
                        ld_dx, ws);
-    hipLaunchKernelGGL(colstat_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, ws, D, da);
+    if (da != nullptr) hipLaunchKernelGGL(colstat_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, ws, D, da);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -924,6 +924,7 @@ class SegAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, U, Vq, we, X, seg, dynB):
         U, Vq, X = _rows(U), _rows(Vq), _rows(X)
+        ctx.defer, ctx.wparams = defer_scope(), [we]
         we = we.reshape(-1).contiguous()
         B, h = Vq.shape
         N, D = X.shape
@@ -949,7 +950,12 @@ class SegAttn(torch.autograd.Function):
                               ptr(we), ptr(seg), B, ptr(ctx.dynB), h, D, N, ptr(dX), D, ptr(dU), h, ptr(dVq), h, ptr(dwp),
                               h, stream())
         dwe = torch.empty(h, device=X.device, dtype=torch.float32)
-        col_sum(dwp, B, h, dwe, ctx.dynB)
+        if h % 4 == 0 and can_defer(ctx.defer, ctx.wparams):
+            # d fc_e = the column sums of the per-session rows (dead sessions' rows are zeros): a 'tall' task of the ONE
+            # end-of-backward slab-sum launch instead of two launches here
+            defer_slab_sum(dwp, dwe, True, tall=True)
+        else:
+            col_sum(dwp, B, h, dwe, ctx.dynB)
         return dU, dVq, dwe.view(1, h), dX, None, None
 
 
@@ -2265,6 +2271,7 @@ class PReLU(torch.autograd.Function):
         lib.srec_prelu_fwd(ptr(x), _ld(x), ptr(a), n, ptr(dyn), D, ptr(y), D, stream())
         ctx.save_for_backward(x, a)
         ctx.dyn = dyn
+        ctx.defer, ctx.wparams = defer_scope(), [a]
         return y
 
     @staticmethod
@@ -2274,8 +2281,15 @@ class PReLU(torch.autograd.Function):
         n, D = x.shape
         dx = torch.empty(n, D, device=x.device, dtype=torch.float32)
         da = torch.empty(D, device=x.device, dtype=torch.float32)
-        lib.srec_prelu_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(a), n, ptr(ctx.dyn), D, ptr(dx), D, ptr(da),
-                           ptr(_ws(32 * D, x.device)), stream())
+        if D % 4 == 0 and n > 0 and can_defer(ctx.defer, ctx.wparams):
+            # the 32 chunk partials of d a wait (private buffer) for the end-of-backward slab-sum launch: da = NULL skips the
+            # kernel's own final sum
+            part = torch.empty(32, D, device=x.device, dtype=torch.float32)
+            lib.srec_prelu_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(a), n, ptr(ctx.dyn), D, ptr(dx), D, None, ptr(part), stream())
+            defer_slab_sum(part, da, True, tall=True)
+        else:
+            lib.srec_prelu_bwd(ptr(gy), _ld(gy), ptr(x), _ld(x), ptr(a), n, ptr(ctx.dyn), D, ptr(dx), D, ptr(da),
+                               ptr(_ws(32 * D, x.device)), stream())
         return dx, da, None
 
 
