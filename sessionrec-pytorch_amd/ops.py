@@ -2321,6 +2321,7 @@ class GRUSeq(torch.autograd.Function):
                              ptr(neigh), D, ptr(gates), ptr(Hprev), ptr(ghn), stream())
         ctx.save_for_backward(Whh, gates, Hprev, ghn)
         ctx.graph, ctx.dyn, ctx.dynE, ctx.shape = graph, dyn, dynE, (N, D, E)
+        ctx.defer, ctx.wparams = defer_scope(), [Whh, bhh]
         return neigh
 
     @staticmethod
@@ -2344,7 +2345,8 @@ class GRUSeq(torch.autograd.Function):
         if E > 0 and _small_linear(Whh):                       # one grouped launch: d W_hh and d b_hh (product with ones)
             sums = torch.empty(4, 3 * D, device=dev, dtype=torch.float32)
             gemm_f32_group([('tn', dGHe[:E], Hprev[:E], dWhh, None, ctx.dynE, 0.0),
-                            ('tn', _ones4(E, dev)[:E], dGHe[:E], sums, None, ctx.dynE, 0.0)])
+                            ('tn', _ones4(E, dev)[:E], dGHe[:E], sums, None, ctx.dynE, 0.0)],
+                           defer=[dWhh, sums] if can_defer(ctx.defer, ctx.wparams) else None)
             dbhh = sums[0]
         elif E > 0:
             gemm_tn(dGHe[:E], Hprev[:E], dWhh, ctx.dynE)       # padded edge records are zero rows
