@@ -644,6 +644,13 @@ def defer_scope():
     return bool(DEFER['on'])
 
 
+def drop_stale_deferred():
+    """a backward pass that raised leaves its waiting sums behind (the engine drops its callbacks): forget them before the next
+    forward - their buffers belong to a graph that is gone, and a non-empty list would keep the next pass from registering its
+    own end-of-backward callback"""
+    del _DEFERRED[:]
+
+
 def can_defer(flag, params):
     """backward-time check: every target parameter still without a gradient and without tensor hooks"""
     if not flag:

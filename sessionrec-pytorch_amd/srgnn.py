@@ -142,6 +142,8 @@ class _ScoringMixin:
         # every parameter of these models feeds exactly one backward node: the split-K sums of the small grouped backward
         # launches may wait for ONE launch at the end of the backward pass (ops.defer_scope; MSGIFSR switches it itself)
         prev_defer = ops.DEFER['on']
+        if not prev_defer:
+            ops.drop_stale_deferred()          # (left behind by a backward pass that raised)
         ops.DEFER['on'] = bool(prev_defer or (self.training and self._table().is_cuda and getattr(self, 'defer_slab_sums', True)))
         try:
             sr = self.session_repr(*inputs, tgrad=st['tgrad'])

@@ -1443,3 +1443,42 @@ def test_gemm_f32_group_split_k_with_bias_beta_and_dynamic_rows(dev):
     o = cat @ Wsr.t() + bias
     o[501:] = 0
     close(ref[2], o, what='out', atol=1e-4)
+
+
+def test_deferred_sums_of_an_aborted_backward_are_forgotten(dev):
+    """a backward pass that raises leaves its deferred slab sums registered; the next training forward drops them instead of
+    summing freed buffers into freed gradients at the end of the next backward (and registers its own callback again)"""
+    ops = _ops()
+    part = torch.ones(4, 8, device=dev)
+    out = torch.zeros(8, device=dev)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            ops.defer_slab_sum(part, out, True)
+            raise RuntimeError('boom')
+
+    x = torch.ones(3, device=dev, requires_grad=True)
+    with pytest.raises(RuntimeError, match='boom'):
+        Boom.apply(x).sum().backward()
+    assert len(ops._DEFERRED) == 1
+    ops.drop_stale_deferred()
+    assert len(ops._DEFERRED) == 0 and float(out.sum()) == 0.0
+
+    class Fine(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            ops.defer_slab_sum(part, out, True)
+            return g
+
+    Fine.apply(x).sum().backward()
+    torch.cuda.synchronize()
+    assert len(ops._DEFERRED) == 0 and float(out.sum()) == 32.0
