@@ -148,7 +148,10 @@ struct DotsArgs {
 // l >> 4) reads 16 bytes of its node row per 16-k block - both operands use the k-order (16 j + 4 (l >> 4) + t), which a
 // reduction does not care about.  A [N, D] x [D, 16] product: 16 row loads + 16 LDS reads + 64 MFMAs per wave and 16 nodes
 // (round 2's thread-per-output loop: 64 + 64 + 256 FMA per thread, 16 nodes per workgroup and a 16-KB V staging each: 25 us).
-constexpr int DOTS_NODES = 64;
+#ifndef SREC_DOTS_NODES
+#define SREC_DOTS_NODES 64
+#endif
+constexpr int DOTS_NODES = SREC_DOTS_NODES;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void hg_dots_kernel(DotsArgs a) {
     extern __shared__ float vt[];                              // [16][D + 4] + 16 (a k tail past D reads finite values: its A side is 0)
@@ -191,31 +194,43 @@ __global__ __launch_bounds__(256) void hg_dots_kernel(DotsArgs a) {
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n0 = ((int)blockIdx.x - a.start[b]) * DOTS_NODES + wave * 16;
-    if (n0 >= a.ncap[b]) return;
     const int nl = dyn_count(a.dyn[b], a.ncap[b]);
+    for (int tl = 0; tl < DOTS_NODES / 64; ++tl) {                // (the staged vectors serve DOTS_NODES nodes)
+    const int n0 = ((int)blockIdx.x - a.start[b]) * DOTS_NODES + tl * 64 + wave * 16;
+    if (n0 >= a.ncap[b]) return;
     const int r = lane & 15, kq = lane >> 4;
     const bool rlive = n0 + r < nl;
     const float* xr = a.x[b] + (size_t)(a.row0[b] + n0 + r) * a.ld_x + 4 * kq;
     const float* v = vt + r * LDV + 4 * kq;                    // B operand: output column r of this lane
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < Dp; k0 += 16) {
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rlive && k0 + 4 * kq < D) xv = *reinterpret_cast<const float4*>(xr + k0);
-        const float4 vv = *reinterpret_cast<const float4*>(v + k0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, vv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, vv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, vv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, vv.w, acc, 0, 0, 0);
+    for (int k0 = 0; k0 < Dp; k0 += 64) {                      // 4 row loads in flight (one by one the loop is a latency chain)
+        float4 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + 16 * u;
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rlive && kk + 4 * kq < D) xv[u] = *reinterpret_cast<const float4*>(xr + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + 16 * u;
+            if (kk < Dp) {                                         // (uniform)
+                const float4 vv = *reinterpret_cast<const float4*>(v + kk);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, vv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, vv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, vv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, vv.w, acc, 0, 0, 0);
+            }
+        }
     }
     // acc[q] = result (node n0 + 4 (lane >> 4) + q, output lane & 15)
     const int o = lane & 15, lr = o >> 3, h = o & 7;
-    if (h >= H) return;
     float* out = lr ? a.eR[b] : a.eL[b];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = n0 + 4 * (lane >> 4) + q;
-        if (n < a.ncap[b]) out[(size_t)n * H + h] = acc[q];
+        if (h < H && n < a.ncap[b]) out[(size_t)n * H + h] = acc[q];
+    }
     }
 }
 
