@@ -521,6 +521,306 @@ def emit(obj):
     f.flush()
 
 
+class Env:
+    """what every job of this process shares"""
+    pass
+
+
+def make_job(env, args, precision, batches, dev_batches, strong, group=None, graph=True, log_prefix=''):
+    """model + optimizer + (captured) training step for one arithmetic mode and one batch geometry, from the same initial
+    weights.  Multi-rank jobs (or --shard / a replayed rank: `group`) row-shard the item table (dist.VocabParallel)."""
+    sp, ops, train, optim, dist, dev = env.sp, env.ops, env.train, env.optim, env.dist, env.dev
+    ops.set_precision(precision)
+    torch.manual_seed(123)
+    model = build_model(sp, args.model, env.V, env.d, args.order, args.dropout)
+    model.load_state_dict(env.state)
+    model = model.to(dev)
+    shard = None
+    if env.world > 1 or args.shard or group is not None:       # item table row-sharded over the node's GPUs (RCCL / xGMI)
+        D = importlib.import_module('sessionrec-pytorch_amd.dist')
+        cap = batches[0][0][0].cap('uniq_items')       # only the distinct items of a batch are exchanged; equal padded
+        if group is None:                              # request length on every rank: no per-step size exchange
+            t = torch.tensor([cap], device=dev)
+            _all_reduce(dist, t, dist.ReduceOp.MAX)
+            cap = int(t.item())
+        elif getattr(env, 'replay_cap', None):
+            cap = env.replay_cap
+        shard = D.VocabParallel(model, group=group, idx_cap=cap)
+    opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
+    replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
+    model.train()
+
+    def eager(b):
+        inp, lab = b
+        opt.zero_grad()
+        loss = model.fused_loss(*inp, lab)
+        loss.backward()
+        if shard is not None:
+            shard.sync_replicated_grads(replicated, opt)
+        opt.step()
+        return loss
+    job = dict(model=model, shard=shard, opt=opt, eager=eager, step=eager, graphed=False, gstep=None, attempts=0,
+               replicated=replicated, strong=strong, precision=precision, captured_on_all_ranks=None)
+    return job
+
+
+def capture_job(env, args, job, dev_batches, warmup=2):
+    """capture the job's step (graph.capture_agreed: the ranks of an N-GPU job retry and fall back TOGETHER)"""
+    dist, dev = env.dist, env.dev
+    G = importlib.import_module('sessionrec-pytorch_amd.graph')
+    model, opt, shard, replicated = job['model'], job['opt'], job['shard'], job['replicated']
+    multi = shard is not None and env.world > 1 and dist is not None
+    agree = (lambda x: _all_reduce(dist, torch.tensor([x], device=dev), dist.ReduceOp.MIN).item()) if multi else None
+    after = (lambda: shard.sync_replicated_grads(replicated, opt)) if shard is not None else None
+    # host-staged collectives (the gloo dry run) can never be captured: one attempt; RCCL: one agreed retry
+    retries = 1 if (shard is not None and dist is not None and dist.is_initialized() and dist.get_backend() == 'nccl') else 0
+    log = lambda m: print(m, file=sys.stderr, flush=True)
+    gstep, attempts, err = G.capture_agreed(
+        lambda: G.GraphedTrainStep(model, opt, dev_batches[0][0], dev_batches[0][1], after_backward=after, warmup=warmup),
+        agree, retries=retries, log=log)
+    job['attempts'] = attempts
+    if gstep is None:
+        if shard is None:
+            raise err
+        print('graph capture with the collectives failed (%s); running eager'
+              % (('%s: %s' % (type(err).__name__, str(err)[:300])) if err is not None else 'on another rank'),
+              file=sys.stderr, flush=True)
+    else:
+        job.update(step=(lambda b: gstep(b[0], b[1])), graphed=True, gstep=gstep)
+    job['captured_on_all_ranks'] = bool(gstep is not None)     # (agreed: the same on every rank)
+    return job
+
+
+def loss_check(env, args, job, dev_batch, first_samples, strong):
+    """the correctness bit of an N-rank line: the loss of the first global batch through the row-sharded forward (all ranks,
+    evaluation mode - dropout off - so the two paths see the same function) against the single-device forward rank 0 runs on the
+    same sessions from the same weights (train.py:97-99: model(*inputs) -> nll_loss)."""
+    dist, dev = env.dist, env.dev
+    model = job['model']
+    model.eval()
+    with torch.no_grad():
+        l_sh = float(model.fused_loss(*dev_batch[0], dev_batch[1]).item())
+    model.train()
+    # every rank's first batch travels to rank 0 as the sample lists (weak scaling: different sessions per rank)
+    if strong or dist is None or env.world == 1:
+        parts = [first_samples]
+    else:
+        parts = [None] * env.world
+        dist.all_gather_object(parts, first_samples)
+    out = None
+    if env.rank == 0:
+        env.ops.set_precision(job['precision'])
+        torch.manual_seed(123)
+        ref = build_model(env.sp, args.model, env.V, env.d, args.order, args.dropout)
+        ref.load_state_dict(env.state)
+        ref = ref.to(dev).eval()
+        col = importlib.import_module('sessionrec-pytorch_amd.collate')
+        if args.model in ('SRGNN', 'NISER'):
+            fn = col.collate_fn_factory(col.seq_to_session_graph)
+        elif args.model == 'LESSR':
+            fn = col.collate_fn_factory(col.seq_to_eop_multigraph)
+        else:
+            fn = col.collate_fn_factory_ccs((col.seq_to_ccs_graph,), args.order)
+        tot, n = 0.0, 0
+        with torch.no_grad():
+            for smp in parts:
+                inp, lab = fn(smp)
+                tot += float(ref.fused_loss(*[x.to(dev) for x in inp], lab.to(dev)).item()) * len(smp)
+                n += len(smp)
+        l_1 = tot / max(n, 1)
+        tol = 5e-3 if job['precision'] == 'bf16' else 1e-4
+        rel = abs(l_sh - l_1) / max(abs(l_1), 1e-12)
+        out = dict(sharded_loss=l_sh, single_device_loss=l_1, rel_err=rel, tol=tol, ok=bool(rel <= tol), sessions=n,
+                   what='loss of the first global batch, evaluation mode: row-sharded forward over all ranks vs the '
+                        'single-device forward on rank 0 (same weights, same sessions)')
+        del ref
+    return out
+
+
+def time_collectives(env, job, dev_batches, steps=3):
+    """per-exchange time on this rank's timeline: HIP events around every collective of `steps` EAGER steps (dist.TIMING),
+    the first one dropped; all ranks run the steps (the exchanges pair up), rank 0 reports"""
+    D = importlib.import_module('sessionrec-pytorch_amd.dist')
+    per_step = []
+    for i in range(steps + 1):
+        D.TIMING = []
+        job['eager'](dev_batches[i % len(dev_batches)])
+        torch.cuda.synchronize()
+        if i > 0:
+            per_step.append(D.timing_summary(D.TIMING))
+    D.TIMING = None
+    n = min(len(x) for x in per_step)
+    out = []
+    for j in range(n):
+        e = per_step[0][j]
+        out.append(dict(kind=e['kind'], bytes=e['bytes'], us=round(float(np.mean([st[j]['us'] for st in per_step])), 2)))
+    return dict(per_exchange=out, sum_us=round(sum(e['us'] for e in out), 1), steps=len(per_step),
+                note='eager steps, HIP events on the issuing stream around each exchange (waiting for the slowest rank included); '
+                     'in the captured step the bucket all-reduces overlap the backward on a side stream')
+
+
+def run_job(env, args, precision, strong, Bg, B, n_batches, warm, steps, repeats, with_timing=True):
+    """one multi- or single-rank configuration end to end: batches, job, correctness bit, capture, timed regions"""
+    dist, dev, rank, world = env.dist, env.dev, env.rank, env.world
+    if strong:       # every rank collates ITS slice of the same global batches (same seed everywhere)
+        batches, samples = make_batches(args.model, args.order, n_batches, Bg, env.V, 20, 123, padded=True, part=(rank, world))
+        first = samples[0]
+    else:
+        batches, samples = make_batches(args.model, args.order, n_batches, B, env.V, 20, 123 + rank, padded=True)
+        first = samples[0]
+    dev_batches = [([x.to(dev) for x in inp], lab.to(dev)) for inp, lab in batches]
+    job = make_job(env, args, precision, batches, dev_batches, strong)
+    shard = job['shard']
+    check = None
+    if shard is not None and world > 1:
+        check = loss_check(env, args, job, dev_batches[0], first, strong)
+    if not args.no_graph:
+        capture_job(env, args, job, dev_batches)
+    coll = None
+    D = importlib.import_module('sessionrec-pytorch_amd.dist') if shard is not None else None
+    if shard is not None:
+        if job['graphed'] and getattr(job['gstep'], 'collectives', None):
+            coll = dict(job['gstep'].collectives, captured_in_graph=True)
+        else:
+            D.STATS['count'] = D.STATS['bytes'] = 0
+            job['step'](dev_batches[0])
+            coll = dict(D.STATS, captured_in_graph=False)
+        coll['per'] = 'training step and rank'
+        coll['buckets'] = list(D.BUCKETS['bytes'])          # replicated-gradient all-reduces, in backward completion order
+        coll['backend'] = dist.get_backend() if (dist is not None and dist.is_initialized()) else 'replayed tape'
+        coll['capture_attempts'] = job['attempts']
+        coll['captured_on_all_ranks'] = job['captured_on_all_ranks']
+        coll['capture_mode'] = getattr(job['gstep'], 'capture_mode', None)
+        coll['bucket_copy_tasks'] = dict(getattr(shard, 'copy_tasks_last', {}))
+    regions, loss = run_timed(job['step'], dev_batches, warm, steps, max(repeats, 1), dist if world > 1 or args.shard else None, dev)
+    final_loss = loss.item()
+    if coll is not None and with_timing and world > 1:
+        coll['timed'] = time_collectives(env, job, dev_batches)
+    dt = sorted(regions)[len(regions) // 2]              # median region
+    ms = [r / steps * 1e3 for r in regions]
+    nodes = job['gstep'].node_counts() if job['graphed'] and hasattr(job['gstep'], 'node_counts') else None
+    return dict(job=job, batches=batches, samples=samples, dev_batches=dev_batches, coll=coll, check=check, dt=dt, ms=ms,
+                nodes=nodes, final_loss=final_loss, Bg=Bg, B=B, strong=strong, steps=steps)
+
+
+def record_tape(args):
+    """rank side of `--replay-rank R --of W`: W rank processes on ONE GPU over gloo (device tensors staged through the host),
+    every rank running the real per-rank kernels on its row shard; rank R records what the collectives of the second step
+    (steady state: the bucket layout is agreed) - and of the first - handed it, and saves the tapes."""
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    env = _env(args, dist, torch.device('cuda', 0), rank, world)
+    D = importlib.import_module('sessionrec-pytorch_amd.dist')
+    strong = args.global_batch is not None
+    Bg = args.global_batch if strong else args.batch * world
+    B = Bg // world
+    n_batches = min(args.steps + args.warmup, 48)
+    if strong:
+        batches, samples = make_batches(args.model, args.order, n_batches, Bg, env.V, 20, 123, padded=True, part=(rank, world))
+    else:
+        batches, samples = make_batches(args.model, args.order, n_batches, B, env.V, 20, 123 + rank, padded=True)
+    dev_b = ([x.to(env.dev) for x in batches[0][0]], batches[0][1].to(env.dev))
+    cap = torch.tensor([batches[0][0][0].cap('uniq_items')])
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+    env.replay_cap = int(cap.item())
+    group = D.RecordingGroup()
+    job = make_job(env, args, args.precision, batches, [dev_b], strong, group=group)
+    tapes, losses = [], []
+    for _ in range(2):
+        group.tape = []
+        loss = job['eager'](dev_b)
+        tapes.append(list(group.tape))
+        losses.append(float(loss.item()))
+    if rank == args.replay_rank:
+        torch.save(dict(tapes=tapes, losses=losses, cap=env.replay_cap, lo=job['shard'].lo, hi=job['shard'].hi), args.record_tape)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def replay_rank(args):
+    """`bench.py --replay-rank R --of W [--global-batch 512]` on ONE GPU: the step rank R of a W-rank job runs - V/W table rows;
+    weak scaling: W x 512 sessions scored, 512 encoded; strong: 512 scored, 512/W encoded - captured and timed with the
+    collectives replaced by their recorded results (dist.ReplayGroup: a device-to-device copy where the job has its RCCL call).
+    Transport-free prediction of the N-GPU point: measured N-GPU step - this = what RCCL / xGMI cost."""
+    import subprocess
+    import tempfile
+    R, W = args.replay_rank, args.of
+    assert 0 <= R < W
+    tape_path = os.path.join(tempfile.mkdtemp(prefix='srec_tape_'), 'tape.pt')
+    env_ = dict(os.environ, SREC_BENCH_BACKEND='gloo')
+    env_.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env_.setdefault('OMP_NUM_THREADS', '4')
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(W), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv + ['--record-tape', tape_path]
+    t0 = time.time()
+    rc = subprocess.call(cmd, env=env_, stdout=sys.stderr)
+    if rc != 0:
+        sys.exit(rc)
+    t_rec = time.time() - t0
+    rec = torch.load(tape_path, weights_only=False)
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    env = _env(args, None, dev, R, W)
+    env.replay_cap = rec['cap']
+    D = importlib.import_module('sessionrec-pytorch_amd.dist')
+    strong = args.global_batch is not None
+    Bg = args.global_batch if strong else args.batch * W
+    B = Bg // W
+    n_batches = min(args.steps + args.warmup, 48)
+    if strong:
+        batches, samples = make_batches(args.model, args.order, n_batches, Bg, env.V, 20, 123, padded=True, part=(R, W))
+    else:
+        batches, samples = make_batches(args.model, args.order, n_batches, B, env.V, 20, 123 + R, padded=True)
+    dev_b = ([x.to(dev) for x in batches[0][0]], batches[0][1].to(dev))
+    group = D.ReplayGroup(W, R, dev, rtol=2e-3 if args.precision == 'bf16' else 1e-4, atol=1e-5).load(rec['tapes'][0])
+    job = make_job(env, args, args.precision, batches, [dev_b], strong, group=group)
+    shard = job['shard']
+    assert (shard.lo, shard.hi) == (rec['lo'], rec['hi'])
+    loss0 = float(job['eager'](dev_b).item())                  # step 1, eager: every collective input is checked against the job's
+    checked = group.checked
+    group.load(rec['tapes'][1])
+    G = importlib.import_module('sessionrec-pytorch_amd.graph')
+    D.STATS['count'] = D.STATS['bytes'] = 0
+    gstep = G.GraphedTrainStep(job['model'], job['opt'], dev_b[0], dev_b[1],
+                               after_backward=lambda: shard.sync_replicated_grads(job['replicated'], job['opt']), warmup=1)
+    regions, loss = run_timed(lambda b: gstep(b[0], b[1]), [dev_b], args.warmup, args.steps, max(args.repeats, 1), None, dev)
+    dt = sorted(regions)[len(regions) // 2]
+    ms = dt / args.steps * 1e3
+    tape = rec['tapes'][1]
+    exch = [dict(kind=k, bytes_in=int(i.numel() * i.element_size()), bytes_out=int(o.numel() * o.element_size())) for k, i, o in tape]
+    out = dict(replay_rank=R, of=W, scaling='strong' if strong else 'weak', global_batch=Bg, sessions_encoded_per_rank=B,
+               table_rows_per_rank=shard.n_live, ms_per_step_kernels=ms, repeats_ms=[r / args.steps * 1e3 for r in regions],
+               predicted_value=Bg / (ms * 1e-3), unit='sessions/s (transport-free: collectives = recorded results copied on the device)',
+               launches=gstep.node_counts(), collectives=dict(count=len(tape), per_exchange=exch,
+                                                              bytes_total=sum(e['bytes_out'] for e in exch),
+                                                              buckets=list(D.BUCKETS['bytes'])),
+               eager_step_loss=loss0, job_step_loss=rec['losses'][0], collective_inputs_checked=checked,
+               bucket_copy_tasks=dict(getattr(shard, 'copy_tasks_last', {})),
+               precision=args.precision, model=args.model, V=env.V, d=env.d, order=args.order, dropout=args.dropout,
+               batch='batch 0 of rank %d (one batch: the recorded exchange results belong to it)' % R,
+               recording_seconds=round(t_rec, 1), steps=args.steps, warmup=args.warmup)
+    emit(out)
+
+
+def _env(args, dist, dev, rank, world):
+    env = Env()
+    env.sp = importlib.import_module('sessionrec-pytorch_amd')
+    env.ops = importlib.import_module('sessionrec-pytorch_amd.ops')
+    env.train = importlib.import_module('sessionrec-pytorch_amd.train')
+    env.optim = importlib.import_module('sessionrec-pytorch_amd.optim')
+    env.dist, env.dev, env.rank, env.world = dist, dev, rank, world
+    env.V, env.d = args.items, args.dim
+    env.ops.set_precision(args.precision)
+    torch.manual_seed(123)
+    env.state = {k: v.clone() for k, v in build_model(env.sp, args.model, env.V, env.d, args.order, args.dropout).state_dict().items()}
+    return env
+
+
 def main():
     # stdout carries exactly one JSON line.  RCCL prints its version banner with plain printf at communicator teardown
     # (NCCL_DEBUG=VERSION in this image), i.e. AFTER the line: from here on file descriptor 1 of this process is stderr, and the
@@ -537,8 +837,10 @@ def main():
     ap.add_argument('--items', type=int, default=V_YOOCHOOSE)
     ap.add_argument('--batch', type=int, default=512, help='sessions per GPU and step (weak scaling)')
     ap.add_argument('--global-batch', type=int, default=None,
-                    help='strong scaling: this many sessions per step over ALL ranks (512 = the reference batch, '
-                         'train.py:94-101); rank r encodes the contiguous slice r of every global batch')
+                    help='strong scaling ONLY: this many sessions per step over ALL ranks (512 = the reference batch, '
+                         'train.py:94-101); rank r encodes the contiguous slice r of every global batch.  Without it an N > 1 run '
+                         'times BOTH: weak scaling (the headline value) and strong scaling at 512 (the `strong` object)')
+    ap.add_argument('--no-strong', action='store_true', help='N > 1: skip the strong-scaling (global batch 512) side run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32', action='store_true', help='skip the fp32 side run (the reference arithmetic) of the same step')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the DataLoader-inclusive run of the same workload')
@@ -560,11 +862,24 @@ def main():
     ap.add_argument('--launch-only', action='store_true',
                     help='initialise the process group over --gpus ranks, print what was seen, exit (launcher self-test; '
                          'gloo on a box without GPUs)')
+    ap.add_argument('--replay-rank', type=int, default=None,
+                    help='with --of W, on ONE GPU: time the step rank R of a W-rank job runs, collectives replaced by their '
+                         'recorded results (transport-free prediction of the W-GPU point; weak scaling, or strong with --global-batch)')
+    ap.add_argument('--of', type=int, default=None, help='world size of the job whose rank --replay-rank is replayed')
+    ap.add_argument('--record-tape', default=None, help=argparse.SUPPRESS)      # (rank side of --replay-rank)
     args = ap.parse_args()
     if args.step_only:
         args.no_cpu_baseline = args.no_fp32 = args.no_end_to_end = args.no_quality = True
         args.repeats = 1
 
+    if args.record_tape is not None:                      # a rank process of the recording job (stdout = the parent's stderr)
+        return record_tape(args)
+    if args.replay_rank is not None:
+        assert args.of and args.of >= 1, '--replay-rank R needs --of W'
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+        return replay_rank(args)
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     sys.stdout.flush()                                    # (a rank process from here on: the launcher parent keeps its stdout)
@@ -603,14 +918,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    sp = importlib.import_module('sessionrec-pytorch_amd')
-    ops = importlib.import_module('sessionrec-pytorch_amd.ops')
-    ops.set_precision(args.precision)
-    train = importlib.import_module('sessionrec-pytorch_amd.train')
-    optim = importlib.import_module('sessionrec-pytorch_amd.optim')
-    V, d = args.items, args.dim
-    strong = args.global_batch is not None
-    if strong:
+    env = _env(args, dist, dev, rank, world)
+    sp, ops, V, d, state = env.sp, env.ops, env.V, env.d, env.state
+    only_strong = args.global_batch is not None
+    if only_strong:
         assert args.global_batch % world == 0, 'global batch must divide over the ranks'
         Bg, B = args.global_batch, args.global_batch // world
     else:
@@ -622,96 +933,42 @@ def main():
         emit(kt)
         return
     n_batches = min(args.steps + args.warmup, 48)      # distinct resident batches; longer runs cycle through them
-    padded = True
-    use_graph = (not args.no_graph) and padded       # N > 1: the RCCL calls are captured in the step graph too
-    if strong:       # every rank collates ITS slice of the same global batches (same seed everywhere)
-        batches, samples = make_batches(args.model, args.order, n_batches, Bg, V, 20, 123, padded=padded,
-                                        part=(rank, world))
-    else:
-        batches, samples = make_batches(args.model, args.order, n_batches, B, V, 20, 123 + rank, padded=padded)
-    torch.manual_seed(123)
-    state = {k: v.clone() for k, v in build_model(sp, args.model, V, d, args.order, args.dropout).state_dict().items()}
-    dev_batches = [([x.to(dev) for x in inp], lab.to(dev)) for inp, lab in batches]
 
-    def setup(precision):
-        """model + optimizer + (graphed) step for one arithmetic mode, from the same initial weights"""
-        ops.set_precision(precision)
-        torch.manual_seed(123)
-        model = build_model(sp, args.model, V, d, args.order, args.dropout)
-        model.load_state_dict(state)
-        model = model.to(dev)
-        shard = None
-        if world > 1 or args.shard:                    # item table row-sharded over the node's GPUs (RCCL / xGMI)
-            D = importlib.import_module('sessionrec-pytorch_amd.dist')
-            cap = batches[0][0][0].cap('uniq_items')   # only the distinct items of a batch are exchanged; equal padded
-            t = torch.tensor([cap], device=dev)        # request length on every rank: no per-step size exchange
-            _all_reduce(dist, t, dist.ReduceOp.MAX)
-            shard = D.VocabParallel(model, idx_cap=int(t.item()))
-        opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-3, weight_decay=1e-4, model=model, fuse_projection=True)
-        replicated = [p for p in model.parameters() if p is not model._table() and p.requires_grad]
-        model.train()
-
-        def eager(b):
-            inp, lab = b
-            opt.zero_grad()
-            loss = model.fused_loss(*inp, lab)
-            loss.backward()
-            if shard is not None:
-                shard.sync_replicated_grads(replicated, opt)
-            opt.step()
-            return loss
-        step, graphed, gstep = eager, False, None
-        if use_graph:
-            G = importlib.import_module('sessionrec-pytorch_amd.graph')
-            try:
-                gstep = G.GraphedTrainStep(model, opt, dev_batches[0][0], dev_batches[0][1],
-                                           after_backward=(lambda: shard.sync_replicated_grads(replicated, opt)) if shard is not None else None)
-                step, graphed = (lambda b: gstep(b[0], b[1])), True
-            except Exception as e:                         # capture of the collectives refused: eager launches
-                if shard is None:
-                    raise
-                print('graph capture with the collectives failed (%s: %s); running eager' % (type(e).__name__, str(e)[:300]),
-                      file=sys.stderr, flush=True)
-            if shard is not None and world > 1:
-                # the ranks decide TOGETHER (as TrainRunner does): a rank whose capture failed has skipped the exchanges of
-                # the capture lap - from here on either all replay or all launch eagerly
-                ok = _all_reduce(dist, torch.tensor([1.0 if graphed else 0.0], device=dev), dist.ReduceOp.MIN)
-                if ok.item() < 1.0:
-                    step, graphed, gstep = eager, False, None
-        return model, shard, step, graphed, gstep
-
-    model, shard, step, graphed, gstep = setup(args.precision)
+    main_run = run_job(env, args, args.precision, only_strong, Bg, B, n_batches, args.warmup, args.steps, args.repeats)
+    job = main_run['job']
+    model, shard, graphed, gstep = job['model'], job['shard'], job['graphed'], job['gstep']
+    batches, samples, dev_batches = main_run['batches'], main_run['samples'], main_run['dev_batches']
+    coll, dt, ms, nodes, final_loss = main_run['coll'], main_run['dt'], main_run['ms'], main_run['nodes'], main_run['final_loss']
+    strong = only_strong
     # every rank contributes 1 through the job's own backend (RCCL): the sum is the number of ranks the collectives reach
     ranks_seen = 1
     if dist is not None:
         ranks_seen = int(_all_reduce(dist, torch.ones(1, device=dev)).item())
-    coll = None
-    if shard is not None:
-        D = importlib.import_module('sessionrec-pytorch_amd.dist')
-        if graphed and getattr(gstep, 'collectives', None):
-            coll = dict(gstep.collectives, captured_in_graph=True)
-        else:
-            D.STATS['count'] = D.STATS['bytes'] = 0
-            step(dev_batches[0])
-            coll = dict(D.STATS, captured_in_graph=False)
-        coll['per'] = 'training step and rank'
-        coll['buckets'] = list(D.BUCKETS['bytes'])          # replicated-gradient all-reduces, in backward completion order
-        coll['backend'] = dist.get_backend()
-    regions, loss = run_timed(step, dev_batches, args.warmup, args.steps, max(args.repeats, 1), dist, dev)
-    final_loss = loss.item()
-    dt = sorted(regions)[len(regions) // 2]              # median region
-    ms = [r / args.steps * 1e3 for r in regions]
-    nodes = gstep.node_counts() if graphed and hasattr(gstep, 'node_counts') else None
+
+    strong_run = None
+    if world > 1 and not only_strong and not args.no_strong and not args.step_only and args.batch % world == 0:
+        # the reference's own semantics (main_msgifsr.py:46,148-157: ONE batch of 512 consecutive samples per optimiser step):
+        # the same 512 sessions as the 1-GPU run, every rank encoding its slice - timed in the same process, same launch mode
+        sr = run_job(env, args, args.precision, True, args.batch, args.batch // world, n_batches, args.warmup, args.steps,
+                     max(1, min(args.repeats, 2)))
+        strong_run = dict(scaling='strong', global_batch=args.batch, sessions_encoded_per_rank=args.batch // world,
+                          value=args.batch * args.steps / sr['dt'], unit='sessions/s', ms_per_step=sr['dt'] / args.steps * 1e3,
+                          repeats_ms_per_step=sr['ms'], launch='hipGraph replay' if sr['job']['graphed'] else 'eager',
+                          launches=sr['nodes'], collectives=sr['coll'], correctness=sr['check'], final_loss=sr['final_loss'],
+                          note='the reference batch (train.py:94-101): the SAME 512 consecutive sessions per step as on one GPU')
+        del sr
+        ops.set_precision(args.precision)
 
     fp32 = None
-    if not args.no_fp32 and args.precision != 'fp32' and world == 1:      # (side run on one GPU only: N > 1 times the job once)
+    if not args.no_fp32 and args.precision != 'fp32' and world == 1 and not args.shard:      # (side run on one GPU only)
         # the reference's own arithmetic (fp32 operands everywhere) on the same batches, same launch mode, same run
-        del step, gstep
-        m32, s32, step32, g32, _ = setup('fp32')
-        r32, _ = run_timed(step32, dev_batches, args.warmup, args.steps, 1, dist, dev)
+        j32 = make_job(env, args, 'fp32', batches, dev_batches, strong)
+        if not args.no_graph:
+            capture_job(env, args, j32, dev_batches)
+        r32, _ = run_timed(j32['step'], dev_batches, args.warmup, args.steps, 1, None, dev)
         fp32 = dict(ms_per_step=r32[0] / args.steps * 1e3, value=Bg * args.steps / r32[0], unit='sessions/s',
-                    launch='hipGraph replay' if g32 else 'eager')
-        del m32, s32, step32
+                    launch='hipGraph replay' if j32['graphed'] else 'eager')
+        del j32
         ops.set_precision(args.precision)
 
     e2e = None
@@ -730,7 +987,7 @@ def main():
 
     if rank == 0 and args.step_only:
         emit(dict(step_only=True, ms_per_step=dt / args.steps * 1e3, value=Bg * args.steps / dt, launches=nodes,
-                  final_loss=final_loss))
+                  final_loss=final_loss, collectives=coll))
     elif rank == 0:
         Vk = V if shard is None else shard.n_live      # rows of the catalog this rank scores
         kt = time_dominant_kernel(model, Bg, Vk, d, dev)
@@ -754,7 +1011,7 @@ def main():
             if (w['V'], w['d'], w['B']) == (Vk, d, Bg):
                 traffic = pm['kernels'][pkey]['traffic_bytes']
                 tsrc = ('profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 2x FETCH '
-                        'correction)' % pmc)
+                        'correction; read from the committed file, not measured in this run)' % pmc)
         except Exception:
             pass
         # ---- the whole step against both roofs: 40 V d table bytes + ~6 N d 4 node bytes; 6 B V d
@@ -779,11 +1036,11 @@ def main():
                     algorithmic_bytes=alg_bytes, algorithmic_flop=flop, kernel_ms=kms, step=step_roof)
         cpu = None
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline belongs to the N = 1 line (rank 0)
-            full = samples if not strong else samples      # the CPU oracle runs whole 512-session batches
-            cpu = cpu_baseline(args.model, full, V, d, args.order, state, dropout=args.dropout)
+            cpu = cpu_baseline(args.model, samples, V, d, args.order, state, dropout=args.dropout)   # whole 512-session batches
         scaling = 'strong' if strong else 'weak'
         out = dict(metric='sessions/sec training, Yoochoose-1/64 batch 512', value=Bg * args.steps / dt,
-                   unit='sessions/s', n_gpus=world, ranks_seen=ranks_seen, collectives=coll,
+                   unit='sessions/s', n_gpus=world, ranks_seen=ranks_seen, collectives=coll, correctness=main_run['check'],
+                   strong=strong_run,
                    steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, repeats_ms_per_step=ms, spread_ms=max(ms) - min(ms),
                    higher_is_better=True, scaling=scaling, vs_baseline=None,

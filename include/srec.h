@@ -425,7 +425,10 @@ int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* d
 int srec_gru_bias_final(int np, const void* part, const int* rows, int ncol, const void* out, void* stream);
 /* np <= 32 outputs out_i [n_i] = sum_r part_i [R_i, n_i] in one launch (row-split weight gradients); HOST arrays.  tall
  * (nullable HOST array): tall_i != 0 = few columns summed over hundreds of rows (the GRU bias partials of srec_gru_fused_bwd
- * / srec_gru_step_bwd, what srec_gru_bias_final does as a launch of its own) */
+ * / srec_gru_step_bwd, what srec_gru_bias_final does as a launch of its own).  Column tasks: n_i % 4 == 0, both pointers
+ * 16-byte aligned; tall tasks are scalar (any n_i, any alignment).  With R_i = 1 a task is a copy: the row-sharded path fills
+ * its gradient-bucket arenas with it (dist.VocabParallel._bucket_fill: gradients that did not land in their slot, zeros for
+ * parameters without a gradient on this rank, the flag tail) - no torch.cat in the rank step. */
 int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
                          void* stream);
 /* ... with strided destinations: w_i > 0 = out_i is a block of w_i columns in rows of stride ld_i floats (a column slice of a

@@ -349,7 +349,7 @@ extern "C" int srec_gru_bias_final(int np, const void* part, const int* rows, in
     return 0;
 }
 
-// np <= 32 outputs out_i [n_i] = sum_r part_i [R_i, n_i] (n_i % 4 == 0) in one launch; HOST arrays.  tall (nullable): tall_i != 0
+// np <= 32 outputs out_i [n_i] = sum_r part_i [R_i, n_i] (n_i % 4 == 0 and 16-byte aligned unless tall_i) in one launch; HOST arrays.  tall (nullable): tall_i != 0
 // marks an output of few columns summed over many rows (row lanes instead of column threads); w / ld (nullable, both or neither):
 // w_i > 0 = out_i is a block of w_i columns in rows of stride ld_i (both % 4 == 0; not with tall_i)
 extern "C" int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
@@ -363,7 +363,9 @@ extern "C" int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, c
         a.part[p] = ((const float* const*)part)[p]; a.out[p] = ((float* const*)out)[p]; a.R[p] = R[p]; a.n[p] = n[p];
         const bool tl = tall != nullptr && tall[p] != 0;
         if (tl) a.tall |= 1u << p;
-        if (a.part[p] == nullptr || a.out[p] == nullptr || R[p] <= 0 || n[p] <= 0 || (n[p] & 3)) return SREC_BAD_ARG;
+        // (column-thread tasks move 16 bytes per access; the row-lane ("tall") tasks are scalar: any n, any alignment)
+        if (a.part[p] == nullptr || a.out[p] == nullptr || R[p] <= 0 || n[p] <= 0 || (!tl && (n[p] & 3))) return SREC_BAD_ARG;
+        if (!tl && ((((size_t)a.part[p]) | ((size_t)a.out[p])) & 15)) return SREC_BAD_ARG;
         a.w[p] = 0; a.ld[p] = 0;
         if (w != nullptr && w[p] > 0 && ld[p] != w[p]) {
             if (tl || (w[p] & 3) || (ld[p] & 3) || ld[p] < w[p] || n[p] % w[p]) return SREC_BAD_ARG;

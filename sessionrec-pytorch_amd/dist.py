@@ -66,6 +66,28 @@ def _count(nbytes):
     STATS['bytes'] += int(nbytes)
 
 
+TIMING = None                         # a list: every collective issued through this module is bracketed by HIP events on the
+#                                       stream it is issued from and appended as (kind, payload bytes, start, end) - eager steps
+#                                       only (bench.py's `collectives.timed`: what an exchange costs on the rank's timeline,
+#                                       waiting for the slowest rank included)
+
+
+def _timed(kind, nbytes, fn, t):
+    if TIMING is None or not t.is_cuda or torch.cuda.is_current_stream_capturing():
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    TIMING.append((kind, int(nbytes), e0, e1))
+    return out
+
+
+def timing_summary(entries):
+    """[(kind, bytes, start, end)] of whole steps -> [dict(kind, bytes, us)] (device synchronised by the caller)"""
+    return [dict(kind=k, bytes=b, us=round(e0.elapsed_time(e1) * 1e3, 2)) for k, b, e0, e1 in entries]
+
+
 def _host_staged(t, group):
     """gloo moves host memory: device tensors are staged through the host (the W-ranks-on-one-GPU tests; production = RCCL)"""
     return t.is_cuda and dist.get_backend(group) != 'nccl'
@@ -76,8 +98,9 @@ def all_gather_cat(t, group=None):
     if not _active(group):
         return t
     t = t.contiguous()
-    _count(_world(group) * t.numel() * t.element_size())
-    return group.collective('all_gather', t) if _loop(group) else all_gather_cat_pg(t, group)
+    nb = _world(group) * t.numel() * t.element_size()
+    _count(nb)
+    return _timed('all_gather', nb, lambda: group.collective('all_gather', t) if _loop(group) else all_gather_cat_pg(t, group), t)
 
 
 def reduce_scatter_sum(t, group=None):
@@ -86,7 +109,8 @@ def reduce_scatter_sum(t, group=None):
         return t
     t = t.contiguous()
     _count(t.numel() * t.element_size())
-    return group.collective('reduce_scatter', t) if _loop(group) else reduce_scatter_pg(t, group)
+    return _timed('reduce_scatter', t.numel() * t.element_size(),
+                  lambda: group.collective('reduce_scatter', t) if _loop(group) else reduce_scatter_pg(t, group), t)
 
 
 def all_reduce_(t, op=None, group=None, always=False):
@@ -95,16 +119,18 @@ def all_reduce_(t, op=None, group=None, always=False):
         return t
     op = dist.ReduceOp.SUM if op is None else op
     _count(t.numel() * t.element_size())
-    if _loop(group):
-        t.copy_(group.collective('all_reduce:' + {dist.ReduceOp.MAX: 'MAX', dist.ReduceOp.MIN: 'MIN'}.get(op, 'SUM'), t))
+
+    def run():
+        if _loop(group):
+            t.copy_(group.collective('all_reduce:' + {dist.ReduceOp.MAX: 'MAX', dist.ReduceOp.MIN: 'MIN'}.get(op, 'SUM'), t))
+        elif _host_staged(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=group)
         return t
-    if _host_staged(t, group):
-        h = t.cpu()
-        dist.all_reduce(h, op=op, group=group)
-        t.copy_(h)
-        return t
-    dist.all_reduce(t, op=op, group=group)
-    return t
+    return _timed('all_reduce', t.numel() * t.element_size(), run, t)
 
 
 def all_reduce_sum(t, group=None):
@@ -429,7 +455,14 @@ class ShardedLookup(torch.autograd.Function):
         lab = vp.labels_hint if vp is not None else None
         if lab is not None:
             parts.append(lab if lab.dtype == items_pad.dtype else lab.to(items_pad.dtype))
-        packed = all_gather_cat((torch.cat(parts) if len(parts) > 1 else parts[0]).unsqueeze(0), group)    # [w, ucap (+ B)]
+        if len(parts) > 1 and vp is not None and items_pad.is_cuda and items_pad.dtype == torch.int32:
+            # (ids | labels) into a request buffer by the library's multi-copy launch (no aten concatenation in the rank step)
+            req = torch.empty(ucap + parts[1].numel(), device=items_pad.device, dtype=torch.int32)
+            vp._copy_tasks([(items_pad.view(torch.float32), req[:ucap].view(torch.float32)),
+                            (parts[1].contiguous().view(torch.float32), req[ucap:].view(torch.float32))])
+        else:
+            req = torch.cat(parts) if len(parts) > 1 else parts[0]
+        packed = all_gather_cat(req.unsqueeze(0), group)                                      # [w, ucap (+ B)]
         ctx.items_all = packed[:, :ucap].reshape(-1)
         if lab is not None:
             vp.lab_all = packed[:, ucap:].reshape(-1)
@@ -570,8 +603,9 @@ class VocabParallel:
         self._ws = {}
         self.model = model
         self._names = {id(p): n for n, p in model.named_parameters()} if hasattr(model, 'named_parameters') else {}
-        self._bucket_flat, self._bucket_early, self._bucket_zero = {}, {}, {}
-        self._side, self._side_used = None, False
+        self._bucket_early, self._bucket_zero = {}, {}
+        self._side, self._side_used, self._no_sync = None, False, False
+        self._arena, self._slot = [], {}
         self.early_launches = 0                # buckets whose all-reduce was issued from inside a backward pass (bucket_ready)
         # side stream for the early buckets: on by default where the collective is RCCL between real ranks (it then runs beside
         # the backward); a 1-rank / loopback rehearsal keeps one stream unless asked (graph branches cost there: DESIGN 7)
@@ -596,6 +630,8 @@ class VocabParallel:
         return (int(t.item()) + 255) // 256 * 256
 
     def lookup(self, table, idx, uniq, drop=None):
+        if torch.is_grad_enabled() and table.requires_grad:
+            self.begin_step()                  # (a training forward: every model's first use of the sharded table is its lookup)
         items, uptr, upos = uniq[:3]
         n, U = idx.numel(), items.numel()
         ucap = self.capacity(U)
@@ -713,51 +749,139 @@ class VocabParallel:
         i, n = order
         return min(self.N_BUCKETS - 1, (n - 1 - i) * self.N_BUCKETS // max(n, 1))
 
-    def _bucket_pieces(self, ps):
-        pieces = []
-        for p in ps:
-            if p.grad is not None:
-                pieces.append(p.grad.reshape(-1))
-            else:                                      # this rank's batch gave it no gradient: zeros (static buffer)
-                z = self._bucket_zero.get(id(p))
-                if z is None:
-                    z = self._bucket_zero[id(p)] = torch.zeros(p.numel(), device=p.device, dtype=p.dtype)
-                pieces.append(z)
-        return pieces
+    def _arena_setup(self, parts, n_flags):
+        """one flat fp32 ARENA per bucket, laid out in parameter order; the last one ends in the flag tail.  Every bucketed
+        parameter gets its slot (`p._srec_gslot`): the backward nodes that allocate a gradient write it straight into the
+        slot (ops.grad_buf), the all-reduce runs in place on the arena, the optimizer reads views of it - no concatenation
+        pass, no copy back (round 5: four torch.cat kernels, 23 us of the rank step)."""
+        for p in getattr(self, '_bucket_live', ()):
+            p.__dict__.pop('_srec_gslot', None)
+        self._arena, self._slot = [], {}
+        last = len(parts) - 1
+        for k, bp in enumerate(parts):
+            n = sum((int(p.numel()) + 3) // 4 * 4 for p in bp) + (n_flags if k == last else 0)
+            dev = bp[0].device if bp else self.dE.device
+            buf = torch.zeros(n, device=dev, dtype=torch.float32) if n else None
+            off = 0
+            for p in bp:
+                assert p.dtype == torch.float32, 'replicated parameters are fp32'
+                self._slot[id(p)] = (k, off, int(p.numel()))
+                p._srec_gslot = [buf, off, -1]
+                off += (int(p.numel()) + 3) // 4 * 4       # slots start on 16-byte boundaries (the kernels' float4 accesses)
+            self._arena.append(buf)
 
-    def _bucket_reduce(self, k, pieces, side):
-        """concatenate into bucket k's static buffer and all-reduce it - on the side stream when `side` (the copy and the
-        collective then run beside whatever the compute stream does next; sync_replicated_grads joins before the optimizer)"""
-        n = sum(int(t.numel()) for t in pieces)
-        flat = self._bucket_flat.get(k)
-        if flat is None or flat.numel() != n:
-            flat = self._bucket_flat[k] = torch.empty(n, device=pieces[0].device, dtype=torch.float32)
+    def release_slots(self):
+        """detach the parameters from the arenas (the model goes on without this VocabParallel)"""
+        for p in getattr(self, '_bucket_live', ()):
+            p.__dict__.pop('_srec_gslot', None)
+
+    def _zero_of(self, p):
+        z = self._bucket_zero.get(id(p))
+        if z is None:
+            z = self._bucket_zero[id(p)] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32)
+        return z
+
+    @staticmethod
+    def _copy_tasks(tasks):
+        """[(src flat, dst flat)]: ONE launch for all of them on the GPU (the multi-slab sum with one slab per task)"""
+        if not tasks:
+            return
+        if tasks[0][1].is_cuda:
+            from . import ops
+            # (16-byte column threads where sizes and addresses allow, the scalar row-lane form otherwise)
+            odd = lambda a, b: bool(a.numel() & 3 or (a.data_ptr() | b.data_ptr()) & 15)
+            ops._launch_slab_sums([(src.reshape(1, -1), dst, odd(src, dst)) for src, dst in tasks])
+        else:
+            for src, dst in tasks:
+                dst.copy_(src)
+
+    def _bucket_fill(self, k, bp, tail=None):
+        """make arena k hold this rank's contribution: gradients already written into their slots stay, the others are copied
+        in (a gradient autograd summed from two nodes, a slot taken twice, an aten-made gradient), parameters without a
+        gradient on this rank contribute zeros; `tail` = the flag tail of the last bucket.  One copy launch for all of it."""
+        buf = self._arena[k]
+        tasks = []
+        esz = 4
+        for p in bp:
+            _, off, n = self._slot[id(p)]
+            dst = buf[off:off + n]
+            g = p.grad
+            if g is None:
+                tasks.append((self._zero_of(p), dst))
+            elif g.data_ptr() != buf.data_ptr() + off * esz or not g.is_contiguous():
+                tasks.append((g.contiguous().reshape(-1), dst))
+        if tail is not None:
+            tasks.append((tail, buf[buf.numel() - tail.numel():]))
+        self._copy_tasks(tasks)
+        self.copy_tasks_last = getattr(self, 'copy_tasks_last', {})
+        self.copy_tasks_last[k] = len(tasks)
+        return buf
+
+    def _bucket_reduce(self, k, bp, side, tail=None):
+        """fill arena k (see _bucket_fill) and all-reduce it IN PLACE - on the side stream when `side` (the collective then runs
+        beside whatever the compute stream does next; sync_replicated_grads joins before the optimizer)"""
         if side:
             cur = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream(device=flat.device)
+                self._side = torch.cuda.Stream(device=self._arena[k].device)
             self._side.wait_stream(cur)                # the gradients are complete; the buffer's last reader (Adam) is behind us
             with torch.cuda.stream(self._side):
-                torch.cat(pieces, out=flat)
+                flat = self._bucket_fill(k, bp, tail)
                 all_reduce_(flat, None, self.group)
             self._side_used = True
         else:
-            torch.cat(pieces, out=flat)
+            flat = self._bucket_fill(k, bp, tail)
             all_reduce_(flat, None, self.group)
         return flat
 
+    def begin_step(self):
+        """called at the head of every training forward (lookup): a new hand-out round of the arena slots, and the state of a
+        step that never reached sync_replicated_grads is dealt with - an aborted backward / a refused capture (no gradients
+        held any more: forget its early launches) or, loudly, a second backward on top of all-reduced gradients."""
+        from . import ops
+        ops.grad_epoch()
+        if self._bucket_early or self._side_used:
+            held = any(p.grad is not None for p in getattr(self, '_bucket_live', ()))
+            if held and not self._no_sync:
+                raise RuntimeError('a backward pass launched the all-reduce of its gradient buckets and no '
+                                   'sync_replicated_grads() / optimizer step followed: the gradients held are partly summed '
+                                   'over the ranks.  Accumulating micro-batches: run all but the last under `with '
+                                   'shard.no_sync():`, or zero_grad() first.')
+            if self._side_used and self._side is not None and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().wait_stream(self._side)
+            self._bucket_early, self._side_used = {}, False
+
+    def abort_step(self):
+        """a capture of the step was refused / a step was abandoned: nothing of it ran or will be used - forget its early
+        bucket launches (GraphedTrainStep's failure path; the eager fallback starts from a clean slate)"""
+        self._bucket_early, self._side_used = {}, False
+
+    def no_sync(self):
+        """context for gradient accumulation (like DDP's): backward passes inside it launch no bucket all-reduce; the LAST
+        micro-batch runs outside it and sync_replicated_grads() then exchanges the accumulated sums once."""
+        vp = self
+
+        class _NoSync:
+            def __enter__(self_):
+                self_.prev, vp._no_sync = vp._no_sync, True
+
+            def __exit__(self_, *exc):
+                vp._no_sync = self_.prev
+                return False
+        return _NoSync()
+
     def bucket_ready(self, k):
         """called from inside the backward pass (ops.grad_mark placed by the model) when every gradient of bucket k has been
-        accumulated: its all-reduce is issued NOW, under the rest of the backward, instead of after it.  Only for a bucket all
-        of whose parameters carry a gradient on this rank (the steady state), never for the last bucket (it carries the
-        presence flags) - everything else is picked up by sync_replicated_grads."""
+        accumulated: its all-reduce is issued NOW, under the rest of the backward, instead of after it.  Never for the last
+        bucket (it carries the presence flags).  The decision depends on rank-AGREED state only (the bucket partition fixed by
+        agree(), the marker the model places in every training forward): every rank issues the same collectives in the same
+        order; a parameter without a gradient on this rank contributes zeros."""
         parts = getattr(self, '_bucket_parts', None)
-        if not _active(self.group) or parts is None or not (0 <= k < len(parts) - 1) or k in self._bucket_early or not parts[k]:
+        if not _active(self.group) or parts is None or self._no_sync or not (0 <= k < len(parts) - 1) \
+                or k in self._bucket_early or not parts[k]:
             return
         self.ops_flush()                               # deferred slab sums of the layers behind us: their gradients are written
-        if any(p.grad is None for p in parts[k]):
-            return
-        self._bucket_early[k] = self._bucket_reduce(k, self._bucket_pieces(parts[k]), self.side_stream)
+        self._bucket_early[k] = self._bucket_reduce(k, parts[k], self.side_stream)
         self.early_launches += 1
 
     def ops_flush(self):
@@ -783,6 +907,8 @@ class VocabParallel:
         handed over as the gradient source (views), so nothing is copied back per parameter."""
         if not _active(self.group):
             return
+        if self._no_sync:
+            raise RuntimeError('sync_replicated_grads() inside no_sync(): run the last micro-batch outside the context')
         params = list(params)
         key = tuple(id(p) for p in params)
         capturing = bool(params) and params[0].is_cuda and torch.cuda.is_current_stream_capturing()
@@ -795,80 +921,96 @@ class VocabParallel:
             if self.world > 1:
                 all_reduce_(present, dist.ReduceOp.MAX, self.group)
             old = getattr(self, '_bucket_ids', set()) if getattr(self, '_bucket_key', None) == key else set()
-            self._bucket_live = [p for p, f in zip(params, present.tolist()) if f > 0 or id(p) in old]
-            self._bucket_ids = {id(p) for p in self._bucket_live}
-            self._bucket_key = key
-            self._bucket_zero = {}
-            self._bucket_flags = None
+            live = [p for p, f in zip(params, present.tolist()) if f > 0 or id(p) in old]
             n = len(params)
             idx = {id(p): i for i, p in enumerate(params)}
             parts = [[] for _ in range(self.N_BUCKETS)]
-            for p in self._bucket_live:
+            for p in live:
                 parts[self._bucket_index(p, (idx[id(p)], n))].append(p)
+            self._arena_setup(parts, len(live) + 1)        # (detaches the old layout's parameters from their slots first)
+            self._bucket_live = live
+            self._bucket_ids = {id(p) for p in live}
+            self._bucket_key = key
+            self._bucket_zero = {}
+            self._bucket_flags = None
             self._bucket_parts = parts
             self._bucket_early = {}                        # (early results were laid out for the old partition)
+            self._bucket_seen = None
+            return old
         if getattr(self, '_bucket_key', None) != key:
             agree()
-        for attempt in (0, 1):
-            ps = self._bucket_live
-            parts = self._bucket_parts
-            n_late = sum(1 for p in params if p.grad is not None and id(p) not in self._bucket_ids)
-            if n_late and capturing:
-                raise RuntimeError('%d replicated parameters carry a gradient that the captured bucket layout has no room for' % n_late)
-            pat = tuple(p.grad is not None for p in ps) + (n_late,)
-            fl = self._bucket_flags
-            if fl is None or fl[0] != pat:                 # the tail changes only when this rank's presence pattern does
-                if capturing and fl is not None:
-                    raise RuntimeError('gradient presence pattern changed between the warm-up and the capture')
-                fl = self._bucket_flags = (pat, torch.tensor([1.0 if f else 0.0 for f in pat[:-1]] + [float(n_late)],
-                                                            device=dev, dtype=torch.float32))
-            flats = []
-            last = len(parts) - 1
-            for k, bp in enumerate(parts):
-                if k in self._bucket_early:
-                    flats.append(self._bucket_early[k])
-                    continue
-                pieces = self._bucket_pieces(bp) + ([fl[1]] if k == last else [])
-                # (under capture also the late buckets leave on the side stream: the table's Adam pass runs beside them)
-                flats.append(self._bucket_reduce(k, pieces, self.side_stream and capturing) if pieces else None)
-            self._bucket_early = {}
-            if getattr(self, '_side_used', False):
-                # join: the early buckets become visible to the compute stream.  FusedAdam takes the join over and places it
-                # behind its row pass over the table, which needs none of these gradients (optim.FusedAdam.grad_join) - unless
-                # this (eager) step is about to read the flag tail back, which synchronises anyway
-                self._side_used = False
-                if capturing and optimizer is not None and hasattr(optimizer, '_join_grads'):
-                    side = self._side
-                    optimizer.grad_join = lambda: torch.cuda.current_stream().wait_stream(side)
-                else:
-                    torch.cuda.current_stream().wait_stream(self._side)
-            BUCKETS['bytes'] = [0 if f is None else int(f.numel()) * 4 for f in flats]
-            nfl = len(ps) + 1
-            seen = None
-            if not capturing:
-                seen = flats[last][-nfl:].tolist()
-                if seen[-1] > 0 and attempt == 0:          # somebody holds a gradient the layout has no slot for: everybody
-                    agree()                                # sees the same count - re-agree and repeat the exchange
-                    continue
-                self._bucket_seen = seen
-            break
-        seen = getattr(self, '_bucket_seen', None)
-        pos = {id(p): i for i, p in enumerate(ps)}
-        views = {}
+        ps, parts, arenas, slots = self._bucket_live, self._bucket_parts, self._arena, self._slot
+        n_late = sum(1 for p in params if p.grad is not None and id(p) not in self._bucket_ids)
+        if n_late and capturing:
+            raise RuntimeError('%d replicated parameters carry a gradient that the captured bucket layout has no room for' % n_late)
+        pat = tuple(p.grad is not None for p in ps) + (n_late,)
+        fl = self._bucket_flags
+        if fl is None or fl[0] != pat:                     # the tail changes only when this rank's presence pattern does
+            if capturing and fl is not None:
+                raise RuntimeError('gradient presence pattern changed between the warm-up and the capture')
+            fl = self._bucket_flags = (pat, torch.tensor([1.0 if f else 0.0 for f in pat[:-1]] + [float(n_late)],
+                                                        device=dev, dtype=torch.float32))
+        flats = []
+        last = len(parts) - 1
         for k, bp in enumerate(parts):
-            off = 0
-            for p in bp:
-                n = p.numel()
-                if seen is None or seen[pos[id(p)]] > 0:   # nobody had a gradient this step: skipped, as on one device
-                    views[id(p)] = flats[k][off:off + n].view_as(p)
-                off += n
+            if k in self._bucket_early:
+                flats.append(self._bucket_early[k])
+                continue
+            # the flag tail is read by eager steps only: a captured step replays the skip pattern of its capture (the tail's
+            # slots still travel - every rank all-reduces the same length - but nobody refreshes or reads them)
+            tail = fl[1] if (k == last and not capturing) else None
+            # (under capture also the late buckets leave on the side stream: the table's Adam pass runs beside them)
+            flats.append(self._bucket_reduce(k, bp, self.side_stream and capturing, tail) if arenas[k] is not None else None)
+        self._bucket_early = {}
+        if self._side_used:
+            # join: the early buckets become visible to the compute stream.  FusedAdam takes the join over and places it
+            # behind its row pass over the table, which needs none of these gradients (optim.FusedAdam.grad_join) - unless
+            # this (eager) step is about to read the flag tail back, which synchronises anyway
+            self._side_used = False
+            if capturing and optimizer is not None and hasattr(optimizer, '_join_grads'):
+                side = self._side
+                optimizer.grad_join = lambda: torch.cuda.current_stream().wait_stream(side)
+            else:
+                torch.cuda.current_stream().wait_stream(self._side)
+        BUCKETS['bytes'] = [0 if f is None else int(f.numel()) * 4 for f in flats]
+        nfl = len(ps) + 1
+        pos = {id(p): i for i, p in enumerate(ps)}
+        extra = {}
+        if not capturing:
+            seen = flats[last][-nfl:].tolist()
+            self._bucket_seen = seen
+            if seen[-1] > 0:
+                # somebody holds a gradient the layout has no slot for - everybody sees the same count.  The buckets above are
+                # exchanged and stay as they are (the all-reduce ran in place: the local values are gone); the ranks agree on a
+                # layout with room for the newcomers (from the next step on) and exchange THEIR gradients in one more
+                # all-reduce now - nothing dropped, no rank raises alone
+                old_ids = agree()
+                late = [p for p in self._bucket_live if id(p) not in old_ids]
+                pieces = [(p.grad.reshape(-1).to(torch.float32) if p.grad is not None else self._zero_of(p)) for p in late]
+                pieces.append(torch.tensor([1.0 if p.grad is not None else 0.0 for p in late], device=dev))
+                buf = torch.cat(pieces)
+                all_reduce_(buf, None, self.group)
+                seen_late = buf[-len(late):].tolist()
+                off = 0
+                for p, f in zip(late, seen_late):
+                    if f > 0:
+                        extra[id(p)] = buf[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+        else:
+            seen = getattr(self, '_bucket_seen', None)
+        views = dict(extra)
+        for p in ps:
+            k, off, n = slots[id(p)]
+            if seen is None or seen[pos[id(p)]] > 0:       # nobody had a gradient this step: skipped, as on one device
+                views[id(p)] = arenas[k][off:off + n].view_as(p)
         if optimizer is not None and hasattr(optimizer, 'grad_override'):
             optimizer.grad_override = views
         else:
-            for p in ps:
-                if id(p) not in views:
+            for p in params:
+                v = views.get(id(p))
+                if v is None:
                     continue
                 if p.grad is None:
-                    p.grad = views[id(p)].clone()
-                else:
-                    p.grad.copy_(views[id(p)])
+                    p.grad = v.clone()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    p.grad.copy_(v)

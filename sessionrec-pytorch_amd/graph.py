@@ -104,11 +104,12 @@ class GraphedTrainStep:
             self.loss_ring = torch.zeros(LOSS_RING, device=labels.device, dtype=torch.float32)
         work = None
         from . import dist as _dist
+        self.capture_mode = self._capture_mode()
         self._quiesce_collectives()
         c0 = dict(_dist.STATS)
         err = None
         try:
-            with torch.cuda.graph(self.graph, stream=self._stream):
+            with torch.cuda.graph(self.graph, stream=self._stream, capture_error_mode=self.capture_mode):
                 try:
                     self._capture_intake()
                     self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
@@ -145,6 +146,11 @@ class GraphedTrainStep:
             optimizer._frozen = None
             self._restore(model, optimizer, snap_p, snap_b, snap_o)
             optimizer.zero_grad(set_to_none=True)
+            sh = getattr(model, 'shard', None)
+            if sh is not None and hasattr(sh, 'abort_step'):
+                sh.abort_step()                          # early gradient buckets recorded by the dead capture never ran
+            if hasattr(optimizer, 'grad_join'):
+                optimizer.grad_join = None
             raise
         # collectives captured inside the step (row-sharded table): count and payload bytes of ONE step
         self.collectives = {k: _dist.STATS[k] - c0[k] for k in c0}
@@ -161,23 +167,40 @@ class GraphedTrainStep:
                 pass
 
     @staticmethod
-    def _quiesce_collectives():
-        """RCCL through torch.distributed: every eager collective of the warm-up left a work item with the process group's
-        watchdog thread, which polls their completion EVENTS every ~100 ms until it has retired them.  An event query from that
-        thread while this thread captures (global capture mode) invalidates the capture or aborts the process ("operation not
-        permitted on an event last recorded in a capturing stream" / "operation failed due to a previous error during
-        capture": 1 run in ~10 of `bench.py --shard`, profiles/r05_notes.md).  All device work is complete here: wait two polling
-        periods so that the watchdog's list is empty before the capture begins."""
-        import time
+    def _nccl_group():
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             try:
-                nccl = dist.get_backend() == 'nccl'
+                return dist.get_backend() == 'nccl'
             except Exception:
-                nccl = False
-            if nccl:
-                torch.cuda.synchronize()
-                time.sleep(0.3)
+                return False
+        return False
+
+    @classmethod
+    def _capture_mode(cls):
+        """hipStreamCaptureMode of the step capture.  RCCL through torch.distributed: every eager collective of the warm-up
+        left a work item with the process group's WATCHDOG THREAD, which polls their completion events every ~100 ms until it
+        has retired them.  Under the default 'global' mode an event query from that thread while this thread captures is an
+        illegal call: it invalidated the capture or aborted the process in 1 run of ~10 of `bench.py --shard`
+        (profiles/r05_notes.md; round 5 slept 0.3 s in front of the capture instead).  'thread_local' confines the legality
+        check to the capturing thread - what the watchdog thread does no longer concerns the capture.  SREC_CAPTURE_MODE
+        overrides (global | thread_local | relaxed)."""
+        m = os.environ.get('SREC_CAPTURE_MODE')
+        if m in ('global', 'thread_local', 'relaxed'):
+            return m
+        return 'thread_local' if cls._nccl_group() else 'global'
+
+    @classmethod
+    def _quiesce_collectives(cls):
+        """all device work of the warm-up is complete before the capture begins (one synchronise when an RCCL group exists);
+        SREC_CAPTURE_SLEEP=<seconds> additionally waits that long for the watchdog to retire its list (the round-5 workaround,
+        0.3 s: kept as a switch, off by default - see _capture_mode and tools/shard_loop.sh)"""
+        if cls._nccl_group():
+            torch.cuda.synchronize()
+            t = float(os.environ.get('SREC_CAPTURE_SLEEP', '0') or 0)
+            if t > 0:
+                import time
+                time.sleep(t)
 
     def _setup_mailbox(self, optimizer, device):
         """Batch intake as the FIRST kernels of the captured step: each reads where this replay's batch lives from a mailbox
@@ -404,3 +427,28 @@ class GraphedTrainStep:
             if mb['calls'] % 512 == 0:
                 self.check()
         return self.loss
+
+
+def capture_agreed(make, agree_min=None, retries=1, log=None):
+    """GraphedTrainStep construction for a job of several ranks: `make()` builds (warms up + captures) the step or raises;
+    `agree_min(x)` returns the minimum of x over the ranks (None: one rank).  The ranks decide TOGETHER after every attempt:
+    if any rank's capture failed, every rank drops its graph, and - because the constructor's eager warm-up steps issue the
+    step's collectives - every rank retries together (`retries` times), so the collective sequences stay paired; after the
+    last attempt all ranks replay or all ranks launch eagerly.  -> (step or None, attempts made, last local error or None)"""
+    err = None
+    for attempt in range(retries + 1):
+        gs, e = None, None
+        try:
+            gs = make()
+        except Exception as ex:                          # capture refused on THIS rank (the constructor has undone its effects)
+            e = ex
+            if log is not None:
+                log('hipGraph capture failed on this rank, attempt %d (%s: %s)' % (attempt + 1, type(ex).__name__, str(ex)[:300]))
+        ok = 1.0 if gs is not None else 0.0
+        if agree_min is not None:
+            ok = float(agree_min(ok))
+        if ok >= 1.0:
+            return gs, attempt + 1, None
+        err = e if e is not None else err
+        gs = None                                        # (another rank failed: this rank's graph is dropped too)
+    return None, retries + 1, err

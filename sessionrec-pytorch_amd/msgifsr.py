@@ -316,7 +316,7 @@ class MSGIFSR(_ScoringMixin, nn.Module):
                 copied = False
             if not (renormed and copied):
                 st['tb16'].refresh(W, 1.0)
-            self._tb16_fresh = True
+            self._tb16_fresh = W._version
         elif not renormed:
             self._renorm()
         self._table_ready = True

@@ -704,6 +704,60 @@ def flush_deferred():
         _launch_slab_sums(tasks)
 
 
+# ------------------------------------------------------------------------------------------ gradient arenas
+# Row-sharded training all-reduces the replicated parameters' gradients in a few flat buckets (dist.VocabParallel).  A
+# parameter with a slot in such a bucket carries `_srec_gslot = [arena, offset, epoch]`; a backward node that ALLOCATES the
+# gradient it returns asks grad_buf(p) for the destination and gets the slot itself - the kernel then writes the gradient where
+# the all-reduce reads it, and autograd's AccumulateGrad takes the view over as p.grad (no concatenation pass).  A slot is
+# handed out once per training forward (`grad_epoch()`): a parameter that feeds two backward nodes gets a private buffer for
+# the second one (the engine sums the two before AccumulateGrad runs), and one that already holds a gradient (accumulation
+# over micro-batches) always does - whatever does not end up in its slot is copied there by the bucket code.
+_GRAD_EPOCH = [0]
+
+
+def grad_epoch():
+    """a new training forward begins: every arena slot may be handed out once more"""
+    _GRAD_EPOCH[0] += 1
+
+
+def grad_slot(p, numel=None):
+    """the arena view for parameter p's gradient (flat, `numel` elements: p's own slot, or a run of adjacent slots starting
+    at p's), or None when p has no slot / the slot is taken / p already holds a gradient or carries hooks"""
+    slot = getattr(p, '_srec_gslot', None)
+    if slot is None or slot[2] == _GRAD_EPOCH[0] or p.grad is not None or not p.is_leaf:
+        return None
+    if getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None):
+        return None
+    n = p.numel() if numel is None else numel
+    if slot[1] + n > slot[0].numel():
+        return None
+    slot[2] = _GRAD_EPOCH[0]
+    return slot[0][slot[1]:slot[1] + n]
+
+
+def grad_buf(p, like=None):
+    """where a backward node writes the gradient of parameter p (shape of `like`, default p): its bucket slot or a new tensor"""
+    like = p if like is None else like
+    v = grad_slot(p) if like.numel() == p.numel() else None
+    if v is not None:
+        return v.view(like.shape)
+    return torch.empty(like.shape, device=like.device, dtype=torch.float32)
+
+
+def grad_buf_pair(p, q):
+    """ONE flat buffer [p.numel() + q.numel()] for two gradients a kernel writes back to back (the GRU's two bias vectors):
+    the two slots when they are neighbours in the arena (nn.GRU lists bias_ih, bias_hh one after the other)"""
+    sp, sq = getattr(p, '_srec_gslot', None), getattr(q, '_srec_gslot', None)
+    if sp is not None and sq is not None and sp[0] is sq[0] and sq[1] == sp[1] + p.numel() and sq[2] != _GRAD_EPOCH[0] \
+            and q.grad is None and q.is_leaf and not getattr(q, '_backward_hooks', None) \
+            and not getattr(q, '_post_accumulate_grad_hooks', None):
+        v = grad_slot(p, p.numel() + q.numel())
+        if v is not None:
+            sq[2] = _GRAD_EPOCH[0]
+            return v
+    return torch.empty(p.numel() + q.numel(), device=p.device, dtype=torch.float32)
+
+
 class GradMark(torch.autograd.Function):
     """identity; its backward calls fn() when the gradient of x has arrived - i.e. when every node downstream of x, and the
     AccumulateGrad nodes of their parameters (the engine runs those first), are done.  dist.VocabParallel.bucket_ready hangs
@@ -1298,7 +1352,7 @@ class ReadoutHeadFused(torch.autograd.Function):
         probs, grads, blocks = [], [], []
         for i, (v, Wu, Wv, we, Wsr, U, Vq, alpha, cat, y, inv) in enumerate(per):
             gy, gs, gcat, dX, dU, dVq, dwp = outs[i]
-            gWu, gWv, gWsr = torch.empty_like(Wu), torch.empty_like(Wv), torch.empty_like(Wsr)
+            gWu, gWv, gWsr = grad_buf(Wu), grad_buf(Wv), grad_buf(Wsr)       # (bucket slots when the table is row-sharded)
             gv = gcat[:, :D]                                              # d v: the concat half, + dVq Wv in place
             probs.append(('nn', dU, Wu, dX, None, dT, 1.0))               # d allf (this order) = read-out term + dU Wu
             probs.append(('tn', dU, allf, gWu, None, dT, 0.0))
@@ -2068,8 +2122,9 @@ class GRUExpandAll(torch.autograd.Function):
         # weight gradients: the reduction runs over rows - split in-kernel into ~512-row pieces (hundreds of short workgroups
         # instead of a dozen long ones), each writing its own slab; the slabs are summed in fixed order
         probs, slabs = [], []
-        gWih = [torch.empty(d3, d, device=dev, dtype=torch.float32) for _ in range(P)]
-        gWhh = [torch.empty(d3, d, device=dev, dtype=torch.float32) for _ in range(P)]
+        # (ctx.wparams = [W_ih, W_hh] per order, ctx.bparams = [b_ih, b_hh] per order: bucket slots when row-sharded)
+        gWih = [grad_buf(ctx.wparams[2 * p]) for p in range(P)]
+        gWhh = [grad_buf(ctx.wparams[2 * p + 1]) for p in range(P)]
         for p in range(P):
             nsp = max(1, (rows[p] + 511) // 512)
             sl = torch.empty(nsp, d3, d, device=dev, dtype=torch.float32) if nsp > 1 else gWih[p].unsqueeze(0)
@@ -2085,7 +2140,7 @@ class GRUExpandAll(torch.autograd.Function):
         for i in range(0, len(probs), 16):
             gemm16('tn', probs[i:i + 16], d3, d, d)
         # bias gradients from the partial rows
-        gb = [torch.empty(6 * d, device=dev, dtype=torch.float32) for _ in range(P)]
+        gb = [grad_buf_pair(ctx.bparams[2 * p], ctx.bparams[2 * p + 1]) for p in range(P)]
         # the weight-gradient slab sums join the ONE end-of-backward launch (defer_slab_sum); the bias partials keep their own
         # kernel: hundreds of partial rows of only 6 d columns - as a task of the generic slab sum (one thread per 4 columns
         # walking all rows) they made that launch 44 us (profiles/r03d), gru_bias_final splits the rows over 16 lanes: 5 us
@@ -2617,7 +2672,7 @@ class HgPlan:
             d.attn_l[m], d.attn_r[m], d.bias[m] = ptr(al), ptr(ar), ptr(bias)
             if dP is not None:
                 d.dP[m] = ptr(dP[m])
-                d.d_attn_l[m], d.d_attn_r[m], d.d_bias[m] = (grads[m, j].data_ptr() for j in range(3))
+                d.d_attn_l[m], d.d_attn_r[m], d.d_bias[m] = (grads[m][j].data_ptr() for j in range(3))
         for m in range(len(self.modules), len(self.types)):
             d.Z[m] = base + 4 * lay[('Z', m)]
         for t in range(len(self.types)):
@@ -2765,7 +2820,8 @@ class HGATLayer(torch.autograd.Function):
         # gradient from the kernels: those buffers start from zero
         cov = [sum(plan.types[bt][1] for bm, bt in plan.blocks if bm == m) for m in range(nm)]
         dP = [torch.empty_like(p) if cov[m] == p.shape[0] else torch.zeros_like(p) for m, p in enumerate(P)]
-        grads = torch.empty(nm, 3, HD, device=dev, dtype=torch.float32)
+        # (attn_l, attn_r, bias gradients: [HD] each - the parameters' bucket slots when the table is row-sharded, ops.grad_buf)
+        grads = [[grad_buf(params[4 * m + 1 + j]).view(-1) for j in range(3)] for m in range(nm)]
         dx = torch.empty(NT, D, device=dev, dtype=torch.float32)
         flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
         desc = plan.fill(HgDesc(), small, lay, P, dP, flat, grads, dstate)
@@ -2783,7 +2839,7 @@ class HGATLayer(torch.autograd.Function):
             ws = _HG_WS[key] = torch.empty(max(n.value, 1), device=dev, dtype=torch.float32)
         lib.srec_hg_bwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(g), _ld(g), ptr(arg), ptr(dx), D, ptr(ws), stream())
         xin = (lambda m: dstate[0][plan.mod_conv[m]]) if dstate is not None else (lambda m: x)
-        gWs = [torch.empty_like(params[4 * m]) for m in range(nm)]
+        gWs = [grad_buf(params[4 * m]) for m in range(nm)]
         convs = (0, 1) if dstate is not None else (None,)
         tgts = None
         S = 1
@@ -2853,9 +2909,8 @@ class HGATLayer(torch.autograd.Function):
             multi = [m for m in range(nm) if len(pcs[m]) > 1]
             slabs = {}
             if multi:
-                gWm = torch.empty(len(multi), HD, D, device=dev, dtype=torch.float32)
+                gWm = [gWs[m] for m in multi]
                 for i, m in enumerate(multi):
-                    gWs[m] = gWm[i]
                     slabs[m] = torch.empty(len(pcs[m]), HD, D, device=dev, dtype=torch.float32)
             probs = []
             for m in range(nm):
@@ -2877,8 +2932,8 @@ class HGATLayer(torch.autograd.Function):
             gW = gWs[m]
             if not ctx.grouped:
                 gemm_tn(dP[m], xin(m)[r0:r0 + nr], gW, dyn)
-            outs += [gW, grads[m, 0].view(params[4 * m + 1].shape), grads[m, 1].view(params[4 * m + 2].shape),
-                     grads[m, 2].view(params[4 * m + 3].shape)]
+            outs += [gW, grads[m][0].view(params[4 * m + 1].shape), grads[m][1].view(params[4 * m + 2].shape),
+                     grads[m][2].view(params[4 * m + 3].shape)]
         return (dx, None, None) + tuple(outs)
 
 

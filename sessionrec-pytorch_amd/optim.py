@@ -282,7 +282,7 @@ class FusedAdam(torch.optim.Optimizer):
                     # checkpoint taken there holds what the reference's next forward would have made of them).
                     mn_model = float(getattr(model, '_max_norm', 0.0) or 0.0)
                     mn = mn_model if cs_out is not None else 0.0
-                    fold = bool(getattr(model, '_fold_table_prep', False)) and st is not None and p.shape[1] <= 1024
+                    fold = st is not None and self.folds_table_prep()    # ONE predicate: graph.py pre-prepares the table by it
                     tb = model._table_copy(st, p) if (fold and hasattr(model, '_table_copy')) else None
                     renorm_write = 1 if (fold and mn_model > 0) else 0
                     if renorm_write:

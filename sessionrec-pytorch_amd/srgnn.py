@@ -94,15 +94,32 @@ class _ScoringMixin:
             st['tb16'] = ops.TableBF16(W)
         return st['tb16']
 
-    def _take_prepared(self, st):
+    def _take_prepared(self, st, mark=True):
         """(rows renormalised, bf16 copy written) by the optimizer's last row pass - consumed once, and only while the table
-        has not been written through PyTorch since (copy_ / load_state_dict bump its version counter; the HIP kernels do not)"""
+        has not been written through PyTorch since (copy_ / load_state_dict bump its version counter; the HIP kernels do not).
+        mark: leave the "copy is fresh" note for the _table_bf16 call of THIS forward (_prepare_table runs ahead of it); the
+        note carries the table version it was taken at, so a write through PyTorch in between voids it."""
         prep = st.pop('table_prepared', None) if st is not None else None
         if prep is None or prep[2] != self._table()._version:
             return False, False
-        if prep[1] and self.shard is None:
-            self._tb16_fresh = True                      # consumed by _table_bf16 of this forward
+        if mark and prep[1] and self.shard is None:
+            self._tb16_fresh = self._table()._version    # consumed by _table_bf16 of this forward
         return prep[0], prep[1] and self.shard is None
+
+    def _pop_tb16_fresh(self):
+        """the note _prepare_table / _take_prepared left: valid for the table version it was written at only"""
+        v = self.__dict__.pop('_tb16_fresh', None)
+        return v is not None and v is not False and v == self._table()._version
+
+    def table_written(self):
+        """the table (or its optimizer state) was replaced from outside the step (load_state_dict, a restored checkpoint):
+        every note about prepared rows / fresh bf16 copies is void"""
+        self.__dict__.pop('_tb16_fresh', None)
+        self.__dict__.pop('_table_ready', None)
+        st = self.__dict__.get('_srec_state')
+        if st is not None:
+            st.pop('table_prepared', None)
+            st['cs_fresh'] = False
 
     shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
     graph_capable = False      # True: every kernel of the step reads its live extents from the padded batch (hipGraph replay)
@@ -163,9 +180,9 @@ class _ScoringMixin:
             return None
         if st.get('tb16') is None:
             st['tb16'] = ops.TableBF16(W)
-        if self.__dict__.pop('_tb16_fresh', False):      # _prepare_table wrote the copy together with the renorm
+        if self._pop_tb16_fresh():                       # _prepare_table wrote the copy together with the renorm
             return st['tb16']
-        if self._take_prepared(st)[1]:                   # the optimizer's row pass of the previous step wrote it
+        if self._take_prepared(st, mark=False)[1]:       # the optimizer's row pass of the previous step wrote it
             return st['tb16']
         return st['tb16'].refresh(W)
 

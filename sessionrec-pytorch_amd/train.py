@@ -96,26 +96,31 @@ class TrainRunner:
             return None
         if not all(getattr(x, 'meta', None) is not None and x.meta.get('padded') for x in inputs):
             return None
-        from .graph import GraphedTrainStep
+        from .graph import GraphedTrainStep, capture_agreed
         if self._gstep is None:
-            try:
-                dev_in = [x.to(self.device) for x in inputs]
-                self._gstep = GraphedTrainStep(self.model, self.optimizer, dev_in, labels.to(self.device),
-                                               after_backward=self._sync_grads if self.shard is not None else None)
-            except Exception as e:                     # capture refused: stay eager for the rest of the run (the
-                # constructor has put parameters, buffers and optimizer state back: same trajectory)
-                print('hipGraph capture failed (%s: %s); eager launches' % (type(e).__name__, e))
-                self.graph = False
+            dev_in = [x.to(self.device) for x in inputs]
+            dev_lab = labels.to(self.device)
+            agree = None
             if self.shard is not None and self.shard.world > 1:
-                # the ranks decide TOGETHER: a rank replaying a captured step next to a rank that fell back to eager launches
-                # would still issue the same collectives, but a rank whose capture failed has also skipped the warm-up's
-                # exchanges - from here on either all replay or all launch eagerly
+                # the ranks decide TOGETHER (graph.capture_agreed): a rank whose capture failed retries with all the others
+                # (the constructor's warm-up steps issue the step's collectives), and after the last attempt either all
+                # replay or all launch eagerly
                 import torch.distributed as dist
                 from .dist import all_reduce_
-                ok = th.tensor([1.0 if self._gstep is not None else 0.0], device=self.device)
-                all_reduce_(ok, dist.ReduceOp.MIN, self.shard.group)
-                if ok.item() < 1.0:
-                    self._gstep, self.graph = None, False
+
+                def agree(x):
+                    ok = th.tensor([x], device=self.device)
+                    all_reduce_(ok, dist.ReduceOp.MIN, self.shard.group)
+                    return ok.item()
+            # (a refused capture: the constructor has put parameters, buffers and optimizer state back - same trajectory)
+            self._gstep, self.capture_attempts, err = capture_agreed(
+                lambda: GraphedTrainStep(self.model, self.optimizer, dev_in, dev_lab,
+                                         after_backward=self._sync_grads if self.shard is not None else None),
+                agree, retries=1, log=print)
+            if self._gstep is None:
+                print('hipGraph capture failed (%s); eager launches' % (('%s: %s' % (type(err).__name__, err)) if err is not None
+                                                                        else 'on another rank'))
+                self.graph = False
             if self._gstep is None:
                 return None
         try:
@@ -210,6 +215,8 @@ class TrainRunner:
             from . import ops
             ops.weights_changed()          # cached bf16 copies / column scales belong to the old weights
             self.model.__dict__.pop('_srec_state', None)
+            if hasattr(self.model, 'table_written'):
+                self.model.table_written() # notes about rows prepared / copies written by the old optimizer's row pass
 
     def _loader_generators(self):
         """the torch.Generators that shuffle the training loader (sampler / batch sampler and what they wrap), in a fixed order"""

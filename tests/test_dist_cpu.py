@@ -444,6 +444,111 @@ def test_replicated_gradient_bucket_is_rank_independent():
         assert keys4 == [0, 2, 3], keys4
 
 
+def _accum_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        D = pkg('dist')
+        ops = pkg('ops')
+        table, _ = _make(world)
+        vp = D.VocabParallel(FakeModel(table), local=TorchLocal())
+        ps = [torch.nn.Parameter(torch.zeros(n)) for n in (3, 4, 5, 6)]     # default partition: p3, p2 -> bucket 0; p1 -> 1; p0 -> 2
+
+        class Opt:
+            grad_override = None
+        opt = Opt()
+
+        def backward(scale, marks=True):
+            """what a backward pass does: every node asks ops.grad_buf for its destination, autograd accumulates, the model's
+            markers fire when a bucket is complete"""
+            for i, p in enumerate(ps):
+                g = ops.grad_buf(p)
+                g.copy_(torch.full_like(p, scale * (i + 1) * (rank + 1)))
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad += g
+            if marks:
+                vp.bucket_ready(0)
+                vp.bucket_ready(1)
+
+        def zero():
+            for p in ps:
+                p.grad = None
+        # step 1: agrees on the layout (no arena yet: every gradient is copied in)
+        vp.begin_step()
+        backward(1.0)
+        vp.sync_replicated_grads(ps, opt)
+        one = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps)}
+        zero()
+        # step 2: the gradients are written INTO the arena slots (nothing to copy but the flag tail), buckets 0 and 1 leave early
+        vp.begin_step()
+        backward(1.0)
+        resident = [ps[i].grad.data_ptr() == vp._arena[vp._slot[id(ps[i])][0]][vp._slot[id(ps[i])][1]:].data_ptr() for i in range(4)]
+        early = sorted(vp._bucket_early)
+        vp.sync_replicated_grads(ps, opt)
+        two = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps)}
+        copies = dict(vp.copy_tasks_last)
+        zero()
+        # step 3: two micro-batches, the first under no_sync(): ONE exchange of the accumulated sums
+        with vp.no_sync():
+            vp.begin_step()
+            backward(1.0)
+            none_early = dict(vp._bucket_early)
+        vp.begin_step()
+        backward(10.0)
+        vp.sync_replicated_grads(ps, opt)
+        acc = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps)}
+        zero()
+        # step 4: misuse - a second backward on top of early-reduced gradients, no no_sync(): loud on every rank
+        vp.begin_step()
+        backward(1.0)
+        try:
+            vp.begin_step()
+            raised = False
+        except RuntimeError as e:
+            raised = 'no_sync' in str(e)
+        # ... and an aborted step (gradients dropped) is forgotten quietly; the early all-reduces it issued were issued by
+        # every rank, so the next step's collectives still pair up
+        zero()
+        vp.begin_step()
+        backward(2.0)
+        vp.sync_replicated_grads(ps, opt)
+        rec = {i: opt.grad_override[id(p)].clone() for i, p in enumerate(ps)}
+        q.put((rank, {k: v.tolist() for k, v in one.items()}, {k: v.tolist() for k, v in two.items()}, resident, early, copies,
+               len(none_early), {k: v.tolist() for k, v in acc.items()}, raised, {k: v.tolist() for k, v in rec.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_arena_accumulation_and_early_launch_protocol():
+    """the early bucket launches depend on rank-agreed state only, micro-batch accumulation goes through
+    no_sync(), a backward on top of all-reduced gradients raises instead of mixing them, an aborted step leaves nothing
+    behind; and the gradients land in the bucket arenas without a concatenation pass"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tot = sum(r + 1 for r in range(world))
+    for rank, one, two, resident, early, copies, n_none, acc, raised, rec in res:
+        for i, n in enumerate((3, 4, 5, 6)):
+            assert one[i] == [float((i + 1) * tot)] * n, (rank, one)
+            assert two[i] == one[i], (rank, two)
+            assert acc[i] == [float(11 * (i + 1) * tot)] * n, (rank, acc)
+            assert rec[i] == [float(2 * (i + 1) * tot)] * n, (rank, rec)
+        assert resident == [True] * 4 and early == [0, 1], (resident, early)
+        assert copies == {0: 0, 1: 0, 2: 1}, copies           # only the flag tail of the last bucket is copied (eager step)
+        assert n_none == 0 and raised
+
+
 def test_bench_gpus_flag_launches_that_many_ranks():
     """`python bench.py --gpus 2` with no torchrun environment must spawn two ranks itself (the flag used to
     be parsed and ignored).  --launch-only stops after the process group is up (gloo on a box without GPUs)."""

@@ -441,3 +441,16 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(dev):
     assert out['launch'] == 'eager' and 'graph capture with the collectives failed' in p.stderr
     assert 1.0 < out['config']['final_loss'] < 12.0          # ~ln V at the start of training
     assert out['roofline']['frac'] > 0 and out['cpu_baseline'] is None and out['fp32'] is None
+    # round 6: the line carries the whole metric - the agreed capture verdict, a correctness bit (row-sharded loss of the first
+    # global batch vs the single-device loss rank 0 computes on the same 1024 sessions), per-exchange times of eager steps, and
+    # the STRONG-scaling point (the reference's own 512-session batch, train.py:94-101) next to the weak one
+    assert c['captured_on_all_ranks'] is False and c['capture_attempts'] == 1
+    ok = out['correctness']
+    assert ok['ok'] and ok['sessions'] == 1024 and ok['rel_err'] <= ok['tol'], ok
+    t = c['timed']
+    assert len(t['per_exchange']) == 9 and all(e['us'] > 0 for e in t['per_exchange']) and t['sum_us'] > 0
+    assert [e['kind'] for e in t['per_exchange']].count('all_reduce') == 3
+    st = out['strong']
+    assert st['scaling'] == 'strong' and st['global_batch'] == 512 and st['sessions_encoded_per_rank'] == 256
+    assert st['value'] > 0 and st['collectives']['count'] == 9 and st['correctness']['ok'] and st['correctness']['sessions'] == 512
+    assert 1.0 < st['final_loss'] < 12.0
