@@ -356,14 +356,6 @@ int srec_hg_drop_merge(const float* t, int S, const float* ms, long n, float* dx
 int srec_hg_pre_merge(const void* desc, const float* g, int ld_g, const float* t, int S, float* dx, int ld_dx, void* stream);
 int srec_hg_bwd(const void* desc, const float* x, int ld_x, const float* g, int ld_g, const unsigned char* arg, float* dx,
                 int ld_dx, float* ws, void* stream);
-/* d fc.weight of every GAT module of the layer WITHOUT reading the projection gradients dP (csrc/hgw.hip; gatconv.py:267-311
- * under autograd, msgifsr.py:47-91): dW[hD+j, c] = sum over the module's EDGES of a[e,h] g[v_e,j] [arg[v_e,j] == h] x[u_e,c]
- * (a GEMM over edges whose A operand is generated while it is staged) + attn_l[hD+j] Z_l[h,c] + attn_r[hD+j] Z_r[h,c] (Z as
- * srec_hg_bwd left it in desc.Z).  x16: HOST array of n_mods device pointers to the bf16 input rows [NT, D] each module
- * projected; out: HOST array of n_mods device pointers to [nsplit[m]][H D, D] fp32 slabs (slab 0 carries the rank-1 terms; the
- * caller sums the slabs, srec_sum_slabs_multi); nsplit: HOST int array >= 1.  H == 8, D == 256, <= 4 instances per module. */
-int srec_hg_wgrad(const void* desc, const void* x16, const float* g, int ld_g, const unsigned char* arg, const void* out,
-                  const int* nsplit, void* stream);
 
 /* grouped, K-segmented bf16-operand GEMM (gemm_group_bf16.hip): up to 8 problems C_p [M,N] (+)= sum_s opA(A_ps) opB(B_ps)
  * in one launch.  desc: host srec_gemm_group (srec_hg.h).  mode 0: A [M,K], B [N,K] (nn.Linear forward); 1: A [M,K],

@@ -79,9 +79,6 @@ typedef struct {
     const int* rm_counter;
     float rm_p;
     int rm_seed, rm_salt;
-    /* (nullable) Am[i] [E, H] bf16 = A x Mk, the soft-max weights times the attention-dropout multipliers, written by
-     * srec_hg_bwd (H == 8) for srec_hg_wgrad: the edge GEMM's A tiles are generated from 16 bytes per edge */
-    void* Am[SREC_HG_MAXI];
 } srec_hg_desc;
 
 /* problem table of srec_gemm_group_bf16 (srec.h) */

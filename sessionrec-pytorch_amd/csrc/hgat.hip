@@ -1128,7 +1128,6 @@ struct SrcArgs {
     const float* g; int ld_g;
     const unsigned char* arg;
     int skip_dead;                      // dP rows past the live count stay unwritten (their readers stop at the live rows)
-    unsigned short* Am[MAXI];           // (nullable, H == 8) [E, 8] bf16 = A x Mk per edge, for srec_hg_wgrad (csrc/hgw.hip)
 };
 
 // per (projection block, node u), ALL heads in one wavefront:
@@ -1195,10 +1194,6 @@ __global__ __launch_bounds__(64 * WPB_SRC, WV) void hg_bwd_src_kernel(SrcArgs a)
 #pragma unroll
                     for (int h = 0; h < 8; ++h) p8[h] *= m8[h];
                 }
-                if (a.Am[i] != nullptr)                  // every edge is an out-edge of exactly one node of one instance
-                    *reinterpret_cast<uint4*>(a.Am[i] + (size_t)e * 8) =
-                        make_uint4(srec_pack_bf16(p8[0], p8[1]), srec_pack_bf16(p8[2], p8[3]), srec_pack_bf16(p8[4], p8[5]),
-                                   srec_pack_bf16(p8[6], p8[7]));
             }
             HGT_W(1);
             {   // del[u, h] = sum of DP over all out-edges: 8 wave sums in 10 shuffles, then head h to the lanes with hl == h
@@ -1268,10 +1263,6 @@ __global__ __launch_bounds__(64 * WPB_SRC, WV) void hg_bwd_src_kernel(SrcArgs a)
 #pragma unroll
                         for (int h = 0; h < MAXH; ++h) p[h] = h < H ? (me != nullptr ? ae[h] * me[h] : ae[h]) : 0.f;
                     }
-                    if (H == MAXH && lane == 0 && a.Am[i] != nullptr)
-                        *reinterpret_cast<uint4*>(a.Am[i] + (size_t)e * 8) =
-                            make_uint4(srec_pack_bf16(p[0], p[1]), srec_pack_bf16(p[2], p[3]), srec_pack_bf16(p[4], p[5]),
-                                       srec_pack_bf16(p[6], p[7]));
 #pragma unroll
                     for (int h = 0; h < MAXH; ++h) {
                         if (h < H) {
@@ -1779,7 +1770,6 @@ extern "C" int srec_hg_bwd(const void* desc_, const float* x, int ld_x, const fl
             a.A[i] = d->A[i]; a.DP[i] = d->DP[i]; a.der[i] = d->der[i]; a.Mk[i] = d->Mk[i];
             a.out_ptr[i] = d->out_ptr[i]; a.out_idx[i] = d->out_idx[i]; a.edst[i] = d->edst[i];
             a.row0_d[i] = d->row0[d->blk_type[db]];
-            a.Am[i] = H == MAXH ? (unsigned short*)d->Am[i] : nullptr;
         }
         if (blocks > 0) {
             const size_t lds = (size_t)2 * HD * sizeof(float);

@@ -2518,7 +2518,7 @@ class HgDesc(_ct.Structure):
                 [(n, _ct.c_void_p * 16) for n in ('in_ptr', 'in_idx', 'esrc', 'out_ptr', 'out_idx', 'edst', 'A', 'DP', 'der', 'Mk')] +
                 [('smean', _ct.c_void_p * 4), ('sess', _ct.c_void_p)] +
                 [('rm_cnt', _ct.c_void_p), ('rm_counter', _ct.c_void_p), ('rm_p', _ct.c_float), ('rm_seed', _ct.c_int),
-                 ('rm_salt', _ct.c_int), ('Am', _ct.c_void_p * 16)])
+                 ('rm_salt', _ct.c_int)])
 
 
 class GemmGroup(_ct.Structure):
@@ -2635,9 +2635,9 @@ class HgPlan:
         for i, (m, sb, db, gr) in enumerate(self.insts):
             E = max(gr[4].numel(), 1) * H
             nd = self.types[self.blocks[db][1]][1] * H
-            for nm, n in (('A', E), ('DP', E), ('der', nd), ('Am', E // 2)):     # (Am: bf16 [E, H] = A x Mk for srec_hg_wgrad)
+            for nm, n in (('A', E), ('DP', E), ('der', nd)):
                 lay[(nm, i)] = off
-                off += (n + 3) // 4 * 4
+                off += n
         for t in range(len(self.types)):                   # session means of the input rows per node type [B, D]
             lay[('smean', t)] = off
             off += self.B * self.D
@@ -2687,7 +2687,7 @@ class HgPlan:
             d.inst_mod[i], d.inst_sblk[i], d.inst_dblk[i] = m, sb, db
             for nm, g in zip(('in_ptr', 'in_idx', 'out_ptr', 'out_idx', 'esrc', 'edst'), gr):
                 getattr(d, nm)[i] = ptr(g)
-            for nm in ('A', 'DP', 'der', 'Am'):
+            for nm in ('A', 'DP', 'der'):
                 getattr(d, nm)[i] = base + 4 * lay[(nm, i)]
         return d
 
@@ -2713,11 +2713,6 @@ def _inst_counts(plan, NT, dev):
         cnt = _CNT_CACHE[key] = host.to(dev)
     return cnt
 
-
-# MSHGNN weight gradients as a GEMM over EDGES with generated operand tiles (csrc/hgw.hip) instead of dP^T x (gemm16 tn);
-# SREC_HG_WGRAD=dp keeps the round-5 product (A / B runs, tests compare the two)
-HG_EDGE_WGRAD = os.environ.get('SREC_HG_WGRAD', 'edge') != 'dp'
-HG_EDGE_SPLIT = int(os.environ.get('SREC_HG_WSPLIT', '1'))       # k-split pieces per relation instance of a module
 
 DROP_TAP = None      # tests: set to a list to receive {'ms': [2, NT, D], 'mk': [per instance (E*H,)]} of every dropout layer call
 
@@ -2917,28 +2912,13 @@ class HGATLayer(torch.autograd.Function):
                 gWm = [gWs[m] for m in multi]
                 for i, m in enumerate(multi):
                     slabs[m] = torch.empty(len(pcs[m]), HD, D, device=dev, dtype=torch.float32)
-            if HG_EDGE_WGRAD and plan.H == 8 and D == 256 and _ld(g) % 2 == 0:
-                # the edge formulation (csrc/hgw.hip): reduction over the module's edges, A tiles generated from g / arg / the
-                # soft-max weights, dP not read; modules with several relation instances (the shared 'inter' ones) are k-split
-                ninst = [sum(1 for (im, _, _, _) in plan.insts if im == m) for m in range(nm)]
-                nsp = [max(1, min(8, ninst[m] * HG_EDGE_SPLIT)) for m in range(nm)]
-                slabs = {m: torch.empty(nsp[m], HD, D, device=dev, dtype=torch.float32) for m in range(nm) if nsp[m] > 1}
-                multi = sorted(slabs)
-                gWm = [gWs[m] for m in multi]
-                arr = _ct.c_void_p * nm
-                a_x = arr(*[xin16(m).data_ptr() for m in range(nm)])
-                a_o = arr(*[(slabs[m] if m in slabs else gWs[m]).data_ptr() for m in range(nm)])
-                a_n = (_ct.c_int * nm)(*nsp)
-                lib.srec_hg_wgrad(_ct.addressof(desc), _ct.addressof(a_x), ptr(g), _ld(g), ptr(arg), _ct.addressof(a_o),
-                                  _ct.addressof(a_n), stream())
-            else:
-                probs = []
-                for m in range(nm):
-                    for pi, (o, t0, nc, dyn_t) in enumerate(pcs[m]):
-                        tgt = gWs[m] if m not in slabs else slabs[m][pi:pi + 1]
-                        probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t, 0, 1))
-                for i in range(0, len(probs), 16):
-                    gemm16('tn', probs[i:i + 16], HD, D, D)
+            probs = []
+            for m in range(nm):
+                for pi, (o, t0, nc, dyn_t) in enumerate(pcs[m]):
+                    tgt = gWs[m] if m not in slabs else slabs[m][pi:pi + 1]
+                    probs.append((HD, D, nc, [(dP[m][o:o + nc], xin16(m)[t0:t0 + nc])], tgt, dyn_t, 0, 1))
+            for i in range(0, len(probs), 16):
+                gemm16('tn', probs[i:i + 16], HD, D, D)
             if multi and can_defer(ctx.defer, [ctx.wparams[m] for m in multi]):
                 for i, m in enumerate(multi):
                     defer_slab_sum(slabs[m], gWm[i])

@@ -637,41 +637,6 @@ def test_msgifsr_bf16_gemm16_path_against_the_oracle(dev, d, dropout, big):
     assert (num / den) ** 0.5 < 3e-2, 'bf16 gradients off by %.3e (norm-wise)' % (num / den) ** 0.5
 
 
-@pytest.mark.parametrize('dropout,big', [(0.0, False), (0.1, True)])
-def test_mshgnn_edge_weight_gradient_equals_the_dp_product(dev, dropout, big):
-    """round 6: d fc.weight of the GAT modules as a GEMM over EDGES with generated operand tiles (csrc/hgw.hip:
-    sum_e a[e,h] g[v,j] [arg == h] x[u,c] + the rank-1 attention terms) against the round-5 product dP^T x (gemm16 tn) on the
-    same batch and weights - two roundings of the same algebra (gatconv.py:267-311 under autograd): bf16 operand noise only."""
-    sp, ops = pkg(), pkg('ops')
-    K, V, d = 3, 3429, 256
-    z, samples, _ = load_golden('msgifsr_K3_s32')
-    if big:
-        from dist_gpu_worker import synth_samples
-        samples = synth_samples(512, V, 11)
-    grads = {}
-    ops.set_precision('bf16')
-    try:
-        for mode in (True, False):
-            ops.HG_EDGE_WGRAD = mode
-            torch.manual_seed(123)
-            ops.seed_dropout(7)
-            model = sp.MSGIFSR(V, 'sample', d, 1, dropout=dropout, order=K, extra=False, fusion=False).to(dev).train()
-            (mg,), labels = _collate('msgifsr_K3_s32', samples)
-            loss = model.fused_loss(mg.to(dev), labels.to(dev))
-            loss.backward()
-            grads[mode] = {k: p.grad.double().cpu() for k, p in model.named_parameters()
-                           if k.startswith('layers.') and k.endswith('fc.weight') and p.grad is not None}
-    finally:
-        ops.HG_EDGE_WGRAD = True
-        ops.set_precision('fp32')
-    assert len(grads[True]) == 8 and set(grads[True]) == set(grads[False])
-    for k in grads[True]:
-        a, b = grads[True][k].reshape(-1), grads[False][k].reshape(-1)
-        rel = float((a - b).norm() / b.norm())
-        cos = float(a @ b / (a.norm() * b.norm()))
-        assert rel < 1e-2 and cos > 0.9999, '%s: edge vs dP^T x weight gradient rel %.3e cos %.6f' % (k, rel, cos)
-
-
 @pytest.mark.parametrize('name', ['niser_s32', 'msgifsr_K3_s32', 'msgifsr_K3_fus_s32'])
 def test_projection_fused_in_the_row_sharded_path(dev, name):
     """the same with the table row-sharded (dist.VocabParallel on a one-rank world: the code every rank of an N-GPU job runs):
