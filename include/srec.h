@@ -73,18 +73,25 @@ int srec_score_logp(const float* sr, int ld_sr, const float* E, int ld_e, const 
  * once per head for the session vectors.
  * ws_stats >= 2 * n_stat_slabs * B floats, ws_dsr >= n_ranges * B * d floats.  Soft-max statistics, exp and all
  * accumulation stay fp32; dE / dsr are fp32.  The backward runs both parts in one launch (parts bits as above;
- * bit3 = leave the d-sr partial slabs in ws_dsr unreduced); it reads only the row-major copies (srT16 / ET16 are ignored and
- * may be NULL: the transposed MFMA fragments are taken from the row-major LDS image by ds_read_b64_tr_b16). */
+ * bit3 = leave the d-sr partial slabs in ws_dsr unreduced); it reads only the row-major copies (ET16 is ignored and may be
+ * NULL: the transposed MFMA fragments are taken from the row-major LDS image by ds_read_b64_tr_b16; ws_de: see
+ * srec_ce_de_split below, NULL = no session split). */
 int srec_bf16_prepare(const float* src, int ld, int R, const int* dynR, int d, void* dst16, void* dstT16, int Rp,
                       void* stream);
 int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_ranges, int* d_pad);
 int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16, int Vp, const float* cs, const int* labels,
                            int B, int V, int d, const int* dynB, float* ws_stats, float* lab_logit, float* lse,
                            float* lossvec, float* loss, void* stream);
-int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int Bp, const void* E16, const void* ET16, int Vp,
+int srec_score_ce_bwd_bf16(const void* sr16, float* ws_de, int Bp, const void* E16, const void* ET16, int Vp,
                            const float* cs, const int* labels, const float* lse, const float* gscale, const float* ga,
                            const float* gc, int B, int V, int d, const int* dynB, float* dE, int ld_de, float* ws_dsr,
                            float* dsr, int parts, void* stream);
+/* Session split of the backward's item tiles (round 6; the step a rank of an N-GPU job runs scores N x 512 sessions against V / N
+ * table rows: few item tiles, each streaming N x the sessions - train.py:94-101 sharded): srec_ce_de_split(B, V, d, &split): workgroups
+ * per item tile at this shape (1 = none).  The caller may pass ws_de (nullable) >= split x V x d floats and the split in `parts`
+ * bits 8 - 15: workgroup (tile, s) then writes slab s, and the slabs are summed in order into dE (added to it with parts bit 2)
+ * by one more launch.  Needs ld_de == d == d_pad. */
+int srec_ce_de_split(int B, int V, int d, int* split);
 
 /* ---- embedding rows (rowops.hip) --------------------------------------------------------------------
  * gather: nn.Embedding lookup srgnn.py:133 niser.py:133 lessr.py:168 msgifsr.py:247.

@@ -429,30 +429,47 @@ __global__ void localize_idx_kernel(const I* __restrict__ idx, long n, long long
 // (lse - lab).  lab_all (nullable) = the gathered global labels: a session with label < 0 is capacity padding of its
 // rank's batch (dead): it is left out of the mean and gets weight 0 in gw (nullable) = d loss / d (lse_b - lab_b), i.e.
 // 1 / n_live for the live sessions - the per-session coefficients the backward kernels take as ga / gc.  One workgroup.
+// (1024 threads, the per-rank statistics of a session fetched side by side: at 8 ranks x 4 096 sessions the first version - 256
+//  threads, one dependent load after the other - took 53 us of the rank's step, profiles/r06_rank8_weak_breakdown.txt)
 template <typename I>
-__global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, const I* __restrict__ lab_all,
-                                   float* __restrict__ lse, float* __restrict__ lab, float* __restrict__ loss,
-                                   float* __restrict__ gw) {
-    __shared__ float red[4];
-    __shared__ int cnt[4];
+__global__ __launch_bounds__(1024) void merge_stats_kernel(const float* __restrict__ st, int w, int B, const I* __restrict__ lab_all,
+                                                          float* __restrict__ lse, float* __restrict__ lab, float* __restrict__ loss,
+                                                          float* __restrict__ gw) {
+    __shared__ float red[16];
+    __shared__ int cnt[16];
+    const int nw = blockDim.x >> 6;
     int c = 0;
     for (int b = threadIdx.x; b < B; b += blockDim.x) c += (lab_all == nullptr || lab_all[b] >= 0) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
     __syncthreads();
-    const int n_live = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    int n_live = 0;
+    for (int i = 0; i < nw; ++i) n_live += cnt[i];
     const float inv = 1.f / (float)(n_live > 0 ? n_live : 1);
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const bool live = lab_all == nullptr || lab_all[b] >= 0;
-        float m = -INFINITY, t = 0.f;
-        for (int r = 0; r < w; ++r) {
-            m = fmaxf(m, st[((size_t)r * 2) * B + b]);
-            t += st[((size_t)r * 2 + 1) * B + b];
+        float m = -INFINITY, t = 0.f, l = 0.f;
+        for (int r0 = 0; r0 < w; r0 += 8) {                              // 8 ranks' (lse, label logit) pairs in flight
+            float sv[8], tv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = min(r0 + k, w - 1);
+                sv[k] = st[((size_t)r * 2) * B + b];
+                tv[k] = st[((size_t)r * 2 + 1) * B + b];
+            }
+            float mb = m;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (r0 + k < w) { mb = fmaxf(mb, sv[k]); t += tv[k]; }
+            l *= expf(m - mb);                                           // (m = -inf in the first block: l = 0 stays 0)
+            if (m == -INFINITY) l = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (r0 + k < w) l += expf(sv[k] - mb);
+            m = mb;
         }
-        float l = 0.f;
-        for (int r = 0; r < w; ++r) l += expf(st[((size_t)r * 2) * B + b] - m);
         const float v = m + logf(l);
         lse[b] = v;
         lab[b] = t;
@@ -462,7 +479,11 @@ __global__ void merge_stats_kernel(const float* __restrict__ st, int w, int B, c
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) * inv;
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nw; ++i) s += red[i];
+        loss[0] = s * inv;
+    }
 }
 
 // inv[pos[e]] = u for e in [ptr[u], ptr[u+1]); one wavefront per item.  inv is pre-filled with -1 by the first pass.
@@ -815,8 +836,8 @@ extern "C" int srec_localize_idx32(const int* idx, long n, long lo, int n_loc, i
 extern "C" int srec_merge_stats(const float* st, int w, int B, const long long* lab_all, float* lse, float* lab,
                                 float* loss, float* gw, void* stream) {
     if (w <= 0 || B <= 0) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(merge_stats_kernel<long long>, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lab_all, lse, lab, loss,
-                       gw);
+    hipLaunchKernelGGL(merge_stats_kernel<long long>, dim3(1), dim3(B > 1024 ? 1024 : 256), 0, (hipStream_t)stream, st, w, B, lab_all, lse,
+                       lab, loss, gw);
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -825,7 +846,8 @@ extern "C" int srec_merge_stats(const float* st, int w, int B, const long long* 
 extern "C" int srec_merge_stats32(const float* st, int w, int B, const int* lab_all, float* lse, float* lab, float* loss,
                                   float* gw, void* stream) {
     if (w <= 0 || B <= 0) return SREC_BAD_ARG;
-    hipLaunchKernelGGL(merge_stats_kernel<int>, dim3(1), dim3(256), 0, (hipStream_t)stream, st, w, B, lab_all, lse, lab, loss, gw);
+    hipLaunchKernelGGL(merge_stats_kernel<int>, dim3(1), dim3(B > 1024 ? 1024 : 256), 0, (hipStream_t)stream, st, w, B, lab_all, lse, lab, loss,
+                       gw);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -80,6 +80,8 @@ struct BArgs {
     int B, V, d;
     float* part_m; float* part_l; float* lab_logit;
     float* dE; int ld_de; int acc_dE;
+    float* de_slab; int de_split, de_per;   // backward: every item tile's sessions are split over de_split workgroups (de_per sessions
+    //                                         each), workgroup (tile, sb) writes slab sb [V, D] of de_slab (summed by de_reduce_kernel)
     float* part_dsr;
     int n_de_pad;                // item-tile workgroups (padded to a multiple of 8); 0 = none
     int n_ranges, chunks_per_range, n_sess_tiles;
@@ -143,9 +145,13 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         // position measured worse: 55.7 -> 58.4 us)
         if ((int)blockIdx.x < a.n_de_pad) {
             role_de = true;
-            x0 = blockIdx.x * OWN;
+            // (a rank of an N-GPU job scores N x 512 sessions against V / N rows: few item tiles, each with N x the sessions -
+            //  34 workgroups of 128 chunks at N = 8, 244 us; split over the sessions they are 272 of 16 chunks again)
+            const int tile = (int)blockIdx.x / a.de_split;
+            range = (int)blockIdx.x - tile * a.de_split;            // (the slab this workgroup writes)
+            x0 = tile * OWN;
             if (x0 >= a.V) return;
-            ybeg = 0; yend = Bd;
+            ybeg = min(Bd, range * a.de_per); yend = min(Bd, ybeg + a.de_per);
         } else {
             const int b = blockIdx.x - a.n_de_pad;
             const int xcd = b & 7, j = b >> 3;
@@ -465,9 +471,10 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     }
     if ((KO & 8) && acc[0][0] != 12345.678f) return;          // (keeps the accumulators alive)
     const int d = a.d;
-    float* const outp = role_de ? a.dE : a.part_dsr + (size_t)range * a.B * d;
-    const int ld_out = role_de ? a.ld_de : d, nrows = role_de ? a.V : a.B;
-    const bool accum = role_de && a.acc_dE;
+    const bool slab = role_de && a.de_split > 1;
+    float* const outp = role_de ? (slab ? a.de_slab + (size_t)range * a.V * d : a.dE) : a.part_dsr + (size_t)range * a.B * d;
+    const int ld_out = role_de ? (slab ? d : a.ld_de) : d, nrows = role_de ? a.V : a.B;
+    const bool accum = role_de && a.acc_dE && !slab;
     if (d == D && (ld_out & 3) == 0 && ((size_t)outp & 15) == 0) {
         // Rows leave as 16-byte stores (a 1 KiB row per wave instruction at D = 256) through a per-wave LDS patch of 8 rows
         // (the chunk ring is free now): the accumulator layout has ONE float of a row per lane, and 4-byte stores of 128
@@ -570,8 +577,8 @@ constexpr int XCDS = 8, XCD_SLOTS = 64;                   // 32 CUs x 2 resident
 // rx_pref (nullable): prefix sums of the ranges per XCD; returns the largest per-XCD count.  An XCD hosts
 // floor(free slots / session tiles) ranges, free = 64 - (its item tiles in the last round): at V = 37 484 five XCDs carry 37
 // item tiles (6 ranges) and three carry 36 (7 ranges) - 51 ranges instead of 8 x 6.
-int pick_ranges_bwd(int B, int V, bool with_de, int* n_ranges, int* chunks_per_range, int* rx_pref = nullptr) {
-    const int T = cdiv(B, OWN), chunks = cdiv(V, CH), de_tiles = cdiv(V, OWN);
+int pick_ranges_bwd(int B, int V, bool with_de, int* n_ranges, int* chunks_per_range, int* rx_pref = nullptr, int de_split = 1) {
+    const int T = cdiv(B, OWN), chunks = cdiv(V, CH), de_tiles = cdiv(V, OWN) * de_split;
     int rx[XCDS], total = 0;
     for (int x = 0; x < XCDS; ++x) {
         int free_slots = XCD_SLOTS;
@@ -603,6 +610,33 @@ int pick_ranges_bwd(int B, int V, bool with_de, int* n_ranges, int* chunks_per_r
 }
 
 inline bool bad_d(int d) { return d <= 0 || d > 256 || (d & 3); }
+
+// session split of the backward's item tiles: ~293 workgroups of that kind fill the chip next to the d-sr ranges (the C3
+// shape: 293 tiles x 16 chunks); fewer, longer tiles (a row shard scored against the sessions of all ranks) are cut into
+// pieces of >= 512 sessions
+inline int de_split_for(int B, int V) {
+    const int tiles = cdiv(V, OWN);
+    int s = (293 + tiles / 2) / tiles;
+    const int cap = B / 512;
+    if (s > cap) s = cap;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+// dE (+)= sum of the session-split slabs, in slab order (deterministic)
+__global__ void de_reduce_kernel(const float* __restrict__ part, int R, size_t n, float* __restrict__ out, int acc) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 s = acc ? *reinterpret_cast<const float4*>(out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r0 = 0; r0 < R; r0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = r0 + k < R ? *reinterpret_cast<const float4*>(part + (size_t)(r0 + k) * n + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
+}
 
 }  // namespace
 
@@ -637,6 +671,10 @@ extern "C" int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_
     pick_ranges_bwd(B, V, true, &R, &cpr);
     pick_ranges_bwd(B, V, false, &R2, &cpr);
     *n_ranges = R > R2 ? R : R2;
+    if (d == dpad(d) && de_split_for(B, V) > 1) {          // (the session-split launch counts its item-tile workgroups differently)
+        pick_ranges_bwd(B, V, true, &R2, &cpr, nullptr, de_split_for(B, V));
+        if (R2 > *n_ranges) *n_ranges = R2;
+    }
     *d_pad = dpad(d);
     return 0;
 }
@@ -666,7 +704,15 @@ extern "C" int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16,
 }
 
 // backward with the bf16 copies (row-major and transposed) of both operands; dE / dsr fp32 as in srec_score_ce_bwd.
-extern "C" int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int Bp, const void* E16, const void* ET16,
+// workgroups per item tile the backward should split the sessions over at this shape (1: none) - the caller allocates
+// ws_de >= that many x V x d floats and passes the count in `parts` bits 8 - 15
+extern "C" int srec_ce_de_split(int B, int V, int d, int* split) {
+    if (split == nullptr || bad_d(d) || B <= 0 || V <= 0) return SREC_BAD_ARG;
+    *split = d == dpad(d) ? de_split_for(B, V) : 1;
+    return 0;
+}
+
+extern "C" int srec_score_ce_bwd_bf16(const void* sr16, float* ws_de, int Bp, const void* E16, const void* ET16,
                                       int Vp, const float* cs, const int* labels, const float* lse,
                                       const float* gscale, const float* ga, const float* gc, int B, int V, int d,
                                       const int* dynB, float* dE, int ld_de, float* ws_dsr, float* dsr, int parts,
@@ -675,22 +721,34 @@ extern "C" int srec_score_ce_bwd_bf16(const void* sr16, const void* srT16, int B
     if (!(parts & 3)) return 0;
     hipStream_t st = (hipStream_t)stream;
     BArgs a{};
-    a.S16 = (const unsigned short*)sr16; a.ST16 = (const unsigned short*)srT16; a.Bp = Bp;
+    a.S16 = (const unsigned short*)sr16; a.ST16 = nullptr; a.Bp = Bp;
     a.E16 = (const unsigned short*)E16; a.ET16 = (const unsigned short*)ET16; a.Vp = Vp;
     a.cs = cs; a.labels = labels; a.lse = lse; a.gscale = gscale; a.ga = ga; a.gc = gc; a.dynB = dynB;
     a.B = B; a.V = V; a.d = d; a.dE = dE; a.ld_de = ld_de; a.acc_dE = (parts & 4) ? 1 : 0; a.part_dsr = ws_dsr;
     a.n_sess_tiles = cdiv(B, OWN);
     const bool with_de = parts & 1, with_dsr = parts & 2;
-    a.n_de_pad = with_de ? 8 * cdiv(cdiv(V, OWN), 8) : 0;
+    // session split of the item tiles: the caller says how many slabs ws_de holds (parts bits 8 - 15, from srec_ce_de_split)
+    a.de_split = 1; a.de_slab = nullptr; a.de_per = B;
+    const int ds = (parts >> 8) & 0xff;
+    if (with_de && ws_de != nullptr && ds > 1 && ld_de == d && d == dpad(d) && ((size_t)V * d) % 4 == 0) {
+        a.de_split = ds; a.de_slab = ws_de;
+        a.de_per = (cdiv(B, ds) + CH - 1) / CH * CH;
+    }
+    a.n_de_pad = with_de ? 8 * cdiv(cdiv(V, OWN) * a.de_split, 8) : 0;
     int nblocks = a.n_de_pad;
     if (with_dsr) {
-        const int rmax = pick_ranges_bwd(B, V, with_de, &a.n_ranges, &a.chunks_per_range, a.rx_pref);
+        const int rmax = pick_ranges_bwd(B, V, with_de, &a.n_ranges, &a.chunks_per_range, a.rx_pref, a.de_split);
         nblocks += 8 * rmax * a.n_sess_tiles;
     } else {
         a.n_ranges = 0; a.chunks_per_range = 1;
     }
     int rc = launch_kind<KIND_BWD>(a, nblocks, st);
     if (rc) return rc;
+    if (a.de_split > 1) {
+        const size_t n = (size_t)V * d;
+        hipLaunchKernelGGL(de_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a.de_slab, a.de_split, n, dE,
+                           (parts & 4) ? 1 : 0);
+    }
     if (with_dsr && !(parts & 8)) {
         const size_t n = (size_t)B * d;
         hipLaunchKernelGGL(dsr_reduce_kernel, dim3((unsigned)cdiv((int)(n / 4), 64)), dim3(256), 0, st, ws_dsr,

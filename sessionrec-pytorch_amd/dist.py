@@ -463,9 +463,19 @@ class ShardedLookup(torch.autograd.Function):
         else:
             req = torch.cat(parts) if len(parts) > 1 else parts[0]
         packed = all_gather_cat(req.unsqueeze(0), group)                                      # [w, ucap (+ B)]
-        ctx.items_all = packed[:, :ucap].reshape(-1)
-        if lab is not None:
-            vp.lab_all = packed[:, ucap:].reshape(-1)
+        w_ = packed.shape[0]
+        if lab is not None and w_ > 1 and w_ <= 16 and vp is not None and packed.is_cuda and packed.dtype == torch.int32:
+            # the two column blocks as contiguous lists, one multi-copy launch (two strided aten copies before)
+            nb = packed.shape[1] - ucap
+            both = torch.empty(w_ * (ucap + nb), device=packed.device, dtype=torch.int32)
+            ctx.items_all, vp.lab_all = both[:w_ * ucap], both[w_ * ucap:]
+            pf, bf = packed.view(torch.float32), both.view(torch.float32)
+            vp._copy_tasks([(pf[r, :ucap], bf[r * ucap:(r + 1) * ucap]) for r in range(w_)] +
+                           [(pf[r, ucap:], bf[w_ * ucap + r * nb:w_ * ucap + (r + 1) * nb]) for r in range(w_)])
+        else:
+            ctx.items_all = packed[:, :ucap].reshape(-1)
+            if lab is not None:
+                vp.lab_all = packed[:, ucap:].reshape(-1)
         ctx.rel = local.localize(ctx.items_all, lo, n_loc)     # local row of every requested item (-1: another rank's); reused by the backward
         rows_all = local.gather_masked(shard, ctx.rel)                                        # [w * ucap, d]
         mine = reduce_scatter_sum(rows_all, group)                                            # [ucap, d]: my items' rows

@@ -1468,8 +1468,27 @@ class CEWorkspace:
         self.Bp = (B + 127) // 128 * 128
         self.sr16 = self.srT16 = None
         self.sr_key = None
+        self._de = {}
         if _bf16_dim_ok(d):
             self.sr16 = torch.zeros(self.Bp, dp.value, device=device, dtype=torch.bfloat16)
+
+
+def _ce_de_slabs(self, B, V, d):
+    """(split, workspace) of the session-split scoring backward at this shape (allocated by an eager step: a captured step
+    finds it in the cache)"""
+    ent = self._de.get((B, V))
+    if ent is None:
+        sp = _ct.c_int(1)
+        lib.srec_ce_de_split(B, V, d, _ct.addressof(sp))
+        split = int(sp.value)
+        if split > 1 and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('the scoring workspace must be sized by an eager warm-up step before graph capture')
+        buf = torch.empty(split * V * d, device=self.stats.device, dtype=torch.float32) if split > 1 else None
+        ent = self._de[(B, V)] = (split, buf)
+    return ent
+
+
+CEWorkspace.de_slabs = _ce_de_slabs
 
 
 class TableBF16:
@@ -1534,9 +1553,12 @@ def _ce_bwd(sr, table, cs, labels, lse, gl, ga, gc, ws, dynB, tb, dE, dsr, parts
     V = table.shape[0]
     if tb is not None:
         _prepare_sr(sr, ws, dynB)
-        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), None, ws.Bp, ptr(tb.E16), None, tb.Vp, ptr(cs),
+        # many sessions against few table rows (a rank's shard scored for the sessions of ALL ranks): the item tiles of the
+        # backward are split over the sessions, slabs in a workspace the split decides the size of (srec_ce_de_split)
+        split, slabs = ws.de_slabs(B, V, d) if (parts & 1) and dE.stride(0) == d else (1, None)
+        lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), ptr(slabs), ws.Bp, ptr(tb.E16), None, tb.Vp, ptr(cs),
                                    ptr(labels), ptr(lse), ptr(gl), ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE),
-                                   dE.stride(0), ptr(ws.dsr_part), ptr(dsr), parts, stream())
+                                   dE.stride(0), ptr(ws.dsr_part), ptr(dsr), parts | (split << 8), stream())
     else:
         lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), ptr(gl),
                               ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE), dE.stride(0), ptr(ws.dsr_part), ptr(dsr),

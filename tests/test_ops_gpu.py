@@ -810,7 +810,10 @@ def _ce_reference_chunked(sr, E, cs, labels, chunk=512):
 
 @pytest.mark.parametrize('B,V,d,cosine,tag', [(512, 37484, 256, True, 'C3: the launch BENCH reports'),
                                               (512, 43097, 96, False, 'C2: SRGNN / Diginetica'),
-                                              (512, 43097, 96, True, 'C2 shape, cosine (NISER)')])
+                                              (512, 43097, 96, True, 'C2 shape, cosine (NISER)'),
+                                              (4096, 4332, 256, True, 'C3 / C4 as rank 7 of 8 scores it (weak scaling): split 8'),
+                                              (2048, 9260, 256, True, 'C3 as a rank of 4 scores it: split 4'),
+                                              (1000, 18732, 256, True, 'a rank of 2, ragged session count (1000 < 1024: one piece)')])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_score_ce_at_benchmarked_shapes(dev, B, V, d, cosine, tag, precision):
     """The fused scoring / CE kernels at exactly the shapes the benchmark and BASELINE configs C2 / C3 name (the bf16
@@ -836,6 +839,12 @@ def test_score_ce_at_benchmarked_shapes(dev, B, V, d, cosine, tag, precision):
         loss, lse = ops.ScoreCE.apply(srg, E, cs, labels.int(), ws, tg, None, 0.0, tb)
         # cs_inv_scale = 0: rownorm_project subtracts nothing -> tg.buf is d loss / d E_v at fixed cs, like the reference
         loss.backward()
+        if precision == 'bf16' and 'split' in tag:
+            # the session-split backward (round 6: item tiles of a row shard cut over the sessions of all ranks) ran: its
+            # slab workspace exists and has the advertised number of pieces
+            want = int(tag.split('split ')[1])
+            (split, slabs), = ws._de.values()
+            assert split == want and slabs is not None and slabs.numel() == split * V * d, (split, want)
     finally:
         ops.set_precision('fp32')
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
