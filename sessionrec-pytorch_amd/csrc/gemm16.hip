@@ -24,7 +24,6 @@
 //         a packing pass): consecutive lanes read consecutive 2-byte columns, conflict free.
 #include "common.h"
 #include "../../include/srec_hg.h"
-#include <cstdlib>
 
 namespace {
 
@@ -517,185 +516,6 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(G16Args g) {
         }
 }
 
-// -------------------------------------------------------------------------------------------------- tn16, register staged
-// The same product with both operand tiles fetched by PLAIN loads into registers and written to LDS one step later
-// (round 6).  The LDS-DMA path above sustains ~one 1-KiB instruction per ~115 cycles and CU whatever issues it: 16 KB of
-// operands per 32-row step = 1 840 cycles next to 256 cycles of MFMA per SIMD.  Plain loads stream several times faster but
-// need registers and latency hiding; what makes that work was found on the edge-GEMM experiment of this round
-// (profiles/r06_notes.md §1): every load visible to the compiler (its vmcnt bookkeeping then waits for exactly the oldest
-// set), a branch-free loop body, three named register sets rotating with the step (two steps = ~2 us of loads in flight).
-// Tile 128 x 128, 32 reduction rows per step, two LDS stages of 16 KB; 64 accumulator registers: 2 - 3 workgroups per CU.
-template <int WV>
-__global__ __launch_bounds__(256, WV) void gemm16_tn_rs_kernel(G16Args g) {
-    constexpr int T = 128, BR = 32;
-    constexpr int STG = 2 * BR * T;                      // bf16 elements per stage (A tile + B tile)
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int bid = xcd_tile(g);
-    if (bid >= g.start[g.np]) return;
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < G16_MAXP; ++i)
-        if (i < g.np && bid >= g.start[i]) p = i;
-    const int N1 = g.M[p], N2 = g.N[p];
-    const int tn = (N2 + T - 1) / T, ntile = ((N1 + T - 1) / T) * tn;
-    const int split = (bid - g.start[p]) / ntile, tile = (bid - g.start[p]) % ntile;
-    const int i0 = (tile / tn) * T, j0 = (tile % tn) * T;
-    const int Klive = g.dyn[p] == nullptr ? g.K[p] : max(0, min(g.K[p], *g.dyn[p] - g.koff[p]));
-    const int chunk = ((Klive + g.nsplit[p] - 1) / g.nsplit[p] + 63) / 64 * 64;
-    const int kbeg = split * chunk, klen = max(0, min(chunk, g.K[p] - kbeg));
-    const int Kr = g.dyn[p] == nullptr ? klen : max(0, min(klen, *g.dyn[p] - g.koff[p] - kbeg));
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    float* __restrict__ C = static_cast<float*>(g.C[p]) + (size_t)split * N1 * g.ldcp[p];
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nst = (Kr + BR - 1) / BR;
-    const int total = nst * g.nseg[p];
-    // thread roles: rows tr0 and tr0 + 16 of the step, 16-byte piece pc of the 256-byte tile row, of both operands
-    const int tr0 = tid >> 4, pc = tid & 15;
-    const int acol = min(i0 + pc * 8, N1 - 8), bcol = min(j0 + pc * 8, N2 - 8);
-    const unsigned so0 = (unsigned)(tr0 * T + ((pc ^ (4 * (tr0 & 3))) << 3));             // LDS element offset of (row tr0, piece pc)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(1))) unsigned short* gup;
-    struct Set { u32x4 a0, a1, b0, b1; int live; };        // live: reduction rows of the step that exist (rows >= live are zero)
-    Set sa{}, sb{}, sc{};
-    auto load_set = [&](int it, Set& o) {                  // step `it` (clamped by the caller): 4 loads, 16 registers
-        const int sg = it / nst, r0 = (it - sg * nst) * BR;
-        o.live = Kr - r0;
-        const size_t ra = (size_t)(kbeg + min(r0 + tr0, Kr - 1)), rb = (size_t)(kbeg + min(r0 + tr0 + 16, Kr - 1));
-        gup A = (gup)g.A[p][sg]; gup B = (gup)g.B[p][sg];
-        o.a0 = *(const __attribute__((address_space(1))) u32x4*)(A + ra * g.ldap[p] + acol);
-        o.a1 = *(const __attribute__((address_space(1))) u32x4*)(A + rb * g.ldap[p] + acol);
-        o.b0 = *(const __attribute__((address_space(1))) u32x4*)(B + ra * g.ldbp[p] + bcol);
-        o.b1 = *(const __attribute__((address_space(1))) u32x4*)(B + rb * g.ldbp[p] + bcol);
-    };
-    auto store_set = [&](const Set& c, int st) {
-        unsigned short* base = smem + st * STG;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(base + so0) = tr0 < c.live ? c.a0 : z;                   // (the A side carries the row mask)
-        *reinterpret_cast<u32x4*>(base + so0 + 16 * T) = tr0 + 16 < c.live ? c.a1 : z;     // (row + 16: same r & 3, same slot)
-        *reinterpret_cast<u32x4*>(base + BR * T + so0) = c.b0;
-        *reinterpret_cast<u32x4*>(base + BR * T + so0 + 16 * T) = c.b1;
-    };
-    const int ti = lane & 15, trr = ti >> 2;
-    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (ti & 3);
-    auto tr_off = [&](int col, int row) {
-        return (unsigned)(row * 256 + ((((col >> 3) ^ (4 * (row & 3))) << 4) | ((col & 7) << 1)));
-    };
-    auto compute = [&](int st) {
-        const unsigned short* abase = smem + st * STG;
-        const unsigned short* bbase = abase + BR * T;
-#pragma unroll
-        for (int ks = 0; ks < BR / 16; ++ks) {
-            const int kb = ks * 16 + 8 * half;
-            uint2 ra[2][2], rb[2][2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    ra[f][e] = lds_tr16(abase, tr_off(wm * 64 + f * 32 + tcol, kb + 4 * e + trr));
-                    rb[f][e] = lds_tr16(bbase, tr_off(wn * 64 + f * 32 + tcol, kb + 4 * e + trr));
-                }
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                a[f] = __builtin_bit_cast(bf16x8, make_uint4(ra[f][0].x, ra[f][0].y, ra[f][1].x, ra[f][1].y));
-                b[f] = __builtin_bit_cast(bf16x8, make_uint4(rb[f][0].x, rb[f][0].y, rb[f][1].x, rb[f][1].y));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    if (total > 0) {
-        // prologue: step 0 in LDS, steps 1 and 2 in flight
-        load_set(0, sa);
-        load_set(min(1, total - 1), sb);
-        load_set(min(2, total - 1), sc);
-        store_set(sa, 0);
-#define G16RS_STEP(IT, DN, DF)                                                                            \
-        {                                                                                                 \
-            __syncthreads();                               /* stage IT visible; stage IT + 1 free */      \
-            load_set(min((IT) + 3, total - 1), DF);                                                       \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
-            compute((IT) & 1);                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
-            store_set(DN, ((IT) + 1) & 1);                 /* step IT + 1: issued two steps ago */         \
-        }
-        int it = 0;
-        for (; it + 3 < total; it += 3) {
-            G16RS_STEP(it, sb, sa)
-            G16RS_STEP(it + 1, sc, sb)
-            G16RS_STEP(it + 2, sa, sc)
-        }
-#undef G16RS_STEP
-        __syncthreads();
-        compute(it & 1);
-        if (it + 1 < total) {
-            store_set(sb, (it + 1) & 1);
-            __syncthreads();
-            compute((it + 1) & 1);
-            if (it + 2 < total) {
-                store_set(sc, (it + 2) & 1);
-                __syncthreads();
-                compute((it + 2) & 1);
-            }
-        }
-    }
-    constexpr int PS = 36;
-    __syncthreads();                                                   // every wave is done with the stages
-    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PS);
-    const bool wide = (N2 & 3) == 0 && (g.ldcp[p] & 3) == 0 && ((uintptr_t)C & 15) == 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (wide) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PS + l31] = acc[i][j][r];
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int idx = q4 * 64 + lane, rl = idx >> 3, c4 = (idx & 7) * 4;
-                    const int row = i0 + wm * 64 + i * 32 + rl, col = j0 + wn * 64 + j * 32 + c4;
-                    if (row < N1 && col < N2) {
-                        float4* q = reinterpret_cast<float4*>(C + (size_t)row * g.ldcp[p] + col);
-                        float4 v = *reinterpret_cast<const float4*>(patch + rl * PS + c4);
-                        if (g.beta != 0.f) {
-                            const float4 o = *q;
-                            v.x += g.beta * o.x; v.y += g.beta * o.y; v.z += g.beta * o.z; v.w += g.beta * o.w;
-                        }
-                        *q = v;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                const int col = j0 + wn * 64 + j * 32 + l31;
-                if (col < N2) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (row < N1) {
-                            float* q = C + (size_t)row * g.ldcp[p] + col;
-                            *q = g.beta != 0.f ? acc[i][j][r] + g.beta * *q : acc[i][j][r];
-                        }
-                    }
-                }
-            }
-        }
-}
-
 // -------------------------------------------------------------------------------------------------- operand copies
 // fp32 rows -> bf16 rows (zero past the live count): the activations a GEMM reads that no producer wrote as bf16
 __global__ void rows_bf16_kernel(const float* __restrict__ src, int ld, int n, const int* __restrict__ dyn, int d,
@@ -915,14 +735,6 @@ extern "C" int srec_gemm16_tn(const void* desc_, void* stream) {
     g.per_xcd = cdiv(blocks, 8); blocks = 8 * g.per_xcd;
     hipStream_t st = (hipStream_t)stream;
     static std::atomic<unsigned long long> om;
-    static const int rs_mode = [] { const char* e = getenv("SREC_G16_TN"); return e == nullptr ? 1 : (e[0] == 'd' ? 0 : (e[0] == '3' ? 3 : 1)); }();
-    if (rs_mode) {                   // register-staged operands (default); SREC_G16_TN=dma: the LDS-DMA ring below
-        const size_t lds_rs = (size_t)2 * 2 * 32 * 128 * 2;
-        if (rs_mode == 3) hipLaunchKernelGGL((gemm16_tn_rs_kernel<3>), dim3(blocks), dim3(256), lds_rs, st, g);
-        else hipLaunchKernelGGL((gemm16_tn_rs_kernel<2>), dim3(blocks), dim3(256), lds_rs, st, g);
-        SREC_LAUNCH_CHECK();
-        return 0;
-    }
     // 2 stages of 64 reduction rows (34 us at the bench shapes vs 37-38 for the 32-row rings)
     const size_t lds = (size_t)2 * 2 * 64 * 128 * 2;
     if (int rc = optin(gemm16_tn_kernel<64, 2>, (int)lds, om)) return rc;
