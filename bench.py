@@ -694,8 +694,8 @@ def run_job(env, args, precision, strong, Bg, B, n_batches, warm, steps, repeats
         coll['bucket_copy_tasks'] = dict(getattr(shard, 'copy_tasks_last', {}))
     regions, loss = run_timed(job['step'], dev_batches, warm, steps, max(repeats, 1), dist if world > 1 or args.shard else None, dev)
     final_loss = loss.item()
-    if coll is not None and with_timing and world > 1:
-        coll['timed'] = time_collectives(env, job, dev_batches)
+    if coll is not None and with_timing and (world > 1 or args.shard) and not args.step_only:
+        coll['timed'] = time_collectives(env, job, dev_batches)   # (eager steps next to a captured graph: also on the 1-rank rehearsal)
     dt = sorted(regions)[len(regions) // 2]              # median region
     ms = [r / steps * 1e3 for r in regions]
     nodes = job['gstep'].node_counts() if job['graphed'] and hasattr(job['gstep'], 'node_counts') else None

@@ -117,6 +117,13 @@ int srec_scatter_add_sorted_drop(const float* g, int ld_g, const int* items, con
 int srec_scatter_add_sorted_ex(const float* g, int ld_g, const int* items, const int* ptr, const int* pos, float* dst,
                                int ld_dst, int u_cap, const int* dyn, int d, int accumulate, float p, int seed,
                                const int* counter, int salt, const float* projW, int ld_w, float* radial, void* stream);
+/* row-sharded lookup backward (the nn.Embedding gradient of srgnn.py:133 / msgifsr.py:247 when the table is sharded over the
+ * ranks): dst[rel[q], :] += rows[q, :] for every request q < w ucap with rel[q] >= 0, the requests of ALL w <= 16 ranks in one launch
+ * and - an item may be requested by several ranks - added per item in rank order (the bits of w rank-by-rank
+ * srec_scatter_add_sorted calls).  ids [w ucap] = the requests' global item ids, ascending inside each rank's list of ucap (-1
+ * padding behind them); rows [w ucap, d] dense.  radial (nullable) as in srec_scatter_add_sorted_ex. */
+int srec_add_rows_ranks(const float* rows, int d, const int* rel, const int* ids, int w, int ucap, float* dst, int ld_dst,
+                        const float* projW, int ld_w, float* radial, void* stream);
 /* Embedding(max_norm) in-place renorm, idx distinct or NULL (= all rows): lessr.py:126 msgifsr.py:162 */
 int srec_renorm_rows(float* W, int ld, const int* idx, int n_cap, const int* dyn, int d, float max_norm,
                      void* stream);

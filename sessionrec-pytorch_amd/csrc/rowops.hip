@@ -562,6 +562,89 @@ extern "C" int srec_scatter_add_sorted_drop(const float* g, int ld_g, const int*
     return 0;
 }
 
+// ---- row-sharded lookup backward: the per-item gradient rows of ALL ranks into this shard's dense gradient in ONE launch.
+// rows [w * ucap, d] = the all-gathered rows, rel [w * ucap] = local row of every request (-1: another shard's / padding), ids
+// [w * ucap] = the requests' global item ids (ascending inside each rank's list, -1 padding behind them).  The same item may sit
+// in several ranks' lists (Zipf-popular items in all of them): the LOWEST rank holding it owns the sum and adds the ranks' rows
+// to dst[item] in rank order - the order, and so the bits, of w launches of srec_scatter_add_sorted rank by rank (what this
+// replaces: w x ~4.6 us of launch floor in the rank step, profiles/r06_rank8_weak_breakdown.txt).  One wavefront per request:
+// lane r < w binary-searches rank r's list for the item.
+namespace {
+__global__ void add_rows_ranks_kernel(const float* __restrict__ rows, int d, const int* __restrict__ rel,
+                                      const int* __restrict__ ids, int w, int ucap, float* __restrict__ dst, int ld_dst,
+                                      const float* __restrict__ projW, int ld_w, float* __restrict__ radial) {
+    const int q = blockIdx.x * WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= w * ucap) return;
+    const int item = rel[q];
+    if (item < 0) return;
+    const int r_me = q / ucap, gid = ids[q];
+    // slot of gid in rank `lane`'s list (ascending, -1 = +infinity), or -1
+    int found = -1;
+    if (lane < w) {
+        if (lane == r_me) found = q;
+        else {
+            const int* L = ids + (size_t)lane * ucap;
+            int lo = 0, hi = ucap;
+            while (lo < hi) {                               // first position whose id is >= gid (padding counts as larger)
+                const int mid = (lo + hi) >> 1;
+                const int v = L[mid];
+                if (v >= 0 && v < gid) lo = mid + 1; else hi = mid;
+            }
+            if (lo < ucap && L[lo] == gid) found = lane * ucap + lo;
+        }
+    }
+    const unsigned long long have = __ballot(found >= 0);
+    if ((have & ((1ull << r_me) - 1ull)) != 0ull) return;   // a lower rank holds the item too: it owns the sum
+    float rd = 0.f;
+    const bool proj = radial != nullptr;
+    if (proj && lane == 0) rd = radial[item];
+    float dots[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dots[k] = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        float4 s = *reinterpret_cast<const float4*>(dst + (size_t)item * ld_dst + c);
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (proj) wv = *reinterpret_cast<const float4*>(projW + (size_t)item * ld_w + c);
+        float4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                      // the ranks' rows in flight together, added in rank order
+            const int slot = __shfl(found, k, 64);
+            v[k] = (k < w && slot >= 0) ? *reinterpret_cast<const float4*>(rows + (size_t)slot * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < w && ((have >> k) & 1ull)) {
+                s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w;
+                dots[k] += wv.x * v[k].x + wv.y * v[k].y + wv.z * v[k].z + wv.w * v[k].w;
+            }
+        }
+        *reinterpret_cast<float4*>(dst + (size_t)item * ld_dst + c) = s;
+    }
+    if (proj) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < w && ((have >> k) & 1ull)) {            // (wave-uniform)
+                const float t = wave_sum(dots[k]);
+                rd += t;                                    // rank order, one wave sum per rank: as the w launches did
+            }
+        }
+        if (lane == 0) radial[item] = rd;
+    }
+}
+}  // namespace
+
+extern "C" int srec_add_rows_ranks(const float* rows, int d, const int* rel, const int* ids, int w, int ucap, float* dst,
+                                   int ld_dst, const float* projW, int ld_w, float* radial, void* stream) {
+    if (w <= 0 || ucap <= 0) return 0;
+    if (w > 16 || d <= 0 || (d & 3) || (ld_dst & 3) || rows == nullptr || rel == nullptr || ids == nullptr || dst == nullptr)
+        return SREC_BAD_ARG;
+    if (radial != nullptr && (projW == nullptr || (ld_w & 3))) return SREC_BAD_ARG;
+    hipLaunchKernelGGL(add_rows_ranks_kernel, dim3(cdiv(w * ucap, WPB)), dim3(256), 0, (hipStream_t)stream, rows, d, rel, ids, w,
+                       ucap, dst, ld_dst, projW, ld_w, radial);
+    SREC_LAUNCH_CHECK();
+    return 0;
+}
+
 // the general form: dropout mask (p = 0: none) and the radial side sum (radial = NULL: none) of the deferred projection
 extern "C" int srec_scatter_add_sorted_ex(const float* g, int ld_g, const int* items, const int* ptr, const int* pos,
                                           float* dst, int ld_dst, int u_cap, const int* dyn, int d, int accumulate,

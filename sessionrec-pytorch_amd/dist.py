@@ -335,6 +335,18 @@ class HipLocal:
             lib.srec_scatter_add_sorted(ptr(rows), d, ptr(items_local), ptr(ar), ptr(ar), ptr(dst), dst.stride(0), U, None,
                                         d, 1, stream())
 
+    def add_rows_all(self, rows_all, rel, ids, w, ucap, dst, proj=None):
+        """add_rows for the lists of all w ranks in ONE launch, per item in rank order (csrc/rowops.hip add_rows_ranks_kernel);
+        False when the shapes are outside the kernel's contract (the caller then loops over the ranks)"""
+        from ._lib import lib, ptr, stream
+        if w > 16 or ids is None or ids.dtype != torch.int32 or rel.dtype != torch.int32 or not rows_all.is_contiguous():
+            return False
+        d = rows_all.shape[1]
+        lib.srec_add_rows_ranks(ptr(rows_all), d, ptr(rel), ptr(ids), w, ucap, ptr(dst), dst.stride(0),
+                                ptr(proj[0]) if proj is not None else None, proj[0].stride(0) if proj is not None else 0,
+                                ptr(proj[1]) if proj is not None else None, stream())
+        return True
+
     def _tb(self, table, refresh):
         """bf16 operand copies of this rank's shard when set_precision('bf16') is on (refreshed once per step)"""
         ops = self.ops
@@ -503,7 +515,11 @@ class ShardedLookup(torch.autograd.Function):
         proj = (ctx.shard, tg.radial) if (tg is not None and tg.pending is not None) else None
         if proj is not None:
             tg.radial_dirty = True
-        for r in range(_world(ctx.group)):                   # rank by rank: distinct items within each call
+        w = _world(ctx.group)
+        if w > 1 and hasattr(ctx.local, 'add_rows_all') and \
+                ctx.local.add_rows_all(rows_all, rel, ctx.items_all, w, ucap, ctx.dE, proj):
+            return (None,) * 10
+        for r in range(w):                                   # rank by rank: distinct items within each call
             if proj is not None:
                 ctx.local.add_rows(rows_all[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], ctx.dE, proj)
             else:
