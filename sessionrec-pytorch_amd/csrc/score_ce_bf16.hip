@@ -620,6 +620,11 @@ inline int de_split_for(int B, int V) {
     const int cap = B / 512;
     if (s > cap) s = cap;
     if (s > 16) s = 16;
+    // ... and the launch stays ONE round of the chip: per XCD its share of the item-tile pieces + one range of every session tile
+    // within the 64 resident workgroups (8 pieces x 34 tiles + 8 x 32 session tiles = 528 on 512 slots took two workgroup lives:
+    // 83.6 us at 4 096 x 4 332)
+    const int T = cdiv(B, OWN);
+    while (s > 1 && cdiv(tiles * s, XCDS) + T > XCD_SLOTS) --s;
     return s < 1 ? 1 : s;
 }
 

@@ -182,9 +182,9 @@ class GraphedTrainStep:
         left a work item with the process group's WATCHDOG THREAD, which polls their completion events every ~100 ms until it
         has retired them.  Under the default 'global' mode an event query from that thread while this thread captures is an
         illegal call: it invalidated the capture or aborted the process in 1 run of ~10 of `bench.py --shard`
-        (profiles/r05_notes.md; round 5 slept 0.3 s in front of the capture instead).  'thread_local' confines the legality
-        check to the capturing thread - what the watchdog thread does no longer concerns the capture.  SREC_CAPTURE_MODE
-        overrides (global | thread_local | relaxed)."""
+        (profiles/r05_notes.md).  'thread_local' confines the legality check to the capturing thread - what the watchdog thread
+        does no longer invalidates the capture (the first of two failure modes; the second one: _quiesce_collectives).
+        SREC_CAPTURE_MODE overrides (global | thread_local | relaxed)."""
         m = os.environ.get('SREC_CAPTURE_MODE')
         if m in ('global', 'thread_local', 'relaxed'):
             return m
@@ -192,12 +192,17 @@ class GraphedTrainStep:
 
     @classmethod
     def _quiesce_collectives(cls):
-        """all device work of the warm-up is complete before the capture begins (one synchronise when an RCCL group exists);
-        SREC_CAPTURE_SLEEP=<seconds> additionally waits that long for the watchdog to retire its list (the round-5 workaround,
-        0.3 s: kept as a switch, off by default - see _capture_mode and tools/shard_loop.sh)"""
+        """The second failure mode of the watchdog race, which the capture mode does NOT remove: every eager collective of the
+        warm-up left a work item whose completion EVENT the watchdog queries until it has retired the item - and HIP refuses
+        the query of an event whose stream is capturing by now ("operation not permitted on an event last recorded in a capturing
+        stream", hipErrorCapturedEvent: the exception ends the watchdog thread and aborts the process; 4 runs of 34 of
+        `SREC_BUCKET_SIDE_STREAM=1 bench.py --shard` with thread_local capture and no wait, tools/shard_loop.sh).  There is no
+        handle on the watchdog's list; it wakes on a 100 ms timer (and on every new work item, which it cannot retire yet).  So:
+        synchronise - every work item is complete - and wait three timer periods: the list is empty when the capture begins.
+        SREC_CAPTURE_SLEEP=<seconds> overrides (0: no wait)."""
         if cls._nccl_group():
             torch.cuda.synchronize()
-            t = float(os.environ.get('SREC_CAPTURE_SLEEP', '0') or 0)
+            t = float(os.environ.get('SREC_CAPTURE_SLEEP', '0.3') or 0)
             if t > 0:
                 import time
                 time.sleep(t)

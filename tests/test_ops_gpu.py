@@ -811,7 +811,7 @@ def _ce_reference_chunked(sr, E, cs, labels, chunk=512):
 @pytest.mark.parametrize('B,V,d,cosine,tag', [(512, 37484, 256, True, 'C3: the launch BENCH reports'),
                                               (512, 43097, 96, False, 'C2: SRGNN / Diginetica'),
                                               (512, 43097, 96, True, 'C2 shape, cosine (NISER)'),
-                                              (4096, 4332, 256, True, 'C3 / C4 as rank 7 of 8 scores it (weak scaling): split 8'),
+                                              (4096, 4332, 256, True, 'C3 / C4 as rank 7 of 8 scores it (weak scaling): split 7'),
                                               (2048, 9260, 256, True, 'C3 as a rank of 4 scores it: split 4'),
                                               (1000, 18732, 256, True, 'a rank of 2, ragged session count (1000 < 1024: one piece)')])
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
@@ -1491,3 +1491,67 @@ def test_deferred_sums_of_an_aborted_backward_are_forgotten(dev):
     Fine.apply(x).sum().backward()
     torch.cuda.synchronize()
     assert len(ops._DEFERRED) == 0 and float(out.sum()) == 32.0
+
+
+@pytest.mark.parametrize('w,ucap,nloc,proj', [(2, 256, 700, False), (8, 512, 4332, True), (5, 300, 97, True)])
+def test_add_rows_of_all_ranks_in_one_launch_equals_the_rank_by_rank_loop(dev, w, ucap, nloc, proj):
+    """round 6, row-sharded lookup backward (the nn.Embedding gradient of srgnn.py:133 / msgifsr.py:247 with the table sharded over
+    the ranks): srec_add_rows_ranks adds the per-item gradient rows of ALL ranks' request lists - the same item sits in several
+    lists - per item in rank order.  BIT-identical to w rank-by-rank srec_scatter_add_sorted(_ex) launches, dense gradient and
+    the radial side sums of the deferred row-normalisation projection alike."""
+    D = importlib.import_module('sessionrec-pytorch_amd.dist')
+    local = D.HipLocal()
+    g = torch.Generator().manual_seed(w * 1000 + ucap)
+    d, lo, V = 256, 3 * nloc, 8 * nloc
+    ids = torch.full((w, ucap), -1, dtype=torch.int32)
+    for r in range(w):
+        # Zipf-ish: hot items land in every rank's list; ascending, -1 padding behind (collate: np.unique + caps)
+        n = int(torch.randint(ucap // 2, ucap + 1, (1,), generator=g))
+        hot = torch.arange(lo, lo + min(40, nloc))
+        rest = torch.randperm(V, generator=g)[:n]
+        u = torch.unique(torch.cat([hot, rest]))[:n]
+        ids[r, :u.numel()] = u.to(torch.int32)
+    ids = ids.reshape(-1).to(dev)
+    rows = torch.randn(w * ucap, d, generator=g).to(dev)
+    rel = local.localize(ids, lo, nloc)
+    assert int((rel >= 0).sum()) > 40 * w // 2
+    base = torch.randn(nloc, d, generator=g).to(dev)
+    W = torch.randn(nloc, d, generator=g).to(dev) if proj else None
+    rad0 = torch.randn(nloc, generator=g).to(dev) if proj else None
+    # reference: the loop the launch replaces
+    dst_a, rad_a = base.clone(), (rad0.clone() if proj else None)
+    for r in range(w):
+        local.add_rows(rows[r * ucap:(r + 1) * ucap], rel[r * ucap:(r + 1) * ucap], dst_a, (W, rad_a) if proj else None)
+    dst_b, rad_b = base.clone(), (rad0.clone() if proj else None)
+    assert local.add_rows_all(rows, rel, ids, w, ucap, dst_b, (W, rad_b) if proj else None)
+    torch.cuda.synchronize()
+    assert torch.equal(dst_a, dst_b), (dst_a - dst_b).abs().max().item()
+    if proj:
+        assert torch.equal(rad_a, rad_b), (rad_a - rad_b).abs().max().item()
+    touched = torch.unique(rel[rel >= 0]).long()
+    untouched = torch.ones(nloc, dtype=torch.bool, device=dev)
+    untouched[touched] = False
+    assert torch.equal(dst_b[untouched], base[untouched])
+
+
+@pytest.mark.parametrize('w,B', [(1, 37), (2, 512), (8, 4096), (11, 1500)])
+def test_merge_stats_of_the_shards(dev, w, B):
+    """global (lse, label logit, mean loss, per-session weights) from the shards' partial statistics (dist._merge_stats ->
+    srec_merge_stats32; train.py:99 nll_loss(mean) over the row-sharded catalog): against torch.logsumexp, padding sessions
+    (label < 0) left out of the mean.  8 x 4 096 is what a rank of 8 merges per weak-scaling step (1 024-thread form)."""
+    D = importlib.import_module('sessionrec-pytorch_amd.dist')
+    local = D.HipLocal()
+    g = torch.Generator().manual_seed(w * 31 + B)
+    st = torch.randn(w, 2, B, generator=g) * 3.0
+    lab = torch.randint(0, 1000, (B,), generator=g).to(torch.int32)
+    lab[torch.rand(B, generator=g) < 0.1] = -1
+    lse, lb, loss, gw = local.merge_stats(st.to(dev), lab.to(dev))
+    ref_lse = torch.logsumexp(st[:, 0].double(), dim=0)
+    ref_lab = st[:, 1].double().sum(0)
+    live = (lab >= 0)
+    n = int(live.sum())
+    close(lse, ref_lse.float(), rtol=1e-6, atol=1e-5, what='lse')
+    close(lb, ref_lab.float(), rtol=1e-6, atol=1e-5, what='label logit')
+    ref_loss = float(((ref_lse - ref_lab) * live).sum() / max(n, 1))
+    assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+    assert torch.equal(gw.cpu() > 0, live) and abs(float(gw.sum()) - (1.0 if n else 0.0)) < 1e-5
