@@ -851,7 +851,7 @@ def main():
     ap.add_argument('--e2e-probe', action='store_true', help='end-to-end run: also time the loader alone and the step fed from pre-collated batches')
     ap.add_argument('--dropout', type=float, default=0.1,
                     help='MSGIFSR feature / attention dropout (0.1 = --feat-drop default of the reference launcher, main_msgifsr.py:42)')
-    ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16', 'fp32x3'],
+    ap.add_argument('--precision', default=os.environ.get('SREC_PRECISION', 'bf16'), choices=['fp32', 'bf16'],
                     help="MFMA operand type of the forward / backward-data GEMMs ('bf16' = BASELINE config C3)")
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the captured whole-step hipGraph')
     ap.add_argument('--shard', action='store_true', help='debug: row-sharded path + RCCL calls on a 1-rank communicator (set SREC_FORCE_COLLECTIVES=1)')
@@ -960,7 +960,7 @@ def main():
         ops.set_precision(args.precision)
 
     fp32 = None
-    if not args.no_fp32 and args.precision == 'bf16' and world == 1 and not args.shard:      # (side run on one GPU only)
+    if not args.no_fp32 and args.precision != 'fp32' and world == 1 and not args.shard:      # (side run on one GPU only)
         # the reference's own arithmetic (fp32 operands everywhere) on the same batches, same launch mode, same run
         j32 = make_job(env, args, 'fp32', batches, dev_batches, strong)
         if not args.no_graph:

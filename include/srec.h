@@ -26,8 +26,6 @@ extern "C" {
 
 #define SREC_BAD_ARG 1001
 
-/* set_precision('fp32x3'): every fp32 product as a 3-term hi / lo bf16 split (msgifsr.py:276-321 arithmetic to ~2^-17) */
-int srec_set_split3(int on);
 /* ---- dense linear algebra on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ----------------
  * C[m,n] = alpha * sum_k A(m,k) B(n,k) + beta*C[m,n] + bias[n];  A(m,k)=A[m*a_rs+k*a_cs], same for B.
  * dyn_mode: 0 none, 1 clamps M, 2 clamps K.  ws (nullable): ws_floats of scratch for split-K slabs.

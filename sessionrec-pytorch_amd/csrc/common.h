@@ -17,21 +17,6 @@ __device__ __forceinline__ unsigned srec_pack_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ unsigned short srec_f2bf(float a) { return (unsigned short)(srec_pack_bf16(a, 0.f) & 0xffffu); }
 
-// 8 fp32 -> bf16 hi (round to nearest even) and bf16 lo = bf16(x - hi): x = hi + lo to ~2^-17 relative.
-typedef __bf16 srec_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void srec_split8(const float (&v)[8], srec_bf16x8& hi, srec_bf16x8& lo) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = srec_pack_bf16(v[2 * i], v[2 * i + 1]);
-        const float a = __builtin_bit_cast(float, h[i] << 16), b = __builtin_bit_cast(float, h[i] & 0xffff0000u);
-        l[i] = srec_pack_bf16(v[2 * i] - a, v[2 * i + 1] - b);
-    }
-    hi = __builtin_bit_cast(srec_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
-    lo = __builtin_bit_cast(srec_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
-}
-extern int srec_split3_on;     // process-wide switch of the 3-term split products in the fp32 entry points (srec_set_split3)
-
 #define SREC_LAUNCH_CHECK()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \

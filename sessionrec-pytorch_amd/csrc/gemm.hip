@@ -351,7 +351,7 @@ __device__ __forceinline__ void gemm_f32_tile(
         }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool S3 = false>
+template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const float* __restrict__ A, int a_rs, int a_cs, const float* __restrict__ B, int b_rs, int b_cs,
     float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     constexpr int BK = TileK<BM>::value;
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
-    gemm_f32_tile<BM, BN, A_KC, B_KC, S3>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, part,
-                                          blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, As, Bs);
+    gemm_f32_tile<BM, BN, A_KC, B_KC>(A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, part,
+                                      blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, As, Bs);
 }
 
 // ---- grouped launch: up to SREC_GEMM32_MAXP independent products (any mix of the three operand layouts) in ONE grid.
@@ -468,15 +468,9 @@ int launch(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_c
            float* ws, int nsplit, hipStream_t st) {
     dim3 grid(cdiv(N, BN), cdiv(M, BM), nsplit);
     const bool akc = (a_cs == 1), bkc = (b_cs == 1);
-#define SREC_GEMM_GO(AK, BK_)                                                                                      \
-    do {                                                                                                           \
-        if (srec_split3_on)                                                                                        \
-            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_, true>), grid, dim3(256), 0, st, A, a_rs, a_cs, B, b_rs, \
-                               b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, ws);                        \
-        else                                                                                                       \
-            hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_>), grid, dim3(256), 0, st, A, a_rs, a_cs, B, b_rs, \
-                               b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, ws);                        \
-    } while (0)
+#define SREC_GEMM_GO(AK, BK_)                                                                             \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AK, BK_>), grid, dim3(256), 0, st, A, a_rs, a_cs, B, b_rs, \
+                       b_cs, C, ldc, bias, M, N, K, dyn, dyn_mode, alpha, beta, ws)
     if (akc && bkc) SREC_GEMM_GO(true, true);
     else if (akc && !bkc) SREC_GEMM_GO(true, false);
     else if (!akc && bkc) SREC_GEMM_GO(false, true);
@@ -490,9 +484,6 @@ int launch(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_c
 }
 
 }  // namespace
-
-int srec_split3_on = 0;
-extern "C" int srec_set_split3(int on) { srec_split3_on = on ? 1 : 0; return 0; }
 
 extern "C" int srec_gemm_f32(const float* A, int a_rs, int a_cs, const float* B, int b_rs, int b_cs, float* C,
                              int ldc, const float* bias, int M, int N, int K, const int* dyn, int dyn_mode,
@@ -651,7 +642,7 @@ static int gemm_f32_group_go(const void* desc, float* ws, long ws_floats, long* 
         k.tile_end[p] = end;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (gin->split3 || srec_split3_on) hipLaunchKernelGGL(gemm_f32_group_kernel<true>, dim3(end), dim3(256), 0, st, k);
+    if (gin->split3) hipLaunchKernelGGL(gemm_f32_group_kernel<true>, dim3(end), dim3(256), 0, st, k);
     else hipLaunchKernelGGL(gemm_f32_group_kernel<false>, dim3(end), dim3(256), 0, st, k);
     if (any_split)
         hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(max_red, k.g.np), dim3(64), 0, st, k);

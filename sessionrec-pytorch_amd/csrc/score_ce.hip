@@ -108,8 +108,7 @@ __device__ __forceinline__ void lstore_tile(float* __restrict__ tile, const floa
     }
 }
 
-// S3 (set_precision('fp32x3')): both products as the 3-term hi / lo bf16 split - the SAME operand registers as the fp32 path
-template <int NT, int MODE, bool S3 = false>
+template <int NT, int MODE>
 __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
     constexpr int DP = NT * 32, LD = DP + 1, PLD = 65;
     constexpr int NCB = (NT + 1) / 2;                      // output col blocks per wave
@@ -214,16 +213,8 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
                     for (int u = 0; u < UB; ++u) { a1[u] = xn[2 * u]; b1[u] = yn[2 * u]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (S3) {
-                    srec_bf16x8 ah, al, bh, bl;
-                    srec_split8(a0, ah, al); srec_split8(b0, bh, bl);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, s, 0, 0, 0);
-                } else {
 #pragma unroll
-                    for (int u = 0; u < UB; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], s, 0, 0, 0);
-                }
+                for (int u = 0; u < UB; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], s, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (blk + 2 < NBLK) {
                     const float* xn = xa + 2 * UB * (blk + 2);
@@ -232,16 +223,8 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
                     for (int u = 0; u < UB; ++u) { a0[u] = xn[2 * u]; b0[u] = yn[2 * u]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (S3) {
-                    srec_bf16x8 ah, al, bh, bl;
-                    srec_split8(a1, ah, al); srec_split8(b1, bh, bl);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, s, 0, 0, 0);
-                } else {
 #pragma unroll
-                    for (int u = 0; u < UB; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], s, 0, 0, 0);
-                }
+                for (int u = 0; u < UB; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], s, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -311,31 +294,7 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
             __syncthreads();                                               // (B) P visible
             // ---- ACC += P Y : this wave owns row block si, col blocks sj, sj+2, ...  (operands of step
             // k2+1 are read while the MFMAs of step k2 run)
-            if constexpr (S3) {
-                const float* pa = Ps + (si * 32 + l31) * PLD + half;
-                const float* yb = Ys + half * LD + sj * 32 + l31;
-#pragma unroll
-                for (int blk = 0; blk < 4; ++blk) {
-                    float av[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) av[u] = pa[16 * blk + 2 * u];
-                    srec_bf16x8 ah, al;
-                    srec_split8(av, ah, al);
-#pragma unroll
-                    for (int c = 0; c < NCB; ++c) {
-                        if (sj + 2 * c < NT) {
-                            float bv[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) bv[u] = yb[(16 * blk + 2 * u) * LD + c * 64];
-                            srec_bf16x8 bh, bl;
-                            srec_split8(bv, bh, bl);
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[c], 0, 0, 0);
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[c], 0, 0, 0);
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[c], 0, 0, 0);
-                        }
-                    }
-                }
-            } else {
+            {
                 const float* pa = Ps + (si * 32 + l31) * PLD + half;
                 const float* yb = Ys + half * LD + sj * 32 + l31;
                 float av0, av1, bv0[NCB], bv1[NCB];
@@ -393,14 +352,9 @@ __global__ __launch_bounds__(256) void flash_ce_kernel(CEArgs a) {
 template <int NTV, int MODE>
 int launch_nt(const CEArgs& a, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * 64 * (NTV * 32 + 1) + 64 * 65) * sizeof(float);
-    static std::atomic<unsigned long long> optin{0}, optin3{0};   // > 64 KiB dynamic LDS needs the opt-in once per device
-    if (srec_split3_on) {
-        if (int rc = srec_lds_optin((const void*)flash_ce_kernel<NTV, MODE, true>, (int)lds, optin3)) return rc;
-        hipLaunchKernelGGL((flash_ce_kernel<NTV, MODE, true>), grid, dim3(256), lds, st, a);
-    } else {
-        if (int rc = srec_lds_optin((const void*)flash_ce_kernel<NTV, MODE>, (int)lds, optin)) return rc;
-        hipLaunchKernelGGL((flash_ce_kernel<NTV, MODE>), grid, dim3(256), lds, st, a);
-    }
+    static std::atomic<unsigned long long> optin{0};   // > 64 KiB dynamic LDS needs the opt-in once per device
+    if (int rc = srec_lds_optin((const void*)flash_ce_kernel<NTV, MODE>, (int)lds, optin)) return rc;
+    hipLaunchKernelGGL((flash_ce_kernel<NTV, MODE>), grid, dim3(256), lds, st, a);
     SREC_LAUNCH_CHECK();
     return 0;
 }

@@ -101,10 +101,8 @@ _WT_CACHE = {}
 
 
 def set_precision(mode):
-    assert mode in ('fp32', 'bf16', 'fp32x3')       # fp32x3: the fp32 path with 3-term hi / lo bf16 split products
-    PRECISION['matmul'] = 'fp32' if mode == 'fp32x3' else mode
-    if torch.cuda.is_available():
-        lib.srec_set_split3(1 if mode == 'fp32x3' else 0)
+    assert mode in ('fp32', 'bf16')
+    PRECISION['matmul'] = mode
     _WT_CACHE.clear()
     _HEAD_WF_CACHE.clear()
 
