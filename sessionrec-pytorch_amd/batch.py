@@ -66,7 +66,7 @@ class FlatBatch:
                 # capacity padding: offset arrays repeat their last value (empty segments), index arrays -1
                 if name.endswith('ptr') or name.startswith(('seg', 'eseg', 'cat_seg')):
                     buf[o + a.size:o + cap] = a[-1] if a.size else 0
-                elif name.startswith(('iid', 'gidx', 'uniq_items', 'cat_perm', 'last')):
+                elif name.startswith(('iid', 'gidx', 'uniq_items', 'uniq_inv', 'cat_perm', 'last')):
                     buf[o + a.size:o + cap] = -1
         m = dict(meta)
         m['counts'] = {k: int(v) for k, v in counts.items()}

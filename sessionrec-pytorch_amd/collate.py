@@ -119,13 +119,14 @@ def _csr(key, n):
 
 
 def _uniq_csr(gidx):
-    """distinct items and, per item, the positions where it is looked up."""
+    """distinct items, per item the positions where it is looked up, and per position the slot of its item (the inverse map:
+    what the row-sharded lookup gathers the exchanged rows through - dist.VocabParallel.lookup)."""
     gidx = np.asarray(gidx, dtype=np.int64)
     pos = np.argsort(gidx, kind='stable').astype(np.int32)
-    items, cnt = np.unique(gidx, return_counts=True)
+    items, inv, cnt = np.unique(gidx, return_inverse=True, return_counts=True)
     ptr = np.zeros(len(items) + 1, dtype=np.int32)
     np.cumsum(cnt, out=ptr[1:])
-    return items.astype(np.int32), ptr, pos
+    return items.astype(np.int32), ptr, pos, np.asarray(inv).reshape(-1).astype(np.int32)
 
 
 CHUNK = 16
@@ -174,9 +175,9 @@ def batch_homogeneous(graphs, caps=None):
         iid = _cat([g[1] for g in graphs])
         fields['iid'] = iid
         fields['last'] = np.array([g[2] + seg[i] for i, g in enumerate(graphs)], dtype=np.int64)
-        ui, up, upos = _uniq_csr(iid)
+        ui, up, upos, uinv = _uniq_csr(iid)
         cptr, chptr = _chunk_csr(up)
-        fields.update(uniq_items=ui, uniq_ptr=up, uniq_pos=upos, uniq_cptr=cptr, chunk_ptr=chptr)
+        fields.update(uniq_items=ui, uniq_ptr=up, uniq_pos=upos, uniq_inv=uinv, uniq_cptr=cptr, chunk_ptr=chptr)
         counts['U'] = len(ui)
         counts['C'] = len(chptr) - 1
     if kind == 'session':
@@ -189,7 +190,7 @@ def batch_homogeneous(graphs, caps=None):
         if N > Nc or E > Ec:
             raise CapacityExceeded('nodes %d / %d, edges %d / %d' % (N, Nc, E, Ec))
         fcaps = dict(seg=Bc + 1, eseg=Bc + 1, esrc=Ec, edst=Ec, in_ptr=Nc + 1, in_idx=Ec, out_ptr=Nc + 1, out_idx=Ec,
-                     iid=Nc, last=Bc, uniq_items=Uc, uniq_ptr=Uc + 1, uniq_pos=Nc, uniq_cptr=Uc + 1,
+                     iid=Nc, last=Bc, uniq_items=Uc, uniq_ptr=Uc + 1, uniq_pos=Nc, uniq_inv=Nc, uniq_cptr=Uc + 1,
                      chunk_ptr=Uc + Nc // CHUNK + 2, ew=Ec)
         fcaps = {k: v for k, v in fcaps.items() if k in fields}
     return FlatBatch.build(fields, counts, meta, fcaps)
@@ -227,10 +228,12 @@ def batch_ccs(graphs, caps=None):
         blocks.append(blk)
     gidx = np.concatenate(blocks)
     livepos = np.nonzero(gidx >= 0)[0]
-    ui, up, upos = _uniq_csr(gidx[livepos])
+    ui, up, upos, uinv_live = _uniq_csr(gidx[livepos])
     upos = livepos[upos].astype(np.int32)
+    uinv = np.full(len(gidx), -1, dtype=np.int32)          # (capacity padding inside the order blocks: no item)
+    uinv[livepos] = uinv_live
     cptr, chptr = _chunk_csr(up)
-    fields.update(gidx=gidx, uniq_items=ui, uniq_ptr=up, uniq_pos=upos, uniq_cptr=cptr, chunk_ptr=chptr)
+    fields.update(gidx=gidx, uniq_items=ui, uniq_ptr=up, uniq_pos=upos, uniq_inv=uinv, uniq_cptr=cptr, chunk_ptr=chptr)
     counts['G'] = len(gidx)
     counts['U'] = len(ui)
     counts['C'] = len(chptr) - 1
@@ -267,7 +270,7 @@ def batch_ccs(graphs, caps=None):
     fcaps = None
     if caps:
         N, E, U = caps['N'], caps['E'], caps['U']
-        fcaps = dict(uniq_items=U, uniq_ptr=U + 1, uniq_pos=len(gidx), uniq_cptr=U + 1,
+        fcaps = dict(uniq_items=U, uniq_ptr=U + 1, uniq_pos=len(gidx), uniq_inv=len(gidx), uniq_cptr=U + 1,
                      chunk_ptr=U + len(gidx) // CHUNK + 2, cat_perm=N * K, cat_seg=Bc + 1)
         for k in range(1, K + 1):
             fcaps.update({'seg%d' % k: Bc + 1, 'iid%d' % k: N * k, 'last%d' % k: Bc, 'lastcat%d' % k: Bc})
@@ -301,7 +304,7 @@ def _native():
 
 
 _HOMOG_FIELDS = ['seg', 'eseg', 'esrc', 'edst', 'in_ptr', 'in_idx', 'out_ptr', 'out_idx']
-_ITEM_FIELDS = ['iid', 'last', 'uniq_items', 'uniq_ptr', 'uniq_pos', 'uniq_cptr', 'chunk_ptr']
+_ITEM_FIELDS = ['iid', 'last', 'uniq_items', 'uniq_ptr', 'uniq_pos', 'uniq_inv', 'uniq_cptr', 'chunk_ptr']
 
 
 def _ccs_schema(K):
@@ -314,7 +317,7 @@ def _ccs_schema(K):
         if k > 1:
             shapes['iid%d' % k] = (k,)
         counts += ['N%d' % k, 'GK%d' % k]
-    names += ['gidx', 'uniq_items', 'uniq_ptr', 'uniq_pos', 'uniq_cptr', 'chunk_ptr']
+    names += ['gidx', 'uniq_items', 'uniq_ptr', 'uniq_pos', 'uniq_inv', 'uniq_cptr', 'chunk_ptr']
     counts += ['G', 'U', 'C']
     for _, n in rels:
         names += [n + sfx for sfx in ('_src', '_dst', '_in_ptr', '_in_idx', '_out_ptr', '_out_idx')]

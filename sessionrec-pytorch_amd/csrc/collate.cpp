@@ -80,17 +80,20 @@ void csr(const vec& key, long n, vec& ptr, vec& idx) {
 }
 
 // distinct items + positions (stable), chunked
-void uniq_csr(const vec& gidx, vec& items, vec& ptr, vec& pos, vec& cptr, vec& chunk_ptr) {
+// inv[p] = slot of position p's item in `items` (-1: a padded position) - the map the row-sharded lookup gathers through
+void uniq_csr(const vec& gidx, vec& items, vec& ptr, vec& pos, vec& inv, vec& cptr, vec& chunk_ptr) {
     std::vector<int64_t> live;
     for (size_t i = 0; i < gidx.size(); ++i)
         if (gidx[i] >= 0) live.push_back((int64_t)i);
     std::stable_sort(live.begin(), live.end(), [&](int64_t a, int64_t b) { return gidx[a] < gidx[b]; });
     items.clear(); ptr.assign(1, 0); pos = live;
+    inv.assign(gidx.size(), -1);
     for (size_t i = 0; i < live.size(); ++i) {
         if (i == 0 || gidx[live[i]] != gidx[live[i - 1]]) {
             if (i) ptr.push_back((int64_t)i);
             items.push_back(gidx[live[i]]);
         }
+        inv[live[i]] = (int64_t)items.size() - 1;
     }
     if (!live.empty()) ptr.push_back((int64_t)live.size());
     const long U = (long)items.size();
@@ -195,12 +198,13 @@ long build_homogeneous(int kind, const int64_t* seqs, const int64_t* offs, int B
     bd.add("out_ptr", std::move(out_ptr), 1); bd.add("out_idx", std::move(out_idx));
     bd.counts = {{"B", B}, {"N", N}, {"E", E}};
     if (kind != 2) {
-        vec ui, up, upos, cptr, chptr;
-        uniq_csr(iid, ui, up, upos, cptr, chptr);
+        vec ui, up, upos, uinv, cptr, chptr;
+        uniq_csr(iid, ui, up, upos, uinv, cptr, chptr);
         bd.counts.push_back({"U", (int64_t)ui.size()});
         bd.counts.push_back({"C", (int64_t)chptr.size() - 1});
         bd.add("iid", std::move(iid), 2); bd.add("last", std::move(last), 2);
         bd.add("uniq_items", std::move(ui), 2); bd.add("uniq_ptr", std::move(up), 1); bd.add("uniq_pos", std::move(upos));
+        bd.add("uniq_inv", std::move(uinv), 2);
         bd.add("uniq_cptr", std::move(cptr), 1); bd.add("chunk_ptr", std::move(chptr), 1);
     }
     if (kind == 0) bd.add("ew", std::move(ew));
@@ -210,7 +214,7 @@ long build_homogeneous(int kind, const int64_t* seqs, const int64_t* offs, int B
         bd.cap("seg", Bc + 1); bd.cap("eseg", Bc + 1); bd.cap("esrc", Ec); bd.cap("edst", Ec);
         bd.cap("in_ptr", Nc + 1); bd.cap("in_idx", Ec); bd.cap("out_ptr", Nc + 1); bd.cap("out_idx", Ec);
         bd.cap("iid", Nc); bd.cap("last", Bc); bd.cap("uniq_items", Uc); bd.cap("uniq_ptr", Uc + 1);
-        bd.cap("uniq_pos", Nc); bd.cap("uniq_cptr", Uc + 1); bd.cap("chunk_ptr", Uc + Nc / CHUNK + 2); bd.cap("ew", Ec);
+        bd.cap("uniq_pos", Nc); bd.cap("uniq_inv", Nc); bd.cap("uniq_cptr", Uc + 1); bd.cap("chunk_ptr", Uc + Nc / CHUNK + 2); bd.cap("ew", Ec);
     }
     return bd.emit(out, out_cap, info, max_fields, n_fields);
 }
@@ -323,11 +327,12 @@ long build_ccs(const int64_t* seqs, const int64_t* offs, int B, int K, const int
         std::copy(iid[k].begin(), iid[k].end(), blk.begin());
         gidx.insert(gidx.end(), blk.begin(), blk.end());
     }
-    vec ui, up, upos, cptr, chptr;
-    uniq_csr(gidx, ui, up, upos, cptr, chptr);
+    vec ui, up, upos, uinv, cptr, chptr;
+    uniq_csr(gidx, ui, up, upos, uinv, cptr, chptr);
     const long G = (long)gidx.size(), U = (long)ui.size(), C = (long)chptr.size() - 1;
     bd.add("gidx", std::move(gidx), 2);
     bd.add("uniq_items", std::move(ui), 2); bd.add("uniq_ptr", std::move(up), 1); bd.add("uniq_pos", std::move(upos));
+    bd.add("uniq_inv", std::move(uinv), 2);
     bd.add("uniq_cptr", std::move(cptr), 1); bd.add("chunk_ptr", std::move(chptr), 1);
     bd.counts.push_back({"G", G}); bd.counts.push_back({"U", U}); bd.counts.push_back({"C", C});
     static char names[64][6][32];
@@ -363,7 +368,7 @@ long build_ccs(const int64_t* seqs, const int64_t* offs, int B, int K, const int
     bd.counts.push_back({"NT", NT});
     if (caps) {
         const long Bc = caps[0], N = caps[1], E = caps[2], U2 = caps[3];
-        bd.cap("uniq_items", U2); bd.cap("uniq_ptr", U2 + 1); bd.cap("uniq_pos", G); bd.cap("uniq_cptr", U2 + 1);
+        bd.cap("uniq_items", U2); bd.cap("uniq_ptr", U2 + 1); bd.cap("uniq_pos", G); bd.cap("uniq_inv", G); bd.cap("uniq_cptr", U2 + 1);
         bd.cap("chunk_ptr", U2 + G / CHUNK + 2); bd.cap("cat_perm", N * K); bd.cap("cat_seg", Bc + 1);
         for (int k = 1; k <= K; ++k) {
             bd.cap(SEG[k], Bc + 1); bd.cap(IID[k], N * k); bd.cap(LAST[k], Bc); bd.cap(LASTCAT[k], Bc);

@@ -655,7 +655,9 @@ class VocabParallel:
             all_reduce_(t, dist.ReduceOp.MAX, self.group)
         return (int(t.item()) + 255) // 256 * 256
 
-    def lookup(self, table, idx, uniq, drop=None):
+    def lookup(self, table, idx, uniq, drop=None, inv=None):
+        """inv: position -> slot of its item in `items` (-1: padding) when the batch carries it (FlatBatch.uniq_inv, built by
+        the collate workers) - else derived from the item CSR here (two small launches)"""
         if torch.is_grad_enabled() and table.requires_grad:
             self.begin_step()                  # (a training forward: every model's first use of the sharded table is its lookup)
         items, uptr, upos = uniq[:3]
@@ -664,7 +666,8 @@ class VocabParallel:
         # capacity-padded batches: the distinct-item field of the batch buffer IS the padded request list (int32, -1 in the
         # unused slots) - no conversion, no copy; exact layouts pad a copy
         items_pad = items if U == ucap else self._pad(items if items.dtype == torch.int32 else items.to(torch.int64), ucap)
-        inv = self.local.inverse_index(uptr, upos, U, n)      # position -> slot of its item in `items`
+        if inv is None or inv.numel() != n or inv.dtype != torch.int32:
+            inv = self.local.inverse_index(uptr, upos, U, n)      # position -> slot of its item in `items`
         uq = (items, uptr[:U + 1], upos) + tuple(uniq[3:])
         self.lab_all = None
         rows = ShardedLookup.apply(table, items_pad, inv, uq, self.dE, self.lo, self.local, self.group, self, drop)

@@ -127,7 +127,7 @@ class LESSR(_ScoringMixin, nn.Module):
             if sg is not None:
                 ops.check_limits(sg, 'sgat_deg')
         feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
-                            dN, mg.dynp('U'))
+                            dN, mg.dynp('U'), inv=mg.uniq_inv if mg.has('uniq_inv') else None)
         for i, layer in enumerate(self.layers):
             out = layer(mg, feat) if i % 2 == 0 else layer(sg, feat)
             feat = torch.cat([out, feat], dim=1)

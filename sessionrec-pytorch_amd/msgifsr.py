@@ -340,7 +340,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         W = self._table()
         d = self.embedding_dim
         rows = self._lookup(mg.gidx, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
-                            None, mg.dynp('U'), drop=self.feat_drop)     # padded slots of gidx are -1 -> zero rows; the
+                            None, mg.dynp('U'), drop=self.feat_drop,
+                            inv=mg.uniq_inv if mg.has('uniq_inv') else None)     # padded slots of gidx are -1 -> zero rows; the
         #                                                                  feature dropout of msgifsr.py:247 rides in the gather
         feats = {}
         dB = mg.dynp('B')

@@ -124,7 +124,7 @@ class _ScoringMixin:
     shard = None               # set by dist.VocabParallel(model): row-sharded table over the node's GPUs
     graph_capable = False      # True: every kernel of the step reads its live extents from the padded batch (hipGraph replay)
 
-    def _lookup(self, idx, uniq, tgrad, dyn_n=None, dyn_u=None, drop=None):
+    def _lookup(self, idx, uniq, tgrad, dyn_n=None, dyn_u=None, drop=None, inv=None):
         """item rows for the batch: local gather, or the collective lookup when the table is sharded.  drop: an nn.Dropout
         applied to the rows - fused into the gather kernels on the single-device path."""
         p = drop.p if isinstance(drop, nn.Dropout) and drop.training else 0.0
@@ -138,7 +138,7 @@ class _ScoringMixin:
             ops.RNG_COUNTER.pop(str(W.device), None)
         if self.shard is not None:
             fused = p > 0 and getattr(self.shard.local, 'fused_dropout', False)      # HipLocal: the mask rides in the gather
-            rows = self.shard.lookup(self._table(), idx, uniq, (p, 7) if fused else None)
+            rows = self.shard.lookup(self._table(), idx, uniq, (p, 7) if fused else None, inv=inv)
             return rows if (fused or drop is None) else drop(rows)
         if drop is not None and not isinstance(drop, nn.Dropout):
             return drop(ops.embedding_lookup(self._table(), idx, uniq, tgrad, dyn_n, dyn_u))    # replaced module (tests)
@@ -278,7 +278,7 @@ class SRGNN(_ScoringMixin, nn.Module):
         if mg.buf.is_cuda:
             ops.check_limits(mg)
         feat = self._lookup(mg.iid, (mg.uniq_items, mg.uniq_ptr, mg.uniq_pos, mg.uniq_cptr, mg.chunk_ptr), tgrad,
-                            dN, mg.dynp('U'))
+                            dN, mg.dynp('U'), inv=mg.uniq_inv if mg.has('uniq_inv') else None)
         feat = self._pre(self.feat_drop(feat), dN)
         if self.use_gnn_output:
             for layer in self.layers:

@@ -130,6 +130,9 @@ def test_collate_homogeneous_matches_oracle(kind):
         for u in range(len(it)):
             assert np.all(fb.iid.numpy()[ps[pt[u]:pt[u + 1]]] == it[u])
         assert pt[-1] == len(fb.iid)
+        # ... and the per-position inverse (what the row-sharded lookup gathers the exchanged rows through) names each
+        # position's item
+        assert np.array_equal(it[fb.uniq_inv.numpy()], fb.iid.numpy())
     if kind == 'session':
         assert np.array_equal(fb.ew.numpy(), ob['w'])
     # in-edge CSR: grouped by destination, edge ids ascending inside a group (EOPA's time order)
@@ -167,6 +170,9 @@ def test_collate_ccs_matches_oracle(K):
         want = np.concatenate([np.arange(int(fb.field("seg%d" % k)[i]), int(fb.field("seg%d" % k)[i + 1])) + offs[k - 1]
                                for k in range(1, K + 1)])
         assert np.array_equal(perm[cseg[i]:cseg[i + 1]], want)
+    # the flat lookup list, its distinct items and the per-position inverse (-1: no item at that position)
+    g, it, ui = fb.gidx.numpy(), fb.uniq_items.numpy(), fb.uniq_inv.numpy()
+    assert np.array_equal(ui >= 0, g >= 0) and np.array_equal(it[ui[g >= 0]], g[g >= 0])
 
 
 def test_reference_collate_smoke_answer():
