@@ -343,12 +343,19 @@ int srec_adam_rows_proj(float* W, const float* G, float* M, float* V, int n, int
 /* ---- MSGIFSR MSHGNN layer, all relations of both HeteroGraphConvs in one batched pass (hgat.hip) ------------------
  * Replaces msgifsr.py:70-89 (conv1(g) + conv2(reverse g), relation sum, head max, + session mean) around the fc GEMMs
  * of the GAT modules; `desc` points to a host srec_hg_desc (srec_hg.h).
- *   fwd: the caller has filled P[m] = x[rows of m] fc_m^T; writes out[NT, D] = max_h(sum_rel rst + bias + n_rel x) +
+ *   fwd: the caller has filled P[m] = x[rows of m] fc_m^T (p16 bit 3: and run srec_hg_fold); writes out[NT, D] = max_h(sum_rel rst + bias + n_rel x) +
  *        session mean of x, arg[NT, D] (winning head), and the saved A / eL / eR.
  *   bwd: g = d out; writes dx = n_rel g + session-mean term (the caller then accumulates dP[m] fc_m into it), dP[m],
  *        d_attn_l / d_attn_r / d_bias of every module.  ws: srec_hg_ws_floats() floats of scratch. */
 int srec_hg_ws_floats(const void* desc, long* n_floats);
 int srec_hg_fwd(const void* desc, const float* x, int ld_x, float* out, int ld_out, unsigned char* arg, void* stream);
+/* the weight-only part of srec_hg_fwd on its own: V[m] (attention vectors folded into fc_m, gatconv.py:285-292 as a product over x)
+ * and the per-type bias sums of desc.  srec_hg_fwd runs it itself unless bit 3 of desc.p16 says it was done since the weights
+ * last changed - by this call or by the step's prologue launch: */
+int srec_hg_fold(const void* desc, void* stream);
+/* desc: HOST srec_step_prep_desc (srec_hg.h): fold + bf16 weight copies + GRU / head fragment copies + mailbox intake, one launch
+ * in front of a step (each of them a ~5 us graph node of its own otherwise; utils/train.py:94-101 is the step) */
+int srec_step_prep(const void* desc, void* stream);
 /* feature-dropout glue of a layer call in one pass each (GATConv feat_drop, gatconv.py:268-283): masks from the counter-based
  * hash of srec_gather_rows_drop (one mask per conv) and cnt [2, rows] (relation instances of the conv into each row): ms = mask / (1-p),
  * xc = x * ms (the convs' dropped inputs), rm = cnt0 ms0 + cnt1 ms1, xres = x * rm (summed identity residuals);

@@ -27,7 +27,8 @@ typedef struct {
     float slope;
     int p16;                       /* bit 0: P / dP hold bf16 (2-byte) elements (0: fp32); bit 1 (srec_hg_bwd): leave the dP rows past
                                       the live count unwritten - the caller's readers of dP stop at *dyn_n (srec_gemm16_group.dyn);
-                                      bit 2 (srec_hg_bwd): do not write dx - the caller finishes it with srec_hg_pre_merge */
+                                      bit 2 (srec_hg_bwd): do not write dx - the caller finishes it with srec_hg_pre_merge;
+                                      bit 3 (srec_hg_fwd): V / the bias sums in Z are current (srec_hg_fold or srec_step_prep ran) */
     const int* dynB;
     /* node types */
     int row0[SREC_HG_MAXT], ncap[SREC_HG_MAXT];
@@ -280,5 +281,35 @@ typedef struct {
     float* dVq[SREC_HEAD_MAXH];
     float* dwp[SREC_HEAD_MAXH];
 } srec_head_bwd_desc;
+
+/* the prologue of a step in ONE launch (srec_step_prep, csrc/prep.hip): the operand copies of the weights the optimizer just wrote
+ * and the intake of the batch - the work of srec_hg_fold, srec_weights_bf16, srec_gru_wfrag_both, srec_head_wfrag and
+ * srec_copy_words_mailbox (srec.h; arguments as documented there, HOST arrays of n entries) as workgroup ranges of one kernel.
+ * None of them reads the batch or another one's output.  A role is absent with hg = NULL / n = 0 / box_cap = 0. */
+typedef struct {
+    const void* hg;                    /* HOST srec_hg_desc whose fold is wanted (the caller then sets bit 3 of ITS p16 for srec_hg_fwd) */
+    int n_w16;                         /* srec_weights_bf16 */
+    const void* w16_W;
+    const void* w16_out;
+    const void* w16_T;
+    const int* w16_R;
+    const int* w16_C;
+    int n_gru, gru_d;                  /* srec_gru_wfrag_both */
+    const void* gru_W;
+    const void* gru_fwd;
+    const void* gru_bwd;
+    int n_head;                        /* srec_head_wfrag */
+    const void* head_W;
+    const void* head_out;
+    const int* head_rows;
+    const int* head_cols;
+    const int* head_trans;
+    const int* mailbox;                /* srec_copy_words_mailbox */
+    int M;
+    const int* counter;
+    int* box_dst;
+    long box_cap;
+    int* box_err;
+} srec_step_prep_desc;
 
 #endif

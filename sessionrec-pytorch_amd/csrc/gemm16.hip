@@ -531,67 +531,6 @@ __global__ void rows_bf16_kernel(const float* __restrict__ src, int ld, int n, c
     *reinterpret_cast<uint2*>(dst + i) = o;
 }
 
-// fc weights of up to 8 modules: W [R, Cc] fp32 -> W16 [R, Cc] and WT16 [Cc, R] bf16 (64 x 64 tiles through LDS)
-struct WArgs {
-    const float* W[8];
-    unsigned short* W16[8];
-    unsigned short* WT16[8];
-    int R[8], Cc[8], start[9];
-    int n;
-};
-__global__ void weights_bf16_kernel(WArgs a) {
-    __shared__ unsigned short tile[64][68];
-    int t = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i)
-        if (i < a.n && (int)blockIdx.x >= a.start[i]) t = i;
-    const int R = a.R[t], Cc = a.Cc[t];
-    const int tc = (Cc + 63) / 64, b = blockIdx.x - a.start[t];
-    const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
-    const float* __restrict__ W = a.W[t];
-    if (((R | Cc) & 3) == 0) {
-        // 4 columns per thread: float4 in, 8-byte bf16 stores in both layouts (2-byte stores ran at a third of this rate)
-        const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
-        for (int rr = y; rr < 64; rr += 16) {
-            const int r = r0 + rr, c = c0 + 4 * x;
-            uint2 v = make_uint2(0u, 0u);
-            if (r < R && c < Cc) {
-                const float4 f = *reinterpret_cast<const float4*>(W + (size_t)r * Cc + c);
-                v = make_uint2(srec_pack_bf16(f.x, f.y), srec_pack_bf16(f.z, f.w));
-                *reinterpret_cast<uint2*>(a.W16[t] + (size_t)r * Cc + c) = v;
-            }
-            *reinterpret_cast<uint2*>(&tile[rr][4 * x]) = v;
-        }
-        if (a.WT16[t] == nullptr) return;
-        __syncthreads();
-        for (int cc = y; cc < 64; cc += 16) {
-            const int c = c0 + cc, r = r0 + 4 * x;
-            if (c < Cc && r < R) {
-                const unsigned lo = tile[4 * x][cc] | ((unsigned)tile[4 * x + 1][cc] << 16);
-                const unsigned hi = tile[4 * x + 2][cc] | ((unsigned)tile[4 * x + 3][cc] << 16);
-                *reinterpret_cast<uint2*>(a.WT16[t] + (size_t)c * R + r) = make_uint2(lo, hi);
-            }
-        }
-        return;
-    }
-    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    for (int rr = y; rr < 64; rr += 4) {
-        const int r = r0 + rr, c = c0 + x;
-        unsigned short v = 0;
-        if (r < R && c < Cc) {
-            v = srec_f2bf(W[(size_t)r * Cc + c]);
-            a.W16[t][(size_t)r * Cc + c] = v;
-        }
-        tile[rr][x] = v;
-    }
-    __syncthreads();
-    if (a.WT16[t] != nullptr)
-        for (int cc = y; cc < 64; cc += 4) {
-            const int c = c0 + cc, r = r0 + x;
-            if (c < Cc && r < R) a.WT16[t][(size_t)c * R + r] = tile[x][cc];
-        }
-}
-
 // out[c][i] = sum_r part[c][r][i] (fixed order: deterministic), i < n (n % 4 == 0); grid.y = c
 __global__ void sum_slabs_kernel(const float* __restrict__ part, int R, long n, float* __restrict__ out) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -763,26 +702,4 @@ extern "C" int srec_rows_bf16(const float* src, int ld, int n, const int* dyn, i
     return 0;
 }
 
-// n <= 8 weight matrices W_i [R_i, C_i] fp32 (contiguous) -> bf16 copy W16_i and transposed bf16 copy WT16_i [C_i, R_i]
-// (WT16 entries may be NULL).  W / W16 / WT16 / R / Cc are HOST arrays of n entries.
-extern "C" int srec_weights_bf16(int n, const void* W, const void* W16, const void* WT16, const int* R, const int* Cc,
-                                 void* stream) {
-    if (n <= 0) return 0;
-    if (n > 8 || W == nullptr || W16 == nullptr || WT16 == nullptr) return SREC_BAD_ARG;
-    WArgs a{};
-    a.n = n;
-    int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        a.W[i] = ((const float* const*)W)[i];
-        a.W16[i] = ((unsigned short* const*)W16)[i];
-        a.WT16[i] = ((unsigned short* const*)WT16)[i];
-        a.R[i] = R[i]; a.Cc[i] = Cc[i];
-        if (a.W[i] == nullptr || a.W16[i] == nullptr || R[i] <= 0 || Cc[i] <= 0) return SREC_BAD_ARG;
-        a.start[i] = blocks;
-        blocks += cdiv(R[i], 64) * cdiv(Cc[i], 64);
-    }
-    a.start[n] = blocks;
-    hipLaunchKernelGGL(weights_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
+// (srec_weights_bf16 - the bf16 / transposed copies of the fc weights - is a role of the step's prologue launch: prep.hip)

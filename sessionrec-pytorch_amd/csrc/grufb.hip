@@ -735,64 +735,9 @@ __global__ __launch_bounds__(256) void gru_wfrag_t_kernel(WfbArgs a) {
     *reinterpret_cast<uint4*>(a.dst[blockIdx.y] + (size_t)idx * 8) = o;
 }
 
-struct WfBothArgs {
-    int d, jb;
-    const float* W[2 * GB_MAXP];
-    unsigned short* dstf[2 * GB_MAXP];
-    unsigned short* dstb[2 * GB_MAXP];
-};
-
-// both fragment-major copies of a GRU weight in one launch: blockIdx.z = 0 the forward layout (gruf.hip: fragment ((w KS + s)
-// 3 JB + g JB + j), lane l <- W[g d + w d/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]), 1 the backward-data layout above
-__global__ __launch_bounds__(256) void gru_wfrag_both_kernel(WfBothArgs a) {
-    const int d = a.d, JB = a.jb;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 3 * d * d / 8) return;
-    const int lane = idx & 63, frag = idx >> 6;
-    float v[8];
-    unsigned short* dst;
-    if (blockIdx.z == 0) {
-        const int KS = d / 16, NF = 3 * JB;
-        const int f = frag % NF, ws = frag / NF, s = ws % KS, w = ws / KS, g = f / JB, j = f % JB;
-        const int nrow = g * d + w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
-        const float* src = a.W[blockIdx.y] + (size_t)nrow * d + kk;
-        const float4 v0 = ld4(src), v1 = ld4(src + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-        dst = a.dstf[blockIdx.y];
-    } else {
-        const int KS3 = 3 * d / 16;
-        const int j = frag % JB, ws = frag / JB, s = ws % KS3, w = ws / KS3;
-        const int col = w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
-        const float* src = a.W[blockIdx.y] + (size_t)kk * d + col;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = src[(size_t)e * d];
-        dst = a.dstb[blockIdx.y];
-    }
-    uint4 o;
-    o.x = srec_pack_bf16(v[0], v[1]); o.y = srec_pack_bf16(v[2], v[3]);
-    o.z = srec_pack_bf16(v[4], v[5]); o.w = srec_pack_bf16(v[6], v[7]);
-    *reinterpret_cast<uint4*>(dst + (size_t)idx * 8) = o;
-}
-
 }  // namespace
 
-// srec_gru_wfrag and srec_gru_wfrag_t of the same n <= 8 weights in ONE launch (dst_fwd, dst_bwd: HOST arrays of device pointers)
-extern "C" int srec_gru_wfrag_both(int n, const void* W, const void* dst_fwd, const void* dst_bwd, int d, void* stream) {
-    if (n <= 0) return 0;
-    if (n > 2 * GB_MAXP || W == nullptr || dst_fwd == nullptr || dst_bwd == nullptr || (d != 128 && d != 256)) return SREC_BAD_ARG;
-    WfBothArgs a{};
-    int nw = 4;
-    if (int rc = srec_gru_fused_waves(d, &nw)) return rc;
-    a.d = d; a.jb = d / (32 * nw);
-    for (int i = 0; i < n; ++i) {
-        a.W[i] = ((const float* const*)W)[i];
-        a.dstf[i] = ((unsigned short* const*)dst_fwd)[i]; a.dstb[i] = ((unsigned short* const*)dst_bwd)[i];
-        if (a.W[i] == nullptr || a.dstf[i] == nullptr || a.dstb[i] == nullptr) return SREC_BAD_ARG;
-    }
-    hipLaunchKernelGGL(gru_wfrag_both_kernel, dim3((3 * d * d / 8 + 255) / 256, n, 2), dim3(256), 0, (hipStream_t)stream, a);
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
+// (srec_gru_wfrag_both - both layouts of the same weights in one launch - is a role of the step's prologue launch: prep.hip)
 
 #ifdef SREC_GRUF_TIMING
 extern "C" int srec_grub_timing(unsigned long long* tim16, unsigned long long* blk) {

@@ -628,41 +628,6 @@ __global__ __launch_bounds__(64 * NW, 1) void head_bwd_kernel(HeadBwdArgs a) {
 #endif
 }
 
-struct WfragArgs {
-    int n;
-    const float* W[SREC_HEAD_MAXW];
-    unsigned short* dst[SREC_HEAD_MAXW];
-    int rows[SREC_HEAD_MAXW], cols[SREC_HEAD_MAXW], trans[SREC_HEAD_MAXW];
-};
-
-// hi / lo fragment-major copy of an operand matrix M [N, K] (trans = 0: M = W [rows = N, cols = K] as stored; trans = 1:
-// M = W^T of the stored W [rows = K, cols = N]): fragment (((w KS + s) 2 + t) JB + j), JB = N / 128, KS = K / 16, holds for lane l
-// the 8 bf16 of t(M[w N/4 + 32 j + (l & 31)][16 s + 8 (l >> 5) .. + 7]), t = hi / lo
-__global__ __launch_bounds__(256) void head_wfrag_kernel(WfragArgs a) {
-    const int m = blockIdx.y;
-    const int N = a.trans[m] ? a.cols[m] : a.rows[m], K = a.trans[m] ? a.rows[m] : a.cols[m];
-    const int JB = N / (32 * NW), KS = K / 16;
-    const int idx = blockIdx.x * 256 + threadIdx.x;              // (w, s, j, lane)
-    if (idx >= N * K / 8) return;
-    const int lane = idx & 63, f = idx >> 6;
-    const int j = f % JB, ws = f / JB, s = ws % KS, w = ws / KS;
-    const int nrow = w * 32 * JB + 32 * j + (lane & 31), kk = 16 * s + 8 * (lane >> 5);
-    float v[8];
-    const float* W = a.W[m];
-    if (!a.trans[m]) {
-        const float4 v0 = *reinterpret_cast<const float4*>(W + (size_t)nrow * K + kk), v1 = *reinterpret_cast<const float4*>(W + (size_t)nrow * K + kk + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = W[(size_t)(kk + i) * N + nrow];
-    }
-    uint4 h, l;
-    split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y); split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
-    unsigned short* dst = a.dst[m] + ((((size_t)(w * KS + s) * 2) * JB + j) * 64 + lane) * 8;
-    *reinterpret_cast<uint4*>(dst) = h;
-    *reinterpret_cast<uint4*>(dst + (size_t)JB * 512) = l;
-}
-
 }  // namespace
 
 #ifdef SREC_HEADF_TIMING
@@ -672,27 +637,7 @@ extern "C" int srec_headf_timing(unsigned long long* tim, unsigned long long* bl
 }
 #endif
 
-// n <= SREC_HEAD_MAXW matrices W_i [rows_i, cols_i] fp32 row-major (HOST arrays) -> hi / lo fragment-major bf16 copies dst_i
-// [2 rows_i cols_i] of W_i (trans_i = 0) or W_i^T (trans_i = 1) as the A operands of srec_head_fwd; operand rows % 128 == 0,
-// operand columns % 16 == 0.  One launch.
-extern "C" int srec_head_wfrag(int n, const void* W, const void* dst, const int* rows, const int* cols, const int* trans,
-                               void* stream) {
-    if (n <= 0) return 0;
-    if (n > SREC_HEAD_MAXW || W == nullptr || dst == nullptr || rows == nullptr || cols == nullptr || trans == nullptr) return SREC_BAD_ARG;
-    WfragArgs a{};
-    a.n = n;
-    int maxe = 0;
-    for (int i = 0; i < n; ++i) {
-        a.W[i] = ((const float* const*)W)[i]; a.dst[i] = ((unsigned short* const*)dst)[i];
-        a.rows[i] = rows[i]; a.cols[i] = cols[i]; a.trans[i] = trans[i];
-        const int N = trans[i] ? cols[i] : rows[i], K = trans[i] ? rows[i] : cols[i];
-        if (a.W[i] == nullptr || a.dst[i] == nullptr || N <= 0 || K <= 0 || (N % 128) || (K % 16)) return SREC_BAD_ARG;
-        maxe = max(maxe, N * K / 8);
-    }
-    hipLaunchKernelGGL(head_wfrag_kernel, dim3((maxe + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, a);
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
+// (srec_head_wfrag - the hi / lo fragment-major operand copies of the weights - is a role of the step's prologue launch: prep.hip)
 
 // desc: HOST srec_head_desc (srec_hg.h)
 extern "C" int srec_head_fwd(const void* desc, void* stream) {

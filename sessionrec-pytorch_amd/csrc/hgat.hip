@@ -23,6 +23,8 @@
 #include "common.h"
 #include "../../include/srec_hg.h"
 
+extern "C" int srec_hg_fold(const void* desc, void* stream);      // prep.hip
+
 namespace {
 
 constexpr int WPB = 4;
@@ -62,69 +64,10 @@ __device__ __forceinline__ int find_range(const int (&start)[N], int n, int x) {
 }
 
 // ------------------------------------------------------------------------------------------------ logits
-// el[n,h] = <P[n,h,:], a_l[h,:]> with P = x W^T  ==  x[n,:] . V_l[:,h],  V_l[c,h] = sum_j W[hD+j, c] a_l[hD+j].
-// Folding the attention vectors into the fc weights first (2 MB of W per module, once) turns the logits into a
-// [N, D] x [D, 2H] product over x instead of a pass over the 8x larger projections.  V[m] layout: [2][D][H].
-struct FoldArgs {
-    const float* W[MAXM]; const float* al[MAXM]; const float* ar[MAXM];
-    float* V[MAXM];
-    int H, D;
-    // per node type t < nt: bsum[t][h D + c] = sum of the bias vectors of the relation instances into t (the workgroups
-    // (m, h) with m < nt compute it on the side: hg_agg then reads ONE bias row per (node, head) instead of one per instance)
-    int nt, tn[MAXT];
-    const float* tb[MAXT][8];
-    float* bsum[MAXT];
-};
-
-// block = (module, head, 64-column slice); 256 threads = 16 row groups x 16 column quads: a thread reads 16 bytes of 16 rows of
-// W (one-column threads issued 64 four-byte loads per wave for the same bytes: the kernel was bound by their issue, 9.5 us for
-// 16 MB), the attention vectors of the head wait in LDS; the 16 row groups are summed through LDS in row-group order.
-// (One 1024-thread block per (module, head) - 64 workgroups - kept 3/4 of the CUs idle: 12 us.)
-constexpr int FOLD_COLS = 64, MAXD_FOLD = 256;        // (D <= 256, D % 4 == 0: checked by the launchers)
-__global__ __launch_bounds__(256) void hg_fold_kernel(FoldArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2][16][FOLD_COLS];
-    __shared__ float av[2][MAXD_FOLD];
-    const int H = a.H, D = a.D;
-    const int ncq = (D + FOLD_COLS - 1) / FOLD_COLS;
-    const int cq = blockIdx.x % ncq, mh = blockIdx.x / ncq;
-    const int m = mh / H, h = mh % H;
-    for (int j = threadIdx.x; j < D; j += 256) { av[0][j] = a.al[m][h * D + j]; av[1][j] = a.ar[m][h * D + j]; }
-    __syncthreads();
-    const int c4 = threadIdx.x & 15, jg = threadIdx.x >> 4;
-    const int c = cq * FOLD_COLS + 4 * c4;
-    float4 sl = make_float4(0.f, 0.f, 0.f, 0.f), sr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < D) {
-        const float* W = a.W[m] + (size_t)h * D * D + c;
-#pragma unroll 8
-        for (int j = jg; j < D; j += 16) {
-            const float4 w = *reinterpret_cast<const float4*>(W + (size_t)j * D);
-            const float l = av[0][j], r = av[1][j];
-            sl.x += w.x * l; sl.y += w.y * l; sl.z += w.z * l; sl.w += w.w * l;
-            sr.x += w.x * r; sr.y += w.y * r; sr.z += w.z * r; sr.w += w.w * r;
-        }
-    }
-    *reinterpret_cast<float4*>(&red[0][jg][4 * c4]) = sl;
-    *reinterpret_cast<float4*>(&red[1][jg][4 * c4]) = sr;
-    __syncthreads();
-    const int cl = threadIdx.x & (FOLD_COLS - 1), part = threadIdx.x / FOLD_COLS, cc = cq * FOLD_COLS + cl;
-    if (part < 2 && cc < D) {                            // threads 0 .. 63: V_l, 64 .. 127: V_r
-        float t = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[part][g][cl];
-        a.V[m][(size_t)(part * D + cc) * H + h] = t;
-    }
-    if (part == 2 && cc < D) {
-        // node types are dealt to the module workgroups round-robin: a tiny batch may have fewer live modules than types
-        const int nmods = (int)gridDim.x / (H * ncq);
-        for (int t = m; t < a.nt; t += nmods) {
-            if (a.bsum[t] == nullptr) continue;
-            float b = 0.f;
-            for (int q = 0; q < a.tn[t]; ++q) b += a.tb[t][q][h * D + cc];  // instance order = the order hg_agg used
-            a.bsum[t][h * D + cc] = b;
-        }
-    }
-}
-
+// el[n,h] = <P[n,h,:], a_l[h,:]> with P = x W^T  ==  x[n,:] . V_l[:,h],  V_l[c,h] = sum_j W[hD+j, c] a_l[hD+j]: the attention
+// vectors are folded into the fc weights first (V[m] [2][D][H] and the per-type bias sums: srec_hg_fold, a role of the step's
+// prologue launch, prep.hip), which turns the logits into a [N, D] x [D, 2H] product over x instead of a pass over the 8x
+// larger projections.
 struct DotsArgs {
     const float* V[MAXB];
     float* eL[MAXB]; float* eR[MAXB];
@@ -242,7 +185,7 @@ struct AggArgs {
     int nt, B;
     const int* dynB;
     // instances
-    const float* bsum[MAXT];            // per node type: the summed bias rows of its instances (hg_fold_kernel)
+    const float* bsum[MAXT];            // per node type: the summed bias rows of its instances (srec_hg_fold, prep.hip)
     const void* Ps[MAXI]; const float* eLs[MAXI]; const float* eRd[MAXI]; const float* bias[MAXI];
     const int* in_ptr[MAXI]; const int* in_idx[MAXI]; const int* esrc[MAXI];
     float* A[MAXI];
@@ -1577,23 +1520,10 @@ extern "C" int srec_hg_fwd(const void* desc_, const float* x, int ld_x, float* o
     hipStream_t st = (hipStream_t)stream;
     const int H = d->H, D = d->D, HD = H * D;
     const size_t esz = (d->p16 & 1) ? 2 : 4;
-    if (d->n_mods > 0) {
-        FoldArgs f{};
-        f.H = H; f.D = D;
-        for (int m = 0; m < d->n_mods; ++m) { f.W[m] = d->W[m]; f.al[m] = d->attn_l[m]; f.ar[m] = d->attn_r[m]; f.V[m] = d->V[m]; }
-        // bias sums per node type, kept in the first H D floats of the backward's Z scratch (free during the forward)
-        f.nt = d->n_types;
-        for (int t = 0; t < d->n_types; ++t) { f.tn[t] = 0; f.bsum[t] = d->Z[t]; }
-        for (int i = 0; i < d->n_inst; ++i) {
-            const int t = d->blk_type[d->inst_dblk[i]];
-            if (f.tn[t] >= 8) return SREC_BAD_ARG;
-            f.tb[t][f.tn[t]++] = d->bias[d->inst_mod[i]];
-        }
-        // (the caller provides Z slots for max(n_mods, n_types): a batch of very short sessions has fewer live modules than types)
-        for (int t = 0; t < d->n_types; ++t)
-            if (f.tn[t] > 0 && f.bsum[t] == nullptr) return SREC_BAD_ARG;
-        hipLaunchKernelGGL(hg_fold_kernel, dim3(d->n_mods * H * cdiv(D, FOLD_COLS)), dim3(256), 0, st, f);
-    }
+    // (bit 3 of p16: V and the bias sums of this descriptor's weights were written since the optimizer last changed them - by
+    // srec_hg_fold or, in a step that starts with srec_step_prep, by the prologue launch)
+    if (d->n_mods > 0 && !(d->p16 & 8))
+        if (int rc = srec_hg_fold(d, stream)) return rc;
     if (d->sess == nullptr || d->B <= 0) return SREC_BAD_ARG;
     for (int t = 0; t < d->n_types; ++t)
         if (d->smean[t] == nullptr) return SREC_BAD_ARG;

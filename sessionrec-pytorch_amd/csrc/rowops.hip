@@ -1139,40 +1139,7 @@ __global__ void copy_words_kernel(const int4* __restrict__ src, int4* __restrict
 }
 }  // namespace
 
-namespace {
-// batch intake INSIDE a captured step: where this replay's batch lives is looked up in a mailbox the host fills ahead of the
-// launch - entry (*counter % M) = {source address (2 words), words to copy, the counter value the host expects} in page-locked
-// host memory - so a replayed step needs no copy command in front of its graph launch (the copy command + the gap behind it
-// cost ~12 us per step, profiles/r03_notes.md "gap legs").  A mismatch of the expected counter raises *err (checked by the host).
-__global__ void copy_words_mailbox_kernel(const int4* __restrict__ mailbox, int M, const int* __restrict__ counter,
-                                          int4* __restrict__ dst, long cap4, int* __restrict__ err) {
-    const int ctr = *counter;
-    const int4 e = mailbox[ctr % M];
-    const int4* src = reinterpret_cast<const int4*>(((unsigned long long)(unsigned)e.y << 32) | (unsigned long long)(unsigned)e.x);
-    const long n4 = min((long)e.z / 4, cap4);
-    if (e.w != ctr) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *err = 1;
-        return;
-    }
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n4) dst[i] = src[i];
-}
-}  // namespace
-
-// dst [<= cap words] (device) = the words mailbox[*counter % M] points at (page-locked host or device memory, 16-byte
-// aligned, a multiple of 4 words); mailbox: M entries of 4 int32 in page-locked host memory (address lo, address hi, words,
-// expected counter); err: device int32, set to 1 when the entry does not carry the counter's value
-extern "C" int srec_copy_words_mailbox(const int* mailbox, int M, const int* counter, int* dst, long cap, int* err, void* stream) {
-    if (cap <= 0) return 0;
-    if (mailbox == nullptr || counter == nullptr || dst == nullptr || err == nullptr || M <= 0 || ((uintptr_t)dst & 15) ||
-        ((uintptr_t)mailbox & 15))
-        return SREC_BAD_ARG;
-    const long cap4 = cap / 4;
-    hipLaunchKernelGGL(copy_words_mailbox_kernel, dim3((unsigned)((cap4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const int4*)mailbox, M, counter, (int4*)dst, cap4, err);
-    SREC_LAUNCH_CHECK();
-    return 0;
-}
+// (srec_copy_words_mailbox - batch intake inside a captured step - is a role of the step's prologue launch: prep.hip)
 
 // dst [n] (device) = src [n] (page-locked host memory or device memory), int32 words; both 16-byte aligned
 extern "C" int srec_copy_words(const int* src, int* dst, long n, void* stream) {

@@ -113,6 +113,9 @@ class GraphedTrainStep:
                 try:
                     self._capture_intake()
                     self.loss = self.model.fused_loss(*self.static_inputs, self.static_labels)
+                    from . import ops as _ops
+                    if _ops.PENDING_INTAKE:
+                        raise RuntimeError('the model never launched the batch intake of its captured step (ops.flush_intake)')
                     self.loss.backward(self._one)
                     if self.after_backward is not None:
                         self.after_backward()
@@ -146,6 +149,8 @@ class GraphedTrainStep:
             optimizer._frozen = None
             self._restore(model, optimizer, snap_p, snap_b, snap_o)
             optimizer.zero_grad(set_to_none=True)
+            from . import ops as _ops
+            del _ops.PENDING_INTAKE[:]                   # (an intake the dead capture never launched)
             sh = getattr(model, 'shard', None)
             if sh is not None and hasattr(sh, 'abort_step'):
                 sh.abort_step()                          # early gradient buckets recorded by the dead capture never ran
@@ -233,12 +238,14 @@ class GraphedTrainStep:
                                'every later one were skipped (parameters and optimizer state are those before it)')
 
     def _capture_intake(self):
+        """the intake kernels of the captured step: handed to the model, whose first launch takes one along (ops.step_prologue:
+        one node for the intake and the step's weight copies) or launches them ahead of its first read of the batch
+        (ops.flush_intake in the models' lookup)"""
         if self._mb is None:
             return
-        from ._lib import lib, stream
-        for i, st in enumerate(self.static_inputs):
-            lib.srec_copy_words_mailbox(self._mb['box'][i].data_ptr(), _MAILBOX, self._mb['counter'].data_ptr(), st.buf.data_ptr(),
-                                        st.buf.numel(), self._mb['err'].data_ptr(), stream())
+        from . import ops
+        ops.PENDING_INTAKE[:] = [(self._mb['box'][i].data_ptr(), _MAILBOX, self._mb['counter'].data_ptr(), st.buf.data_ptr(),
+                                  st.buf.numel(), self._mb['err'].data_ptr(), self._mb) for i, st in enumerate(self.static_inputs)]
 
     def _post(self, i, x, T):
         """entry T % _MAILBOX of input i <- (address, words, T); the batch buffer must stay untouched until the replay has

@@ -152,7 +152,11 @@ class MSHGNN(nn.Module):
 
     def forward_stacked(self, mg, x, all_rels=False):
         """x: [NT, d] node features of all orders stacked (order-1 rows first) -> [NT, d]; one batched pass"""
-        plan, params = self.plan(mg, x.shape[1], all_rels)
+        pre = self.__dict__.pop('_pre', None)        # the plan the model's prologue launch already folded the weights for
+        if pre is not None and pre[0] is mg and pre[1] == (x.shape[1], bool(all_rels)):
+            plan, params = pre[2]
+        else:
+            plan, params = self.plan(mg, x.shape[1], all_rels)
         mod = self.conv1.mods['intra1']
         drop = (mod.feat_drop, mod.attn_drop) if self.training and (mod.feat_drop > 0 or mod.attn_drop > 0) else None
         return ops.hgat_layer(x, plan, params, drop)
@@ -331,10 +335,42 @@ class MSGIFSR(_ScoringMixin, nn.Module):
         finally:
             ops.DEFER['on'] = False
 
+    def _step_prologue(self, mg):
+        """the operand copies of this step's weights (k-gram GRUs, the first MSHGNN layer's fc weights and its folded attention
+        vectors, the read-out head) and the batch intake of a captured step in ONE launch ahead of the lookup (ops.step_prologue,
+        csrc/prep.hip) - 5 launches of 5 - 8 us each otherwise, one in front of each reader.  The conditions mirror the
+        readers'; a reader that finds no copies makes its own."""
+        K, d = self.order, self.embedding_dim
+        bf16 = ops.PRECISION['matmul'] == 'bf16'
+        grad = torch.is_grad_enabled() and self.training
+        gru, w16, head, fold = [], [], [], None
+        if bf16 and 1 < K <= 5 and ops.gru_expand_fast_ok(d, self.reducer) and ops.gru_fused_ok(d, K - 1):
+            gru = [w for k in range(2, K + 1) for w in (self.expander.GRUs[k - 2].weight_ih_l0, self.expander.GRUs[k - 2].weight_hh_l0)]
+            if not all(w.is_contiguous() for w in gru):
+                gru = []
+        if len(self.layers) > 0:
+            layer = self.layers[0]
+            multi = self.shard is not None and self.shard.world > 1
+            plan, params = layer.plan(mg, d, multi)
+            layer._pre = (mg, (d, bool(multi)), (plan, params))
+            fold = (plan, params)
+            nm = len(plan.modules)
+            if bf16 and d % 64 == 0 and nm <= 8 and all(params[4 * m].is_contiguous() for m in range(nm)):
+                w16 = [params[4 * m] for m in range(nm)]
+        live = range(K) if (K == 1 or self.fusion) else (0,)
+        if (bf16 and ops.FUSED_HEAD and self.norm and K > 1 and len(live) <= 4 and d in (128, 256) and 1 < mg.B <= ops.HEAD_FUSED_MAX_B):
+            ro = self.readout
+            hw = [w for i in live for w in (ro.fc_u[i].weight, ro.fc_v[i].weight, self.fc_sr[i].weight)]
+            if all(w.is_contiguous() for w in hw):
+                head = [(w, 0) for w in hw] + ([(self.fc_sr[i].weight, 1) for i in live] if grad else [])
+        ops.step_prologue(w16, gru, head, fold)
+
     def _session_repr(self, mg, tgrad=None):
         K = self.order
         if mg.buf.is_cuda:
             ops.check_limits(mg)
+            if ops.STEP_PROLOGUE:
+                self._step_prologue(mg)
         if not self.__dict__.pop('_table_ready', False):
             self._renorm(mg)
         W = self._table()

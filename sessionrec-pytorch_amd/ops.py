@@ -103,14 +103,29 @@ _WT_CACHE = {}
 def set_precision(mode):
     assert mode in ('fp32', 'bf16')
     PRECISION['matmul'] = mode
-    _WT_CACHE.clear()
-    _HEAD_WF_CACHE.clear()
+    weights_changed()
 
 
 def weights_changed():
     """called by the optimizer after it updated parameters: cached transposed weight copies are stale"""
     _WT_CACHE.clear()
     _HEAD_WF_CACHE.clear()
+    _WPREP.clear()
+
+
+# bf16 operand copies of weights made by the prologue launch of the CURRENT forward pass (step_prologue) for the one node that
+# reads them (weights_bf16 in HGATLayer, gru_wfrag_both in GRUExpandAll): (kind, data_ptr, shape) -> (tensor version, buffers).
+# The reader TAKES its entry - nothing outlives the forward it was made for; weights_changed drops what was never read.
+_WPREP = {}
+
+
+def _wprep_take(kind, w):
+    e = _WPREP.pop((kind, w.data_ptr(), tuple(w.shape)), None)
+    return e[1] if e is not None and e[0] == w._version else None
+
+
+def _wprep_put(kind, w, bufs):
+    _WPREP[(kind, w.data_ptr(), tuple(w.shape))] = (w._version, bufs)
 
 
 def _transposed(w):
@@ -1228,9 +1243,21 @@ def _readout_head_backward(allf, seg, per, dT, dB, has_bu, gs):
 _HEAD_WF_CACHE = {}    # (data_ptr, shape, trans) -> hi / lo fragment-major bf16 copy of this step (dropped by weights_changed)
 
 
+def _head_wfrag_args(ws, trans):
+    """output buffers + the HOST argument arrays of srec_head_wfrag for <= 16 weights (kept alive by the caller across the call)"""
+    m = len(ws)
+    assert 0 < m <= 16
+    for w in ws:
+        assert w.is_contiguous() and w.dtype == torch.float32
+    bufs = [torch.empty(2 * w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
+    arr, ints = _ct.c_void_p * m, _ct.c_int * m
+    return bufs, (arr(*[w.data_ptr() for w in ws]), arr(*[b.data_ptr() for b in bufs]), ints(*[w.shape[0] for w in ws]),
+                  ints(*[w.shape[1] for w in ws]), ints(*[int(t) for t in trans]))
+
+
 def head_wfrag(ws, trans):
     """hi / lo fragment-major bf16 operand copies of fp32 weights (W_i or W_i^T), computed once per optimizer step, all
-    missing ones in ONE launch (srec_head_wfrag)"""
+    missing ones in ONE launch (srec_head_wfrag) - normally none: the step's prologue launch made them (step_prologue)"""
     out, todo = [None] * len(ws), []
     for i, (w, t) in enumerate(zip(ws, trans)):
         c = _HEAD_WF_CACHE.get((w.data_ptr(), tuple(w.shape), int(t)))
@@ -1240,15 +1267,8 @@ def head_wfrag(ws, trans):
             out[i] = c
     for c0 in range(0, len(todo), 16):
         ch = todo[c0:c0 + 16]
-        m = len(ch)
-        for i in ch:
-            assert ws[i].is_contiguous() and ws[i].dtype == torch.float32
-        bufs = [torch.empty(2 * ws[i].numel(), device=ws[i].device, dtype=torch.bfloat16) for i in ch]
-        arr, ints = _ct.c_void_p * m, _ct.c_int * m
-        a_w, a_o = arr(*[ws[i].data_ptr() for i in ch]), arr(*[b.data_ptr() for b in bufs])
-        i_r, i_c, i_t = ints(*[ws[i].shape[0] for i in ch]), ints(*[ws[i].shape[1] for i in ch]), ints(*[int(trans[i]) for i in ch])
-        lib.srec_head_wfrag(m, _ct.addressof(a_w), _ct.addressof(a_o), _ct.addressof(i_r), _ct.addressof(i_c), _ct.addressof(i_t),
-                            stream())
+        bufs, args = _head_wfrag_args([ws[i] for i in ch], [trans[i] for i in ch])
+        lib.srec_head_wfrag(len(ch), *[_ct.addressof(a) for a in args], stream())
         for i, b in zip(ch, bufs):
             out[i] = _HEAD_WF_CACHE[(ws[i].data_ptr(), tuple(ws[i].shape), int(trans[i]))] = b
     return out
@@ -1939,19 +1959,30 @@ def gru_wfrag_t(ws):
     return outs
 
 
-def gru_wfrag_both(ws):
-    """gru_wfrag and gru_wfrag_t of the same weights in one launch -> (forward copies, backward copies)"""
-    n, d = len(ws), ws[0].shape[1]
+def _gru_wfrag_args(ws):
+    n = len(ws)
     of = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
     ob = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
     arr = _ct.c_void_p * n
-    a_w, a_f, a_b = arr(*[w.data_ptr() for w in ws]), arr(*[o.data_ptr() for o in of]), arr(*[o.data_ptr() for o in ob])
-    lib.srec_gru_wfrag_both(n, _ct.addressof(a_w), _ct.addressof(a_f), _ct.addressof(a_b), d, stream())
+    return of, ob, (arr(*[w.data_ptr() for w in ws]), arr(*[o.data_ptr() for o in of]), arr(*[o.data_ptr() for o in ob]))
+
+
+def gru_wfrag_both(ws):
+    """gru_wfrag and gru_wfrag_t of the same weights in one launch -> (forward copies, backward copies) - unless the prologue
+    launch of this forward pass made them (step_prologue)"""
+    hit = [_wprep_take('gru', w) for w in ws]
+    if all(h is not None for h in hit):
+        return [h[0] for h in hit], [h[1] for h in hit]
+    of, ob, args = _gru_wfrag_args(ws)
+    lib.srec_gru_wfrag_both(len(ws), *[_ct.addressof(a) for a in args], ws[0].shape[1], stream())
     return of, ob
 
 
 def gru_wfrag(ws):
     """fragment-major bf16 copies of GRU weights [3 d, d] (the B operands of the fused forward, csrc/gruf.hip), one launch"""
+    hit = [_wprep_take('gru', w) for w in ws]
+    if all(h is not None for h in hit):
+        return [h[0] for h in hit]
     n, d = len(ws), ws[0].shape[1]
     outs = [torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16) for w in ws]
     arr = _ct.c_void_p * n
@@ -2603,18 +2634,26 @@ def rows_bf16(x, dyn=None):
     return out
 
 
-def weights_bf16(ws, transposed=True):
-    """[(W16, WT16)] bf16 copies (and transposed copies) of up to 8 contiguous fp32 matrices, one launch"""
+def _weights_bf16_args(ws, transposed=True):
     n = len(ws)
     assert 0 < n <= 8
     dev = ws[0].device
     w16 = [torch.empty(w.shape, device=dev, dtype=torch.bfloat16) for w in ws]
     wt16 = [torch.empty(w.shape[1], w.shape[0], device=dev, dtype=torch.bfloat16) if transposed else None for w in ws]
     arr = _ct.c_void_p * n
-    a_w, a_16 = arr(*[w.data_ptr() for w in ws]), arr(*[w.data_ptr() for w in w16])      # kept alive across the call
-    a_t = arr(*[(w.data_ptr() if w is not None else None) for w in wt16])
-    a_r, a_c = (_ct.c_int * n)(*[w.shape[0] for w in ws]), (_ct.c_int * n)(*[w.shape[1] for w in ws])
-    lib.srec_weights_bf16(n, _ct.addressof(a_w), _ct.addressof(a_16), _ct.addressof(a_t), _ct.addressof(a_r), _ct.addressof(a_c), stream())
+    return w16, wt16, (arr(*[w.data_ptr() for w in ws]), arr(*[w.data_ptr() for w in w16]),
+                       arr(*[(w.data_ptr() if w is not None else None) for w in wt16]),
+                       (_ct.c_int * n)(*[w.shape[0] for w in ws]), (_ct.c_int * n)(*[w.shape[1] for w in ws]))
+
+
+def weights_bf16(ws, transposed=True):
+    """[(W16, WT16)] bf16 copies (and transposed copies) of up to 8 contiguous fp32 matrices, one launch - unless the prologue
+    launch of this forward pass made them (step_prologue)"""
+    hit = [_wprep_take('w16', w) for w in ws]
+    if all(h is not None and (h[1] is not None or not transposed) for h in hit):
+        return [h[0] for h in hit], [h[1] for h in hit]
+    w16, wt16, args = _weights_bf16_args(ws, transposed)          # (args: kept alive across the call)
+    lib.srec_weights_bf16(len(ws), *[_ct.addressof(a) for a in args], stream())
     return w16, wt16
 
 
@@ -2680,7 +2719,7 @@ class HgPlan:
             for i in range(len(self.insts)):
                 d.Mk[i] = ptr(mk[i]) if mk is not None else None
         d.H, d.D, d.slope, d.B = self.H, self.D, self.slope, self.B
-        d.p16 = int(P[0].dtype == torch.bfloat16) if len(P) else 0
+        d.p16 = int(P[0].dtype == torch.bfloat16) if P else 0          # (P = None: the weight-only view srec_hg_fold reads)
         d.n_types, d.n_mods, d.n_blocks, d.n_inst = len(self.types), len(self.modules), len(self.blocks), len(self.insts)
         d.dynB = ptr(self.dynB)
         for t, (r0, nc, dyn, seg) in enumerate(self.types):
@@ -2688,7 +2727,7 @@ class HgPlan:
         base = small.data_ptr()
         for m in range(len(self.modules)):
             W, al, ar, bias = params[4 * m:4 * m + 4]
-            d.P[m] = ptr(P[m])
+            d.P[m] = ptr(P[m]) if P else None
             d.W[m] = ptr(W)
             d.V[m], d.Z[m] = base + 4 * lay[('V', m)], base + 4 * lay[('Z', m)]
             d.attn_l[m], d.attn_r[m], d.bias[m] = ptr(al), ptr(ar), ptr(bias)
@@ -2715,6 +2754,81 @@ class HgPlan:
 
 
 _HG_WS = {}
+
+
+# ---- the step's prologue launch (csrc/prep.hip) ----------------------------------------------------------------------------
+class StepPrepDesc(_ct.Structure):
+    """host mirror of srec_step_prep_desc (include/srec_hg.h)"""
+    _fields_ = [('hg', _ct.c_void_p), ('n_w16', _ct.c_int), ('w16_W', _ct.c_void_p), ('w16_out', _ct.c_void_p), ('w16_T', _ct.c_void_p),
+                ('w16_R', _ct.c_void_p), ('w16_C', _ct.c_void_p), ('n_gru', _ct.c_int), ('gru_d', _ct.c_int), ('gru_W', _ct.c_void_p),
+                ('gru_fwd', _ct.c_void_p), ('gru_bwd', _ct.c_void_p), ('n_head', _ct.c_int), ('head_W', _ct.c_void_p),
+                ('head_out', _ct.c_void_p), ('head_rows', _ct.c_void_p), ('head_cols', _ct.c_void_p), ('head_trans', _ct.c_void_p),
+                ('mailbox', _ct.c_void_p), ('M', _ct.c_int), ('counter', _ct.c_void_p), ('box_dst', _ct.c_void_p),
+                ('box_cap', _ct.c_long), ('box_err', _ct.c_void_p)]
+
+
+# graph.GraphedTrainStep: the mailbox intake of the step being captured, (mailbox, M, counter, dst, cap, err) as srec_copy_words_mailbox
+# takes them, waiting to leave with the model's prologue launch (or on its own, ahead of the first read of the batch: flush_intake)
+PENDING_INTAKE = []
+STEP_PROLOGUE = os.environ.get('SREC_STEP_PROLOGUE', '1') != '0'     # (tests / A-B runs: 0 = the one-launch-per-reader sequence)
+
+
+def flush_intake():
+    """launch a pending batch intake on its own: called where a model first reads its batch on the device (the lookup) - a model
+    with a prologue launch (MSGIFSR) has taken it along before"""
+    while PENDING_INTAKE:
+        box, M, counter, dst, cap, err = PENDING_INTAKE.pop(0)[:6]
+        lib.srec_copy_words_mailbox(box, M, counter, dst, cap, err, stream())
+
+
+def step_prologue(w16=(), gru=(), head=(), fold=None):
+    """Everything a forward pass does to its WEIGHTS before it reads the first row of its batch, plus a pending batch intake, as
+    ONE launch (srec_step_prep, csrc/prep.hip) instead of one small launch in front of each reader:
+      w16:  fp32 matrices (<= 8) -> bf16 + transposed bf16 copies, taken by weights_bf16 (HGATLayer);
+      gru:  GRU weights [3 d, d] (<= 8) -> both fragment-major layouts, taken by gru_wfrag_both / gru_wfrag (GRUExpandAll);
+      head: [(W, trans)] (<= 16) -> hi / lo fragment-major copies, found by head_wfrag (ReadoutHeadFused) in its per-step cache;
+      fold: (plan, params) of an MSHGNN layer call -> plan.pre = its scratch with V / the bias sums written (HGATLayer).
+    Purely an optimisation: a reader that does not find its copies makes them itself."""
+    q, keep = StepPrepDesc(), []
+    w16 = [w for i, w in enumerate(w16) if all(w is not v for v in w16[:i])][:8]
+    if w16:
+        a16, t16, args = _weights_bf16_args(w16)
+        q.n_w16 = len(w16)
+        q.w16_W, q.w16_out, q.w16_T, q.w16_R, q.w16_C = (_ct.addressof(a) for a in args)
+        keep.append(args)
+    gru = list(gru)[:8]
+    if gru:
+        of, ob, args = _gru_wfrag_args(gru)
+        q.n_gru, q.gru_d = len(gru), gru[0].shape[1]
+        q.gru_W, q.gru_fwd, q.gru_bwd = (_ct.addressof(a) for a in args)
+        keep.append(args)
+    head = [(w, int(t)) for w, t in head if (w.data_ptr(), tuple(w.shape), int(t)) not in _HEAD_WF_CACHE][:16]
+    if head:
+        hb, args = _head_wfrag_args([w for w, _ in head], [t for _, t in head])
+        q.n_head = len(head)
+        q.head_W, q.head_out, q.head_rows, q.head_cols, q.head_trans = (_ct.addressof(a) for a in args)
+        keep.append(args)
+    if fold is not None:
+        plan, params = fold
+        nfl, lay = plan.scratch_layout()
+        small = torch.empty(max(nfl, 1), device=params[0].device, dtype=torch.float32)
+        flat = [p_.reshape(-1) if i % 4 else p_ for i, p_ in enumerate(params)]
+        hd = plan.fill(HgDesc(), small, lay, None, None, flat, None, None)
+        q.hg = _ct.addressof(hd)
+        keep.append((hd, flat))
+    box = PENDING_INTAKE.pop() if PENDING_INTAKE else None           # (one intake rides along; others leave ahead of it)
+    flush_intake()
+    if box is not None:
+        q.mailbox, q.M, q.counter, q.box_dst, q.box_cap, q.box_err = box[:6]
+    lib.srec_step_prep(_ct.addressof(q), stream())
+    for w, a, t in zip(w16, a16 if w16 else (), t16 if w16 else ()):
+        _wprep_put('w16', w, (a, t))
+    for w, f, b_ in zip(gru, of if gru else (), ob if gru else ()):
+        _wprep_put('gru', w, (f, b_))
+    for (w, t), b_ in zip(head, hb if head else ()):
+        _HEAD_WF_CACHE[(w.data_ptr(), tuple(w.shape), t)] = b_
+    if fold is not None:
+        plan.pre = (small, lay)
 
 
 _CNT_CACHE = {}
@@ -2815,12 +2929,18 @@ class HGATLayer(torch.autograd.Function):
         else:
             for m, (r0, nr, dyn) in enumerate(plan.modules):
                 gemm_nt(xin(m)[r0:r0 + nr], _rows(params[4 * m]), P[m], None, dyn, 1 if dyn is not None else 0)
-        nfl, lay = plan.scratch_layout()
-        small = torch.empty(max(nfl, 1), device=dev, dtype=torch.float32)
+        pre = plan.__dict__.pop('pre', None)         # the prologue launch of this forward already folded the weights (step_prologue)
+        if pre is not None:
+            small, lay = pre
+        else:
+            nfl, lay = plan.scratch_layout()
+            small = torch.empty(max(nfl, 1), device=dev, dtype=torch.float32)
         out = torch.empty(NT, D, device=dev, dtype=torch.float32)
         arg = torch.empty(NT, D, device=dev, dtype=torch.uint8)
         flat = [p.reshape(-1) if i % 4 else p for i, p in enumerate(params)]
         desc = plan.fill(HgDesc(), small, lay, P, None, flat, None, dstate)
+        if pre is not None:
+            desc.p16 |= 8
         lib.srec_hg_fwd(_ct.addressof(desc), ptr(x), _ld(x), ptr(out), D, ptr(arg), stream())
         ctx.save_for_backward(x, small, arg, *P, *params)
         ctx.plan, ctx.lay, ctx.grouped, ctx.dstate, ctx.g16 = plan, lay, grouped, dstate, g16

@@ -130,6 +130,7 @@ class _ScoringMixin:
         p = drop.p if isinstance(drop, nn.Dropout) and drop.training else 0.0
         # the device step counter the dropout masks of THIS model's forward are keyed by (ops.rng_args): that of its own
         # FusedAdam, or none (another optimizer: the per-call nonce alone renews the masks)
+        ops.flush_intake()          # (a captured step's batch intake that no prologue launch took along: ahead of the first read)
         W = self._table()
         c = self.__dict__.get('_srec_rng_counter')
         if c is not None and c.device == W.device:

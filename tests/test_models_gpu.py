@@ -741,3 +741,42 @@ def test_projection_fused_into_the_optimizer_equals_the_separate_pass(dev, name,
             close(r1[1], r0[1], rtol=1e-5, atol=1e-8, what='projected table gradient')
     for (k, p), (_, q) in zip(models[1].named_parameters(), models[0].named_parameters()):
         adam_close(p, q, lr=1e-3, steps=3, what=k)
+
+
+@pytest.mark.parametrize('d,dropout,fusion,mode', [(128, 0.0, False, 'bf16'), (256, 0.1, False, 'bf16'), (128, 0.1, True, 'bf16'),
+                                                    (64, 0.0, False, 'bf16'), (32, 0.0, False, 'fp32')])
+def test_step_prologue_launch_changes_nothing(dev, d, dropout, fusion, mode, monkeypatch):
+    """ops.step_prologue (csrc/prep.hip) runs the weight-only work of a step - the k-gram GRUs' and the read-out head's
+    fragment copies, the MSHGNN layer's bf16 weights and folded attention vectors - as roles of ONE launch ahead of the
+    lookup instead of one launch in front of each reader: the same device code on the same inputs, so loss and every gradient
+    must be BIT-identical with the prologue switched off (every reader then makes its own copies, the sequence of rounds 1-5).
+    Covers widths on and off the fused paths (d = 64: no fused GRU / head; fp32 mode: only the fold), the IFR fusion heads and
+    dropout (the masks are keyed by the device counter, not by launch order)."""
+    sp, ops = pkg(), pkg('ops')
+    z, samples, _ = load_golden('msgifsr_K3_s32')
+    K, V = 3, 3429
+    torch.manual_seed(7)
+    model = sp.MSGIFSR(V, 'sample', d, 1, dropout=dropout, order=K, extra=False, fusion=fusion).to(dev).train()
+    (mg,), labels = _collate('msgifsr_K3_s32', samples)
+    mg, labels = mg.to(dev), labels.to(dev)
+
+    def run(on):
+        monkeypatch.setattr(ops, 'STEP_PROLOGUE', on)
+        reseed(11)                                   # the same dropout nonces in both runs
+        ops.weights_changed()
+        model.zero_grad(set_to_none=True)
+        loss = model.fused_loss(mg, labels)
+        loss.backward()
+        assert not ops._WPREP, 'every copy of the prologue launch is taken by its reader: %r' % list(ops._WPREP)
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    ops.set_precision(mode)
+    try:
+        l0, g0 = run(False)
+        l1, g1 = run(True)
+    finally:
+        ops.set_precision('fp32')
+    assert torch.equal(l0, l1), (l0.item(), l1.item())
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k

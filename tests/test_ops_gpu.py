@@ -1555,3 +1555,36 @@ def test_merge_stats_of_the_shards(dev, w, B):
     ref_loss = float(((ref_lse - ref_lab) * live).sum() / max(n, 1))
     assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
     assert torch.equal(gw.cpu() > 0, live) and abs(float(gw.sum()) - (1.0 if n else 0.0)) < 1e-5
+
+
+def test_step_prep_roles_equal_the_single_launches(dev):
+    """srec_step_prep (csrc/prep.hip): the bf16 / transposed copies of fc weights, both fragment layouts of GRU weights and the
+    hi / lo fragment copies of the head's weights as workgroup ranges of ONE launch - bit-identical to srec_weights_bf16,
+    srec_gru_wfrag_both and srec_head_wfrag run one by one (the same role code behind all of them); the bf16 copy itself
+    against torch's round-to-nearest-even, the transposed copy against its transpose, odd shapes included."""
+    ops = _ops()
+    torch.manual_seed(3)
+    w16 = [torch.randn(512, 64, device=dev), torch.randn(1024, 128, device=dev), torch.randn(70, 33, device=dev)]
+    gru = [torch.randn(384, 128, device=dev) for _ in range(4)]
+    head = [(torch.randn(128, 128, device=dev), 0), (torch.randn(128, 256, device=dev), 0), (torch.randn(128, 256, device=dev), 1)]
+    ops.weights_changed()
+    a16, t16 = ops.weights_bf16(w16)
+    gf, gb = ops.gru_wfrag_both(gru)
+    hf = ops.head_wfrag([w for w, _ in head], [t for _, t in head])
+    for w, a, t in zip(w16, a16, t16):
+        assert torch.equal(a, w.to(torch.bfloat16)) and torch.equal(t, a.t().contiguous())
+    ref = [x.clone() for x in a16 + t16 + gf + gb + hf]
+    ops.weights_changed()
+    ops.step_prologue(w16, gru, head)
+    b16, u16 = ops.weights_bf16(w16)                      # taken from the prologue's copies: no launch
+    hf2 = ops.head_wfrag([w for w, _ in head], [t for _, t in head])
+    gf2, gb2 = ops.gru_wfrag_both(gru)
+    assert not ops._WPREP
+    for x, y in zip(ref, b16 + u16 + gf2 + gb2 + hf2):
+        assert x.data_ptr() != y.data_ptr() and torch.equal(x, y)
+    # an in-place update of a weight between the prologue and its reader: the copy is not used
+    ops.step_prologue(w16[:1])
+    w16[0].mul_(2.0)
+    c16, _ = ops.weights_bf16(w16[:1])
+    assert torch.equal(c16[0], w16[0].to(torch.bfloat16))
+    ops.weights_changed()

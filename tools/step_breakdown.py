@@ -19,7 +19,8 @@ def short(k):
     return k[:70]
 
 
-GROUPS = [('scoring', r'flash_ce|ce_reduce|ce_mean|dsr_reduce|bf16_prepare|rownorm_project|row_invnorm|renorm_rows_bf16'),
+GROUPS = [('prologue (weight copies + intake)', r'step_prep'),
+          ('scoring', r'flash_ce|ce_reduce|ce_mean|dsr_reduce|bf16_prepare|rownorm_project|row_invnorm|renorm_rows_bf16'),
           ('adam', r'adam'),
           ('readout head', r'head_fwd|head_bwd|head_wfrag|gemm_f32_group|splitk_reduce_group|seg_attn|cat_cols|normalize_fwd|normalize_bwd'),
           ('bf16 GEMMs (GAT + GRU)', r'gemm_group|gemm16|rows_bf16|weights_bf16|sum_slabs'),
