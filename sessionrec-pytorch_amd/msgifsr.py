@@ -353,8 +353,8 @@ class MSGIFSR(_ScoringMixin, nn.Module):
             multi = self.shard is not None and self.shard.world > 1
             plan, params = layer.plan(mg, d, multi)
             layer._pre = (mg, (d, bool(multi)), (plan, params))
-            fold = (plan, params)
             nm = len(plan.modules)
+            fold = (plan, params) if nm > 0 else None        # (a batch without a live relation: nothing to fold)
             if bf16 and d % 64 == 0 and nm <= 8 and all(params[4 * m].is_contiguous() for m in range(nm)):
                 w16 = [params[4 * m] for m in range(nm)]
         live = range(K) if (K == 1 or self.fusion) else (0,)
