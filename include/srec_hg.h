@@ -230,9 +230,10 @@ typedef struct {
  *   (out), y16 (nullable) [B, ld16] bf16 copy of y (the scoring kernels' operand)
  * X = allf [NT, d] (row stride ld_x; NT = row capacity), seg [B + 1] = first row of every session (seg[live B] = live rows),
  * dynB (nullable) = live sessions; sessions past it get zero rows.  A workgroup owns the sessions that START in its window of
- * SREC_HEAD_ROWS rows, SREC_HEAD_SESSIONS of them per pass.  A session may have at most SREC_MAX_SESSION_NODES rows (srec_limits). */
+ * SREC_HEAD_WINDOW rows, SREC_HEAD_SESSIONS of them per pass, their rows in chunks of SREC_HEAD_ROWS.  A session may have at most SREC_MAX_SESSION_NODES rows (srec_limits). */
 #define SREC_HEAD_SESSIONS 16
 #define SREC_HEAD_ROWS 64
+#define SREC_HEAD_WINDOW 32
 #define SREC_HEAD_MAXH 4
 #define SREC_HEAD_MAXW 16
 typedef struct {

@@ -5,9 +5,11 @@
 //     scoring kernels)
 // As grouped batch-wide launches (ops.ReadoutHead: {U, Vq} GEMM, read-out kernel, {s} GEMM, split-K sum, normalise) these are
 // five latency-bound kernel nodes of ~50 us for 0.9 GFLOP.  Here a workgroup OWNS the sessions that start in its window of
-// HR = 64 rows of the per-session concatenation `allf` (work is dealt by ROWS: 8 consecutive sessions of the bench batch hold
-// 20 - 300 rows, and with one round of workgroups the launch is as long as its longest one) - a session's rows are
-// contiguous - and runs the whole chain on them, HS = 16 sessions per pass:
+// HWIN = 32 rows of the per-session concatenation `allf` (work is dealt by ROWS: 8 consecutive sessions of the bench batch hold
+// 20 - 300 rows, and with one round of workgroups the launch is as long as its longest one; 32-row windows are ~220 workgroups
+// on the 256 CUs at the bench shape - with 64-row windows half of the chip idled: forward 36.8 -> 32.8 us, backward 33.2 ->
+// 29.5 us, medians of 60 replays) - a session's rows are contiguous - and runs the whole chain on them, HS = 16 sessions per
+// pass, their rows in chunks of HR = 64:
 //   * every product is computed TRANSPOSED on the bf16 matrix pipe, D^T = W . X^T with v_mfma_f32_32x32x16_bf16: the A
 //     operand is a 32-column block of the weight, the B operand 32 rows of activations, so the result puts a ROW in the lane
 //     and 16 hidden columns in its registers: the per-row reductions that follow (we . sigmoid(.), |s|^2) are sums over a
@@ -17,8 +19,8 @@
 //     of the bf16 rate on gfx950: three bf16 products cost 3/16 - the kernel is then bound by what feeds the pipe;
 //   * the weights stream from L2 in FRAGMENT-MAJOR hi / lo copies (srec_head_wfrag, once per step: the 64 lanes x 16 B of one
 //     MFMA operand contiguous, ordered wave / k-step / {hi, lo} / column block), plain 1-KiB coalesced loads straight into
-//     the registers that feed the MFMAs through a 4-stage register ring (the idiom of gruf.hip); 64 workgroups x
-//     (Wv 256 KB + ~3 chunks x Wu 256 KB + Wsr 512 KB) ~ 100 MB out of L2 per launch at B = 512, d = 256;
+//     the registers that feed the MFMAs through a 4-stage register ring (the idiom of gruf.hip); ~220 workgroups x
+//     (Wv 256 KB + 1 - 2 chunks x Wu 256 KB + Wsr 512 KB) ~ 250 MB out of L2 per launch at B = 512, d = 256;
 //   * activations (32-row chunks of the group's node rows, the 8 query rows, the [v | g] rows) are split while they are staged
 //     into LDS (row-major bf16, 16-B pieces XOR-swizzled by the row: conflict-free ds_read_b128).
 // Saved for the backward: alpha [NT], cat = [v | g] [B, 2 d], Vq [B, d], y [B, d], 1 / |s| [B]; U only on request (the
@@ -31,7 +33,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int HS = SREC_HEAD_SESSIONS;   // sessions per pass of a workgroup (MFMA columns of the B x d products)
-constexpr int HR = SREC_HEAD_ROWS;       // rows of the per-session concatenation per workgroup window / per chunk (2 MFMA tiles)
+constexpr int HR = SREC_HEAD_ROWS;       // rows of the per-session concatenation per chunk (2 MFMA tiles)
+constexpr int HWIN = SREC_HEAD_WINDOW;   // rows per workgroup window: a workgroup owns the sessions that START in its window
 constexpr int NW = 4;                    // waves per workgroup: wave w owns the hidden / output columns [w d/4, (w+1) d/4)
 constexpr int NS = 4, PF = NS - 1;       // register ring of weight fragments: stages, k-steps in flight
 constexpr int MAXN = SREC_MAX_SESSION_NODES;
@@ -151,10 +154,10 @@ __global__ __launch_bounds__(64 * NW, 1) void head_fwd_kernel(HeadArgs a) {
     unsigned short* Y16 = (unsigned short*)q.y16[hd];
     const int ld16 = q.ld16;
 
-    // this workgroup owns the sessions whose FIRST row lies in its window of HR rows of the per-session concatenation: work
+    // this workgroup owns the sessions whose FIRST row lies in its window of HWIN rows of the per-session concatenation: work
     // is dealt by rows, not by sessions (a group of 8 sessions has 20 - 300 rows in the bench batch).  One pass over seg[]
     // (every thread a few entries, kept in LDS for the rest of the kernel) counts the sessions that start before / inside it
-    const int w0 = (int)blockIdx.x * HR, w1 = w0 + HR;
+    const int w0 = (int)blockIdx.x * HWIN, w1 = w0 + HWIN;
 #ifdef SREC_HEADF_TIMING
     unsigned long long tim_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tim_c = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_headf_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(64 * NW, 1) void head_bwd_kernel(HeadBwdArgs a) {
     const int ld_x = q.ld_x;
     float* dX = q.dX[hd];
     float* dU = q.dU[hd];
-    const int w0 = (int)blockIdx.x * HR, w1 = w0 + HR;
+    const int w0 = (int)blockIdx.x * HWIN, w1 = w0 + HWIN;
     if (tid < 2) cnt[tid] = 0;
     __syncthreads();
     {
@@ -655,7 +658,7 @@ extern "C" int srec_head_fwd(const void* desc, void* stream) {
     const int D = q->d;
     const size_t lds = (size_t)(2 * HR * D + 2 * HS * 2 * D) * 2 + (size_t)(HS * (D + VQ_PAD) + 2 * D + HR + MAXN + NW * HR) * 4 +
                        (size_t)(HS + 1 + HR + 2 + q->B + 1) * 4;
-    const dim3 grid((q->NT + HR - 1) / HR, q->nh);
+    const dim3 grid((q->NT + HWIN - 1) / HWIN, q->nh);
     static std::atomic<unsigned long long> om[2];
     if (D == 256) {
         if (int rc = srec_lds_optin((const void*)head_fwd_kernel<2>, (int)lds, om[0])) return rc;
@@ -683,7 +686,7 @@ extern "C" int srec_head_bwd(const void* desc, void* stream) {
     a.d = *q;
     const int D = q->d;
     const size_t lds = (size_t)(2 * HS * D) * 2 + (size_t)(HS * (D + 8) + HS * D + 3 * (HR + MAXN)) * 4 + (size_t)(HS + 1 + 2 + q->B + 1) * 4;
-    const dim3 grid((q->NT + HR - 1) / HR, q->nh);
+    const dim3 grid((q->NT + HWIN - 1) / HWIN, q->nh);
     static std::atomic<unsigned long long> omb[2];        // (B-dependent dynamic LDS: above 64 KiB it needs the per-device opt-in)
     if (D == 256) {
         if (int rc = srec_lds_optin((const void*)head_bwd_kernel<2>, (int)lds, omb[0])) return rc;
