@@ -287,8 +287,9 @@ int srec_sgat_bwd_src(const float* dout, int ld_o, const float* A, const float* 
  * hyper (device, 8 floats) = {lr/(1-b1^t), beta1, beta2, eps, weight_decay, 1-beta1, 1-beta2, sqrt(1-b2^t)} */
 /* row-sharded item table: global ids (int64; -1 = padding) -> local row of the shard [lo, lo + n_loc) or -1 */
 int srec_localize_idx(const long long* idx, long n, long lo, int n_loc, int* out, void* stream);
-/* int32 ids (padded batches); zero (nullable): n floats cleared by the same launch (the label-logit array of the sharded forward) */
-int srec_localize_idx32(const int* idx, long n, long lo, int n_loc, int* out, float* zero, void* stream);
+/* int32 ids (padded batches); zero (nullable): n - zero_from floats cleared by the same launch (the label-logit array of the sharded
+ * forward: idx = (requested ids | labels) of one exchange, the labels from zero_from on) */
+int srec_localize_idx32(const int* idx, long n, long lo, int n_loc, int* out, float* zero, long zero_from, void* stream);
 
 /* inv[p] = u for the positions p = pos[ptr[u] .. ptr[u+1]) of item u < U (uniq_ptr / uniq_pos of a FlatBatch), -1 elsewhere */
 int srec_inverse_index(const int* ptr, const int* pos, int U, int n, int* inv, void* stream);

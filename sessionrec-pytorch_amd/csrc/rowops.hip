@@ -416,10 +416,10 @@ __global__ void col_sum_final_kernel(const float* __restrict__ part, int ncol, f
 // out[i] = idx[i] - lo when idx[i] is a row of this shard ([lo, lo + n_loc)), else -1 (also for the -1 padding)
 template <typename I>
 __global__ void localize_idx_kernel(const I* __restrict__ idx, long n, long long lo, int n_loc, int* __restrict__ out,
-                                    float* __restrict__ zero = nullptr) {
+                                    float* __restrict__ zero = nullptr, long zero_from = 0) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (zero != nullptr) zero[i] = 0.f;
+    if (zero != nullptr && i >= zero_from) zero[i - zero_from] = 0.f;
     const long long v = (long long)idx[i], r = v - lo;
     out[i] = (v >= 0 && r >= 0 && r < n_loc) ? (int)r : -1;
 }
@@ -905,12 +905,14 @@ extern "C" int srec_localize_idx(const long long* idx, long n, long lo, int n_lo
 }
 
 // the same for int32 ids (the request lists of capacity-padded batches travel as the int32 words they are collated as);
-// zero (nullable) [n] floats cleared by the same launch: the label-logit array of the sharded scoring forward, whose kernels write an
-// entry only where they meet the label (the labels are localised right in front of it: no fill launch of its own)
-extern "C" int srec_localize_idx32(const int* idx, long n, long lo, int n_loc, int* out, float* zero, void* stream) {
+// zero (nullable) [n - zero_from] floats cleared by the same launch: the label-logit array of the sharded scoring forward, whose
+// kernels write an entry only where they meet the label - no fill launch of its own.  zero_from: the list is (requested ids |
+// labels) of ONE exchange, localised together; the label part starts there
+extern "C" int srec_localize_idx32(const int* idx, long n, long lo, int n_loc, int* out, float* zero, long zero_from, void* stream) {
     if (n <= 0) return 0;
+    if (zero_from < 0 || zero_from > n) return SREC_BAD_ARG;
     hipLaunchKernelGGL(localize_idx_kernel<int>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n,
-                       (long long)lo, n_loc, out, zero);
+                       (long long)lo, n_loc, out, zero, zero_from);
     SREC_LAUNCH_CHECK();
     return 0;
 }

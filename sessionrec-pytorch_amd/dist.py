@@ -242,15 +242,15 @@ class HipLocal:
         from . import ops
         self.ops = ops
 
-    def localize(self, idx_all, lo, n_loc, zero=None):
-        """global ids (int64 / int32, -1 padding) -> int32 rows of this shard, -1 elsewhere.  zero: a float array of the same
-        length cleared by the same launch (int32 ids) - else by a fill"""
+    def localize(self, idx_all, lo, n_loc, zero=None, zero_from=0):
+        """global ids (int64 / int32, -1 padding) -> int32 rows of this shard, -1 elsewhere.  zero: a float array as long as the
+        list from entry zero_from on, cleared by the same launch (int32 ids) - else by a fill"""
         from ._lib import lib, ptr, stream
         idx_all = idx_all.contiguous()
         out = torch.empty(idx_all.numel(), device=idx_all.device, dtype=torch.int32)
         if idx_all.dtype == torch.int32:
-            assert zero is None or (zero.numel() == idx_all.numel() and zero.is_contiguous())
-            lib.srec_localize_idx32(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), ptr(zero), stream())
+            assert zero is None or (zero.numel() == idx_all.numel() - zero_from and zero.is_contiguous())
+            lib.srec_localize_idx32(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), ptr(zero), int(zero_from), stream())
         else:
             lib.srec_localize_idx(ptr(idx_all), idx_all.numel(), int(lo), int(n_loc), ptr(out), stream())
             if zero is not None:
@@ -485,10 +485,18 @@ class ShardedLookup(torch.autograd.Function):
             vp._copy_tasks([(pf[r, :ucap], bf[r * ucap:(r + 1) * ucap]) for r in range(w_)] +
                            [(pf[r, ucap:], bf[w_ * ucap + r * nb:w_ * ucap + (r + 1) * nb]) for r in range(w_)])
         else:
+            both = None
             ctx.items_all = packed[:, :ucap].reshape(-1)
             if lab is not None:
                 vp.lab_all = packed[:, ucap:].reshape(-1)
-        ctx.rel = local.localize(ctx.items_all, lo, n_loc)     # local row of every requested item (-1: another rank's); reused by the backward
+        if both is not None and getattr(local, 'takes_gl', False):
+            # requests and labels localised by ONE launch, which also clears the label-logit row of the scoring forward
+            # (ShardedScoreCE takes both from vp.lab_pre: one small launch less in front of it)
+            pair = torch.empty(2, w_ * nb, device=both.device, dtype=torch.float32)
+            rel_both = local.localize(both, lo, n_loc, zero=pair[1], zero_from=w_ * ucap)
+            ctx.rel, vp.lab_pre = rel_both[:w_ * ucap], (rel_both[w_ * ucap:], pair, n_loc, lo)
+        else:
+            ctx.rel = local.localize(ctx.items_all, lo, n_loc)     # local row of every requested item (-1: another rank's); reused by the backward
         rows_all = local.gather_masked(shard, ctx.rel)                                        # [w * ucap, d]
         mine = reduce_scatter_sum(rows_all, group)                                            # [ucap, d]: my items' rows
         ctx.drop = None
@@ -531,12 +539,17 @@ class ShardedScoreCE(torch.autograd.Function):
     """mean CE over the GLOBAL batch (world*B sessions) against the row-sharded catalog."""
 
     @staticmethod
-    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group, lab_all=None, tgrad=None):
+    def forward(ctx, sr, shard, cs, labels, dE, lo, ws, cs_inv_scale, local, group, lab_all=None, tgrad=None, lab_pre=None):
         n_loc = shard.shape[0]
         sr_all = all_gather_cat(sr.contiguous(), group)
         if lab_all is None:                                            # not exchanged with the lookup's request lists
             lab_all = all_gather_cat(labels if labels.dtype == torch.int32 else labels.to(torch.int64), group)
-        if getattr(local, 'takes_gl', False):      # HipLocal: the label-logit row is cleared by the launch that localises the labels
+            lab_pre = None
+        if lab_pre is not None and lab_pre[3] == lo and lab_pre[2] >= n_loc and lab_pre[0].numel() == sr_all.shape[0]:
+            # (the lookup localised against ALL rows of the shard, capacity padding included: no label names a padding row)
+            lab_loc, pair = lab_pre[:2]            # localised (and the label-logit row cleared) by the lookup's launch
+            lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws, pair=pair)
+        elif getattr(local, 'takes_gl', False):      # HipLocal: the label-logit row is cleared by the launch that localises the labels
             pair = torch.empty(2, sr_all.shape[0], device=sr_all.device, dtype=torch.float32)
             lab_loc = local.localize(lab_all, lo, n_loc, zero=pair[1])
             lse_r, lab_logit = local.ce_fwd(sr_all, shard, cs, lab_loc, ws, pair=pair)
@@ -565,7 +578,7 @@ class ShardedScoreCE(torch.autograd.Function):
         else:
             dsr_part = local.stats_bwd(sr_all, shard, cs, lab_loc, lse, g, g, dE, ws, cs_inv_scale, False, **kw)
         dsr = reduce_scatter_sum(dsr_part, group)
-        return (dsr,) + (None,) * 11
+        return (dsr,) + (None,) * 12
 
 
 class ShardedScoreStats(torch.autograd.Function):
@@ -669,7 +682,7 @@ class VocabParallel:
         if inv is None or inv.numel() != n or inv.dtype != torch.int32:
             inv = self.local.inverse_index(uptr, upos, U, n)      # position -> slot of its item in `items`
         uq = (items, uptr[:U + 1], upos) + tuple(uniq[3:])
-        self.lab_all = None
+        self.lab_all = self.lab_pre = None
         rows = ShardedLookup.apply(table, items_pad, inv, uq, self.dE, self.lo, self.local, self.group, self, drop)
         self.labels_hint = None
         return rows
@@ -685,8 +698,9 @@ class VocabParallel:
         lab_all, self.lab_all = self.lab_all, None
         if lab_all is not None and lab_all.numel() != B:
             lab_all = None
+        lab_pre, self.lab_pre = self.__dict__.get('lab_pre'), None
         out = ShardedScoreCE.apply(sr, live, csl, labels, dE, self.lo, self._ws[key], cs_inv_scale, self.local, self.group,
-                                   lab_all, self.tgrad)
+                                   lab_all, self.tgrad, lab_pre if lab_all is not None else None)
         self.tgrad.fresh = True                      # the backward of `out` overwrites every live row of dE
         return out
 
