@@ -193,7 +193,7 @@ def batch_homogeneous(graphs, caps=None):
                      iid=Nc, last=Bc, uniq_items=Uc, uniq_ptr=Uc + 1, uniq_pos=Nc, uniq_inv=Nc, uniq_cptr=Uc + 1,
                      chunk_ptr=Uc + Nc // CHUNK + 2, ew=Ec)
         fcaps = {k: v for k, v in fcaps.items() if k in fields}
-    return FlatBatch.build(fields, counts, meta, fcaps)
+    return FlatBatch.build(_items_last(fields), counts, meta, fcaps)
 
 
 def batch_ccs(graphs, caps=None):
@@ -277,7 +277,7 @@ def batch_ccs(graphs, caps=None):
         for _, name in rel_names:
             fcaps.update({name + '_src': E, name + '_dst': E, name + '_in_idx': E, name + '_out_idx': E,
                           name + '_in_ptr': N + 1, name + '_out_ptr': N + 1})
-    return FlatBatch.build(fields, counts, meta, fcaps)
+    return FlatBatch.build(_items_last(fields), counts, meta, fcaps)
 
 
 # ------------------------------------------------------------------------------------ native builder
@@ -303,6 +303,17 @@ def _native():
     return _NATIVE or None
 
 
+def _items_last(fields):
+    """the distinct-item list is the LAST field of a batch (dict of fields, or list of field names): the labels the loaders write
+    behind the batch then follow it without a gap (capacities are multiples of 4 words), and (items | labels) is one contiguous
+    request list for the row-sharded lookup (dist.ShardedLookup) - no copy launch in the rank step"""
+    if isinstance(fields, dict):
+        if 'uniq_items' in fields:
+            fields['uniq_items'] = fields.pop('uniq_items')
+        return fields
+    return [n for n in fields if n != 'uniq_items'] + (['uniq_items'] if 'uniq_items' in fields else [])
+
+
 _HOMOG_FIELDS = ['seg', 'eseg', 'esrc', 'edst', 'in_ptr', 'in_idx', 'out_ptr', 'out_idx']
 _ITEM_FIELDS = ['iid', 'last', 'uniq_items', 'uniq_ptr', 'uniq_pos', 'uniq_inv', 'uniq_cptr', 'chunk_ptr']
 
@@ -324,7 +335,7 @@ def _ccs_schema(K):
         counts.append('E_' + n)
     names += ['cat_perm', 'cat_inv', 'cat_seg'] + ['lastcat%d' % k for k in range(1, K + 1)]
     counts.append('NT')
-    return names, shapes, counts, rels
+    return _items_last(names), shapes, counts, rels
 
 
 class FlatSeqs:
@@ -360,7 +371,7 @@ def collate_native(kind, seqs, order=1, caps=None, into=None):
     if kind == 'ccs':
         names, shapes, cnames, rels = _ccs_schema(order)
     else:
-        names = list(_HOMOG_FIELDS) + (list(_ITEM_FIELDS) if kind != 'shortcut' else []) + (['ew'] if kind == 'session' else [])
+        names = _items_last(list(_HOMOG_FIELDS) + (list(_ITEM_FIELDS) if kind != 'shortcut' else []) + (['ew'] if kind == 'session' else []))
         shapes, rels = {}, None
         cnames = ['B', 'N', 'E'] + (['U', 'C'] if kind != 'shortcut' else [])
     capv = None if caps is None else np.array([caps['B'], caps['N'], caps['E'], caps['U']], dtype=np.int64)

@@ -119,6 +119,15 @@ struct Builder {
         for (auto& f : fields)
             if (!strcmp(f.first, name)) f.second.cap = c;
     }
+    // the distinct-item list is the LAST field of a batch: the labels the loader writes behind the batch then follow it without a
+    // gap (capacities are multiples of 4 words) and (items | labels) is one contiguous request list for the row-sharded lookup
+    void move_last(const char* name) {
+        for (size_t i = 0; i + 1 < fields.size(); ++i)
+            if (!strcmp(fields[i].first, name)) {
+                std::rotate(fields.begin() + i, fields.begin() + i + 1, fields.end());
+                return;
+            }
+    }
     long emit(int32_t* out, long out_cap, int64_t* info, int max_fields, int* n_fields) {
         long off = HEADER;
         std::vector<long> offs;
@@ -216,6 +225,7 @@ long build_homogeneous(int kind, const int64_t* seqs, const int64_t* offs, int B
         bd.cap("iid", Nc); bd.cap("last", Bc); bd.cap("uniq_items", Uc); bd.cap("uniq_ptr", Uc + 1);
         bd.cap("uniq_pos", Nc); bd.cap("uniq_inv", Nc); bd.cap("uniq_cptr", Uc + 1); bd.cap("chunk_ptr", Uc + Nc / CHUNK + 2); bd.cap("ew", Ec);
     }
+    bd.move_last("uniq_items");
     return bd.emit(out, out_cap, info, max_fields, n_fields);
 }
 
@@ -382,6 +392,7 @@ long build_ccs(const int64_t* seqs, const int64_t* offs, int B, int K, const int
             if (!strcmp(f.first, "r_in_ptr") || !strcmp(f.first, "r_out_ptr")) f.second.cap = N + 1;
         }
     }
+    bd.move_last("uniq_items");
     return bd.emit(out, out_cap, info, max_fields, n_fields);
 }
 

@@ -450,6 +450,13 @@ def _merge_stats(lse_r, lab_logit_r, group, local=None, lab_all=None):
     return torch_merge(torch.logsumexp(st[:, 0], dim=0).contiguous(), st[:, 1].sum(0))
 
 
+def _follows(a, b):
+    """b starts where a ends, in the same storage (two fields of one batch buffer): a | b is then one contiguous list"""
+    return (a.dtype == b.dtype and a.dim() == 1 and b.dim() == 1 and a.is_contiguous() and b.is_contiguous() and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel())
+
+
 class ShardedLookup(torch.autograd.Function):
     """rows = E[idx] with E row-sharded.  Only the DISTINCT items of a rank's batch travel: their ids are all-gathered
     (padded with -1 to a capacity that is equal on all ranks), every rank contributes the rows it owns (zeros elsewhere),
@@ -467,7 +474,10 @@ class ShardedLookup(torch.autograd.Function):
         lab = vp.labels_hint if vp is not None else None
         if lab is not None:
             parts.append(lab if lab.dtype == items_pad.dtype else lab.to(items_pad.dtype))
-        if len(parts) > 1 and vp is not None and items_pad.is_cuda and items_pad.dtype == torch.int32:
+        if len(parts) > 1 and _follows(items_pad, parts[1]):
+            # the batch buffer already holds (distinct items | labels) back to back (collate._items_last): the request list is a view
+            req = items_pad.as_strided((ucap + parts[1].numel(),), (1,), items_pad.storage_offset())
+        elif len(parts) > 1 and vp is not None and items_pad.is_cuda and items_pad.dtype == torch.int32:
             # (ids | labels) into a request buffer by the library's multi-copy launch (no aten concatenation in the rank step)
             req = torch.empty(ucap + parts[1].numel(), device=items_pad.device, dtype=torch.int32)
             vp._copy_tasks([(items_pad.view(torch.float32), req[:ucap].view(torch.float32)),

@@ -602,3 +602,22 @@ def test_c4_sized_ingest_index_caps_and_rank_slices(tmp_path):
               n_sess, n, t_write, t_first, t_cached, t_index, t_caps, t_loader, exact, rss))
     assert seen == 200 and exact <= 20
     assert t_first < 60 and t_cached < 5 and t_index < 30 and t_caps < 10 and t_loader < 30 and rss < 4.0
+
+
+def test_padded_batch_ends_with_the_item_list_and_the_labels():
+    """capacity-padded batches carry (distinct items | labels) back to back at the end of their buffer - both builders, both
+    batch kinds: the row-sharded lookup sends that stretch as its request list without a copy (dist.ShardedLookup)"""
+    c = pkg('collate')
+    rng = np.random.default_rng(5)
+    samples = EDGE + _rand_samples(rng, 30)
+    caps = c.default_caps(64, 15)
+    for fac in (c.collate_fn_factory_ccs((c.seq_to_ccs_graph,), 3, caps), c.collate_fn_factory(c.seq_to_session_graph, caps=caps)):
+        (fb,), lab = fac(samples)
+        (o, cap, _), (lo, n, _) = fb.layout['uniq_items'], fb.layout['labels']
+        assert cap == caps['U'] and o + cap == lo and lo + ((n + 3) & ~3) == fb.buf.numel() and n == caps['B']
+        both = fb.buf[o:lo + n].numpy()
+        U = fb.count('U')
+        assert np.all(both[:U] >= 0) and np.all(np.diff(both[:U]) > 0) and np.all(both[U:cap] == -1)
+        assert np.array_equal(both[cap:], lab.numpy())
+        dist = pkg('dist')
+        assert dist._follows(fb.uniq_items, fb.field('labels'))
