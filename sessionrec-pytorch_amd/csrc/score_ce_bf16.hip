@@ -255,6 +255,17 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
 #ifdef SREC_FLASH_TIMING
     const unsigned long long tim_loop0 = tim_t[7];
 #endif
+    // probe (KO bit 5): the logits come back from memory (fp16, fragment-major: 32 B per lane and chunk, as the forward would have
+    // left them) instead of being recomputed, one chunk ahead; the item-tile role pays 16 two-byte LDS reads for the transposition
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 sv0 = {}, sv1 = {};
+    constexpr bool KO_S = (KO & 32) && KIND == KIND_BWD;
+    const size_t ko_nblk = KO_S ? (size_t)a.n_ranges * a.B * D / (64 * 8) / 2 : 1;        // 1-KiB pairs inside part_dsr
+    auto ko_sload = [&](int c) {
+        const h8* sp = reinterpret_cast<const h8*>(a.part_dsr) + ((((size_t)blockIdx.x * 61 + c) * 4 + wave) % ko_nblk) * 128 + lane * 2;
+        sv0 = sp[0]; sv1 = sp[1];
+    };
+    if (KO_S && nchunks > 0) ko_sload(0);
     for (int c = 0; c < nchunks; ++c) {
         TIM(0);
         const int y0 = ybeg + c * CH;
@@ -287,7 +298,17 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         }
         __syncthreads();                                          // ... everyone's has; chunk c - 1's buffer is free again
         TIM(1);
+        float s_pre[16];
+        if (KO_S) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s_pre[r] = (float)sv0[r]; s_pre[8 + r] = (float)sv1[r]; }
+            if (role_de) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_pre[r] += (float)(smem16 + (c % NSC) * BUF)[(r * 32 + l31v) * 16 + halfv];
+            }
+        }
         if (c + PDC < nchunks) stage(y0 + PDC * CH, (c + PDC) % NSC, lane_v);
+        if (KO_S && c + 1 < nchunks) ko_sload(c + 1);
         TIM(2);
 
         // ---- S^T = Y X^T : 32 streamed rows x 32 owner rows per wave, K = D.  Fragment reads run PF steps ahead of
@@ -295,7 +316,10 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        {
+        if (KO_S) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = s_pre[r];
+        } else {
             constexpr int PF = KS < PFD ? KS : PFD;
             const int hsw = halfv ^ ((l31v >> 3) & 1);
             const unsigned short* ybe = cur + l31v * 16 + hsw * 8;            // even blocks

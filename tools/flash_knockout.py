@@ -1,6 +1,7 @@
 """Development probe: what the fused scoring/CE backward (flash_ce_bf16_kernel<8, 1>, B 512, V 37 484, d 256) would take with
 one of its costs removed - private builds of score_ce_bf16.hip with -DSREC_FLASH_KO=<bits> (bit 0: no exp, 1: no accumulate
-product, 2: no S product, 3: no result stores, 4: MFMA fragments from registers instead of LDS), each timed in its own
+product, 2: no S product, 3: no result stores, 4: MFMA fragments from registers instead of LDS, 5: the logits read back from
+memory as fp16 fragments instead of recomputed - what a forward that STORES them would buy the backward), each timed in its own
 process (HIP events over 20 launches of the merged backward).  Results of a knocked-out build are garbage by construction.
 usage (GPU box): python tools/flash_knockout.py [bits ...]"""
 import glob, importlib, os, subprocess, sys
@@ -49,7 +50,8 @@ if __name__ == '__main__':
         sys.exit(0)
     kos = [int(a) for a in sys.argv[1:]] or [0, 1, 16, 17, 8, 25, 2, 4, 27, 29]
     objs = [o for o in glob.glob(pk + '/csrc/*.o') if not o.endswith('score_ce_bf16.o')]
-    names = {1: 'no exp', 2: 'no accumulate product', 4: 'no S product', 8: 'no stores', 16: 'no LDS fragment reads'}
+    names = {1: 'no exp', 2: 'no accumulate product', 4: 'no S product', 8: 'no stores', 16: 'no LDS fragment reads',
+             32: 'logits read back from memory (fp16 fragments, one chunk ahead) instead of recomputed'}
     for ko in kos:
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DSREC_FLASH_KO=%d' % ko,
                                '-I', root + '/include', '-c', pk + '/csrc/score_ce_bf16.hip', '-o', '/tmp/score_ce_bf16_ko.o'])
