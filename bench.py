@@ -140,10 +140,9 @@ def time_dominant_kernel(model, B, V, d, dev, iters=20, force_fp32=False):
         ops._ce_bwd(sr, table, None, labels, lse, None, None, None, ws, None, tb, dE, dsr, parts)
 
     def bwd_kernel():         # the backward launch alone: session copies already prepared, slabs left unreduced
-        lg = ws.logits(tb.Vp) if getattr(ws, 'logits_key', None) is not None else None      # (left by fwd() for these operands)
         lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), None, ws.Bp, ptr(tb.E16), None, tb.Vp, None,
                                    ptr(labels), ptr(lse), None, None, None, B, V, d, None, ptr(dE), dE.stride(0),
-                                   ptr(ws.dsr_part), ptr(dsr), 3 | 8, ptr(lg), stream())
+                                   ptr(ws.dsr_part), ptr(dsr), 3 | 8, stream())
     fwd()
     out = {}
 

@@ -79,18 +79,13 @@ int srec_score_logp(const float* sr, int ld_sr, const float* E, int ld_e, const 
 int srec_bf16_prepare(const float* src, int ld, int R, const int* dynR, int d, void* dst16, void* dstT16, int Rp,
                       void* stream);
 int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_ranges, int* d_pad);
-/* logits16 (nullable; round 6): Bp x Vp halves in which the forward leaves its logits - the fp16 images of the 32 x 32 MFMA result
- * fragments, block (session block, item chunk) after block - for the backward OF THE SAME OPERANDS, which then reads them back
- * (32 B per lane and block, the item-tile role through a transposing LDS patch) instead of recomputing S in both of its roles:
- * 19.6 of the 39.3 GFLOP the backward executed at the C3 shape were that recomputation.  d_pad 128 / 256 only (ignored elsewhere);
- * relative error of a logit 2^-11, below the bf16 rounding of the probabilities that multiply the operands. */
 int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16, int Vp, const float* cs, const int* labels,
                            int B, int V, int d, const int* dynB, float* ws_stats, float* lab_logit, float* lse,
-                           float* lossvec, float* loss, void* logits16, void* stream);
+                           float* lossvec, float* loss, void* stream);
 int srec_score_ce_bwd_bf16(const void* sr16, float* ws_de, int Bp, const void* E16, const void* ET16, int Vp,
                            const float* cs, const int* labels, const float* lse, const float* gscale, const float* ga,
                            const float* gc, int B, int V, int d, const int* dynB, float* dE, int ld_de, float* ws_dsr,
-                           float* dsr, int parts, const void* logits16, void* stream);
+                           float* dsr, int parts, void* stream);
 /* Session split of the backward's item tiles (round 6; the step a rank of an N-GPU job runs scores N x 512 sessions against V / N
  * table rows: few item tiles, each streaming N x the sessions - train.py:94-101 sharded): srec_ce_de_split(B, V, d, &split): workgroups
  * per item tile at this shape (1 = none).  The caller may pass ws_de (nullable) >= split x V x d floats and the split in `parts`

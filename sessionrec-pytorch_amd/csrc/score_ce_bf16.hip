@@ -86,10 +86,6 @@ struct BArgs {
     int n_de_pad;                // item-tile workgroups (padded to a multiple of 8); 0 = none
     int n_ranges, chunks_per_range, n_sess_tiles;
     int rx_pref[9];              // backward: item ranges are counted per XCD (prefix sums; rx_pref[8] = slots enumerated)
-    // stored logits (ST instantiations): the forward leaves every 32 x 32 block of S^T it computes as the fp16 image of its MFMA
-    // result fragment - block (session block xb, item chunk yc) at ((xb n_ych + yc) 64 + lane) 16 halves, lane = session, registers =
-    // the chunk's items in the k-order above - and the backward reads them back instead of recomputing S in both of its roles
-    _Float16* slog; int n_ych;
 };
 
 enum { KIND_FWD = 0, KIND_BWD = 1, KIND_BWD_G = 2 };
@@ -115,7 +111,7 @@ __device__ unsigned long long g_flash_blk[1024][2];    // wall-clock (s_memrealt
 constexpr int KO = SREC_FLASH_KO;
 #define KO_EXP2(x) ((KO & 1) ? (x) : __builtin_amdgcn_exp2f(x))
 
-template <int NT, int KIND_, bool ST = false>
+template <int NT, int KIND_>
 __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     constexpr int PFD = (NT == 8 && KIND_ != KIND_FWD) ? 2 : 4;   // fragment prefetch depth (D = 256 backward sits at 256 VGPRs)
     constexpr int KIND = KIND_ == KIND_FWD ? KIND_FWD : KIND_BWD;
@@ -130,7 +126,6 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     float* sideGa = reinterpret_cast<float*>(sideI + SB);        // [SB] per-session coefficients (dE, order fusion)
     float* sideGc = sideGa + SB;
     int* sideHit = reinterpret_cast<int*>(sideGc + SB);          // [SB / CH] chunk may contain a label of this item tile (dE)
-    _Float16* tpatch = reinterpret_cast<_Float16*>(sideHit + SB / CH) + (threadIdx.x >> 6) * 1024;   // ST: 2 KiB per wave (item-tile role)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,9 +181,8 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     const int xi = x0 + wave * 32 + l31;                          // this lane's owner row (column of S^T)
 
     // owner rows as MFMA B-fragments of S^T = Y X^T: row xi, k = ks*16 + 8*half .. +7 (padded copy: no masks)
-    constexpr bool RD = ST && KIND == KIND_BWD;                 // this instantiation reads the logits back
     bf16x8 xf[KS];
-    if (!RD) {
+    {
         const unsigned short* xp = X16 + (size_t)xi * D + 8 * half;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + ks * 16);
@@ -261,18 +255,17 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
 #ifdef SREC_FLASH_TIMING
     const unsigned long long tim_loop0 = tim_t[7];
 #endif
-    // ST: fragment images of the logits, 32 B per lane and block.  The backward fetches block c + 1 while it works on block c
-    // (plain loads, issued BEHIND the chunk's LDS-DMA: the vmcnt(0) at the head of the next iteration covers both); the forward
-    // stores block c at the head of iteration c + 1, ahead of that iteration's DMA, so no iteration waits for a fresh store.
+    // probe (KO bit 5): the logits come back from memory (fp16, fragment-major: 32 B per lane and chunk, as the forward would have
+    // left them) instead of being recomputed, one chunk ahead; the item-tile role pays 16 two-byte LDS reads for the transposition
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 sv0 = {}, sv1 = {};
-    h8* const slog8 = reinterpret_cast<h8*>(a.slog);
-    auto sblock = [&](int y0) -> h8* {
-        // session-owner roles: (my session block, item chunk y0 / 32); item-tile role: (session block y0 / 32, my item chunk)
-        const size_t xb = (size_t)(x0 >> 5) + wave, yb = (size_t)(y0 >> 5);
-        return slog8 + ((role_de ? yb * a.n_ych + xb : xb * a.n_ych + yb) * 64 + lane) * 2;
+    constexpr bool KO_S = (KO & 32) && KIND == KIND_BWD;
+    const size_t ko_nblk = KO_S ? (size_t)a.n_ranges * a.B * D / (64 * 8) / 2 : 1;        // 1-KiB pairs inside part_dsr
+    auto ko_sload = [&](int c) {
+        const h8* sp = reinterpret_cast<const h8*>(a.part_dsr) + ((((size_t)blockIdx.x * 61 + c) * 4 + wave) % ko_nblk) * 128 + lane * 2;
+        sv0 = sp[0]; sv1 = sp[1];
     };
-    if (RD && nchunks > 0) { const h8* sp = sblock(ybeg); sv0 = sp[0]; sv1 = sp[1]; }
+    if (KO_S && nchunks > 0) ko_sload(0);
     for (int c = 0; c < nchunks; ++c) {
         TIM(0);
         const int y0 = ybeg + c * CH;
@@ -306,24 +299,16 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         __syncthreads();                                          // ... everyone's has; chunk c - 1's buffer is free again
         TIM(1);
         float s_pre[16];
-        if (RD) {
+        if (KO_S) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s_pre[r] = (float)sv0[r]; s_pre[8 + r] = (float)sv1[r]; }
             if (role_de) {
-                // transposition through a private LDS patch: the stored fragment has lane = session, registers = items; this
-                // role wants lane = item (l31), registers = the chunk's sessions.  Element (session sl, item j) sits in source lane
-                // sl + 32 ((j >> 2) & 1), register (j & 3) + 4 (j >> 3).
-                *reinterpret_cast<h8*>(tpatch + lane_v * 16) = sv0;
-                *reinterpret_cast<h8*>(tpatch + lane_v * 16 + 8) = sv1;
-                const _Float16* tp = tpatch + (32 * ((l31v >> 2) & 1)) * 16 + (l31v & 3) + 4 * (l31v >> 3) + 64 * halfv;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_pre[r] = (float)tp[((r & 3) + 8 * (r >> 2)) * 16];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { s_pre[r] = (float)sv0[r]; s_pre[8 + r] = (float)sv1[r]; }
+                for (int r = 0; r < 16; ++r) s_pre[r] += (float)(smem16 + (c % NSC) * BUF)[(r * 32 + l31v) * 16 + halfv];
             }
         }
-        if (ST && KIND == KIND_FWD && c > 0) { h8* dp = sblock(y0 - CH); dp[0] = sv0; dp[1] = sv1; }
         if (c + PDC < nchunks) stage(y0 + PDC * CH, (c + PDC) % NSC, lane_v);
-        if (RD && c + 1 < nchunks) { const h8* sp = sblock(y0 + CH); sv0 = sp[0]; sv1 = sp[1]; }
+        if (KO_S && c + 1 < nchunks) ko_sload(c + 1);
         TIM(2);
 
         // ---- S^T = Y X^T : 32 streamed rows x 32 owner rows per wave, K = D.  Fragment reads run PF steps ahead of
@@ -331,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        if (RD) {
+        if (KO_S) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = s_pre[r];
         } else {
@@ -358,10 +343,6 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
         }
         TIM(3);
         // register r of s <-> streamed row (r&3) + 8*(r>>2) + 4*half, owner row = xi
-        if (ST && KIND == KIND_FWD) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { sv0[r] = (_Float16)s[r]; sv1[r] = (_Float16)s[8 + r]; }
-        }
         if (KIND == KIND_FWD) {
             const int nvalid = yend - y0 - 4 * half;              // rows >= this are beyond the range
             const int labrel = labL - y0 - 4 * half;
@@ -500,7 +481,6 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
     const unsigned long long tim_loop1 = tim_t[0];
 #endif
 
-    if (ST && KIND == KIND_FWD && nchunks > 0) { h8* dp = sblock(ybeg + (nchunks - 1) * CH); dp[0] = sv0; dp[1] = sv1; }
     if (KIND == KIND_FWD) {
         // the two halves of a wave hold disjoint rows of the same session: merge, one partial per (range, session)
         const float mo = __shfl_xor(m_run, 32, 64), lo = __shfl_xor(l_run, 32, 64);
@@ -572,17 +552,14 @@ __global__ __launch_bounds__(256, 2) void flash_ce_bf16_kernel(BArgs a) {
 #endif
 }
 
-template <int NTV, int KIND, bool ST = false>
+template <int NTV, int KIND>
 int launch_b(const BArgs& a, int nblocks, hipStream_t st) {
-    if (KIND == KIND_BWD && a.ga != nullptr) return launch_b<NTV, KIND == KIND_BWD ? KIND_BWD_G : KIND, ST>(a, nblocks, st);
-    // stored logits: instantiated at the widths whose backward is worth it (d = 128 / 256); elsewhere S is recomputed
-    if (!ST && a.slog != nullptr && (NTV == 8 || NTV == 4)) return launch_b<NTV, KIND, (NTV == 8 || NTV == 4)>(a, nblocks, st);
+    if (KIND == KIND_BWD && a.ga != nullptr) return launch_b<NTV, KIND == KIND_BWD ? KIND_BWD_G : KIND>(a, nblocks, st);
     constexpr int D = NTV * 32;
-    constexpr size_t lds = (size_t)NSC * CH * D * sizeof(unsigned short) + 4 * SB * sizeof(float) + (SB / CH) * sizeof(int) +
-                           (ST && KIND != KIND_FWD ? 4 * 2048 : 0);
+    constexpr size_t lds = (size_t)NSC * CH * D * sizeof(unsigned short) + 4 * SB * sizeof(float) + (SB / CH) * sizeof(int);
     static std::atomic<unsigned long long> optin{0};   // per (kernel instantiation, device)
-    if (int rc = srec_lds_optin((const void*)flash_ce_bf16_kernel<NTV, KIND, ST>, (int)lds, optin)) return rc;
-    hipLaunchKernelGGL((flash_ce_bf16_kernel<NTV, KIND, ST>), dim3(nblocks), dim3(256), lds, st, a);
+    if (int rc = srec_lds_optin((const void*)flash_ce_bf16_kernel<NTV, KIND>, (int)lds, optin)) return rc;
+    hipLaunchKernelGGL((flash_ce_bf16_kernel<NTV, KIND>), dim3(nblocks), dim3(256), lds, st, a);
     SREC_LAUNCH_CHECK();
     return 0;
 }
@@ -732,16 +709,12 @@ extern "C" int srec_ce_plan_bf16(int B, int V, int d, int* n_stat_slabs, int* n_
 }
 
 // sr16 [Bp, Dp], E16 [Vp, Dp] from srec_bf16_prepare.  Outputs as srec_score_ce_fwd.
-// logits16 (nullable): Bp x Vp halves - the forward leaves its logits there (fp16 images of the MFMA result fragments) for a
-// srec_score_ce_bwd_bf16 of the SAME operands, which then reads them back instead of recomputing them in both of its roles
-// (d padded to 128 / 256; ignored at other widths: the backward recomputes)
 extern "C" int srec_score_ce_fwd_bf16(const void* sr16, int Bp, const void* E16, int Vp, const float* cs,
                                       const int* labels, int B, int V, int d, const int* dynB, float* ws_stats,
-                                      float* lab_logit, float* lse, float* lossvec, float* loss, void* logits16, void* stream) {
+                                      float* lab_logit, float* lse, float* lossvec, float* loss, void* stream) {
     if (bad_d(d) || (Bp & 127) || (Vp & 127) || Bp < B || Vp < V) return SREC_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     BArgs a{};
-    a.slog = (_Float16*)logits16; a.n_ych = Vp / CH;
     a.S16 = (const unsigned short*)sr16; a.E16 = (const unsigned short*)E16; a.Bp = Bp; a.Vp = Vp;
     a.cs = cs; a.labels = labels; a.dynB = dynB; a.B = B; a.V = V; a.d = d;
     a.n_sess_tiles = cdiv(B, OWN);
@@ -772,12 +745,11 @@ extern "C" int srec_score_ce_bwd_bf16(const void* sr16, float* ws_de, int Bp, co
                                       int Vp, const float* cs, const int* labels, const float* lse,
                                       const float* gscale, const float* ga, const float* gc, int B, int V, int d,
                                       const int* dynB, float* dE, int ld_de, float* ws_dsr, float* dsr, int parts,
-                                      const void* logits16, void* stream) {
+                                      void* stream) {
     if (bad_d(d) || (Bp & 127) || (Vp & 127) || Bp < B || Vp < V) return SREC_BAD_ARG;
     if (!(parts & 3)) return 0;
     hipStream_t st = (hipStream_t)stream;
     BArgs a{};
-    a.slog = (_Float16*)logits16; a.n_ych = Vp / CH;       // (what srec_score_ce_fwd_bf16 left for these operands, or NULL)
     a.S16 = (const unsigned short*)sr16; a.ST16 = nullptr; a.Bp = Bp;
     a.E16 = (const unsigned short*)E16; a.ET16 = (const unsigned short*)ET16; a.Vp = Vp;
     a.cs = cs; a.labels = labels; a.lse = lse; a.gscale = gscale; a.ga = ga; a.gc = gc; a.dynB = dynB;

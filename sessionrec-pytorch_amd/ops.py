@@ -1510,24 +1510,6 @@ def _ce_de_slabs(self, B, V, d):
 
 CEWorkspace.de_slabs = _ce_de_slabs
 
-LOGITS_MAX_BYTES = 1 << 29       # stored logits (Bp x Vp halves) beyond this stay recomputed: they should live in the 256 MB memory-side cache
-
-
-def _ce_logits(self, Vp):
-    """Bp x Vp halves the bf16 scoring forward leaves its logits in for its backward (srec_score_ce_fwd_bf16 logits16), or
-    None where the kernels recompute them (other widths, very large batch x catalogue products)"""
-    if self.sr16 is None or self.sr16.shape[1] not in (128, 256) or 2 * self.Bp * Vp > LOGITS_MAX_BYTES:
-        return None
-    buf = self.__dict__.get('_logits')
-    if buf is None or buf.numel() < self.Bp * Vp:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('the scoring workspace must be sized by an eager warm-up step before graph capture')
-        buf = self._logits = torch.empty(self.Bp * Vp, device=self.stats.device, dtype=torch.float16)
-    return buf
-
-
-CEWorkspace.logits = _ce_logits
-
 
 class TableBF16:
     """bf16 copy of the item table for the bf16 scoring kernels: E16 [Vp, d_pad] (row-major only: the backward takes its
@@ -1569,13 +1551,6 @@ def _prepare_sr(sr, ws, dynB):
         ws.sr_key = key
 
 
-STORE_LOGITS = os.environ.get('SREC_STORE_LOGITS', '1') != '0'     # (tests / A-B runs: 0 = the backward recomputes the logits)
-
-
-def _logits_key(sr, table, cs, B, V):
-    return (sr.data_ptr(), sr._version, table.data_ptr(), table._version, None if cs is None else cs.data_ptr(), B, V)
-
-
 def _ce_fwd(sr, table, cs, labels, ws, dynB, tb, lab, lse, lossvec, loss):
     B, d = sr.shape
     V = table.shape[0]
@@ -1586,12 +1561,8 @@ def _ce_fwd(sr, table, cs, labels, ws, dynB, tb, lab, lse, lossvec, loss):
             ws.sr_key = None
             _prepare_sr(sr, ws, dynB)
         ws.sr_fresh = None
-        # the forward leaves its logits (fp16 fragment images) for its backward, which then does not recompute them (a forward-only
-        # call pays ~6 us of stores for nothing: every caller of this function is a training loss)
-        lg = ws.logits(tb.Vp) if STORE_LOGITS else None
-        ws.logits_key = _logits_key(sr, table, cs, B, V) if lg is not None else None
         lib.srec_score_ce_fwd_bf16(ptr(ws.sr16), ws.Bp, ptr(tb.E16), tb.Vp, ptr(cs), ptr(labels), B, V, d, ptr(dynB),
-                                   ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), ptr(lg), stream())
+                                   ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
     else:
         lib.srec_score_ce_fwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), B, V, d, ptr(dynB),
                               ptr(ws.stats), ptr(lab), ptr(lse), ptr(lossvec), ptr(loss), stream())
@@ -1605,11 +1576,9 @@ def _ce_bwd(sr, table, cs, labels, lse, gl, ga, gc, ws, dynB, tb, dE, dsr, parts
         # many sessions against few table rows (a rank's shard scored for the sessions of ALL ranks): the item tiles of the
         # backward are split over the sessions, slabs in a workspace the split decides the size of (srec_ce_de_split)
         split, slabs = ws.de_slabs(B, V, d) if (parts & 1) and dE.stride(0) == d else (1, None)
-        # the logits the forward of exactly these operands left behind (anything else in the buffer: recompute)
-        lg = ws.logits(tb.Vp) if (getattr(ws, 'logits_key', None) is not None and ws.logits_key == _logits_key(sr, table, cs, B, V)) else None
         lib.srec_score_ce_bwd_bf16(ptr(ws.sr16), ptr(slabs), ws.Bp, ptr(tb.E16), None, tb.Vp, ptr(cs),
                                    ptr(labels), ptr(lse), ptr(gl), ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE),
-                                   dE.stride(0), ptr(ws.dsr_part), ptr(dsr), parts | (split << 8), ptr(lg), stream())
+                                   dE.stride(0), ptr(ws.dsr_part), ptr(dsr), parts | (split << 8), stream())
     else:
         lib.srec_score_ce_bwd(ptr(sr), _ld(sr), ptr(table), table.stride(0), ptr(cs), ptr(labels), ptr(lse), ptr(gl),
                               ptr(ga), ptr(gc), B, V, d, ptr(dynB), ptr(dE), dE.stride(0), ptr(ws.dsr_part), ptr(dsr),
