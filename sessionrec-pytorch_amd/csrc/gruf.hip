@@ -25,6 +25,7 @@
 #include <type_traits>
 
 extern "C" int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes);      // grufb.hip
+extern "C" int srec_gru_fused_wide(int np, const int* n, const int* k, int* mask);   // grufb.hip: problems (in launch order) that take 32-node tiles
 extern "C" int srec_gru_fused_waves(int d, int* waves);
 
 namespace {
@@ -37,6 +38,7 @@ constexpr int NS = 4, PF = NS - 1; // register ring: stages, k-steps of B fragme
 struct FusedArgs {
     srec_gru_fused_desc d;
     int start[GF_MAXP + 1];
+    int wide;                      // mixed launch: bit p = problem p runs in 32-node workgroups (the others in 16-node ones)
 };
 
 #ifdef SREC_GRUF_TIMING   // development probe (tools/gruf_timing.py): phase clocks of wave 0 of one workgroup, workgroup lives
@@ -55,7 +57,7 @@ __device__ unsigned long long g_gruf_blk[1024][2];
 // NW: waves per workgroup, 4 or 8 (D = 256 only).  With 8 each wave owns d / 8 = 32 columns (one block): the same weight bytes
 // per node as with 4, half the gate epilogue per wave and twice the loads in flight for the k-loop; 256 registers per wave.
 template <int DD, int NR, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_kernel(FusedArgs a) {
+__device__ __forceinline__ void gru_fused_fwd_body(const FusedArgs& a) {
     constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;   // JB: 32-column blocks per wave
     constexpr int KS = D / 16, NF = 3 * JB;
     constexpr int NRR = NR / 2;                  // accumulator registers per block that hold live nodes (rows (r&3) + 8 (r>>2) + 4 half)
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_kernel(FusedArgs a) 
 // (MFMA result layout: registers 8 (t & 1) .. + 7 of tile t >> 1 hold the 16 nodes of step t); the recurrent half and the gate
 // epilogue are those of gru_fused_fwd_kernel (r / z pre-activations = gi + gh, two chains added instead of one chain).
 template <int DD, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd16_kernel(FusedArgs a) {
+__device__ __forceinline__ void gru_fused_fwd16_body(const FusedArgs& a) {
     constexpr int NR = 16;
     constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;
     constexpr int KS = D / 16, NF = 3 * JB, NRR = NR / 2;
@@ -530,6 +532,27 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd16_kernel(FusedArgs a
     }
 }
 
+template <int DD, int NR, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_kernel(FusedArgs a) { gru_fused_fwd_body<DD, NR, NW>(a); }
+
+template <int DD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd16_kernel(FusedArgs a) { gru_fused_fwd16_body<DD, NW>(a); }
+
+// Mixed launch: the long problems in 16-node workgroups (gru_fused_fwd16_body: the projections of all steps batched), the SHORT
+// ones (a.wide) in 32-node workgroups (gru_fused_fwd_body) - half as many of them.  A workgroup takes a CU for itself (registers)
+// and lives as long as its weight stream whatever its node count: with every problem in 16-node tiles the bench batches have 250 -
+// 280 live workgroups for 256 CUs, and the ~45 % of them above 256 ran a second round (forward 26 -> 37 us, backward 34 -> 46 us:
+// profiles/r05_notes.md 5, r06_kernel_spread.txt); with the order-2 problem in 32-node tiles every batch is one round.
+template <int DD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_fwd_mixed_kernel(FusedArgs a) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < GF_MAXP; ++i)
+        if (i < a.d.np && (int)blockIdx.x >= a.start[i]) p = i;
+    if ((a.wide >> p) & 1) gru_fused_fwd_body<DD, 32, NW>(a);
+    else gru_fused_fwd16_body<DD, NW>(a);
+}
+
 struct WfArgs {
     int d, jb;
     const float* W[2 * GF_MAXP];
@@ -619,8 +642,11 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
     bool batch = NRv == 16;                      // gru_fused_fwd16_kernel holds the projections of <= 4 time steps
     for (int p = 0; p < q->np; ++p) batch = batch && q->k[p] <= 4;
     if (NRv == 16) {
+        // one round of the chip: while the 16-node tiles of all problems exceed the CUs, the shortest problems go to 32-node tiles
+        if (batch)
+            if (int rc = srec_gru_fused_wide(q->np, q->n, q->k, &a.wide)) return rc;
         blocks = 0;
-        for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + 15) / 16; }
+        for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + (((a.wide >> p) & 1) ? 31 : 15)) / (((a.wide >> p) & 1) ? 32 : 16); }
     }
     a.start[q->np] = blocks;
     for (int p = q->np + 1; p <= GF_MAXP; ++p) a.start[p] = blocks;
@@ -635,7 +661,18 @@ extern "C" int srec_gru_fused_fwd(const void* desc, void* stream) {
         if (int rc = srec_lds_optin((const void*)gru_fused_fwd_kernel<DDV, NRV, NWV>, (int)lds, om[slot])) return rc;  \
         hipLaunchKernelGGL((gru_fused_fwd_kernel<DDV, NRV, NWV>), dim3(blocks), dim3(64 * NWV), lds, (hipStream_t)stream, a); \
     } while (0)
-    if (batch) {
+    if (batch && a.wide) {
+        const size_t lds16 = (size_t)(96 * D) * 2 + (size_t)NWv * 16 * 40 * 4, lds32 = (size_t)(2 * RT * D) * 2 + (size_t)NWv * 32 * 40 * 4;
+        const size_t ldsm = lds16 > lds32 ? lds16 : lds32;
+        static std::atomic<unsigned long long> omm[2];
+        if (D == 256) {
+            if (int rc = srec_lds_optin((const void*)gru_fused_fwd_mixed_kernel<2, 8>, (int)ldsm, omm[0])) return rc;
+            hipLaunchKernelGGL((gru_fused_fwd_mixed_kernel<2, 8>), dim3(blocks), dim3(64 * 8), ldsm, (hipStream_t)stream, a);
+        } else {
+            if (int rc = srec_lds_optin((const void*)gru_fused_fwd_mixed_kernel<1, 4>, (int)ldsm, omm[1])) return rc;
+            hipLaunchKernelGGL((gru_fused_fwd_mixed_kernel<1, 4>), dim3(blocks), dim3(64 * 4), ldsm, (hipStream_t)stream, a);
+        }
+    } else if (batch) {
         const size_t lds16 = (size_t)(96 * D) * 2 + (size_t)NWv * 16 * 40 * 4;
         if (D == 256) {
             if (int rc = srec_lds_optin((const void*)gru_fused_fwd16_kernel<2, 8>, (int)lds16, om[0])) return rc;

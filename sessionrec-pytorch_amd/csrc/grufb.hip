@@ -32,6 +32,7 @@ constexpr int NS = 4, PF = NS - 1; // register ring: stages, k-steps of B fragme
 struct BwdArgs {
     srec_gru_fused_bwd_desc d;
     int start[GB_MAXP + 1];
+    int wide;                      // mixed launch: bit p = problem p runs in 32-node workgroups (gruf.hip)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -48,7 +49,7 @@ __device__ unsigned long long g_grub_blk[1024][2];
 // NR: nodes per workgroup, 32 or 16 (16: the lower half of every 32-row MFMA tile idles - see gruf.hip)
 // NW: waves per workgroup, 4 or 8 (D = 256; each wave then owns d / 8 = 32 output columns of both products - see gruf.hip)
 template <int DD, int NR, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
+__device__ __forceinline__ void gru_fused_bwd_body(const BwdArgs& a) {
     constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;   // JB: 32-column blocks per wave
     constexpr int KS = D / 16, TPR = D / 4, RPP = NT / TPR, NP = NR / RPP;
     static_assert(NP >= 2 && NP % 2 == 0, "phase E fetches its rows in two halves");
@@ -79,7 +80,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) {
     unsigned short* dGI16 = (unsigned short*)q.dGI16[p];
     unsigned short* dGH16 = (unsigned short*)q.dGH16[p];
     float* dX = q.dX[p];
-    float* part = q.bias_part[p] + (size_t)(q.part_row0[p] + tile) * 6 * D;
+    // (mixed launch, a.wide: the caller sized bias_part with one row per 16 nodes - this workgroup's sums go to row 2 tile and
+    //  row 2 tile + 1, when the problem has it, is zero)
+    const bool twin = NR == 32 && ((a.wide >> p) & 1);
+    float* part = q.bias_part[p] + (size_t)(q.part_row0[p] + (twin ? 2 * tile : tile)) * 6 * D;
+    if (twin && (2 * tile + 1) * 16 < n)
+        for (int i = threadIdx.x; i < 6 * D; i += NT) part[6 * D + i] = 0.f;
     const int erow = tid / TPR, ec = (tid % TPR) * 4;           // phase E: this thread's row (per pass) and 4 columns
 
     if (node0 >= nl) {                           // capacity padding: zero operands and gradients, no arithmetic
@@ -367,7 +373,7 @@ __device__ __forceinline__ void stnt4(float* p, float4 v) {
 // d x rows of all steps: k passes over the weights instead of 2 k - 1, (k - 1) + ceil(k / 2) MFMA tiles per k-step instead of
 // 2 k - 1.  The patches of the d x store and the bias reduction reuse the d(gi) tiles once they are dead.
 template <int DD, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) {
+__device__ __forceinline__ void gru_fused_bwd16_body(const BwdArgs& a) {
     constexpr int NR = 16, KMAX = 4;
     constexpr int D = 128 * DD, JB = D / (32 * NW), NT = 64 * NW;
     constexpr int KS = D / 16, TPR = D / 4, RPP = NT / TPR, NP = NR / RPP;
@@ -710,6 +716,23 @@ __global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) 
 extern "C" int srec_gru_fused_waves(int d, int* waves);
 namespace {
 
+template <int DD, int NR, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_kernel(BwdArgs a) { gru_fused_bwd_body<DD, NR, NW>(a); }
+
+template <int DD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd16_kernel(BwdArgs a) { gru_fused_bwd16_body<DD, NW>(a); }
+
+// mixed launch (see gru_fused_fwd_mixed_kernel, gruf.hip): the problems of a.wide in 32-node workgroups, the others in 16-node ones
+template <int DD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_fused_bwd_mixed_kernel(BwdArgs a) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < GB_MAXP; ++i)
+        if (i < a.d.np && (int)blockIdx.x >= a.start[i]) p = i;
+    if ((a.wide >> p) & 1) gru_fused_bwd_body<DD, 32, NW>(a);
+    else gru_fused_bwd16_body<DD, NW>(a);
+}
+
 struct WfbArgs {
     int d, jb;
     const float* W[2 * GB_MAXP];
@@ -784,6 +807,35 @@ extern "C" int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes) {
     return 0;
 }
 
+// Mixed launches (16-node workgroups, every problem with k <= 4): which problems - given in LAUNCH order, longest first - take
+// 32-node tiles so that the workgroups of one launch are at most one per CU: the shortest first, as many as it takes.  Decided on
+// the CAPACITIES (the launch shape of a captured step is fixed): at the bench shape 160 + 160 sixteen-node tiles become 160 + 80.
+extern "C" int srec_gru_fused_wide(int np, const int* n, const int* k, int* mask) {
+    if (np < 0 || np > GB_MAXP || (np > 0 && (n == nullptr || k == nullptr)) || mask == nullptr) return SREC_BAD_ARG;
+    *mask = 0;
+    int cus = 256;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    static const char* env = getenv("SREC_GRU_MIXED");           // development: 0 = never widen (A / B)
+    if (env != nullptr && atoi(env) == 0) return 0;
+    for (int p = 0; p < np; ++p)
+        if (k[p] > 4) return 0;                                  // (the 16-node kernels of the mixed launch hold <= 4 time steps)
+    int tiles = 0, wide = 0;
+    for (int p = 0; p < np; ++p) tiles += (n[p] + 15) / 16;
+    while (tiles > cus) {
+        int best = -1;
+        for (int p = 0; p < np; ++p)
+            if (!((wide >> p) & 1) && n[p] > 16 && (best < 0 || k[p] < k[best] || (k[p] == k[best] && n[p] > n[best]))) best = p;
+        if (best < 0) break;
+        wide |= 1 << best;
+        tiles -= (n[best] + 15) / 16 - (n[best] + 31) / 32;
+    }
+    *mask = wide;
+    return 0;
+}
+
 // Workgroups start in index order and an order-k workgroup lives ~k time steps: with more live workgroups than CUs (one per CU:
 // the d(gi) tiles fill most of the LDS) the ones that wait start when the first residents retire.  Longest problems first: the
 // late starters are then the SHORT ones, behind the first short residents (measured on the C3 batches whose live 16-node tiles
@@ -823,9 +875,14 @@ extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
     // one row per 16 nodes is always enough)
     int NRv = 32;
     if (int rc = srec_gru_fused_nodes(q->np, q->n, q->d, &NRv)) return rc;
+    bool batch = NRv == 16;                      // gru_fused_bwd16_kernel holds the d(gi) rows of <= 4 time steps
+    for (int p = 0; p < q->np; ++p) batch = batch && q->k[p] <= 4;
+    static const bool no16 = getenv("SREC_GRU_BWD16") != nullptr && atoi(getenv("SREC_GRU_BWD16")) == 0;   // development: A / B
     if (NRv == 16) {
+        if (batch && !no16)                                                          // (the same choice as the forward's)
+            if (int rc = srec_gru_fused_wide(q->np, q->n, q->k, &a.wide)) return rc;
         blocks = 0;
-        for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + 15) / 16; }
+        for (int p = 0; p < q->np; ++p) { a.start[p] = blocks; blocks += (q->n[p] + (((a.wide >> p) & 1) ? 31 : 15)) / (((a.wide >> p) & 1) ? 32 : 16); }
     }
     for (int p = q->np; p <= GB_MAXP; ++p) a.start[p] = blocks;
     if (blocks == 0) return 0;
@@ -840,9 +897,20 @@ extern "C" int srec_gru_fused_bwd(const void* desc, void* stream) {
         if (int rc = srec_lds_optin((const void*)gru_fused_bwd_kernel<DDV, NRV, NWV>, (int)lds, om[slot])) return rc;  \
         hipLaunchKernelGGL((gru_fused_bwd_kernel<DDV, NRV, NWV>), dim3(blocks), dim3(64 * NWV), lds, (hipStream_t)stream, a); \
     } while (0)
-    bool batch = NRv == 16;                      // gru_fused_bwd16_kernel holds the d(gi) rows of <= 4 time steps
-    for (int p = 0; p < q->np; ++p) batch = batch && q->k[p] <= 4;
-    static const bool no16 = getenv("SREC_GRU_BWD16") != nullptr && atoi(getenv("SREC_GRU_BWD16")) == 0;   // development: A / B
+    if (batch && !no16 && a.wide) {
+        const size_t lds16 = (size_t)(16 * 4 * 3 * D) * 2 + (size_t)16 * D * 2 + (size_t)16 * (D + 8) * 4;
+        const size_t ldsm = lds16 > lds ? lds16 : lds;
+        static std::atomic<unsigned long long> omm[2];
+        if (D == 256) {
+            if (int rc = srec_lds_optin((const void*)gru_fused_bwd_mixed_kernel<2, 8>, (int)ldsm, omm[0])) return rc;
+            hipLaunchKernelGGL((gru_fused_bwd_mixed_kernel<2, 8>), dim3(blocks), dim3(64 * 8), ldsm, (hipStream_t)stream, a);
+        } else {
+            if (int rc = srec_lds_optin((const void*)gru_fused_bwd_mixed_kernel<1, 4>, (int)ldsm, omm[1])) return rc;
+            hipLaunchKernelGGL((gru_fused_bwd_mixed_kernel<1, 4>), dim3(blocks), dim3(64 * 4), ldsm, (hipStream_t)stream, a);
+        }
+        SREC_LAUNCH_CHECK();
+        return 0;
+    }
     if (batch && !no16) {
         const size_t lds16 = (size_t)(16 * 4 * 3 * D) * 2 + (size_t)16 * D * 2 + (size_t)16 * (D + 8) * 4;
         static std::atomic<unsigned long long> om16[2];

@@ -1588,3 +1588,23 @@ def test_step_prep_roles_equal_the_single_launches(dev):
     c16, _ = ops.weights_bf16(w16[:1])
     assert torch.equal(c16[0], w16[0].to(torch.bfloat16))
     ops.weights_changed()
+
+
+def test_gru_mixed_launch_plan(dev):
+    """srec_gru_fused_wide: which k-gram problems of a fused GRU launch take 32-node workgroups so that the launch is one round
+    of the chip (at most one workgroup per CU) - the shortest first, none while the 16-node tiles fit or when an order exceeds
+    the 16-node kernels' 4 time steps; the benchmarked capacities (2560 nodes of order 3 and of order 2) widen order 2 only."""
+    import ctypes as ct
+    L = importlib.import_module('sessionrec-pytorch_amd._lib')
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+
+    def wide(ns, ks):
+        m, a_n, a_k = ct.c_int(-1), (ct.c_int * len(ns))(*ns), (ct.c_int * len(ks))(*ks)      # (kept alive across the call)
+        L.lib.srec_gru_fused_wide(len(ns), ct.addressof(a_n), ct.addressof(a_k), ct.addressof(m))
+        return m.value
+
+    assert wide([2560, 2560], [3, 2]) == 0b10                 # 160 + 160 tiles -> 160 + 80
+    assert wide([1000, 1000], [3, 2]) == 0                    # 63 + 63 tiles fit
+    assert wide([16 * cus, 16], [3, 2]) == 0b01               # the short problem cannot shrink (one tile): the long one does
+    assert wide([4000, 4000, 4000], [4, 3, 2]) == 0b111       # 750 tiles: every problem, still more than one round
+    assert wide([2560, 2560], [5, 2]) == 0                    # order 5: not a launch of the 16-node kernels
