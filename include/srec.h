@@ -439,7 +439,7 @@ int srec_gru_fused_bwd(const void* desc, void* stream);
 int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes);
 /* mixed launches (round 6): with 16-node workgroups and every k[p] <= 4, the problems - in LAUNCH order: longest k first, as both
  * launchers sort them - whose workgroups hold 32 nodes instead, so that one launch is at most one workgroup per CU (bit p of
- * *mask; the shortest problems first; 0 = none).  A workgroup of the fused kernels owns a CU and lives as long as its weight
+ * *mask; the shortest problems first, never those of the longest order - their 16-node kernel batches the input projections; 0 = none).  A workgroup of the fused kernels owns a CU and lives as long as its weight
  * stream whatever its node count: the bench batches (250 - 280 live 16-node tiles on 256 CUs) ran a second round on ~45 % of the
  * steps.  bias_part keeps one row per 16 nodes: a 32-node workgroup writes row 2 t and zeroes row 2 t + 1. */
 int srec_gru_fused_wide(int np, const int* n, const int* k, int* mask);

@@ -822,12 +822,16 @@ extern "C" int srec_gru_fused_wide(int np, const int* n, const int* k, int* mask
     if (env != nullptr && atoi(env) == 0) return 0;
     for (int p = 0; p < np; ++p)
         if (k[p] > 4) return 0;                                  // (the 16-node kernels of the mixed launch hold <= 4 time steps)
-    int tiles = 0, wide = 0;
-    for (int p = 0; p < np; ++p) tiles += (n[p] + 15) / 16;
+    // ... but never the longest order: its 16-node kernel batches the input projections of all steps (k weight passes), the 32-node
+    // one streams 2 k - 1 - a launch with every order in 32-node tiles is slower than a second round of short 16-node ones (the
+    // end-to-end loop's capacities, 192 + 192 tiles: 0.783 -> 0.800 ms per batch when both orders widened).  The count is taken on
+    // the capacities, the live tiles are fewer.
+    int tiles = 0, wide = 0, kmax = 0;
+    for (int p = 0; p < np; ++p) { tiles += (n[p] + 15) / 16; kmax = k[p] > kmax ? k[p] : kmax; }
     while (tiles > cus) {
         int best = -1;
         for (int p = 0; p < np; ++p)
-            if (!((wide >> p) & 1) && n[p] > 16 && (best < 0 || k[p] < k[best] || (k[p] == k[best] && n[p] > n[best]))) best = p;
+            if (!((wide >> p) & 1) && n[p] > 16 && k[p] < kmax && (best < 0 || k[p] < k[best] || (k[p] == k[best] && n[p] > n[best]))) best = p;
         if (best < 0) break;
         wide |= 1 << best;
         tiles -= (n[best] + 15) / 16 - (n[best] + 31) / 32;

@@ -1592,8 +1592,8 @@ def test_step_prep_roles_equal_the_single_launches(dev):
 
 def test_gru_mixed_launch_plan(dev):
     """srec_gru_fused_wide: which k-gram problems of a fused GRU launch take 32-node workgroups so that the launch is one round
-    of the chip (at most one workgroup per CU) - the shortest first, none while the 16-node tiles fit or when an order exceeds
-    the 16-node kernels' 4 time steps; the benchmarked capacities (2560 nodes of order 3 and of order 2) widen order 2 only."""
+    of the chip (at most one workgroup per CU) - the shortest first and never the longest order, none while the 16-node tiles fit or
+    when an order exceeds the 16-node kernels' 4 time steps; the benchmarked capacities (2560 nodes of order 3 and of order 2) widen order 2 only."""
     import ctypes as ct
     L = importlib.import_module('sessionrec-pytorch_amd._lib')
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -1605,6 +1605,7 @@ def test_gru_mixed_launch_plan(dev):
 
     assert wide([2560, 2560], [3, 2]) == 0b10                 # 160 + 160 tiles -> 160 + 80
     assert wide([1000, 1000], [3, 2]) == 0                    # 63 + 63 tiles fit
-    assert wide([16 * cus, 16], [3, 2]) == 0b01               # the short problem cannot shrink (one tile): the long one does
-    assert wide([4000, 4000, 4000], [4, 3, 2]) == 0b111       # 750 tiles: every problem, still more than one round
+    assert wide([16 * cus, 16], [3, 2]) == 0                  # the short problem cannot shrink (one tile); the longest order never widens
+    assert wide([4000, 4000, 4000], [4, 3, 2]) == 0b110       # 750 tiles: every problem but the longest, still more than one round
+    assert wide([3072, 3072], [3, 2]) == 0b10                 # the end-to-end loop's capacities: 192 + 96 by capacity, ~200 live
     assert wide([2560, 2560], [5, 2]) == 0                    # order 5: not a launch of the 16-node kernels
