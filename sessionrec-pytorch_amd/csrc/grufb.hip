@@ -813,11 +813,15 @@ extern "C" int srec_gru_fused_nodes(int np, const int* n, int d, int* nodes) {
 extern "C" int srec_gru_fused_wide(int np, const int* n, const int* k, int* mask) {
     if (np < 0 || np > GB_MAXP || (np > 0 && (n == nullptr || k == nullptr)) || mask == nullptr) return SREC_BAD_ARG;
     *mask = 0;
-    int cus = 256;
+    static std::atomic<int> cu_count[64];                        // per device ordinal (the query costs ~0.1 ms: once)
     int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int cus = cu_count[dev & 63].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cu_count[dev & 63].store(cus, std::memory_order_relaxed);
+    }
     static const char* env = getenv("SREC_GRU_MIXED");           // development: 0 = never widen (A / B)
     if (env != nullptr && atoi(env) == 0) return 0;
     for (int p = 0; p < np; ++p)
