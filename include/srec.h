@@ -463,6 +463,12 @@ int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, 
  * weight gradient: the concat-free linear layers); w, ld: HOST int arrays, both or neither nullable */
 int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
                             const int* w, const int* ld, void* stream);
+/* ... and with the optimizer's step-scalar role (srec_adam_hyper_multi, arguments as there) in one more workgroup of the same launch:
+ * the end-of-backward sums of a captured step and the Adam scalars need nothing of each other (one ~6 us graph node less) */
+int srec_sum_slabs_multi_hyper(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                               const int* w, const int* ld, int nh, const void* counter, const void* cfg, const void* hyper,
+                               const int* tap_counter, const float* tap_src, float* tap_ring, int tap_n, const int* skip,
+                               void* stream);
 
 /* ---- evaluation: K best items per session without the (B, V) score matrix (topk.hip) -----------------------------
  * Replaces `logits = model(...); logits.topk(20)` of train.py:36-55 for models whose score is one soft-max

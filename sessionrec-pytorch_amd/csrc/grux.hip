@@ -13,6 +13,7 @@
 //            of d x (the d(gi) W_ih GEMM accumulates onto it).
 // Saved per step: gates [n, 4 d] = r, z, n, (gh_n + b_hh_n).
 #include "common.h"
+#include "hyper_role.h"
 #include "../../include/srec_hg.h"
 
 namespace {
@@ -233,8 +234,13 @@ struct SlabArgs {
     const float* part[SLAB_MAXP]; float* out[SLAB_MAXP]; long n[SLAB_MAXP]; int R[SLAB_MAXP]; int start[SLAB_MAXP + 1];
     int w[SLAB_MAXP]; int ld[SLAB_MAXP]; unsigned tall; int np;
 };
-__global__ void sum_slabs_multi_kernel(SlabArgs a) {
+// (h.n > 0: the workgroup behind the last task carries the optimizer's step-scalar role - hyper_role.h)
+__global__ void sum_slabs_multi_kernel(SlabArgs a, HyperArgs h) {
     __shared__ float red[4][64];
+    if ((int)blockIdx.x >= a.start[a.np]) {
+        hyper_role(h, (int)threadIdx.x);
+        return;
+    }
     int p = 0;
     for (int i = 1; i < a.np; ++i)
         if ((int)blockIdx.x >= a.start[i]) p = i;
@@ -352,9 +358,9 @@ extern "C" int srec_gru_bias_final(int np, const void* part, const int* rows, in
 // np <= 32 outputs out_i [n_i] = sum_r part_i [R_i, n_i] (n_i % 4 == 0 and 16-byte aligned unless tall_i) in one launch; HOST arrays.  tall (nullable): tall_i != 0
 // marks an output of few columns summed over many rows (row lanes instead of column threads); w / ld (nullable, both or neither):
 // w_i > 0 = out_i is a block of w_i columns in rows of stride ld_i (both % 4 == 0; not with tall_i)
-extern "C" int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
-                                       const int* w, const int* ld, void* stream) {
-    if (np <= 0) return 0;
+static int slab_sums(int np, const void* part, const int* R, const long* n, const void* out, const int* tall, const int* w,
+                     const int* ld, const HyperArgs& h, void* stream) {
+    if (np <= 0) return h.n > 0 ? SREC_BAD_ARG : 0;
     if (np > SLAB_MAXP || part == nullptr || out == nullptr || (w == nullptr) != (ld == nullptr)) return SREC_BAD_ARG;
     SlabArgs a{};
     a.np = np;
@@ -375,9 +381,25 @@ extern "C" int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, c
         blocks += tl ? (int)((n[p] + 63) / 64) : (int)((n[p] / 4 + 255) / 256);
     }
     a.start[np] = blocks;
-    hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3(blocks + (h.n > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, a, h);
     SREC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int srec_sum_slabs_multi_ld(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                                       const int* w, const int* ld, void* stream) {
+    return slab_sums(np, part, R, n, out, tall, w, ld, HyperArgs{}, stream);
+}
+
+// the same launch carrying the optimizer's step-scalar role (srec_adam_hyper_multi: arguments as there) in one more workgroup:
+// the end-of-backward sums of a captured training step and the scalars of the Adam kernels behind them need nothing of each other
+extern "C" int srec_sum_slabs_multi_hyper(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,
+                                          const int* w, const int* ld, int nh, const void* counter, const void* cfg,
+                                          const void* hyper, const int* tap_counter, const float* tap_src, float* tap_ring, int tap_n,
+                                          const int* skip, void* stream) {
+    HyperArgs h{};
+    if (int rc = hyper_fill(nh, counter, cfg, hyper, tap_counter, tap_src, tap_ring, tap_n, skip, h)) return rc;
+    return slab_sums(np, part, R, n, out, tall, w, ld, h, stream);
 }
 
 extern "C" int srec_sum_slabs_multi(int np, const void* part, const int* R, const long* n, const void* out, const int* tall,

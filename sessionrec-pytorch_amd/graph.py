@@ -116,6 +116,12 @@ class GraphedTrainStep:
                     from . import ops as _ops
                     if _ops.PENDING_INTAKE:
                         raise RuntimeError('the model never launched the batch intake of its captured step (ops.flush_intake)')
+                    # the tap and the intake's fault flag are arguments of THIS capture's launches only (see below); the
+                    # optimizer's step-scalar kernel rides in the end-of-backward slab-sum launch when there is one
+                    tap = (self.loss.detach(), self.loss_ring) if self._mb is not None else None
+                    skip = self._mb['err'] if self._mb is not None else None
+                    if hasattr(optimizer, 'hyper_rider') and os.environ.get('SREC_HYPER_RIDER', '1') != '0':
+                        optimizer.hyper_rider(tap, skip)
                     self.loss.backward(self._one)
                     if self.after_backward is not None:
                         self.after_backward()
@@ -126,8 +132,6 @@ class GraphedTrainStep:
                     # cloning the static loss tensor between two graph launches (train.py:99-104 reads it every step).
                     # The tap and the intake's fault flag are arguments of THIS launch only: nothing of a graph stays behind
                     # in the optimizer (an eager step after a refused capture would write into a dead graph's tensors)
-                    tap = (self.loss.detach(), self.loss_ring) if self._mb is not None else None
-                    skip = self._mb['err'] if self._mb is not None else None
                     # the step counters that matter live on the device and are advanced by the captured step itself; the
                     # host-side bookkeeping is bumped before every replay (advance()): bump once here for a consistent
                     # capture and take it back afterwards
@@ -151,6 +155,7 @@ class GraphedTrainStep:
             optimizer.zero_grad(set_to_none=True)
             from . import ops as _ops
             del _ops.PENDING_INTAKE[:]                   # (an intake the dead capture never launched)
+            del _ops.PENDING_HYPER[:], _ops.HYPER_DONE[:]
             sh = getattr(model, 'shard', None)
             if sh is not None and hasattr(sh, 'abort_step'):
                 sh.abort_step()                          # early gradient buckets recorded by the dead capture never ran

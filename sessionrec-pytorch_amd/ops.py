@@ -695,8 +695,16 @@ def defer_slab_sum(part, out, ok=True, tall=False):
     _DEFERRED.append((part, out.detach(), tall))
 
 
-def _launch_slab_sums(tasks):
-    """out: contiguous, or a column block [r, w] of a row-major matrix (stride(0) = ld > w: a slice of a weight gradient)"""
+# the optimizer's step-scalar launch as a rider of the END-of-backward slab-sum launch of a captured step (optim.FusedAdam.hyper_rider
+# puts the arguments of srec_adam_hyper_multi here before the backward pass; flush_deferred takes them along and notes which slots
+# it advanced in HYPER_DONE; FusedAdam.launch then skips its own launch)
+PENDING_HYPER = []
+HYPER_DONE = []
+
+
+def _launch_slab_sums(tasks, rider=None):
+    """out: contiguous, or a column block [r, w] of a row-major matrix (stride(0) = ld > w: a slice of a weight gradient).
+    rider: arguments of srec_adam_hyper_multi (without the stream) that leave with the LAST launch"""
     for i in range(0, len(tasks), 32):
         chunk = tasks[i:i + 32]
         m = len(chunk)
@@ -708,15 +716,23 @@ def _launch_slab_sums(tasks):
         for t, (w, ld) in zip(chunk, wl):
             assert w == 0 or (t[1].dim() == 2 and t[1].stride(1) == 1), (t[1].shape, t[1].stride())
         a_w, a_l = (_ct.c_int * m)(*[w for w, _ in wl]), (_ct.c_int * m)(*[ld for _, ld in wl])
-        lib.srec_sum_slabs_multi_ld(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o),
-                                    _ct.addressof(a_t), _ct.addressof(a_w), _ct.addressof(a_l), stream())
+        if rider is not None and i + 32 >= len(tasks):
+            lib.srec_sum_slabs_multi_hyper(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o),
+                                           _ct.addressof(a_t), _ct.addressof(a_w), _ct.addressof(a_l), *rider, stream())
+        else:
+            lib.srec_sum_slabs_multi_ld(m, _ct.addressof(a_p), _ct.addressof(a_r), _ct.addressof(a_n), _ct.addressof(a_o),
+                                        _ct.addressof(a_t), _ct.addressof(a_w), _ct.addressof(a_l), stream())
 
 
 def flush_deferred():
     if _DEFERRED:
         tasks = list(_DEFERRED)
         _DEFERRED.clear()
-        _launch_slab_sums(tasks)
+        pend = PENDING_HYPER.pop() if PENDING_HYPER else None
+        del PENDING_HYPER[:]
+        _launch_slab_sums(tasks, pend[0] if pend is not None else None)
+        if pend is not None:
+            HYPER_DONE[:] = [pend[1]]
 
 
 # ------------------------------------------------------------------------------------------ gradient arenas

@@ -219,6 +219,35 @@ class FusedAdam(torch.optim.Optimizer):
                     ent['cfg_host'] = cfg
         return work
 
+    def hyper_rider(self, tap=None, skip=None):
+        """Before the backward pass of a CAPTURED step: hand the step-scalar launch of the coming launch() to the end-of-backward
+        slab-sum launch (ops.PENDING_HYPER -> srec_sum_slabs_multi_hyper: one workgroup more there, one ~6 us graph node less).
+        The slots are those the eager warm-up step advanced (_used_keys); launch() checks that the rider advanced exactly the slots
+        of its work list and raises otherwise (the capture is then refused, nothing has run).  Without waiting slab sums the
+        rider is never taken and launch() runs its own kernel as always."""
+        from . import ops
+        del ops.PENDING_HYPER[:], ops.HYPER_DONE[:]
+        keys = sorted(getattr(self, '_used_keys', ()) or ())
+        if not keys or len(keys) > 16 or not isinstance(getattr(self, '_hyper', None), dict):
+            return False
+        ents = []
+        for gi, off in keys:
+            ent = self._hyper.get((gi, off))
+            if ent is None or ent.get('cfg_host') is None:
+                return False
+            ents.append(ent)
+        n = len(ents)
+        arr = _ct.c_void_p * n
+        cs, cf, hy = (arr(*[e[k].data_ptr() for e in ents]) for k in ('counter', 'cfg', 'hyper'))
+        first = self._hyper.get((0, 0))
+        if tap is not None and first is not None and any(e is first for e in ents):
+            args = (n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), ptr(first['counter']), ptr(tap[0]), ptr(tap[1]),
+                    tap[1].numel(), ptr(skip))
+        else:
+            args = (n, _ct.addressof(cs), _ct.addressof(cf), _ct.addressof(hy), None, None, None, 0, ptr(skip))
+        ops.PENDING_HYPER[:] = [(args, frozenset(keys), (cs, cf, hy, tap, skip))]          # (last: kept alive until the launch)
+        return True
+
     def launch(self, work, tap=None, skip=None):
         """device work only (capturable): the step-scalar kernel + the Adam kernels.
         tap = (loss scalar, ring): the step's loss goes to ring[(step count before it) % len] (graph.GraphedTrainStep's loss
@@ -239,7 +268,13 @@ class FusedAdam(torch.optim.Optimizer):
                 ents.append(ent)
                 used.add((gi, off))
         self._used_keys = used                                  # (group, step offset) slots this step advanced
-        for i in range(0, len(ents), 16):
+        from . import ops as _ops
+        done = _ops.HYPER_DONE.pop() if _ops.HYPER_DONE else None
+        del _ops.PENDING_HYPER[:], _ops.HYPER_DONE[:]             # (a rider nobody took: this launch does the work itself)
+        if done is not None and done != frozenset(used):
+            raise RuntimeError('the step scalars were advanced for other slots than this step uses (hyper_rider): %r vs %r'
+                               % (sorted(done), sorted(used)))
+        for i in range(0, len(ents) if done is None else 0, 16):
             chunk = ents[i:i + 16]
             n = len(chunk)
             arr = _ct.c_void_p * n

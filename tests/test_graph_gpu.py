@@ -263,3 +263,41 @@ def test_mailbox_fault_is_contained(dev, kind):
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
             runner.train(1, log_interval=2)
+
+
+@pytest.mark.parametrize('kind', ['msgifsr', 'niser', 'msgifsr_bf16_d128'])
+def test_step_scalars_riding_in_the_slab_sum_launch_change_nothing(dev, kind, monkeypatch):
+    """In a captured step the optimizer's step-scalar kernel (device step counters, Adam bias corrections, the loss tap) rides in the
+    end-of-backward slab-sum launch (optim.FusedAdam.hyper_rider -> srec_sum_slabs_multi_hyper) instead of being a launch of its
+    own behind it: one kernel node less, the same arithmetic - parameters, losses (read from the device ring the rider writes) and
+    step counters after six replays are BIT-identical to the captured step without the rider (SREC_HYPER_RIDER=0)."""
+    c, train, optim, G = pkg('collate'), pkg('train'), pkg('optim'), pkg('graph')
+    V = 400
+    caps = c.default_caps(32, 12)
+    runs = {}
+    wide = kind == 'msgifsr_bf16_d128'                      # (the configuration whose backward DOES defer slab sums: the rider is taken)
+    if wide:
+        monkeypatch.setitem(pkg('ops').PRECISION, 'matmul', 'bf16')        # (restored by the fixture, whatever happens below)
+        pkg('ops').weights_changed()
+    for rider in ('0', '1'):
+        monkeypatch.setenv('SREC_HYPER_RIDER', rider)
+        rng = np.random.default_rng(9)
+        model, mk = _setup('msgifsr' if wide else kind, dev, V, d=128 if wide else 32)
+        opt = optim.FusedAdam(train.fix_weight_decay(model), lr=1e-2, weight_decay=1e-4, model=model)
+        model.train()
+        padded = [mk(caps)(_samples(rng, n, V)) for n in (32, 32, 20, 32, 27, 32)]
+        x0, l0 = padded[0]
+        step = G.GraphedTrainStep(model, opt, [x.to(dev) for x in x0], l0.to(dev))
+        losses = [step([x.to(dev) for x in xs], lab.to(dev)).item() for xs, lab in padded]
+        step.check()
+        nodes = step.node_counts()
+        runs[rider] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()},
+                       int(opt._hyper[(0, 0)]['counter'].item()), nodes['kernel'] if nodes else None)
+    (l0_, p0, c0, n0), (l1_, p1, c1, n1) = runs['0'], runs['1']
+    if wide and n0 is not None:
+        assert n1 == n0 - 1, (n0, n1)
+    assert l0_ == l1_ and c0 == c1 == 6                     # (six steps taken, whoever advanced the device counter)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    if n0 is not None:                                      # (a backward that defers no slab sums has no launch to ride in: d = 32 here;
+        assert n1 in (n0, n0 - 1), (n0, n1)                 #  the benchmarked step goes from 35 to 34 kernels)
